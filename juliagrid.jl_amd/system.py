@@ -1,0 +1,308 @@
+"""Host-side power-system container and AC model (the INPUT PRODUCER of the hot path).
+
+Mirrors, by name and meaning, the reference types the NR / Gauss-Newton path reads:
+
+  PowerSystem{bus, branch, generator, model}      src/definition/system.jl:213-271
+  powerSystem(file)                               src/powerSystem/load.jl:36-67 (npz fixtures and
+                                                  MATPOWER .m here; the HDF5 reader is a "next" row)
+  acModel!(system)      -> acModel_(system)       src/powerSystem/model.jl:23-78
+  updateBranch!(system; label, status)            src/powerSystem/branch.jl:313-431 (status toggles
+  -> updateBranch_(system, label, status=...)     only: :344-350 outage, :381-386 re-close)
+
+All containers keep the reference's conventions: per-unit, radians, 1-based Int64 indices, CSC with
+sorted rows and duplicates summed in insertion order (src/backend/sparse.jl:43-95), explicit stored
+zeros for out-of-service branches (model.jl:70-71).
+
+This module is product host code (numpy). It never imports anything from oracle/.
+"""
+from __future__ import annotations
+
+import os
+import re
+from types import SimpleNamespace as NS
+
+import numpy as np
+
+_CASE_DIRS = [
+    os.path.join(os.path.dirname(os.path.abspath(__file__)), "data"),
+    os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "cases"),
+]
+
+
+class PowerSystem:
+    """Container with the reference's field names (bus/branch/generator/model)."""
+
+    def __init__(self, tables: dict):
+        t = {k: np.array(v) for k, v in tables.items()}
+        n = t["bus_type"].size
+        nb = t["br_from"].size
+        ng = t["gen_bus"].size
+        label = t["bus_label"] if "bus_label" in t else np.arange(1, n + 1, dtype=np.int64)
+        self.base = NS(power=float(t.get("base_power", 1e8)))
+        self.bus = NS(
+            number=n,
+            label={int(l): i + 1 for i, l in enumerate(label)},
+            layout=NS(type=t["bus_type"].astype(np.int8), slack=0),
+            demand=NS(active=t["bus_pd"].astype(np.float64), reactive=t["bus_qd"].astype(np.float64)),
+            supply=NS(active=np.zeros(n), reactive=np.zeros(n), generator={}),
+            shunt=NS(conductance=t["bus_gs"].astype(np.float64), susceptance=t["bus_bs"].astype(np.float64)),
+            voltage=NS(magnitude=t["bus_vm"].astype(np.float64), angle=t["bus_va"].astype(np.float64)),
+        )
+        # slack = first type-3 bus (load.jl:155-160); none -> bus 1 (load.jl:434-437)
+        s = np.flatnonzero(self.bus.layout.type == 3)
+        self.bus.layout.slack = int(s[0]) + 1 if s.size else 1
+        self.branch = NS(
+            number=nb,
+            layout=NS(from_=t["br_from"].astype(np.int64), to=t["br_to"].astype(np.int64),
+                      status=t["br_status"].astype(np.int8)),
+            parameter=NS(resistance=t["br_r"].astype(np.float64), reactance=t["br_x"].astype(np.float64),
+                         conductance=t["br_g"].astype(np.float64), susceptance=t["br_b"].astype(np.float64),
+                         turnsRatio=t["br_tap"].astype(np.float64), shiftAngle=t["br_shift"].astype(np.float64)),
+        )
+        self.generator = NS(
+            number=ng,
+            layout=NS(bus=t["gen_bus"].astype(np.int64), status=t["gen_status"].astype(np.int8)),
+            output=NS(active=t["gen_pg"].astype(np.float64), reactive=t["gen_qg"].astype(np.float64)),
+            voltage=NS(magnitude=t["gen_vg"].astype(np.float64)),
+            capability=NS(minReactive=t.get("gen_qmin", np.zeros(ng)), maxReactive=t.get("gen_qmax", np.zeros(ng))),
+        )
+        # bus.supply = sum of in-service generator outputs, generator lists in index order
+        # (load.jl:271-277, 589-596)
+        for k in range(ng):
+            if self.generator.layout.status[k] == 1:
+                i = int(self.generator.layout.bus[k])
+                self.bus.supply.generator.setdefault(i, []).append(k + 1)
+                self.bus.supply.active[i - 1] += self.generator.output.active[k]
+                self.bus.supply.reactive[i - 1] += self.generator.output.reactive[k]
+        self.model = NS(
+            ac=NS(nodalMatrix=None, nodalMatrixTranspose=None, nodalFromFrom=None, nodalFromTo=None,
+                  nodalToTo=None, nodalToFrom=None, admittance=None),
+            revision=NS(topology=0, type=0, slack=0, acModel=0, acPattern=0),
+        )
+
+    def copy(self) -> "PowerSystem":
+        import copy as _copy
+        return _copy.deepcopy(self)
+
+
+class CscMatrix:
+    """Minimal CSC holder with the reference's field names (1-based colptr/rowval)."""
+
+    def __init__(self, n, colptr, rowval, nzval):
+        self.n = int(n)
+        self.colptr = np.ascontiguousarray(colptr, dtype=np.int64)
+        self.rowval = np.ascontiguousarray(rowval, dtype=np.int64)
+        self.nzval = np.ascontiguousarray(nzval)
+
+    @property
+    def nnz(self):
+        return int(self.rowval.size)
+
+    def position(self, row, col):
+        """storedPosition (src/backend/sparse.jl:104-121), 0-based pointer into nzval."""
+        lo, hi = self.colptr[col - 1] - 1, self.colptr[col] - 1
+        p = lo + int(np.searchsorted(self.rowval[lo:hi], row))
+        if p >= hi or self.rowval[p] != row:
+            raise KeyError("The sparse matrix pattern does not contain the requested entry.")
+        return p
+
+    def toscipy(self):
+        import scipy.sparse as sp
+        return sp.csc_matrix((self.nzval, self.rowval - 1, self.colptr - 1), shape=(self.n, self.n))
+
+
+def _matpower_tables(path: str) -> dict:
+    """MATPOWER .m reader with the unit conventions of src/powerSystem/load.jl:341-619."""
+    text = open(path).read()
+
+    def matrix(name):
+        m = re.search(r"mpc\." + name + r"\s*=\s*\[(.*?)\];", text, re.S)
+        rows = []
+        for line in m.group(1).splitlines():
+            line = line.split("%")[0].strip().rstrip(";").strip()
+            if line:
+                rows.append([float(x) for x in line.replace(",", " ").split()])
+        return rows
+
+    base = float(re.search(r"mpc\.baseMVA\s*=\s*([^;]+);", text).group(1))
+    binv, d2r = 1.0 / base, np.pi / 180
+    bus, gen, br = matrix("bus"), matrix("gen"), matrix("branch")
+    lab = {int(r[0]): k + 1 for k, r in enumerate(bus)}
+    col = lambda rows, j: np.array([r[j] for r in rows], dtype=np.float64)
+    tap = col(br, 8)
+    tap[tap == 0.0] = 1.0
+    return dict(
+        base_power=base * 1e6, bus_label=np.array([int(r[0]) for r in bus]),
+        bus_type=col(bus, 1).astype(np.int8), bus_pd=col(bus, 2) * binv, bus_qd=col(bus, 3) * binv,
+        bus_gs=col(bus, 4) * binv, bus_bs=col(bus, 5) * binv, bus_vm=col(bus, 7), bus_va=col(bus, 8) * d2r,
+        br_from=np.array([lab[int(r[0])] for r in br]), br_to=np.array([lab[int(r[1])] for r in br]),
+        br_status=col(br, 10).astype(np.int8), br_r=col(br, 2), br_x=col(br, 3), br_g=np.zeros(len(br)),
+        br_b=col(br, 4), br_tap=tap, br_shift=col(br, 9) * d2r,
+        gen_bus=np.array([lab[int(r[0])] for r in gen]), gen_status=col(gen, 7).astype(np.int8),
+        gen_pg=col(gen, 1) * binv, gen_qg=col(gen, 2) * binv, gen_vg=col(gen, 5),
+        gen_qmax=col(gen, 3) * binv, gen_qmin=col(gen, 4) * binv,
+    )
+
+
+def powerSystem(source) -> PowerSystem:
+    """powerSystem("case14") / powerSystem("x.npz") / powerSystem("x.m") / powerSystem(dict)."""
+    if isinstance(source, dict):
+        return PowerSystem(source)
+    path = str(source)
+    if path.endswith(".m"):
+        return PowerSystem(_matpower_tables(path))
+    if not os.path.exists(path):
+        for d in _CASE_DIRS:
+            for cand in (os.path.join(d, path), os.path.join(d, path + ".npz")):
+                if os.path.exists(cand):
+                    path = cand
+                    break
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"power system case {source!r} not found")
+    with np.load(path) as z:
+        return PowerSystem({k: z[k] for k in z.files})
+
+
+def _branch_two_port(r, x, g, b, tap, shift):
+    """Unified branch model Y-parameters (model.jl:54-64), explicit real arithmetic (Smith 1/z)."""
+    r, x = np.asarray(r, dtype=np.float64), np.asarray(x, dtype=np.float64)
+    big = np.abs(r) >= np.abs(x)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        q1 = np.where(big, x / r, r / x)
+        d = np.where(big, r + x * q1, r * q1 + x)
+        yre = np.where(big, 1.0 / d, q1 / d)
+        yim = np.where(big, -q1 / d, -1.0 / d)
+    y = yre + 1j * yim
+    tinv = 1.0 / tap
+    tr = tinv * np.cos(-shift) + 1j * (tinv * np.sin(-shift))   # turnsRatioInv * cis(-shift)
+    ytt = y + 0.5 * (g + 1j * b)
+    yff = (tinv * tinv) * ytt
+    yft = -np.conj(tr) * y
+    ytf = -tr * y
+    return y, yff, yft, ytt, ytf
+
+
+def acModel_(system: PowerSystem) -> None:
+    """acModel!(system): Ybus, its transpose copy and per-branch two-port parameters.
+
+    Reference: src/powerSystem/model.jl:23-78 with the CSC builder of src/backend/sparse.jl:2-101.
+    Entries of a column are inserted as [diagonal, then branch stamps in branch order], stably
+    sorted by row, duplicates summed in that order; out-of-service branches insert zeros.
+    """
+    n, nb = system.bus.number, system.branch.number
+    lay, par = system.branch.layout, system.branch.parameter
+    f = lay.from_ - 1
+    t = lay.to - 1
+    on = lay.status == 1
+    y, yff, yft, ytt, ytf = _branch_two_port(par.resistance, par.reactance, par.conductance,
+                                             par.susceptance, par.turnsRatio, par.shiftAngle)
+    zero = np.zeros(nb, dtype=np.complex128)
+    y, yff, yft, ytt, ytf = (np.where(on, a, zero) for a in (y, yff, yft, ytt, ytf))
+
+    # diagonal: shunt, then += yff[from], += ytt[to] sequentially in branch order (model.jl:66-67)
+    diag = system.bus.shunt.conductance + 1j * system.bus.shunt.susceptance
+    diag = diag.astype(np.complex128)
+    idx = np.empty(2 * nb, dtype=np.int64)
+    val = np.empty(2 * nb, dtype=np.complex128)
+    idx[0::2], idx[1::2] = f, t
+    val[0::2], val[1::2] = yff, ytt
+    sel = np.repeat(on, 2)
+    np.add.at(diag, idx[sel], val[sel])
+
+    # off-diagonals in insertion order: (from,to)->column `to`, then (to,from)->column `from`
+    rows = np.empty(2 * nb, dtype=np.int64)
+    cols = np.empty(2 * nb, dtype=np.int64)
+    vals = np.empty(2 * nb, dtype=np.complex128)
+    rows[0::2], cols[0::2], vals[0::2] = f, t, yft
+    rows[1::2], cols[1::2], vals[1::2] = t, f, ytf
+    rows = np.concatenate([np.arange(n), rows])
+    cols = np.concatenate([np.arange(n), cols])
+    vals = np.concatenate([diag, vals])
+    order = np.lexsort((np.arange(rows.size), rows, cols))          # stable by (col, row, insertion)
+    rows, cols, vals = rows[order], cols[order], vals[order]
+    first = np.ones(rows.size, dtype=bool)
+    first[1:] = (rows[1:] != rows[:-1]) | (cols[1:] != cols[:-1])
+    group = np.cumsum(first) - 1
+    nzval = np.zeros(int(group[-1]) + 1, dtype=np.complex128)
+    np.add.at(nzval, group, vals)                                    # sequential -> insertion order
+    rowval = rows[first] + 1
+    colptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(colptr, cols[first] + 1, 1)
+    colptr = np.cumsum(colptr) + 1
+
+    ac = system.model.ac
+    ac.nodalMatrix = CscMatrix(n, colptr, rowval, nzval)
+    # transpose copy (model.jl:75): pattern is symmetric, so the transpose shares colptr/rowval
+    # and value p of the transpose is Y[col, row] of pointer p.
+    ac.nodalMatrixTranspose = CscMatrix(n, colptr.copy(), rowval.copy(), _transpose_values(ac.nodalMatrix))
+    ac.admittance, ac.nodalFromFrom, ac.nodalFromTo, ac.nodalToTo, ac.nodalToFrom = y, yff, yft, ytt, ytf
+
+
+def _transpose_perm(A: CscMatrix) -> np.ndarray:
+    """perm[p] = pointer of entry (col, row) for pointer p = (row, col); needs a symmetric pattern."""
+    n = A.n
+    col_of = np.repeat(np.arange(n, dtype=np.int64), np.diff(A.colptr))
+    row_of = A.rowval - 1
+    key = row_of * n + col_of            # key of the transposed entry in column-major order
+    perm = np.argsort(key, kind="stable")
+    # entry p=(r,c) has column-major key c*n+r; transposed entry (c,r) has key r*n+c
+    own = col_of * n + row_of
+    pos = np.searchsorted(own, key)      # own is sorted (CSC order)
+    if not np.array_equal(own[pos], key):
+        raise ValueError("Ybus pattern is not structurally symmetric")
+    del perm
+    return pos
+
+
+def _transpose_values(A: CscMatrix) -> np.ndarray:
+    return A.nzval[_transpose_perm(A)]
+
+
+def _ac_nodal_update(system: PowerSystem, k: int, sign: float) -> None:
+    """acNodalUpdate! (model.jl:81-110): add sign*two-port stamps of branch k (0-based) in place."""
+    ac = system.model.ac
+    i, j = int(system.branch.layout.from_[k]), int(system.branch.layout.to[k])
+    Y, YT = ac.nodalMatrix, ac.nodalMatrixTranspose
+    ff, tt = sign * ac.nodalFromFrom[k], sign * ac.nodalToTo[k]
+    ft, tf = sign * ac.nodalFromTo[k], sign * ac.nodalToFrom[k]
+    Y.nzval[Y.position(i, i)] += ff
+    Y.nzval[Y.position(j, j)] += tt
+    YT.nzval[YT.position(i, i)] += ff
+    YT.nzval[YT.position(j, j)] += tt
+    Y.nzval[Y.position(i, j)] += ft
+    Y.nzval[Y.position(j, i)] += tf
+    YT.nzval[YT.position(j, i)] += ft
+    YT.nzval[YT.position(i, j)] += tf
+    system.model.revision.acModel += 1
+
+
+def updateBranch_(system: PowerSystem, label: int, status: int | None = None) -> None:
+    """updateBranch!(system; label, status): status toggles only (branch.jl:313-431).
+
+    Outage (:344-350): subtract the stamps (pattern kept -> stored zeros), zero the two-port
+    parameters.  Re-close (:381-386): recompute the parameters, add the stamps.
+    """
+    k = int(label) - 1
+    if not 0 <= k < system.branch.number:
+        raise KeyError(f"The branch label {label} that has been specified does not exist.")
+    old = int(system.branch.layout.status[k])
+    new = old if status is None else int(status)
+    if new not in (0, 1):
+        raise ValueError("The status 0 or 1 is required.")
+    ac = system.model.ac
+    has = ac.nodalMatrix is not None
+    if has and old == 1 and new == 0:
+        _ac_nodal_update(system, k, -1.0)
+        for a in (ac.nodalFromFrom, ac.nodalFromTo, ac.nodalToTo, ac.nodalToFrom, ac.admittance):
+            a[k] = 0.0
+    if has and new == 1 and old == 0:
+        par = system.branch.parameter
+        y, yff, yft, ytt, ytf = _branch_two_port(par.resistance[k:k + 1], par.reactance[k:k + 1],
+                                                 par.conductance[k:k + 1], par.susceptance[k:k + 1],
+                                                 par.turnsRatio[k:k + 1], par.shiftAngle[k:k + 1])
+        ac.admittance[k], ac.nodalFromFrom[k], ac.nodalFromTo[k] = y[0], yff[0], yft[0]
+        ac.nodalToTo[k], ac.nodalToFrom[k] = ytt[0], ytf[0]
+        _ac_nodal_update(system, k, +1.0)
+    system.branch.layout.status[k] = new
+    if new != old:
+        system.model.revision.topology += 1
