@@ -1,0 +1,120 @@
+/*
+ * jgrid.h -- C ABI of libjgrid_hip.so: MI355X-native Newton-Raphson AC power flow and Gauss-Newton
+ * WLS state estimation inner loops, drop-in behind JuliaGrid's newtonRaphson()/mismatch!()/solve!()
+ * and gaussNewton()/increment!()/solve!() (reference paths relative to /root/reference).
+ *
+ * Conventions
+ *  - Every array argument is a HOST pointer owned by the caller and copied during the call; no
+ *    pointer outlives the call.  Device memory lives behind the opaque handle.
+ *  - Index arrays are the reference's own containers: 1-based int64, CSC (Julia SparseMatrixCSC).
+ *  - `batch` independent scenarios of one grid are solved at once.  Per-scenario arrays are
+ *    scenario-major on the host ([batch][n], C order); the library keeps them batch-minor in HBM.
+ *  - Return codes: 0 ok, 1 bad argument, 2 HIP runtime error, 3 zero / non-finite pivot,
+ *    4 stale model.  jg_last_error() gives the text of the last failure on this thread.
+ *  - A handle is bound to one device and one HIP stream; handles are independent, a single handle
+ *    is not thread-safe.  No global mutable state.
+ */
+#ifndef JGRID_H
+#define JGRID_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct jg_nr jg_nr;
+typedef struct jg_gn jg_gn;
+
+const char* jg_last_error(void);
+/* Number of visible HIP devices (<0 on runtime failure). */
+int jg_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Newton-Raphson AC power flow
+ * ------------------------------------------------------------------------------------------- */
+
+/*
+ * newtonRaphson(system)  -- src/powerFlow/acPowerFlow.jl:39-87 after initializeACPowerFlow (:1312-1331).
+ * Builds the index maps pq/pvpq and the Jacobian CSC pattern exactly as newtonJacobian (:89-175),
+ * runs the symbolic analysis that replaces the first `lu(J)` (src/backend/utility.jl:470-476),
+ * and uploads the grid.
+ *   n               number of buses
+ *   colptr,rowval   Ybus pattern, system.model.ac.nodalMatrix (src/definition/system.jl:213-221)
+ *   y_reim          nodalMatrix.nzval as (re,im) pairs, 2*nnz doubles
+ *   yt_reim         nodalMatrixTranspose.nzval, same pattern (src/powerSystem/model.jl:75)
+ *   type            bus.layout.type AFTER bus-type normalisation (1 PQ, 2 PV, 3 slack)
+ *   slack           bus.layout.slack (1-based)
+ *   batch           number of scenarios resident on this device (>= 1)
+ *   max_patch       Ybus entries a scenario may override (4 per branch outage), >= 0
+ *   device          HIP device ordinal
+ */
+int jg_nr_create(jg_nr** h, int64_t n, const int64_t* colptr, const int64_t* rowval,
+                 const double* y_reim, const double* yt_reim, const int8_t* type, int64_t slack,
+                 int64_t batch, int64_t max_patch, int device);
+void jg_nr_destroy(jg_nr* h);
+
+/* sizes: dims[0]=dimJ, dims[1]=nnz(J), dims[2]=nnz blocks of L+D+U, dims[3]=LU update terms,
+ * dims[4]=LU kernel launches per factorization, dims[5]=fwd+bwd launches per solve */
+int jg_nr_dims(jg_nr* h, int64_t* dims);
+
+/* bus.supply - bus.demand per scenario (acPowerFlow.jl:676-680). [batch][n] each;
+ * batch_stride 0 broadcasts one [n] vector to all scenarios. */
+int jg_nr_set_injection(jg_nr* h, const double* p_inj, const double* q_inj, int64_t batch_stride);
+/* analysis.voltage.{magnitude,angle} (setInitialPoint!, acPowerFlow.jl:1226-1249, 1281-1295). */
+int jg_nr_set_voltage(jg_nr* h, const double* vm, const double* va, int64_t batch_stride);
+int jg_nr_get_voltage(jg_nr* h, double* vm, double* va);
+
+/*
+ * Per-scenario Ybus edit on top of the shared base matrix -- what acNodalUpdate!
+ * (src/powerSystem/model.jl:81-110) does for updateBranch!(...; status = 0)
+ * (src/powerSystem/branch.jl:344-350): k entries, ptr[] = 1-based pointers into nodalMatrix.nzval
+ * (entry (row,col)); dy_reim = values ADDED to Y[row,col].  Pattern never changes (stored zeros).
+ * Replaces any previous patch of that scenario; k = 0 clears it.
+ */
+int jg_nr_patch_ybus(jg_nr* h, int64_t scenario, int64_t k, const int64_t* ptr, const double* dy_reim);
+
+/* Re-upload the SHARED Ybus values after an in-place edit of the system (updateBranch!(analysis; ...),
+ * src/powerSystem/branch.jl:453-459 -> acNodalUpdate!, model.jl:81-110).  Same pattern as at create. */
+int jg_nr_set_ybus(jg_nr* h, const double* y_reim, const double* yt_reim);
+
+/* mismatch!(analysis) -- acPowerFlow.jl:645-685. max_p/max_q: [batch] infinity norms. */
+int jg_nr_mismatch(jg_nr* h, double* max_p, double* max_q);
+/* solve!(analysis) -- acPowerFlow.jl:793-911: Jacobian fill, refactorization, solve, state update,
+ * iteration += 1, for every scenario. */
+int jg_nr_solve(jg_nr* h);
+/* powerFlow!(analysis; iteration, tolerance) -- acPowerFlow.jl:1389-1433, per scenario, with the
+ * reference's loop accounting.  iters/status: [batch]; status 0 converged, 1 iteration limit,
+ * 3 numeric failure. */
+int jg_nr_run(jg_nr* h, int64_t max_iter, double tol, int32_t* iters, int32_t* status);
+
+/* analysis.method.{mismatch,increment,jacobian.nzval} in the reference's own ordering
+ * (rows/cols pvpq then pq; CSC of newtonJacobian).  [batch][dimJ] / [batch][nnzJ]. */
+int jg_nr_get_mismatch(jg_nr* h, double* mism);
+int jg_nr_get_increment(jg_nr* h, double* incr);
+int jg_nr_get_jacobian(jg_nr* h, double* nzval);
+/* analysis.method.{pq,pvpq,pcount} and jacobian.{colptr,rowval} (1-based, bit-exact). */
+int jg_nr_get_maps(jg_nr* h, int64_t* pq, int64_t* pvpq, int64_t* pcount, int64_t* jcolptr, int64_t* jrowval);
+/* analysis.method.iteration per scenario. */
+int jg_nr_get_iteration(jg_nr* h, int32_t* iters);
+
+/* Measurement hooks (HIP events on the handle's own stream).
+ * kernel: 0 fused mismatch+Jacobian assembly, 1 LU refactorization (all launches), 2 fwd+bwd solve
+ * (no state update).  Returns the mean milliseconds of `reps` back-to-back executions. */
+int jg_nr_time_kernel(jg_nr* h, int kernel, int reps, double* mean_ms);
+
+/* ---------------------------------------------------------------------------------------------
+ * Symbolic analysis only (no device needed): the static schedule that replaces the symbolic half
+ * of `lu`/`klu` (src/backend/utility.jl:470-476, 486-492).  Used by the CPU test-suite to replay
+ * and race-check the schedule.  pattern: 0-based int32 block CSR, structurally symmetric, full
+ * diagonal.  jg_plan_export(which): see csrc/jg_plan_api.cpp; out == NULL returns the length.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct jg_plan jg_plan;
+int jg_plan_create(jg_plan** p, int64_t n, const int32_t* rowptr, const int32_t* col, int policy);
+void jg_plan_destroy(jg_plan* p);
+int64_t jg_plan_export(jg_plan* p, int which, int32_t* out, int64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JGRID_H */

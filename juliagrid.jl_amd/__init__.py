@@ -1,0 +1,16 @@
+"""juliagrid.jl_amd -- MI355X-native Newton-Raphson power flow / Gauss-Newton state estimation.
+
+Host-side mirror of the JuliaGrid interface for the hot path only; all numerics run
+in libjgrid_hip.so (hand-written HIP for gfx950) through the C ABI of include/jgrid.h.
+"""
+from .system import PowerSystem, CscMatrix, powerSystem, acModel_          # noqa: F401
+from .system import updateBranch_ as updateBranchSystem_                   # noqa: F401
+from .powerflow import (AcPowerFlow, newtonRaphson, mismatch_, solve_, powerFlow_, setInitialPoint_,   # noqa: F401
+                        updateBranch_, setOutage_, setInjection_, outagePatch, initializeACPowerFlow)
+from . import _lib                                                           # noqa: F401
+
+__all__ = [
+    "PowerSystem", "CscMatrix", "powerSystem", "acModel_", "updateBranchSystem_", "AcPowerFlow", "newtonRaphson",
+    "mismatch_", "solve_", "powerFlow_", "setInitialPoint_", "updateBranch_", "setOutage_", "setInjection_",
+    "outagePatch", "initializeACPowerFlow",
+]

@@ -1,0 +1,115 @@
+"""ctypes binding of libjgrid_hip.so (the C ABI declared in include/jgrid.h).
+
+There is NO fallback: if the HIP library is missing or fails to load, importing the compute API
+raises.  Nothing here (or anywhere in this package) imports oracle/.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libjgrid_hip.so")
+
+I64P = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+I32P = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+I8P = np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")
+F64P = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+VP = C.c_void_p
+
+_lib = None
+
+
+class JGridError(RuntimeError):
+    """ErrorException of the Julia shim: any non-zero return code of the C ABI."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"libjgrid_hip error {code}: {msg}")
+        self.code = code
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.jg_last_error.restype = C.c_char_p
+    L.jg_device_count.restype = C.c_int
+    sig = {
+        "jg_nr_create": [C.POINTER(VP), C.c_int64, I64P, I64P, F64P, F64P, I8P, C.c_int64, C.c_int64, C.c_int64, C.c_int],
+        "jg_nr_dims": [VP, I64P],
+        "jg_nr_set_injection": [VP, F64P, F64P, C.c_int64],
+        "jg_nr_set_voltage": [VP, F64P, F64P, C.c_int64],
+        "jg_nr_get_voltage": [VP, F64P, F64P],
+        "jg_nr_patch_ybus": [VP, C.c_int64, C.c_int64, I64P, F64P],
+        "jg_nr_set_ybus": [VP, F64P, F64P],
+        "jg_nr_mismatch": [VP, F64P, F64P],
+        "jg_nr_solve": [VP],
+        "jg_nr_run": [VP, C.c_int64, C.c_double, I32P, I32P],
+        "jg_nr_get_mismatch": [VP, F64P],
+        "jg_nr_get_increment": [VP, F64P],
+        "jg_nr_get_jacobian": [VP, F64P],
+        "jg_nr_get_maps": [VP, I64P, I64P, I64P, I64P, I64P],
+        "jg_nr_get_iteration": [VP, I32P],
+        "jg_nr_time_kernel": [VP, C.c_int, C.c_int, C.POINTER(C.c_double)],
+        "jg_plan_create": [C.POINTER(VP), C.c_int64, I32P, I32P, C.c_int],
+    }
+    for name, args in sig.items():
+        f = getattr(L, name)
+        f.argtypes = args
+        f.restype = C.c_int
+    L.jg_nr_destroy.argtypes = [VP]
+    L.jg_nr_destroy.restype = None
+    L.jg_plan_destroy.argtypes = [VP]
+    L.jg_plan_destroy.restype = None
+    L.jg_plan_export.argtypes = [VP, C.c_int, VP, C.c_int64]
+    L.jg_plan_export.restype = C.c_int64
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise JGridError(rc, lib().jg_last_error().decode())
+
+
+def device_count():
+    return int(lib().jg_device_count())
+
+
+class Plan:
+    """Device-free symbolic analysis (schedule export for tests)."""
+
+    NAMES = dict(perm=0, e_row=1, e_col=2, e_src=3, t_ptr=4, t_a=5, t_b=6, e_level=7, e_diag=8, diag=9,
+                 l_ptr=10, l_ent=11, l_col=12, u_ptr=13, u_ent=14, u_col=15)
+
+    def __init__(self, n, rowptr, col, policy=0):
+        self.h = VP()
+        rc = lib().jg_plan_create(C.byref(self.h), int(n), np.ascontiguousarray(rowptr, dtype=np.int32),
+                                  np.ascontiguousarray(col, dtype=np.int32), int(policy))
+        if rc:
+            raise JGridError(rc, "block pattern must be structurally symmetric with a full diagonal")
+        self.n = int(n)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().jg_plan_destroy(self.h)
+            self.h = None
+
+    def get(self, which):
+        w = self.NAMES[which] if isinstance(which, str) else int(which)
+        m = lib().jg_plan_export(self.h, w, None, 0)
+        if m < 0:
+            raise KeyError(which)
+        out = np.zeros(max(m, 1), dtype=np.int32)
+        lib().jg_plan_export(self.h, w, out.ctypes.data, m)
+        return out[:m]
+
+    def schedule(self, kind):
+        base = {"lu": 20, "fwd": 30, "bwd": 40}[kind]
+        return dict(launches=self.get(base).reshape(-1, 3), task_ptr=self.get(base + 1),
+                    step_ptr=self.get(base + 2), items=self.get(base + 3))

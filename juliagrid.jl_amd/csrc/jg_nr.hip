@@ -1,0 +1,613 @@
+// jg_nr.hip -- Newton-Raphson AC power flow on MI355X: C ABI (include/jgrid.h) + fused
+// mismatch/Jacobian assembly kernel + per-scenario convergence control.
+//
+// Reference behaviour restated (paths relative to /root/reference):
+//   newtonJacobian      src/powerFlow/acPowerFlow.jl:89-175   (index maps, CSC pattern; bit-exact)
+//   mismatch!           src/powerFlow/acPowerFlow.jl:645-685  + src/backend/equations.jl:63-103,126-128
+//   solve! (fill)       src/powerFlow/acPowerFlow.jl:820-888  + src/backend/equations.jl:105-144
+//   solve! (linear)     src/powerFlow/acPowerFlow.jl:890-906  -> jg_engine (device LU / solves / update)
+//   powerFlow!          src/powerFlow/acPowerFlow.jl:1389-1433
+//
+// Design (not a translation): the reference walks Ybus three times per iteration with one sincos
+// each (mismatch, off-diagonal partials, diagonal re-sum).  Here ONE pass over bus row i with one
+// sincos per stored (i,j) produces f_P, f_Q and the whole 2x2-block Jacobian row; PV / slack rows
+// and columns are padded with identity so the Jacobian is an n x n matrix of 2x2 blocks with the
+// Ybus pattern -- the layout the block LU engine consumes directly.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/jgrid.h"
+#include "jg_engine.hpp"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string& msg) { g_error = msg; return code; }
+
+#define NR_HIP(expr)                                                                   \
+    do {                                                                               \
+        hipError_t err__ = (expr);                                                     \
+        if (err__ != hipSuccess) return fail(2, std::string(#expr) + ": " + hipGetErrorString(err__)); \
+    } while (0)
+
+constexpr int ASM_ROWS = 32;   // bus rows per workgroup
+constexpr int ASM_WAVES = 4;
+
+struct AsmArgs {
+    const int* rowptr; const int* col; const double* G; const double* Bv; const signed char* type;
+    const double* vm; const double* va; const double* p; const double* q;
+    const int* ppos; const double* pdg; const double* pdb;
+    double* A; double* F; double* part;
+    int n; int ld; int mp;
+};
+
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Fused mismatch + Jacobian assembly. blockDim (64, ASM_WAVES); grid (ceil(n/ASM_ROWS), ld/64).
+template <int MP>
+__global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(AsmArgs a) {
+    __shared__ double red[2][ASM_WAVES][64];
+    const int lane = threadIdx.x;
+    const int wave = uniform(threadIdx.y);
+    const size_t ld = (size_t)a.ld;
+    const size_t b = (size_t)blockIdx.y * 64 + lane;
+    int ppos[MP > 0 ? MP : 1];
+#pragma unroll
+    for (int m = 0; m < MP; ++m) ppos[m] = a.ppos[(size_t)m * ld + b];
+    double maxp = 0.0, maxq = 0.0;
+    const int r0 = blockIdx.x * ASM_ROWS;
+    const int r1 = min(r0 + ASM_ROWS, a.n);
+    for (int i = r0 + wave; i < r1; i += ASM_WAVES) {
+        const int ti = uniform((int)a.type[i]);
+        const double vi = a.vm[(size_t)i * ld + b];
+        const double thi = a.va[(size_t)i * ld + b];
+        const int p0 = uniform(a.rowptr[i]), p1 = uniform(a.rowptr[i + 1]);
+        double s1 = 0.0, s2 = 0.0, gii = 0.0, bii = 0.0;
+        int pd = p0;
+        for (int p = p0; p < p1; ++p) {
+            const int j = uniform(a.col[p]);
+            double g = a.G[p], bb = a.Bv[p];
+#pragma unroll
+            for (int m = 0; m < MP; ++m)
+                if (ppos[m] == p) { g += a.pdg[(size_t)m * ld + b]; bb += a.pdb[(size_t)m * ld + b]; }
+            const double vj = a.vm[(size_t)j * ld + b];
+            const double thj = a.va[(size_t)j * ld + b];
+            double s, c;
+            sincos(thi - thj, &s, &c);
+            const double ac = g * c + bb * s;      // G cos + B sin
+            const double ad = g * s - bb * c;      // G sin - B cos
+            s1 += vj * ac;
+            s2 += vj * ad;
+            if (j == i) { pd = p; gii = g; bii = bb; continue; }
+            const int tj = uniform((int)a.type[j]);
+            // rows: P exists unless slack, Q exists for PQ; cols: theta unless slack, V for PQ
+            const double rp = ti != 3 ? 1.0 : 0.0, rq = ti == 1 ? 1.0 : 0.0;
+            const double ct = tj != 3 ? 1.0 : 0.0, cv = tj == 1 ? 1.0 : 0.0;
+            double* o = a.A + (size_t)p * 4 * ld + b;
+            o[0] = rp * ct * (vi * vj * ad);        // dP_i/dtheta_j   equations.jl:109-111
+            o[ld] = rp * cv * (vi * ac);            // dP_i/dV_j       equations.jl:117-119
+            o[2 * ld] = rq * ct * (-(vi * vj) * ac);  // dQ_i/dtheta_j   equations.jl:134-136
+            o[3 * ld] = rq * cv * (vi * ad);        // dQ_i/dV_j       equations.jl:142-144
+        }
+        double fp = vi * s1 - a.p[(size_t)i * ld + b];     // acPowerFlow.jl:676
+        double fq = vi * s2 - a.q[(size_t)i * ld + b];     // acPowerFlow.jl:679
+        double d00 = -vi * s2 - bii * (vi * vi);           // equations.jl:105-107, acPowerFlow.jl:872
+        double d01 = s1 + gii * vi;                        // equations.jl:113-115
+        double d10 = vi * s1 - gii * (vi * vi);            // equations.jl:130-132
+        double d11 = s2 - bii * vi;                        // equations.jl:138-140
+        if (ti == 3) { d00 = 1.0; d01 = 0.0; d10 = 0.0; d11 = 1.0; fp = 0.0; fq = 0.0; }
+        else if (ti == 2) { d01 = 0.0; d10 = 0.0; d11 = 1.0; fq = 0.0; }
+        double* o = a.A + (size_t)pd * 4 * ld + b;
+        o[0] = d00; o[ld] = d01; o[2 * ld] = d10; o[3 * ld] = d11;
+        a.F[((size_t)i * 2) * ld + b] = fp;
+        a.F[((size_t)i * 2 + 1) * ld + b] = fq;
+        // NaN-propagating max: a NaN mismatch must not look converged
+        const double afp = fabs(fp), afq = fabs(fq);
+        maxp = (afp > maxp || afp != afp) ? afp : maxp;
+        maxq = (afq > maxq || afq != afq) ? afq : maxq;
+    }
+    red[0][wave][lane] = maxp;
+    red[1][wave][lane] = maxq;
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int w = 1; w < ASM_WAVES; ++w) {
+            const double x = red[0][w][lane], y = red[1][w][lane];
+            maxp = (x > maxp || x != x) ? x : maxp;
+            maxq = (y > maxq || y != y) ? y : maxq;
+        }
+        a.part[((size_t)blockIdx.x * 2) * ld + b] = maxp;
+        a.part[((size_t)blockIdx.x * 2 + 1) * ld + b] = maxq;
+    }
+}
+
+struct CheckArgs {
+    const double* part; int nchunk; int ld; int batch;
+    const double* params;      // [0] tolerance, [1] max iterations
+    double* normp; double* normq; int* active; int* iters; int* status; const int* lu_status; int* counter;
+    int mode;                  // 0 = norms only, 1 = powerFlow! loop control
+};
+
+__global__ void k_check(CheckArgs a) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.ld) return;
+    double mp = 0.0, mq = 0.0;
+    for (int c = 0; c < a.nchunk; ++c) {
+        const double x = a.part[((size_t)c * 2) * a.ld + b], y = a.part[((size_t)c * 2 + 1) * a.ld + b];
+        mp = (x > mp || x != x) ? x : mp;
+        mq = (y > mq || y != y) ? y : mq;
+    }
+    a.normp[b] = mp;
+    a.normq[b] = mq;
+    if (a.mode == 0) return;
+    const double tol = a.params[0];
+    const int maxit = (int)a.params[1];
+    const bool real = b < a.batch;
+    const bool conv = mp < tol && mq < tol;                       // acPowerFlow.jl:1410 (strict)
+    const bool bad = (a.lu_status[b] & 4) || mp != mp || mq != mq;
+    const bool act = real && !conv && !bad && a.iters[b] < maxit; // acPowerFlow.jl:1414
+    a.active[b] = act ? 1 : 0;
+    a.status[b] = conv ? 0 : (bad ? 3 : 1);
+    if (act) { a.iters[b] += 1; atomicAdd(a.counter, 1); }        // solve! follows: iteration += 1 (:908)
+}
+
+__global__ void k_add_iter(int* iters, int n) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < n) iters[b] += 1;
+}
+
+}  // namespace
+
+struct jg_nr {
+    int n = 0, nnz = 0, batch = 0, ld = 0, mp = 0, device = 0, nchunk = 0;
+    int64_t dimJ = 0, nnzJ = 0, slack = 0;
+    std::vector<int64_t> colptr, rowval, pq, pvpq, pcount, jcolptr, jrowval;
+    std::vector<int8_t> type;
+    std::vector<int> tperm;          // Ybus CSC pointer -> block CSR index of the same (row, col)
+    std::vector<int64_t> jmap;       // Jacobian CSC nz -> csr*4 + component
+    // device
+    int* d_rowptr = nullptr; int* d_col = nullptr; double* d_G = nullptr; double* d_B = nullptr;
+    signed char* d_type = nullptr; signed char* d_flags = nullptr;
+    double* d_vm = nullptr; double* d_va = nullptr; double* d_p = nullptr; double* d_q = nullptr;
+    int* d_ppos = nullptr; double* d_pdg = nullptr; double* d_pdb = nullptr;
+    double* d_A = nullptr; double* d_F = nullptr; double* d_inc = nullptr; double* d_part = nullptr;
+    double* d_normp = nullptr; double* d_normq = nullptr; double* d_params = nullptr;
+    int* d_active = nullptr; int* d_iters = nullptr; int* d_status = nullptr; int* d_counter = nullptr;
+    jg::Engine eng;
+    hipStream_t stream = nullptr;
+    hipGraph_t graphA = nullptr, graphB = nullptr;
+    hipGraphExec_t execA = nullptr, execB = nullptr;
+    bool jac_valid = false;
+    int* h_counter = nullptr;        // pinned
+};
+
+namespace {
+
+int set_device(jg_nr* h) { NR_HIP(hipSetDevice(h->device)); return 0; }
+
+void launch_assemble(jg_nr* h) {
+    AsmArgs a{h->d_rowptr, h->d_col, h->d_G, h->d_B, h->d_type, h->d_vm, h->d_va, h->d_p, h->d_q,
+              h->d_ppos, h->d_pdg, h->d_pdb, h->d_A, h->d_F, h->d_part, h->n, h->ld, h->mp};
+    dim3 grid(h->nchunk, h->ld / 64), block(64, ASM_WAVES);
+    switch (h->mp) {
+        case 0: hipLaunchKernelGGL(k_assemble<0>, grid, block, 0, h->stream, a); break;
+        case 4: hipLaunchKernelGGL(k_assemble<4>, grid, block, 0, h->stream, a); break;
+        default: hipLaunchKernelGGL(k_assemble<8>, grid, block, 0, h->stream, a); break;
+    }
+}
+
+void launch_check(jg_nr* h, int mode) {
+    CheckArgs c{h->d_part, h->nchunk, h->ld, h->batch, h->d_params, h->d_normp, h->d_normq, h->d_active,
+                h->d_iters, h->d_status, h->eng.status, h->d_counter, mode};
+    hipLaunchKernelGGL(k_check, dim3((h->ld + 255) / 256), dim3(256), 0, h->stream, c);
+}
+
+// host [batch][n] (or one [n] broadcast) -> device [n][ld]
+int put_bus_array(jg_nr* h, double* dst, const double* src, int64_t stride) {
+    std::vector<double> t((size_t)h->n * h->ld, 0.0);
+    for (int b = 0; b < h->ld; ++b) {
+        const double* s = src + (size_t)(b < h->batch ? b : h->batch - 1) * (size_t)stride;   // pad with last scenario
+        for (int i = 0; i < h->n; ++i) t[(size_t)i * h->ld + b] = s[i];
+    }
+    NR_HIP(hipMemcpy(dst, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int build_graphs(jg_nr* h) {
+    if (h->execA) return 0;
+    NR_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    hipMemsetAsync(h->d_counter, 0, sizeof(int), h->stream);
+    launch_assemble(h);
+    launch_check(h, 1);
+    hipMemcpyAsync(h->h_counter, h->d_counter, sizeof(int), hipMemcpyDeviceToHost, h->stream);
+    NR_HIP(hipStreamEndCapture(h->stream, &h->graphA));
+    NR_HIP(hipGraphInstantiate(&h->execA, h->graphA, nullptr, nullptr, 0));
+    NR_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    int rc = h->eng.factor(h->stream, h->d_A);
+    jg::StateUpdate upd{h->d_va, h->d_vm, h->d_flags, h->d_active, -1.0};
+    if (!rc) rc = h->eng.solve(h->stream, h->d_F, h->d_inc, upd);
+    hipError_t e = hipStreamEndCapture(h->stream, &h->graphB);
+    if (rc) return fail(rc, h->eng.error);
+    NR_HIP(e);
+    NR_HIP(hipGraphInstantiate(&h->execB, h->graphB, nullptr, nullptr, 0));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* jg_last_error(void) { return g_error.c_str(); }
+
+int jg_device_count(void) {
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return -1;
+    return c;
+}
+
+int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* y_reim,
+                 const double* yt_reim, const int8_t* type, int64_t slack, int64_t batch, int64_t max_patch,
+                 int device) {
+    if (!out || n < 1 || !colptr || !rowval || !y_reim || !yt_reim || !type || batch < 1 || max_patch < 0 || max_patch > 8)
+        return fail(1, "jg_nr_create: bad argument");
+    if (slack < 1 || slack > n || type[slack - 1] != 3) return fail(1, "The slack bus is missing.");
+    int ndev = 0;
+    NR_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(1, "jg_nr_create: no such HIP device");
+    jg_nr* h = new jg_nr();
+    h->n = (int)n; h->batch = (int)batch; h->ld = (int)((batch + 63) / 64 * 64);
+    h->mp = max_patch == 0 ? 0 : (max_patch <= 4 ? 4 : 8);
+    h->device = device; h->slack = slack;
+    h->nnz = (int)(colptr[n] - 1);
+    h->colptr.assign(colptr, colptr + n + 1);
+    h->rowval.assign(rowval, rowval + h->nnz);
+    h->type.assign(type, type + n);
+    const int nnz = h->nnz;
+    // transpose permutation of the (structurally symmetric) pattern: tperm[p of (r,c)] = pointer of (c,r)
+    h->tperm.assign(nnz, -1);
+    for (int c = 0; c < n; ++c)
+        for (int64_t p = colptr[c] - 1; p < colptr[c + 1] - 1; ++p) {
+            const int64_t r = rowval[p] - 1;
+            if (r < 0 || r >= n) { delete h; return fail(1, "jg_nr_create: row index out of range"); }
+            int64_t lo = colptr[r] - 1, hi = colptr[r + 1] - 2, q = -1;
+            while (lo <= hi) { int64_t m = (lo + hi) >> 1; if (rowval[m] - 1 < c) lo = m + 1; else if (rowval[m] - 1 > c) hi = m - 1; else { q = m; break; } }
+            if (q < 0) { delete h; return fail(1, "jg_nr_create: Ybus pattern is not structurally symmetric"); }
+            h->tperm[p] = (int)q;
+        }
+    // ---- newtonJacobian (acPowerFlow.jl:89-175), integer only -------------------------------
+    h->pq.assign(n, 0); h->pvpq.assign(n, 0); h->pcount.assign(n, 0);
+    int64_t pvpqNum = 0, pqNum = 0;
+    for (int i = 0; i < n; ++i) {
+        if (type[i] == 1) { pqNum++; h->pq[i] = pqNum + n - 1; }
+        if (type[i] != 3) { pvpqNum++; h->pvpq[i] = pvpqNum; }
+    }
+    h->dimJ = n + pqNum - 1;
+    std::vector<int64_t> colcount(h->dimJ, 0), qcount(n, 0);
+    for (int i = 0; i < n; ++i) {
+        if (i + 1 == slack) continue;
+        for (int64_t p = colptr[i] - 1; p < colptr[i + 1] - 1; ++p) {
+            const int8_t tr = type[rowval[p] - 1];
+            if (tr != 3) h->pcount[i]++;
+            if (tr == 1) qcount[i]++;
+        }
+        colcount[h->pvpq[i] - 1] = h->pcount[i] + qcount[i];
+        if (type[i] == 1) colcount[h->pq[i] - 1] = h->pcount[i] + qcount[i];
+    }
+    h->jcolptr.assign(h->dimJ + 1, 1);
+    for (int64_t c = 0; c < h->dimJ; ++c) h->jcolptr[c + 1] = h->jcolptr[c] + colcount[c];
+    h->nnzJ = h->jcolptr[h->dimJ] - 1;
+    h->jrowval.assign(h->nnzJ, 0);
+    h->jmap.assign(h->nnzJ, 0);
+    for (int i = 0; i < n; ++i) {
+        if (i + 1 == slack) continue;
+        const bool isPQ = type[i] == 1;
+        int64_t pA = h->jcolptr[h->pvpq[i] - 1], qA = pA + h->pcount[i];
+        int64_t pM = isPQ ? h->jcolptr[h->pq[i] - 1] : 0, qM = isPQ ? pM + h->pcount[i] : 0;
+        for (int64_t p = colptr[i] - 1; p < colptr[i + 1] - 1; ++p) {
+            const int64_t row = rowval[p] - 1;
+            const int8_t tr = type[row];
+            const int64_t blk = (int64_t)h->tperm[p] * 4;      // block (row, i) in row-CSR order
+            if (tr != 3) {
+                h->jrowval[pA - 1] = h->pvpq[row]; h->jmap[pA - 1] = blk + 0; pA++;
+                if (isPQ) { h->jrowval[pM - 1] = h->pvpq[row]; h->jmap[pM - 1] = blk + 1; pM++; }
+            }
+            if (tr == 1) {
+                h->jrowval[qA - 1] = h->pq[row]; h->jmap[qA - 1] = blk + 2; qA++;
+                if (isPQ) { h->jrowval[qM - 1] = h->pq[row]; h->jmap[qM - 1] = blk + 3; qM++; }
+            }
+        }
+    }
+    // ---- device upload ----------------------------------------------------------------------
+    int rc = set_device(h);
+    if (rc) { delete h; return rc; }
+    std::vector<int> rp(n + 1), cl(nnz);
+    std::vector<double> G(nnz), B(nnz);
+    for (int i = 0; i <= n; ++i) rp[i] = (int)(colptr[i] - 1);
+    for (int p = 0; p < nnz; ++p) { cl[p] = (int)(rowval[p] - 1); G[p] = yt_reim[2 * p]; B[p] = yt_reim[2 * p + 1]; }
+    // consistency of the two value arrays the reference keeps (T1): yT[p] must equal y[tperm[p]]
+    for (int p = 0; p < nnz; ++p)
+        if (y_reim[2 * (size_t)h->tperm[p]] != yt_reim[2 * p] || y_reim[2 * (size_t)h->tperm[p] + 1] != yt_reim[2 * p + 1]) {
+            delete h; return fail(4, "jg_nr_create: nodalMatrix and nodalMatrixTranspose disagree (stale model)");
+        }
+    std::vector<signed char> flags(n);
+    for (int i = 0; i < n; ++i) flags[i] = (signed char)((type[i] != 3 ? 1 : 0) | (type[i] == 1 ? 2 : 0));
+    std::string err;
+    std::vector<signed char> tp(type, type + n);
+    if (jg::upload(&h->d_rowptr, rp, err) || jg::upload(&h->d_col, cl, err) || jg::upload(&h->d_G, G, err) ||
+        jg::upload(&h->d_B, B, err) || jg::upload(&h->d_type, tp, err) || jg::upload(&h->d_flags, flags, err)) {
+        jg_nr_destroy(h); return fail(2, err);
+    }
+    h->nchunk = (h->n + ASM_ROWS - 1) / ASM_ROWS;
+    const size_t ld = h->ld;
+    auto dmalloc = [&](void** p, size_t bytes) -> bool {
+        if (hipMalloc(p, bytes) != hipSuccess) return false;
+        return hipMemset(*p, 0, bytes) == hipSuccess;
+    };
+    const size_t mpn = h->mp > 0 ? h->mp : 1;
+    bool ok = dmalloc((void**)&h->d_vm, n * ld * 8) && dmalloc((void**)&h->d_va, n * ld * 8) &&
+              dmalloc((void**)&h->d_p, n * ld * 8) && dmalloc((void**)&h->d_q, n * ld * 8) &&
+              dmalloc((void**)&h->d_ppos, mpn * ld * 4) && dmalloc((void**)&h->d_pdg, mpn * ld * 8) &&
+              dmalloc((void**)&h->d_pdb, mpn * ld * 8) && dmalloc((void**)&h->d_A, (size_t)nnz * 4 * ld * 8) &&
+              dmalloc((void**)&h->d_F, n * 2 * ld * 8) && dmalloc((void**)&h->d_inc, n * 2 * ld * 8) &&
+              dmalloc((void**)&h->d_part, (size_t)h->nchunk * 2 * ld * 8) && dmalloc((void**)&h->d_normp, ld * 8) &&
+              dmalloc((void**)&h->d_normq, ld * 8) && dmalloc((void**)&h->d_params, 2 * 8) &&
+              dmalloc((void**)&h->d_active, ld * 4) && dmalloc((void**)&h->d_iters, ld * 4) &&
+              dmalloc((void**)&h->d_status, ld * 4) && dmalloc((void**)&h->d_counter, 4);
+    if (!ok) { jg_nr_destroy(h); return fail(2, "jg_nr_create: device allocation failed"); }
+    if (hipMemset(h->d_ppos, 0xff, mpn * ld * 4) != hipSuccess ||                 // -1 = no patch
+        hipHostMalloc((void**)&h->h_counter, sizeof(int)) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        jg_nr_destroy(h); return fail(2, "jg_nr_create: stream / pinned allocation failed");
+    }
+    rc = h->eng.create(n, rp.data(), cl.data(), h->ld, 0);
+    if (rc) { std::string m = h->eng.error; jg_nr_destroy(h); return fail(rc, m); }
+    *out = h;
+    return 0;
+}
+
+void jg_nr_destroy(jg_nr* h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->execA) hipGraphExecDestroy(h->execA);
+    if (h->execB) hipGraphExecDestroy(h->execB);
+    if (h->graphA) hipGraphDestroy(h->graphA);
+    if (h->graphB) hipGraphDestroy(h->graphB);
+    h->eng.destroy();
+    hipFree(h->d_rowptr); hipFree(h->d_col); hipFree(h->d_G); hipFree(h->d_B); hipFree(h->d_type); hipFree(h->d_flags);
+    hipFree(h->d_vm); hipFree(h->d_va); hipFree(h->d_p); hipFree(h->d_q); hipFree(h->d_ppos); hipFree(h->d_pdg);
+    hipFree(h->d_pdb); hipFree(h->d_A); hipFree(h->d_F); hipFree(h->d_inc); hipFree(h->d_part); hipFree(h->d_normp);
+    hipFree(h->d_normq); hipFree(h->d_params); hipFree(h->d_active); hipFree(h->d_iters); hipFree(h->d_status);
+    hipFree(h->d_counter);
+    if (h->h_counter) hipHostFree(h->h_counter);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int jg_nr_dims(jg_nr* h, int64_t* dims) {
+    if (!h || !dims) return fail(1, "jg_nr_dims: bad argument");
+    dims[0] = h->dimJ; dims[1] = h->nnzJ; dims[2] = h->eng.S.n_entries; dims[3] = h->eng.S.n_terms;
+    dims[4] = (int64_t)h->eng.S.lu.launches.size();
+    dims[5] = (int64_t)(h->eng.S.fwd.launches.size() + h->eng.S.bwd.launches.size());
+    return 0;
+}
+
+int jg_nr_set_injection(jg_nr* h, const double* p, const double* q, int64_t stride) {
+    if (!h || !p || !q || stride < 0) return fail(1, "jg_nr_set_injection: bad argument");
+    if (int rc = set_device(h)) return rc;
+    NR_HIP(hipStreamSynchronize(h->stream));
+    if (int rc = put_bus_array(h, h->d_p, p, stride)) return rc;
+    if (int rc = put_bus_array(h, h->d_q, q, stride)) return rc;
+    h->jac_valid = false;
+    return 0;
+}
+
+int jg_nr_set_voltage(jg_nr* h, const double* vm, const double* va, int64_t stride) {
+    if (!h || !vm || !va || stride < 0) return fail(1, "jg_nr_set_voltage: bad argument");
+    if (int rc = set_device(h)) return rc;
+    NR_HIP(hipStreamSynchronize(h->stream));
+    if (int rc = put_bus_array(h, h->d_vm, vm, stride)) return rc;
+    if (int rc = put_bus_array(h, h->d_va, va, stride)) return rc;
+    h->jac_valid = false;
+    return 0;
+}
+
+static int get_bus_array(jg_nr* h, const double* src, double* dst, int comps) {
+    // device [n*comps][ld] -> host [batch][n*comps]
+    const size_t rows = (size_t)h->n * comps;
+    std::vector<double> t(rows * h->ld);
+    NR_HIP(hipMemcpy(t.data(), src, t.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int b = 0; b < h->batch; ++b)
+        for (size_t r = 0; r < rows; ++r) dst[(size_t)b * rows + r] = t[r * h->ld + b];
+    return 0;
+}
+
+int jg_nr_get_voltage(jg_nr* h, double* vm, double* va) {
+    if (!h || !vm || !va) return fail(1, "jg_nr_get_voltage: bad argument");
+    if (int rc = set_device(h)) return rc;
+    NR_HIP(hipStreamSynchronize(h->stream));
+    if (int rc = get_bus_array(h, h->d_vm, vm, 1)) return rc;
+    return get_bus_array(h, h->d_va, va, 1);
+}
+
+int jg_nr_patch_ybus(jg_nr* h, int64_t scenario, int64_t k, const int64_t* ptr, const double* dy) {
+    if (!h || scenario < 0 || scenario >= h->batch || k < 0 || k > h->mp || (k > 0 && (!ptr || !dy)))
+        return fail(1, "jg_nr_patch_ybus: bad argument (scenario / entry count beyond max_patch)");
+    if (int rc = set_device(h)) return rc;
+    NR_HIP(hipStreamSynchronize(h->stream));
+    for (int m = 0; m < h->mp; ++m) {
+        int pos = -1; double g = 0.0, b = 0.0;
+        if (m < k) {
+            if (ptr[m] < 1 || ptr[m] > h->nnz) return fail(1, "jg_nr_patch_ybus: pointer out of range");
+            pos = h->tperm[ptr[m] - 1]; g = dy[2 * m]; b = dy[2 * m + 1];
+            for (int mm = 0; mm < m; ++mm) if (ptr[mm] == ptr[m]) return fail(1, "jg_nr_patch_ybus: duplicate pointer");
+        }
+        const size_t off = (size_t)m * h->ld + scenario;
+        NR_HIP(hipMemcpy(h->d_ppos + off, &pos, sizeof(int), hipMemcpyHostToDevice));
+        NR_HIP(hipMemcpy(h->d_pdg + off, &g, sizeof(double), hipMemcpyHostToDevice));
+        NR_HIP(hipMemcpy(h->d_pdb + off, &b, sizeof(double), hipMemcpyHostToDevice));
+    }
+    h->jac_valid = false;
+    return 0;
+}
+
+int jg_nr_set_ybus(jg_nr* h, const double* y_reim, const double* yt_reim) {
+    if (!h || !y_reim || !yt_reim) return fail(1, "jg_nr_set_ybus: bad argument");
+    if (int rc = set_device(h)) return rc;
+    std::vector<double> G(h->nnz), B(h->nnz);
+    for (int p = 0; p < h->nnz; ++p) {
+        G[p] = yt_reim[2 * p]; B[p] = yt_reim[2 * p + 1];
+        if (y_reim[2 * (size_t)h->tperm[p]] != G[p] || y_reim[2 * (size_t)h->tperm[p] + 1] != B[p])
+            return fail(4, "jg_nr_set_ybus: nodalMatrix and nodalMatrixTranspose disagree (stale model)");
+    }
+    NR_HIP(hipStreamSynchronize(h->stream));
+    NR_HIP(hipMemcpy(h->d_G, G.data(), G.size() * 8, hipMemcpyHostToDevice));
+    NR_HIP(hipMemcpy(h->d_B, B.data(), B.size() * 8, hipMemcpyHostToDevice));
+    h->jac_valid = false;
+    return 0;
+}
+
+int jg_nr_mismatch(jg_nr* h, double* max_p, double* max_q) {
+    if (!h) return fail(1, "jg_nr_mismatch: bad argument");
+    if (int rc = set_device(h)) return rc;
+    launch_assemble(h);
+    launch_check(h, 0);
+    NR_HIP(hipGetLastError());
+    NR_HIP(hipStreamSynchronize(h->stream));
+    h->jac_valid = true;
+    if (max_p) NR_HIP(hipMemcpy(max_p, h->d_normp, (size_t)h->batch * 8, hipMemcpyDeviceToHost));
+    if (max_q) NR_HIP(hipMemcpy(max_q, h->d_normq, (size_t)h->batch * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int jg_nr_solve(jg_nr* h) {
+    if (!h) return fail(1, "jg_nr_solve: bad argument");
+    if (int rc = set_device(h)) return rc;
+    if (!h->jac_valid) launch_assemble(h);
+    NR_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
+    if (int rc = h->eng.factor(h->stream, h->d_A)) return fail(rc, h->eng.error);
+    jg::StateUpdate upd{h->d_va, h->d_vm, h->d_flags, nullptr, -1.0};
+    if (int rc = h->eng.solve(h->stream, h->d_F, h->d_inc, upd)) return fail(rc, h->eng.error);
+    hipLaunchKernelGGL(k_add_iter, dim3((h->ld + 255) / 256), dim3(256), 0, h->stream, h->d_iters, h->ld);
+    NR_HIP(hipGetLastError());
+    NR_HIP(hipStreamSynchronize(h->stream));
+    h->jac_valid = false;
+    std::vector<int> st(h->ld);
+    NR_HIP(hipMemcpy(st.data(), h->eng.status, (size_t)h->ld * 4, hipMemcpyDeviceToHost));
+    for (int b = 0; b < h->batch; ++b) if (st[b] & 4) return fail(3, "jg_nr_solve: zero or non-finite pivot (singular Jacobian)");
+    return 0;
+}
+
+int jg_nr_run(jg_nr* h, int64_t max_iter, double tol, int32_t* iters, int32_t* status) {
+    if (!h || max_iter < 0 || !(tol > 0.0)) return fail(1, "jg_nr_run: bad argument");
+    if (int rc = set_device(h)) return rc;
+    if (int rc = build_graphs(h)) return rc;
+    const double params[2] = {tol, (double)max_iter};
+    NR_HIP(hipMemcpyAsync(h->d_params, params, sizeof(params), hipMemcpyHostToDevice, h->stream));
+    NR_HIP(hipMemsetAsync(h->d_iters, 0, (size_t)h->ld * 4, h->stream));      // acPowerFlow.jl:1401
+    NR_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
+    for (int64_t it = 0; it <= max_iter; ++it) {                               // acPowerFlow.jl:1406
+        NR_HIP(hipGraphLaunch(h->execA, h->stream));
+        NR_HIP(hipStreamSynchronize(h->stream));
+        if (*h->h_counter == 0) break;
+        NR_HIP(hipGraphLaunch(h->execB, h->stream));
+    }
+    NR_HIP(hipStreamSynchronize(h->stream));
+    h->jac_valid = true;
+    if (iters) NR_HIP(hipMemcpy(iters, h->d_iters, (size_t)h->batch * 4, hipMemcpyDeviceToHost));
+    if (status) NR_HIP(hipMemcpy(status, h->d_status, (size_t)h->batch * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int jg_nr_get_mismatch(jg_nr* h, double* mism) {
+    if (!h || !mism) return fail(1, "jg_nr_get_mismatch: bad argument");
+    if (int rc = set_device(h)) return rc;
+    NR_HIP(hipStreamSynchronize(h->stream));
+    std::vector<double> t((size_t)h->n * 2 * h->batch);
+    if (int rc = get_bus_array(h, h->d_F, t.data(), 2)) return rc;
+    for (int b = 0; b < h->batch; ++b) {
+        const double* s = t.data() + (size_t)b * h->n * 2;
+        double* d = mism + (size_t)b * h->dimJ;
+        for (int i = 0; i < h->n; ++i) {
+            if (h->pvpq[i]) d[h->pvpq[i] - 1] = s[2 * i];
+            if (h->pq[i]) d[h->pq[i] - 1] = s[2 * i + 1];
+        }
+    }
+    return 0;
+}
+
+int jg_nr_get_increment(jg_nr* h, double* incr) {
+    if (!h || !incr) return fail(1, "jg_nr_get_increment: bad argument");
+    if (int rc = set_device(h)) return rc;
+    NR_HIP(hipStreamSynchronize(h->stream));
+    std::vector<double> t((size_t)h->n * 2 * h->batch);
+    if (int rc = get_bus_array(h, h->d_inc, t.data(), 2)) return rc;
+    for (int b = 0; b < h->batch; ++b) {
+        const double* s = t.data() + (size_t)b * h->n * 2;
+        double* d = incr + (size_t)b * h->dimJ;
+        for (int i = 0; i < h->n; ++i) {
+            if (h->pvpq[i]) d[h->pvpq[i] - 1] = s[2 * i];
+            if (h->pq[i]) d[h->pq[i] - 1] = s[2 * i + 1];
+        }
+    }
+    return 0;
+}
+
+int jg_nr_get_jacobian(jg_nr* h, double* nzval) {
+    if (!h || !nzval) return fail(1, "jg_nr_get_jacobian: bad argument");
+    if (int rc = set_device(h)) return rc;
+    NR_HIP(hipStreamSynchronize(h->stream));
+    std::vector<double> t((size_t)h->nnz * 4 * h->ld);
+    NR_HIP(hipMemcpy(t.data(), h->d_A, t.size() * 8, hipMemcpyDeviceToHost));
+    for (int b = 0; b < h->batch; ++b)
+        for (int64_t k = 0; k < h->nnzJ; ++k) nzval[(size_t)b * h->nnzJ + k] = t[(size_t)h->jmap[k] * h->ld + b];
+    return 0;
+}
+
+int jg_nr_get_maps(jg_nr* h, int64_t* pq, int64_t* pvpq, int64_t* pcount, int64_t* jcolptr, int64_t* jrowval) {
+    if (!h) return fail(1, "jg_nr_get_maps: bad argument");
+    if (pq) std::memcpy(pq, h->pq.data(), h->pq.size() * 8);
+    if (pvpq) std::memcpy(pvpq, h->pvpq.data(), h->pvpq.size() * 8);
+    if (pcount) std::memcpy(pcount, h->pcount.data(), h->pcount.size() * 8);
+    if (jcolptr) std::memcpy(jcolptr, h->jcolptr.data(), h->jcolptr.size() * 8);
+    if (jrowval) std::memcpy(jrowval, h->jrowval.data(), h->jrowval.size() * 8);
+    return 0;
+}
+
+int jg_nr_get_iteration(jg_nr* h, int32_t* iters) {
+    if (!h || !iters) return fail(1, "jg_nr_get_iteration: bad argument");
+    if (int rc = set_device(h)) return rc;
+    NR_HIP(hipStreamSynchronize(h->stream));
+    NR_HIP(hipMemcpy(iters, h->d_iters, (size_t)h->batch * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int jg_nr_time_kernel(jg_nr* h, int kernel, int reps, double* mean_ms) {
+    if (!h || reps < 1 || !mean_ms || kernel < 0 || kernel > 2) return fail(1, "jg_nr_time_kernel: bad argument");
+    if (int rc = set_device(h)) return rc;
+    hipEvent_t e0, e1;
+    NR_HIP(hipEventCreate(&e0));
+    NR_HIP(hipEventCreate(&e1));
+    jg::StateUpdate none{};
+    NR_HIP(hipStreamSynchronize(h->stream));
+    NR_HIP(hipEventRecord(e0, h->stream));
+    for (int r = 0; r < reps; ++r) {
+        if (kernel == 0) launch_assemble(h);
+        else if (kernel == 1) { if (int rc = h->eng.factor(h->stream, h->d_A)) return fail(rc, h->eng.error); }
+        else { if (int rc = h->eng.solve(h->stream, h->d_F, h->d_inc, none)) return fail(rc, h->eng.error); }
+    }
+    NR_HIP(hipEventRecord(e1, h->stream));
+    NR_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    NR_HIP(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *mean_ms = (double)ms / reps;
+    return 0;
+}
+
+}  // extern "C"

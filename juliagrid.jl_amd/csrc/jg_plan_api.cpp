@@ -1,0 +1,68 @@
+// jg_plan_api.cpp -- device-free access to the symbolic analysis (C ABI, see include/jgrid.h).
+// Lets the CPU test-suite replay the static LU / solve schedules in numpy and check every
+// dependency (a race detector for the schedule) without a GPU.  No numeric code here.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/jgrid.h"
+#include "jg_symbolic.hpp"
+
+struct jg_plan {
+    jg::BlockSymbolic S;
+};
+
+namespace {
+void flatten(const jg::Schedule& s, std::vector<int>& launch) {
+    launch.clear();
+    for (const jg::Launch& L : s.launches) { launch.push_back(L.task_begin); launch.push_back(L.task_end); launch.push_back(L.waves); }
+}
+}  // namespace
+
+extern "C" {
+
+int jg_plan_create(jg_plan** out, int64_t n, const int32_t* rowptr, const int32_t* col, int policy) {
+    if (!out || !rowptr || !col || n < 1) return 1;
+    jg_plan* p = new jg_plan();
+    if (jg::analyze((int)n, rowptr, col, policy, p->S)) { delete p; return 1; }
+    *out = p;
+    return 0;
+}
+
+void jg_plan_destroy(jg_plan* p) { delete p; }
+
+// which: 0 perm, 1 e_row, 2 e_col, 3 e_src, 4 t_ptr, 5 t_a, 6 t_b, 7 e_level, 8 e_diag, 9 diag,
+//        10 l_ptr, 11 l_ent, 12 l_col, 13 u_ptr, 14 u_ent, 15 u_col,
+//        20/30/40 + k: schedule lu/fwd/bwd: k=0 launches (begin,end,waves triples), 1 task_ptr, 2 step_ptr, 3 items
+// out == NULL returns the length.
+int64_t jg_plan_export(jg_plan* p, int which, int32_t* out, int64_t cap) {
+    if (!p) return -1;
+    const jg::BlockSymbolic& S = p->S;
+    std::vector<int> tmp;
+    const std::vector<int>* v = nullptr;
+    switch (which) {
+        case 0: v = &S.perm; break;   case 1: v = &S.e_row; break;  case 2: v = &S.e_col; break;
+        case 3: v = &S.e_src; break;  case 4: v = &S.t_ptr; break;  case 5: v = &S.t_a; break;
+        case 6: v = &S.t_b; break;    case 7: v = &S.e_level; break; case 8: v = &S.e_diag; break;
+        case 9: v = &S.diag; break;   case 10: v = &S.l_ptr; break; case 11: v = &S.l_ent; break;
+        case 12: v = &S.l_col; break; case 13: v = &S.u_ptr; break; case 14: v = &S.u_ent; break;
+        case 15: v = &S.u_col; break;
+        default: {
+            const jg::Schedule* s = which >= 40 ? &S.bwd : (which >= 30 ? &S.fwd : (which >= 20 ? &S.lu : nullptr));
+            if (!s) return -1;
+            switch (which % 10) {
+                case 0: flatten(*s, tmp); v = &tmp; break;
+                case 1: v = &s->task_ptr; break;
+                case 2: v = &s->step_ptr; break;
+                case 3: v = &s->items; break;
+                default: return -1;
+            }
+        }
+    }
+    if (!out) return (int64_t)v->size();
+    if ((int64_t)v->size() > cap) return -1;
+    std::memcpy(out, v->data(), v->size() * sizeof(int));
+    return (int64_t)v->size();
+}
+
+}  // extern "C"

@@ -1,0 +1,256 @@
+"""Newton-Raphson AC power flow: host-side mirror of the reference interface over the C ABI.
+
+Reference surface (paths relative to /root/reference)      here
+  newtonRaphson(system)        acPowerFlow.jl:39-87          newtonRaphson(system, batch=1)
+  mismatch!(analysis)          acPowerFlow.jl:645-685        mismatch_(analysis)
+  solve!(analysis)             acPowerFlow.jl:793-911        solve_(analysis)
+  powerFlow!(analysis; ...)    acPowerFlow.jl:1389-1433      powerFlow_(analysis, iteration=20, tolerance=1e-8)
+  setInitialPoint!(analysis)   acPowerFlow.jl:1226-1249      setInitialPoint_(analysis[, source])
+  updateBranch!(analysis; ...) branch.jl:453-459             updateBranch_(analysis, label, status=...)
+  analysis.voltage.{magnitude,angle}, analysis.method.{jacobian,mismatch,increment,pq,pvpq,iteration}
+
+(`!` is spelled with a trailing underscore.)  The only addition is `batch`: B independent scenarios
+of the same grid (N-1 outages through setOutage_, Monte-Carlo injections through setInjection_)
+advance in lock-step on the device; with batch == 1 every container has the reference's shape.
+
+All numerics run in libjgrid_hip.so (hand-written HIP); this file is plumbing and bookkeeping.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from types import SimpleNamespace as NS
+
+import numpy as np
+
+from . import _lib
+from .system import CscMatrix, PowerSystem, acModel_, updateBranch_ as _update_branch_system
+
+
+def _reim(z):
+    out = np.empty(2 * z.size, dtype=np.float64)
+    out[0::2], out[1::2] = z.real, z.imag
+    return out
+
+
+def initializeACPowerFlow(system: PowerSystem):
+    """Bus-type normalisation, start voltages, slack relocation (acPowerFlow.jl:1312-1358)."""
+    bus, gen = system.bus, system.generator
+    magnitude = bus.voltage.magnitude.copy()
+    angle = bus.voltage.angle.copy()
+    typ = bus.layout.type
+    for i in range(bus.number):
+        has = (i + 1) in bus.supply.generator
+        if not has and typ[i] == 2:
+            typ[i] = 1
+            system.model.revision.type += 1
+        if has and typ[i] != 1:
+            magnitude[i] = gen.voltage.magnitude[bus.supply.generator[i + 1][0] - 1]
+    slack = bus.layout.slack
+    if slack not in bus.supply.generator:                      # changeSlackBus! (:1334-1358)
+        typ[slack - 1] = 1
+        system.model.revision.type += 1
+        for i in range(bus.number):
+            if typ[i] == 2 and (i + 1) in bus.supply.generator:
+                typ[i] = 3
+                bus.layout.slack = i + 1
+                system.model.revision.type += 1
+                system.model.revision.slack += 1
+                break
+        if typ[bus.layout.slack - 1] == 1:
+            raise RuntimeError("No generator buses with an in-service generator found in the power system.")
+    return magnitude, angle
+
+
+class AcPowerFlow:
+    """AcPowerFlow{NewtonRaphson{HIP}} (src/definition/analysis.jl:154-164, 252-258)."""
+
+    def __init__(self, system: PowerSystem, batch: int, device: int, max_patch: int):
+        L = _lib.lib()
+        self.system = system
+        self.batch = int(batch)
+        ac = system.model.ac
+        Y, YT = ac.nodalMatrix, ac.nodalMatrixTranspose
+        n = system.bus.number
+        self._h = _lib.VP()
+        _lib.check(L.jg_nr_create(C.byref(self._h), n, Y.colptr, Y.rowval, _reim(Y.nzval), _reim(YT.nzval),
+                                  np.ascontiguousarray(system.bus.layout.type, dtype=np.int8),
+                                  system.bus.layout.slack, self.batch, int(max_patch), int(device)))
+        dims = np.zeros(8, dtype=np.int64)
+        _lib.check(L.jg_nr_dims(self._h, dims))
+        self.dims = dict(dimJ=int(dims[0]), nnzJ=int(dims[1]), lu_blocks=int(dims[2]), lu_terms=int(dims[3]),
+                         lu_launches=int(dims[4]), solve_launches=int(dims[5]), nnzY=Y.nnz, n=n)
+        pq, pvpq, pcount = (np.zeros(n, dtype=np.int64) for _ in range(3))
+        jcolptr = np.zeros(self.dims["dimJ"] + 1, dtype=np.int64)
+        jrowval = np.zeros(self.dims["nnzJ"], dtype=np.int64)
+        _lib.check(L.jg_nr_get_maps(self._h, pq, pvpq, pcount, jcolptr, jrowval))
+        self.method = NS(pq=pq, pvpq=pvpq, pcount=pcount, iteration=0, _jcolptr=jcolptr, _jrowval=jrowval,
+                         signature=NS(topology=system.model.revision.topology, type=system.model.revision.type))
+        self.voltage = NS(magnitude=None, angle=None)
+        self.status = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().jg_nr_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # ---- containers with the reference's names --------------------------------------------
+    def _shape(self, a):
+        return a[0] if self.batch == 1 else a
+
+    def _pull_voltage(self):
+        n = self.system.bus.number
+        vm = np.zeros((self.batch, n))
+        va = np.zeros((self.batch, n))
+        _lib.check(_lib.lib().jg_nr_get_voltage(self._h, vm, va))
+        self.voltage.magnitude, self.voltage.angle = self._shape(vm), self._shape(va)
+
+    @property
+    def mismatch(self):
+        m = np.zeros((self.batch, self.dims["dimJ"]))
+        _lib.check(_lib.lib().jg_nr_get_mismatch(self._h, m))
+        return self._shape(m)
+
+    @property
+    def increment(self):
+        m = np.zeros((self.batch, self.dims["dimJ"]))
+        _lib.check(_lib.lib().jg_nr_get_increment(self._h, m))
+        return self._shape(m)
+
+    @property
+    def jacobian(self):
+        """analysis.method.jacobian: CSC with the reference's pattern; nzval [nnzJ] (or [batch, nnzJ])."""
+        v = np.zeros((self.batch, self.dims["nnzJ"]))
+        _lib.check(_lib.lib().jg_nr_get_jacobian(self._h, v))
+        return CscMatrix(self.dims["dimJ"], self.method._jcolptr, self.method._jrowval, self._shape(v))
+
+    @property
+    def iterations(self):
+        it = np.zeros(self.batch, dtype=np.int32)
+        _lib.check(_lib.lib().jg_nr_get_iteration(self._h, it))
+        return it
+
+    def time_kernel(self, kernel: int, reps: int = 10) -> float:
+        ms = C.c_double(0.0)
+        _lib.check(_lib.lib().jg_nr_time_kernel(self._h, int(kernel), int(reps), C.byref(ms)))
+        return ms.value
+
+
+def _push_voltage(an: AcPowerFlow, vm, va):
+    vm = np.ascontiguousarray(vm, dtype=np.float64)
+    va = np.ascontiguousarray(va, dtype=np.float64)
+    n = an.system.bus.number
+    stride = 0 if vm.ndim == 1 else n
+    if vm.ndim == 2 and vm.shape[0] != an.batch:
+        raise ValueError("voltage batch dimension mismatch")
+    _lib.check(_lib.lib().jg_nr_set_voltage(an._h, vm.reshape(-1), va.reshape(-1), stride))
+    an._pull_voltage()
+
+
+def setInjection_(an: AcPowerFlow, active=None, reactive=None):
+    """Net injections supply - demand per scenario ([n] broadcast or [batch, n]);
+    default = the system's own bus.supply - bus.demand (acPowerFlow.jl:676-680)."""
+    bus = an.system.bus
+    p = bus.supply.active - bus.demand.active if active is None else active
+    q = bus.supply.reactive - bus.demand.reactive if reactive is None else reactive
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    stride = 0 if p.ndim == 1 else bus.number
+    _lib.check(_lib.lib().jg_nr_set_injection(an._h, p.reshape(-1), q.reshape(-1), stride))
+
+
+def newtonRaphson(system: PowerSystem, batch: int = 1, device: int = 0, max_patch: int | None = None) -> AcPowerFlow:
+    """newtonRaphson(system) (acPowerFlow.jl:39-87). Mutates bus types / slack like the reference."""
+    if system.bus.layout.slack == 0:
+        raise RuntimeError("The slack bus is missing.")
+    if system.model.ac.nodalMatrix is None:
+        acModel_(system)                                          # model!(system, ac) :43
+    vm, va = initializeACPowerFlow(system)
+    if max_patch is None:
+        max_patch = 0 if batch == 1 else 4
+    an = AcPowerFlow(system, batch, device, max_patch)
+    setInjection_(an)
+    _push_voltage(an, vm, va)
+    return an
+
+
+def mismatch_(an: AcPowerFlow):
+    """mismatch!(analysis) -> (max|f_P|, max|f_Q|); arrays of length batch when batch > 1."""
+    p = np.zeros(an.batch)
+    q = np.zeros(an.batch)
+    _lib.check(_lib.lib().jg_nr_mismatch(an._h, p, q))
+    return (float(p[0]), float(q[0])) if an.batch == 1 else (p, q)
+
+
+def _check_signature(an: AcPowerFlow):
+    rev, sig = an.system.model.revision, an.method.signature
+    if rev.topology != sig.topology or rev.type != sig.type:     # acPowerFlow.jl:802-804
+        raise RuntimeError("The power flow model cannot be reused due to required bus type conversion.")
+
+
+def solve_(an: AcPowerFlow):
+    """solve!(analysis): Jacobian fill + refactorization + solve + state update on the device."""
+    _check_signature(an)
+    _lib.check(_lib.lib().jg_nr_solve(an._h))
+    an.method.iteration += 1
+    an._pull_voltage()
+
+
+def powerFlow_(an: AcPowerFlow, iteration: int = 20, tolerance: float = 1e-8):
+    """powerFlow!(analysis; iteration, tolerance). Sets analysis.method.iteration (array if batch > 1)
+    and analysis.status (0 converged, 1 iteration limit, 3 numeric failure)."""
+    _check_signature(an)
+    it = np.zeros(an.batch, dtype=np.int32)
+    st = np.zeros(an.batch, dtype=np.int32)
+    _lib.check(_lib.lib().jg_nr_run(an._h, int(iteration), float(tolerance), it, st))
+    an.method.iteration = int(it[0]) if an.batch == 1 else it
+    an.status = int(st[0]) if an.batch == 1 else st
+    an._pull_voltage()
+
+
+def setInitialPoint_(an: AcPowerFlow, source=None):
+    """setInitialPoint!(analysis) / setInitialPoint!(target, source) (acPowerFlow.jl:1226-1295)."""
+    bus, gen = an.system.bus, an.system.generator
+    if source is not None:
+        _push_voltage(an, source.voltage.magnitude, source.voltage.angle)
+        return
+    vm = bus.voltage.magnitude.copy()
+    for i in range(bus.number):
+        if (i + 1) in bus.supply.generator and bus.layout.type[i] != 1:
+            vm[i] = gen.voltage.magnitude[bus.supply.generator[i + 1][0] - 1]
+    _push_voltage(an, vm, bus.voltage.angle.copy())
+
+
+def _upload_ybus(an: AcPowerFlow):
+    ac = an.system.model.ac
+    _lib.check(_lib.lib().jg_nr_set_ybus(an._h, _reim(ac.nodalMatrix.nzval), _reim(ac.nodalMatrixTranspose.nzval)))
+
+
+def updateBranch_(an: AcPowerFlow, label: int, status: int | None = None):
+    """updateBranch!(analysis; label, status): edits the system (stored zeros keep the pattern, so the
+    symbolic analysis is reused exactly like the reference's `lu!` path) and syncs the device copy."""
+    _update_branch_system(an.system, label, status=status)
+    _upload_ybus(an)
+    an.method.signature.topology = an.system.model.revision.topology     # syncTopology! branch.jl:461-463
+
+
+def outagePatch(system: PowerSystem, label: int):
+    """The 4 Ybus edits of `updateBranch!(...; label, status = 0)` (branch.jl:344-350, model.jl:93-101)
+    as (1-based pointers into nodalMatrix.nzval, complex deltas)."""
+    k = int(label) - 1
+    ac, Y = system.model.ac, system.model.ac.nodalMatrix
+    i, j = int(system.branch.layout.from_[k]), int(system.branch.layout.to[k])
+    ptr = np.array([Y.position(i, i), Y.position(j, j), Y.position(i, j), Y.position(j, i)], dtype=np.int64) + 1
+    dy = -np.array([ac.nodalFromFrom[k], ac.nodalToTo[k], ac.nodalFromTo[k], ac.nodalToFrom[k]], dtype=np.complex128)
+    return ptr, dy
+
+
+def setOutage_(an: AcPowerFlow, scenario: int, label: int | None):
+    """Scenario `scenario` of a batched analysis = base grid with branch `label` out of service
+    (None restores the base grid)."""
+    if label is None:
+        _lib.check(_lib.lib().jg_nr_patch_ybus(an._h, int(scenario), 0, np.zeros(1, dtype=np.int64), np.zeros(2)))
+        return
+    ptr, dy = outagePatch(an.system, label)
+    _lib.check(_lib.lib().jg_nr_patch_ybus(an._h, int(scenario), 4, ptr, _reim(dy)))

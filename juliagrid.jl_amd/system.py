@@ -38,7 +38,7 @@ class PowerSystem:
         nb = t["br_from"].size
         ng = t["gen_bus"].size
         label = t["bus_label"] if "bus_label" in t else np.arange(1, n + 1, dtype=np.int64)
-        self.base = NS(power=float(t.get("base_power", 1e8)))
+        self.base = NS(power=float(np.asarray(t.get("base_power", 1e8)).reshape(-1)[0]))
         self.bus = NS(
             number=n,
             label={int(l): i + 1 for i, l in enumerate(label)},

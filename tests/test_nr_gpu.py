@@ -1,0 +1,245 @@
+"""Parity of the HIP Newton-Raphson path (through the C ABI) with the CPU oracle and the reference's
+golden vectors.  Tolerances (floating point, f64 everywhere):
+  * index maps pq/pvpq/pcount/jacobian colptr,rowval ........ bit-exact
+  * mismatch / Jacobian entries at the same state ............ 1e-12 relative to the largest entry
+    (device sincos differs from libm by <= 2 ulp; summation order is identical)
+  * Newton increment ......................................... 1e-9 relative (different LU algorithm:
+    static-pivot block LU on the device vs threshold-pivoting Gilbert-Peierls in the oracle)
+  * converged V, theta ....................................... 1e-8 absolute (the reference's own test bar,
+    test/utility/utility.jl:34-40, 197-206); iteration counts equal
+"""
+import numpy as np
+import pytest
+
+from conftest import load_case, load_golden
+
+pytestmark = pytest.mark.gpu
+
+SMALL = ["case14", "case14test", "case30test", "case118", "case300"]
+
+
+def _pair(jg, oracle, name, batch=1):
+    t = load_case(name)
+    s = jg.powerSystem(t)
+    an = jg.newtonRaphson(s, batch=batch)
+    o = oracle.OracleNR(oracle.OracleSystem(t))
+    return s, an, o
+
+
+@pytest.mark.parametrize("name", SMALL + ["case1354pegase", "case_ACTIVSg10k"])
+def test_index_maps_bit_exact(jg, oracle, name):
+    s, an, o = _pair(jg, oracle, name)
+    assert np.array_equal(an.method.pq, o.pq)
+    assert np.array_equal(an.method.pvpq, o.pvpq)
+    assert np.array_equal(an.method.pcount, o.pcount)
+    J = an.jacobian
+    assert np.array_equal(J.colptr, o.jcolptr)
+    assert np.array_equal(J.rowval, o.jrowval)
+    assert an.dims["dimJ"] == o.dim and an.dims["nnzJ"] == o.nnzJ
+
+
+@pytest.mark.parametrize("name", SMALL + ["case1354pegase", "case_ACTIVSg10k"])
+def test_mismatch_and_jacobian_elementwise(jg, oracle, name):
+    s, an, o = _pair(jg, oracle, name)
+    dp, dq = jg.mismatch_(an)
+    op, oq = o.mismatch()
+    _, f_ref, _ = o.vectors()
+    f = an.mismatch
+    scale = max(1.0, np.abs(f_ref).max())
+    assert np.abs(f - f_ref).max() <= 1e-12 * scale
+    assert abs(dp - op) <= 1e-12 * scale and abs(dq - oq) <= 1e-12 * scale
+    jv = an.jacobian.nzval                       # filled by the fused kernel
+    o.solve()
+    j_ref, _, inc_ref = o.vectors()
+    assert np.abs(jv - j_ref).max() <= 1e-12 * np.abs(j_ref).max()
+    jg.solve_(an)
+    inc = an.increment
+    assert np.abs(inc - inc_ref).max() <= 1e-9 * max(1.0, np.abs(inc_ref).max())
+    vm, va = o.voltage()
+    assert np.abs(an.voltage.magnitude - vm).max() <= 1e-9
+    assert np.abs(an.voltage.angle - va).max() <= 1e-9
+    assert an.method.iteration == 1 == o.iteration
+
+
+@pytest.mark.parametrize("name,iters", [("case14test", 7), ("case30test", 4)])
+def test_matpower_goldens(jg, name, iters):
+    """test/powerFlow/analysis.jl:1-44 through testVoltage: iteration count and V, theta."""
+    g = load_golden(name)
+    an = jg.newtonRaphson(jg.powerSystem(load_case(name)))
+    jg.powerFlow_(an)
+    assert an.status == 0
+    assert an.method.iteration == iters == int(g["newtonRaphson_iteration"][0])
+    assert np.abs(an.voltage.magnitude - g["newtonRaphson_voltageMagnitude"]).max() <= 1e-8
+    assert np.abs(an.voltage.angle - g["newtonRaphson_voltageAngle"]).max() <= 1e-8
+
+
+@pytest.mark.parametrize("name", ["case14", "case118", "case300", "case1354pegase", "case1951rte", "case_ACTIVSg10k"])
+def test_power_flow_matches_oracle(jg, oracle, name):
+    s, an, o = _pair(jg, oracle, name)
+    jg.powerFlow_(an)
+    assert o.power_flow() == 0 and an.status == 0
+    assert an.method.iteration == o.iteration
+    vm, va = o.voltage()
+    assert np.abs(an.voltage.magnitude - vm).max() <= 1e-8
+    assert np.abs(an.voltage.angle - va).max() <= 1e-8
+    # residual of the device solution evaluated by the oracle
+    o.set_voltage(an.voltage.magnitude, an.voltage.angle)
+    assert max(o.mismatch()) < 1e-8
+
+
+def test_iteration_limit_and_loop_accounting(jg, oracle):
+    """acPowerFlow.jl:1406-1420: at most `iteration` solves; status 1 when the limit hits."""
+    s, an, o = _pair(jg, oracle, "case14test")
+    jg.powerFlow_(an, iteration=3)
+    assert o.power_flow(iteration=3) == 1
+    assert an.status == 1 and an.method.iteration == 3 == o.iteration
+    vm, va = o.voltage()
+    assert np.abs(an.voltage.magnitude - vm).max() <= 1e-9 and np.abs(an.voltage.angle - va).max() <= 1e-9
+    jg.powerFlow_(an, iteration=0)
+    assert an.method.iteration == 0
+
+
+def test_set_initial_point_and_rerun(jg):
+    """test/powerFlow/analysis.jl:52-57: setInitialPoint! restores the start voltages exactly."""
+    an = jg.newtonRaphson(jg.powerSystem(load_case("case30test")))
+    vm0, va0 = an.voltage.magnitude.copy(), an.voltage.angle.copy()
+    jg.powerFlow_(an)
+    v1 = an.voltage.magnitude.copy()
+    jg.setInitialPoint_(an)
+    assert np.array_equal(an.voltage.magnitude, vm0) and np.array_equal(an.voltage.angle, va0)
+    jg.powerFlow_(an)
+    assert an.method.iteration == 4
+    assert np.array_equal(an.voltage.magnitude, v1)          # run-to-run bitwise determinism
+
+
+def test_update_branch_reuse_equals_fresh(jg):
+    """test/powerFlow/reusing.jl:59-69 + test/utility/utility.jl:197-206: after status toggles a reused
+    analysis (refactorization path, stored zeros) equals a freshly built one: iterations equal,
+    voltages within 1e-8 at tolerance 1e-10."""
+    t = load_case("case14test")
+    s = jg.powerSystem(t)
+    an = jg.newtonRaphson(s)
+    jg.powerFlow_(an, tolerance=1e-10)
+    for label, status in ((12, 0), (3, 1), (12, 1), (5, 0)):
+        jg.updateBranch_(an, label, status=status)
+        jg.setInitialPoint_(an)
+        jg.powerFlow_(an, tolerance=1e-10)
+        t2 = dict(t)
+        t2["br_status"] = s.branch.layout.status.copy()
+        fresh = jg.newtonRaphson(jg.powerSystem(t2))
+        jg.powerFlow_(fresh, tolerance=1e-10)
+        assert an.method.iteration == fresh.method.iteration
+        assert np.abs(an.voltage.magnitude - fresh.voltage.magnitude).max() <= 1e-8
+        assert np.abs(an.voltage.angle - fresh.voltage.angle).max() <= 1e-8
+
+
+def test_stale_bus_type_raises(jg):
+    """acPowerFlow.jl:802-804: a bus-type revision invalidates the analysis."""
+    s = jg.powerSystem(load_case("case14"))
+    an = jg.newtonRaphson(s)
+    s.model.revision.type += 1
+    with pytest.raises(RuntimeError):
+        jg.solve_(an)
+
+
+def _non_bridge_branches(t, count, seed):
+    """in-service branches whose removal keeps the grid connected (parallel pairs or cycle edges)."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import connected_components
+    n = t["bus_type"].size
+    on = np.flatnonzero(t["br_status"] == 1)
+    rng = np.random.default_rng(seed)
+    rng.shuffle(on)
+    out = []
+    for k in on:
+        keep = on[on != k]
+        g = sp.coo_matrix((np.ones(keep.size), (t["br_from"][keep] - 1, t["br_to"][keep] - 1)), shape=(n, n))
+        if connected_components(g, directed=False)[0] == 1:
+            out.append(int(k) + 1)
+        if len(out) == count:
+            break
+    return out
+
+
+@pytest.mark.parametrize("name,batch", [("case118", 70), ("case1354pegase", 16)])
+def test_batched_outages_match_oracle(jg, oracle, name, batch):
+    """Batched N-1: scenario s = base grid with one branch out, expressed as 4 Ybus
+    edits; each scenario must agree with the oracle solving that outage on its own."""
+    t = load_case(name)
+    labels = _non_bridge_branches(t, batch - 1, seed=7)
+    s = jg.powerSystem(t)
+    an = jg.newtonRaphson(s, batch=batch)
+    for sc, lab in enumerate(labels):
+        jg.setOutage_(an, sc, lab)          # last scenario stays the base case
+    jg.powerFlow_(an)
+    osys = oracle.OracleSystem(t)
+    for sc in range(batch):
+        o = oracle.OracleNR(osys)
+        if sc < len(labels):
+            ptr, dy = jg.outagePatch(s, labels[sc])
+            for p, d in zip(ptr, dy):
+                o.add_ybus(p - 1, d)
+        st = o.power_flow()
+        assert an.status[sc] == st
+        if st == 0:
+            assert an.method.iteration[sc] == o.iteration, (sc, labels[sc] if sc < len(labels) else None)
+            vm, va = o.voltage()
+            assert np.abs(an.voltage.magnitude[sc] - vm).max() <= 1e-8
+            assert np.abs(an.voltage.angle[sc] - va).max() <= 1e-8
+
+
+def test_batched_injections_match_oracle(jg, oracle):
+    """Monte-Carlo load variations: per-scenario injections, shared topology."""
+    t = load_case("case300")
+    s = jg.powerSystem(t)
+    B = 5
+    an = jg.newtonRaphson(s, batch=B)
+    rng = np.random.default_rng(3)
+    scale = 1.0 + 0.05 * rng.standard_normal((B, 1))
+    pd = s.bus.demand.active[None, :] * scale
+    qd = s.bus.demand.reactive[None, :] * scale
+    jg.setInjection_(an, s.bus.supply.active[None, :] - pd, s.bus.supply.reactive[None, :] - qd)
+    jg.powerFlow_(an)
+    osys = oracle.OracleSystem(t)
+    for b in range(B):
+        o = oracle.OracleNR(osys)
+        o.set_power(osys.ps, osys.qs, pd[b], qd[b])
+        assert o.power_flow() == 0 and an.status[b] == 0
+        assert an.method.iteration[b] == o.iteration
+        vm, va = o.voltage()
+        assert np.abs(an.voltage.magnitude[b] - vm).max() <= 1e-8
+        assert np.abs(an.voltage.angle[b] - va).max() <= 1e-8
+
+
+def test_full_size_batch_properties(jg, oracle):
+    """BASELINE config 5 shape on one GPU (ACTIVSg10k, 128 outage scenarios): size-independent
+    properties -- every converged scenario satisfies the power-flow equations when its state is
+    re-evaluated by the oracle; identical scenarios give bitwise-identical results; the base-case
+    scenario equals the single-instance solution."""
+    t = load_case("case_ACTIVSg10k")
+    B = 128
+    labels = _non_bridge_branches(t, B - 2, seed=512)
+    s = jg.powerSystem(t)
+    an = jg.newtonRaphson(s, batch=B)
+    for sc, lab in enumerate(labels):
+        jg.setOutage_(an, sc, lab)
+    jg.setOutage_(an, B - 2, labels[0])           # duplicate of scenario 0
+    jg.powerFlow_(an)
+    assert (an.status == 0).sum() >= B - 4
+    assert np.array_equal(an.voltage.magnitude[0], an.voltage.magnitude[B - 2])
+    assert np.array_equal(an.voltage.angle[0], an.voltage.angle[B - 2])
+    single = jg.newtonRaphson(jg.powerSystem(t))
+    jg.powerFlow_(single)
+    assert np.array_equal(single.voltage.magnitude, an.voltage.magnitude[B - 1])
+    assert single.method.iteration == an.method.iteration[B - 1]
+    osys = oracle.OracleSystem(t)
+    for sc in (0, 17, 63, 64, 100, B - 1):
+        if an.status[sc] != 0:
+            continue
+        o = oracle.OracleNR(osys)
+        if sc < len(labels):
+            ptr, dy = jg.outagePatch(s, labels[sc])
+            for p, d in zip(ptr, dy):
+                o.add_ybus(p - 1, d)
+        o.set_voltage(an.voltage.magnitude[sc], an.voltage.angle[sc])
+        assert max(o.mismatch()) < 1e-8
