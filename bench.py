@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py -- NR iterations/s on the 10k-bus grid (BASELINE.json metric), one process per GPU.
+
+  python bench.py --gpus N --steps K --warmup W            (N=1 direct; N>1 under torch.distributed.run)
+
+Workload (config.workload): batched N-1 contingency AC power flow on the shipped 10 000-bus grid
+case_ACTIVSg10k ("10k-bus grid" of the metric; case9241pegase is not shipped by the reference):
+`--batch` (default 512) single-branch outage scenarios PER GPU, each started from the base-case
+solution and iterated to 1e-8 with the reference's loop accounting.  One step = one pass of the hot
+path over the batch: restore the start point inside HBM, run powerFlow! for every scenario
+(fused mismatch+Jacobian assembly, block-LU refactorization, triangular solves, update, per
+scenario convergence control), and for N > 1 gather the results over RCCL.  Scenarios shard
+contiguously across ranks with no data-path collective (weak scaling: per-GPU batch fixed).
+
+value = total Newton-Raphson iterations (sum over all scenarios, all ranks, all K steps) / seconds.
+Inputs are resident in HBM when the timed region starts.  The JSON line also carries `roofline`
+(dominant kernel, algorithmic bytes / HIP-event time / 8 TB/s) and `cpu_baseline` (the C oracle on
+one host core, bounded sample of the same scenarios).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes(d, batch):
+    """SURVEY.md 8(d) per-unit figures x units per launch (see DESIGN.md 'Algorithmic bytes').
+    Assembly: per scenario J values + mismatch written, V/theta + injections read; shared: Ybus values,
+    column index, row pointers, bus type.  Block layout: 4 doubles per Ybus block."""
+    n, nnzY = d["n"], d["nnzY"]
+    asm_per = 32 * nnzY + 16 * n + 16 * n + 16 * n          # J blocks + f(2) written; V,theta; P,Q read
+    asm_shared = 20 * nnzY + 4 * (n + 1) + n                  # G,B (16) + col (4), rowptr, type
+    lu_per = 32 * nnzY + 2 * 32 * d["lu_blocks"]              # read J once, write+read-back L/U/Dinv blocks
+    solve_per = 32 * d["lu_blocks"] + 4 * 16 * n              # factor read once; rhs, work, increment
+    return dict(assembly=batch * asm_per + asm_shared, lu=batch * lu_per, solve=batch * solve_per)
+
+
+def cpu_baseline(case_tables, labels, start_vm, start_va, budget_s=12.0):
+    """The oracle (restatement of the reference algorithm; KLU-style LU with refactor reuse) on ONE host
+    core: the reference's own contingency loop over a bounded sample of the same scenarios."""
+    from oracle import oracle as O
+    import juliagrid.jl_amd as jg
+    osys = O.OracleSystem(case_tables)
+    o = O.OracleNR(osys)
+    o.power_flow()                                   # base case: symbolic + first factorization
+    s = jg.powerSystem(case_tables)
+    jg.acModel_(s)
+    iters = 0
+    done = 0
+    t0 = time.perf_counter()
+    for lab in labels:
+        ptr, dy = jg.outagePatch(s, int(lab))
+        for p, dv in zip(ptr, dy):
+            o.add_ybus(p - 1, dv)
+        o.set_voltage(start_vm, start_va)
+        o.power_flow(iteration=20, tolerance=1e-8)
+        iters += o.iteration
+        for p, dv in zip(ptr, dy):
+            o.add_ybus(p - 1, -dv)
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": iters / dt, "unit": "NR iterations/s", "cores": 1, "kind": "port",
+            "sample": f"{done} of the same N-1 scenarios (case_ACTIVSg10k), {iters} iterations in {dt:.2f} s, "
+                      "oracle/jg_oracle.c: serial assembly + KLU-style refactor/solve, single thread",
+            "ms_per_iteration": 1e3 * dt / max(iters, 1), "ms_per_solve": 1e3 * dt / max(done, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=512, help="scenarios per GPU")
+    ap.add_argument("--case", default="case_ACTIVSg10k")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import juliagrid.jl_amd as jg
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))      # RCCL over xGMI
+
+    with np.load(os.path.join(ROOT, "tests", "golden", "cases", args.case + ".npz")) as z:
+        tables = {k: z[k] for k in z.files}
+
+    # ---- setup (untimed): base case, scenario list, shard, upload ---------------------------
+    B = args.batch
+    system = jg.powerSystem(tables)
+    base = jg.newtonRaphson(system, batch=1, device=local)
+    jg.powerFlow_(base)
+    assert base.status == 0
+    base_iters = int(base.method.iteration)
+    vm0, va0 = base.voltage.magnitude.copy(), base.voltage.angle.copy()
+    # single-instance latency (BASELINE config 2/3 "ms/solve"), same handle, from the case's start point
+    t_single = []
+    for _ in range(5):
+        jg.setInitialPoint_(base)
+        t0 = time.perf_counter()
+        jg.powerFlow_(base, fetch=False)
+        t_single.append(time.perf_counter() - t0)
+    base.close()
+
+    labels_all = jg.outageList(system, B * world, seed=512)
+    lo, hi = jg.shard(B * world, rank, world)
+    labels = labels_all[lo:hi]
+    an = jg.contingencyAnalysis(system, labels, device=local)
+    jg.powerflow._push_voltage(an, vm0, va0)
+    an.snapshot_voltage()
+    n = system.bus.number
+    out_vm = torch.empty((B, n), dtype=torch.float64, device="cuda")
+    out_va = torch.empty((B, n), dtype=torch.float64, device="cuda")
+    res = torch.empty((B, 2), dtype=torch.int32, device="cuda")
+    if world > 1:
+        g_vm = torch.empty((world * B, n), dtype=torch.float64, device="cuda")
+        g_va = torch.empty((world * B, n), dtype=torch.float64, device="cuda")
+        g_res = torch.empty((world * B, 2), dtype=torch.int32, device="cuda")
+
+    def step():
+        an.restore_voltage()                          # start point, HBM -> HBM
+        jg.powerFlow_(an, iteration=20, tolerance=1e-8, fetch=False)
+        if world > 1:                                 # the only collective: final gather of results
+            an.voltage_device(out_vm.data_ptr(), out_va.data_ptr())
+            res.copy_(torch.from_numpy(np.stack([an.method.iteration, an.status], axis=1).astype(np.int32)))
+            dist.all_gather_into_tensor(g_vm, out_vm)
+            dist.all_gather_into_tensor(g_va, out_va)
+            dist.all_gather_into_tensor(g_res, res)
+        return int(np.sum(an.method.iteration))
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    iters_local = 0
+    for _ in range(args.steps):
+        iters_local += step()
+    fence()
+    dt = time.perf_counter() - t0
+
+    conv_local = int(np.sum(an.status == 0))
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        cnt = torch.tensor([iters_local, conv_local], dtype=torch.int64, device="cuda")
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        dt = float(tt.item())
+        iters_total, conv_total = int(cnt[0].item()), int(cnt[1].item())
+    else:
+        iters_total, conv_total = iters_local, conv_local
+
+    if rank == 0:
+        d = an.dims
+        ab = algorithmic_bytes(d, an.batch)
+        # live kernel timing with HIP events on the library's own stream
+        t_asm = an.time_kernel(0, 20)
+        t_lu = an.time_kernel(1, 10)
+        t_sol = an.time_kernel(2, 10)
+        kern = {
+            "assembly": {"ms": t_asm, "bytes": ab["assembly"], "launches": 1},
+            "lu": {"ms": t_lu, "bytes": ab["lu"], "launches": d["lu_launches"]},
+            "solve": {"ms": t_sol, "bytes": ab["solve"], "launches": d["solve_launches"]},
+        }
+        for k in kern.values():
+            k["GBps"] = k["bytes"] / (k["ms"] * 1e-3) / 1e9
+            k["frac"] = k["GBps"] / HBM_PEAK_GBS
+        dom = max(kern, key=lambda k: kern[k]["ms"])
+        names = {"assembly": "k_assemble", "lu": "k_lu", "solve": "k_fwd+k_bwd"}
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(names[dom])
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": names[dom], "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": kern[dom]["frac"], "traffic": traffic,
+                    "per_launch_ms": kern[dom]["ms"] / kern[dom]["launches"],
+                    "algorithmic_bytes": kern[dom]["bytes"]}
+        line = {
+            "metric": "NR iterations/sec (batched N-1 AC power flow, 10k-bus grid)",
+            "value": iters_total / dt, "unit": "NR iterations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.case} batched N-1 contingency Newton-Raphson, {B} scenarios per GPU "
+                                   f"({B * world} total), start = base-case solution, tol 1e-8, max 20 iterations",
+                       "grid": args.case, "buses": n, "batch_per_gpu": B, "dimJ": d["dimJ"], "nnzJ": d["nnzJ"],
+                       "lu_blocks_2x2": d["lu_blocks"], "lu_terms": d["lu_terms"],
+                       "launches_per_iteration": 2 + d["lu_launches"] + d["solve_launches"],
+                       "parallelism": f"scenario-sharded x{world}, RCCL all-gather of results only"},
+            "scenarios_per_s": B * world * args.steps / dt,
+            "ms_per_solve_batched": 1e3 * dt / (B * world * args.steps),
+            "iterations_per_scenario": iters_total / (B * world * args.steps),
+            "converged_fraction": conv_total / (B * world),
+            "single_instance": {"ms_per_solve": 1e3 * float(np.median(t_single)), "iterations": base_iters,
+                                "ms_per_iteration": 1e3 * float(np.median(t_single)) / max(base_iters, 1)},
+            "roofline": roofline,
+            "kernels": kern,
+        }
+        if world == 1 and not args.no_cpu:
+            cb = cpu_baseline(tables, labels_all[: max(64, min(B, 512))], vm0, va0)
+            line["cpu_baseline"] = cb
+            line["speedup_vs_cpu_baseline"] = line["value"] / cb["value"]
+        print(json.dumps(line))
+    an.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

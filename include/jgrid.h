@@ -64,6 +64,14 @@ int jg_nr_set_injection(jg_nr* h, const double* p_inj, const double* q_inj, int6
 /* analysis.voltage.{magnitude,angle} (setInitialPoint!, acPowerFlow.jl:1226-1249, 1281-1295). */
 int jg_nr_set_voltage(jg_nr* h, const double* vm, const double* va, int64_t batch_stride);
 int jg_nr_get_voltage(jg_nr* h, double* vm, double* va);
+/* Device-resident start point: snapshot the current voltages inside HBM / restore them (the
+ * setInitialPoint! of a benchmark or Monte-Carlo loop without a PCIe round trip). */
+int jg_nr_snapshot_voltage(jg_nr* h);
+int jg_nr_restore_voltage(jg_nr* h);
+/* Same as jg_nr_get_voltage but into DEVICE buffers of the caller (e.g. for an RCCL gather):
+ * vm_dev/va_dev are device pointers, [batch][n] doubles, written on the handle's stream and
+ * synchronised before return. */
+int jg_nr_get_voltage_device(jg_nr* h, double* vm_dev, double* va_dev);
 
 /*
  * Per-scenario Ybus edit on top of the shared base matrix -- what acNodalUpdate!

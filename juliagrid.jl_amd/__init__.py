@@ -7,10 +7,11 @@ from .system import PowerSystem, CscMatrix, powerSystem, acModel_          # noq
 from .system import updateBranch_ as updateBranchSystem_                   # noqa: F401
 from .powerflow import (AcPowerFlow, newtonRaphson, mismatch_, solve_, powerFlow_, setInitialPoint_,   # noqa: F401
                         updateBranch_, setOutage_, setInjection_, outagePatch, initializeACPowerFlow)
+from .contingency import bridges, outageList, shard, contingencyAnalysis   # noqa: F401
 from . import _lib                                                           # noqa: F401
 
 __all__ = [
     "PowerSystem", "CscMatrix", "powerSystem", "acModel_", "updateBranchSystem_", "AcPowerFlow", "newtonRaphson",
     "mismatch_", "solve_", "powerFlow_", "setInitialPoint_", "updateBranch_", "setOutage_", "setInjection_",
-    "outagePatch", "initializeACPowerFlow",
+    "outagePatch", "initializeACPowerFlow", "bridges", "outageList", "shard", "contingencyAnalysis",
 ]

@@ -45,6 +45,9 @@ def lib():
         "jg_nr_set_injection": [VP, F64P, F64P, C.c_int64],
         "jg_nr_set_voltage": [VP, F64P, F64P, C.c_int64],
         "jg_nr_get_voltage": [VP, F64P, F64P],
+        "jg_nr_snapshot_voltage": [VP],
+        "jg_nr_restore_voltage": [VP],
+        "jg_nr_get_voltage_device": [VP, VP, VP],
         "jg_nr_patch_ybus": [VP, C.c_int64, C.c_int64, I64P, F64P],
         "jg_nr_set_ybus": [VP, F64P, F64P],
         "jg_nr_mismatch": [VP, F64P, F64P],
@@ -111,5 +114,5 @@ class Plan:
 
     def schedule(self, kind):
         base = {"lu": 20, "fwd": 30, "bwd": 40}[kind]
-        return dict(launches=self.get(base).reshape(-1, 3), task_ptr=self.get(base + 1),
+        return dict(launches=self.get(base).reshape(-1, 4), task_ptr=self.get(base + 1),
                     step_ptr=self.get(base + 2), items=self.get(base + 3))

@@ -1,0 +1,86 @@
+"""Batched N-1 contingency screening on top of the batched Newton-Raphson analysis.
+
+The reference has no batch API: users loop `updateBranch!(analysis; label, status = 0)` ->
+`setInitialPoint!` -> `powerFlow!` -> `updateBranch!(...; status = 1)`
+(/root/reference/src/powerSystem/branch.jl:453-459, src/powerFlow/acPowerFlow.jl:1226-1249, 1389-1433;
+SURVEY.md 3.5).  Here every scenario of that loop is one lane of the batch: the outage is expressed as
+the 4 Ybus edits acNodalUpdate! would make (model.jl:93-101) on top of the shared base matrix, the
+Jacobian pattern is shared (stored zeros, model.jl:70-71), and all scenarios advance together.
+Scenarios shard across GPUs contiguously with no communication (see shard()).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .powerflow import AcPowerFlow, newtonRaphson, powerFlow_, setOutage_
+from .system import PowerSystem
+
+
+def bridges(system: PowerSystem) -> np.ndarray:
+    """Boolean mask over branches: True where removing the (in-service) branch islands the grid.
+    Iterative DFS low-link; parallel in-service branches are never bridges."""
+    n, nb = system.bus.number, system.branch.number
+    f = system.branch.layout.from_ - 1
+    t = system.branch.layout.to - 1
+    on = np.flatnonzero(system.branch.layout.status == 1)
+    adj = [[] for _ in range(n)]
+    for k in on:
+        adj[f[k]].append((int(t[k]), int(k)))
+        adj[t[k]].append((int(f[k]), int(k)))
+    disc = np.full(n, -1)
+    low = np.zeros(n, dtype=np.int64)
+    is_bridge = np.zeros(nb, dtype=bool)
+    timer = 0
+    for root in range(n):
+        if disc[root] >= 0:
+            continue
+        stack = [(root, -1, 0)]
+        disc[root] = low[root] = timer
+        timer += 1
+        while stack:
+            v, pe, idx = stack.pop()
+            if idx < len(adj[v]):
+                stack.append((v, pe, idx + 1))
+                u, e = adj[v][idx]
+                if e == pe:
+                    continue
+                if disc[u] < 0:
+                    disc[u] = low[u] = timer
+                    timer += 1
+                    stack.append((u, e, 0))
+                else:
+                    low[v] = min(low[v], disc[u])
+            elif stack:
+                p = stack[-1][0]
+                low[p] = min(low[p], low[v])
+                if low[v] > disc[p]:
+                    is_bridge[pe] = True
+    return is_bridge
+
+
+def outageList(system: PowerSystem, count: int, seed: int = 512) -> np.ndarray:
+    """`count` branch labels (1-based) drawn by a seeded shuffle of the non-bridge in-service branches
+    (BASELINE config 5); wraps around if the grid has fewer candidates."""
+    ok = np.flatnonzero((system.branch.layout.status == 1) & ~bridges(system)
+                        & (system.branch.layout.from_ != system.branch.layout.to))
+    rng = np.random.default_rng(seed)
+    rng.shuffle(ok)
+    reps = -(-count // ok.size)
+    return (np.tile(ok, reps)[:count] + 1).astype(np.int64)
+
+
+def shard(count: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous block of scenarios owned by `rank`: [lo, hi)."""
+    per = -(-count // world)
+    lo = min(rank * per, count)
+    return lo, min(lo + per, count)
+
+
+def contingencyAnalysis(system: PowerSystem, labels, device: int = 0) -> AcPowerFlow:
+    """Batched analysis with scenario s = outage of branch labels[s] (None / 0 = base case)."""
+    labels = list(labels)
+    an = newtonRaphson(system, batch=len(labels), device=device, max_patch=4)
+    for s, lab in enumerate(labels):
+        if lab:
+            setOutage_(an, s, int(lab))
+    return an

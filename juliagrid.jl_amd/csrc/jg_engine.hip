@@ -31,7 +31,63 @@ struct SolveArgs {
 
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// X(e) -= sum over terms L(a) * U(b);  diagonal -> store inverse;  lower -> scale by Dinv(col).
+struct Blk { double v00, v01, v10, v11; };
+
+__device__ __forceinline__ Blk load_blk(const double* p, size_t ld) { return Blk{p[0], p[ld], p[2 * ld], p[3 * ld]}; }
+
+// acc -= L(a) * U(b) over terms t0, t0+stride, ... < t1 ; four terms (64 loads of 512 B per wave) in flight
+__device__ __forceinline__ void lu_terms(const LuArgs& a, int t0, int t1, int stride, size_t b, size_t ld, Blk& c) {
+    int t = t0;
+    for (; t + 3 * stride < t1; t += 4 * stride) {
+        Blk l[4], u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            l[k] = load_blk(a.X + (size_t)uniform(a.t_a[t + k * stride]) * 4 * ld + b, ld);
+            u[k] = load_blk(a.X + (size_t)uniform(a.t_b[t + k * stride]) * 4 * ld + b, ld);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            c.v00 -= l[k].v00 * u[k].v00 + l[k].v01 * u[k].v10;
+            c.v01 -= l[k].v00 * u[k].v01 + l[k].v01 * u[k].v11;
+            c.v10 -= l[k].v10 * u[k].v00 + l[k].v11 * u[k].v10;
+            c.v11 -= l[k].v10 * u[k].v01 + l[k].v11 * u[k].v11;
+        }
+    }
+    for (; t < t1; t += stride) {
+        const Blk l = load_blk(a.X + (size_t)uniform(a.t_a[t]) * 4 * ld + b, ld);
+        const Blk u = load_blk(a.X + (size_t)uniform(a.t_b[t]) * 4 * ld + b, ld);
+        c.v00 -= l.v00 * u.v00 + l.v01 * u.v10;
+        c.v01 -= l.v00 * u.v01 + l.v01 * u.v11;
+        c.v10 -= l.v10 * u.v00 + l.v11 * u.v10;
+        c.v11 -= l.v10 * u.v01 + l.v11 * u.v11;
+    }
+}
+
+// diagonal -> store inverse;  lower -> scale by Dinv(col);  upper -> store
+__device__ __forceinline__ void lu_finish(const LuArgs& a, int e, size_t b, size_t ld, const Blk& c) {
+    const int kind = uniform(a.e_diag[e]);
+    double* q = a.X + (size_t)e * 4 * ld + b;
+    if (kind == -2) {
+        const double det = c.v00 * c.v11 - c.v01 * c.v10;
+        const double r = 1.0 / det;
+        if (!(fabs(det) > 0.0) || !(fabs(r) < 1.0e300)) atomicOr(a.status + b, 4);
+        q[0] = c.v11 * r; q[ld] = -c.v01 * r; q[2 * ld] = -c.v10 * r; q[3 * ld] = c.v00 * r;
+    } else if (kind >= 0) {
+        const Blk d = load_blk(a.X + (size_t)kind * 4 * ld + b, ld);
+        q[0] = c.v00 * d.v00 + c.v01 * d.v10; q[ld] = c.v00 * d.v01 + c.v01 * d.v11;
+        q[2 * ld] = c.v10 * d.v00 + c.v11 * d.v10; q[3 * ld] = c.v10 * d.v01 + c.v11 * d.v11;
+    } else {
+        q[0] = c.v00; q[ld] = c.v01; q[2 * ld] = c.v10; q[3 * ld] = c.v11;
+    }
+}
+
+__device__ __forceinline__ Blk lu_source(const LuArgs& a, int e, size_t b, size_t ld) {
+    const int src = uniform(a.e_src[e]);
+    if (src < 0) return Blk{0.0, 0.0, 0.0, 0.0};
+    return load_blk(a.A + (size_t)src * 4 * ld + b, ld);
+}
+
+// One wave per item; a task may chain several barrier-separated steps.
 __global__ __launch_bounds__(256) void k_lu(LuArgs a) {
     const int lane = threadIdx.x;
     const int wave = uniform(threadIdx.y);
@@ -44,46 +100,96 @@ __global__ __launch_bounds__(256) void k_lu(LuArgs a) {
         const int i0 = a.step_ptr[s], i1 = a.step_ptr[s + 1];
         for (int idx = i0 + wave; idx < i1; idx += W) {
             const int e = uniform(a.items[idx]);
-            const int src = uniform(a.e_src[e]);
-            double c00 = 0.0, c01 = 0.0, c10 = 0.0, c11 = 0.0;
-            if (src >= 0) {
-                const double* p = a.A + (size_t)src * 4 * ld + b;
-                c00 = p[0]; c01 = p[ld]; c10 = p[2 * ld]; c11 = p[3 * ld];
-            }
-            const int t0 = uniform(a.t_ptr[e]), t1 = uniform(a.t_ptr[e + 1]);
-#pragma unroll 2
-            for (int t = t0; t < t1; ++t) {
-                const double* pl = a.X + (size_t)uniform(a.t_a[t]) * 4 * ld + b;
-                const double* pu = a.X + (size_t)uniform(a.t_b[t]) * 4 * ld + b;
-                const double l00 = pl[0], l01 = pl[ld], l10 = pl[2 * ld], l11 = pl[3 * ld];
-                const double u00 = pu[0], u01 = pu[ld], u10 = pu[2 * ld], u11 = pu[3 * ld];
-                c00 -= l00 * u00 + l01 * u10;
-                c01 -= l00 * u01 + l01 * u11;
-                c10 -= l10 * u00 + l11 * u10;
-                c11 -= l10 * u01 + l11 * u11;
-            }
-            const int kind = uniform(a.e_diag[e]);
-            double* q = a.X + (size_t)e * 4 * ld + b;
-            if (kind == -2) {                       // diagonal block: keep the inverse
-                const double det = c00 * c11 - c01 * c10;
-                const double r = 1.0 / det;
-                if (!(fabs(det) > 0.0) || !(fabs(r) < 1.0e300)) atomicOr(a.status + b, 4);
-                q[0] = c11 * r; q[ld] = -c01 * r; q[2 * ld] = -c10 * r; q[3 * ld] = c00 * r;
-            } else if (kind >= 0) {                 // lower: L = acc * inv(U_jj)
-                const double* d = a.X + (size_t)kind * 4 * ld + b;
-                const double d00 = d[0], d01 = d[ld], d10 = d[2 * ld], d11 = d[3 * ld];
-                q[0] = c00 * d00 + c01 * d10; q[ld] = c00 * d01 + c01 * d11;
-                q[2 * ld] = c10 * d00 + c11 * d10; q[3 * ld] = c10 * d01 + c11 * d11;
-            } else {                                // upper
-                q[0] = c00; q[ld] = c01; q[2 * ld] = c10; q[3 * ld] = c11;
-            }
+            Blk c = lu_source(a, e, b, ld);
+            lu_terms(a, uniform(a.t_ptr[e]), uniform(a.t_ptr[e + 1]), 1, b, ld, c);
+            lu_finish(a, e, b, ld, c);
         }
         if (s + 1 < s1) __syncthreads();
     }
 }
 
-// Forward substitution with unit-lower L:  W_k = rhs_{perm k} - sum_c L(k,c) W_c
-__global__ __launch_bounds__(256) void k_fwd(SolveArgs a) {
+// `wpi` waves share one item: wave `sub` takes terms sub, sub+wpi, ...; partial sums meet in LDS and
+// are added in a fixed order (run-to-run deterministic).  Single-step tasks of blockDim.y/wpi items.
+__global__ __launch_bounds__(1024) void k_lu_split(LuArgs a, int wpi) {
+    extern __shared__ __attribute__((aligned(16))) double red[];   // [W][4][64]
+    const int lane = threadIdx.x;
+    const int wave = uniform(threadIdx.y);
+    const int task = a.task0 + blockIdx.x;
+    const size_t ld = (size_t)a.ld;
+    const size_t b = (size_t)blockIdx.y * 64 + lane;
+    const int s = a.task_ptr[task];
+    const int i0 = a.step_ptr[s], i1 = a.step_ptr[s + 1];
+    const int slot = wave / wpi, sub = wave - slot * wpi;
+    const int idx = i0 + slot;
+    const bool valid = idx < i1;
+    int e = 0;
+    Blk c{0.0, 0.0, 0.0, 0.0};
+    if (valid) {
+        e = uniform(a.items[idx]);
+        if (sub == 0) c = lu_source(a, e, b, ld);
+        lu_terms(a, uniform(a.t_ptr[e]) + sub, uniform(a.t_ptr[e + 1]), wpi, b, ld, c);
+        if (sub != 0) {
+            double* r = red + (size_t)wave * 256 + lane;
+            r[0] = c.v00; r[64] = c.v01; r[128] = c.v10; r[192] = c.v11;
+        }
+    }
+    __syncthreads();
+    if (valid && sub == 0) {
+        for (int w = 1; w < wpi; ++w) {
+            const double* r = red + (size_t)(wave + w) * 256 + lane;
+            c.v00 += r[0]; c.v01 += r[64]; c.v10 += r[128]; c.v11 += r[192];
+        }
+        lu_finish(a, e, b, ld, c);
+    }
+}
+
+// y -= sum over row entries X(ent) * W(col), entries p0, p0+stride, ... < p1; four in flight
+__device__ __forceinline__ void row_terms(const SolveArgs& a, int p0, int p1, int stride, size_t b, size_t ld, double& y0, double& y1) {
+    int p = p0;
+    for (; p + 3 * stride < p1; p += 4 * stride) {
+        Blk m[4]; double w0[4], w1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            m[k] = load_blk(a.X + (size_t)uniform(a.r_ent[p + k * stride]) * 4 * ld + b, ld);
+            const double* pw = a.W + (size_t)uniform(a.r_col[p + k * stride]) * 2 * ld + b;
+            w0[k] = pw[0]; w1[k] = pw[ld];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            y0 -= m[k].v00 * w0[k] + m[k].v01 * w1[k];
+            y1 -= m[k].v10 * w0[k] + m[k].v11 * w1[k];
+        }
+    }
+    for (; p < p1; p += stride) {
+        const Blk m = load_blk(a.X + (size_t)uniform(a.r_ent[p]) * 4 * ld + b, ld);
+        const double* pw = a.W + (size_t)uniform(a.r_col[p]) * 2 * ld + b;
+        const double w0 = pw[0], w1 = pw[ld];
+        y0 -= m.v00 * w0 + m.v01 * w1;
+        y1 -= m.v10 * w0 + m.v11 * w1;
+    }
+}
+
+__device__ __forceinline__ void bwd_finish(const SolveArgs& a, int k, size_t b, size_t ld, double y0, double y1, bool act) {
+    const Blk d = load_blk(a.X + (size_t)uniform(a.diag[k]) * 4 * ld + b, ld);
+    const double x0 = d.v00 * y0 + d.v01 * y1;
+    const double x1 = d.v10 * y0 + d.v11 * y1;
+    a.W[((size_t)k * 2) * ld + b] = x0;
+    a.W[((size_t)k * 2 + 1) * ld + b] = x1;
+    const int bus = uniform(a.perm[k]);
+    a.out[((size_t)bus * 2) * ld + b] = x0;
+    a.out[((size_t)bus * 2 + 1) * ld + b] = x1;
+    if (a.upd.va) {
+        const int fl = uniform((int)a.upd.flags[bus]);
+        if (act && (fl & 1)) a.upd.va[(size_t)bus * ld + b] += a.upd.sign * x0;
+        if (act && (fl & 2)) a.upd.vm[(size_t)bus * ld + b] += a.upd.sign * x1;
+    }
+}
+
+// Forward substitution with unit-lower L:  W_k = rhs_{perm k} - sum_c L(k,c) W_c         (BWD = false)
+// Backward substitution: x_k = Dinv_k (W_k - sum_c U(k,c) x_c), scatter to original order, optional
+// fused state update (NR: V/theta -= increment on active scenarios)                      (BWD = true)
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_tri(SolveArgs a) {
     const int lane = threadIdx.x;
     const int wave = uniform(threadIdx.y);
     const int W = blockDim.y;
@@ -91,68 +197,59 @@ __global__ __launch_bounds__(256) void k_fwd(SolveArgs a) {
     const size_t ld = (size_t)a.ld;
     const size_t b = (size_t)blockIdx.y * 64 + lane;
     const int s0 = a.task_ptr[task], s1 = a.task_ptr[task + 1];
+    const bool act = (BWD && a.upd.active) ? (a.upd.active[b] != 0) : true;
     for (int s = s0; s < s1; ++s) {
         const int i0 = a.step_ptr[s], i1 = a.step_ptr[s + 1];
         for (int idx = i0 + wave; idx < i1; idx += W) {
             const int k = uniform(a.items[idx]);
-            const int bus = uniform(a.perm[k]);
-            double y0 = a.rhs[((size_t)bus * 2) * ld + b], y1 = a.rhs[((size_t)bus * 2 + 1) * ld + b];
-            const int p0 = uniform(a.r_ptr[k]), p1 = uniform(a.r_ptr[k + 1]);
-#pragma unroll 2
-            for (int p = p0; p < p1; ++p) {
-                const double* pl = a.X + (size_t)uniform(a.r_ent[p]) * 4 * ld + b;
-                const double* pw = a.W + (size_t)uniform(a.r_col[p]) * 2 * ld + b;
-                const double w0 = pw[0], w1 = pw[ld];
-                y0 -= pl[0] * w0 + pl[ld] * w1;
-                y1 -= pl[2 * ld] * w0 + pl[3 * ld] * w1;
+            double y0, y1;
+            if (BWD) {
+                y0 = a.W[((size_t)k * 2) * ld + b]; y1 = a.W[((size_t)k * 2 + 1) * ld + b];
+            } else {
+                const int bus = uniform(a.perm[k]);
+                y0 = a.rhs[((size_t)bus * 2) * ld + b]; y1 = a.rhs[((size_t)bus * 2 + 1) * ld + b];
             }
-            a.W[((size_t)k * 2) * ld + b] = y0;
-            a.W[((size_t)k * 2 + 1) * ld + b] = y1;
+            row_terms(a, uniform(a.r_ptr[k]), uniform(a.r_ptr[k + 1]), 1, b, ld, y0, y1);
+            if (BWD) bwd_finish(a, k, b, ld, y0, y1, act);
+            else { a.W[((size_t)k * 2) * ld + b] = y0; a.W[((size_t)k * 2 + 1) * ld + b] = y1; }
         }
         if (s + 1 < s1) __syncthreads();
     }
 }
 
-// Backward substitution: x_k = Dinv_k (W_k - sum_c U(k,c) x_c); scatter to original order; optional
-// fused state update (NR: V/theta -= increment on active scenarios).
-__global__ __launch_bounds__(256) void k_bwd(SolveArgs a) {
+template <bool BWD>
+__global__ __launch_bounds__(1024) void k_tri_split(SolveArgs a, int wpi) {
+    extern __shared__ __attribute__((aligned(16))) double red[];   // [W][2][64]
     const int lane = threadIdx.x;
     const int wave = uniform(threadIdx.y);
-    const int W = blockDim.y;
     const int task = a.task0 + blockIdx.x;
     const size_t ld = (size_t)a.ld;
     const size_t b = (size_t)blockIdx.y * 64 + lane;
-    const int s0 = a.task_ptr[task], s1 = a.task_ptr[task + 1];
-    const bool act = a.upd.active ? (a.upd.active[b] != 0) : true;
-    for (int s = s0; s < s1; ++s) {
-        const int i0 = a.step_ptr[s], i1 = a.step_ptr[s + 1];
-        for (int idx = i0 + wave; idx < i1; idx += W) {
-            const int k = uniform(a.items[idx]);
-            double y0 = a.W[((size_t)k * 2) * ld + b], y1 = a.W[((size_t)k * 2 + 1) * ld + b];
-            const int p0 = uniform(a.r_ptr[k]), p1 = uniform(a.r_ptr[k + 1]);
-#pragma unroll 2
-            for (int p = p0; p < p1; ++p) {
-                const double* pu = a.X + (size_t)uniform(a.r_ent[p]) * 4 * ld + b;
-                const double* pw = a.W + (size_t)uniform(a.r_col[p]) * 2 * ld + b;
-                const double w0 = pw[0], w1 = pw[ld];
-                y0 -= pu[0] * w0 + pu[ld] * w1;
-                y1 -= pu[2 * ld] * w0 + pu[3 * ld] * w1;
-            }
-            const double* d = a.X + (size_t)uniform(a.diag[k]) * 4 * ld + b;
-            const double x0 = d[0] * y0 + d[ld] * y1;
-            const double x1 = d[2 * ld] * y0 + d[3 * ld] * y1;
-            a.W[((size_t)k * 2) * ld + b] = x0;
-            a.W[((size_t)k * 2 + 1) * ld + b] = x1;
-            const int bus = uniform(a.perm[k]);
-            a.out[((size_t)bus * 2) * ld + b] = x0;
-            a.out[((size_t)bus * 2 + 1) * ld + b] = x1;
-            if (a.upd.va) {
-                const int fl = uniform((int)a.upd.flags[bus]);
-                if (act && (fl & 1)) a.upd.va[(size_t)bus * ld + b] += a.upd.sign * x0;
-                if (act && (fl & 2)) a.upd.vm[(size_t)bus * ld + b] += a.upd.sign * x1;
+    const int s = a.task_ptr[task];
+    const int i0 = a.step_ptr[s], i1 = a.step_ptr[s + 1];
+    const int slot = wave / wpi, sub = wave - slot * wpi;
+    const int idx = i0 + slot;
+    const bool valid = idx < i1;
+    const bool act = (BWD && a.upd.active) ? (a.upd.active[b] != 0) : true;
+    int k = 0;
+    double y0 = 0.0, y1 = 0.0;
+    if (valid) {
+        k = uniform(a.items[idx]);
+        if (sub == 0) {
+            if (BWD) { y0 = a.W[((size_t)k * 2) * ld + b]; y1 = a.W[((size_t)k * 2 + 1) * ld + b]; }
+            else {
+                const int bus = uniform(a.perm[k]);
+                y0 = a.rhs[((size_t)bus * 2) * ld + b]; y1 = a.rhs[((size_t)bus * 2 + 1) * ld + b];
             }
         }
-        if (s + 1 < s1) __syncthreads();
+        row_terms(a, uniform(a.r_ptr[k]) + sub, uniform(a.r_ptr[k + 1]), wpi, b, ld, y0, y1);
+        if (sub != 0) { red[(size_t)wave * 128 + lane] = y0; red[(size_t)wave * 128 + 64 + lane] = y1; }
+    }
+    __syncthreads();
+    if (valid && sub == 0) {
+        for (int w = 1; w < wpi; ++w) { y0 += red[(size_t)(wave + w) * 128 + lane]; y1 += red[(size_t)(wave + w) * 128 + 64 + lane]; }
+        if (BWD) bwd_finish(a, k, b, ld, y0, y1, act);
+        else { a.W[((size_t)k * 2) * ld + b] = y0; a.W[((size_t)k * 2 + 1) * ld + b] = y1; }
     }
 }
 
@@ -207,7 +304,8 @@ int Engine::factor(hipStream_t st, const double* A) {
     for (const Launch& L : lu.launches) {
         a.task0 = L.task_begin;
         dim3 grid(L.task_end - L.task_begin, ld / 64), block(64, L.waves);
-        hipLaunchKernelGGL(k_lu, grid, block, 0, st, a);
+        if (L.wpi == 1) hipLaunchKernelGGL(k_lu, grid, block, 0, st, a);
+        else hipLaunchKernelGGL(k_lu_split, grid, block, (size_t)L.waves * 256 * sizeof(double), st, a, L.wpi);
     }
     JG_HIP(hipGetLastError());
     return 0;
@@ -218,14 +316,16 @@ int Engine::solve(hipStream_t st, const double* rhs, double* out, const StateUpd
     for (const Launch& L : fwd.launches) {
         a.task0 = L.task_begin;
         dim3 grid(L.task_end - L.task_begin, ld / 64), block(64, L.waves);
-        hipLaunchKernelGGL(k_fwd, grid, block, 0, st, a);
+        if (L.wpi == 1) hipLaunchKernelGGL(k_tri<false>, grid, block, 0, st, a);
+        else hipLaunchKernelGGL(k_tri_split<false>, grid, block, (size_t)L.waves * 128 * sizeof(double), st, a, L.wpi);
     }
     a.task_ptr = bwd.task_ptr; a.step_ptr = bwd.step_ptr; a.items = bwd.items;
     a.r_ptr = u_ptr; a.r_ent = u_ent; a.r_col = u_col;
     for (const Launch& L : bwd.launches) {
         a.task0 = L.task_begin;
         dim3 grid(L.task_end - L.task_begin, ld / 64), block(64, L.waves);
-        hipLaunchKernelGGL(k_bwd, grid, block, 0, st, a);
+        if (L.wpi == 1) hipLaunchKernelGGL(k_tri<true>, grid, block, 0, st, a);
+        else hipLaunchKernelGGL(k_tri_split<true>, grid, block, (size_t)L.waves * 128 * sizeof(double), st, a, L.wpi);
     }
     JG_HIP(hipGetLastError());
     return 0;

@@ -156,6 +156,21 @@ __global__ void k_check(CheckArgs a) {
     if (act) { a.iters[b] += 1; atomicAdd(a.counter, 1); }        // solve! follows: iteration += 1 (:908)
 }
 
+// [n][ld] batch-minor -> [batch][n] scenario-major, tiled through LDS so both sides stay coalesced
+__global__ void k_to_scenario_major(const double* src, double* dst, int n, int ld, int batch) {
+    __shared__ double tile[32][33];
+    const int i0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int i = i0 + r, b = b0 + threadIdx.x;
+        tile[r][threadIdx.x] = (i < n && b < ld) ? src[(size_t)i * ld + b] : 0.0;
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int b = b0 + r, i = i0 + threadIdx.x;
+        if (b < batch && i < n) dst[(size_t)b * n + i] = tile[threadIdx.x][r];
+    }
+}
+
 __global__ void k_add_iter(int* iters, int n) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < n) iters[b] += 1;
@@ -177,6 +192,7 @@ struct jg_nr {
     int* d_ppos = nullptr; double* d_pdg = nullptr; double* d_pdb = nullptr;
     double* d_A = nullptr; double* d_F = nullptr; double* d_inc = nullptr; double* d_part = nullptr;
     double* d_normp = nullptr; double* d_normq = nullptr; double* d_params = nullptr;
+    double* d_vm0 = nullptr; double* d_va0 = nullptr;   // snapshot of the start point
     int* d_active = nullptr; int* d_iters = nullptr; int* d_status = nullptr; int* d_counter = nullptr;
     jg::Engine eng;
     hipStream_t stream = nullptr;
@@ -383,7 +399,7 @@ void jg_nr_destroy(jg_nr* h) {
     hipFree(h->d_vm); hipFree(h->d_va); hipFree(h->d_p); hipFree(h->d_q); hipFree(h->d_ppos); hipFree(h->d_pdg);
     hipFree(h->d_pdb); hipFree(h->d_A); hipFree(h->d_F); hipFree(h->d_inc); hipFree(h->d_part); hipFree(h->d_normp);
     hipFree(h->d_normq); hipFree(h->d_params); hipFree(h->d_active); hipFree(h->d_iters); hipFree(h->d_status);
-    hipFree(h->d_counter);
+    hipFree(h->d_counter); hipFree(h->d_vm0); hipFree(h->d_va0);
     if (h->h_counter) hipHostFree(h->h_counter);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -433,6 +449,38 @@ int jg_nr_get_voltage(jg_nr* h, double* vm, double* va) {
     NR_HIP(hipStreamSynchronize(h->stream));
     if (int rc = get_bus_array(h, h->d_vm, vm, 1)) return rc;
     return get_bus_array(h, h->d_va, va, 1);
+}
+
+int jg_nr_snapshot_voltage(jg_nr* h) {
+    if (!h) return fail(1, "jg_nr_snapshot_voltage: bad argument");
+    if (int rc = set_device(h)) return rc;
+    const size_t bytes = (size_t)h->n * h->ld * 8;
+    if (!h->d_vm0) { NR_HIP(hipMalloc((void**)&h->d_vm0, bytes)); NR_HIP(hipMalloc((void**)&h->d_va0, bytes)); }
+    NR_HIP(hipMemcpyAsync(h->d_vm0, h->d_vm, bytes, hipMemcpyDeviceToDevice, h->stream));
+    NR_HIP(hipMemcpyAsync(h->d_va0, h->d_va, bytes, hipMemcpyDeviceToDevice, h->stream));
+    NR_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int jg_nr_restore_voltage(jg_nr* h) {
+    if (!h || !h->d_vm0) return fail(1, "jg_nr_restore_voltage: no snapshot");
+    if (int rc = set_device(h)) return rc;
+    const size_t bytes = (size_t)h->n * h->ld * 8;
+    NR_HIP(hipMemcpyAsync(h->d_vm, h->d_vm0, bytes, hipMemcpyDeviceToDevice, h->stream));
+    NR_HIP(hipMemcpyAsync(h->d_va, h->d_va0, bytes, hipMemcpyDeviceToDevice, h->stream));
+    h->jac_valid = false;
+    return 0;
+}
+
+int jg_nr_get_voltage_device(jg_nr* h, double* vm_dev, double* va_dev) {
+    if (!h || !vm_dev || !va_dev) return fail(1, "jg_nr_get_voltage_device: bad argument");
+    if (int rc = set_device(h)) return rc;
+    dim3 grid((h->n + 31) / 32, (h->ld + 31) / 32), block(32, 8);
+    hipLaunchKernelGGL(k_to_scenario_major, grid, block, 0, h->stream, h->d_vm, vm_dev, h->n, h->ld, h->batch);
+    hipLaunchKernelGGL(k_to_scenario_major, grid, block, 0, h->stream, h->d_va, va_dev, h->n, h->ld, h->batch);
+    NR_HIP(hipGetLastError());
+    NR_HIP(hipStreamSynchronize(h->stream));
+    return 0;
 }
 
 int jg_nr_patch_ybus(jg_nr* h, int64_t scenario, int64_t k, const int64_t* ptr, const double* dy) {

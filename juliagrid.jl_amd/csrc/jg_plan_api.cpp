@@ -15,7 +15,7 @@ struct jg_plan {
 namespace {
 void flatten(const jg::Schedule& s, std::vector<int>& launch) {
     launch.clear();
-    for (const jg::Launch& L : s.launches) { launch.push_back(L.task_begin); launch.push_back(L.task_end); launch.push_back(L.waves); }
+    for (const jg::Launch& L : s.launches) { launch.push_back(L.task_begin); launch.push_back(L.task_end); launch.push_back(L.waves); launch.push_back(L.wpi); }
 }
 }  // namespace
 
@@ -33,7 +33,7 @@ void jg_plan_destroy(jg_plan* p) { delete p; }
 
 // which: 0 perm, 1 e_row, 2 e_col, 3 e_src, 4 t_ptr, 5 t_a, 6 t_b, 7 e_level, 8 e_diag, 9 diag,
 //        10 l_ptr, 11 l_ent, 12 l_col, 13 u_ptr, 14 u_ent, 15 u_col,
-//        20/30/40 + k: schedule lu/fwd/bwd: k=0 launches (begin,end,waves triples), 1 task_ptr, 2 step_ptr, 3 items
+//        20/30/40 + k: schedule lu/fwd/bwd: k=0 launches (begin,end,waves,wpi quadruples), 1 task_ptr, 2 step_ptr, 3 items
 // out == NULL returns the length.
 int64_t jg_plan_export(jg_plan* p, int which, int32_t* out, int64_t cap) {
     if (!p) return -1;

@@ -64,8 +64,10 @@ int find_in_row(const BlockSymbolic& S, int r, int c) {
     return (p != e && *p == c) ? (int)(p - S.e_col.data()) : -1;
 }
 
-// One launch per level; each task = up to `chunk` items of that level in a single step.
-void schedule_by_level(const std::vector<int>& level, int n_items, int waves, int chunk, Schedule& sch) {
+// One launch per level.  Levels whose items carry long update lists (the dense tail of the
+// elimination order) get several waves per item: the list is split across `wpi` waves and reduced
+// through LDS, so the critical path of a level is ~ (terms / wpi) memory round trips instead of `terms`.
+void schedule_by_level(const std::vector<int>& level, const std::vector<int>& work, int n_items, Schedule& sch) {
     int nlev = 0;
     for (int i = 0; i < n_items; ++i) nlev = std::max(nlev, level[i]);
     std::vector<int> cnt(nlev + 2, 0);
@@ -83,9 +85,17 @@ void schedule_by_level(const std::vector<int>& level, int n_items, int waves, in
     for (int l = 1; l <= nlev; ++l) {
         int b = cnt[l], e = cnt[l + 1];
         if (b == e) continue;
+        // heaviest items first inside the level (they start first on the device)
+        std::stable_sort(sch.items.begin() + b, sch.items.begin() + e, [&](int x, int y) { return work[x] > work[y]; });
+        const int maxw = work[sch.items[b]];
         Launch L;
         L.task_begin = (int)sch.task_ptr.size() - 1;
-        L.waves = waves;
+        int wpi = 1;
+        while (wpi < 16 && maxw > 6 * wpi) wpi *= 2;
+        if (e - b >= 2048) wpi = std::min(wpi, 2);          // wide levels already fill the chip
+        L.wpi = wpi;
+        L.waves = std::max(4, wpi);
+        const int chunk = wpi == 1 ? 16 : L.waves / wpi;
         for (int s = b; s < e; s += chunk) {
             sch.step_ptr.push_back(std::min(s + chunk, e));
             sch.task_ptr.push_back((int)sch.step_ptr.size() - 1);
@@ -236,9 +246,14 @@ int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic&
     for (int r = n - 1; r >= 0; --r)
         for (int p = S.u_ptr[r]; p < S.u_ptr[r + 1]; ++p) S.bwd_level[r] = std::max(S.bwd_level[r], S.bwd_level[S.u_col[p]] + 1);
 
-    schedule_by_level(S.e_level, S.n_entries, 4, 16, S.lu);
-    schedule_by_level(S.fwd_level, n, 4, 16, S.fwd);
-    schedule_by_level(S.bwd_level, n, 4, 16, S.bwd);
+    {
+        std::vector<int> work(S.n_entries), lw(n), uw(n);
+        for (int e = 0; e < S.n_entries; ++e) work[e] = S.t_ptr[e + 1] - S.t_ptr[e];
+        for (int r = 0; r < n; ++r) { lw[r] = S.l_ptr[r + 1] - S.l_ptr[r]; uw[r] = S.u_ptr[r + 1] - S.u_ptr[r]; }
+        schedule_by_level(S.e_level, work, S.n_entries, S.lu);
+        schedule_by_level(S.fwd_level, lw, n, S.fwd);
+        schedule_by_level(S.bwd_level, uw, n, S.bwd);
+    }
     return 0;
 }
 

@@ -19,6 +19,8 @@ namespace jg {
 struct Launch {
     int task_begin = 0, task_end = 0;   // tasks [begin,end) -> one workgroup column each
     int waves = 4;                      // waves per workgroup for this launch
+    int wpi = 1;                        // waves cooperating on ONE item (its update terms are split across
+                                        // them and reduced through LDS); wpi > 1 => single-step tasks
 };
 
 // A schedule = launches -> tasks (one workgroup each) -> steps (barrier separated) -> items.

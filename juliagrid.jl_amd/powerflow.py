@@ -131,6 +131,16 @@ class AcPowerFlow:
         _lib.check(_lib.lib().jg_nr_get_iteration(self._h, it))
         return it
 
+    def snapshot_voltage(self):
+        _lib.check(_lib.lib().jg_nr_snapshot_voltage(self._h))
+
+    def restore_voltage(self):
+        _lib.check(_lib.lib().jg_nr_restore_voltage(self._h))
+
+    def voltage_device(self, vm_ptr: int, va_ptr: int):
+        """Write [batch, n] voltages into caller-owned DEVICE buffers (raw pointers)."""
+        _lib.check(_lib.lib().jg_nr_get_voltage_device(self._h, C.c_void_p(vm_ptr), C.c_void_p(va_ptr)))
+
     def time_kernel(self, kernel: int, reps: int = 10) -> float:
         ms = C.c_double(0.0)
         _lib.check(_lib.lib().jg_nr_time_kernel(self._h, int(kernel), int(reps), C.byref(ms)))
@@ -197,16 +207,18 @@ def solve_(an: AcPowerFlow):
     an._pull_voltage()
 
 
-def powerFlow_(an: AcPowerFlow, iteration: int = 20, tolerance: float = 1e-8):
+def powerFlow_(an: AcPowerFlow, iteration: int = 20, tolerance: float = 1e-8, fetch: bool = True):
     """powerFlow!(analysis; iteration, tolerance). Sets analysis.method.iteration (array if batch > 1)
-    and analysis.status (0 converged, 1 iteration limit, 3 numeric failure)."""
+    and analysis.status (0 converged, 1 iteration limit, 3 numeric failure).  fetch=False leaves the
+    voltages in HBM (batched loops read them later through analysis._pull_voltage / voltage_device)."""
     _check_signature(an)
     it = np.zeros(an.batch, dtype=np.int32)
     st = np.zeros(an.batch, dtype=np.int32)
     _lib.check(_lib.lib().jg_nr_run(an._h, int(iteration), float(tolerance), it, st))
     an.method.iteration = int(it[0]) if an.batch == 1 else it
     an.status = int(st[0]) if an.batch == 1 else st
-    an._pull_voltage()
+    if fetch:
+        an._pull_voltage()
 
 
 def setInitialPoint_(an: AcPowerFlow, source=None):
