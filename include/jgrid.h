@@ -55,7 +55,7 @@ int jg_nr_create(jg_nr** h, int64_t n, const int64_t* colptr, const int64_t* row
 void jg_nr_destroy(jg_nr* h);
 
 /* sizes: dims[0]=dimJ, dims[1]=nnz(J), dims[2]=nnz blocks of L+D+U, dims[3]=LU update terms,
- * dims[4]=LU kernel launches per factorization, dims[5]=fwd+bwd launches per solve */
+ * dims[4]=launches per factorization (forward elimination fused in), dims[5]=launches per backward sweep */
 int jg_nr_dims(jg_nr* h, int64_t* dims);
 
 /* bus.supply - bus.demand per scenario (acPowerFlow.jl:676-680). [batch][n] each;
@@ -107,8 +107,8 @@ int jg_nr_get_maps(jg_nr* h, int64_t* pq, int64_t* pvpq, int64_t* pcount, int64_
 int jg_nr_get_iteration(jg_nr* h, int32_t* iters);
 
 /* Measurement hooks (HIP events on the handle's own stream).
- * kernel: 0 fused mismatch+Jacobian assembly, 1 LU refactorization (all launches), 2 fwd+bwd solve
- * (no state update).  Returns the mean milliseconds of `reps` back-to-back executions. */
+ * kernel: 0 fused mismatch+Jacobian assembly, 1 LU refactorization + fused forward elimination (all
+ * launches), 2 backward sweep (no state update).  Returns the mean milliseconds of `reps` back-to-back executions. */
 int jg_nr_time_kernel(jg_nr* h, int kernel, int reps, double* mean_ms);
 
 /* ---------------------------------------------------------------------------------------------

@@ -88,7 +88,7 @@ class Plan:
     """Device-free symbolic analysis (schedule export for tests)."""
 
     NAMES = dict(perm=0, e_row=1, e_col=2, e_src=3, t_ptr=4, t_a=5, t_b=6, e_level=7, e_diag=8, diag=9,
-                 l_ptr=10, l_ent=11, l_col=12, u_ptr=13, u_ent=14, u_col=15)
+                 l_ptr=10, l_ent=11, l_col=12, u_ptr=13, u_ent=14, u_col=15, t_d=16, y_level=17)
 
     def __init__(self, n, rowptr, col, policy=0):
         self.h = VP()
@@ -113,6 +113,6 @@ class Plan:
         return out[:m]
 
     def schedule(self, kind):
-        base = {"lu": 20, "fwd": 30, "bwd": 40}[kind]
-        return dict(launches=self.get(base).reshape(-1, 4), task_ptr=self.get(base + 1),
+        base = {"fact": 20, "bwd": 40}[kind]
+        return dict(launches=self.get(base).reshape(-1, 7), task_ptr=self.get(base + 1),
                     step_ptr=self.get(base + 2), items=self.get(base + 3))

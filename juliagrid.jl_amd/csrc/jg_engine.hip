@@ -1,10 +1,12 @@
 // jg_engine.hip -- device kernels of the batched block-sparse LU engine (gfx950, wave64).
 //
-// Every kernel runs a static schedule: launch -> tasks (one workgroup each) -> steps (separated by
-// a workgroup barrier) -> items.  blockDim = (64 lanes = 64 scenarios, W waves); blockIdx.y picks the
-// 64-scenario group.  All structural indices are wave-uniform, so they are forced into SGPRs
-// (readfirstlane) and fetched through the scalar cache; the vector memory pipe only moves
-// 512-byte contiguous value segments.
+// Factorisation A = Lh * inv(D) * U (Lh unscaled) with the forward elimination of the right-hand
+// side fused into the same launches, then one backward sweep.  Every launch replays one dependency
+// level of the static schedule (jg_symbolic): blockDim = (64 lanes = 64 scenarios, W waves),
+// blockIdx.y = 64-scenario group.  `wpi` waves cooperate on one item: its update list is dealt out
+// round-robin, partial sums meet in LDS and are added in a fixed order (run-to-run deterministic).
+// All structural data is wave-uniform: one 32-byte descriptor per item through the scalar cache;
+// the vector memory pipe only moves 512-byte contiguous value segments.
 #include "jg_engine.hpp"
 
 #include <algorithm>
@@ -13,20 +15,17 @@ namespace jg {
 
 namespace {
 
-struct LuArgs {
-    const int* task_ptr; const int* step_ptr; const int* items;
-    const int* e_src; const int* e_diag; const int* t_ptr; const int* t_a; const int* t_b;
-    const double* A; double* X; int* status;
-    int task0; int ld;
+struct FactArgs {
+    const ItemDesc* desc; const int* ta; const int* td; const int* tb;
+    const double* A; const double* rhs; double* X; double* W; int* status; const int* group_active;
+    int item_begin, item_end, wpi, rounds, ld;
 };
 
-struct SolveArgs {
-    const int* task_ptr; const int* step_ptr; const int* items;
-    const int* r_ptr; const int* r_ent; const int* r_col;   // L rows (fwd) or U rows (bwd)
-    const int* diag; const int* perm;
-    const double* X; double* W; const double* rhs; double* out;
+struct BwdArgs {
+    const ItemDesc* desc; const int* u_ent; const int* u_col;
+    const double* X; double* W; double* out; const int* group_active;
     StateUpdate upd;
-    int task0; int ld;
+    int item_begin, item_end, wpi, rounds, ld;
 };
 
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -35,235 +34,218 @@ struct Blk { double v00, v01, v10, v11; };
 
 __device__ __forceinline__ Blk load_blk(const double* p, size_t ld) { return Blk{p[0], p[ld], p[2 * ld], p[3 * ld]}; }
 
-// acc -= L(a) * U(b) over terms t0, t0+stride, ... < t1 ; four terms (64 loads of 512 B per wave) in flight
-__device__ __forceinline__ void lu_terms(const LuArgs& a, int t0, int t1, int stride, size_t b, size_t ld, Blk& c) {
+// c -= Lh(a) * Dinv(d) * U(b)
+__device__ __forceinline__ void term3(Blk& c, const Blk& l, const Blk& d, const Blk& u) {
+    const double m00 = l.v00 * d.v00 + l.v01 * d.v10, m01 = l.v00 * d.v01 + l.v01 * d.v11;
+    const double m10 = l.v10 * d.v00 + l.v11 * d.v10, m11 = l.v10 * d.v01 + l.v11 * d.v11;
+    c.v00 -= m00 * u.v00 + m01 * u.v10;
+    c.v01 -= m00 * u.v01 + m01 * u.v11;
+    c.v10 -= m10 * u.v00 + m11 * u.v10;
+    c.v11 -= m10 * u.v01 + m11 * u.v11;
+}
+
+template <int UNROLL>
+__device__ __forceinline__ void lu_terms(const FactArgs& a, int t0, int t1, int stride, size_t b, size_t ld, Blk& c) {
     int t = t0;
-    for (; t + 3 * stride < t1; t += 4 * stride) {
-        Blk l[4], u[4];
+    for (; t + (UNROLL - 1) * stride < t1; t += UNROLL * stride) {
+        Blk l[UNROLL], d[UNROLL], u[UNROLL];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            l[k] = load_blk(a.X + (size_t)uniform(a.t_a[t + k * stride]) * 4 * ld + b, ld);
-            u[k] = load_blk(a.X + (size_t)uniform(a.t_b[t + k * stride]) * 4 * ld + b, ld);
+        for (int k = 0; k < UNROLL; ++k) {
+            l[k] = load_blk(a.X + (size_t)uniform(a.ta[t + k * stride]) * 4 * ld + b, ld);
+            d[k] = load_blk(a.X + (size_t)uniform(a.td[t + k * stride]) * 4 * ld + b, ld);
+            u[k] = load_blk(a.X + (size_t)uniform(a.tb[t + k * stride]) * 4 * ld + b, ld);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            c.v00 -= l[k].v00 * u[k].v00 + l[k].v01 * u[k].v10;
-            c.v01 -= l[k].v00 * u[k].v01 + l[k].v01 * u[k].v11;
-            c.v10 -= l[k].v10 * u[k].v00 + l[k].v11 * u[k].v10;
-            c.v11 -= l[k].v10 * u[k].v01 + l[k].v11 * u[k].v11;
-        }
+        for (int k = 0; k < UNROLL; ++k) term3(c, l[k], d[k], u[k]);
     }
     for (; t < t1; t += stride) {
-        const Blk l = load_blk(a.X + (size_t)uniform(a.t_a[t]) * 4 * ld + b, ld);
-        const Blk u = load_blk(a.X + (size_t)uniform(a.t_b[t]) * 4 * ld + b, ld);
-        c.v00 -= l.v00 * u.v00 + l.v01 * u.v10;
-        c.v01 -= l.v00 * u.v01 + l.v01 * u.v11;
-        c.v10 -= l.v10 * u.v00 + l.v11 * u.v10;
-        c.v11 -= l.v10 * u.v01 + l.v11 * u.v11;
+        const Blk l = load_blk(a.X + (size_t)uniform(a.ta[t]) * 4 * ld + b, ld);
+        const Blk d = load_blk(a.X + (size_t)uniform(a.td[t]) * 4 * ld + b, ld);
+        const Blk u = load_blk(a.X + (size_t)uniform(a.tb[t]) * 4 * ld + b, ld);
+        term3(c, l, d, u);
     }
 }
 
-// diagonal -> store inverse;  lower -> scale by Dinv(col);  upper -> store
-__device__ __forceinline__ void lu_finish(const LuArgs& a, int e, size_t b, size_t ld, const Blk& c) {
-    const int kind = uniform(a.e_diag[e]);
-    double* q = a.X + (size_t)e * 4 * ld + b;
-    if (kind == -2) {
+// y -= Lh(a) * Dinv(d) * y_c
+template <int UNROLL>
+__device__ __forceinline__ void rhs_terms(const FactArgs& a, int t0, int t1, int stride, size_t b, size_t ld, double& y0, double& y1) {
+    int t = t0;
+    for (; t + (UNROLL - 1) * stride < t1; t += UNROLL * stride) {
+        Blk l[UNROLL], d[UNROLL]; double w0[UNROLL], w1[UNROLL];
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k) {
+            l[k] = load_blk(a.X + (size_t)uniform(a.ta[t + k * stride]) * 4 * ld + b, ld);
+            d[k] = load_blk(a.X + (size_t)uniform(a.td[t + k * stride]) * 4 * ld + b, ld);
+            const double* pw = a.W + (size_t)uniform(a.tb[t + k * stride]) * 2 * ld + b;
+            w0[k] = pw[0]; w1[k] = pw[ld];
+        }
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k) {
+            const double z0 = d[k].v00 * w0[k] + d[k].v01 * w1[k], z1 = d[k].v10 * w0[k] + d[k].v11 * w1[k];
+            y0 -= l[k].v00 * z0 + l[k].v01 * z1;
+            y1 -= l[k].v10 * z0 + l[k].v11 * z1;
+        }
+    }
+    for (; t < t1; t += stride) {
+        const Blk l = load_blk(a.X + (size_t)uniform(a.ta[t]) * 4 * ld + b, ld);
+        const Blk d = load_blk(a.X + (size_t)uniform(a.td[t]) * 4 * ld + b, ld);
+        const double* pw = a.W + (size_t)uniform(a.tb[t]) * 2 * ld + b;
+        const double w0 = pw[0], w1 = pw[ld];
+        const double z0 = d.v00 * w0 + d.v01 * w1, z1 = d.v10 * w0 + d.v11 * w1;
+        y0 -= l.v00 * z0 + l.v01 * z1;
+        y1 -= l.v10 * z0 + l.v11 * z1;
+    }
+}
+
+__device__ __forceinline__ void fact_finish(const FactArgs& a, int kind, int id, size_t b, size_t ld, const Blk& c) {
+    if (kind == 3) {
+        a.W[((size_t)id * 2) * ld + b] = c.v00;
+        a.W[((size_t)id * 2 + 1) * ld + b] = c.v01;
+        return;
+    }
+    double* q = a.X + (size_t)id * 4 * ld + b;
+    if (kind == 2) {                            // diagonal block: keep the inverse
         const double det = c.v00 * c.v11 - c.v01 * c.v10;
         const double r = 1.0 / det;
         if (!(fabs(det) > 0.0) || !(fabs(r) < 1.0e300)) atomicOr(a.status + b, 4);
         q[0] = c.v11 * r; q[ld] = -c.v01 * r; q[2 * ld] = -c.v10 * r; q[3 * ld] = c.v00 * r;
-    } else if (kind >= 0) {
-        const Blk d = load_blk(a.X + (size_t)kind * 4 * ld + b, ld);
-        q[0] = c.v00 * d.v00 + c.v01 * d.v10; q[ld] = c.v00 * d.v01 + c.v01 * d.v11;
-        q[2 * ld] = c.v10 * d.v00 + c.v11 * d.v10; q[3 * ld] = c.v10 * d.v01 + c.v11 * d.v11;
     } else {
         q[0] = c.v00; q[ld] = c.v01; q[2 * ld] = c.v10; q[3 * ld] = c.v11;
     }
 }
 
-__device__ __forceinline__ Blk lu_source(const LuArgs& a, int e, size_t b, size_t ld) {
-    const int src = uniform(a.e_src[e]);
-    if (src < 0) return Blk{0.0, 0.0, 0.0, 0.0};
-    return load_blk(a.A + (size_t)src * 4 * ld + b, ld);
-}
-
-// One wave per item; a task may chain several barrier-separated steps.
-__global__ __launch_bounds__(256) void k_lu(LuArgs a) {
+// One dependency level of  A = Lh inv(D) U  and  y = (Lh inv(D))^-1 rhs.
+template <bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? 1024 : 256) void k_fact(FactArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double red[];   // SPLIT: [W][4][64]
+    if (a.group_active && !a.group_active[blockIdx.y]) return;
     const int lane = threadIdx.x;
     const int wave = uniform(threadIdx.y);
-    const int W = blockDim.y;
-    const int task = a.task0 + blockIdx.x;
     const size_t ld = (size_t)a.ld;
     const size_t b = (size_t)blockIdx.y * 64 + lane;
-    const int s0 = a.task_ptr[task], s1 = a.task_ptr[task + 1];
-    for (int s = s0; s < s1; ++s) {
-        const int i0 = a.step_ptr[s], i1 = a.step_ptr[s + 1];
-        for (int idx = i0 + wave; idx < i1; idx += W) {
-            const int e = uniform(a.items[idx]);
-            Blk c = lu_source(a, e, b, ld);
-            lu_terms(a, uniform(a.t_ptr[e]), uniform(a.t_ptr[e + 1]), 1, b, ld, c);
-            lu_finish(a, e, b, ld, c);
-        }
-        if (s + 1 < s1) __syncthreads();
-    }
-}
-
-// `wpi` waves share one item: wave `sub` takes terms sub, sub+wpi, ...; partial sums meet in LDS and
-// are added in a fixed order (run-to-run deterministic).  Single-step tasks of blockDim.y/wpi items.
-__global__ __launch_bounds__(1024) void k_lu_split(LuArgs a, int wpi) {
-    extern __shared__ __attribute__((aligned(16))) double red[];   // [W][4][64]
-    const int lane = threadIdx.x;
-    const int wave = uniform(threadIdx.y);
-    const int task = a.task0 + blockIdx.x;
-    const size_t ld = (size_t)a.ld;
-    const size_t b = (size_t)blockIdx.y * 64 + lane;
-    const int s = a.task_ptr[task];
-    const int i0 = a.step_ptr[s], i1 = a.step_ptr[s + 1];
+    const int wpi = SPLIT ? a.wpi : 1;
+    const int slots = blockDim.y / wpi;
     const int slot = wave / wpi, sub = wave - slot * wpi;
-    const int idx = i0 + slot;
-    const bool valid = idx < i1;
-    int e = 0;
-    Blk c{0.0, 0.0, 0.0, 0.0};
-    if (valid) {
-        e = uniform(a.items[idx]);
-        if (sub == 0) c = lu_source(a, e, b, ld);
-        lu_terms(a, uniform(a.t_ptr[e]) + sub, uniform(a.t_ptr[e + 1]), wpi, b, ld, c);
-        if (sub != 0) {
-            double* r = red + (size_t)wave * 256 + lane;
-            r[0] = c.v00; r[64] = c.v01; r[128] = c.v10; r[192] = c.v11;
+    for (int r = 0; r < a.rounds; ++r) {
+        const int idx = a.item_begin + (blockIdx.x * a.rounds + r) * slots + slot;
+        const bool valid = idx < a.item_end;
+        Blk c{0.0, 0.0, 0.0, 0.0};
+        int kind = 0, id = 0;
+        if (valid) {
+            const ItemDesc* dp = a.desc + idx;
+            kind = uniform(dp->kind); id = uniform(dp->id);
+            const int src = uniform(dp->src), t0 = uniform(dp->t0), t1 = uniform(dp->t1);
+            if (kind == 3) {
+                if (sub == 0) { c.v00 = a.rhs[((size_t)src * 2) * ld + b]; c.v01 = a.rhs[((size_t)src * 2 + 1) * ld + b]; }
+                rhs_terms<4>(a, t0 + sub, t1, wpi, b, ld, c.v00, c.v01);
+            } else {
+                if (sub == 0 && src >= 0) c = load_blk(a.A + (size_t)src * 4 * ld + b, ld);
+                lu_terms<3>(a, t0 + sub, t1, wpi, b, ld, c);
+            }
+            if (SPLIT && sub != 0) {
+                double* q = red + (size_t)wave * 256 + lane;
+                q[0] = c.v00; q[64] = c.v01; q[128] = c.v10; q[192] = c.v11;
+            }
         }
-    }
-    __syncthreads();
-    if (valid && sub == 0) {
-        for (int w = 1; w < wpi; ++w) {
-            const double* r = red + (size_t)(wave + w) * 256 + lane;
-            c.v00 += r[0]; c.v01 += r[64]; c.v10 += r[128]; c.v11 += r[192];
+        if (SPLIT) __syncthreads();
+        if (valid && sub == 0) {
+            if (SPLIT)
+                for (int w = 1; w < wpi; ++w) {
+                    const double* q = red + (size_t)(wave + w) * 256 + lane;
+                    c.v00 += q[0]; c.v01 += q[64]; c.v10 += q[128]; c.v11 += q[192];
+                }
+            fact_finish(a, kind, id, b, ld, c);
         }
-        lu_finish(a, e, b, ld, c);
+        if (SPLIT && r + 1 < a.rounds) __syncthreads();
     }
 }
 
-// y -= sum over row entries X(ent) * W(col), entries p0, p0+stride, ... < p1; four in flight
-__device__ __forceinline__ void row_terms(const SolveArgs& a, int p0, int p1, int stride, size_t b, size_t ld, double& y0, double& y1) {
+template <int UNROLL>
+__device__ __forceinline__ void row_terms(const BwdArgs& a, int p0, int p1, int stride, size_t b, size_t ld, double& y0, double& y1) {
     int p = p0;
-    for (; p + 3 * stride < p1; p += 4 * stride) {
-        Blk m[4]; double w0[4], w1[4];
+    for (; p + (UNROLL - 1) * stride < p1; p += UNROLL * stride) {
+        Blk m[UNROLL]; double w0[UNROLL], w1[UNROLL];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            m[k] = load_blk(a.X + (size_t)uniform(a.r_ent[p + k * stride]) * 4 * ld + b, ld);
-            const double* pw = a.W + (size_t)uniform(a.r_col[p + k * stride]) * 2 * ld + b;
+        for (int k = 0; k < UNROLL; ++k) {
+            m[k] = load_blk(a.X + (size_t)uniform(a.u_ent[p + k * stride]) * 4 * ld + b, ld);
+            const double* pw = a.W + (size_t)uniform(a.u_col[p + k * stride]) * 2 * ld + b;
             w0[k] = pw[0]; w1[k] = pw[ld];
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < UNROLL; ++k) {
             y0 -= m[k].v00 * w0[k] + m[k].v01 * w1[k];
             y1 -= m[k].v10 * w0[k] + m[k].v11 * w1[k];
         }
     }
     for (; p < p1; p += stride) {
-        const Blk m = load_blk(a.X + (size_t)uniform(a.r_ent[p]) * 4 * ld + b, ld);
-        const double* pw = a.W + (size_t)uniform(a.r_col[p]) * 2 * ld + b;
+        const Blk m = load_blk(a.X + (size_t)uniform(a.u_ent[p]) * 4 * ld + b, ld);
+        const double* pw = a.W + (size_t)uniform(a.u_col[p]) * 2 * ld + b;
         const double w0 = pw[0], w1 = pw[ld];
         y0 -= m.v00 * w0 + m.v01 * w1;
         y1 -= m.v10 * w0 + m.v11 * w1;
     }
 }
 
-__device__ __forceinline__ void bwd_finish(const SolveArgs& a, int k, size_t b, size_t ld, double y0, double y1, bool act) {
-    const Blk d = load_blk(a.X + (size_t)uniform(a.diag[k]) * 4 * ld + b, ld);
-    const double x0 = d.v00 * y0 + d.v01 * y1;
-    const double x1 = d.v10 * y0 + d.v11 * y1;
-    a.W[((size_t)k * 2) * ld + b] = x0;
-    a.W[((size_t)k * 2 + 1) * ld + b] = x1;
-    const int bus = uniform(a.perm[k]);
-    a.out[((size_t)bus * 2) * ld + b] = x0;
-    a.out[((size_t)bus * 2 + 1) * ld + b] = x1;
-    if (a.upd.va) {
-        const int fl = uniform((int)a.upd.flags[bus]);
-        if (act && (fl & 1)) a.upd.va[(size_t)bus * ld + b] += a.upd.sign * x0;
-        if (act && (fl & 2)) a.upd.vm[(size_t)bus * ld + b] += a.upd.sign * x1;
-    }
-}
-
-// Forward substitution with unit-lower L:  W_k = rhs_{perm k} - sum_c L(k,c) W_c         (BWD = false)
-// Backward substitution: x_k = Dinv_k (W_k - sum_c U(k,c) x_c), scatter to original order, optional
-// fused state update (NR: V/theta -= increment on active scenarios)                      (BWD = true)
-template <bool BWD>
-__global__ __launch_bounds__(256) void k_tri(SolveArgs a) {
+// Backward sweep: x_k = Dinv_k (y_k - sum_c U(k,c) x_c), scattered to original order; optional fused
+// state update (Newton-Raphson: V/theta -= increment on active scenarios).
+template <bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? 1024 : 256) void k_bwd(BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double red[];   // SPLIT: [W][2][64]
+    if (a.group_active && !a.group_active[blockIdx.y]) return;
     const int lane = threadIdx.x;
     const int wave = uniform(threadIdx.y);
-    const int W = blockDim.y;
-    const int task = a.task0 + blockIdx.x;
     const size_t ld = (size_t)a.ld;
     const size_t b = (size_t)blockIdx.y * 64 + lane;
-    const int s0 = a.task_ptr[task], s1 = a.task_ptr[task + 1];
-    const bool act = (BWD && a.upd.active) ? (a.upd.active[b] != 0) : true;
-    for (int s = s0; s < s1; ++s) {
-        const int i0 = a.step_ptr[s], i1 = a.step_ptr[s + 1];
-        for (int idx = i0 + wave; idx < i1; idx += W) {
-            const int k = uniform(a.items[idx]);
-            double y0, y1;
-            if (BWD) {
-                y0 = a.W[((size_t)k * 2) * ld + b]; y1 = a.W[((size_t)k * 2 + 1) * ld + b];
-            } else {
-                const int bus = uniform(a.perm[k]);
-                y0 = a.rhs[((size_t)bus * 2) * ld + b]; y1 = a.rhs[((size_t)bus * 2 + 1) * ld + b];
-            }
-            row_terms(a, uniform(a.r_ptr[k]), uniform(a.r_ptr[k + 1]), 1, b, ld, y0, y1);
-            if (BWD) bwd_finish(a, k, b, ld, y0, y1, act);
-            else { a.W[((size_t)k * 2) * ld + b] = y0; a.W[((size_t)k * 2 + 1) * ld + b] = y1; }
-        }
-        if (s + 1 < s1) __syncthreads();
-    }
-}
-
-template <bool BWD>
-__global__ __launch_bounds__(1024) void k_tri_split(SolveArgs a, int wpi) {
-    extern __shared__ __attribute__((aligned(16))) double red[];   // [W][2][64]
-    const int lane = threadIdx.x;
-    const int wave = uniform(threadIdx.y);
-    const int task = a.task0 + blockIdx.x;
-    const size_t ld = (size_t)a.ld;
-    const size_t b = (size_t)blockIdx.y * 64 + lane;
-    const int s = a.task_ptr[task];
-    const int i0 = a.step_ptr[s], i1 = a.step_ptr[s + 1];
+    const int wpi = SPLIT ? a.wpi : 1;
+    const int slots = blockDim.y / wpi;
     const int slot = wave / wpi, sub = wave - slot * wpi;
-    const int idx = i0 + slot;
-    const bool valid = idx < i1;
-    const bool act = (BWD && a.upd.active) ? (a.upd.active[b] != 0) : true;
-    int k = 0;
-    double y0 = 0.0, y1 = 0.0;
-    if (valid) {
-        k = uniform(a.items[idx]);
-        if (sub == 0) {
-            if (BWD) { y0 = a.W[((size_t)k * 2) * ld + b]; y1 = a.W[((size_t)k * 2 + 1) * ld + b]; }
-            else {
-                const int bus = uniform(a.perm[k]);
-                y0 = a.rhs[((size_t)bus * 2) * ld + b]; y1 = a.rhs[((size_t)bus * 2 + 1) * ld + b];
+    const bool act = a.upd.active ? (a.upd.active[b] != 0) : true;
+    for (int r = 0; r < a.rounds; ++r) {
+        const int idx = a.item_begin + (blockIdx.x * a.rounds + r) * slots + slot;
+        const bool valid = idx < a.item_end;
+        double y0 = 0.0, y1 = 0.0;
+        int k = 0, bus = 0, dg = 0;
+        if (valid) {
+            const ItemDesc* dp = a.desc + idx;
+            k = uniform(dp->id); bus = uniform(dp->src); dg = uniform(dp->aux);
+            const int p0 = uniform(dp->t0), p1 = uniform(dp->t1);
+            if (sub == 0) { y0 = a.W[((size_t)k * 2) * ld + b]; y1 = a.W[((size_t)k * 2 + 1) * ld + b]; }
+            row_terms<4>(a, p0 + sub, p1, wpi, b, ld, y0, y1);
+            if (SPLIT && sub != 0) { red[(size_t)wave * 128 + lane] = y0; red[(size_t)wave * 128 + 64 + lane] = y1; }
+        }
+        if (SPLIT) __syncthreads();
+        if (valid && sub == 0) {
+            if (SPLIT)
+                for (int w = 1; w < wpi; ++w) { y0 += red[(size_t)(wave + w) * 128 + lane]; y1 += red[(size_t)(wave + w) * 128 + 64 + lane]; }
+            const Blk d = load_blk(a.X + (size_t)dg * 4 * ld + b, ld);
+            const double x0 = d.v00 * y0 + d.v01 * y1;
+            const double x1 = d.v10 * y0 + d.v11 * y1;
+            a.W[((size_t)k * 2) * ld + b] = x0;
+            a.W[((size_t)k * 2 + 1) * ld + b] = x1;
+            a.out[((size_t)bus * 2) * ld + b] = x0;
+            a.out[((size_t)bus * 2 + 1) * ld + b] = x1;
+            if (a.upd.va) {
+                const int fl = uniform((int)a.upd.flags[bus]);
+                if (act && (fl & 1)) a.upd.va[(size_t)bus * ld + b] += a.upd.sign * x0;
+                if (act && (fl & 2)) a.upd.vm[(size_t)bus * ld + b] += a.upd.sign * x1;
             }
         }
-        row_terms(a, uniform(a.r_ptr[k]) + sub, uniform(a.r_ptr[k + 1]), wpi, b, ld, y0, y1);
-        if (sub != 0) { red[(size_t)wave * 128 + lane] = y0; red[(size_t)wave * 128 + 64 + lane] = y1; }
-    }
-    __syncthreads();
-    if (valid && sub == 0) {
-        for (int w = 1; w < wpi; ++w) { y0 += red[(size_t)(wave + w) * 128 + lane]; y1 += red[(size_t)(wave + w) * 128 + 64 + lane]; }
-        if (BWD) bwd_finish(a, k, b, ld, y0, y1, act);
-        else { a.W[((size_t)k * 2) * ld + b] = y0; a.W[((size_t)k * 2 + 1) * ld + b] = y1; }
+        if (SPLIT && r + 1 < a.rounds) __syncthreads();
     }
 }
 
-int upload_schedule(const Schedule& s, DevSchedule& d, std::string& err) {
-    d.launches = s.launches;
-    if (upload(&d.task_ptr, s.task_ptr, err)) return 2;
-    if (upload(&d.step_ptr, s.step_ptr, err)) return 2;
-    if (upload(&d.items, s.items, err)) return 2;
-    return 0;
-}
-
-void free_schedule(DevSchedule& d) {
-    hipFree(d.task_ptr); hipFree(d.step_ptr); hipFree(d.items);
-    d = DevSchedule();
+void flatten(const Schedule& s, std::vector<DevLaunch>& out) {
+    out.clear();
+    for (const Launch& L : s.launches) {
+        DevLaunch d;
+        d.item_begin = L.item_begin; d.item_end = L.item_end;
+        d.waves = L.waves; d.wpi = L.wpi;
+        const int slots = L.waves / L.wpi;
+        d.rounds = std::max(1, L.chunk / slots);
+        const int per_wg = slots * d.rounds;
+        d.grid = (L.item_end - L.item_begin + per_wg - 1) / per_wg;
+        out.push_back(d);
+    }
 }
 
 }  // namespace
@@ -272,15 +254,37 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, int policy
     if (ld_ <= 0 || ld_ % 64) { error = "batch leading dimension must be a positive multiple of 64"; return 1; }
     if (analyze(n, rowptr, col, policy, S)) { error = "block pattern must be structurally symmetric with a full diagonal"; return 1; }
     ld = ld_;
-    std::vector<int> kind(S.n_entries);
-    for (int e = 0; e < S.n_entries; ++e) kind[e] = S.e_row[e] == S.e_col[e] ? -2 : (S.e_row[e] > S.e_col[e] ? S.e_diag[e] : -1);
-    if (upload(&e_src, S.e_src, error) || upload(&e_diag, kind, error) || upload(&t_ptr, S.t_ptr, error) ||
-        upload(&t_a, S.t_a, error) || upload(&t_b, S.t_b, error) || upload(&l_ptr, S.l_ptr, error) ||
-        upload(&l_ent, S.l_ent, error) || upload(&l_col, S.l_col, error) || upload(&u_ptr, S.u_ptr, error) ||
-        upload(&u_ent, S.u_ent, error) || upload(&u_col, S.u_col, error) || upload(&diag, S.diag, error) ||
-        upload(&perm, S.perm, error))
+    const int nE = S.n_entries;
+    // terms: LU terms, then rhs-row terms (Lh entry, diagonal of the column, column pivot)
+    std::vector<int> va(S.t_a), vd(S.t_d), vb(S.t_b);
+    const int rhs_base = (int)va.size();
+    for (int r = 0; r < n; ++r)
+        for (int p = S.l_ptr[r]; p < S.l_ptr[r + 1]; ++p) { va.push_back(S.l_ent[p]); vd.push_back(S.diag[S.l_col[p]]); vb.push_back(S.l_col[p]); }
+    std::vector<ItemDesc> fd(S.fact.items.size());
+    for (size_t i = 0; i < fd.size(); ++i) {
+        const int it = S.fact.items[i];
+        ItemDesc d{};
+        if (it < nE) {
+            d.kind = S.e_row[it] == S.e_col[it] ? 2 : (S.e_row[it] > S.e_col[it] ? 1 : 0);
+            d.id = it; d.src = S.e_src[it]; d.t0 = S.t_ptr[it]; d.t1 = S.t_ptr[it + 1];
+        } else {
+            const int k = it - nE;
+            d.kind = 3; d.id = k; d.src = S.perm[k]; d.t0 = rhs_base + S.l_ptr[k]; d.t1 = rhs_base + S.l_ptr[k + 1];
+        }
+        fd[i] = d;
+    }
+    std::vector<ItemDesc> bd(S.bwd.items.size());
+    for (size_t i = 0; i < bd.size(); ++i) {
+        const int k = S.bwd.items[i];
+        ItemDesc d{};
+        d.kind = 4; d.id = k; d.src = S.perm[k]; d.t0 = S.u_ptr[k]; d.t1 = S.u_ptr[k + 1]; d.aux = S.diag[k];
+        bd[i] = d;
+    }
+    flatten(S.fact, fact);
+    flatten(S.bwd, bwd);
+    if (upload(&fact_desc, fd, error) || upload(&bwd_desc, bd, error) || upload(&ta, va, error) || upload(&td, vd, error) ||
+        upload(&tb, vb, error) || upload(&u_ent, S.u_ent, error) || upload(&u_col, S.u_col, error))
         return 2;
-    if (upload_schedule(S.lu, lu, error) || upload_schedule(S.fwd, fwd, error) || upload_schedule(S.bwd, bwd, error)) return 2;
     JG_HIP(hipMalloc((void**)&X, factor_bytes()));
     JG_HIP(hipMemset(X, 0, factor_bytes()));
     JG_HIP(hipMalloc((void**)&W, (size_t)n * 2 * ld * sizeof(double)));
@@ -291,41 +295,32 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, int policy
 }
 
 void Engine::destroy() {
-    hipFree(e_src); hipFree(e_diag); hipFree(t_ptr); hipFree(t_a); hipFree(t_b);
-    hipFree(l_ptr); hipFree(l_ent); hipFree(l_col); hipFree(u_ptr); hipFree(u_ent); hipFree(u_col);
-    hipFree(diag); hipFree(perm); hipFree(X); hipFree(W); hipFree(status);
-    free_schedule(lu); free_schedule(fwd); free_schedule(bwd);
-    e_src = e_diag = t_ptr = t_a = t_b = l_ptr = l_ent = l_col = u_ptr = u_ent = u_col = diag = perm = status = nullptr;
+    hipFree(fact_desc); hipFree(bwd_desc); hipFree(ta); hipFree(td); hipFree(tb); hipFree(u_ent); hipFree(u_col);
+    hipFree(X); hipFree(W); hipFree(status);
+    fact_desc = bwd_desc = nullptr;
+    ta = td = tb = u_ent = u_col = status = nullptr;
     X = W = nullptr;
 }
 
-int Engine::factor(hipStream_t st, const double* A) {
-    LuArgs a{lu.task_ptr, lu.step_ptr, lu.items, e_src, e_diag, t_ptr, t_a, t_b, A, X, status, 0, ld};
-    for (const Launch& L : lu.launches) {
-        a.task0 = L.task_begin;
-        dim3 grid(L.task_end - L.task_begin, ld / 64), block(64, L.waves);
-        if (L.wpi == 1) hipLaunchKernelGGL(k_lu, grid, block, 0, st, a);
-        else hipLaunchKernelGGL(k_lu_split, grid, block, (size_t)L.waves * 256 * sizeof(double), st, a, L.wpi);
+int Engine::factor(hipStream_t st, const double* A, const double* rhs, const int* group_active) {
+    FactArgs a{fact_desc, ta, td, tb, A, rhs, X, W, status, group_active, 0, 0, 1, 1, ld};
+    for (const DevLaunch& L : fact) {
+        a.item_begin = L.item_begin; a.item_end = L.item_end; a.wpi = L.wpi; a.rounds = L.rounds;
+        dim3 grid(L.grid, ld / 64), block(64, L.waves);
+        if (L.wpi == 1) hipLaunchKernelGGL(k_fact<false>, grid, block, 0, st, a);
+        else hipLaunchKernelGGL(k_fact<true>, grid, block, (size_t)L.waves * 256 * sizeof(double), st, a);
     }
     JG_HIP(hipGetLastError());
     return 0;
 }
 
-int Engine::solve(hipStream_t st, const double* rhs, double* out, const StateUpdate& upd) {
-    SolveArgs a{fwd.task_ptr, fwd.step_ptr, fwd.items, l_ptr, l_ent, l_col, diag, perm, X, W, rhs, out, upd, 0, ld};
-    for (const Launch& L : fwd.launches) {
-        a.task0 = L.task_begin;
-        dim3 grid(L.task_end - L.task_begin, ld / 64), block(64, L.waves);
-        if (L.wpi == 1) hipLaunchKernelGGL(k_tri<false>, grid, block, 0, st, a);
-        else hipLaunchKernelGGL(k_tri_split<false>, grid, block, (size_t)L.waves * 128 * sizeof(double), st, a, L.wpi);
-    }
-    a.task_ptr = bwd.task_ptr; a.step_ptr = bwd.step_ptr; a.items = bwd.items;
-    a.r_ptr = u_ptr; a.r_ent = u_ent; a.r_col = u_col;
-    for (const Launch& L : bwd.launches) {
-        a.task0 = L.task_begin;
-        dim3 grid(L.task_end - L.task_begin, ld / 64), block(64, L.waves);
-        if (L.wpi == 1) hipLaunchKernelGGL(k_tri<true>, grid, block, 0, st, a);
-        else hipLaunchKernelGGL(k_tri_split<true>, grid, block, (size_t)L.waves * 128 * sizeof(double), st, a, L.wpi);
+int Engine::backsolve(hipStream_t st, double* out, const StateUpdate& upd, const int* group_active) {
+    BwdArgs a{bwd_desc, u_ent, u_col, X, W, out, group_active, upd, 0, 0, 1, 1, ld};
+    for (const DevLaunch& L : bwd) {
+        a.item_begin = L.item_begin; a.item_end = L.item_end; a.wpi = L.wpi; a.rounds = L.rounds;
+        dim3 grid(L.grid, ld / 64), block(64, L.waves);
+        if (L.wpi == 1) hipLaunchKernelGGL(k_bwd<false>, grid, block, 0, st, a);
+        else hipLaunchKernelGGL(k_bwd<true>, grid, block, (size_t)L.waves * 128 * sizeof(double), st, a);
     }
     JG_HIP(hipGetLastError());
     return 0;

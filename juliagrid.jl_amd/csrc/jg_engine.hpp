@@ -16,11 +16,20 @@
 
 namespace jg {
 
-struct DevSchedule {
-    int* task_ptr = nullptr;
-    int* step_ptr = nullptr;
-    int* items = nullptr;
-    std::vector<Launch> launches;
+// 32-byte item descriptor, fetched with one scalar load per item (schedule order).
+struct ItemDesc {
+    int kind;      // 0 upper U(k,j), 1 lower Lh(i,k) (unscaled), 2 diagonal (stores the inverse), 3 rhs row y_k
+    int id;        // entry id, or pivot k for rhs rows / backward rows
+    int src;       // block index in the caller's CSR (-1 = fill-in); original block index (bus) for rows
+    int t0, t1;    // term range in (ta, td, tb)
+    int aux;       // backward rows: entry id of the diagonal
+    int pad0, pad1;
+};
+
+struct DevLaunch {
+    int item_begin, item_end;   // range in the descriptor array
+    int waves, wpi, rounds;     // blockDim.y, waves per item, items per slot
+    int grid;                   // workgroups along x
 };
 
 // Optional state update fused into the backward solve (NR: x <- x - dx, masked by bus flags).
@@ -35,27 +44,24 @@ struct StateUpdate {
 struct Engine {
     BlockSymbolic S;
     int ld = 0;                    // padded batch (multiple of 64)
-    int* e_src = nullptr;
-    int* e_diag = nullptr;         // >=0 lower (diag entry of its column), -1 upper, -2 diagonal
-    int* t_ptr = nullptr;
-    int* t_a = nullptr;
-    int* t_b = nullptr;
-    int* l_ptr = nullptr; int* l_ent = nullptr; int* l_col = nullptr;
-    int* u_ptr = nullptr; int* u_ent = nullptr; int* u_col = nullptr;
-    int* diag = nullptr;
-    int* perm = nullptr;
-    double* X = nullptr;           // factor values [n_entries][4][ld]
-    double* W = nullptr;           // solve workspace [n][2][ld], pivot order
+    ItemDesc* fact_desc = nullptr; // factorisation + fused forward elimination, schedule order
+    ItemDesc* bwd_desc = nullptr;
+    int* ta = nullptr; int* td = nullptr; int* tb = nullptr;   // LU terms followed by rhs-row terms
+    int* u_ent = nullptr; int* u_col = nullptr;
+    double* X = nullptr;           // factor values [n_entries][4][ld]: U, unscaled Lh, inverse diagonal
+    double* W = nullptr;           // [n][2][ld] pivot order: y after factor(), x after backsolve()
     int* status = nullptr;         // [ld] bit 2 set on zero / non-finite pivot
-    DevSchedule lu, fwd, bwd;
+    std::vector<DevLaunch> fact, bwd;
     std::string error;
 
     int create(int n, const int* rowptr, const int* col, int ld_, int policy);
     void destroy();
-    // A: block values in the caller's CSR order [nnz][4][ld]
-    int factor(hipStream_t st, const double* A);
-    // rhs, out: [n][2][ld] in original block order. out receives the solution.
-    int solve(hipStream_t st, const double* rhs, double* out, const StateUpdate& upd);
+    // A: block values in the caller's CSR order [nnz][4][ld]; rhs: [n][2][ld] original block order.
+    // Computes A = Lh inv(D) U and y = (Lh inv(D))^-1 rhs in the same launches.
+    // group_active (nullable): [ld/64] flags, workgroups of an inactive 64-scenario group exit at once.
+    int factor(hipStream_t st, const double* A, const double* rhs, const int* group_active);
+    // x = U^-1 D y, scattered to original order into out [n][2][ld]; optional fused state update.
+    int backsolve(hipStream_t st, double* out, const StateUpdate& upd, const int* group_active);
     size_t factor_bytes() const { return (size_t)S.n_entries * 4 * ld * sizeof(double); }
 };
 

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(AsmArgs a) {
 struct CheckArgs {
     const double* part; int nchunk; int ld; int batch;
     const double* params;      // [0] tolerance, [1] max iterations
-    double* normp; double* normq; int* active; int* iters; int* status; const int* lu_status; int* counter;
+    double* normp; double* normq; int* active; int* iters; int* status; const int* lu_status; int* counter; int* group;
     int mode;                  // 0 = norms only, 1 = powerFlow! loop control
 };
 
@@ -153,7 +153,7 @@ __global__ void k_check(CheckArgs a) {
     const bool act = real && !conv && !bad && a.iters[b] < maxit; // acPowerFlow.jl:1414
     a.active[b] = act ? 1 : 0;
     a.status[b] = conv ? 0 : (bad ? 3 : 1);
-    if (act) { a.iters[b] += 1; atomicAdd(a.counter, 1); }        // solve! follows: iteration += 1 (:908)
+    if (act) { a.iters[b] += 1; atomicAdd(a.counter, 1); atomicOr(a.group + (b >> 6), 1); }        // solve! follows: iteration += 1 (:908)
 }
 
 // [n][ld] batch-minor -> [batch][n] scenario-major, tiled through LDS so both sides stay coalesced
@@ -193,7 +193,7 @@ struct jg_nr {
     double* d_A = nullptr; double* d_F = nullptr; double* d_inc = nullptr; double* d_part = nullptr;
     double* d_normp = nullptr; double* d_normq = nullptr; double* d_params = nullptr;
     double* d_vm0 = nullptr; double* d_va0 = nullptr;   // snapshot of the start point
-    int* d_active = nullptr; int* d_iters = nullptr; int* d_status = nullptr; int* d_counter = nullptr;
+    int* d_active = nullptr; int* d_iters = nullptr; int* d_status = nullptr; int* d_counter = nullptr; int* d_group = nullptr;
     jg::Engine eng;
     hipStream_t stream = nullptr;
     hipGraph_t graphA = nullptr, graphB = nullptr;
@@ -219,7 +219,7 @@ void launch_assemble(jg_nr* h) {
 
 void launch_check(jg_nr* h, int mode) {
     CheckArgs c{h->d_part, h->nchunk, h->ld, h->batch, h->d_params, h->d_normp, h->d_normq, h->d_active,
-                h->d_iters, h->d_status, h->eng.status, h->d_counter, mode};
+                h->d_iters, h->d_status, h->eng.status, h->d_counter, h->d_group, mode};
     hipLaunchKernelGGL(k_check, dim3((h->ld + 255) / 256), dim3(256), 0, h->stream, c);
 }
 
@@ -238,15 +238,16 @@ int build_graphs(jg_nr* h) {
     if (h->execA) return 0;
     NR_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     hipMemsetAsync(h->d_counter, 0, sizeof(int), h->stream);
+    hipMemsetAsync(h->d_group, 0, (size_t)(h->ld / 64) * sizeof(int), h->stream);
     launch_assemble(h);
     launch_check(h, 1);
     hipMemcpyAsync(h->h_counter, h->d_counter, sizeof(int), hipMemcpyDeviceToHost, h->stream);
     NR_HIP(hipStreamEndCapture(h->stream, &h->graphA));
     NR_HIP(hipGraphInstantiate(&h->execA, h->graphA, nullptr, nullptr, 0));
     NR_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    int rc = h->eng.factor(h->stream, h->d_A);
+    int rc = h->eng.factor(h->stream, h->d_A, h->d_F, h->d_group);
     jg::StateUpdate upd{h->d_va, h->d_vm, h->d_flags, h->d_active, -1.0};
-    if (!rc) rc = h->eng.solve(h->stream, h->d_F, h->d_inc, upd);
+    if (!rc) rc = h->eng.backsolve(h->stream, h->d_inc, upd, h->d_group);
     hipError_t e = hipStreamEndCapture(h->stream, &h->graphB);
     if (rc) return fail(rc, h->eng.error);
     NR_HIP(e);
@@ -373,7 +374,8 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
               dmalloc((void**)&h->d_part, (size_t)h->nchunk * 2 * ld * 8) && dmalloc((void**)&h->d_normp, ld * 8) &&
               dmalloc((void**)&h->d_normq, ld * 8) && dmalloc((void**)&h->d_params, 2 * 8) &&
               dmalloc((void**)&h->d_active, ld * 4) && dmalloc((void**)&h->d_iters, ld * 4) &&
-              dmalloc((void**)&h->d_status, ld * 4) && dmalloc((void**)&h->d_counter, 4);
+              dmalloc((void**)&h->d_status, ld * 4) && dmalloc((void**)&h->d_counter, 4) &&
+              dmalloc((void**)&h->d_group, (ld / 64) * 4);
     if (!ok) { jg_nr_destroy(h); return fail(2, "jg_nr_create: device allocation failed"); }
     if (hipMemset(h->d_ppos, 0xff, mpn * ld * 4) != hipSuccess ||                 // -1 = no patch
         hipHostMalloc((void**)&h->h_counter, sizeof(int)) != hipSuccess ||
@@ -399,7 +401,7 @@ void jg_nr_destroy(jg_nr* h) {
     hipFree(h->d_vm); hipFree(h->d_va); hipFree(h->d_p); hipFree(h->d_q); hipFree(h->d_ppos); hipFree(h->d_pdg);
     hipFree(h->d_pdb); hipFree(h->d_A); hipFree(h->d_F); hipFree(h->d_inc); hipFree(h->d_part); hipFree(h->d_normp);
     hipFree(h->d_normq); hipFree(h->d_params); hipFree(h->d_active); hipFree(h->d_iters); hipFree(h->d_status);
-    hipFree(h->d_counter); hipFree(h->d_vm0); hipFree(h->d_va0);
+    hipFree(h->d_counter); hipFree(h->d_vm0); hipFree(h->d_va0); hipFree(h->d_group);
     if (h->h_counter) hipHostFree(h->h_counter);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -408,8 +410,8 @@ void jg_nr_destroy(jg_nr* h) {
 int jg_nr_dims(jg_nr* h, int64_t* dims) {
     if (!h || !dims) return fail(1, "jg_nr_dims: bad argument");
     dims[0] = h->dimJ; dims[1] = h->nnzJ; dims[2] = h->eng.S.n_entries; dims[3] = h->eng.S.n_terms;
-    dims[4] = (int64_t)h->eng.S.lu.launches.size();
-    dims[5] = (int64_t)(h->eng.S.fwd.launches.size() + h->eng.S.bwd.launches.size());
+    dims[4] = (int64_t)h->eng.S.fact.launches.size();
+    dims[5] = (int64_t)h->eng.S.bwd.launches.size();
     return 0;
 }
 
@@ -538,9 +540,9 @@ int jg_nr_solve(jg_nr* h) {
     if (int rc = set_device(h)) return rc;
     if (!h->jac_valid) launch_assemble(h);
     NR_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
-    if (int rc = h->eng.factor(h->stream, h->d_A)) return fail(rc, h->eng.error);
+    if (int rc = h->eng.factor(h->stream, h->d_A, h->d_F, nullptr)) return fail(rc, h->eng.error);
     jg::StateUpdate upd{h->d_va, h->d_vm, h->d_flags, nullptr, -1.0};
-    if (int rc = h->eng.solve(h->stream, h->d_F, h->d_inc, upd)) return fail(rc, h->eng.error);
+    if (int rc = h->eng.backsolve(h->stream, h->d_inc, upd, nullptr)) return fail(rc, h->eng.error);
     hipLaunchKernelGGL(k_add_iter, dim3((h->ld + 255) / 256), dim3(256), 0, h->stream, h->d_iters, h->ld);
     NR_HIP(hipGetLastError());
     NR_HIP(hipStreamSynchronize(h->stream));
@@ -646,8 +648,8 @@ int jg_nr_time_kernel(jg_nr* h, int kernel, int reps, double* mean_ms) {
     NR_HIP(hipEventRecord(e0, h->stream));
     for (int r = 0; r < reps; ++r) {
         if (kernel == 0) launch_assemble(h);
-        else if (kernel == 1) { if (int rc = h->eng.factor(h->stream, h->d_A)) return fail(rc, h->eng.error); }
-        else { if (int rc = h->eng.solve(h->stream, h->d_F, h->d_inc, none)) return fail(rc, h->eng.error); }
+        else if (kernel == 1) { if (int rc = h->eng.factor(h->stream, h->d_A, h->d_F, nullptr)) return fail(rc, h->eng.error); }
+        else { if (int rc = h->eng.backsolve(h->stream, h->d_inc, none, nullptr)) return fail(rc, h->eng.error); }
     }
     NR_HIP(hipEventRecord(e1, h->stream));
     NR_HIP(hipEventSynchronize(e1));

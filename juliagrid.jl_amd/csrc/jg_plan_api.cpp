@@ -15,7 +15,7 @@ struct jg_plan {
 namespace {
 void flatten(const jg::Schedule& s, std::vector<int>& launch) {
     launch.clear();
-    for (const jg::Launch& L : s.launches) { launch.push_back(L.task_begin); launch.push_back(L.task_end); launch.push_back(L.waves); launch.push_back(L.wpi); }
+    for (const jg::Launch& L : s.launches) { launch.push_back(L.task_begin); launch.push_back(L.task_end); launch.push_back(L.waves); launch.push_back(L.wpi); launch.push_back(L.chunk); launch.push_back(L.item_begin); launch.push_back(L.item_end); }
 }
 }  // namespace
 
@@ -33,7 +33,8 @@ void jg_plan_destroy(jg_plan* p) { delete p; }
 
 // which: 0 perm, 1 e_row, 2 e_col, 3 e_src, 4 t_ptr, 5 t_a, 6 t_b, 7 e_level, 8 e_diag, 9 diag,
 //        10 l_ptr, 11 l_ent, 12 l_col, 13 u_ptr, 14 u_ent, 15 u_col,
-//        20/30/40 + k: schedule lu/fwd/bwd: k=0 launches (begin,end,waves,wpi quadruples), 1 task_ptr, 2 step_ptr, 3 items
+//        16 t_d, 17 y_level
+//        20/40 + k: schedule fact (factorisation + fused forward elimination) / bwd: k=0 launches (task begin,end, waves, wpi, chunk, item begin,end) x7, 1 task_ptr, 2 step_ptr, 3 items
 // out == NULL returns the length.
 int64_t jg_plan_export(jg_plan* p, int which, int32_t* out, int64_t cap) {
     if (!p) return -1;
@@ -46,9 +47,9 @@ int64_t jg_plan_export(jg_plan* p, int which, int32_t* out, int64_t cap) {
         case 6: v = &S.t_b; break;    case 7: v = &S.e_level; break; case 8: v = &S.e_diag; break;
         case 9: v = &S.diag; break;   case 10: v = &S.l_ptr; break; case 11: v = &S.l_ent; break;
         case 12: v = &S.l_col; break; case 13: v = &S.u_ptr; break; case 14: v = &S.u_ent; break;
-        case 15: v = &S.u_col; break;
+        case 15: v = &S.u_col; break;  case 16: v = &S.t_d; break;  case 17: v = &S.y_level; break;
         default: {
-            const jg::Schedule* s = which >= 40 ? &S.bwd : (which >= 30 ? &S.fwd : (which >= 20 ? &S.lu : nullptr));
+            const jg::Schedule* s = which >= 40 ? &S.bwd : (which >= 20 && which < 30 ? &S.fact : nullptr);
             if (!s) return -1;
             switch (which % 10) {
                 case 0: flatten(*s, tmp); v = &tmp; break;

@@ -96,6 +96,7 @@ void schedule_by_level(const std::vector<int>& level, const std::vector<int>& wo
         L.wpi = wpi;
         L.waves = std::max(4, wpi);
         const int chunk = wpi == 1 ? 16 : L.waves / wpi;
+        L.chunk = chunk; L.item_begin = b; L.item_end = e;
         for (int s = b; s < e; s += chunk) {
             sch.step_ptr.push_back(std::min(s + chunk, e));
             sch.task_ptr.push_back((int)sch.step_ptr.size() - 1);
@@ -184,6 +185,7 @@ int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic&
     for (int e = 0; e < S.n_entries; ++e) S.t_ptr[e + 1] += S.t_ptr[e];
     S.n_terms = S.t_ptr[S.n_entries];
     S.t_a.assign((size_t)S.n_terms, 0);
+    S.t_d.assign((size_t)S.n_terms, 0);
     S.t_b.assign((size_t)S.n_terms, 0);
     {
         std::vector<int> fill(S.t_ptr.begin(), S.t_ptr.end() - 1);
@@ -196,29 +198,31 @@ int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic&
                 for (size_t b = 0; b < s.size(); ++b) {
                     int t = find_in_row(S, s[a], s[b]);
                     S.t_a[fill[t]] = lid[a];
+                    S.t_d[fill[t]] = S.diag[k];
                     S.t_b[fill[t]] = uid[b];
                     fill[t]++;
                 }
         }
     }
 
-    // entry dependency levels (pivots ascending: all sources of pivot-k entries have smaller pivots)
+    // entry dependency levels (pivots ascending: all sources of pivot-k entries have smaller pivots);
+    // D(k), U(k,.) and Lh(.,k) have no mutual dependency, so one level per pivot "generation"
     S.e_level.assign(S.n_entries, 0);
     {
         std::vector<int> acc(S.n_entries, 0);
         for (int k = 0; k < n; ++k) {
             const std::vector<int>& s = strct[k];
-            int d = S.diag[k];
+            const int d = S.diag[k];
             S.e_level[d] = acc[d] + 1;
             for (int j : s) {
-                int u = find_in_row(S, k, j), l = find_in_row(S, j, k);
+                const int u = find_in_row(S, k, j), l = find_in_row(S, j, k);
                 S.e_level[u] = acc[u] + 1;
-                S.e_level[l] = std::max(acc[l], S.e_level[d]) + 1;
+                S.e_level[l] = acc[l] + 1;
             }
             for (int i : s) {
-                int li = S.e_level[find_in_row(S, i, k)];
+                const int li = std::max(S.e_level[find_in_row(S, i, k)], S.e_level[d]);
                 for (int j : s) {
-                    int t = find_in_row(S, i, j);
+                    const int t = find_in_row(S, i, j);
                     acc[t] = std::max(acc[t], std::max(li, S.e_level[find_in_row(S, k, j)]));
                 }
             }
@@ -239,19 +243,25 @@ int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic&
             else if (c > r) { S.u_ent[up] = e; S.u_col[up++] = c; }
         }
     }
-    S.fwd_level.assign(n, 1);
+    S.y_level.assign(n, 1);
     S.bwd_level.assign(n, 1);
     for (int r = 0; r < n; ++r)
-        for (int p = S.l_ptr[r]; p < S.l_ptr[r + 1]; ++p) S.fwd_level[r] = std::max(S.fwd_level[r], S.fwd_level[S.l_col[p]] + 1);
+        for (int p = S.l_ptr[r]; p < S.l_ptr[r + 1]; ++p) {
+            const int c = S.l_col[p];
+            S.y_level[r] = std::max(S.y_level[r], 1 + std::max(S.y_level[c], std::max(S.e_level[S.l_ent[p]], S.e_level[S.diag[c]])));
+        }
     for (int r = n - 1; r >= 0; --r)
         for (int p = S.u_ptr[r]; p < S.u_ptr[r + 1]; ++p) S.bwd_level[r] = std::max(S.bwd_level[r], S.bwd_level[S.u_col[p]] + 1);
 
     {
-        std::vector<int> work(S.n_entries), lw(n), uw(n);
-        for (int e = 0; e < S.n_entries; ++e) work[e] = S.t_ptr[e + 1] - S.t_ptr[e];
-        for (int r = 0; r < n; ++r) { lw[r] = S.l_ptr[r + 1] - S.l_ptr[r]; uw[r] = S.u_ptr[r + 1] - S.u_ptr[r]; }
-        schedule_by_level(S.e_level, work, S.n_entries, S.lu);
-        schedule_by_level(S.fwd_level, lw, n, S.fwd);
+        std::vector<int> level(S.n_entries + n), work(S.n_entries + n), uw(n);
+        for (int e = 0; e < S.n_entries; ++e) { level[e] = S.e_level[e]; work[e] = S.t_ptr[e + 1] - S.t_ptr[e]; }
+        for (int r = 0; r < n; ++r) {
+            level[S.n_entries + r] = S.y_level[r];
+            work[S.n_entries + r] = S.l_ptr[r + 1] - S.l_ptr[r];
+            uw[r] = S.u_ptr[r + 1] - S.u_ptr[r];
+        }
+        schedule_by_level(level, work, S.n_entries + n, S.fact);
         schedule_by_level(S.bwd_level, uw, n, S.bwd);
     }
     return 0;

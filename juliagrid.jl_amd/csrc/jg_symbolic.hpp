@@ -21,6 +21,8 @@ struct Launch {
     int waves = 4;                      // waves per workgroup for this launch
     int wpi = 1;                        // waves cooperating on ONE item (its update terms are split across
                                         // them and reduced through LDS); wpi > 1 => single-step tasks
+    int chunk = 1;                      // items per task (the last task of a launch may hold fewer)
+    int item_begin = 0, item_end = 0;   // the launch's contiguous range in Schedule::items
 };
 
 // A schedule = launches -> tasks (one workgroup each) -> steps (barrier separated) -> items.
@@ -44,14 +46,17 @@ struct BlockSymbolic {
     std::vector<int> e_src;             // index into the caller's block CSR (original order), -1 = fill
     std::vector<int> e_diag;            // for lower entries (row>col): entry id of D(col,col); else -1
     std::vector<int> diag;              // [n] entry id of D(k,k)
-    // LU update terms: entry e accumulates  - X[t_a] * X[t_b]  for t in [t_ptr[e], t_ptr[e+1])
-    std::vector<int> t_ptr, t_a, t_b;
+    // Factorisation A = Lh * inv(D) * U with UNSCALED lower blocks Lh (so a pivot's diagonal inverse,
+    // its U row and its Lh column all become final in the same dependency level):
+    //   entry e accumulates  - X[t_a] * X[t_d] * X[t_b]   (Lh(i,k) * Dinv(k) * U(k,j))  for t in [t_ptr[e], t_ptr[e+1])
+    std::vector<int> t_ptr, t_a, t_d, t_b;
     std::vector<int> e_level;           // dependency level of each entry (1-based)
-    // Triangular solves (pivot numbering): row k of L strictly-lower, row k of U strictly-upper
-    std::vector<int> l_ptr, l_ent, l_col;   // y_k = f_k - sum L(k,c) y_c
-    std::vector<int> u_ptr, u_ent, u_col;   // x_k = Dinv_k (y_k - sum U(k,c) x_c)
-    std::vector<int> fwd_level, bwd_level;
-    Schedule lu, fwd, bwd;
+    // Row lists (pivot numbering): strictly-lower and strictly-upper entries of pivot row k
+    std::vector<int> l_ptr, l_ent, l_col;   // forward elimination fused into the factorisation:
+                                            //   y_k = f_k - sum_c Lh(k,c) Dinv(c) y_c      (item id n_entries + k)
+    std::vector<int> u_ptr, u_ent, u_col;   // x_k = Dinv_k (y_k - sum_c U(k,c) x_c)
+    std::vector<int> y_level, bwd_level;
+    Schedule fact, bwd;                 // fact items: [0,n_entries) entries, [n_entries, n_entries+n) rhs rows
     long long n_terms = 0;
 };
 

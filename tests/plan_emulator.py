@@ -10,7 +10,7 @@ import numpy as np
 
 def _walk(sch):
     """yield (launch_index, task, step, item)"""
-    for li, (t0, t1, _w, _wpi) in enumerate(sch["launches"]):
+    for li, (t0, t1, _w, _wpi, _chunk, _ib, _ie) in enumerate(sch["launches"]):
         for t in range(t0, t1):
             for s in range(sch["task_ptr"][t], sch["task_ptr"][t + 1]):
                 for idx in range(sch["step_ptr"][s], sch["step_ptr"][s + 1]):
@@ -22,57 +22,52 @@ class Replay:
         self.p = plan
         g = plan.get
         self.perm, self.e_row, self.e_col, self.e_src = g("perm"), g("e_row"), g("e_col"), g("e_src")
-        self.t_ptr, self.t_a, self.t_b, self.e_diag, self.diag = g("t_ptr"), g("t_a"), g("t_b"), g("e_diag"), g("diag")
+        self.t_ptr, self.t_a, self.t_d, self.t_b, self.diag = g("t_ptr"), g("t_a"), g("t_d"), g("t_b"), g("diag")
         self.l_ptr, self.l_ent, self.l_col = g("l_ptr"), g("l_ent"), g("l_col")
         self.u_ptr, self.u_ent, self.u_col = g("u_ptr"), g("u_ent"), g("u_col")
         self.nE = self.e_row.size
         self.n = plan.n
 
-    def _visible(self, stamp, src, li, t, s):
+    @staticmethod
+    def _visible(stamp, src, li, t, s):
         """src produced strictly before (launch li, task t, step s)?"""
         if stamp[src] is None:
             return False
         l2, t2, s2 = stamp[src]
         return l2 < li or (l2 == li and t2 == t and s2 < s)
 
-    def factor(self, A):
-        """A: [nnz_blocks, 2, 2] in the caller's CSR order. Returns X [nE,2,2] (diag = inverse)."""
-        X = np.zeros((self.nE, 2, 2))
-        stamp = [None] * self.nE
-        seen = np.zeros(self.nE, dtype=bool)
-        for li, t, s, e in _walk(self.p.schedule("lu")):
-            assert not seen[e], f"entry {e} scheduled twice"
-            seen[e] = True
-            acc = A[self.e_src[e]].copy() if self.e_src[e] >= 0 else np.zeros((2, 2))
-            for k in range(self.t_ptr[e], self.t_ptr[e + 1]):
-                a, b = self.t_a[k], self.t_b[k]
-                assert self._visible(stamp, a, li, t, s) and self._visible(stamp, b, li, t, s), "LU schedule race"
-                acc -= X[a] @ X[b]
-            r, c = self.e_row[e], self.e_col[e]
-            if r == c:
-                X[e] = np.linalg.inv(acc)
-            elif r > c:
-                d = self.diag[c]
-                assert d == self.e_diag[e] and self._visible(stamp, d, li, t, s), "LU schedule race (diag)"
-                X[e] = acc @ X[d]
+    def factor(self, A, rhs):
+        """A: [nnz_blocks,2,2] caller CSR order; rhs [n,2] original order.
+        Returns X [nE,2,2] (U, unscaled Lh, inverse diagonal) and y [n,2] (pivot order)."""
+        nE = self.nE
+        X = np.zeros((nE, 2, 2))
+        Y = np.zeros((self.n, 2))
+        stamp = [None] * (nE + self.n)          # entries, then rhs rows
+        for li, t, s, it in _walk(self.p.schedule("fact")):
+            assert stamp[it] is None, f"item {it} scheduled twice"
+            vis = lambda src: self._visible(stamp, src, li, t, s)
+            if it < nE:
+                e = it
+                acc = A[self.e_src[e]].copy() if self.e_src[e] >= 0 else np.zeros((2, 2))
+                for k in range(self.t_ptr[e], self.t_ptr[e + 1]):
+                    a, d, b = self.t_a[k], self.t_d[k], self.t_b[k]
+                    assert vis(a) and vis(d) and vis(b), "LU schedule race"
+                    acc -= X[a] @ X[d] @ X[b]
+                X[e] = np.linalg.inv(acc) if self.e_row[e] == self.e_col[e] else acc
             else:
-                X[e] = acc
-            stamp[e] = (li, t, s)
-        assert seen.all(), "entries missing from the LU schedule"
-        return X
+                k = it - nE
+                y = rhs[self.perm[k]].copy()
+                for p in range(self.l_ptr[k], self.l_ptr[k + 1]):
+                    c = self.l_col[p]
+                    assert vis(self.l_ent[p]) and vis(self.diag[c]) and vis(nE + c), "forward schedule race"
+                    y -= X[self.l_ent[p]] @ (X[self.diag[c]] @ Y[c])
+                Y[k] = y
+            stamp[it] = (li, t, s)
+        assert all(st is not None for st in stamp), "items missing from the factorisation schedule"
+        return X, Y
 
-    def solve(self, X, rhs):
-        """rhs: [n,2] original order -> x [n,2] original order."""
-        W = np.zeros((self.n, 2))
-        stamp = [None] * self.n
-        for li, t, s, k in _walk(self.p.schedule("fwd")):
-            y = rhs[self.perm[k]].copy()
-            for p in range(self.l_ptr[k], self.l_ptr[k + 1]):
-                assert self._visible(stamp, self.l_col[p], li, t, s), "fwd schedule race"
-                y -= X[self.l_ent[p]] @ W[self.l_col[p]]
-            W[k] = y
-            stamp[k] = (li, t, s)
-        assert all(st is not None for st in stamp)
+    def backsolve(self, X, Y):
+        W = Y.copy()
         stamp = [None] * self.n
         out = np.zeros((self.n, 2))
         for li, t, s, k in _walk(self.p.schedule("bwd")):

@@ -24,14 +24,14 @@ def test_schedule_replay_matches_oracle_increment(jg, oracle, name):
     rowptr, col, A = block_jacobian_from_csc(s.n, s.colptr, s.rowval, a.type, a.pq, a.pvpq, a.jcolptr, a.jrowval, J)
     plan = jg._lib.Plan(s.n, rowptr, col)
     rp = Replay(plan)
-    X = rp.factor(A)
     rhs = np.zeros((s.n, 2))
     for i in range(s.n):
         if a.pvpq[i]:
             rhs[i, 0] = f0[a.pvpq[i] - 1]
         if a.pq[i]:
             rhs[i, 1] = f0[a.pq[i] - 1]
-    x = rp.solve(X, rhs)
+    X, Y = rp.factor(A, rhs)
+    x = rp.backsolve(X, Y)
     got = np.zeros(a.dim)
     for i in range(s.n):
         if a.pvpq[i]:
@@ -57,21 +57,31 @@ def test_plan_structure_invariants(jg):
     # symmetric factor pattern
     pairs = set(zip(e_row.tolist(), e_col.tolist()))
     assert all((c, r) in pairs for r, c in pairs)
-    # every term multiplies L(i,k) by U(k,j) with k < min(i,j)
-    t_a, t_b = plan.get("t_a"), plan.get("t_b")
+    # every term multiplies Lh(i,k) * Dinv(k) * U(k,j) with k < min(i,j)
+    t_a, t_d, t_b = plan.get("t_a"), plan.get("t_d"), plan.get("t_b")
     ent = np.repeat(np.arange(e_row.size), np.diff(t_ptr))
     assert np.all(e_row[t_a] == e_row[ent]) and np.all(e_col[t_b] == e_col[ent])
     assert np.all(e_col[t_a] == e_row[t_b])
+    assert np.all(e_row[t_d] == e_col[t_a]) and np.all(e_col[t_d] == e_col[t_a])
     assert np.all(e_col[t_a] < np.minimum(e_row[ent], e_col[ent]))
     # level monotonicity: an entry is strictly above all its sources
     lev = plan.get("e_level")
-    assert np.all(lev[ent] > lev[t_a]) and np.all(lev[ent] > lev[t_b])
-    # schedules cover every item exactly once
-    for kind, nitems in (("lu", e_row.size), ("fwd", Y.n), ("bwd", Y.n)):
+    assert np.all(lev[ent] > lev[t_a]) and np.all(lev[ent] > lev[t_b]) and np.all(lev[ent] > lev[t_d])
+    # schedules cover every item exactly once; launches tile the task and item ranges; the device's
+    # flattened addressing (item_begin + task*chunk) matches the task/step lists
+    for kind, nitems in (("fact", e_row.size + Y.n), ("bwd", Y.n)):
         sch = plan.schedule(kind)
         assert sorted(sch["items"].tolist()) == list(range(nitems))
-        assert sch["launches"][0, 0] == 0 and sch["launches"][-1, 1] == sch["task_ptr"].size - 1
-        assert np.all(sch["launches"][1:, 0] == sch["launches"][:-1, 1])
+        L = sch["launches"]
+        assert L[0, 0] == 0 and L[-1, 1] == sch["task_ptr"].size - 1
+        assert np.all(L[1:, 0] == L[:-1, 1])
+        assert L[0, 5] == 0 and L[-1, 6] == nitems and np.all(L[1:, 5] == L[:-1, 6])
+        for t0, t1, waves, wpi, chunk, ib, ie in L:
+            assert waves % wpi == 0 and (wpi == 1 or chunk == waves // wpi) and chunk % (waves // wpi) == 0
+            for k, t in enumerate(range(t0, t1)):
+                s0, s1 = sch["task_ptr"][t], sch["task_ptr"][t + 1]
+                assert s1 == s0 + 1
+                assert sch["step_ptr"][s0] == ib + k * chunk and sch["step_ptr"][s1] == min(ib + (k + 1) * chunk, ie)
 
 
 def test_plan_rejects_unsymmetric_pattern(jg):
