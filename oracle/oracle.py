@@ -193,3 +193,190 @@ class OracleNR:
         status = lib().jgo_nr_power_flow(self.h, iteration, tolerance, hist.ctypes.data, C.byref(nh))
         self.history = hist[: 2 * nh.value].reshape(-1, 2)
         return int(status)
+
+
+# ----------------------------------------------------------------------------------------------
+# Gauss-Newton WLS state estimation (oracle/jg_oracle_se.c)
+# ----------------------------------------------------------------------------------------------
+def _se_lib():
+    L = lib()
+    if not hasattr(L, "_se_bound"):
+        L.jgo_exact_quantities.argtypes = [C.c_int64, C.c_int64, I64P, I64P, I8P, F64P, I64P, I64P, F64P, F64P, F64P, F64P, F64P, F64P]
+        L.jgo_gn_create.restype = C.c_void_p
+        L.jgo_gn_create.argtypes = ([C.c_int64, C.c_int64, I64P, I64P, F64P, F64P, F64P, F64P, I64P, I64P, F64P, F64P, F64P, F64P, F64P,
+                                     C.c_int64, C.c_int64, I8P, I8P, I64P, F64P, F64P, I8P, F64P, F64P, I8P, I8P, F64P, F64P])
+        L.jgo_gn_destroy.argtypes = [C.c_void_p]
+        for f in ("jgo_gn_rows", "jgo_gn_nnz", "jgo_gn_iteration"):
+            getattr(L, f).restype = C.c_int64
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.jgo_gn_objective.restype = C.c_double
+        L.jgo_gn_objective.argtypes = [C.c_void_p]
+        L.jgo_gn_get_model.argtypes = [C.c_void_p, I8P, I64P, I64P, F64P, F64P, F64P, I64P, I64P]
+        L.jgo_gn_get_vectors.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+        L.jgo_gn_set_voltage.argtypes = [C.c_void_p, F64P, F64P]
+        L.jgo_gn_set_mean.argtypes = [C.c_void_p, F64P]
+        L.jgo_gn_normal_equation.argtypes = [C.c_void_p]
+        L.jgo_gn_increment.restype = C.c_int
+        L.jgo_gn_increment.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.jgo_gn_solve.argtypes = [C.c_void_p]
+        L.jgo_gn_state_estimation.restype = C.c_int
+        L.jgo_gn_state_estimation.argtypes = [C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_void_p]
+        L._se_bound = True
+    return L
+
+
+KIND = dict(voltmeter=1, ammeter=2, wattmeter=3, varmeter=4, pmu=5)
+
+
+class MeterTable:
+    """Flat device table in the reference's concatenation order (voltmeters, ammeters, wattmeters,
+    varmeters, PMUs): what measurement(system) + add*!(monitoring, pf) hold."""
+
+    FIELDS = ("kind", "loc", "index", "mean1", "var1", "status1", "mean2", "var2", "status2", "flags")
+
+    def __init__(self):
+        self.rows = []
+
+    def add(self, kind, loc, index, mean1, var1, status1=1, mean2=0.0, var2=1.0, status2=1, square=False, polar=False,
+            correlated=False):
+        self.rows.append((KIND[kind], loc, int(index), float(mean1), float(var1), int(status1), float(mean2), float(var2),
+                          int(status2), int(square) | (int(polar) << 1) | (int(correlated) << 2)))
+
+    def arrays(self):
+        rows = sorted(self.rows, key=lambda r: r[0])          # stable: family order, insertion order inside
+        cols = list(zip(*rows)) if rows else [[] for _ in self.FIELDS]
+        dt = (np.int8, np.int8, np.int64, np.float64, np.float64, np.int8, np.float64, np.float64, np.int8, np.int8)
+        return {f: np.ascontiguousarray(c, dtype=d) for f, c, d in zip(self.FIELDS, cols, dt)}
+
+
+def exact_quantities(sys_: OracleSystem, vm, va):
+    L = _se_lib()
+    br = np.zeros(sys_.nb * 8)
+    bus = np.zeros(sys_.n * 2)
+    t = sys_.t
+    L.jgo_exact_quantities(sys_.n, sys_.nb, np.ascontiguousarray(t["br_from"], dtype=np.int64),
+                           np.ascontiguousarray(t["br_to"], dtype=np.int64), sys_.status, sys_.twoport, sys_.colptr,
+                           sys_.rowval, sys_.ytre, sys_.ytim, _f8(vm), _f8(va), br, bus)
+    return br.reshape(-1, 8), bus.reshape(-1, 2)
+
+
+def add_from_power_flow(tab: MeterTable, sys_: OracleSystem, vm, va, family, bus=True, frm=True, to=True, variance=None,
+                        **flags):
+    """add<Family>!(monitoring, pf): every bus in index order, then for each IN-SERVICE branch its from
+    end then its to end (measurement/powermeter.jl:479-523, pmu.jl:327-400), exact noise-free values."""
+    br, bq = exact_quantities(sys_, vm, va)
+    on = np.flatnonzero(sys_.status == 1)
+    var = variance if variance is not None else (1e-8 if family == "pmu" else 1e-4)
+    if family == "voltmeter":
+        for i in range(sys_.n):
+            tab.add("voltmeter", 0, i + 1, vm[i], var)
+        return
+    if family == "ammeter":
+        for k in on:
+            if frm:
+                tab.add("ammeter", 1, k + 1, br[k, 4], var, **flags)
+            if to:
+                tab.add("ammeter", 2, k + 1, br[k, 6], var, **flags)
+        return
+    if family in ("wattmeter", "varmeter"):
+        c = 0 if family == "wattmeter" else 1
+        if bus:
+            for i in range(sys_.n):
+                tab.add(family, 0, i + 1, bq[i, c], var)
+        for k in on:
+            if frm:
+                tab.add(family, 1, k + 1, br[k, c], var)
+            if to:
+                tab.add(family, 2, k + 1, br[k, 2 + c], var)
+        return
+    if family == "pmu":
+        if bus:
+            for i in range(sys_.n):
+                tab.add("pmu", 0, i + 1, vm[i], var, 1, va[i], var, 1, **flags)
+        for k in on:
+            if frm:
+                tab.add("pmu", 1, k + 1, br[k, 4], var, 1, br[k, 5], var, 1, **flags)
+            if to:
+                tab.add("pmu", 2, k + 1, br[k, 6], var, 1, br[k, 7], var, 1, **flags)
+        return
+    raise ValueError(family)
+
+
+class OracleGN:
+    """gaussNewton(monitoring) + increment!/solve!/stateEstimation! on the oracle."""
+
+    def __init__(self, sys_: OracleSystem, table, vm0=None, va0=None):
+        L = _se_lib()
+        self.sys = sys_
+        t = sys_.t
+        a = table.arrays() if isinstance(table, MeterTable) else table
+        self.table = a
+        vm0 = _f8(t["bus_vm"]) if vm0 is None else _f8(vm0)
+        va0 = _f8(t["bus_va"]) if va0 is None else _f8(va0)
+        self.h = L.jgo_gn_create(
+            sys_.n, sys_.nb, sys_.colptr, sys_.rowval, sys_.yre, sys_.yim, sys_.ytre, sys_.ytim,
+            np.ascontiguousarray(t["br_from"], dtype=np.int64), np.ascontiguousarray(t["br_to"], dtype=np.int64),
+            sys_.twoport, _f8(t["br_g"]), _f8(t["br_b"]), _f8(t["br_tap"]), _f8(t["br_shift"]), sys_.slack,
+            a["kind"].size, a["kind"], a["loc"], a["index"], a["mean1"], a["var1"], a["status1"], a["mean2"], a["var2"],
+            a["status2"], a["flags"], vm0, va0)
+        self.m = int(L.jgo_gn_rows(self.h))
+        self.nnzH = int(L.jgo_gn_nnz(self.h))
+        n = sys_.n
+        self.type = np.zeros(self.m, dtype=np.int8)
+        self.index = np.zeros(self.m, dtype=np.int64)
+        self.range = np.zeros(6, dtype=np.int64)
+        self.mean = np.zeros(self.m)
+        self.wdiag = np.zeros(self.m)
+        self.woff = np.zeros(self.m)
+        self.hcolptr = np.zeros(2 * n + 1, dtype=np.int64)
+        self.hrowval = np.zeros(self.nnzH, dtype=np.int64)
+        L.jgo_gn_get_model(self.h, self.type, self.index, self.range, self.mean, self.wdiag, self.woff, self.hcolptr, self.hrowval)
+
+    def __del__(self):
+        try:
+            _se_lib().jgo_gn_destroy(self.h)
+        except Exception:
+            pass
+
+    def precision_dense(self):
+        W = np.diag(self.wdiag)
+        for r in np.flatnonzero(self.woff):
+            W[r, r + 1] = W[r + 1, r] = self.woff[r]
+        return W
+
+    def vectors(self):
+        n = self.sys.n
+        hv, res, inc, vm, va = np.zeros(self.nnzH), np.zeros(self.m), np.zeros(2 * n), np.zeros(n), np.zeros(n)
+        _se_lib().jgo_gn_get_vectors(self.h, hv.ctypes.data, res.ctypes.data, inc.ctypes.data, vm.ctypes.data, va.ctypes.data)
+        return dict(jacobian=hv, residual=res, increment=inc, magnitude=vm, angle=va)
+
+    def set_voltage(self, vm, va):
+        _se_lib().jgo_gn_set_voltage(self.h, _f8(vm), _f8(va))
+
+    def set_mean(self, mean):
+        _se_lib().jgo_gn_set_mean(self.h, _f8(mean))
+
+    def increment(self):
+        mx = C.c_double(0.0)
+        rc = _se_lib().jgo_gn_increment(self.h, C.byref(mx))
+        if rc:
+            raise RuntimeError(f"oracle gain factorisation failure {rc}")
+        return mx.value
+
+    def solve(self):
+        _se_lib().jgo_gn_solve(self.h)
+
+    @property
+    def iteration(self):
+        return int(_se_lib().jgo_gn_iteration(self.h))
+
+    @property
+    def objective(self):
+        return float(_se_lib().jgo_gn_objective(self.h))
+
+    def state_estimation(self, iteration=40, tolerance=1e-8):
+        hist = np.zeros(iteration + 2)
+        nh = C.c_int64(0)
+        st = _se_lib().jgo_gn_state_estimation(self.h, iteration, tolerance, hist.ctypes.data, C.byref(nh))
+        self.history = hist[: nh.value]
+        return int(st)
