@@ -112,6 +112,58 @@ int jg_nr_get_iteration(jg_nr* h, int32_t* iters);
 int jg_nr_time_kernel(jg_nr* h, int kernel, int reps, double* mean_ms);
 
 /* ---------------------------------------------------------------------------------------------
+ * Gauss-Newton WLS state estimation
+ * ------------------------------------------------------------------------------------------- */
+
+/*
+ * gaussNewton(monitoring) -- src/stateEstimation/acStateEstimation.jl:43-75 over acWLS (:77-259).
+ * The caller passes what acWLS derives from the Measurement container row by row (rows ordered
+ * voltmeters, ammeters, wattmeters, varmeters, PMUs x2):
+ *   code[m]     measurement type code 1..21 (Appendix B of SURVEY.md) BEFORE status masking,
+ *   status[m]   0/1; se.type = status * code (:139, :1139, :1161, :1190-1193, :1222),
+ *   index[m]    1-based bus or branch index (se.index),
+ *   corr_row[]  1-based FIRST row of every rectangular PMU with a 2x2 precision block (:220-221).
+ * The library rebuilds the H pattern exactly as oneIndices!/twoIndices!/fourIndices!/nthIndices!
+ * (:1130-1238) + sparse() (:238) do, the block pattern of the gain matrix H'WH, the gather lists
+ * and the symbolic analysis replacing the first lu(gain) (src/backend/utility.jl:470-476).
+ *   colptr,rowval,y_reim,yt_reim,slack   as for jg_nr_create (system.model.ac)
+ *   from,to [nb]                          branch.layout.{from,to}
+ *   branch_param [nb][6]                  re(ac.admittance), im(ac.admittance), branch.parameter.conductance,
+ *                                         susceptance, turnsRatio, shiftAngle  (equations.jl:147-436)
+ */
+int jg_gn_create(jg_gn** h, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* y_reim,
+                 const double* yt_reim, int64_t nb, const int64_t* from, const int64_t* to, const double* branch_param,
+                 int64_t slack, int64_t m, const int8_t* code, const int8_t* status, const int64_t* index,
+                 int64_t n_corr, const int64_t* corr_row, int64_t batch, int device);
+void jg_gn_destroy(jg_gn* h);
+/* dims[0]=m, [1]=nnz(H), [2]=gain blocks, [3]=L+D+U blocks, [4]=LU terms, [5]=factor launches,
+ * [6]=backward launches, [7]=H slots (1x2 blocks) */
+int jg_gn_dims(jg_gn* h, int64_t* dims);
+/* se.mean [batch][m] and se.precision: diagonal [batch][m] + W[r,r+1] of every correlated pair
+ * [batch][n_corr] (acStateEstimation.jl:135-236; equations.jl:576-677).  stride 0 broadcasts. */
+int jg_gn_set_measurement(jg_gn* h, const double* mean, const double* wdiag, const double* woff,
+                          int64_t batch_stride_m, int64_t batch_stride_corr);
+int jg_gn_set_voltage(jg_gn* h, const double* vm, const double* va, int64_t batch_stride);
+int jg_gn_get_voltage(jg_gn* h, double* vm, double* va);
+/* increment!(analysis) -- acStateEstimation.jl:878-904: residual + Jacobian, gain, factor, solve.
+ * max_inc [batch] = maximum(abs, increment). */
+int jg_gn_increment(jg_gn* h, double* max_inc);
+/* solve!(analysis) -- acStateEstimation.jl:1035-1047 */
+int jg_gn_solve(jg_gn* h);
+/* stateEstimation!(analysis; iteration, tolerance) -- acStateEstimation.jl:1286-1329, per scenario.
+ * status 0 converged, 1 iteration limit, 3 singular gain. */
+int jg_gn_run(jg_gn* h, int64_t max_iter, double tol, int32_t* iters, int32_t* status);
+/* se.type and jacobian.{colptr,rowval} (m x 2n CSC, 1-based, bit-exact) */
+int jg_gn_get_maps(jg_gn* h, int8_t* type, int64_t* hcolptr, int64_t* hrowval);
+/* se.jacobian.nzval [batch][nnzH], se.residual [batch][m], se.increment [batch][2n] (theta then V) */
+int jg_gn_get_jacobian(jg_gn* h, double* nzval);
+int jg_gn_get_residual(jg_gn* h, double* residual);
+int jg_gn_get_increment(jg_gn* h, double* increment);
+int jg_gn_get_iteration(jg_gn* h, int32_t* iters);
+/* kernel: 0 measurement rows (H + residual), 1 gain + rhs gather, 2 factor (+ fused forward), 3 backward */
+int jg_gn_time_kernel(jg_gn* h, int kernel, int reps, double* mean_ms);
+
+/* ---------------------------------------------------------------------------------------------
  * Symbolic analysis only (no device needed): the static schedule that replaces the symbolic half
  * of `lu`/`klu` (src/backend/utility.jl:470-476, 486-492).  Used by the CPU test-suite to replay
  * and race-check the schedule.  pattern: 0-based int32 block CSR, structurally symmetric, full

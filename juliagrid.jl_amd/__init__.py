@@ -8,10 +8,17 @@ from .system import updateBranch_ as updateBranchSystem_                   # noq
 from .powerflow import (AcPowerFlow, newtonRaphson, mismatch_, solve_, powerFlow_, setInitialPoint_,   # noqa: F401
                         updateBranch_, setOutage_, setInjection_, outagePatch, initializeACPowerFlow)
 from .contingency import bridges, outageList, shard, contingencyAnalysis   # noqa: F401
+from .measurement import (Measurement, measurement, addVoltmeter_, addAmmeter_, addWattmeter_, addVarmeter_,   # noqa: F401
+                          addPmu_, exactQuantities)
+from .stateestimation import (AcStateEstimation, gaussNewton, increment_ as incrementSE_, solve_ as solveSE_,   # noqa: F401
+                              stateEstimation_, setNoise_)
+from . import powerflow, stateestimation   # noqa: F401
 from . import _lib                                                           # noqa: F401
 
 __all__ = [
     "PowerSystem", "CscMatrix", "powerSystem", "acModel_", "updateBranchSystem_", "AcPowerFlow", "newtonRaphson",
     "mismatch_", "solve_", "powerFlow_", "setInitialPoint_", "updateBranch_", "setOutage_", "setInjection_",
+    "Measurement", "measurement", "addVoltmeter_", "addAmmeter_", "addWattmeter_", "addVarmeter_", "addPmu_",
+    "exactQuantities", "AcStateEstimation", "gaussNewton", "incrementSE_", "solveSE_", "stateEstimation_", "setNoise_",
     "outagePatch", "initializeACPowerFlow", "bridges", "outageList", "shard", "contingencyAnalysis",
 ]

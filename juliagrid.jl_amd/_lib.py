@@ -59,6 +59,21 @@ def lib():
         "jg_nr_get_maps": [VP, I64P, I64P, I64P, I64P, I64P],
         "jg_nr_get_iteration": [VP, I32P],
         "jg_nr_time_kernel": [VP, C.c_int, C.c_int, C.POINTER(C.c_double)],
+        "jg_gn_create": [C.POINTER(VP), C.c_int64, I64P, I64P, F64P, F64P, C.c_int64, I64P, I64P, F64P, C.c_int64, C.c_int64,
+                         I8P, I8P, I64P, C.c_int64, I64P, C.c_int64, C.c_int],
+        "jg_gn_dims": [VP, I64P],
+        "jg_gn_set_measurement": [VP, F64P, F64P, F64P, C.c_int64, C.c_int64],
+        "jg_gn_set_voltage": [VP, F64P, F64P, C.c_int64],
+        "jg_gn_get_voltage": [VP, F64P, F64P],
+        "jg_gn_increment": [VP, F64P],
+        "jg_gn_solve": [VP],
+        "jg_gn_run": [VP, C.c_int64, C.c_double, I32P, I32P],
+        "jg_gn_get_maps": [VP, I8P, I64P, I64P],
+        "jg_gn_get_jacobian": [VP, F64P],
+        "jg_gn_get_residual": [VP, F64P],
+        "jg_gn_get_increment": [VP, F64P],
+        "jg_gn_get_iteration": [VP, I32P],
+        "jg_gn_time_kernel": [VP, C.c_int, C.c_int, C.POINTER(C.c_double)],
         "jg_plan_create": [C.POINTER(VP), C.c_int64, I32P, I32P, C.c_int],
     }
     for name, args in sig.items():
@@ -67,6 +82,8 @@ def lib():
         f.restype = C.c_int
     L.jg_nr_destroy.argtypes = [VP]
     L.jg_nr_destroy.restype = None
+    L.jg_gn_destroy.argtypes = [VP]
+    L.jg_gn_destroy.restype = None
     L.jg_plan_destroy.argtypes = [VP]
     L.jg_plan_destroy.restype = None
     L.jg_plan_export.argtypes = [VP, C.c_int, VP, C.c_int64]

@@ -1,6 +1,6 @@
 // jg_engine.hip -- device kernels of the batched block-sparse LU engine (gfx950, wave64).
 //
-// Factorisation A = Lh * inv(D) * U (Lh unscaled) with the forward elimination of the right-hand
+// Factorisation A = Lh * inv(D) * U (Lh unscaled, D kept as 2x2 LU factors) with the forward elimination of the right-hand
 // side fused into the same launches, then one backward sweep.  Every launch replays one dependency
 // level of the static schedule (jg_symbolic): blockDim = (64 lanes = 64 scenarios, W waves),
 // blockIdx.y = 64-scenario group.  `wpi` waves cooperate on one item: its update list is dealt out
@@ -34,14 +34,28 @@ struct Blk { double v00, v01, v10, v11; };
 
 __device__ __forceinline__ Blk load_blk(const double* p, size_t ld) { return Blk{p[0], p[ld], p[2 * ld], p[3 * ld]}; }
 
-// c -= Lh(a) * Dinv(d) * U(b)
+// Diagonal blocks are kept FACTORED, not inverted: a 2x2 LU with partial pivoting inside the block,
+//   v00 = 1/u11, v01 = u12, v10 = l (+4 when the two rows were swapped; |l| <= 1), v11 = 1/u22.
+// Applying D^-1 through this form is backward stable even when the block itself is badly conditioned
+// (gain matrices with widely spread weights reach block condition numbers ~1e9, where an explicit
+// inverse loses the solution).  y = D^-1 r:
+__device__ __forceinline__ void dsolve(const Blk& d, double r1, double r2, double& y1, double& y2) {
+    const bool sw = d.v10 > 2.0;
+    const double l = sw ? d.v10 - 4.0 : d.v10;
+    const double a = sw ? r2 : r1, b = sw ? r1 : r2;
+    y2 = (b - l * a) * d.v11;
+    y1 = (a - d.v01 * y2) * d.v00;
+}
+
+// c -= Lh(a) * D(d)^-1 * U(b)
 __device__ __forceinline__ void term3(Blk& c, const Blk& l, const Blk& d, const Blk& u) {
-    const double m00 = l.v00 * d.v00 + l.v01 * d.v10, m01 = l.v00 * d.v01 + l.v01 * d.v11;
-    const double m10 = l.v10 * d.v00 + l.v11 * d.v10, m11 = l.v10 * d.v01 + l.v11 * d.v11;
-    c.v00 -= m00 * u.v00 + m01 * u.v10;
-    c.v01 -= m00 * u.v01 + m01 * u.v11;
-    c.v10 -= m10 * u.v00 + m11 * u.v10;
-    c.v11 -= m10 * u.v01 + m11 * u.v11;
+    double z00, z10, z01, z11;
+    dsolve(d, u.v00, u.v10, z00, z10);
+    dsolve(d, u.v01, u.v11, z01, z11);
+    c.v00 -= l.v00 * z00 + l.v01 * z10;
+    c.v01 -= l.v00 * z01 + l.v01 * z11;
+    c.v10 -= l.v10 * z00 + l.v11 * z10;
+    c.v11 -= l.v10 * z01 + l.v11 * z11;
 }
 
 template <int UNROLL>
@@ -81,7 +95,8 @@ __device__ __forceinline__ void rhs_terms(const FactArgs& a, int t0, int t1, int
         }
 #pragma unroll
         for (int k = 0; k < UNROLL; ++k) {
-            const double z0 = d[k].v00 * w0[k] + d[k].v01 * w1[k], z1 = d[k].v10 * w0[k] + d[k].v11 * w1[k];
+            double z0, z1;
+            dsolve(d[k], w0[k], w1[k], z0, z1);
             y0 -= l[k].v00 * z0 + l[k].v01 * z1;
             y1 -= l[k].v10 * z0 + l[k].v11 * z1;
         }
@@ -91,7 +106,8 @@ __device__ __forceinline__ void rhs_terms(const FactArgs& a, int t0, int t1, int
         const Blk d = load_blk(a.X + (size_t)uniform(a.td[t]) * 4 * ld + b, ld);
         const double* pw = a.W + (size_t)uniform(a.tb[t]) * 2 * ld + b;
         const double w0 = pw[0], w1 = pw[ld];
-        const double z0 = d.v00 * w0 + d.v01 * w1, z1 = d.v10 * w0 + d.v11 * w1;
+        double z0, z1;
+        dsolve(d, w0, w1, z0, z1);
         y0 -= l.v00 * z0 + l.v01 * z1;
         y1 -= l.v10 * z0 + l.v11 * z1;
     }
@@ -104,11 +120,16 @@ __device__ __forceinline__ void fact_finish(const FactArgs& a, int kind, int id,
         return;
     }
     double* q = a.X + (size_t)id * 4 * ld + b;
-    if (kind == 2) {                            // diagonal block: keep the inverse
-        const double det = c.v00 * c.v11 - c.v01 * c.v10;
-        const double r = 1.0 / det;
-        if (!(fabs(det) > 0.0) || !(fabs(r) < 1.0e300)) atomicOr(a.status + b, 4);
-        q[0] = c.v11 * r; q[ld] = -c.v01 * r; q[2 * ld] = -c.v10 * r; q[3 * ld] = c.v00 * r;
+    if (kind == 2) {                            // diagonal block: 2x2 LU with in-block partial pivoting
+        const bool sw = fabs(c.v10) > fabs(c.v00);
+        const double u11 = sw ? c.v10 : c.v00, u12 = sw ? c.v11 : c.v01;
+        const double o21 = sw ? c.v00 : c.v10, o22 = sw ? c.v01 : c.v11;
+        const double iu11 = 1.0 / u11;
+        const double l = o21 * iu11;
+        const double u22 = o22 - l * u12;
+        const double iu22 = 1.0 / u22;
+        if (!(fabs(u11) > 0.0) || !(fabs(u22) > 0.0) || !(fabs(iu11) < 1.0e300) || !(fabs(iu22) < 1.0e300)) atomicOr(a.status + b, 4);
+        q[0] = iu11; q[ld] = u12; q[2 * ld] = sw ? l + 4.0 : l; q[3 * ld] = iu22;
     } else {
         q[0] = c.v00; q[ld] = c.v01; q[2 * ld] = c.v10; q[3 * ld] = c.v11;
     }
@@ -218,8 +239,8 @@ __global__ __launch_bounds__(SPLIT ? 1024 : 256) void k_bwd(BwdArgs a) {
             if (SPLIT)
                 for (int w = 1; w < wpi; ++w) { y0 += red[(size_t)(wave + w) * 128 + lane]; y1 += red[(size_t)(wave + w) * 128 + 64 + lane]; }
             const Blk d = load_blk(a.X + (size_t)dg * 4 * ld + b, ld);
-            const double x0 = d.v00 * y0 + d.v01 * y1;
-            const double x1 = d.v10 * y0 + d.v11 * y1;
+            double x0, x1;
+            dsolve(d, y0, y1, x0, x1);
             a.W[((size_t)k * 2) * ld + b] = x0;
             a.W[((size_t)k * 2 + 1) * ld + b] = x1;
             a.out[((size_t)bus * 2) * ld + b] = x0;

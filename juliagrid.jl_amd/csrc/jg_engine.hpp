@@ -16,9 +16,11 @@
 
 namespace jg {
 
+void set_last_error(const std::string& msg);   // thread-local text behind jg_last_error()
+
 // 32-byte item descriptor, fetched with one scalar load per item (schedule order).
 struct ItemDesc {
-    int kind;      // 0 upper U(k,j), 1 lower Lh(i,k) (unscaled), 2 diagonal (stores the inverse), 3 rhs row y_k
+    int kind;      // 0 upper U(k,j), 1 lower Lh(i,k) (unscaled), 2 diagonal (stores its 2x2 LU factors), 3 rhs row y_k
     int id;        // entry id, or pivot k for rhs rows / backward rows
     int src;       // block index in the caller's CSR (-1 = fill-in); original block index (bus) for rows
     int t0, t1;    // term range in (ta, td, tb)
@@ -48,7 +50,7 @@ struct Engine {
     ItemDesc* bwd_desc = nullptr;
     int* ta = nullptr; int* td = nullptr; int* tb = nullptr;   // LU terms followed by rhs-row terms
     int* u_ent = nullptr; int* u_col = nullptr;
-    double* X = nullptr;           // factor values [n_entries][4][ld]: U, unscaled Lh, inverse diagonal
+    double* X = nullptr;           // factor values [n_entries][4][ld]: U, unscaled Lh, factored diagonal blocks
     double* W = nullptr;           // [n][2][ld] pivot order: y after factor(), x after backsolve()
     int* status = nullptr;         // [ld] bit 2 set on zero / non-finite pivot
     std::vector<DevLaunch> fact, bwd;

@@ -1,0 +1,729 @@
+// jg_gn.hip -- Gauss-Newton WLS state estimation on MI355X: C ABI (include/jgrid.h), measurement
+// kernel, gain assembly by gather lists, per-scenario loop control.
+//
+// Reference behaviour restated (paths relative to /root/reference):
+//   acWLS (H pattern, index builders)   src/stateEstimation/acStateEstimation.jl:77-259, 1130-1238
+//   normalEquation!                     src/stateEstimation/acStateEstimation.jl:261-583
+//   measurement functions               src/backend/equations.jl:20-60, 147-573
+//   increment!{Normal}                  src/stateEstimation/acStateEstimation.jl:878-904
+//   solve! / stateEstimation!           src/stateEstimation/acStateEstimation.jl:1035-1047, 1286-1329
+//
+// Design (not a translation).  The reference fills H column by column with a binary-search
+// setindex! per entry and recomputes branch coefficients per entry, then forms H'WH with two
+// allocating sparse products.  Here one wave evaluates one measurement ROW for 64 scenarios: a
+// single sincos (or sincos pair) per row yields the value, the residual and every partial of that
+// row, written as 1x2 (d/dtheta, d/dV) blocks per touched bus.  The gain matrix is an n x n
+// matrix of 2x2 blocks ((theta_i, V_i) per bus) assembled by precomputed GATHER lists (every block
+// knows which (weight, slot, slot) products land in it): deterministic, no atomics, coalesced
+// 512-byte segments; its factorisation and the solve reuse the block LU engine of the NR path.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/jgrid.h"
+#include "jg_engine.hpp"
+
+namespace {
+
+int failg(int code, const std::string& msg) { jg::set_last_error(msg); return code; }
+
+#define GN_HIP(expr)                                                                    \
+    do {                                                                                \
+        hipError_t err__ = (expr);                                                      \
+        if (err__ != hipSuccess) return failg(2, std::string(#expr) + ": " + hipGetErrorString(err__)); \
+    } while (0)
+
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+struct RowDesc { int type; int idx; int slot0; int nslots; };      // idx: bus or branch (0-based)
+struct BranchP { double g, b, gs, bs, tinv, shift; int from, to; double pad; };   // 64 bytes
+
+struct RowArgs {
+    const RowDesc* rows; const int* slot_bus; const BranchP* br;
+    const int* rowptr; const double* G; const double* Bv; const int* ydiag;   // Ybus CSR (Y[i,j]) + diagonal pointers
+    const double* vm; const double* va; const double* mean;
+    double* Hs; double* res;
+    int m; int ld;
+};
+
+constexpr int GN_ROWS = 16;     // measurement rows per workgroup (4 waves x 4)
+
+// value and partials of one branch measurement; i = from, j = to (equations.jl:147-547)
+__device__ __forceinline__ void branch_row(int ty, const BranchP& p, double Vi, double Vj, double thi, double thj,
+                                           double& h, double& ti, double& vi, double& tj, double& vj) {
+    const double g = p.g, b = p.b, gs = p.gs, bs = p.bs, tv = p.tinv;
+    if (ty >= 18) {                                   // rectangular current phasors (types 18-21)
+        double si, ci, sj, cj, A, B;
+        const double C = tv * g, D = tv * b;
+        if (ty == 18 || ty == 20) {                   // psi_ij coefficients, ViVjthetaithetajState
+            A = tv * tv * (g + gs); B = tv * tv * (b + bs);
+            sincos(thi, &si, &ci); sincos(thj + p.shift, &sj, &cj);
+            if (ty == 18) { h = (A * ci - B * si) * Vi - (C * cj - D * sj) * Vj; ti = -(A * si + B * ci) * Vi; vi = A * ci - B * si; tj = (C * sj + D * cj) * Vj; vj = -C * cj + D * sj; }
+            else { h = (A * si + B * ci) * Vi - (C * sj + D * cj) * Vj; ti = (A * ci - B * si) * Vi; vi = A * si + B * ci; tj = (-C * cj + D * sj) * Vj; vj = -C * sj - D * cj; }
+        } else {                                      // psi_ji coefficients, VjVithetajthetaiState
+            A = g + gs; B = b + bs;
+            sincos(thi - p.shift, &si, &ci); sincos(thj, &sj, &cj);
+            if (ty == 19) { h = (A * cj - B * sj) * Vj - (C * ci - D * si) * Vi; ti = (C * si + D * ci) * Vi; vi = -C * ci + D * si; tj = -(A * sj + B * cj) * Vj; vj = A * cj - B * sj; }
+            else { h = (A * sj + B * cj) * Vj - (C * si + D * ci) * Vi; ti = (-C * ci + D * si) * Vi; vi = -C * si - D * ci; tj = (A * cj - B * sj) * Vj; vj = A * sj + B * cj; }
+        }
+        return;
+    }
+    double s, c;
+    sincos(thi - thj - p.shift, &s, &c);              // ViVjthetaijState
+    if (ty == 7 || ty == 8 || ty == 10 || ty == 11) {
+        const double B = tv * g, C = tv * b;
+        if (ty == 7) { const double A = tv * tv * (g + gs);
+            h = A * Vi * Vi - (B * c + C * s) * Vi * Vj; ti = (B * s - C * c) * Vi * Vj; vi = 2 * A * Vi - (B * c + C * s) * Vj; tj = -ti; vj = -(B * c + C * s) * Vi;
+        } else if (ty == 8) { const double A = g + gs;
+            h = A * Vj * Vj - (B * c - C * s) * Vi * Vj; ti = (B * s + C * c) * Vi * Vj; vi = (-B * c + C * s) * Vj; tj = -ti; vj = 2 * A * Vj - (B * c - C * s) * Vi;
+        } else if (ty == 10) { const double A = tv * tv * (b + bs);
+            h = -A * Vi * Vi - (B * s - C * c) * Vi * Vj; ti = -(B * c + C * s) * Vi * Vj; vi = -2 * A * Vi - (B * s - C * c) * Vj; tj = -ti; vj = -(B * s - C * c) * Vi;
+        } else { const double A = b + bs;
+            h = -A * Vj * Vj + (B * s + C * c) * Vi * Vj; ti = (B * c - C * s) * Vi * Vj; vi = (B * s + C * c) * Vj; tj = -ti; vj = -2 * A * Vj + (B * s + C * c) * Vi;
+        }
+        return;
+    }
+    // current magnitude / squared magnitude / angle: I_ij and I_ji coefficient sets
+    const double t2 = tv * tv;
+    double A, B, C, D, sg;                           // sg: sign of the D term inside (C cos -/+ D sin)
+    const bool fromEnd = (ty == 2 || ty == 4 || ty == 14);
+    if (fromEnd) { A = t2 * t2 * ((g + gs) * (g + gs) + (b + bs) * (b + bs)); B = t2 * (g * g + b * b); C = t2 * tv * (g * (g + gs) + b * (b + bs)); D = t2 * tv * (g * bs - b * gs); sg = -1.0; }
+    else { A = t2 * (g * g + b * b); B = (g + gs) * (g + gs) + (b + bs) * (b + bs); C = tv * (g * (g + gs) + b * (b + bs)); D = tv * (g * bs - gs * b); sg = 1.0; }
+    const double e = C * c + sg * D * s;              // (C cos - D sin) for ij, (C cos + D sin) for ji
+    const double f = C * s - sg * D * c;              // (C sin + D cos) for ij, (C sin - D cos) for ji
+    if (ty == 2 || ty == 3) {
+        const double Iinv = 1.0 / sqrt(A * Vi * Vi + B * Vj * Vj - 2 * Vi * Vj * e);
+        h = 1.0 / Iinv; ti = Iinv * f * Vi * Vj; vi = Iinv * (A * Vi - e * Vj); tj = -ti; vj = Iinv * (B * Vj - e * Vi);
+    } else if (ty == 4 || ty == 5) {
+        h = A * Vi * Vi + B * Vj * Vj - 2 * Vi * Vj * e; ti = 2 * f * Vi * Vj; vi = 2 * (A * Vi - e * Vj); tj = -ti; vj = 2 * (B * Vj - e * Vi);
+    } else {                                          // 14 psi_ij, 15 psi_ji: angle of the phasor, partials from the magnitude model
+        double si, ci, sj, cj, re, im;
+        const double Cp = tv * g, Dp = tv * b;
+        if (ty == 14) {
+            const double Ap = t2 * (g + gs), Bp = t2 * (b + bs);
+            sincos(thi, &si, &ci); sincos(thj + p.shift, &sj, &cj);
+            re = (Ap * ci - Bp * si) * Vi - (Cp * cj - Dp * sj) * Vj; im = (Ap * si + Bp * ci) * Vi - (Cp * sj + Dp * cj) * Vj;
+        } else {
+            const double Ap = g + gs, Bp = b + bs;
+            sincos(thi - p.shift, &si, &ci); sincos(thj, &sj, &cj);
+            re = (Ap * cj - Bp * sj) * Vj - (Cp * ci - Dp * si) * Vi; im = (Ap * sj + Bp * cj) * Vj - (Cp * si + Dp * ci) * Vi;
+        }
+        const double Iinv2 = 1.0 / (re * re + im * im);
+        h = atan2(im, re);
+        ti = Iinv2 * (A * Vi * Vi - e * Vi * Vj); vi = -Iinv2 * f * Vj; tj = Iinv2 * (B * Vj * Vj - e * Vi * Vj); vj = Iinv2 * f * Vi;
+    }
+}
+
+// One wave = one measurement row x 64 scenarios.
+__global__ __launch_bounds__(256) void k_gn_rows(RowArgs a) {
+    const int lane = threadIdx.x;
+    const int wave = uniform(threadIdx.y);
+    const size_t ld = (size_t)a.ld;
+    const size_t b = (size_t)blockIdx.y * 64 + lane;
+    const int r0 = blockIdx.x * GN_ROWS;
+    const int r1 = min(r0 + GN_ROWS, a.m);
+    for (int r = r0 + wave; r < r1; r += blockDim.y) {
+        const RowDesc* rd = a.rows + r;
+        const int ty = uniform(rd->type), idx = uniform(rd->idx), s0 = uniform(rd->slot0), ns = uniform(rd->nslots);
+        double* hs = a.Hs + (size_t)s0 * 2 * ld + b;
+        if (ty == 0) {                                 // masked: row kept, H = 0, residual 0 (T7)
+            for (int s = 0; s < ns; ++s) { hs[(size_t)s * 2 * ld] = 0.0; hs[((size_t)s * 2 + 1) * ld] = 0.0; }
+            a.res[(size_t)r * ld + b] = 0.0;
+            continue;
+        }
+        const double z = a.mean[(size_t)r * ld + b];
+        if (ty == 1 || ty == 12 || ty == 13 || ty == 16 || ty == 17) {
+            const double V = a.vm[(size_t)idx * ld + b], th = a.va[(size_t)idx * ld + b];
+            double h, dt, dv;
+            if (ty == 13) { h = th; dt = 1.0; dv = 0.0; }
+            else if (ty == 16) { double s, c; sincos(th, &s, &c); h = V * c; dt = -V * s; dv = c; }
+            else if (ty == 17) { double s, c; sincos(th, &s, &c); h = V * s; dt = V * c; dv = s; }
+            else { h = V; dt = 0.0; dv = 1.0; }
+            hs[0] = dt; hs[ld] = dv;
+            a.res[(size_t)r * ld + b] = z - h;
+        } else if (ty == 6 || ty == 9) {               // injections: slots follow the Ybus row of the bus
+            const int i = idx;
+            const double Vi = a.vm[(size_t)i * ld + b], thi = a.va[(size_t)i * ld + b];
+            const int p0 = uniform(a.rowptr[i]);
+            const int pd = uniform(a.ydiag[i]);
+            double s1 = 0.0, s2 = 0.0;
+            for (int s = 0; s < ns; ++s) {
+                const int p = p0 + s;
+                const int j = uniform(a.slot_bus[s0 + s]);
+                const double g = a.G[p], bb = a.Bv[p];
+                const double Vj = a.vm[(size_t)j * ld + b], thj = a.va[(size_t)j * ld + b];
+                double sn, cs;
+                sincos(thi - thj, &sn, &cs);
+                const double ac = g * cs + bb * sn, ad = g * sn - bb * cs;
+                s1 += Vj * ac; s2 += Vj * ad;
+                if (p != pd) {
+                    if (ty == 6) { hs[(size_t)s * 2 * ld] = Vi * Vj * ad; hs[((size_t)s * 2 + 1) * ld] = Vi * ac; }
+                    else { hs[(size_t)s * 2 * ld] = -(Vi * Vj) * ac; hs[((size_t)s * 2 + 1) * ld] = Vi * ad; }
+                }
+            }
+            const double gii = a.G[pd], bii = a.Bv[pd];
+            const int sd = pd - p0;
+            if (ty == 6) { hs[(size_t)sd * 2 * ld] = -Vi * s2 - bii * (Vi * Vi); hs[((size_t)sd * 2 + 1) * ld] = s1 + gii * Vi; a.res[(size_t)r * ld + b] = z - Vi * s1; }
+            else { hs[(size_t)sd * 2 * ld] = Vi * s1 - gii * (Vi * Vi); hs[((size_t)sd * 2 + 1) * ld] = s2 - bii * Vi; a.res[(size_t)r * ld + b] = z - Vi * s2; }
+        } else {                                       // branch rows: slots = [from, to]
+            BranchP p = a.br[idx];
+            const int i = uniform(p.from), j = uniform(p.to);
+            const double Vi = a.vm[(size_t)i * ld + b], thi = a.va[(size_t)i * ld + b];
+            const double Vj = a.vm[(size_t)j * ld + b], thj = a.va[(size_t)j * ld + b];
+            double h, ti, vi, tj, vj;
+            branch_row(ty, p, Vi, Vj, thi, thj, h, ti, vi, tj, vj);
+            hs[0] = ti; hs[ld] = vi; hs[2 * ld] = tj; hs[3 * ld] = vj;
+            a.res[(size_t)r * ld + b] = z - h;
+        }
+    }
+}
+
+struct GainItem { int kind; int id; int c0; int c1; };   // kind 0: gain block id (CSR order), 1: rhs row (bus)
+struct GainArgs {
+    const GainItem* items; const int* cw; const int* ca; const int* cb;   // contribution: weight idx, slot, slot | row
+    const int* blk_row; const int* blk_col;
+    const double* Hs; const double* res; const double* w;
+    double* Gv; double* rhs;
+    int n_items; int slack; int ld;
+};
+
+// G(i,j) = sum w * Hs[a]^T Hs[b]   (2x2 outer products);  rhs(i) = sum w * Hs[a]^T res[row]
+__global__ __launch_bounds__(256) void k_gn_gain(GainArgs a) {
+    const int lane = threadIdx.x;
+    const int wave = uniform(threadIdx.y);
+    const size_t ld = (size_t)a.ld;
+    const size_t b = (size_t)blockIdx.y * 64 + lane;
+    for (int it = (blockIdx.x * blockDim.y + wave) * 4, e = min(it + 4, a.n_items); it < e; ++it) {
+        const GainItem* gi = a.items + it;
+        const int kind = uniform(gi->kind), id = uniform(gi->id), c0 = uniform(gi->c0), c1 = uniform(gi->c1);
+        if (kind == 0) {
+            double g00 = 0.0, g01 = 0.0, g10 = 0.0, g11 = 0.0;
+            for (int c = c0; c < c1; ++c) {
+                const double w = a.w[(size_t)uniform(a.cw[c]) * ld + b];
+                const double* pa = a.Hs + (size_t)uniform(a.ca[c]) * 2 * ld + b;
+                const double* pb = a.Hs + (size_t)uniform(a.cb[c]) * 2 * ld + b;
+                const double at = w * pa[0], av = w * pa[ld], bt = pb[0], bv = pb[ld];
+                g00 += at * bt; g01 += at * bv; g10 += av * bt; g11 += av * bv;
+            }
+            const int i = uniform(a.blk_row[id]), j = uniform(a.blk_col[id]);
+            if (i == a.slack) { g00 = 0.0; g01 = 0.0; }          // removeColumn(H, slack) on both sides (:885)
+            if (j == a.slack) { g00 = 0.0; g10 = 0.0; }
+            if (i == a.slack && j == a.slack) g00 = 1.0;         // gain[slack, slack] = 1 (:889)
+            double* q = a.Gv + (size_t)id * 4 * ld + b;
+            q[0] = g00; q[ld] = g01; q[2 * ld] = g10; q[3 * ld] = g11;
+        } else {
+            double r0 = 0.0, r1 = 0.0;
+            for (int c = c0; c < c1; ++c) {
+                const double w = a.w[(size_t)uniform(a.cw[c]) * ld + b];
+                const double* pa = a.Hs + (size_t)uniform(a.ca[c]) * 2 * ld + b;
+                const double rr = w * a.res[(size_t)uniform(a.cb[c]) * ld + b];
+                r0 += pa[0] * rr; r1 += pa[ld] * rr;
+            }
+            if (id == a.slack) r0 = 0.0;
+            a.rhs[((size_t)id * 2) * ld + b] = r0;
+            a.rhs[((size_t)id * 2 + 1) * ld + b] = r1;
+        }
+    }
+}
+
+constexpr int NORM_ROWS = 64;
+
+// max |increment| per scenario (partial per bus chunk); forces increment[slack theta] = 0 (:899)
+__global__ __launch_bounds__(256) void k_gn_norm(double* inc, double* part, int n, int slack, int ld) {
+    __shared__ double red[4][64];
+    const int lane = threadIdx.x, wave = threadIdx.y;
+    const size_t b = (size_t)blockIdx.y * 64 + lane;
+    const int r0 = blockIdx.x * NORM_ROWS, r1 = min(r0 + NORM_ROWS, n);
+    double mx = 0.0;
+    for (int i = r0 + wave; i < r1; i += 4) {
+        double t = inc[((size_t)i * 2) * ld + b];
+        const double v = inc[((size_t)i * 2 + 1) * ld + b];
+        if (i == slack) { t = 0.0; inc[((size_t)i * 2) * ld + b] = 0.0; }
+        const double at = fabs(t), av = fabs(v);
+        mx = (at > mx || at != at) ? at : mx;
+        mx = (av > mx || av != av) ? av : mx;
+    }
+    red[wave][lane] = mx;
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 1; w < 4; ++w) { const double x = red[w][lane]; mx = (x > mx || x != x) ? x : mx; }
+        part[(size_t)blockIdx.x * ld + b] = mx;
+    }
+}
+
+struct GnCheckArgs {
+    const double* part; int nchunk; int ld; int batch; const double* params;
+    double* maxinc; int* active; int* iters; int* status; const int* lu_status; int* counter; int* group; int mode;
+};
+
+__global__ void k_gn_check(GnCheckArgs a) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.ld) return;
+    double mx = 0.0;
+    for (int c = 0; c < a.nchunk; ++c) { const double x = a.part[(size_t)c * a.ld + b]; mx = (x > mx || x != x) ? x : mx; }
+    a.maxinc[b] = mx;
+    if (a.mode == 0) return;
+    const double tol = a.params[0];
+    const int maxit = (int)a.params[1];
+    const bool conv = mx < tol;                                   // acStateEstimation.jl:1307
+    const bool bad = (a.lu_status[b] & 4) || mx != mx;
+    const bool act = b < a.batch && !conv && !bad && a.iters[b] < maxit;   // :1311
+    a.active[b] = act ? 1 : 0;
+    a.status[b] = conv ? 0 : (bad ? 3 : 1);
+    if (act) { a.iters[b] += 1; atomicAdd(a.counter, 1); atomicOr(a.group + (b >> 6), 1); }
+}
+
+// solve!: theta += inc[1:n], V += inc[n+1:2n] on active scenarios (:1040-1043)
+__global__ __launch_bounds__(256) void k_gn_update(const double* inc, double* vm, double* va, const int* active, int n, int ld) {
+    const int lane = threadIdx.x, wave = threadIdx.y;
+    const size_t b = (size_t)blockIdx.y * 64 + lane;
+    if (active && !active[b]) return;
+    const int r0 = blockIdx.x * NORM_ROWS, r1 = min(r0 + NORM_ROWS, n);
+    for (int i = r0 + wave; i < r1; i += 4) {
+        va[(size_t)i * ld + b] += inc[((size_t)i * 2) * ld + b];
+        vm[(size_t)i * ld + b] += inc[((size_t)i * 2 + 1) * ld + b];
+    }
+}
+
+__global__ void k_gn_add_iter(int* iters, int n) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < n) iters[b] += 1;
+}
+
+}  // namespace
+
+struct jg_gn {
+    int n = 0, nnzY = 0, nb = 0, m = 0, batch = 0, ld = 0, device = 0, slack0 = 0, nslots = 0, ncorr = 0, nchunk = 0;
+    int64_t nnzH = 0;
+    std::vector<int64_t> hcolptr, hrowval;      // reference CSC pattern of H (1-based)
+    std::vector<int64_t> hmap;                  // CSC nz -> slot*2 + comp
+    std::vector<int> gi_rowptr, gi_col;         // gain block CSR
+    std::vector<int8_t> type;
+    std::vector<int> corr_row;
+    int n_items = 0;
+    // device
+    RowDesc* d_rows = nullptr; int* d_slot_bus = nullptr; BranchP* d_br = nullptr;
+    int* d_rowptr = nullptr; double* d_G = nullptr; double* d_B = nullptr; int* d_ydiag = nullptr;
+    double* d_vm = nullptr; double* d_va = nullptr; double* d_mean = nullptr; double* d_w = nullptr;
+    double* d_Hs = nullptr; double* d_res = nullptr; double* d_Gv = nullptr; double* d_rhs = nullptr; double* d_inc = nullptr;
+    GainItem* d_items = nullptr; int* d_cw = nullptr; int* d_ca = nullptr; int* d_cb = nullptr; int* d_blk_row = nullptr; int* d_blk_col = nullptr;
+    double* d_part = nullptr; double* d_maxinc = nullptr; double* d_params = nullptr;
+    int* d_active = nullptr; int* d_iters = nullptr; int* d_status = nullptr; int* d_counter = nullptr; int* d_group = nullptr;
+    jg::Engine eng;
+    hipStream_t stream = nullptr;
+    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+    int* h_counter = nullptr;
+};
+
+namespace {
+
+int set_device(jg_gn* h) { GN_HIP(hipSetDevice(h->device)); return 0; }
+
+void launch_rows(jg_gn* h) {
+    RowArgs a{h->d_rows, h->d_slot_bus, h->d_br, h->d_rowptr, h->d_G, h->d_B, h->d_ydiag, h->d_vm, h->d_va, h->d_mean,
+              h->d_Hs, h->d_res, h->m, h->ld};
+    hipLaunchKernelGGL(k_gn_rows, dim3((h->m + GN_ROWS - 1) / GN_ROWS, h->ld / 64), dim3(64, 4), 0, h->stream, a);
+}
+
+void launch_gain(jg_gn* h) {
+    GainArgs a{h->d_items, h->d_cw, h->d_ca, h->d_cb, h->d_blk_row, h->d_blk_col, h->d_Hs, h->d_res, h->d_w, h->d_Gv, h->d_rhs,
+               h->n_items, h->slack0, h->ld};
+    hipLaunchKernelGGL(k_gn_gain, dim3((h->n_items + 15) / 16, h->ld / 64), dim3(64, 4), 0, h->stream, a);
+}
+
+int launch_increment(jg_gn* h, const int* group) {
+    launch_rows(h);
+    launch_gain(h);
+    if (int rc = h->eng.factor(h->stream, h->d_Gv, h->d_rhs, group)) return failg(rc, h->eng.error);
+    jg::StateUpdate none{};
+    if (int rc = h->eng.backsolve(h->stream, h->d_inc, none, group)) return failg(rc, h->eng.error);
+    hipLaunchKernelGGL(k_gn_norm, dim3(h->nchunk, h->ld / 64), dim3(64, 4), 0, h->stream, h->d_inc, h->d_part, h->n, h->slack0, h->ld);
+    return 0;
+}
+
+void launch_check(jg_gn* h, int mode) {
+    GnCheckArgs c{h->d_part, h->nchunk, h->ld, h->batch, h->d_params, h->d_maxinc, h->d_active, h->d_iters, h->d_status,
+                  h->eng.status, h->d_counter, h->d_group, mode};
+    hipLaunchKernelGGL(k_gn_check, dim3((h->ld + 255) / 256), dim3(256), 0, h->stream, c);
+}
+
+void launch_update(jg_gn* h, const int* active) {
+    hipLaunchKernelGGL(k_gn_update, dim3(h->nchunk, h->ld / 64), dim3(64, 4), 0, h->stream, h->d_inc, h->d_vm, h->d_va, active, h->n, h->ld);
+}
+
+int put_rows(jg_gn* h, double* dst, const double* src, int64_t stride, int rows) {
+    std::vector<double> t((size_t)rows * h->ld, 0.0);
+    for (int b = 0; b < h->ld; ++b) {
+        const double* s = src + (size_t)(b < h->batch ? b : h->batch - 1) * (size_t)stride;
+        for (int i = 0; i < rows; ++i) t[(size_t)i * h->ld + b] = s[i];
+    }
+    GN_HIP(hipMemcpy(dst, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int get_rows(jg_gn* h, const double* src, double* dst, size_t rows) {
+    std::vector<double> t(rows * h->ld);
+    GN_HIP(hipMemcpy(t.data(), src, t.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int b = 0; b < h->batch; ++b)
+        for (size_t r = 0; r < rows; ++r) dst[(size_t)b * rows + r] = t[r * h->ld + b];
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int jg_gn_create(jg_gn** out, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* y_reim,
+                 const double* yt_reim, int64_t nb, const int64_t* from, const int64_t* to, const double* branch_param,
+                 int64_t slack, int64_t m, const int8_t* code, const int8_t* status, const int64_t* index,
+                 int64_t n_corr, const int64_t* corr_row, int64_t batch, int device) {
+    if (!out || n < 1 || !colptr || !rowval || !y_reim || !yt_reim || nb < 0 || m < 1 || !code || !status || !index ||
+        batch < 1 || slack < 1 || slack > n || n_corr < 0 || (n_corr > 0 && !corr_row) || (nb > 0 && (!from || !to || !branch_param)))
+        return failg(1, "jg_gn_create: bad argument");
+    int ndev = 0;
+    GN_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return failg(1, "jg_gn_create: no such HIP device");
+    jg_gn* h = new jg_gn();
+    h->n = (int)n; h->nb = (int)nb; h->m = (int)m; h->batch = (int)batch; h->ld = (int)((batch + 63) / 64 * 64);
+    h->device = device; h->slack0 = (int)slack - 1; h->ncorr = (int)n_corr;
+    h->nnzY = (int)(colptr[n] - 1);
+    const int nnzY = h->nnzY;
+    // Ybus CSR rows (= transposed CSC, symmetric pattern) and diagonal pointers
+    std::vector<int> rp(n + 1), cl(nnzY), ydiag(n, -1);
+    std::vector<double> G(nnzY), B(nnzY);
+    for (int i = 0; i <= n; ++i) rp[i] = (int)(colptr[i] - 1);
+    for (int p = 0; p < nnzY; ++p) { cl[p] = (int)(rowval[p] - 1); G[p] = yt_reim[2 * p]; B[p] = yt_reim[2 * p + 1]; }
+    for (int i = 0; i < n; ++i)
+        for (int p = rp[i]; p < rp[i + 1]; ++p) if (cl[p] == i) ydiag[i] = p;
+    for (int i = 0; i < n; ++i) if (ydiag[i] < 0) { delete h; return failg(1, "jg_gn_create: Ybus diagonal missing"); }
+    (void)y_reim;
+    // ---- rows, slots and the reference's H pattern (acWLS + index builders, :135-238, :1130-1238) ----
+    std::vector<RowDesc> rows(m);
+    std::vector<int> slot_bus;
+    h->type.assign(m, 0);
+    struct Trip { int64_t row, col; int slotcomp; };
+    std::vector<Trip> trips;
+    for (int64_t r = 0; r < m; ++r) {
+        const int cd = code[r];
+        const int st = status[r];
+        if (st != 0 && st != 1) { delete h; return failg(1, "jg_gn_create: status must be 0 or 1"); }
+        const int64_t k = index[r] - 1;
+        RowDesc d{(int)(st * cd), (int)k, (int)slot_bus.size(), 0};
+        h->type[r] = (int8_t)(st * cd);
+        const int s0 = (int)slot_bus.size();
+        if (cd == 1 || cd == 12 || cd == 13 || cd == 16 || cd == 17) {
+            if (k < 0 || k >= n) { delete h; return failg(1, "jg_gn_create: bus index out of range"); }
+            slot_bus.push_back((int)k);
+            if (cd == 13) trips.push_back({r, k, s0 * 2});                       // oneIndices!(..., col = k)
+            else if (cd == 1 || cd == 12) trips.push_back({r, k + n, s0 * 2 + 1}); // oneIndices!(..., col = k + n)
+            else { trips.push_back({r, k, s0 * 2}); trips.push_back({r, k + n, s0 * 2 + 1}); }   // twoIndices!
+        } else if (cd == 6 || cd == 9) {                                         // nthIndices!
+            if (k < 0 || k >= n) { delete h; return failg(1, "jg_gn_create: bus index out of range"); }
+            for (int p = rp[k]; p < rp[k + 1]; ++p) {
+                const int s = (int)slot_bus.size();
+                slot_bus.push_back(cl[p]);
+                trips.push_back({r, (int64_t)cl[p], s * 2}); trips.push_back({r, (int64_t)cl[p] + n, s * 2 + 1});
+            }
+        } else if ((cd >= 2 && cd <= 5) || cd == 7 || cd == 8 || cd == 10 || cd == 11 || cd == 14 || cd == 15 || (cd >= 18 && cd <= 21)) {
+            if (k < 0 || k >= nb) { delete h; return failg(1, "jg_gn_create: branch index out of range"); }   // fourIndices!
+            const int64_t f = from[k] - 1, t = to[k] - 1;
+            slot_bus.push_back((int)f); slot_bus.push_back((int)t);
+            trips.push_back({r, f, s0 * 2}); trips.push_back({r, t, (s0 + 1) * 2});
+            trips.push_back({r, f + n, s0 * 2 + 1}); trips.push_back({r, t + n, (s0 + 1) * 2 + 1});
+        } else { delete h; return failg(1, "jg_gn_create: unknown measurement type code"); }
+        d.nslots = (int)slot_bus.size() - s0;
+        rows[r] = d;
+    }
+    h->nslots = (int)slot_bus.size();
+    // sparse(row, col, val, m, 2n): CSC, rows ascending inside a column (rows are generated ascending)
+    h->hcolptr.assign(2 * n + 1, 0);
+    for (const Trip& t : trips) h->hcolptr[t.col + 1]++;
+    h->hcolptr[0] = 1;
+    for (int64_t c = 0; c < 2 * n; ++c) h->hcolptr[c + 1] += h->hcolptr[c];
+    h->nnzH = h->hcolptr[2 * n] - 1;
+    h->hrowval.assign(h->nnzH, 0); h->hmap.assign(h->nnzH, 0);
+    {
+        std::vector<int64_t> fill(h->hcolptr.begin(), h->hcolptr.end() - 1);
+        for (const Trip& t : trips) { const int64_t p = fill[t.col]++ - 1; h->hrowval[p] = t.row + 1; h->hmap[p] = t.slotcomp; }
+        for (int64_t c = 0; c < 2 * n; ++c)
+            for (int64_t p = h->hcolptr[c]; p < h->hcolptr[c + 1] - 1; ++p)
+                if (h->hrowval[p] <= h->hrowval[p - 1]) { delete h; return failg(1, "jg_gn_create: duplicate H entry"); }
+    }
+    // ---- gain pattern and gather lists -------------------------------------------------------------
+    h->corr_row.assign(n_corr, 0);
+    std::vector<int> pair_of(m, -1);
+    for (int64_t q = 0; q < n_corr; ++q) {
+        const int64_t r = corr_row[q] - 1;
+        if (r < 0 || r + 1 >= m) { delete h; return failg(1, "jg_gn_create: correlated pair out of range"); }
+        h->corr_row[q] = (int)r; pair_of[r] = (int)q;
+    }
+    struct Contrib { int w, a, b; };
+    std::map<std::pair<int, int>, std::vector<Contrib>> gmap;
+    std::vector<std::vector<Contrib>> rmap(n);
+    for (int i = 0; i < n; ++i) gmap[{i, i}];                                    // full diagonal for the engine
+    for (int r = 0; r < m; ++r) {
+        const RowDesc& d = rows[r];
+        for (int a = 0; a < d.nslots; ++a) {
+            for (int b2 = 0; b2 < d.nslots; ++b2) gmap[{slot_bus[d.slot0 + a], slot_bus[d.slot0 + b2]}].push_back({r, d.slot0 + a, d.slot0 + b2});
+            rmap[slot_bus[d.slot0 + a]].push_back({r, d.slot0 + a, r});
+        }
+        if (pair_of[r] >= 0) {                                                    // 2x2 precision block of a correlated PMU
+            const RowDesc& e = rows[r + 1];
+            const int wq = (int)m + pair_of[r];
+            for (int a = 0; a < d.nslots; ++a)
+                for (int b2 = 0; b2 < e.nslots; ++b2) {
+                    gmap[{slot_bus[d.slot0 + a], slot_bus[e.slot0 + b2]}].push_back({wq, d.slot0 + a, e.slot0 + b2});
+                    gmap[{slot_bus[e.slot0 + b2], slot_bus[d.slot0 + a]}].push_back({wq, e.slot0 + b2, d.slot0 + a});
+                }
+            for (int a = 0; a < d.nslots; ++a) rmap[slot_bus[d.slot0 + a]].push_back({wq, d.slot0 + a, r + 1});
+            for (int b2 = 0; b2 < e.nslots; ++b2) rmap[slot_bus[e.slot0 + b2]].push_back({wq, e.slot0 + b2, r});
+        }
+    }
+    std::vector<GainItem> items;
+    std::vector<int> cw, ca, cb, blk_row, blk_col;
+    h->gi_rowptr.assign(n + 1, 0);
+    for (const auto& kv : gmap) {
+        const int id = (int)blk_row.size();
+        blk_row.push_back(kv.first.first); blk_col.push_back(kv.first.second);
+        h->gi_rowptr[kv.first.first + 1]++;
+        h->gi_col.push_back(kv.first.second);
+        GainItem it{0, id, (int)cw.size(), 0};
+        for (const Contrib& c : kv.second) { cw.push_back(c.w); ca.push_back(c.a); cb.push_back(c.b); }
+        it.c1 = (int)cw.size();
+        items.push_back(it);
+    }
+    for (int i = 0; i < n; ++i) h->gi_rowptr[i + 1] += h->gi_rowptr[i];
+    for (int i = 0; i < n; ++i) {
+        GainItem it{1, i, (int)cw.size(), 0};
+        for (const Contrib& c : rmap[i]) { cw.push_back(c.w); ca.push_back(c.a); cb.push_back(c.b); }
+        it.c1 = (int)cw.size();
+        items.push_back(it);
+    }
+    // heavy gather lists first (they start first on the device)
+    std::stable_sort(items.begin(), items.end(), [](const GainItem& x, const GainItem& y) { return (x.c1 - x.c0) > (y.c1 - y.c0); });
+    h->n_items = (int)items.size();
+    // branch parameters
+    std::vector<BranchP> br(std::max<int64_t>(nb, 1));
+    for (int64_t k = 0; k < nb; ++k) {
+        const double* p = branch_param + 6 * k;
+        br[k] = BranchP{p[0], p[1], 0.5 * p[2], 0.5 * p[3], 1.0 / p[4], p[5], (int)(from[k] - 1), (int)(to[k] - 1), 0.0};
+    }
+    // ---- device -------------------------------------------------------------------------------------
+    int rc = set_device(h);
+    if (rc) { delete h; return rc; }
+    std::string err;
+    if (jg::upload(&h->d_rows, rows, err) || jg::upload(&h->d_slot_bus, slot_bus, err) || jg::upload(&h->d_br, br, err) ||
+        jg::upload(&h->d_rowptr, rp, err) || jg::upload(&h->d_G, G, err) || jg::upload(&h->d_B, B, err) || jg::upload(&h->d_ydiag, ydiag, err) ||
+        jg::upload(&h->d_items, items, err) || jg::upload(&h->d_cw, cw, err) || jg::upload(&h->d_ca, ca, err) || jg::upload(&h->d_cb, cb, err) ||
+        jg::upload(&h->d_blk_row, blk_row, err) || jg::upload(&h->d_blk_col, blk_col, err)) {
+        jg_gn_destroy(h); return failg(2, err);
+    }
+    const size_t ld = h->ld;
+    h->nchunk = (h->n + NORM_ROWS - 1) / NORM_ROWS;
+    auto dmalloc = [&](void** p, size_t bytes) -> bool { return hipMalloc(p, bytes) == hipSuccess && hipMemset(*p, 0, bytes) == hipSuccess; };
+    const size_t nw = (size_t)m + (size_t)std::max<int64_t>(n_corr, 0);
+    bool ok = dmalloc((void**)&h->d_vm, n * ld * 8) && dmalloc((void**)&h->d_va, n * ld * 8) && dmalloc((void**)&h->d_mean, (size_t)m * ld * 8) &&
+              dmalloc((void**)&h->d_w, nw * ld * 8) && dmalloc((void**)&h->d_Hs, (size_t)h->nslots * 2 * ld * 8) &&
+              dmalloc((void**)&h->d_res, (size_t)m * ld * 8) && dmalloc((void**)&h->d_Gv, blk_row.size() * 4 * ld * 8) &&
+              dmalloc((void**)&h->d_rhs, n * 2 * ld * 8) && dmalloc((void**)&h->d_inc, n * 2 * ld * 8) &&
+              dmalloc((void**)&h->d_part, (size_t)h->nchunk * ld * 8) && dmalloc((void**)&h->d_maxinc, ld * 8) &&
+              dmalloc((void**)&h->d_params, 16) && dmalloc((void**)&h->d_active, ld * 4) && dmalloc((void**)&h->d_iters, ld * 4) &&
+              dmalloc((void**)&h->d_status, ld * 4) && dmalloc((void**)&h->d_counter, 4) && dmalloc((void**)&h->d_group, (ld / 64) * 4);
+    if (!ok || hipHostMalloc((void**)&h->h_counter, sizeof(int)) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        jg_gn_destroy(h); return failg(2, "jg_gn_create: device allocation failed");
+    }
+    rc = h->eng.create((int)n, h->gi_rowptr.data(), h->gi_col.data(), h->ld, 0);
+    if (rc) { std::string msg = h->eng.error; jg_gn_destroy(h); return failg(rc, msg); }
+    *out = h;
+    return 0;
+}
+
+void jg_gn_destroy(jg_gn* h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->exec) hipGraphExecDestroy(h->exec);
+    if (h->graph) hipGraphDestroy(h->graph);
+    h->eng.destroy();
+    hipFree(h->d_rows); hipFree(h->d_slot_bus); hipFree(h->d_br); hipFree(h->d_rowptr); hipFree(h->d_G); hipFree(h->d_B); hipFree(h->d_ydiag);
+    hipFree(h->d_vm); hipFree(h->d_va); hipFree(h->d_mean); hipFree(h->d_w); hipFree(h->d_Hs); hipFree(h->d_res); hipFree(h->d_Gv);
+    hipFree(h->d_rhs); hipFree(h->d_inc); hipFree(h->d_items); hipFree(h->d_cw); hipFree(h->d_ca); hipFree(h->d_cb); hipFree(h->d_blk_row);
+    hipFree(h->d_blk_col); hipFree(h->d_part); hipFree(h->d_maxinc); hipFree(h->d_params); hipFree(h->d_active); hipFree(h->d_iters);
+    hipFree(h->d_status); hipFree(h->d_counter); hipFree(h->d_group);
+    if (h->h_counter) hipHostFree(h->h_counter);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int jg_gn_dims(jg_gn* h, int64_t* dims) {
+    if (!h || !dims) return failg(1, "jg_gn_dims: bad argument");
+    dims[0] = h->m; dims[1] = h->nnzH; dims[2] = (int64_t)h->gi_col.size(); dims[3] = h->eng.S.n_entries;
+    dims[4] = h->eng.S.n_terms; dims[5] = (int64_t)h->eng.S.fact.launches.size(); dims[6] = (int64_t)h->eng.S.bwd.launches.size();
+    dims[7] = h->nslots;
+    return 0;
+}
+
+int jg_gn_set_measurement(jg_gn* h, const double* mean, const double* wdiag, const double* woff, int64_t batch_stride_m,
+                          int64_t batch_stride_corr) {
+    if (!h || !mean || !wdiag || (h->ncorr > 0 && !woff)) return failg(1, "jg_gn_set_measurement: bad argument");
+    if (int rc = set_device(h)) return rc;
+    GN_HIP(hipStreamSynchronize(h->stream));
+    if (int rc = put_rows(h, h->d_mean, mean, batch_stride_m, h->m)) return rc;
+    if (int rc = put_rows(h, h->d_w, wdiag, batch_stride_m, h->m)) return rc;
+    if (h->ncorr > 0)
+        if (int rc = put_rows(h, h->d_w + (size_t)h->m * h->ld, woff, batch_stride_corr, h->ncorr)) return rc;
+    return 0;
+}
+
+int jg_gn_set_voltage(jg_gn* h, const double* vm, const double* va, int64_t stride) {
+    if (!h || !vm || !va) return failg(1, "jg_gn_set_voltage: bad argument");
+    if (int rc = set_device(h)) return rc;
+    GN_HIP(hipStreamSynchronize(h->stream));
+    if (int rc = put_rows(h, h->d_vm, vm, stride, h->n)) return rc;
+    return put_rows(h, h->d_va, va, stride, h->n);
+}
+
+int jg_gn_get_voltage(jg_gn* h, double* vm, double* va) {
+    if (!h || !vm || !va) return failg(1, "jg_gn_get_voltage: bad argument");
+    if (int rc = set_device(h)) return rc;
+    GN_HIP(hipStreamSynchronize(h->stream));
+    if (int rc = get_rows(h, h->d_vm, vm, h->n)) return rc;
+    return get_rows(h, h->d_va, va, h->n);
+}
+
+int jg_gn_increment(jg_gn* h, double* maxinc) {
+    if (!h) return failg(1, "jg_gn_increment: bad argument");
+    if (int rc = set_device(h)) return rc;
+    GN_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
+    if (int rc = launch_increment(h, nullptr)) return rc;
+    launch_check(h, 0);
+    GN_HIP(hipGetLastError());
+    GN_HIP(hipStreamSynchronize(h->stream));
+    std::vector<int> st(h->ld);
+    GN_HIP(hipMemcpy(st.data(), h->eng.status, (size_t)h->ld * 4, hipMemcpyDeviceToHost));
+    for (int b = 0; b < h->batch; ++b) if (st[b] & 4) return failg(3, "jg_gn_increment: zero or non-finite pivot (singular gain matrix)");
+    if (maxinc) GN_HIP(hipMemcpy(maxinc, h->d_maxinc, (size_t)h->batch * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int jg_gn_solve(jg_gn* h) {
+    if (!h) return failg(1, "jg_gn_solve: bad argument");
+    if (int rc = set_device(h)) return rc;
+    launch_update(h, nullptr);
+    hipLaunchKernelGGL(k_gn_add_iter, dim3((h->ld + 255) / 256), dim3(256), 0, h->stream, h->d_iters, h->ld);
+    GN_HIP(hipGetLastError());
+    GN_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int jg_gn_run(jg_gn* h, int64_t max_iter, double tol, int32_t* iters, int32_t* status) {
+    if (!h || max_iter < 0 || !(tol > 0.0)) return failg(1, "jg_gn_run: bad argument");
+    if (int rc = set_device(h)) return rc;
+    if (!h->exec) {
+        GN_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        hipMemsetAsync(h->d_counter, 0, sizeof(int), h->stream);
+        // the first pass must see every group active: the flags of the PREVIOUS check drive group skipping
+        int rc = launch_increment(h, h->d_group);
+        hipMemsetAsync(h->d_group, 0, (size_t)(h->ld / 64) * sizeof(int), h->stream);
+        launch_check(h, 1);
+        launch_update(h, h->d_active);
+        hipMemcpyAsync(h->h_counter, h->d_counter, sizeof(int), hipMemcpyDeviceToHost, h->stream);
+        hipError_t e = hipStreamEndCapture(h->stream, &h->graph);
+        if (rc) return rc;
+        GN_HIP(e);
+        GN_HIP(hipGraphInstantiate(&h->exec, h->graph, nullptr, nullptr, 0));
+    }
+    const double params[2] = {tol, (double)max_iter};
+    GN_HIP(hipMemcpyAsync(h->d_params, params, sizeof(params), hipMemcpyHostToDevice, h->stream));
+    GN_HIP(hipMemsetAsync(h->d_iters, 0, (size_t)h->ld * 4, h->stream));          // acStateEstimation.jl:1298
+    GN_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
+    GN_HIP(hipMemsetAsync(h->d_group, 0xff, (size_t)(h->ld / 64) * sizeof(int), h->stream));
+    for (int64_t it = 0; it <= max_iter; ++it) {                                   // :1303
+        GN_HIP(hipGraphLaunch(h->exec, h->stream));
+        GN_HIP(hipStreamSynchronize(h->stream));
+        if (*h->h_counter == 0) break;
+    }
+    if (iters) GN_HIP(hipMemcpy(iters, h->d_iters, (size_t)h->batch * 4, hipMemcpyDeviceToHost));
+    if (status) GN_HIP(hipMemcpy(status, h->d_status, (size_t)h->batch * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int jg_gn_get_maps(jg_gn* h, int8_t* type, int64_t* hcolptr, int64_t* hrowval) {
+    if (!h) return failg(1, "jg_gn_get_maps: bad argument");
+    if (type) std::memcpy(type, h->type.data(), h->type.size());
+    if (hcolptr) std::memcpy(hcolptr, h->hcolptr.data(), h->hcolptr.size() * 8);
+    if (hrowval) std::memcpy(hrowval, h->hrowval.data(), h->hrowval.size() * 8);
+    return 0;
+}
+
+int jg_gn_get_jacobian(jg_gn* h, double* nzval) {
+    if (!h || !nzval) return failg(1, "jg_gn_get_jacobian: bad argument");
+    if (int rc = set_device(h)) return rc;
+    GN_HIP(hipStreamSynchronize(h->stream));
+    std::vector<double> t((size_t)h->nslots * 2 * h->ld);
+    GN_HIP(hipMemcpy(t.data(), h->d_Hs, t.size() * 8, hipMemcpyDeviceToHost));
+    for (int b = 0; b < h->batch; ++b)
+        for (int64_t k = 0; k < h->nnzH; ++k) nzval[(size_t)b * h->nnzH + k] = t[(size_t)h->hmap[k] * h->ld + b];
+    return 0;
+}
+
+int jg_gn_get_residual(jg_gn* h, double* res) {
+    if (!h || !res) return failg(1, "jg_gn_get_residual: bad argument");
+    if (int rc = set_device(h)) return rc;
+    GN_HIP(hipStreamSynchronize(h->stream));
+    return get_rows(h, h->d_res, res, h->m);
+}
+
+int jg_gn_get_increment(jg_gn* h, double* inc) {
+    if (!h || !inc) return failg(1, "jg_gn_get_increment: bad argument");
+    if (int rc = set_device(h)) return rc;
+    GN_HIP(hipStreamSynchronize(h->stream));
+    std::vector<double> t((size_t)h->n * 2 * h->batch);
+    if (int rc = get_rows(h, h->d_inc, t.data(), (size_t)h->n * 2)) return rc;
+    for (int b = 0; b < h->batch; ++b)                                             // [theta_1..n, V_1..n] like se.increment
+        for (int i = 0; i < h->n; ++i) {
+            inc[(size_t)b * 2 * h->n + i] = t[(size_t)b * 2 * h->n + 2 * i];
+            inc[(size_t)b * 2 * h->n + h->n + i] = t[(size_t)b * 2 * h->n + 2 * i + 1];
+        }
+    return 0;
+}
+
+int jg_gn_get_iteration(jg_gn* h, int32_t* iters) {
+    if (!h || !iters) return failg(1, "jg_gn_get_iteration: bad argument");
+    if (int rc = set_device(h)) return rc;
+    GN_HIP(hipStreamSynchronize(h->stream));
+    GN_HIP(hipMemcpy(iters, h->d_iters, (size_t)h->batch * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int jg_gn_time_kernel(jg_gn* h, int kernel, int reps, double* mean_ms) {
+    if (!h || reps < 1 || !mean_ms || kernel < 0 || kernel > 3) return failg(1, "jg_gn_time_kernel: bad argument");
+    if (int rc = set_device(h)) return rc;
+    hipEvent_t e0, e1;
+    GN_HIP(hipEventCreate(&e0));
+    GN_HIP(hipEventCreate(&e1));
+    jg::StateUpdate none{};
+    GN_HIP(hipStreamSynchronize(h->stream));
+    GN_HIP(hipEventRecord(e0, h->stream));
+    for (int r = 0; r < reps; ++r) {
+        if (kernel == 0) launch_rows(h);
+        else if (kernel == 1) launch_gain(h);
+        else if (kernel == 2) { if (int rc = h->eng.factor(h->stream, h->d_Gv, h->d_rhs, nullptr)) return failg(rc, h->eng.error); }
+        else { if (int rc = h->eng.backsolve(h->stream, h->d_inc, none, nullptr)) return failg(rc, h->eng.error); }
+    }
+    GN_HIP(hipEventRecord(e1, h->stream));
+    GN_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    GN_HIP(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *mean_ms = (double)ms / reps;
+    return 0;
+}
+
+}  // extern "C"

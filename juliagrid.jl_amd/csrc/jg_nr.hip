@@ -178,6 +178,10 @@ __global__ void k_add_iter(int* iters, int n) {
 
 }  // namespace
 
+namespace jg {
+void set_last_error(const std::string& msg) { g_error = msg; }
+}
+
 struct jg_nr {
     int n = 0, nnz = 0, batch = 0, ld = 0, mp = 0, device = 0, nchunk = 0;
     int64_t dimJ = 0, nnzJ = 0, slack = 0;

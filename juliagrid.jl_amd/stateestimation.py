@@ -1,0 +1,298 @@
+"""Gauss-Newton WLS state estimation: host-side mirror of the reference interface over the C ABI.
+
+Reference surface (paths relative to /root/reference)                 here
+  gaussNewton(monitoring)      stateEstimation/acStateEstimation.jl:43-75     gaussNewton(monitoring, batch=1)
+  increment!(analysis)         acStateEstimation.jl:878-904                   increment_(analysis)
+  solve!(analysis)             acStateEstimation.jl:1035-1047                 solve_(analysis)
+  stateEstimation!(analysis)   acStateEstimation.jl:1286-1329                 stateEstimation_(analysis, iteration=40, tolerance=1e-8)
+  analysis.voltage, analysis.method.{jacobian,precision,mean,residual,increment,type,index,range,objective,iteration}
+
+The host does the value bookkeeping of acWLS (:77-259): type = status * code, se.mean (squared
+for types 4/5, rectangular z cos / z sin for 16-21), se.precision (1/variance, 4 z^2 sigma^2 for
+squared currents, variancePmu / covariancePmu blocks for rectangular PMUs; equations.jl:576-677,
+measurement/utility.jl:115-129).  Everything numeric per iteration runs in libjgrid_hip.so.
+`batch` > 1 = Monte-Carlo noise realisations of one measurement configuration (setNoise_).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from types import SimpleNamespace as NS
+
+import numpy as np
+
+from . import _lib
+from .measurement import Measurement
+from .powerflow import _reim
+from .system import CscMatrix, acModel_
+
+
+def _wls_layout(mon: Measurement):
+    """Row layout of acWLS: per row (code, status source, index) + per device raw-reading slots."""
+    sysm = mon.system
+    code, index, dev_row = [], [], []       # dev_row: first row of each device, in concatenation order
+    fam_range = [1]
+    devs = []                               # (family, device number)
+    for i, k in enumerate(mon.voltmeter.layout.index):
+        devs.append(("v", i)); dev_row.append(len(code)); code.append(1); index.append(k)
+    fam_range.append(len(code) + 1)
+    a = mon.ammeter
+    for i, k in enumerate(a.layout.index):
+        devs.append(("a", i)); dev_row.append(len(code))
+        code.append((4 if a.layout.from_[i] else 5) if a.layout.square[i] else (2 if a.layout.from_[i] else 3)); index.append(k)
+    fam_range.append(len(code) + 1)
+    for fam, meter, cb, cf, ct in (("w", mon.wattmeter, 6, 7, 8), ("r", mon.varmeter, 9, 10, 11)):
+        for i, k in enumerate(meter.layout.index):
+            devs.append((fam, i)); dev_row.append(len(code))
+            code.append(cb if meter.layout.bus[i] else (cf if meter.layout.from_[i] else ct)); index.append(k)
+        fam_range.append(len(code) + 1)
+    p = mon.pmu
+    corr_rows = []
+    for i, k in enumerate(p.layout.index):
+        devs.append(("p", i)); dev_row.append(len(code))
+        frm = p.layout.from_[i]
+        if p.layout.polar[i]:
+            if p.layout.bus[i]:
+                code += [12, 13]
+            else:
+                code += [((4 if frm else 5) if p.layout.square[i] else (2 if frm else 3)), (14 if frm else 15)]
+        else:
+            if p.layout.correlated[i]:
+                corr_rows.append(len(code) + 1)
+            code += [16, 17] if p.layout.bus[i] else ([18, 20] if frm else [19, 21])
+        index += [k, k]
+    fam_range.append(len(code) + 1)
+    del sysm
+    return (np.array(code, dtype=np.int8), np.array(index, dtype=np.int64), np.array(fam_range, dtype=np.int64),
+            np.array(corr_rows, dtype=np.int64), devs, np.array(dev_row, dtype=np.int64))
+
+
+def _readings(mon: Measurement):
+    """Raw meter readings in device order: z1/var1/st1 (magnitude or the single quantity), z2/var2/st2 (PMU angle)."""
+    z1, v1, s1, z2, v2, s2 = [], [], [], [], [], []
+    for g in (mon.voltmeter.magnitude, mon.ammeter.magnitude, mon.wattmeter.active, mon.varmeter.reactive):
+        z1 += g.mean; v1 += g.variance; s1 += g.status
+        z2 += [0.0] * len(g.mean); v2 += [1.0] * len(g.mean); s2 += [1] * len(g.mean)
+    z1 += mon.pmu.magnitude.mean; v1 += mon.pmu.magnitude.variance; s1 += mon.pmu.magnitude.status
+    z2 += mon.pmu.angle.mean; v2 += mon.pmu.angle.variance; s2 += mon.pmu.angle.status
+    f8 = lambda x: np.array(x, dtype=np.float64)
+    return f8(z1), f8(v1), np.array(s1, dtype=np.int8), f8(z2), f8(v2), np.array(s2, dtype=np.int8)
+
+
+def _wls_values(mon: Measurement, devs, dev_row, m, z1, v1, s1, z2, v2, s2):
+    """se.mean, diag(se.precision), correlated off-diagonals and row status for readings of shape [..., ndev]."""
+    shape = z1.shape[:-1]
+    mean = np.zeros(shape + (m,))
+    wdiag = np.ones(shape + (m,))
+    status = np.zeros(m, dtype=np.int8)
+    woff = []
+    a, p = mon.ammeter, mon.pmu
+    for d, (fam, i) in enumerate(devs):
+        r = int(dev_row[d])
+        zz, var, st = z1[..., d], v1[d], int(s1[d])
+        if fam != "p":
+            sq = fam == "a" and a.layout.square[i]
+            status[r] = st
+            mean[..., r] = st * (zz ** 2 if sq else zz)                        # :138, :149, :163, :177
+            with np.errstate(divide="ignore"):
+                wdiag[..., r] = 1.0 / (4.0 * zz ** 2 * var if sq else var)     # varianceSquare
+            continue
+        za, vara, sta = z2[..., d], v2[d], int(s2[d])
+        if p.layout.polar[i]:
+            sq = p.layout.square[i] and not p.layout.bus[i]
+            status[r], status[r + 1] = st, sta
+            mean[..., r] = st * (zz ** 2 if sq else zz)                        # :195-199
+            wdiag[..., r] = 1.0 / (4.0 * zz ** 2 * var if sq else var)
+            mean[..., r + 1] = sta * za
+            wdiag[..., r + 1] = 1.0 / vara
+        else:
+            s, c = np.sin(za), np.cos(za)
+            stt = st * sta
+            status[r] = status[r + 1] = stt
+            mean[..., r] = stt * zz * c                                        # :216-217
+            mean[..., r + 1] = stt * zz * s
+            vre = var * c ** 2 + vara * (zz * s) ** 2                          # variancePmu (equations.jl:576-588)
+            vim = var * s ** 2 + vara * (zz * c) ** 2
+            if p.layout.correlated[i]:                                         # covariancePmu + precision! (:591-666)
+                l1i = 1.0 / np.sqrt(vre)
+                l2 = s * c * (var - vara * zz ** 2) * l1i
+                l3i2 = 1.0 / (vim - l2 ** 2)
+                off = (-l2 * l1i) * l3i2
+                woff.append(off)
+                wdiag[..., r] = (l1i - l2 * off) * l1i
+                wdiag[..., r + 1] = l3i2
+            else:
+                wdiag[..., r] = 1.0 / vre
+                wdiag[..., r + 1] = 1.0 / vim
+    woff = np.stack(woff, axis=-1) if woff else np.zeros(shape + (0,))
+    if not (np.all(np.isfinite(wdiag)) and np.all(wdiag > 0) and np.all(np.isfinite(woff))):
+        raise ValueError("The variance of a measurement is zero or negative (errorVariance): "
+                         "check zero-magnitude squared-current / rectangular PMU readings.")
+    return mean, wdiag, woff, status
+
+
+class AcStateEstimation:
+    """AcStateEstimation{GaussNewton{HIP}} (src/definition/analysis.jl:532-545, 643-650)."""
+
+    def __init__(self, monitoring: Measurement, batch: int, device: int):
+        L = _lib.lib()
+        self.monitoring = monitoring
+        self.system = sysm = monitoring.system
+        self.batch = int(batch)
+        if sysm.bus.layout.slack == 0:
+            raise RuntimeError("The slack bus is missing.")
+        if sysm.model.ac.nodalMatrix is None:
+            acModel_(sysm)                                                     # model!(system, ac) :88
+        ac = sysm.model.ac
+        Y, YT = ac.nodalMatrix, ac.nodalMatrixTranspose
+        n, nb = sysm.bus.number, sysm.branch.number
+        code, index, rng, corr, devs, dev_row = _wls_layout(monitoring)
+        self._devs, self._dev_row = devs, dev_row
+        m = code.size
+        if m == 0:
+            raise ValueError("the measurement set is empty")
+        z = _readings(monitoring)
+        self._z = z
+        mean, wdiag, woff, status = _wls_values(monitoring, devs, dev_row, m, *z)
+        par = sysm.branch.parameter
+        bp = np.ascontiguousarray(np.stack([ac.admittance.real, ac.admittance.imag, par.conductance, par.susceptance,
+                                            par.turnsRatio, par.shiftAngle], axis=1), dtype=np.float64)
+        self._h = _lib.VP()
+        _lib.check(L.jg_gn_create(C.byref(self._h), n, Y.colptr, Y.rowval, _reim(Y.nzval), _reim(YT.nzval), nb,
+                                  np.ascontiguousarray(sysm.branch.layout.from_, dtype=np.int64),
+                                  np.ascontiguousarray(sysm.branch.layout.to, dtype=np.int64), bp.reshape(-1),
+                                  sysm.bus.layout.slack, m, code, status, index, corr.size,
+                                  corr if corr.size else np.zeros(1, dtype=np.int64), self.batch, int(device)))
+        dims = np.zeros(8, dtype=np.int64)
+        _lib.check(L.jg_gn_dims(self._h, dims))
+        self.dims = dict(m=int(dims[0]), nnzH=int(dims[1]), gain_blocks=int(dims[2]), lu_blocks=int(dims[3]), lu_terms=int(dims[4]),
+                         factor_launches=int(dims[5]), backward_launches=int(dims[6]), slots=int(dims[7]), n=n, nnzY=Y.nnz)
+        typ = np.zeros(m, dtype=np.int8)
+        hcolptr = np.zeros(2 * n + 1, dtype=np.int64)
+        hrowval = np.zeros(self.dims["nnzH"], dtype=np.int64)
+        _lib.check(L.jg_gn_get_maps(self._h, typ, hcolptr, hrowval))
+        self.method = NS(type=typ, index=index, range=rng, mean=mean, iteration=0, _hcolptr=hcolptr, _hrowval=hrowval,
+                         _wdiag=wdiag, _woff=woff, _corr=corr, _code=code)
+        self._upload_measurement(mean, wdiag, woff)
+        self.voltage = NS(magnitude=None, angle=None)
+        self.setVoltage(sysm.bus.voltage.magnitude, sysm.bus.voltage.angle)    # acStateEstimation.jl:52-55
+        self.status = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().jg_gn_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _shape(self, a):
+        return a[0] if self.batch == 1 else a
+
+    def _upload_measurement(self, mean, wdiag, woff):
+        m = self.dims["m"]
+        mean, wdiag, woff = (np.ascontiguousarray(x, dtype=np.float64) for x in (mean, wdiag, woff))
+        sm = 0 if mean.ndim == 1 else m
+        sc = 0 if woff.ndim == 1 else woff.shape[-1]
+        if woff.size == 0:
+            woff = np.zeros(1)
+        _lib.check(_lib.lib().jg_gn_set_measurement(self._h, mean.reshape(-1), wdiag.reshape(-1), woff.reshape(-1), sm, sc))
+        self.method.mean, self.method._wdiag, self.method._woff = mean, wdiag, woff
+
+    def setVoltage(self, magnitude, angle):
+        vm = np.ascontiguousarray(magnitude, dtype=np.float64)
+        va = np.ascontiguousarray(angle, dtype=np.float64)
+        stride = 0 if vm.ndim == 1 else self.system.bus.number
+        _lib.check(_lib.lib().jg_gn_set_voltage(self._h, vm.reshape(-1), va.reshape(-1), stride))
+        self._pull_voltage()
+
+    def _pull_voltage(self):
+        n = self.system.bus.number
+        vm, va = np.zeros((self.batch, n)), np.zeros((self.batch, n))
+        _lib.check(_lib.lib().jg_gn_get_voltage(self._h, vm, va))
+        self.voltage.magnitude, self.voltage.angle = self._shape(vm), self._shape(va)
+
+    @property
+    def jacobian(self):
+        v = np.zeros((self.batch, self.dims["nnzH"]))
+        _lib.check(_lib.lib().jg_gn_get_jacobian(self._h, v))
+        return CscMatrix(2 * self.system.bus.number, self.method._hcolptr, self.method._hrowval, self._shape(v))
+
+    @property
+    def residual(self):
+        r = np.zeros((self.batch, self.dims["m"]))
+        _lib.check(_lib.lib().jg_gn_get_residual(self._h, r))
+        return self._shape(r)
+
+    @property
+    def increment(self):
+        r = np.zeros((self.batch, 2 * self.system.bus.number))
+        _lib.check(_lib.lib().jg_gn_get_increment(self._h, r))
+        return self._shape(r)
+
+    @property
+    def precision(self):
+        """se.precision as a dense [m, m] matrix (first scenario): diagonal + 2x2 PMU blocks."""
+        wd = np.atleast_2d(self.method._wdiag)[0]
+        W = np.diag(wd)
+        wo = np.atleast_2d(self.method._woff)[0] if self.method._corr.size else []
+        for q, r in enumerate(self.method._corr):
+            W[r - 1, r] = W[r, r - 1] = wo[q]
+        return W
+
+    @property
+    def objective(self):
+        """se.objective = r' W r (equations.jl:689-698), evaluated on demand from the device residuals."""
+        res = np.atleast_2d(self.residual)
+        wd = np.broadcast_to(np.atleast_2d(self.method._wdiag), res.shape)
+        obj = np.sum(res * res * wd, axis=1)
+        if self.method._corr.size:
+            wo = np.broadcast_to(np.atleast_2d(self.method._woff), (res.shape[0], self.method._corr.size))
+            r0 = self.method._corr - 1
+            obj = obj + 2.0 * np.sum(res[:, r0] * res[:, r0 + 1] * wo, axis=1)
+        return float(obj[0]) if self.batch == 1 else obj
+
+    def time_kernel(self, kernel: int, reps: int = 10) -> float:
+        ms = C.c_double(0.0)
+        _lib.check(_lib.lib().jg_gn_time_kernel(self._h, int(kernel), int(reps), C.byref(ms)))
+        return ms.value
+
+
+def gaussNewton(monitoring: Measurement, batch: int = 1, device: int = 0) -> AcStateEstimation:
+    """gaussNewton(monitoring): WLS model + symbolic analysis + upload; start = system.bus.voltage."""
+    return AcStateEstimation(monitoring, batch, device)
+
+
+def setNoise_(an: AcStateEstimation, rng, scale: float = 1.0):
+    """Monte-Carlo realisations: scenario b reads z + scale * sigma * N(0,1) on every raw meter quantity
+    (what `noise = true` does in add*!, measurement/utility.jl:70-73), then the acWLS value rules are
+    re-applied per scenario (squared currents and rectangular PMUs make mean AND precision depend on z)."""
+    z1, v1, s1, z2, v2, s2 = an._z
+    B = an.batch
+    n1 = z1[None, :] + scale * np.sqrt(v1)[None, :] * rng.standard_normal((B, z1.size))
+    n2 = z2[None, :] + scale * np.sqrt(v2)[None, :] * rng.standard_normal((B, z2.size))
+    mean, wdiag, woff, _ = _wls_values(an.monitoring, an._devs, an._dev_row, an.dims["m"], n1, v1, s1, n2, v2, s2)
+    an._upload_measurement(mean if B > 1 else mean[0], wdiag if B > 1 else wdiag[0], woff if B > 1 else woff[0])
+
+
+def increment_(an: AcStateEstimation):
+    """increment!(analysis) -> maximum(abs, increment) (array for batch > 1)."""
+    mx = np.zeros(an.batch)
+    _lib.check(_lib.lib().jg_gn_increment(an._h, mx))
+    return float(mx[0]) if an.batch == 1 else mx
+
+
+def solve_(an: AcStateEstimation):
+    """solve!(analysis): theta += increment[1:n], V += increment[n+1:2n]; iteration += 1."""
+    _lib.check(_lib.lib().jg_gn_solve(an._h))
+    an.method.iteration += 1
+    an._pull_voltage()
+
+
+def stateEstimation_(an: AcStateEstimation, iteration: int = 40, tolerance: float = 1e-8, fetch: bool = True):
+    """stateEstimation!(analysis; iteration, tolerance)."""
+    it = np.zeros(an.batch, dtype=np.int32)
+    st = np.zeros(an.batch, dtype=np.int32)
+    _lib.check(_lib.lib().jg_gn_run(an._h, int(iteration), float(tolerance), it, st))
+    an.method.iteration = int(it[0]) if an.batch == 1 else it
+    an.status = int(st[0]) if an.batch == 1 else st
+    if fetch:
+        an._pull_voltage()

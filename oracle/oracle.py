@@ -291,8 +291,9 @@ def add_from_power_flow(tab: MeterTable, sys_: OracleSystem, vm, va, family, bus
         return
     if family == "pmu":
         if bus:
+            bflags = dict(flags, square=False)                 # pmu.jl:335: layout.square = false for bus PMUs
             for i in range(sys_.n):
-                tab.add("pmu", 0, i + 1, vm[i], var, 1, va[i], var, 1, **flags)
+                tab.add("pmu", 0, i + 1, vm[i], var, 1, va[i], var, 1, **bflags)
         for k in on:
             if frm:
                 tab.add("pmu", 1, k + 1, br[k, 4], var, 1, br[k, 5], var, 1, **flags)

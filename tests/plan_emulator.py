@@ -17,6 +17,28 @@ def _walk(sch):
                     yield li, t, s, int(sch["items"][idx])
 
 
+def dfactor(D):
+    """2x2 LU with in-block partial pivoting, stored like the device: [1/u11, u12, l (+4 if swapped), 1/u22]."""
+    a, b, c, d = D[0, 0], D[0, 1], D[1, 0], D[1, 1]
+    sw = abs(c) > abs(a)
+    if sw:
+        a, b, c, d = c, d, a, b
+    l = c / a
+    u22 = d - l * b
+    return np.array([[1.0 / a, b], [l + 4.0 if sw else l, 1.0 / u22]])
+
+
+def dsolve(F, R):
+    """D^-1 R for a stored factor block F; R is a 2-vector or a 2x2 block (column by column)."""
+    sw = F[1, 0] > 2.0
+    l = F[1, 0] - 4.0 if sw else F[1, 0]
+    R = np.asarray(R, dtype=float)
+    a, b = (R[1], R[0]) if sw else (R[0], R[1])
+    y2 = (b - l * a) * F[1, 1]
+    y1 = (a - F[0, 1] * y2) * F[0, 0]
+    return np.array([y1, y2])
+
+
 class Replay:
     def __init__(self, plan):
         self.p = plan
@@ -38,7 +60,7 @@ class Replay:
 
     def factor(self, A, rhs):
         """A: [nnz_blocks,2,2] caller CSR order; rhs [n,2] original order.
-        Returns X [nE,2,2] (U, unscaled Lh, inverse diagonal) and y [n,2] (pivot order)."""
+        Returns X [nE,2,2] (U, unscaled Lh, factored diagonal blocks) and y [n,2] (pivot order)."""
         nE = self.nE
         X = np.zeros((nE, 2, 2))
         Y = np.zeros((self.n, 2))
@@ -52,15 +74,15 @@ class Replay:
                 for k in range(self.t_ptr[e], self.t_ptr[e + 1]):
                     a, d, b = self.t_a[k], self.t_d[k], self.t_b[k]
                     assert vis(a) and vis(d) and vis(b), "LU schedule race"
-                    acc -= X[a] @ X[d] @ X[b]
-                X[e] = np.linalg.inv(acc) if self.e_row[e] == self.e_col[e] else acc
+                    acc -= X[a] @ dsolve(X[d], X[b])
+                X[e] = dfactor(acc) if self.e_row[e] == self.e_col[e] else acc
             else:
                 k = it - nE
                 y = rhs[self.perm[k]].copy()
                 for p in range(self.l_ptr[k], self.l_ptr[k + 1]):
                     c = self.l_col[p]
                     assert vis(self.l_ent[p]) and vis(self.diag[c]) and vis(nE + c), "forward schedule race"
-                    y -= X[self.l_ent[p]] @ (X[self.diag[c]] @ Y[c])
+                    y -= X[self.l_ent[p]] @ dsolve(X[self.diag[c]], Y[c])
                 Y[k] = y
             stamp[it] = (li, t, s)
         assert all(st is not None for st in stamp), "items missing from the factorisation schedule"
@@ -75,7 +97,7 @@ class Replay:
             for p in range(self.u_ptr[k], self.u_ptr[k + 1]):
                 assert self._visible(stamp, self.u_col[p], li, t, s), "bwd schedule race"
                 y -= X[self.u_ent[p]] @ W[self.u_col[p]]
-            W[k] = X[self.diag[k]] @ y
+            W[k] = dsolve(X[self.diag[k]], y)
             out[self.perm[k]] = W[k]
             stamp[k] = (li, t, s)
         assert all(st is not None for st in stamp)

@@ -89,3 +89,45 @@ def test_plan_rejects_unsymmetric_pattern(jg):
     col = np.array([0, 1, 1], dtype=np.int32)
     with pytest.raises(jg._lib.JGridError):
         jg._lib.Plan(2, rowptr, col)
+
+
+def test_replay_is_stable_on_ill_conditioned_gain(jg, oracle):
+    """Gain matrix of the squared-ammeter + weak-PMU set (cond ~7e9, pivot blocks up to cond ~2e9,
+    test/stateEstimation/analysis.jl:43-49): the factored-diagonal block LU must match a dense solve
+    as well as Cholesky does (an explicit 2x2 inverse loses the solution here)."""
+    import scipy.sparse as sp
+    from test_oracle_se import se_case14
+    t, osys, vm, va = se_case14(oracle)
+    tab = oracle.MeterTable()
+    oracle.add_from_power_flow(tab, osys, vm, va, "pmu", bus=True, frm=False, to=False, variance=1.0, polar=True)
+    oracle.add_from_power_flow(tab, osys, vm, va, "ammeter", variance=1e-4, square=True)
+    gn = oracle.OracleGN(osys, tab)
+    gn.increment()
+    v = gn.vectors()
+    n, sl = osys.n, osys.slack - 1
+    H = sp.csc_matrix((v["jacobian"], gn.hrowval - 1, gn.hcolptr - 1), shape=(gn.m, 2 * n)).toarray()
+    H[:, sl] = 0
+    W = gn.precision_dense()
+    G = H.T @ W @ H
+    G[sl, sl] = 1
+    rhs = H.T @ W @ v["residual"]
+    rhs[sl] = 0
+    dx = np.linalg.solve(G, rhs)
+    assert np.linalg.cond(G) > 1e9
+    perm = np.empty(2 * n, dtype=int)
+    perm[0::2], perm[1::2] = np.arange(n), n + np.arange(n)
+    Gb, rb = G[np.ix_(perm, perm)], rhs[perm]
+    rowptr, col, A = [0], [], []
+    for i in range(n):
+        for j in range(n):
+            blk = Gb[2 * i:2 * i + 2, 2 * j:2 * j + 2]
+            if i == j or np.any(blk != 0):
+                col.append(j)
+                A.append(blk)
+        rowptr.append(len(col))
+    rp = Replay(jg._lib.Plan(n, np.array(rowptr), np.array(col)))
+    X, Y = rp.factor(np.array(A), rb.reshape(n, 2))
+    x = rp.backsolve(X, Y)
+    xs = np.concatenate([x[:, 0], x[:, 1]])
+    assert np.abs(xs - dx).max() <= 1e-6 * np.abs(dx).max()       # ~ cond * eps
+    assert np.abs(xs - v["increment"]).max() <= 1e-6 * np.abs(dx).max()
