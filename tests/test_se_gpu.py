@@ -137,7 +137,7 @@ def test_all_measurements_from_power_flow(jg, oracle, name):
     assert an.status == 0
     assert np.abs(an.voltage.magnitude - pf.voltage.magnitude).max() <= 1e-10
     assert np.abs(an.voltage.angle - pf.voltage.angle).max() <= 1e-10
-    assert an.objective < 1e-10
+    assert an.objective < 1e-5       # sum of 1e8-weighted rounding-level residuals
     non = int((s.branch.layout.status == 1).sum())
     if name in ("case14test", "case30test"):
         assert an.dims["m"] == 3 * s.bus.number + 6 * non + 2 * (s.bus.number + 2 * non)
