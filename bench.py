@@ -132,10 +132,6 @@ def main():
     out_vm = torch.empty((B, n), dtype=torch.float64, device="cuda")
     out_va = torch.empty((B, n), dtype=torch.float64, device="cuda")
     res = torch.empty((B, 2), dtype=torch.int32, device="cuda")
-    if world > 1:
-        g_vm = torch.empty((world * B, n), dtype=torch.float64, device="cuda")
-        g_va = torch.empty((world * B, n), dtype=torch.float64, device="cuda")
-        g_res = torch.empty((world * B, 2), dtype=torch.int32, device="cuda")
 
     def step():
         an.restore_voltage()                          # start point, HBM -> HBM
@@ -143,9 +139,7 @@ def main():
         if world > 1:                                 # the only collective: final gather of results
             an.voltage_device(out_vm.data_ptr(), out_va.data_ptr())
             res.copy_(torch.from_numpy(np.stack([an.method.iteration, an.status], axis=1).astype(np.int32)))
-            dist.all_gather_into_tensor(g_vm, out_vm)
-            dist.all_gather_into_tensor(g_va, out_va)
-            dist.all_gather_into_tensor(g_res, res)
+            jg.gatherResults(dist, res[:, 0], res[:, 1], out_vm, out_va)
         return int(np.sum(an.method.iteration))
 
     def fence():

@@ -7,7 +7,7 @@ from .system import PowerSystem, CscMatrix, powerSystem, acModel_          # noq
 from .system import updateBranch_ as updateBranchSystem_                   # noqa: F401
 from .powerflow import (AcPowerFlow, newtonRaphson, mismatch_, solve_, powerFlow_, setInitialPoint_,   # noqa: F401
                         updateBranch_, setOutage_, setInjection_, outagePatch, initializeACPowerFlow)
-from .contingency import bridges, outageList, shard, contingencyAnalysis   # noqa: F401
+from .contingency import bridges, outageList, shard, contingencyAnalysis, gatherResults   # noqa: F401
 from .measurement import (Measurement, measurement, addVoltmeter_, addAmmeter_, addWattmeter_, addVarmeter_,   # noqa: F401
                           addPmu_, exactQuantities)
 from .stateestimation import (AcStateEstimation, gaussNewton, increment_ as incrementSE_, solve_ as solveSE_,   # noqa: F401
@@ -20,5 +20,5 @@ __all__ = [
     "mismatch_", "solve_", "powerFlow_", "setInitialPoint_", "updateBranch_", "setOutage_", "setInjection_",
     "Measurement", "measurement", "addVoltmeter_", "addAmmeter_", "addWattmeter_", "addVarmeter_", "addPmu_",
     "exactQuantities", "AcStateEstimation", "gaussNewton", "incrementSE_", "solveSE_", "stateEstimation_", "setNoise_",
-    "outagePatch", "initializeACPowerFlow", "bridges", "outageList", "shard", "contingencyAnalysis",
+    "outagePatch", "initializeACPowerFlow", "bridges", "outageList", "shard", "contingencyAnalysis", "gatherResults",
 ]

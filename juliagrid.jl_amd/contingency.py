@@ -84,3 +84,22 @@ def contingencyAnalysis(system: PowerSystem, labels, device: int = 0) -> AcPower
         if lab:
             setOutage_(an, s, int(lab))
     return an
+
+
+def gatherResults(dist, iterations, status, magnitude=None, angle=None):
+    """Final gather of a sharded batch: every rank contributes its contiguous block of
+    scenarios; returns the global arrays in scenario order on every rank.  `dist` is an initialised
+    torch.distributed module (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests);
+    tensors must live on the backend's device.  This is the ONLY collective of the path."""
+    import torch
+    world = dist.get_world_size()
+    out = []
+    for t in (iterations, status, magnitude, angle):
+        if t is None:
+            out.append(None)
+            continue
+        t = t.contiguous()
+        g = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(g, t)
+        out.append(g)
+    return tuple(out)

@@ -1,0 +1,79 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the scenario sharding + final gather (the only collective)."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+from conftest import ROOT, load_case
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_shard_is_a_contiguous_partition(jg):
+    for count in (1, 7, 64, 512, 513):
+        for world in (1, 2, 3, 8):
+            blocks = [jg.shard(count, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == count
+            assert all(blocks[r][1] == blocks[r + 1][0] for r in range(world - 1))
+            assert max(hi - lo for lo, hi in blocks) - min(hi - lo for lo, hi in blocks if hi > lo or True) <= -(-count // world)
+
+
+def test_outage_list_is_seeded_and_avoids_bridges(jg):
+    s = jg.powerSystem(load_case("case118"))
+    a = jg.outageList(s, 40, seed=512)
+    b = jg.outageList(s, 40, seed=512)
+    assert np.array_equal(a, b) and a.min() >= 1
+    br = jg.bridges(s)
+    assert not br[a - 1].any()
+    assert np.all(s.branch.layout.status[a - 1] == 1)
+
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, {root!r})
+    import numpy as np, torch, torch.distributed as dist
+    import juliagrid.jl_amd as jg
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    B, n = 6, 5
+    total = B * world
+    lo, hi = jg.shard(total, rank, world)
+    ids = torch.arange(lo, hi)
+    iters = (ids % 4 + 2).to(torch.int32)
+    status = (ids % 3 == 0).to(torch.int32)
+    vm = (ids[:, None] * 10 + torch.arange(n)[None, :]).to(torch.float64)
+    va = -vm
+    g_it, g_st, g_vm, g_va = jg.gatherResults(dist, iters, status, vm, va)
+    all_ids = torch.arange(total)
+    assert torch.equal(g_it, (all_ids % 4 + 2).to(torch.int32))
+    assert torch.equal(g_st, (all_ids % 3 == 0).to(torch.int32))
+    assert torch.equal(g_vm, (all_ids[:, None] * 10 + torch.arange(n)[None, :]).to(torch.float64))
+    assert torch.equal(g_va, -g_vm)
+    # whole-job accounting used by bench.py: sum of iterations, max of times
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    c = torch.tensor([int(iters.sum())], dtype=torch.int64)
+    dist.all_reduce(c, op=dist.ReduceOp.SUM)
+    assert t.item() == world and c.item() == int((all_ids % 4 + 2).sum())
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+def test_two_rank_gloo_gather(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"], str(script)],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
