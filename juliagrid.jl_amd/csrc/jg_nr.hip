@@ -35,11 +35,12 @@ int fail(int code, const std::string& msg) { g_error = msg; return code; }
         if (err__ != hipSuccess) return fail(2, std::string(#expr) + ": " + hipGetErrorString(err__)); \
     } while (0)
 
-constexpr int ASM_ROWS = 32;   // bus rows per workgroup
+constexpr int ASM_ROWS = 16;   // bus rows per workgroup
 constexpr int ASM_WAVES = 4;
+constexpr int CH = 4;          // Ybus entries whose gathers are in flight together
 
 struct AsmArgs {
-    const int* rowptr; const int* col; const double* G; const double* Bv; const signed char* type;
+    const int* rowptr; const int* colm; const double2* GB; const int* rowtype;   // colm = col | (mask << 24); rowtype: int per bus (scalar-loadable)
     const double* vm; const double* va; const double* p; const double* q;
     const int* ppos; const double* pdg; const double* pdb;
     double* A; double* F; double* part;
@@ -63,39 +64,58 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(AsmArgs a) {
     const int r0 = blockIdx.x * ASM_ROWS;
     const int r1 = min(r0 + ASM_ROWS, a.n);
     for (int i = r0 + wave; i < r1; i += ASM_WAVES) {
-        const int ti = uniform((int)a.type[i]);
+        const int p0 = uniform(a.rowptr[i]), p1 = uniform(a.rowptr[i + 1]);
+        const int ti = (int)((unsigned)uniform(a.rowtype[i]));
         const double vi = a.vm[(size_t)i * ld + b];
         const double thi = a.va[(size_t)i * ld + b];
-        const int p0 = uniform(a.rowptr[i]), p1 = uniform(a.rowptr[i + 1]);
+        const double pinj = a.p[(size_t)i * ld + b], qinj = a.q[(size_t)i * ld + b];   // issued early, used after the row
         double s1 = 0.0, s2 = 0.0, gii = 0.0, bii = 0.0;
         int pd = p0;
-        for (int p = p0; p < p1; ++p) {
-            const int j = uniform(a.col[p]);
-            double g = a.G[p], bb = a.Bv[p];
+        // rows are short (3.4 entries on average, <= 19): the cost is the latency of the V/theta gathers,
+        // so the loads of four entries are issued together before any of them is consumed
+        for (int pc = p0; pc < p1; pc += CH) {
+            const int cnt = min(CH, p1 - pc);
+            int cm[CH]; double2 gb[CH]; double vv[CH], tt[CH];
 #pragma unroll
-            for (int m = 0; m < MP; ++m)
-                if (ppos[m] == p) { g += a.pdg[(size_t)m * ld + b]; bb += a.pdb[(size_t)m * ld + b]; }
-            const double vj = a.vm[(size_t)j * ld + b];
-            const double thj = a.va[(size_t)j * ld + b];
-            double s, c;
-            sincos(thi - thj, &s, &c);
-            const double ac = g * c + bb * s;      // G cos + B sin
-            const double ad = g * s - bb * c;      // G sin - B cos
-            s1 += vj * ac;
-            s2 += vj * ad;
-            if (j == i) { pd = p; gii = g; bii = bb; continue; }
-            const int tj = uniform((int)a.type[j]);
-            // rows: P exists unless slack, Q exists for PQ; cols: theta unless slack, V for PQ
-            const double rp = ti != 3 ? 1.0 : 0.0, rq = ti == 1 ? 1.0 : 0.0;
-            const double ct = tj != 3 ? 1.0 : 0.0, cv = tj == 1 ? 1.0 : 0.0;
-            double* o = a.A + (size_t)p * 4 * ld + b;
-            o[0] = rp * ct * (vi * vj * ad);        // dP_i/dtheta_j   equations.jl:109-111
-            o[ld] = rp * cv * (vi * ac);            // dP_i/dV_j       equations.jl:117-119
-            o[2 * ld] = rq * ct * (-(vi * vj) * ac);  // dQ_i/dtheta_j   equations.jl:134-136
-            o[3 * ld] = rq * cv * (vi * ad);        // dQ_i/dV_j       equations.jl:142-144
+            for (int k = 0; k < CH; ++k) {                       // scalar loads of the whole chunk first ...
+                const int p = pc + (k < cnt ? k : 0);
+                cm[k] = uniform(a.colm[p]);
+                gb[k] = a.GB[p];
+            }
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {                       // ... then all gathers in flight together
+                const size_t j = (size_t)(cm[k] & 0xffffff);
+                vv[k] = a.vm[j * ld + b];
+                tt[k] = a.va[j * ld + b];
+            }
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                if (k >= cnt) break;
+                const int p = pc + k;
+                const int j = cm[k] & 0xffffff;
+                const int mk = cm[k] >> 24;                    // bit0 dP/dth, bit1 dP/dV, bit2 dQ/dth, bit3 dQ/dV exist
+                double g = gb[k].x, bb = gb[k].y;
+#pragma unroll
+                for (int m = 0; m < MP; ++m)
+                    if (ppos[m] == p) { g += a.pdg[(size_t)m * ld + b]; bb += a.pdb[(size_t)m * ld + b]; }
+                const double vj = vv[k];
+                double s, c;
+                sincos(thi - tt[k], &s, &c);
+                const double ac = g * c + bb * s;      // G cos + B sin
+                const double ad = g * s - bb * c;      // G sin - B cos
+                s1 += vj * ac;
+                s2 += vj * ad;
+                if (j == i) { pd = p; gii = g; bii = bb; continue; }
+                // rows: P exists unless slack, Q exists for PQ; cols: theta unless slack, V for PQ (mask from the host)
+                double* o = a.A + (size_t)p * 4 * ld + b;
+                o[0] = (mk & 1) ? vi * vj * ad : 0.0;            // dP_i/dtheta_j   equations.jl:109-111
+                o[ld] = (mk & 2) ? vi * ac : 0.0;                // dP_i/dV_j       equations.jl:117-119
+                o[2 * ld] = (mk & 4) ? -(vi * vj) * ac : 0.0;    // dQ_i/dtheta_j   equations.jl:134-136
+                o[3 * ld] = (mk & 8) ? vi * ad : 0.0;            // dQ_i/dV_j       equations.jl:142-144
+            }
         }
-        double fp = vi * s1 - a.p[(size_t)i * ld + b];     // acPowerFlow.jl:676
-        double fq = vi * s2 - a.q[(size_t)i * ld + b];     // acPowerFlow.jl:679
+        double fp = vi * s1 - pinj;                        // acPowerFlow.jl:676
+        double fq = vi * s2 - qinj;                        // acPowerFlow.jl:679
         double d00 = -vi * s2 - bii * (vi * vi);           // equations.jl:105-107, acPowerFlow.jl:872
         double d01 = s1 + gii * vi;                        // equations.jl:113-115
         double d10 = vi * s1 - gii * (vi * vi);            // equations.jl:130-132
@@ -190,7 +210,7 @@ struct jg_nr {
     std::vector<int> tperm;          // Ybus CSC pointer -> block CSR index of the same (row, col)
     std::vector<int64_t> jmap;       // Jacobian CSC nz -> csr*4 + component
     // device
-    int* d_rowptr = nullptr; int* d_col = nullptr; double* d_G = nullptr; double* d_B = nullptr;
+    int* d_rowptr = nullptr; int* d_col = nullptr; double* d_G = nullptr; double* d_B = nullptr; double2* d_GB = nullptr; int* d_rowtype = nullptr;
     signed char* d_type = nullptr; signed char* d_flags = nullptr;
     double* d_vm = nullptr; double* d_va = nullptr; double* d_p = nullptr; double* d_q = nullptr;
     int* d_ppos = nullptr; double* d_pdg = nullptr; double* d_pdb = nullptr;
@@ -211,7 +231,7 @@ namespace {
 int set_device(jg_nr* h) { NR_HIP(hipSetDevice(h->device)); return 0; }
 
 void launch_assemble(jg_nr* h) {
-    AsmArgs a{h->d_rowptr, h->d_col, h->d_G, h->d_B, h->d_type, h->d_vm, h->d_va, h->d_p, h->d_q,
+    AsmArgs a{h->d_rowptr, h->d_col, h->d_GB, h->d_rowtype, h->d_vm, h->d_va, h->d_p, h->d_q,
               h->d_ppos, h->d_pdg, h->d_pdb, h->d_A, h->d_F, h->d_part, h->n, h->ld, h->mp};
     dim3 grid(h->nchunk, h->ld / 64), block(64, ASM_WAVES);
     switch (h->mp) {
@@ -350,6 +370,16 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
     std::vector<double> G(nnz), B(nnz);
     for (int i = 0; i <= n; ++i) rp[i] = (int)(colptr[i] - 1);
     for (int p = 0; p < nnz; ++p) { cl[p] = (int)(rowval[p] - 1); G[p] = yt_reim[2 * p]; B[p] = yt_reim[2 * p + 1]; }
+    if (n >= (1 << 24)) { delete h; return fail(1, "jg_nr_create: more than 2^24 buses"); }
+    std::vector<int> colm(nnz);                 // column | existence mask of the 2x2 block entries (row i, col j types)
+    for (int i = 0; i < n; ++i)
+        for (int p = rp[i]; p < rp[i + 1]; ++p) {
+            const int j = cl[p];
+            const int rpm = type[i] != 3, rq = type[i] == 1, ct = type[j] != 3, cv = type[j] == 1;
+            colm[p] = j | (((rpm & ct) | ((rpm & cv) << 1) | ((rq & ct) << 2) | ((rq & cv) << 3)) << 24);
+        }
+    std::vector<double2> GBv(nnz);
+    for (int p = 0; p < nnz; ++p) GBv[p] = double2{G[p], B[p]};
     // consistency of the two value arrays the reference keeps (T1): yT[p] must equal y[tperm[p]]
     for (int p = 0; p < nnz; ++p)
         if (y_reim[2 * (size_t)h->tperm[p]] != yt_reim[2 * p] || y_reim[2 * (size_t)h->tperm[p] + 1] != yt_reim[2 * p + 1]) {
@@ -359,8 +389,8 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
     for (int i = 0; i < n; ++i) flags[i] = (signed char)((type[i] != 3 ? 1 : 0) | (type[i] == 1 ? 2 : 0));
     std::string err;
     std::vector<signed char> tp(type, type + n);
-    if (jg::upload(&h->d_rowptr, rp, err) || jg::upload(&h->d_col, cl, err) || jg::upload(&h->d_G, G, err) ||
-        jg::upload(&h->d_B, B, err) || jg::upload(&h->d_type, tp, err) || jg::upload(&h->d_flags, flags, err)) {
+    if (jg::upload(&h->d_rowptr, rp, err) || jg::upload(&h->d_col, colm, err) || jg::upload(&h->d_G, G, err) ||
+        jg::upload(&h->d_B, B, err) || jg::upload(&h->d_GB, GBv, err) || jg::upload(&h->d_rowtype, std::vector<int>(type, type + n), err) || jg::upload(&h->d_type, tp, err) || jg::upload(&h->d_flags, flags, err)) {
         jg_nr_destroy(h); return fail(2, err);
     }
     h->nchunk = (h->n + ASM_ROWS - 1) / ASM_ROWS;
@@ -401,7 +431,7 @@ void jg_nr_destroy(jg_nr* h) {
     if (h->graphA) hipGraphDestroy(h->graphA);
     if (h->graphB) hipGraphDestroy(h->graphB);
     h->eng.destroy();
-    hipFree(h->d_rowptr); hipFree(h->d_col); hipFree(h->d_G); hipFree(h->d_B); hipFree(h->d_type); hipFree(h->d_flags);
+    hipFree(h->d_rowptr); hipFree(h->d_col); hipFree(h->d_G); hipFree(h->d_B); hipFree(h->d_GB); hipFree(h->d_rowtype); hipFree(h->d_type); hipFree(h->d_flags);
     hipFree(h->d_vm); hipFree(h->d_va); hipFree(h->d_p); hipFree(h->d_q); hipFree(h->d_ppos); hipFree(h->d_pdg);
     hipFree(h->d_pdb); hipFree(h->d_A); hipFree(h->d_F); hipFree(h->d_inc); hipFree(h->d_part); hipFree(h->d_normp);
     hipFree(h->d_normq); hipFree(h->d_params); hipFree(h->d_active); hipFree(h->d_iters); hipFree(h->d_status);
@@ -520,8 +550,9 @@ int jg_nr_set_ybus(jg_nr* h, const double* y_reim, const double* yt_reim) {
             return fail(4, "jg_nr_set_ybus: nodalMatrix and nodalMatrixTranspose disagree (stale model)");
     }
     NR_HIP(hipStreamSynchronize(h->stream));
-    NR_HIP(hipMemcpy(h->d_G, G.data(), G.size() * 8, hipMemcpyHostToDevice));
-    NR_HIP(hipMemcpy(h->d_B, B.data(), B.size() * 8, hipMemcpyHostToDevice));
+    std::vector<double2> GBv(h->nnz);
+    for (int p = 0; p < h->nnz; ++p) GBv[p] = double2{G[p], B[p]};
+    NR_HIP(hipMemcpy(h->d_GB, GBv.data(), GBv.size() * sizeof(double2), hipMemcpyHostToDevice));
     h->jac_valid = false;
     return 0;
 }
