@@ -15,7 +15,10 @@
 // Ybus pattern -- the layout the block LU engine consumes directly.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -43,16 +46,18 @@ struct AsmArgs {
     const int* rowptr; const int* colm; const double2* GB; const int* rowtype;   // colm = col | (mask << 24); rowtype: int per bus (scalar-loadable)
     const double* vm; const double* va; const double* p; const double* q;
     const int* ppos; const double* pdg; const double* pdb;
-    double* A; double* F; double* part;
+    double* A; double* F; double* part; const int* group;
     int n; int ld; int mp;
 };
 
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // Fused mismatch + Jacobian assembly. blockDim (64, ASM_WAVES); grid (ceil(n/ASM_ROWS), ld/64).
-template <int MP>
+// JAC = false: mismatch only (no Jacobian stores) -- the cheap pre-pass that decides which scenarios are still active.
+template <int MP, bool JAC>
 __global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(AsmArgs a) {
     __shared__ double red[2][ASM_WAVES][64];
+    if (a.group && !a.group[blockIdx.y]) return;          // every scenario of this 64-lane group is finished
     const int lane = threadIdx.x;
     const int wave = uniform(threadIdx.y);
     const size_t ld = (size_t)a.ld;
@@ -106,6 +111,7 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(AsmArgs a) {
                 s1 += vj * ac;
                 s2 += vj * ad;
                 if (j == i) { pd = p; gii = g; bii = bb; continue; }
+                if (!JAC) continue;
                 // rows: P exists unless slack, Q exists for PQ; cols: theta unless slack, V for PQ (mask from the host)
                 double* o = a.A + (size_t)p * 4 * ld + b;
                 o[0] = (mk & 1) ? vi * vj * ad : 0.0;            // dP_i/dtheta_j   equations.jl:109-111
@@ -122,8 +128,10 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(AsmArgs a) {
         double d11 = s2 - bii * vi;                        // equations.jl:138-140
         if (ti == 3) { d00 = 1.0; d01 = 0.0; d10 = 0.0; d11 = 1.0; fp = 0.0; fq = 0.0; }
         else if (ti == 2) { d01 = 0.0; d10 = 0.0; d11 = 1.0; fq = 0.0; }
-        double* o = a.A + (size_t)pd * 4 * ld + b;
-        o[0] = d00; o[ld] = d01; o[2 * ld] = d10; o[3 * ld] = d11;
+        if (JAC) {
+            double* o = a.A + (size_t)pd * 4 * ld + b;
+            o[0] = d00; o[ld] = d01; o[2 * ld] = d10; o[3 * ld] = d11;
+        }
         a.F[((size_t)i * 2) * ld + b] = fp;
         a.F[((size_t)i * 2 + 1) * ld + b] = fq;
         // NaN-propagating max: a NaN mismatch must not look converged
@@ -149,13 +157,14 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(AsmArgs a) {
 struct CheckArgs {
     const double* part; int nchunk; int ld; int batch;
     const double* params;      // [0] tolerance, [1] max iterations
-    double* normp; double* normq; int* active; int* iters; int* status; const int* lu_status; int* counter; int* group;
+    double* normp; double* normq; int* active; int* iters; int* status; const int* lu_status; int* counter; const int* group;
     int mode;                  // 0 = norms only, 1 = powerFlow! loop control
 };
 
 __global__ void k_check(CheckArgs a) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= a.ld) return;
+    if (a.mode == 1 && a.group && !a.group[b >> 6]) return;       // finished group: assembly was skipped, keep its verdict
     double mp = 0.0, mq = 0.0;
     for (int c = 0; c < a.nchunk; ++c) {
         const double x = a.part[((size_t)c * 2) * a.ld + b], y = a.part[((size_t)c * 2 + 1) * a.ld + b];
@@ -173,7 +182,83 @@ __global__ void k_check(CheckArgs a) {
     const bool act = real && !conv && !bad && a.iters[b] < maxit; // acPowerFlow.jl:1414
     a.active[b] = act ? 1 : 0;
     a.status[b] = conv ? 0 : (bad ? 3 : 1);
-    if (act) { a.iters[b] += 1; atomicAdd(a.counter, 1); atomicOr(a.group + (b >> 6), 1); }        // solve! follows: iteration += 1 (:908)
+    if (act) { a.iters[b] += 1; atomicAdd(a.counter, 1); }        // solve! follows: iteration += 1 (:908)
+}
+
+// ---- scenario compaction ------------------------------------------------------------------------
+// Scenarios converge after different iteration counts (2..10 on N-1 sets).  Once enough have finished,
+// the still-active ones are packed into the leading lanes (stable partition) so whole 64-lane groups
+// drop out of every later launch.  flags: [0] permute this iteration, [1] active lanes, [2] groups in use.
+struct CompactArgs {
+    int* active; int* iters; int* status; int* lu_status; int* lid; int* ppos; int mp;
+    int* dest; int* group; int* flags; int* tmp; int ld; int restore;
+};
+
+__global__ __launch_bounds__(1024) void k_compact(CompactArgs a) {
+    __shared__ int scan[1024];
+    const int t = threadIdx.x;
+    const int ld = a.ld, ngroups = ld / 64;
+    const int per = (ld + 1023) / 1024;
+    const int b0 = t * per, b1 = min(b0 + per, ld);
+    int cnt = 0;
+    for (int b = b0; b < b1; ++b) cnt += a.active[b] != 0;
+    scan[t] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {                    // inclusive Hillis-Steele scan
+        const int v = t >= off ? scan[t - off] : 0;
+        __syncthreads();
+        scan[t] += v;
+        __syncthreads();
+    }
+    const int n_active = scan[1023];
+    const int before = scan[t] - cnt;                             // active lanes in front of this thread's chunk
+    const int groups_new = (n_active + 63) / 64;
+    const int groups_cur = a.flags[2];
+    const bool permute = a.restore ? true : (n_active > 0 && groups_new < groups_cur);
+    __syncthreads();
+    if (t == 0) { a.flags[0] = permute ? 1 : 0; a.flags[1] = n_active; if (permute) a.flags[2] = a.restore ? ngroups : groups_new; }
+    if (!permute) {                                               // groups = those that still hold an active lane
+        for (int g = t; g < ngroups; g += 1024) {
+            int any = 0;
+            for (int l = 0; l < 64; ++l) any |= a.active[g * 64 + l];
+            a.group[g] = any;
+        }
+        return;
+    }
+    int run = before;
+    for (int b = b0; b < b1; ++b) {
+        int d;
+        if (a.restore) d = a.lid[b];                              // send every lane home
+        else if (a.active[b]) d = run++;
+        else d = n_active + (b - run);                            // inactive lanes keep their order behind the active ones
+        a.dest[b] = d;
+    }
+    __syncthreads();
+    int* arrays[5] = {a.active, a.iters, a.status, a.lu_status, a.lid};
+    for (int k = 0; k < 5 + a.mp; ++k) {
+        int* x = k < 5 ? arrays[k] : a.ppos + (size_t)(k - 5) * ld;
+        for (int b = b0; b < b1; ++b) a.tmp[a.dest[b]] = x[b];
+        __syncthreads();
+        for (int b = b0; b < b1; ++b) x[b] = a.tmp[b];
+        __syncthreads();
+    }
+    for (int g = t; g < ngroups; g += 1024) a.group[g] = a.restore ? 1 : (g < groups_new);
+}
+
+// dst[row][dest[b]] = src[row][b] for `rows` rows (no-op unless flags[0]); then the copy back
+__global__ void k_lane_permute(const double* src, double* dst, const int* dest, const int* flags, int rows, int ld) {
+    if (!flags[0]) return;
+    const int b = blockIdx.y * 256 + threadIdx.x;
+    if (b >= ld) return;
+    const int d = dest[b];
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) dst[(size_t)r * ld + d] = src[(size_t)r * ld + b];
+}
+
+__global__ void k_lane_copy(const double* src, double* dst, const int* flags, int rows, int ld) {
+    if (!flags[0]) return;
+    const int b = blockIdx.y * 256 + threadIdx.x;
+    if (b >= ld) return;
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) dst[(size_t)r * ld + b] = src[(size_t)r * ld + b];
 }
 
 // [n][ld] batch-minor -> [batch][n] scenario-major, tiled through LDS so both sides stay coalesced
@@ -218,6 +303,7 @@ struct jg_nr {
     double* d_normp = nullptr; double* d_normq = nullptr; double* d_params = nullptr;
     double* d_vm0 = nullptr; double* d_va0 = nullptr;   // snapshot of the start point
     int* d_active = nullptr; int* d_iters = nullptr; int* d_status = nullptr; int* d_counter = nullptr; int* d_group = nullptr;
+    int* d_lid = nullptr; int* d_dest = nullptr; int* d_cflags = nullptr; int* d_itmp = nullptr;   // scenario compaction
     jg::Engine eng;
     hipStream_t stream = nullptr;
     hipGraph_t graphA = nullptr, graphB = nullptr;
@@ -230,20 +316,28 @@ namespace {
 
 int set_device(jg_nr* h) { NR_HIP(hipSetDevice(h->device)); return 0; }
 
-void launch_assemble(jg_nr* h) {
+void launch_assemble(jg_nr* h, const int* group = nullptr, bool jac = true) {
     AsmArgs a{h->d_rowptr, h->d_col, h->d_GB, h->d_rowtype, h->d_vm, h->d_va, h->d_p, h->d_q,
-              h->d_ppos, h->d_pdg, h->d_pdb, h->d_A, h->d_F, h->d_part, h->n, h->ld, h->mp};
+              h->d_ppos, h->d_pdg, h->d_pdb, h->d_A, h->d_F, h->d_part, group, h->n, h->ld, h->mp};
     dim3 grid(h->nchunk, h->ld / 64), block(64, ASM_WAVES);
-    switch (h->mp) {
-        case 0: hipLaunchKernelGGL(k_assemble<0>, grid, block, 0, h->stream, a); break;
-        case 4: hipLaunchKernelGGL(k_assemble<4>, grid, block, 0, h->stream, a); break;
-        default: hipLaunchKernelGGL(k_assemble<8>, grid, block, 0, h->stream, a); break;
+    if (jac) {
+        switch (h->mp) {
+            case 0: hipLaunchKernelGGL((k_assemble<0, true>), grid, block, 0, h->stream, a); break;
+            case 4: hipLaunchKernelGGL((k_assemble<4, true>), grid, block, 0, h->stream, a); break;
+            default: hipLaunchKernelGGL((k_assemble<8, true>), grid, block, 0, h->stream, a); break;
+        }
+    } else {
+        switch (h->mp) {
+            case 0: hipLaunchKernelGGL((k_assemble<0, false>), grid, block, 0, h->stream, a); break;
+            case 4: hipLaunchKernelGGL((k_assemble<4, false>), grid, block, 0, h->stream, a); break;
+            default: hipLaunchKernelGGL((k_assemble<8, false>), grid, block, 0, h->stream, a); break;
+        }
     }
 }
 
-void launch_check(jg_nr* h, int mode) {
+void launch_check(jg_nr* h, int mode, const int* group = nullptr) {
     CheckArgs c{h->d_part, h->nchunk, h->ld, h->batch, h->d_params, h->d_normp, h->d_normq, h->d_active,
-                h->d_iters, h->d_status, h->eng.status, h->d_counter, h->d_group, mode};
+                h->d_iters, h->d_status, h->eng.status, h->d_counter, group, mode};
     hipLaunchKernelGGL(k_check, dim3((h->ld + 255) / 256), dim3(256), 0, h->stream, c);
 }
 
@@ -258,17 +352,37 @@ int put_bus_array(jg_nr* h, double* dst, const double* src, int64_t stride) {
     return 0;
 }
 
+// pack the active scenarios into the leading lanes (restore = 1: send every lane back home)
+void launch_compact(jg_nr* h, int restore) {
+    CompactArgs c{h->d_active, h->d_iters, h->d_status, h->eng.status, h->d_lid, h->d_ppos, h->mp, h->d_dest, h->d_group,
+                  h->d_cflags, h->d_itmp, h->ld, restore};
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, c);
+    double* tmp = h->eng.X;                        // the factor is dead here (rebuilt by the next factorisation)
+    const dim3 block(256), gy((unsigned)((h->ld + 255) / 256));
+    auto permute = [&](double* x, int rows) {
+        const dim3 grid((unsigned)std::min(rows, 2048), gy.x);
+        hipLaunchKernelGGL(k_lane_permute, grid, block, 0, h->stream, x, tmp, h->d_dest, h->d_cflags, rows, h->ld);
+        hipLaunchKernelGGL(k_lane_copy, grid, block, 0, h->stream, tmp, x, h->d_cflags, rows, h->ld);
+    };
+    permute(h->d_vm, h->n); permute(h->d_va, h->n); permute(h->d_p, h->n); permute(h->d_q, h->n);
+    if (h->mp > 0) { permute(h->d_pdg, h->mp); permute(h->d_pdb, h->mp); }
+    if (restore) { permute(h->d_F, 2 * h->n); permute(h->d_inc, 2 * h->n); }
+}
+
 int build_graphs(jg_nr* h) {
     if (h->execA) return 0;
     NR_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    // graph A: who is still active?  mismatch-only pass -> verdict per scenario -> pack the active ones
     hipMemsetAsync(h->d_counter, 0, sizeof(int), h->stream);
-    hipMemsetAsync(h->d_group, 0, (size_t)(h->ld / 64) * sizeof(int), h->stream);
-    launch_assemble(h);
-    launch_check(h, 1);
+    launch_assemble(h, h->d_group, false);
+    launch_check(h, 1, h->d_group);
+    launch_compact(h, 0);
     hipMemcpyAsync(h->h_counter, h->d_counter, sizeof(int), hipMemcpyDeviceToHost, h->stream);
     NR_HIP(hipStreamEndCapture(h->stream, &h->graphA));
     NR_HIP(hipGraphInstantiate(&h->execA, h->graphA, nullptr, nullptr, 0));
     NR_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    // graph B: the iteration itself, on the packed lanes only
+    launch_assemble(h, h->d_group, true);
     int rc = h->eng.factor(h->stream, h->d_A, h->d_F, h->d_group);
     jg::StateUpdate upd{h->d_va, h->d_vm, h->d_flags, h->d_active, -1.0};
     if (!rc) rc = h->eng.backsolve(h->stream, h->d_inc, upd, h->d_group);
@@ -409,7 +523,8 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
               dmalloc((void**)&h->d_normq, ld * 8) && dmalloc((void**)&h->d_params, 2 * 8) &&
               dmalloc((void**)&h->d_active, ld * 4) && dmalloc((void**)&h->d_iters, ld * 4) &&
               dmalloc((void**)&h->d_status, ld * 4) && dmalloc((void**)&h->d_counter, 4) &&
-              dmalloc((void**)&h->d_group, (ld / 64) * 4);
+              dmalloc((void**)&h->d_group, (ld / 64) * 4) && dmalloc((void**)&h->d_lid, ld * 4) &&
+              dmalloc((void**)&h->d_dest, ld * 4) && dmalloc((void**)&h->d_cflags, 16) && dmalloc((void**)&h->d_itmp, ld * 4);
     if (!ok) { jg_nr_destroy(h); return fail(2, "jg_nr_create: device allocation failed"); }
     if (hipMemset(h->d_ppos, 0xff, mpn * ld * 4) != hipSuccess ||                 // -1 = no patch
         hipHostMalloc((void**)&h->h_counter, sizeof(int)) != hipSuccess ||
@@ -435,7 +550,7 @@ void jg_nr_destroy(jg_nr* h) {
     hipFree(h->d_vm); hipFree(h->d_va); hipFree(h->d_p); hipFree(h->d_q); hipFree(h->d_ppos); hipFree(h->d_pdg);
     hipFree(h->d_pdb); hipFree(h->d_A); hipFree(h->d_F); hipFree(h->d_inc); hipFree(h->d_part); hipFree(h->d_normp);
     hipFree(h->d_normq); hipFree(h->d_params); hipFree(h->d_active); hipFree(h->d_iters); hipFree(h->d_status);
-    hipFree(h->d_counter); hipFree(h->d_vm0); hipFree(h->d_va0); hipFree(h->d_group);
+    hipFree(h->d_counter); hipFree(h->d_vm0); hipFree(h->d_va0); hipFree(h->d_group); hipFree(h->d_lid); hipFree(h->d_dest); hipFree(h->d_cflags); hipFree(h->d_itmp);
     if (h->h_counter) hipHostFree(h->h_counter);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -596,14 +711,34 @@ int jg_nr_run(jg_nr* h, int64_t max_iter, double tol, int32_t* iters, int32_t* s
     NR_HIP(hipMemcpyAsync(h->d_params, params, sizeof(params), hipMemcpyHostToDevice, h->stream));
     NR_HIP(hipMemsetAsync(h->d_iters, 0, (size_t)h->ld * 4, h->stream));      // acPowerFlow.jl:1401
     NR_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
+    {   // every real scenario starts active, lanes in home order, all groups in use
+        std::vector<int> act(h->ld, 0), lid(h->ld);
+        for (int b = 0; b < h->ld; ++b) { act[b] = b < h->batch; lid[b] = b; }
+        const int cf[4] = {0, h->batch, h->ld / 64, 0};
+        NR_HIP(hipMemcpyAsync(h->d_active, act.data(), (size_t)h->ld * 4, hipMemcpyHostToDevice, h->stream));
+        NR_HIP(hipMemcpyAsync(h->d_lid, lid.data(), (size_t)h->ld * 4, hipMemcpyHostToDevice, h->stream));
+        NR_HIP(hipMemcpyAsync(h->d_cflags, cf, sizeof(cf), hipMemcpyHostToDevice, h->stream));
+        std::vector<int> grp(h->ld / 64, 1);
+        NR_HIP(hipMemcpyAsync(h->d_group, grp.data(), grp.size() * 4, hipMemcpyHostToDevice, h->stream));
+        NR_HIP(hipStreamSynchronize(h->stream));
+    }
+    const bool trace = getenv("JG_TRACE") != nullptr;
     for (int64_t it = 0; it <= max_iter; ++it) {                               // acPowerFlow.jl:1406
         NR_HIP(hipGraphLaunch(h->execA, h->stream));
         NR_HIP(hipStreamSynchronize(h->stream));
+        if (trace) {
+            int cf[4];
+            hipMemcpy(cf, h->d_cflags, sizeof(cf), hipMemcpyDeviceToHost);
+            fprintf(stderr, "[jg_nr_run] iteration %lld: %d scenarios still active, %d of %d lane groups in use%s\n", (long long)it,
+                    *h->h_counter, cf[2], h->ld / 64, cf[0] ? " (compacted)" : "");
+        }
         if (*h->h_counter == 0) break;
         NR_HIP(hipGraphLaunch(h->execB, h->stream));
     }
+    launch_compact(h, 1);                                                      // lanes back to their home order
+    NR_HIP(hipGetLastError());
     NR_HIP(hipStreamSynchronize(h->stream));
-    h->jac_valid = true;
+    h->jac_valid = false;
     if (iters) NR_HIP(hipMemcpy(iters, h->d_iters, (size_t)h->batch * 4, hipMemcpyDeviceToHost));
     if (status) NR_HIP(hipMemcpy(status, h->d_status, (size_t)h->batch * 4, hipMemcpyDeviceToHost));
     return 0;
@@ -646,6 +781,7 @@ int jg_nr_get_increment(jg_nr* h, double* incr) {
 int jg_nr_get_jacobian(jg_nr* h, double* nzval) {
     if (!h || !nzval) return fail(1, "jg_nr_get_jacobian: bad argument");
     if (int rc = set_device(h)) return rc;
+    if (!h->jac_valid) { launch_assemble(h); h->jac_valid = true; }      // Jacobian at the current state
     NR_HIP(hipStreamSynchronize(h->stream));
     std::vector<double> t((size_t)h->nnz * 4 * h->ld);
     NR_HIP(hipMemcpy(t.data(), h->d_A, t.size() * 8, hipMemcpyDeviceToHost));
