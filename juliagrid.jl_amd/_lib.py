@@ -131,5 +131,5 @@ class Plan:
 
     def schedule(self, kind):
         base = {"fact": 20, "bwd": 40}[kind]
-        return dict(launches=self.get(base).reshape(-1, 7), task_ptr=self.get(base + 1),
+        return dict(launches=self.get(base).reshape(-1, 8), step_wpi=self.get(base + 4), task_ptr=self.get(base + 1),
                     step_ptr=self.get(base + 2), items=self.get(base + 3))

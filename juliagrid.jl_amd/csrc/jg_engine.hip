@@ -207,8 +207,42 @@ __device__ __forceinline__ void row_terms(const BwdArgs& a, int p0, int p1, int 
     }
 }
 
+// One backward item (pivot row) handled by `wpi` cooperating waves; contains the two workgroup barriers of
+// the LDS reduction when SPLIT.
+template <bool SPLIT>
+__device__ __forceinline__ void bwd_item(const BwdArgs& a, double* red, int idx, bool valid, int wave, int sub, int wpi,
+                                         size_t b, size_t ld, bool act, int lane) {
+    double y0 = 0.0, y1 = 0.0;
+    int k = 0, bus = 0, dg = 0;
+    if (valid) {
+        const ItemDesc* dp = a.desc + idx;
+        k = uniform(dp->id); bus = uniform(dp->src); dg = uniform(dp->aux);
+        const int p0 = uniform(dp->t0), p1 = uniform(dp->t1);
+        if (sub == 0) { y0 = a.W[((size_t)k * 2) * ld + b]; y1 = a.W[((size_t)k * 2 + 1) * ld + b]; }
+        row_terms<4>(a, p0 + sub, p1, wpi, b, ld, y0, y1);
+        if (SPLIT && sub != 0) { red[(size_t)wave * 128 + lane] = y0; red[(size_t)wave * 128 + 64 + lane] = y1; }
+    }
+    if (SPLIT) __syncthreads();
+    if (valid && sub == 0) {
+        if (SPLIT)
+            for (int w = 1; w < wpi; ++w) { y0 += red[(size_t)(wave + w) * 128 + lane]; y1 += red[(size_t)(wave + w) * 128 + 64 + lane]; }
+        const Blk d = load_blk(a.X + (size_t)dg * 4 * ld + b, ld);
+        double x0, x1;
+        dsolve(d, y0, y1, x0, x1);
+        a.W[((size_t)k * 2) * ld + b] = x0;
+        a.W[((size_t)k * 2 + 1) * ld + b] = x1;
+        a.out[((size_t)bus * 2) * ld + b] = x0;
+        a.out[((size_t)bus * 2 + 1) * ld + b] = x1;
+        if (a.upd.va) {
+            const int fl = uniform((int)a.upd.flags[bus]);
+            if (act && (fl & 1)) a.upd.va[(size_t)bus * ld + b] += a.upd.sign * x0;
+            if (act && (fl & 2)) a.upd.vm[(size_t)bus * ld + b] += a.upd.sign * x1;
+        }
+    }
+}
+
 // Backward sweep: x_k = Dinv_k (y_k - sum_c U(k,c) x_c), scattered to original order; optional fused
-// state update (Newton-Raphson: V/theta -= increment on active scenarios).
+// state update (Newton-Raphson: V/theta -= increment on active scenarios).  One dependency level per launch.
 template <bool SPLIT>
 __global__ __launch_bounds__(SPLIT ? 1024 : 256) void k_bwd(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) double red[];   // SPLIT: [W][2][64]
@@ -223,42 +257,47 @@ __global__ __launch_bounds__(SPLIT ? 1024 : 256) void k_bwd(BwdArgs a) {
     const bool act = a.upd.active ? (a.upd.active[b] != 0) : true;
     for (int r = 0; r < a.rounds; ++r) {
         const int idx = a.item_begin + (blockIdx.x * a.rounds + r) * slots + slot;
-        const bool valid = idx < a.item_end;
-        double y0 = 0.0, y1 = 0.0;
-        int k = 0, bus = 0, dg = 0;
-        if (valid) {
-            const ItemDesc* dp = a.desc + idx;
-            k = uniform(dp->id); bus = uniform(dp->src); dg = uniform(dp->aux);
-            const int p0 = uniform(dp->t0), p1 = uniform(dp->t1);
-            if (sub == 0) { y0 = a.W[((size_t)k * 2) * ld + b]; y1 = a.W[((size_t)k * 2 + 1) * ld + b]; }
-            row_terms<4>(a, p0 + sub, p1, wpi, b, ld, y0, y1);
-            if (SPLIT && sub != 0) { red[(size_t)wave * 128 + lane] = y0; red[(size_t)wave * 128 + 64 + lane] = y1; }
-        }
-        if (SPLIT) __syncthreads();
-        if (valid && sub == 0) {
-            if (SPLIT)
-                for (int w = 1; w < wpi; ++w) { y0 += red[(size_t)(wave + w) * 128 + lane]; y1 += red[(size_t)(wave + w) * 128 + 64 + lane]; }
-            const Blk d = load_blk(a.X + (size_t)dg * 4 * ld + b, ld);
-            double x0, x1;
-            dsolve(d, y0, y1, x0, x1);
-            a.W[((size_t)k * 2) * ld + b] = x0;
-            a.W[((size_t)k * 2 + 1) * ld + b] = x1;
-            a.out[((size_t)bus * 2) * ld + b] = x0;
-            a.out[((size_t)bus * 2 + 1) * ld + b] = x1;
-            if (a.upd.va) {
-                const int fl = uniform((int)a.upd.flags[bus]);
-                if (act && (fl & 1)) a.upd.va[(size_t)bus * ld + b] += a.upd.sign * x0;
-                if (act && (fl & 2)) a.upd.vm[(size_t)bus * ld + b] += a.upd.sign * x1;
-            }
-        }
+        bwd_item<SPLIT>(a, red, idx, idx < a.item_end, wave, sub, wpi, b, ld, act, lane);
         if (SPLIT && r + 1 < a.rounds) __syncthreads();
     }
 }
 
-void flatten(const Schedule& s, std::vector<DevLaunch>& out) {
+// The narrow leading levels of the backward sweep (the dense tail of the elimination order: 1-4 rows per
+// level) in ONE launch: one 16-wave workgroup per scenario group walks the levels as barrier-separated steps.
+__global__ __launch_bounds__(1024) void k_bwd_fused(BwdArgs a, const int* steps, int n_steps) {
+    extern __shared__ __attribute__((aligned(16))) double red[];   // [16][2][64]
+    if (a.group_active && !a.group_active[blockIdx.y]) return;
+    const int lane = threadIdx.x;
+    const int wave = uniform(threadIdx.y);
+    const size_t ld = (size_t)a.ld;
+    const size_t b = (size_t)blockIdx.y * 64 + lane;
+    const bool act = a.upd.active ? (a.upd.active[b] != 0) : true;
+    for (int s = 0; s < n_steps; ++s) {
+        const int ib = uniform(steps[3 * s]), ie = uniform(steps[3 * s + 1]), wpi = uniform(steps[3 * s + 2]);
+        const int slots = 16 / wpi;
+        const int slot = wave / wpi, sub = wave - slot * wpi;
+        for (int base = ib; base < ie; base += slots) {
+            const int idx = base + slot;
+            bwd_item<true>(a, red, idx, idx < ie, wave, sub, wpi, b, ld, act, lane);
+            __syncthreads();                       // LDS reuse + makes this level's x visible to the next step
+        }
+    }
+}
+
+void flatten(const Schedule& s, std::vector<DevLaunch>& out, std::vector<int>* step_table = nullptr) {
     out.clear();
     for (const Launch& L : s.launches) {
         DevLaunch d;
+        if (L.fused && step_table) {
+            d.item_begin = L.item_begin; d.item_end = L.item_end; d.waves = L.waves; d.wpi = 1; d.rounds = 1; d.grid = 1;
+            d.fused = 1; d.step0 = (int)step_table->size() / 3;
+            for (int st = s.task_ptr[L.task_begin]; st < s.task_ptr[L.task_begin + 1]; ++st) {
+                step_table->push_back(s.step_ptr[st]); step_table->push_back(s.step_ptr[st + 1]); step_table->push_back(s.step_wpi[st]);
+            }
+            d.n_steps = (int)step_table->size() / 3 - d.step0;
+            out.push_back(d);
+            continue;
+        }
         d.item_begin = L.item_begin; d.item_end = L.item_end;
         d.waves = L.waves; d.wpi = L.wpi;
         const int slots = L.waves / L.wpi;
@@ -302,7 +341,9 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, int policy
         bd[i] = d;
     }
     flatten(S.fact, fact);
-    flatten(S.bwd, bwd);
+    std::vector<int> bsteps;
+    flatten(S.bwd, bwd, &bsteps);
+    if (upload(&bwd_steps, bsteps, error)) return 2;
     if (upload(&fact_desc, fd, error) || upload(&bwd_desc, bd, error) || upload(&ta, va, error) || upload(&td, vd, error) ||
         upload(&tb, vb, error) || upload(&u_ent, S.u_ent, error) || upload(&u_col, S.u_col, error))
         return 2;
@@ -316,7 +357,7 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, int policy
 }
 
 void Engine::destroy() {
-    hipFree(fact_desc); hipFree(bwd_desc); hipFree(ta); hipFree(td); hipFree(tb); hipFree(u_ent); hipFree(u_col);
+    hipFree(fact_desc); hipFree(bwd_desc); hipFree(ta); hipFree(td); hipFree(tb); hipFree(u_ent); hipFree(u_col); hipFree(bwd_steps); bwd_steps = nullptr;
     hipFree(X); hipFree(W); hipFree(status);
     fact_desc = bwd_desc = nullptr;
     ta = td = tb = u_ent = u_col = status = nullptr;
@@ -340,6 +381,7 @@ int Engine::backsolve(hipStream_t st, double* out, const StateUpdate& upd, const
     for (const DevLaunch& L : bwd) {
         a.item_begin = L.item_begin; a.item_end = L.item_end; a.wpi = L.wpi; a.rounds = L.rounds;
         dim3 grid(L.grid, ld / 64), block(64, L.waves);
+        if (L.fused) { hipLaunchKernelGGL(k_bwd_fused, grid, block, (size_t)16 * 128 * sizeof(double), st, a, bwd_steps + 3 * L.step0, L.n_steps); continue; }
         if (L.wpi == 1) hipLaunchKernelGGL(k_bwd<false>, grid, block, 0, st, a);
         else hipLaunchKernelGGL(k_bwd<true>, grid, block, (size_t)L.waves * 128 * sizeof(double), st, a);
     }

@@ -32,6 +32,7 @@ struct DevLaunch {
     int item_begin, item_end;   // range in the descriptor array
     int waves, wpi, rounds;     // blockDim.y, waves per item, items per slot
     int grid;                   // workgroups along x
+    int fused = 0, n_steps = 0, step0 = 0;   // fused launch: step table rows [step0, step0 + n_steps) of {begin, end, wpi}
 };
 
 // Optional state update fused into the backward solve (NR: x <- x - dx, masked by bus flags).
@@ -50,6 +51,7 @@ struct Engine {
     ItemDesc* bwd_desc = nullptr;
     int* ta = nullptr; int* td = nullptr; int* tb = nullptr;   // LU terms followed by rhs-row terms
     int* u_ent = nullptr; int* u_col = nullptr;
+    int* bwd_steps = nullptr;     // {item_begin, item_end, wpi} per step of fused backward launches
     double* X = nullptr;           // factor values [n_entries][4][ld]: U, unscaled Lh, factored diagonal blocks
     double* W = nullptr;           // [n][2][ld] pivot order: y after factor(), x after backsolve()
     int* status = nullptr;         // [ld] bit 2 set on zero / non-finite pivot

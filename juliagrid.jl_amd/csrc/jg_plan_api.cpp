@@ -15,7 +15,7 @@ struct jg_plan {
 namespace {
 void flatten(const jg::Schedule& s, std::vector<int>& launch) {
     launch.clear();
-    for (const jg::Launch& L : s.launches) { launch.push_back(L.task_begin); launch.push_back(L.task_end); launch.push_back(L.waves); launch.push_back(L.wpi); launch.push_back(L.chunk); launch.push_back(L.item_begin); launch.push_back(L.item_end); }
+    for (const jg::Launch& L : s.launches) { launch.push_back(L.task_begin); launch.push_back(L.task_end); launch.push_back(L.waves); launch.push_back(L.wpi); launch.push_back(L.chunk); launch.push_back(L.item_begin); launch.push_back(L.item_end); launch.push_back(L.fused); }
 }
 }  // namespace
 
@@ -34,7 +34,7 @@ void jg_plan_destroy(jg_plan* p) { delete p; }
 // which: 0 perm, 1 e_row, 2 e_col, 3 e_src, 4 t_ptr, 5 t_a, 6 t_b, 7 e_level, 8 e_diag, 9 diag,
 //        10 l_ptr, 11 l_ent, 12 l_col, 13 u_ptr, 14 u_ent, 15 u_col,
 //        16 t_d, 17 y_level
-//        20/40 + k: schedule fact (factorisation + fused forward elimination) / bwd: k=0 launches (task begin,end, waves, wpi, chunk, item begin,end) x7, 1 task_ptr, 2 step_ptr, 3 items
+//        20/40 + k: schedule fact (factorisation + fused forward elimination) / bwd: k=0 launches (task begin,end, waves, wpi, chunk, item begin,end, fused) x8; 4 step_wpi, 1 task_ptr, 2 step_ptr, 3 items
 // out == NULL returns the length.
 int64_t jg_plan_export(jg_plan* p, int which, int32_t* out, int64_t cap) {
     if (!p) return -1;
@@ -56,6 +56,7 @@ int64_t jg_plan_export(jg_plan* p, int which, int32_t* out, int64_t cap) {
                 case 1: v = &s->task_ptr; break;
                 case 2: v = &s->step_ptr; break;
                 case 3: v = &s->items; break;
+                case 4: v = &s->step_wpi; break;
                 default: return -1;
             }
         }

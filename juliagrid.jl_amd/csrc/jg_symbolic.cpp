@@ -67,7 +67,7 @@ int find_in_row(const BlockSymbolic& S, int r, int c) {
 // One launch per level.  Levels whose items carry long update lists (the dense tail of the
 // elimination order) get several waves per item: the list is split across `wpi` waves and reduced
 // through LDS, so the critical path of a level is ~ (terms / wpi) memory round trips instead of `terms`.
-void schedule_by_level(const std::vector<int>& level, const std::vector<int>& work, int n_items, Schedule& sch) {
+void schedule_by_level(const std::vector<int>& level, const std::vector<int>& work, int n_items, Schedule& sch, bool fuse_narrow_prefix = false) {
     int nlev = 0;
     for (int i = 0; i < n_items; ++i) nlev = std::max(nlev, level[i]);
     std::vector<int> cnt(nlev + 2, 0);
@@ -82,7 +82,41 @@ void schedule_by_level(const std::vector<int>& level, const std::vector<int>& wo
     sch.task_ptr.assign(1, 0);
     sch.step_ptr.assign(1, 0);
     sch.launches.clear();
-    for (int l = 1; l <= nlev; ++l) {
+    sch.step_wpi.clear();
+    int first_level = 1;
+    if (fuse_narrow_prefix) {
+        // Leading levels that are narrow (a handful of items, short lists) are latency-bound: a launch per level
+        // costs more than the work.  One workgroup of 16 waves per scenario group walks them as steps.
+        constexpr int FW = 16;
+        int last = 0;
+        for (int l = 1; l <= nlev; ++l) {
+            int items = cnt[l + 1] - cnt[l], tot = 0;
+            for (int i = cnt[l]; i < cnt[l + 1]; ++i) tot += work[sch.items[i]];
+            if (items == 0) continue;
+            if (items > FW || tot > 64 * FW) break;
+            last = l;
+        }
+        if (last >= 2) {
+            Launch L;
+            L.fused = 1; L.waves = FW; L.wpi = 1; L.chunk = 0;
+            L.task_begin = (int)sch.task_ptr.size() - 1;
+            L.item_begin = cnt[1]; L.item_end = cnt[last + 1];
+            for (int l = 1; l <= last; ++l) {
+                int b = cnt[l], e = cnt[l + 1];
+                if (b == e) continue;
+                std::stable_sort(sch.items.begin() + b, sch.items.begin() + e, [&](int x, int y) { return work[x] > work[y]; });
+                int wpi = 1;
+                while (wpi * 2 * (e - b) <= FW && work[sch.items[b]] > 2 * wpi) wpi *= 2;
+                sch.step_ptr.push_back(e);
+                sch.step_wpi.push_back(wpi);
+            }
+            sch.task_ptr.push_back((int)sch.step_ptr.size() - 1);
+            L.task_end = (int)sch.task_ptr.size() - 1;
+            sch.launches.push_back(L);
+            first_level = last + 1;
+        }
+    }
+    for (int l = first_level; l <= nlev; ++l) {
         int b = cnt[l], e = cnt[l + 1];
         if (b == e) continue;
         // heaviest items first inside the level (they start first on the device)
@@ -99,6 +133,7 @@ void schedule_by_level(const std::vector<int>& level, const std::vector<int>& wo
         L.chunk = chunk; L.item_begin = b; L.item_end = e;
         for (int s = b; s < e; s += chunk) {
             sch.step_ptr.push_back(std::min(s + chunk, e));
+            sch.step_wpi.push_back(wpi);
             sch.task_ptr.push_back((int)sch.step_ptr.size() - 1);
         }
         L.task_end = (int)sch.task_ptr.size() - 1;
@@ -262,7 +297,7 @@ int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic&
             uw[r] = S.u_ptr[r + 1] - S.u_ptr[r];
         }
         schedule_by_level(level, work, S.n_entries + n, S.fact);
-        schedule_by_level(S.bwd_level, uw, n, S.bwd);
+        schedule_by_level(S.bwd_level, uw, n, S.bwd, /*fuse_narrow_prefix=*/true);
     }
     return 0;
 }

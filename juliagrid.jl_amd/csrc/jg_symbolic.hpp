@@ -22,6 +22,8 @@ struct Launch {
     int wpi = 1;                        // waves cooperating on ONE item (its update terms are split across
                                         // them and reduced through LDS); wpi > 1 => single-step tasks
     int chunk = 1;                      // items per task (the last task of a launch may hold fewer)
+    int fused = 0;                      // 1: ONE task (one workgroup per scenario group) walks several narrow
+                                        //    dependency levels as barrier-separated steps (step_wpi per step)
     int item_begin = 0, item_end = 0;   // the launch's contiguous range in Schedule::items
 };
 
@@ -31,6 +33,7 @@ struct Schedule {
     std::vector<int> task_ptr;          // steps of task t: [task_ptr[t], task_ptr[t+1])
     std::vector<int> step_ptr;          // items of step s: [step_ptr[s], step_ptr[s+1])
     std::vector<int> items;             // entry ids (LU) or pivot ids (solves)
+    std::vector<int> step_wpi;          // waves per item of every step (1 unless the step belongs to a fused launch)
     int n_levels = 0;
 };
 

@@ -10,7 +10,7 @@ import numpy as np
 
 def _walk(sch):
     """yield (launch_index, task, step, item)"""
-    for li, (t0, t1, _w, _wpi, _chunk, _ib, _ie) in enumerate(sch["launches"]):
+    for li, (t0, t1, _w, _wpi, _chunk, _ib, _ie, _fused) in enumerate(sch["launches"]):
         for t in range(t0, t1):
             for s in range(sch["task_ptr"][t], sch["task_ptr"][t + 1]):
                 for idx in range(sch["step_ptr"][s], sch["step_ptr"][s + 1]):

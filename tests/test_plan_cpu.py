@@ -76,7 +76,15 @@ def test_plan_structure_invariants(jg):
         assert L[0, 0] == 0 and L[-1, 1] == sch["task_ptr"].size - 1
         assert np.all(L[1:, 0] == L[:-1, 1])
         assert L[0, 5] == 0 and L[-1, 6] == nitems and np.all(L[1:, 5] == L[:-1, 6])
-        for t0, t1, waves, wpi, chunk, ib, ie in L:
+        for t0, t1, waves, wpi, chunk, ib, ie, fused in L:
+            if fused:                            # one task walking several narrow levels as steps
+                assert t1 == t0 + 1 and waves == 16
+                s0, s1 = sch["task_ptr"][t0], sch["task_ptr"][t1]
+                assert sch["step_ptr"][s0] == ib and sch["step_ptr"][s1] == ie and s1 - s0 >= 2
+                for st in range(s0, s1):
+                    w, cnt = sch["step_wpi"][st], sch["step_ptr"][st + 1] - sch["step_ptr"][st]
+                    assert 16 % w == 0 and cnt >= 1
+                continue
             assert waves % wpi == 0 and (wpi == 1 or chunk == waves // wpi) and chunk % (waves // wpi) == 0
             for k, t in enumerate(range(t0, t1)):
                 s0, s1 = sch["task_ptr"][t], sch["task_ptr"][t + 1]
