@@ -161,13 +161,24 @@ struct CheckArgs {
     int mode;                  // 0 = norms only, 1 = powerFlow! loop control
 };
 
-__global__ void k_check(CheckArgs a) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= a.ld) return;
-    if (a.mode == 1 && a.group && !a.group[b >> 6]) return;       // finished group: assembly was skipped, keep its verdict
+// blockDim (64, 16): one workgroup per 64-scenario group; the 16 waves split the per-chunk partial norms
+__global__ __launch_bounds__(1024) void k_check(CheckArgs a) {
+    __shared__ double red[2][16][64];
+    const int lane = threadIdx.x, wave = threadIdx.y;
+    const int b = blockIdx.x * 64 + lane;
+    if (a.mode == 1 && a.group && !a.group[blockIdx.x]) return;   // finished group: assembly was skipped, keep its verdict
     double mp = 0.0, mq = 0.0;
-    for (int c = 0; c < a.nchunk; ++c) {
+    for (int c = wave; c < a.nchunk; c += 16) {
         const double x = a.part[((size_t)c * 2) * a.ld + b], y = a.part[((size_t)c * 2 + 1) * a.ld + b];
+        mp = (x > mp || x != x) ? x : mp;
+        mq = (y > mq || y != y) ? y : mq;
+    }
+    red[0][wave][lane] = mp;
+    red[1][wave][lane] = mq;
+    __syncthreads();
+    if (wave != 0) return;
+    for (int w = 1; w < 16; ++w) {
+        const double x = red[0][w][lane], y = red[1][w][lane];
         mp = (x > mp || x != x) ? x : mp;
         mq = (y > mq || y != y) ? y : mq;
     }
@@ -338,7 +349,7 @@ void launch_assemble(jg_nr* h, const int* group = nullptr, bool jac = true) {
 void launch_check(jg_nr* h, int mode, const int* group = nullptr) {
     CheckArgs c{h->d_part, h->nchunk, h->ld, h->batch, h->d_params, h->d_normp, h->d_normq, h->d_active,
                 h->d_iters, h->d_status, h->eng.status, h->d_counter, group, mode};
-    hipLaunchKernelGGL(k_check, dim3((h->ld + 255) / 256), dim3(256), 0, h->stream, c);
+    hipLaunchKernelGGL(k_check, dim3(h->ld / 64), dim3(64, 16), 0, h->stream, c);
 }
 
 // host [batch][n] (or one [n] broadcast) -> device [n][ld]
