@@ -1,34 +1,39 @@
 // jg_engine.hip -- device kernels of the batched block-sparse LU engine (gfx950, wave64).
 //
 // Factorisation A = Lh * inv(D) * U (Lh unscaled, D kept as 2x2 LU factors) with the forward elimination of the right-hand
-// side fused into the same launches, then one backward sweep.  Every launch replays one dependency
-// level of the static schedule (jg_symbolic): blockDim = (64 lanes = 64 scenarios, W waves),
-// blockIdx.y = 64-scenario group.  `wpi` waves cooperate on one item: its update list is dealt out
-// round-robin, partial sums meet in LDS and are added in a fixed order (run-to-run deterministic).
-// All structural data is wave-uniform: one 32-byte descriptor per item through the scalar cache;
-// the vector memory pipe only moves 512-byte contiguous value segments.
+// side fused in, then one backward sweep.  Lanes = 64 scenarios of one group; a wave works on one structural item, `wpi`
+// waves share an item's update list (dealt round-robin, partial sums meet in LDS in a fixed order => bitwise
+// run-to-run determinism).
+//
+// Replay tables (jg_symbolic.hpp): each wave's work is a 64-byte RECORD whose address follows from
+// (segment, chunk, wave) arithmetic, fetched with ONE scalar load -- no descriptor -> index -> value pointer chase
+// (that chain cost ~10 us per item, measured).  Two executors replay the same tables:
+//   * per-level launches  (k_fact_level / k_bwd_level): one kernel per dependency level, whole chip per level;
+//   * persistent walker   (k_fact_walk / k_bwd_walk):   ONE launch, XCD teams, team-local level barriers (~0.7 us),
+//     records prefetched one chunk ahead -- across barriers too, the tables are static.
 #include "jg_engine.hpp"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
 
 namespace jg {
 
 namespace {
 
 struct FactArgs {
-    const ItemDesc* desc; const int* ta; const int* td; const int* tb;
-    const double* A; const double* rhs; double* X; double* W; int* status; const int* group_active;
-    int item_begin, item_end, wpi, rounds, ld;
+    const Rec* rec; const Segment* seg;
+    const double* A; const double* rhs; double* X; double* W; int* status; GroupSel sel;
+    int ld, seg_begin;         // per-level launches: blockIdx.y selects the level's segment seg_begin + y
 };
 
 struct BwdArgs {
-    const ItemDesc* desc; const int* u_ent; const int* u_col;
-    const double* X; double* W; double* out; const int* group_active;
+    const Rec* rec; const Segment* seg;
+    const double* X; double* W; double* out; GroupSel sel;
     StateUpdate upd;
-    int item_begin, item_end, wpi, rounds, ld;
+    int ld, seg_begin;
 };
-
-__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 struct Blk { double v00, v01, v10, v11; };
 
@@ -58,58 +63,43 @@ __device__ __forceinline__ void term3(Blk& c, const Blk& l, const Blk& d, const 
     c.v11 -= l.v10 * z01 + l.v11 * z11;
 }
 
-template <int UNROLL>
-__device__ __forceinline__ void lu_terms(const FactArgs& a, int t0, int t1, int stride, size_t b, size_t ld, Blk& c) {
-    int t = t0;
-    for (; t + (UNROLL - 1) * stride < t1; t += UNROLL * stride) {
-        Blk l[UNROLL], d[UNROLL], u[UNROLL];
-#pragma unroll
-        for (int k = 0; k < UNROLL; ++k) {
-            l[k] = load_blk(a.X + (size_t)uniform(a.ta[t + k * stride]) * 4 * ld + b, ld);
-            d[k] = load_blk(a.X + (size_t)uniform(a.td[t + k * stride]) * 4 * ld + b, ld);
-            u[k] = load_blk(a.X + (size_t)uniform(a.tb[t + k * stride]) * 4 * ld + b, ld);
-        }
-#pragma unroll
-        for (int k = 0; k < UNROLL; ++k) term3(c, l[k], d[k], u[k]);
-    }
-    for (; t < t1; t += stride) {
-        const Blk l = load_blk(a.X + (size_t)uniform(a.ta[t]) * 4 * ld + b, ld);
-        const Blk d = load_blk(a.X + (size_t)uniform(a.td[t]) * 4 * ld + b, ld);
-        const Blk u = load_blk(a.X + (size_t)uniform(a.tb[t]) * 4 * ld + b, ld);
-        term3(c, l, d, u);
-    }
-}
+// 64-byte record through the scalar cache: ONE s_load_dwordx16 into 16 SGPRs.  The tables are immutable for the
+// life of the engine, so they are read through the constant address space -- that is what lets the compiler keep the
+// load scalar inside loops that also store (the factor values), and hoist the prefetch of the next record.
+typedef int RecS __attribute__((ext_vector_type(16)));
+typedef const RecS __attribute__((address_space(4)))* RecPtr;
+__device__ __forceinline__ RecS load_rec(const Rec* base, size_t index) { return ((RecPtr)base)[index]; }
+__device__ __forceinline__ int rec_word(const RecS& r, int k) { return r[k]; }
 
-// y -= Lh(a) * Dinv(d) * y_c
-template <int UNROLL>
-__device__ __forceinline__ void rhs_terms(const FactArgs& a, int t0, int t1, int stride, size_t b, size_t ld, double& y0, double& y1) {
-    int t = t0;
-    for (; t + (UNROLL - 1) * stride < t1; t += UNROLL * stride) {
-        Blk l[UNROLL], d[UNROLL]; double w0[UNROLL], w1[UNROLL];
+// one record of a factorisation item: up to FACT_T update terms, every operand load issued before the first use
+__device__ __forceinline__ void fact_record(const FactArgs& a, const RecS& r, int kind, size_t b, size_t ld, Blk& c) {
+    const int nt = rec_word(r, 3);
+    Blk l[FACT_T], d[FACT_T], u[FACT_T];
 #pragma unroll
-        for (int k = 0; k < UNROLL; ++k) {
-            l[k] = load_blk(a.X + (size_t)uniform(a.ta[t + k * stride]) * 4 * ld + b, ld);
-            d[k] = load_blk(a.X + (size_t)uniform(a.td[t + k * stride]) * 4 * ld + b, ld);
-            const double* pw = a.W + (size_t)uniform(a.tb[t + k * stride]) * 2 * ld + b;
-            w0[k] = pw[0]; w1[k] = pw[ld];
-        }
-#pragma unroll
-        for (int k = 0; k < UNROLL; ++k) {
-            double z0, z1;
-            dsolve(d[k], w0[k], w1[k], z0, z1);
-            y0 -= l[k].v00 * z0 + l[k].v01 * z1;
-            y1 -= l[k].v10 * z0 + l[k].v11 * z1;
+    for (int t = 0; t < FACT_T; ++t) {
+        if (t < nt) {
+            l[t] = load_blk(a.X + (size_t)rec_word(r, 4 + 3 * t) * 4 * ld + b, ld);
+            d[t] = load_blk(a.X + (size_t)rec_word(r, 5 + 3 * t) * 4 * ld + b, ld);
+            if (kind == 3) {
+                const double* pw = a.W + (size_t)rec_word(r, 6 + 3 * t) * 2 * ld + b;
+                u[t].v00 = pw[0]; u[t].v10 = pw[ld]; u[t].v01 = 0.0; u[t].v11 = 0.0;
+            } else {
+                u[t] = load_blk(a.X + (size_t)rec_word(r, 6 + 3 * t) * 4 * ld + b, ld);
+            }
         }
     }
-    for (; t < t1; t += stride) {
-        const Blk l = load_blk(a.X + (size_t)uniform(a.ta[t]) * 4 * ld + b, ld);
-        const Blk d = load_blk(a.X + (size_t)uniform(a.td[t]) * 4 * ld + b, ld);
-        const double* pw = a.W + (size_t)uniform(a.tb[t]) * 2 * ld + b;
-        const double w0 = pw[0], w1 = pw[ld];
-        double z0, z1;
-        dsolve(d, w0, w1, z0, z1);
-        y0 -= l.v00 * z0 + l.v01 * z1;
-        y1 -= l.v10 * z0 + l.v11 * z1;
+#pragma unroll
+    for (int t = 0; t < FACT_T; ++t) {
+        if (t < nt) {
+            if (kind == 3) {          // y -= Lh(a) * D(d)^-1 * y_c
+                double z0, z1;
+                dsolve(d[t], u[t].v00, u[t].v10, z0, z1);
+                c.v00 -= l[t].v00 * z0 + l[t].v01 * z1;
+                c.v01 -= l[t].v10 * z0 + l[t].v11 * z1;
+            } else {
+                term3(c, l[t], d[t], u[t]);
+            }
+        }
     }
 }
 
@@ -135,98 +125,82 @@ __device__ __forceinline__ void fact_finish(const FactArgs& a, int kind, int id,
     }
 }
 
-// One dependency level of  A = Lh inv(D) U  and  y = (Lh inv(D))^-1 rhs.
-template <bool SPLIT>
-__global__ __launch_bounds__(SPLIT ? 1024 : 256) void k_fact(FactArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double red[];   // SPLIT: [W][4][64]
-    if (a.group_active && !a.group_active[blockIdx.y]) return;
-    const int lane = threadIdx.x;
-    const int wave = uniform(threadIdx.y);
-    const size_t ld = (size_t)a.ld;
-    const size_t b = (size_t)blockIdx.y * 64 + lane;
-    const int wpi = SPLIT ? a.wpi : 1;
-    const int slots = blockDim.y / wpi;
-    const int slot = wave / wpi, sub = wave - slot * wpi;
-    for (int r = 0; r < a.rounds; ++r) {
-        const int idx = a.item_begin + (blockIdx.x * a.rounds + r) * slots + slot;
-        const bool valid = idx < a.item_end;
-        Blk c{0.0, 0.0, 0.0, 0.0};
-        int kind = 0, id = 0;
-        if (valid) {
-            const ItemDesc* dp = a.desc + idx;
-            kind = uniform(dp->kind); id = uniform(dp->id);
-            const int src = uniform(dp->src), t0 = uniform(dp->t0), t1 = uniform(dp->t1);
-            if (kind == 3) {
-                if (sub == 0) { c.v00 = a.rhs[((size_t)src * 2) * ld + b]; c.v01 = a.rhs[((size_t)src * 2 + 1) * ld + b]; }
-                rhs_terms<4>(a, t0 + sub, t1, wpi, b, ld, c.v00, c.v01);
-            } else {
-                if (sub == 0 && src >= 0) c = load_blk(a.A + (size_t)src * 4 * ld + b, ld);
-                lu_terms<3>(a, t0 + sub, t1, wpi, b, ld, c);
-            }
-            if (SPLIT && sub != 0) {
-                double* q = red + (size_t)wave * 256 + lane;
-                q[0] = c.v00; q[64] = c.v01; q[128] = c.v10; q[192] = c.v11;
-            }
+// One chunk (16 waves) of a factorisation segment for the 64 scenarios at lane offset b.  `first` is the wave's first
+// record (already loaded); its remaining rpw - 1 records follow it.  Two workgroup barriers when wpi > 1.
+__device__ __forceinline__ void fact_chunk(const FactArgs& a, double* red, const RecS& first, size_t rec_index, int rpw, int wpi,
+                                           int wave, int lane, size_t b, size_t ld) {
+    const int sub = wave & (wpi - 1);
+    const int kind = rec_word(first, 0), id = rec_word(first, 1), src = rec_word(first, 2);
+    Blk c{0.0, 0.0, 0.0, 0.0};
+    if (kind >= 0) {
+        if (sub == 0) {
+            if (kind == 3) { c.v00 = a.rhs[((size_t)src * 2) * ld + b]; c.v01 = a.rhs[((size_t)src * 2 + 1) * ld + b]; }
+            else if (src >= 0) c = load_blk(a.A + (size_t)src * 4 * ld + b, ld);
         }
-        if (SPLIT) __syncthreads();
-        if (valid && sub == 0) {
-            if (SPLIT)
-                for (int w = 1; w < wpi; ++w) {
-                    const double* q = red + (size_t)(wave + w) * 256 + lane;
-                    c.v00 += q[0]; c.v01 += q[64]; c.v10 += q[128]; c.v11 += q[192];
-                }
-            fact_finish(a, kind, id, b, ld, c);
+        fact_record(a, first, kind, b, ld, c);
+        for (int j = 1; j < rpw; ++j) {
+            const RecS r = load_rec(a.rec, rec_index + j);
+            fact_record(a, r, kind, b, ld, c);
         }
-        if (SPLIT && r + 1 < a.rounds) __syncthreads();
+        if (wpi > 1 && sub != 0) {
+            double* q = red + (size_t)wave * 256 + lane;
+            q[0] = c.v00; q[64] = c.v01; q[128] = c.v10; q[192] = c.v11;
+        }
+    }
+    if (wpi > 1) __syncthreads();
+    if (kind >= 0 && sub == 0) {
+        for (int w = 1; w < wpi; ++w) {
+            const double* q = red + (size_t)(wave + w) * 256 + lane;
+            c.v00 += q[0]; c.v01 += q[64]; c.v10 += q[128]; c.v11 += q[192];
+        }
+        fact_finish(a, kind, id, b, ld, c);
+    }
+    if (wpi > 1) __syncthreads();
+}
+
+__device__ __forceinline__ void bwd_record(const BwdArgs& a, const RecS& r, size_t b, size_t ld, double& y0, double& y1) {
+    const int nt = rec_word(r, 3);
+    Blk m[BWD_T]; double w0[BWD_T], w1[BWD_T];
+#pragma unroll
+    for (int t = 0; t < BWD_T; ++t) {
+        if (t < nt) {
+            m[t] = load_blk(a.X + (size_t)rec_word(r, 4 + 2 * t) * 4 * ld + b, ld);
+            const double* pw = a.W + (size_t)rec_word(r, 5 + 2 * t) * 2 * ld + b;
+            w0[t] = pw[0]; w1[t] = pw[ld];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < BWD_T; ++t) {
+        if (t < nt) {
+            y0 -= m[t].v00 * w0[t] + m[t].v01 * w1[t];
+            y1 -= m[t].v10 * w0[t] + m[t].v11 * w1[t];
+        }
     }
 }
 
-template <int UNROLL>
-__device__ __forceinline__ void row_terms(const BwdArgs& a, int p0, int p1, int stride, size_t b, size_t ld, double& y0, double& y1) {
-    int p = p0;
-    for (; p + (UNROLL - 1) * stride < p1; p += UNROLL * stride) {
-        Blk m[UNROLL]; double w0[UNROLL], w1[UNROLL];
-#pragma unroll
-        for (int k = 0; k < UNROLL; ++k) {
-            m[k] = load_blk(a.X + (size_t)uniform(a.u_ent[p + k * stride]) * 4 * ld + b, ld);
-            const double* pw = a.W + (size_t)uniform(a.u_col[p + k * stride]) * 2 * ld + b;
-            w0[k] = pw[0]; w1[k] = pw[ld];
-        }
-#pragma unroll
-        for (int k = 0; k < UNROLL; ++k) {
-            y0 -= m[k].v00 * w0[k] + m[k].v01 * w1[k];
-            y1 -= m[k].v10 * w0[k] + m[k].v11 * w1[k];
-        }
-    }
-    for (; p < p1; p += stride) {
-        const Blk m = load_blk(a.X + (size_t)uniform(a.u_ent[p]) * 4 * ld + b, ld);
-        const double* pw = a.W + (size_t)uniform(a.u_col[p]) * 2 * ld + b;
-        const double w0 = pw[0], w1 = pw[ld];
-        y0 -= m.v00 * w0 + m.v01 * w1;
-        y1 -= m.v10 * w0 + m.v11 * w1;
-    }
-}
-
-// One backward item (pivot row) handled by `wpi` cooperating waves; contains the two workgroup barriers of
-// the LDS reduction when SPLIT.
-template <bool SPLIT>
-__device__ __forceinline__ void bwd_item(const BwdArgs& a, double* red, int idx, bool valid, int wave, int sub, int wpi,
-                                         size_t b, size_t ld, bool act, int lane) {
+// One chunk of a backward segment: x_k = Dinv_k (y_k - sum_c U(k,c) x_c), scattered to original order; optional fused
+// state update (Newton-Raphson: V/theta -= increment on active scenarios).
+__device__ __forceinline__ void bwd_chunk(const BwdArgs& a, double* red, const RecS& first, size_t rec_index, int rpw, int wpi,
+                                          int wave, int lane, size_t b, size_t ld) {
+    const int sub = wave & (wpi - 1);
+    const int k = rec_word(first, 0), bus = rec_word(first, 1), dg = rec_word(first, 2);
     double y0 = 0.0, y1 = 0.0;
-    int k = 0, bus = 0, dg = 0;
-    if (valid) {
-        const ItemDesc* dp = a.desc + idx;
-        k = uniform(dp->id); bus = uniform(dp->src); dg = uniform(dp->aux);
-        const int p0 = uniform(dp->t0), p1 = uniform(dp->t1);
-        if (sub == 0) { y0 = a.W[((size_t)k * 2) * ld + b]; y1 = a.W[((size_t)k * 2 + 1) * ld + b]; }
-        row_terms<4>(a, p0 + sub, p1, wpi, b, ld, y0, y1);
-        if (SPLIT && sub != 0) { red[(size_t)wave * 128 + lane] = y0; red[(size_t)wave * 128 + 64 + lane] = y1; }
+    Blk d{0.0, 0.0, 0.0, 0.0};
+    if (k >= 0) {
+        if (sub == 0) {
+            y0 = a.W[((size_t)k * 2) * ld + b]; y1 = a.W[((size_t)k * 2 + 1) * ld + b];
+            d = load_blk(a.X + (size_t)dg * 4 * ld + b, ld);
+        }
+        bwd_record(a, first, b, ld, y0, y1);
+        for (int j = 1; j < rpw; ++j) {
+            const RecS r = load_rec(a.rec, rec_index + j);
+            bwd_record(a, r, b, ld, y0, y1);
+        }
+        if (wpi > 1 && sub != 0) { red[(size_t)wave * 128 + lane] = y0; red[(size_t)wave * 128 + 64 + lane] = y1; }
     }
-    if (SPLIT) __syncthreads();
-    if (valid && sub == 0) {
-        if (SPLIT)
-            for (int w = 1; w < wpi; ++w) { y0 += red[(size_t)(wave + w) * 128 + lane]; y1 += red[(size_t)(wave + w) * 128 + 64 + lane]; }
-        const Blk d = load_blk(a.X + (size_t)dg * 4 * ld + b, ld);
+    if (wpi > 1) __syncthreads();
+    if (k >= 0 && sub == 0) {
+        for (int w = 1; w < wpi; ++w) { y0 += red[(size_t)(wave + w) * 128 + lane]; y1 += red[(size_t)(wave + w) * 128 + 64 + lane]; }
         double x0, x1;
         dsolve(d, y0, y1, x0, x1);
         a.W[((size_t)k * 2) * ld + b] = x0;
@@ -234,79 +208,229 @@ __device__ __forceinline__ void bwd_item(const BwdArgs& a, double* red, int idx,
         a.out[((size_t)bus * 2) * ld + b] = x0;
         a.out[((size_t)bus * 2 + 1) * ld + b] = x1;
         if (a.upd.va) {
+            const bool act = a.upd.active ? (a.upd.active[b] != 0) : true;
             const int fl = uniform((int)a.upd.flags[bus]);
             if (act && (fl & 1)) a.upd.va[(size_t)bus * ld + b] += a.upd.sign * x0;
             if (act && (fl & 2)) a.upd.vm[(size_t)bus * ld + b] += a.upd.sign * x1;
         }
     }
+    if (wpi > 1) __syncthreads();
 }
 
-// Backward sweep: x_k = Dinv_k (y_k - sum_c U(k,c) x_c), scattered to original order; optional fused
-// state update (Newton-Raphson: V/theta -= increment on active scenarios).  One dependency level per launch.
-template <bool SPLIT>
-__global__ __launch_bounds__(SPLIT ? 1024 : 256) void k_bwd(BwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double red[];   // SPLIT: [W][2][64]
-    if (a.group_active && !a.group_active[blockIdx.y]) return;
+// ---- executor 1: one launch per dependency level ------------------------------------------------------------
+// grid.y = segments of the level (one per wpi class), grid.x = (most chunks of any of them) x group stride with the
+// scenario group fastest (jg::map_block); the segment header comes through the scalar cache.
+typedef int SegS __attribute__((ext_vector_type(8)));
+typedef const SegS __attribute__((address_space(4)))* SegPtr;
+
+template <bool BWD, class Args>
+__device__ __forceinline__ void level_body(const Args& a, double* red) {
+    const SegS sg = ((SegPtr)a.seg)[a.seg_begin + blockIdx.y];
+    const int base = sg[0], wpi = sg[2], rpw = sg[3];
+    int grp, bx;
+    if (!map_block(a.sel, a.ld, sg[1], grp, bx)) return;
     const int lane = threadIdx.x;
     const int wave = uniform(threadIdx.y);
     const size_t ld = (size_t)a.ld;
-    const size_t b = (size_t)blockIdx.y * 64 + lane;
-    const int wpi = SPLIT ? a.wpi : 1;
-    const int slots = blockDim.y / wpi;
-    const int slot = wave / wpi, sub = wave - slot * wpi;
-    const bool act = a.upd.active ? (a.upd.active[b] != 0) : true;
-    for (int r = 0; r < a.rounds; ++r) {
-        const int idx = a.item_begin + (blockIdx.x * a.rounds + r) * slots + slot;
-        bwd_item<SPLIT>(a, red, idx, idx < a.item_end, wave, sub, wpi, b, ld, act, lane);
-        if (SPLIT && r + 1 < a.rounds) __syncthreads();
-    }
+    const size_t b = (size_t)grp * 64 + lane;
+    const size_t ri = (size_t)base + ((size_t)bx * 16 + wave) * rpw;
+    const RecS r = load_rec(a.rec, ri);
+    if constexpr (BWD) bwd_chunk(a, red, r, ri, rpw, wpi, wave, lane, b, ld);
+    else fact_chunk(a, red, r, ri, rpw, wpi, wave, lane, b, ld);
 }
 
-// The narrow leading levels of the backward sweep (the dense tail of the elimination order: 1-4 rows per
-// level) in ONE launch: one 16-wave workgroup per scenario group walks the levels as barrier-separated steps.
-__global__ __launch_bounds__(1024) void k_bwd_fused(BwdArgs a, const int* steps, int n_steps) {
+__global__ __launch_bounds__(1024) void k_fact_level(FactArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double red[];   // [16][4][64]
+    level_body<false>(a, red);
+}
+
+__global__ __launch_bounds__(1024) void k_bwd_level(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) double red[];   // [16][2][64]
-    if (a.group_active && !a.group_active[blockIdx.y]) return;
-    const int lane = threadIdx.x;
-    const int wave = uniform(threadIdx.y);
-    const size_t ld = (size_t)a.ld;
-    const size_t b = (size_t)blockIdx.y * 64 + lane;
-    const bool act = a.upd.active ? (a.upd.active[b] != 0) : true;
-    for (int s = 0; s < n_steps; ++s) {
-        const int ib = uniform(steps[3 * s]), ie = uniform(steps[3 * s + 1]), wpi = uniform(steps[3 * s + 2]);
-        const int slots = 16 / wpi;
-        const int slot = wave / wpi, sub = wave - slot * wpi;
-        for (int base = ib; base < ie; base += slots) {
-            const int idx = base + slot;
-            bwd_item<true>(a, red, idx, idx < ie, wave, sub, wpi, b, ld, act, lane);
-            __syncthreads();                       // LDS reuse + makes this level's x visible to the next step
+    level_body<true>(a, red);
+}
+
+// ---- executor 2: persistent level walker ----------------------------------------------------------------------
+// One launch replays ALL dependency levels.  The chip's workgroups (one 16-wave workgroup per CU) form TEAMS by
+// the XCD they physically run on (HW_REG_XCC_ID, read at run time -- nothing is assumed about blockIdx -> XCD
+// placement).  A 64-scenario group belongs to exactly one team for the whole walk, so every value that crosses a
+// level travels CU -> that XCD's L2 -> CU and the level barrier is a team-local arrival counter (0.6-0.8 us measured)
+// instead of a kernel boundary.
+// Visibility argument (no fences needed; holds for ANY placement because the teams ARE the physical XCDs):
+//   * every factor entry / rhs row is written exactly ONCE per launch (by one wave, whole 128-byte lines) and read by
+//     other CUs only after the barrier that follows its level, so no CU's L1 can hold a line older than the launch
+//     (L1 is invalidated at kernel start and fills on demand only); rows rewritten in place (y -> x in the backward
+//     sweep) are read before the rewrite by their owner wave alone;
+//   * producer and consumers of a group share one L2 (the coherence point of an XCD); `s_waitcnt vmcnt(0)` before the
+//     arrival makes the write-through stores L2-visible;
+//   * counters are agent-scope atomics (L1-bypassing), polled by one lane per workgroup.
+// Every spin is bounded (wall clock): a stalled walk sets the error words and all workgroups drain out.
+enum { SYNC_REG = 0, SYNC_ERR = 1, SYNC_TEAM = 16 /* +xcc: team size */, SYNC_BAR = 64 /* +32*xcc: arrivals */,
+       SYNC_WORDS = 64 + 32 * 16 /* zeroed before every walk; word [SYNC_WORDS] is a sticky error flag */ };
+
+struct WalkArgs {
+    int n_seg;
+    int* sync;
+    long long timeout_ticks;   // wall_clock64 ticks (100 MHz)
+    long long* prof;           // optional [n_levels][3] timestamps of team 0 / rank 0 (JG_WALK_PROFILE), else nullptr
+};
+
+__device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// one lane: wait until *p >= target; false on timeout / foreign error
+__device__ __forceinline__ bool spin_ge(const int* p, int target, int* err, long long ticks) {
+    const long long t0 = wall_clock64();
+    for (unsigned it = 0;; ++it) {
+        if (ld_agent(p) >= target) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if ((it & 63) == 63) {
+            if (ld_agent(err) != 0) return false;
+            if (wall_clock64() - t0 > ticks) { atomicExch(err, 2); atomicExch(err + (SYNC_WORDS - SYNC_ERR), 2); return false; }   // + the sticky word
         }
     }
 }
 
-void flatten(const Schedule& s, std::vector<DevLaunch>& out, std::vector<int>* step_table = nullptr) {
-    out.clear();
-    for (const Launch& L : s.launches) {
-        DevLaunch d;
-        if (L.fused && step_table) {
-            d.item_begin = L.item_begin; d.item_end = L.item_end; d.waves = L.waves; d.wpi = 1; d.rounds = 1; d.grid = 1;
-            d.fused = 1; d.step0 = (int)step_table->size() / 3;
-            for (int st = s.task_ptr[L.task_begin]; st < s.task_ptr[L.task_begin + 1]; ++st) {
-                step_table->push_back(s.step_ptr[st]); step_table->push_back(s.step_ptr[st + 1]); step_table->push_back(s.step_wpi[st]);
-            }
-            d.n_steps = (int)step_table->size() / 3 - d.step0;
-            out.push_back(d);
-            continue;
+struct Team { int xcc, size, rank, index, nteams; };
+
+// registration: every workgroup announces its XCD, waits for the whole grid, then reads the team census
+__device__ __forceinline__ bool team_join(const WalkArgs& w, int* sh, Team& t) {
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        const int xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15;      // HW_REG_XCC_ID[3:0]
+        const int rank = atomicAdd(w.sync + SYNC_TEAM + xcc, 1);
+        atomicAdd(w.sync + SYNC_REG, 1);
+        int ok = spin_ge(w.sync + SYNC_REG, (int)gridDim.x, w.sync + SYNC_ERR, w.timeout_ticks) ? 1 : 0;
+        int nteams = 0, index = 0, size = 0;
+        for (int x = 0; x < 16; ++x) {
+            const int sz = ld_agent(w.sync + SYNC_TEAM + x);
+            if (x == xcc) { index = nteams; size = sz; }
+            nteams += sz > 0;
         }
-        d.item_begin = L.item_begin; d.item_end = L.item_end;
-        d.waves = L.waves; d.wpi = L.wpi;
-        const int slots = L.waves / L.wpi;
-        d.rounds = std::max(1, L.chunk / slots);
-        const int per_wg = slots * d.rounds;
-        d.grid = (L.item_end - L.item_begin + per_wg - 1) / per_wg;
+        sh[0] = ok; sh[1] = xcc; sh[2] = size; sh[3] = rank; sh[4] = index; sh[5] = nteams;
+    }
+    __syncthreads();
+    t.xcc = sh[1]; t.size = sh[2]; t.rank = sh[3]; t.index = sh[4]; t.nteams = sh[5];
+    const bool ok = sh[0] != 0;
+    __syncthreads();
+    return ok;
+}
+
+// team-local level barrier: arrivals are counted monotonically, barrier number q completes at size * (q + 1)
+__device__ __forceinline__ bool team_barrier(const WalkArgs& w, int* sh, const Team& t, int q) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores have reached the XCD's L2
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        int* bar = w.sync + SYNC_BAR + 32 * t.xcc;
+        atomicAdd(bar, 1);
+        sh[0] = spin_ge(bar, t.size * (q + 1), w.sync + SYNC_ERR, w.timeout_ticks) ? 1 : 0;
+    }
+    __syncthreads();
+    const bool ok = sh[0] != 0;
+    __syncthreads();
+    return ok;
+}
+
+// position of a workgroup in its team's work list: (segment s, unit u); units of a segment = chunks x team groups
+struct Cursor { int s, u; };
+
+template <bool BWD, class Args>
+__device__ __forceinline__ void walk_body(Args& a, const WalkArgs& w, double* red, int* sh, const Segment* segs /* LDS copy */) {
+    const int lane = threadIdx.x;
+    const int wave = uniform(threadIdx.y);
+    const size_t ld = (size_t)a.ld;
+    Team t;
+    if (!team_join(w, sh, t)) return;
+    // groups of this team: slots index, index + nteams, ... < gact
+    const int gact = a.sel.list ? uniform(*a.sel.count) : a.ld / 64;
+    const int ng = gact > t.index ? (gact - t.index + t.nteams - 1) / t.nteams : 0;
+    if (ng == 0) return;                                       // a team without groups shares no data and no barrier
+    const bool prof = w.prof && t.index == 0 && t.rank == 0 && wave == 0 && lane == 0;
+    auto units = [&](int s) { return uniform(segs[s].nchunks) * ng; };
+    auto normalise = [&](Cursor& c) {                          // first segment at or after c.s that holds a unit for this rank
+        while (c.s < w.n_seg && c.u >= units(c.s)) { ++c.s; c.u = t.rank; }
+    };
+    auto rec_index = [&](const Cursor& c) {
+        const int chunk = c.u / ng;
+        return (size_t)uniform(segs[c.s].rec_base) + ((size_t)chunk * 16 + wave) * uniform(segs[c.s].rpw);
+    };
+    // cursor of the unit this workgroup executes next, and the (prefetched) first record of this wave in it
+    Cursor cur{0, t.rank};
+    normalise(cur);
+    RecS nxt{};
+    if (cur.s < w.n_seg) nxt = load_rec(a.rec, rec_index(cur));
+    int barriers = 0;
+    for (int s = 0; s < w.n_seg; ++s) {
+        if (prof && (s == 0 || segs[s - 1].last)) w.prof[3 * (segs[s].level - 1)] = wall_clock64();
+        while (cur.s == s) {
+            const RecS r = nxt;
+            const size_t ri = rec_index(cur);
+            const int gs = cur.u % ng;
+            const int wpi = uniform(segs[s].wpi), rpw = uniform(segs[s].rpw);
+            Cursor nx{cur.s, cur.u + t.size};
+            normalise(nx);
+            if (nx.s < w.n_seg) nxt = load_rec(a.rec, rec_index(nx));      // prefetch: static tables, safe across barriers
+            const int slot = t.index + gs * t.nteams;
+            const int g = a.sel.list ? uniform(a.sel.list[slot]) : slot;
+            if (!(a.sel.flags && !a.sel.flags[g])) {
+                const size_t b = (size_t)g * 64 + lane;
+                if constexpr (BWD) bwd_chunk(a, red, r, ri, rpw, wpi, wave, lane, b, ld);
+                else fact_chunk(a, red, r, ri, rpw, wpi, wave, lane, b, ld);
+            }
+            cur = nx;
+        }
+        if (segs[s].last) {
+            if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); w.prof[3 * (segs[s].level - 1) + 1] = wall_clock64(); }
+            if (s + 1 < w.n_seg && !team_barrier(w, sh, t, barriers++)) return;
+            if (prof) w.prof[3 * (segs[s].level - 1) + 2] = wall_clock64();
+        }
+    }
+}
+
+constexpr int WALK_MAX_SEG = 1536;      // segment table staged in LDS (32 bytes each)
+
+__device__ __forceinline__ void stage_segments(const Segment* g, Segment* l, int n) {
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const int4* src = (const int4*)g;
+    int4* dst = (int4*)l;
+    for (int i = tid; i < 2 * n; i += 1024) dst[i] = src[i];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void k_fact_walk(FactArgs a, WalkArgs w) {
+    extern __shared__ __attribute__((aligned(16))) double red[];   // [16][4][64] doubles | 16 ints | segments
+    int* sh = (int*)(red + 16 * 256);
+    Segment* segs = (Segment*)(sh + 16);
+    stage_segments(a.seg, segs, w.n_seg);
+    walk_body<false>(a, w, red, sh, segs);
+}
+
+__global__ __launch_bounds__(1024) void k_bwd_walk(BwdArgs a, WalkArgs w) {
+    extern __shared__ __attribute__((aligned(16))) double red[];   // [16][4][64] doubles | 16 ints | segments
+    int* sh = (int*)(red + 16 * 256);
+    Segment* segs = (Segment*)(sh + 16);
+    stage_segments(a.seg, segs, w.n_seg);
+    walk_body<true>(a, w, red, sh, segs);
+}
+
+size_t walk_lds(int n_seg) { return 16 * 256 * sizeof(double) + 64 + (size_t)n_seg * sizeof(Segment); }
+
+// per-level launch table: segment ranges and chunk totals
+void level_launches(const std::vector<Segment>& segs, std::vector<DevLaunch>& out) {
+    out.clear();
+    size_t s = 0;
+    while (s < segs.size()) {
+        DevLaunch d{};
+        d.seg_begin = (int)s;
+        d.grid = 0; d.nseg = 0;
+        while (true) {
+            d.nseg++; d.grid = std::max(d.grid, segs[s].nchunks);
+            if (segs[s++].last) break;
+        }
+        d.seg_end = (int)s;
         out.push_back(d);
     }
 }
+
+std::mutex g_walk_mu;
+hipEvent_t g_walk_ev[64] = {};
 
 }  // namespace
 
@@ -314,38 +438,10 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, int policy
     if (ld_ <= 0 || ld_ % 64) { error = "batch leading dimension must be a positive multiple of 64"; return 1; }
     if (analyze(n, rowptr, col, policy, S)) { error = "block pattern must be structurally symmetric with a full diagonal"; return 1; }
     ld = ld_;
-    const int nE = S.n_entries;
-    // terms: LU terms, then rhs-row terms (Lh entry, diagonal of the column, column pivot)
-    std::vector<int> va(S.t_a), vd(S.t_d), vb(S.t_b);
-    const int rhs_base = (int)va.size();
-    for (int r = 0; r < n; ++r)
-        for (int p = S.l_ptr[r]; p < S.l_ptr[r + 1]; ++p) { va.push_back(S.l_ent[p]); vd.push_back(S.diag[S.l_col[p]]); vb.push_back(S.l_col[p]); }
-    std::vector<ItemDesc> fd(S.fact.items.size());
-    for (size_t i = 0; i < fd.size(); ++i) {
-        const int it = S.fact.items[i];
-        ItemDesc d{};
-        if (it < nE) {
-            d.kind = S.e_row[it] == S.e_col[it] ? 2 : (S.e_row[it] > S.e_col[it] ? 1 : 0);
-            d.id = it; d.src = S.e_src[it]; d.t0 = S.t_ptr[it]; d.t1 = S.t_ptr[it + 1];
-        } else {
-            const int k = it - nE;
-            d.kind = 3; d.id = k; d.src = S.perm[k]; d.t0 = rhs_base + S.l_ptr[k]; d.t1 = rhs_base + S.l_ptr[k + 1];
-        }
-        fd[i] = d;
-    }
-    std::vector<ItemDesc> bd(S.bwd.items.size());
-    for (size_t i = 0; i < bd.size(); ++i) {
-        const int k = S.bwd.items[i];
-        ItemDesc d{};
-        d.kind = 4; d.id = k; d.src = S.perm[k]; d.t0 = S.u_ptr[k]; d.t1 = S.u_ptr[k + 1]; d.aux = S.diag[k];
-        bd[i] = d;
-    }
-    flatten(S.fact, fact);
-    std::vector<int> bsteps;
-    flatten(S.bwd, bwd, &bsteps);
-    if (upload(&bwd_steps, bsteps, error)) return 2;
-    if (upload(&fact_desc, fd, error) || upload(&bwd_desc, bd, error) || upload(&ta, va, error) || upload(&td, vd, error) ||
-        upload(&tb, vb, error) || upload(&u_ent, S.u_ent, error) || upload(&u_col, S.u_col, error))
+    level_launches(S.fact_seg, fact);
+    level_launches(S.bwd_seg, bwd);
+    if (upload(&fact_rec, S.fact_rec, error) || upload(&bwd_rec, S.bwd_rec, error) || upload(&fact_seg, S.fact_seg, error) ||
+        upload(&bwd_seg, S.bwd_seg, error))
         return 2;
     JG_HIP(hipMalloc((void**)&X, factor_bytes()));
     JG_HIP(hipMemset(X, 0, factor_bytes()));
@@ -353,37 +449,116 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, int policy
     JG_HIP(hipMemset(W, 0, (size_t)n * 2 * ld * sizeof(double)));
     JG_HIP(hipMalloc((void**)&status, (size_t)ld * sizeof(int)));
     JG_HIP(hipMemset(status, 0, (size_t)ld * sizeof(int)));
+    JG_HIP(hipMalloc((void**)&sync, (SYNC_WORDS + 1) * sizeof(int)));
+    JG_HIP(hipMemset(sync, 0, (SYNC_WORDS + 1) * sizeof(int)));
+    JG_HIP(hipGetDevice(&device));
+    int cus = 0;
+    JG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+    walk_grid = cus;                                   // one 16-wave workgroup per CU: all co-resident by construction
+    if (getenv("JG_WALK_PROFILE")) {
+        JG_HIP(hipMalloc((void**)&prof, (size_t)S.n_fact_levels * 3 * sizeof(long long)));
+        JG_HIP(hipMemset(prof, 0, (size_t)S.n_fact_levels * 3 * sizeof(long long)));
+    }
+    // The walker is OPT-IN (JG_WALKER=1).  Measured on MI355X (ACTIVSg10k): its barrier costs 0.6-0.8 us against ~2 us
+    // for a kernel boundary, but binding a scenario group to ONE XCD caps the group at 32 CUs x 64 B/clk of L1 fill,
+    // and a level's cost is set by exactly that (one item's update list = up to 540 KB through one CU): 3.8 ms per
+    // factorisation against 1.5 ms (64 scenarios) / 4.3 against 2.7 ms (512) for the per-level launches, which spread
+    // every level over all 256 CUs.
+    const char* env = getenv("JG_WALKER");
+    walker = false;
+    const bool fits = (int)S.fact_seg.size() <= WALK_MAX_SEG && (int)S.bwd_seg.size() <= WALK_MAX_SEG;
+    if (env && env[0] == '1' && walk_grid > 0 && fits) {
+        JG_HIP(hipFuncSetAttribute((const void*)k_fact_walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds(WALK_MAX_SEG)));
+        JG_HIP(hipFuncSetAttribute((const void*)k_bwd_walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds(WALK_MAX_SEG)));
+        // census: can every workgroup of a walk become resident and do the XCD teams form?  (a walk with no segments)
+        FactArgs a{};
+        a.seg = fact_seg; a.ld = ld;
+        WalkArgs w{0, sync, 5000000LL /* 50 ms */, nullptr};
+        hipLaunchKernelGGL(k_fact_walk, dim3(walk_grid), dim3(64, 16), walk_lds(0), 0, a, w);
+        JG_HIP(hipDeviceSynchronize());
+        int h[SYNC_TEAM + 16];
+        JG_HIP(hipMemcpy(h, sync, sizeof(h), hipMemcpyDeviceToHost));
+        int members = 0;
+        for (int x = 0; x < 16; ++x) members += h[SYNC_TEAM + x];
+        walker = h[SYNC_ERR] == 0 && h[SYNC_REG] == walk_grid && members == walk_grid;
+        JG_HIP(hipMemset(sync, 0, (SYNC_WORDS + 1) * sizeof(int)));
+    }
     return 0;
 }
 
 void Engine::destroy() {
-    hipFree(fact_desc); hipFree(bwd_desc); hipFree(ta); hipFree(td); hipFree(tb); hipFree(u_ent); hipFree(u_col); hipFree(bwd_steps); bwd_steps = nullptr;
+    if (prof) {
+        const int nl = S.n_fact_levels;
+        std::vector<long long> t((size_t)nl * 3);
+        if (hipMemcpy(t.data(), prof, t.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess && nl > 0 && t[0]) {
+            fprintf(stderr, "[jg walk profile] level | work_us barrier_us\n");
+            for (int l = 0; l < nl; ++l)
+                fprintf(stderr, "[jg walk profile] %3d | %7.2f %7.2f\n", l, (t[3 * l + 1] - t[3 * l]) * 0.01,
+                        l + 1 < nl ? (t[3 * l + 2] - t[3 * l + 1]) * 0.01 : 0.0);
+            fprintf(stderr, "[jg walk profile] total %.2f us\n", (t[3 * (size_t)nl - 2] - t[0]) * 0.01);
+        }
+        hipFree(prof); prof = nullptr;
+    }
+    hipFree(fact_rec); hipFree(bwd_rec); hipFree(fact_seg); hipFree(bwd_seg); hipFree(sync);
     hipFree(X); hipFree(W); hipFree(status);
-    fact_desc = bwd_desc = nullptr;
-    ta = td = tb = u_ent = u_col = status = nullptr;
+    fact_rec = bwd_rec = nullptr; fact_seg = bwd_seg = nullptr; sync = nullptr; status = nullptr;
     X = W = nullptr;
 }
 
-int Engine::factor(hipStream_t st, const double* A, const double* rhs, const int* group_active) {
-    FactArgs a{fact_desc, ta, td, tb, A, rhs, X, W, status, group_active, 0, 0, 1, 1, ld};
+void Engine::serialize_begin(hipStream_t st) {
+    if (!walker || device < 0 || device >= 64) return;
+    std::lock_guard<std::mutex> lk(g_walk_mu);
+    if (g_walk_ev[device]) hipStreamWaitEvent(st, g_walk_ev[device], 0);
+}
+
+void Engine::serialize_end(hipStream_t st) {
+    if (!walker || device < 0 || device >= 64) return;
+    std::lock_guard<std::mutex> lk(g_walk_mu);
+    if (!g_walk_ev[device] && hipEventCreateWithFlags(&g_walk_ev[device], hipEventDisableTiming) != hipSuccess) { g_walk_ev[device] = nullptr; return; }
+    hipEventRecord(g_walk_ev[device], st);
+}
+
+int Engine::walk_status(hipStream_t st) {
+    if (!walker) return 0;
+    int e = 0;
+    JG_HIP(hipMemcpyAsync(&e, sync + SYNC_WORDS, sizeof(int), hipMemcpyDeviceToHost, st));
+    JG_HIP(hipStreamSynchronize(st));
+    if (e) { error = "persistent level walk stalled (a workgroup never became resident: is another process using this GPU?); set JG_WALKER=0"; return 2; }
+    return 0;
+}
+
+int Engine::factor(hipStream_t st, const double* A, const double* rhs, const GroupSel& sel, int mode) {
+    if (!S.inplace && !A) { error = "factor: no source matrix"; return 1; }
+    FactArgs a{fact_rec, fact_seg, S.inplace ? X : A, rhs, X, W, status, sel, ld, 0};
+    if (walker && mode != 1) {
+        WalkArgs w{(int)S.fact_seg.size(), sync, 100000000LL /* 1 s */, prof};
+        JG_HIP(hipMemsetAsync(sync, 0, SYNC_WORDS * sizeof(int), st));
+        hipLaunchKernelGGL(k_fact_walk, dim3(walk_grid), dim3(64, 16), walk_lds(w.n_seg), st, a, w);
+        JG_HIP(hipGetLastError());
+        return 0;
+    }
+    const int gs = group_stride(ld / 64);
     for (const DevLaunch& L : fact) {
-        a.item_begin = L.item_begin; a.item_end = L.item_end; a.wpi = L.wpi; a.rounds = L.rounds;
-        dim3 grid(L.grid, ld / 64), block(64, L.waves);
-        if (L.wpi == 1) hipLaunchKernelGGL(k_fact<false>, grid, block, 0, st, a);
-        else hipLaunchKernelGGL(k_fact<true>, grid, block, (size_t)L.waves * 256 * sizeof(double), st, a);
+        a.seg_begin = L.seg_begin;
+        hipLaunchKernelGGL(k_fact_level, dim3((unsigned)L.grid * gs, L.nseg), dim3(64, 16), 16 * 256 * sizeof(double), st, a);
     }
     JG_HIP(hipGetLastError());
     return 0;
 }
 
-int Engine::backsolve(hipStream_t st, double* out, const StateUpdate& upd, const int* group_active) {
-    BwdArgs a{bwd_desc, u_ent, u_col, X, W, out, group_active, upd, 0, 0, 1, 1, ld};
+int Engine::backsolve(hipStream_t st, double* out, const StateUpdate& upd, const GroupSel& sel, int mode) {
+    BwdArgs a{bwd_rec, bwd_seg, X, W, out, sel, upd, ld, 0};
+    if (walker && mode != 1) {
+        WalkArgs w{(int)S.bwd_seg.size(), sync, 100000000LL /* 1 s */, nullptr};
+        JG_HIP(hipMemsetAsync(sync, 0, SYNC_WORDS * sizeof(int), st));
+        hipLaunchKernelGGL(k_bwd_walk, dim3(walk_grid), dim3(64, 16), walk_lds(w.n_seg), st, a, w);
+        JG_HIP(hipGetLastError());
+        return 0;
+    }
+    const int gs = group_stride(ld / 64);
     for (const DevLaunch& L : bwd) {
-        a.item_begin = L.item_begin; a.item_end = L.item_end; a.wpi = L.wpi; a.rounds = L.rounds;
-        dim3 grid(L.grid, ld / 64), block(64, L.waves);
-        if (L.fused) { hipLaunchKernelGGL(k_bwd_fused, grid, block, (size_t)16 * 128 * sizeof(double), st, a, bwd_steps + 3 * L.step0, L.n_steps); continue; }
-        if (L.wpi == 1) hipLaunchKernelGGL(k_bwd<false>, grid, block, 0, st, a);
-        else hipLaunchKernelGGL(k_bwd<true>, grid, block, (size_t)L.waves * 128 * sizeof(double), st, a);
+        a.seg_begin = L.seg_begin;
+        hipLaunchKernelGGL(k_bwd_level, dim3((unsigned)L.grid * gs, L.nseg), dim3(64, 16), 16 * 128 * sizeof(double), st, a);
     }
     JG_HIP(hipGetLastError());
     return 0;

@@ -18,21 +18,11 @@ namespace jg {
 
 void set_last_error(const std::string& msg);   // thread-local text behind jg_last_error()
 
-// 32-byte item descriptor, fetched with one scalar load per item (schedule order).
-struct ItemDesc {
-    int kind;      // 0 upper U(k,j), 1 lower Lh(i,k) (unscaled), 2 diagonal (stores its 2x2 LU factors), 3 rhs row y_k
-    int id;        // entry id, or pivot k for rhs rows / backward rows
-    int src;       // block index in the caller's CSR (-1 = fill-in); original block index (bus) for rows
-    int t0, t1;    // term range in (ta, td, tb)
-    int aux;       // backward rows: entry id of the diagonal
-    int pad0, pad1;
-};
-
+// one per-level launch: grid.y walks the level's segments (at most one per wpi class 1, 2, 4, 8, 16)
 struct DevLaunch {
-    int item_begin, item_end;   // range in the descriptor array
-    int waves, wpi, rounds;     // blockDim.y, waves per item, items per slot
-    int grid;                   // workgroups along x
-    int fused = 0, n_steps = 0, step0 = 0;   // fused launch: step table rows [step0, step0 + n_steps) of {begin, end, wpi}
+    int seg_begin, seg_end;     // range in the segment table
+    int grid;                   // most chunks of any of its segments (workgroups along x before the group stride)
+    int nseg;
 };
 
 // Optional state update fused into the backward solve (NR: x <- x - dx, masked by bus flags).
@@ -44,29 +34,73 @@ struct StateUpdate {
     double sign = 0.0;             // -1 (Newton-Raphson) / +1 (Gauss-Newton)
 };
 
+// Which 64-scenario groups a launch works on.  flags (nullable): [ld/64], a group whose flag is 0 is skipped.
+// list/count (nullable): the active groups are list[0 .. *count) -- the launch then spreads exactly those over the
+// chip.  Both live in device memory so captured graphs follow the per-iteration verdicts.
+struct GroupSel {
+    const int* flags = nullptr;
+    const int* list = nullptr;
+    const int* count = nullptr;
+};
+
+// Workgroup -> (scenario group, work chunk) with the group as the FAST index of a 1-D grid.  Workgroup b lands on
+// XCD b % 8 (MI355X_MICROARCH.md, dispatch), so with 8 | groups every XCD -- and its private 4 MiB L2 -- serves only
+// the groups congruent to it: operands re-read by many items of one group stay in ONE L2 instead of eight.
+// groups < 8 are rounded to a power of two so a group still maps to a fixed subset of XCDs.
+__host__ __device__ inline int group_stride(int groups) {
+    return groups >= 8 ? (groups + 7) & ~7 : (groups <= 1 ? 1 : (groups <= 2 ? 2 : (groups <= 4 ? 4 : 8)));
+}
+
+#ifdef __HIPCC__
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// blockIdx.x -> (scenario group g, chunk x) of an nx-chunk launch; false: nothing to do for this workgroup
+__device__ __forceinline__ bool map_block(const GroupSel& sel, int ld, int nx, int& g, int& x) {
+    const int id = blockIdx.x;
+    const int gact = sel.list ? uniform(*sel.count) : ld / 64;
+    const int gs = group_stride(gact);
+    const int slot = id % gs;
+    x = id / gs;
+    if (slot >= gact || x >= nx) return false;
+    g = sel.list ? uniform(sel.list[slot]) : slot;
+    return !(sel.flags && !sel.flags[g]);
+}
+#endif
+
 struct Engine {
     BlockSymbolic S;
     int ld = 0;                    // padded batch (multiple of 64)
-    ItemDesc* fact_desc = nullptr; // factorisation + fused forward elimination, schedule order
-    ItemDesc* bwd_desc = nullptr;
-    int* ta = nullptr; int* td = nullptr; int* tb = nullptr;   // LU terms followed by rhs-row terms
-    int* u_ent = nullptr; int* u_col = nullptr;
-    int* bwd_steps = nullptr;     // {item_begin, item_end, wpi} per step of fused backward launches
+    Rec* fact_rec = nullptr; Rec* bwd_rec = nullptr;           // wave records (jg_symbolic.hpp), replay order
+    Segment* fact_seg = nullptr; Segment* bwd_seg = nullptr;
     double* X = nullptr;           // factor values [n_entries][4][ld]: U, unscaled Lh, factored diagonal blocks
     double* W = nullptr;           // [n][2][ld] pivot order: y after factor(), x after backsolve()
     int* status = nullptr;         // [ld] bit 2 set on zero / non-finite pivot
     std::vector<DevLaunch> fact, bwd;
+    // persistent level walker (one launch per factorisation / per backward sweep, see jg_engine.hip)
+    int* sync = nullptr;           // registration / team census / barrier counters / error word, zeroed before every walk
+    int walk_grid = 0;             // workgroups of a walk = CUs of the device (all must be co-resident)
+    bool walker = false;           // census passed and JG_WALKER != 0
+    long long* prof = nullptr;     // JG_WALK_PROFILE: per-level timestamps of one workgroup of the last factor walk
+    int device = 0;
     std::string error;
 
     int create(int n, const int* rowptr, const int* col, int ld_, int policy);
     void destroy();
     // A: block values in the caller's CSR order [nnz][4][ld]; rhs: [n][2][ld] original block order.
     // Computes A = Lh inv(D) U and y = (Lh inv(D))^-1 rhs in the same launches.
-    // group_active (nullable): [ld/64] flags, workgroups of an inactive 64-scenario group exit at once.
-    int factor(hipStream_t st, const double* A, const double* rhs, const int* group_active);
+    // sel: which 64-scenario groups take part (workgroups of the others exit at once).
+    // mode: 0 = persistent walker when available, 1 = one launch per dependency level.
+    // In-place engines (policy bit 0) ignore A: the caller has assembled into X (entry S.src_entry[p] for its block p).
+    int factor(hipStream_t st, const double* A, const double* rhs, const GroupSel& sel, int mode = 0);
     // x = U^-1 D y, scattered to original order into out [n][2][ld]; optional fused state update.
-    int backsolve(hipStream_t st, double* out, const StateUpdate& upd, const int* group_active);
+    int backsolve(hipStream_t st, double* out, const StateUpdate& upd, const GroupSel& sel, int mode = 0);
     size_t factor_bytes() const { return (size_t)S.n_entries * 4 * ld * sizeof(double); }
+    // 0 ok; 2 + error text when a walk stalled (a workgroup never became resident, e.g. another process holds CUs)
+    int walk_status(hipStream_t st);
+    // Walks of different handles must not overlap on one device (each needs every CU): the owner brackets whatever
+    // it submits (graph launch or direct calls) with these; they chain the streams through one per-device event.
+    void serialize_begin(hipStream_t st);
+    void serialize_end(hipStream_t st);
 };
 
 #define JG_HIP(expr)                                                                      \

@@ -339,9 +339,9 @@ void launch_gain(jg_gn* h) {
 int launch_increment(jg_gn* h, const int* group) {
     launch_rows(h);
     launch_gain(h);
-    if (int rc = h->eng.factor(h->stream, h->d_Gv, h->d_rhs, group)) return failg(rc, h->eng.error);
+    if (int rc = h->eng.factor(h->stream, h->d_Gv, h->d_rhs, jg::GroupSel{group})) return failg(rc, h->eng.error);
     jg::StateUpdate none{};
-    if (int rc = h->eng.backsolve(h->stream, h->d_inc, none, group)) return failg(rc, h->eng.error);
+    if (int rc = h->eng.backsolve(h->stream, h->d_inc, none, jg::GroupSel{group})) return failg(rc, h->eng.error);
     hipLaunchKernelGGL(k_gn_norm, dim3(h->nchunk, h->ld / 64), dim3(64, 4), 0, h->stream, h->d_inc, h->d_part, h->n, h->slack0, h->ld);
     return 0;
 }
@@ -564,7 +564,7 @@ void jg_gn_destroy(jg_gn* h) {
 int jg_gn_dims(jg_gn* h, int64_t* dims) {
     if (!h || !dims) return failg(1, "jg_gn_dims: bad argument");
     dims[0] = h->m; dims[1] = h->nnzH; dims[2] = (int64_t)h->gi_col.size(); dims[3] = h->eng.S.n_entries;
-    dims[4] = h->eng.S.n_terms; dims[5] = (int64_t)h->eng.S.fact.launches.size(); dims[6] = (int64_t)h->eng.S.bwd.launches.size();
+    dims[4] = h->eng.S.n_terms; dims[5] = (int64_t)h->eng.fact.size(); dims[6] = (int64_t)h->eng.bwd.size();
     dims[7] = h->nslots;
     return 0;
 }
@@ -601,7 +601,9 @@ int jg_gn_increment(jg_gn* h, double* maxinc) {
     if (!h) return failg(1, "jg_gn_increment: bad argument");
     if (int rc = set_device(h)) return rc;
     GN_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
+    h->eng.serialize_begin(h->stream);
     if (int rc = launch_increment(h, nullptr)) return rc;
+    h->eng.serialize_end(h->stream);
     launch_check(h, 0);
     GN_HIP(hipGetLastError());
     GN_HIP(hipStreamSynchronize(h->stream));
@@ -645,10 +647,13 @@ int jg_gn_run(jg_gn* h, int64_t max_iter, double tol, int32_t* iters, int32_t* s
     GN_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
     GN_HIP(hipMemsetAsync(h->d_group, 0xff, (size_t)(h->ld / 64) * sizeof(int), h->stream));
     for (int64_t it = 0; it <= max_iter; ++it) {                                   // :1303
+        h->eng.serialize_begin(h->stream);
         GN_HIP(hipGraphLaunch(h->exec, h->stream));
+        h->eng.serialize_end(h->stream);
         GN_HIP(hipStreamSynchronize(h->stream));
         if (*h->h_counter == 0) break;
     }
+    if (int rc = h->eng.walk_status(h->stream)) return failg(rc, h->eng.error);
     if (iters) GN_HIP(hipMemcpy(iters, h->d_iters, (size_t)h->batch * 4, hipMemcpyDeviceToHost));
     if (status) GN_HIP(hipMemcpy(status, h->d_status, (size_t)h->batch * 4, hipMemcpyDeviceToHost));
     return 0;
@@ -714,8 +719,8 @@ int jg_gn_time_kernel(jg_gn* h, int kernel, int reps, double* mean_ms) {
     for (int r = 0; r < reps; ++r) {
         if (kernel == 0) launch_rows(h);
         else if (kernel == 1) launch_gain(h);
-        else if (kernel == 2) { if (int rc = h->eng.factor(h->stream, h->d_Gv, h->d_rhs, nullptr)) return failg(rc, h->eng.error); }
-        else { if (int rc = h->eng.backsolve(h->stream, h->d_inc, none, nullptr)) return failg(rc, h->eng.error); }
+        else if (kernel == 2) { if (int rc = h->eng.factor(h->stream, h->d_Gv, h->d_rhs, jg::GroupSel{})) return failg(rc, h->eng.error); }
+        else { if (int rc = h->eng.backsolve(h->stream, h->d_inc, none, jg::GroupSel{})) return failg(rc, h->eng.error); }
     }
     GN_HIP(hipEventRecord(e1, h->stream));
     GN_HIP(hipEventSynchronize(e1));

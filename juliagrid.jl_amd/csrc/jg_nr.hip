@@ -44,29 +44,32 @@ constexpr int CH = 4;          // Ybus entries whose gathers are in flight toget
 
 struct AsmArgs {
     const int* rowptr; const int* colm; const double2* GB; const int* rowtype;   // colm = col | (mask << 24); rowtype: int per bus (scalar-loadable)
+    const int* dst;            // Ybus CSR position -> entry of the LU factor storage: the Jacobian is assembled IN PLACE
     const double* vm; const double* va; const double* p; const double* q;
     const int* ppos; const double* pdg; const double* pdb;
-    double* A; double* F; double* part; const int* group;
-    int n; int ld; int mp;
+    double* A; double* F; double* part; jg::GroupSel sel;
+    int n; int ld; int mp; int nchunk;
 };
 
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// Fused mismatch + Jacobian assembly. blockDim (64, ASM_WAVES); grid (ceil(n/ASM_ROWS), ld/64).
+// Fused mismatch + Jacobian assembly. blockDim (64, ASM_WAVES); 1-D grid, scenario group fastest (jg::map_block:
+// a group's V/theta gathers stay in one XCD's L2).
 // JAC = false: mismatch only (no Jacobian stores) -- the cheap pre-pass that decides which scenarios are still active.
 template <int MP, bool JAC>
 __global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(AsmArgs a) {
     __shared__ double red[2][ASM_WAVES][64];
-    if (a.group && !a.group[blockIdx.y]) return;          // every scenario of this 64-lane group is finished
+    int grp, bx;
+    if (!jg::map_block(a.sel, a.ld, a.nchunk, grp, bx)) return;   // every scenario of a skipped 64-lane group is finished
     const int lane = threadIdx.x;
     const int wave = uniform(threadIdx.y);
     const size_t ld = (size_t)a.ld;
-    const size_t b = (size_t)blockIdx.y * 64 + lane;
+    const size_t b = (size_t)grp * 64 + lane;
     int ppos[MP > 0 ? MP : 1];
 #pragma unroll
     for (int m = 0; m < MP; ++m) ppos[m] = a.ppos[(size_t)m * ld + b];
     double maxp = 0.0, maxq = 0.0;
-    const int r0 = blockIdx.x * ASM_ROWS;
+    const int r0 = bx * ASM_ROWS;
     const int r1 = min(r0 + ASM_ROWS, a.n);
     for (int i = r0 + wave; i < r1; i += ASM_WAVES) {
         const int p0 = uniform(a.rowptr[i]), p1 = uniform(a.rowptr[i + 1]);
@@ -75,16 +78,17 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(AsmArgs a) {
         const double thi = a.va[(size_t)i * ld + b];
         const double pinj = a.p[(size_t)i * ld + b], qinj = a.q[(size_t)i * ld + b];   // issued early, used after the row
         double s1 = 0.0, s2 = 0.0, gii = 0.0, bii = 0.0;
-        int pd = p0;
+        int pd = 0;                                        // factor entry of the diagonal block
         // rows are short (3.4 entries on average, <= 19): the cost is the latency of the V/theta gathers,
         // so the loads of four entries are issued together before any of them is consumed
         for (int pc = p0; pc < p1; pc += CH) {
             const int cnt = min(CH, p1 - pc);
-            int cm[CH]; double2 gb[CH]; double vv[CH], tt[CH];
+            int cm[CH], de[CH]; double2 gb[CH]; double vv[CH], tt[CH];
 #pragma unroll
             for (int k = 0; k < CH; ++k) {                       // scalar loads of the whole chunk first ...
                 const int p = pc + (k < cnt ? k : 0);
                 cm[k] = uniform(a.colm[p]);
+                de[k] = JAC ? uniform(a.dst[p]) : 0;
                 gb[k] = a.GB[p];
             }
 #pragma unroll
@@ -110,10 +114,10 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(AsmArgs a) {
                 const double ad = g * s - bb * c;      // G sin - B cos
                 s1 += vj * ac;
                 s2 += vj * ad;
-                if (j == i) { pd = p; gii = g; bii = bb; continue; }
+                if (j == i) { pd = de[k]; gii = g; bii = bb; continue; }
                 if (!JAC) continue;
                 // rows: P exists unless slack, Q exists for PQ; cols: theta unless slack, V for PQ (mask from the host)
-                double* o = a.A + (size_t)p * 4 * ld + b;
+                double* o = a.A + (size_t)de[k] * 4 * ld + b;
                 o[0] = (mk & 1) ? vi * vj * ad : 0.0;            // dP_i/dtheta_j   equations.jl:109-111
                 o[ld] = (mk & 2) ? vi * ac : 0.0;                // dP_i/dV_j       equations.jl:117-119
                 o[2 * ld] = (mk & 4) ? -(vi * vj) * ac : 0.0;    // dQ_i/dtheta_j   equations.jl:134-136
@@ -149,8 +153,8 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(AsmArgs a) {
             maxp = (x > maxp || x != x) ? x : maxp;
             maxq = (y > maxq || y != y) ? y : maxq;
         }
-        a.part[((size_t)blockIdx.x * 2) * ld + b] = maxp;
-        a.part[((size_t)blockIdx.x * 2 + 1) * ld + b] = maxq;
+        a.part[((size_t)bx * 2) * ld + b] = maxp;
+        a.part[((size_t)bx * 2 + 1) * ld + b] = maxq;
     }
 }
 
@@ -199,10 +203,11 @@ __global__ __launch_bounds__(1024) void k_check(CheckArgs a) {
 // ---- scenario compaction ------------------------------------------------------------------------
 // Scenarios converge after different iteration counts (2..10 on N-1 sets).  Once enough have finished,
 // the still-active ones are packed into the leading lanes (stable partition) so whole 64-lane groups
-// drop out of every later launch.  flags: [0] permute this iteration, [1] active lanes, [2] groups in use.
+// drop out of every later launch.  flags: [0] permute this iteration, [1] active lanes, [2] groups in use,
+// [3] length of glist (the ids of the groups that still hold an active lane; the launches spread exactly those).
 struct CompactArgs {
     int* active; int* iters; int* status; int* lu_status; int* lid; int* ppos; int mp;
-    int* dest; int* group; int* flags; int* tmp; int ld; int restore;
+    int* dest; int* group; int* glist; int* flags; int* tmp; int ld; int restore;
 };
 
 __global__ __launch_bounds__(1024) void k_compact(CompactArgs a) {
@@ -234,6 +239,12 @@ __global__ __launch_bounds__(1024) void k_compact(CompactArgs a) {
             for (int l = 0; l < 64; ++l) any |= a.active[g * 64 + l];
             a.group[g] = any;
         }
+        __syncthreads();
+        if (t == 0) {
+            int m = 0;
+            for (int g = 0; g < ngroups; ++g) if (a.group[g]) a.glist[m++] = g;
+            a.flags[3] = m;
+        }
         return;
     }
     int run = before;
@@ -253,7 +264,8 @@ __global__ __launch_bounds__(1024) void k_compact(CompactArgs a) {
         for (int b = b0; b < b1; ++b) x[b] = a.tmp[b];
         __syncthreads();
     }
-    for (int g = t; g < ngroups; g += 1024) a.group[g] = a.restore ? 1 : (g < groups_new);
+    for (int g = t; g < ngroups; g += 1024) { a.group[g] = a.restore ? 1 : (g < groups_new); a.glist[g] = g; }
+    if (t == 0) a.flags[3] = a.restore ? ngroups : groups_new;
 }
 
 // dst[row][dest[b]] = src[row][b] for `rows` rows (no-op unless flags[0]); then the copy back
@@ -304,17 +316,17 @@ struct jg_nr {
     std::vector<int64_t> colptr, rowval, pq, pvpq, pcount, jcolptr, jrowval;
     std::vector<int8_t> type;
     std::vector<int> tperm;          // Ybus CSC pointer -> block CSR index of the same (row, col)
-    std::vector<int64_t> jmap;       // Jacobian CSC nz -> csr*4 + component
+    std::vector<int64_t> jmap;       // Jacobian CSC nz -> (factor entry holding the block)*4 + component
     // device
     int* d_rowptr = nullptr; int* d_col = nullptr; double* d_G = nullptr; double* d_B = nullptr; double2* d_GB = nullptr; int* d_rowtype = nullptr;
     signed char* d_type = nullptr; signed char* d_flags = nullptr;
     double* d_vm = nullptr; double* d_va = nullptr; double* d_p = nullptr; double* d_q = nullptr;
     int* d_ppos = nullptr; double* d_pdg = nullptr; double* d_pdb = nullptr;
-    double* d_A = nullptr; double* d_F = nullptr; double* d_inc = nullptr; double* d_part = nullptr;
+    int* d_dst = nullptr; double* d_F = nullptr; double* d_inc = nullptr; double* d_part = nullptr;
     double* d_normp = nullptr; double* d_normq = nullptr; double* d_params = nullptr;
     double* d_vm0 = nullptr; double* d_va0 = nullptr;   // snapshot of the start point
     int* d_active = nullptr; int* d_iters = nullptr; int* d_status = nullptr; int* d_counter = nullptr; int* d_group = nullptr;
-    int* d_lid = nullptr; int* d_dest = nullptr; int* d_cflags = nullptr; int* d_itmp = nullptr;   // scenario compaction
+    int* d_lid = nullptr; int* d_dest = nullptr; int* d_cflags = nullptr; int* d_itmp = nullptr; int* d_glist = nullptr;   // scenario compaction
     jg::Engine eng;
     hipStream_t stream = nullptr;
     hipGraph_t graphA = nullptr, graphB = nullptr;
@@ -327,10 +339,12 @@ namespace {
 
 int set_device(jg_nr* h) { NR_HIP(hipSetDevice(h->device)); return 0; }
 
-void launch_assemble(jg_nr* h, const int* group = nullptr, bool jac = true) {
-    AsmArgs a{h->d_rowptr, h->d_col, h->d_GB, h->d_rowtype, h->d_vm, h->d_va, h->d_p, h->d_q,
-              h->d_ppos, h->d_pdg, h->d_pdb, h->d_A, h->d_F, h->d_part, group, h->n, h->ld, h->mp};
-    dim3 grid(h->nchunk, h->ld / 64), block(64, ASM_WAVES);
+jg::GroupSel active_groups(jg_nr* h) { return jg::GroupSel{nullptr, h->d_glist, h->d_cflags + 3}; }
+
+void launch_assemble(jg_nr* h, const jg::GroupSel& sel = jg::GroupSel{}, bool jac = true) {
+    AsmArgs a{h->d_rowptr, h->d_col, h->d_GB, h->d_rowtype, h->d_dst, h->d_vm, h->d_va, h->d_p, h->d_q,
+              h->d_ppos, h->d_pdg, h->d_pdb, h->eng.X, h->d_F, h->d_part, sel, h->n, h->ld, h->mp, h->nchunk};
+    dim3 grid((unsigned)h->nchunk * jg::group_stride(h->ld / 64)), block(64, ASM_WAVES);
     if (jac) {
         switch (h->mp) {
             case 0: hipLaunchKernelGGL((k_assemble<0, true>), grid, block, 0, h->stream, a); break;
@@ -366,7 +380,7 @@ int put_bus_array(jg_nr* h, double* dst, const double* src, int64_t stride) {
 // pack the active scenarios into the leading lanes (restore = 1: send every lane back home)
 void launch_compact(jg_nr* h, int restore) {
     CompactArgs c{h->d_active, h->d_iters, h->d_status, h->eng.status, h->d_lid, h->d_ppos, h->mp, h->d_dest, h->d_group,
-                  h->d_cflags, h->d_itmp, h->ld, restore};
+                  h->d_glist, h->d_cflags, h->d_itmp, h->ld, restore};
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, c);
     double* tmp = h->eng.X;                        // the factor is dead here (rebuilt by the next factorisation)
     const dim3 block(256), gy((unsigned)((h->ld + 255) / 256));
@@ -385,7 +399,7 @@ int build_graphs(jg_nr* h) {
     NR_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     // graph A: who is still active?  mismatch-only pass -> verdict per scenario -> pack the active ones
     hipMemsetAsync(h->d_counter, 0, sizeof(int), h->stream);
-    launch_assemble(h, h->d_group, false);
+    launch_assemble(h, active_groups(h), false);
     launch_check(h, 1, h->d_group);
     launch_compact(h, 0);
     hipMemcpyAsync(h->h_counter, h->d_counter, sizeof(int), hipMemcpyDeviceToHost, h->stream);
@@ -393,10 +407,10 @@ int build_graphs(jg_nr* h) {
     NR_HIP(hipGraphInstantiate(&h->execA, h->graphA, nullptr, nullptr, 0));
     NR_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     // graph B: the iteration itself, on the packed lanes only
-    launch_assemble(h, h->d_group, true);
-    int rc = h->eng.factor(h->stream, h->d_A, h->d_F, h->d_group);
+    launch_assemble(h, active_groups(h), true);
+    int rc = h->eng.factor(h->stream, nullptr, h->d_F, active_groups(h));
     jg::StateUpdate upd{h->d_va, h->d_vm, h->d_flags, h->d_active, -1.0};
-    if (!rc) rc = h->eng.backsolve(h->stream, h->d_inc, upd, h->d_group);
+    if (!rc) rc = h->eng.backsolve(h->stream, h->d_inc, upd, active_groups(h));
     hipError_t e = hipStreamEndCapture(h->stream, &h->graphB);
     if (rc) return fail(rc, h->eng.error);
     NR_HIP(e);
@@ -528,22 +542,25 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
     bool ok = dmalloc((void**)&h->d_vm, n * ld * 8) && dmalloc((void**)&h->d_va, n * ld * 8) &&
               dmalloc((void**)&h->d_p, n * ld * 8) && dmalloc((void**)&h->d_q, n * ld * 8) &&
               dmalloc((void**)&h->d_ppos, mpn * ld * 4) && dmalloc((void**)&h->d_pdg, mpn * ld * 8) &&
-              dmalloc((void**)&h->d_pdb, mpn * ld * 8) && dmalloc((void**)&h->d_A, (size_t)nnz * 4 * ld * 8) &&
+              dmalloc((void**)&h->d_pdb, mpn * ld * 8) &&
               dmalloc((void**)&h->d_F, n * 2 * ld * 8) && dmalloc((void**)&h->d_inc, n * 2 * ld * 8) &&
               dmalloc((void**)&h->d_part, (size_t)h->nchunk * 2 * ld * 8) && dmalloc((void**)&h->d_normp, ld * 8) &&
               dmalloc((void**)&h->d_normq, ld * 8) && dmalloc((void**)&h->d_params, 2 * 8) &&
               dmalloc((void**)&h->d_active, ld * 4) && dmalloc((void**)&h->d_iters, ld * 4) &&
               dmalloc((void**)&h->d_status, ld * 4) && dmalloc((void**)&h->d_counter, 4) &&
               dmalloc((void**)&h->d_group, (ld / 64) * 4) && dmalloc((void**)&h->d_lid, ld * 4) &&
-              dmalloc((void**)&h->d_dest, ld * 4) && dmalloc((void**)&h->d_cflags, 16) && dmalloc((void**)&h->d_itmp, ld * 4);
+              dmalloc((void**)&h->d_dest, ld * 4) && dmalloc((void**)&h->d_cflags, 16) && dmalloc((void**)&h->d_itmp, ld * 4) &&
+              dmalloc((void**)&h->d_glist, (ld / 64) * 4);
     if (!ok) { jg_nr_destroy(h); return fail(2, "jg_nr_create: device allocation failed"); }
     if (hipMemset(h->d_ppos, 0xff, mpn * ld * 4) != hipSuccess ||                 // -1 = no patch
         hipHostMalloc((void**)&h->h_counter, sizeof(int)) != hipSuccess ||
         hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         jg_nr_destroy(h); return fail(2, "jg_nr_create: stream / pinned allocation failed");
     }
-    rc = h->eng.create(n, rp.data(), cl.data(), h->ld, 0);
+    rc = h->eng.create(n, rp.data(), cl.data(), h->ld, 1);          // in place: the assembly kernel writes into the factor storage
     if (rc) { std::string m = h->eng.error; jg_nr_destroy(h); return fail(rc, m); }
+    if (jg::upload(&h->d_dst, h->eng.S.src_entry, err)) { jg_nr_destroy(h); return fail(2, err); }
+    for (int64_t k = 0; k < h->nnzJ; ++k) h->jmap[k] = (int64_t)h->eng.S.src_entry[h->jmap[k] >> 2] * 4 + (h->jmap[k] & 3);
     *out = h;
     return 0;
 }
@@ -559,9 +576,9 @@ void jg_nr_destroy(jg_nr* h) {
     h->eng.destroy();
     hipFree(h->d_rowptr); hipFree(h->d_col); hipFree(h->d_G); hipFree(h->d_B); hipFree(h->d_GB); hipFree(h->d_rowtype); hipFree(h->d_type); hipFree(h->d_flags);
     hipFree(h->d_vm); hipFree(h->d_va); hipFree(h->d_p); hipFree(h->d_q); hipFree(h->d_ppos); hipFree(h->d_pdg);
-    hipFree(h->d_pdb); hipFree(h->d_A); hipFree(h->d_F); hipFree(h->d_inc); hipFree(h->d_part); hipFree(h->d_normp);
+    hipFree(h->d_pdb); hipFree(h->d_dst); hipFree(h->d_F); hipFree(h->d_inc); hipFree(h->d_part); hipFree(h->d_normp);
     hipFree(h->d_normq); hipFree(h->d_params); hipFree(h->d_active); hipFree(h->d_iters); hipFree(h->d_status);
-    hipFree(h->d_counter); hipFree(h->d_vm0); hipFree(h->d_va0); hipFree(h->d_group); hipFree(h->d_lid); hipFree(h->d_dest); hipFree(h->d_cflags); hipFree(h->d_itmp);
+    hipFree(h->d_counter); hipFree(h->d_vm0); hipFree(h->d_va0); hipFree(h->d_group); hipFree(h->d_lid); hipFree(h->d_dest); hipFree(h->d_cflags); hipFree(h->d_itmp); hipFree(h->d_glist);
     if (h->h_counter) hipHostFree(h->h_counter);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -570,8 +587,8 @@ void jg_nr_destroy(jg_nr* h) {
 int jg_nr_dims(jg_nr* h, int64_t* dims) {
     if (!h || !dims) return fail(1, "jg_nr_dims: bad argument");
     dims[0] = h->dimJ; dims[1] = h->nnzJ; dims[2] = h->eng.S.n_entries; dims[3] = h->eng.S.n_terms;
-    dims[4] = (int64_t)h->eng.S.fact.launches.size();
-    dims[5] = (int64_t)h->eng.S.bwd.launches.size();
+    dims[4] = (int64_t)h->eng.fact.size();
+    dims[5] = (int64_t)h->eng.bwd.size();
     return 0;
 }
 
@@ -701,12 +718,15 @@ int jg_nr_solve(jg_nr* h) {
     if (int rc = set_device(h)) return rc;
     if (!h->jac_valid) launch_assemble(h);
     NR_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
-    if (int rc = h->eng.factor(h->stream, h->d_A, h->d_F, nullptr)) return fail(rc, h->eng.error);
+    h->eng.serialize_begin(h->stream);
+    if (int rc = h->eng.factor(h->stream, nullptr, h->d_F, jg::GroupSel{})) return fail(rc, h->eng.error);
     jg::StateUpdate upd{h->d_va, h->d_vm, h->d_flags, nullptr, -1.0};
-    if (int rc = h->eng.backsolve(h->stream, h->d_inc, upd, nullptr)) return fail(rc, h->eng.error);
+    if (int rc = h->eng.backsolve(h->stream, h->d_inc, upd, jg::GroupSel{})) return fail(rc, h->eng.error);
+    h->eng.serialize_end(h->stream);
     hipLaunchKernelGGL(k_add_iter, dim3((h->ld + 255) / 256), dim3(256), 0, h->stream, h->d_iters, h->ld);
     NR_HIP(hipGetLastError());
     NR_HIP(hipStreamSynchronize(h->stream));
+    if (int rc = h->eng.walk_status(h->stream)) return fail(rc, h->eng.error);
     h->jac_valid = false;
     std::vector<int> st(h->ld);
     NR_HIP(hipMemcpy(st.data(), h->eng.status, (size_t)h->ld * 4, hipMemcpyDeviceToHost));
@@ -725,12 +745,14 @@ int jg_nr_run(jg_nr* h, int64_t max_iter, double tol, int32_t* iters, int32_t* s
     {   // every real scenario starts active, lanes in home order, all groups in use
         std::vector<int> act(h->ld, 0), lid(h->ld);
         for (int b = 0; b < h->ld; ++b) { act[b] = b < h->batch; lid[b] = b; }
-        const int cf[4] = {0, h->batch, h->ld / 64, 0};
+        const int cf[4] = {0, h->batch, h->ld / 64, h->ld / 64};
         NR_HIP(hipMemcpyAsync(h->d_active, act.data(), (size_t)h->ld * 4, hipMemcpyHostToDevice, h->stream));
         NR_HIP(hipMemcpyAsync(h->d_lid, lid.data(), (size_t)h->ld * 4, hipMemcpyHostToDevice, h->stream));
         NR_HIP(hipMemcpyAsync(h->d_cflags, cf, sizeof(cf), hipMemcpyHostToDevice, h->stream));
-        std::vector<int> grp(h->ld / 64, 1);
+        std::vector<int> grp(h->ld / 64, 1), gl(h->ld / 64);
+        for (size_t g = 0; g < gl.size(); ++g) gl[g] = (int)g;
         NR_HIP(hipMemcpyAsync(h->d_group, grp.data(), grp.size() * 4, hipMemcpyHostToDevice, h->stream));
+        NR_HIP(hipMemcpyAsync(h->d_glist, gl.data(), gl.size() * 4, hipMemcpyHostToDevice, h->stream));
         NR_HIP(hipStreamSynchronize(h->stream));
     }
     const bool trace = getenv("JG_TRACE") != nullptr;
@@ -744,11 +766,14 @@ int jg_nr_run(jg_nr* h, int64_t max_iter, double tol, int32_t* iters, int32_t* s
                     *h->h_counter, cf[2], h->ld / 64, cf[0] ? " (compacted)" : "");
         }
         if (*h->h_counter == 0) break;
+        h->eng.serialize_begin(h->stream);
         NR_HIP(hipGraphLaunch(h->execB, h->stream));
+        h->eng.serialize_end(h->stream);
     }
     launch_compact(h, 1);                                                      // lanes back to their home order
     NR_HIP(hipGetLastError());
     NR_HIP(hipStreamSynchronize(h->stream));
+    if (int rc = h->eng.walk_status(h->stream)) return fail(rc, h->eng.error);
     h->jac_valid = false;
     if (iters) NR_HIP(hipMemcpy(iters, h->d_iters, (size_t)h->batch * 4, hipMemcpyDeviceToHost));
     if (status) NR_HIP(hipMemcpy(status, h->d_status, (size_t)h->batch * 4, hipMemcpyDeviceToHost));
@@ -794,8 +819,8 @@ int jg_nr_get_jacobian(jg_nr* h, double* nzval) {
     if (int rc = set_device(h)) return rc;
     if (!h->jac_valid) { launch_assemble(h); h->jac_valid = true; }      // Jacobian at the current state
     NR_HIP(hipStreamSynchronize(h->stream));
-    std::vector<double> t((size_t)h->nnz * 4 * h->ld);
-    NR_HIP(hipMemcpy(t.data(), h->d_A, t.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> t((size_t)h->eng.S.n_entries * 4 * h->ld);     // the factor storage holds the Jacobian until the next factorisation
+    NR_HIP(hipMemcpy(t.data(), h->eng.X, t.size() * 8, hipMemcpyDeviceToHost));
     for (int b = 0; b < h->batch; ++b)
         for (int64_t k = 0; k < h->nnzJ; ++k) nzval[(size_t)b * h->nnzJ + k] = t[(size_t)h->jmap[k] * h->ld + b];
     return 0;
@@ -827,13 +852,15 @@ int jg_nr_time_kernel(jg_nr* h, int kernel, int reps, double* mean_ms) {
     NR_HIP(hipEventCreate(&e1));
     jg::StateUpdate none{};
     NR_HIP(hipStreamSynchronize(h->stream));
+    h->eng.serialize_begin(h->stream);
     NR_HIP(hipEventRecord(e0, h->stream));
     for (int r = 0; r < reps; ++r) {
         if (kernel == 0) launch_assemble(h);
-        else if (kernel == 1) { if (int rc = h->eng.factor(h->stream, h->d_A, h->d_F, nullptr)) return fail(rc, h->eng.error); }
-        else { if (int rc = h->eng.backsolve(h->stream, h->d_inc, none, nullptr)) return fail(rc, h->eng.error); }
+        else if (kernel == 1) { if (int rc = h->eng.factor(h->stream, nullptr, h->d_F, jg::GroupSel{})) return fail(rc, h->eng.error); }
+        else { if (int rc = h->eng.backsolve(h->stream, h->d_inc, none, jg::GroupSel{})) return fail(rc, h->eng.error); }
     }
     NR_HIP(hipEventRecord(e1, h->stream));
+    h->eng.serialize_end(h->stream);
     NR_HIP(hipEventSynchronize(e1));
     float ms = 0.f;
     NR_HIP(hipEventElapsedTime(&ms, e0, e1));

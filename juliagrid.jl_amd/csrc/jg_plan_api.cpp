@@ -12,13 +12,6 @@ struct jg_plan {
     jg::BlockSymbolic S;
 };
 
-namespace {
-void flatten(const jg::Schedule& s, std::vector<int>& launch) {
-    launch.clear();
-    for (const jg::Launch& L : s.launches) { launch.push_back(L.task_begin); launch.push_back(L.task_end); launch.push_back(L.waves); launch.push_back(L.wpi); launch.push_back(L.chunk); launch.push_back(L.item_begin); launch.push_back(L.item_end); launch.push_back(L.fused); }
-}
-}  // namespace
-
 extern "C" {
 
 int jg_plan_create(jg_plan** out, int64_t n, const int32_t* rowptr, const int32_t* col, int policy) {
@@ -34,7 +27,8 @@ void jg_plan_destroy(jg_plan* p) { delete p; }
 // which: 0 perm, 1 e_row, 2 e_col, 3 e_src, 4 t_ptr, 5 t_a, 6 t_b, 7 e_level, 8 e_diag, 9 diag,
 //        10 l_ptr, 11 l_ent, 12 l_col, 13 u_ptr, 14 u_ent, 15 u_col,
 //        16 t_d, 17 y_level
-//        20/40 + k: schedule fact (factorisation + fused forward elimination) / bwd: k=0 launches (task begin,end, waves, wpi, chunk, item begin,end, fused) x8; 4 step_wpi, 1 task_ptr, 2 step_ptr, 3 items
+//        60 fact segments (x8), 61 fact wave records (x16), 62 bwd segments, 63 bwd records, 64 src_entry (device replay tables)
+//        18 bwd_level
 // out == NULL returns the length.
 int64_t jg_plan_export(jg_plan* p, int which, int32_t* out, int64_t cap) {
     if (!p) return -1;
@@ -48,18 +42,13 @@ int64_t jg_plan_export(jg_plan* p, int which, int32_t* out, int64_t cap) {
         case 9: v = &S.diag; break;   case 10: v = &S.l_ptr; break; case 11: v = &S.l_ent; break;
         case 12: v = &S.l_col; break; case 13: v = &S.u_ptr; break; case 14: v = &S.u_ent; break;
         case 15: v = &S.u_col; break;  case 16: v = &S.t_d; break;  case 17: v = &S.y_level; break;
-        default: {
-            const jg::Schedule* s = which >= 40 ? &S.bwd : (which >= 20 && which < 30 ? &S.fact : nullptr);
-            if (!s) return -1;
-            switch (which % 10) {
-                case 0: flatten(*s, tmp); v = &tmp; break;
-                case 1: v = &s->task_ptr; break;
-                case 2: v = &s->step_ptr; break;
-                case 3: v = &s->items; break;
-                case 4: v = &s->step_wpi; break;
-                default: return -1;
-            }
-        }
+        case 18: v = &S.bwd_level; break;
+        case 60: tmp.assign((const int*)S.fact_seg.data(), (const int*)S.fact_seg.data() + S.fact_seg.size() * 8); v = &tmp; break;
+        case 61: tmp.assign((const int*)S.fact_rec.data(), (const int*)S.fact_rec.data() + S.fact_rec.size() * 16); v = &tmp; break;
+        case 62: tmp.assign((const int*)S.bwd_seg.data(), (const int*)S.bwd_seg.data() + S.bwd_seg.size() * 8); v = &tmp; break;
+        case 63: tmp.assign((const int*)S.bwd_rec.data(), (const int*)S.bwd_rec.data() + S.bwd_rec.size() * 16); v = &tmp; break;
+        case 64: v = &S.src_entry; break;
+        default: return -1;
     }
     if (!out) return (int64_t)v->size();
     if ((int64_t)v->size() > cap) return -1;

@@ -8,6 +8,8 @@
 
 namespace jg {
 
+void build_tables(BlockSymbolic& S);
+
 namespace {
 
 // Exact minimum-degree elimination on the (small, sparse) bus graph.  Returns the elimination
@@ -64,88 +66,99 @@ int find_in_row(const BlockSymbolic& S, int r, int c) {
     return (p != e && *p == c) ? (int)(p - S.e_col.data()) : -1;
 }
 
-// One launch per level.  Levels whose items carry long update lists (the dense tail of the
-// elimination order) get several waves per item: the list is split across `wpi` waves and reduced
-// through LDS, so the critical path of a level is ~ (terms / wpi) memory round trips instead of `terms`.
-void schedule_by_level(const std::vector<int>& level, const std::vector<int>& work, int n_items, Schedule& sch, bool fuse_narrow_prefix = false) {
+int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+// Levels -> segments -> chunks -> wave records.  `level[i]` (1-based; 0 = not scheduled) and `work[i]` (terms) per item;
+// `emit(item, first_term_slot q0, stride, out)` fills one wave's records.
+template <class Fill>
+void build_replay(const std::vector<int>& level, const std::vector<int>& work, int T, std::vector<Segment>& segs,
+                  std::vector<Rec>& recs, int& n_levels, Fill fill) {
+    const int n_items = (int)level.size();
     int nlev = 0;
     for (int i = 0; i < n_items; ++i) nlev = std::max(nlev, level[i]);
-    std::vector<int> cnt(nlev + 2, 0);
-    for (int i = 0; i < n_items; ++i) cnt[level[i] + 1]++;
-    for (int l = 0; l <= nlev; ++l) cnt[l + 1] += cnt[l];
-    sch.items.assign(n_items, 0);
-    {
-        std::vector<int> pos(cnt.begin(), cnt.end() - 1);
-        for (int i = 0; i < n_items; ++i) sch.items[pos[level[i]]++] = i;
-    }
-    sch.n_levels = nlev;
-    sch.task_ptr.assign(1, 0);
-    sch.step_ptr.assign(1, 0);
-    sch.launches.clear();
-    sch.step_wpi.clear();
-    int first_level = 1;
-    if (fuse_narrow_prefix) {
-        // Leading levels that are narrow (a handful of items, short lists) are latency-bound: a launch per level
-        // costs more than the work.  One workgroup of 16 waves per scenario group walks them as steps.
-        constexpr int FW = 16;
-        int last = 0;
-        for (int l = 1; l <= nlev; ++l) {
-            int items = cnt[l + 1] - cnt[l], tot = 0;
-            for (int i = cnt[l]; i < cnt[l + 1]; ++i) tot += work[sch.items[i]];
-            if (items == 0) continue;
-            if (items > FW || tot > 64 * FW) break;
-            last = l;
+    std::vector<std::vector<int>> by(nlev + 1);
+    for (int i = 0; i < n_items; ++i) if (level[i] > 0) by[level[i]].push_back(i);
+    segs.clear(); recs.clear();
+    n_levels = 0;
+    for (int l = 1; l <= nlev; ++l) {
+        std::vector<int>& it = by[l];
+        if (it.empty()) continue;
+        ++n_levels;
+        std::stable_sort(it.begin(), it.end(), [&](int x, int y) { return work[x] > work[y]; });   // heaviest first
+        const bool wide = it.size() >= 2048;                      // wide levels already fill the chip: do not split lists
+        auto wpi_of = [&](int i) { return std::min(wide ? 2 : 16, pow2ceil(std::max(1, (work[i] + T - 1) / T))); };
+        size_t p = 0;
+        while (p < it.size()) {
+            const int wpi = wpi_of(it[p]);
+            size_t q = p;
+            while (q < it.size() && wpi_of(it[q]) == wpi) ++q;
+            Segment sg{};
+            sg.rec_base = (int)recs.size(); sg.wpi = wpi; sg.level = l; sg.items = (int)(q - p);
+            const int slots = 16 / wpi;
+            sg.nchunks = (sg.items + slots - 1) / slots;
+            sg.rpw = std::max(1, ((work[it[p]] + wpi - 1) / wpi + T - 1) / T);
+            sg.last = q == it.size();
+            recs.resize(recs.size() + (size_t)sg.nchunks * 16 * sg.rpw);
+            for (int c = 0; c < sg.nchunks; ++c)
+                for (int w = 0; w < 16; ++w) {
+                    const size_t idx = p + (size_t)c * slots + w / wpi;
+                    Rec* r = &recs[sg.rec_base + ((size_t)c * 16 + w) * sg.rpw];
+                    for (int j = 0; j < sg.rpw; ++j) { for (int k = 0; k < 16; ++k) r[j].w[k] = 0; r[j].w[0] = -1; }
+                    if (idx < q) fill(it[idx], w % wpi, wpi, sg.rpw, r);
+                }
+            segs.push_back(sg);
+            p = q;
         }
-        if (last >= 2) {
-            Launch L;
-            L.fused = 1; L.waves = FW; L.wpi = 1; L.chunk = 0;
-            L.task_begin = (int)sch.task_ptr.size() - 1;
-            L.item_begin = cnt[1]; L.item_end = cnt[last + 1];
-            for (int l = 1; l <= last; ++l) {
-                int b = cnt[l], e = cnt[l + 1];
-                if (b == e) continue;
-                std::stable_sort(sch.items.begin() + b, sch.items.begin() + e, [&](int x, int y) { return work[x] > work[y]; });
-                int wpi = 1;
-                while (wpi * 2 * (e - b) <= FW && work[sch.items[b]] > 2 * wpi) wpi *= 2;
-                sch.step_ptr.push_back(e);
-                sch.step_wpi.push_back(wpi);
-            }
-            sch.task_ptr.push_back((int)sch.step_ptr.size() - 1);
-            L.task_end = (int)sch.task_ptr.size() - 1;
-            sch.launches.push_back(L);
-            first_level = last + 1;
-        }
-    }
-    for (int l = first_level; l <= nlev; ++l) {
-        int b = cnt[l], e = cnt[l + 1];
-        if (b == e) continue;
-        // heaviest items first inside the level (they start first on the device)
-        std::stable_sort(sch.items.begin() + b, sch.items.begin() + e, [&](int x, int y) { return work[x] > work[y]; });
-        const int maxw = work[sch.items[b]];
-        Launch L;
-        L.task_begin = (int)sch.task_ptr.size() - 1;
-        int wpi = 1;
-        while (wpi < 16 && maxw > 6 * wpi) wpi *= 2;
-        if (e - b >= 2048) wpi = std::min(wpi, 2);          // wide levels already fill the chip
-        L.wpi = wpi;
-        L.waves = std::max(4, wpi);
-        const int chunk = wpi == 1 ? 16 : L.waves / wpi;
-        L.chunk = chunk; L.item_begin = b; L.item_end = e;
-        for (int s = b; s < e; s += chunk) {
-            sch.step_ptr.push_back(std::min(s + chunk, e));
-            sch.step_wpi.push_back(wpi);
-            sch.task_ptr.push_back((int)sch.step_ptr.size() - 1);
-        }
-        L.task_end = (int)sch.task_ptr.size() - 1;
-        sch.launches.push_back(L);
     }
 }
 
 }  // namespace
 
+void build_tables(BlockSymbolic& S) {
+    const int nE = S.n_entries, n = S.n;
+    // factorisation + fused forward elimination
+    std::vector<int> level(nE + n), work(nE + n);
+    for (int e = 0; e < nE; ++e) {
+        level[e] = S.e_level[e]; work[e] = S.t_ptr[e + 1] - S.t_ptr[e];
+        if (S.inplace && work[e] == 0 && S.e_row[e] != S.e_col[e] && S.e_src[e] >= 0) level[e] = 0;   // already in place
+    }
+    for (int r = 0; r < n; ++r) { level[nE + r] = S.y_level[r]; work[nE + r] = S.l_ptr[r + 1] - S.l_ptr[r]; }
+    build_replay(level, work, FACT_T, S.fact_seg, S.fact_rec, S.n_fact_levels, [&](int it, int sub, int wpi, int rpw, Rec* r) {
+        int kind, id, src, t0, t1;
+        if (it < nE) {
+            kind = S.e_row[it] == S.e_col[it] ? 2 : (S.e_row[it] > S.e_col[it] ? 1 : 0);
+            id = it; src = S.e_src[it] < 0 ? -1 : (S.inplace ? it : S.e_src[it]); t0 = S.t_ptr[it]; t1 = S.t_ptr[it + 1];
+        } else {
+            kind = 3; id = it - nE; src = S.perm[id]; t0 = S.l_ptr[id]; t1 = S.l_ptr[id + 1];
+        }
+        for (int j = 0; j < rpw; ++j) { r[j].w[0] = kind; r[j].w[1] = id; r[j].w[2] = src; r[j].w[3] = 0; }
+        int q = 0;
+        for (int t = t0 + sub; t < t1; t += wpi, ++q) {
+            Rec& x = r[q / FACT_T];
+            const int s = 4 + 3 * (q % FACT_T);
+            if (it < nE) { x.w[s] = S.t_a[t]; x.w[s + 1] = S.t_d[t]; x.w[s + 2] = S.t_b[t]; }
+            else { x.w[s] = S.l_ent[t]; x.w[s + 1] = S.diag[S.l_col[t]]; x.w[s + 2] = S.l_col[t]; }
+            x.w[3]++;
+        }
+    });
+    // backward sweep
+    std::vector<int> uw(n);
+    for (int r = 0; r < n; ++r) uw[r] = S.u_ptr[r + 1] - S.u_ptr[r];
+    build_replay(S.bwd_level, uw, BWD_T, S.bwd_seg, S.bwd_rec, S.n_bwd_levels, [&](int k, int sub, int wpi, int rpw, Rec* r) {
+        for (int j = 0; j < rpw; ++j) { r[j].w[0] = k; r[j].w[1] = S.perm[k]; r[j].w[2] = S.diag[k]; r[j].w[3] = 0; }
+        int q = 0;
+        for (int p = S.u_ptr[k] + sub; p < S.u_ptr[k + 1]; p += wpi, ++q) {
+            Rec& x = r[q / BWD_T];
+            const int s = 4 + 2 * (q % BWD_T);
+            x.w[s] = S.u_ent[p]; x.w[s + 1] = S.u_col[p];
+            x.w[3]++;
+        }
+    });
+}
+
 int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic& S) {
-    (void)policy;
     S = BlockSymbolic();
+    S.inplace = policy & 1;
     S.n = n;
     if (n <= 0) return 1;
     // adjacency without the diagonal; verify structural symmetry and diagonal presence
@@ -203,12 +216,14 @@ int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic&
 
     // source positions in the caller's block CSR
     S.e_src.assign(S.n_entries, -1);
+    S.src_entry.assign(rowptr[n], -1);
     for (int i = 0; i < n; ++i)
         for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) {
             int e = find_in_row(S, S.iperm[i], S.iperm[col[p]]);
             if (e < 0) return 1;
             if (S.e_src[e] >= 0) return 1;                    // duplicate block in the input pattern
             S.e_src[e] = p;
+            S.src_entry[p] = e;
         }
 
     // update terms: pivot k contributes -L(i,k) U(k,j) to every (i,j) in struct(k)^2
@@ -288,17 +303,7 @@ int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic&
     for (int r = n - 1; r >= 0; --r)
         for (int p = S.u_ptr[r]; p < S.u_ptr[r + 1]; ++p) S.bwd_level[r] = std::max(S.bwd_level[r], S.bwd_level[S.u_col[p]] + 1);
 
-    {
-        std::vector<int> level(S.n_entries + n), work(S.n_entries + n), uw(n);
-        for (int e = 0; e < S.n_entries; ++e) { level[e] = S.e_level[e]; work[e] = S.t_ptr[e + 1] - S.t_ptr[e]; }
-        for (int r = 0; r < n; ++r) {
-            level[S.n_entries + r] = S.y_level[r];
-            work[S.n_entries + r] = S.l_ptr[r + 1] - S.l_ptr[r];
-            uw[r] = S.u_ptr[r + 1] - S.u_ptr[r];
-        }
-        schedule_by_level(level, work, S.n_entries + n, S.fact);
-        schedule_by_level(S.bwd_level, uw, n, S.bwd, /*fuse_narrow_prefix=*/true);
-    }
+    build_tables(S);
     return 0;
 }
 

@@ -2,8 +2,8 @@
 //
 // Replaces (as a whole) the symbolic half of the reference's third-party factorizations
 // (`lu`/`klu`/`ldlt` first call, /root/reference/src/backend/utility.jl:470-476, 486-492, 534-540):
-// fill-reducing ordering, fill pattern, and -- new here -- a static dependency schedule that the
-// device numeric kernels replay every iteration (the `lu!`/`klu!` path, utility.jl:478-484).
+// fill-reducing ordering, fill pattern, and -- new here -- static dependency levels and replay tables that
+// the device numeric kernels walk every iteration (the `lu!`/`klu!` path, utility.jl:478-484).
 //
 // The matrix is an n x n BLOCK matrix with a structurally symmetric pattern (Ybus pattern for the
 // Newton-Raphson Jacobian, pattern of H'H for the Gauss-Newton gain); every block is 2x2
@@ -16,26 +16,25 @@
 
 namespace jg {
 
-struct Launch {
-    int task_begin = 0, task_end = 0;   // tasks [begin,end) -> one workgroup column each
-    int waves = 4;                      // waves per workgroup for this launch
-    int wpi = 1;                        // waves cooperating on ONE item (its update terms are split across
-                                        // them and reduced through LDS); wpi > 1 => single-step tasks
-    int chunk = 1;                      // items per task (the last task of a launch may hold fewer)
-    int fused = 0;                      // 1: ONE task (one workgroup per scenario group) walks several narrow
-                                        //    dependency levels as barrier-separated steps (step_wpi per step)
-    int item_begin = 0, item_end = 0;   // the launch's contiguous range in Schedule::items
+// ---- device replay tables ("wave records") -----------------------------------------------------------------
+// The numeric kernels never chase pointers: every wave's work is a fixed-size 64-byte record at an address that
+// follows from (segment, chunk, wave) arithmetic alone, so it is fetched with ONE scalar load and can be
+// prefetched while the previous chunk (or the level barrier) is still in flight.
+//   segment = items of one dependency level that share (wpi, rpw); chunk = 16 waves = 16 / wpi items;
+//   record index = seg.rec_base + ((chunk * 16 + wave) * rpw + j), j < rpw.
+struct Segment {
+    int rec_base;      // first record
+    int nchunks;       // chunks of 16 waves
+    int wpi;           // waves sharing one item (update list dealt round-robin, LDS reduction)
+    int rpw;           // records per wave (a wave's share of the list: FACT_T / BWD_T terms per record)
+    int level;         // dependency level (1-based)
+    int last;          // 1: last segment of its level (a barrier / kernel boundary follows)
+    int items;         // items in the segment
+    int pad;
 };
-
-// A schedule = launches -> tasks (one workgroup each) -> steps (barrier separated) -> items.
-struct Schedule {
-    std::vector<Launch> launches;
-    std::vector<int> task_ptr;          // steps of task t: [task_ptr[t], task_ptr[t+1])
-    std::vector<int> step_ptr;          // items of step s: [step_ptr[s], step_ptr[s+1])
-    std::vector<int> items;             // entry ids (LU) or pivot ids (solves)
-    std::vector<int> step_wpi;          // waves per item of every step (1 unless the step belongs to a fused launch)
-    int n_levels = 0;
-};
+constexpr int FACT_T = 4;   // FactRec: {kind, id, src, nterms, (a, d, b) x 4}; kind -1 = idle wave
+constexpr int BWD_T = 6;    // BwdRec:  {k, bus, diag, nterms, (u_ent, u_col) x 6}; k -1 = idle wave
+struct Rec { int w[16]; };
 
 struct BlockSymbolic {
     int n = 0;
@@ -59,12 +58,19 @@ struct BlockSymbolic {
                                             //   y_k = f_k - sum_c Lh(k,c) Dinv(c) y_c      (item id n_entries + k)
     std::vector<int> u_ptr, u_ent, u_col;   // x_k = Dinv_k (y_k - sum_c U(k,c) x_c)
     std::vector<int> y_level, bwd_level;
-    Schedule fact, bwd;                 // fact items: [0,n_entries) entries, [n_entries, n_entries+n) rhs rows
     long long n_terms = 0;
+    // replay tables (see above).  policy bit 0 ("in place"): the caller assembles its blocks straight into the factor
+    // storage (entry src_entry[p] for block p), so off-diagonal entries without update terms need no work at all and
+    // are not scheduled; FactRec.src then names the entry itself.
+    int inplace = 0;
+    std::vector<int> src_entry;         // [nnz of the caller's pattern] -> entry id
+    std::vector<Segment> fact_seg, bwd_seg;
+    std::vector<Rec> fact_rec, bwd_rec;
+    int n_fact_levels = 0, n_bwd_levels = 0;
 };
 
 // pattern: CSR (rowptr[n+1], col[nnz]) 0-based, must contain the diagonal and be structurally
-// symmetric. policy: 0 = one launch per dependency level (baseline), 1 = subtree tasks + level tail.
+// symmetric. policy bit 0: in-place factor storage (see BlockSymbolic::inplace).
 // Returns 0, or 1 on a malformed pattern.
 int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic& out);
 

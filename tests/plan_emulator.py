@@ -1,20 +1,11 @@
-"""numpy replay of the static block-LU / triangular-solve schedules (TEST INFRASTRUCTURE).
+"""numpy replay of the static block-LU / triangular-solve replay tables (TEST INFRASTRUCTURE).
 
-Mirrors what the HIP kernels k_lu / k_fwd / k_bwd do for ONE scenario, walking the schedule exactly
-as the device does (launch -> task -> step -> item) and asserting that every value an item reads
-was produced in an earlier launch or an earlier step of the same task: a race detector for the
-schedule.  Not used by the product.
+Mirrors what the HIP kernels (k_fact_level / k_bwd_level and the persistent walker) do for ONE scenario:
+it walks the very tables the device reads (segment -> chunk -> wave -> 64-byte record, jg_symbolic.hpp)
+and asserts that every value a record reads was produced in an EARLIER dependency level (all items of a
+level run concurrently on the device): a race detector for the schedule.  Not used by the product.
 """
 import numpy as np
-
-
-def _walk(sch):
-    """yield (launch_index, task, step, item)"""
-    for li, (t0, t1, _w, _wpi, _chunk, _ib, _ie, _fused) in enumerate(sch["launches"]):
-        for t in range(t0, t1):
-            for s in range(sch["task_ptr"][t], sch["task_ptr"][t + 1]):
-                for idx in range(sch["step_ptr"][s], sch["step_ptr"][s + 1]):
-                    yield li, t, s, int(sch["items"][idx])
 
 
 def dfactor(D):
@@ -40,23 +31,29 @@ def dsolve(F, R):
 
 
 class Replay:
-    def __init__(self, plan):
+    """inplace=True mirrors policy bit 0: the caller's blocks already sit in the factor storage and
+    off-diagonal entries without update terms are not scheduled at all."""
+
+    def __init__(self, plan, inplace=False):
         self.p = plan
         g = plan.get
         self.perm, self.e_row, self.e_col, self.e_src = g("perm"), g("e_row"), g("e_col"), g("e_src")
-        self.t_ptr, self.t_a, self.t_d, self.t_b, self.diag = g("t_ptr"), g("t_a"), g("t_d"), g("t_b"), g("diag")
-        self.l_ptr, self.l_ent, self.l_col = g("l_ptr"), g("l_ent"), g("l_col")
-        self.u_ptr, self.u_ent, self.u_col = g("u_ptr"), g("u_ent"), g("u_col")
+        self.t_ptr, self.diag = g("t_ptr"), g("diag")
+        self.l_ptr, self.u_ptr = g("l_ptr"), g("u_ptr")
         self.nE = self.e_row.size
         self.n = plan.n
+        self.inplace = inplace
+        self.fseg, self.frec = plan.replay_tables("fact")
+        self.bseg, self.brec = plan.replay_tables("bwd")
 
     @staticmethod
-    def _visible(stamp, src, li, t, s):
-        """src produced strictly before (launch li, task t, step s)?"""
-        if stamp[src] is None:
-            return False
-        l2, t2, s2 = stamp[src]
-        return l2 < li or (l2 == li and t2 == t and s2 < s)
+    def _waves(seg, rec):
+        """yield (level, wave-group key, sub, [records of the wave]) in device order"""
+        for si, (base, nchunks, wpi, rpw, level, _last, _items, _pad) in enumerate(seg):
+            for c in range(nchunks):
+                for w in range(16):
+                    r0 = base + (c * 16 + w) * rpw
+                    yield level, (si, c, w // wpi), w % wpi, rec[r0:r0 + rpw]
 
     def factor(self, A, rhs):
         """A: [nnz_blocks,2,2] caller CSR order; rhs [n,2] original order.
@@ -64,44 +61,105 @@ class Replay:
         nE = self.nE
         X = np.zeros((nE, 2, 2))
         Y = np.zeros((self.n, 2))
-        stamp = [None] * (nE + self.n)          # entries, then rhs rows
-        for li, t, s, it in _walk(self.p.schedule("fact")):
-            assert stamp[it] is None, f"item {it} scheduled twice"
-            vis = lambda src: self._visible(stamp, src, li, t, s)
-            if it < nE:
-                e = it
-                acc = A[self.e_src[e]].copy() if self.e_src[e] >= 0 else np.zeros((2, 2))
-                for k in range(self.t_ptr[e], self.t_ptr[e + 1]):
-                    a, d, b = self.t_a[k], self.t_d[k], self.t_b[k]
-                    assert vis(a) and vis(d) and vis(b), "LU schedule race"
-                    acc -= X[a] @ dsolve(X[d], X[b])
-                X[e] = dfactor(acc) if self.e_row[e] == self.e_col[e] else acc
-            else:
-                k = it - nE
-                y = rhs[self.perm[k]].copy()
-                for p in range(self.l_ptr[k], self.l_ptr[k + 1]):
-                    c = self.l_col[p]
-                    assert vis(self.l_ent[p]) and vis(self.diag[c]) and vis(nE + c), "forward schedule race"
-                    y -= X[self.l_ent[p]] @ dsolve(X[self.diag[c]], Y[c])
-                Y[k] = y
-            stamp[it] = (li, t, s)
-        assert all(st is not None for st in stamp), "items missing from the factorisation schedule"
+        level_of = np.full(nE + self.n, -1)      # level at which an entry / rhs row becomes final (-1: never yet)
+        if self.inplace:
+            has = self.e_src >= 0
+            X[has] = A[self.e_src[has]]
+            work = np.diff(self.t_ptr)
+            untouched = has & (work == 0) & (self.e_row != self.e_col)
+            level_of[:nE][untouched] = 0         # already final before the first level
+        acc, meta = {}, {}
+
+        def flush():                              # the level is complete: its items become final together
+            for key, (lev, kind, ident) in meta.items():
+                v = acc[key]
+                if kind == 3:
+                    assert level_of[nE + ident] < 0, f"rhs row {ident} scheduled twice"
+                    Y[ident] = v
+                    level_of[nE + ident] = lev
+                else:
+                    assert level_of[ident] < 0, f"entry {ident} scheduled twice"
+                    X[ident] = dfactor(v) if kind == 2 else v
+                    level_of[ident] = lev
+            acc.clear()
+            meta.clear()
+
+        current = None
+        for level, key, sub, recs in self._waves(self.fseg, self.frec):
+            if level != current:
+                assert current is None or level > current, "segments out of level order"
+                flush()
+                current = level
+            kind, ident, src = int(recs[0][0]), int(recs[0][1]), int(recs[0][2])
+            if kind < 0:
+                continue
+            if sub == 0:
+                assert key not in meta, "two leaders in one wave group"
+                meta[key] = (level, kind, ident)
+                if kind == 3:
+                    acc[key] = np.array(rhs[src], dtype=float)
+                elif src >= 0:
+                    acc[key] = (X[src] if self.inplace else A[src]).copy()
+                    assert not self.inplace or src == ident
+                else:
+                    acc[key] = np.zeros((2, 2))
+            part = np.zeros(2) if kind == 3 else np.zeros((2, 2))
+            for r in recs:
+                assert (int(r[0]), int(r[1])) == (kind, ident), "continuation record of another item"
+                for t in range(int(r[3])):
+                    a, d, b = (int(v) for v in r[4 + 3 * t: 7 + 3 * t])
+                    assert 0 <= level_of[a] < level and 0 <= level_of[d] < level, "LU schedule race"
+                    if kind == 3:
+                        assert 0 <= level_of[nE + b] < level, "forward schedule race"
+                        part -= X[a] @ dsolve(X[d], Y[b])
+                    else:
+                        assert 0 <= level_of[b] < level, "LU schedule race"
+                        part -= X[a] @ dsolve(X[d], X[b])
+            acc[key] = acc[key] + part            # the leader (sub 0) comes first and seeds the accumulator
+        flush()
+        terms_seen = 0
+        for r in self.frec:
+            if r[0] >= 0:
+                terms_seen += int(r[3])
+        assert terms_seen == int(self.t_ptr[-1]) + int(self.l_ptr[-1]), "update terms lost or duplicated in the records"
+        assert (level_of >= 0).all(), "items missing from the factorisation schedule"
         return X, Y
 
     def backsolve(self, X, Y):
         W = Y.copy()
-        stamp = [None] * self.n
+        level_of = np.full(self.n, -1)
         out = np.zeros((self.n, 2))
-        for li, t, s, k in _walk(self.p.schedule("bwd")):
-            y = W[k].copy()
-            for p in range(self.u_ptr[k], self.u_ptr[k + 1]):
-                assert self._visible(stamp, self.u_col[p], li, t, s), "bwd schedule race"
-                y -= X[self.u_ent[p]] @ W[self.u_col[p]]
-            W[k] = dsolve(X[self.diag[k]], y)
-            out[self.perm[k]] = W[k]
-            stamp[k] = (li, t, s)
-        assert all(st is not None for st in stamp)
+        acc, meta = {}, {}
+        for level, key, sub, recs in self._waves(self.bseg, self.brec):
+            k = int(recs[0][0])
+            if k < 0:
+                continue
+            part = np.zeros(2)
+            for r in recs:
+                assert int(r[0]) == k
+                for t in range(int(r[3])):
+                    ent, col = int(r[4 + 2 * t]), int(r[5 + 2 * t])
+                    assert 0 <= level_of[col] < level, "bwd schedule race"
+                    part -= X[ent] @ W[col]
+            if sub == 0:
+                meta[key] = (level, k, int(recs[0][1]), int(recs[0][2]))
+                acc[key] = Y[k] + part
+            else:
+                acc[key] = acc[key] + part
+            # rows of one level are independent, so finishing them as soon as the group's last wave is seen is safe
+            if key in meta and sub == self._wpi_of(key) - 1:
+                lev, kk, bus, dg = meta[key]
+                assert dg == self.diag[kk] and bus == self.perm[kk]
+                W[kk] = dsolve(X[dg], acc[key])
+                out[bus] = W[kk]
+                level_of[kk] = lev
+        assert (level_of >= 0).all(), "rows missing from the backward schedule"
+        terms = sum(int(r[3]) for r in self.brec if r[0] >= 0)
+        assert terms == int(self.u_ptr[-1]), "U terms lost or duplicated in the records"
         return out
+
+    def _wpi_of(self, key):
+        return int(self.bseg[key[0]][2])
 
 
 def block_jacobian_from_csc(n, ycolptr, yrowval, typ, pq, pvpq, jcolptr, jrowval, jnz):

@@ -18,12 +18,13 @@ def _oracle_jacobian(oracle, name):
     return s, a, J, f0, inc
 
 
+@pytest.mark.parametrize("inplace", [False, True])
 @pytest.mark.parametrize("name", ["case14test", "case30test", "case118", "case1354pegase"])
-def test_schedule_replay_matches_oracle_increment(jg, oracle, name):
+def test_schedule_replay_matches_oracle_increment(jg, oracle, name, inplace):
     s, a, J, f0, inc = _oracle_jacobian(oracle, name)
     rowptr, col, A = block_jacobian_from_csc(s.n, s.colptr, s.rowval, a.type, a.pq, a.pvpq, a.jcolptr, a.jrowval, J)
-    plan = jg._lib.Plan(s.n, rowptr, col)
-    rp = Replay(plan)
+    plan = jg._lib.Plan(s.n, rowptr, col, policy=1 if inplace else 0)
+    rp = Replay(plan, inplace=inplace)
     rhs = np.zeros((s.n, 2))
     for i in range(s.n):
         if a.pvpq[i]:
@@ -67,29 +68,41 @@ def test_plan_structure_invariants(jg):
     # level monotonicity: an entry is strictly above all its sources
     lev = plan.get("e_level")
     assert np.all(lev[ent] > lev[t_a]) and np.all(lev[ent] > lev[t_b]) and np.all(lev[ent] > lev[t_d])
-    # schedules cover every item exactly once; launches tile the task and item ranges; the device's
-    # flattened addressing (item_begin + task*chunk) matches the task/step lists
-    for kind, nitems in (("fact", e_row.size + Y.n), ("bwd", Y.n)):
-        sch = plan.schedule(kind)
-        assert sorted(sch["items"].tolist()) == list(range(nitems))
-        L = sch["launches"]
-        assert L[0, 0] == 0 and L[-1, 1] == sch["task_ptr"].size - 1
-        assert np.all(L[1:, 0] == L[:-1, 1])
-        assert L[0, 5] == 0 and L[-1, 6] == nitems and np.all(L[1:, 5] == L[:-1, 6])
-        for t0, t1, waves, wpi, chunk, ib, ie, fused in L:
-            if fused:                            # one task walking several narrow levels as steps
-                assert t1 == t0 + 1 and waves == 16
-                s0, s1 = sch["task_ptr"][t0], sch["task_ptr"][t1]
-                assert sch["step_ptr"][s0] == ib and sch["step_ptr"][s1] == ie and s1 - s0 >= 2
-                for st in range(s0, s1):
-                    w, cnt = sch["step_wpi"][st], sch["step_ptr"][st + 1] - sch["step_ptr"][st]
-                    assert 16 % w == 0 and cnt >= 1
-                continue
-            assert waves % wpi == 0 and (wpi == 1 or chunk == waves // wpi) and chunk % (waves // wpi) == 0
-            for k, t in enumerate(range(t0, t1)):
-                s0, s1 = sch["task_ptr"][t], sch["task_ptr"][t + 1]
-                assert s1 == s0 + 1
-                assert sch["step_ptr"][s0] == ib + k * chunk and sch["step_ptr"][s1] == min(ib + (k + 1) * chunk, ie)
+    # replay tables: segments in level order, `last` closes every level, at most one segment per wpi class and
+    # level, records tile exactly, every item appears once (leader wave) and every term exactly once
+    src_entry = plan.get("src_entry")
+    assert np.array_equal(e_src[src_entry], np.arange(Y.nnz))
+    for kind, nitems, T in (("fact", e_row.size + Y.n, 4), ("bwd", Y.n, 6)):
+        seg, rec = plan.replay_tables(kind)
+        base, nchunks, wpi, rpw, level, last = (seg[:, k] for k in range(6))
+        assert np.all(np.diff(level) >= 0) and last[-1] == 1
+        assert np.all(last[:-1] == (level[1:] > level[:-1]))
+        assert np.all(np.isin(wpi, [1, 2, 4, 8, 16]))
+        for l in np.unique(level):
+            assert np.unique(wpi[level == l]).size == (level == l).sum() <= 5
+        assert base[0] == 0 and np.all(base[1:] == base[:-1] + nchunks[:-1] * 16 * rpw[:-1])
+        assert rec.shape[0] == base[-1] + nchunks[-1] * 16 * rpw[-1]
+        assert np.all(rec[:, 3] <= T) and np.all(rec[rec[:, 0] < 0, 3] == 0)
+    seg, rec = plan.replay_tables("fact")
+    lead = np.concatenate([np.arange(b, b + c * 16 * r, r * w) for b, c, w, r in seg[:, :4]])   # first record of each leader wave
+    lead = lead[rec[lead, 0] >= 0]
+    ids = np.where(rec[lead, 0] == 3, e_row.size + rec[lead, 1], rec[lead, 1])
+    assert sorted(ids.tolist()) == list(range(e_row.size + Y.n))
+    assert rec[rec[:, 0] >= 0, 3].sum() == t_ptr[-1] + plan.get("l_ptr")[-1]
+    seg, rec = plan.replay_tables("bwd")
+    lead = np.concatenate([np.arange(b, b + c * 16 * r, r * w) for b, c, w, r in seg[:, :4]])
+    lead = lead[rec[lead, 0] >= 0]
+    assert sorted(rec[lead, 0].tolist()) == list(range(Y.n))
+    # in-place policy: entries the assembly already finalised (off-diagonal, no update terms) are not scheduled
+    plan1 = jg._lib.Plan(Y.n, Y.colptr - 1, Y.rowval - 1, policy=1)
+    seg1, rec1 = plan1.replay_tables("fact")
+    lead1 = np.concatenate([np.arange(b, b + c * 16 * r, r * w) for b, c, w, r in seg1[:, :4]])
+    lead1 = lead1[rec1[lead1, 0] >= 0]
+    skipped = (e_src >= 0) & (np.diff(t_ptr) == 0) & (e_row != e_col)
+    assert lead1.size == e_row.size + Y.n - skipped.sum() and skipped.sum() > 20000
+    ent1 = rec1[lead1][rec1[lead1, 0] != 3]
+    assert not np.any(skipped[ent1[:, 1]])
+    assert np.all(ent1[ent1[:, 2] >= 0, 2] == ent1[ent1[:, 2] >= 0, 1])       # src names the entry itself
 
 
 def test_plan_rejects_unsymmetric_pattern(jg):
