@@ -12,6 +12,7 @@ from .measurement import (Measurement, measurement, addVoltmeter_, addAmmeter_, 
                           addPmu_, exactQuantities)
 from .stateestimation import (AcStateEstimation, gaussNewton, increment_ as incrementSE_, solve_ as solveSE_,   # noqa: F401
                               stateEstimation_, setNoise_)
+from .synthetic import pegaseShaped, case9241synth                          # noqa: F401
 from . import powerflow, stateestimation   # noqa: F401
 from . import _lib                                                           # noqa: F401
 
@@ -21,4 +22,5 @@ __all__ = [
     "Measurement", "measurement", "addVoltmeter_", "addAmmeter_", "addWattmeter_", "addVarmeter_", "addPmu_",
     "exactQuantities", "AcStateEstimation", "gaussNewton", "incrementSE_", "solveSE_", "stateEstimation_", "setNoise_",
     "outagePatch", "initializeACPowerFlow", "bridges", "outageList", "shard", "contingencyAnalysis", "gatherResults",
+    "pegaseShaped", "case9241synth",
 ]

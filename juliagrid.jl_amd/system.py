@@ -145,10 +145,14 @@ def _matpower_tables(path: str) -> dict:
 
 
 def powerSystem(source) -> PowerSystem:
-    """powerSystem("case14") / powerSystem("x.npz") / powerSystem("x.m") / powerSystem(dict)."""
+    """powerSystem("case14") / powerSystem("x.npz") / powerSystem("x.m") / powerSystem(dict);
+    "case9241synth" = the seeded PEGASE-shaped grid of synthetic.py (stands in for case9241pegase)."""
     if isinstance(source, dict):
         return PowerSystem(source)
     path = str(source)
+    if path == "case9241synth":
+        from .synthetic import case9241synth
+        return PowerSystem(case9241synth())
     if path.endswith(".m"):
         return PowerSystem(_matpower_tables(path))
     if not os.path.exists(path):

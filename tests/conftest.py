@@ -16,7 +16,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+_SYNTH = {}
+
+
 def load_case(name):
+    if name == "case9241synth":                      # seeded generator (juliagrid.jl_amd/synthetic.py), cached per session
+        if name not in _SYNTH:
+            from juliagrid.jl_amd.synthetic import case9241synth
+            _SYNTH[name] = case9241synth()
+        return {k: np.array(v) for k, v in _SYNTH[name].items()}
     with np.load(os.path.join(CASES, name + ".npz")) as z:
         return {k: z[k] for k in z.files}
 

@@ -26,7 +26,7 @@ def _pair(jg, oracle, name, batch=1):
     return s, an, o
 
 
-@pytest.mark.parametrize("name", SMALL + ["case1354pegase", "case_ACTIVSg10k"])
+@pytest.mark.parametrize("name", SMALL + ["case1354pegase", "case_ACTIVSg10k", "case9241synth"])
 def test_index_maps_bit_exact(jg, oracle, name):
     s, an, o = _pair(jg, oracle, name)
     assert np.array_equal(an.method.pq, o.pq)
@@ -38,7 +38,7 @@ def test_index_maps_bit_exact(jg, oracle, name):
     assert an.dims["dimJ"] == o.dim and an.dims["nnzJ"] == o.nnzJ
 
 
-@pytest.mark.parametrize("name", SMALL + ["case1354pegase", "case_ACTIVSg10k"])
+@pytest.mark.parametrize("name", SMALL + ["case1354pegase", "case_ACTIVSg10k", "case9241synth"])
 def test_mismatch_and_jacobian_elementwise(jg, oracle, name):
     s, an, o = _pair(jg, oracle, name)
     dp, dq = jg.mismatch_(an)
@@ -73,7 +73,8 @@ def test_matpower_goldens(jg, name, iters):
     assert np.abs(an.voltage.angle - g["newtonRaphson_voltageAngle"]).max() <= 1e-8
 
 
-@pytest.mark.parametrize("name", ["case14", "case118", "case300", "case1354pegase", "case1951rte", "case_ACTIVSg10k"])
+@pytest.mark.parametrize("name", ["case14", "case118", "case300", "case1354pegase", "case1951rte", "case_ACTIVSg10k",
+                                  "case9241synth"])
 def test_power_flow_matches_oracle(jg, oracle, name):
     s, an, o = _pair(jg, oracle, name)
     jg.powerFlow_(an)
@@ -243,3 +244,27 @@ def test_full_size_batch_properties(jg, oracle):
                 o.add_ybus(p - 1, d)
         o.set_voltage(an.voltage.magnitude[sc], an.voltage.angle[sc])
         assert max(o.mismatch()) < 1e-8
+
+
+def test_config5_shape_on_the_synthetic_9241_grid(jg, oracle):
+    """BASELINE config 5 (case9241pegase-shaped grid, batched N-1): a 64-scenario shard (what one of 8 GPUs gets
+    of the 512) from the flat start; spot-checked scenarios equal the oracle solving that outage alone."""
+    t = load_case("case9241synth")
+    s = jg.powerSystem(t)
+    labels = jg.outageList(s, 64, seed=512)
+    an = jg.contingencyAnalysis(s, labels)
+    jg.powerFlow_(an, iteration=20, tolerance=1e-8)
+    assert (an.status == 0).sum() >= 60
+    osys = oracle.OracleSystem(t)
+    for sc in (0, 13, 31, 63):
+        o = oracle.OracleNR(osys)
+        ptr, dy = jg.outagePatch(s, int(labels[sc]))
+        for p, d in zip(ptr, dy):
+            o.add_ybus(p - 1, d)
+        st = o.power_flow(iteration=20, tolerance=1e-8)
+        assert an.status[sc] == st
+        if st == 0:
+            assert an.method.iteration[sc] == o.iteration
+            vm, va = o.voltage()
+            assert np.abs(an.voltage.magnitude[sc] - vm).max() <= 1e-8
+            assert np.abs(an.voltage.angle[sc] - va).max() <= 1e-8

@@ -213,3 +213,25 @@ def test_large_grid_known_answer_and_properties(jg):
     assert np.abs(an.voltage.angle[0] - pf.voltage.angle).max() <= 1e-10
     assert np.array_equal(an.voltage.magnitude[0], an.voltage.magnitude[2])
     assert np.array_equal(an.voltage.angle[1], an.voltage.angle[2])
+
+
+def test_config4_on_the_synthetic_9241_grid(jg):
+    """BASELINE config 4 (case9241pegase-shaped grid, PMU + legacy): voltmeter at every bus, wattmeter
+    and varmeter at every bus and both ends of every in-service branch, PMUs at every 10th bus (bus phasor + from-end
+    current phasors); noise-free => the estimate is the power-flow state to 1e-10; ~0.97e5 rows."""
+    s = jg.powerSystem("case9241synth")
+    pf = jg.newtonRaphson(s)
+    jg.powerFlow_(pf, tolerance=1e-11)
+    assert pf.status == 0
+    mon = jg.measurement(s)
+    jg.addVoltmeter_(mon, pf)
+    jg.addWattmeter_(mon, pf)
+    jg.addVarmeter_(mon, pf)
+    jg.addPmu_(mon, pf, buses=range(1, s.bus.number + 1, 10), statusTo=-1, minMagnitude=1e-6)
+    an = jg.gaussNewton(mon, batch=2)
+    assert 0.9e5 <= an.dims["m"] <= 1.05e5
+    jg.stateEstimation_(an, iteration=40, tolerance=1e-11)
+    assert np.all(an.status == 0)
+    assert np.abs(an.voltage.magnitude[0] - pf.voltage.magnitude).max() <= 1e-10
+    assert np.abs(an.voltage.angle[0] - pf.voltage.angle).max() <= 1e-10
+    assert np.array_equal(an.voltage.magnitude[0], an.voltage.magnitude[1])

@@ -21,7 +21,7 @@ def load(path):
 
 
 def short(name):
-    for k in ("k_assemble", "k_fact", "k_bwd_fused", "k_bwd", "k_check", "k_compact", "k_lane_permute", "k_lane_copy",
+    for k in ("k_assemble", "k_fact_level", "k_bwd_level", "k_fact_walk", "k_bwd_walk", "k_check", "k_compact", "k_lane_permute", "k_lane_copy",
               "k_gn_rows", "k_gn_gain"):
         if k in name:
             if k == "k_assemble":
@@ -54,11 +54,11 @@ def main(fetch_csv, write_csv, n, ld, solves, out_json):
            "calibration": check, "batch_ld": ld, "solves": solves, "per_kernel_total": agg}
     per = {}
     for k, a in agg.items():
-        div = {"k_fact": solves, "k_bwd": solves, "k_bwd_fused": solves}.get(k, a["launches"] if a["launches"] else 1)
+        div = {"k_fact_level": solves, "k_bwd_level": solves, "k_fact_walk": solves, "k_bwd_walk": solves}.get(k, a["launches"] if a["launches"] else 1)
         per[k] = (a["fetch"] + a["write"]) / div
-    per["k_fwd+k_bwd"] = per.get("k_bwd", 0.0) + per.get("k_bwd_fused", 0.0)
+    per["k_fwd+k_bwd"] = per.get("k_bwd_level", 0.0) + per.get("k_bwd_walk", 0.0)
     per["k_assemble"] = per.get("k_assemble<jac>", 0.0)
-    per["k_lu"] = per.get("k_fact", 0.0)
+    per["k_lu"] = per["k_fact"] = per.get("k_fact_level", 0.0) + per.get("k_fact_walk", 0.0)
     res["traffic_per_logical_launch"] = per          # one assembly pass / one factorisation (all levels) / one backward sweep
     json.dump(res, open(out_json, "w"), indent=1)
     for k, a in sorted(agg.items()):
