@@ -70,7 +70,7 @@ def cpu_baseline(case_tables, labels, start_vm, start_va, budget_s=12.0):
             break
     dt = time.perf_counter() - t0
     return {"value": iters / dt, "unit": "NR iterations/s", "cores": 1, "kind": "port",
-            "sample": f"{done} of the same N-1 scenarios (case_ACTIVSg10k), {iters} iterations in {dt:.2f} s, "
+            "sample": f"{done} of the same N-1 scenarios, {iters} iterations in {dt:.2f} s, "
                       "oracle/jg_oracle.c: serial assembly + KLU-style refactor/solve, single thread",
             "ms_per_iteration": 1e3 * dt / max(iters, 1), "ms_per_solve": 1e3 * dt / max(done, 1)}
 
@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=512, help="scenarios per GPU")
-    ap.add_argument("--case", default="case_ACTIVSg10k")
+    ap.add_argument("--case", default="case_ACTIVSg10k", help="case_ACTIVSg10k (the metric's 10k-bus grid) | case9241synth | any fixture")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
 
@@ -102,8 +102,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))      # RCCL over xGMI
 
-    with np.load(os.path.join(ROOT, "tests", "golden", "cases", args.case + ".npz")) as z:
-        tables = {k: z[k] for k in z.files}
+    if args.case == "case9241synth":                 # the seeded PEGASE-shaped stand-in for case9241pegase
+        tables = jg.case9241synth()
+    else:
+        with np.load(os.path.join(ROOT, "tests", "golden", "cases", args.case + ".npz")) as z:
+            tables = {k: z[k] for k in z.files}
 
     # ---- setup (untimed): base case, scenario list, shard, upload ---------------------------
     B = args.batch

@@ -117,11 +117,12 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(AsmArgs a) {
                 if (j == i) { pd = de[k]; gii = g; bii = bb; continue; }
                 if (!JAC) continue;
                 // rows: P exists unless slack, Q exists for PQ; cols: theta unless slack, V for PQ (mask from the host)
+                // write-once stream (read back by the factorisation only): nontemporal, so the V/theta gathers keep the L2
                 double* o = a.A + (size_t)de[k] * 4 * ld + b;
-                o[0] = (mk & 1) ? vi * vj * ad : 0.0;            // dP_i/dtheta_j   equations.jl:109-111
-                o[ld] = (mk & 2) ? vi * ac : 0.0;                // dP_i/dV_j       equations.jl:117-119
-                o[2 * ld] = (mk & 4) ? -(vi * vj) * ac : 0.0;    // dQ_i/dtheta_j   equations.jl:134-136
-                o[3 * ld] = (mk & 8) ? vi * ad : 0.0;            // dQ_i/dV_j       equations.jl:142-144
+                __builtin_nontemporal_store((mk & 1) ? vi * vj * ad : 0.0, o);               // dP_i/dtheta_j   equations.jl:109-111
+                __builtin_nontemporal_store((mk & 2) ? vi * ac : 0.0, o + ld);               // dP_i/dV_j       equations.jl:117-119
+                __builtin_nontemporal_store((mk & 4) ? -(vi * vj) * ac : 0.0, o + 2 * ld);   // dQ_i/dtheta_j   equations.jl:134-136
+                __builtin_nontemporal_store((mk & 8) ? vi * ad : 0.0, o + 3 * ld);           // dQ_i/dV_j       equations.jl:142-144
             }
         }
         double fp = vi * s1 - pinj;                        // acPowerFlow.jl:676
@@ -134,7 +135,8 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(AsmArgs a) {
         else if (ti == 2) { d01 = 0.0; d10 = 0.0; d11 = 1.0; fq = 0.0; }
         if (JAC) {
             double* o = a.A + (size_t)pd * 4 * ld + b;
-            o[0] = d00; o[ld] = d01; o[2 * ld] = d10; o[3 * ld] = d11;
+            __builtin_nontemporal_store(d00, o); __builtin_nontemporal_store(d01, o + ld);
+            __builtin_nontemporal_store(d10, o + 2 * ld); __builtin_nontemporal_store(d11, o + 3 * ld);
         }
         a.F[((size_t)i * 2) * ld + b] = fp;
         a.F[((size_t)i * 2 + 1) * ld + b] = fq;

@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""BASELINE config 4: Gauss-Newton WLS state estimation (PMU + legacy) on the 9241-bus PEGASE-shaped grid, 1 GPU.
+
+  python tools/bench_se.py [--batch 64] [--steps 10] [--case case9241synth]
+
+Measurement set: voltmeter at every bus, wattmeter + varmeter at every bus and both ends of every
+in-service branch (variance 1e-4), PMUs at every 10th bus (bus phasor + from-end current phasors, variance 1e-8),
+synthesised from the converged power flow; scenario b reads z + sigma * N(0,1) (seed 4).  One step = restore the flat
+start in HBM and run stateEstimation! (tol 1e-8, max 40) for the whole batch.  Prints one JSON line:
+GN iterations/s, ms per solve, per-kernel times with algorithmic bytes, and the CPU oracle on one host core.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(jg, s, case, pf, budget_s=15.0):
+    """The C oracle (restatement of acWLS / normalEquation! / increment! / solve!, KLU-style LU with refactor reuse) on
+    ONE host core: the same measurement configuration, noise-free readings, flat start, repeated until the budget."""
+    from oracle import oracle as O
+    tables = jg.case9241synth() if case == "case9241synth" else None
+    if tables is None:
+        with np.load(os.path.join(ROOT, "tests", "golden", "cases", case + ".npz")) as z:
+            tables = {k: z[k] for k in z.files}
+    osys = O.OracleSystem(tables)
+    on = O.OracleNR(osys)
+    assert on.power_flow(iteration=20, tolerance=1e-11) == 0
+    vm, va = on.voltage()
+    br, _ = O.exact_quantities(osys, vm, va)
+    tab = O.MeterTable()
+    O.add_from_power_flow(tab, osys, vm, va, "voltmeter")
+    O.add_from_power_flow(tab, osys, vm, va, "wattmeter")
+    O.add_from_power_flow(tab, osys, vm, va, "varmeter")
+    sel = set(range(1, osys.n + 1, 10))
+    for i in range(osys.n):
+        if (i + 1) in sel:
+            tab.add("pmu", 0, i + 1, vm[i], 1e-8, 1, va[i], 1e-8, 1)
+    for k in np.flatnonzero(osys.status == 1):
+        if int(tables["br_from"][k]) in sel and br[k, 4] >= 1e-6:
+            tab.add("pmu", 1, k + 1, br[k, 4], 1e-8, 1, br[k, 5], 1e-8, 1)
+    n = osys.n
+    t0 = time.perf_counter()
+    gn = O.OracleGN(osys, tab, np.ones(n), np.zeros(n))           # includes the symbolic analysis, like the first GPU solve does not
+    t_setup = time.perf_counter() - t0
+    iters = solves = 0
+    t0 = time.perf_counter()
+    while True:
+        gn.set_voltage(np.ones(n), np.zeros(n))
+        gn.state_estimation(iteration=40, tolerance=1e-8)
+        iters += gn.iteration
+        solves += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": iters / dt, "unit": "GN iterations/s", "cores": 1, "kind": "port",
+            "sample": f"{solves} solves of the same measurement configuration (noise-free), {iters} iterations in {dt:.2f} s, "
+                      f"oracle/jg_oracle_se.c, single thread; model setup {t_setup:.2f} s not counted",
+            "ms_per_iteration": 1e3 * dt / max(iters, 1), "ms_per_solve": 1e3 * dt / max(solves, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--case", default="case9241synth")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+    import juliagrid.jl_amd as jg
+
+    s = jg.powerSystem(args.case)
+    pf = jg.newtonRaphson(s)
+    jg.powerFlow_(pf, tolerance=1e-11)
+    assert pf.status == 0
+    mon = jg.measurement(s)
+    jg.addVoltmeter_(mon, pf, variance=1e-4)
+    jg.addWattmeter_(mon, pf, variance=1e-4)
+    jg.addVarmeter_(mon, pf, variance=1e-4)
+    jg.addPmu_(mon, pf, buses=range(1, s.bus.number + 1, 10), statusTo=-1, minMagnitude=1e-6)
+    an = jg.gaussNewton(mon, batch=args.batch)
+    jg.setNoise_(an, np.random.Generator(np.random.PCG64(4)), scale=1.0)
+    n = s.bus.number
+    flat_vm, flat_va = np.ones(n), np.zeros(n)
+
+    def step():
+        an.setVoltage(flat_vm, flat_va)
+        jg.stateEstimation_(an, iteration=40, tolerance=1e-8, fetch=False)
+        return int(np.sum(an.method.iteration))
+
+    for _ in range(args.warmup):
+        step()
+    t0 = time.perf_counter()
+    iters = 0
+    for _ in range(args.steps):
+        iters += step()
+    dt = time.perf_counter() - t0
+    d = an.dims
+    B = args.batch
+    kern = {}
+    nnzH = d["nnzH"]
+    algo = {"rows": B * (16 * d["slots"] + 16 * d["m"] + 16 * n), "gain": B * (16 * d["slots"] + 8 * d["m"] + 32 * d["gain_blocks"] + 16 * n),
+            "factor": B * (32 * d["gain_blocks"] + 64 * d["lu_blocks"]), "backward": B * (32 * d["lu_blocks"] + 64 * n)}
+    for k, name in enumerate(("rows", "gain", "factor", "backward")):
+        ms = an.time_kernel(k, 5)
+        kern[name] = {"ms": ms, "bytes": algo[name], "GBps": algo[name] / ms / 1e6, "frac": algo[name] / ms / 1e6 / HBM_PEAK_GBS}
+    line = {"metric": "GN iterations/sec (WLS state estimation, PMU + legacy, 9241-bus PEGASE-shaped grid)", "value": iters / dt,
+            "unit": "GN iterations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "ms_per_solve_batched": 1e3 * dt / (B * args.steps), "iterations_per_scenario": iters / (B * args.steps),
+            "converged_fraction": float(np.mean(an.status == 0)), "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.case} Gauss-Newton WLS SE, {B} noisy realisations, flat start, tol 1e-8, max 40", "rows": d["m"],
+                       "nnzH": nnzH, "gain_blocks": d["gain_blocks"], "lu_blocks": d["lu_blocks"], "lu_terms": d["lu_terms"],
+                       "factor_launches": d["factor_launches"], "backward_launches": d["backward_launches"]},
+            "kernels": kern}
+    if not args.no_cpu:
+        line["cpu_baseline"] = cpu_baseline(jg, s, args.case, pf)
+        line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()
