@@ -82,6 +82,10 @@ int jg_nr_get_voltage_device(jg_nr* h, double* vm_dev, double* va_dev);
  */
 int jg_nr_patch_ybus(jg_nr* h, int64_t scenario, int64_t k, const int64_t* ptr, const double* dy_reim);
 
+/* The same for `count` consecutive scenarios starting at `scenario0` in one call (a contingency screen re-targets a
+ * whole batch between solves): ptr [count][k], dy_reim [count][k][2]; ptr 0 = unused slot of that scenario. */
+int jg_nr_patch_ybus_batch(jg_nr* h, int64_t scenario0, int64_t count, int64_t k, const int64_t* ptr, const double* dy_reim);
+
 /* Re-upload the SHARED Ybus values after an in-place edit of the system (updateBranch!(analysis; ...),
  * src/powerSystem/branch.jl:453-459 -> acNodalUpdate!, model.jl:81-110).  Same pattern as at create. */
 int jg_nr_set_ybus(jg_nr* h, const double* y_reim, const double* yt_reim);

@@ -434,30 +434,35 @@ hipEvent_t g_walk_ev[64] = {};
 
 }  // namespace
 
-int Engine::create(int n, const int* rowptr, const int* col, int ld_, int policy) {
+std::mutex& capture_mutex() {
+    static std::mutex m;
+    return m;
+}
+
+int Engine::create(int n, const int* rowptr, const int* col, int ld_, int policy, hipStream_t st) {
     if (ld_ <= 0 || ld_ % 64) { error = "batch leading dimension must be a positive multiple of 64"; return 1; }
     if (analyze(n, rowptr, col, policy, S)) { error = "block pattern must be structurally symmetric with a full diagonal"; return 1; }
     ld = ld_;
     level_launches(S.fact_seg, fact);
     level_launches(S.bwd_seg, bwd);
-    if (upload(&fact_rec, S.fact_rec, error) || upload(&bwd_rec, S.bwd_rec, error) || upload(&fact_seg, S.fact_seg, error) ||
-        upload(&bwd_seg, S.bwd_seg, error))
+    if (upload(&fact_rec, S.fact_rec, error, st) || upload(&bwd_rec, S.bwd_rec, error, st) || upload(&fact_seg, S.fact_seg, error, st) ||
+        upload(&bwd_seg, S.bwd_seg, error, st))
         return 2;
     JG_HIP(hipMalloc((void**)&X, factor_bytes()));
-    JG_HIP(hipMemset(X, 0, factor_bytes()));
+    JG_HIP(sync_fill(X, 0, factor_bytes(), st));
     JG_HIP(hipMalloc((void**)&W, (size_t)n * 2 * ld * sizeof(double)));
-    JG_HIP(hipMemset(W, 0, (size_t)n * 2 * ld * sizeof(double)));
+    JG_HIP(sync_fill(W, 0, (size_t)n * 2 * ld * sizeof(double), st));
     JG_HIP(hipMalloc((void**)&status, (size_t)ld * sizeof(int)));
-    JG_HIP(hipMemset(status, 0, (size_t)ld * sizeof(int)));
+    JG_HIP(sync_fill(status, 0, (size_t)ld * sizeof(int), st));
     JG_HIP(hipMalloc((void**)&sync, (SYNC_WORDS + 1) * sizeof(int)));
-    JG_HIP(hipMemset(sync, 0, (SYNC_WORDS + 1) * sizeof(int)));
+    JG_HIP(sync_fill(sync, 0, (SYNC_WORDS + 1) * sizeof(int), st));
     JG_HIP(hipGetDevice(&device));
     int cus = 0;
     JG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
     walk_grid = cus;                                   // one 16-wave workgroup per CU: all co-resident by construction
     if (getenv("JG_WALK_PROFILE")) {
         JG_HIP(hipMalloc((void**)&prof, (size_t)S.n_fact_levels * 3 * sizeof(long long)));
-        JG_HIP(hipMemset(prof, 0, (size_t)S.n_fact_levels * 3 * sizeof(long long)));
+        JG_HIP(sync_fill(prof, 0, (size_t)S.n_fact_levels * 3 * sizeof(long long), st));
     }
     // The walker is OPT-IN (JG_WALKER=1).  Measured on MI355X (ACTIVSg10k): its barrier costs 0.6-0.8 us against ~2 us
     // for a kernel boundary, but binding a scenario group to ONE XCD caps the group at 32 CUs x 64 B/clk of L1 fill,
@@ -474,14 +479,14 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, int policy
         FactArgs a{};
         a.seg = fact_seg; a.ld = ld;
         WalkArgs w{0, sync, 5000000LL /* 50 ms */, nullptr};
-        hipLaunchKernelGGL(k_fact_walk, dim3(walk_grid), dim3(64, 16), walk_lds(0), 0, a, w);
-        JG_HIP(hipDeviceSynchronize());
+        hipLaunchKernelGGL(k_fact_walk, dim3(walk_grid), dim3(64, 16), walk_lds(0), st, a, w);
+        JG_HIP(hipStreamSynchronize(st));
         int h[SYNC_TEAM + 16];
-        JG_HIP(hipMemcpy(h, sync, sizeof(h), hipMemcpyDeviceToHost));
+        JG_HIP(sync_copy(h, sync, sizeof(h), hipMemcpyDeviceToHost, st));
         int members = 0;
         for (int x = 0; x < 16; ++x) members += h[SYNC_TEAM + x];
         walker = h[SYNC_ERR] == 0 && h[SYNC_REG] == walk_grid && members == walk_grid;
-        JG_HIP(hipMemset(sync, 0, (SYNC_WORDS + 1) * sizeof(int)));
+        JG_HIP(sync_fill(sync, 0, (SYNC_WORDS + 1) * sizeof(int), st));
     }
     return 0;
 }

@@ -9,6 +9,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -17,6 +18,7 @@
 namespace jg {
 
 void set_last_error(const std::string& msg);   // thread-local text behind jg_last_error()
+std::mutex& capture_mutex();                   // one graph capture at a time per process (host threads must not interleave captures)
 
 // one per-level launch: grid.y walks the level's segments (at most one per wpi class 1, 2, 4, 8, 16)
 struct DevLaunch {
@@ -84,7 +86,7 @@ struct Engine {
     int device = 0;
     std::string error;
 
-    int create(int n, const int* rowptr, const int* col, int ld_, int policy);
+    int create(int n, const int* rowptr, const int* col, int ld_, int policy, hipStream_t st);   // st: the owner's stream (setup copies)
     void destroy();
     // A: block values in the caller's CSR order [nnz][4][ld]; rhs: [n][2][ld] original block order.
     // Computes A = Lh inv(D) U and y = (Lh inv(D))^-1 rhs in the same launches.
@@ -112,11 +114,23 @@ struct Engine {
         }                                                                                 \
     } while (0)
 
+// Blocking copies / fills on the HANDLE's stream, never on the legacy stream: handles are driven from several host
+// threads (ContingencyPipeline), and a legacy-stream operation issued while another thread captures its graphs fails
+// ("would make the legacy stream depend on a capturing blocking stream").
+inline hipError_t sync_copy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st) {
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, st);
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
+}
+inline hipError_t sync_fill(void* dst, int value, size_t bytes, hipStream_t st) {
+    const hipError_t e = hipMemsetAsync(dst, value, bytes, st);
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
+}
+
 template <class T>
-int upload(T** dst, const std::vector<T>& src, std::string& err) {
+int upload(T** dst, const std::vector<T>& src, std::string& err, hipStream_t st) {
     size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
     hipError_t e = hipMalloc((void**)dst, bytes);
-    if (e == hipSuccess && !src.empty()) e = hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !src.empty()) e = sync_copy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, st);
     if (e != hipSuccess) { err = std::string("upload: ") + hipGetErrorString(e); return 2; }
     return 0;
 }

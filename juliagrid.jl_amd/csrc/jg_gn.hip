@@ -362,13 +362,13 @@ int put_rows(jg_gn* h, double* dst, const double* src, int64_t stride, int rows)
         const double* s = src + (size_t)(b < h->batch ? b : h->batch - 1) * (size_t)stride;
         for (int i = 0; i < rows; ++i) t[(size_t)i * h->ld + b] = s[i];
     }
-    GN_HIP(hipMemcpy(dst, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    GN_HIP(jg::sync_copy(dst, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     return 0;
 }
 
 int get_rows(jg_gn* h, const double* src, double* dst, size_t rows) {
     std::vector<double> t(rows * h->ld);
-    GN_HIP(hipMemcpy(t.data(), src, t.size() * sizeof(double), hipMemcpyDeviceToHost));
+    GN_HIP(jg::sync_copy(t.data(), src, t.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     for (int b = 0; b < h->batch; ++b)
         for (size_t r = 0; r < rows; ++r) dst[(size_t)b * rows + r] = t[r * h->ld + b];
     return 0;
@@ -516,16 +516,17 @@ int jg_gn_create(jg_gn** out, int64_t n, const int64_t* colptr, const int64_t* r
     // ---- device -------------------------------------------------------------------------------------
     int rc = set_device(h);
     if (rc) { delete h; return rc; }
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return failg(2, "jg_gn_create: stream creation failed"); }
     std::string err;
-    if (jg::upload(&h->d_rows, rows, err) || jg::upload(&h->d_slot_bus, slot_bus, err) || jg::upload(&h->d_br, br, err) ||
-        jg::upload(&h->d_rowptr, rp, err) || jg::upload(&h->d_G, G, err) || jg::upload(&h->d_B, B, err) || jg::upload(&h->d_ydiag, ydiag, err) ||
-        jg::upload(&h->d_items, items, err) || jg::upload(&h->d_cw, cw, err) || jg::upload(&h->d_ca, ca, err) || jg::upload(&h->d_cb, cb, err) ||
-        jg::upload(&h->d_blk_row, blk_row, err) || jg::upload(&h->d_blk_col, blk_col, err)) {
+    if (jg::upload(&h->d_rows, rows, err, h->stream) || jg::upload(&h->d_slot_bus, slot_bus, err, h->stream) || jg::upload(&h->d_br, br, err, h->stream) ||
+        jg::upload(&h->d_rowptr, rp, err, h->stream) || jg::upload(&h->d_G, G, err, h->stream) || jg::upload(&h->d_B, B, err, h->stream) || jg::upload(&h->d_ydiag, ydiag, err, h->stream) ||
+        jg::upload(&h->d_items, items, err, h->stream) || jg::upload(&h->d_cw, cw, err, h->stream) || jg::upload(&h->d_ca, ca, err, h->stream) || jg::upload(&h->d_cb, cb, err, h->stream) ||
+        jg::upload(&h->d_blk_row, blk_row, err, h->stream) || jg::upload(&h->d_blk_col, blk_col, err, h->stream)) {
         jg_gn_destroy(h); return failg(2, err);
     }
     const size_t ld = h->ld;
     h->nchunk = (h->n + NORM_ROWS - 1) / NORM_ROWS;
-    auto dmalloc = [&](void** p, size_t bytes) -> bool { return hipMalloc(p, bytes) == hipSuccess && hipMemset(*p, 0, bytes) == hipSuccess; };
+    auto dmalloc = [&](void** p, size_t bytes) -> bool { return hipMalloc(p, bytes) == hipSuccess && jg::sync_fill(*p, 0, bytes, h->stream) == hipSuccess; };
     const size_t nw = (size_t)m + (size_t)std::max<int64_t>(n_corr, 0);
     bool ok = dmalloc((void**)&h->d_vm, n * ld * 8) && dmalloc((void**)&h->d_va, n * ld * 8) && dmalloc((void**)&h->d_mean, (size_t)m * ld * 8) &&
               dmalloc((void**)&h->d_w, nw * ld * 8) && dmalloc((void**)&h->d_Hs, (size_t)h->nslots * 2 * ld * 8) &&
@@ -534,11 +535,10 @@ int jg_gn_create(jg_gn** out, int64_t n, const int64_t* colptr, const int64_t* r
               dmalloc((void**)&h->d_part, (size_t)h->nchunk * ld * 8) && dmalloc((void**)&h->d_maxinc, ld * 8) &&
               dmalloc((void**)&h->d_params, 16) && dmalloc((void**)&h->d_active, ld * 4) && dmalloc((void**)&h->d_iters, ld * 4) &&
               dmalloc((void**)&h->d_status, ld * 4) && dmalloc((void**)&h->d_counter, 4) && dmalloc((void**)&h->d_group, (ld / 64) * 4);
-    if (!ok || hipHostMalloc((void**)&h->h_counter, sizeof(int)) != hipSuccess ||
-        hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (!ok || hipHostMalloc((void**)&h->h_counter, sizeof(int)) != hipSuccess) {
         jg_gn_destroy(h); return failg(2, "jg_gn_create: device allocation failed");
     }
-    rc = h->eng.create((int)n, h->gi_rowptr.data(), h->gi_col.data(), h->ld, 0);
+    rc = h->eng.create((int)n, h->gi_rowptr.data(), h->gi_col.data(), h->ld, 0, h->stream);
     if (rc) { std::string msg = h->eng.error; jg_gn_destroy(h); return failg(rc, msg); }
     *out = h;
     return 0;
@@ -608,9 +608,9 @@ int jg_gn_increment(jg_gn* h, double* maxinc) {
     GN_HIP(hipGetLastError());
     GN_HIP(hipStreamSynchronize(h->stream));
     std::vector<int> st(h->ld);
-    GN_HIP(hipMemcpy(st.data(), h->eng.status, (size_t)h->ld * 4, hipMemcpyDeviceToHost));
+    GN_HIP(jg::sync_copy(st.data(), h->eng.status, (size_t)h->ld * 4, hipMemcpyDeviceToHost, h->stream));
     for (int b = 0; b < h->batch; ++b) if (st[b] & 4) return failg(3, "jg_gn_increment: zero or non-finite pivot (singular gain matrix)");
-    if (maxinc) GN_HIP(hipMemcpy(maxinc, h->d_maxinc, (size_t)h->batch * 8, hipMemcpyDeviceToHost));
+    if (maxinc) GN_HIP(jg::sync_copy(maxinc, h->d_maxinc, (size_t)h->batch * 8, hipMemcpyDeviceToHost, h->stream));
     return 0;
 }
 
@@ -628,6 +628,7 @@ int jg_gn_run(jg_gn* h, int64_t max_iter, double tol, int32_t* iters, int32_t* s
     if (!h || max_iter < 0 || !(tol > 0.0)) return failg(1, "jg_gn_run: bad argument");
     if (int rc = set_device(h)) return rc;
     if (!h->exec) {
+        std::lock_guard<std::mutex> lk(jg::capture_mutex());
         GN_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
         hipMemsetAsync(h->d_counter, 0, sizeof(int), h->stream);
         // the first pass must see every group active: the flags of the PREVIOUS check drive group skipping
@@ -654,8 +655,8 @@ int jg_gn_run(jg_gn* h, int64_t max_iter, double tol, int32_t* iters, int32_t* s
         if (*h->h_counter == 0) break;
     }
     if (int rc = h->eng.walk_status(h->stream)) return failg(rc, h->eng.error);
-    if (iters) GN_HIP(hipMemcpy(iters, h->d_iters, (size_t)h->batch * 4, hipMemcpyDeviceToHost));
-    if (status) GN_HIP(hipMemcpy(status, h->d_status, (size_t)h->batch * 4, hipMemcpyDeviceToHost));
+    if (iters) GN_HIP(jg::sync_copy(iters, h->d_iters, (size_t)h->batch * 4, hipMemcpyDeviceToHost, h->stream));
+    if (status) GN_HIP(jg::sync_copy(status, h->d_status, (size_t)h->batch * 4, hipMemcpyDeviceToHost, h->stream));
     return 0;
 }
 
@@ -672,7 +673,7 @@ int jg_gn_get_jacobian(jg_gn* h, double* nzval) {
     if (int rc = set_device(h)) return rc;
     GN_HIP(hipStreamSynchronize(h->stream));
     std::vector<double> t((size_t)h->nslots * 2 * h->ld);
-    GN_HIP(hipMemcpy(t.data(), h->d_Hs, t.size() * 8, hipMemcpyDeviceToHost));
+    GN_HIP(jg::sync_copy(t.data(), h->d_Hs, t.size() * 8, hipMemcpyDeviceToHost, h->stream));
     for (int b = 0; b < h->batch; ++b)
         for (int64_t k = 0; k < h->nnzH; ++k) nzval[(size_t)b * h->nnzH + k] = t[(size_t)h->hmap[k] * h->ld + b];
     return 0;
@@ -703,7 +704,7 @@ int jg_gn_get_iteration(jg_gn* h, int32_t* iters) {
     if (!h || !iters) return failg(1, "jg_gn_get_iteration: bad argument");
     if (int rc = set_device(h)) return rc;
     GN_HIP(hipStreamSynchronize(h->stream));
-    GN_HIP(hipMemcpy(iters, h->d_iters, (size_t)h->batch * 4, hipMemcpyDeviceToHost));
+    GN_HIP(jg::sync_copy(iters, h->d_iters, (size_t)h->batch * 4, hipMemcpyDeviceToHost, h->stream));
     return 0;
 }
 

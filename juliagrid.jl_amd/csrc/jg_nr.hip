@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -375,7 +376,7 @@ int put_bus_array(jg_nr* h, double* dst, const double* src, int64_t stride) {
         const double* s = src + (size_t)(b < h->batch ? b : h->batch - 1) * (size_t)stride;   // pad with last scenario
         for (int i = 0; i < h->n; ++i) t[(size_t)i * h->ld + b] = s[i];
     }
-    NR_HIP(hipMemcpy(dst, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    NR_HIP(jg::sync_copy(dst, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     return 0;
 }
 
@@ -398,6 +399,7 @@ void launch_compact(jg_nr* h, int restore) {
 
 int build_graphs(jg_nr* h) {
     if (h->execA) return 0;
+    std::lock_guard<std::mutex> lk(jg::capture_mutex());
     NR_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     // graph A: who is still active?  mismatch-only pass -> verdict per scenario -> pack the active ones
     hipMemsetAsync(h->d_counter, 0, sizeof(int), h->stream);
@@ -507,6 +509,7 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
     // ---- device upload ----------------------------------------------------------------------
     int rc = set_device(h);
     if (rc) { delete h; return rc; }
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(2, "jg_nr_create: stream creation failed"); }
     std::vector<int> rp(n + 1), cl(nnz);
     std::vector<double> G(nnz), B(nnz);
     for (int i = 0; i <= n; ++i) rp[i] = (int)(colptr[i] - 1);
@@ -530,15 +533,15 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
     for (int i = 0; i < n; ++i) flags[i] = (signed char)((type[i] != 3 ? 1 : 0) | (type[i] == 1 ? 2 : 0));
     std::string err;
     std::vector<signed char> tp(type, type + n);
-    if (jg::upload(&h->d_rowptr, rp, err) || jg::upload(&h->d_col, colm, err) || jg::upload(&h->d_G, G, err) ||
-        jg::upload(&h->d_B, B, err) || jg::upload(&h->d_GB, GBv, err) || jg::upload(&h->d_rowtype, std::vector<int>(type, type + n), err) || jg::upload(&h->d_type, tp, err) || jg::upload(&h->d_flags, flags, err)) {
+    if (jg::upload(&h->d_rowptr, rp, err, h->stream) || jg::upload(&h->d_col, colm, err, h->stream) || jg::upload(&h->d_G, G, err, h->stream) ||
+        jg::upload(&h->d_B, B, err, h->stream) || jg::upload(&h->d_GB, GBv, err, h->stream) || jg::upload(&h->d_rowtype, std::vector<int>(type, type + n), err, h->stream) || jg::upload(&h->d_type, tp, err, h->stream) || jg::upload(&h->d_flags, flags, err, h->stream)) {
         jg_nr_destroy(h); return fail(2, err);
     }
     h->nchunk = (h->n + ASM_ROWS - 1) / ASM_ROWS;
     const size_t ld = h->ld;
     auto dmalloc = [&](void** p, size_t bytes) -> bool {
         if (hipMalloc(p, bytes) != hipSuccess) return false;
-        return hipMemset(*p, 0, bytes) == hipSuccess;
+        return jg::sync_fill(*p, 0, bytes, h->stream) == hipSuccess;
     };
     const size_t mpn = h->mp > 0 ? h->mp : 1;
     bool ok = dmalloc((void**)&h->d_vm, n * ld * 8) && dmalloc((void**)&h->d_va, n * ld * 8) &&
@@ -554,14 +557,13 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
               dmalloc((void**)&h->d_dest, ld * 4) && dmalloc((void**)&h->d_cflags, 16) && dmalloc((void**)&h->d_itmp, ld * 4) &&
               dmalloc((void**)&h->d_glist, (ld / 64) * 4);
     if (!ok) { jg_nr_destroy(h); return fail(2, "jg_nr_create: device allocation failed"); }
-    if (hipMemset(h->d_ppos, 0xff, mpn * ld * 4) != hipSuccess ||                 // -1 = no patch
-        hipHostMalloc((void**)&h->h_counter, sizeof(int)) != hipSuccess ||
-        hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
-        jg_nr_destroy(h); return fail(2, "jg_nr_create: stream / pinned allocation failed");
+    if (jg::sync_fill(h->d_ppos, 0xff, mpn * ld * 4, h->stream) != hipSuccess ||     // -1 = no patch
+        hipHostMalloc((void**)&h->h_counter, sizeof(int)) != hipSuccess) {
+        jg_nr_destroy(h); return fail(2, "jg_nr_create: pinned allocation failed");
     }
-    rc = h->eng.create(n, rp.data(), cl.data(), h->ld, 1);          // in place: the assembly kernel writes into the factor storage
+    rc = h->eng.create(n, rp.data(), cl.data(), h->ld, 1, h->stream);          // in place: the assembly kernel writes into the factor storage
     if (rc) { std::string m = h->eng.error; jg_nr_destroy(h); return fail(rc, m); }
-    if (jg::upload(&h->d_dst, h->eng.S.src_entry, err)) { jg_nr_destroy(h); return fail(2, err); }
+    if (jg::upload(&h->d_dst, h->eng.S.src_entry, err, h->stream)) { jg_nr_destroy(h); return fail(2, err); }
     for (int64_t k = 0; k < h->nnzJ; ++k) h->jmap[k] = (int64_t)h->eng.S.src_entry[h->jmap[k] >> 2] * 4 + (h->jmap[k] & 3);
     *out = h;
     return 0;
@@ -618,7 +620,7 @@ static int get_bus_array(jg_nr* h, const double* src, double* dst, int comps) {
     // device [n*comps][ld] -> host [batch][n*comps]
     const size_t rows = (size_t)h->n * comps;
     std::vector<double> t(rows * h->ld);
-    NR_HIP(hipMemcpy(t.data(), src, t.size() * sizeof(double), hipMemcpyDeviceToHost));
+    NR_HIP(jg::sync_copy(t.data(), src, t.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     for (int b = 0; b < h->batch; ++b)
         for (size_t r = 0; r < rows; ++r) dst[(size_t)b * rows + r] = t[r * h->ld + b];
     return 0;
@@ -677,9 +679,35 @@ int jg_nr_patch_ybus(jg_nr* h, int64_t scenario, int64_t k, const int64_t* ptr, 
             for (int mm = 0; mm < m; ++mm) if (ptr[mm] == ptr[m]) return fail(1, "jg_nr_patch_ybus: duplicate pointer");
         }
         const size_t off = (size_t)m * h->ld + scenario;
-        NR_HIP(hipMemcpy(h->d_ppos + off, &pos, sizeof(int), hipMemcpyHostToDevice));
-        NR_HIP(hipMemcpy(h->d_pdg + off, &g, sizeof(double), hipMemcpyHostToDevice));
-        NR_HIP(hipMemcpy(h->d_pdb + off, &b, sizeof(double), hipMemcpyHostToDevice));
+        NR_HIP(jg::sync_copy(h->d_ppos + off, &pos, sizeof(int), hipMemcpyHostToDevice, h->stream));
+        NR_HIP(jg::sync_copy(h->d_pdg + off, &g, sizeof(double), hipMemcpyHostToDevice, h->stream));
+        NR_HIP(jg::sync_copy(h->d_pdb + off, &b, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    h->jac_valid = false;
+    return 0;
+}
+
+int jg_nr_patch_ybus_batch(jg_nr* h, int64_t scenario0, int64_t count, int64_t k, const int64_t* ptr, const double* dy) {
+    if (!h || scenario0 < 0 || count < 1 || scenario0 + count > h->batch || k < 0 || k > h->mp || (k > 0 && (!ptr || !dy)))
+        return fail(1, "jg_nr_patch_ybus_batch: bad argument (scenario range / entry count beyond max_patch)");
+    if (int rc = set_device(h)) return rc;
+    NR_HIP(hipStreamSynchronize(h->stream));
+    std::vector<int> pos((size_t)count);
+    std::vector<double> g((size_t)count), b((size_t)count);
+    for (int m = 0; m < h->mp; ++m) {
+        for (int64_t s = 0; s < count; ++s) {
+            pos[s] = -1; g[s] = 0.0; b[s] = 0.0;
+            if (m < k && ptr[s * k + m] != 0) {
+                const int64_t p = ptr[s * k + m];
+                if (p < 1 || p > h->nnz) return fail(1, "jg_nr_patch_ybus_batch: pointer out of range");
+                for (int mm = 0; mm < m; ++mm) if (ptr[s * k + mm] == p) return fail(1, "jg_nr_patch_ybus_batch: duplicate pointer");
+                pos[s] = h->tperm[p - 1]; g[s] = dy[2 * (s * k + m)]; b[s] = dy[2 * (s * k + m) + 1];
+            }
+        }
+        const size_t off = (size_t)m * h->ld + scenario0;
+        NR_HIP(jg::sync_copy(h->d_ppos + off, pos.data(), (size_t)count * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        NR_HIP(jg::sync_copy(h->d_pdg + off, g.data(), (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        NR_HIP(jg::sync_copy(h->d_pdb + off, b.data(), (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->stream));
     }
     h->jac_valid = false;
     return 0;
@@ -697,7 +725,7 @@ int jg_nr_set_ybus(jg_nr* h, const double* y_reim, const double* yt_reim) {
     NR_HIP(hipStreamSynchronize(h->stream));
     std::vector<double2> GBv(h->nnz);
     for (int p = 0; p < h->nnz; ++p) GBv[p] = double2{G[p], B[p]};
-    NR_HIP(hipMemcpy(h->d_GB, GBv.data(), GBv.size() * sizeof(double2), hipMemcpyHostToDevice));
+    NR_HIP(jg::sync_copy(h->d_GB, GBv.data(), GBv.size() * sizeof(double2), hipMemcpyHostToDevice, h->stream));
     h->jac_valid = false;
     return 0;
 }
@@ -710,8 +738,8 @@ int jg_nr_mismatch(jg_nr* h, double* max_p, double* max_q) {
     NR_HIP(hipGetLastError());
     NR_HIP(hipStreamSynchronize(h->stream));
     h->jac_valid = true;
-    if (max_p) NR_HIP(hipMemcpy(max_p, h->d_normp, (size_t)h->batch * 8, hipMemcpyDeviceToHost));
-    if (max_q) NR_HIP(hipMemcpy(max_q, h->d_normq, (size_t)h->batch * 8, hipMemcpyDeviceToHost));
+    if (max_p) NR_HIP(jg::sync_copy(max_p, h->d_normp, (size_t)h->batch * 8, hipMemcpyDeviceToHost, h->stream));
+    if (max_q) NR_HIP(jg::sync_copy(max_q, h->d_normq, (size_t)h->batch * 8, hipMemcpyDeviceToHost, h->stream));
     return 0;
 }
 
@@ -731,7 +759,7 @@ int jg_nr_solve(jg_nr* h) {
     if (int rc = h->eng.walk_status(h->stream)) return fail(rc, h->eng.error);
     h->jac_valid = false;
     std::vector<int> st(h->ld);
-    NR_HIP(hipMemcpy(st.data(), h->eng.status, (size_t)h->ld * 4, hipMemcpyDeviceToHost));
+    NR_HIP(jg::sync_copy(st.data(), h->eng.status, (size_t)h->ld * 4, hipMemcpyDeviceToHost, h->stream));
     for (int b = 0; b < h->batch; ++b) if (st[b] & 4) return fail(3, "jg_nr_solve: zero or non-finite pivot (singular Jacobian)");
     return 0;
 }
@@ -763,7 +791,7 @@ int jg_nr_run(jg_nr* h, int64_t max_iter, double tol, int32_t* iters, int32_t* s
         NR_HIP(hipStreamSynchronize(h->stream));
         if (trace) {
             int cf[4];
-            hipMemcpy(cf, h->d_cflags, sizeof(cf), hipMemcpyDeviceToHost);
+            jg::sync_copy(cf, h->d_cflags, sizeof(cf), hipMemcpyDeviceToHost, h->stream);
             fprintf(stderr, "[jg_nr_run] iteration %lld: %d scenarios still active, %d of %d lane groups in use%s\n", (long long)it,
                     *h->h_counter, cf[2], h->ld / 64, cf[0] ? " (compacted)" : "");
         }
@@ -777,8 +805,8 @@ int jg_nr_run(jg_nr* h, int64_t max_iter, double tol, int32_t* iters, int32_t* s
     NR_HIP(hipStreamSynchronize(h->stream));
     if (int rc = h->eng.walk_status(h->stream)) return fail(rc, h->eng.error);
     h->jac_valid = false;
-    if (iters) NR_HIP(hipMemcpy(iters, h->d_iters, (size_t)h->batch * 4, hipMemcpyDeviceToHost));
-    if (status) NR_HIP(hipMemcpy(status, h->d_status, (size_t)h->batch * 4, hipMemcpyDeviceToHost));
+    if (iters) NR_HIP(jg::sync_copy(iters, h->d_iters, (size_t)h->batch * 4, hipMemcpyDeviceToHost, h->stream));
+    if (status) NR_HIP(jg::sync_copy(status, h->d_status, (size_t)h->batch * 4, hipMemcpyDeviceToHost, h->stream));
     return 0;
 }
 
@@ -822,7 +850,7 @@ int jg_nr_get_jacobian(jg_nr* h, double* nzval) {
     if (!h->jac_valid) { launch_assemble(h); h->jac_valid = true; }      // Jacobian at the current state
     NR_HIP(hipStreamSynchronize(h->stream));
     std::vector<double> t((size_t)h->eng.S.n_entries * 4 * h->ld);     // the factor storage holds the Jacobian until the next factorisation
-    NR_HIP(hipMemcpy(t.data(), h->eng.X, t.size() * 8, hipMemcpyDeviceToHost));
+    NR_HIP(jg::sync_copy(t.data(), h->eng.X, t.size() * 8, hipMemcpyDeviceToHost, h->stream));
     for (int b = 0; b < h->batch; ++b)
         for (int64_t k = 0; k < h->nnzJ; ++k) nzval[(size_t)b * h->nnzJ + k] = t[(size_t)h->jmap[k] * h->ld + b];
     return 0;
@@ -842,7 +870,7 @@ int jg_nr_get_iteration(jg_nr* h, int32_t* iters) {
     if (!h || !iters) return fail(1, "jg_nr_get_iteration: bad argument");
     if (int rc = set_device(h)) return rc;
     NR_HIP(hipStreamSynchronize(h->stream));
-    NR_HIP(hipMemcpy(iters, h->d_iters, (size_t)h->batch * 4, hipMemcpyDeviceToHost));
+    NR_HIP(jg::sync_copy(iters, h->d_iters, (size_t)h->batch * 4, hipMemcpyDeviceToHost, h->stream));
     return 0;
 }
 

@@ -266,3 +266,15 @@ def setOutage_(an: AcPowerFlow, scenario: int, label: int | None):
         return
     ptr, dy = outagePatch(an.system, label)
     _lib.check(_lib.lib().jg_nr_patch_ybus(an._h, int(scenario), 4, ptr, _reim(dy)))
+
+
+def setOutages_(an: AcPowerFlow, labels, scenario0: int = 0):
+    """setOutage_ for consecutive scenarios in ONE upload: scenario scenario0 + s = base grid with branch labels[s] out
+    of service (0 / None = base grid)."""
+    labels = list(labels)
+    ptr = np.zeros((len(labels), 4), dtype=np.int64)
+    dy = np.zeros((len(labels), 4), dtype=np.complex128)
+    for s, lab in enumerate(labels):
+        if lab:
+            ptr[s], dy[s] = outagePatch(an.system, int(lab))
+    _lib.check(_lib.lib().jg_nr_patch_ybus_batch(an._h, int(scenario0), len(labels), 4, ptr.reshape(-1), _reim(dy.reshape(-1))))

@@ -268,3 +268,28 @@ def test_config5_shape_on_the_synthetic_9241_grid(jg, oracle):
             vm, va = o.voltage()
             assert np.abs(an.voltage.magnitude[sc] - vm).max() <= 1e-8
             assert np.abs(an.voltage.angle[sc] - va).max() <= 1e-8
+
+
+def test_pipeline_equals_one_batch_at_a_time(jg):
+    """ContingencyPipeline (several batches in flight on separate handles / streams / host threads) returns, per
+    scenario, exactly what one handle solving the batches one after the other returns (bitwise)."""
+    s = jg.powerSystem(load_case("case1354pegase"))
+    base = jg.newtonRaphson(s)
+    jg.powerFlow_(base)
+    start = (base.voltage.magnitude.copy(), base.voltage.angle.copy())
+    labels = [int(x) for x in jg.outageList(s, 150, seed=3)]          # 150 scenarios in batches of 64: 64 + 64 + 22
+    pipe = jg.ContingencyPipeline(s, 64, inflight=3, start=start)
+    states = {}
+    jobs = [labels[i:i + 64] for i in range(0, len(labels), 64)]
+    res = pipe.run(jobs, on_done=lambda j, h: states.__setitem__(j, (h._pull_voltage(), h.voltage.magnitude.copy(), h.voltage.angle.copy())))
+    it, st = pipe.screen(labels)
+    assert np.array_equal(it, np.concatenate([r[0][:len(j)] for r, j in zip(res, jobs)]))
+    one = jg.ContingencyPipeline(s, 64, inflight=1, start=start)
+    for j, job in enumerate(jobs):
+        ref = one.run([job], fetch=True)[0]
+        assert np.array_equal(ref[0][:len(job)], res[j][0][:len(job)]) and np.array_equal(ref[1][:len(job)], res[j][1][:len(job)])
+        assert np.array_equal(one.handles[0].voltage.magnitude[:len(job)], states[j][1][:len(job)])
+        assert np.array_equal(one.handles[0].voltage.angle[:len(job)], states[j][2][:len(job)])
+    assert (st == 0).sum() >= len(labels) - 3
+    pipe.close()
+    one.close()
