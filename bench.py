@@ -190,15 +190,15 @@ def main():
             k["GBps"] = k["bytes"] / (k["ms"] * 1e-3) / 1e9
             k["frac"] = k["GBps"] / HBM_PEAK_GBS
         dom = max(kern, key=lambda k: kern[k]["ms"])
-        names = {"assembly": "k_assemble", "lu": "k_fact", "solve": "k_bwd"}
+        names = {"assembly": "k_assemble", "lu": "k_fact_level", "solve": "k_bwd_level"}
         # HBM bytes per logical launch from the committed PMC passes (profiles/pmc_traffic.json: FETCH_SIZE x2 +
-        # WRITE_SIZE, calibrated on a kernel of known byte count); only valid for the batch it was collected at
+        # WRITE_SIZE, calibrated on a kernel of known byte count); only valid for the grid and batch it was collected at
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 pj = json.load(open(pmc))
-                if int(pj.get("batch_ld", 0)) == an.batch:
+                if int(pj.get("batch_ld", 0)) == an.batch and pj.get("grid") == args.case:
                     key = {"assembly": "k_assemble", "lu": "k_fact", "solve": "k_fwd+k_bwd"}[dom]
                     traffic = pj["traffic_per_logical_launch"].get(key)
                     for kk, nm in (("assembly", "k_assemble"), ("lu", "k_fact"), ("solve", "k_fwd+k_bwd")):

@@ -30,7 +30,7 @@ def short(name):
     return name[:40]
 
 
-def main(fetch_csv, write_csv, n, ld, solves, out_json):
+def main(fetch_csv, write_csv, n, ld, solves, out_json, grid="case_ACTIVSg10k"):
     f, w = load(fetch_csv), load(write_csv)
     # calibration on the n-row lane permutation launches (known: n*ld*8 bytes read and written)
     known = n * ld * 8
@@ -51,7 +51,7 @@ def main(fetch_csv, write_csv, n, ld, solves, out_json):
             a[tag] += sum(v[0] for v in vals) * 1024.0 * fac
             a["launches"] = max(a["launches"], len(vals))
     res = {"unit": "bytes", "corrections": {"FETCH_SIZE": "KiB x 2 (gfx950 half-count)", "WRITE_SIZE": "KiB x 1"},
-           "calibration": check, "batch_ld": ld, "solves": solves, "per_kernel_total": agg}
+           "calibration": check, "grid": grid, "batch_ld": ld, "solves": solves, "per_kernel_total": agg}
     per = {}
     for k, a in agg.items():
         div = {"k_fact_level": solves, "k_bwd_level": solves, "k_fact_walk": solves, "k_bwd_walk": solves}.get(k, a["launches"] if a["launches"] else 1)
@@ -68,4 +68,4 @@ def main(fetch_csv, write_csv, n, ld, solves, out_json):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6])
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6], *(sys.argv[7:8]))

@@ -10,4 +10,4 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace -d $REPO/gpurun_out/pmc_${TAG}_$C -o p --output-format csv -- python $REPO/tools/profile_kernels.py $B $S > $REPO/gpurun_out/pmc_${TAG}_$C.log 2>&1
 done
 cd $REPO
-python tools/pmc_summary.py gpurun_out/pmc_${TAG}_FETCH_SIZE/p_counter_collection.csv gpurun_out/pmc_${TAG}_WRITE_SIZE/p_counter_collection.csv 10000 $B $S gpurun_out/pmc_${TAG}.json
+python tools/pmc_summary.py gpurun_out/pmc_${TAG}_FETCH_SIZE/p_counter_collection.csv gpurun_out/pmc_${TAG}_WRITE_SIZE/p_counter_collection.csv 10000 $B $S gpurun_out/pmc_${TAG}.json case_ACTIVSg10k
