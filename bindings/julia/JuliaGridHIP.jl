@@ -99,4 +99,24 @@ function JuliaGrid.updateBranch!(a::HipPowerFlow; label, kwargs...)   # branch.j
         a.handle.ptr, reim_interleaved(ac.nodalMatrix.nzval), reim_interleaved(ac.nodalMatrixTranspose.nzval)))
 end
 
+# Batched N-1 screening (no counterpart in the reference, which loops updateBranch!/powerFlow! per outage,
+# branch.jl:453-459): scenario s of a batched analysis = base grid with branch labels[s] out of service, expressed as the
+# 4 Ybus edits acNodalUpdate! would make (model.jl:93-101); one upload for the whole batch.
+function setOutages!(a::HipPowerFlow, labels::Vector{Int64})
+    ac, Y = a.base.system.model.ac, a.base.system.model.ac.nodalMatrix
+    lay = a.base.system.branch.layout
+    ptr = zeros(Int64, 4, length(labels)); dy = zeros(Float64, 2, 4, length(labels))
+    position(r, c) = (p = searchsortedfirst(view(Y.rowval, Y.colptr[c]:(Y.colptr[c + 1] - 1)), r); Y.colptr[c] + p - 1)
+    for (s, k) in enumerate(labels)
+        k == 0 && continue
+        i, j = lay.from[k], lay.to[k]
+        ptr[:, s] = [position(i, i), position(j, j), position(i, j), position(j, i)]
+        for (m, v) in enumerate((ac.nodalFromFrom[k], ac.nodalToTo[k], ac.nodalFromTo[k], ac.nodalToFrom[k]))
+            dy[1, m, s], dy[2, m, s] = -real(v), -imag(v)
+        end
+    end
+    check(ccall((:jg_nr_patch_ybus_batch, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Float64}),
+        a.handle.ptr, 0, length(labels), 4, ptr, dy))
+end
+
 end # module

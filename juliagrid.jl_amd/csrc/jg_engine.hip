@@ -137,11 +137,14 @@ __device__ __forceinline__ void fact_chunk(const FactArgs& a, double* red, const
             if (kind == 3) { c.v00 = a.rhs[((size_t)src * 2) * ld + b]; c.v01 = a.rhs[((size_t)src * 2 + 1) * ld + b]; }
             else if (src >= 0) c = load_blk(a.A + (size_t)src * 4 * ld + b, ld);
         }
-        fact_record(a, first, kind, b, ld, c);
+        // long lists: the wave's next record is requested before the current one is consumed (the tables are static)
+        RecS cur = first;
         for (int j = 1; j < rpw; ++j) {
-            const RecS r = load_rec(a.rec, rec_index + j);
-            fact_record(a, r, kind, b, ld, c);
+            const RecS nxt = load_rec(a.rec, rec_index + j);
+            fact_record(a, cur, kind, b, ld, c);
+            cur = nxt;
         }
+        fact_record(a, cur, kind, b, ld, c);
         if (wpi > 1 && sub != 0) {
             double* q = red + (size_t)wave * 256 + lane;
             q[0] = c.v00; q[64] = c.v01; q[128] = c.v10; q[192] = c.v11;
@@ -191,11 +194,13 @@ __device__ __forceinline__ void bwd_chunk(const BwdArgs& a, double* red, const R
             y0 = a.W[((size_t)k * 2) * ld + b]; y1 = a.W[((size_t)k * 2 + 1) * ld + b];
             d = load_blk(a.X + (size_t)dg * 4 * ld + b, ld);
         }
-        bwd_record(a, first, b, ld, y0, y1);
+        RecS cur = first;
         for (int j = 1; j < rpw; ++j) {
-            const RecS r = load_rec(a.rec, rec_index + j);
-            bwd_record(a, r, b, ld, y0, y1);
+            const RecS nxt = load_rec(a.rec, rec_index + j);
+            bwd_record(a, cur, b, ld, y0, y1);
+            cur = nxt;
         }
+        bwd_record(a, cur, b, ld, y0, y1);
         if (wpi > 1 && sub != 0) { red[(size_t)wave * 128 + lane] = y0; red[(size_t)wave * 128 + 64 + lane] = y1; }
     }
     if (wpi > 1) __syncthreads();
