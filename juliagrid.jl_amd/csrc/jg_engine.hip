@@ -26,6 +26,7 @@ struct FactArgs {
     const Rec* rec; const Segment* seg;
     const double* A; const double* rhs; double* X; double* W; int* status; GroupSel sel;
     int ld, seg_begin;         // per-level launches: blockIdx.y selects the level's segment seg_begin + y
+    int lanes;                 // real scenarios: lane offsets are clamped to lanes - 1
 };
 
 struct BwdArgs {
@@ -33,11 +34,9 @@ struct BwdArgs {
     const double* X; double* W; double* out; GroupSel sel;
     StateUpdate upd;
     int ld, seg_begin;
+    int lanes;
 };
 
-struct Blk { double v00, v01, v10, v11; };
-
-__device__ __forceinline__ Blk load_blk(const double* p, size_t ld) { return Blk{p[0], p[ld], p[2 * ld], p[3 * ld]}; }
 
 // Diagonal blocks are kept FACTORED, not inverted: a 2x2 LU with partial pivoting inside the block,
 //   v00 = 1/u11, v01 = u12, v10 = l (+4 when the two rows were swapped; |l| <= 1), v11 = 1/u22.
@@ -78,13 +77,13 @@ __device__ __forceinline__ void fact_record(const FactArgs& a, const RecS& r, in
 #pragma unroll
     for (int t = 0; t < FACT_T; ++t) {
         if (t < nt) {
-            l[t] = load_blk(a.X + (size_t)rec_word(r, 4 + 3 * t) * 4 * ld + b, ld);
-            d[t] = load_blk(a.X + (size_t)rec_word(r, 5 + 3 * t) * 4 * ld + b, ld);
+            l[t] = load_blk(a.X, (size_t)rec_word(r, 4 + 3 * t), b, ld);
+            d[t] = load_blk(a.X, (size_t)rec_word(r, 5 + 3 * t), b, ld);
             if (kind == 3) {
-                const double* pw = a.W + (size_t)rec_word(r, 6 + 3 * t) * 2 * ld + b;
-                u[t].v00 = pw[0]; u[t].v10 = pw[ld]; u[t].v01 = 0.0; u[t].v11 = 0.0;
+                const double2 w = load_vec(a.W, (size_t)rec_word(r, 6 + 3 * t), b, ld);
+                u[t].v00 = w.x; u[t].v10 = w.y; u[t].v01 = 0.0; u[t].v11 = 0.0;
             } else {
-                u[t] = load_blk(a.X + (size_t)rec_word(r, 6 + 3 * t) * 4 * ld + b, ld);
+                u[t] = load_blk(a.X, (size_t)rec_word(r, 6 + 3 * t), b, ld);
             }
         }
     }
@@ -105,11 +104,9 @@ __device__ __forceinline__ void fact_record(const FactArgs& a, const RecS& r, in
 
 __device__ __forceinline__ void fact_finish(const FactArgs& a, int kind, int id, size_t b, size_t ld, const Blk& c) {
     if (kind == 3) {
-        a.W[((size_t)id * 2) * ld + b] = c.v00;
-        a.W[((size_t)id * 2 + 1) * ld + b] = c.v01;
+        store_vec(a.W, (size_t)id, b, ld, c.v00, c.v01);
         return;
     }
-    double* q = a.X + (size_t)id * 4 * ld + b;
     if (kind == 2) {                            // diagonal block: 2x2 LU with in-block partial pivoting
         const bool sw = fabs(c.v10) > fabs(c.v00);
         const double u11 = sw ? c.v10 : c.v00, u12 = sw ? c.v11 : c.v01;
@@ -119,9 +116,9 @@ __device__ __forceinline__ void fact_finish(const FactArgs& a, int kind, int id,
         const double u22 = o22 - l * u12;
         const double iu22 = 1.0 / u22;
         if (!(fabs(u11) > 0.0) || !(fabs(u22) > 0.0) || !(fabs(iu11) < 1.0e300) || !(fabs(iu22) < 1.0e300)) atomicOr(a.status + b, 4);
-        q[0] = iu11; q[ld] = u12; q[2 * ld] = sw ? l + 4.0 : l; q[3 * ld] = iu22;
+        store_blk(a.X, (size_t)id, b, ld, iu11, u12, sw ? l + 4.0 : l, iu22);
     } else {
-        q[0] = c.v00; q[ld] = c.v01; q[2 * ld] = c.v10; q[3 * ld] = c.v11;
+        store_blk(a.X, (size_t)id, b, ld, c.v00, c.v01, c.v10, c.v11);
     }
 }
 
@@ -134,8 +131,8 @@ __device__ __forceinline__ void fact_chunk(const FactArgs& a, double* red, const
     Blk c{0.0, 0.0, 0.0, 0.0};
     if (kind >= 0) {
         if (sub == 0) {
-            if (kind == 3) { c.v00 = a.rhs[((size_t)src * 2) * ld + b]; c.v01 = a.rhs[((size_t)src * 2 + 1) * ld + b]; }
-            else if (src >= 0) c = load_blk(a.A + (size_t)src * 4 * ld + b, ld);
+            if (kind == 3) { const double2 f = load_vec(a.rhs, (size_t)src, b, ld); c.v00 = f.x; c.v01 = f.y; }
+            else if (src >= 0) c = load_blk(a.A, (size_t)src, b, ld);
         }
         // long lists: the wave's next record is requested before the current one is consumed (the tables are static)
         RecS cur = first;
@@ -145,16 +142,17 @@ __device__ __forceinline__ void fact_chunk(const FactArgs& a, double* red, const
             cur = nxt;
         }
         fact_record(a, cur, kind, b, ld, c);
-        if (wpi > 1 && sub != 0) {
-            double* q = red + (size_t)wave * 256 + lane;
-            q[0] = c.v00; q[64] = c.v01; q[128] = c.v10; q[192] = c.v11;
+        if (wpi > 1 && sub != 0) {                              // partial sums as two 16-byte halves: [wave][half][lane]
+            double2* q = (double2*)red + (size_t)wave * 128 + lane;
+            q[0] = double2{c.v00, c.v01}; q[64] = double2{c.v10, c.v11};
         }
     }
     if (wpi > 1) __syncthreads();
     if (kind >= 0 && sub == 0) {
         for (int w = 1; w < wpi; ++w) {
-            const double* q = red + (size_t)(wave + w) * 256 + lane;
-            c.v00 += q[0]; c.v01 += q[64]; c.v10 += q[128]; c.v11 += q[192];
+            const double2* q = (const double2*)red + (size_t)(wave + w) * 128 + lane;
+            const double2 h0 = q[0], h1 = q[64];
+            c.v00 += h0.x; c.v01 += h0.y; c.v10 += h1.x; c.v11 += h1.y;
         }
         fact_finish(a, kind, id, b, ld, c);
     }
@@ -167,9 +165,9 @@ __device__ __forceinline__ void bwd_record(const BwdArgs& a, const RecS& r, size
 #pragma unroll
     for (int t = 0; t < BWD_T; ++t) {
         if (t < nt) {
-            m[t] = load_blk(a.X + (size_t)rec_word(r, 4 + 2 * t) * 4 * ld + b, ld);
-            const double* pw = a.W + (size_t)rec_word(r, 5 + 2 * t) * 2 * ld + b;
-            w0[t] = pw[0]; w1[t] = pw[ld];
+            m[t] = load_blk(a.X, (size_t)rec_word(r, 4 + 2 * t), b, ld);
+            const double2 w = load_vec(a.W, (size_t)rec_word(r, 5 + 2 * t), b, ld);
+            w0[t] = w.x; w1[t] = w.y;
         }
     }
 #pragma unroll
@@ -191,8 +189,9 @@ __device__ __forceinline__ void bwd_chunk(const BwdArgs& a, double* red, const R
     Blk d{0.0, 0.0, 0.0, 0.0};
     if (k >= 0) {
         if (sub == 0) {
-            y0 = a.W[((size_t)k * 2) * ld + b]; y1 = a.W[((size_t)k * 2 + 1) * ld + b];
-            d = load_blk(a.X + (size_t)dg * 4 * ld + b, ld);
+            const double2 y = load_vec(a.W, (size_t)k, b, ld);
+            y0 = y.x; y1 = y.y;
+            d = load_blk(a.X, (size_t)dg, b, ld);
         }
         RecS cur = first;
         for (int j = 1; j < rpw; ++j) {
@@ -201,17 +200,15 @@ __device__ __forceinline__ void bwd_chunk(const BwdArgs& a, double* red, const R
             cur = nxt;
         }
         bwd_record(a, cur, b, ld, y0, y1);
-        if (wpi > 1 && sub != 0) { red[(size_t)wave * 128 + lane] = y0; red[(size_t)wave * 128 + 64 + lane] = y1; }
+        if (wpi > 1 && sub != 0) ((double2*)red)[(size_t)wave * 64 + lane] = double2{y0, y1};
     }
     if (wpi > 1) __syncthreads();
     if (k >= 0 && sub == 0) {
-        for (int w = 1; w < wpi; ++w) { y0 += red[(size_t)(wave + w) * 128 + lane]; y1 += red[(size_t)(wave + w) * 128 + 64 + lane]; }
+        for (int w = 1; w < wpi; ++w) { const double2 p = ((const double2*)red)[(size_t)(wave + w) * 64 + lane]; y0 += p.x; y1 += p.y; }
         double x0, x1;
         dsolve(d, y0, y1, x0, x1);
-        a.W[((size_t)k * 2) * ld + b] = x0;
-        a.W[((size_t)k * 2 + 1) * ld + b] = x1;
-        a.out[((size_t)bus * 2) * ld + b] = x0;
-        a.out[((size_t)bus * 2 + 1) * ld + b] = x1;
+        store_vec(a.W, (size_t)k, b, ld, x0, x1);
+        store_vec(a.out, (size_t)bus, b, ld, x0, x1);
         if (a.upd.va) {
             const bool act = a.upd.active ? (a.upd.active[b] != 0) : true;
             const int fl = uniform((int)a.upd.flags[bus]);
@@ -237,7 +234,7 @@ __device__ __forceinline__ void level_body(const Args& a, double* red) {
     const int lane = threadIdx.x;
     const int wave = uniform(threadIdx.y);
     const size_t ld = (size_t)a.ld;
-    const size_t b = (size_t)grp * 64 + lane;
+    const size_t b = (size_t)min(grp * 64 + lane, a.lanes - 1);
     const size_t ri = (size_t)base + ((size_t)bx * 16 + wave) * rpw;
     const RecS r = load_rec(a.rec, ri);
     if constexpr (BWD) bwd_chunk(a, red, r, ri, rpw, wpi, wave, lane, b, ld);
@@ -375,7 +372,7 @@ __device__ __forceinline__ void walk_body(Args& a, const WalkArgs& w, double* re
             const int slot = t.index + gs * t.nteams;
             const int g = a.sel.list ? uniform(a.sel.list[slot]) : slot;
             if (!(a.sel.flags && !a.sel.flags[g])) {
-                const size_t b = (size_t)g * 64 + lane;
+                const size_t b = (size_t)min(g * 64 + lane, a.lanes - 1);
                 if constexpr (BWD) bwd_chunk(a, red, r, ri, rpw, wpi, wave, lane, b, ld);
                 else fact_chunk(a, red, r, ri, rpw, wpi, wave, lane, b, ld);
             }
@@ -482,7 +479,7 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, int policy
         JG_HIP(hipFuncSetAttribute((const void*)k_bwd_walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds(WALK_MAX_SEG)));
         // census: can every workgroup of a walk become resident and do the XCD teams form?  (a walk with no segments)
         FactArgs a{};
-        a.seg = fact_seg; a.ld = ld;
+        a.seg = fact_seg; a.ld = ld; a.lanes = ld;
         WalkArgs w{0, sync, 5000000LL /* 50 ms */, nullptr};
         hipLaunchKernelGGL(k_fact_walk, dim3(walk_grid), dim3(64, 16), walk_lds(0), st, a, w);
         JG_HIP(hipStreamSynchronize(st));
@@ -539,7 +536,7 @@ int Engine::walk_status(hipStream_t st) {
 
 int Engine::factor(hipStream_t st, const double* A, const double* rhs, const GroupSel& sel, int mode) {
     if (!S.inplace && !A) { error = "factor: no source matrix"; return 1; }
-    FactArgs a{fact_rec, fact_seg, S.inplace ? X : A, rhs, X, W, status, sel, ld, 0};
+    FactArgs a{fact_rec, fact_seg, S.inplace ? X : A, rhs, X, W, status, sel, ld, 0, lanes > 0 ? lanes : ld};
     if (walker && mode != 1) {
         WalkArgs w{(int)S.fact_seg.size(), sync, 100000000LL /* 1 s */, prof};
         JG_HIP(hipMemsetAsync(sync, 0, SYNC_WORDS * sizeof(int), st));
@@ -557,7 +554,7 @@ int Engine::factor(hipStream_t st, const double* A, const double* rhs, const Gro
 }
 
 int Engine::backsolve(hipStream_t st, double* out, const StateUpdate& upd, const GroupSel& sel, int mode) {
-    BwdArgs a{bwd_rec, bwd_seg, X, W, out, sel, upd, ld, 0};
+    BwdArgs a{bwd_rec, bwd_seg, X, W, out, sel, upd, ld, 0, lanes > 0 ? lanes : ld};
     if (walker && mode != 1) {
         WalkArgs w{(int)S.bwd_seg.size(), sync, 100000000LL /* 1 s */, nullptr};
         JG_HIP(hipMemsetAsync(sync, 0, SYNC_WORDS * sizeof(int), st));

@@ -2,10 +2,15 @@
 //
 // Numeric half of the factorization seam of the reference
 // (/root/reference/src/backend/utility.jl:478-484 `lu!`/`klu!`, :576-586 `ldiv!`), for B
-// independent scenarios at once.  Layout is batch-minor ("structure of scenarios"):
-//     value(entry e, component c, scenario b) = X[(e*4 + c) * ld + b]
-// so the 64 lanes of a wavefront work on the same structural block of 64 scenarios: every load
-// and store is a contiguous 512-byte segment, no divergence, one shared symbolic structure.
+// independent scenarios at once.  Layout is batch-minor with the components of an item interleaved per scenario:
+//     block entry e, component c = 2h + c', scenario b:  X[((e * 2 + h) * ld + b) * 2 + c']   (block row h = 16 bytes per scenario)
+//     2-vector row k, component c, scenario b:           W[(k * ld + b) * 2 + c]             (16 bytes per scenario)
+// so the 64 lanes of a wavefront work on the same structural item of 64 scenarios and move it with 16-byte-per-lane
+// instructions (global_load/store_dwordx4), each covering 1 KiB of CONTIGUOUS memory (a [e][ld][4] interleave would
+// make every instruction touch 2 KiB at half density: measured 0.16 -> 0.25 ms on the assembly's write stream).  Why 16 bytes: a CU retires one vector
+// memory instruction per ~16 clocks whatever its width (measured, scratch_gpu/ldrate.hip: 6.8 ns per wave-instruction
+// for 8 B and for 16 B per lane), and the narrow dependency levels of the LU are bound by exactly that issue rate,
+// so a 2x2 block costs 2 instructions instead of 4.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -56,6 +61,28 @@ __host__ __device__ inline int group_stride(int groups) {
 #ifdef __HIPCC__
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// 2x2 block / 2-vector of one scenario: two (one) 16-byte accesses
+struct Blk { double v00, v01, v10, v11; };
+__device__ __forceinline__ Blk load_blk(const double* base, size_t item, size_t b, size_t ld) {
+    const double2* p = (const double2*)base + item * 2 * ld + b;
+    const double2 r0 = p[0], r1 = p[ld];
+    return Blk{r0.x, r0.y, r1.x, r1.y};
+}
+__device__ __forceinline__ void store_blk(double* base, size_t item, size_t b, size_t ld, double v00, double v01, double v10, double v11) {
+    double2* p = (double2*)base + item * 2 * ld + b;
+    p[0] = double2{v00, v01}; p[ld] = double2{v10, v11};
+}
+__device__ __forceinline__ void store_blk_nt(double* base, size_t item, size_t b, size_t ld, double v00, double v01, double v10, double v11) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2* p = (d2*)base + item * 2 * ld + b;       // write-once stream: nontemporal, two 16-byte stores of 1 KiB per wave each
+    __builtin_nontemporal_store(d2{v00, v01}, p);
+    __builtin_nontemporal_store(d2{v10, v11}, p + ld);
+}
+__device__ __forceinline__ double2 load_vec(const double* base, size_t item, size_t b, size_t ld) { return *(const double2*)(base + (item * ld + b) * 2); }
+__device__ __forceinline__ void store_vec(double* base, size_t item, size_t b, size_t ld, double v0, double v1) {
+    *(double2*)(base + (item * ld + b) * 2) = double2{v0, v1};
+}
+
 // blockIdx.x -> (scenario group g, chunk x) of an nx-chunk launch; false: nothing to do for this workgroup
 __device__ __forceinline__ bool map_block(const GroupSel& sel, int ld, int nx, int& g, int& x) {
     const int id = blockIdx.x;
@@ -72,6 +99,8 @@ __device__ __forceinline__ bool map_block(const GroupSel& sel, int ld, int nx, i
 struct Engine {
     BlockSymbolic S;
     int ld = 0;                    // padded batch (multiple of 64)
+    int lanes = 0;                 // real scenarios (<= ld; set by the owner, default ld): lanes beyond alias the last real one,
+                                   // so a small batch moves 8 bytes per load instruction instead of 512
     Rec* fact_rec = nullptr; Rec* bwd_rec = nullptr;           // wave records (jg_symbolic.hpp), replay order
     Segment* fact_seg = nullptr; Segment* bwd_seg = nullptr;
     double* X = nullptr;           // factor values [n_entries][4][ld]: U, unscaled Lh, factored diagonal blocks

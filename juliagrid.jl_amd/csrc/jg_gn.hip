@@ -214,8 +214,7 @@ __global__ __launch_bounds__(256) void k_gn_gain(GainArgs a) {
             if (i == a.slack) { g00 = 0.0; g01 = 0.0; }          // removeColumn(H, slack) on both sides (:885)
             if (j == a.slack) { g00 = 0.0; g10 = 0.0; }
             if (i == a.slack && j == a.slack) g00 = 1.0;         // gain[slack, slack] = 1 (:889)
-            double* q = a.Gv + (size_t)id * 4 * ld + b;
-            q[0] = g00; q[ld] = g01; q[2 * ld] = g10; q[3 * ld] = g11;
+            jg::store_blk(a.Gv, (size_t)id, b, ld, g00, g01, g10, g11);
         } else {
             double r0 = 0.0, r1 = 0.0;
             for (int c = c0; c < c1; ++c) {
@@ -225,8 +224,7 @@ __global__ __launch_bounds__(256) void k_gn_gain(GainArgs a) {
                 r0 += pa[0] * rr; r1 += pa[ld] * rr;
             }
             if (id == a.slack) r0 = 0.0;
-            a.rhs[((size_t)id * 2) * ld + b] = r0;
-            a.rhs[((size_t)id * 2 + 1) * ld + b] = r1;
+            jg::store_vec(a.rhs, (size_t)id, b, ld, r0, r1);
         }
     }
 }
@@ -241,9 +239,10 @@ __global__ __launch_bounds__(256) void k_gn_norm(double* inc, double* part, int 
     const int r0 = blockIdx.x * NORM_ROWS, r1 = min(r0 + NORM_ROWS, n);
     double mx = 0.0;
     for (int i = r0 + wave; i < r1; i += 4) {
-        double t = inc[((size_t)i * 2) * ld + b];
-        const double v = inc[((size_t)i * 2 + 1) * ld + b];
-        if (i == slack) { t = 0.0; inc[((size_t)i * 2) * ld + b] = 0.0; }
+        const double2 iv = jg::load_vec(inc, (size_t)i, b, ld);
+        double t = iv.x;
+        const double v = iv.y;
+        if (i == slack) { t = 0.0; jg::store_vec(inc, (size_t)i, b, ld, 0.0, v); }
         const double at = fabs(t), av = fabs(v);
         mx = (at > mx || at != at) ? at : mx;
         mx = (av > mx || av != av) ? av : mx;
@@ -285,8 +284,9 @@ __global__ __launch_bounds__(256) void k_gn_update(const double* inc, double* vm
     if (active && !active[b]) return;
     const int r0 = blockIdx.x * NORM_ROWS, r1 = min(r0 + NORM_ROWS, n);
     for (int i = r0 + wave; i < r1; i += 4) {
-        va[(size_t)i * ld + b] += inc[((size_t)i * 2) * ld + b];
-        vm[(size_t)i * ld + b] += inc[((size_t)i * 2 + 1) * ld + b];
+        const double2 iv = jg::load_vec(inc, (size_t)i, b, ld);
+        va[(size_t)i * ld + b] += iv.x;
+        vm[(size_t)i * ld + b] += iv.y;
     }
 }
 
@@ -690,12 +690,12 @@ int jg_gn_get_increment(jg_gn* h, double* inc) {
     if (!h || !inc) return failg(1, "jg_gn_get_increment: bad argument");
     if (int rc = set_device(h)) return rc;
     GN_HIP(hipStreamSynchronize(h->stream));
-    std::vector<double> t((size_t)h->n * 2 * h->batch);
-    if (int rc = get_rows(h, h->d_inc, t.data(), (size_t)h->n * 2)) return rc;
+    std::vector<double> t((size_t)h->n * 2 * h->ld);                               // device [n][ld][2]
+    GN_HIP(jg::sync_copy(t.data(), h->d_inc, t.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     for (int b = 0; b < h->batch; ++b)                                             // [theta_1..n, V_1..n] like se.increment
         for (int i = 0; i < h->n; ++i) {
-            inc[(size_t)b * 2 * h->n + i] = t[(size_t)b * 2 * h->n + 2 * i];
-            inc[(size_t)b * 2 * h->n + h->n + i] = t[(size_t)b * 2 * h->n + 2 * i + 1];
+            inc[(size_t)b * 2 * h->n + i] = t[((size_t)i * h->ld + b) * 2];
+            inc[(size_t)b * 2 * h->n + h->n + i] = t[((size_t)i * h->ld + b) * 2 + 1];
         }
     return 0;
 }

@@ -49,7 +49,7 @@ struct AsmArgs {
     const double* vm; const double* va; const double* p; const double* q;
     const int* ppos; const double* pdg; const double* pdb;
     double* A; double* F; double* part; jg::GroupSel sel;
-    int n; int ld; int mp; int nchunk;
+    int n; int ld; int mp; int nchunk; int lanes;
 };
 
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(AsmArgs a) {
     const int lane = threadIdx.x;
     const int wave = uniform(threadIdx.y);
     const size_t ld = (size_t)a.ld;
-    const size_t b = (size_t)grp * 64 + lane;
+    const size_t b = (size_t)min(grp * 64 + lane, a.lanes - 1);        // lanes beyond the batch alias its last scenario
     int ppos[MP > 0 ? MP : 1];
 #pragma unroll
     for (int m = 0; m < MP; ++m) ppos[m] = a.ppos[(size_t)m * ld + b];
@@ -119,11 +119,11 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(AsmArgs a) {
                 if (!JAC) continue;
                 // rows: P exists unless slack, Q exists for PQ; cols: theta unless slack, V for PQ (mask from the host)
                 // write-once stream (read back by the factorisation only): nontemporal, so the V/theta gathers keep the L2
-                double* o = a.A + (size_t)de[k] * 4 * ld + b;
-                __builtin_nontemporal_store((mk & 1) ? vi * vj * ad : 0.0, o);               // dP_i/dtheta_j   equations.jl:109-111
-                __builtin_nontemporal_store((mk & 2) ? vi * ac : 0.0, o + ld);               // dP_i/dV_j       equations.jl:117-119
-                __builtin_nontemporal_store((mk & 4) ? -(vi * vj) * ac : 0.0, o + 2 * ld);   // dQ_i/dtheta_j   equations.jl:134-136
-                __builtin_nontemporal_store((mk & 8) ? vi * ad : 0.0, o + 3 * ld);           // dQ_i/dV_j       equations.jl:142-144
+                jg::store_blk_nt(a.A, (size_t)de[k], b, ld,
+                                 (mk & 1) ? vi * vj * ad : 0.0,            // dP_i/dtheta_j   equations.jl:109-111
+                                 (mk & 2) ? vi * ac : 0.0,                 // dP_i/dV_j       equations.jl:117-119
+                                 (mk & 4) ? -(vi * vj) * ac : 0.0,         // dQ_i/dtheta_j   equations.jl:134-136
+                                 (mk & 8) ? vi * ad : 0.0);                // dQ_i/dV_j       equations.jl:142-144
             }
         }
         double fp = vi * s1 - pinj;                        // acPowerFlow.jl:676
@@ -135,12 +135,9 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(AsmArgs a) {
         if (ti == 3) { d00 = 1.0; d01 = 0.0; d10 = 0.0; d11 = 1.0; fp = 0.0; fq = 0.0; }
         else if (ti == 2) { d01 = 0.0; d10 = 0.0; d11 = 1.0; fq = 0.0; }
         if (JAC) {
-            double* o = a.A + (size_t)pd * 4 * ld + b;
-            __builtin_nontemporal_store(d00, o); __builtin_nontemporal_store(d01, o + ld);
-            __builtin_nontemporal_store(d10, o + 2 * ld); __builtin_nontemporal_store(d11, o + 3 * ld);
+            jg::store_blk_nt(a.A, (size_t)pd, b, ld, d00, d01, d10, d11);
         }
-        a.F[((size_t)i * 2) * ld + b] = fp;
-        a.F[((size_t)i * 2 + 1) * ld + b] = fq;
+        jg::store_vec(a.F, (size_t)i, b, ld, fp, fq);
         // NaN-propagating max: a NaN mismatch must not look converged
         const double afp = fabs(fp), afq = fabs(fq);
         maxp = (afp > maxp || afp != afp) ? afp : maxp;
@@ -272,19 +269,26 @@ __global__ __launch_bounds__(1024) void k_compact(CompactArgs a) {
 }
 
 // dst[row][dest[b]] = src[row][b] for `rows` rows (no-op unless flags[0]); then the copy back
+// ELEM doubles per (row, lane): 1 for V / theta / P / Q rows, 2 for the interleaved mismatch / increment rows
+template <int ELEM>
 __global__ void k_lane_permute(const double* src, double* dst, const int* dest, const int* flags, int rows, int ld) {
     if (!flags[0]) return;
     const int b = blockIdx.y * 256 + threadIdx.x;
     if (b >= ld) return;
     const int d = dest[b];
-    for (int r = blockIdx.x; r < rows; r += gridDim.x) dst[(size_t)r * ld + d] = src[(size_t)r * ld + b];
+    for (int r = blockIdx.x; r < rows; r += gridDim.x)
+#pragma unroll
+        for (int e = 0; e < ELEM; ++e) dst[((size_t)r * ld + d) * ELEM + e] = src[((size_t)r * ld + b) * ELEM + e];
 }
 
+template <int ELEM>
 __global__ void k_lane_copy(const double* src, double* dst, const int* flags, int rows, int ld) {
     if (!flags[0]) return;
     const int b = blockIdx.y * 256 + threadIdx.x;
     if (b >= ld) return;
-    for (int r = blockIdx.x; r < rows; r += gridDim.x) dst[(size_t)r * ld + b] = src[(size_t)r * ld + b];
+    for (int r = blockIdx.x; r < rows; r += gridDim.x)
+#pragma unroll
+        for (int e = 0; e < ELEM; ++e) dst[((size_t)r * ld + b) * ELEM + e] = src[((size_t)r * ld + b) * ELEM + e];
 }
 
 // [n][ld] batch-minor -> [batch][n] scenario-major, tiled through LDS so both sides stay coalesced
@@ -346,7 +350,7 @@ jg::GroupSel active_groups(jg_nr* h) { return jg::GroupSel{nullptr, h->d_glist, 
 
 void launch_assemble(jg_nr* h, const jg::GroupSel& sel = jg::GroupSel{}, bool jac = true) {
     AsmArgs a{h->d_rowptr, h->d_col, h->d_GB, h->d_rowtype, h->d_dst, h->d_vm, h->d_va, h->d_p, h->d_q,
-              h->d_ppos, h->d_pdg, h->d_pdb, h->eng.X, h->d_F, h->d_part, sel, h->n, h->ld, h->mp, h->nchunk};
+              h->d_ppos, h->d_pdg, h->d_pdb, h->eng.X, h->d_F, h->d_part, sel, h->n, h->ld, h->mp, h->nchunk, h->batch};
     dim3 grid((unsigned)h->nchunk * jg::group_stride(h->ld / 64)), block(64, ASM_WAVES);
     if (jac) {
         switch (h->mp) {
@@ -389,12 +393,17 @@ void launch_compact(jg_nr* h, int restore) {
     const dim3 block(256), gy((unsigned)((h->ld + 255) / 256));
     auto permute = [&](double* x, int rows) {
         const dim3 grid((unsigned)std::min(rows, 2048), gy.x);
-        hipLaunchKernelGGL(k_lane_permute, grid, block, 0, h->stream, x, tmp, h->d_dest, h->d_cflags, rows, h->ld);
-        hipLaunchKernelGGL(k_lane_copy, grid, block, 0, h->stream, tmp, x, h->d_cflags, rows, h->ld);
+        hipLaunchKernelGGL(k_lane_permute<1>, grid, block, 0, h->stream, x, tmp, h->d_dest, h->d_cflags, rows, h->ld);
+        hipLaunchKernelGGL(k_lane_copy<1>, grid, block, 0, h->stream, tmp, x, h->d_cflags, rows, h->ld);
+    };
+    auto permute2 = [&](double* x, int rows) {                 // rows of interleaved 2-vectors
+        const dim3 grid((unsigned)std::min(rows, 2048), gy.x);
+        hipLaunchKernelGGL(k_lane_permute<2>, grid, block, 0, h->stream, x, tmp, h->d_dest, h->d_cflags, rows, h->ld);
+        hipLaunchKernelGGL(k_lane_copy<2>, grid, block, 0, h->stream, tmp, x, h->d_cflags, rows, h->ld);
     };
     permute(h->d_vm, h->n); permute(h->d_va, h->n); permute(h->d_p, h->n); permute(h->d_q, h->n);
     if (h->mp > 0) { permute(h->d_pdg, h->mp); permute(h->d_pdb, h->mp); }
-    if (restore) { permute(h->d_F, 2 * h->n); permute(h->d_inc, 2 * h->n); }
+    if (restore) { permute2(h->d_F, h->n); permute2(h->d_inc, h->n); }
 }
 
 int build_graphs(jg_nr* h) {
@@ -564,6 +573,7 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
     rc = h->eng.create(n, rp.data(), cl.data(), h->ld, 1, h->stream);          // in place: the assembly kernel writes into the factor storage
     if (rc) { std::string m = h->eng.error; jg_nr_destroy(h); return fail(rc, m); }
     if (jg::upload(&h->d_dst, h->eng.S.src_entry, err, h->stream)) { jg_nr_destroy(h); return fail(2, err); }
+    h->eng.lanes = h->batch;
     for (int64_t k = 0; k < h->nnzJ; ++k) h->jmap[k] = (int64_t)h->eng.S.src_entry[h->jmap[k] >> 2] * 4 + (h->jmap[k] & 3);
     *out = h;
     return 0;
@@ -617,12 +627,13 @@ int jg_nr_set_voltage(jg_nr* h, const double* vm, const double* va, int64_t stri
 }
 
 static int get_bus_array(jg_nr* h, const double* src, double* dst, int comps) {
-    // device [n*comps][ld] -> host [batch][n*comps]
+    // device [n][ld][comps] -> host [batch][n*comps]
     const size_t rows = (size_t)h->n * comps;
     std::vector<double> t(rows * h->ld);
     NR_HIP(jg::sync_copy(t.data(), src, t.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     for (int b = 0; b < h->batch; ++b)
-        for (size_t r = 0; r < rows; ++r) dst[(size_t)b * rows + r] = t[r * h->ld + b];
+        for (size_t i = 0; i < (size_t)h->n; ++i)
+            for (int c = 0; c < comps; ++c) dst[(size_t)b * rows + i * comps + c] = t[(i * h->ld + b) * comps + c];
     return 0;
 }
 
@@ -852,7 +863,7 @@ int jg_nr_get_jacobian(jg_nr* h, double* nzval) {
     std::vector<double> t((size_t)h->eng.S.n_entries * 4 * h->ld);     // the factor storage holds the Jacobian until the next factorisation
     NR_HIP(jg::sync_copy(t.data(), h->eng.X, t.size() * 8, hipMemcpyDeviceToHost, h->stream));
     for (int b = 0; b < h->batch; ++b)
-        for (int64_t k = 0; k < h->nnzJ; ++k) nzval[(size_t)b * h->nnzJ + k] = t[(size_t)h->jmap[k] * h->ld + b];
+        for (int64_t k = 0; k < h->nnzJ; ++k) nzval[(size_t)b * h->nnzJ + k] = t[(((size_t)(h->jmap[k] >> 2) * 2 + ((h->jmap[k] >> 1) & 1)) * h->ld + b) * 2 + (h->jmap[k] & 1)];
     return 0;
 }
 
