@@ -27,6 +27,8 @@ struct FactArgs {
     const double* A; const double* rhs; double* X; double* W; int* status; GroupSel sel;
     int ld, seg_begin;         // per-level launches: blockIdx.y selects the level's segment seg_begin + y
     int lanes;                 // real scenarios: lane offsets are clamped to lanes - 1
+    int s0_base, s0_nchunks, s0_wpi, s0_rpw;   // the level's FIRST segment travels in the kernel arguments (one dependent
+                                               // scalar load less on the critical path of every level; most narrow levels have one)
 };
 
 struct BwdArgs {
@@ -35,6 +37,7 @@ struct BwdArgs {
     StateUpdate upd;
     int ld, seg_begin;
     int lanes;
+    int s0_base, s0_nchunks, s0_wpi, s0_rpw;
 };
 
 
@@ -227,10 +230,13 @@ typedef const SegS __attribute__((address_space(4)))* SegPtr;
 
 template <bool BWD, class Args>
 __device__ __forceinline__ void level_body(const Args& a, double* red) {
-    const SegS sg = ((SegPtr)a.seg)[a.seg_begin + blockIdx.y];
-    const int base = sg[0], wpi = sg[2], rpw = sg[3];
+    int base = a.s0_base, nchunks = a.s0_nchunks, wpi = a.s0_wpi, rpw = a.s0_rpw;
+    if (blockIdx.y != 0) {
+        const SegS sg = ((SegPtr)a.seg)[a.seg_begin + blockIdx.y];
+        base = sg[0]; nchunks = sg[1]; wpi = sg[2]; rpw = sg[3];
+    }
     int grp, bx;
-    if (!map_block(a.sel, a.ld, sg[1], grp, bx)) return;
+    if (!map_block(a.sel, a.ld, nchunks, grp, bx)) return;
     const int lane = threadIdx.x;
     const int wave = uniform(threadIdx.y);
     const size_t ld = (size_t)a.ld;
@@ -536,7 +542,7 @@ int Engine::walk_status(hipStream_t st) {
 
 int Engine::factor(hipStream_t st, const double* A, const double* rhs, const GroupSel& sel, int mode) {
     if (!S.inplace && !A) { error = "factor: no source matrix"; return 1; }
-    FactArgs a{fact_rec, fact_seg, S.inplace ? X : A, rhs, X, W, status, sel, ld, 0, lanes > 0 ? lanes : ld};
+    FactArgs a{fact_rec, fact_seg, S.inplace ? X : A, rhs, X, W, status, sel, ld, 0, lanes > 0 ? lanes : ld, 0, 0, 1, 1};
     if (walker && mode != 1) {
         WalkArgs w{(int)S.fact_seg.size(), sync, 100000000LL /* 1 s */, prof};
         JG_HIP(hipMemsetAsync(sync, 0, SYNC_WORDS * sizeof(int), st));
@@ -547,6 +553,7 @@ int Engine::factor(hipStream_t st, const double* A, const double* rhs, const Gro
     const int gs = group_stride(ld / 64);
     for (const DevLaunch& L : fact) {
         a.seg_begin = L.seg_begin;
+        { const Segment& g = S.fact_seg[L.seg_begin]; a.s0_base = g.rec_base; a.s0_nchunks = g.nchunks; a.s0_wpi = g.wpi; a.s0_rpw = g.rpw; }
         hipLaunchKernelGGL(k_fact_level, dim3((unsigned)L.grid * gs, L.nseg), dim3(64, 16), 16 * 256 * sizeof(double), st, a);
     }
     JG_HIP(hipGetLastError());
@@ -554,7 +561,7 @@ int Engine::factor(hipStream_t st, const double* A, const double* rhs, const Gro
 }
 
 int Engine::backsolve(hipStream_t st, double* out, const StateUpdate& upd, const GroupSel& sel, int mode) {
-    BwdArgs a{bwd_rec, bwd_seg, X, W, out, sel, upd, ld, 0, lanes > 0 ? lanes : ld};
+    BwdArgs a{bwd_rec, bwd_seg, X, W, out, sel, upd, ld, 0, lanes > 0 ? lanes : ld, 0, 0, 1, 1};
     if (walker && mode != 1) {
         WalkArgs w{(int)S.bwd_seg.size(), sync, 100000000LL /* 1 s */, nullptr};
         JG_HIP(hipMemsetAsync(sync, 0, SYNC_WORDS * sizeof(int), st));
@@ -565,6 +572,7 @@ int Engine::backsolve(hipStream_t st, double* out, const StateUpdate& upd, const
     const int gs = group_stride(ld / 64);
     for (const DevLaunch& L : bwd) {
         a.seg_begin = L.seg_begin;
+        { const Segment& g = S.bwd_seg[L.seg_begin]; a.s0_base = g.rec_base; a.s0_nchunks = g.nchunks; a.s0_wpi = g.wpi; a.s0_rpw = g.rpw; }
         hipLaunchKernelGGL(k_bwd_level, dim3((unsigned)L.grid * gs, L.nseg), dim3(64, 16), 16 * 128 * sizeof(double), st, a);
     }
     JG_HIP(hipGetLastError());
