@@ -32,7 +32,7 @@ struct FactArgs {
 };
 
 struct BwdArgs {
-    const Rec* rec; const Segment* seg;
+    const Rec* rec; const Segment* seg; const int* chain;
     const double* X; double* W; double* out; GroupSel sel;
     StateUpdate upd;
     int ld, seg_begin;
@@ -182,6 +182,113 @@ __device__ __forceinline__ void bwd_record(const BwdArgs& a, const RecS& r, size
     }
 }
 
+// x_k = D_k^-1 y, stored in pivot order (W), scattered to original order (out), optional fused state update
+__device__ __forceinline__ double2 bwd_finish(const BwdArgs& a, const Blk& d, double y0, double y1, int k, int bus, size_t b, size_t ld) {
+    double x0, x1;
+    dsolve(d, y0, y1, x0, x1);
+    store_vec(a.W, (size_t)k, b, ld, x0, x1);
+    store_vec(a.out, (size_t)bus, b, ld, x0, x1);
+    if (a.upd.va) {
+        const bool act = a.upd.active ? (a.upd.active[b] != 0) : true;
+        const int fl = uniform((int)a.upd.flags[bus]);
+        if (act && (fl & 1)) a.upd.va[(size_t)bus * ld + b] += a.upd.sign * x0;
+        if (act && (fl & 2)) a.upd.vm[(size_t)bus * ld + b] += a.upd.sign * x1;
+    }
+    return double2{x0, x1};
+}
+
+// One backward CHAIN (jg_symbolic.hpp): rows k_0 < ... < k_{nb-1} of one supernode, external columns E shared by all.
+//   phase A (parallel): acc_p = y_p - sum_{e in E} U(k_p, e) x_e, x_E staged once in LDS, wpr waves per row;
+//   phase B (sequential over the chain, one workgroup barrier per pivot): x_c = D_c^-1 acc_c, then acc_p -= U(k_p, k_c) x_c
+//   for p < c.  Row p is owned by wave p % 16 in phase B, so the only hand-off per pivot is x_c (double-buffered in LDS);
+//   the blocks of a step are requested CHAIN_PF steps ahead (they do not depend on x).
+// LDS: acc[CHAIN_MAX_ROWS] | xe[CHAIN_MAX_EXT] | part[16] | xc[2]  (double2 per lane each).
+constexpr int CHAIN_PF = 3;
+typedef const int __attribute__((address_space(4)))* CIntPtr;     // immutable task data: scalar loads
+constexpr int CHAIN_LDS_D2 = (CHAIN_MAX_ROWS + CHAIN_MAX_EXT + 16 + 2) * 64;
+
+__device__ __forceinline__ void bwd_chain_task(const BwdArgs& a, double* lds, const RecS& rec, int wave, int lane, size_t b, size_t ld) {
+    const int nb = rec[0], nE = rec[1], wpr = rec[3];
+    CIntPtr rows = (CIntPtr)a.chain + rec[2];
+    CIntPtr ecol = rows + 3 * nb;
+    CIntPtr uext = ecol + nE;
+    CIntPtr uin = uext + nb * nE;
+    double2* acc = (double2*)lds;
+    double2* xe = acc + CHAIN_MAX_ROWS * 64;
+    double2* part = xe + CHAIN_MAX_EXT * 64;
+    double2* xc = part + 16 * 64;
+    for (int q = wave; q < nE; q += 16) xe[q * 64 + lane] = load_vec(a.W, (size_t)ecol[q], b, ld);
+    __syncthreads();
+    // ---- phase A
+    const int rpr = 16 / wpr, sub = wave & (wpr - 1);
+    const int len = (nE + wpr - 1) / wpr;
+    for (int p0 = 0; p0 < nb; p0 += rpr) {
+        const int p = p0 + wave / wpr;
+        double y0 = 0.0, y1 = 0.0;
+        if (p < nb) {
+            const int q1 = min(sub * len + len, nE);
+            for (int q = sub * len; q < q1; q += 4) {
+                Blk m[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) if (q + t < q1) m[t] = load_blk(a.X, (size_t)uext[p * nE + q + t], b, ld);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (q + t < q1) {
+                        const double2 x = xe[(q + t) * 64 + lane];
+                        y0 -= m[t].v00 * x.x + m[t].v01 * x.y;
+                        y1 -= m[t].v10 * x.x + m[t].v11 * x.y;
+                    }
+            }
+            if (sub == 0) { const double2 y = load_vec(a.W, (size_t)rows[3 * p], b, ld); y0 += y.x; y1 += y.y; }
+        }
+        if (wpr > 1) {
+            part[wave * 64 + lane] = double2{y0, y1};
+            __syncthreads();
+            if (p < nb && sub == 0) for (int w = 1; w < wpr; ++w) { const double2 t = part[(wave + w) * 64 + lane]; y0 += t.x; y1 += t.y; }
+        }
+        if (p < nb && sub == 0) acc[p * 64 + lane] = double2{y0, y1};
+        if (wpr > 1) __syncthreads();
+    }
+    __syncthreads();
+    // ---- phase B: wave w owns rows p = w, w + 16 (CHAIN_MAX_ROWS = 32)
+    Blk mb[CHAIN_PF][2], db[CHAIN_PF];
+    auto request = [&](int c, Blk (&m)[2], Blk& d) {
+        if (c < 0) return;
+        if (wave == (c & 15)) d = load_blk(a.X, (size_t)rows[3 * c + 2], b, ld);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { const int p = wave + 16 * i; if (p < c) m[i] = load_blk(a.X, (size_t)uin[p * nb + c], b, ld); }
+    };
+#pragma unroll
+    for (int s = 0; s < CHAIN_PF; ++s) request(nb - 1 - s, mb[s], db[s]);
+    for (int c0 = nb - 1; c0 >= 0; c0 -= CHAIN_PF) {
+#pragma unroll
+        for (int s = 0; s < CHAIN_PF; ++s) {
+            const int c = c0 - s;
+            if (c >= 0) {                                       // uniform across the workgroup
+                double2* slot = xc + (c & 1) * 64;
+                if (wave == (c & 15)) {
+                    const double2 y = acc[c * 64 + lane];
+                    slot[lane] = bwd_finish(a, db[s], y.x, y.y, rows[3 * c], rows[3 * c + 1], b, ld);
+                }
+                __syncthreads();
+                const double2 x = slot[lane];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int p = wave + 16 * i;
+                    if (p < c) {
+                        double2 t = acc[p * 64 + lane];
+                        t.x -= mb[s][i].v00 * x.x + mb[s][i].v01 * x.y;
+                        t.y -= mb[s][i].v10 * x.x + mb[s][i].v11 * x.y;
+                        acc[p * 64 + lane] = t;
+                    }
+                }
+                request(c - CHAIN_PF, mb[s], db[s]);
+            }
+        }
+    }
+    __syncthreads();
+}
+
 // One chunk of a backward segment: x_k = Dinv_k (y_k - sum_c U(k,c) x_c), scattered to original order; optional fused
 // state update (Newton-Raphson: V/theta -= increment on active scenarios).
 __device__ __forceinline__ void bwd_chunk(const BwdArgs& a, double* red, const RecS& first, size_t rec_index, int rpw, int wpi,
@@ -208,16 +315,7 @@ __device__ __forceinline__ void bwd_chunk(const BwdArgs& a, double* red, const R
     if (wpi > 1) __syncthreads();
     if (k >= 0 && sub == 0) {
         for (int w = 1; w < wpi; ++w) { const double2 p = ((const double2*)red)[(size_t)(wave + w) * 64 + lane]; y0 += p.x; y1 += p.y; }
-        double x0, x1;
-        dsolve(d, y0, y1, x0, x1);
-        store_vec(a.W, (size_t)k, b, ld, x0, x1);
-        store_vec(a.out, (size_t)bus, b, ld, x0, x1);
-        if (a.upd.va) {
-            const bool act = a.upd.active ? (a.upd.active[b] != 0) : true;
-            const int fl = uniform((int)a.upd.flags[bus]);
-            if (act && (fl & 1)) a.upd.va[(size_t)bus * ld + b] += a.upd.sign * x0;
-            if (act && (fl & 2)) a.upd.vm[(size_t)bus * ld + b] += a.upd.sign * x1;
-        }
+        bwd_finish(a, d, y0, y1, k, bus, b, ld);
     }
     if (wpi > 1) __syncthreads();
 }
@@ -241,6 +339,12 @@ __device__ __forceinline__ void level_body(const Args& a, double* red) {
     const int wave = uniform(threadIdx.y);
     const size_t ld = (size_t)a.ld;
     const size_t b = (size_t)min(grp * 64 + lane, a.lanes - 1);
+    if constexpr (BWD) {
+        if (wpi == 0) {                                          // chain segment: one task (one record) per workgroup
+            bwd_chain_task(a, red, load_rec(a.rec, (size_t)base + bx), wave, lane, b, ld);
+            return;
+        }
+    }
     const size_t ri = (size_t)base + ((size_t)bx * 16 + wave) * rpw;
     const RecS r = load_rec(a.rec, ri);
     if constexpr (BWD) bwd_chunk(a, red, r, ri, rpw, wpi, wave, lane, b, ld);
@@ -357,6 +461,7 @@ __device__ __forceinline__ void walk_body(Args& a, const WalkArgs& w, double* re
     };
     auto rec_index = [&](const Cursor& c) {
         const int chunk = c.u / ng;
+        if (uniform(segs[c.s].wpi) == 0) return (size_t)uniform(segs[c.s].rec_base) + (size_t)chunk;     // chain task: one record
         return (size_t)uniform(segs[c.s].rec_base) + ((size_t)chunk * 16 + wave) * uniform(segs[c.s].rpw);
     };
     // cursor of the unit this workgroup executes next, and the (prefetched) first record of this wave in it
@@ -379,8 +484,10 @@ __device__ __forceinline__ void walk_body(Args& a, const WalkArgs& w, double* re
             const int g = a.sel.list ? uniform(a.sel.list[slot]) : slot;
             if (!(a.sel.flags && !a.sel.flags[g])) {
                 const size_t b = (size_t)min(g * 64 + lane, a.lanes - 1);
-                if constexpr (BWD) bwd_chunk(a, red, r, ri, rpw, wpi, wave, lane, b, ld);
-                else fact_chunk(a, red, r, ri, rpw, wpi, wave, lane, b, ld);
+                if constexpr (BWD) {
+                    if (wpi == 0) bwd_chain_task(a, red, r, wave, lane, b, ld);
+                    else bwd_chunk(a, red, r, ri, rpw, wpi, wave, lane, b, ld);
+                } else fact_chunk(a, red, r, ri, rpw, wpi, wave, lane, b, ld);
             }
             cur = nx;
         }
@@ -392,7 +499,7 @@ __device__ __forceinline__ void walk_body(Args& a, const WalkArgs& w, double* re
     }
 }
 
-constexpr int WALK_MAX_SEG = 1536;      // segment table staged in LDS (32 bytes each)
+constexpr int WALK_MAX_SEG = 1024;      // segment table staged in LDS (32 bytes each)
 
 __device__ __forceinline__ void stage_segments(const Segment* g, Segment* l, int n) {
     const int tid = threadIdx.y * 64 + threadIdx.x;
@@ -402,23 +509,25 @@ __device__ __forceinline__ void stage_segments(const Segment* g, Segment* l, int
     __syncthreads();
 }
 
+constexpr int WALK_RED = CHAIN_LDS_D2 * 2;      // doubles: covers the factor partial sums (16*256) and the chain staging
+
 __global__ __launch_bounds__(1024) void k_fact_walk(FactArgs a, WalkArgs w) {
-    extern __shared__ __attribute__((aligned(16))) double red[];   // [16][4][64] doubles | 16 ints | segments
-    int* sh = (int*)(red + 16 * 256);
+    extern __shared__ __attribute__((aligned(16))) double red[];   // WALK_RED doubles | 16 ints | segments
+    int* sh = (int*)(red + WALK_RED);
     Segment* segs = (Segment*)(sh + 16);
     stage_segments(a.seg, segs, w.n_seg);
     walk_body<false>(a, w, red, sh, segs);
 }
 
 __global__ __launch_bounds__(1024) void k_bwd_walk(BwdArgs a, WalkArgs w) {
-    extern __shared__ __attribute__((aligned(16))) double red[];   // [16][4][64] doubles | 16 ints | segments
-    int* sh = (int*)(red + 16 * 256);
+    extern __shared__ __attribute__((aligned(16))) double red[];   // WALK_RED doubles | 16 ints | segments
+    int* sh = (int*)(red + WALK_RED);
     Segment* segs = (Segment*)(sh + 16);
     stage_segments(a.seg, segs, w.n_seg);
     walk_body<true>(a, w, red, sh, segs);
 }
 
-size_t walk_lds(int n_seg) { return 16 * 256 * sizeof(double) + 64 + (size_t)n_seg * sizeof(Segment); }
+size_t walk_lds(int n_seg) { return WALK_RED * sizeof(double) + 64 + (size_t)n_seg * sizeof(Segment); }
 
 // per-level launch table: segment ranges and chunk totals
 void level_launches(const std::vector<Segment>& segs, std::vector<DevLaunch>& out) {
@@ -428,8 +537,10 @@ void level_launches(const std::vector<Segment>& segs, std::vector<DevLaunch>& ou
         DevLaunch d{};
         d.seg_begin = (int)s;
         d.grid = 0; d.nseg = 0;
+        d.chain = 0;
         while (true) {
             d.nseg++; d.grid = std::max(d.grid, segs[s].nchunks);
+            if (segs[s].wpi == 0) d.chain = 1;
             if (segs[s++].last) break;
         }
         d.seg_end = (int)s;
@@ -454,8 +565,9 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, int policy
     level_launches(S.fact_seg, fact);
     level_launches(S.bwd_seg, bwd);
     if (upload(&fact_rec, S.fact_rec, error, st) || upload(&bwd_rec, S.bwd_rec, error, st) || upload(&fact_seg, S.fact_seg, error, st) ||
-        upload(&bwd_seg, S.bwd_seg, error, st))
+        upload(&bwd_seg, S.bwd_seg, error, st) || upload(&bwd_chain, S.bwd_chain, error, st))
         return 2;
+    JG_HIP(hipFuncSetAttribute((const void*)k_bwd_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CHAIN_LDS_D2 * sizeof(double2))));
     JG_HIP(hipMalloc((void**)&X, factor_bytes()));
     JG_HIP(sync_fill(X, 0, factor_bytes(), st));
     JG_HIP(hipMalloc((void**)&W, (size_t)n * 2 * ld * sizeof(double)));
@@ -512,7 +624,8 @@ void Engine::destroy() {
         }
         hipFree(prof); prof = nullptr;
     }
-    hipFree(fact_rec); hipFree(bwd_rec); hipFree(fact_seg); hipFree(bwd_seg); hipFree(sync);
+    hipFree(fact_rec); hipFree(bwd_rec); hipFree(fact_seg); hipFree(bwd_seg); hipFree(bwd_chain); hipFree(sync);
+    bwd_chain = nullptr;
     hipFree(X); hipFree(W); hipFree(status);
     fact_rec = bwd_rec = nullptr; fact_seg = bwd_seg = nullptr; sync = nullptr; status = nullptr;
     X = W = nullptr;
@@ -561,7 +674,7 @@ int Engine::factor(hipStream_t st, const double* A, const double* rhs, const Gro
 }
 
 int Engine::backsolve(hipStream_t st, double* out, const StateUpdate& upd, const GroupSel& sel, int mode) {
-    BwdArgs a{bwd_rec, bwd_seg, X, W, out, sel, upd, ld, 0, lanes > 0 ? lanes : ld, 0, 0, 1, 1};
+    BwdArgs a{bwd_rec, bwd_seg, bwd_chain, X, W, out, sel, upd, ld, 0, lanes > 0 ? lanes : ld, 0, 0, 1, 1};
     if (walker && mode != 1) {
         WalkArgs w{(int)S.bwd_seg.size(), sync, 100000000LL /* 1 s */, nullptr};
         JG_HIP(hipMemsetAsync(sync, 0, SYNC_WORDS * sizeof(int), st));
@@ -573,7 +686,8 @@ int Engine::backsolve(hipStream_t st, double* out, const StateUpdate& upd, const
     for (const DevLaunch& L : bwd) {
         a.seg_begin = L.seg_begin;
         { const Segment& g = S.bwd_seg[L.seg_begin]; a.s0_base = g.rec_base; a.s0_nchunks = g.nchunks; a.s0_wpi = g.wpi; a.s0_rpw = g.rpw; }
-        hipLaunchKernelGGL(k_bwd_level, dim3((unsigned)L.grid * gs, L.nseg), dim3(64, 16), 16 * 128 * sizeof(double), st, a);
+        hipLaunchKernelGGL(k_bwd_level, dim3((unsigned)L.grid * gs, L.nseg), dim3(64, 16),
+                           L.chain ? (size_t)CHAIN_LDS_D2 * sizeof(double2) : 16 * 128 * sizeof(double), st, a);
     }
     JG_HIP(hipGetLastError());
     return 0;

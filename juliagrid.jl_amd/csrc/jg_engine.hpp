@@ -30,6 +30,7 @@ struct DevLaunch {
     int seg_begin, seg_end;     // range in the segment table
     int grid;                   // most chunks of any of its segments (workgroups along x before the group stride)
     int nseg;
+    int chain;                  // 1: the level holds backward chain tasks (larger LDS staging)
 };
 
 // Optional state update fused into the backward solve (NR: x <- x - dx, masked by bus flags).
@@ -103,6 +104,7 @@ struct Engine {
                                    // so a small batch moves 8 bytes per load instruction instead of 512
     Rec* fact_rec = nullptr; Rec* bwd_rec = nullptr;           // wave records (jg_symbolic.hpp), replay order
     Segment* fact_seg = nullptr; Segment* bwd_seg = nullptr;
+    int* bwd_chain = nullptr;                                   // backward chain task data (jg_symbolic.hpp)
     double* X = nullptr;           // factor values [n_entries][4][ld]: U, unscaled Lh, factored diagonal blocks
     double* W = nullptr;           // [n][2][ld] pivot order: y after factor(), x after backsolve()
     int* status = nullptr;         // [ld] bit 2 set on zero / non-finite pivot

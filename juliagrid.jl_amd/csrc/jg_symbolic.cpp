@@ -70,11 +70,14 @@ int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 // Levels -> segments -> chunks -> wave records.  `level[i]` (1-based; 0 = not scheduled) and `work[i]` (terms) per item;
 // `emit(item, first_term_slot q0, stride, out)` fills one wave's records.
-template <class Fill>
+struct NoExtra { void operator()(int, std::vector<Segment>&, std::vector<Rec>&) const {} };
+
+// `extra(level, segs, recs)` may append further segments of that level (backward chains); extra_levels = highest level it uses
+template <class Fill, class Extra = NoExtra>
 void build_replay(const std::vector<int>& level, const std::vector<int>& work, int T, std::vector<Segment>& segs,
-                  std::vector<Rec>& recs, int& n_levels, Fill fill) {
+                  std::vector<Rec>& recs, int& n_levels, Fill fill, Extra extra = Extra(), int extra_levels = 0) {
     const int n_items = (int)level.size();
-    int nlev = 0;
+    int nlev = extra_levels;
     for (int i = 0; i < n_items; ++i) nlev = std::max(nlev, level[i]);
     std::vector<std::vector<int>> by(nlev + 1);
     for (int i = 0; i < n_items; ++i) if (level[i] > 0) by[level[i]].push_back(i);
@@ -82,8 +85,7 @@ void build_replay(const std::vector<int>& level, const std::vector<int>& work, i
     n_levels = 0;
     for (int l = 1; l <= nlev; ++l) {
         std::vector<int>& it = by[l];
-        if (it.empty()) continue;
-        ++n_levels;
+        const size_t seg0 = segs.size();
         std::stable_sort(it.begin(), it.end(), [&](int x, int y) { return work[x] > work[y]; });   // heaviest first
         const bool wide = it.size() >= 2048;                      // wide levels already fill the chip: do not split lists
         auto wpi_of = [&](int i) { return std::min(wide ? 2 : 16, pow2ceil(std::max(1, (work[i] + T - 1) / T))); };
@@ -97,7 +99,7 @@ void build_replay(const std::vector<int>& level, const std::vector<int>& work, i
             const int slots = 16 / wpi;
             sg.nchunks = (sg.items + slots - 1) / slots;
             sg.rpw = std::max(1, ((work[it[p]] + wpi - 1) / wpi + T - 1) / T);
-            sg.last = q == it.size();
+            sg.last = 0;
             recs.resize(recs.size() + (size_t)sg.nchunks * 16 * sg.rpw);
             for (int c = 0; c < sg.nchunks; ++c)
                 for (int w = 0; w < 16; ++w) {
@@ -109,6 +111,8 @@ void build_replay(const std::vector<int>& level, const std::vector<int>& work, i
             segs.push_back(sg);
             p = q;
         }
+        extra(l, segs, recs);
+        if (segs.size() > seg0) { segs.back().last = 1; ++n_levels; }
     }
 }
 
@@ -141,10 +145,38 @@ void build_tables(BlockSymbolic& S) {
             x.w[3]++;
         }
     });
-    // backward sweep
+    // backward sweep: chains of a supernode go to ONE workgroup each (CHAIN_MAX_ROWS), the other rows stay wave records
     std::vector<int> uw(n);
     for (int r = 0; r < n; ++r) uw[r] = S.u_ptr[r + 1] - S.u_ptr[r];
-    build_replay(S.bwd_level, uw, BWD_T, S.bwd_seg, S.bwd_rec, S.n_bwd_levels, [&](int k, int sub, int wpi, int rpw, Rec* r) {
+    std::vector<int> cstart, clen;                           // chains in ascending pivot order
+    std::vector<int> chain_of(n);
+    for (int k = 0; k < n;) {
+        int e = k;
+        while (e + 1 < n && e + 1 - k < CHAIN_MAX_ROWS && uw[e] >= 1 && S.u_col[S.u_ptr[e]] == e + 1 && uw[e] == uw[e + 1] + 1) ++e;
+        if (uw[e] > CHAIN_MAX_EXT) e = k;                    // too many external columns for the LDS staging: plain rows
+        for (int r = k; r <= e; ++r) chain_of[r] = (int)cstart.size();
+        cstart.push_back(k); clen.push_back(e - k + 1);
+        k = e + 1;
+    }
+    const int nc = (int)cstart.size();
+    std::vector<int> clevel(nc, 1);
+    for (int c = nc - 1; c >= 0; --c) {
+        const int last = cstart[c] + clen[c] - 1;
+        for (int p = S.u_ptr[last]; p < S.u_ptr[last + 1]; ++p) clevel[c] = std::max(clevel[c], clevel[chain_of[S.u_col[p]]] + 1);
+    }
+    S.chain_level.assign(n, 0);
+    std::vector<int> row_level(n, 0);
+    int max_level = 0;
+    std::vector<std::vector<int>> chains_at;
+    for (int c = 0; c < nc; ++c) {
+        max_level = std::max(max_level, clevel[c]);
+        for (int r = cstart[c]; r < cstart[c] + clen[c]; ++r) S.chain_level[r] = clevel[c];
+        if (clen[c] == 1) row_level[cstart[c]] = clevel[c];
+    }
+    chains_at.assign(max_level + 1, {});
+    for (int c = 0; c < nc; ++c) if (clen[c] > 1) chains_at[clevel[c]].push_back(c);
+    S.bwd_chain.clear();
+    build_replay(row_level, uw, BWD_T, S.bwd_seg, S.bwd_rec, S.n_bwd_levels, [&](int k, int sub, int wpi, int rpw, Rec* r) {
         for (int j = 0; j < rpw; ++j) { r[j].w[0] = k; r[j].w[1] = S.perm[k]; r[j].w[2] = S.diag[k]; r[j].w[3] = 0; }
         int q = 0;
         for (int p = S.u_ptr[k] + sub; p < S.u_ptr[k + 1]; p += wpi, ++q) {
@@ -153,7 +185,30 @@ void build_tables(BlockSymbolic& S) {
             x.w[s] = S.u_ent[p]; x.w[s + 1] = S.u_col[p];
             x.w[3]++;
         }
-    });
+    }, [&](int l, std::vector<Segment>& segs, std::vector<Rec>& recs) {
+        const std::vector<int>& cs = chains_at[l];
+        if (cs.empty()) return;
+        Segment sg{};
+        sg.rec_base = (int)recs.size(); sg.nchunks = (int)cs.size(); sg.wpi = 0; sg.rpw = 1; sg.level = l; sg.last = 0; sg.items = 0;
+        for (int c : cs) {
+            const int b = clen[c], first = cstart[c], last = first + b - 1;
+            const int nE = uw[last];
+            Rec r{};
+            r.w[0] = b; r.w[1] = nE; r.w[2] = (int)S.bwd_chain.size();
+            int wpr = 1;
+            while (wpr * 2 * b <= 16) wpr *= 2;              // waves per row in the external phase
+            r.w[3] = wpr;
+            recs.push_back(r);
+            sg.items += b;
+            for (int p = 0; p < b; ++p) { S.bwd_chain.push_back(first + p); S.bwd_chain.push_back(S.perm[first + p]); S.bwd_chain.push_back(S.diag[first + p]); }
+            for (int q = 0; q < nE; ++q) S.bwd_chain.push_back(S.u_col[S.u_ptr[last] + q]);
+            for (int p = 0; p < b; ++p)
+                for (int q = 0; q < nE; ++q) S.bwd_chain.push_back(find_in_row(S, first + p, S.u_col[S.u_ptr[last] + q]));
+            for (int p = 0; p < b; ++p)
+                for (int c2 = 0; c2 < b; ++c2) S.bwd_chain.push_back(c2 > p ? find_in_row(S, first + p, first + c2) : -1);
+        }
+        segs.push_back(sg);
+    }, max_level);
 }
 
 int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic& S) {

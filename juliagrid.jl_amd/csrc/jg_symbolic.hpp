@@ -34,6 +34,12 @@ struct Segment {
 };
 constexpr int FACT_T = 4;   // FactRec: {kind, id, src, nterms, (a, d, b) x 4}; kind -1 = idle wave
 constexpr int BWD_T = 6;    // BwdRec:  {k, bus, diag, nterms, (u_ent, u_col) x 6}; k -1 = idle wave
+// Backward CHAINS: consecutive pivots k..k+b-1 of one supernode (each the parent of the previous, nested structure)
+// are solved by ONE workgroup in one launch -- the dense in-chain triangle is a sequence of workgroup barriers, not
+// of kernel launches.  A chain segment has wpi = 0 and ONE record per task: {b, nE, off, wpr}; at bwd_chain[off]:
+//   rows[b] x {pivot, original block index, diagonal entry} | ecol[nE] external columns (pivots) |
+//   uext[b][nE] entries U(row, ecol) | uin[b][b] entries U(row p, row c) for c > p (else -1)
+constexpr int CHAIN_MAX_ROWS = 32, CHAIN_MAX_EXT = 72;
 struct Rec { int w[16]; };
 
 struct BlockSymbolic {
@@ -66,6 +72,8 @@ struct BlockSymbolic {
     std::vector<int> src_entry;         // [nnz of the caller's pattern] -> entry id
     std::vector<Segment> fact_seg, bwd_seg;
     std::vector<Rec> fact_rec, bwd_rec;
+    std::vector<int> bwd_chain;         // chain task data (see CHAIN_MAX_ROWS)
+    std::vector<int> chain_level;       // [n] backward level of the chain (or single row) a pivot belongs to
     int n_fact_levels = 0, n_bwd_levels = 0;
 };
 

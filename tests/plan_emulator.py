@@ -126,35 +126,73 @@ class Replay:
         return X, Y
 
     def backsolve(self, X, Y):
+        """Replays the backward tables: wave-record rows and CHAIN tasks (segments with wpi == 0: consecutive pivots of a
+        supernode solved by one workgroup: external part first, then the in-chain triangle from the last pivot up)."""
         W = Y.copy()
         level_of = np.full(self.n, -1)
         out = np.zeros((self.n, 2))
-        acc, meta = {}, {}
-        for level, key, sub, recs in self._waves(self.bseg, self.brec):
-            k = int(recs[0][0])
-            if k < 0:
+        chain = self.p.get("bwd_chain")
+        terms = 0
+        for si, (base, nchunks, wpi, rpw, level, _last, _items, _pad) in enumerate(self.bseg):
+            if wpi == 0:
+                for t in range(nchunks):
+                    nb, nE, off, wpr = (int(v) for v in self.brec[base + t][:4])
+                    assert 2 <= nb <= 32 and nE <= 72 and wpr in (1, 2, 4, 8) and (wpr == 1 or wpr * nb <= 16)
+                    rows = chain[off:off + 3 * nb].reshape(nb, 3)
+                    ecol = chain[off + 3 * nb: off + 3 * nb + nE]
+                    uext = chain[off + 3 * nb + nE: off + 3 * nb + nE + nb * nE].reshape(nb, nE)
+                    uin = chain[off + 3 * nb + nE + nb * nE: off + 3 * nb + nE + nb * nE + nb * nb].reshape(nb, nb)
+                    assert np.all(np.diff(rows[:, 0]) == 1), "a chain is a run of consecutive pivots"
+                    acc = np.zeros((nb, 2))
+                    for p in range(nb):
+                        k, bus, dg = (int(v) for v in rows[p])
+                        assert dg == self.diag[k] and bus == self.perm[k] and level_of[k] < 0
+                        acc[p] = Y[k]
+                        for q in range(nE):
+                            assert 0 <= level_of[ecol[q]] < level, "bwd chain race (external column)"
+                            assert self.e_row[uext[p, q]] == k and self.e_col[uext[p, q]] == ecol[q]
+                            acc[p] -= X[uext[p, q]] @ W[ecol[q]]
+                            terms += 1
+                    for c in range(nb - 1, -1, -1):
+                        k = int(rows[c, 0])
+                        W[k] = dsolve(X[int(rows[c, 2])], acc[c])
+                        out[int(rows[c, 1])] = W[k]
+                        for p in range(c):
+                            e = int(uin[p, c])
+                            assert self.e_row[e] == rows[p, 0] and self.e_col[e] == k
+                            acc[p] -= X[e] @ W[k]
+                            terms += 1
+                    for p in range(nb):
+                        level_of[int(rows[p, 0])] = level
                 continue
-            part = np.zeros(2)
-            for r in recs:
-                assert int(r[0]) == k
-                for t in range(int(r[3])):
-                    ent, col = int(r[4 + 2 * t]), int(r[5 + 2 * t])
-                    assert 0 <= level_of[col] < level, "bwd schedule race"
-                    part -= X[ent] @ W[col]
-            if sub == 0:
-                meta[key] = (level, k, int(recs[0][1]), int(recs[0][2]))
-                acc[key] = Y[k] + part
-            else:
-                acc[key] = acc[key] + part
-            # rows of one level are independent, so finishing them as soon as the group's last wave is seen is safe
-            if key in meta and sub == self._wpi_of(key) - 1:
-                lev, kk, bus, dg = meta[key]
-                assert dg == self.diag[kk] and bus == self.perm[kk]
+            acc, meta = {}, {}
+            for c in range(nchunks):
+                for w in range(16):
+                    r0 = base + (c * 16 + w) * rpw
+                    recs, key, sub = self.brec[r0:r0 + rpw], (c, w // wpi), w % wpi
+                    k = int(recs[0][0])
+                    if k < 0:
+                        continue
+                    part = np.zeros(2)
+                    for r in recs:
+                        assert int(r[0]) == k
+                        for t in range(int(r[3])):
+                            ent, col = int(r[4 + 2 * t]), int(r[5 + 2 * t])
+                            assert 0 <= level_of[col] < level, "bwd schedule race"
+                            part -= X[ent] @ W[col]
+                            terms += 1
+                    if sub == 0:
+                        meta[key] = (k, int(recs[0][1]), int(recs[0][2]))
+                        acc[key] = Y[k] + part
+                    else:
+                        acc[key] = acc[key] + part
+            for key, (kk, bus, dg) in meta.items():           # rows of one segment are independent of each other
+                assert dg == self.diag[kk] and bus == self.perm[kk] and level_of[kk] < 0
                 W[kk] = dsolve(X[dg], acc[key])
                 out[bus] = W[kk]
-                level_of[kk] = lev
+            for key, (kk, bus, dg) in meta.items():
+                level_of[kk] = level
         assert (level_of >= 0).all(), "rows missing from the backward schedule"
-        terms = sum(int(r[3]) for r in self.brec if r[0] >= 0)
         assert terms == int(self.u_ptr[-1]), "U terms lost or duplicated in the records"
         return out
 

@@ -77,12 +77,14 @@ def test_plan_structure_invariants(jg):
         base, nchunks, wpi, rpw, level, last = (seg[:, k] for k in range(6))
         assert np.all(np.diff(level) >= 0) and last[-1] == 1
         assert np.all(last[:-1] == (level[1:] > level[:-1]))
-        assert np.all(np.isin(wpi, [1, 2, 4, 8, 16]))
+        assert np.all(np.isin(wpi, [0, 1, 2, 4, 8, 16])) and (kind == "bwd" or np.all(wpi > 0))     # wpi 0 = backward chain tasks
         for l in np.unique(level):
-            assert np.unique(wpi[level == l]).size == (level == l).sum() <= 5
-        assert base[0] == 0 and np.all(base[1:] == base[:-1] + nchunks[:-1] * 16 * rpw[:-1])
-        assert rec.shape[0] == base[-1] + nchunks[-1] * 16 * rpw[-1]
-        assert np.all(rec[:, 3] <= T) and np.all(rec[rec[:, 0] < 0, 3] == 0)
+            assert np.unique(wpi[level == l]).size == (level == l).sum() <= 6
+        count = np.where(wpi > 0, nchunks * 16 * rpw, nchunks)                                      # one record per chain task
+        assert base[0] == 0 and np.all(base[1:] == base[:-1] + count[:-1])
+        assert rec.shape[0] == base[-1] + count[-1]
+        rows = np.concatenate([np.arange(b, b + c) for b, c, w in zip(base, count, wpi) if w > 0])
+        assert np.all(rec[rows, 3] <= T) and np.all(rec[rows][rec[rows, 0] < 0, 3] == 0)
     seg, rec = plan.replay_tables("fact")
     lead = np.concatenate([np.arange(b, b + c * 16 * r, r * w) for b, c, w, r in seg[:, :4]])   # first record of each leader wave
     lead = lead[rec[lead, 0] >= 0]
@@ -90,9 +92,16 @@ def test_plan_structure_invariants(jg):
     assert sorted(ids.tolist()) == list(range(e_row.size + Y.n))
     assert rec[rec[:, 0] >= 0, 3].sum() == t_ptr[-1] + plan.get("l_ptr")[-1]
     seg, rec = plan.replay_tables("bwd")
-    lead = np.concatenate([np.arange(b, b + c * 16 * r, r * w) for b, c, w, r in seg[:, :4]])
+    rows_seg = seg[seg[:, 2] > 0]
+    lead = np.concatenate([np.arange(b, b + c * 16 * r, r * w) for b, c, w, r in rows_seg[:, :4]])
     lead = lead[rec[lead, 0] >= 0]
-    assert sorted(rec[lead, 0].tolist()) == list(range(Y.n))
+    chain = plan.get("bwd_chain")
+    in_chains = []
+    for b, c in seg[seg[:, 2] == 0][:, :2]:
+        for nb, nE, off, wpr in rec[b:b + c, :4]:
+            in_chains += chain[off:off + 3 * nb:3].tolist()
+    assert sorted(rec[lead, 0].tolist() + in_chains) == list(range(Y.n))                            # every pivot exactly once
+    assert len(in_chains) > 300 and seg[-1, 4] < 80                                                 # 157 row levels -> chain levels
     # in-place policy: entries the assembly already finalised (off-diagonal, no update terms) are not scheduled
     plan1 = jg._lib.Plan(Y.n, Y.colptr - 1, Y.rowval - 1, policy=1)
     seg1, rec1 = plan1.replay_tables("fact")
