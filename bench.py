@@ -76,7 +76,35 @@ def cpu_baseline(case_tables, labels, start_vm, start_va, budget_s=12.0):
     return {"value": iters / dt, "unit": "NR iterations/s", "cores": 1, "kind": "port",
             "sample": f"{done} of the same N-1 scenarios, {iters} iterations in {dt:.2f} s, "
                       "oracle/jg_oracle.c: serial assembly + KLU-style refactor/solve, single thread",
-            "ms_per_iteration": 1e3 * dt / max(iters, 1), "ms_per_solve": 1e3 * dt / max(done, 1)}
+            "ms_per_iteration": 1e3 * dt / max(iters, 1), "ms_per_solve": 1e3 * dt / max(done, 1),
+            "_iters": iters, "_done": done}
+
+
+def cpu_baseline_all_cores(case, count, seed, total, cores, timeout_s=180):
+    """The same oracle loop on every host core (one process per core, scenarios dealt out contiguously): the
+    OpenMP-over-scenarios variant of SURVEY.md 8(d).  The reference itself is single-threaded.  Workers are plain
+    subprocesses with a timeout (the parent holds a live HIP context); any failure just omits this leg."""
+    import subprocess
+    per = max(1, -(-count // cores))
+    cmds = [[sys.executable, os.path.join(ROOT, "oracle", "baseline_worker.py"), case, str(f), str(min(per, count - f)), str(seed), str(total)]
+            for f in range(0, count, per)]
+    try:
+        procs = [subprocess.Popen(c, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for c in cmds]
+        out = []
+        deadline = time.time() + timeout_s
+        for p in procs:
+            so, _ = p.communicate(timeout=max(1.0, deadline - time.time()))
+            out.append(json.loads(so.strip().splitlines()[-1]))
+    except Exception:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        return None
+    iters, done, dt = sum(o["iters"] for o in out), sum(o["done"] for o in out), max(o["seconds"] for o in out)
+    return {"value": iters / dt, "unit": "NR iterations/s", "cores": len(cmds), "kind": "port",
+            "sample": f"{done} of the same N-1 scenarios over {len(cmds)} processes (one per host core), {iters} iterations, "
+                      f"slowest process {dt:.2f} s (each process's base-case solve and symbolic analysis not counted, as in the "
+                      "single-thread leg)"}
 
 
 def main():
@@ -232,8 +260,15 @@ def main():
         }
         if world == 1 and not args.no_cpu:
             cb = cpu_baseline(tables, labels_all[: max(64, min(B, 512))], vm0, va0)
+            cb.pop("_iters"), cb.pop("_done")
             line["cpu_baseline"] = cb
             line["speedup_vs_cpu_baseline"] = line["value"] / cb["value"]
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            if cores > 1:                               # the box's whole host: reported next to the single-thread reference path
+                allc = cpu_baseline_all_cores(args.case, max(64, min(B, 512)), 512, B * world, min(cores, 64))
+                if allc:
+                    line["cpu_baseline_all_cores"] = allc
+                    line["speedup_vs_cpu_all_cores"] = line["value"] / allc["value"]
         print(json.dumps(line))
     pipe.close()
     if world > 1:
