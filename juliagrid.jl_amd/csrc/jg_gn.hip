@@ -198,15 +198,36 @@ __global__ __launch_bounds__(256) void k_gn_gain(GainArgs a) {
     const int wave = uniform(threadIdx.y);
     const size_t ld = (size_t)a.ld;
     const size_t b = (size_t)blockIdx.y * 64 + lane;
+    // the gather lists are immutable: read them through the constant address space (scalar loads, no readfirstlane chase)
+    typedef const int __attribute__((address_space(4)))* CInt;
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    typedef const i4 __attribute__((address_space(4)))* CInt4;
+    CInt cw = (CInt)a.cw, ca = (CInt)a.ca, cb = (CInt)a.cb;
     for (int it = (blockIdx.x * blockDim.y + wave) * 4, e = min(it + 4, a.n_items); it < e; ++it) {
-        const GainItem* gi = a.items + it;
-        const int kind = uniform(gi->kind), id = uniform(gi->id), c0 = uniform(gi->c0), c1 = uniform(gi->c1);
+        const i4 gi = ((CInt4)a.items)[it];
+        const int kind = gi[0], id = gi[1], c0 = gi[2], c1 = gi[3];
         if (kind == 0) {
             double g00 = 0.0, g01 = 0.0, g10 = 0.0, g11 = 0.0;
-            for (int c = c0; c < c1; ++c) {
-                const double w = a.w[(size_t)uniform(a.cw[c]) * ld + b];
-                const double* pa = a.Hs + (size_t)uniform(a.ca[c]) * 2 * ld + b;
-                const double* pb = a.Hs + (size_t)uniform(a.cb[c]) * 2 * ld + b;
+            int c = c0;
+            for (; c + 4 <= c1; c += 4) {                        // four contributions in flight
+                double w[4], a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    w[u] = a.w[(size_t)cw[c + u] * ld + b];
+                    const double* pa = a.Hs + (size_t)ca[c + u] * 2 * ld + b;
+                    const double* pb = a.Hs + (size_t)cb[c + u] * 2 * ld + b;
+                    a0[u] = pa[0]; a1[u] = pa[ld]; b0[u] = pb[0]; b1[u] = pb[ld];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double at = w[u] * a0[u], av = w[u] * a1[u];
+                    g00 += at * b0[u]; g01 += at * b1[u]; g10 += av * b0[u]; g11 += av * b1[u];
+                }
+            }
+            for (; c < c1; ++c) {
+                const double w = a.w[(size_t)cw[c] * ld + b];
+                const double* pa = a.Hs + (size_t)ca[c] * 2 * ld + b;
+                const double* pb = a.Hs + (size_t)cb[c] * 2 * ld + b;
                 const double at = w * pa[0], av = w * pa[ld], bt = pb[0], bv = pb[ld];
                 g00 += at * bt; g01 += at * bv; g10 += av * bt; g11 += av * bv;
             }
@@ -218,9 +239,9 @@ __global__ __launch_bounds__(256) void k_gn_gain(GainArgs a) {
         } else {
             double r0 = 0.0, r1 = 0.0;
             for (int c = c0; c < c1; ++c) {
-                const double w = a.w[(size_t)uniform(a.cw[c]) * ld + b];
-                const double* pa = a.Hs + (size_t)uniform(a.ca[c]) * 2 * ld + b;
-                const double rr = w * a.res[(size_t)uniform(a.cb[c]) * ld + b];
+                const double w = a.w[(size_t)cw[c] * ld + b];
+                const double* pa = a.Hs + (size_t)ca[c] * 2 * ld + b;
+                const double rr = w * a.res[(size_t)cb[c] * ld + b];
                 r0 += pa[0] * rr; r1 += pa[ld] * rr;
             }
             if (id == a.slack) r0 = 0.0;
