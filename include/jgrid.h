@@ -110,6 +110,27 @@ int jg_nr_get_maps(jg_nr* h, int64_t* pq, int64_t* pvpq, int64_t* pcount, int64_
 /* analysis.method.iteration per scenario. */
 int jg_nr_get_iteration(jg_nr* h, int32_t* iters);
 
+/*
+ * power!(analysis) / current!(analysis) for every scenario of the batch at its CURRENT state --
+ * src/postprocessing/acAnalysis.jl:30-169 (power!), 672-704 (current!), formula helpers :838-925.
+ * jg_nr_set_branches (once): the branch table the post-processing needs,
+ *   from,to [nb] 1-based; status [nb]; param [nb][16] = re,im of nodalFromFrom, nodalFromTo, nodalToFrom, nodalToTo,
+ *   admittance (model.jl:54-67), re,im of t_ij = (1/turnsRatio) cis(-shiftAngle) (:846-851), branch conductance,
+ *   susceptance, 1/turnsRatio, 0.
+ * jg_nr_set_outage_labels: label[batch] = 1-based branch that is out of service in that scenario (0 none): its
+ *   quantities are zero there, like an out-of-service branch of the reference (:71-81, :693-701).
+ * jg_nr_branch_quantities: any output may be NULL; each [batch][nb][2]:
+ *   from_pq, to_pq = PijQij, PjiQji (:898-904); series_pq = PlQl (:906-908); charging_pq = PcQc (:910-919);
+ *   from_i, to_i, series_i = (magnitude, angle) of Iij, Iji, Is (:921-931).
+ * jg_nr_bus_injection: inj_pq [batch][n][2] = PiQi (:891-896); the injection current, shunt, supply and generator
+ *   powers follow from it on the host (juliagrid.jl_amd/powerflow.py:power_, O(n) each).
+ */
+int jg_nr_set_branches(jg_nr* h, int64_t nb, const int64_t* from, const int64_t* to, const int8_t* status, const double* param);
+int jg_nr_set_outage_labels(jg_nr* h, const int64_t* label);
+int jg_nr_branch_quantities(jg_nr* h, double* from_pq, double* to_pq, double* series_pq, double* charging_pq,
+                            double* from_i, double* to_i, double* series_i);
+int jg_nr_bus_injection(jg_nr* h, double* inj_pq);
+
 /* Measurement hooks (HIP events on the handle's own stream).
  * kernel: 0 fused mismatch+Jacobian assembly, 1 LU refactorization + fused forward elimination (all
  * launches), 2 backward sweep (no state update).  Returns the mean milliseconds of `reps` back-to-back executions. */

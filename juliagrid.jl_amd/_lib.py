@@ -60,6 +60,10 @@ def lib():
         "jg_nr_get_maps": [VP, I64P, I64P, I64P, I64P, I64P],
         "jg_nr_get_iteration": [VP, I32P],
         "jg_nr_time_kernel": [VP, C.c_int, C.c_int, C.POINTER(C.c_double)],
+        "jg_nr_set_branches": [VP, C.c_int64, I64P, I64P, I8P, F64P],
+        "jg_nr_set_outage_labels": [VP, I64P],
+        "jg_nr_branch_quantities": [VP, VP, VP, VP, VP, VP, VP, VP],
+        "jg_nr_bus_injection": [VP, F64P],
         "jg_gn_create": [C.POINTER(VP), C.c_int64, I64P, I64P, F64P, F64P, C.c_int64, I64P, I64P, F64P, C.c_int64, C.c_int64,
                          I8P, I8P, I64P, C.c_int64, I64P, C.c_int64, C.c_int],
         "jg_gn_dims": [VP, I64P],

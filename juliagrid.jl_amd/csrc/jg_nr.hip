@@ -48,7 +48,7 @@ struct AsmArgs {
     const int* dst;            // Ybus CSR position -> entry of the LU factor storage: the Jacobian is assembled IN PLACE
     const double* vm; const double* va; const double* p; const double* q;
     const int* ppos; const double* pdg; const double* pdb;
-    double* A; double* F; double* part; jg::GroupSel sel;
+    double* A; double* F; double* part; double* pq_out; jg::GroupSel sel;   // pq_out (nullable): [n][ld][2] calculated injections P_i, Q_i
     int n; int ld; int mp; int nchunk; int lanes;
 };
 
@@ -126,6 +126,7 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(AsmArgs a) {
                                  (mk & 8) ? vi * ad : 0.0);                // dQ_i/dV_j       equations.jl:142-144
             }
         }
+        if (!JAC && a.pq_out) jg::store_vec(a.pq_out, (size_t)i, b, ld, vi * s1, vi * s2);     // PiQi (acAnalysis.jl:891-896)
         double fp = vi * s1 - pinj;                        // acPowerFlow.jl:676
         double fq = vi * s2 - qinj;                        // acPowerFlow.jl:679
         double d00 = -vi * s2 - bii * (vi * vi);           // equations.jl:105-107, acPowerFlow.jl:872
@@ -156,6 +157,49 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(AsmArgs a) {
         a.part[((size_t)bx * 2) * ld + b] = maxp;
         a.part[((size_t)bx * 2 + 1) * ld + b] = maxq;
     }
+}
+
+// ---- post-processing: power!/current! branch quantities (acAnalysis.jl:66-81, 688-701) -------------------------
+struct BranchArgs {
+    const int* from; const int* to; const signed char* status; const double* param;   // param [nb][16], see jgrid.h
+    const double* vm; const double* va; const int* outage;                              // outage [ld]: 1-based branch out in that scenario
+    double* from_pq; double* to_pq; double* series_pq; double* charging_pq; double* from_i; double* to_i; double* series_i;
+    int nb; int ld; int lanes;
+};
+
+// one wave per branch x 64 scenarios, 16 branches per workgroup; the branch table travels through the scalar cache
+__global__ __launch_bounds__(1024) void k_branch_quantities(BranchArgs a) {
+    typedef const double __attribute__((address_space(4)))* CDbl;
+    typedef const int __attribute__((address_space(4)))* CInt;
+    const int lane = threadIdx.x;
+    const int k = blockIdx.x * 16 + uniform(threadIdx.y);
+    if (k >= a.nb) return;
+    const size_t ld = (size_t)a.ld;
+    const size_t b = (size_t)min((int)blockIdx.y * 64 + lane, a.lanes - 1);
+    CDbl p = (CDbl)a.param + (size_t)k * 16;
+    const int i = ((CInt)a.from)[k], j = ((CInt)a.to)[k];
+    const bool on = a.status[k] == 1 && a.outage[b] != k + 1;
+    const double Vi = a.vm[(size_t)i * ld + b], Vj = a.vm[(size_t)j * ld + b];
+    double si, ci, sj, cj;
+    sincos(a.va[(size_t)i * ld + b], &si, &ci);
+    sincos(a.va[(size_t)j * ld + b], &sj, &cj);
+    const double vir = Vi * ci, vii = Vi * si, vjr = Vj * cj, vji = Vj * sj;
+    // Iij = Vi yff + Vj yft, Iji = Vi ytf + Vj ytt (:921-927);  Vij = tij Vi - Vj (:846-851), Is = y Vij (:929-931)
+    const double ifr = vir * p[0] - vii * p[1] + vjr * p[2] - vji * p[3], ifi = vir * p[1] + vii * p[0] + vjr * p[3] + vji * p[2];
+    const double itr = vir * p[4] - vii * p[5] + vjr * p[6] - vji * p[7], iti = vir * p[5] + vii * p[4] + vjr * p[7] + vji * p[6];
+    const double wr = p[10] * vir - p[11] * vii - vjr, wi = p[10] * vii + p[11] * vir - vji;
+    const double isr = p[8] * wr - p[9] * wi, isi = p[8] * wi + p[9] * wr;
+    const double z = on ? 1.0 : 0.0;                                         // out of service: zeros, like initialize! (:66, :688)
+    if (a.from_pq) jg::store_vec(a.from_pq, (size_t)k, b, ld, z * (vir * ifr + vii * ifi), z * (vii * ifr - vir * ifi));      // Vi conj(Iij)
+    if (a.to_pq) jg::store_vec(a.to_pq, (size_t)k, b, ld, z * (vjr * itr + vji * iti), z * (vji * itr - vjr * iti));          // Vj conj(Iji)
+    if (a.series_pq) jg::store_vec(a.series_pq, (size_t)k, b, ld, z * (wr * isr + wi * isi), z * (wi * isr - wr * isi));      // Vij conj(y Vij)
+    if (a.charging_pq) {                                                     // 0.5 conj(g + jb) ((Vi/tau)^2 + Vj^2)  (:910-919)
+        const double m = 0.5 * ((p[14] * Vi) * (p[14] * Vi) + Vj * Vj);
+        jg::store_vec(a.charging_pq, (size_t)k, b, ld, z * p[12] * m, -z * p[13] * m);
+    }
+    if (a.from_i) jg::store_vec(a.from_i, (size_t)k, b, ld, z * hypot(ifr, ifi), on ? atan2(ifi, ifr) : 0.0);
+    if (a.to_i) jg::store_vec(a.to_i, (size_t)k, b, ld, z * hypot(itr, iti), on ? atan2(iti, itr) : 0.0);
+    if (a.series_i) jg::store_vec(a.series_i, (size_t)k, b, ld, z * hypot(isr, isi), on ? atan2(isi, isr) : 0.0);
 }
 
 struct CheckArgs {
@@ -334,6 +378,9 @@ struct jg_nr {
     double* d_vm0 = nullptr; double* d_va0 = nullptr;   // snapshot of the start point
     int* d_active = nullptr; int* d_iters = nullptr; int* d_status = nullptr; int* d_counter = nullptr; int* d_group = nullptr;
     int* d_lid = nullptr; int* d_dest = nullptr; int* d_cflags = nullptr; int* d_itmp = nullptr; int* d_glist = nullptr;   // scenario compaction
+    int nb = 0;                                       // post-processing (jg_nr_set_branches)
+    int* d_bfrom = nullptr; int* d_bto = nullptr; signed char* d_bstatus = nullptr; double* d_bparam = nullptr; int* d_outage = nullptr;
+    double* d_post = nullptr; size_t post_bytes = 0;  // staging for branch / bus quantities, grown on demand
     jg::Engine eng;
     hipStream_t stream = nullptr;
     hipGraph_t graphA = nullptr, graphB = nullptr;
@@ -348,9 +395,9 @@ int set_device(jg_nr* h) { NR_HIP(hipSetDevice(h->device)); return 0; }
 
 jg::GroupSel active_groups(jg_nr* h) { return jg::GroupSel{nullptr, h->d_glist, h->d_cflags + 3}; }
 
-void launch_assemble(jg_nr* h, const jg::GroupSel& sel = jg::GroupSel{}, bool jac = true) {
+void launch_assemble(jg_nr* h, const jg::GroupSel& sel = jg::GroupSel{}, bool jac = true, double* pq_out = nullptr) {
     AsmArgs a{h->d_rowptr, h->d_col, h->d_GB, h->d_rowtype, h->d_dst, h->d_vm, h->d_va, h->d_p, h->d_q,
-              h->d_ppos, h->d_pdg, h->d_pdb, h->eng.X, h->d_F, h->d_part, sel, h->n, h->ld, h->mp, h->nchunk, h->batch};
+              h->d_ppos, h->d_pdg, h->d_pdb, h->eng.X, h->d_F, h->d_part, pq_out, sel, h->n, h->ld, h->mp, h->nchunk, h->batch};
     dim3 grid((unsigned)h->nchunk * jg::group_stride(h->ld / 64)), block(64, ASM_WAVES);
     if (jac) {
         switch (h->mp) {
@@ -588,6 +635,7 @@ void jg_nr_destroy(jg_nr* h) {
     if (h->graphA) hipGraphDestroy(h->graphA);
     if (h->graphB) hipGraphDestroy(h->graphB);
     h->eng.destroy();
+    hipFree(h->d_bfrom); hipFree(h->d_bto); hipFree(h->d_bstatus); hipFree(h->d_bparam); hipFree(h->d_outage); hipFree(h->d_post);
     hipFree(h->d_rowptr); hipFree(h->d_col); hipFree(h->d_G); hipFree(h->d_B); hipFree(h->d_GB); hipFree(h->d_rowtype); hipFree(h->d_type); hipFree(h->d_flags);
     hipFree(h->d_vm); hipFree(h->d_va); hipFree(h->d_p); hipFree(h->d_q); hipFree(h->d_ppos); hipFree(h->d_pdg);
     hipFree(h->d_pdb); hipFree(h->d_dst); hipFree(h->d_F); hipFree(h->d_inc); hipFree(h->d_part); hipFree(h->d_normp);
@@ -883,6 +931,96 @@ int jg_nr_get_iteration(jg_nr* h, int32_t* iters) {
     NR_HIP(hipStreamSynchronize(h->stream));
     NR_HIP(jg::sync_copy(iters, h->d_iters, (size_t)h->batch * 4, hipMemcpyDeviceToHost, h->stream));
     return 0;
+}
+
+int jg_nr_set_branches(jg_nr* h, int64_t nb, const int64_t* from, const int64_t* to, const int8_t* status, const double* param) {
+    if (!h || nb < 1 || !from || !to || !status || !param) return fail(1, "jg_nr_set_branches: bad argument");
+    if (int rc = set_device(h)) return rc;
+    std::vector<int> f(nb), t(nb);
+    for (int64_t k = 0; k < nb; ++k) {
+        if (from[k] < 1 || from[k] > h->n || to[k] < 1 || to[k] > h->n) return fail(1, "jg_nr_set_branches: bus index out of range");
+        f[k] = (int)(from[k] - 1); t[k] = (int)(to[k] - 1);
+    }
+    NR_HIP(hipStreamSynchronize(h->stream));
+    hipFree(h->d_bfrom); hipFree(h->d_bto); hipFree(h->d_bstatus); hipFree(h->d_bparam);
+    h->d_bfrom = h->d_bto = nullptr; h->d_bstatus = nullptr; h->d_bparam = nullptr;
+    std::string err;
+    if (jg::upload(&h->d_bfrom, f, err, h->stream) || jg::upload(&h->d_bto, t, err, h->stream) ||
+        jg::upload(&h->d_bstatus, std::vector<signed char>(status, status + nb), err, h->stream) ||
+        jg::upload(&h->d_bparam, std::vector<double>(param, param + nb * 16), err, h->stream))
+        return fail(2, err);
+    if (!h->d_outage) {
+        NR_HIP(hipMalloc((void**)&h->d_outage, (size_t)h->ld * sizeof(int)));
+        NR_HIP(jg::sync_fill(h->d_outage, 0, (size_t)h->ld * sizeof(int), h->stream));
+    }
+    h->nb = (int)nb;
+    return 0;
+}
+
+int jg_nr_set_outage_labels(jg_nr* h, const int64_t* label) {
+    if (!h || !label) return fail(1, "jg_nr_set_outage_labels: bad argument");
+    if (!h->d_outage) return fail(1, "jg_nr_set_outage_labels: call jg_nr_set_branches first");
+    if (int rc = set_device(h)) return rc;
+    std::vector<int> v(h->ld, 0);
+    for (int b = 0; b < h->batch; ++b) {
+        if (label[b] < 0 || label[b] > h->nb) return fail(1, "jg_nr_set_outage_labels: label out of range");
+        v[b] = (int)label[b];
+    }
+    NR_HIP(hipStreamSynchronize(h->stream));
+    NR_HIP(jg::sync_copy(h->d_outage, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    return 0;
+}
+
+static int post_staging(jg_nr* h, size_t bytes) {
+    if (bytes <= h->post_bytes) return 0;
+    hipFree(h->d_post); h->d_post = nullptr; h->post_bytes = 0;
+    NR_HIP(hipMalloc((void**)&h->d_post, bytes));
+    h->post_bytes = bytes;
+    return 0;
+}
+
+// device [rows][ld][2] -> host [batch][rows][2]
+static int get_pairs(jg_nr* h, const double* src, double* dst, size_t rows) {
+    std::vector<double> t(rows * h->ld * 2);
+    NR_HIP(jg::sync_copy(t.data(), src, t.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    for (int b = 0; b < h->batch; ++b)
+        for (size_t r = 0; r < rows; ++r) { dst[((size_t)b * rows + r) * 2] = t[(r * h->ld + b) * 2]; dst[((size_t)b * rows + r) * 2 + 1] = t[(r * h->ld + b) * 2 + 1]; }
+    return 0;
+}
+
+int jg_nr_branch_quantities(jg_nr* h, double* from_pq, double* to_pq, double* series_pq, double* charging_pq,
+                            double* from_i, double* to_i, double* series_i) {
+    if (!h) return fail(1, "jg_nr_branch_quantities: bad argument");
+    if (!h->d_bparam) return fail(1, "jg_nr_branch_quantities: call jg_nr_set_branches first");
+    if (int rc = set_device(h)) return rc;
+    double* host[7] = {from_pq, to_pq, series_pq, charging_pq, from_i, to_i, series_i};
+    const size_t one = (size_t)h->nb * h->ld * 2 * sizeof(double);
+    int want = 0;
+    for (double* p : host) want += p != nullptr;
+    if (!want) return 0;
+    if (int rc = post_staging(h, one * want)) return rc;
+    double* dev[7];
+    int q = 0;
+    for (int k = 0; k < 7; ++k) dev[k] = host[k] ? h->d_post + (size_t)(q++) * (one / sizeof(double)) : nullptr;
+    BranchArgs a{h->d_bfrom, h->d_bto, h->d_bstatus, h->d_bparam, h->d_vm, h->d_va, h->d_outage,
+                 dev[0], dev[1], dev[2], dev[3], dev[4], dev[5], dev[6], h->nb, h->ld, h->batch};
+    hipLaunchKernelGGL(k_branch_quantities, dim3((h->nb + 15) / 16, h->ld / 64), dim3(64, 16), 0, h->stream, a);
+    NR_HIP(hipGetLastError());
+    NR_HIP(hipStreamSynchronize(h->stream));
+    for (int k = 0; k < 7; ++k)
+        if (host[k]) if (int rc = get_pairs(h, dev[k], host[k], (size_t)h->nb)) return rc;
+    return 0;
+}
+
+int jg_nr_bus_injection(jg_nr* h, double* inj_pq) {
+    if (!h || !inj_pq) return fail(1, "jg_nr_bus_injection: bad argument");
+    if (int rc = set_device(h)) return rc;
+    if (int rc = post_staging(h, (size_t)h->n * h->ld * 2 * sizeof(double))) return rc;
+    launch_assemble(h, jg::GroupSel{}, false, h->d_post);          // the mismatch pass of the assembly kernel: one Ybus row walk, patches applied
+    NR_HIP(hipGetLastError());
+    NR_HIP(hipStreamSynchronize(h->stream));
+    h->jac_valid = false;
+    return get_pairs(h, h->d_post, inj_pq, (size_t)h->n);
 }
 
 int jg_nr_time_kernel(jg_nr* h, int kernel, int reps, double* mean_ms) {

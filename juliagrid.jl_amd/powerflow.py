@@ -86,6 +86,10 @@ class AcPowerFlow:
         self.method = NS(pq=pq, pvpq=pvpq, pcount=pcount, iteration=0, _jcolptr=jcolptr, _jrowval=jrowval,
                          signature=NS(topology=system.model.revision.topology, type=system.model.revision.type))
         self.voltage = NS(magnitude=None, angle=None)
+        self.power = NS(injection=None, supply=None, shunt=None, from_=None, to=None, charging=None, series=None, generator=None)
+        self.current = NS(injection=None, from_=None, to=None, series=None)
+        self._outage_labels = np.zeros(self.batch, dtype=np.int64)     # branch out of service per scenario (0 = none)
+        self._branches_on_device = False
         self.status = None
 
     def close(self):
@@ -263,9 +267,11 @@ def setOutage_(an: AcPowerFlow, scenario: int, label: int | None):
     (None restores the base grid)."""
     if label is None:
         _lib.check(_lib.lib().jg_nr_patch_ybus(an._h, int(scenario), 0, np.zeros(1, dtype=np.int64), np.zeros(2)))
+        an._outage_labels[int(scenario)] = 0
         return
     ptr, dy = outagePatch(an.system, label)
     _lib.check(_lib.lib().jg_nr_patch_ybus(an._h, int(scenario), 4, ptr, _reim(dy)))
+    an._outage_labels[int(scenario)] = int(label)
 
 
 def setOutages_(an: AcPowerFlow, labels, scenario0: int = 0):
@@ -278,3 +284,127 @@ def setOutages_(an: AcPowerFlow, labels, scenario0: int = 0):
         if lab:
             ptr[s], dy[s] = outagePatch(an.system, int(lab))
     _lib.check(_lib.lib().jg_nr_patch_ybus_batch(an._h, int(scenario0), len(labels), 4, ptr.reshape(-1), _reim(dy.reshape(-1))))
+    an._outage_labels[scenario0:scenario0 + len(labels)] = [int(lab) if lab else 0 for lab in labels]
+
+
+# ---- post-processing (N2): power!(analysis) / current!(analysis) for every scenario of the batch ------------------
+def _upload_branches(an: AcPowerFlow):
+    system = an.system
+    ac, par, lay = system.model.ac, system.branch.parameter, system.branch.layout
+    nb = system.branch.number
+    tij = (1.0 / par.turnsRatio) * np.exp(-1j * par.shiftAngle)                     # acAnalysis.jl:846-851
+    tab = np.zeros((nb, 16))
+    for c, z in enumerate((ac.nodalFromFrom, ac.nodalFromTo, ac.nodalToFrom, ac.nodalToTo, ac.admittance, tij)):
+        tab[:, 2 * c], tab[:, 2 * c + 1] = np.real(z), np.imag(z)
+    tab[:, 12], tab[:, 13], tab[:, 14] = par.conductance, par.susceptance, 1.0 / par.turnsRatio
+    L = _lib.lib()
+    _lib.check(L.jg_nr_set_branches(an._h, nb, np.ascontiguousarray(lay.from_, dtype=np.int64), np.ascontiguousarray(lay.to, dtype=np.int64),
+                                    np.ascontiguousarray(lay.status, dtype=np.int8), np.ascontiguousarray(tab.reshape(-1))))
+    an._branches_on_device = True
+
+
+def _pairs(an, fn, rows, *slots):
+    """Call a C-ABI post-processing entry with [batch][rows][2] host buffers for the requested slots."""
+    bufs = [np.zeros((an.batch, rows, 2)) if want else None for want in slots]
+    _lib.check(fn(an._h, *[b.ctypes.data if b is not None else None for b in bufs]))
+    return bufs
+
+
+def _ns2(an, buf, names=("active", "reactive")):
+    return NS(**{names[0]: an._shape(buf[:, :, 0]), names[1]: an._shape(buf[:, :, 1])})
+
+
+def power_(an: AcPowerFlow):
+    """power!(analysis::AcPowerFlow) (src/postprocessing/acAnalysis.jl:30-169) at the current state of EVERY scenario:
+    the Ybus row walk (injections) and the branch formulas run on the device, the O(n) bus / generator bookkeeping
+    (shunt :884-889, supply :53-61, generators :84-166) on the host.  Arrays are [batch, ...] (1-D for batch 1)."""
+    system, bus, gen = an.system, an.system.bus, an.system.generator
+    L = _lib.lib()
+    if not an._branches_on_device:
+        _upload_branches(an)
+    _lib.check(L.jg_nr_set_outage_labels(an._h, np.ascontiguousarray(an._outage_labels, dtype=np.int64)))
+    inj = np.zeros((an.batch, bus.number, 2))
+    _lib.check(L.jg_nr_bus_injection(an._h, inj.reshape(-1)))
+    fr, to, se, ch = _pairs(an, lambda h, a, b, c, d: L.jg_nr_branch_quantities(h, a, b, c, d, None, None, None),
+                            system.branch.number, True, True, True, True)
+    an._pull_voltage()
+    vm = np.atleast_2d(an.voltage.magnitude)
+    P, Q = inj[:, :, 0], inj[:, :, 1]
+    v2 = vm * vm
+    shunt = np.stack([v2 * bus.shunt.conductance[None, :], -v2 * bus.shunt.susceptance[None, :]], axis=2)   # V^2 conj(g + jb)
+    typ, slack = bus.layout.type, bus.layout.slack - 1
+    sup_p = np.broadcast_to(bus.supply.active[None, :], P.shape).copy()
+    sup_q = np.where(typ[None, :] != 1, Q + bus.demand.reactive[None, :], bus.supply.reactive[None, :])        # :55-59
+    sup_p[:, slack] = P[:, slack] + bus.demand.active[slack]                                                 # :61
+    # generators (:84-166)
+    ng = gen.number
+    gp, gq = np.zeros((an.batch, ng)), np.zeros((an.batch, ng))
+    base_mva = system.base.power * 1e-6
+    qmin_all, qmax_all = np.asarray(gen.capability.minReactive, dtype=float), np.asarray(gen.capability.maxReactive, dtype=float)
+    for i in range(ng):
+        if gen.layout.status[i] != 1:
+            continue
+        ib = int(gen.layout.bus[i]) - 1
+        idx = [g - 1 for g in bus.supply.generator[ib + 1]]
+        Pi, Qi = P[:, ib], Q[:, ib]
+        if len(idx) == 1:
+            gp[:, i] = gen.output.active[i]
+            gq[:, i] = Qi + bus.demand.reactive[ib]
+            if ib == slack:
+                gp[:, i] = Pi + bus.demand.active[ib]
+            continue
+        qgen = Qi + bus.demand.reactive[ib]
+        qmins = sum(qmin_all[j] for j in idx if not np.isinf(qmin_all[j]))
+        qmaxs = sum(qmax_all[j] for j in idx if not np.isinf(qmax_all[j]))
+        big = np.abs(qgen) + abs(qmins) + abs(qmaxs)
+        qmin_new = np.full(an.batch, qmin_all[i])
+        qmax_new = np.full(an.batch, qmax_all[i])
+        qmin_inf = np.zeros(an.batch)
+        qmax_inf = np.zeros(an.batch)
+        for j in idx:
+            if np.isinf(qmin_all[j]):
+                qm = -big if qmin_all[j] != np.inf else big
+                if j == i:
+                    qmin_new = qm
+                qmin_inf = qmin_inf + qm
+            if np.isinf(qmax_all[j]):
+                qm = big if qmax_all[j] != -np.inf else -big
+                if j == i:
+                    qmax_new = qm
+                qmax_inf = qmax_inf + qm
+        qmin_sum, qmax_sum = qmins + qmin_inf, qmaxs + qmax_inf
+        prop = base_mva * np.abs(qmin_sum - qmax_sum) > 10 * np.finfo(float).eps
+        with np.errstate(divide="ignore", invalid="ignore"):
+            gq[:, i] = np.where(prop, qmin_new + ((qgen - qmin_sum) / (qmax_sum - qmin_sum)) * (qmax_new - qmin_new),
+                                qmin_new + (qgen - qmin_sum) / len(idx))
+        if ib == slack and idx[0] == i:
+            gp[:, i] = Pi + bus.demand.active[ib] - sum(gen.output.active[j] for j in idx[1:])
+        else:
+            gp[:, i] = gen.output.active[i]
+    pw = an.power
+    pw.injection, pw.shunt = _ns2(an, inj), _ns2(an, shunt)
+    pw.supply = NS(active=an._shape(sup_p), reactive=an._shape(sup_q))
+    pw.from_, pw.to, pw.series, pw.charging = _ns2(an, fr), _ns2(an, to), _ns2(an, se), _ns2(an, ch)
+    pw.generator = NS(active=an._shape(gp), reactive=an._shape(gq))
+
+
+def current_(an: AcPowerFlow):
+    """current!(analysis) (acAnalysis.jl:672-704): injection, from, to and series currents (magnitude, angle)."""
+    system = an.system
+    L = _lib.lib()
+    if not an._branches_on_device:
+        _upload_branches(an)
+    _lib.check(L.jg_nr_set_outage_labels(an._h, np.ascontiguousarray(an._outage_labels, dtype=np.int64)))
+    inj = np.zeros((an.batch, system.bus.number, 2))
+    _lib.check(L.jg_nr_bus_injection(an._h, inj.reshape(-1)))
+    fi, ti, si = _pairs(an, lambda h, a, b, c: L.jg_nr_branch_quantities(h, None, None, None, None, a, b, c),
+                        system.branch.number, True, True, True)
+    an._pull_voltage()
+    vm, va = np.atleast_2d(an.voltage.magnitude), np.atleast_2d(an.voltage.angle)
+    # I_i = conj(S_i / V_i): |I_i| = |S_i| / V_i, arg I_i = theta_i - arg S_i   (Ii, :867-882)
+    S = inj[:, :, 0] + 1j * inj[:, :, 1]
+    I = np.conj(S / (vm * np.exp(1j * va)))
+    cur = an.current
+    cur.injection = NS(magnitude=an._shape(np.abs(I)), angle=an._shape(np.angle(I)))
+    names = ("magnitude", "angle")
+    cur.from_, cur.to, cur.series = _ns2(an, fi, names), _ns2(an, ti, names), _ns2(an, si, names)

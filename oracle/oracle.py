@@ -381,3 +381,91 @@ class OracleGN:
         st = _se_lib().jgo_gn_state_estimation(self.h, iteration, tolerance, hist.ctypes.data, C.byref(nh))
         self.history = hist[: nh.value]
         return int(st)
+
+
+# ---- power!(analysis) / current!(analysis) restated (TEST ORACLE; src/postprocessing/acAnalysis.jl) ------------------
+def power_and_current(sys_: OracleSystem, vm, va):
+    """One voltage profile -> dict of the reference's power! (:30-169) and current! (:672-704) containers.
+    Branch from/to powers and currents and the bus injections come from the C restatement (jgo_exact_quantities,
+    :891-931); series (:906-908, :929-931), charging (:910-919), shunt (:884-889), supply (:53-61) and the generator
+    allocation (:84-166) are restated here line by line in numpy / Python loops."""
+    t = sys_.t
+    n, nb, ng = sys_.n, sys_.nb, sys_.ng
+    vm, va = _f8(vm), _f8(va)
+    br, bq = exact_quantities(sys_, vm, va)
+    on = sys_.status == 1
+    V = vm * np.exp(1j * va)
+    f, to = t["br_from"].astype(int) - 1, t["br_to"].astype(int) - 1
+    tau_inv = 1.0 / _f8(t["br_tap"])
+    tij = tau_inv * np.exp(-1j * _f8(t["br_shift"]))                                   # ViVjVij :846-851
+    Vij = tij * V[f] - V[to]
+    tp = sys_.twoport.reshape(nb, 10)
+    y = tp[:, 0] + 1j * tp[:, 1]
+    Is = np.where(on, y * Vij, 0)                                                      # IsPsis :929-931
+    Sl = Vij * np.conj(Is)                                                             # PlQl :906-908
+    Sc = np.where(on, 0.5 * np.conj(_f8(t["br_g"]) + 1j * _f8(t["br_b"])) * ((tau_inv * vm[f]) ** 2 + vm[to] ** 2), 0)   # PcQc :910-919
+    Ss = vm ** 2 * np.conj(_f8(t["bus_gs"]) + 1j * _f8(t["bus_bs"]))                   # PsQs :884-889
+    P, Q = bq[:, 0], bq[:, 1]
+    slack = sys_.slack - 1
+    sup_p = sys_.ps.copy()
+    sup_q = np.where(sys_.type != 1, Q + sys_.qd, sys_.qs)                             # :53-59
+    sup_p[slack] = P[slack] + sys_.pd[slack]                                           # :61
+    S = P + 1j * Q
+    Ii = np.conj(S / V)                                                                # Ii :867-882 (I = conj(S / V))
+    # generators :84-166
+    gbus = t["gen_bus"].astype(int) - 1
+    gstat = t["gen_status"].astype(int)
+    gpg = _f8(t["gen_pg"])
+    qmin = _f8(t["gen_qmin"]) if "gen_qmin" in t else np.zeros(ng)
+    qmax = _f8(t["gen_qmax"]) if "gen_qmax" in t else np.zeros(ng)
+    at_bus = {}
+    for k in range(ng):
+        if gstat[k] == 1:
+            at_bus.setdefault(int(gbus[k]), []).append(k)
+    base_mva = float(np.asarray(t.get("base_power", 1e8)).reshape(-1)[0]) * 1e-6
+    gp, gq = np.zeros(ng), np.zeros(ng)
+    for i in range(ng):
+        if gstat[i] != 1:
+            continue
+        ib = int(gbus[i])
+        idx = at_bus[ib]
+        if len(idx) == 1:
+            gp[i] = gpg[i]
+            gq[i] = Q[ib] + sys_.qd[ib]
+            if ib == slack:
+                gp[i] = P[ib] + sys_.pd[ib]
+            continue
+        qmins = sum(qmin[j] for j in idx if not np.isinf(qmin[j]))
+        qmaxs = sum(qmax[j] for j in idx if not np.isinf(qmax[j]))
+        qgen = Q[ib] + sys_.qd[ib]
+        qmin_inf = qmax_inf = 0.0
+        qmin_new, qmax_new = qmin[i], qmax[i]
+        for j in idx:
+            if np.isinf(qmin[j]):
+                v = -abs(qgen) - abs(qmins) - abs(qmaxs)
+                if qmin[j] == np.inf:
+                    v = -v
+                if i == j:
+                    qmin_new = v
+                qmin_inf += v
+            if np.isinf(qmax[j]):
+                v = abs(qgen) + abs(qmins) + abs(qmaxs)
+                if qmax[j] == -np.inf:
+                    v = -v
+                if i == j:
+                    qmax_new = v
+                qmax_inf += v
+        qmins += qmin_inf
+        qmaxs += qmax_inf
+        if base_mva * abs(qmins - qmaxs) > 10 * np.finfo(float).eps:
+            gq[i] = qmin_new + ((qgen - qmins) / (qmaxs - qmins)) * (qmax_new - qmin_new)
+        else:
+            gq[i] = qmin_new + (qgen - qmins) / len(idx)
+        if ib == slack and idx[0] == i:
+            gp[i] = P[ib] + sys_.pd[ib] - sum(gpg[j] for j in idx[1:])
+        else:
+            gp[i] = gpg[i]
+    return dict(injection=(P, Q), shunt=(Ss.real, Ss.imag), supply=(sup_p, sup_q), from_=(br[:, 0], br[:, 1]), to=(br[:, 2], br[:, 3]),
+                series=(np.where(on, Sl.real, 0), np.where(on, Sl.imag, 0)), charging=(Sc.real, Sc.imag), generator=(gp, gq),
+                i_injection=(np.abs(Ii), np.angle(Ii)), i_from=(br[:, 4], br[:, 5]), i_to=(br[:, 6], br[:, 7]),
+                i_series=(np.abs(Is), np.where(on, np.angle(Is), 0)))

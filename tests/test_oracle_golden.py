@@ -75,3 +75,22 @@ def test_oracle_jacobian_matches_finite_differences(oracle):
     c.mismatch()
     _, f1, _ = c.vectors()
     assert np.abs((f1 - f0) - Jm @ dx).max() < 1e-9
+
+
+@pytest.mark.parametrize("name", ["case14test", "case30test"])
+def test_power_restatement_hits_the_matpower_goldens(oracle, name):
+    """testPower (test/utility/utility.jl:41-59) on the oracle's restatement of power! (acAnalysis.jl:30-169): the
+    MATPOWER goldens of test/data/results.h5 pin injections, supply, shunt, branch flows, charging, series losses and
+    the generator allocation; atol 1e-8 as in test/powerFlow/analysis.jl."""
+    g = load_golden(name)
+    o = oracle.OracleNR(oracle.OracleSystem(load_case(name)))
+    assert o.power_flow() == 0
+    vm, va = o.voltage()
+    r = oracle.power_and_current(o.sys, vm, va)
+    pairs = [("injection", "injectionActive", "injectionReactive"), ("supply", "supplyActive", "supplyReactive"),
+             ("shunt", "shuntActive", "shuntReactive"), ("from_", "fromActive", "fromReactive"), ("to", "toActive", "toReactive"),
+             ("series", "lossActive", "lossReactive"), ("generator", "generatorActive", "generatorReactive")]
+    for fam, ka, kr in pairs:
+        assert np.abs(r[fam][0] - g["newtonRaphson_" + ka]).max() <= 1e-8, (fam, "active")
+        assert np.abs(r[fam][1] - g["newtonRaphson_" + kr]).max() <= 1e-8, (fam, "reactive")
+    assert np.abs(r["charging"][1] - (g["newtonRaphson_chargingFrom"] + g["newtonRaphson_chargingTo"])).max() <= 1e-8
