@@ -8,7 +8,7 @@
 // so the 64 lanes of a wavefront work on the same structural item of 64 scenarios and move it with 16-byte-per-lane
 // instructions (global_load/store_dwordx4), each covering 1 KiB of CONTIGUOUS memory (a [e][ld][4] interleave would
 // make every instruction touch 2 KiB at half density: measured 0.16 -> 0.25 ms on the assembly's write stream).  Why 16 bytes: a CU retires one vector
-// memory instruction per ~16 clocks whatever its width (measured, scratch_gpu/ldrate.hip: 6.8 ns per wave-instruction
+// memory instruction per ~16 clocks whatever its width (measured, tools/microbench/ldrate.hip: 6.8 ns per wave-instruction
 // for 8 B and for 16 B per lane), and the narrow dependency levels of the LU are bound by exactly that issue rate,
 // so a 2x2 block costs 2 instructions instead of 4.
 #pragma once
