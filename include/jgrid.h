@@ -133,7 +133,8 @@ int jg_nr_bus_injection(jg_nr* h, double* inj_pq);
 
 /* Measurement hooks (HIP events on the handle's own stream).
  * kernel: 0 fused mismatch+Jacobian assembly, 1 LU refactorization + fused forward elimination (all
- * launches), 2 backward sweep (no state update).  Returns the mean milliseconds of `reps` back-to-back executions. */
+ * launches), 2 backward sweep (no state update), 3 power!/current! branch kernel (all outputs).  Returns the mean
+ * milliseconds of `reps` back-to-back executions. */
 int jg_nr_time_kernel(jg_nr* h, int kernel, int reps, double* mean_ms);
 
 /* ---------------------------------------------------------------------------------------------

@@ -1024,8 +1024,17 @@ int jg_nr_bus_injection(jg_nr* h, double* inj_pq) {
 }
 
 int jg_nr_time_kernel(jg_nr* h, int kernel, int reps, double* mean_ms) {
-    if (!h || reps < 1 || !mean_ms || kernel < 0 || kernel > 2) return fail(1, "jg_nr_time_kernel: bad argument");
+    if (!h || reps < 1 || !mean_ms || kernel < 0 || kernel > 3) return fail(1, "jg_nr_time_kernel: bad argument");
     if (int rc = set_device(h)) return rc;
+    BranchArgs ba{};
+    if (kernel == 3) {                                           // power!/current! branch kernel, all seven outputs
+        if (!h->d_bparam) return fail(1, "jg_nr_time_kernel: call jg_nr_set_branches first");
+        const size_t one = (size_t)h->nb * h->ld * 2;
+        if (int rc = post_staging(h, one * 7 * sizeof(double))) return rc;
+        ba = BranchArgs{h->d_bfrom, h->d_bto, h->d_bstatus, h->d_bparam, h->d_vm, h->d_va, h->d_outage, h->d_post, h->d_post + one,
+                        h->d_post + 2 * one, h->d_post + 3 * one, h->d_post + 4 * one, h->d_post + 5 * one, h->d_post + 6 * one,
+                        h->nb, h->ld, h->batch};
+    }
     hipEvent_t e0, e1;
     NR_HIP(hipEventCreate(&e0));
     NR_HIP(hipEventCreate(&e1));
@@ -1036,6 +1045,7 @@ int jg_nr_time_kernel(jg_nr* h, int kernel, int reps, double* mean_ms) {
     for (int r = 0; r < reps; ++r) {
         if (kernel == 0) launch_assemble(h);
         else if (kernel == 1) { if (int rc = h->eng.factor(h->stream, nullptr, h->d_F, jg::GroupSel{})) return fail(rc, h->eng.error); }
+        else if (kernel == 3) hipLaunchKernelGGL(k_branch_quantities, dim3((h->nb + 15) / 16, h->ld / 64), dim3(64, 16), 0, h->stream, ba);
         else { if (int rc = h->eng.backsolve(h->stream, h->d_inc, none, jg::GroupSel{})) return fail(rc, h->eng.error); }
     }
     NR_HIP(hipEventRecord(e1, h->stream));

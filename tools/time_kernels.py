@@ -10,6 +10,7 @@ case = sys.argv[2] if len(sys.argv) > 2 else "case_ACTIVSg10k"
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 s = jg.powerSystem(case)
 an = jg.contingencyAnalysis(s, jg.outageList(s, batch, seed=512))
+jg.powerflow._upload_branches(an)
 for _ in range(3):
-    print(case, batch, "asm %.4f  fact %.4f  bwd %.4f ms" % tuple(an.time_kernel(k, reps) for k in (0, 1, 2)))
+    print(case, batch, "asm %.4f  fact %.4f  bwd %.4f  branch-post %.4f ms" % tuple(an.time_kernel(k, reps) for k in (0, 1, 2, 3)))
 an.close()
