@@ -171,6 +171,10 @@ int jg_gn_set_measurement(jg_gn* h, const double* mean, const double* wdiag, con
                           int64_t batch_stride_m, int64_t batch_stride_corr);
 int jg_gn_set_voltage(jg_gn* h, const double* vm, const double* va, int64_t batch_stride);
 int jg_gn_get_voltage(jg_gn* h, double* vm, double* va);
+/* Keep / restore the current state inside HBM (restart of a Monte-Carlo batch from the same start point without a
+ * host round trip; the counterpart of jg_nr_snapshot_voltage / jg_nr_restore_voltage). */
+int jg_gn_snapshot_voltage(jg_gn* h);
+int jg_gn_restore_voltage(jg_gn* h);
 /* increment!(analysis) -- acStateEstimation.jl:878-904: residual + Jacobian, gain, factor, solve.
  * max_inc [batch] = maximum(abs, increment). */
 int jg_gn_increment(jg_gn* h, double* max_inc);

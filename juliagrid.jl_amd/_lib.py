@@ -70,6 +70,8 @@ def lib():
         "jg_gn_set_measurement": [VP, F64P, F64P, F64P, C.c_int64, C.c_int64],
         "jg_gn_set_voltage": [VP, F64P, F64P, C.c_int64],
         "jg_gn_get_voltage": [VP, F64P, F64P],
+        "jg_gn_snapshot_voltage": [VP],
+        "jg_gn_restore_voltage": [VP],
         "jg_gn_increment": [VP, F64P],
         "jg_gn_solve": [VP],
         "jg_gn_run": [VP, C.c_int64, C.c_double, I32P, I32P],

@@ -334,6 +334,7 @@ struct jg_gn {
     double* d_Hs = nullptr; double* d_res = nullptr; double* d_Gv = nullptr; double* d_rhs = nullptr; double* d_inc = nullptr;
     GainItem* d_items = nullptr; int* d_cw = nullptr; int* d_ca = nullptr; int* d_cb = nullptr; int* d_blk_row = nullptr; int* d_blk_col = nullptr;
     double* d_part = nullptr; double* d_maxinc = nullptr; double* d_params = nullptr;
+    double* d_vm0 = nullptr; double* d_va0 = nullptr;   // snapshot of the start point (jg_gn_snapshot_voltage)
     int* d_active = nullptr; int* d_iters = nullptr; int* d_status = nullptr; int* d_counter = nullptr; int* d_group = nullptr;
     jg::Engine eng;
     hipStream_t stream = nullptr;
@@ -573,6 +574,7 @@ void jg_gn_destroy(jg_gn* h) {
     if (h->graph) hipGraphDestroy(h->graph);
     h->eng.destroy();
     hipFree(h->d_rows); hipFree(h->d_slot_bus); hipFree(h->d_br); hipFree(h->d_rowptr); hipFree(h->d_G); hipFree(h->d_B); hipFree(h->d_ydiag);
+    hipFree(h->d_vm0); hipFree(h->d_va0);
     hipFree(h->d_vm); hipFree(h->d_va); hipFree(h->d_mean); hipFree(h->d_w); hipFree(h->d_Hs); hipFree(h->d_res); hipFree(h->d_Gv);
     hipFree(h->d_rhs); hipFree(h->d_inc); hipFree(h->d_items); hipFree(h->d_cw); hipFree(h->d_ca); hipFree(h->d_cb); hipFree(h->d_blk_row);
     hipFree(h->d_blk_col); hipFree(h->d_part); hipFree(h->d_maxinc); hipFree(h->d_params); hipFree(h->d_active); hipFree(h->d_iters);
@@ -608,6 +610,26 @@ int jg_gn_set_voltage(jg_gn* h, const double* vm, const double* va, int64_t stri
     GN_HIP(hipStreamSynchronize(h->stream));
     if (int rc = put_rows(h, h->d_vm, vm, stride, h->n)) return rc;
     return put_rows(h, h->d_va, va, stride, h->n);
+}
+
+int jg_gn_snapshot_voltage(jg_gn* h) {
+    if (!h) return failg(1, "jg_gn_snapshot_voltage: bad argument");
+    if (int rc = set_device(h)) return rc;
+    const size_t bytes = (size_t)h->n * h->ld * 8;
+    if (!h->d_vm0) { GN_HIP(hipMalloc((void**)&h->d_vm0, bytes)); GN_HIP(hipMalloc((void**)&h->d_va0, bytes)); }
+    GN_HIP(hipMemcpyAsync(h->d_vm0, h->d_vm, bytes, hipMemcpyDeviceToDevice, h->stream));
+    GN_HIP(hipMemcpyAsync(h->d_va0, h->d_va, bytes, hipMemcpyDeviceToDevice, h->stream));
+    GN_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int jg_gn_restore_voltage(jg_gn* h) {
+    if (!h || !h->d_vm0) return failg(1, "jg_gn_restore_voltage: no snapshot");
+    if (int rc = set_device(h)) return rc;
+    const size_t bytes = (size_t)h->n * h->ld * 8;
+    GN_HIP(hipMemcpyAsync(h->d_vm, h->d_vm0, bytes, hipMemcpyDeviceToDevice, h->stream));
+    GN_HIP(hipMemcpyAsync(h->d_va, h->d_va0, bytes, hipMemcpyDeviceToDevice, h->stream));
+    return 0;
 }
 
 int jg_gn_get_voltage(jg_gn* h, double* vm, double* va) {

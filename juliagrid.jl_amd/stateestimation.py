@@ -204,6 +204,13 @@ class AcStateEstimation:
         _lib.check(_lib.lib().jg_gn_set_voltage(self._h, vm.reshape(-1), va.reshape(-1), stride))
         self._pull_voltage()
 
+    def snapshot_voltage(self):
+        """Keep the current state in HBM as the start point of later restarts (restore_voltage)."""
+        _lib.check(_lib.lib().jg_gn_snapshot_voltage(self._h))
+
+    def restore_voltage(self):
+        _lib.check(_lib.lib().jg_gn_restore_voltage(self._h))
+
     def _pull_voltage(self):
         n = self.system.bus.number
         vm, va = np.zeros((self.batch, n)), np.zeros((self.batch, n))
