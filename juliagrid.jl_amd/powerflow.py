@@ -408,3 +408,62 @@ def current_(an: AcPowerFlow):
     cur.injection = NS(magnitude=an._shape(np.abs(I)), angle=an._shape(np.angle(I)))
     names = ("magnitude", "angle")
     cur.from_, cur.to, cur.series = _ns2(an, fi, names), _ns2(an, ti, names), _ns2(an, si, names)
+
+
+def reactiveLimit_(an: AcPowerFlow):
+    """reactiveLimit!(analysis) (src/powerFlow/acPowerFlow.jl:1081-1155), single-scenario analyses: generator outputs
+    from power! on the device, then the reference's bookkeeping on the PowerSystem container -- a generator whose
+    reactive output violates its limits pins Q at the limit and turns its bus into a demand bus; a converted slack
+    hands over to the first generator bus.  Mutates `an.system` like the reference; returns the violate vector.
+    The caller then builds a new analysis (`newtonRaphson(system)`) and solves again."""
+    if an.batch != 1:
+        raise ValueError("reactiveLimit_ works on a single-scenario analysis")
+    system, bus, gen = an.system, an.system.bus, an.system.generator
+    power_(an)
+    gp, gq = an.power.generator.active, an.power.generator.reactive
+    violate = np.zeros(gen.number, dtype=np.int64)
+    bus.supply.active[:] = 0.0
+    bus.supply.reactive[:] = 0.0
+    out_q = np.zeros(gen.number)
+    for k in range(gen.number):                                            # :1093-1103
+        if gen.layout.status[k] == 1:
+            i = int(gen.layout.bus[k]) - 1
+            gen.output.active[k] = gp[k]
+            bus.supply.active[i] += gp[k]
+            bus.supply.reactive[i] += gq[k]
+            out_q[k] = gq[k]
+    qmin, qmax = gen.capability.minReactive, gen.capability.maxReactive
+    typ = bus.layout.type
+    for i in range(gen.number):                                            # :1105-1148
+        if gen.layout.status[i] == 0 or not (qmin[i] < qmax[i]):
+            continue
+        j = int(gen.layout.bus[i]) - 1
+        lo, hi = out_q[i] < qmin[i], out_q[i] > qmax[i]
+        if typ[j] != 1 and (lo or hi):
+            if lo:
+                violate[i], new_q = -1, qmin[i]
+            if hi:
+                violate[i], new_q = 1, qmax[i]
+            typ[j] = 1
+            system.model.revision.type += 1
+            bus.supply.reactive[j] -= out_q[i]
+            gen.output.reactive[i] = new_q
+            bus.supply.reactive[j] += new_q
+            if j == bus.layout.slack - 1:
+                for k in range(bus.number):
+                    if typ[k] == 2:
+                        bus.layout.slack = k + 1
+                        system.model.revision.slack += 1
+                        typ[k] = 3
+                        system.model.revision.type += 1
+                        break
+    if typ[bus.layout.slack - 1] != 3:
+        raise RuntimeError("The slack bus is not defined.")                # errorSlackDefinition (:1151-1153)
+    return violate
+
+
+def adjustAngle_(an: AcPowerFlow, slack: int):
+    """adjustAngle!(analysis; slack) (acPowerFlow.jl:1196-1206): shift every angle so that bus `slack` (1-based index)
+    carries the angle the PowerSystem container holds for it."""
+    shift = an.system.bus.voltage.angle[int(slack) - 1] - np.atleast_2d(an.voltage.angle)[:, int(slack) - 1]
+    an.voltage.angle = an._shape(np.atleast_2d(an.voltage.angle) + shift[:, None])

@@ -469,3 +469,56 @@ def power_and_current(sys_: OracleSystem, vm, va):
                 series=(np.where(on, Sl.real, 0), np.where(on, Sl.imag, 0)), charging=(Sc.real, Sc.imag), generator=(gp, gq),
                 i_injection=(np.abs(Ii), np.angle(Ii)), i_from=(br[:, 4], br[:, 5]), i_to=(br[:, 6], br[:, 7]),
                 i_series=(np.abs(Is), np.where(on, np.angle(Is), 0)))
+
+
+def reactive_limit(sys_: OracleSystem, nr_type, vm, va):
+    """reactiveLimit!(analysis) restated (src/powerFlow/acPowerFlow.jl:1081-1155) on the oracle's system container:
+    generator outputs from power! (:1093-1103), violated PV / slack buses become PQ with Q pinned at the limit
+    (:1105-1130), a converted slack hands over to the first generator bus (:1131-1146).  Mutates sys_ (type, slack,
+    supply, gen_pg / gen_qg) like the reference mutates `system`; returns the violate vector."""
+    t = sys_.t
+    saved_type = sys_.type
+    sys_.type = np.ascontiguousarray(nr_type, dtype=np.int8).copy()      # the bus types newtonRaphson() settled on
+    r = power_and_current(sys_, vm, va)
+    gp, gq = r["generator"]
+    ng = sys_.ng
+    violate = np.zeros(ng, dtype=np.int64)
+    sys_.ps[:] = 0.0
+    sys_.qs[:] = 0.0
+    out_q = np.zeros(ng)
+    gstat, gbus = t["gen_status"].astype(int), t["gen_bus"].astype(int) - 1
+    pg = _f8(t["gen_pg"]).copy()
+    qg = _f8(t["gen_qg"]).copy()
+    for k in range(ng):                                                   # label order = index order in our fixtures
+        if gstat[k] == 1:
+            pg[k] = gp[k]
+            sys_.ps[gbus[k]] += gp[k]
+            sys_.qs[gbus[k]] += gq[k]
+            out_q[k] = gq[k]
+    qmin, qmax = _f8(t["gen_qmin"]), _f8(t["gen_qmax"])
+    for i in range(ng):
+        if gstat[i] == 0 or not (qmin[i] < qmax[i]):
+            continue
+        j = int(gbus[i])
+        lo, hi = out_q[i] < qmin[i], out_q[i] > qmax[i]
+        if sys_.type[j] != 1 and (lo or hi):
+            if lo:
+                violate[i], new_q = -1, qmin[i]
+            if hi:
+                violate[i], new_q = 1, qmax[i]
+            sys_.type[j] = 1
+            sys_.qs[j] -= out_q[i]
+            qg[i] = new_q
+            sys_.qs[j] += new_q
+            if j == sys_.slack - 1:
+                for k in range(sys_.n):
+                    if sys_.type[k] == 2:
+                        sys_.slack = k + 1
+                        sys_.type[k] = 3
+                        break
+    if sys_.type[sys_.slack - 1] != 3:
+        sys_.type = saved_type
+        raise RuntimeError("The slack bus is not defined.")
+    t["gen_pg"], t["gen_qg"] = pg, qg
+    t["bus_type"] = sys_.type.copy()
+    return violate

@@ -94,3 +94,26 @@ def test_power_restatement_hits_the_matpower_goldens(oracle, name):
         assert np.abs(r[fam][0] - g["newtonRaphson_" + ka]).max() <= 1e-8, (fam, "active")
         assert np.abs(r[fam][1] - g["newtonRaphson_" + kr]).max() <= 1e-8, (fam, "reactive")
     assert np.abs(r["charging"][1] - (g["newtonRaphson_chargingFrom"] + g["newtonRaphson_chargingTo"])).max() <= 1e-8
+
+
+@pytest.mark.parametrize("name", ["case14test", "case30test"])
+def test_reactive_limits_hit_the_matpower_goldens(oracle, name):
+    """test/powerFlow/limits.jl:4-42 on the oracle: solve, reactiveLimit!, solve again from the container's start,
+    adjustAngle! to the original slack; iteration counts add up; V, theta to 1e-8 of MATPOWER's enforce-Q-limits run."""
+    g = load_golden(name)
+    t = load_case(name)
+    osys = oracle.OracleSystem(t)
+    slack0 = osys.slack
+    o = oracle.OracleNR(osys)
+    assert o.power_flow() == 0
+    it0 = o.iteration
+    vm, va = o.voltage()
+    violate = oracle.reactive_limit(osys, o.type, vm, va)
+    assert np.any(violate != 0)
+    o2 = oracle.OracleNR(osys)
+    assert o2.power_flow() == 0
+    vm2, va2 = o2.voltage()
+    va2 = va2 + (t["bus_va"][slack0 - 1] - va2[slack0 - 1])          # adjustAngle!(analysis; slack = original slack)
+    assert it0 + o2.iteration == int(g["reactiveLimit_newtonRaphson_iteration"][0])
+    assert np.abs(vm2 - g["reactiveLimit_newtonRaphson_voltageMagnitude"]).max() <= 1e-8
+    assert np.abs(va2 - g["reactiveLimit_newtonRaphson_voltageAngle"]).max() <= 1e-8

@@ -87,3 +87,23 @@ def test_power_hits_the_matpower_goldens(jg, name):
     assert np.abs(pw.series.active - g["newtonRaphson_lossActive"]).max() <= 1e-8
     assert np.abs(pw.series.reactive - g["newtonRaphson_lossReactive"]).max() <= 1e-8
     assert np.abs(pw.charging.reactive - (g["newtonRaphson_chargingFrom"] + g["newtonRaphson_chargingTo"])).max() <= 1e-8
+
+
+@pytest.mark.parametrize("name", ["case14test", "case30test"])
+def test_reactive_limits_hit_the_matpower_goldens(jg, name):
+    """test/powerFlow/limits.jl:4-42 through the device path (newtonRaphson -> powerFlow! -> reactiveLimit! ->
+    newtonRaphson -> powerFlow! -> adjustAngle!)."""
+    g = load_golden(name)
+    system = jg.powerSystem(load_case(name))
+    slack0 = system.bus.layout.slack
+    an = jg.newtonRaphson(system)
+    jg.powerFlow_(an)
+    it0 = int(an.method.iteration)
+    violate = jg.reactiveLimit_(an)
+    assert np.any(violate != 0)
+    an2 = jg.newtonRaphson(system)
+    jg.powerFlow_(an2)
+    jg.adjustAngle_(an2, slack0)
+    assert it0 + int(an2.method.iteration) == int(g["reactiveLimit_newtonRaphson_iteration"][0])
+    assert np.abs(an2.voltage.magnitude - g["reactiveLimit_newtonRaphson_voltageMagnitude"]).max() <= 1e-8
+    assert np.abs(an2.voltage.angle - g["reactiveLimit_newtonRaphson_voltageAngle"]).max() <= 1e-8
