@@ -522,3 +522,145 @@ def reactive_limit(sys_: OracleSystem, nr_type, vm, va):
     t["gen_pg"], t["gen_qg"] = pg, qg
     t["bus_type"] = sys_.type.copy()
     return violate
+
+
+class OracleFastNR:
+    """fastNewtonRaphsonBX / XB restated (TEST ORACLE, numpy + scipy.sparse.linalg.splu):
+      fastNewtonRaphsonModel, fastNewtonJacobian, fastNewtonJacobian!, jacobianCoefficient   acPowerFlow.jl:259-506
+      mismatch!                                                                              acPowerFlow.jl:687-730
+      solve!                                                                                 acPowerFlow.jl:913-983
+      powerFlow!                                                                             acPowerFlow.jl:1389-1433
+    Bus types / start voltages come from the same initializeACPowerFlow restatement the Newton-Raphson oracle uses."""
+
+    def __init__(self, sys_: OracleSystem, bx: bool):
+        import scipy.sparse as sp
+        import scipy.sparse.linalg as spl
+        self.sys, self.bx = sys_, bool(bx)
+        nr = OracleNR(sys_)                                    # type normalisation + start point (:1312-1358)
+        self.type, self.slack = nr.type.copy(), nr.slack
+        self.vm, self.va = nr.vm.copy(), nr.va.copy()
+        t, n = sys_.t, sys_.n
+        typ = self.type
+        self.pq = np.zeros(n, dtype=np.int64)
+        self.pvpq = np.zeros(n, dtype=np.int64)
+        npq = npvpq = 0
+        for i in range(n):                                     # fastNewtonJacobian :343-356
+            if typ[i] == 1:
+                npq += 1
+                self.pq[i] = npq
+            if typ[i] != 3:
+                npvpq += 1
+                self.pvpq[i] = npvpq
+        self.npq = npq
+        cp, rv = sys_.colptr, sys_.rowval
+        # patterns with stored zeros, column by column of Ybus (:358-404)
+        colP, rowP, colQ, rowQ = [], [], [], []
+        for i in range(n):
+            if i + 1 == self.slack:
+                continue
+            for p in range(cp[i] - 1, cp[i + 1] - 1):
+                r = rv[p] - 1
+                if typ[r] != 3:
+                    colP.append(self.pvpq[i] - 1)
+                    rowP.append(self.pvpq[r] - 1)
+                if typ[i] == 1 and typ[r] == 1:
+                    colQ.append(self.pq[i] - 1)
+                    rowQ.append(self.pq[r] - 1)
+        P = sp.csc_matrix((np.zeros(len(rowP)), (rowP, colP)), shape=(n - 1, n - 1)).tolil()
+        Q = sp.csc_matrix((np.zeros(len(rowQ)), (rowQ, colQ)), shape=(npq, npq)).tolil()
+        tp = sys_.twoport.reshape(sys_.nb, 10)
+        for k in range(sys_.nb):                               # fastNewtonJacobian! over in-service branches (:322-326, 407-447)
+            if sys_.status[k] != 1:
+                continue
+            i, j = int(t["br_from"][k]) - 1, int(t["br_to"][k]) - 1
+            bsi = 0.5 * float(t["br_b"][k])
+            tinv = 1.0 / float(t["br_tap"][k])
+            sn, cs = np.sin(float(t["br_shift"][k])), np.cos(float(t["br_shift"][k]))
+            yre, yim = tp[k, 0], tp[k, 1]
+            if self.bx:                                        # jacobianCoefficient :449-474
+                bmk, A, B = -1.0 / float(t["br_x"][k]), yre, yim
+            else:
+                bmk, A, B = yim, 0.0, -1.0 / float(t["br_x"][k])
+            qA, qB, qC = -bmk * tinv, (bmk + bsi) * tinv ** 2, bmk + bsi
+            den = cs * cs + sn * sn
+            m, nn = self.pvpq[i] - 1, self.pvpq[j] - 1
+            if i + 1 != self.slack and j + 1 != self.slack:
+                P[m, nn] += (-A * sn - B * cs) / den           # Pij_theta_ij :476-481
+                P[nn, m] += (A * sn - B * cs) / den
+            if i + 1 != self.slack:
+                P[m, m] += B / den
+            if j + 1 != self.slack:
+                P[nn, nn] += B
+            ri, rj = self.pq[i] - 1, self.pq[j] - 1
+            if ri >= 0 and rj >= 0:
+                Q[ri, rj] += qA
+                Q[rj, ri] += qA
+            if typ[i] == 1:
+                Q[ri, ri] += qB
+            if typ[j] == 1:
+                Q[rj, rj] += qC
+        for i in range(n):                                     # shunt susceptance on the Q diagonal (:328-334)
+            if typ[i] == 1 and t["bus_bs"][i] != 0:
+                Q[self.pq[i] - 1, self.pq[i] - 1] += float(t["bus_bs"][i])
+        self.P, self.Q = P.tocsc(), Q.tocsc()
+        self.luP, self.luQ = spl.splu(self.P), spl.splu(self.Q)
+        self.iteration = 0
+        self.mismP = np.zeros(n - 1)
+        self.mismQ = np.zeros(npq)
+
+    def _row_sums(self, i, want_q):
+        s = self.sys
+        cp, rv = s.colptr, s.rowval
+        cur_p = cur_q = 0.0
+        for p in range(cp[i] - 1, cp[i + 1] - 1):
+            r = rv[p] - 1
+            g, b = s.ytre[p], s.ytim[p]                         # GijBijθij reads nodalMatrixTranspose.nzval (T1)
+            d = self.va[i] - self.va[r]
+            sn, cs = np.sin(d), np.cos(d)
+            cur_p += self.vm[r] * (g * cs + b * sn)             # PiQiSumPlus
+            if want_q:
+                cur_q += self.vm[r] * (g * sn - b * cs)         # PiQiSumMinus
+        return cur_p, cur_q
+
+    def mismatch(self):
+        s = self.sys
+        stop_p = stop_q = 0.0
+        for i in range(s.n):
+            if i + 1 == self.slack:
+                continue
+            is_pq = self.type[i] == 1
+            cp_, cq_ = self._row_sums(i, is_pq)
+            vinv = 1.0 / self.vm[i]
+            self.mismP[self.pvpq[i] - 1] = cp_ - (s.ps[i] - s.pd[i]) * vinv
+            stop_p = max(stop_p, abs(self.mismP[self.pvpq[i] - 1]))
+            if is_pq:
+                self.mismQ[self.pq[i] - 1] = cq_ - (s.qs[i] - s.qd[i]) * vinv
+                stop_q = max(stop_q, abs(self.mismQ[self.pq[i] - 1]))
+        return stop_p, stop_q
+
+    def solve(self):
+        s = self.sys
+        inc = self.luP.solve(self.mismP)
+        for i in range(s.n):
+            if i + 1 != self.slack:
+                self.va[i] += inc[self.pvpq[i] - 1]
+        for i in range(s.n):
+            if self.type[i] == 1:
+                _, cq_ = self._row_sums(i, True)
+                self.mismQ[self.pq[i] - 1] = cq_ - (s.qs[i] - s.qd[i]) / self.vm[i]
+        incq = self.luQ.solve(self.mismQ)
+        for i in range(s.n):
+            if self.type[i] == 1:
+                self.vm[i] += incq[self.pq[i] - 1]
+        self.iteration += 1
+
+    def power_flow(self, iteration=20, tolerance=1e-8):
+        self.iteration = 0
+        for _ in range(iteration + 1):
+            dp, dq = self.mismatch()
+            if dp < tolerance and dq < tolerance:
+                return 0
+            if self.iteration == iteration:
+                return 1
+            self.solve()
+        return 1

@@ -117,3 +117,17 @@ def test_reactive_limits_hit_the_matpower_goldens(oracle, name):
     assert it0 + o2.iteration == int(g["reactiveLimit_newtonRaphson_iteration"][0])
     assert np.abs(vm2 - g["reactiveLimit_newtonRaphson_voltageMagnitude"]).max() <= 1e-8
     assert np.abs(va2 - g["reactiveLimit_newtonRaphson_voltageAngle"]).max() <= 1e-8
+
+
+@pytest.mark.parametrize("name", ["case14test", "case30test"])
+@pytest.mark.parametrize("bx", [True, False])
+def test_fast_newton_raphson_hits_the_matpower_goldens(oracle, name, bx):
+    """test/powerFlow/analysis.jl:70-142 on the oracle's restatement of fastNewtonRaphsonBX / XB: iteration counts
+    equal the reference's, V and theta within isapprox's default (sqrt(eps) relative)."""
+    g = load_golden(name)
+    key = "fastNewtonRaphsonBX" if bx else "fastNewtonRaphsonXB"
+    o = oracle.OracleFastNR(oracle.OracleSystem(load_case(name)), bx)
+    assert o.power_flow(iteration=30) == 0
+    assert o.iteration == int(g[key + "_iteration"][0])
+    for got, ref in ((o.vm, g[key + "_voltageMagnitude"]), (o.va, g[key + "_voltageAngle"])):
+        assert np.linalg.norm(got - ref) <= 1.5e-8 * max(np.linalg.norm(got), np.linalg.norm(ref))

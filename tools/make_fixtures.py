@@ -139,7 +139,9 @@ def case_from_matpower(path):
 def goldens(path, case):
     out = {}
     for d in h5_list(path):
-        if d.startswith("/" + case + "/newtonRaphson/") or d.startswith("/" + case + "/reactiveLimit/newtonRaphson/"):
+        if (d.startswith("/" + case + "/newtonRaphson/") or d.startswith("/" + case + "/reactiveLimit/newtonRaphson/")
+                or any(d == "/" + case + "/" + m + "/" + q for m in ("fastNewtonRaphsonBX", "fastNewtonRaphsonXB")
+                       for q in ("iteration", "voltageMagnitude", "voltageAngle"))):
             a = h5_read(path, d)
             if a is not None:
                 key = d[len(case) + 2:].replace("/", "_")
