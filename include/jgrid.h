@@ -111,6 +111,22 @@ int jg_nr_get_maps(jg_nr* h, int64_t* pq, int64_t* pvpq, int64_t* pcount, int64_
 int jg_nr_get_iteration(jg_nr* h, int32_t* iters);
 
 /*
+ * Fast Newton-Raphson (fastNewtonRaphsonBX / XB) on the same handle -- acPowerFlow.jl:215-537 (model), 687-730
+ * (mismatch!), 913-983 (solve!), 1389-1433 (powerFlow!).  The two constant matrices are factorised ONCE on the device
+ * (as one block matrix diag(B', B'') per bus pair) and every iteration is two forward/backward sweeps.
+ * jg_nr_fast_setup: bp, bq [nnz of Ybus] = B'[pvpq r, pvpq c] and B''[pq r, pq c] of the stored Ybus entry (r, c) at
+ *   that CSC pointer (fastNewtonJacobian!, :407-447), identity on the diagonal / zero elsewhere for rows and
+ *   columns that are not in the reduced matrices (slack; PV buses in B'').  Shared by all scenarios of the batch.
+ * jg_nr_fast_mismatch / _solve / _run mirror jg_nr_mismatch / _solve / _run; jg_nr_get_mismatch returns
+ *   [active.mismatch | reactive.mismatch], jg_nr_fast_get_increment [active.increment | reactive.increment].
+ */
+int jg_nr_fast_setup(jg_nr* h, const double* bp, const double* bq);
+int jg_nr_fast_mismatch(jg_nr* h, double* max_p, double* max_q);
+int jg_nr_fast_solve(jg_nr* h);
+int jg_nr_fast_run(jg_nr* h, int64_t max_iter, double tol, int32_t* iters, int32_t* status);
+int jg_nr_fast_get_increment(jg_nr* h, double* incr);
+
+/*
  * power!(analysis) / current!(analysis) for every scenario of the batch at its CURRENT state --
  * src/postprocessing/acAnalysis.jl:30-169 (power!), 672-704 (current!), formula helpers :838-925.
  * jg_nr_set_branches (once): the branch table the post-processing needs,

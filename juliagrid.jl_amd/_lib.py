@@ -60,6 +60,11 @@ def lib():
         "jg_nr_get_maps": [VP, I64P, I64P, I64P, I64P, I64P],
         "jg_nr_get_iteration": [VP, I32P],
         "jg_nr_time_kernel": [VP, C.c_int, C.c_int, C.POINTER(C.c_double)],
+        "jg_nr_fast_setup": [VP, F64P, F64P],
+        "jg_nr_fast_mismatch": [VP, F64P, F64P],
+        "jg_nr_fast_solve": [VP],
+        "jg_nr_fast_run": [VP, C.c_int64, C.c_double, I32P, I32P],
+        "jg_nr_fast_get_increment": [VP, F64P],
         "jg_nr_set_branches": [VP, C.c_int64, I64P, I64P, I8P, F64P],
         "jg_nr_set_outage_labels": [VP, I64P],
         "jg_nr_branch_quantities": [VP, VP, VP, VP, VP, VP, VP, VP],
@@ -139,5 +144,5 @@ class Plan:
     def replay_tables(self, kind):
         """Device replay tables (jg_symbolic.hpp): segments [n,8] = rec_base, nchunks, wpi, rpw, level, last, items, -;
         wave records [m,16]."""
-        base = {"fact": 60, "bwd": 62}[kind]
+        base = {"fact": 60, "bwd": 62, "fwd": 66}[kind]
         return self.get(base).reshape(-1, 8), self.get(base + 1).reshape(-1, 16)

@@ -564,8 +564,10 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, int policy
     ld = ld_;
     level_launches(S.fact_seg, fact);
     level_launches(S.bwd_seg, bwd);
+    level_launches(S.fwd_seg, fwd);
     if (upload(&fact_rec, S.fact_rec, error, st) || upload(&bwd_rec, S.bwd_rec, error, st) || upload(&fact_seg, S.fact_seg, error, st) ||
-        upload(&bwd_seg, S.bwd_seg, error, st) || upload(&bwd_chain, S.bwd_chain, error, st))
+        upload(&bwd_seg, S.bwd_seg, error, st) || upload(&bwd_chain, S.bwd_chain, error, st) ||
+        upload(&fwd_rec, S.fwd_rec, error, st) || upload(&fwd_seg, S.fwd_seg, error, st))
         return 2;
     JG_HIP(hipFuncSetAttribute((const void*)k_bwd_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CHAIN_LDS_D2 * sizeof(double2))));
     JG_HIP(hipMalloc((void**)&X, factor_bytes()));
@@ -625,6 +627,7 @@ void Engine::destroy() {
         hipFree(prof); prof = nullptr;
     }
     hipFree(fact_rec); hipFree(bwd_rec); hipFree(fact_seg); hipFree(bwd_seg); hipFree(bwd_chain); hipFree(sync);
+    hipFree(fwd_rec); hipFree(fwd_seg); fwd_rec = nullptr; fwd_seg = nullptr;
     bwd_chain = nullptr;
     hipFree(X); hipFree(W); hipFree(status);
     fact_rec = bwd_rec = nullptr; fact_seg = bwd_seg = nullptr; sync = nullptr; status = nullptr;
@@ -670,6 +673,42 @@ int Engine::factor(hipStream_t st, const double* A, const double* rhs, const Gro
         hipLaunchKernelGGL(k_fact_level, dim3((unsigned)L.grid * gs, L.nseg), dim3(64, 16), 16 * 256 * sizeof(double), st, a);
     }
     JG_HIP(hipGetLastError());
+    return 0;
+}
+
+int Engine::forward(hipStream_t st, const double* rhs, const GroupSel& sel) {
+    FactArgs a{fwd_rec, fwd_seg, X, rhs, X, W, status, sel, ld, 0, lanes > 0 ? lanes : ld, 0, 0, 1, 1};
+    const int gs = group_stride(ld / 64);
+    for (const DevLaunch& L : fwd) {
+        a.seg_begin = L.seg_begin;
+        { const Segment& g = S.fwd_seg[L.seg_begin]; a.s0_base = g.rec_base; a.s0_nchunks = g.nchunks; a.s0_wpi = g.wpi; a.s0_rpw = g.rpw; }
+        hipLaunchKernelGGL(k_fact_level, dim3((unsigned)L.grid * gs, L.nseg), dim3(64, 16), 16 * 256 * sizeof(double), st, a);
+    }
+    JG_HIP(hipGetLastError());
+    return 0;
+}
+
+namespace {
+// X[entry of block p] <- blocks[p] for every scenario
+__global__ void k_fill_shared(const double* blocks, const int* src_entry, double* X, int nnz, int ld) {
+    const int p = blockIdx.x * blockDim.y + threadIdx.y;
+    if (p >= nnz) return;
+    const size_t b = (size_t)blockIdx.y * 64 + threadIdx.x;
+    const double* v = blocks + (size_t)p * 4;
+    store_blk(X, (size_t)src_entry[p], b, (size_t)ld, v[0], v[1], v[2], v[3]);
+}
+}  // namespace
+
+int Engine::set_shared_matrix(hipStream_t st, const double* blocks_host) {
+    if (!S.inplace) { error = "set_shared_matrix needs an in-place engine"; return 1; }
+    const int nnz = (int)S.src_entry.size();
+    double* dblk = nullptr; int* dmap = nullptr;
+    std::vector<double> hb(blocks_host, blocks_host + (size_t)nnz * 4);
+    if (upload(&dblk, hb, error, st) || upload(&dmap, S.src_entry, error, st)) { hipFree(dblk); hipFree(dmap); return 2; }
+    hipLaunchKernelGGL(k_fill_shared, dim3((nnz + 3) / 4, ld / 64), dim3(64, 4), 0, st, dblk, dmap, X, nnz, ld);
+    hipError_t e = hipStreamSynchronize(st);
+    hipFree(dblk); hipFree(dmap);
+    JG_HIP(e);
     return 0;
 }
 

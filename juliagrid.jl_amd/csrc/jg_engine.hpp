@@ -104,11 +104,12 @@ struct Engine {
                                    // so a small batch moves 8 bytes per load instruction instead of 512
     Rec* fact_rec = nullptr; Rec* bwd_rec = nullptr;           // wave records (jg_symbolic.hpp), replay order
     Segment* fact_seg = nullptr; Segment* bwd_seg = nullptr;
+    Rec* fwd_rec = nullptr; Segment* fwd_seg = nullptr;          // forward elimination alone (factor once, solve many)
     int* bwd_chain = nullptr;                                   // backward chain task data (jg_symbolic.hpp)
     double* X = nullptr;           // factor values [n_entries][4][ld]: U, unscaled Lh, factored diagonal blocks
     double* W = nullptr;           // [n][2][ld] pivot order: y after factor(), x after backsolve()
     int* status = nullptr;         // [ld] bit 2 set on zero / non-finite pivot
-    std::vector<DevLaunch> fact, bwd;
+    std::vector<DevLaunch> fact, bwd, fwd;
     // persistent level walker (one launch per factorisation / per backward sweep, see jg_engine.hip)
     int* sync = nullptr;           // registration / team census / barrier counters / error word, zeroed before every walk
     int walk_grid = 0;             // workgroups of a walk = CUs of the device (all must be co-resident)
@@ -125,6 +126,11 @@ struct Engine {
     // mode: 0 = persistent walker when available, 1 = one launch per dependency level.
     // In-place engines (policy bit 0) ignore A: the caller has assembled into X (entry S.src_entry[p] for its block p).
     int factor(hipStream_t st, const double* A, const double* rhs, const GroupSel& sel, int mode = 0);
+    // y = (Lh inv(D))^-1 rhs with the factor of the last factor() call (solve many right-hand sides with one factorisation).
+    int forward(hipStream_t st, const double* rhs, const GroupSel& sel);
+    // Fill the (in-place) factor storage with ONE shared matrix: blocks [nnz of the caller's pattern][4] (row-major 2x2),
+    // replicated over every scenario; fill-in entries need nothing.
+    int set_shared_matrix(hipStream_t st, const double* blocks_host);
     // x = U^-1 D y, scattered to original order into out [n][2][ld]; optional fused state update.
     int backsolve(hipStream_t st, double* out, const StateUpdate& upd, const GroupSel& sel, int mode = 0);
     size_t factor_bytes() const { return (size_t)S.n_entries * 4 * ld * sizeof(double); }

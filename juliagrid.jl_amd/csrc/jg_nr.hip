@@ -49,6 +49,7 @@ struct AsmArgs {
     const double* vm; const double* va; const double* p; const double* q;
     const int* ppos; const double* pdg; const double* pdb;
     double* A; double* F; double* part; double* pq_out; jg::GroupSel sel;   // pq_out (nullable): [n][ld][2] calculated injections P_i, Q_i
+    double* R; int fd_mode;    // fast decoupled passes (acPowerFlow.jl:687-730, 952-962): 1 = mismatches / V, R = (f_P, 0); 2 = R = (0, f_Q)
     int n; int ld; int mp; int nchunk; int lanes;
 };
 
@@ -129,6 +130,11 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(AsmArgs a) {
         if (!JAC && a.pq_out) jg::store_vec(a.pq_out, (size_t)i, b, ld, vi * s1, vi * s2);     // PiQi (acAnalysis.jl:891-896)
         double fp = vi * s1 - pinj;                        // acPowerFlow.jl:676
         double fq = vi * s2 - qinj;                        // acPowerFlow.jl:679
+        if (!JAC && a.fd_mode) {                           // fast Newton-Raphson: calc - spec / V  (acPowerFlow.jl:720-726, 952-961)
+            const double vinv = 1.0 / vi;
+            fp = s1 - pinj * vinv;
+            fq = s2 - qinj * vinv;
+        }
         double d00 = -vi * s2 - bii * (vi * vi);           // equations.jl:105-107, acPowerFlow.jl:872
         double d01 = s1 + gii * vi;                        // equations.jl:113-115
         double d10 = vi * s1 - gii * (vi * vi);            // equations.jl:130-132
@@ -138,7 +144,12 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(AsmArgs a) {
         if (JAC) {
             jg::store_blk_nt(a.A, (size_t)pd, b, ld, d00, d01, d10, d11);
         }
-        jg::store_vec(a.F, (size_t)i, b, ld, fp, fq);
+        if (!JAC && a.fd_mode) {
+            if (a.fd_mode == 1) { jg::store_vec(a.F, (size_t)i, b, ld, fp, fq); jg::store_vec(a.R, (size_t)i, b, ld, fp, 0.0); }
+            else jg::store_vec(a.R, (size_t)i, b, ld, 0.0, fq);
+        } else {
+            jg::store_vec(a.F, (size_t)i, b, ld, fp, fq);
+        }
         // NaN-propagating max: a NaN mismatch must not look converged
         const double afp = fabs(fp), afq = fabs(fq);
         maxp = (afp > maxp || afp != afp) ? afp : maxp;
@@ -378,6 +389,11 @@ struct jg_nr {
     double* d_vm0 = nullptr; double* d_va0 = nullptr;   // snapshot of the start point
     int* d_active = nullptr; int* d_iters = nullptr; int* d_status = nullptr; int* d_counter = nullptr; int* d_group = nullptr;
     int* d_lid = nullptr; int* d_dest = nullptr; int* d_cflags = nullptr; int* d_itmp = nullptr; int* d_glist = nullptr;   // scenario compaction
+    bool fast = false;                                // fast decoupled mode (jg_nr_fast_setup): constant B', B'' factorised once
+    double* d_R = nullptr;                            // rhs of the half-iterations
+    double* d_inc2[2] = {nullptr, nullptr};           // increments of the theta / V half-iterations
+    const int* fast_mask = nullptr;                   // scenarios that take the update (nullptr: all)
+    hipGraph_t graphFA = nullptr, graphFB = nullptr; hipGraphExec_t execFA = nullptr, execFB = nullptr;
     int nb = 0;                                       // post-processing (jg_nr_set_branches)
     int* d_bfrom = nullptr; int* d_bto = nullptr; signed char* d_bstatus = nullptr; double* d_bparam = nullptr; int* d_outage = nullptr;
     double* d_post = nullptr; size_t post_bytes = 0;  // staging for branch / bus quantities, grown on demand
@@ -395,9 +411,9 @@ int set_device(jg_nr* h) { NR_HIP(hipSetDevice(h->device)); return 0; }
 
 jg::GroupSel active_groups(jg_nr* h) { return jg::GroupSel{nullptr, h->d_glist, h->d_cflags + 3}; }
 
-void launch_assemble(jg_nr* h, const jg::GroupSel& sel = jg::GroupSel{}, bool jac = true, double* pq_out = nullptr) {
+void launch_assemble(jg_nr* h, const jg::GroupSel& sel = jg::GroupSel{}, bool jac = true, double* pq_out = nullptr, int fd_mode = 0) {
     AsmArgs a{h->d_rowptr, h->d_col, h->d_GB, h->d_rowtype, h->d_dst, h->d_vm, h->d_va, h->d_p, h->d_q,
-              h->d_ppos, h->d_pdg, h->d_pdb, h->eng.X, h->d_F, h->d_part, pq_out, sel, h->n, h->ld, h->mp, h->nchunk, h->batch};
+              h->d_ppos, h->d_pdg, h->d_pdb, h->eng.X, h->d_F, h->d_part, pq_out, sel, fd_mode ? h->d_R : nullptr, fd_mode, h->n, h->ld, h->mp, h->nchunk, h->batch};
     dim3 grid((unsigned)h->nchunk * jg::group_stride(h->ld / 64)), block(64, ASM_WAVES);
     if (jac) {
         switch (h->mp) {
@@ -635,6 +651,11 @@ void jg_nr_destroy(jg_nr* h) {
     if (h->graphA) hipGraphDestroy(h->graphA);
     if (h->graphB) hipGraphDestroy(h->graphB);
     h->eng.destroy();
+    hipFree(h->d_R); hipFree(h->d_inc2[0]); hipFree(h->d_inc2[1]);
+    if (h->execFA) hipGraphExecDestroy(h->execFA);
+    if (h->execFB) hipGraphExecDestroy(h->execFB);
+    if (h->graphFA) hipGraphDestroy(h->graphFA);
+    if (h->graphFB) hipGraphDestroy(h->graphFB);
     hipFree(h->d_bfrom); hipFree(h->d_bto); hipFree(h->d_bstatus); hipFree(h->d_bparam); hipFree(h->d_outage); hipFree(h->d_post);
     hipFree(h->d_rowptr); hipFree(h->d_col); hipFree(h->d_G); hipFree(h->d_B); hipFree(h->d_GB); hipFree(h->d_rowtype); hipFree(h->d_type); hipFree(h->d_flags);
     hipFree(h->d_vm); hipFree(h->d_va); hipFree(h->d_p); hipFree(h->d_q); hipFree(h->d_ppos); hipFree(h->d_pdg);
@@ -933,6 +954,128 @@ int jg_nr_get_iteration(jg_nr* h, int32_t* iters) {
     return 0;
 }
 
+// ---- fast decoupled Newton-Raphson (fastNewtonRaphsonBX / XB, acPowerFlow.jl:215-537, 687-730, 913-983) ---------------
+static int fast_half(jg_nr* h, int pass) {
+    // pass 1: rhs = (f_P / V, 0) is already in d_R (written by the mismatch pass); pass 2: Q mismatches at the new angles first
+    if (pass == 2) launch_assemble(h, jg::GroupSel{}, false, nullptr, 2);
+    if (int rc = h->eng.forward(h->stream, h->d_R, jg::GroupSel{})) return fail(rc, h->eng.error);
+    jg::StateUpdate upd{h->d_va, h->d_vm, h->d_flags, h->fast_mask, +1.0};            // theta += / V += (:946-950, 966-970)
+    if (int rc = h->eng.backsolve(h->stream, h->d_inc2[pass - 1], upd, jg::GroupSel{}, 1)) return fail(rc, h->eng.error);
+    return 0;
+}
+
+int jg_nr_fast_setup(jg_nr* h, const double* bp, const double* bq) {
+    if (!h || !bp || !bq) return fail(1, "jg_nr_fast_setup: bad argument");
+    if (int rc = set_device(h)) return rc;
+    NR_HIP(hipStreamSynchronize(h->stream));
+    // block (r, c) of the shared matrix = diag(B'[r,c], B''[r,c]); the caller pads slack / PV rows and columns with identity
+    std::vector<double> blk((size_t)h->nnz * 4, 0.0);
+    for (int p = 0; p < h->nnz; ++p) { blk[(size_t)h->tperm[p] * 4] = bp[p]; blk[(size_t)h->tperm[p] * 4 + 3] = bq[p]; }
+    // (engine block q sits at row = the column that pointer q belongs to, col = rowval[q]; tperm[p of (r, c)] = pointer of (c, r))
+    if (int rc = h->eng.set_shared_matrix(h->stream, blk.data())) return fail(rc, h->eng.error);
+    const size_t vec = (size_t)h->n * 2 * h->ld * 8;
+    if (!h->d_R) {
+        NR_HIP(hipMalloc((void**)&h->d_R, vec));
+        NR_HIP(hipMalloc((void**)&h->d_inc2[0], vec));
+        NR_HIP(hipMalloc((void**)&h->d_inc2[1], vec));
+    }
+    NR_HIP(jg::sync_fill(h->d_R, 0, vec, h->stream));
+    NR_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
+    if (int rc = h->eng.factor(h->stream, nullptr, h->d_R, jg::GroupSel{}, 1)) return fail(rc, h->eng.error);   // ONCE (lu(jacobian), :? utility.jl:470-476)
+    NR_HIP(hipStreamSynchronize(h->stream));
+    std::vector<int> st(h->ld);
+    NR_HIP(jg::sync_copy(st.data(), h->eng.status, (size_t)h->ld * 4, hipMemcpyDeviceToHost, h->stream));
+    for (int b = 0; b < h->batch; ++b) if (st[b] & 4) return fail(3, "jg_nr_fast_setup: zero or non-finite pivot (singular B matrix)");
+    h->fast = true;
+    h->jac_valid = false;
+    return 0;
+}
+
+int jg_nr_fast_mismatch(jg_nr* h, double* max_p, double* max_q) {
+    if (!h || !h->fast) return fail(1, "jg_nr_fast_mismatch: call jg_nr_fast_setup first");
+    if (int rc = set_device(h)) return rc;
+    launch_assemble(h, jg::GroupSel{}, false, nullptr, 1);
+    launch_check(h, 0);
+    NR_HIP(hipGetLastError());
+    NR_HIP(hipStreamSynchronize(h->stream));
+    if (max_p) NR_HIP(jg::sync_copy(max_p, h->d_normp, (size_t)h->batch * 8, hipMemcpyDeviceToHost, h->stream));
+    if (max_q) NR_HIP(jg::sync_copy(max_q, h->d_normq, (size_t)h->batch * 8, hipMemcpyDeviceToHost, h->stream));
+    return 0;
+}
+
+int jg_nr_fast_solve(jg_nr* h) {
+    if (!h || !h->fast) return fail(1, "jg_nr_fast_solve: call jg_nr_fast_setup first");
+    if (int rc = set_device(h)) return rc;
+    launch_assemble(h, jg::GroupSel{}, false, nullptr, 1);                      // solve! uses the mismatches of the current state
+    h->fast_mask = nullptr;
+    if (int rc = fast_half(h, 1)) return rc;
+    if (int rc = fast_half(h, 2)) return rc;
+    hipLaunchKernelGGL(k_add_iter, dim3((h->ld + 255) / 256), dim3(256), 0, h->stream, h->d_iters, h->ld);
+    NR_HIP(hipGetLastError());
+    NR_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int jg_nr_fast_get_increment(jg_nr* h, double* incr) {
+    if (!h || !h->fast || !incr) return fail(1, "jg_nr_fast_get_increment: bad argument");
+    if (int rc = set_device(h)) return rc;
+    NR_HIP(hipStreamSynchronize(h->stream));
+    std::vector<double> t0((size_t)h->n * 2 * h->batch), t1((size_t)h->n * 2 * h->batch);
+    if (int rc = get_bus_array(h, h->d_inc2[0], t0.data(), 2)) return rc;
+    if (int rc = get_bus_array(h, h->d_inc2[1], t1.data(), 2)) return rc;
+    for (int b = 0; b < h->batch; ++b) {                          // [active.increment (pvpq order) | reactive.increment (pq order)]
+        double* d = incr + (size_t)b * h->dimJ;
+        for (int i = 0; i < h->n; ++i) {
+            if (h->pvpq[i]) d[h->pvpq[i] - 1] = t0[((size_t)b * h->n + i) * 2];
+            if (h->pq[i]) d[h->pq[i] - 1] = t1[((size_t)b * h->n + i) * 2 + 1];
+        }
+    }
+    return 0;
+}
+
+int jg_nr_fast_run(jg_nr* h, int64_t max_iter, double tol, int32_t* iters, int32_t* status) {
+    if (!h || !h->fast || max_iter < 0 || !(tol > 0.0)) return fail(1, "jg_nr_fast_run: bad argument (or jg_nr_fast_setup missing)");
+    if (int rc = set_device(h)) return rc;
+    if (!h->execFA) {
+        std::lock_guard<std::mutex> lk(jg::capture_mutex());
+        NR_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        hipMemsetAsync(h->d_counter, 0, sizeof(int), h->stream);
+        launch_assemble(h, jg::GroupSel{}, false, nullptr, 1);                  // mismatch! (:687-730)
+        launch_check(h, 1);                                                     // powerFlow! accounting (:1406-1420)
+        hipMemcpyAsync(h->h_counter, h->d_counter, sizeof(int), hipMemcpyDeviceToHost, h->stream);
+        NR_HIP(hipStreamEndCapture(h->stream, &h->graphFA));
+        NR_HIP(hipGraphInstantiate(&h->execFA, h->graphFA, nullptr, nullptr, 0));
+        NR_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        h->fast_mask = h->d_active;                                             // solve! (:913-983) on the scenarios still iterating
+        int rc = fast_half(h, 1);
+        if (!rc) rc = fast_half(h, 2);
+        hipError_t e = hipStreamEndCapture(h->stream, &h->graphFB);
+        if (rc) return rc;
+        NR_HIP(e);
+        NR_HIP(hipGraphInstantiate(&h->execFB, h->graphFB, nullptr, nullptr, 0));
+    }
+    const double params[2] = {tol, (double)max_iter};
+    NR_HIP(hipMemcpyAsync(h->d_params, params, sizeof(params), hipMemcpyHostToDevice, h->stream));
+    NR_HIP(hipMemsetAsync(h->d_iters, 0, (size_t)h->ld * 4, h->stream));
+    NR_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
+    {
+        std::vector<int> act(h->ld, 0);
+        for (int b = 0; b < h->batch; ++b) act[b] = 1;
+        NR_HIP(hipMemcpyAsync(h->d_active, act.data(), (size_t)h->ld * 4, hipMemcpyHostToDevice, h->stream));
+        NR_HIP(hipStreamSynchronize(h->stream));
+    }
+    for (int64_t it = 0; it <= max_iter; ++it) {
+        NR_HIP(hipGraphLaunch(h->execFA, h->stream));
+        NR_HIP(hipStreamSynchronize(h->stream));
+        if (*h->h_counter == 0) break;
+        NR_HIP(hipGraphLaunch(h->execFB, h->stream));
+    }
+    NR_HIP(hipStreamSynchronize(h->stream));
+    if (iters) NR_HIP(jg::sync_copy(iters, h->d_iters, (size_t)h->batch * 4, hipMemcpyDeviceToHost, h->stream));
+    if (status) NR_HIP(jg::sync_copy(status, h->d_status, (size_t)h->batch * 4, hipMemcpyDeviceToHost, h->stream));
+    return 0;
+}
+
 int jg_nr_set_branches(jg_nr* h, int64_t nb, const int64_t* from, const int64_t* to, const int8_t* status, const double* param) {
     if (!h || nb < 1 || !from || !to || !status || !param) return fail(1, "jg_nr_set_branches: bad argument");
     if (int rc = set_device(h)) return rc;
@@ -942,6 +1085,11 @@ int jg_nr_set_branches(jg_nr* h, int64_t nb, const int64_t* from, const int64_t*
         f[k] = (int)(from[k] - 1); t[k] = (int)(to[k] - 1);
     }
     NR_HIP(hipStreamSynchronize(h->stream));
+    hipFree(h->d_R); hipFree(h->d_inc2[0]); hipFree(h->d_inc2[1]);
+    if (h->execFA) hipGraphExecDestroy(h->execFA);
+    if (h->execFB) hipGraphExecDestroy(h->execFB);
+    if (h->graphFA) hipGraphDestroy(h->graphFA);
+    if (h->graphFB) hipGraphDestroy(h->graphFB);
     hipFree(h->d_bfrom); hipFree(h->d_bto); hipFree(h->d_bstatus); hipFree(h->d_bparam);
     h->d_bfrom = h->d_bto = nullptr; h->d_bstatus = nullptr; h->d_bparam = nullptr;
     std::string err;

@@ -28,7 +28,7 @@ void jg_plan_destroy(jg_plan* p) { delete p; }
 //        10 l_ptr, 11 l_ent, 12 l_col, 13 u_ptr, 14 u_ent, 15 u_col,
 //        16 t_d, 17 y_level
 //        60 fact segments (x8), 61 fact wave records (x16), 62 bwd segments, 63 bwd records, 64 src_entry (device replay tables)
-//        18 bwd_level (row-wise), 19 chain_level (level of the backward chain / row a pivot belongs to), 65 backward chain task data
+//        18 bwd_level (row-wise), 19 chain_level (level of the backward chain / row a pivot belongs to), 65 backward chain task data, 66 / 67 forward-only segments / records
 // out == NULL returns the length.
 int64_t jg_plan_export(jg_plan* p, int which, int32_t* out, int64_t cap) {
     if (!p) return -1;
@@ -49,6 +49,8 @@ int64_t jg_plan_export(jg_plan* p, int which, int32_t* out, int64_t cap) {
         case 63: tmp.assign((const int*)S.bwd_rec.data(), (const int*)S.bwd_rec.data() + S.bwd_rec.size() * 16); v = &tmp; break;
         case 64: v = &S.src_entry; break;
         case 65: v = &S.bwd_chain; break;
+        case 66: tmp.assign((const int*)S.fwd_seg.data(), (const int*)S.fwd_seg.data() + S.fwd_seg.size() * 8); v = &tmp; break;
+        case 67: tmp.assign((const int*)S.fwd_rec.data(), (const int*)S.fwd_rec.data() + S.fwd_rec.size() * 16); v = &tmp; break;
         case 19: v = &S.chain_level; break;
         default: return -1;
     }

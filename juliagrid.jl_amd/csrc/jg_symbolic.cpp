@@ -127,7 +127,7 @@ void build_tables(BlockSymbolic& S) {
         if (S.inplace && work[e] == 0 && S.e_row[e] != S.e_col[e] && S.e_src[e] >= 0) level[e] = 0;   // already in place
     }
     for (int r = 0; r < n; ++r) { level[nE + r] = S.y_level[r]; work[nE + r] = S.l_ptr[r + 1] - S.l_ptr[r]; }
-    build_replay(level, work, FACT_T, S.fact_seg, S.fact_rec, S.n_fact_levels, [&](int it, int sub, int wpi, int rpw, Rec* r) {
+    auto fill_fact = [&](int it, int sub, int wpi, int rpw, Rec* r) {
         int kind, id, src, t0, t1;
         if (it < nE) {
             kind = S.e_row[it] == S.e_col[it] ? 2 : (S.e_row[it] > S.e_col[it] ? 1 : 0);
@@ -144,7 +144,19 @@ void build_tables(BlockSymbolic& S) {
             else { x.w[s] = S.l_ent[t]; x.w[s + 1] = S.diag[S.l_col[t]]; x.w[s + 2] = S.l_col[t]; }
             x.w[3]++;
         }
-    });
+    };
+    build_replay(level, work, FACT_T, S.fact_seg, S.fact_rec, S.n_fact_levels, fill_fact);
+    // forward elimination ALONE (factor once, solve many: fast decoupled power flow): the rhs rows only, levelled on
+    // each other (every factor entry is final)
+    {
+        std::vector<int> flevel(nE + n, 0), fwork(nE + n, 0);
+        for (int r = 0; r < n; ++r) {
+            int l = 1;
+            for (int p = S.l_ptr[r]; p < S.l_ptr[r + 1]; ++p) l = std::max(l, flevel[nE + S.l_col[p]] + 1);
+            flevel[nE + r] = l; fwork[nE + r] = S.l_ptr[r + 1] - S.l_ptr[r];
+        }
+        build_replay(flevel, fwork, FACT_T, S.fwd_seg, S.fwd_rec, S.n_fwd_levels, fill_fact);
+    }
     // backward sweep: chains of a supernode go to ONE workgroup each (CHAIN_MAX_ROWS), the other rows stay wave records
     std::vector<int> uw(n);
     for (int r = 0; r < n; ++r) uw[r] = S.u_ptr[r + 1] - S.u_ptr[r];

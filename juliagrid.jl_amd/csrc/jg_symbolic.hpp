@@ -70,11 +70,11 @@ struct BlockSymbolic {
     // are not scheduled; FactRec.src then names the entry itself.
     int inplace = 0;
     std::vector<int> src_entry;         // [nnz of the caller's pattern] -> entry id
-    std::vector<Segment> fact_seg, bwd_seg;
-    std::vector<Rec> fact_rec, bwd_rec;
+    std::vector<Segment> fact_seg, bwd_seg, fwd_seg;    // fwd: the forward elimination alone (rhs rows of the fact tables)
+    std::vector<Rec> fact_rec, bwd_rec, fwd_rec;
     std::vector<int> bwd_chain;         // chain task data (see CHAIN_MAX_ROWS)
     std::vector<int> chain_level;       // [n] backward level of the chain (or single row) a pivot belongs to
-    int n_fact_levels = 0, n_bwd_levels = 0;
+    int n_fact_levels = 0, n_bwd_levels = 0, n_fwd_levels = 0;
 };
 
 // pattern: CSR (rowptr[n+1], col[nnz]) 0-based, must contain the diagonal and be structurally

@@ -119,7 +119,8 @@ class AcPowerFlow:
     @property
     def increment(self):
         m = np.zeros((self.batch, self.dims["dimJ"]))
-        _lib.check(_lib.lib().jg_nr_get_increment(self._h, m))
+        fn = _lib.lib().jg_nr_fast_get_increment if getattr(self.method, "fast", False) else _lib.lib().jg_nr_get_increment
+        _lib.check(fn(self._h, m))
         return self._shape(m)
 
     @property
@@ -189,11 +190,107 @@ def newtonRaphson(system: PowerSystem, batch: int = 1, device: int = 0, max_patc
     return an
 
 
+def _fast_model(system: PowerSystem, bx: bool):
+    """fastNewtonJacobian + fastNewtonJacobian! + jacobianCoefficient (acPowerFlow.jl:338-474) and the shunt terms
+    (:328-334): the two constant matrices in the reference's CSC layout (stored zeros kept) and, per stored Ybus entry,
+    the pair (B'[r,c], B''[r,c]) the device factorises as one block matrix (identity padding where a bus is not in a
+    reduced matrix)."""
+    bus, br, ac = system.bus, system.branch, system.model.ac
+    n, typ, slack = bus.number, bus.layout.type, bus.layout.slack
+    Y = ac.nodalMatrix
+    pq = np.zeros(n, dtype=np.int64)
+    pvpq = np.zeros(n, dtype=np.int64)
+    pq[typ == 1] = np.arange(1, int(np.sum(typ == 1)) + 1)
+    pvpq[typ != 3] = np.arange(1, n)
+    col_of = np.repeat(np.arange(n), np.diff(Y.colptr))
+    row_of = Y.rowval - 1
+    inP = (typ[row_of] != 3) & (col_of != slack - 1)
+    inQ = (typ[row_of] == 1) & (typ[col_of] == 1)
+    posP = np.cumsum(inP) - 1                                   # Ybus pointer -> pointer in the P / Q matrix (column major, same order)
+    posQ = np.cumsum(inQ) - 1
+    valP, valQ = np.zeros(int(inP.sum())), np.zeros(int(inQ.sum()))
+    par = br.parameter
+
+    def add(mat_in, pos, val, r, c, v):                         # addStored!: the entry exists whenever both buses are in the matrix
+        p = Y.position(r + 1, c + 1)
+        if mat_in[p]:
+            val[pos[p]] += v
+
+    for k in np.flatnonzero(br.layout.status == 1):
+        i, j = int(br.layout.from_[k]) - 1, int(br.layout.to[k]) - 1
+        bsi, tinv = 0.5 * par.susceptance[k], 1.0 / par.turnsRatio[k]
+        sn, cs = np.sin(par.shiftAngle[k]), np.cos(par.shiftAngle[k])
+        y = ac.admittance[k]
+        if bx:
+            bmk, A, B = -1.0 / par.reactance[k], y.real, y.imag
+        else:
+            bmk, A, B = y.imag, 0.0, -1.0 / par.reactance[k]
+        den = cs * cs + sn * sn
+        if i != slack - 1 and j != slack - 1:
+            add(inP, posP, valP, i, j, (-A * sn - B * cs) / den)
+            add(inP, posP, valP, j, i, (A * sn - B * cs) / den)
+        if i != slack - 1:
+            add(inP, posP, valP, i, i, B / den)
+        if j != slack - 1:
+            add(inP, posP, valP, j, j, B)
+        qA, qB, qC = -bmk * tinv, (bmk + bsi) * tinv ** 2, bmk + bsi
+        if typ[i] == 1 and typ[j] == 1:
+            add(inQ, posQ, valQ, i, j, qA)
+            add(inQ, posQ, valQ, j, i, qA)
+        if typ[i] == 1:
+            add(inQ, posQ, valQ, i, i, qB)
+        if typ[j] == 1:
+            add(inQ, posQ, valQ, j, j, qC)
+    for i in np.flatnonzero((typ == 1) & (bus.shunt.susceptance != 0)):
+        add(inQ, posQ, valQ, int(i), int(i), bus.shunt.susceptance[i])
+    cols = np.flatnonzero(np.arange(n) != slack - 1)
+    colptrP = np.concatenate([[1], 1 + np.cumsum([inP[Y.colptr[c] - 1:Y.colptr[c + 1] - 1].sum() for c in cols])]).astype(np.int64)
+    colsQ = np.flatnonzero(typ == 1)
+    colptrQ = np.concatenate([[1], 1 + np.cumsum([inQ[Y.colptr[c] - 1:Y.colptr[c + 1] - 1].sum() for c in colsQ])]).astype(np.int64)
+    P = CscMatrix(n - 1, colptrP, pvpq[row_of[inP]], valP)
+    Q = CscMatrix(colsQ.size, colptrQ, pq[row_of[inQ]], valQ)
+    diag = row_of == col_of
+    bp = np.where(inP, 0.0, diag.astype(float))
+    bq = np.where(inQ, 0.0, diag.astype(float))
+    bp[inP] = valP
+    bq[inQ] = valQ
+    return P, Q, pq, pvpq, bp, bq
+
+
+def _fast_newton_raphson(system: PowerSystem, bx: bool, batch: int, device: int) -> AcPowerFlow:
+    if system.bus.layout.slack == 0:
+        raise RuntimeError("The slack bus is missing.")
+    if system.model.ac.nodalMatrix is None:
+        acModel_(system)
+    vm, va = initializeACPowerFlow(system)
+    an = AcPowerFlow(system, batch, device, 0)
+    P, Q, pq, pvpq, bp, bq = _fast_model(system, bx)
+    _lib.check(_lib.lib().jg_nr_fast_setup(an._h, np.ascontiguousarray(bp), np.ascontiguousarray(bq)))
+    an.method.fast, an.method.bx = True, bool(bx)
+    an.method.active = NS(jacobian=P)
+    an.method.reactive = NS(jacobian=Q)
+    an.method.pq, an.method.pvpq = pq, pvpq                      # fast numbering: pq = 1..npq (acPowerFlow.jl:343-356)
+    setInjection_(an)
+    _push_voltage(an, vm, va)
+    return an
+
+
+def fastNewtonRaphsonBX(system: PowerSystem, batch: int = 1, device: int = 0) -> AcPowerFlow:
+    """fastNewtonRaphsonBX(system) (acPowerFlow.jl:215-217, 259-336): both constant matrices factorised once on the device."""
+    return _fast_newton_raphson(system, True, batch, device)
+
+
+def fastNewtonRaphsonXB(system: PowerSystem, batch: int = 1, device: int = 0) -> AcPowerFlow:
+    """fastNewtonRaphsonXB(system) (acPowerFlow.jl:255-257)."""
+    return _fast_newton_raphson(system, False, batch, device)
+
+
 def mismatch_(an: AcPowerFlow):
     """mismatch!(analysis) -> (max|f_P|, max|f_Q|); arrays of length batch when batch > 1."""
     p = np.zeros(an.batch)
     q = np.zeros(an.batch)
-    _lib.check(_lib.lib().jg_nr_mismatch(an._h, p, q))
+    fn = _lib.lib().jg_nr_fast_mismatch if getattr(an.method, "fast", False) else _lib.lib().jg_nr_mismatch
+    _lib.check(fn(an._h, p, q))
     return (float(p[0]), float(q[0])) if an.batch == 1 else (p, q)
 
 
@@ -206,7 +303,8 @@ def _check_signature(an: AcPowerFlow):
 def solve_(an: AcPowerFlow):
     """solve!(analysis): Jacobian fill + refactorization + solve + state update on the device."""
     _check_signature(an)
-    _lib.check(_lib.lib().jg_nr_solve(an._h))
+    fn = _lib.lib().jg_nr_fast_solve if getattr(an.method, "fast", False) else _lib.lib().jg_nr_solve
+    _lib.check(fn(an._h))
     an.method.iteration += 1
     an._pull_voltage()
 
@@ -218,7 +316,8 @@ def powerFlow_(an: AcPowerFlow, iteration: int = 20, tolerance: float = 1e-8, fe
     _check_signature(an)
     it = np.zeros(an.batch, dtype=np.int32)
     st = np.zeros(an.batch, dtype=np.int32)
-    _lib.check(_lib.lib().jg_nr_run(an._h, int(iteration), float(tolerance), it, st))
+    fn = _lib.lib().jg_nr_fast_run if getattr(an.method, "fast", False) else _lib.lib().jg_nr_run
+    _lib.check(fn(an._h, int(iteration), float(tolerance), it, st))
     an.method.iteration = int(it[0]) if an.batch == 1 else it
     an.status = int(st[0]) if an.batch == 1 else st
     if fetch:
