@@ -130,9 +130,10 @@ __global__ __launch_bounds__(256) void k_gn_rows(RowArgs a) {
     for (int r = r0 + wave; r < r1; r += blockDim.y) {
         const RowDesc* rd = a.rows + r;
         const int ty = uniform(rd->type), idx = uniform(rd->idx), s0 = uniform(rd->slot0), ns = uniform(rd->nslots);
-        double* hs = a.Hs + (size_t)s0 * 2 * ld + b;
+        // a slot = the 1x2 block (d/dtheta, d/dV) of one (row, bus) pair, interleaved per scenario: one 16-byte store
+        auto put = [&](int s, double dth, double dvm) { jg::store_vec(a.Hs, (size_t)(s0 + s), b, ld, dth, dvm); };
         if (ty == 0) {                                 // masked: row kept, H = 0, residual 0 (T7)
-            for (int s = 0; s < ns; ++s) { hs[(size_t)s * 2 * ld] = 0.0; hs[((size_t)s * 2 + 1) * ld] = 0.0; }
+            for (int s = 0; s < ns; ++s) put(s, 0.0, 0.0);
             a.res[(size_t)r * ld + b] = 0.0;
             continue;
         }
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256) void k_gn_rows(RowArgs a) {
             else if (ty == 16) { double s, c; sincos(th, &s, &c); h = V * c; dt = -V * s; dv = c; }
             else if (ty == 17) { double s, c; sincos(th, &s, &c); h = V * s; dt = V * c; dv = s; }
             else { h = V; dt = 0.0; dv = 1.0; }
-            hs[0] = dt; hs[ld] = dv;
+            put(0, dt, dv);
             a.res[(size_t)r * ld + b] = z - h;
         } else if (ty == 6 || ty == 9) {               // injections: slots follow the Ybus row of the bus
             const int i = idx;
@@ -162,14 +163,14 @@ __global__ __launch_bounds__(256) void k_gn_rows(RowArgs a) {
                 const double ac = g * cs + bb * sn, ad = g * sn - bb * cs;
                 s1 += Vj * ac; s2 += Vj * ad;
                 if (p != pd) {
-                    if (ty == 6) { hs[(size_t)s * 2 * ld] = Vi * Vj * ad; hs[((size_t)s * 2 + 1) * ld] = Vi * ac; }
-                    else { hs[(size_t)s * 2 * ld] = -(Vi * Vj) * ac; hs[((size_t)s * 2 + 1) * ld] = Vi * ad; }
+                    if (ty == 6) put(s, Vi * Vj * ad, Vi * ac);
+                    else put(s, -(Vi * Vj) * ac, Vi * ad);
                 }
             }
             const double gii = a.G[pd], bii = a.Bv[pd];
             const int sd = pd - p0;
-            if (ty == 6) { hs[(size_t)sd * 2 * ld] = -Vi * s2 - bii * (Vi * Vi); hs[((size_t)sd * 2 + 1) * ld] = s1 + gii * Vi; a.res[(size_t)r * ld + b] = z - Vi * s1; }
-            else { hs[(size_t)sd * 2 * ld] = Vi * s1 - gii * (Vi * Vi); hs[((size_t)sd * 2 + 1) * ld] = s2 - bii * Vi; a.res[(size_t)r * ld + b] = z - Vi * s2; }
+            if (ty == 6) { put(sd, -Vi * s2 - bii * (Vi * Vi), s1 + gii * Vi); a.res[(size_t)r * ld + b] = z - Vi * s1; }
+            else { put(sd, Vi * s1 - gii * (Vi * Vi), s2 - bii * Vi); a.res[(size_t)r * ld + b] = z - Vi * s2; }
         } else {                                       // branch rows: slots = [from, to]
             BranchP p = a.br[idx];
             const int i = uniform(p.from), j = uniform(p.to);
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256) void k_gn_rows(RowArgs a) {
             const double Vj = a.vm[(size_t)j * ld + b], thj = a.va[(size_t)j * ld + b];
             double h, ti, vi, tj, vj;
             branch_row(ty, p, Vi, Vj, thi, thj, h, ti, vi, tj, vj);
-            hs[0] = ti; hs[ld] = vi; hs[2 * ld] = tj; hs[3 * ld] = vj;
+            put(0, ti, vi); put(1, tj, vj);
             a.res[(size_t)r * ld + b] = z - h;
         }
     }
@@ -214,9 +215,8 @@ __global__ __launch_bounds__(256) void k_gn_gain(GainArgs a) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     w[u] = a.w[(size_t)cw[c + u] * ld + b];
-                    const double* pa = a.Hs + (size_t)ca[c + u] * 2 * ld + b;
-                    const double* pb = a.Hs + (size_t)cb[c + u] * 2 * ld + b;
-                    a0[u] = pa[0]; a1[u] = pa[ld]; b0[u] = pb[0]; b1[u] = pb[ld];
+                    const double2 pa = jg::load_vec(a.Hs, (size_t)ca[c + u], b, ld), pb = jg::load_vec(a.Hs, (size_t)cb[c + u], b, ld);
+                    a0[u] = pa.x; a1[u] = pa.y; b0[u] = pb.x; b1[u] = pb.y;
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -226,9 +226,8 @@ __global__ __launch_bounds__(256) void k_gn_gain(GainArgs a) {
             }
             for (; c < c1; ++c) {
                 const double w = a.w[(size_t)cw[c] * ld + b];
-                const double* pa = a.Hs + (size_t)ca[c] * 2 * ld + b;
-                const double* pb = a.Hs + (size_t)cb[c] * 2 * ld + b;
-                const double at = w * pa[0], av = w * pa[ld], bt = pb[0], bv = pb[ld];
+                const double2 pa = jg::load_vec(a.Hs, (size_t)ca[c], b, ld), pb = jg::load_vec(a.Hs, (size_t)cb[c], b, ld);
+                const double at = w * pa.x, av = w * pa.y, bt = pb.x, bv = pb.y;
                 g00 += at * bt; g01 += at * bv; g10 += av * bt; g11 += av * bv;
             }
             const int i = uniform(a.blk_row[id]), j = uniform(a.blk_col[id]);
@@ -240,9 +239,9 @@ __global__ __launch_bounds__(256) void k_gn_gain(GainArgs a) {
             double r0 = 0.0, r1 = 0.0;
             for (int c = c0; c < c1; ++c) {
                 const double w = a.w[(size_t)cw[c] * ld + b];
-                const double* pa = a.Hs + (size_t)ca[c] * 2 * ld + b;
+                const double2 pa = jg::load_vec(a.Hs, (size_t)ca[c], b, ld);
                 const double rr = w * a.res[(size_t)cb[c] * ld + b];
-                r0 += pa[0] * rr; r1 += pa[ld] * rr;
+                r0 += pa.x * rr; r1 += pa.y * rr;
             }
             if (id == a.slack) r0 = 0.0;
             jg::store_vec(a.rhs, (size_t)id, b, ld, r0, r1);
@@ -718,7 +717,7 @@ int jg_gn_get_jacobian(jg_gn* h, double* nzval) {
     std::vector<double> t((size_t)h->nslots * 2 * h->ld);
     GN_HIP(jg::sync_copy(t.data(), h->d_Hs, t.size() * 8, hipMemcpyDeviceToHost, h->stream));
     for (int b = 0; b < h->batch; ++b)
-        for (int64_t k = 0; k < h->nnzH; ++k) nzval[(size_t)b * h->nnzH + k] = t[(size_t)h->hmap[k] * h->ld + b];
+        for (int64_t k = 0; k < h->nnzH; ++k) nzval[(size_t)b * h->nnzH + k] = t[((size_t)(h->hmap[k] >> 1) * h->ld + b) * 2 + (h->hmap[k] & 1)];     // hmap = slot * 2 + component
     return 0;
 }
 

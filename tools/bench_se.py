@@ -69,9 +69,10 @@ def cpu_baseline(jg, s, case, pf, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--case", default="case9241synth")
+    ap.add_argument("--inflight", type=int, default=3, help="batches in flight (own handle, stream and host thread each)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
     import juliagrid.jl_amd as jg
@@ -85,23 +86,38 @@ def main():
     jg.addWattmeter_(mon, pf, variance=1e-4)
     jg.addVarmeter_(mon, pf, variance=1e-4)
     jg.addPmu_(mon, pf, buses=range(1, s.bus.number + 1, 10), statusTo=-1, minMagnitude=1e-6)
-    an = jg.gaussNewton(mon, batch=args.batch)
-    jg.setNoise_(an, np.random.Generator(np.random.PCG64(4)), scale=1.0)
+    import threading
     n = s.bus.number
-    an.setVoltage(np.ones(n), np.zeros(n))
-    an.snapshot_voltage()                             # the flat start stays resident in HBM
+    handles = []
+    for k in range(max(1, args.inflight)):            # like ContingencyPipeline: the batches of different handles overlap on the GPU
+        h = jg.gaussNewton(mon, batch=args.batch)
+        jg.setNoise_(h, np.random.Generator(np.random.PCG64(4 + k)), scale=1.0)
+        h.setVoltage(np.ones(n), np.zeros(n))
+        h.snapshot_voltage()                          # the flat start stays resident in HBM
+        handles.append(h)
+    an = handles[0]
 
-    def step():
-        an.restore_voltage()
-        jg.stateEstimation_(an, iteration=40, tolerance=1e-8, fetch=False)
-        return int(np.sum(an.method.iteration))
+    def step(h):
+        h.restore_voltage()
+        jg.stateEstimation_(h, iteration=40, tolerance=1e-8, fetch=False)
+        return int(np.sum(h.method.iteration))
 
-    for _ in range(args.warmup):
-        step()
+    def run(steps):
+        out = [0] * len(handles)
+
+        def work(k):
+            for _ in range(k, steps, len(handles)):
+                out[k] += step(handles[k])
+        ths = [threading.Thread(target=work, args=(k,)) for k in range(len(handles))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        return sum(out)
+
+    run(args.warmup * len(handles))
     t0 = time.perf_counter()
-    iters = 0
-    for _ in range(args.steps):
-        iters += step()
+    iters = run(args.steps)
     dt = time.perf_counter() - t0
     d = an.dims
     B = args.batch
@@ -116,7 +132,8 @@ def main():
             "unit": "GN iterations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "ms_per_solve_batched": 1e3 * dt / (B * args.steps), "iterations_per_scenario": iters / (B * args.steps),
             "converged_fraction": float(np.mean(an.status == 0)), "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.case} Gauss-Newton WLS SE, {B} noisy realisations, flat start, tol 1e-8, max 40", "rows": d["m"],
+            "config": {"workload": f"{args.case} Gauss-Newton WLS SE, {B} noisy realisations per batch, {len(handles)} batches in flight, "
+                                   "flat start, tol 1e-8, max 40", "rows": d["m"],
                        "nnzH": nnzH, "gain_blocks": d["gain_blocks"], "lu_blocks": d["lu_blocks"], "lu_terms": d["lu_terms"],
                        "factor_launches": d["factor_launches"], "backward_launches": d["backward_launches"]},
             "kernels": kern}
