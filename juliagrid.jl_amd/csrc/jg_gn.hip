@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void k_gn_rows(RowArgs a) {
 struct GainItem { int kind; int id; int c0; int c1; };   // kind 0: gain block id (CSR order), 1: rhs row (bus)
 struct GainArgs {
     const GainItem* items; const int* cw; const int* ca; const int* cb;   // contribution: weight idx, slot, slot | row
-    const int* blk_row; const int* blk_col;
+    const int* blk_row; const int* blk_col; const int* dst;   // dst: gain block -> entry of the factor storage (assembled in place)
     const double* Hs; const double* res; const double* w;
     double* Gv; double* rhs;
     int n_items; int slack; int ld;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void k_gn_gain(GainArgs a) {
             if (i == a.slack) { g00 = 0.0; g01 = 0.0; }          // removeColumn(H, slack) on both sides (:885)
             if (j == a.slack) { g00 = 0.0; g10 = 0.0; }
             if (i == a.slack && j == a.slack) g00 = 1.0;         // gain[slack, slack] = 1 (:889)
-            jg::store_blk(a.Gv, (size_t)id, b, ld, g00, g01, g10, g11);
+            jg::store_blk(a.Gv, (size_t)uniform(a.dst[id]), b, ld, g00, g01, g10, g11);
         } else {
             double r0 = 0.0, r1 = 0.0;
             for (int c = c0; c < c1; ++c) {
@@ -330,8 +330,8 @@ struct jg_gn {
     RowDesc* d_rows = nullptr; int* d_slot_bus = nullptr; BranchP* d_br = nullptr;
     int* d_rowptr = nullptr; double* d_G = nullptr; double* d_B = nullptr; int* d_ydiag = nullptr;
     double* d_vm = nullptr; double* d_va = nullptr; double* d_mean = nullptr; double* d_w = nullptr;
-    double* d_Hs = nullptr; double* d_res = nullptr; double* d_Gv = nullptr; double* d_rhs = nullptr; double* d_inc = nullptr;
-    GainItem* d_items = nullptr; int* d_cw = nullptr; int* d_ca = nullptr; int* d_cb = nullptr; int* d_blk_row = nullptr; int* d_blk_col = nullptr;
+    double* d_Hs = nullptr; double* d_res = nullptr; double* d_rhs = nullptr; double* d_inc = nullptr;
+    GainItem* d_items = nullptr; int* d_cw = nullptr; int* d_ca = nullptr; int* d_cb = nullptr; int* d_blk_row = nullptr; int* d_blk_col = nullptr; int* d_dst = nullptr;
     double* d_part = nullptr; double* d_maxinc = nullptr; double* d_params = nullptr;
     double* d_vm0 = nullptr; double* d_va0 = nullptr;   // snapshot of the start point (jg_gn_snapshot_voltage)
     int* d_active = nullptr; int* d_iters = nullptr; int* d_status = nullptr; int* d_counter = nullptr; int* d_group = nullptr;
@@ -352,7 +352,7 @@ void launch_rows(jg_gn* h) {
 }
 
 void launch_gain(jg_gn* h) {
-    GainArgs a{h->d_items, h->d_cw, h->d_ca, h->d_cb, h->d_blk_row, h->d_blk_col, h->d_Hs, h->d_res, h->d_w, h->d_Gv, h->d_rhs,
+    GainArgs a{h->d_items, h->d_cw, h->d_ca, h->d_cb, h->d_blk_row, h->d_blk_col, h->d_dst, h->d_Hs, h->d_res, h->d_w, h->eng.X, h->d_rhs,
                h->n_items, h->slack0, h->ld};
     hipLaunchKernelGGL(k_gn_gain, dim3((h->n_items + 15) / 16, h->ld / 64), dim3(64, 4), 0, h->stream, a);
 }
@@ -360,7 +360,7 @@ void launch_gain(jg_gn* h) {
 int launch_increment(jg_gn* h, const int* group) {
     launch_rows(h);
     launch_gain(h);
-    if (int rc = h->eng.factor(h->stream, h->d_Gv, h->d_rhs, jg::GroupSel{group})) return failg(rc, h->eng.error);
+    if (int rc = h->eng.factor(h->stream, nullptr, h->d_rhs, jg::GroupSel{group})) return failg(rc, h->eng.error);
     jg::StateUpdate none{};
     if (int rc = h->eng.backsolve(h->stream, h->d_inc, none, jg::GroupSel{group})) return failg(rc, h->eng.error);
     hipLaunchKernelGGL(k_gn_norm, dim3(h->nchunk, h->ld / 64), dim3(64, 4), 0, h->stream, h->d_inc, h->d_part, h->n, h->slack0, h->ld);
@@ -551,7 +551,7 @@ int jg_gn_create(jg_gn** out, int64_t n, const int64_t* colptr, const int64_t* r
     const size_t nw = (size_t)m + (size_t)std::max<int64_t>(n_corr, 0);
     bool ok = dmalloc((void**)&h->d_vm, n * ld * 8) && dmalloc((void**)&h->d_va, n * ld * 8) && dmalloc((void**)&h->d_mean, (size_t)m * ld * 8) &&
               dmalloc((void**)&h->d_w, nw * ld * 8) && dmalloc((void**)&h->d_Hs, (size_t)h->nslots * 2 * ld * 8) &&
-              dmalloc((void**)&h->d_res, (size_t)m * ld * 8) && dmalloc((void**)&h->d_Gv, blk_row.size() * 4 * ld * 8) &&
+              dmalloc((void**)&h->d_res, (size_t)m * ld * 8) &&
               dmalloc((void**)&h->d_rhs, n * 2 * ld * 8) && dmalloc((void**)&h->d_inc, n * 2 * ld * 8) &&
               dmalloc((void**)&h->d_part, (size_t)h->nchunk * ld * 8) && dmalloc((void**)&h->d_maxinc, ld * 8) &&
               dmalloc((void**)&h->d_params, 16) && dmalloc((void**)&h->d_active, ld * 4) && dmalloc((void**)&h->d_iters, ld * 4) &&
@@ -559,8 +559,9 @@ int jg_gn_create(jg_gn** out, int64_t n, const int64_t* colptr, const int64_t* r
     if (!ok || hipHostMalloc((void**)&h->h_counter, sizeof(int)) != hipSuccess) {
         jg_gn_destroy(h); return failg(2, "jg_gn_create: device allocation failed");
     }
-    rc = h->eng.create((int)n, h->gi_rowptr.data(), h->gi_col.data(), h->ld, 0, h->stream);
+    rc = h->eng.create((int)n, h->gi_rowptr.data(), h->gi_col.data(), h->ld, 1, h->stream);     // in place: k_gn_gain writes into the factor storage
     if (rc) { std::string msg = h->eng.error; jg_gn_destroy(h); return failg(rc, msg); }
+    if (jg::upload(&h->d_dst, h->eng.S.src_entry, err, h->stream)) { jg_gn_destroy(h); return failg(2, err); }
     *out = h;
     return 0;
 }
@@ -574,7 +575,7 @@ void jg_gn_destroy(jg_gn* h) {
     h->eng.destroy();
     hipFree(h->d_rows); hipFree(h->d_slot_bus); hipFree(h->d_br); hipFree(h->d_rowptr); hipFree(h->d_G); hipFree(h->d_B); hipFree(h->d_ydiag);
     hipFree(h->d_vm0); hipFree(h->d_va0);
-    hipFree(h->d_vm); hipFree(h->d_va); hipFree(h->d_mean); hipFree(h->d_w); hipFree(h->d_Hs); hipFree(h->d_res); hipFree(h->d_Gv);
+    hipFree(h->d_vm); hipFree(h->d_va); hipFree(h->d_mean); hipFree(h->d_w); hipFree(h->d_Hs); hipFree(h->d_res); hipFree(h->d_dst);
     hipFree(h->d_rhs); hipFree(h->d_inc); hipFree(h->d_items); hipFree(h->d_cw); hipFree(h->d_ca); hipFree(h->d_cb); hipFree(h->d_blk_row);
     hipFree(h->d_blk_col); hipFree(h->d_part); hipFree(h->d_maxinc); hipFree(h->d_params); hipFree(h->d_active); hipFree(h->d_iters);
     hipFree(h->d_status); hipFree(h->d_counter); hipFree(h->d_group);
@@ -762,7 +763,7 @@ int jg_gn_time_kernel(jg_gn* h, int kernel, int reps, double* mean_ms) {
     for (int r = 0; r < reps; ++r) {
         if (kernel == 0) launch_rows(h);
         else if (kernel == 1) launch_gain(h);
-        else if (kernel == 2) { if (int rc = h->eng.factor(h->stream, h->d_Gv, h->d_rhs, jg::GroupSel{})) return failg(rc, h->eng.error); }
+        else if (kernel == 2) { if (int rc = h->eng.factor(h->stream, nullptr, h->d_rhs, jg::GroupSel{})) return failg(rc, h->eng.error); }
         else { if (int rc = h->eng.backsolve(h->stream, h->d_inc, none, jg::GroupSel{})) return failg(rc, h->eng.error); }
     }
     GN_HIP(hipEventRecord(e1, h->stream));
