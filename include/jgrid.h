@@ -161,7 +161,10 @@ int jg_nr_time_kernel(jg_nr* h, int kernel, int reps, double* mean_ms);
  * gaussNewton(monitoring) -- src/stateEstimation/acStateEstimation.jl:43-75 over acWLS (:77-259).
  * The caller passes what acWLS derives from the Measurement container row by row (rows ordered
  * voltmeters, ammeters, wattmeters, varmeters, PMUs x2):
- *   code[m]     measurement type code 1..21 (Appendix B of SURVEY.md) BEFORE status masking,
+ *   code[m]     measurement type code 1..21 (Appendix B of SURVEY.md) BEFORE status masking; codes 22..27 are the
+ *               LINEAR rows of pmuStateEstimation (src/stateEstimation/pmuStateEstimation.jl:72-177): state = (Re V, Im V)
+ *               per bus (kept in the angle / magnitude arrays), 22/23 bus phasor Re/Im, 24/25 from-end current Re/Im,
+ *               26/27 to-end current Re/Im; pass slack = 0 for that model (no reference bus; every variable is estimated),
  *   status[m]   0/1; se.type = status * code (:139, :1139, :1161, :1190-1193, :1222),
  *   index[m]    1-based bus or branch index (se.index),
  *   corr_row[]  1-based FIRST row of every rectangular PMU with a 2x2 precision block (:220-221).

@@ -138,6 +138,25 @@ __global__ __launch_bounds__(256) void k_gn_rows(RowArgs a) {
             continue;
         }
         const double z = a.mean[(size_t)r * ld + b];
+        if (ty >= 22) {                                // LINEAR rows of the PMU-only model: the state is (Re V, Im V) per bus, kept in (va, vm)
+            if (ty <= 23) {                            // bus phasor (pmuStateEstimation.jl:128-139)
+                const double x = ty == 22 ? a.va[(size_t)idx * ld + b] : a.vm[(size_t)idx * ld + b];
+                put(0, ty == 22 ? 1.0 : 0.0, ty == 22 ? 0.0 : 1.0);
+                a.res[(size_t)r * ld + b] = z - x;
+            } else {                                   // branch current phasor (:140-166, backend/expressions.jl:291-349)
+                const BranchP p = a.br[idx];
+                const int i = uniform(p.from), j = uniform(p.to);
+                double sn, cs, A, B, Cc, D;
+                sincos(p.shift, &sn, &cs);
+                if (ty <= 25) { A = p.tinv * p.tinv * (p.g + p.gs); B = -p.tinv * p.tinv * (p.b + p.bs); Cc = -p.tinv * (p.g * cs - p.b * sn); D = p.tinv * (p.b * cs + p.g * sn); }
+                else { A = -p.tinv * (p.g * cs + p.b * sn); B = p.tinv * (p.b * cs - p.g * sn); Cc = p.g + p.gs; D = -p.b - p.bs; }
+                const double ri = a.va[(size_t)i * ld + b], xi = a.vm[(size_t)i * ld + b];
+                const double rj = a.va[(size_t)j * ld + b], xj = a.vm[(size_t)j * ld + b];
+                if (ty == 24 || ty == 26) { put(0, A, B); put(1, Cc, D); a.res[(size_t)r * ld + b] = z - (A * ri + B * xi + Cc * rj + D * xj); }
+                else { put(0, -B, A); put(1, -D, Cc); a.res[(size_t)r * ld + b] = z - (-B * ri + A * xi - D * rj + Cc * xj); }
+            }
+            continue;
+        }
         if (ty == 1 || ty == 12 || ty == 13 || ty == 16 || ty == 17) {
             const double V = a.vm[(size_t)idx * ld + b], th = a.va[(size_t)idx * ld + b];
             double h, dt, dv;
@@ -404,7 +423,7 @@ int jg_gn_create(jg_gn** out, int64_t n, const int64_t* colptr, const int64_t* r
                  int64_t slack, int64_t m, const int8_t* code, const int8_t* status, const int64_t* index,
                  int64_t n_corr, const int64_t* corr_row, int64_t batch, int device) {
     if (!out || n < 1 || !colptr || !rowval || !y_reim || !yt_reim || nb < 0 || m < 1 || !code || !status || !index ||
-        batch < 1 || slack < 1 || slack > n || n_corr < 0 || (n_corr > 0 && !corr_row) || (nb > 0 && (!from || !to || !branch_param)))
+        batch < 1 || slack < 0 || slack > n || n_corr < 0 || (n_corr > 0 && !corr_row) || (nb > 0 && (!from || !to || !branch_param)))
         return failg(1, "jg_gn_create: bad argument");
     int ndev = 0;
     GN_HIP(hipGetDeviceCount(&ndev));
@@ -452,6 +471,16 @@ int jg_gn_create(jg_gn** out, int64_t n, const int64_t* colptr, const int64_t* r
             }
         } else if ((cd >= 2 && cd <= 5) || cd == 7 || cd == 8 || cd == 10 || cd == 11 || cd == 14 || cd == 15 || (cd >= 18 && cd <= 21)) {
             if (k < 0 || k >= nb) { delete h; return failg(1, "jg_gn_create: branch index out of range"); }   // fourIndices!
+            const int64_t f = from[k] - 1, t = to[k] - 1;
+            slot_bus.push_back((int)f); slot_bus.push_back((int)t);
+            trips.push_back({r, f, s0 * 2}); trips.push_back({r, t, (s0 + 1) * 2});
+            trips.push_back({r, f + n, s0 * 2 + 1}); trips.push_back({r, t + n, (s0 + 1) * 2 + 1});
+        } else if (cd == 22 || cd == 23) {                                       // linear PMU model, bus phasor: pmuIndices (pmuStateEstimation.jl:549-557)
+            if (k < 0 || k >= n) { delete h; return failg(1, "jg_gn_create: bus index out of range"); }
+            slot_bus.push_back((int)k);
+            if (cd == 22) trips.push_back({r, k, s0 * 2}); else trips.push_back({r, k + n, s0 * 2 + 1});
+        } else if (cd >= 24 && cd <= 27) {                                       // linear PMU model, branch current phasor
+            if (k < 0 || k >= nb) { delete h; return failg(1, "jg_gn_create: branch index out of range"); }
             const int64_t f = from[k] - 1, t = to[k] - 1;
             slot_bus.push_back((int)f); slot_bus.push_back((int)t);
             trips.push_back({r, f, s0 * 2}); trips.push_back({r, t, (s0 + 1) * 2});

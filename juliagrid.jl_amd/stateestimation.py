@@ -78,6 +78,21 @@ def _readings(mon: Measurement):
     return f8(z1), f8(v1), np.array(s1, dtype=np.int8), f8(z2), f8(v2), np.array(s2, dtype=np.int8)
 
 
+def _rectangular_pmu(zz, var, za, vara, correlated):
+    """Rectangular form of one polar PMU reading: (z cos, z sin), the diagonal of its precision block and the
+    off-diagonal (None when uncorrelated): variancePmu / covariancePmu + precision! (equations.jl:576-666)."""
+    s, c = np.sin(za), np.cos(za)
+    vre = var * c ** 2 + vara * (zz * s) ** 2
+    vim = var * s ** 2 + vara * (zz * c) ** 2
+    if not correlated:
+        return zz * c, zz * s, 1.0 / vre, 1.0 / vim, None
+    l1i = 1.0 / np.sqrt(vre)
+    l2 = s * c * (var - vara * zz ** 2) * l1i
+    l3i2 = 1.0 / (vim - l2 ** 2)
+    off = (-l2 * l1i) * l3i2
+    return zz * c, zz * s, (l1i - l2 * off) * l1i, l3i2, off
+
+
 def _wls_values(mon: Measurement, devs, dev_row, m, z1, v1, s1, z2, v2, s2):
     """se.mean, diag(se.precision), correlated off-diagonals and row status for readings of shape [..., ndev]."""
     shape = z1.shape[:-1]
@@ -105,24 +120,14 @@ def _wls_values(mon: Measurement, devs, dev_row, m, z1, v1, s1, z2, v2, s2):
             mean[..., r + 1] = sta * za
             wdiag[..., r + 1] = 1.0 / vara
         else:
-            s, c = np.sin(za), np.cos(za)
             stt = st * sta
             status[r] = status[r + 1] = stt
-            mean[..., r] = stt * zz * c                                        # :216-217
-            mean[..., r + 1] = stt * zz * s
-            vre = var * c ** 2 + vara * (zz * s) ** 2                          # variancePmu (equations.jl:576-588)
-            vim = var * s ** 2 + vara * (zz * c) ** 2
-            if p.layout.correlated[i]:                                         # covariancePmu + precision! (:591-666)
-                l1i = 1.0 / np.sqrt(vre)
-                l2 = s * c * (var - vara * zz ** 2) * l1i
-                l3i2 = 1.0 / (vim - l2 ** 2)
-                off = (-l2 * l1i) * l3i2
+            re, im, wre, wim, off = _rectangular_pmu(zz, var, za, vara, p.layout.correlated[i])
+            mean[..., r] = stt * re                                            # :216-217
+            mean[..., r + 1] = stt * im
+            wdiag[..., r], wdiag[..., r + 1] = wre, wim
+            if off is not None:
                 woff.append(off)
-                wdiag[..., r] = (l1i - l2 * off) * l1i
-                wdiag[..., r + 1] = l3i2
-            else:
-                wdiag[..., r] = 1.0 / vre
-                wdiag[..., r + 1] = 1.0 / vim
     woff = np.stack(woff, axis=-1) if woff else np.zeros(shape + (0,))
     if not (np.all(np.isfinite(wdiag)) and np.all(wdiag > 0) and np.all(np.isfinite(woff))):
         raise ValueError("The variance of a measurement is zero or negative (errorVariance): "
@@ -138,21 +143,21 @@ class AcStateEstimation:
         self.monitoring = monitoring
         self.system = sysm = monitoring.system
         self.batch = int(batch)
-        if sysm.bus.layout.slack == 0:
+        if self._needs_slack and sysm.bus.layout.slack == 0:
             raise RuntimeError("The slack bus is missing.")
         if sysm.model.ac.nodalMatrix is None:
             acModel_(sysm)                                                     # model!(system, ac) :88
         ac = sysm.model.ac
         Y, YT = ac.nodalMatrix, ac.nodalMatrixTranspose
         n, nb = sysm.bus.number, sysm.branch.number
-        code, index, rng, corr, devs, dev_row = _wls_layout(monitoring)
+        code, index, rng, corr, devs, dev_row = self._layout(monitoring)
         self._devs, self._dev_row = devs, dev_row
         m = code.size
         if m == 0:
             raise ValueError("the measurement set is empty")
-        z = _readings(monitoring)
+        z = self._raw(monitoring)
         self._z = z
-        mean, wdiag, woff, status = _wls_values(monitoring, devs, dev_row, m, *z)
+        mean, wdiag, woff, status = self._values(monitoring, devs, dev_row, m, *z)
         par = sysm.branch.parameter
         bp = np.ascontiguousarray(np.stack([ac.admittance.real, ac.admittance.imag, par.conductance, par.susceptance,
                                             par.turnsRatio, par.shiftAngle], axis=1), dtype=np.float64)
@@ -160,7 +165,7 @@ class AcStateEstimation:
         _lib.check(L.jg_gn_create(C.byref(self._h), n, Y.colptr, Y.rowval, _reim(Y.nzval), _reim(YT.nzval), nb,
                                   np.ascontiguousarray(sysm.branch.layout.from_, dtype=np.int64),
                                   np.ascontiguousarray(sysm.branch.layout.to, dtype=np.int64), bp.reshape(-1),
-                                  sysm.bus.layout.slack, m, code, status, index, corr.size,
+                                  sysm.bus.layout.slack if self._needs_slack else 0, m, code, status, index, corr.size,
                                   corr if corr.size else np.zeros(1, dtype=np.int64), self.batch, int(device)))
         dims = np.zeros(8, dtype=np.int64)
         _lib.check(L.jg_gn_dims(self._h, dims))
@@ -174,8 +179,16 @@ class AcStateEstimation:
                          _wdiag=wdiag, _woff=woff, _corr=corr, _code=code)
         self._upload_measurement(mean, wdiag, woff)
         self.voltage = NS(magnitude=None, angle=None)
-        self.setVoltage(sysm.bus.voltage.magnitude, sysm.bus.voltage.angle)    # acStateEstimation.jl:52-55
+        self._start(sysm)
         self.status = None
+
+    _needs_slack = True
+    _layout = staticmethod(_wls_layout)
+    _raw = staticmethod(_readings)
+    _values = staticmethod(_wls_values)
+
+    def _start(self, sysm):
+        self.setVoltage(sysm.bus.voltage.magnitude, sysm.bus.voltage.angle)    # acStateEstimation.jl:52-55
 
     def close(self):
         if getattr(self, "_h", None):
@@ -263,6 +276,98 @@ class AcStateEstimation:
         return ms.value
 
 
+def _pmu_layout(mon: Measurement):
+    """Rows of pmuEstimationWls (pmuStateEstimation.jl:72-177): two LINEAR rows (Re, Im) per PMU in device order."""
+    p = mon.pmu
+    code, index, corr_rows, devs, dev_row = [], [], [], [], []
+    for i, k in enumerate(p.layout.index):
+        devs.append(("p", i)); dev_row.append(len(code))
+        if p.layout.correlated[i]:
+            corr_rows.append(len(code) + 1)
+        code += [22, 23] if p.layout.bus[i] else ([24, 25] if p.layout.from_[i] else [26, 27])
+        index += [k, k]
+    return (np.array(code, dtype=np.int8), np.array(index, dtype=np.int64), np.array([1, len(code) + 1], dtype=np.int64),
+            np.array(corr_rows, dtype=np.int64), devs, np.array(dev_row, dtype=np.int64))
+
+
+def _pmu_readings(mon: Measurement):
+    f8 = lambda x: np.array(x, dtype=np.float64)
+    p = mon.pmu
+    return (f8(p.magnitude.mean), f8(p.magnitude.variance), np.array(p.magnitude.status, dtype=np.int8),
+            f8(p.angle.mean), f8(p.angle.variance), np.array(p.angle.status, dtype=np.int8))
+
+
+def _pmu_values(mon: Measurement, devs, dev_row, m, z1, v1, s1, z2, v2, s2):
+    """se.mean and se.precision of the linear model (:98-117): every PMU in rectangular form, whatever its `polar` flag."""
+    shape = z1.shape[:-1]
+    mean, wdiag = np.zeros(shape + (m,)), np.ones(shape + (m,))
+    status = np.zeros(m, dtype=np.int8)
+    woff = []
+    for d, (_, i) in enumerate(devs):
+        r = int(dev_row[d])
+        stt = int(s1[d]) * int(s2[d])                                          # both channels in service (:120, :133)
+        status[r] = status[r + 1] = stt
+        re, im, wre, wim, off = _rectangular_pmu(z1[..., d], v1[d], z2[..., d], v2[d], mon.pmu.layout.correlated[i])
+        mean[..., r], mean[..., r + 1] = stt * re, stt * im
+        wdiag[..., r], wdiag[..., r + 1] = wre, wim
+        if off is not None:
+            woff.append(off)
+    woff = np.stack(woff, axis=-1) if woff else np.zeros(shape + (0,))
+    if not (np.all(np.isfinite(wdiag)) and np.all(wdiag > 0) and np.all(np.isfinite(woff))):
+        raise ValueError("The variance of a measurement is zero or negative (errorVariance).")
+    return mean, wdiag, woff, status
+
+
+class PmuStateEstimation(AcStateEstimation):
+    """PmuStateEstimation{WLS{HIP}} (src/definition/analysis.jl, src/stateEstimation/pmuStateEstimation.jl:43-70): the
+    linear model z = H [Re V; Im V] + u.  The device runs it as ONE Gauss-Newton step of linear rows from the zero
+    state (residual = z): per-scenario gain H' W H (W depends on the readings through variancePmu), block LU, solve.
+    `method.coefficient` is H (constant), `method.precision`/`mean` as in the reference."""
+    _needs_slack = False
+    _layout = staticmethod(_pmu_layout)
+    _raw = staticmethod(_pmu_readings)
+    _values = staticmethod(_pmu_values)
+
+    def _start(self, sysm):
+        n = sysm.bus.number
+        self._zero = np.zeros(n)
+        self._rect = None
+        self.voltage.magnitude = self._shape(np.tile(np.asarray(sysm.bus.voltage.magnitude, dtype=np.float64), (self.batch, 1)))
+        self.voltage.angle = self._shape(np.tile(np.asarray(sysm.bus.voltage.angle, dtype=np.float64), (self.batch, 1)))
+
+    @property
+    def coefficient(self):
+        """se.coefficient: the constant H [2 * pmu.number, 2 * bus.number] (CSC, the reference's pattern)."""
+        L = _lib.lib()
+        _lib.check(L.jg_gn_set_voltage(self._h, self._zero, self._zero, 0))
+        mx = np.zeros(self.batch)
+        _lib.check(L.jg_gn_increment(self._h, mx))
+        return self.jacobian
+
+
+def pmuStateEstimation(monitoring: Measurement, batch: int = 1, device: int = 0) -> PmuStateEstimation:
+    """pmuStateEstimation(monitoring) (pmuStateEstimation.jl:43-70): linear WLS model with PMUs only."""
+    if monitoring.pmu.number == 0:
+        raise ValueError("the measurement set holds no PMU")
+    return PmuStateEstimation(monitoring, batch, device)
+
+
+def _solve_pmu(an: PmuStateEstimation, fetch: bool = True):
+    """solve!(analysis::PmuStateEstimation{WLS{Normal}}) (:369-399): gain = H' W H, b = H' W z, factorise, solve,
+    then (Re, Im) -> (magnitude, angle)."""
+    L = _lib.lib()
+    _lib.check(L.jg_gn_set_voltage(an._h, an._zero, an._zero, 0))
+    mx = np.zeros(an.batch)
+    _lib.check(L.jg_gn_increment(an._h, mx))
+    _lib.check(L.jg_gn_solve(an._h))
+    an.status = 0 if an.batch == 1 else np.zeros(an.batch, dtype=np.int32)   # a singular gain raised above
+    if fetch:
+        n = an.system.bus.number
+        im, re = np.zeros((an.batch, n)), np.zeros((an.batch, n))
+        _lib.check(L.jg_gn_get_voltage(an._h, im, re))                         # (vm, va) hold (Im, Re)
+        an.voltage.magnitude, an.voltage.angle = an._shape(np.hypot(re, im)), an._shape(np.arctan2(im, re))
+
+
 def gaussNewton(monitoring: Measurement, batch: int = 1, device: int = 0) -> AcStateEstimation:
     """gaussNewton(monitoring): WLS model + symbolic analysis + upload; start = system.bus.voltage."""
     return AcStateEstimation(monitoring, batch, device)
@@ -276,7 +381,7 @@ def setNoise_(an: AcStateEstimation, rng, scale: float = 1.0):
     B = an.batch
     n1 = z1[None, :] + scale * np.sqrt(v1)[None, :] * rng.standard_normal((B, z1.size))
     n2 = z2[None, :] + scale * np.sqrt(v2)[None, :] * rng.standard_normal((B, z2.size))
-    mean, wdiag, woff, _ = _wls_values(an.monitoring, an._devs, an._dev_row, an.dims["m"], n1, v1, s1, n2, v2, s2)
+    mean, wdiag, woff, _ = an._values(an.monitoring, an._devs, an._dev_row, an.dims["m"], n1, v1, s1, n2, v2, s2)
     an._upload_measurement(mean if B > 1 else mean[0], wdiag if B > 1 else wdiag[0], woff if B > 1 else woff[0])
 
 
@@ -288,7 +393,10 @@ def increment_(an: AcStateEstimation):
 
 
 def solve_(an: AcStateEstimation):
-    """solve!(analysis): theta += increment[1:n], V += increment[n+1:2n]; iteration += 1."""
+    """solve!(analysis): theta += increment[1:n], V += increment[n+1:2n]; iteration += 1.
+    For a PmuStateEstimation: the whole linear WLS solve."""
+    if isinstance(an, PmuStateEstimation):
+        return _solve_pmu(an)
     _lib.check(_lib.lib().jg_gn_solve(an._h))
     an.method.iteration += 1
     an._pull_voltage()
@@ -296,6 +404,8 @@ def solve_(an: AcStateEstimation):
 
 def stateEstimation_(an: AcStateEstimation, iteration: int = 40, tolerance: float = 1e-8, fetch: bool = True):
     """stateEstimation!(analysis; iteration, tolerance)."""
+    if isinstance(an, PmuStateEstimation):
+        return _solve_pmu(an, fetch)
     it = np.zeros(an.batch, dtype=np.int32)
     st = np.zeros(an.batch, dtype=np.int32)
     _lib.check(_lib.lib().jg_gn_run(an._h, int(iteration), float(tolerance), it, st))

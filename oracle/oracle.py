@@ -664,3 +664,69 @@ class OracleFastNR:
                 return 1
             self.solve()
         return 1
+
+
+# ---- pmuStateEstimation(monitoring) + solve! restated (TEST ORACLE; src/stateEstimation/pmuStateEstimation.jl) -------
+class OraclePmuWLS:
+    """Linear WLS with PMUs only: coefficient / mean / precision as pmuEstimationWls builds them (:72-177), then
+    solve!{Normal} (:369-399): gain = H' W H, b = H' W z, sparse LU, (Re, Im) -> polar.  Plain numpy / scipy.
+    Pinned by the reference's own acceptance test (test/stateEstimation/analysis.jl:347-440, testPmuEstimation in
+    test/utility/utility.jl:293-297): PMUs built from a solved power flow return its voltages to 1e-10."""
+
+    def __init__(self, sys_: OracleSystem, table):
+        import scipy.sparse as sp
+        a = table.arrays() if isinstance(table, MeterTable) else table
+        sel = np.flatnonzero(a["kind"] == KIND["pmu"])
+        t, n = sys_.t, sys_.n
+        y = 1.0 / (_f8(t["br_r"]) + 1j * _f8(t["br_x"]))               # ac.admittance (model.jl:55)
+        g, b = y.real, y.imag
+        gs, bs = 0.5 * _f8(t["br_g"]), 0.5 * _f8(t["br_b"])
+        tinv, phi = 1.0 / _f8(t["br_tap"]), _f8(t["br_shift"])
+        frm, to = np.asarray(t["br_from"], dtype=np.int64) - 1, np.asarray(t["br_to"], dtype=np.int64) - 1
+        m = 2 * sel.size
+        rows, cols, vals = [], [], []
+        self.mean = np.zeros(m)
+        W = sp.lil_matrix((m, m))
+        for q, d in enumerate(sel):
+            r = 2 * q
+            zm, vm_, zs = a["mean1"][d], a["var1"][d], a["mean2"][d]
+            va_ = a["var2"][d]
+            s, c = np.sin(zs), np.cos(zs)
+            vre = vm_ * c ** 2 + va_ * (zm * s) ** 2                     # variancePmu (equations.jl:576-588)
+            vim = vm_ * s ** 2 + va_ * (zm * c) ** 2
+            if a["flags"][d] & 4:                                        # correlated: inverse of the 2x2 covariance (:591-666)
+                cov = s * c * (vm_ - va_ * zm ** 2)
+                blk = np.linalg.inv(np.array([[vre, cov], [cov, vim]]))
+                W[r, r], W[r, r + 1], W[r + 1, r], W[r + 1, r + 1] = blk[0, 0], blk[0, 1], blk[1, 0], blk[1, 1]
+            else:
+                W[r, r], W[r + 1, r + 1] = 1.0 / vre, 1.0 / vim
+            if not (a["status1"][d] == 1 and a["status2"][d] == 1):
+                continue                                                 # row kept, coefficients and mean zero (:120, :133)
+            self.mean[r], self.mean[r + 1] = zm * c, zm * s
+            k = int(a["index"][d]) - 1
+            if a["loc"][d] == 0:
+                rows += [r, r + 1]; cols += [k, k + n]; vals += [1.0, 1.0]
+                continue
+            cp, sn = np.cos(phi[k]), np.sin(phi[k])
+            if a["loc"][d] == 1:                                         # ReImIijCoefficient (backend/expressions.jl:291-302)
+                A = tinv[k] ** 2 * (g[k] + gs[k]); B = -tinv[k] ** 2 * (b[k] + bs[k])
+                Cc = -tinv[k] * (g[k] * cp - b[k] * sn); D = tinv[k] * (b[k] * cp + g[k] * sn)
+            else:                                                        # ReImIjiCoefficient (:338-349)
+                A = -tinv[k] * (g[k] * cp + b[k] * sn); B = tinv[k] * (b[k] * cp - g[k] * sn)
+                Cc = g[k] + gs[k]; D = -b[k] - bs[k]
+            i, j = int(frm[k]), int(to[k])
+            rows += [r, r + 1, r, r + 1, r, r + 1, r, r + 1]             # pmuIndices order (:158-161)
+            cols += [i, i + n, j, j + n, i + n, i, j + n, j]
+            vals += [A, A, Cc, Cc, B, -B, D, -D]
+        self.n, self.m = n, m
+        self.coefficient = sp.csc_matrix((vals, (rows, cols)), shape=(m, 2 * n))
+        self.precision = W.tocsc()
+
+    def solve(self):
+        from scipy.sparse.linalg import splu
+        temp = self.coefficient.T @ self.precision
+        gain = (temp @ self.coefficient).tocsc()
+        x = splu(gain).solve(temp @ self.mean)
+        v = x[: self.n] + 1j * x[self.n:]
+        self.magnitude, self.angle = np.abs(v), np.angle(v)
+        return self.magnitude, self.angle
