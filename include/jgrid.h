@@ -209,7 +209,18 @@ int jg_gn_get_jacobian(jg_gn* h, double* nzval);
 int jg_gn_get_residual(jg_gn* h, double* residual);
 int jg_gn_get_increment(jg_gn* h, double* increment);
 int jg_gn_get_iteration(jg_gn* h, int32_t* iters);
-/* kernel: 0 measurement rows (H + residual), 1 gain + rhs gather, 2 factor (+ fused forward), 3 backward */
+/* residualTest!(analysis) -- src/stateEstimation/badData.jl:119-311, the numeric part, per scenario: residual, Jacobian,
+ * gain and its factor at the CURRENT state, selected inverse of the gain on its factor pattern (replaces
+ * takahashiCholeskyLower / selectedInverse, :536-637), c = rowProjection (:289-311), normalised residuals
+ * |r_i| / sqrt(|1 / W_ii - c_i|) (0 where r_i == 0 or the row carries no weight in that scenario).
+ * max_nres [batch], index [batch] = 1-based row of the largest one (first on ties, 0 if all are zero). */
+int jg_gn_residual_test(jg_gn* h, double* max_nres, int32_t* index);
+/* residual and Jacobian at the CURRENT state, nothing else (se.residual for chiTest after the last solve!) */
+int jg_gn_evaluate(jg_gn* h);
+/* all normalised residuals of the last jg_gn_residual_test [batch][m] */
+int jg_gn_get_normalized_residual(jg_gn* h, double* nres);
+/* kernel: 0 measurement rows (H + residual), 1 gain + rhs gather, 2 factor (+ fused forward), 3 backward,
+ * 4 selected inverse (needs a factor: call after an increment) */
 int jg_gn_time_kernel(jg_gn* h, int kernel, int reps, double* mean_ms);
 
 /* ---------------------------------------------------------------------------------------------

@@ -11,7 +11,7 @@ from .contingency import bridges, outageList, shard, contingencyAnalysis, gather
 from .measurement import (Measurement, measurement, addVoltmeter_, addAmmeter_, addWattmeter_, addVarmeter_,   # noqa: F401
                           addPmu_, exactQuantities)
 from .stateestimation import (AcStateEstimation, PmuStateEstimation, pmuStateEstimation, gaussNewton, increment_ as incrementSE_, solve_ as solveSE_,   # noqa: F401
-                              stateEstimation_, setNoise_)
+                              stateEstimation_, setNoise_, residualTest_, normalizedResidual, chiTest)
 from .synthetic import pegaseShaped, case9241synth                          # noqa: F401
 from . import powerflow, stateestimation   # noqa: F401
 from . import _lib                                                           # noqa: F401
@@ -20,7 +20,7 @@ __all__ = [
     "PowerSystem", "CscMatrix", "powerSystem", "acModel_", "updateBranchSystem_", "AcPowerFlow", "newtonRaphson", "fastNewtonRaphsonBX", "fastNewtonRaphsonXB",
     "mismatch_", "solve_", "powerFlow_", "setInitialPoint_", "updateBranch_", "setOutage_", "setInjection_",
     "Measurement", "measurement", "addVoltmeter_", "addAmmeter_", "addWattmeter_", "addVarmeter_", "addPmu_",
-    "exactQuantities", "AcStateEstimation", "PmuStateEstimation", "pmuStateEstimation", "gaussNewton", "incrementSE_", "solveSE_", "stateEstimation_", "setNoise_",
+    "exactQuantities", "AcStateEstimation", "PmuStateEstimation", "pmuStateEstimation", "gaussNewton", "incrementSE_", "solveSE_", "stateEstimation_", "setNoise_", "residualTest_", "normalizedResidual", "chiTest",
     "outagePatch", "initializeACPowerFlow", "bridges", "outageList", "shard", "contingencyAnalysis", "gatherResults",
     "pegaseShaped", "case9241synth", "ContingencyPipeline", "setOutages_", "power_", "current_", "reactiveLimit_", "adjustAngle_",
 ]

@@ -79,6 +79,9 @@ def lib():
         "jg_gn_restore_voltage": [VP],
         "jg_gn_increment": [VP, F64P],
         "jg_gn_solve": [VP],
+        "jg_gn_residual_test": [VP, F64P, I32P],
+        "jg_gn_get_normalized_residual": [VP, F64P],
+        "jg_gn_evaluate": [VP],
         "jg_gn_run": [VP, C.c_int64, C.c_double, I32P, I32P],
         "jg_gn_get_maps": [VP, I8P, I64P, I64P],
         "jg_gn_get_jacobian": [VP, F64P],
@@ -144,5 +147,5 @@ class Plan:
     def replay_tables(self, kind):
         """Device replay tables (jg_symbolic.hpp): segments [n,8] = rec_base, nchunks, wpi, rpw, level, last, items, -;
         wave records [m,16]."""
-        base = {"fact": 60, "bwd": 62, "fwd": 66}[kind]
+        base = {"fact": 60, "bwd": 62, "fwd": 66, "sel": 68}[kind]
         return self.get(base).reshape(-1, 8), self.get(base + 1).reshape(-1, 16)

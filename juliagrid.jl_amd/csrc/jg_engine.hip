@@ -361,6 +361,85 @@ __global__ __launch_bounds__(1024) void k_bwd_level(BwdArgs a) {
     level_body<true>(a, red);
 }
 
+// ---- selected inverse (Takahashi recursion on the factor pattern, symmetric matrices; tables: jg_symbolic.cpp) ----------
+struct SelArgs {
+    const Rec* rec; const Segment* seg;
+    const double* X; double* Z; GroupSel sel;
+    int ld, seg_begin, lanes;
+    int s0_base, s0_nchunks, s0_wpi, s0_rpw;
+};
+
+// T += U(i,k) * Z(k,j)   (Z entry read transposed when bit 30 of its id is set)
+__device__ __forceinline__ void sel_record(const SelArgs& a, const RecS& r, size_t b, size_t ld, Blk& t) {
+    const int nt = rec_word(r, 3);
+    Blk u[BWD_T], z[BWD_T];
+#pragma unroll
+    for (int q = 0; q < BWD_T; ++q) {
+        if (q < nt) {
+            u[q] = load_blk(a.X, (size_t)rec_word(r, 4 + 2 * q), b, ld);
+            z[q] = load_blk(a.Z, (size_t)(rec_word(r, 5 + 2 * q) & 0x3fffffff), b, ld);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < BWD_T; ++q) {
+        if (q < nt) {
+            const bool tr = (rec_word(r, 5 + 2 * q) >> 30) & 1;
+            const double z01 = tr ? z[q].v10 : z[q].v01, z10 = tr ? z[q].v01 : z[q].v10;
+            t.v00 += u[q].v00 * z[q].v00 + u[q].v01 * z10;
+            t.v01 += u[q].v00 * z01 + u[q].v01 * z[q].v11;
+            t.v10 += u[q].v10 * z[q].v00 + u[q].v11 * z10;
+            t.v11 += u[q].v10 * z01 + u[q].v11 * z[q].v11;
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_sel_level(SelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double red[];   // [16][2][64] double2
+    int base = a.s0_base, nchunks = a.s0_nchunks, wpi = a.s0_wpi, rpw = a.s0_rpw;
+    if (blockIdx.y != 0) {
+        const SegS sg = ((SegPtr)a.seg)[a.seg_begin + blockIdx.y];
+        base = sg[0]; nchunks = sg[1]; wpi = sg[2]; rpw = sg[3];
+    }
+    int grp, bx;
+    if (!map_block(a.sel, a.ld, nchunks, grp, bx)) return;
+    const int lane = threadIdx.x;
+    const int wave = uniform(threadIdx.y);
+    const size_t ld = (size_t)a.ld;
+    const size_t b = (size_t)min(grp * 64 + lane, a.lanes - 1);
+    const size_t ri = (size_t)base + ((size_t)bx * 16 + wave) * rpw;
+    const RecS first = load_rec(a.rec, ri);
+    const int sub = wave & (wpi - 1);
+    const int target = rec_word(first, 0);
+    Blk t{0.0, 0.0, 0.0, 0.0}, d{0.0, 0.0, 0.0, 0.0};
+    if (target >= 0) {
+        if (sub == 0) d = load_blk(a.X, (size_t)rec_word(first, 1), b, ld);
+        RecS cur = first;
+        for (int j = 1; j < rpw; ++j) {
+            const RecS nxt = load_rec(a.rec, ri + j);
+            sel_record(a, cur, b, ld, t);
+            cur = nxt;
+        }
+        sel_record(a, cur, b, ld, t);
+        if (wpi > 1 && sub != 0) {
+            double2* q = (double2*)red + (size_t)wave * 128 + lane;
+            q[0] = double2{t.v00, t.v01}; q[64] = double2{t.v10, t.v11};
+        }
+    }
+    if (wpi > 1) __syncthreads();
+    if (target >= 0 && sub == 0) {
+        for (int w = 1; w < wpi; ++w) {
+            const double2* q = (const double2*)red + (size_t)(wave + w) * 128 + lane;
+            const double2 h0 = q[0], h1 = q[64];
+            t.v00 += h0.x; t.v01 += h0.y; t.v10 += h1.x; t.v11 += h1.y;
+        }
+        const double e = rec_word(first, 2) ? 1.0 : 0.0;          // diagonal: D^-1 (I - T); off-diagonal: -D^-1 T
+        double z00, z10, z01, z11;
+        dsolve(d, e - t.v00, -t.v10, z00, z10);
+        dsolve(d, -t.v01, e - t.v11, z01, z11);
+        store_blk(a.Z, (size_t)target, b, ld, z00, z01, z10, z11);
+    }
+}
+
 // ---- executor 2: persistent level walker ----------------------------------------------------------------------
 // One launch replays ALL dependency levels.  The chip's workgroups (one 16-wave workgroup per CU) form TEAMS by
 // the XCD they physically run on (HW_REG_XCC_ID, read at run time -- nothing is assumed about blockIdx -> XCD
@@ -628,6 +707,7 @@ void Engine::destroy() {
     }
     hipFree(fact_rec); hipFree(bwd_rec); hipFree(fact_seg); hipFree(bwd_seg); hipFree(bwd_chain); hipFree(sync);
     hipFree(fwd_rec); hipFree(fwd_seg); fwd_rec = nullptr; fwd_seg = nullptr;
+    hipFree(sel_rec); hipFree(sel_seg); hipFree(Zs); sel_rec = nullptr; sel_seg = nullptr; Zs = nullptr;
     bwd_chain = nullptr;
     hipFree(X); hipFree(W); hipFree(status);
     fact_rec = bwd_rec = nullptr; fact_seg = bwd_seg = nullptr; sync = nullptr; status = nullptr;
@@ -671,6 +751,25 @@ int Engine::factor(hipStream_t st, const double* A, const double* rhs, const Gro
         a.seg_begin = L.seg_begin;
         { const Segment& g = S.fact_seg[L.seg_begin]; a.s0_base = g.rec_base; a.s0_nchunks = g.nchunks; a.s0_wpi = g.wpi; a.s0_rpw = g.rpw; }
         hipLaunchKernelGGL(k_fact_level, dim3((unsigned)L.grid * gs, L.nseg), dim3(64, 16), 16 * 256 * sizeof(double), st, a);
+    }
+    JG_HIP(hipGetLastError());
+    return 0;
+}
+
+int Engine::selected_inverse(hipStream_t st, const GroupSel& sel) {
+    if (!Zs) {                                          // tables and storage on first use
+        build_selected_inverse(S);
+        level_launches(S.sel_seg, selv);
+        if (upload(&sel_rec, S.sel_rec, error, st) || upload(&sel_seg, S.sel_seg, error, st)) return 2;
+        JG_HIP(hipMalloc((void**)&Zs, factor_bytes()));
+        JG_HIP(sync_fill(Zs, 0, factor_bytes(), st));
+    }
+    SelArgs a{sel_rec, sel_seg, X, Zs, sel, ld, 0, lanes > 0 ? lanes : ld, 0, 0, 1, 1};
+    const int gs = group_stride(ld / 64);
+    for (const DevLaunch& L : selv) {
+        a.seg_begin = L.seg_begin;
+        { const Segment& g = S.sel_seg[L.seg_begin]; a.s0_base = g.rec_base; a.s0_nchunks = g.nchunks; a.s0_wpi = g.wpi; a.s0_rpw = g.rpw; }
+        hipLaunchKernelGGL(k_sel_level, dim3((unsigned)L.grid * gs, L.nseg), dim3(64, 16), 16 * 128 * sizeof(double2), st, a);
     }
     JG_HIP(hipGetLastError());
     return 0;

@@ -104,12 +104,13 @@ struct Engine {
                                    // so a small batch moves 8 bytes per load instruction instead of 512
     Rec* fact_rec = nullptr; Rec* bwd_rec = nullptr;           // wave records (jg_symbolic.hpp), replay order
     Segment* fact_seg = nullptr; Segment* bwd_seg = nullptr;
+    Rec* sel_rec = nullptr; Segment* sel_seg = nullptr; double* Zs = nullptr;   // selected inverse (allocated on first use)
     Rec* fwd_rec = nullptr; Segment* fwd_seg = nullptr;          // forward elimination alone (factor once, solve many)
     int* bwd_chain = nullptr;                                   // backward chain task data (jg_symbolic.hpp)
     double* X = nullptr;           // factor values [n_entries][4][ld]: U, unscaled Lh, factored diagonal blocks
     double* W = nullptr;           // [n][2][ld] pivot order: y after factor(), x after backsolve()
     int* status = nullptr;         // [ld] bit 2 set on zero / non-finite pivot
-    std::vector<DevLaunch> fact, bwd, fwd;
+    std::vector<DevLaunch> fact, bwd, fwd, selv;
     // persistent level walker (one launch per factorisation / per backward sweep, see jg_engine.hip)
     int* sync = nullptr;           // registration / team census / barrier counters / error word, zeroed before every walk
     int walk_grid = 0;             // workgroups of a walk = CUs of the device (all must be co-resident)
@@ -128,6 +129,9 @@ struct Engine {
     int factor(hipStream_t st, const double* A, const double* rhs, const GroupSel& sel, int mode = 0);
     // y = (Lh inv(D))^-1 rhs with the factor of the last factor() call (solve many right-hand sides with one factorisation).
     int forward(hipStream_t st, const double* rhs, const GroupSel& sel);
+    // Zs = A^-1 on the upper factor pattern + diagonal (same entry numbering as X) for a SYMMETRIC matrix, from the factor
+    // of the last factor() call: Takahashi recursion, two launches per backward level (off-diagonals, then diagonals).
+    int selected_inverse(hipStream_t st, const GroupSel& sel);
     // Fill the (in-place) factor storage with ONE shared matrix: blocks [nnz of the caller's pattern][4] (row-major 2x2),
     // replicated over every scenario; fill-in entries need nothing.
     int set_shared_matrix(hipStream_t st, const double* blocks_host);

@@ -294,6 +294,68 @@ __global__ __launch_bounds__(256) void k_gn_norm(double* inc, double* part, int 
     }
 }
 
+// Largest normalised residual test (src/stateEstimation/badData.jl:181-311): c_r = h_r Z h_r' from the selected inverse
+// Z of the gain matrix (rowProjection, :289-311), nres_r = |res_r| / sqrt(|1 / W_rr - c_r|), 0 for rows without residual
+// or without weight (removed for this scenario).  One wave per row; the pair list of a row names (slot, slot, Z entry).
+struct ProjArgs {
+    const int* pair_ptr; const int* pa; const int* pb; const int* pz;
+    const int* slot_bus; const double* Hs; const double* Z; const double* res; const double* w;
+    double* nres; int m; int slack; int ld;
+};
+
+__global__ __launch_bounds__(256) void k_gn_project(ProjArgs a) {
+    const int lane = threadIdx.x;
+    const int wave = uniform(threadIdx.y);
+    const size_t ld = (size_t)a.ld;
+    const size_t b = (size_t)blockIdx.y * 64 + lane;
+    typedef const int __attribute__((address_space(4)))* CInt;
+    CInt pp = (CInt)a.pair_ptr, pa = (CInt)a.pa, pb = (CInt)a.pb, pz = (CInt)a.pz, sb = (CInt)a.slot_bus;
+    const int r0 = blockIdx.x * GN_ROWS, r1 = min(r0 + GN_ROWS, a.m);
+    for (int r = r0 + wave; r < r1; r += blockDim.y) {
+        double c = 0.0;
+        for (int q = pp[r], e = pp[r + 1]; q < e; ++q) {
+            const int sa = pa[q], sc = pb[q];
+            double2 ha = jg::load_vec(a.Hs, (size_t)sa, b, ld), hb = jg::load_vec(a.Hs, (size_t)sc, b, ld);
+            const jg::Blk z = jg::load_blk(a.Z, (size_t)pz[q], b, ld);
+            if (sb[sa] == a.slack) ha.x = 0.0;                   // removeColumn(jacobian, slack) (:200)
+            if (sb[sc] == a.slack) hb.x = 0.0;
+            const double t = ha.x * (z.v00 * hb.x + z.v01 * hb.y) + ha.y * (z.v10 * hb.x + z.v11 * hb.y);
+            c += sa == sc ? t : 2.0 * t;                         // Z is symmetric: the (b, a) pair is the same number
+        }
+        const double res = a.res[(size_t)r * ld + b], w = a.w[(size_t)r * ld + b];
+        a.nres[(size_t)r * ld + b] = (res != 0.0 && w != 0.0) ? fabs(res) / sqrt(fabs(1.0 / w - c)) : 0.0;
+    }
+}
+
+// (max, first argmax) of nres over the rows, per scenario: stage 1 per row chunk, stage 2 over the chunks
+__global__ __launch_bounds__(256) void k_gn_argmax(const double* nres, double* part_v, int* part_i, int m, int rows_per, int ld) {
+    __shared__ double rv[4][64];
+    __shared__ int rix[4][64];
+    const int lane = threadIdx.x, wave = threadIdx.y;
+    const size_t b = (size_t)blockIdx.y * 64 + lane;
+    const int r0 = blockIdx.x * rows_per, r1 = min(r0 + rows_per, m);
+    const int per = (rows_per + 3) / 4;
+    double mx = 0.0; int ix = -1;
+    for (int r = r0 + wave * per, e = min(r + per, r1); r < e; ++r) {      // contiguous rows per wave: first maximum wins
+        const double v = nres[(size_t)r * ld + b];
+        if (v > mx) { mx = v; ix = r; }
+    }
+    rv[wave][lane] = mx; rix[wave][lane] = ix;
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 1; w < 4; ++w) if (rv[w][lane] > mx) { mx = rv[w][lane]; ix = rix[w][lane]; }
+        part_v[(size_t)blockIdx.x * ld + b] = mx; part_i[(size_t)blockIdx.x * ld + b] = ix;
+    }
+}
+
+__global__ void k_gn_argmax2(const double* part_v, const int* part_i, double* out_v, int* out_i, int nchunk, int ld) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= ld) return;
+    double mx = 0.0; int ix = -1;
+    for (int c = 0; c < nchunk; ++c) { const double v = part_v[(size_t)c * ld + b]; if (v > mx) { mx = v; ix = part_i[(size_t)c * ld + b]; } }
+    out_v[b] = mx; out_i[b] = ix + 1;                            // 1-based row, 0 = every normalised residual is zero
+}
+
 struct GnCheckArgs {
     const double* part; int nchunk; int ld; int batch; const double* params;
     double* maxinc; int* active; int* iters; int* status; const int* lu_status; int* counter; int* group; int mode;
@@ -351,6 +413,11 @@ struct jg_gn {
     double* d_vm = nullptr; double* d_va = nullptr; double* d_mean = nullptr; double* d_w = nullptr;
     double* d_Hs = nullptr; double* d_res = nullptr; double* d_rhs = nullptr; double* d_inc = nullptr;
     GainItem* d_items = nullptr; int* d_cw = nullptr; int* d_ca = nullptr; int* d_cb = nullptr; int* d_blk_row = nullptr; int* d_blk_col = nullptr; int* d_dst = nullptr;
+    // bad-data test (built on first use)
+    std::vector<RowDesc> rows_host; std::vector<int> slot_bus_host;
+    int* d_pair_ptr = nullptr; int* d_pa = nullptr; int* d_pb = nullptr; int* d_pz = nullptr;
+    double* d_nres = nullptr; double* d_amax_v = nullptr; int* d_amax_i = nullptr; double* d_bad_v = nullptr; int* d_bad_i = nullptr;
+    int amax_chunks = 0;
     double* d_part = nullptr; double* d_maxinc = nullptr; double* d_params = nullptr;
     double* d_vm0 = nullptr; double* d_va0 = nullptr;   // snapshot of the start point (jg_gn_snapshot_voltage)
     int* d_active = nullptr; int* d_iters = nullptr; int* d_status = nullptr; int* d_counter = nullptr; int* d_group = nullptr;
@@ -490,6 +557,7 @@ int jg_gn_create(jg_gn** out, int64_t n, const int64_t* colptr, const int64_t* r
         rows[r] = d;
     }
     h->nslots = (int)slot_bus.size();
+    h->rows_host = rows; h->slot_bus_host = slot_bus;
     // sparse(row, col, val, m, 2n): CSC, rows ascending inside a column (rows are generated ascending)
     h->hcolptr.assign(2 * n + 1, 0);
     for (const Trip& t : trips) h->hcolptr[t.col + 1]++;
@@ -605,6 +673,8 @@ void jg_gn_destroy(jg_gn* h) {
     hipFree(h->d_rows); hipFree(h->d_slot_bus); hipFree(h->d_br); hipFree(h->d_rowptr); hipFree(h->d_G); hipFree(h->d_B); hipFree(h->d_ydiag);
     hipFree(h->d_vm0); hipFree(h->d_va0);
     hipFree(h->d_vm); hipFree(h->d_va); hipFree(h->d_mean); hipFree(h->d_w); hipFree(h->d_Hs); hipFree(h->d_res); hipFree(h->d_dst);
+    hipFree(h->d_pair_ptr); hipFree(h->d_pa); hipFree(h->d_pb); hipFree(h->d_pz); hipFree(h->d_nres); hipFree(h->d_amax_v); hipFree(h->d_amax_i);
+    hipFree(h->d_bad_v); hipFree(h->d_bad_i);
     hipFree(h->d_rhs); hipFree(h->d_inc); hipFree(h->d_items); hipFree(h->d_cw); hipFree(h->d_ca); hipFree(h->d_cb); hipFree(h->d_blk_row);
     hipFree(h->d_blk_col); hipFree(h->d_part); hipFree(h->d_maxinc); hipFree(h->d_params); hipFree(h->d_active); hipFree(h->d_iters);
     hipFree(h->d_status); hipFree(h->d_counter); hipFree(h->d_group);
@@ -780,8 +850,76 @@ int jg_gn_get_iteration(jg_gn* h, int32_t* iters) {
     return 0;
 }
 
+int jg_gn_evaluate(jg_gn* h) {
+    if (!h) return failg(1, "jg_gn_evaluate: bad argument");
+    if (int rc = set_device(h)) return rc;
+    launch_rows(h);
+    GN_HIP(hipGetLastError());
+    GN_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int jg_gn_residual_test(jg_gn* h, double* max_nres, int32_t* index) {
+    if (!h || !max_nres || !index) return failg(1, "jg_gn_residual_test: bad argument");
+    if (int rc = set_device(h)) return rc;
+    constexpr int ROWS_PER = 256;
+    if (!h->d_nres) {                                            // pair lists: every (slot, slot) of a row with its Z entry
+        const jg::BlockSymbolic& S = h->eng.S;
+        std::vector<int> pp(h->m + 1, 0), pa, pb, pz;
+        for (int r = 0; r < h->m; ++r) {
+            const RowDesc& d = h->rows_host[r];
+            for (int x = 0; x < d.nslots; ++x)
+                for (int y = x; y < d.nslots; ++y) {
+                    int sa = d.slot0 + x, sc = d.slot0 + y;
+                    int ka = S.iperm[h->slot_bus_host[sa]], kc = S.iperm[h->slot_bus_host[sc]];
+                    if (ka > kc) { std::swap(sa, sc); std::swap(ka, kc); }     // h_a Z_ac h_c' == h_c Z_ca h_a'
+                    const int e = ka == kc ? S.diag[ka] : jg::entry_of(S, ka, kc);
+                    if (e < 0 || (ka == kc && sa != sc)) return failg(1, "jg_gn_residual_test: a row's buses are not a clique of the gain pattern");
+                    pa.push_back(sa); pb.push_back(sc); pz.push_back(e);
+                }
+            pp[r + 1] = (int)pa.size();
+        }
+        if (pa.empty()) { pa.push_back(0); pb.push_back(0); pz.push_back(0); }
+        std::string err;
+        h->amax_chunks = (h->m + ROWS_PER - 1) / ROWS_PER;
+        if (jg::upload(&h->d_pair_ptr, pp, err, h->stream) || jg::upload(&h->d_pa, pa, err, h->stream) || jg::upload(&h->d_pb, pb, err, h->stream) ||
+            jg::upload(&h->d_pz, pz, err, h->stream)) return failg(2, err);
+        GN_HIP(hipMalloc((void**)&h->d_nres, (size_t)h->m * h->ld * 8));
+        GN_HIP(hipMalloc((void**)&h->d_amax_v, (size_t)h->amax_chunks * h->ld * 8));
+        GN_HIP(hipMalloc((void**)&h->d_amax_i, (size_t)h->amax_chunks * h->ld * 4));
+        GN_HIP(hipMalloc((void**)&h->d_bad_v, (size_t)h->ld * 8));
+        GN_HIP(hipMalloc((void**)&h->d_bad_i, (size_t)h->ld * 4));
+    }
+    GN_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
+    h->eng.serialize_begin(h->stream);
+    launch_rows(h);                                              // residual and Jacobian at the CURRENT state
+    launch_gain(h);
+    if (int rc = h->eng.factor(h->stream, nullptr, h->d_rhs, jg::GroupSel{})) return failg(rc, h->eng.error);
+    if (int rc = h->eng.selected_inverse(h->stream, jg::GroupSel{})) return failg(rc, h->eng.error);
+    h->eng.serialize_end(h->stream);
+    ProjArgs a{h->d_pair_ptr, h->d_pa, h->d_pb, h->d_pz, h->d_slot_bus, h->d_Hs, h->eng.Zs, h->d_res, h->d_w, h->d_nres, h->m, h->slack0, h->ld};
+    hipLaunchKernelGGL(k_gn_project, dim3((h->m + GN_ROWS - 1) / GN_ROWS, h->ld / 64), dim3(64, 4), 0, h->stream, a);
+    hipLaunchKernelGGL(k_gn_argmax, dim3(h->amax_chunks, h->ld / 64), dim3(64, 4), 0, h->stream, h->d_nres, h->d_amax_v, h->d_amax_i, h->m, ROWS_PER, h->ld);
+    hipLaunchKernelGGL(k_gn_argmax2, dim3((h->ld + 255) / 256), dim3(256), 0, h->stream, h->d_amax_v, h->d_amax_i, h->d_bad_v, h->d_bad_i, h->amax_chunks, h->ld);
+    GN_HIP(hipGetLastError());
+    GN_HIP(hipStreamSynchronize(h->stream));
+    std::vector<int> st(h->ld);
+    GN_HIP(jg::sync_copy(st.data(), h->eng.status, (size_t)h->ld * 4, hipMemcpyDeviceToHost, h->stream));
+    for (int b = 0; b < h->batch; ++b) if (st[b] & 4) return failg(3, "jg_gn_residual_test: zero or non-finite pivot (singular gain matrix)");
+    GN_HIP(jg::sync_copy(max_nres, h->d_bad_v, (size_t)h->batch * 8, hipMemcpyDeviceToHost, h->stream));
+    GN_HIP(jg::sync_copy(index, h->d_bad_i, (size_t)h->batch * 4, hipMemcpyDeviceToHost, h->stream));
+    return 0;
+}
+
+int jg_gn_get_normalized_residual(jg_gn* h, double* nres) {
+    if (!h || !nres) return failg(1, "jg_gn_get_normalized_residual: bad argument");
+    if (!h->d_nres) return failg(1, "jg_gn_get_normalized_residual: call jg_gn_residual_test first");
+    if (int rc = set_device(h)) return rc;
+    return get_rows(h, h->d_nres, nres, h->m);
+}
+
 int jg_gn_time_kernel(jg_gn* h, int kernel, int reps, double* mean_ms) {
-    if (!h || reps < 1 || !mean_ms || kernel < 0 || kernel > 3) return failg(1, "jg_gn_time_kernel: bad argument");
+    if (!h || reps < 1 || !mean_ms || kernel < 0 || kernel > 4) return failg(1, "jg_gn_time_kernel: bad argument");
     if (int rc = set_device(h)) return rc;
     hipEvent_t e0, e1;
     GN_HIP(hipEventCreate(&e0));
@@ -793,7 +931,8 @@ int jg_gn_time_kernel(jg_gn* h, int kernel, int reps, double* mean_ms) {
         if (kernel == 0) launch_rows(h);
         else if (kernel == 1) launch_gain(h);
         else if (kernel == 2) { if (int rc = h->eng.factor(h->stream, nullptr, h->d_rhs, jg::GroupSel{})) return failg(rc, h->eng.error); }
-        else { if (int rc = h->eng.backsolve(h->stream, h->d_inc, none, jg::GroupSel{})) return failg(rc, h->eng.error); }
+        else if (kernel == 3) { if (int rc = h->eng.backsolve(h->stream, h->d_inc, none, jg::GroupSel{})) return failg(rc, h->eng.error); }
+        else { if (int rc = h->eng.selected_inverse(h->stream, jg::GroupSel{})) return failg(rc, h->eng.error); }
     }
     GN_HIP(hipEventRecord(e1, h->stream));
     GN_HIP(hipEventSynchronize(e1));

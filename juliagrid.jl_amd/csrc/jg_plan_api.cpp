@@ -28,10 +28,12 @@ void jg_plan_destroy(jg_plan* p) { delete p; }
 //        10 l_ptr, 11 l_ent, 12 l_col, 13 u_ptr, 14 u_ent, 15 u_col,
 //        16 t_d, 17 y_level
 //        60 fact segments (x8), 61 fact wave records (x16), 62 bwd segments, 63 bwd records, 64 src_entry (device replay tables)
-//        18 bwd_level (row-wise), 19 chain_level (level of the backward chain / row a pivot belongs to), 65 backward chain task data, 66 / 67 forward-only segments / records
+//        18 bwd_level (row-wise), 19 chain_level (level of the backward chain / row a pivot belongs to), 65 backward chain task data, 66 / 67 forward-only segments / records,
+//        68 / 69 selected-inverse segments / records
 // out == NULL returns the length.
 int64_t jg_plan_export(jg_plan* p, int which, int32_t* out, int64_t cap) {
     if (!p) return -1;
+    if (which == 68 || which == 69) jg::build_selected_inverse(p->S);     // built on demand
     const jg::BlockSymbolic& S = p->S;
     std::vector<int> tmp;
     const std::vector<int>* v = nullptr;
@@ -52,6 +54,8 @@ int64_t jg_plan_export(jg_plan* p, int which, int32_t* out, int64_t cap) {
         case 66: tmp.assign((const int*)S.fwd_seg.data(), (const int*)S.fwd_seg.data() + S.fwd_seg.size() * 8); v = &tmp; break;
         case 67: tmp.assign((const int*)S.fwd_rec.data(), (const int*)S.fwd_rec.data() + S.fwd_rec.size() * 16); v = &tmp; break;
         case 19: v = &S.chain_level; break;
+        case 68: tmp.assign((const int*)S.sel_seg.data(), (const int*)S.sel_seg.data() + S.sel_seg.size() * 8); v = &tmp; break;
+        case 69: tmp.assign((const int*)S.sel_rec.data(), (const int*)S.sel_rec.data() + S.sel_rec.size() * 16); v = &tmp; break;
         default: return -1;
     }
     if (!out) return (int64_t)v->size();

@@ -223,6 +223,46 @@ void build_tables(BlockSymbolic& S) {
     }, max_level);
 }
 
+// Selected inverse Z = A^-1 on the pattern of the factor (Takahashi recursion, for a SYMMETRIC matrix: only the upper part
+// and the diagonal are formed, Z(k,j) with k > j is read as Z(j,k)^T):
+//   Z(i,j) = -D(i)^-1 * sum_{k in struct(i)} U(i,k) Z(k,j)            j in struct(i)           (level 2 l(i) - 1)
+//   Z(i,i) =  D(i)^-1 * (I - sum_{k in struct(i)} U(i,k) Z(i,k)^T)                              (level 2 l(i))
+// l(i) = backward-sweep level of pivot i (roots first).  Z lives in its own array with the factor's entry numbering.
+// Record: w0 target entry, w1 D(i), w2 kind (0 off-diagonal, 1 diagonal), w3 terms, then (U entry, Z entry | transpose << 30) x 6.
+int entry_of(const BlockSymbolic& S, int r, int c) { return find_in_row(S, r, c); }
+
+void build_selected_inverse(BlockSymbolic& S) {
+    if (!S.sel_seg.empty()) return;
+    const int n = S.n;
+    struct Item { int pivot, q; };                      // q = position in the U row of the pivot; -1 = the diagonal
+    std::vector<Item> items;
+    std::vector<int> level, work;
+    for (int i = 0; i < n; ++i) {
+        const int s = S.u_ptr[i + 1] - S.u_ptr[i];
+        for (int q = 0; q < s; ++q) { items.push_back(Item{i, q}); level.push_back(2 * S.bwd_level[i] - 1); work.push_back(s); }
+        items.push_back(Item{i, -1}); level.push_back(2 * S.bwd_level[i]); work.push_back(s);
+    }
+    build_replay(level, work, BWD_T, S.sel_seg, S.sel_rec, S.n_sel_levels, [&](int x, int sub, int wpi, int rpw, Rec* r) {
+        const int i = items[x].pivot, q = items[x].q;
+        const int target = q < 0 ? S.diag[i] : S.u_ent[S.u_ptr[i] + q];
+        const int j = q < 0 ? i : S.u_col[S.u_ptr[i] + q];
+        for (int t = 0; t < rpw; ++t) { r[t].w[0] = target; r[t].w[1] = S.diag[i]; r[t].w[2] = q < 0 ? 1 : 0; r[t].w[3] = 0; }
+        int c = 0;
+        for (int p = S.u_ptr[i] + sub; p < S.u_ptr[i + 1]; p += wpi, ++c) {
+            const int k = S.u_col[p];
+            int z;
+            if (q < 0) z = S.u_ent[p] | 1 << 30;                                        // Z(k,i) = Z(i,k)^T
+            else if (k == j) z = S.diag[j];
+            else if (k < j) z = find_in_row(S, k, j);
+            else z = find_in_row(S, j, k) | 1 << 30;
+            Rec& rec = r[c / BWD_T];
+            rec.w[4 + 2 * (c % BWD_T)] = S.u_ent[p];
+            rec.w[5 + 2 * (c % BWD_T)] = z;
+            rec.w[3]++;
+        }
+    });
+}
+
 int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic& S) {
     S = BlockSymbolic();
     S.inplace = policy & 1;

@@ -75,11 +75,18 @@ struct BlockSymbolic {
     std::vector<int> bwd_chain;         // chain task data (see CHAIN_MAX_ROWS)
     std::vector<int> chain_level;       // [n] backward level of the chain (or single row) a pivot belongs to
     int n_fact_levels = 0, n_bwd_levels = 0, n_fwd_levels = 0;
+    std::vector<Segment> sel_seg;       // selected inverse (built on demand: build_selected_inverse)
+    std::vector<Rec> sel_rec;
+    int n_sel_levels = 0;
 };
 
 // pattern: CSR (rowptr[n+1], col[nnz]) 0-based, must contain the diagonal and be structurally
 // symmetric. policy bit 0: in-place factor storage (see BlockSymbolic::inplace).
 // Returns 0, or 1 on a malformed pattern.
 int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic& out);
+// Replay tables of the selected inverse of a SYMMETRIC matrix on the factor pattern (see jg_symbolic.cpp); idempotent.
+void build_selected_inverse(BlockSymbolic& S);
+// entry id of block (r, c) in pivot numbering, -1 if outside the factor pattern
+int entry_of(const BlockSymbolic& S, int r, int c);
 
 }  // namespace jg

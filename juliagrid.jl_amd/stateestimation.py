@@ -413,3 +413,108 @@ def stateEstimation_(an: AcStateEstimation, iteration: int = 40, tolerance: floa
     an.status = int(st[0]) if an.batch == 1 else st
     if fetch:
         an._pull_voltage()
+
+
+# ---- bad data processing (src/stateEstimation/badData.jl) ----------------------------------------------------------------
+_FAMILY = {"v": ("Voltmeter", "voltmeter", "magnitude"), "a": ("Ammeter", "ammeter", "magnitude"),
+           "w": ("Wattmeter", "wattmeter", "active"), "r": ("Varmeter", "varmeter", "reactive"), "p": ("PMU", "pmu", None)}
+
+
+def _device_of_row(an, row0):
+    """(device position d, first row of the device) for a 0-based measurement row."""
+    d = int(np.searchsorted(an._dev_row, row0, side="right") - 1)
+    return d, int(an._dev_row[d])
+
+
+def residualTest_(an: AcStateEstimation, threshold: float = 3.0):
+    """residualTest!(analysis; threshold) (badData.jl:119-311), for every scenario of the batch.
+
+    The device recomputes residual, Jacobian, gain and its factor at the current state, forms the selected inverse of
+    the gain on its factor pattern and the normalised residuals |r_i| / sqrt(|1 / W_ii - c_i|) (jg_gn_residual_test).
+    Here: the reference's bookkeeping.  When the largest normalised residual of a scenario exceeds `threshold`, that
+    measurement leaves the scenario's model (its weight becomes 0 = removeRow + mean = residual = 0 + type = 0; both
+    rows of a rectangular PMU, :280-290 / :155-166) and the iteration counter restarts.  batch == 1 additionally sets the
+    device's status in the Measurement container, like the reference.
+    Returns a namespace (detect, maxNormalizedResidual, label, index), fields are arrays for batch > 1; index is the
+    1-based row of se.mean (0: every residual is zero)."""
+    mx = np.zeros(an.batch)
+    idx = np.zeros(an.batch, dtype=np.int32)
+    _lib.check(_lib.lib().jg_gn_residual_test(an._h, mx, idx))
+    detect = mx > threshold
+    mon, m = an.monitoring, an.dims["m"]
+    linear = isinstance(an, PmuStateEstimation)
+    labels = []
+    wd = np.array(np.broadcast_to(np.atleast_2d(an.method._wdiag), (an.batch, m)))
+    nc = an.method._corr.size
+    wo = np.array(np.broadcast_to(np.atleast_2d(an.method._woff), (an.batch, max(nc, 1)))) if nc else np.zeros((an.batch, 0))
+    mean = np.array(np.broadcast_to(np.atleast_2d(an.method.mean), (an.batch, m)))
+    changed = False
+    for b in range(an.batch):
+        if idx[b] == 0:
+            labels.append("")
+            continue
+        r = int(idx[b]) - 1
+        d, r0 = _device_of_row(an, r)
+        fam, i = an._devs[d]
+        name, field, chan = _FAMILY[fam]
+        labels.append(f"{name} {i + 1}")
+        if not detect[b]:
+            continue
+        rows = [r]
+        both = fam == "p" and (linear or not mon.pmu.layout.polar[i])
+        if both:
+            rows = [r0, r0 + 1]
+        for q in rows:
+            wd[b, q] = 0.0
+            mean[b, q] = 0.0
+        if both and nc:
+            hit = np.flatnonzero(an.method._corr - 1 == r0)
+            wo[b, hit] = 0.0
+        changed = True
+        if an.batch == 1:                                   # the Measurement container follows, like the reference
+            if fam != "p":
+                getattr(getattr(mon, field), chan).status[i] = 0
+            elif both:
+                mon.pmu.magnitude.status[i] = 0
+                mon.pmu.angle.status[i] = 0
+            elif an.method._code[r] in (2, 3, 4, 5, 12):
+                mon.pmu.magnitude.status[i] = 0
+            else:
+                mon.pmu.angle.status[i] = 0
+            for q in rows:
+                an.method.type[q] = 0
+    if changed:
+        one = an.batch == 1
+        an._upload_measurement(mean[0] if one else mean, wd[0] if one else wd, (wo[0] if one else wo) if nc else np.zeros(0))
+        an._removed = getattr(an, "_removed", np.zeros((an.batch, m), dtype=bool)) | (wd == 0.0)
+        an.method.iteration = 0
+    one = an.batch == 1
+    return NS(detect=bool(detect[0]) if one else detect, maxNormalizedResidual=float(mx[0]) if one else mx,
+              label=labels[0] if one else labels, index=int(idx[0]) if one else idx)
+
+
+def normalizedResidual(an: AcStateEstimation):
+    """All normalised residuals of the last residualTest_ call [batch, m] (the reference keeps only the largest)."""
+    r = np.zeros((an.batch, an.dims["m"]))
+    _lib.check(_lib.lib().jg_gn_get_normalized_residual(an._h, r))
+    return an._shape(r)
+
+
+def chiTest(an: AcStateEstimation, confidence: float = 0.95):
+    """chiTest(analysis; confidence) (badData.jl:948-995): objective r' W r at the current state against the
+    chi-square quantile with df = rows in service - state variables.  Returns (detect, threshold, objective)."""
+    from scipy.stats import chi2
+    _lib.check(_lib.lib().jg_gn_evaluate(an._h))
+    n = an.system.bus.number
+    dead = np.count_nonzero(an.method.type == 0)
+    gone = getattr(an, "_removed", None)
+    extra = (gone & (an.method.type != 0)[None, :]).sum(axis=1) if gone is not None and an.batch > 1 else 0
+    if isinstance(an, PmuStateEstimation):
+        df = an.method.type.size - dead - extra - 2 * n                       # se.inservice - 2 * bus.number (:992)
+    else:
+        df = an.method.type.size - dead - extra - 2 * n + 1                   # :958
+    thr = chi2.ppf(confidence, df)
+    obj = an.objective
+    if an.batch == 1:
+        return NS(detect=bool(obj >= thr), threshold=float(thr), objective=float(obj))
+    return NS(detect=obj >= thr, threshold=np.broadcast_to(thr, obj.shape).copy(), objective=obj)

@@ -730,3 +730,45 @@ class OraclePmuWLS:
         v = x[: self.n] + 1j * x[self.n:]
         self.magnitude, self.angle = np.abs(v), np.angle(v)
         return self.magnitude, self.angle
+
+
+# ---- residualTest! / chiTest restated (TEST ORACLE; src/stateEstimation/badData.jl) --------------------------------------
+def normalized_residuals(H, W, residual, slack_col=None):
+    """|r_i| / sqrt(|1 / W_ii - c_i|), c = diag(H G^-1 H'), G = H' W H (badData.jl:133-150, 200-217, rowProjection
+    :289-311) with dense linear algebra; slack_col (0-based) = column removed from H with gain[slack, slack] = 1 (:200-203).
+    Rows with a zero residual get 0 (they are skipped by the reference's argmax loop)."""
+    H = np.array(H, dtype=float)
+    if slack_col is not None:
+        H[:, slack_col] = 0.0
+    G = H.T @ W @ H
+    if slack_col is not None:
+        G[slack_col, slack_col] = 1.0
+    c = np.einsum("ij,ji->i", H, np.linalg.solve(G, H.T))
+    d = np.abs(1.0 / np.diag(W) - c)
+    out = np.zeros(H.shape[0])
+    nz = residual != 0.0
+    out[nz] = np.abs(residual[nz]) / np.sqrt(d[nz])
+    return out
+
+
+def gn_normalized_residuals(gn: "OracleGN"):
+    """residualTest!(analysis::AcStateEstimation{GaussNewton}) up to the argmax: uses se.jacobian / se.residual as the last
+    increment! left them (call gn.increment() at the state to test)."""
+    import scipy.sparse as sp
+    v = gn.vectors()
+    n = gn.sys.n
+    H = sp.csc_matrix((v["jacobian"], gn.hrowval - 1, gn.hcolptr - 1), shape=(gn.m, 2 * n)).toarray()
+    return normalized_residuals(H, gn.precision_dense(), v["residual"], slack_col=gn.sys.slack - 1)
+
+
+def pmu_normalized_residuals(p: "OraclePmuWLS"):
+    """residualTest!(analysis::PmuStateEstimation) (:119-179) up to the argmax, at the estimate p.solve() produced."""
+    x = np.concatenate([p.magnitude * np.cos(p.angle), p.magnitude * np.sin(p.angle)])
+    r = p.mean - p.coefficient @ x
+    return normalized_residuals(p.coefficient.toarray(), p.precision.toarray(), r)
+
+
+def chi_threshold(df, confidence=0.95):
+    """quantile(Chisq(df), confidence) (:960, :994)."""
+    from scipy.stats import chi2
+    return float(chi2.ppf(confidence, df))

@@ -196,6 +196,53 @@ class Replay:
         assert terms == int(self.u_ptr[-1]), "U terms lost or duplicated in the records"
         return out
 
+    def selected_inverse(self, X):
+        """Replays the selected-inverse tables (symmetric matrix): Z on the upper factor pattern + diagonal, [nE,2,2];
+        asserts that every Z block a record reads was finished in an earlier level."""
+        seg, rec = self.p.replay_tables("sel")
+        Z = np.zeros((self.nE, 2, 2))
+        level_of = np.full(self.nE, -1)
+        acc, meta = {}, {}
+
+        def flush():
+            for key, (lev, target, dg, kind) in meta.items():
+                assert level_of[target] < 0, "Z entry scheduled twice"
+                T = acc[key]
+                R = np.eye(2) - T if kind == 1 else -T
+                Z[target] = np.stack([dsolve(X[dg], R[:, 0]), dsolve(X[dg], R[:, 1])], axis=1)
+                level_of[target] = lev
+            acc.clear()
+            meta.clear()
+
+        current, terms = None, 0
+        for level, key, sub, recs in self._waves(seg, rec):
+            if level != current:
+                assert current is None or level > current
+                flush()
+                current = level
+            target = int(recs[0][0])
+            if target < 0:
+                continue
+            part = np.zeros((2, 2))
+            for r in recs:
+                assert int(r[0]) == target
+                for t in range(int(r[3])):
+                    u, z = int(r[4 + 2 * t]), int(r[5 + 2 * t])
+                    tr, z = z >> 30, z & ((1 << 30) - 1)
+                    assert 0 <= level_of[z] < level, "selected-inverse schedule race"
+                    assert self.e_row[u] == self.e_row[target] or self.e_col[target] == self.e_row[target]
+                    part += X[u] @ (Z[z].T if tr else Z[z])
+                    terms += 1
+            if sub == 0:
+                meta[key] = (level, target, int(recs[0][1]), int(recs[0][2]))
+                acc[key] = part
+            else:
+                acc[key] = acc[key] + part
+        flush()
+        upper = self.e_col >= self.e_row
+        assert (level_of[upper] >= 0).all() and (level_of[~upper] < 0).all()
+        return Z
+
     def _wpi_of(self, key):
         return int(self.bseg[key[0]][2])
 

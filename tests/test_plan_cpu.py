@@ -161,3 +161,38 @@ def test_replay_is_stable_on_ill_conditioned_gain(jg, oracle):
     xs = np.concatenate([x[:, 0], x[:, 1]])
     assert np.abs(xs - dx).max() <= 1e-6 * np.abs(dx).max()       # ~ cond * eps
     assert np.abs(xs - v["increment"]).max() <= 1e-6 * np.abs(dx).max()
+
+
+@pytest.mark.parametrize("name", ["case14test", "case118", "case1354pegase"])
+def test_selected_inverse_replay_matches_dense_inverse(jg, name):
+    """Takahashi recursion on the factor pattern (tables of the bad-data test): a random symmetric, diagonally dominant
+    block matrix on the Ybus pattern; every Z block of the upper pattern + diagonal equals the dense inverse."""
+    s = jg.powerSystem(load_case(name))
+    jg.acModel_(s)
+    Y = s.model.ac.nodalMatrix
+    n = Y.n
+    rowptr, col = (Y.colptr - 1).astype(np.int32), (Y.rowval - 1).astype(np.int32)
+    rng = np.random.default_rng(5)
+    dense = np.zeros((2 * n, 2 * n))
+    for i in range(n):
+        for p in range(rowptr[i], rowptr[i + 1]):
+            j = col[p]
+            if j > i:
+                b = rng.standard_normal((2, 2))
+                dense[2 * i:2 * i + 2, 2 * j:2 * j + 2] = b
+                dense[2 * j:2 * j + 2, 2 * i:2 * i + 2] = b.T
+    dense += np.diag(np.abs(dense).sum(axis=1) + 1.0)
+    A = np.array([dense[2 * i:2 * i + 2, 2 * col[p]:2 * col[p] + 2] for i in range(n) for p in range(rowptr[i], rowptr[i + 1])])
+    plan = jg._lib.Plan(n, rowptr, col, policy=1)
+    rp = Replay(plan, inplace=True)
+    X, _ = rp.factor(A, np.zeros((n, 2)))
+    Z = rp.selected_inverse(X)
+    inv = np.linalg.inv(dense)
+    perm, e_row, e_col = plan.get("perm"), plan.get("e_row"), plan.get("e_col")
+    worst = 0.0
+    for e in np.flatnonzero(e_col >= e_row):
+        i, j = perm[e_row[e]], perm[e_col[e]]
+        worst = max(worst, np.abs(Z[e] - inv[2 * i:2 * i + 2, 2 * j:2 * j + 2]).max())
+    assert worst <= 1e-12 * np.abs(inv).max()
+    seg, rec = plan.replay_tables("sel")
+    assert seg[-1, 4] == 2 * plan.get("bwd_level").max()
