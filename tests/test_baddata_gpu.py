@@ -138,3 +138,41 @@ def test_batch_every_scenario_finds_its_own_outlier(jg, oracle):
     chi = jg.chiTest(an)
     assert not chi.detect.any()
     an.close()
+
+
+def test_config4_scale_planted_errors_are_found(jg):
+    """BASELINE config 4 measurement set on the 9241-bus grid (~0.97e5 rows, ~1.5e5 factor blocks), 66 scenarios: scenario
+    b >= 1 carries one gross wattmeter error at a different place of the grid.  Size-independent properties: every
+    scenario flags exactly its planted row, the clean scenario flags nothing, and after removal the estimates return
+    to the power-flow state."""
+    s = jg.powerSystem("case9241synth")
+    pf = jg.newtonRaphson(s)
+    jg.powerFlow_(pf, tolerance=1e-11)
+    mon = jg.measurement(s)
+    jg.addVoltmeter_(mon, pf)
+    jg.addWattmeter_(mon, pf)
+    jg.addVarmeter_(mon, pf)
+    jg.addPmu_(mon, pf, buses=range(1, s.bus.number + 1, 10), statusTo=-1, minMagnitude=1e-6)
+    B = 66
+    an = jg.gaussNewton(mon, batch=B)
+    z1, v1, s1, z2, v2, s2 = an._z
+    n1 = np.tile(z1, (B, 1))
+    nv, nw = mon.voltmeter.number, mon.wattmeter.number
+    planted = np.zeros(B, dtype=int)
+    for b in range(1, B):
+        planted[b] = nv + (b * 641) % nw
+        n1[b, planted[b]] += 2.0                                  # 200 MW on a 100 MVA base, sigma = 0.1
+    mean, wd, wo, _ = an._values(mon, an._devs, an._dev_row, an.dims["m"], n1, v1, s1, np.tile(z2, (B, 1)), v2, s2)
+    an._upload_measurement(mean, wd, wo)
+    jg.stateEstimation_(an)
+    assert np.all(an.status == 0)
+    out = jg.residualTest_(an)
+    assert not out.detect[0] and out.maxNormalizedResidual[0] < 0.5      # rounding residue over sqrt(~0) of near-critical rows
+    assert out.detect[1:].all() and out.maxNormalizedResidual[1:].min() > 10.0
+    assert [int(i) - 1 for i in out.index[1:]] == [int(an._dev_row[p]) for p in planted[1:]]
+    jg.stateEstimation_(an, iteration=60, tolerance=1e-11)
+    assert np.all(an.status == 0)
+    assert np.abs(an.voltage.magnitude - pf.voltage.magnitude[None, :]).max() < 1e-8
+    assert np.abs(an.voltage.angle - pf.voltage.angle[None, :]).max() < 1e-8
+    assert not jg.residualTest_(an).detect.any()
+    an.close()

@@ -16,4 +16,10 @@ jg.addPmu_(mon, pf, buses=range(1, s.bus.number + 1, 10), statusTo=-1, minMagnit
 an = jg.gaussNewton(mon, batch=batch)
 print(an.dims)
 for _ in range(2):
-    print(case, batch, "rows %.4f  gain %.4f  fact %.4f  bwd %.4f ms" % tuple(an.time_kernel(k, 5) for k in (0, 1, 2, 3)))
+    print(case, batch, "rows %.4f  gain %.4f  fact %.4f  bwd %.4f  selected-inverse %.4f ms" % tuple(an.time_kernel(k, 5) for k in (0, 1, 2, 3, 4)))
+import time
+jg.stateEstimation_(an)
+t0 = time.perf_counter(); out = jg.residualTest_(an); t1 = time.perf_counter()
+print("residualTest_ wall %.2f ms (first call builds the tables), max nres %.3g" % (1e3 * (t1 - t0), float(np.max(out.maxNormalizedResidual))))
+t0 = time.perf_counter(); out = jg.residualTest_(an); t1 = time.perf_counter()
+print("residualTest_ wall %.2f ms" % (1e3 * (t1 - t0)))
