@@ -119,4 +119,13 @@ function setOutages!(a::HipPowerFlow, labels::Vector{Int64})
         a.handle.ptr, 0, length(labels), 4, ptr, dy))
 end
 
+# residualTest!(analysis; threshold) -- badData.jl:181-311: the numeric part on the device (gain, its factor, the selected
+# inverse on the factor pattern, normalised residuals, arg-max); returns (maxNormalizedResidual, index) and leaves the
+# label / status bookkeeping of the reference untouched (it follows from `index` exactly as in badData.jl:225-300).
+function largestNormalizedResidual(handle::HipHandle)
+    mx = Ref(0.0); idx = Ref{Int32}(0)
+    check(ccall((:jg_gn_residual_test, lib), Cint, (Ptr{Cvoid}, Ref{Float64}, Ref{Int32}), handle.ptr, mx, idx))
+    return mx[], Int64(idx[])
+end
+
 end # module
