@@ -215,6 +215,10 @@ int jg_gn_get_iteration(jg_gn* h, int32_t* iters);
  * |r_i| / sqrt(|1 / W_ii - c_i|) (0 where r_i == 0 or the row carries no weight in that scenario).
  * max_nres [batch], index [batch] = 1-based row of the largest one (first on ties, 0 if all are zero). */
 int jg_gn_residual_test(jg_gn* h, double* max_nres, int32_t* index);
+/* update<Meter>!(analysis; label, status) -- src/measurement/powermeter.jl:640-677 and siblings: new in-service mask,
+ * se.type = status * code; the Jacobian pattern (and every table derived from it) stays.  code (optional, NULL = keep):
+ * new type codes; only 2 <-> 4 and 3 <-> 5 may change (updateAmmeter!(...; square), ammeter.jl:367-420). */
+int jg_gn_set_status(jg_gn* h, const int8_t* status, const int8_t* code);
 /* residual and Jacobian at the CURRENT state, nothing else (se.residual for chiTest after the last solve!) */
 int jg_gn_evaluate(jg_gn* h);
 /* all normalised residuals of the last jg_gn_residual_test [batch][m] */

@@ -11,7 +11,8 @@ from .contingency import bridges, outageList, shard, contingencyAnalysis, gather
 from .measurement import (Measurement, measurement, addVoltmeter_, addAmmeter_, addWattmeter_, addVarmeter_,   # noqa: F401
                           addPmu_, exactQuantities)
 from .stateestimation import (AcStateEstimation, PmuStateEstimation, pmuStateEstimation, gaussNewton, increment_ as incrementSE_, solve_ as solveSE_,   # noqa: F401
-                              stateEstimation_, setNoise_, residualTest_, normalizedResidual, chiTest)
+                              stateEstimation_, setNoise_, residualTest_, normalizedResidual, chiTest,
+                              updateVoltmeter_, updateAmmeter_, updateWattmeter_, updateVarmeter_, updatePmu_)
 from .synthetic import pegaseShaped, case9241synth                          # noqa: F401
 from . import powerflow, stateestimation   # noqa: F401
 from . import _lib                                                           # noqa: F401
@@ -21,6 +22,7 @@ __all__ = [
     "mismatch_", "solve_", "powerFlow_", "setInitialPoint_", "updateBranch_", "setOutage_", "setInjection_",
     "Measurement", "measurement", "addVoltmeter_", "addAmmeter_", "addWattmeter_", "addVarmeter_", "addPmu_",
     "exactQuantities", "AcStateEstimation", "PmuStateEstimation", "pmuStateEstimation", "gaussNewton", "incrementSE_", "solveSE_", "stateEstimation_", "setNoise_", "residualTest_", "normalizedResidual", "chiTest",
+    "updateVoltmeter_", "updateAmmeter_", "updateWattmeter_", "updateVarmeter_", "updatePmu_",
     "outagePatch", "initializeACPowerFlow", "bridges", "outageList", "shard", "contingencyAnalysis", "gatherResults",
     "pegaseShaped", "case9241synth", "ContingencyPipeline", "setOutages_", "power_", "current_", "reactiveLimit_", "adjustAngle_",
 ]

@@ -82,6 +82,7 @@ def lib():
         "jg_gn_residual_test": [VP, F64P, I32P],
         "jg_gn_get_normalized_residual": [VP, F64P],
         "jg_gn_evaluate": [VP],
+        "jg_gn_set_status": [VP, I8P, I8P],
         "jg_gn_run": [VP, C.c_int64, C.c_double, I32P, I32P],
         "jg_gn_get_maps": [VP, I8P, I64P, I64P],
         "jg_gn_get_jacobian": [VP, F64P],

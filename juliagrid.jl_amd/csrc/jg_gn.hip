@@ -404,7 +404,7 @@ struct jg_gn {
     std::vector<int64_t> hcolptr, hrowval;      // reference CSC pattern of H (1-based)
     std::vector<int64_t> hmap;                  // CSC nz -> slot*2 + comp
     std::vector<int> gi_rowptr, gi_col;         // gain block CSR
-    std::vector<int8_t> type;
+    std::vector<int8_t> type, code;
     std::vector<int> corr_row;
     int n_items = 0;
     // device
@@ -513,6 +513,7 @@ int jg_gn_create(jg_gn** out, int64_t n, const int64_t* colptr, const int64_t* r
     std::vector<RowDesc> rows(m);
     std::vector<int> slot_bus;
     h->type.assign(m, 0);
+    h->code.assign(code, code + m);
     struct Trip { int64_t row, col; int slotcomp; };
     std::vector<Trip> trips;
     for (int64_t r = 0; r < m; ++r) {
@@ -847,6 +848,25 @@ int jg_gn_get_iteration(jg_gn* h, int32_t* iters) {
     if (int rc = set_device(h)) return rc;
     GN_HIP(hipStreamSynchronize(h->stream));
     GN_HIP(jg::sync_copy(iters, h->d_iters, (size_t)h->batch * 4, hipMemcpyDeviceToHost, h->stream));
+    return 0;
+}
+
+int jg_gn_set_status(jg_gn* h, const int8_t* status, const int8_t* code) {
+    if (!h || !status) return failg(1, "jg_gn_set_status: bad argument");
+    for (int r = 0; r < h->m; ++r) if (status[r] != 0 && status[r] != 1) return failg(1, "jg_gn_set_status: status must be 0 or 1");
+    if (code) {                                                 // magnitude <-> squared magnitude of a current: same two slots
+        auto cls = [](int c) { return c == 4 ? 2 : (c == 5 ? 3 : c); };
+        for (int r = 0; r < h->m; ++r)
+            if (cls(code[r]) != cls(h->code[r])) return failg(1, "jg_gn_set_status: a type code may only switch between a current magnitude and its square");
+        h->code.assign(code, code + h->m);
+    }
+    if (int rc = set_device(h)) return rc;
+    for (int r = 0; r < h->m; ++r) {                            // se.type = status * code; the pattern keeps every row
+        h->type[r] = (int8_t)(status[r] * h->code[r]);
+        h->rows_host[r].type = h->type[r];
+    }
+    GN_HIP(hipStreamSynchronize(h->stream));
+    GN_HIP(jg::sync_copy(h->d_rows, h->rows_host.data(), h->rows_host.size() * sizeof(RowDesc), hipMemcpyHostToDevice, h->stream));
     return 0;
 }
 

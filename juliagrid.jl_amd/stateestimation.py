@@ -518,3 +518,72 @@ def chiTest(an: AcStateEstimation, confidence: float = 0.95):
     if an.batch == 1:
         return NS(detect=bool(obj >= thr), threshold=float(thr), objective=float(obj))
     return NS(detect=obj >= thr, threshold=np.broadcast_to(thr, obj.shape).copy(), objective=obj)
+
+
+# ---- update<Meter>!(monitoring | analysis; label, ...) (src/measurement/*.jl) -------------------------------------------
+def _refresh(an: AcStateEstimation):
+    """The analysis follows its Measurement container (powermeter.jl:640-677, voltmeter.jl:258-290, ammeter.jl:367-420,
+    pmu.jl:559-700): se.type = status * code, se.mean, se.precision; the Jacobian pattern stays.  For batch > 1 every
+    scenario restarts from the container's readings (noise realisations of setNoise_ are dropped)."""
+    z = an._raw(an.monitoring)
+    an._z = z
+    code = an._layout(an.monitoring)[0]
+    mean, wdiag, woff, status = an._values(an.monitoring, an._devs, an._dev_row, an.dims["m"], *z)
+    _lib.check(_lib.lib().jg_gn_set_status(an._h, np.ascontiguousarray(status, dtype=np.int8), code))
+    an.method._code = code
+    an.method.type = (status * code).astype(np.int8)
+    an._upload_measurement(mean, wdiag, woff)
+    an._removed = None
+
+
+def _update(target, family, label, channels, layout=None):
+    """channels: {gauss field: (mean, variance, status)}; label = 1-based device number inside its family;
+    layout: {layout flag: new value or None}."""
+    mon = target.monitoring if isinstance(target, AcStateEstimation) else target
+    meter = getattr(mon, family)
+    i = int(label) - 1
+    if not 0 <= i < meter.number:
+        raise KeyError(f"The {family} labelled {label} does not exist.")
+    for flag, value in (layout or {}).items():
+        if value is not None:
+            getattr(meter.layout, flag)[i] = bool(value)
+    for field, (mean, variance, status) in channels.items():
+        g = getattr(meter, field)
+        if mean is not None:
+            g.mean[i] = float(mean)
+        if variance is not None:
+            g.variance[i] = float(variance)
+        if status is not None:
+            if status not in (0, 1):
+                raise ValueError("status must be 0 or 1")
+            g.status[i] = int(status)
+    if isinstance(target, AcStateEstimation):
+        _refresh(target)
+
+
+def updateVoltmeter_(target, label, magnitude=None, variance=None, status=None):
+    """updateVoltmeter!(monitoring | analysis; label, magnitude, variance, status) (voltmeter.jl:194-290)."""
+    _update(target, "voltmeter", label, {"magnitude": (magnitude, variance, status)})
+
+
+def updateAmmeter_(target, label, magnitude=None, variance=None, status=None, square=None):
+    """updateAmmeter!(...) (ammeter.jl:293-420); `square` switches between the magnitude and its square."""
+    _update(target, "ammeter", label, {"magnitude": (magnitude, variance, status)}, {"square": square})
+
+
+def updateWattmeter_(target, label, active=None, variance=None, status=None):
+    """updateWattmeter!(...) (powermeter.jl:561-677)."""
+    _update(target, "wattmeter", label, {"active": (active, variance, status)})
+
+
+def updateVarmeter_(target, label, reactive=None, variance=None, status=None):
+    """updateVarmeter!(...) (powermeter.jl:822-940)."""
+    _update(target, "varmeter", label, {"reactive": (reactive, variance, status)})
+
+
+def updatePmu_(target, label, magnitude=None, angle=None, varianceMagnitude=None, varianceAngle=None,
+               statusMagnitude=None, statusAngle=None, status=None):
+    """updatePmu!(...) (pmu.jl:435-700); `status` sets both channels."""
+    sm = status if statusMagnitude is None else statusMagnitude
+    sa = status if statusAngle is None else statusAngle
+    _update(target, "pmu", label, {"magnitude": (magnitude, varianceMagnitude, sm), "angle": (angle, varianceAngle, sa)})
