@@ -4,9 +4,10 @@ Host-side mirror of the JuliaGrid interface for the hot path only (see DESIGN.md
 in libjgrid_hip.so (hand-written HIP for gfx950) through the C ABI of include/jgrid.h.
 """
 from .system import PowerSystem, CscMatrix, powerSystem, acModel_          # noqa: F401
-from .system import updateBranch_ as updateBranchSystem_                   # noqa: F401
+from .system import (updateBranch_ as updateBranchSystem_, updateBus_ as updateBusSystem_,   # noqa: F401
+                     updateGenerator_ as updateGeneratorSystem_)
 from .powerflow import (AcPowerFlow, newtonRaphson, fastNewtonRaphsonBX, fastNewtonRaphsonXB, mismatch_, solve_, powerFlow_, setInitialPoint_,   # noqa: F401
-                        updateBranch_, setOutage_, setOutages_, setInjection_, outagePatch, initializeACPowerFlow, power_, current_, reactiveLimit_, adjustAngle_)
+                        updateBranch_, updateBus_, updateGenerator_, setOutage_, setOutages_, setInjection_, outagePatch, initializeACPowerFlow, power_, current_, reactiveLimit_, adjustAngle_)
 from .contingency import bridges, outageList, shard, contingencyAnalysis, gatherResults, ContingencyPipeline   # noqa: F401
 from .measurement import (Measurement, measurement, addVoltmeter_, addAmmeter_, addWattmeter_, addVarmeter_,   # noqa: F401
                           addPmu_, exactQuantities)
@@ -18,7 +19,7 @@ from . import powerflow, stateestimation   # noqa: F401
 from . import _lib                                                           # noqa: F401
 
 __all__ = [
-    "PowerSystem", "CscMatrix", "powerSystem", "acModel_", "updateBranchSystem_", "AcPowerFlow", "newtonRaphson", "fastNewtonRaphsonBX", "fastNewtonRaphsonXB",
+    "PowerSystem", "CscMatrix", "powerSystem", "acModel_", "updateBranchSystem_", "updateBusSystem_", "updateGeneratorSystem_", "updateBus_", "updateGenerator_", "AcPowerFlow", "newtonRaphson", "fastNewtonRaphsonBX", "fastNewtonRaphsonXB",
     "mismatch_", "solve_", "powerFlow_", "setInitialPoint_", "updateBranch_", "setOutage_", "setInjection_",
     "Measurement", "measurement", "addVoltmeter_", "addAmmeter_", "addWattmeter_", "addVarmeter_", "addPmu_",
     "exactQuantities", "AcStateEstimation", "PmuStateEstimation", "pmuStateEstimation", "gaussNewton", "incrementSE_", "solveSE_", "stateEstimation_", "setNoise_", "residualTest_", "normalizedResidual", "chiTest",

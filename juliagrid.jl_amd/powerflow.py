@@ -23,7 +23,8 @@ from types import SimpleNamespace as NS
 import numpy as np
 
 from . import _lib
-from .system import CscMatrix, PowerSystem, acModel_, updateBranch_ as _update_branch_system
+from .system import (CscMatrix, PowerSystem, acModel_, updateBranch_ as _update_branch_system,
+                     updateBus_ as _update_bus_system, updateGenerator_ as _update_generator_system)
 
 
 def _reim(z):
@@ -342,12 +343,49 @@ def _upload_ybus(an: AcPowerFlow):
     _lib.check(_lib.lib().jg_nr_set_ybus(an._h, _reim(ac.nodalMatrix.nzval), _reim(ac.nodalMatrixTranspose.nzval)))
 
 
-def updateBranch_(an: AcPowerFlow, label: int, status: int | None = None):
-    """updateBranch!(analysis; label, status): edits the system (stored zeros keep the pattern, so the
-    symbolic analysis is reused exactly like the reference's `lu!` path) and syncs the device copy."""
-    _update_branch_system(an.system, label, status=status)
+def updateBranch_(an: AcPowerFlow, label: int, status: int | None = None, **parameters):
+    """updateBranch!(analysis; label, status, resistance, reactance, conductance, susceptance, turnsRatio, shiftAngle)
+    (branch.jl:453-463): edits the system (stored zeros keep the pattern, so the symbolic analysis is reused exactly like
+    the reference's `lu!` path) and syncs the device copy of the nodal matrix."""
+    _update_branch_system(an.system, label, status=status, **parameters)
     _upload_ybus(an)
+    an._branches_on_device = False                                       # power!/current! re-upload the branch table
     an.method.signature.topology = an.system.model.revision.topology     # syncTopology! branch.jl:461-463
+    _refresh_fast(an)
+
+
+def _refresh_fast(an: AcPowerFlow):
+    """fast Newton-Raphson keeps two CONSTANT matrices: after a change of the grid they are rebuilt and refactorised
+    (the reference patches them entry by entry and calls lu! again, acPowerFlow.jl:476-537)."""
+    if not getattr(an.method, "fast", False):
+        return
+    P, Q, _, _, bp, bq = _fast_model(an.system, an.method.bx)
+    _lib.check(_lib.lib().jg_nr_fast_setup(an._h, np.ascontiguousarray(bp), np.ascontiguousarray(bq)))
+    an.method.active.jacobian, an.method.reactive.jacobian = P, Q
+
+
+def updateBus_(an: AcPowerFlow, label: int, **kwargs):
+    """updateBus!(analysis; label, active, reactive, conductance, susceptance, magnitude, angle) (bus.jl:343-420):
+    demand -> injections, shunt -> nodal matrix diagonal; magnitude / angle are start values (setInitialPoint_)."""
+    _update_bus_system(an.system, label, **kwargs)
+    if "conductance" in kwargs or "susceptance" in kwargs:
+        _upload_ybus(an)
+        _refresh_fast(an)
+    if "active" in kwargs or "reactive" in kwargs:
+        setInjection_(an)
+
+
+def updateGenerator_(an: AcPowerFlow, label: int, **kwargs):
+    """updateGenerator!(analysis; label, status, active, reactive, magnitude) (generator.jl:382-408): supply ->
+    injections; a generator bus that would lose its last unit needs a new analysis (errorTypeConversion)."""
+    sysm = an.system
+    k = int(label) - 1
+    if 0 <= k < sysm.generator.number and kwargs.get("status") == 0 and sysm.generator.layout.status[k] == 1:
+        i = int(sysm.generator.layout.bus[k])
+        if sysm.bus.layout.type[i - 1] in (2, 3) and sysm.bus.supply.generator.get(i, []) == [k + 1]:
+            raise RuntimeError("The power flow model cannot be reused due to required bus type conversion.")
+    _update_generator_system(sysm, label, **kwargs)
+    setInjection_(an)
 
 
 def outagePatch(system: PowerSystem, label: int):

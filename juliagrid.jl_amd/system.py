@@ -280,12 +280,13 @@ def _ac_nodal_update(system: PowerSystem, k: int, sign: float) -> None:
     system.model.revision.acModel += 1
 
 
-def updateBranch_(system: PowerSystem, label: int, status: int | None = None) -> None:
-    """updateBranch!(system; label, status): status toggles only (branch.jl:313-431).
+def updateBranch_(system: PowerSystem, label: int, status: int | None = None, resistance=None, reactance=None,
+                  conductance=None, susceptance=None, turnsRatio=None, shiftAngle=None) -> None:
+    """updateBranch!(system; label, status, resistance, reactance, conductance, susceptance, turnsRatio, shiftAngle)
+    (branch.jl:313-431).
 
-    Outage (:344-350): subtract the stamps (pattern kept -> stored zeros), zero the two-port
-    parameters.  Re-close (:381-386): recompute the parameters, add the stamps.
-    """
+    A branch in service first leaves the nodal matrix with its OLD two-port stamps (:344-350; the pattern keeps stored
+    zeros), the parameters change, and a branch that ends up in service re-enters with the new stamps (:381-386)."""
     k = int(label) - 1
     if not 0 <= k < system.branch.number:
         raise KeyError(f"The branch label {label} that has been specified does not exist.")
@@ -293,14 +294,20 @@ def updateBranch_(system: PowerSystem, label: int, status: int | None = None) ->
     new = old if status is None else int(status)
     if new not in (0, 1):
         raise ValueError("The status 0 or 1 is required.")
+    par = system.branch.parameter
+    edits = dict(resistance=resistance, reactance=reactance, conductance=conductance, susceptance=susceptance,
+                 turnsRatio=turnsRatio, shiftAngle=shiftAngle)
+    changed = any(v is not None for v in edits.values())
     ac = system.model.ac
     has = ac.nodalMatrix is not None
-    if has and old == 1 and new == 0:
+    if has and old == 1 and (new == 0 or changed):
         _ac_nodal_update(system, k, -1.0)
         for a in (ac.nodalFromFrom, ac.nodalFromTo, ac.nodalToTo, ac.nodalToFrom, ac.admittance):
             a[k] = 0.0
-    if has and new == 1 and old == 0:
-        par = system.branch.parameter
+    for name, v in edits.items():
+        if v is not None:
+            getattr(par, name)[k] = float(v)
+    if has and new == 1 and (old == 0 or changed):
         y, yff, yft, ytt, ytf = _branch_two_port(par.resistance[k:k + 1], par.reactance[k:k + 1],
                                                  par.conductance[k:k + 1], par.susceptance[k:k + 1],
                                                  par.turnsRatio[k:k + 1], par.shiftAngle[k:k + 1])
@@ -308,5 +315,71 @@ def updateBranch_(system: PowerSystem, label: int, status: int | None = None) ->
         ac.nodalToTo[k], ac.nodalToFrom[k] = ytt[0], ytf[0]
         _ac_nodal_update(system, k, +1.0)
     system.branch.layout.status[k] = new
-    if new != old:
-        system.model.revision.topology += 1
+
+
+def updateBus_(system: PowerSystem, label: int, active=None, reactive=None, conductance=None, susceptance=None,
+               magnitude=None, angle=None) -> None:
+    """updateBus!(system; label, active, reactive, conductance, susceptance, magnitude, angle) (bus.jl:230-330): demand,
+    shunt (the nodal matrix diagonal follows, :286-296) and the initial voltage.  Bus TYPE changes need a new analysis
+    in the reference too (errorTypeConversion) and are not offered here."""
+    if int(label) not in system.bus.label:
+        raise KeyError(f"The bus label {label} that has been specified does not exist.")
+    i = system.bus.label[int(label)] - 1
+    bus = system.bus
+    if active is not None:
+        bus.demand.active[i] = float(active)
+    if reactive is not None:
+        bus.demand.reactive[i] = float(reactive)
+    if conductance is not None or susceptance is not None:
+        ac = system.model.ac
+        g = bus.shunt.conductance[i] if conductance is None else float(conductance)
+        b = bus.shunt.susceptance[i] if susceptance is None else float(susceptance)
+        if ac.nodalMatrix is not None:
+            d = (g - bus.shunt.conductance[i]) + 1j * (b - bus.shunt.susceptance[i])
+            ac.nodalMatrix.nzval[ac.nodalMatrix.position(i + 1, i + 1)] += d
+            ac.nodalMatrixTranspose.nzval[ac.nodalMatrixTranspose.position(i + 1, i + 1)] += d
+            system.model.revision.acModel += 1
+        bus.shunt.conductance[i], bus.shunt.susceptance[i] = g, b
+    if magnitude is not None:
+        bus.voltage.magnitude[i] = float(magnitude)
+    if angle is not None:
+        bus.voltage.angle[i] = float(angle)
+
+
+def updateGenerator_(system: PowerSystem, label: int, status: int | None = None, active=None, reactive=None,
+                     magnitude=None) -> None:
+    """updateGenerator!(system; label, status, active, reactive, magnitude) (generator.jl:262-360): the bus supply and
+    the per-bus generator lists follow the status and the outputs."""
+    k = int(label) - 1
+    gen, bus = system.generator, system.bus
+    if not 0 <= k < gen.number:
+        raise KeyError(f"The generator label {label} that has been specified does not exist.")
+    old = int(gen.layout.status[k])
+    new = old if status is None else int(status)
+    if new not in (0, 1):
+        raise ValueError("The status 0 or 1 is required.")
+    i = int(gen.layout.bus[k])
+    output = active is not None or reactive is not None
+    if old == 1:
+        if new == 0 or output:
+            bus.supply.active[i - 1] -= gen.output.active[k]
+            bus.supply.reactive[i - 1] -= gen.output.reactive[k]
+        if new == 0:
+            bus.supply.generator[i].remove(k + 1)
+            if not bus.supply.generator[i]:
+                del bus.supply.generator[i]
+    if active is not None:
+        gen.output.active[k] = float(active)
+    if reactive is not None:
+        gen.output.reactive[k] = float(reactive)
+    if new == 1:
+        if old == 0 or output:
+            bus.supply.active[i - 1] += gen.output.active[k]
+            bus.supply.reactive[i - 1] += gen.output.reactive[k]
+        if old == 0:
+            lst = bus.supply.generator.setdefault(i, [])
+            lst.append(k + 1)
+            lst.sort()
+    gen.layout.status[k] = new
+    if magnitude is not None:
+        gen.voltage.magnitude[k] = float(magnitude)
