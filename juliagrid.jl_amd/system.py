@@ -315,6 +315,8 @@ def updateBranch_(system: PowerSystem, label: int, status: int | None = None, re
         ac.nodalToTo[k], ac.nodalToFrom[k] = ytt[0], ytf[0]
         _ac_nodal_update(system, k, +1.0)
     system.branch.layout.status[k] = new
+    if new != old:
+        system.model.revision.topology += 1
 
 
 def updateBus_(system: PowerSystem, label: int, active=None, reactive=None, conductance=None, susceptance=None,
