@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <iterator>
 #include <queue>
+#include <cstdio>
 #include <cstdlib>
 #include <numeric>
 
@@ -41,8 +42,11 @@ void elimination_order(int n, const std::vector<std::vector<int>>& adj0, std::ve
         for (int a : nb) for (int w : adj[a]) if (mark[w] == stamp) ++present;
         return d * (d - 1) / 2 - present / 2;
     };
+    long long wf = 4, wh = 3, wd = 0;                          // experiments: JG_ORDER="fill,height,degree" weights
+    if (const char* e = getenv("JG_ORDER")) { long long a, b, c; if (sscanf(e, "%lld,%lld,%lld", &a, &b, &c) == 3) { wf = a; wh = b; wd = c; } }
     auto key = [&](int v) -> long long {                       // score, then degree, packed (degree < 2^20)
-        return ((4 * fill_of(v) + 3 * (long long)hv[v]) << 20) | (long long)std::min<size_t>(adj[v].size(), (1u << 20) - 1);
+        const long long d = (long long)adj[v].size();
+        return ((wf * fill_of(v) + wh * (long long)hv[v] + wd * d) << 20) | std::min<long long>(d, (1 << 20) - 1);
     };
     typedef std::pair<long long, int> Entry;
     std::priority_queue<Entry, std::vector<Entry>, std::greater<Entry>> heap;
