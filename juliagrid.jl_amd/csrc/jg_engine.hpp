@@ -54,9 +54,12 @@ struct GroupSel {
 // Workgroup -> (scenario group, work chunk) with the group as the FAST index of a 1-D grid.  Workgroup b lands on
 // XCD b % 8 (MI355X_MICROARCH.md, dispatch), so with 8 | groups every XCD -- and its private 4 MiB L2 -- serves only
 // the groups congruent to it: operands re-read by many items of one group stay in ONE L2 instead of eight.
-// groups < 8 are rounded to a power of two so a group still maps to a fixed subset of XCDs.
+// groups < 8 are rounded to a power of two so a group still maps to a fixed subset of XCDs.  More than 8 groups: a
+// multiple of 8 keeps the pinning (group g on XCD g % 8); any other count is NOT padded (padding 9 groups to 16 slots
+// gave one XCD two groups and the others one: 1.79 -> 2.83 ms) -- workgroup (x, slot) then lands on XCD
+// (x * groups + slot) % 8, which rotates a group over the XCDs and balances them.
 __host__ __device__ inline int group_stride(int groups) {
-    return groups >= 8 ? (groups + 7) & ~7 : (groups <= 1 ? 1 : (groups <= 2 ? 2 : (groups <= 4 ? 4 : 8)));
+    return groups >= 8 ? groups : (groups <= 1 ? 1 : (groups <= 2 ? 2 : (groups <= 4 ? 4 : 8)));
 }
 
 #ifdef __HIPCC__
