@@ -80,7 +80,9 @@ __device__ __forceinline__ void fact_record(const FactArgs& a, const RecS& r, in
 #pragma unroll
     for (int t = 0; t < FACT_T; ++t) {
         if (t < nt) {
-            l[t] = load_blk(a.X, (size_t)rec_word(r, 4 + 3 * t), b, ld);
+            const int ia = rec_word(r, 4 + 3 * t);              // bit 30: read the block transposed (symmetric matrices: Lh(i,k) = U(k,i)')
+            l[t] = load_blk(a.X, (size_t)(ia & 0x3fffffff), b, ld);
+            if (ia >> 30) { const double x = l[t].v01; l[t].v01 = l[t].v10; l[t].v10 = x; }
             d[t] = load_blk(a.X, (size_t)rec_word(r, 5 + 3 * t), b, ld);
             if (kind == 3) {
                 const double2 w = load_vec(a.W, (size_t)rec_word(r, 6 + 3 * t), b, ld);

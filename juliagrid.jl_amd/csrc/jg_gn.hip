@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void k_gn_rows(RowArgs a) {
 struct GainItem { int kind; int id; int c0; int c1; };   // kind 0: gain block id (CSR order), 1: rhs row (bus)
 struct GainArgs {
     const GainItem* items; const int* cw; const int* ca; const int* cb;   // contribution: weight idx, slot, slot | row
-    const int* blk_row; const int* blk_col; const int* blk_mirror; const int* dst;   // dst: gain block -> entry of the factor storage (assembled in place)
+    const int* blk_row; const int* blk_col; const int* dst;   // dst: gain block -> entry of the factor storage (assembled in place)
     const double* Hs; const double* res; const double* w;
     double* Gv; double* rhs;
     int n_items; int slack; int ld;
@@ -254,7 +254,6 @@ __global__ __launch_bounds__(256) void k_gn_gain(GainArgs a) {
             if (j == a.slack) { g00 = 0.0; g10 = 0.0; }
             if (i == a.slack && j == a.slack) g00 = 1.0;         // gain[slack, slack] = 1 (:889)
             jg::store_blk(a.Gv, (size_t)uniform(a.dst[id]), b, ld, g00, g01, g10, g11);
-            if (i != j) jg::store_blk(a.Gv, (size_t)uniform(a.dst[uniform(a.blk_mirror[id])]), b, ld, g00, g10, g01, g11);   // G is symmetric: G(j,i) = G(i,j)'
 
         } else {
             double r0 = 0.0, r1 = 0.0;
@@ -414,7 +413,7 @@ struct jg_gn {
     int* d_rowptr = nullptr; double* d_G = nullptr; double* d_B = nullptr; int* d_ydiag = nullptr;
     double* d_vm = nullptr; double* d_va = nullptr; double* d_mean = nullptr; double* d_w = nullptr;
     double* d_Hs = nullptr; double* d_res = nullptr; double* d_rhs = nullptr; double* d_inc = nullptr;
-    GainItem* d_items = nullptr; int* d_cw = nullptr; int* d_ca = nullptr; int* d_cb = nullptr; int* d_blk_row = nullptr; int* d_blk_col = nullptr; int* d_blk_mirror = nullptr; int* d_dst = nullptr;
+    GainItem* d_items = nullptr; int* d_cw = nullptr; int* d_ca = nullptr; int* d_cb = nullptr; int* d_blk_row = nullptr; int* d_blk_col = nullptr; int* d_dst = nullptr;
     // bad-data test (built on first use)
     std::vector<RowDesc> rows_host; std::vector<int> slot_bus_host;
     int* d_pair_ptr = nullptr; int* d_pa = nullptr; int* d_pb = nullptr; int* d_pz = nullptr;
@@ -440,7 +439,7 @@ void launch_rows(jg_gn* h) {
 }
 
 void launch_gain(jg_gn* h) {
-    GainArgs a{h->d_items, h->d_cw, h->d_ca, h->d_cb, h->d_blk_row, h->d_blk_col, h->d_blk_mirror, h->d_dst, h->d_Hs, h->d_res, h->d_w, h->eng.X, h->d_rhs,
+    GainArgs a{h->d_items, h->d_cw, h->d_ca, h->d_cb, h->d_blk_row, h->d_blk_col, h->d_dst, h->d_Hs, h->d_res, h->d_w, h->eng.X, h->d_rhs,
                h->n_items, h->slack0, h->ld};
     hipLaunchKernelGGL(k_gn_gain, dim3((h->n_items + 15) / 16, h->ld / 64), dim3(64, 4), 0, h->stream, a);
 }
@@ -590,10 +589,7 @@ int jg_gn_create(jg_gn** out, int64_t n, const int64_t* colptr, const int64_t* r
     for (int r = 0; r < m; ++r) {
         const RowDesc& d = rows[r];
         for (int a = 0; a < d.nslots; ++a) {
-            for (int b2 = 0; b2 < d.nslots; ++b2) {
-                auto& lst = gmap[{slot_bus[d.slot0 + a], slot_bus[d.slot0 + b2]}];          // the block exists on both sides of the diagonal,
-                if (slot_bus[d.slot0 + a] <= slot_bus[d.slot0 + b2]) lst.push_back({r, d.slot0 + a, d.slot0 + b2});   // only the upper one is gathered
-            }
+            for (int b2 = 0; b2 < d.nslots; ++b2) gmap[{slot_bus[d.slot0 + a], slot_bus[d.slot0 + b2]}].push_back({r, d.slot0 + a, d.slot0 + b2});
             rmap[slot_bus[d.slot0 + a]].push_back({r, d.slot0 + a, r});
         }
         if (pair_of[r] >= 0) {                                                    // 2x2 precision block of a correlated PMU
@@ -601,34 +597,44 @@ int jg_gn_create(jg_gn** out, int64_t n, const int64_t* colptr, const int64_t* r
             const int wq = (int)m + pair_of[r];
             for (int a = 0; a < d.nslots; ++a)
                 for (int b2 = 0; b2 < e.nslots; ++b2) {
-                    const int ba = slot_bus[d.slot0 + a], bb = slot_bus[e.slot0 + b2];
-                    auto& up = gmap[{ba, bb}];
-                    auto& lo = gmap[{bb, ba}];
-                    if (ba <= bb) up.push_back({wq, d.slot0 + a, e.slot0 + b2});
-                    if (bb <= ba) lo.push_back({wq, e.slot0 + b2, d.slot0 + a});
+                    gmap[{slot_bus[d.slot0 + a], slot_bus[e.slot0 + b2]}].push_back({wq, d.slot0 + a, e.slot0 + b2});
+                    gmap[{slot_bus[e.slot0 + b2], slot_bus[d.slot0 + a]}].push_back({wq, e.slot0 + b2, d.slot0 + a});
                 }
             for (int a = 0; a < d.nslots; ++a) rmap[slot_bus[d.slot0 + a]].push_back({wq, d.slot0 + a, r + 1});
             for (int b2 = 0; b2 < e.nslots; ++b2) rmap[slot_bus[e.slot0 + b2]].push_back({wq, e.slot0 + b2, r});
         }
     }
-    std::vector<GainItem> items;
-    std::vector<int> cw, ca, cb, blk_row, blk_col, blk_mirror;
+    // gain pattern -> symbolic analysis (the engine must exist before the gather lists: a symmetric engine reads only the
+    // blocks on and above the diagonal IN PIVOT ORDER, so only those are gathered)
+    std::vector<int> blk_row, blk_col;
     h->gi_rowptr.assign(n + 1, 0);
-    std::map<std::pair<int, int>, int> id_of;
-    for (const auto& kv : gmap) { const int id = (int)id_of.size(); id_of[kv.first] = id; }
     for (const auto& kv : gmap) {
-        const int id = (int)blk_row.size();
         blk_row.push_back(kv.first.first); blk_col.push_back(kv.first.second);
-        blk_mirror.push_back(id_of.at({kv.first.second, kv.first.first}));
         h->gi_rowptr[kv.first.first + 1]++;
         h->gi_col.push_back(kv.first.second);
-        if (kv.first.first > kv.first.second) continue;                          // the lower block is the transpose of its mirror
-        GainItem it{0, id, (int)cw.size(), 0};
-        for (const Contrib& c : kv.second) { cw.push_back(c.w); ca.push_back(c.a); cb.push_back(c.b); }
-        it.c1 = (int)cw.size();
-        items.push_back(it);
     }
     for (int i = 0; i < n; ++i) h->gi_rowptr[i + 1] += h->gi_rowptr[i];
+    int rc = set_device(h);
+    if (rc) { delete h; return rc; }
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return failg(2, "jg_gn_create: stream creation failed"); }
+    // in place (k_gn_gain writes into the factor storage) + symmetric (the factorisation reads U(k,i)' for Lh(i,k): LDL'
+    // with half the update terms)
+    rc = h->eng.create((int)n, h->gi_rowptr.data(), h->gi_col.data(), h->ld, 3, h->stream);
+    if (rc) { std::string msg = h->eng.error; jg_gn_destroy(h); return failg(rc, msg); }
+    const std::vector<int>& ip = h->eng.S.iperm;
+    std::vector<GainItem> items;
+    std::vector<int> cw, ca, cb;
+    {
+        int id = 0;
+        for (const auto& kv : gmap) {
+            const int this_id = id++;
+            if (ip[kv.first.first] > ip[kv.first.second]) continue;              // below the diagonal in pivot order: never read
+            GainItem it{0, this_id, (int)cw.size(), 0};
+            for (const Contrib& c : kv.second) { cw.push_back(c.w); ca.push_back(c.a); cb.push_back(c.b); }
+            it.c1 = (int)cw.size();
+            items.push_back(it);
+        }
+    }
     for (int i = 0; i < n; ++i) {
         GainItem it{1, i, (int)cw.size(), 0};
         for (const Contrib& c : rmap[i]) { cw.push_back(c.w); ca.push_back(c.a); cb.push_back(c.b); }
@@ -645,15 +651,11 @@ int jg_gn_create(jg_gn** out, int64_t n, const int64_t* colptr, const int64_t* r
         br[k] = BranchP{p[0], p[1], 0.5 * p[2], 0.5 * p[3], 1.0 / p[4], p[5], (int)(from[k] - 1), (int)(to[k] - 1), 0.0};
     }
     // ---- device -------------------------------------------------------------------------------------
-    int rc = set_device(h);
-    if (rc) { delete h; return rc; }
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return failg(2, "jg_gn_create: stream creation failed"); }
     std::string err;
     if (jg::upload(&h->d_rows, rows, err, h->stream) || jg::upload(&h->d_slot_bus, slot_bus, err, h->stream) || jg::upload(&h->d_br, br, err, h->stream) ||
         jg::upload(&h->d_rowptr, rp, err, h->stream) || jg::upload(&h->d_G, G, err, h->stream) || jg::upload(&h->d_B, B, err, h->stream) || jg::upload(&h->d_ydiag, ydiag, err, h->stream) ||
         jg::upload(&h->d_items, items, err, h->stream) || jg::upload(&h->d_cw, cw, err, h->stream) || jg::upload(&h->d_ca, ca, err, h->stream) || jg::upload(&h->d_cb, cb, err, h->stream) ||
-        jg::upload(&h->d_blk_row, blk_row, err, h->stream) || jg::upload(&h->d_blk_col, blk_col, err, h->stream) ||
-        jg::upload(&h->d_blk_mirror, blk_mirror, err, h->stream)) {
+        jg::upload(&h->d_blk_row, blk_row, err, h->stream) || jg::upload(&h->d_blk_col, blk_col, err, h->stream)) {
         jg_gn_destroy(h); return failg(2, err);
     }
     const size_t ld = h->ld;
@@ -670,8 +672,6 @@ int jg_gn_create(jg_gn** out, int64_t n, const int64_t* colptr, const int64_t* r
     if (!ok || hipHostMalloc((void**)&h->h_counter, sizeof(int)) != hipSuccess) {
         jg_gn_destroy(h); return failg(2, "jg_gn_create: device allocation failed");
     }
-    rc = h->eng.create((int)n, h->gi_rowptr.data(), h->gi_col.data(), h->ld, 1, h->stream);     // in place: k_gn_gain writes into the factor storage
-    if (rc) { std::string msg = h->eng.error; jg_gn_destroy(h); return failg(rc, msg); }
     if (jg::upload(&h->d_dst, h->eng.S.src_entry, err, h->stream)) { jg_gn_destroy(h); return failg(2, err); }
     *out = h;
     return 0;
@@ -686,7 +686,7 @@ void jg_gn_destroy(jg_gn* h) {
     h->eng.destroy();
     hipFree(h->d_rows); hipFree(h->d_slot_bus); hipFree(h->d_br); hipFree(h->d_rowptr); hipFree(h->d_G); hipFree(h->d_B); hipFree(h->d_ydiag);
     hipFree(h->d_vm0); hipFree(h->d_va0);
-    hipFree(h->d_vm); hipFree(h->d_va); hipFree(h->d_mean); hipFree(h->d_w); hipFree(h->d_Hs); hipFree(h->d_res); hipFree(h->d_dst); hipFree(h->d_blk_mirror);
+    hipFree(h->d_vm); hipFree(h->d_va); hipFree(h->d_mean); hipFree(h->d_w); hipFree(h->d_Hs); hipFree(h->d_res); hipFree(h->d_dst);
     hipFree(h->d_pair_ptr); hipFree(h->d_pa); hipFree(h->d_pb); hipFree(h->d_pz); hipFree(h->d_nres); hipFree(h->d_amax_v); hipFree(h->d_amax_i);
     hipFree(h->d_bad_v); hipFree(h->d_bad_i);
     hipFree(h->d_rhs); hipFree(h->d_inc); hipFree(h->d_items); hipFree(h->d_cw); hipFree(h->d_ca); hipFree(h->d_cb); hipFree(h->d_blk_row);

@@ -147,9 +147,14 @@ void build_tables(BlockSymbolic& S) {
     const int nE = S.n_entries, n = S.n;
     // factorisation + fused forward elimination
     std::vector<int> level(nE + n), work(nE + n);
+    // symmetric matrices (policy bit 1): Lh(i,k) = U(k,i)' -- the lower entries are neither computed nor stored; a term
+    // names U(k,i) with the TRANSPOSE bit (bit 30) where it would read Lh(i,k).  Half the update terms.
+    const bool sym = S.symmetric != 0;
+    auto lower_operand = [&](int e) { return sym ? (find_in_row(S, S.e_col[e], S.e_row[e]) | 1 << 30) : e; };
     for (int e = 0; e < nE; ++e) {
         level[e] = S.e_level[e]; work[e] = S.t_ptr[e + 1] - S.t_ptr[e];
         if (S.inplace && work[e] == 0 && S.e_row[e] != S.e_col[e] && S.e_src[e] >= 0) level[e] = 0;   // already in place
+        if (sym && S.e_row[e] > S.e_col[e]) level[e] = 0;
     }
     for (int r = 0; r < n; ++r) { level[nE + r] = S.y_level[r]; work[nE + r] = S.l_ptr[r + 1] - S.l_ptr[r]; }
     auto fill_fact = [&](int it, int sub, int wpi, int rpw, Rec* r) {
@@ -165,8 +170,8 @@ void build_tables(BlockSymbolic& S) {
         for (int t = t0 + sub; t < t1; t += wpi, ++q) {
             Rec& x = r[q / FACT_T];
             const int s = 4 + 3 * (q % FACT_T);
-            if (it < nE) { x.w[s] = S.t_a[t]; x.w[s + 1] = S.t_d[t]; x.w[s + 2] = S.t_b[t]; }
-            else { x.w[s] = S.l_ent[t]; x.w[s + 1] = S.diag[S.l_col[t]]; x.w[s + 2] = S.l_col[t]; }
+            if (it < nE) { x.w[s] = lower_operand(S.t_a[t]); x.w[s + 1] = S.t_d[t]; x.w[s + 2] = S.t_b[t]; }
+            else { x.w[s] = lower_operand(S.l_ent[t]); x.w[s + 1] = S.diag[S.l_col[t]]; x.w[s + 2] = S.l_col[t]; }
             x.w[3]++;
         }
     };
@@ -291,6 +296,7 @@ void build_selected_inverse(BlockSymbolic& S) {
 int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic& S) {
     S = BlockSymbolic();
     S.inplace = policy & 1;
+    S.symmetric = (policy >> 1) & 1;
     S.n = n;
     if (n <= 0) return 1;
     // adjacency without the diagonal; verify structural symmetry and diagonal presence

@@ -69,6 +69,7 @@ struct BlockSymbolic {
     // storage (entry src_entry[p] for block p), so off-diagonal entries without update terms need no work at all and
     // are not scheduled; FactRec.src then names the entry itself.
     int inplace = 0;
+    int symmetric = 0;                  // policy bit 1: the matrix is symmetric, Lh(i,k) = U(k,i)' is read through the upper entry
     std::vector<int> src_entry;         // [nnz of the caller's pattern] -> entry id
     std::vector<Segment> fact_seg, bwd_seg, fwd_seg;    // fwd: the forward elimination alone (rhs rows of the fact tables)
     std::vector<Rec> fact_rec, bwd_rec, fwd_rec;
@@ -81,7 +82,8 @@ struct BlockSymbolic {
 };
 
 // pattern: CSR (rowptr[n+1], col[nnz]) 0-based, must contain the diagonal and be structurally
-// symmetric. policy bit 0: in-place factor storage (see BlockSymbolic::inplace).
+// symmetric. policy bit 0: in-place factor storage (see BlockSymbolic::inplace); bit 1: symmetric VALUES (LDL' by
+// reading U(k,i)' for Lh(i,k): half the update terms; only the blocks on and above the diagonal must be assembled).
 // Returns 0, or 1 on a malformed pattern.
 int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic& out);
 // Replay tables of the selected inverse of a SYMMETRIC matrix on the factor pattern (see jg_symbolic.cpp); idempotent.

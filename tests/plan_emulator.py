@@ -34,7 +34,7 @@ class Replay:
     """inplace=True mirrors policy bit 0: the caller's blocks already sit in the factor storage and
     off-diagonal entries without update terms are not scheduled at all."""
 
-    def __init__(self, plan, inplace=False):
+    def __init__(self, plan, inplace=False, symmetric=False):
         self.p = plan
         g = plan.get
         self.perm, self.e_row, self.e_col, self.e_src = g("perm"), g("e_row"), g("e_col"), g("e_src")
@@ -43,6 +43,7 @@ class Replay:
         self.nE = self.e_row.size
         self.n = plan.n
         self.inplace = inplace
+        self.symmetric = symmetric      # policy bit 1: only the upper entries are scheduled (LDL' through transposed reads)
         self.fseg, self.frec = plan.replay_tables("fact")
         self.bseg, self.brec = plan.replay_tables("bwd")
 
@@ -108,21 +109,30 @@ class Replay:
                 assert (int(r[0]), int(r[1])) == (kind, ident), "continuation record of another item"
                 for t in range(int(r[3])):
                     a, d, b = (int(v) for v in r[4 + 3 * t: 7 + 3 * t])
+                    tr, a = a >> 30, a & ((1 << 30) - 1)          # symmetric plans read Lh(i,k) as U(k,i)'
                     assert 0 <= level_of[a] < level and 0 <= level_of[d] < level, "LU schedule race"
+                    La = X[a].T if tr else X[a]
                     if kind == 3:
                         assert 0 <= level_of[nE + b] < level, "forward schedule race"
-                        part -= X[a] @ dsolve(X[d], Y[b])
+                        part -= La @ dsolve(X[d], Y[b])
                     else:
                         assert 0 <= level_of[b] < level, "LU schedule race"
-                        part -= X[a] @ dsolve(X[d], X[b])
+                        part -= La @ dsolve(X[d], X[b])
             acc[key] = acc[key] + part            # the leader (sub 0) comes first and seeds the accumulator
         flush()
         terms_seen = 0
         for r in self.frec:
             if r[0] >= 0:
                 terms_seen += int(r[3])
-        assert terms_seen == int(self.t_ptr[-1]) + int(self.l_ptr[-1]), "update terms lost or duplicated in the records"
-        assert (level_of >= 0).all(), "items missing from the factorisation schedule"
+        work = np.diff(self.t_ptr)
+        if self.symmetric:
+            lower = self.e_row > self.e_col
+            assert (level_of[:nE][lower] <= 0).all(), "a symmetric plan must not schedule the lower entries"
+            assert terms_seen == int(work[~lower].sum()) + int(self.l_ptr[-1])
+            assert (level_of[:nE][~lower] >= 0).all() and (level_of[nE:] >= 0).all()
+        else:
+            assert terms_seen == int(self.t_ptr[-1]) + int(self.l_ptr[-1]), "update terms lost or duplicated in the records"
+            assert (level_of >= 0).all(), "items missing from the factorisation schedule"
         return X, Y
 
     def backsolve(self, X, Y):

@@ -163,8 +163,9 @@ def test_replay_is_stable_on_ill_conditioned_gain(jg, oracle):
     assert np.abs(xs - v["increment"]).max() <= 1e-6 * np.abs(dx).max()
 
 
+@pytest.mark.parametrize("symmetric", [False, True])
 @pytest.mark.parametrize("name", ["case14test", "case118", "case1354pegase"])
-def test_selected_inverse_replay_matches_dense_inverse(jg, name):
+def test_selected_inverse_replay_matches_dense_inverse(jg, name, symmetric):
     """Takahashi recursion on the factor pattern (tables of the bad-data test): a random symmetric, diagonally dominant
     block matrix on the Ybus pattern; every Z block of the upper pattern + diagonal equals the dense inverse."""
     s = jg.powerSystem(load_case(name))
@@ -183,9 +184,12 @@ def test_selected_inverse_replay_matches_dense_inverse(jg, name):
                 dense[2 * j:2 * j + 2, 2 * i:2 * i + 2] = b.T
     dense += np.diag(np.abs(dense).sum(axis=1) + 1.0)
     A = np.array([dense[2 * i:2 * i + 2, 2 * col[p]:2 * col[p] + 2] for i in range(n) for p in range(rowptr[i], rowptr[i + 1])])
-    plan = jg._lib.Plan(n, rowptr, col, policy=1)
-    rp = Replay(plan, inplace=True)
-    X, _ = rp.factor(A, np.zeros((n, 2)))
+    plan = jg._lib.Plan(n, rowptr, col, policy=3 if symmetric else 1)
+    rp = Replay(plan, inplace=True, symmetric=symmetric)
+    rhs = rng.standard_normal((n, 2))
+    X, Yf = rp.factor(A, rhs)
+    xs = rp.backsolve(X, Yf)                                     # LDL' through transposed reads solves the system too
+    assert np.abs(xs.reshape(-1) - np.linalg.solve(dense, rhs.reshape(-1))).max() <= 1e-12
     Z = rp.selected_inverse(X)
     inv = np.linalg.inv(dense)
     perm, e_row, e_col = plan.get("perm"), plan.get("e_row"), plan.get("e_col")
