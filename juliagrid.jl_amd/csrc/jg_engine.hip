@@ -716,17 +716,19 @@ void Engine::destroy() {
     X = W = nullptr;
 }
 
+// Walks of different handles form ONE chain per process: wait for the previous walk's event, enqueue, record the
+// event again -- atomically with respect to other host threads (the mutex is held from begin to end; use WalkTurn).
 void Engine::serialize_begin(hipStream_t st) {
     if (!walker || device < 0 || device >= 64) return;
-    std::lock_guard<std::mutex> lk(g_walk_mu);
+    g_walk_mu.lock();
     if (g_walk_ev[device]) hipStreamWaitEvent(st, g_walk_ev[device], 0);
 }
 
 void Engine::serialize_end(hipStream_t st) {
     if (!walker || device < 0 || device >= 64) return;
-    std::lock_guard<std::mutex> lk(g_walk_mu);
-    if (!g_walk_ev[device] && hipEventCreateWithFlags(&g_walk_ev[device], hipEventDisableTiming) != hipSuccess) { g_walk_ev[device] = nullptr; return; }
-    hipEventRecord(g_walk_ev[device], st);
+    if (g_walk_ev[device] || hipEventCreateWithFlags(&g_walk_ev[device], hipEventDisableTiming) == hipSuccess) hipEventRecord(g_walk_ev[device], st);
+    else g_walk_ev[device] = nullptr;
+    g_walk_mu.unlock();
 }
 
 int Engine::walk_status(hipStream_t st) {

@@ -143,6 +143,14 @@ struct Engine {
     size_t factor_bytes() const { return (size_t)S.n_entries * 4 * ld * sizeof(double); }
     // 0 ok; 2 + error text when a walk stalled (a workgroup never became resident, e.g. another process holds CUs)
     int walk_status(hipStream_t st);
+    // scope of one enqueue of walks on `st` (serialize_begin ... serialize_end even on early returns)
+    struct WalkTurn {
+        Engine& e; hipStream_t st;
+        WalkTurn(Engine& e_, hipStream_t st_) : e(e_), st(st_) { e.serialize_begin(st); }
+        ~WalkTurn() { e.serialize_end(st); }
+        WalkTurn(const WalkTurn&) = delete;
+        WalkTurn& operator=(const WalkTurn&) = delete;
+    };
     // Walks of different handles must not overlap on one device (each needs every CU): the owner brackets whatever
     // it submits (graph launch or direct calls) with these; they chain the streams through one per-device event.
     void serialize_begin(hipStream_t st);

@@ -757,9 +757,10 @@ int jg_gn_increment(jg_gn* h, double* maxinc) {
     if (!h) return failg(1, "jg_gn_increment: bad argument");
     if (int rc = set_device(h)) return rc;
     GN_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
-    h->eng.serialize_begin(h->stream);
-    if (int rc = launch_increment(h, nullptr)) return rc;
-    h->eng.serialize_end(h->stream);
+    {
+        jg::Engine::WalkTurn turn(h->eng, h->stream);
+        if (int rc = launch_increment(h, nullptr)) return rc;
+    }
     launch_check(h, 0);
     GN_HIP(hipGetLastError());
     GN_HIP(hipStreamSynchronize(h->stream));
@@ -804,9 +805,10 @@ int jg_gn_run(jg_gn* h, int64_t max_iter, double tol, int32_t* iters, int32_t* s
     GN_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
     GN_HIP(hipMemsetAsync(h->d_group, 0xff, (size_t)(h->ld / 64) * sizeof(int), h->stream));
     for (int64_t it = 0; it <= max_iter; ++it) {                                   // :1303
-        h->eng.serialize_begin(h->stream);
-        GN_HIP(hipGraphLaunch(h->exec, h->stream));
-        h->eng.serialize_end(h->stream);
+        {
+            jg::Engine::WalkTurn turn(h->eng, h->stream);
+            GN_HIP(hipGraphLaunch(h->exec, h->stream));
+        }
         GN_HIP(hipStreamSynchronize(h->stream));
         if (*h->h_counter == 0) break;
     }
@@ -924,12 +926,13 @@ int jg_gn_residual_test(jg_gn* h, double* max_nres, int32_t* index) {
         GN_HIP(hipMalloc((void**)&h->d_bad_i, (size_t)h->ld * 4));
     }
     GN_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
-    h->eng.serialize_begin(h->stream);
-    launch_rows(h);                                              // residual and Jacobian at the CURRENT state
-    launch_gain(h);
-    if (int rc = h->eng.factor(h->stream, nullptr, h->d_rhs, jg::GroupSel{})) return failg(rc, h->eng.error);
-    if (int rc = h->eng.selected_inverse(h->stream, jg::GroupSel{})) return failg(rc, h->eng.error);
-    h->eng.serialize_end(h->stream);
+    {
+        jg::Engine::WalkTurn turn(h->eng, h->stream);
+        launch_rows(h);                                              // residual and Jacobian at the CURRENT state
+        launch_gain(h);
+        if (int rc = h->eng.factor(h->stream, nullptr, h->d_rhs, jg::GroupSel{})) return failg(rc, h->eng.error);
+        if (int rc = h->eng.selected_inverse(h->stream, jg::GroupSel{})) return failg(rc, h->eng.error);
+    }
     ProjArgs a{h->d_pair_ptr, h->d_pa, h->d_pb, h->d_pz, h->d_slot_bus, h->d_Hs, h->eng.Zs, h->d_res, h->d_w, h->d_nres, h->m, h->slack0, h->ld};
     hipLaunchKernelGGL(k_gn_project, dim3((h->m + GN_ROWS - 1) / GN_ROWS, h->ld / 64), dim3(64, 4), 0, h->stream, a);
     hipLaunchKernelGGL(k_gn_argmax, dim3(h->amax_chunks, h->ld / 64), dim3(64, 4), 0, h->stream, h->d_nres, h->d_amax_v, h->d_amax_i, h->m, ROWS_PER, h->ld);

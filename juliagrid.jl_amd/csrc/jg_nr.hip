@@ -828,11 +828,12 @@ int jg_nr_solve(jg_nr* h) {
     if (int rc = set_device(h)) return rc;
     if (!h->jac_valid) launch_assemble(h);
     NR_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
-    h->eng.serialize_begin(h->stream);
-    if (int rc = h->eng.factor(h->stream, nullptr, h->d_F, jg::GroupSel{})) return fail(rc, h->eng.error);
-    jg::StateUpdate upd{h->d_va, h->d_vm, h->d_flags, nullptr, -1.0};
-    if (int rc = h->eng.backsolve(h->stream, h->d_inc, upd, jg::GroupSel{})) return fail(rc, h->eng.error);
-    h->eng.serialize_end(h->stream);
+    {
+        jg::Engine::WalkTurn turn(h->eng, h->stream);
+        if (int rc = h->eng.factor(h->stream, nullptr, h->d_F, jg::GroupSel{})) return fail(rc, h->eng.error);
+        jg::StateUpdate upd{h->d_va, h->d_vm, h->d_flags, nullptr, -1.0};
+        if (int rc = h->eng.backsolve(h->stream, h->d_inc, upd, jg::GroupSel{})) return fail(rc, h->eng.error);
+    }
     hipLaunchKernelGGL(k_add_iter, dim3((h->ld + 255) / 256), dim3(256), 0, h->stream, h->d_iters, h->ld);
     NR_HIP(hipGetLastError());
     NR_HIP(hipStreamSynchronize(h->stream));
@@ -876,9 +877,10 @@ int jg_nr_run(jg_nr* h, int64_t max_iter, double tol, int32_t* iters, int32_t* s
                     *h->h_counter, cf[2], h->ld / 64, cf[0] ? " (compacted)" : "");
         }
         if (*h->h_counter == 0) break;
-        h->eng.serialize_begin(h->stream);
-        NR_HIP(hipGraphLaunch(h->execB, h->stream));
-        h->eng.serialize_end(h->stream);
+        {
+            jg::Engine::WalkTurn turn(h->eng, h->stream);
+            NR_HIP(hipGraphLaunch(h->execB, h->stream));
+        }
     }
     launch_compact(h, 1);                                                      // lanes back to their home order
     NR_HIP(hipGetLastError());
@@ -1188,16 +1190,17 @@ int jg_nr_time_kernel(jg_nr* h, int kernel, int reps, double* mean_ms) {
     NR_HIP(hipEventCreate(&e1));
     jg::StateUpdate none{};
     NR_HIP(hipStreamSynchronize(h->stream));
-    h->eng.serialize_begin(h->stream);
-    NR_HIP(hipEventRecord(e0, h->stream));
-    for (int r = 0; r < reps; ++r) {
-        if (kernel == 0) launch_assemble(h);
-        else if (kernel == 1) { if (int rc = h->eng.factor(h->stream, nullptr, h->d_F, jg::GroupSel{})) return fail(rc, h->eng.error); }
-        else if (kernel == 3) hipLaunchKernelGGL(k_branch_quantities, dim3((h->nb + 15) / 16, h->ld / 64), dim3(64, 16), 0, h->stream, ba);
-        else { if (int rc = h->eng.backsolve(h->stream, h->d_inc, none, jg::GroupSel{})) return fail(rc, h->eng.error); }
+    {
+        jg::Engine::WalkTurn turn(h->eng, h->stream);
+        NR_HIP(hipEventRecord(e0, h->stream));
+        for (int r = 0; r < reps; ++r) {
+            if (kernel == 0) launch_assemble(h);
+            else if (kernel == 1) { if (int rc = h->eng.factor(h->stream, nullptr, h->d_F, jg::GroupSel{})) return fail(rc, h->eng.error); }
+            else if (kernel == 3) hipLaunchKernelGGL(k_branch_quantities, dim3((h->nb + 15) / 16, h->ld / 64), dim3(64, 16), 0, h->stream, ba);
+            else { if (int rc = h->eng.backsolve(h->stream, h->d_inc, none, jg::GroupSel{})) return fail(rc, h->eng.error); }
+        }
+        NR_HIP(hipEventRecord(e1, h->stream));
     }
-    NR_HIP(hipEventRecord(e1, h->stream));
-    h->eng.serialize_end(h->stream);
     NR_HIP(hipEventSynchronize(e1));
     float ms = 0.f;
     NR_HIP(hipEventElapsedTime(&ms, e0, e1));
