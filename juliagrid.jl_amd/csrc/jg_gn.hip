@@ -700,7 +700,7 @@ void jg_gn_destroy(jg_gn* h) {
 int jg_gn_dims(jg_gn* h, int64_t* dims) {
     if (!h || !dims) return failg(1, "jg_gn_dims: bad argument");
     dims[0] = h->m; dims[1] = h->nnzH; dims[2] = (int64_t)h->gi_col.size(); dims[3] = h->eng.S.n_entries;
-    dims[4] = h->eng.S.n_terms; dims[5] = (int64_t)h->eng.fact.size(); dims[6] = (int64_t)h->eng.bwd.size();
+    dims[4] = h->eng.S.n_sched_terms; dims[5] = (int64_t)h->eng.fact.size(); dims[6] = (int64_t)h->eng.bwd.size();
     dims[7] = h->nslots;
     return 0;
 }

@@ -669,7 +669,7 @@ void jg_nr_destroy(jg_nr* h) {
 
 int jg_nr_dims(jg_nr* h, int64_t* dims) {
     if (!h || !dims) return fail(1, "jg_nr_dims: bad argument");
-    dims[0] = h->dimJ; dims[1] = h->nnzJ; dims[2] = h->eng.S.n_entries; dims[3] = h->eng.S.n_terms;
+    dims[0] = h->dimJ; dims[1] = h->nnzJ; dims[2] = h->eng.S.n_entries; dims[3] = h->eng.S.n_sched_terms;
     dims[4] = (int64_t)h->eng.fact.size();
     dims[5] = (int64_t)h->eng.bwd.size();
     return 0;

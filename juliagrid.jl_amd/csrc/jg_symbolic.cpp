@@ -175,6 +175,8 @@ void build_tables(BlockSymbolic& S) {
             x.w[3]++;
         }
     };
+    S.n_sched_terms = 0;
+    for (int it = 0; it < nE + n; ++it) if (level[it] > 0) S.n_sched_terms += work[it];
     build_replay(level, work, FACT_T, S.fact_seg, S.fact_rec, S.n_fact_levels, fill_fact);
     // forward elimination ALONE (factor once, solve many: fast decoupled power flow): the rhs rows only, levelled on
     // each other (every factor entry is final)

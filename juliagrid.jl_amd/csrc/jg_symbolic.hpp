@@ -65,6 +65,8 @@ struct BlockSymbolic {
     std::vector<int> u_ptr, u_ent, u_col;   // x_k = Dinv_k (y_k - sum_c U(k,c) x_c)
     std::vector<int> y_level, bwd_level;
     long long n_terms = 0;
+    long long n_sched_terms = 0;        // update terms the factorisation launches actually execute (entries + rhs rows; half of
+                                        // the entry terms in symmetric mode)
     // replay tables (see above).  policy bit 0 ("in place"): the caller assembles its blocks straight into the factor
     // storage (entry src_entry[p] for block p), so off-diagonal entries without update terms need no work at all and
     // are not scheduled; FactRec.src then names the entry itself.
