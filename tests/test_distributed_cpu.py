@@ -64,7 +64,7 @@ WORKER = textwrap.dedent("""
     assert t.item() == world and c.item() == int((all_ids % 4 + 2).sum())
     dist.barrier()
     dist.destroy_process_group()
-    sys.stdout.write("rank %d ok\n" % rank)          # ONE write: the two ranks share the pipe
+    sys.stdout.write("rank %d ok" % rank + chr(10))          # ONE write: the two ranks share the pipe
     sys.stdout.flush()
 """)
 
