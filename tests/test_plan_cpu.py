@@ -200,3 +200,61 @@ def test_selected_inverse_replay_matches_dense_inverse(jg, name, symmetric):
     assert worst <= 1e-12 * np.abs(inv).max()
     seg, rec = plan.replay_tables("sel")
     assert seg[-1, 4] == 2 * plan.get("bwd_level").max()
+
+
+def _solve_with_plan(jg, n, edges, rng, symmetric=False):
+    adj = {(i, i) for i in range(n)} | {(a, b) for a, b in edges} | {(b, a) for a, b in edges}
+    rowptr, col = [0], []
+    for i in range(n):
+        cols = sorted(j for (r, j) in adj if r == i)
+        col += cols
+        rowptr.append(len(col))
+    rowptr, col = np.array(rowptr, dtype=np.int32), np.array(col, dtype=np.int32)
+    dense = np.zeros((2 * n, 2 * n))
+    for i in range(n):
+        for p in range(rowptr[i], rowptr[i + 1]):
+            j = col[p]
+            if not symmetric or j >= i:
+                b = rng.standard_normal((2, 2))
+                dense[2 * i:2 * i + 2, 2 * j:2 * j + 2] = b
+                if symmetric and j > i:
+                    dense[2 * j:2 * j + 2, 2 * i:2 * i + 2] = b.T
+    if symmetric:
+        dense = (dense + dense.T) / 2
+    dense += np.diag(np.abs(dense).sum(axis=1) + 1.0)
+    A = np.array([dense[2 * i:2 * i + 2, 2 * col[p]:2 * col[p] + 2] for i in range(n) for p in range(rowptr[i], rowptr[i + 1])])
+    plan = jg._lib.Plan(n, rowptr, col, policy=3 if symmetric else 1)
+    assert sorted(plan.get("perm")) == list(range(n))
+    rp = Replay(plan, inplace=True, symmetric=symmetric)
+    rhs = rng.standard_normal((n, 2))
+    X, Yf = rp.factor(A, rhs)
+    x = rp.backsolve(X, Yf)
+    assert np.abs(x.reshape(-1) - np.linalg.solve(dense, rhs.reshape(-1))).max() <= 1e-11
+    return plan
+
+
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_ordering_and_tables_on_degenerate_graphs(jg, symmetric):
+    """One bus, isolated buses, islands, a path, a star, a complete graph, a ladder, random sparse graphs: the greedy
+    minimum-fill / height ordering and every replay table must stay valid (checked by replaying a solve)."""
+    rng = np.random.default_rng(11)
+    cases = [
+        (1, []),
+        (3, []),                                                             # three isolated buses
+        (6, [(0, 1), (1, 2), (3, 4)]),                                       # two islands + one isolated bus
+        (12, [(i, i + 1) for i in range(11)]),                               # path
+        (9, [(0, i) for i in range(1, 9)]),                                  # star: the hub must go last
+        (8, [(i, j) for i in range(8) for j in range(i + 1, 8)]),            # complete graph
+        (20, [(i, i + 1) for i in range(0, 19)] + [(i, i + 10) for i in range(10)]),
+    ]
+    for _ in range(4):
+        n = int(rng.integers(15, 60))
+        m = int(rng.integers(n, 3 * n))
+        cases.append((n, [tuple(sorted(rng.choice(n, 2, replace=False))) for _ in range(m)]))
+    for n, edges in cases:
+        plan = _solve_with_plan(jg, n, edges, rng, symmetric)
+        if n == 9 and len(edges) == 8:
+            assert plan.get("perm")[-1] == 0 and plan.get("e_row").size == 9 + 16      # no fill on the star
+        if n == 12 and len(edges) == 11:                                                 # path: the height penalty trades a little fill
+            assert plan.get("e_row").size <= 12 + 22 + 12                                # for a shallower tree (dissection, not a chain)
+            assert plan.replay_tables("fact")[0][-1, 4] < 12
