@@ -16,13 +16,14 @@ void build_tables(BlockSymbolic& S);
 namespace {
 
 // Elimination order of the (small, sparse) bus graph: greedy MINIMUM LOCAL FILL with a height penalty.
-//   score(v) = 4 * fill(v) + 3 * h(v)      fill(v) = pairs of alive neighbours of v that are not adjacent yet,
+//   score(v) = 20 * fill(v) + h(v)^2       fill(v) = pairs of alive neighbours of v that are not adjacent yet,
 //                                          h(v)    = longest chain of already eliminated vertices hanging below v
-// (ties: smaller degree, then smaller index => deterministic).  Against exact minimum degree this gives 20 % fewer
-// update terms AND a third fewer dependency levels on transmission grids (ACTIVSg10k: 293k -> 237k terms, elimination
-// tree height 152 -> 101; 9241-bus PEGASE-shaped grid: 87k -> 79k, 97 -> 64): the fill term does what minimum degree
+// (ties: smaller degree, then smaller index => deterministic).  Against exact minimum degree this gives ~15-20 % fewer
+// update terms AND 40 % fewer dependency levels on transmission grids (ACTIVSg10k: 293k -> 248k terms, elimination
+// tree height 152 -> 84; 9241-bus PEGASE-shaped grid: 87k -> 80k, 97 -> 58): the fill term does what minimum degree
 // approximates, the height term stops the greedy choice from growing one long chain when an equally cheap vertex in a
-// shallow part of the graph is available.  Both numbers are what the device pays for: terms are HBM traffic, levels are
+// shallow part of the graph is available (quadratic: free near the leaves, decisive near the top; a linear penalty
+// 4 fill + 3 h gave 237k terms / 101 levels).  Both numbers are what the device pays for: terms are HBM traffic, levels are
 // dependent launches.  Returns the order and, for every eliminated vertex, its alive neighbourhood at elimination time
 // (= the off-diagonal structure of that pivot row/column of the factor).  Cost: O(sum over eliminations of
 // |two-hop neighbourhood| * degree^2) -- 0.1 s for 10 000 buses.
@@ -42,11 +43,14 @@ void elimination_order(int n, const std::vector<std::vector<int>>& adj0, std::ve
         for (int a : nb) for (int w : adj[a]) if (mark[w] == stamp) ++present;
         return d * (d - 1) / 2 - present / 2;
     };
-    long long wf = 4, wh = 3, wd = 0;                          // experiments: JG_ORDER="fill,height,degree" weights
-    if (const char* e = getenv("JG_ORDER")) { long long a, b, c; if (sscanf(e, "%lld,%lld,%lld", &a, &b, &c) == 3) { wf = a; wh = b; wd = c; } }
+    long long wf = 20, wh = 0, wd = 0, wq = 1;                 // experiments: JG_ORDER="fill,height,degree,height^2" weights
+    if (const char* e = getenv("JG_ORDER")) {
+        long long a, b, c, q;
+        if (sscanf(e, "%lld,%lld,%lld,%lld", &a, &b, &c, &q) == 4) { wf = a; wh = b; wd = c; wq = q; }
+    }
     auto key = [&](int v) -> long long {                       // score, then degree, packed (degree < 2^20)
-        const long long d = (long long)adj[v].size();
-        return ((wf * fill_of(v) + wh * (long long)hv[v] + wd * d) << 20) | std::min<long long>(d, (1 << 20) - 1);
+        const long long d = (long long)adj[v].size(), h = hv[v];
+        return ((wf * fill_of(v) + wh * h + wd * d + wq * h * h) << 20) | std::min<long long>(d, (1 << 20) - 1);
     };
     typedef std::pair<long long, int> Entry;
     std::priority_queue<Entry, std::vector<Entry>, std::greater<Entry>> heap;
@@ -82,6 +86,49 @@ void elimination_order(int n, const std::vector<std::vector<int>>& adj0, std::ve
         for (int u : touched) { cur[u] = key(u); heap.push(Entry(cur[u], u)); }
         strct[k] = std::move(nb);
     }
+}
+
+// Postorder of the elimination tree (any topological order of the tree gives the same fill and the same levels): the
+// pivots of a subtree become consecutive, and a child that forms a supernode with its parent (nested structure) is
+// visited LAST, so parent = child + 1 -- that is what the backward-chain detection in build_tables looks for.  The
+// greedy order interleaves subtrees and hides most chains.
+void postorder(std::vector<int>& order, std::vector<std::vector<int>>& strct) {
+    const int n = (int)order.size();
+    std::vector<int> pos(n), parent(n, -1);
+    int maxv = 0;
+    for (int v : order) maxv = std::max(maxv, v);
+    std::vector<int> where(maxv + 1, -1);
+    for (int k = 0; k < n; ++k) where[order[k]] = k;
+    for (int k = 0; k < n; ++k)
+        for (int u : strct[k]) { const int p = where[u]; if (parent[k] < 0 || p < parent[k]) parent[k] = p; }
+    std::vector<std::vector<int>> kids(n);
+    for (int k = 0; k < n; ++k) if (parent[k] >= 0) kids[parent[k]].push_back(k);
+    std::vector<int> size(n, 1);
+    for (int k = 0; k < n; ++k) if (parent[k] >= 0) size[parent[k]] += size[k];          // children precede parents in `order`
+    for (int p = 0; p < n; ++p) {
+        auto nested = [&](int c) { return strct[c].size() == strct[p].size() + 1; };   // struct(c) = {p} + struct(p)
+        std::stable_sort(kids[p].begin(), kids[p].end(), [&](int a, int b) {
+            if (nested(a) != nested(b)) return nested(b);                                // the supernode child last
+            return size[a] < size[b];                                                    // else the largest subtree last
+        });
+    }
+    std::vector<int> seq;
+    seq.reserve(n);
+    std::vector<std::pair<int, size_t>> stack;
+    for (int r = 0; r < n; ++r) {
+        if (parent[r] >= 0) continue;
+        stack.push_back({r, 0});
+        while (!stack.empty()) {
+            auto& top = stack.back();
+            if (top.second < kids[top.first].size()) { const int c = kids[top.first][top.second++]; stack.push_back({c, 0}); }
+            else { seq.push_back(top.first); stack.pop_back(); }
+        }
+    }
+    std::vector<int> order2(n);
+    std::vector<std::vector<int>> strct2(n);
+    for (int i = 0; i < n; ++i) { order2[i] = order[seq[i]]; strct2[i] = std::move(strct[seq[i]]); }
+    order.swap(order2);
+    strct.swap(strct2);
 }
 
 int find_in_row(const BlockSymbolic& S, int r, int c) {
@@ -321,6 +368,7 @@ int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic&
 
     std::vector<std::vector<int>> strct;
     elimination_order(n, adj, S.perm, strct);
+    postorder(S.perm, strct);
     S.iperm.assign(n, 0);
     for (int k = 0; k < n; ++k) S.iperm[S.perm[k]] = k;
     for (int k = 0; k < n; ++k) {
