@@ -336,7 +336,7 @@ __device__ __forceinline__ void level_body(const Args& a, double* red) {
         base = sg[0]; nchunks = sg[1]; wpi = sg[2]; rpw = sg[3];
     }
     int grp, bx;
-    if (!map_block(a.sel, a.ld, nchunks, grp, bx)) return;
+    if (!map_block(a.sel, a.ld, BWD ? nchunks : nchunks * (16 / FACT_WAVES), grp, bx)) return;
     const int lane = threadIdx.x;
     const int wave = uniform(threadIdx.y);
     const size_t ld = (size_t)a.ld;
@@ -347,13 +347,13 @@ __device__ __forceinline__ void level_body(const Args& a, double* red) {
             return;
         }
     }
-    const size_t ri = (size_t)base + ((size_t)bx * 16 + wave) * rpw;
+    const size_t ri = (size_t)base + ((size_t)bx * (BWD ? 16 : FACT_WAVES) + wave) * rpw;
     const RecS r = load_rec(a.rec, ri);
     if constexpr (BWD) bwd_chunk(a, red, r, ri, rpw, wpi, wave, lane, b, ld);
     else fact_chunk(a, red, r, ri, rpw, wpi, wave, lane, b, ld);
 }
 
-__global__ __launch_bounds__(1024) void k_fact_level(FactArgs a) {
+__global__ __launch_bounds__(64 * FACT_WAVES, 4) void k_fact_level(FactArgs a) {
     extern __shared__ __attribute__((aligned(16))) double red[];   // [16][4][64]
     level_body<false>(a, red);
 }
@@ -754,7 +754,7 @@ int Engine::factor(hipStream_t st, const double* A, const double* rhs, const Gro
     for (const DevLaunch& L : fact) {
         a.seg_begin = L.seg_begin;
         { const Segment& g = S.fact_seg[L.seg_begin]; a.s0_base = g.rec_base; a.s0_nchunks = g.nchunks; a.s0_wpi = g.wpi; a.s0_rpw = g.rpw; }
-        hipLaunchKernelGGL(k_fact_level, dim3((unsigned)L.grid * gs, L.nseg), dim3(64, 16), 16 * 256 * sizeof(double), st, a);
+        hipLaunchKernelGGL(k_fact_level, dim3((unsigned)L.grid * (16 / FACT_WAVES) * gs, L.nseg), dim3(64, FACT_WAVES), FACT_WAVES * 256 * sizeof(double), st, a);
     }
     JG_HIP(hipGetLastError());
     return 0;
@@ -785,7 +785,7 @@ int Engine::forward(hipStream_t st, const double* rhs, const GroupSel& sel) {
     for (const DevLaunch& L : fwd) {
         a.seg_begin = L.seg_begin;
         { const Segment& g = S.fwd_seg[L.seg_begin]; a.s0_base = g.rec_base; a.s0_nchunks = g.nchunks; a.s0_wpi = g.wpi; a.s0_rpw = g.rpw; }
-        hipLaunchKernelGGL(k_fact_level, dim3((unsigned)L.grid * gs, L.nseg), dim3(64, 16), 16 * 256 * sizeof(double), st, a);
+        hipLaunchKernelGGL(k_fact_level, dim3((unsigned)L.grid * (16 / FACT_WAVES) * gs, L.nseg), dim3(64, FACT_WAVES), FACT_WAVES * 256 * sizeof(double), st, a);
     }
     JG_HIP(hipGetLastError());
     return 0;

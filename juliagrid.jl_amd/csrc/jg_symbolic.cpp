@@ -147,7 +147,7 @@ struct NoExtra { void operator()(int, std::vector<Segment>&, std::vector<Rec>&) 
 // `extra(level, segs, recs)` may append further segments of that level (backward chains); extra_levels = highest level it uses
 template <class Fill, class Extra = NoExtra>
 void build_replay(const std::vector<int>& level, const std::vector<int>& work, int T, std::vector<Segment>& segs,
-                  std::vector<Rec>& recs, int& n_levels, Fill fill, Extra extra = Extra(), int extra_levels = 0) {
+                  std::vector<Rec>& recs, int& n_levels, Fill fill, Extra extra = Extra(), int extra_levels = 0, int max_wpi = 16) {
     const int n_items = (int)level.size();
     int nlev = extra_levels;
     for (int i = 0; i < n_items; ++i) nlev = std::max(nlev, level[i]);
@@ -160,7 +160,7 @@ void build_replay(const std::vector<int>& level, const std::vector<int>& work, i
         const size_t seg0 = segs.size();
         std::stable_sort(it.begin(), it.end(), [&](int x, int y) { return work[x] > work[y]; });   // heaviest first
         const bool wide = it.size() >= 2048;                      // wide levels already fill the chip: do not split lists
-        auto wpi_of = [&](int i) { return std::min(wide ? 2 : 16, pow2ceil(std::max(1, (work[i] + T - 1) / T))); };
+        auto wpi_of = [&](int i) { return std::min(wide ? 2 : max_wpi, pow2ceil(std::max(1, (work[i] + T - 1) / T))); };
         size_t p = 0;
         while (p < it.size()) {
             const int wpi = wpi_of(it[p]);
@@ -224,7 +224,7 @@ void build_tables(BlockSymbolic& S) {
     };
     S.n_sched_terms = 0;
     for (int it = 0; it < nE + n; ++it) if (level[it] > 0) S.n_sched_terms += work[it];
-    build_replay(level, work, FACT_T, S.fact_seg, S.fact_rec, S.n_fact_levels, fill_fact);
+    build_replay(level, work, FACT_T, S.fact_seg, S.fact_rec, S.n_fact_levels, fill_fact, NoExtra(), 0, FACT_WAVES);
     // forward elimination ALONE (factor once, solve many: fast decoupled power flow): the rhs rows only, levelled on
     // each other (every factor entry is final)
     {
@@ -234,7 +234,7 @@ void build_tables(BlockSymbolic& S) {
             for (int p = S.l_ptr[r]; p < S.l_ptr[r + 1]; ++p) l = std::max(l, flevel[nE + S.l_col[p]] + 1);
             flevel[nE + r] = l; fwork[nE + r] = S.l_ptr[r + 1] - S.l_ptr[r];
         }
-        build_replay(flevel, fwork, FACT_T, S.fwd_seg, S.fwd_rec, S.n_fwd_levels, fill_fact);
+        build_replay(flevel, fwork, FACT_T, S.fwd_seg, S.fwd_rec, S.n_fwd_levels, fill_fact, NoExtra(), 0, FACT_WAVES);
     }
     // backward sweep: chains of a supernode go to ONE workgroup each (CHAIN_MAX_ROWS), the other rows stay wave records
     std::vector<int> uw(n);
