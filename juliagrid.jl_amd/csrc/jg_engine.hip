@@ -395,20 +395,20 @@ __device__ __forceinline__ void sel_record(const SelArgs& a, const RecS& r, size
     }
 }
 
-__global__ __launch_bounds__(1024) void k_sel_level(SelArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double red[];   // [16][2][64] double2
+__global__ __launch_bounds__(64 * FACT_WAVES, 4) void k_sel_level(SelArgs a) {   // workgroups like k_fact_level
+    extern __shared__ __attribute__((aligned(16))) double red[];   // [FACT_WAVES][2][64] double2
     int base = a.s0_base, nchunks = a.s0_nchunks, wpi = a.s0_wpi, rpw = a.s0_rpw;
     if (blockIdx.y != 0) {
         const SegS sg = ((SegPtr)a.seg)[a.seg_begin + blockIdx.y];
         base = sg[0]; nchunks = sg[1]; wpi = sg[2]; rpw = sg[3];
     }
     int grp, bx;
-    if (!map_block(a.sel, a.ld, nchunks, grp, bx)) return;
+    if (!map_block(a.sel, a.ld, nchunks * (16 / FACT_WAVES), grp, bx)) return;
     const int lane = threadIdx.x;
     const int wave = uniform(threadIdx.y);
     const size_t ld = (size_t)a.ld;
     const size_t b = (size_t)min(grp * 64 + lane, a.lanes - 1);
-    const size_t ri = (size_t)base + ((size_t)bx * 16 + wave) * rpw;
+    const size_t ri = (size_t)base + ((size_t)bx * FACT_WAVES + wave) * rpw;
     const RecS first = load_rec(a.rec, ri);
     const int sub = wave & (wpi - 1);
     const int target = rec_word(first, 0);
@@ -773,7 +773,7 @@ int Engine::selected_inverse(hipStream_t st, const GroupSel& sel) {
     for (const DevLaunch& L : selv) {
         a.seg_begin = L.seg_begin;
         { const Segment& g = S.sel_seg[L.seg_begin]; a.s0_base = g.rec_base; a.s0_nchunks = g.nchunks; a.s0_wpi = g.wpi; a.s0_rpw = g.rpw; }
-        hipLaunchKernelGGL(k_sel_level, dim3((unsigned)L.grid * gs, L.nseg), dim3(64, 16), 16 * 128 * sizeof(double2), st, a);
+        hipLaunchKernelGGL(k_sel_level, dim3((unsigned)L.grid * (16 / FACT_WAVES) * gs, L.nseg), dim3(64, FACT_WAVES), FACT_WAVES * 128 * sizeof(double2), st, a);
     }
     JG_HIP(hipGetLastError());
     return 0;

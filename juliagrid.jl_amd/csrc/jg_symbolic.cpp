@@ -339,7 +339,7 @@ void build_selected_inverse(BlockSymbolic& S) {
             rec.w[5 + 2 * (c % BWD_T)] = z;
             rec.w[3]++;
         }
-    });
+    }, NoExtra(), 0, FACT_WAVES);
 }
 
 int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic& S) {
