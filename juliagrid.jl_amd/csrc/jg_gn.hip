@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256) void k_gn_rows(RowArgs a) {
     }
 }
 
+constexpr int GAIN_U = 4;
 struct GainItem { int kind; int id; int c0; int c1; };   // kind 0: gain block id (CSR order), 1: rhs row (bus)
 struct GainArgs {
     const GainItem* items; const int* cw; const int* ca; const int* cb;   // contribution: weight idx, slot, slot | row
@@ -223,22 +224,24 @@ __global__ __launch_bounds__(256) void k_gn_gain(GainArgs a) {
     typedef int i4 __attribute__((ext_vector_type(4)));
     typedef const i4 __attribute__((address_space(4)))* CInt4;
     CInt cw = (CInt)a.cw, ca = (CInt)a.ca, cb = (CInt)a.cb;
-    for (int it = (blockIdx.x * blockDim.y + wave) * 4, e = min(it + 4, a.n_items); it < e; ++it) {
+    // items are sorted heaviest first: a wave takes items w, w + W, w + 2W, ... (W = waves of the launch) so that the
+    // long gather lists spread over all waves instead of sitting four in a row in the first ones
+    for (int it = blockIdx.x * blockDim.y + wave, W = gridDim.x * blockDim.y; it < a.n_items; it += W) {
         const i4 gi = ((CInt4)a.items)[it];
         const int kind = gi[0], id = gi[1], c0 = gi[2], c1 = gi[3];
         if (kind == 0) {
             double g00 = 0.0, g01 = 0.0, g10 = 0.0, g11 = 0.0;
             int c = c0;
-            for (; c + 4 <= c1; c += 4) {                        // four contributions in flight
-                double w[4], a0[4], a1[4], b0[4], b1[4];
+            for (; c + GAIN_U <= c1; c += GAIN_U) {              // GAIN_U contributions in flight
+                double w[GAIN_U], a0[GAIN_U], a1[GAIN_U], b0[GAIN_U], b1[GAIN_U];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < GAIN_U; ++u) {
                     w[u] = a.w[(size_t)cw[c + u] * ld + b];
                     const double2 pa = jg::load_vec(a.Hs, (size_t)ca[c + u], b, ld), pb = jg::load_vec(a.Hs, (size_t)cb[c + u], b, ld);
                     a0[u] = pa.x; a1[u] = pa.y; b0[u] = pb.x; b1[u] = pb.y;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < GAIN_U; ++u) {
                     const double at = w[u] * a0[u], av = w[u] * a1[u];
                     g00 += at * b0[u]; g01 += at * b1[u]; g10 += av * b0[u]; g11 += av * b1[u];
                 }
