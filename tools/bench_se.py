@@ -22,48 +22,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(jg, s, case, pf, budget_s=15.0):
-    """The C oracle (restatement of acWLS / normalEquation! / increment! / solve!, KLU-style LU with refactor reuse) on
-    ONE host core: the same measurement configuration, noise-free readings, flat start, repeated until the budget."""
-    from oracle import oracle as O
-    tables = jg.case9241synth() if case == "case9241synth" else None
-    if tables is None:
-        with np.load(os.path.join(ROOT, "tests", "golden", "cases", case + ".npz")) as z:
-            tables = {k: z[k] for k in z.files}
-    osys = O.OracleSystem(tables)
-    on = O.OracleNR(osys)
-    assert on.power_flow(iteration=20, tolerance=1e-11) == 0
-    vm, va = on.voltage()
-    br, _ = O.exact_quantities(osys, vm, va)
-    tab = O.MeterTable()
-    O.add_from_power_flow(tab, osys, vm, va, "voltmeter")
-    O.add_from_power_flow(tab, osys, vm, va, "wattmeter")
-    O.add_from_power_flow(tab, osys, vm, va, "varmeter")
-    sel = set(range(1, osys.n + 1, 10))
-    for i in range(osys.n):
-        if (i + 1) in sel:
-            tab.add("pmu", 0, i + 1, vm[i], 1e-8, 1, va[i], 1e-8, 1)
-    for k in np.flatnonzero(osys.status == 1):
-        if int(tables["br_from"][k]) in sel and br[k, 4] >= 1e-6:
-            tab.add("pmu", 1, k + 1, br[k, 4], 1e-8, 1, br[k, 5], 1e-8, 1)
-    n = osys.n
-    t0 = time.perf_counter()
-    gn = O.OracleGN(osys, tab, np.ones(n), np.zeros(n))           # includes the symbolic analysis, like the first GPU solve does not
-    t_setup = time.perf_counter() - t0
-    iters = solves = 0
-    t0 = time.perf_counter()
-    while True:
-        gn.set_voltage(np.ones(n), np.zeros(n))
-        gn.state_estimation(iteration=40, tolerance=1e-8)
-        iters += gn.iteration
-        solves += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": iters / dt, "unit": "GN iterations/s", "cores": 1, "kind": "port",
-            "sample": f"{solves} solves of the same measurement configuration (noise-free), {iters} iterations in {dt:.2f} s, "
-                      f"oracle/jg_oracle_se.c, single thread; model setup {t_setup:.2f} s not counted",
-            "ms_per_iteration": 1e3 * dt / max(iters, 1), "ms_per_solve": 1e3 * dt / max(solves, 1)}
+from bench import cpu_baseline_se as cpu_baseline      # noqa: E402  (the oracle is only ever touched from bench.py's CPU legs)
 
 
 def main():
