@@ -27,11 +27,11 @@ from bench import cpu_baseline_se as cpu_baseline      # noqa: E402  (the oracle
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--case", default="case9241synth")
-    ap.add_argument("--inflight", type=int, default=3, help="batches in flight (own handle, stream and host thread each)")
+    ap.add_argument("--inflight", type=int, default=2, help="batches in flight (own handle, stream and host thread each)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
     import juliagrid.jl_amd as jg
