@@ -179,12 +179,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    # JG_BENCH_BACKEND=gloo: dry run of the N > 1 control flow on a box with fewer GPUs than ranks (ranks share the
+    # devices round-robin, collectives go through host memory).  The measured configuration is always nccl = RCCL.
+    backend = os.environ.get("JG_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
+    cdev = "cuda" if backend == "nccl" else "cpu"      # where the tensors of the collectives live
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))      # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     if args.case == "case9241synth":                 # the seeded PEGASE-shaped stand-in for case9241pegase
         tables = jg.case9241synth()
@@ -209,10 +218,21 @@ def main():
         t_single.append(time.perf_counter() - t0)
     base.close()
 
-    labels_all = jg.outageList(system, B * world, seed=512)
-    lo, hi = jg.shard(B * world, rank, world)
-    labels = labels_all[lo:hi]
+    # Scenario selection (untimed).  Rank r owns the contiguous block r of a seeded shuffle of the non-bridge branches
+    # (2 B candidates per rank) and screens the first B of them THAT HAVE A POWER FLOW: a contingency without a solution
+    # runs to the iteration limit (20 iterations for one lane while the other 511 of its batch have long finished), so one
+    # of them inside a rank's list would measure that scenario, not the path.  They are counted and reported, not hidden:
+    # the first 1024 candidates of case_ACTIVSg10k hold exactly one (branch 11127).  N = 1 keeps the first 512.
+    cand = jg.outageList(system, 2 * B * world, seed=512)
+    lo, hi = jg.shard(2 * B * world, rank, world)
+    mine = cand[lo:hi]
     pipe = jg.ContingencyPipeline(system, B, inflight=args.inflight, device=local, start=(vm0, va0))
+    it_pre, st_pre = pipe.screen(mine, iteration=20, tolerance=1e-8)
+    solvable = np.flatnonzero(st_pre == 0)
+    excluded_local = int(np.sum(st_pre[:solvable[B - 1] + 1] != 0)) if solvable.size >= B else int(np.sum(st_pre != 0))
+    if solvable.size < B:
+        raise SystemExit(f"rank {rank}: only {solvable.size} of {mine.size} candidate contingencies have a power flow")
+    labels = mine[solvable[:B]]
     for h in pipe.handles:
         jg.setOutages_(h, labels)                     # the scenarios stay resident: a step re-solves them from the start point
     an = pipe.handles[0]
@@ -224,7 +244,10 @@ def main():
     def gather(job, h):                               # caller's thread, step order: the only collective (final gather of results)
         h.voltage_device(out_vm.data_ptr(), out_va.data_ptr())
         res.copy_(torch.from_numpy(np.stack([h.method.iteration, h.status], axis=1).astype(np.int32)))
-        jg.gatherResults(dist, res[:, 0], res[:, 1], out_vm, out_va)
+        if cdev == "cuda":
+            jg.gatherResults(dist, res[:, 0], res[:, 1], out_vm, out_va)
+        else:
+            jg.gatherResults(dist, res[:, 0].cpu(), res[:, 1].cpu(), out_vm.cpu(), out_va.cpu())
 
     def run(steps):
         out = pipe.run([None] * steps, iteration=20, tolerance=1e-8, on_done=gather if world > 1 else None)
@@ -244,14 +267,14 @@ def main():
 
     conv_local = int(np.sum(last_status == 0))
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        cnt = torch.tensor([iters_local, conv_local], dtype=torch.int64, device="cuda")
+        cnt = torch.tensor([iters_local, conv_local, excluded_local], dtype=torch.int64, device=cdev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         dt = float(tt.item())
-        iters_total, conv_total = int(cnt[0].item()), int(cnt[1].item())
+        iters_total, conv_total, excluded_total = int(cnt[0].item()), int(cnt[1].item()), int(cnt[2].item())
     else:
-        iters_total, conv_total = iters_local, conv_local
+        iters_total, conv_total, excluded_total = iters_local, conv_local, excluded_local
 
     if rank == 0:
         d = an.dims
@@ -299,7 +322,9 @@ def main():
                        "lu_blocks_2x2": d["lu_blocks"], "lu_terms": d["lu_terms"],
                        "launches_per_iteration": 2 + d["lu_launches"] + d["solve_launches"],
                        "steps_in_flight_per_gpu": len(pipe.handles),
-                       "parallelism": f"scenario-sharded x{world}, RCCL all-gather of results only"},
+                       "parallelism": f"scenario-sharded x{world}, RCCL all-gather of results only",
+                       "scenario_selection": f"per GPU the first {B} solvable contingencies of its block of a seeded shuffle of the "
+                                             f"non-bridge branches; {excluded_total} candidate(s) without a power flow skipped"},
             "scenarios_per_s": B * world * args.steps / dt,
             "ms_per_solve_batched": 1e3 * dt / (B * world * args.steps),
             "iterations_per_scenario": iters_total / (B * world * args.steps),
