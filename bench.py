@@ -335,7 +335,7 @@ def main():
             "kernels": kern,
         }
         if world == 1 and not args.no_cpu:
-            cb = cpu_baseline(tables, labels_all[: max(64, min(B, 512))], vm0, va0)
+            cb = cpu_baseline(tables, labels[: max(64, min(B, 512))], vm0, va0)
             cb.pop("_iters"), cb.pop("_done")
             line["cpu_baseline"] = cb
             line["speedup_vs_cpu_baseline"] = line["value"] / cb["value"]
