@@ -4,7 +4,7 @@ Mirrors, by name and meaning, the reference types the NR / Gauss-Newton path rea
 
   PowerSystem{bus, branch, generator, model}      src/definition/system.jl:213-271
   powerSystem(file)                               src/powerSystem/load.jl:36-67 (npz fixtures and
-                                                  MATPOWER .m here; the HDF5 reader is a "next" row)
+                                                  MATPOWER .m and the reference's HDF5 case files here: hdf5.py)
   acModel!(system)      -> acModel_(system)       src/powerSystem/model.jl:23-78
   updateBranch!(system; label, status)            src/powerSystem/branch.jl:313-431 (status toggles
   -> updateBranch_(system, label, status=...)     only: :344-350 outage, :381-386 re-close)
@@ -145,7 +145,7 @@ def _matpower_tables(path: str) -> dict:
 
 
 def powerSystem(source) -> PowerSystem:
-    """powerSystem("case14") / powerSystem("x.npz") / powerSystem("x.m") / powerSystem(dict);
+    """powerSystem("case14") / powerSystem("x.npz") / powerSystem("x.m") / powerSystem("x.h5") / powerSystem(dict);
     "case9241synth" = the seeded PEGASE-shaped grid of synthetic.py (stands in for case9241pegase)."""
     if isinstance(source, dict):
         return PowerSystem(source)
@@ -155,6 +155,9 @@ def powerSystem(source) -> PowerSystem:
         return PowerSystem(case9241synth())
     if path.endswith(".m"):
         return PowerSystem(_matpower_tables(path))
+    if path.endswith(".h5"):                         # the reference's own case format (load.jl:36-67, 141-289)
+        from .hdf5 import case_tables
+        return PowerSystem(case_tables(path))
     if not os.path.exists(path):
         for d in _CASE_DIRS:
             for cand in (os.path.join(d, path), os.path.join(d, path + ".npz")):

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import load_case
+from conftest import ROOT, load_case
 
 CASES = ["case14", "case14test", "case30test", "case118", "case300", "case1354pegase", "case_ACTIVSg10k"]
 
@@ -95,3 +95,37 @@ def test_matpower_reader_matches_fixture(jg, tmp_path):
     assert np.array_equal(s.branch.layout.from_, t["br_from"])
     assert np.abs(s.bus.demand.active - t["bus_pd"]).max() < 1e-15
     assert np.abs(s.branch.parameter.reactance - t["br_x"]).max() == 0
+
+
+def test_hdf5_reader_matches_the_fixtures(jg):
+    """N1: the pure-Python reader of the reference's HDF5 case layout (compact and dense groups, contiguous datasets,
+    one-element datasets broadcast) gives bit-identical tables to the converter that went through h5dump."""
+    import glob
+    import os
+    from juliagrid.jl_amd.hdf5 import H5File, case_tables
+    here = os.path.join(ROOT, "tests", "golden", "h5")
+    files = {os.path.basename(p)[:-3]: p for p in glob.glob(os.path.join(here, "*.h5"))}
+    assert set(files) == {"case14", "case_ieee30"}
+    for p in glob.glob("/root/reference/docs/src/examples/cases/hdf5/*.h5"):      # build container only: every shipped case
+        files.setdefault(os.path.basename(p)[:-3], p)
+    for name, p in files.items():
+        t = case_tables(p)
+        ref = load_case(name)
+        for k, v in t.items():
+            assert np.array_equal(np.asarray(v).reshape(-1), np.asarray(ref[k]).reshape(-1)), (name, k)
+        f = H5File(p)
+        assert len(f.datasets()) == 56 and not f.skipped                         # every group enumerated, dense ones included
+        assert f.read("/bus/label") is None or f.read("/bus/label").size in (1, t["bus_type"].size)
+    s = jg.powerSystem(files["case14"])
+    jg.acModel_(s)
+    s2 = jg.powerSystem(load_case("case14"))
+    jg.acModel_(s2)
+    assert np.array_equal(s.model.ac.nodalMatrix.nzval, s2.model.ac.nodalMatrix.nzval)
+
+
+def test_hdf5_reader_rejects_other_files(jg, tmp_path):
+    from juliagrid.jl_amd.hdf5 import H5File
+    p = tmp_path / "x.h5"
+    p.write_bytes(b"not an hdf5 file at all")
+    with pytest.raises(ValueError):
+        H5File(str(p))
