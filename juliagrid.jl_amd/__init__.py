@@ -9,7 +9,7 @@ from .system import (updateBranch_ as updateBranchSystem_, updateBus_ as updateB
 from .powerflow import (AcPowerFlow, newtonRaphson, fastNewtonRaphsonBX, fastNewtonRaphsonXB, mismatch_, solve_, powerFlow_, setInitialPoint_,   # noqa: F401
                         updateBranch_, updateBus_, updateGenerator_, setOutage_, setOutages_, setInjection_, outagePatch, initializeACPowerFlow, power_, current_, reactiveLimit_, adjustAngle_)
 from .contingency import bridges, outageList, shard, contingencyAnalysis, gatherResults, ContingencyPipeline   # noqa: F401
-from .measurement import (Measurement, measurement, addVoltmeter_, addAmmeter_, addWattmeter_, addVarmeter_,   # noqa: F401
+from .measurement import (Measurement, measurement, ems, addVoltmeter_, addAmmeter_, addWattmeter_, addVarmeter_,   # noqa: F401
                           addPmu_, exactQuantities)
 from .stateestimation import (AcStateEstimation, PmuStateEstimation, pmuStateEstimation, gaussNewton, increment_ as incrementSE_, solve_ as solveSE_,   # noqa: F401
                               stateEstimation_, setNoise_, residualTest_, normalizedResidual, chiTest,
@@ -21,7 +21,7 @@ from . import _lib                                                           # n
 __all__ = [
     "PowerSystem", "CscMatrix", "powerSystem", "acModel_", "updateBranchSystem_", "updateBusSystem_", "updateGeneratorSystem_", "updateBus_", "updateGenerator_", "AcPowerFlow", "newtonRaphson", "fastNewtonRaphsonBX", "fastNewtonRaphsonXB",
     "mismatch_", "solve_", "powerFlow_", "setInitialPoint_", "updateBranch_", "setOutage_", "setInjection_",
-    "Measurement", "measurement", "addVoltmeter_", "addAmmeter_", "addWattmeter_", "addVarmeter_", "addPmu_",
+    "Measurement", "measurement", "ems", "addVoltmeter_", "addAmmeter_", "addWattmeter_", "addVarmeter_", "addPmu_",
     "exactQuantities", "AcStateEstimation", "PmuStateEstimation", "pmuStateEstimation", "gaussNewton", "incrementSE_", "solveSE_", "stateEstimation_", "setNoise_", "residualTest_", "normalizedResidual", "chiTest",
     "updateVoltmeter_", "updateAmmeter_", "updateWattmeter_", "updateVarmeter_", "updatePmu_",
     "outagePatch", "initializeACPowerFlow", "bridges", "outageList", "shard", "contingencyAnalysis", "gatherResults",

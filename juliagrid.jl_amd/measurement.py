@@ -44,8 +44,49 @@ class Measurement:
                       magnitude=_gauss(), angle=_gauss())
 
 
-def measurement(system: PowerSystem) -> Measurement:
-    return Measurement(system)
+def measurement(system: PowerSystem, source: str | None = None) -> Measurement:
+    """measurement(system) / measurement(system, "monitoring.h5") (src/measurement/load.jl: the reference's HDF5 layout,
+    one group per meter family, layout / mean / variance / status datasets, one-element datasets broadcast)."""
+    mon = Measurement(system)
+    if source is None:
+        return mon
+    from .hdf5 import H5File
+    f = H5File(str(source))
+
+    def col(name, count, cast):
+        if name not in f:
+            return None
+        a = f.read(name)
+        a = np.full(count, a[0], dtype=a.dtype) if a.size == 1 and count != 1 else a
+        if a.size != count:
+            raise ValueError(f"{source}: {name} has {a.size} elements, expected {count} or 1")
+        return [cast(x) for x in a]
+
+    families = (("voltmeter", ("magnitude",), ()), ("ammeter", ("magnitude",), ("from", "to", "square")),
+                ("wattmeter", ("active",), ("bus", "from", "to")), ("varmeter", ("reactive",), ("bus", "from", "to")),
+                ("pmu", ("magnitude", "angle"), ("bus", "from", "to", "correlated", "polar", "square")))
+    for fam, channels, flags in families:
+        if f"/{fam}/layout/index" not in f:
+            continue
+        meter = getattr(mon, fam)
+        index = [int(x) for x in f.read(f"/{fam}/layout/index")]
+        k = len(index)
+        meter.layout.index = index
+        for flag in flags:
+            setattr(meter.layout, "from_" if flag == "from" else flag, col(f"/{fam}/layout/{flag}", k, bool) or [False] * k)
+        for ch in channels:
+            g = getattr(meter, ch)
+            g.mean, g.variance, g.status = (col(f"/{fam}/{ch}/mean", k, float), col(f"/{fam}/{ch}/variance", k, float),
+                                            col(f"/{fam}/{ch}/status", k, int))
+        meter.number = k
+    return mon
+
+
+def ems(case: str, monitoring: str):
+    """ems("case14.h5", "monitoring.h5") (src/JuliaGrid.jl export; load.jl): the power system and its measurements."""
+    from .system import powerSystem
+    system = powerSystem(case)
+    return system, measurement(system, monitoring)
 
 
 # ---- exact quantities from a solved state (postprocessing/acAnalysis.jl:838-931) -------------------

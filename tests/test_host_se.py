@@ -82,3 +82,19 @@ def test_wls_model_values_match_oracle(jg, oracle, pmu_kw):
     assert np.all(gn.woff[~mask] == 0.0)          # (a pair whose angle is exactly 0 has a zero off-diagonal too)
     if corr.size:
         assert np.allclose(woff, gn.woff[corr - 1], rtol=1e-12, atol=0)
+
+
+def test_ems_loads_the_reference_example_files(jg):
+    """ems("case14.h5", "monitoring.h5") on copies of the reference's own example data (src/data/)."""
+    import os
+    from conftest import ROOT
+    d = os.path.join(ROOT, "tests", "golden", "h5")
+    system, mon = jg.ems(os.path.join(d, "case14.h5"), os.path.join(d, "monitoring.h5"))
+    assert (mon.voltmeter.number, mon.ammeter.number, mon.wattmeter.number, mon.varmeter.number, mon.pmu.number) == (14, 40, 54, 54, 54)
+    assert mon.voltmeter.layout.index == list(range(1, 15))
+    assert all(mon.ammeter.layout.square) and not any(mon.pmu.layout.polar)
+    assert mon.ammeter.layout.from_[:4] == [True, False, True, False] and mon.ammeter.layout.to[:4] == [False, True, False, True]
+    assert set(mon.wattmeter.active.variance) == {1e-4} and set(mon.pmu.angle.variance) == {1e-8}
+    assert set(mon.varmeter.reactive.status) == {1}
+    assert abs(mon.voltmeter.magnitude.mean[0] - 1.06018914) < 1e-8 and abs(mon.wattmeter.active.mean[0] - 2.31931565) < 1e-8
+    assert sum(mon.wattmeter.layout.bus) == 14 and sum(mon.wattmeter.layout.from_) == 20 and sum(mon.wattmeter.layout.to) == 20

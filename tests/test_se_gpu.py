@@ -235,3 +235,26 @@ def test_config4_on_the_synthetic_9241_grid(jg):
     assert np.abs(an.voltage.magnitude[0] - pf.voltage.magnitude).max() <= 1e-10
     assert np.abs(an.voltage.angle[0] - pf.voltage.angle).max() <= 1e-10
     assert np.array_equal(an.voltage.magnitude[0], an.voltage.magnitude[1])
+
+
+def test_reference_example_files_end_to_end(jg, oracle):
+    """ems("case14.h5", "monitoring.h5") -> gaussNewton -> stateEstimation!: the reference's own example (docstrings of
+    acStateEstimation.jl) from copies of its data files; the estimate equals the oracle's on the same (noisy) set."""
+    import os
+    from conftest import ROOT
+    from test_reusing_gpu import _table_of
+    d = os.path.join(ROOT, "tests", "golden", "h5")
+    system, mon = jg.ems(os.path.join(d, "case14.h5"), os.path.join(d, "monitoring.h5"))
+    an = jg.gaussNewton(mon)
+    jg.stateEstimation_(an)
+    assert an.status == 0
+    osys = oracle.OracleSystem(load_case("case14"))
+    opf = oracle.OracleNR(osys)
+    assert opf.power_flow() == 0                                 # type normalisation as newtonRaphson / gaussNewton see it
+    gn = oracle.OracleGN(osys, _table_of(oracle, mon))
+    assert gn.state_estimation(40, 1e-8) == 0 and gn.iteration == an.method.iteration
+    v = gn.vectors()
+    assert np.abs(an.voltage.magnitude - v["magnitude"]).max() < 1e-8 and np.abs(an.voltage.angle - v["angle"]).max() < 1e-8
+    vm, va = opf.voltage()
+    assert np.abs(an.voltage.magnitude - vm).max() < 5e-3        # the set carries measurement noise: close to the power flow
+    an.close()
