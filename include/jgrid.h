@@ -184,6 +184,14 @@ void jg_gn_destroy(jg_gn* h);
 /* dims[0]=m, [1]=nnz(H), [2]=gain blocks, [3]=L+D+U blocks, [4]=LU terms, [5]=factor launches,
  * [6]=backward launches, [7]=H slots (1x2 blocks) */
 int jg_gn_dims(jg_gn* h, int64_t* dims);
+/* The WlsMethod tag of gaussNewton(monitoring, T) (src/definition/analysis.jl:36-99; increment! methods
+ * acStateEstimation.jl:878-971).  method 0 = the Normal tags (LU, KLU, QR, LDLt, LL: gain matrix H'WH, factorised by the
+ * block engine).  method 1 = the Orthogonal and PetersWilkinson tags: the least-squares increment of
+ * sqrt(W) H d = sqrt(W) r without forming Q -- the triangular factor of the reference's qr(sqrt(W) H) is the Cholesky factor of
+ * the gain the engine already holds, and one correction pass through H itself (rho = r - H d; d += G^-1 H'W rho: corrected
+ * semi-normal equations) replaces the multiplication by Q'.  Needs a diagonal precision matrix (the reference's
+ * sqrtPrecision!, dcStateEstimation.jl:488-492, has the same restriction); returns 1 if the set has correlated PMUs. */
+int jg_gn_set_method(jg_gn* h, int method);
 /* se.mean [batch][m] and se.precision: diagonal [batch][m] + W[r,r+1] of every correlated pair
  * [batch][n_corr] (acStateEstimation.jl:135-236; equations.jl:576-677).  stride 0 broadcasts. */
 int jg_gn_set_measurement(jg_gn* h, const double* mean, const double* wdiag, const double* woff,

@@ -11,7 +11,8 @@ from .powerflow import (AcPowerFlow, newtonRaphson, fastNewtonRaphsonBX, fastNew
 from .contingency import bridges, outageList, shard, contingencyAnalysis, gatherResults, ContingencyPipeline   # noqa: F401
 from .measurement import (Measurement, measurement, ems, addVoltmeter_, addAmmeter_, addWattmeter_, addVarmeter_,   # noqa: F401
                           addPmu_, exactQuantities)
-from .stateestimation import (AcStateEstimation, PmuStateEstimation, pmuStateEstimation, gaussNewton, increment_ as incrementSE_, solve_ as solveSE_,   # noqa: F401
+from .stateestimation import (WlsMethod, Normal, LU, KLU, QR, LDLt, LL, Orthogonal, PetersWilkinson,   # noqa: F401
+                              AcStateEstimation, PmuStateEstimation, pmuStateEstimation, gaussNewton, increment_ as incrementSE_, solve_ as solveSE_,   # noqa: F401
                               stateEstimation_, setNoise_, residualTest_, normalizedResidual, chiTest,
                               updateVoltmeter_, updateAmmeter_, updateWattmeter_, updateVarmeter_, updatePmu_)
 from .synthetic import pegaseShaped, case9241synth                          # noqa: F401
@@ -25,5 +26,6 @@ __all__ = [
     "exactQuantities", "AcStateEstimation", "PmuStateEstimation", "pmuStateEstimation", "gaussNewton", "incrementSE_", "solveSE_", "stateEstimation_", "setNoise_", "residualTest_", "normalizedResidual", "chiTest",
     "updateVoltmeter_", "updateAmmeter_", "updateWattmeter_", "updateVarmeter_", "updatePmu_",
     "outagePatch", "initializeACPowerFlow", "bridges", "outageList", "shard", "contingencyAnalysis", "gatherResults",
+    "WlsMethod", "Normal", "LU", "KLU", "QR", "LDLt", "LL", "Orthogonal", "PetersWilkinson",
     "pegaseShaped", "case9241synth", "ContingencyPipeline", "setOutages_", "power_", "current_", "reactiveLimit_", "adjustAngle_",
 ]

@@ -72,6 +72,7 @@ def lib():
         "jg_gn_create": [C.POINTER(VP), C.c_int64, I64P, I64P, F64P, F64P, C.c_int64, I64P, I64P, F64P, C.c_int64, C.c_int64,
                          I8P, I8P, I64P, C.c_int64, I64P, C.c_int64, C.c_int],
         "jg_gn_dims": [VP, I64P],
+        "jg_gn_set_method": [VP, C.c_int],
         "jg_gn_set_measurement": [VP, F64P, F64P, F64P, C.c_int64, C.c_int64],
         "jg_gn_set_voltage": [VP, F64P, F64P, C.c_int64],
         "jg_gn_get_voltage": [VP, F64P, F64P],

@@ -211,6 +211,7 @@ struct GainArgs {
     const double* Hs; const double* res; const double* w;
     double* Gv; double* rhs;
     int n_items; int slack; int ld;
+    int rhs_only;     // 1: only the right-hand-side items (H' W res with another residual vector: the correction pass)
 };
 
 // G(i,j) = sum w * Hs[a]^T Hs[b]   (2x2 outer products);  rhs(i) = sum w * Hs[a]^T res[row]
@@ -229,6 +230,7 @@ __global__ __launch_bounds__(256) void k_gn_gain(GainArgs a) {
     for (int it = blockIdx.x * blockDim.y + wave, W = gridDim.x * blockDim.y; it < a.n_items; it += W) {
         const i4 gi = ((CInt4)a.items)[it];
         const int kind = gi[0], id = gi[1], c0 = gi[2], c1 = gi[3];
+        if (kind == 0 && a.rhs_only) continue;
         if (kind == 0) {
             double g00 = 0.0, g01 = 0.0, g10 = 0.0, g11 = 0.0;
             int c = c0;
@@ -273,6 +275,38 @@ __global__ __launch_bounds__(256) void k_gn_gain(GainArgs a) {
 }
 
 constexpr int NORM_ROWS = 64;
+
+// Correction pass of the orthogonal (Q-less) method: rho = res - H * inc over the slots of a row (the slack angle column
+// of H is removed, acStateEstimation.jl:914).  One wave per row x 64 scenarios.
+__global__ __launch_bounds__(256) void k_gn_hdelta(const RowDesc* rows, const int* slot_bus, const double* Hs, const double* inc,
+                                                   const double* res, double* rho, int m, int slack, int ld_) {
+    const int lane = threadIdx.x;
+    const int wave = uniform(threadIdx.y);
+    const size_t ld = (size_t)ld_;
+    const size_t b = (size_t)blockIdx.y * 64 + lane;
+    const int r0 = blockIdx.x * GN_ROWS, r1 = min(r0 + GN_ROWS, m);
+    for (int r = r0 + wave; r < r1; r += blockDim.y) {
+        const int s0 = uniform(rows[r].slot0), ns = uniform(rows[r].nslots);
+        double acc = 0.0;
+        for (int s = s0; s < s0 + ns; ++s) {
+            const int bus = uniform(slot_bus[s]);
+            const double2 hv = jg::load_vec(Hs, (size_t)s, b, ld), d = jg::load_vec(inc, (size_t)bus, b, ld);
+            acc += (bus == slack ? 0.0 : hv.x * d.x) + hv.y * d.y;
+        }
+        rho[(size_t)r * ld + b] = res[(size_t)r * ld + b] - acc;
+    }
+}
+
+// inc += cor (the slack angle stays whatever k_gn_norm makes of it afterwards)
+__global__ __launch_bounds__(256) void k_gn_add(double* inc, const double* cor, int n, int ld) {
+    const int lane = threadIdx.x, wave = threadIdx.y;
+    const size_t b = (size_t)blockIdx.y * 64 + lane;
+    const int r0 = blockIdx.x * NORM_ROWS, r1 = min(r0 + NORM_ROWS, n);
+    for (int i = r0 + wave; i < r1; i += 4) {
+        const double2 x = jg::load_vec(inc, (size_t)i, b, ld), y = jg::load_vec(cor, (size_t)i, b, ld);
+        jg::store_vec(inc, (size_t)i, b, ld, x.x + y.x, x.y + y.y);
+    }
+}
 
 // max |increment| per scenario (partial per bus chunk); forces increment[slack theta] = 0 (:899)
 __global__ __launch_bounds__(256) void k_gn_norm(double* inc, double* part, int n, int slack, int ld) {
@@ -424,6 +458,8 @@ struct jg_gn {
     int amax_chunks = 0;
     double* d_part = nullptr; double* d_maxinc = nullptr; double* d_params = nullptr;
     double* d_vm0 = nullptr; double* d_va0 = nullptr;   // snapshot of the start point (jg_gn_snapshot_voltage)
+    int method = 0;                                     // jg_gn_set_method: 0 normal equations, 1 + one least-squares correction pass
+    double* d_rho = nullptr; double* d_rhs2 = nullptr; double* d_inc2 = nullptr;   // correction pass (allocated by jg_gn_set_method)
     int* d_active = nullptr; int* d_iters = nullptr; int* d_status = nullptr; int* d_counter = nullptr; int* d_group = nullptr;
     jg::Engine eng;
     hipStream_t stream = nullptr;
@@ -441,9 +477,9 @@ void launch_rows(jg_gn* h) {
     hipLaunchKernelGGL(k_gn_rows, dim3((h->m + GN_ROWS - 1) / GN_ROWS, h->ld / 64), dim3(64, 4), 0, h->stream, a);
 }
 
-void launch_gain(jg_gn* h) {
-    GainArgs a{h->d_items, h->d_cw, h->d_ca, h->d_cb, h->d_blk_row, h->d_blk_col, h->d_dst, h->d_Hs, h->d_res, h->d_w, h->eng.X, h->d_rhs,
-               h->n_items, h->slack0, h->ld};
+void launch_gain(jg_gn* h, bool correction = false) {
+    GainArgs a{h->d_items, h->d_cw, h->d_ca, h->d_cb, h->d_blk_row, h->d_blk_col, h->d_dst, h->d_Hs, correction ? h->d_rho : h->d_res, h->d_w, h->eng.X,
+               correction ? h->d_rhs2 : h->d_rhs, h->n_items, h->slack0, h->ld, correction ? 1 : 0};
     hipLaunchKernelGGL(k_gn_gain, dim3((h->n_items + 15) / 16, h->ld / 64), dim3(64, 4), 0, h->stream, a);
 }
 
@@ -453,6 +489,19 @@ int launch_increment(jg_gn* h, const int* group) {
     if (int rc = h->eng.factor(h->stream, nullptr, h->d_rhs, jg::GroupSel{group})) return failg(rc, h->eng.error);
     jg::StateUpdate none{};
     if (int rc = h->eng.backsolve(h->stream, h->d_inc, none, jg::GroupSel{group})) return failg(rc, h->eng.error);
+    if (h->method == 1) {
+        // Orthogonal / Peters-Wilkinson tags (acStateEstimation.jl:906-971): the increment is the least-squares solution of
+        // sqrt(W) H d = sqrt(W) r.  The triangular factor R of the reference's QR IS the Cholesky factor of the gain the engine
+        // already holds (R'R = H'WH); Q is never formed.  One correction pass with the residual taken through H itself
+        // (rho = r - H d, d += G^-1 H'W rho: the corrected semi-normal equations) gives the increment the error bound of the QR
+        // method instead of the squared condition number of the plain normal equations.
+        hipLaunchKernelGGL(k_gn_hdelta, dim3((h->m + GN_ROWS - 1) / GN_ROWS, h->ld / 64), dim3(64, 4), 0, h->stream, h->d_rows, h->d_slot_bus, h->d_Hs,
+                           h->d_inc, h->d_res, h->d_rho, h->m, h->slack0, h->ld);
+        launch_gain(h, true);
+        if (int rc = h->eng.forward(h->stream, h->d_rhs2, jg::GroupSel{group})) return failg(rc, h->eng.error);
+        if (int rc = h->eng.backsolve(h->stream, h->d_inc2, none, jg::GroupSel{group}, 1)) return failg(rc, h->eng.error);
+        hipLaunchKernelGGL(k_gn_add, dim3(h->nchunk, h->ld / 64), dim3(64, 4), 0, h->stream, h->d_inc, h->d_inc2, h->n, h->ld);
+    }
     hipLaunchKernelGGL(k_gn_norm, dim3(h->nchunk, h->ld / 64), dim3(64, 4), 0, h->stream, h->d_inc, h->d_part, h->n, h->slack0, h->ld);
     return 0;
 }
@@ -688,7 +737,7 @@ void jg_gn_destroy(jg_gn* h) {
     if (h->graph) hipGraphDestroy(h->graph);
     h->eng.destroy();
     hipFree(h->d_rows); hipFree(h->d_slot_bus); hipFree(h->d_br); hipFree(h->d_rowptr); hipFree(h->d_G); hipFree(h->d_B); hipFree(h->d_ydiag);
-    hipFree(h->d_vm0); hipFree(h->d_va0);
+    hipFree(h->d_vm0); hipFree(h->d_va0); hipFree(h->d_rho); hipFree(h->d_rhs2); hipFree(h->d_inc2);
     hipFree(h->d_vm); hipFree(h->d_va); hipFree(h->d_mean); hipFree(h->d_w); hipFree(h->d_Hs); hipFree(h->d_res); hipFree(h->d_dst);
     hipFree(h->d_pair_ptr); hipFree(h->d_pa); hipFree(h->d_pb); hipFree(h->d_pz); hipFree(h->d_nres); hipFree(h->d_amax_v); hipFree(h->d_amax_i);
     hipFree(h->d_bad_v); hipFree(h->d_bad_i);
@@ -705,6 +754,25 @@ int jg_gn_dims(jg_gn* h, int64_t* dims) {
     dims[0] = h->m; dims[1] = h->nnzH; dims[2] = (int64_t)h->gi_col.size(); dims[3] = h->eng.S.n_entries;
     dims[4] = h->eng.S.n_sched_terms; dims[5] = (int64_t)h->eng.fact.size(); dims[6] = (int64_t)h->eng.bwd.size();
     dims[7] = h->nslots;
+    return 0;
+}
+
+int jg_gn_set_method(jg_gn* h, int method) {
+    if (!h || method < 0 || method > 1) return failg(1, "jg_gn_set_method: method must be 0 (normal equations) or 1 (orthogonal: corrected semi-normal equations)");
+    if (method == 1 && h->ncorr > 0) return failg(1, "jg_gn_set_method: the orthogonal method needs a diagonal precision matrix (no correlated PMUs)");
+    if (int rc = set_device(h)) return rc;
+    GN_HIP(hipStreamSynchronize(h->stream));
+    if (method == 1 && !h->d_rho) {
+        const size_t ld = h->ld;
+        auto dmalloc = [&](void** p, size_t bytes) -> bool { return hipMalloc(p, bytes) == hipSuccess && jg::sync_fill(*p, 0, bytes, h->stream) == hipSuccess; };
+        if (!dmalloc((void**)&h->d_rho, (size_t)h->m * ld * 8) || !dmalloc((void**)&h->d_rhs2, (size_t)h->n * 2 * ld * 8) || !dmalloc((void**)&h->d_inc2, (size_t)h->n * 2 * ld * 8))
+            return failg(2, "jg_gn_set_method: device allocation failed");
+    }
+    if (method != h->method && h->exec) {               // the captured iteration holds the other launch sequence
+        hipGraphExecDestroy(h->exec); hipGraphDestroy(h->graph);
+        h->exec = nullptr; h->graph = nullptr;
+    }
+    h->method = method;
     return 0;
 }
 

@@ -345,11 +345,43 @@ class PmuStateEstimation(AcStateEstimation):
         return self.jacobian
 
 
-def pmuStateEstimation(monitoring: Measurement, batch: int = 1, device: int = 0) -> PmuStateEstimation:
-    """pmuStateEstimation(monitoring) (pmuStateEstimation.jl:43-70): linear WLS model with PMUs only."""
+class WlsMethod:
+    """Factorisation tags of the reference (src/definition/analysis.jl:36-99).  The Normal tags all run the gain matrix through
+    the block engine (the L/U factors are parity-unpinned); Orthogonal and PetersWilkinson -- the reference's two
+    ways around the squared condition number of the gain matrix -- run the corrected semi-normal equations (include/jgrid.h,
+    jg_gn_set_method)."""
+    code = 0
+
+
+class Normal(WlsMethod): pass          # noqa: E701
+class LU(Normal): pass                 # noqa: E701
+class KLU(Normal): pass                # noqa: E701
+class QR(Normal): pass                 # noqa: E701
+class LDLt(Normal): pass               # noqa: E701
+class LL(Normal): pass                 # noqa: E701
+class Orthogonal(WlsMethod): code = 1          # noqa: E701
+class PetersWilkinson(WlsMethod): code = 1     # noqa: E701
+
+
+def _tagged(an, method, who):
+    if not (isinstance(method, type) and issubclass(method, WlsMethod)):
+        an.close()
+        raise TypeError(who + "(monitoring, T): T must be one of LU, KLU, QR, LDLt, LL, Orthogonal, PetersWilkinson")
+    an.factorization = method
+    if method.code:
+        try:
+            _lib.check(_lib.lib().jg_gn_set_method(an._h, method.code))
+        except Exception:
+            an.close()
+            raise
+    return an
+
+
+def pmuStateEstimation(monitoring: Measurement, method=LU, batch: int = 1, device: int = 0) -> PmuStateEstimation:
+    """pmuStateEstimation(monitoring[, T]) (pmuStateEstimation.jl:43-70): linear WLS model with PMUs only."""
     if monitoring.pmu.number == 0:
         raise ValueError("the measurement set holds no PMU")
-    return PmuStateEstimation(monitoring, batch, device)
+    return _tagged(PmuStateEstimation(monitoring, batch, device), method, "pmuStateEstimation")
 
 
 def _solve_pmu(an: PmuStateEstimation, fetch: bool = True):
@@ -368,9 +400,10 @@ def _solve_pmu(an: PmuStateEstimation, fetch: bool = True):
         an.voltage.magnitude, an.voltage.angle = an._shape(np.hypot(re, im)), an._shape(np.arctan2(im, re))
 
 
-def gaussNewton(monitoring: Measurement, batch: int = 1, device: int = 0) -> AcStateEstimation:
-    """gaussNewton(monitoring): WLS model + symbolic analysis + upload; start = system.bus.voltage."""
-    return AcStateEstimation(monitoring, batch, device)
+def gaussNewton(monitoring: Measurement, method=LU, batch: int = 1, device: int = 0) -> AcStateEstimation:
+    """gaussNewton(monitoring[, T]) (acStateEstimation.jl:43-75): WLS model + symbolic analysis + upload; start = system.bus.voltage.
+    T: LU (default) | KLU | QR | LDLt | LL | Orthogonal | PetersWilkinson."""
+    return _tagged(AcStateEstimation(monitoring, batch, device), method, "gaussNewton")
 
 
 def setNoise_(an: AcStateEstimation, rng, scale: float = 1.0):

@@ -375,6 +375,60 @@ class OracleGN:
     def objective(self):
         return float(_se_lib().jgo_gn_objective(self.h))
 
+    # ---- increment!(::AcStateEstimation{GaussNewton{Orthogonal}}) / {PetersWilkinson} restated in dense numpy / scipy
+    # (acStateEstimation.jl:906-932 and :934-971; small cases only).  Both start from normalEquation! (the C restatement,
+    # through increment()), remove the slack angle column (:914 / :947) and scale by sqrt(W) (sqrtPrecision!,
+    # dcStateEstimation.jl:488-492: diagonal precision only).
+    def _scaled_system(self):
+        import scipy.sparse as sp
+        n = self.sys.n
+        self.increment()                                              # normalEquation!: H and the residual at the current state
+        v = self.vectors()
+        assert not np.any(self.woff), "Orthogonal / PetersWilkinson need a diagonal precision matrix"
+        H = sp.csc_matrix((v["jacobian"], self.hrowval - 1, self.hcolptr - 1), shape=(self.m, 2 * n)).toarray()
+        sw = np.sqrt(self.wdiag)
+        H = sw[:, None] * H
+        H[:, self.sys.slack - 1] = 0.0                                # removeColumn(jacobian, slack)
+        return H, sw * v["residual"], v
+
+    def increment_orthogonal(self):
+        """:906-932: qr(sqrt(W) H) \\ (sqrt(W) r), increment[slack] = 0."""
+        H, z, _ = self._scaled_system()
+        keep = np.flatnonzero(np.arange(H.shape[1]) != self.sys.slack - 1)
+        Q, R = np.linalg.qr(H[:, keep])
+        inc = np.zeros(H.shape[1])
+        inc[keep] = np.linalg.solve(R, Q.T @ z)
+        return inc
+
+    def increment_peters_wilkinson(self):
+        """:934-971: lu([sqrt(W) H; e_slack']) = L U (row permutation p), y = (L'L) \\ (L' z[p]), increment = U \\ y, increment[slack] = 0."""
+        import scipy.linalg as sl
+        H, z, _ = self._scaled_system()
+        e = np.zeros((1, H.shape[1]))
+        e[0, self.sys.slack - 1] = 1.0
+        P, Lw, U = sl.lu(np.vstack([H, e]))                           # [H; e] = P L U, L (m+1) x 2n unit lower trapezoidal
+        zp = P.T @ np.append(z, 0.0)
+        y = np.linalg.solve(Lw.T @ Lw, Lw.T @ zp)
+        inc = sl.solve_triangular(U, y)
+        inc[self.sys.slack - 1] = 0.0
+        return inc
+
+    def state_estimation_with(self, increment, iteration=40, tolerance=1e-8):
+        """stateEstimation! (:1286-1329) around one of the two increments above; returns (converged, iterations)."""
+        n = self.sys.n
+        it = 0
+        for _ in range(iteration + 1):
+            inc = increment()
+            self.last_increment = inc
+            if np.max(np.abs(inc)) < tolerance:
+                return True, it
+            if it == iteration:
+                break
+            v = self.vectors()
+            self.set_voltage(v["magnitude"] + inc[n:], v["angle"] + inc[:n])    # solve! :1035-1047
+            it += 1
+        return False, it
+
     def state_estimation(self, iteration=40, tolerance=1e-8):
         hist = np.zeros(iteration + 2)
         nh = C.c_int64(0)
