@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -346,6 +347,25 @@ __global__ void k_lane_copy(const double* src, double* dst, const int* flags, in
         for (int e = 0; e < ELEM; ++e) dst[((size_t)r * ld + b) * ELEM + e] = src[((size_t)r * ld + b) * ELEM + e];
 }
 
+// All per-scenario arrays of a compaction in TWO launches (scatter into the staging area, copy back) instead of two per array:
+// the launches are predicated on flags[0] and mostly return at once, so what they cost is their number.
+struct LaneSet { double* x[8]; int rows[8]; int elem[8]; long long off[8]; };
+__global__ void k_lanes_move(LaneSet s, double* tmp, const int* dest, const int* flags, int ld, int back) {
+    if (!flags[0]) return;
+    const int b = blockIdx.y * 256 + threadIdx.x;
+    if (b >= ld) return;
+    const int a = blockIdx.z;
+    const int rows = s.rows[a], E = s.elem[a];
+    double* x = s.x[a];
+    double* t = tmp + s.off[a];
+    const int d = back ? b : dest[b];
+    for (int r = blockIdx.x; r < rows; r += gridDim.x)
+        for (int e = 0; e < E; ++e) {
+            if (back) x[((size_t)r * ld + b) * E + e] = t[((size_t)r * ld + b) * E + e];
+            else t[((size_t)r * ld + d) * E + e] = x[((size_t)r * ld + b) * E + e];
+        }
+}
+
 // [n][ld] batch-minor -> [batch][n] scenario-major, tiled through LDS so both sides stay coalesced
 __global__ void k_to_scenario_major(const double* src, double* dst, int n, int ld, int batch) {
     __shared__ double tile[32][33];
@@ -452,8 +472,27 @@ void launch_compact(jg_nr* h, int restore) {
     CompactArgs c{h->d_active, h->d_iters, h->d_status, h->eng.status, h->d_lid, h->d_ppos, h->mp, h->d_dest, h->d_group,
                   h->d_glist, h->d_cflags, h->d_itmp, h->ld, restore};
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, c);
+    if (h->ld == 64) return;                       // one lane group: nothing to pack, lanes never leave their home order
     double* tmp = h->eng.X;                        // the factor is dead here (rebuilt by the next factorisation)
     const dim3 block(256), gy((unsigned)((h->ld + 255) / 256));
+    {
+        LaneSet ls{};
+        int na = 0, max_rows = 0;
+        long long off = 0;
+        auto add = [&](double* x, int rows, int elem) {
+            ls.x[na] = x; ls.rows[na] = rows; ls.elem[na] = elem; ls.off[na] = off;
+            off += (long long)rows * elem * h->ld; max_rows = std::max(max_rows, rows); ++na;
+        };
+        add(h->d_vm, h->n, 1); add(h->d_va, h->n, 1); add(h->d_p, h->n, 1); add(h->d_q, h->n, 1);
+        if (h->mp > 0) { add(h->d_pdg, h->mp, 1); add(h->d_pdb, h->mp, 1); }
+        if (restore) { add(h->d_F, h->n, 2); add(h->d_inc, h->n, 2); }
+        if ((size_t)off * sizeof(double) <= h->eng.factor_bytes()) {      // always, except for grids of a handful of buses
+            const dim3 grid((unsigned)std::min(max_rows, 1024), gy.x, (unsigned)na);
+            hipLaunchKernelGGL(k_lanes_move, grid, block, 0, h->stream, ls, tmp, h->d_dest, h->d_cflags, h->ld, 0);
+            hipLaunchKernelGGL(k_lanes_move, grid, block, 0, h->stream, ls, tmp, h->d_dest, h->d_cflags, h->ld, 1);
+            return;
+        }
+    }
     auto permute = [&](double* x, int rows) {
         const dim3 grid((unsigned)std::min(rows, 2048), gy.x);
         hipLaunchKernelGGL(k_lane_permute<1>, grid, block, 0, h->stream, x, tmp, h->d_dest, h->d_cflags, rows, h->ld);
@@ -847,6 +886,7 @@ int jg_nr_solve(jg_nr* h) {
 
 int jg_nr_run(jg_nr* h, int64_t max_iter, double tol, int32_t* iters, int32_t* status) {
     if (!h || max_iter < 0 || !(tol > 0.0)) return fail(1, "jg_nr_run: bad argument");
+    const double t_enter = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
     if (int rc = set_device(h)) return rc;
     if (int rc = build_graphs(h)) return rc;
     const double params[2] = {tol, (double)max_iter};
@@ -867,9 +907,15 @@ int jg_nr_run(jg_nr* h, int64_t max_iter, double tol, int32_t* iters, int32_t* s
         NR_HIP(hipStreamSynchronize(h->stream));
     }
     const bool trace = getenv("JG_TRACE") != nullptr;
+    auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_setup = now_us();
+    if (trace) fprintf(stderr, "[jg_nr_run] setup %.1f us\n", t_setup - t_enter);
     for (int64_t it = 0; it <= max_iter; ++it) {                               // acPowerFlow.jl:1406
+        const double ta = now_us();
         NR_HIP(hipGraphLaunch(h->execA, h->stream));
+        const double tb = now_us();
         NR_HIP(hipStreamSynchronize(h->stream));
+        if (trace) fprintf(stderr, "[jg_nr_run] it %lld: since previous launch-B return ... launchA %.1f us, syncA %.1f us\n", (long long)it, tb - ta, now_us() - tb);
         if (trace) {
             int cf[4];
             jg::sync_copy(cf, h->d_cflags, sizeof(cf), hipMemcpyDeviceToHost, h->stream);
@@ -878,10 +924,13 @@ int jg_nr_run(jg_nr* h, int64_t max_iter, double tol, int32_t* iters, int32_t* s
         }
         if (*h->h_counter == 0) break;
         {
+            const double tc = now_us();
             jg::Engine::WalkTurn turn(h->eng, h->stream);
             NR_HIP(hipGraphLaunch(h->execB, h->stream));
+            if (trace) { const double td = now_us(); hipStreamSynchronize(h->stream); fprintf(stderr, "[jg_nr_run] launchB %.1f us, B alone (launch to idle) %.1f us\n", td - tc, now_us() - tc); }
         }
     }
+    const double t_loop = now_us();
     launch_compact(h, 1);                                                      // lanes back to their home order
     NR_HIP(hipGetLastError());
     NR_HIP(hipStreamSynchronize(h->stream));
@@ -889,6 +938,7 @@ int jg_nr_run(jg_nr* h, int64_t max_iter, double tol, int32_t* iters, int32_t* s
     h->jac_valid = false;
     if (iters) NR_HIP(jg::sync_copy(iters, h->d_iters, (size_t)h->batch * 4, hipMemcpyDeviceToHost, h->stream));
     if (status) NR_HIP(jg::sync_copy(status, h->d_status, (size_t)h->batch * 4, hipMemcpyDeviceToHost, h->stream));
+    if (trace) fprintf(stderr, "[jg_nr_run] tail %.1f us, total %.1f us\n", now_us() - t_loop, now_us() - t_enter);
     return 0;
 }
 
