@@ -359,11 +359,19 @@ __global__ void k_lanes_move(LaneSet s, double* tmp, const int* dest, const int*
     double* x = s.x[a];
     double* t = tmp + s.off[a];
     const int d = back ? b : dest[b];
-    for (int r = blockIdx.x; r < rows; r += gridDim.x)
-        for (int e = 0; e < E; ++e) {
-            if (back) x[((size_t)r * ld + b) * E + e] = t[((size_t)r * ld + b) * E + e];
-            else t[((size_t)r * ld + d) * E + e] = x[((size_t)r * ld + b) * E + e];
+    if (E == 2) {                                  // interleaved 2-vectors: one 16-byte access per lane
+        double2* x2 = (double2*)x;
+        double2* t2 = (double2*)t;
+        for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+            if (back) x2[(size_t)r * ld + b] = t2[(size_t)r * ld + b];
+            else t2[(size_t)r * ld + d] = x2[(size_t)r * ld + b];
         }
+        return;
+    }
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+        if (back) x[(size_t)r * ld + b] = t[(size_t)r * ld + b];
+        else t[(size_t)r * ld + d] = x[(size_t)r * ld + b];
+    }
 }
 
 // [n][ld] batch-minor -> [batch][n] scenario-major, tiled through LDS so both sides stay coalesced

@@ -21,7 +21,7 @@ def load(path):
 
 
 def short(name):
-    for k in ("k_assemble", "k_fact_level", "k_bwd_level", "k_fact_walk", "k_bwd_walk", "k_check", "k_compact", "k_lane_permute", "k_lane_copy",
+    for k in ("k_assemble", "k_fact_level", "k_bwd_level", "k_fact_walk", "k_bwd_walk", "k_check", "k_compact", "k_lane_permute", "k_lane_copy", "k_lanes_move",
               "k_gn_rows", "k_gn_gain"):
         if k in name:
             if k == "k_assemble":
@@ -33,14 +33,21 @@ def short(name):
 def main(fetch_csv, write_csv, n, ld, solves, out_json, grid="case_ACTIVSg10k"):
     f, w = load(fetch_csv), load(write_csv)
     # calibration on the n-row lane permutation launches (known: n*ld*8 bytes read and written)
-    known = n * ld * 8
-    key = [k for k in f if "k_lane_permute" in k][0]
-    cf = sorted(v[0] for v in f[key] if v[0] > 1000)
-    cw = sorted(v[0] for v in w[key] if v[0] > 1000)
-    # the n-row launches are the most frequent large value
     from collections import Counter
-    cal_f_raw = Counter(round(x) for x in cf).most_common(1)[0][0] * 1024.0
-    cal_w_raw = Counter(round(x) for x in cw).most_common(1)[0][0] * 1024.0
+    keys = [k for k in f if "k_lane_permute" in k]
+    if keys:                                     # older builds: one launch per array, the n-row launches are the most frequent large value
+        known = n * ld * 8
+        key = keys[0]
+        cf = sorted(v[0] for v in f[key] if v[0] > 1000)
+        cw = sorted(v[0] for v in w[key] if v[0] > 1000)
+        cal_f_raw = Counter(round(x) for x in cf).most_common(1)[0][0] * 1024.0
+        cal_w_raw = Counter(round(x) for x in cw).most_common(1)[0][0] * 1024.0
+    else:                                        # k_lanes_move: the restore at the end of a run moves V, theta, P, Q (n rows each), the
+        key = [k for k in f if "k_lanes_move" in k][0]    # patch values (2 x 4 rows) and mismatch + increment (2n doubles per lane each)
+        known = (8 * n + 2 * 4) * ld * 8         # read and written by each of its two launches
+        # of the two launches the copy-back is the clean one (whole lines on both sides; the scatter writes permuted lanes)
+        cal_f_raw = min(v[0] for v in f[key] if v[0] > 0.5 * max(x[0] for x in f[key])) * 1024.0
+        cal_w_raw = min(v[0] for v in w[key] if v[0] > 0.5 * max(x[0] for x in w[key])) * 1024.0
     fetch_factor, write_factor = 2.0, 1.0        # MI355X_MICROARCH.md (HBM): FETCH_SIZE = half the bytes on gfx950
     check = {"known_bytes": known, "fetch_raw_bytes": cal_f_raw, "write_raw_bytes": cal_w_raw,
              "fetch_corrected_over_known": fetch_factor * cal_f_raw / known, "write_corrected_over_known": write_factor * cal_w_raw / known}
