@@ -52,6 +52,7 @@ struct AsmArgs {
     double* A; double* F; double* part; double* pq_out; jg::GroupSel sel;   // pq_out (nullable): [n][ld][2] calculated injections P_i, Q_i
     double* R; int fd_mode;    // fast decoupled passes (acPowerFlow.jl:687-730, 952-962): 1 = mismatches / V, R = (f_P, 0); 2 = R = (0, f_Q)
     int n; int ld; int mp; int nchunk; int lanes;
+    const int* only_if;        // nullable: the launch does nothing unless *only_if != 0 (re-assembly after a lane compaction)
 };
 
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -63,6 +64,7 @@ template <int MP, bool JAC>
 __global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(AsmArgs a) {
     __shared__ double red[2][ASM_WAVES][64];
     int grp, bx;
+    if (a.only_if && !uniform(*a.only_if)) return;
     if (!jg::map_block(a.sel, a.ld, a.nchunk, grp, bx)) return;   // every scenario of a skipped 64-lane group is finished
     const int lane = threadIdx.x;
     const int wave = uniform(threadIdx.y);
@@ -439,9 +441,9 @@ int set_device(jg_nr* h) { NR_HIP(hipSetDevice(h->device)); return 0; }
 
 jg::GroupSel active_groups(jg_nr* h) { return jg::GroupSel{nullptr, h->d_glist, h->d_cflags + 3}; }
 
-void launch_assemble(jg_nr* h, const jg::GroupSel& sel = jg::GroupSel{}, bool jac = true, double* pq_out = nullptr, int fd_mode = 0) {
+void launch_assemble(jg_nr* h, const jg::GroupSel& sel = jg::GroupSel{}, bool jac = true, double* pq_out = nullptr, int fd_mode = 0, const int* only_if = nullptr) {
     AsmArgs a{h->d_rowptr, h->d_col, h->d_GB, h->d_rowtype, h->d_dst, h->d_vm, h->d_va, h->d_p, h->d_q,
-              h->d_ppos, h->d_pdg, h->d_pdb, h->eng.X, h->d_F, h->d_part, pq_out, sel, fd_mode ? h->d_R : nullptr, fd_mode, h->n, h->ld, h->mp, h->nchunk, h->batch};
+              h->d_ppos, h->d_pdg, h->d_pdb, h->eng.X, h->d_F, h->d_part, pq_out, sel, fd_mode ? h->d_R : nullptr, fd_mode, h->n, h->ld, h->mp, h->nchunk, h->batch, only_if};
     dim3 grid((unsigned)h->nchunk * jg::group_stride(h->ld / 64)), block(64, ASM_WAVES);
     if (jac) {
         switch (h->mp) {
@@ -520,20 +522,29 @@ int build_graphs(jg_nr* h) {
     if (h->execA) return 0;
     std::lock_guard<std::mutex> lk(jg::capture_mutex());
     NR_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    // graph A: who is still active?  mismatch-only pass -> verdict per scenario -> pack the active ones
-    hipMemsetAsync(h->d_counter, 0, sizeof(int), h->stream);
-    launch_assemble(h, active_groups(h), false);
-    launch_check(h, 1, h->d_group);
-    launch_compact(h, 0);
-    hipMemcpyAsync(h->h_counter, h->d_counter, sizeof(int), hipMemcpyDeviceToHost, h->stream);
+    // One pass decides AND prepares: mismatch + Jacobian in one assembly (the Jacobian of a finished batch is the only waste:
+    // one write stream per solve, against a second walk over Ybus per iteration), verdict per scenario, compaction of the
+    // still-active lanes.  A compaction moves lanes (and stages them in the factor storage), so the assembly is repeated
+    // on the packed lanes -- a launch that returns at once unless the compaction flag is set.
+    auto verdict = [&]() {
+        hipMemsetAsync(h->d_counter, 0, sizeof(int), h->stream);
+        launch_assemble(h, active_groups(h), true);
+        launch_check(h, 1, h->d_group);
+        launch_compact(h, 0);
+        if (h->ld > 64) launch_assemble(h, active_groups(h), true, nullptr, 0, h->d_cflags);
+        hipMemcpyAsync(h->h_counter, h->d_counter, sizeof(int), hipMemcpyDeviceToHost, h->stream);
+    };
+    // graph A: the verdict on the start point
+    verdict();
     NR_HIP(hipStreamEndCapture(h->stream, &h->graphA));
     NR_HIP(hipGraphInstantiate(&h->execA, h->graphA, nullptr, nullptr, 0));
     NR_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    // graph B: the iteration itself, on the packed lanes only
-    launch_assemble(h, active_groups(h), true);
+    // graph B: one iteration on the packed lanes (factorise the Jacobian that is already in place, solve, update), then the
+    // verdict on the new state
     int rc = h->eng.factor(h->stream, nullptr, h->d_F, active_groups(h));
     jg::StateUpdate upd{h->d_va, h->d_vm, h->d_flags, h->d_active, -1.0};
     if (!rc) rc = h->eng.backsolve(h->stream, h->d_inc, upd, active_groups(h));
+    verdict();
     hipError_t e = hipStreamEndCapture(h->stream, &h->graphB);
     if (rc) return fail(rc, h->eng.error);
     NR_HIP(e);
@@ -918,24 +929,21 @@ int jg_nr_run(jg_nr* h, int64_t max_iter, double tol, int32_t* iters, int32_t* s
     auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_setup = now_us();
     if (trace) fprintf(stderr, "[jg_nr_run] setup %.1f us\n", t_setup - t_enter);
-    for (int64_t it = 0; it <= max_iter; ++it) {                               // acPowerFlow.jl:1406
-        const double ta = now_us();
-        NR_HIP(hipGraphLaunch(h->execA, h->stream));
-        const double tb = now_us();
+    NR_HIP(hipGraphLaunch(h->execA, h->stream));                               // acPowerFlow.jl:1406: mismatch!, verdict
+    NR_HIP(hipStreamSynchronize(h->stream));
+    if (trace) fprintf(stderr, "[jg_nr_run] start point: %d scenarios active, %.1f us\n", *h->h_counter, now_us() - t_setup);
+    for (int64_t it = 0; it <= max_iter && *h->h_counter != 0; ++it) {          // the iteration limit itself is kept on the device (k_check)
+        const double tc = now_us();
+        {
+            jg::Engine::WalkTurn turn(h->eng, h->stream);
+            NR_HIP(hipGraphLaunch(h->execB, h->stream));                       // solve!, then mismatch! and the verdict on the new state
+        }
         NR_HIP(hipStreamSynchronize(h->stream));
-        if (trace) fprintf(stderr, "[jg_nr_run] it %lld: since previous launch-B return ... launchA %.1f us, syncA %.1f us\n", (long long)it, tb - ta, now_us() - tb);
         if (trace) {
             int cf[4];
             jg::sync_copy(cf, h->d_cflags, sizeof(cf), hipMemcpyDeviceToHost, h->stream);
-            fprintf(stderr, "[jg_nr_run] iteration %lld: %d scenarios still active, %d of %d lane groups in use%s\n", (long long)it,
-                    *h->h_counter, cf[2], h->ld / 64, cf[0] ? " (compacted)" : "");
-        }
-        if (*h->h_counter == 0) break;
-        {
-            const double tc = now_us();
-            jg::Engine::WalkTurn turn(h->eng, h->stream);
-            NR_HIP(hipGraphLaunch(h->execB, h->stream));
-            if (trace) { const double td = now_us(); hipStreamSynchronize(h->stream); fprintf(stderr, "[jg_nr_run] launchB %.1f us, B alone (launch to idle) %.1f us\n", td - tc, now_us() - tc); }
+            fprintf(stderr, "[jg_nr_run] iteration %lld: %.1f us, %d scenarios still active, %d of %d lane groups in use%s\n", (long long)it + 1,
+                    now_us() - tc, *h->h_counter, cf[2], h->ld / 64, cf[0] ? " (compacted)" : "");
         }
     }
     const double t_loop = now_us();
