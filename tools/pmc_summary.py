@@ -56,7 +56,10 @@ def main(fetch_csv, write_csv, n, ld, solves, out_json, grid="case_ACTIVSg10k"):
         for name, vals in per.items():
             a = agg.setdefault(short(name), {"launches": 0, "fetch": 0.0, "write": 0.0})
             a[tag] += sum(v[0] for v in vals) * 1024.0 * fac
-            a["launches"] = max(a["launches"], len(vals))
+            # launches that did work: predicated launches (re-assembly after a compaction, lane moves) return at once and
+            # must not dilute the per-launch figure
+            top = max(v[0] for v in vals)
+            a["launches"] = max(a["launches"], sum(1 for v in vals if v[0] > 0.01 * top) if top > 0 else len(vals))
     res = {"unit": "bytes", "corrections": {"FETCH_SIZE": "KiB x 2 (gfx950 half-count)", "WRITE_SIZE": "KiB x 1"},
            "calibration": check, "grid": grid, "batch_ld": ld, "solves": solves, "per_kernel_total": agg}
     per = {}
