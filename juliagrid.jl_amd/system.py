@@ -322,15 +322,33 @@ def updateBranch_(system: PowerSystem, label: int, status: int | None = None, re
         system.model.revision.topology += 1
 
 
-def updateBus_(system: PowerSystem, label: int, active=None, reactive=None, conductance=None, susceptance=None,
+def updateBus_(system: PowerSystem, label: int, type=None, active=None, reactive=None, conductance=None, susceptance=None,
                magnitude=None, angle=None) -> None:
-    """updateBus!(system; label, active, reactive, conductance, susceptance, magnitude, angle) (bus.jl:230-330): demand,
-    shunt (the nodal matrix diagonal follows, :286-296) and the initial voltage.  Bus TYPE changes need a new analysis
-    in the reference too (errorTypeConversion) and are not offered here."""
+    """updateBus!(system; label, type, active, reactive, conductance, susceptance, magnitude, angle) (bus.jl:170-255): bus
+    type and slack (:179-206; a live analysis goes stale, acPowerFlow.jl:802-804 -- build a new one, as in the reference),
+    demand, shunt (the nodal matrix diagonal follows) and the initial voltage."""
     if int(label) not in system.bus.label:
         raise KeyError(f"The bus label {label} that has been specified does not exist.")
     i = system.bus.label[int(label)] - 1
     bus = system.bus
+    if type is not None:
+        if int(type) not in (1, 2, 3):
+            raise ValueError("bus type must be 1 (demand), 2 (generator) or 3 (slack)")
+        type_old, slack_old = int(bus.layout.type[i]), int(bus.layout.slack)
+        if int(type) in (1, 2):
+            if bus.layout.slack == i + 1:
+                bus.layout.slack = 0
+            bus.layout.type[i] = int(type)
+        else:
+            if bus.layout.slack not in (0, i + 1):
+                raise RuntimeError(f"To set bus with label {label} as the slack bus, reassign the current slack bus to either a "
+                                   "generator or demand bus.")
+            bus.layout.type[i] = 3
+            bus.layout.slack = i + 1
+        if int(bus.layout.type[i]) != type_old:
+            system.model.revision.type += 1
+        if int(bus.layout.slack) != slack_old:
+            system.model.revision.slack += 1
     if active is not None:
         bus.demand.active[i] = float(active)
     if reactive is not None:

@@ -129,3 +129,19 @@ def test_hdf5_reader_rejects_other_files(jg, tmp_path):
     p.write_bytes(b"not an hdf5 file at all")
     with pytest.raises(ValueError):
         H5File(str(p))
+
+
+def test_update_bus_type_and_slack_rules(jg):
+    """updateBus!(system; label, type) (src/powerSystem/bus.jl:179-206): slack hand-over order and revision counters."""
+    import pytest
+    s = jg.powerSystem(load_case("case30test"))
+    rev = (s.model.revision.type, s.model.revision.slack)
+    with pytest.raises(RuntimeError):
+        jg.updateBusSystem_(s, label=3, type=3)
+    jg.updateBusSystem_(s, label=1, type=2)
+    assert s.bus.layout.slack == 0 and s.bus.layout.type[s.bus.label[1] - 1] == 2
+    jg.updateBusSystem_(s, label=3, type=3)
+    assert s.bus.layout.slack == s.bus.label[3] and s.bus.layout.type[s.bus.label[3] - 1] == 3
+    assert s.model.revision.type == rev[0] + 2 and s.model.revision.slack == rev[1] + 2
+    jg.updateBusSystem_(s, label=3, type=3)                       # no change, no new revision
+    assert s.model.revision.type == rev[0] + 2

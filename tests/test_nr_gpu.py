@@ -293,3 +293,21 @@ def test_pipeline_equals_one_batch_at_a_time(jg):
     assert (st == 0).sum() >= len(labels) - 3
     pipe.close()
     one.close()
+
+
+def test_change_of_the_slack_bus(jg):
+    """test/powerFlow/analysis.jl:59-67: bus 1 becomes a generator bus, bus 3 the slack; a fresh analysis hits the same goldens."""
+    s = jg.powerSystem(load_case("case30test"))
+    with pytest.raises(RuntimeError):
+        jg.updateBusSystem_(s, label=3, type=3)                   # bus.jl:190-195: the old slack must be reassigned first
+    jg.updateBusSystem_(s, label=1, type=2)
+    assert s.bus.layout.slack == 0
+    with pytest.raises(RuntimeError):
+        jg.newtonRaphson(s)                                       # "The slack bus is missing."
+    jg.updateBusSystem_(s, label=3, type=3)
+    an = jg.newtonRaphson(s)
+    jg.powerFlow_(an)
+    g = load_golden("case30test")
+    assert an.status == 0
+    assert np.abs(an.voltage.magnitude - g["newtonRaphson_voltageMagnitude"]).max() <= 1e-8
+    assert np.abs(an.voltage.angle - g["newtonRaphson_voltageAngle"]).max() <= 1e-8
