@@ -204,6 +204,7 @@ __global__ __launch_bounds__(256) void k_gn_rows(RowArgs a) {
 }
 
 constexpr int GAIN_U = 4;
+constexpr int GAIN_CHUNK = 16;   // items per workgroup in local mode
 struct GainItem { int kind; int id; int c0; int c1; };   // kind 0: gain block id (CSR order), 1: rhs row (bus)
 struct GainArgs {
     const GainItem* items; const int* cw; const int* ca; const int* cb;   // contribution: weight idx, slot, slot | row
@@ -211,6 +212,7 @@ struct GainArgs {
     const double* Hs; const double* res; const double* w;
     double* Gv; double* rhs;
     int n_items; int slack; int ld;
+    int local;        // 1: items in bus order, chunked per workgroup, XCD-aware grid (see k_gn_gain)
     int rhs_only;     // 1: only the right-hand-side items (H' W res with another residual vector: the correction pass)
 };
 
@@ -227,7 +229,19 @@ __global__ __launch_bounds__(256) void k_gn_gain(GainArgs a) {
     CInt cw = (CInt)a.cw, ca = (CInt)a.ca, cb = (CInt)a.cb;
     // items are sorted heaviest first: a wave takes items w, w + W, w + 2W, ... (W = waves of the launch) so that the
     // long gather lists spread over all waves instead of sitting four in a row in the first ones
-    for (int it = blockIdx.x * blockDim.y + wave, W = gridDim.x * blockDim.y; it < a.n_items; it += W) {
+    // local mode (items in bus order): a workgroup takes GAIN_CHUNK consecutive items, the scenario group is the fast index of
+    // the 1-D grid (jg::map_block) -- the items of one group run on one XCD in list order, so the slots that neighbouring
+    // items share (every row that touches bus i feeds all blocks (i, .) and rhs(i)) are found in that XCD's L2
+    int it0, it1, step;
+    size_t bb = b;
+    if (a.local) {
+        int grp, bx;
+        if (!jg::map_block(jg::GroupSel{}, a.ld, (a.n_items + GAIN_CHUNK - 1) / GAIN_CHUNK, grp, bx)) return;
+        it0 = bx * GAIN_CHUNK + wave; it1 = min((bx + 1) * GAIN_CHUNK, a.n_items); step = blockDim.y;
+        bb = (size_t)grp * 64 + lane;
+    } else { it0 = blockIdx.x * blockDim.y + wave; it1 = a.n_items; step = gridDim.x * blockDim.y; }
+    const size_t b_ = bb;
+    for (int it = it0; it < it1; it += step) {
         const i4 gi = ((CInt4)a.items)[it];
         const int kind = gi[0], id = gi[1], c0 = gi[2], c1 = gi[3];
         if (kind == 0 && a.rhs_only) continue;
@@ -238,8 +252,8 @@ __global__ __launch_bounds__(256) void k_gn_gain(GainArgs a) {
                 double w[GAIN_U], a0[GAIN_U], a1[GAIN_U], b0[GAIN_U], b1[GAIN_U];
 #pragma unroll
                 for (int u = 0; u < GAIN_U; ++u) {
-                    w[u] = a.w[(size_t)cw[c + u] * ld + b];
-                    const double2 pa = jg::load_vec(a.Hs, (size_t)ca[c + u], b, ld), pb = jg::load_vec(a.Hs, (size_t)cb[c + u], b, ld);
+                    w[u] = a.w[(size_t)cw[c + u] * ld + b_];
+                    const double2 pa = jg::load_vec(a.Hs, (size_t)ca[c + u], b_, ld), pb = jg::load_vec(a.Hs, (size_t)cb[c + u], b_, ld);
                     a0[u] = pa.x; a1[u] = pa.y; b0[u] = pb.x; b1[u] = pb.y;
                 }
 #pragma unroll
@@ -249,8 +263,8 @@ __global__ __launch_bounds__(256) void k_gn_gain(GainArgs a) {
                 }
             }
             for (; c < c1; ++c) {
-                const double w = a.w[(size_t)cw[c] * ld + b];
-                const double2 pa = jg::load_vec(a.Hs, (size_t)ca[c], b, ld), pb = jg::load_vec(a.Hs, (size_t)cb[c], b, ld);
+                const double w = a.w[(size_t)cw[c] * ld + b_];
+                const double2 pa = jg::load_vec(a.Hs, (size_t)ca[c], b_, ld), pb = jg::load_vec(a.Hs, (size_t)cb[c], b_, ld);
                 const double at = w * pa.x, av = w * pa.y, bt = pb.x, bv = pb.y;
                 g00 += at * bt; g01 += at * bv; g10 += av * bt; g11 += av * bv;
             }
@@ -258,18 +272,18 @@ __global__ __launch_bounds__(256) void k_gn_gain(GainArgs a) {
             if (i == a.slack) { g00 = 0.0; g01 = 0.0; }          // removeColumn(H, slack) on both sides (:885)
             if (j == a.slack) { g00 = 0.0; g10 = 0.0; }
             if (i == a.slack && j == a.slack) g00 = 1.0;         // gain[slack, slack] = 1 (:889)
-            jg::store_blk(a.Gv, (size_t)uniform(a.dst[id]), b, ld, g00, g01, g10, g11);
+            jg::store_blk(a.Gv, (size_t)uniform(a.dst[id]), b_, ld, g00, g01, g10, g11);
 
         } else {
             double r0 = 0.0, r1 = 0.0;
             for (int c = c0; c < c1; ++c) {
-                const double w = a.w[(size_t)cw[c] * ld + b];
-                const double2 pa = jg::load_vec(a.Hs, (size_t)ca[c], b, ld);
-                const double rr = w * a.res[(size_t)cb[c] * ld + b];
+                const double w = a.w[(size_t)cw[c] * ld + b_];
+                const double2 pa = jg::load_vec(a.Hs, (size_t)ca[c], b_, ld);
+                const double rr = w * a.res[(size_t)cb[c] * ld + b_];
                 r0 += pa.x * rr; r1 += pa.y * rr;
             }
             if (id == a.slack) r0 = 0.0;
-            jg::store_vec(a.rhs, (size_t)id, b, ld, r0, r1);
+            jg::store_vec(a.rhs, (size_t)id, b_, ld, r0, r1);
         }
     }
 }
@@ -445,6 +459,7 @@ struct jg_gn {
     std::vector<int8_t> type, code;
     std::vector<int> corr_row;
     int n_items = 0;
+    int gain_local = 1;
     // device
     RowDesc* d_rows = nullptr; int* d_slot_bus = nullptr; BranchP* d_br = nullptr;
     int* d_rowptr = nullptr; double* d_G = nullptr; double* d_B = nullptr; int* d_ydiag = nullptr;
@@ -479,8 +494,11 @@ void launch_rows(jg_gn* h) {
 
 void launch_gain(jg_gn* h, bool correction = false) {
     GainArgs a{h->d_items, h->d_cw, h->d_ca, h->d_cb, h->d_blk_row, h->d_blk_col, h->d_dst, h->d_Hs, correction ? h->d_rho : h->d_res, h->d_w, h->eng.X,
-               correction ? h->d_rhs2 : h->d_rhs, h->n_items, h->slack0, h->ld, correction ? 1 : 0};
-    hipLaunchKernelGGL(k_gn_gain, dim3((h->n_items + 15) / 16, h->ld / 64), dim3(64, 4), 0, h->stream, a);
+               correction ? h->d_rhs2 : h->d_rhs, h->n_items, h->slack0, h->ld, h->gain_local, correction ? 1 : 0};
+    if (h->gain_local)
+        hipLaunchKernelGGL(k_gn_gain, dim3((unsigned)((h->n_items + GAIN_CHUNK - 1) / GAIN_CHUNK) * jg::group_stride(h->ld / 64)), dim3(64, 4), 0, h->stream, a);
+    else
+        hipLaunchKernelGGL(k_gn_gain, dim3((h->n_items + 15) / 16, h->ld / 64), dim3(64, 4), 0, h->stream, a);
 }
 
 int launch_increment(jg_gn* h, const int* group) {
@@ -676,25 +694,40 @@ int jg_gn_create(jg_gn** out, int64_t n, const int64_t* colptr, const int64_t* r
     const std::vector<int>& ip = h->eng.S.iperm;
     std::vector<GainItem> items;
     std::vector<int> cw, ca, cb;
-    {
-        int id = 0;
-        for (const auto& kv : gmap) {
-            const int this_id = id++;
-            if (ip[kv.first.first] > ip[kv.first.second]) continue;              // below the diagonal in pivot order: never read
-            GainItem it{0, this_id, (int)cw.size(), 0};
-            for (const Contrib& c : kv.second) { cw.push_back(c.w); ca.push_back(c.a); cb.push_back(c.b); }
-            it.c1 = (int)cw.size();
-            items.push_back(it);
-        }
-    }
-    for (int i = 0; i < n; ++i) {
+    if (const char* e = getenv("JG_GAIN_LOCAL")) h->gain_local = atoi(e) != 0;
+    auto rhs_item = [&](int i) {
         GainItem it{1, i, (int)cw.size(), 0};
         for (const Contrib& c : rmap[i]) { cw.push_back(c.w); ca.push_back(c.a); cb.push_back(c.b); }
         it.c1 = (int)cw.size();
         items.push_back(it);
+    };
+    {
+        // local mode: bus rows in PIVOT order -- the postorder of the elimination tree keeps electrical neighbours together
+        // whatever the bus numbering of the case is, and neighbours are what shares measurement rows
+        std::vector<std::vector<std::pair<int, const std::vector<Contrib>*>>> by_row(n);   // (block id, contributions) per bus row
+        int id = 0;
+        for (const auto& kv : gmap) {
+            const int this_id = id++;
+            if (ip[kv.first.first] > ip[kv.first.second]) continue;              // below the diagonal in pivot order: never read
+            by_row[kv.first.first].push_back({this_id, &kv.second});
+        }
+        const std::vector<int>& perm = h->eng.S.perm;
+        for (int k = 0; k < n; ++k) {
+            const int i = h->gain_local ? perm[k] : k;
+            for (const auto& blk : by_row[i]) {
+                GainItem it{0, blk.first, (int)cw.size(), 0};
+                for (const Contrib& c : *blk.second) { cw.push_back(c.w); ca.push_back(c.a); cb.push_back(c.b); }
+                it.c1 = (int)cw.size();
+                items.push_back(it);
+            }
+            if (h->gain_local) rhs_item(i);
+        }
     }
-    // heavy gather lists first (they start first on the device)
-    std::stable_sort(items.begin(), items.end(), [](const GainItem& x, const GainItem& y) { return (x.c1 - x.c0) > (y.c1 - y.c0); });
+    if (!h->gain_local) {
+        for (int i = 0; i < n; ++i) rhs_item(i);
+        // heavy gather lists first (they start first on the device)
+        std::stable_sort(items.begin(), items.end(), [](const GainItem& x, const GainItem& y) { return (x.c1 - x.c0) > (y.c1 - y.c0); });
+    }
     h->n_items = (int)items.size();
     // branch parameters
     std::vector<BranchP> br(std::max<int64_t>(nb, 1));
