@@ -120,7 +120,7 @@ __device__ __forceinline__ void branch_row(int ty, const BranchP& p, double Vi, 
 }
 
 // One wave = one measurement row x 64 scenarios.
-__global__ __launch_bounds__(256) void k_gn_rows(RowArgs a) {
+__global__ __launch_bounds__(256, 4) void k_gn_rows(RowArgs a) {
     const int lane = threadIdx.x;
     const int wave = uniform(threadIdx.y);
     const size_t ld = (size_t)a.ld;
