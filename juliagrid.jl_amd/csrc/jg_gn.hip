@@ -203,88 +203,80 @@ __global__ __launch_bounds__(256, 4) void k_gn_rows(RowArgs a) {
     }
 }
 
-constexpr int GAIN_U = 4;
-constexpr int GAIN_CHUNK = 16;   // items per workgroup in local mode
-struct GainItem { int kind; int id; int c0; int c1; };   // kind 0: gain block id (CSR order), 1: rhs row (bus)
+// Gather-list assembly of the gain blocks and of H'W res as WAVE RECORDS (the idiom of the LU engine, jg_symbolic.hpp): an item
+// (one gain block, or one rhs row) is a run of 64-byte records {head, dst, n, -, (weight, slot, slot | row) x 4}; a wave owns a
+// contiguous run of records (whole items, bus rows in pivot order) and fetches each with ONE scalar load, the next one while
+// the 12 operand loads of the current one are in flight.  (The first build chased item -> three index lists -> values and
+// finished the last < 4 contributions one by one: two dependent round trips per contribution for the many 2-term blocks of
+// two-hop neighbours.)  Sums run in list order: bitwise the same result as before.
+//   head: bit 0 kind (0 gain block, 1 rhs row), bit 4 row is the slack bus, bit 5 column is the slack bus, bit 8 last record
+constexpr int GAIN_T = 4;
+struct GainRec { int w[16]; };
+typedef int GRecS __attribute__((ext_vector_type(16)));
+typedef const GRecS __attribute__((address_space(4)))* GRecPtr;
 struct GainArgs {
-    const GainItem* items; const int* cw; const int* ca; const int* cb;   // contribution: weight idx, slot, slot | row
-    const int* blk_row; const int* blk_col; const int* dst;   // dst: gain block -> entry of the factor storage (assembled in place)
+    const GainRec* rec; const int* wave_ptr;      // wave v owns records [wave_ptr[v], wave_ptr[v + 1])
     const double* Hs; const double* res; const double* w;
     double* Gv; double* rhs;
-    int n_items; int slack; int ld;
-    int local;        // 1: items in bus order, chunked per workgroup, XCD-aware grid (see k_gn_gain)
-    int rhs_only;     // 1: only the right-hand-side items (H' W res with another residual vector: the correction pass)
+    int n_waves; int ld;
 };
 
-// G(i,j) = sum w * Hs[a]^T Hs[b]   (2x2 outer products);  rhs(i) = sum w * Hs[a]^T res[row]
 __global__ __launch_bounds__(256) void k_gn_gain(GainArgs a) {
     const int lane = threadIdx.x;
     const int wave = uniform(threadIdx.y);
     const size_t ld = (size_t)a.ld;
-    const size_t b = (size_t)blockIdx.y * 64 + lane;
-    // the gather lists are immutable: read them through the constant address space (scalar loads, no readfirstlane chase)
+    int grp, bx;
+    if (!jg::map_block(jg::GroupSel{}, a.ld, (a.n_waves + 3) / 4, grp, bx)) return;    // scenario group = fast grid index: one group, one XCD
+    const int wv = bx * 4 + wave;
+    if (wv >= a.n_waves) return;
+    const size_t b = (size_t)grp * 64 + lane;
     typedef const int __attribute__((address_space(4)))* CInt;
-    typedef int i4 __attribute__((ext_vector_type(4)));
-    typedef const i4 __attribute__((address_space(4)))* CInt4;
-    CInt cw = (CInt)a.cw, ca = (CInt)a.ca, cb = (CInt)a.cb;
-    // items are sorted heaviest first: a wave takes items w, w + W, w + 2W, ... (W = waves of the launch) so that the
-    // long gather lists spread over all waves instead of sitting four in a row in the first ones
-    // local mode (items in bus order): a workgroup takes GAIN_CHUNK consecutive items, the scenario group is the fast index of
-    // the 1-D grid (jg::map_block) -- the items of one group run on one XCD in list order, so the slots that neighbouring
-    // items share (every row that touches bus i feeds all blocks (i, .) and rhs(i)) are found in that XCD's L2
-    int it0, it1, step;
-    size_t bb = b;
-    if (a.local) {
-        int grp, bx;
-        if (!jg::map_block(jg::GroupSel{}, a.ld, (a.n_items + GAIN_CHUNK - 1) / GAIN_CHUNK, grp, bx)) return;
-        it0 = bx * GAIN_CHUNK + wave; it1 = min((bx + 1) * GAIN_CHUNK, a.n_items); step = blockDim.y;
-        bb = (size_t)grp * 64 + lane;
-    } else { it0 = blockIdx.x * blockDim.y + wave; it1 = a.n_items; step = gridDim.x * blockDim.y; }
-    const size_t b_ = bb;
-    for (int it = it0; it < it1; it += step) {
-        const i4 gi = ((CInt4)a.items)[it];
-        const int kind = gi[0], id = gi[1], c0 = gi[2], c1 = gi[3];
-        if (kind == 0 && a.rhs_only) continue;
-        if (kind == 0) {
-            double g00 = 0.0, g01 = 0.0, g10 = 0.0, g11 = 0.0;
-            int c = c0;
-            for (; c + GAIN_U <= c1; c += GAIN_U) {              // GAIN_U contributions in flight
-                double w[GAIN_U], a0[GAIN_U], a1[GAIN_U], b0[GAIN_U], b1[GAIN_U];
+    CInt wp = (CInt)a.wave_ptr;
+    int r = wp[wv];
+    const int r1 = wp[wv + 1];
+    if (r >= r1) return;
+    GRecS cur = ((GRecPtr)a.rec)[r];
+    double g00 = 0.0, g01 = 0.0, g10 = 0.0, g11 = 0.0;
+    for (; r < r1; ++r) {
+        GRecS nxt = cur;
+        if (r + 1 < r1) nxt = ((GRecPtr)a.rec)[r + 1];
+        const int head = cur[0], n = cur[2];
+        const bool is_rhs = head & 1;
+        double wt[GAIN_T], x0[GAIN_T], x1[GAIN_T], y0[GAIN_T], y1[GAIN_T];
 #pragma unroll
-                for (int u = 0; u < GAIN_U; ++u) {
-                    w[u] = a.w[(size_t)cw[c + u] * ld + b_];
-                    const double2 pa = jg::load_vec(a.Hs, (size_t)ca[c + u], b_, ld), pb = jg::load_vec(a.Hs, (size_t)cb[c + u], b_, ld);
-                    a0[u] = pa.x; a1[u] = pa.y; b0[u] = pb.x; b1[u] = pb.y;
-                }
-#pragma unroll
-                for (int u = 0; u < GAIN_U; ++u) {
-                    const double at = w[u] * a0[u], av = w[u] * a1[u];
-                    g00 += at * b0[u]; g01 += at * b1[u]; g10 += av * b0[u]; g11 += av * b1[u];
-                }
+        for (int t = 0; t < GAIN_T; ++t) {
+            if (t < n) {
+                wt[t] = a.w[(size_t)cur[4 + 3 * t] * ld + b];
+                const double2 pa = jg::load_vec(a.Hs, (size_t)cur[5 + 3 * t], b, ld);
+                x0[t] = pa.x; x1[t] = pa.y;
+                if (is_rhs) { y0[t] = a.res[(size_t)cur[6 + 3 * t] * ld + b]; y1[t] = 0.0; }
+                else if (cur[6 + 3 * t] == cur[5 + 3 * t]) { y0[t] = pa.x; y1[t] = pa.y; }     // diagonal blocks: the same slot on both sides (half of all block terms)
+                else { const double2 pb = jg::load_vec(a.Hs, (size_t)cur[6 + 3 * t], b, ld); y0[t] = pb.x; y1[t] = pb.y; }
             }
-            for (; c < c1; ++c) {
-                const double w = a.w[(size_t)cw[c] * ld + b_];
-                const double2 pa = jg::load_vec(a.Hs, (size_t)ca[c], b_, ld), pb = jg::load_vec(a.Hs, (size_t)cb[c], b_, ld);
-                const double at = w * pa.x, av = w * pa.y, bt = pb.x, bv = pb.y;
-                g00 += at * bt; g01 += at * bv; g10 += av * bt; g11 += av * bv;
-            }
-            const int i = uniform(a.blk_row[id]), j = uniform(a.blk_col[id]);
-            if (i == a.slack) { g00 = 0.0; g01 = 0.0; }          // removeColumn(H, slack) on both sides (:885)
-            if (j == a.slack) { g00 = 0.0; g10 = 0.0; }
-            if (i == a.slack && j == a.slack) g00 = 1.0;         // gain[slack, slack] = 1 (:889)
-            jg::store_blk(a.Gv, (size_t)uniform(a.dst[id]), b_, ld, g00, g01, g10, g11);
-
-        } else {
-            double r0 = 0.0, r1 = 0.0;
-            for (int c = c0; c < c1; ++c) {
-                const double w = a.w[(size_t)cw[c] * ld + b_];
-                const double2 pa = jg::load_vec(a.Hs, (size_t)ca[c], b_, ld);
-                const double rr = w * a.res[(size_t)cb[c] * ld + b_];
-                r0 += pa.x * rr; r1 += pa.y * rr;
-            }
-            if (id == a.slack) r0 = 0.0;
-            jg::store_vec(a.rhs, (size_t)id, b_, ld, r0, r1);
         }
+#pragma unroll
+        for (int t = 0; t < GAIN_T; ++t) {
+            if (t < n) {
+                if (is_rhs) { const double rr = wt[t] * y0[t]; g00 += x0[t] * rr; g01 += x1[t] * rr; }
+                else {
+                    const double at = wt[t] * x0[t], av = wt[t] * x1[t];
+                    g00 += at * y0[t]; g01 += at * y1[t]; g10 += av * y0[t]; g11 += av * y1[t];
+                }
+            }
+        }
+        if (head & 256) {                                                // last record of the item
+            if (is_rhs) {
+                if (head & 16) g00 = 0.0;                                // the slack angle has no equation (:899)
+                jg::store_vec(a.rhs, (size_t)cur[1], b, ld, g00, g01);
+            } else {
+                if (head & 16) { g00 = 0.0; g01 = 0.0; }                 // removeColumn(H, slack) on both sides (:885)
+                if (head & 32) { g00 = 0.0; g10 = 0.0; }
+                if ((head & 48) == 48) g00 = 1.0;                        // gain[slack, slack] = 1 (:889)
+                jg::store_blk(a.Gv, (size_t)cur[1], b, ld, g00, g01, g10, g11);
+            }
+            g00 = 0.0; g01 = 0.0; g10 = 0.0; g11 = 0.0;
+        }
+        cur = nxt;
     }
 }
 
@@ -458,14 +450,13 @@ struct jg_gn {
     std::vector<int> gi_rowptr, gi_col;         // gain block CSR
     std::vector<int8_t> type, code;
     std::vector<int> corr_row;
-    int n_items = 0;
-    int gain_local = 1;
+    int gain_waves = 0, rhs_waves = 0;          // waves of the gain launch / of the rhs-only (correction) launch
     // device
     RowDesc* d_rows = nullptr; int* d_slot_bus = nullptr; BranchP* d_br = nullptr;
     int* d_rowptr = nullptr; double* d_G = nullptr; double* d_B = nullptr; int* d_ydiag = nullptr;
     double* d_vm = nullptr; double* d_va = nullptr; double* d_mean = nullptr; double* d_w = nullptr;
     double* d_Hs = nullptr; double* d_res = nullptr; double* d_rhs = nullptr; double* d_inc = nullptr;
-    GainItem* d_items = nullptr; int* d_cw = nullptr; int* d_ca = nullptr; int* d_cb = nullptr; int* d_blk_row = nullptr; int* d_blk_col = nullptr; int* d_dst = nullptr;
+    GainRec* d_grec = nullptr; int* d_gwave = nullptr; GainRec* d_rrec = nullptr; int* d_rwave = nullptr;   // gain + rhs records, rhs records alone
     // bad-data test (built on first use)
     std::vector<RowDesc> rows_host; std::vector<int> slot_bus_host;
     int* d_pair_ptr = nullptr; int* d_pa = nullptr; int* d_pb = nullptr; int* d_pz = nullptr;
@@ -493,12 +484,10 @@ void launch_rows(jg_gn* h) {
 }
 
 void launch_gain(jg_gn* h, bool correction = false) {
-    GainArgs a{h->d_items, h->d_cw, h->d_ca, h->d_cb, h->d_blk_row, h->d_blk_col, h->d_dst, h->d_Hs, correction ? h->d_rho : h->d_res, h->d_w, h->eng.X,
-               correction ? h->d_rhs2 : h->d_rhs, h->n_items, h->slack0, h->ld, h->gain_local, correction ? 1 : 0};
-    if (h->gain_local)
-        hipLaunchKernelGGL(k_gn_gain, dim3((unsigned)((h->n_items + GAIN_CHUNK - 1) / GAIN_CHUNK) * jg::group_stride(h->ld / 64)), dim3(64, 4), 0, h->stream, a);
-    else
-        hipLaunchKernelGGL(k_gn_gain, dim3((h->n_items + 15) / 16, h->ld / 64), dim3(64, 4), 0, h->stream, a);
+    const int nw = correction ? h->rhs_waves : h->gain_waves;
+    GainArgs a{correction ? h->d_rrec : h->d_grec, correction ? h->d_rwave : h->d_gwave, h->d_Hs, correction ? h->d_rho : h->d_res, h->d_w, h->eng.X,
+               correction ? h->d_rhs2 : h->d_rhs, nw, h->ld};
+    hipLaunchKernelGGL(k_gn_gain, dim3((unsigned)((nw + 3) / 4) * jg::group_stride(h->ld / 64)), dim3(64, 4), 0, h->stream, a);
 }
 
 int launch_increment(jg_gn* h, const int* group) {
@@ -692,18 +681,25 @@ int jg_gn_create(jg_gn** out, int64_t n, const int64_t* colptr, const int64_t* r
     rc = h->eng.create((int)n, h->gi_rowptr.data(), h->gi_col.data(), h->ld, 3, h->stream);
     if (rc) { std::string msg = h->eng.error; jg_gn_destroy(h); return failg(rc, msg); }
     const std::vector<int>& ip = h->eng.S.iperm;
-    std::vector<GainItem> items;
-    std::vector<int> cw, ca, cb;
-    if (const char* e = getenv("JG_GAIN_LOCAL")) h->gain_local = atoi(e) != 0;
-    auto rhs_item = [&](int i) {
-        GainItem it{1, i, (int)cw.size(), 0};
-        for (const Contrib& c : rmap[i]) { cw.push_back(c.w); ca.push_back(c.a); cb.push_back(c.b); }
-        it.c1 = (int)cw.size();
-        items.push_back(it);
-    };
+    // wave records (see k_gn_gain): bus rows in PIVOT order -- the postorder of the elimination tree keeps electrical
+    // neighbours together whatever the bus numbering of the case is, and neighbours are what shares measurement rows
+    std::vector<GainRec> grec, rrec;
+    std::vector<int> gwave{0}, rwave{0};
     {
-        // local mode: bus rows in PIVOT order -- the postorder of the elimination tree keeps electrical neighbours together
-        // whatever the bus numbering of the case is, and neighbours are what shares measurement rows
+        const int slack = h->slack0;                                             // -1: the model has no slack (PMU-only)
+        const std::vector<int>& src_entry = h->eng.S.src_entry;
+        auto emit = [&](std::vector<GainRec>& out, int head, int dst, const std::vector<Contrib>& cs) {
+            size_t q = 0;
+            do {
+                GainRec r{};
+                r.w[0] = head; r.w[1] = dst;
+                int nt = 0;
+                for (; nt < GAIN_T && q < cs.size(); ++nt, ++q) { r.w[4 + 3 * nt] = cs[q].w; r.w[5 + 3 * nt] = cs[q].a; r.w[6 + 3 * nt] = cs[q].b; }
+                r.w[2] = nt;
+                if (q >= cs.size()) r.w[0] |= 256;
+                out.push_back(r);
+            } while (q < cs.size());
+        };
         std::vector<std::vector<std::pair<int, const std::vector<Contrib>*>>> by_row(n);   // (block id, contributions) per bus row
         int id = 0;
         for (const auto& kv : gmap) {
@@ -712,23 +708,23 @@ int jg_gn_create(jg_gn** out, int64_t n, const int64_t* colptr, const int64_t* r
             by_row[kv.first.first].push_back({this_id, &kv.second});
         }
         const std::vector<int>& perm = h->eng.S.perm;
+        constexpr size_t WAVE_RECS = 8;                                          // a wave's share: about 8 records, whole items
         for (int k = 0; k < n; ++k) {
-            const int i = h->gain_local ? perm[k] : k;
+            const int i = perm[k];
             for (const auto& blk : by_row[i]) {
-                GainItem it{0, blk.first, (int)cw.size(), 0};
-                for (const Contrib& c : *blk.second) { cw.push_back(c.w); ca.push_back(c.a); cb.push_back(c.b); }
-                it.c1 = (int)cw.size();
-                items.push_back(it);
+                const int j = blk_col[blk.first];
+                emit(grec, 0 | (i == slack ? 16 : 0) | (j == slack ? 32 : 0), src_entry[blk.first], *blk.second);
+                if (grec.size() - (size_t)gwave.back() >= WAVE_RECS) gwave.push_back((int)grec.size());
             }
-            if (h->gain_local) rhs_item(i);
+            emit(grec, 1 | (i == slack ? 16 : 0), i, rmap[i]);
+            if (grec.size() - (size_t)gwave.back() >= WAVE_RECS) gwave.push_back((int)grec.size());
+            emit(rrec, 1 | (i == slack ? 16 : 0), i, rmap[i]);
+            if (rrec.size() - (size_t)rwave.back() >= WAVE_RECS) rwave.push_back((int)rrec.size());
         }
+        if (gwave.back() != (int)grec.size()) gwave.push_back((int)grec.size());
+        if (rwave.back() != (int)rrec.size()) rwave.push_back((int)rrec.size());
+        h->gain_waves = (int)gwave.size() - 1; h->rhs_waves = (int)rwave.size() - 1;
     }
-    if (!h->gain_local) {
-        for (int i = 0; i < n; ++i) rhs_item(i);
-        // heavy gather lists first (they start first on the device)
-        std::stable_sort(items.begin(), items.end(), [](const GainItem& x, const GainItem& y) { return (x.c1 - x.c0) > (y.c1 - y.c0); });
-    }
-    h->n_items = (int)items.size();
     // branch parameters
     std::vector<BranchP> br(std::max<int64_t>(nb, 1));
     for (int64_t k = 0; k < nb; ++k) {
@@ -739,8 +735,8 @@ int jg_gn_create(jg_gn** out, int64_t n, const int64_t* colptr, const int64_t* r
     std::string err;
     if (jg::upload(&h->d_rows, rows, err, h->stream) || jg::upload(&h->d_slot_bus, slot_bus, err, h->stream) || jg::upload(&h->d_br, br, err, h->stream) ||
         jg::upload(&h->d_rowptr, rp, err, h->stream) || jg::upload(&h->d_G, G, err, h->stream) || jg::upload(&h->d_B, B, err, h->stream) || jg::upload(&h->d_ydiag, ydiag, err, h->stream) ||
-        jg::upload(&h->d_items, items, err, h->stream) || jg::upload(&h->d_cw, cw, err, h->stream) || jg::upload(&h->d_ca, ca, err, h->stream) || jg::upload(&h->d_cb, cb, err, h->stream) ||
-        jg::upload(&h->d_blk_row, blk_row, err, h->stream) || jg::upload(&h->d_blk_col, blk_col, err, h->stream)) {
+        jg::upload(&h->d_grec, grec, err, h->stream) || jg::upload(&h->d_gwave, gwave, err, h->stream) || jg::upload(&h->d_rrec, rrec, err, h->stream) ||
+        jg::upload(&h->d_rwave, rwave, err, h->stream)) {
         jg_gn_destroy(h); return failg(2, err);
     }
     const size_t ld = h->ld;
@@ -757,7 +753,6 @@ int jg_gn_create(jg_gn** out, int64_t n, const int64_t* colptr, const int64_t* r
     if (!ok || hipHostMalloc((void**)&h->h_counter, sizeof(int)) != hipSuccess) {
         jg_gn_destroy(h); return failg(2, "jg_gn_create: device allocation failed");
     }
-    if (jg::upload(&h->d_dst, h->eng.S.src_entry, err, h->stream)) { jg_gn_destroy(h); return failg(2, err); }
     *out = h;
     return 0;
 }
@@ -771,11 +766,11 @@ void jg_gn_destroy(jg_gn* h) {
     h->eng.destroy();
     hipFree(h->d_rows); hipFree(h->d_slot_bus); hipFree(h->d_br); hipFree(h->d_rowptr); hipFree(h->d_G); hipFree(h->d_B); hipFree(h->d_ydiag);
     hipFree(h->d_vm0); hipFree(h->d_va0); hipFree(h->d_rho); hipFree(h->d_rhs2); hipFree(h->d_inc2);
-    hipFree(h->d_vm); hipFree(h->d_va); hipFree(h->d_mean); hipFree(h->d_w); hipFree(h->d_Hs); hipFree(h->d_res); hipFree(h->d_dst);
+    hipFree(h->d_vm); hipFree(h->d_va); hipFree(h->d_mean); hipFree(h->d_w); hipFree(h->d_Hs); hipFree(h->d_res);
     hipFree(h->d_pair_ptr); hipFree(h->d_pa); hipFree(h->d_pb); hipFree(h->d_pz); hipFree(h->d_nres); hipFree(h->d_amax_v); hipFree(h->d_amax_i);
     hipFree(h->d_bad_v); hipFree(h->d_bad_i);
-    hipFree(h->d_rhs); hipFree(h->d_inc); hipFree(h->d_items); hipFree(h->d_cw); hipFree(h->d_ca); hipFree(h->d_cb); hipFree(h->d_blk_row);
-    hipFree(h->d_blk_col); hipFree(h->d_part); hipFree(h->d_maxinc); hipFree(h->d_params); hipFree(h->d_active); hipFree(h->d_iters);
+    hipFree(h->d_rhs); hipFree(h->d_inc); hipFree(h->d_grec); hipFree(h->d_gwave); hipFree(h->d_rrec); hipFree(h->d_rwave);
+    hipFree(h->d_part); hipFree(h->d_maxinc); hipFree(h->d_params); hipFree(h->d_active); hipFree(h->d_iters);
     hipFree(h->d_status); hipFree(h->d_counter); hipFree(h->d_group);
     if (h->h_counter) hipHostFree(h->h_counter);
     if (h->stream) hipStreamDestroy(h->stream);
