@@ -246,6 +246,7 @@ def main():
         res.copy_(torch.from_numpy(np.stack([h.method.iteration, h.status], axis=1).astype(np.int32)))
         if cdev == "cuda":
             jg.gatherResults(dist, res[:, 0], res[:, 1], out_vm, out_va)
+            torch.cuda.current_stream().synchronize()   # the staging buffers are rewritten by the next step's results
         else:
             jg.gatherResults(dist, res[:, 0].cpu(), res[:, 1].cpu(), out_vm.cpu(), out_va.cpu())
 
