@@ -266,6 +266,8 @@ __global__ __launch_bounds__(1024) void k_check(CheckArgs a) {
 struct CompactArgs {
     int* active; int* iters; int* status; int* lu_status; int* lid; int* ppos; int mp;
     int* dest; int* group; int* glist; int* flags; int* tmp; int ld; int restore;
+    int* host_count;           // nullable: pinned host word that receives the number of active scenarios (what the host loop polls:
+                               // a store from this kernel instead of a memset node and a 4-byte copy node per iteration, ~20 us each)
 };
 
 __global__ __launch_bounds__(1024) void k_compact(CompactArgs a) {
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(1024) void k_compact(CompactArgs a) {
     const int groups_cur = a.flags[2];
     const bool permute = a.restore ? true : (n_active > 0 && groups_new < groups_cur);
     __syncthreads();
-    if (t == 0) { a.flags[0] = permute ? 1 : 0; a.flags[1] = n_active; if (permute) a.flags[2] = a.restore ? ngroups : groups_new; }
+    if (t == 0) { a.flags[0] = permute ? 1 : 0; a.flags[1] = n_active; if (permute) a.flags[2] = a.restore ? ngroups : groups_new; if (a.host_count) *a.host_count = n_active; }
     if (!permute) {                                               // groups = those that still hold an active lane
         for (int g = t; g < ngroups; g += 1024) {
             int any = 0;
@@ -433,6 +435,7 @@ struct jg_nr {
     hipGraphExec_t execA = nullptr, execB = nullptr;
     bool jac_valid = false;
     int* h_counter = nullptr;        // pinned
+    int* h_counter_dev = nullptr;    // its device alias
 };
 
 namespace {
@@ -478,9 +481,9 @@ int put_bus_array(jg_nr* h, double* dst, const double* src, int64_t stride) {
 }
 
 // pack the active scenarios into the leading lanes (restore = 1: send every lane back home)
-void launch_compact(jg_nr* h, int restore) {
+void launch_compact(jg_nr* h, int restore, bool report = false) {
     CompactArgs c{h->d_active, h->d_iters, h->d_status, h->eng.status, h->d_lid, h->d_ppos, h->mp, h->d_dest, h->d_group,
-                  h->d_glist, h->d_cflags, h->d_itmp, h->ld, restore};
+                  h->d_glist, h->d_cflags, h->d_itmp, h->ld, restore, report ? h->h_counter_dev : nullptr};
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, c);
     if (h->ld == 64) return;                       // one lane group: nothing to pack, lanes never leave their home order
     double* tmp = h->eng.X;                        // the factor is dead here (rebuilt by the next factorisation)
@@ -527,12 +530,10 @@ int build_graphs(jg_nr* h) {
     // still-active lanes.  A compaction moves lanes (and stages them in the factor storage), so the assembly is repeated
     // on the packed lanes -- a launch that returns at once unless the compaction flag is set.
     auto verdict = [&]() {
-        hipMemsetAsync(h->d_counter, 0, sizeof(int), h->stream);
         launch_assemble(h, active_groups(h), true);
         launch_check(h, 1, h->d_group);
-        launch_compact(h, 0);
+        launch_compact(h, 0, true);                    // also reports the number of active scenarios to the host word
         if (h->ld > 64) launch_assemble(h, active_groups(h), true, nullptr, 0, h->d_cflags);
-        hipMemcpyAsync(h->h_counter, h->d_counter, sizeof(int), hipMemcpyDeviceToHost, h->stream);
     };
     // graph A: the verdict on the start point
     verdict();
@@ -691,6 +692,7 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
         hipHostMalloc((void**)&h->h_counter, sizeof(int)) != hipSuccess) {
         jg_nr_destroy(h); return fail(2, "jg_nr_create: pinned allocation failed");
     }
+    if (hipHostGetDevicePointer((void**)&h->h_counter_dev, h->h_counter, 0) != hipSuccess) { jg_nr_destroy(h); return fail(2, "jg_nr_create: pinned host word is not device-visible"); }
     rc = h->eng.create(n, rp.data(), cl.data(), h->ld, 1, h->stream);          // in place: the assembly kernel writes into the factor storage
     if (rc) { std::string m = h->eng.error; jg_nr_destroy(h); return fail(rc, m); }
     if (jg::upload(&h->d_dst, h->eng.S.src_entry, err, h->stream)) { jg_nr_destroy(h); return fail(2, err); }
