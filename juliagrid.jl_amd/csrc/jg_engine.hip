@@ -185,16 +185,27 @@ __device__ __forceinline__ void bwd_record(const BwdArgs& a, const RecS& r, size
 }
 
 // x_k = D_k^-1 y, stored in pivot order (W), scattered to original order (out), optional fused state update
-__device__ __forceinline__ double2 bwd_finish(const BwdArgs& a, const Blk& d, double y0, double y1, int k, int bus, size_t b, size_t ld) {
+// What the fused state update needs besides x: requested when the row's record arrives, not after its solve (the bus flag was a
+// dependent vector load + readfirstlane and the old state a dependent read-modify-write at the very end of every backward level)
+struct UpdPre { int fl; bool act; double va, vm; };
+__device__ __forceinline__ UpdPre upd_prefetch(const BwdArgs& a, int bus, size_t b, size_t ld) {
+    UpdPre p{0, false, 0.0, 0.0};
+    if (a.upd.va) {
+        p.act = a.upd.active ? (a.upd.active[b] != 0) : true;
+        p.fl = uniform((int)a.upd.flags[bus]);
+        p.va = a.upd.va[(size_t)bus * ld + b];
+        p.vm = a.upd.vm[(size_t)bus * ld + b];
+    }
+    return p;
+}
+__device__ __forceinline__ double2 bwd_finish(const BwdArgs& a, const Blk& d, double y0, double y1, int k, int bus, size_t b, size_t ld, const UpdPre& p) {
     double x0, x1;
     dsolve(d, y0, y1, x0, x1);
     store_vec(a.W, (size_t)k, b, ld, x0, x1);
     store_vec(a.out, (size_t)bus, b, ld, x0, x1);
     if (a.upd.va) {
-        const bool act = a.upd.active ? (a.upd.active[b] != 0) : true;
-        const int fl = uniform((int)a.upd.flags[bus]);
-        if (act && (fl & 1)) a.upd.va[(size_t)bus * ld + b] += a.upd.sign * x0;
-        if (act && (fl & 2)) a.upd.vm[(size_t)bus * ld + b] += a.upd.sign * x1;
+        if (p.act && (p.fl & 1)) a.upd.va[(size_t)bus * ld + b] = p.va + a.upd.sign * x0;
+        if (p.act && (p.fl & 2)) a.upd.vm[(size_t)bus * ld + b] = p.vm + a.upd.sign * x1;
     }
     return double2{x0, x1};
 }
@@ -220,6 +231,10 @@ __device__ __forceinline__ void bwd_chain_task(const BwdArgs& a, double* lds, co
     double2* part = xe + CHAIN_MAX_EXT * 64;
     double2* xc = part + 16 * 64;
     for (int q = wave; q < nE; q += 16) xe[q * 64 + lane] = load_vec(a.W, (size_t)ecol[q], b, ld);
+    // the state-update operands of the (at most two) pivots this wave finishes in phase B: requested now, off the sequential path
+    UpdPre up0{0, false, 0.0, 0.0}, up1{0, false, 0.0, 0.0};
+    if (wave < nb) up0 = upd_prefetch(a, rows[3 * wave + 1], b, ld);
+    if (wave + 16 < nb) up1 = upd_prefetch(a, rows[3 * (wave + 16) + 1], b, ld);
     __syncthreads();
     // ---- phase A
     const int rpr = 16 / wpr, sub = wave & (wpr - 1);
@@ -270,7 +285,7 @@ __device__ __forceinline__ void bwd_chain_task(const BwdArgs& a, double* lds, co
                 double2* slot = xc + (c & 1) * 64;
                 if (wave == (c & 15)) {
                     const double2 y = acc[c * 64 + lane];
-                    slot[lane] = bwd_finish(a, db[s], y.x, y.y, rows[3 * c], rows[3 * c + 1], b, ld);
+                    slot[lane] = bwd_finish(a, db[s], y.x, y.y, rows[3 * c], rows[3 * c + 1], b, ld, c < 16 ? up0 : up1);
                 }
                 __syncthreads();
                 const double2 x = slot[lane];
@@ -299,8 +314,10 @@ __device__ __forceinline__ void bwd_chunk(const BwdArgs& a, double* red, const R
     const int k = rec_word(first, 0), bus = rec_word(first, 1), dg = rec_word(first, 2);
     double y0 = 0.0, y1 = 0.0;
     Blk d{0.0, 0.0, 0.0, 0.0};
+    UpdPre up{0, false, 0.0, 0.0};
     if (k >= 0) {
         if (sub == 0) {
+            up = upd_prefetch(a, bus, b, ld);
             const double2 y = load_vec(a.W, (size_t)k, b, ld);
             y0 = y.x; y1 = y.y;
             d = load_blk(a.X, (size_t)dg, b, ld);
@@ -317,7 +334,7 @@ __device__ __forceinline__ void bwd_chunk(const BwdArgs& a, double* red, const R
     if (wpi > 1) __syncthreads();
     if (k >= 0 && sub == 0) {
         for (int w = 1; w < wpi; ++w) { const double2 p = ((const double2*)red)[(size_t)(wave + w) * 64 + lane]; y0 += p.x; y1 += p.y; }
-        bwd_finish(a, d, y0, y1, k, bus, b, ld);
+        bwd_finish(a, d, y0, y1, k, bus, b, ld, up);
     }
     if (wpi > 1) __syncthreads();
 }

@@ -87,16 +87,31 @@ __device__ __forceinline__ void store_vec(double* base, size_t item, size_t b, s
     *(double2*)(base + (item * ld + b) * 2) = double2{v0, v1};
 }
 
-// blockIdx.x -> (scenario group g, chunk x) of an nx-chunk launch; false: nothing to do for this workgroup
+// blockIdx.x -> (scenario group g, chunk x) of an nx-chunk launch; false: nothing to do for this workgroup.
+// The group list and its length sit on the critical path of EVERY level launch (a workgroup cannot fetch its record before it
+// knows its group), so they are read through the scalar cache, the count and the first eight list entries in parallel (the
+// list is padded to eight entries; both are written by an earlier kernel and constant within a launch): one round trip
+// instead of two dependent vector loads + readfirstlane -- 0.88 -> 0.78 ms per iteration graph of a single instance.
+typedef const int __attribute__((address_space(4)))* SelIntPtr;
+typedef int SelInt8 __attribute__((ext_vector_type(8)));
+typedef const SelInt8 __attribute__((address_space(4)))* SelInt8Ptr;
 __device__ __forceinline__ bool map_block(const GroupSel& sel, int ld, int nx, int& g, int& x) {
     const int id = blockIdx.x;
-    const int gact = sel.list ? uniform(*sel.count) : ld / 64;
+    int gact = ld / 64;
+    SelInt8 first{};
+    if (sel.list) { first = *(SelInt8Ptr)sel.list; gact = *(SelIntPtr)sel.count; }
     const int gs = group_stride(gact);
     const int slot = id % gs;
     x = id / gs;
     if (slot >= gact || x >= nx) return false;
-    g = sel.list ? uniform(sel.list[slot]) : slot;
-    return !(sel.flags && !sel.flags[g]);
+    if (sel.list) {
+        if (gs <= 8) {
+            g = first[0];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) g = slot == k ? first[k] : g;
+        } else g = ((SelIntPtr)sel.list)[slot];
+    } else g = slot;
+    return !(sel.flags && !((SelIntPtr)sel.flags)[g]);
 }
 #endif
 

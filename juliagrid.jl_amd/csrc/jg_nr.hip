@@ -686,7 +686,7 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
               dmalloc((void**)&h->d_status, ld * 4) && dmalloc((void**)&h->d_counter, 4) &&
               dmalloc((void**)&h->d_group, (ld / 64) * 4) && dmalloc((void**)&h->d_lid, ld * 4) &&
               dmalloc((void**)&h->d_dest, ld * 4) && dmalloc((void**)&h->d_cflags, 16) && dmalloc((void**)&h->d_itmp, ld * 4) &&
-              dmalloc((void**)&h->d_glist, (ld / 64) * 4);
+              dmalloc((void**)&h->d_glist, std::max<size_t>(ld / 64, 8) * 4);    // map_block reads the first eight entries in one scalar load
     if (!ok) { jg_nr_destroy(h); return fail(2, "jg_nr_create: device allocation failed"); }
     if (jg::sync_fill(h->d_ppos, 0xff, mpn * ld * 4, h->stream) != hipSuccess ||     // -1 = no patch
         hipHostMalloc((void**)&h->h_counter, sizeof(int)) != hipSuccess) {
@@ -936,11 +936,15 @@ int jg_nr_run(jg_nr* h, int64_t max_iter, double tol, int32_t* iters, int32_t* s
     if (trace) fprintf(stderr, "[jg_nr_run] start point: %d scenarios active, %.1f us\n", *h->h_counter, now_us() - t_setup);
     for (int64_t it = 0; it <= max_iter && *h->h_counter != 0; ++it) {          // the iteration limit itself is kept on the device (k_check)
         const double tc = now_us();
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (trace) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, h->stream); }
         {
             jg::Engine::WalkTurn turn(h->eng, h->stream);
             NR_HIP(hipGraphLaunch(h->execB, h->stream));                       // solve!, then mismatch! and the verdict on the new state
         }
+        if (trace) hipEventRecord(e1, h->stream);
         NR_HIP(hipStreamSynchronize(h->stream));
+        if (trace) { float ms = 0.f; hipEventElapsedTime(&ms, e0, e1); fprintf(stderr, "[jg_nr_run] graph on the device: %.1f us\n", 1e3 * ms); hipEventDestroy(e0); hipEventDestroy(e1); }
         if (trace) {
             int cf[4];
             jg::sync_copy(cf, h->d_cflags, sizeof(cf), hipMemcpyDeviceToHost, h->stream);
