@@ -92,7 +92,7 @@ class ContingencyPipeline:
     Why: the sparse LU replays ~100 dependency levels per iteration and most of them occupy a fraction of the chip for
     a few microseconds (latency bound), and the last iterations of a batch run on the few scenarios that have not
     converged yet.  A second and third batch fill those holes: kernels of different streams run concurrently.  Measured
-    on MI355X, case_ACTIVSg10k, 512 scenarios per batch: 131k NR iterations/s with 1 batch in flight, 213k with 3.
+    on MI355X, case_ACTIVSg10k, 512 scenarios per batch: 131k NR iterations/s with 1 batch in flight, 215k with 3.
 
     jobs are processed in order; `on_done(job, analysis)` (optional) is called on the CALLER's thread in job order while
     the batch's results are still resident (this is where a sharded run issues its RCCL gather: collectives must be
