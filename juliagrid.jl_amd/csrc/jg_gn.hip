@@ -127,9 +127,20 @@ __global__ __launch_bounds__(256, 4) void k_gn_rows(RowArgs a) {
     const size_t b = (size_t)blockIdx.y * 64 + lane;
     const int r0 = blockIdx.x * GN_ROWS;
     const int r1 = min(r0 + GN_ROWS, a.m);
+    // the row table, the slot -> bus map, the branch parameters and Ybus are wave-uniform and immutable within a launch: they come
+    // through the scalar cache (constant address space), not as 64 identical vector loads followed by readfirstlane
+    typedef const int __attribute__((address_space(4)))* CInt;
+    typedef const double __attribute__((address_space(4)))* CDbl;
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    typedef const i4 __attribute__((address_space(4)))* CInt4;
+    typedef int i16 __attribute__((ext_vector_type(16)));
+    typedef const i16 __attribute__((address_space(4)))* CBranch;       // a BranchP is 64 bytes: one s_load_dwordx16
+    auto branch = [&](int k) { const i16 raw = ((CBranch)a.br)[k]; BranchP q; __builtin_memcpy(&q, &raw, sizeof(q)); return q; };
+    CInt slot_bus = (CInt)a.slot_bus, rowptr = (CInt)a.rowptr, ydiag = (CInt)a.ydiag;
+    CDbl Gs = (CDbl)a.G, Bs = (CDbl)a.Bv;
     for (int r = r0 + wave; r < r1; r += blockDim.y) {
-        const RowDesc* rd = a.rows + r;
-        const int ty = uniform(rd->type), idx = uniform(rd->idx), s0 = uniform(rd->slot0), ns = uniform(rd->nslots);
+        const i4 rd = ((CInt4)a.rows)[r];
+        const int ty = rd[0], idx = rd[1], s0 = rd[2], ns = rd[3];
         // a slot = the 1x2 block (d/dtheta, d/dV) of one (row, bus) pair, interleaved per scenario: one 16-byte store
         auto put = [&](int s, double dth, double dvm) { jg::store_vec(a.Hs, (size_t)(s0 + s), b, ld, dth, dvm); };
         if (ty == 0) {                                 // masked: row kept, H = 0, residual 0 (T7)
@@ -144,8 +155,8 @@ __global__ __launch_bounds__(256, 4) void k_gn_rows(RowArgs a) {
                 put(0, ty == 22 ? 1.0 : 0.0, ty == 22 ? 0.0 : 1.0);
                 a.res[(size_t)r * ld + b] = z - x;
             } else {                                   // branch current phasor (:140-166, backend/expressions.jl:291-349)
-                const BranchP p = a.br[idx];
-                const int i = uniform(p.from), j = uniform(p.to);
+                const BranchP p = branch(idx);
+                const int i = p.from, j = p.to;
                 double sn, cs, A, B, Cc, D;
                 sincos(p.shift, &sn, &cs);
                 if (ty <= 25) { A = p.tinv * p.tinv * (p.g + p.gs); B = -p.tinv * p.tinv * (p.b + p.bs); Cc = -p.tinv * (p.g * cs - p.b * sn); D = p.tinv * (p.b * cs + p.g * sn); }
@@ -169,13 +180,13 @@ __global__ __launch_bounds__(256, 4) void k_gn_rows(RowArgs a) {
         } else if (ty == 6 || ty == 9) {               // injections: slots follow the Ybus row of the bus
             const int i = idx;
             const double Vi = a.vm[(size_t)i * ld + b], thi = a.va[(size_t)i * ld + b];
-            const int p0 = uniform(a.rowptr[i]);
-            const int pd = uniform(a.ydiag[i]);
+            const int p0 = rowptr[i];
+            const int pd = ydiag[i];
             double s1 = 0.0, s2 = 0.0;
             for (int s = 0; s < ns; ++s) {
                 const int p = p0 + s;
-                const int j = uniform(a.slot_bus[s0 + s]);
-                const double g = a.G[p], bb = a.Bv[p];
+                const int j = slot_bus[s0 + s];
+                const double g = Gs[p], bb = Bs[p];
                 const double Vj = a.vm[(size_t)j * ld + b], thj = a.va[(size_t)j * ld + b];
                 double sn, cs;
                 sincos(thi - thj, &sn, &cs);
@@ -186,13 +197,13 @@ __global__ __launch_bounds__(256, 4) void k_gn_rows(RowArgs a) {
                     else put(s, -(Vi * Vj) * ac, Vi * ad);
                 }
             }
-            const double gii = a.G[pd], bii = a.Bv[pd];
+            const double gii = Gs[pd], bii = Bs[pd];
             const int sd = pd - p0;
             if (ty == 6) { put(sd, -Vi * s2 - bii * (Vi * Vi), s1 + gii * Vi); a.res[(size_t)r * ld + b] = z - Vi * s1; }
             else { put(sd, Vi * s1 - gii * (Vi * Vi), s2 - bii * Vi); a.res[(size_t)r * ld + b] = z - Vi * s2; }
         } else {                                       // branch rows: slots = [from, to]
-            BranchP p = a.br[idx];
-            const int i = uniform(p.from), j = uniform(p.to);
+            const BranchP p = branch(idx);
+            const int i = p.from, j = p.to;
             const double Vi = a.vm[(size_t)i * ld + b], thi = a.va[(size_t)i * ld + b];
             const double Vj = a.vm[(size_t)j * ld + b], thj = a.va[(size_t)j * ld + b];
             double h, ti, vi, tj, vj;
@@ -291,11 +302,15 @@ __global__ __launch_bounds__(256) void k_gn_hdelta(const RowDesc* rows, const in
     const size_t ld = (size_t)ld_;
     const size_t b = (size_t)blockIdx.y * 64 + lane;
     const int r0 = blockIdx.x * GN_ROWS, r1 = min(r0 + GN_ROWS, m);
+    typedef const int __attribute__((address_space(4)))* CInt;
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    typedef const i4 __attribute__((address_space(4)))* CInt4;
     for (int r = r0 + wave; r < r1; r += blockDim.y) {
-        const int s0 = uniform(rows[r].slot0), ns = uniform(rows[r].nslots);
+        const i4 rd = ((CInt4)rows)[r];                             // {type, idx, slot0, nslots} through the scalar cache
+        const int s0 = rd[2], ns = rd[3];
         double acc = 0.0;
         for (int s = s0; s < s0 + ns; ++s) {
-            const int bus = uniform(slot_bus[s]);
+            const int bus = ((CInt)slot_bus)[s];
             const double2 hv = jg::load_vec(Hs, (size_t)s, b, ld), d = jg::load_vec(inc, (size_t)bus, b, ld);
             acc += (bus == slack ? 0.0 : hv.x * d.x) + hv.y * d.y;
         }
