@@ -243,6 +243,7 @@ __device__ __forceinline__ void bwd_chain_task(const BwdArgs& a, double* lds, co
         const int p = p0 + wave / wpr;
         double y0 = 0.0, y1 = 0.0;
         if (p < nb) {
+            if (sub == 0) { const double2 y = load_vec(a.W, (size_t)rows[3 * p], b, ld); y0 = y.x; y1 = y.y; }   // requested with the first blocks, not after the last
             const int q1 = min(sub * len + len, nE);
             for (int q = sub * len; q < q1; q += 4) {
                 Blk m[4];
@@ -256,7 +257,6 @@ __device__ __forceinline__ void bwd_chain_task(const BwdArgs& a, double* lds, co
                         y1 -= m[t].v10 * x.x + m[t].v11 * x.y;
                     }
             }
-            if (sub == 0) { const double2 y = load_vec(a.W, (size_t)rows[3 * p], b, ld); y0 += y.x; y1 += y.y; }
         }
         if (wpr > 1) {
             part[wave * 64 + lane] = double2{y0, y1};
