@@ -31,6 +31,7 @@ struct DevLaunch {
     int grid;                   // most chunks of any of its segments (workgroups along x before the group stride)
     int nseg;
     int chain;                  // 1: the level holds backward chain tasks (larger LDS staging)
+    int wpi_max;                // most waves per item of any of its segments
 };
 
 // Optional state update fused into the backward solve (NR: x <- x - dx, masked by bus flags).
