@@ -7,10 +7,9 @@
 //
 // Replay tables (jg_symbolic.hpp): each wave's work is a 64-byte RECORD whose address follows from
 // (segment, chunk, wave) arithmetic, fetched with ONE scalar load -- no descriptor -> index -> value pointer chase
-// (that chain cost ~10 us per item, measured).  Two executors replay the same tables:
-//   * per-level launches  (k_fact_level / k_bwd_level): one kernel per dependency level, whole chip per level;
-//   * persistent walker   (k_fact_walk / k_bwd_walk):   ONE launch, XCD teams, team-local level barriers (~0.7 us),
-//     records prefetched one chunk ahead -- across barriers too, the tables are static.
+// (that chain cost ~10 us per item, measured).  The bottom of the elimination tree is replayed with one launch per
+// dependency level (k_fact_level / k_bwd_level: whole chip per level); the top of the tree -- long chains, few items per
+// level -- by multifrontal tasks with one workgroup per scenario (k_fact_top).
 #include "jg_engine.hpp"
 
 #include <algorithm>
@@ -465,173 +464,184 @@ __global__ __launch_bounds__(64 * FACT_WAVES, 4) void k_sel_level(SelArgs a) {  
     }
 }
 
-// ---- executor 2: persistent level walker ----------------------------------------------------------------------
-// One launch replays ALL dependency levels.  The chip's workgroups (one 16-wave workgroup per CU) form TEAMS by
-// the XCD they physically run on (HW_REG_XCC_ID, read at run time -- nothing is assumed about blockIdx -> XCD
-// placement).  A 64-scenario group belongs to exactly one team for the whole walk, so every value that crosses a
-// level travels CU -> that XCD's L2 -> CU and the level barrier is a team-local arrival counter (0.6-0.8 us measured)
-// instead of a kernel boundary.
-// Visibility argument (no fences needed; holds for ANY placement because the teams ARE the physical XCDs):
-//   * every factor entry / rhs row is written exactly ONCE per launch (by one wave, whole 128-byte lines) and read by
-//     other CUs only after the barrier that follows its level, so no CU's L1 can hold a line older than the launch
-//     (L1 is invalidated at kernel start and fills on demand only); rows rewritten in place (y -> x in the backward
-//     sweep) are read before the rewrite by their owner wave alone;
-//   * producer and consumers of a group share one L2 (the coherence point of an XCD); `s_waitcnt vmcnt(0)` before the
-//     arrival makes the write-through stores L2-visible;
-//   * counters are agent-scope atomics (L1-bypassing), polled by one lane per workgroup.
-// Every spin is bounded (wall clock): a stalled walk sets the error words and all workgroups drain out.
-enum { SYNC_REG = 0, SYNC_ERR = 1, SYNC_TEAM = 16 /* +xcc: team size */, SYNC_BAR = 64 /* +32*xcc: arrivals */,
-       SYNC_WORDS = 64 + 32 * 16 /* zeroed before every walk; word [SYNC_WORDS] is a sticky error flag */ };
-
-struct WalkArgs {
-    int n_seg;
-    int* sync;
-    long long timeout_ticks;   // wall_clock64 ticks (100 MHz)
-    long long* prof;           // optional [n_levels][3] timestamps of team 0 / rank 0 (JG_WALK_PROFILE), else nullptr
+// ---- multifrontal top (jg_symbolic.hpp): one workgroup per (task, scenario), dense front in LDS -------------------------
+// The pivots above BlockSymbolic::top_level are not level items: a TASK owns a chain of consecutive pivots k0 .. k0+m-1
+// (parent(k) = k + 1) and its front of f = m + e block rows / columns (e = |struct(last pivot)|).  Lanes run across the front
+// of ONE scenario (the level kernels run 64 scenarios across the lanes): a pivot step is LDS reads + 2x2 block FMAs + one
+// workgroup barrier, not a kernel boundary with cold caches.
+//   load:   owned entries (rows / columns of the chain) from the batch-minor factor storage -- they hold the assembled value
+//           plus the terms of bottom pivots (level items) --, the rhs rows, the children's update matrices from the stack;
+//   steps:  for pivot q: F(i,j) -= F(i,q) D(q)^-1 F(q,j) over struct(q)^2 (+ the rhs column), the lane that finishes
+//           D(q+1) factorises it in place (2x2 LU with partial pivoting, as fact_finish);
+//   store:  U, unscaled Lh, factored D, y back to the batch-minor storage (the backward sweep, the forward-only sweep and the
+//           selected inverse read them there), the e x e update matrix + update vector to the scenario-major stack.
+// Same arithmetic per term as term3(), terms of an entry in ascending pivot order => bitwise run-to-run determinism.
+struct TopArgs {
+    const Rec* task; const int* data;
+    double* X; double* W; double* stack; int* status; GroupSel sel;
+    long long stack_stride;        // doubles per scenario
+    int ld, lanes, task_begin, ntasks, lpg;   // lpg: scenarios per 64-lane group that get a workgroup (64, or the real count of a single small group)
 };
 
-__device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ Blk lds_blk(const double* F, int r, int c, int fp) {
+    const double2* p = (const double2*)(F + ((size_t)r * fp + c) * 4);
+    const double2 r0 = p[0], r1 = p[1];
+    return Blk{r0.x, r0.y, r1.x, r1.y};
+}
+__device__ __forceinline__ void lds_put(double* F, int r, int c, int fp, const Blk& v) {
+    double2* p = (double2*)(F + ((size_t)r * fp + c) * 4);
+    p[0] = double2{v.v00, v.v01}; p[1] = double2{v.v10, v.v11};
+}
+// 2x2 LU with in-block partial pivoting, stored form of fact_finish
+__device__ __forceinline__ Blk factor_diag(const Blk& c, int* status) {
+    const bool sw = fabs(c.v10) > fabs(c.v00);
+    const double u11 = sw ? c.v10 : c.v00, u12 = sw ? c.v11 : c.v01;
+    const double o21 = sw ? c.v00 : c.v10, o22 = sw ? c.v01 : c.v11;
+    const double iu11 = 1.0 / u11;
+    const double l = o21 * iu11;
+    const double u22 = o22 - l * u12;
+    const double iu22 = 1.0 / u22;
+    if (!(fabs(u11) > 0.0) || !(fabs(u22) > 0.0) || !(fabs(iu11) < 1.0e300) || !(fabs(iu22) < 1.0e300)) atomicOr(status, 4);
+    return Blk{iu11, u12, sw ? l + 4.0 : l, iu22};
+}
 
-// one lane: wait until *p >= target; false on timeout / foreign error
-__device__ __forceinline__ bool spin_ge(const int* p, int target, int* err, long long ticks) {
-    const long long t0 = wall_clock64();
-    for (unsigned it = 0;; ++it) {
-        if (ld_agent(p) >= target) return true;
-        __builtin_amdgcn_s_sleep(1);
-        if ((it & 63) == 63) {
-            if (ld_agent(err) != 0) return false;
-            if (wall_clock64() - t0 > ticks) { atomicExch(err, 2); atomicExch(err + (SYNC_WORDS - SYNC_ERR), 2); return false; }   // + the sticky word
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_fact_top(TopArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int NT = 64 * NW;
+    int grp, x;
+    if (!map_block(a.sel, a.ld, a.ntasks * a.lpg, grp, x)) return;
+    const int ti = x / a.lpg;
+    const int bb = grp * 64 + (x - ti * a.lpg);
+    if (bb >= a.lanes) return;                                   // padding lanes of the last group: no scenario, no work
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = uniform(tid >> 6);
+    const RecS h = load_rec(a.task, (size_t)a.task_begin + ti);
+    const int m = h[0], e = h[1], k0 = h[2], nload = h[5], nchild = h[6], fp = h[7], nlist = h[8];
+    const int* td = a.data + h[3];
+    const int f = m + e;
+    double* F = lds;                                             // [f][fp] blocks of 4 doubles
+    double2* Y = (double2*)(F + (size_t)f * fp * 4);             // [f] rhs column
+    int* L = (int*)(Y + f);                                      // step table + struct lists
+    const size_t b = (size_t)bb, ld = (size_t)a.ld;
+    double* stk = a.stack + b * (size_t)a.stack_stride;
+
+    // ---- load
+    for (int i = tid; i < nlist; i += NT) L[i] = td[i];
+    for (int r = m + wave; r < f; r += NW)
+        if (lane < e) lds_put(F, r, m + lane, fp, Blk{0.0, 0.0, 0.0, 0.0});
+    if (tid < e) Y[m + tid] = double2{0.0, 0.0};
+    const int2* ll = (const int2*)(td + h[9]);
+    for (int i0 = tid; i0 < nload; i0 += 4 * NT) {              // four gathers in flight per lane
+        int2 d[4]; Blk v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * NT; d[u] = ll[i < nload ? i : i0]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v[u] = Blk{0.0, 0.0, 0.0, 0.0};
+            if (i0 + u * NT < nload && !((unsigned)d[u].x >> 28 & 1)) v[u] = load_blk(a.X, (size_t)(d[u].x & 0x0fffffff), b, ld);
         }
-    }
-}
-
-struct Team { int xcc, size, rank, index, nteams; };
-
-// registration: every workgroup announces its XCD, waits for the whole grid, then reads the team census
-__device__ __forceinline__ bool team_join(const WalkArgs& w, int* sh, Team& t) {
-    if (threadIdx.x == 0 && threadIdx.y == 0) {
-        const int xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15;      // HW_REG_XCC_ID[3:0]
-        const int rank = atomicAdd(w.sync + SYNC_TEAM + xcc, 1);
-        atomicAdd(w.sync + SYNC_REG, 1);
-        int ok = spin_ge(w.sync + SYNC_REG, (int)gridDim.x, w.sync + SYNC_ERR, w.timeout_ticks) ? 1 : 0;
-        int nteams = 0, index = 0, size = 0;
-        for (int x = 0; x < 16; ++x) {
-            const int sz = ld_agent(w.sync + SYNC_TEAM + x);
-            if (x == xcc) { index = nteams; size = sz; }
-            nteams += sz > 0;
-        }
-        sh[0] = ok; sh[1] = xcc; sh[2] = size; sh[3] = rank; sh[4] = index; sh[5] = nteams;
-    }
-    __syncthreads();
-    t.xcc = sh[1]; t.size = sh[2]; t.rank = sh[3]; t.index = sh[4]; t.nteams = sh[5];
-    const bool ok = sh[0] != 0;
-    __syncthreads();
-    return ok;
-}
-
-// team-local level barrier: arrivals are counted monotonically, barrier number q completes at size * (q + 1)
-__device__ __forceinline__ bool team_barrier(const WalkArgs& w, int* sh, const Team& t, int q) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores have reached the XCD's L2
-    __syncthreads();
-    if (threadIdx.x == 0 && threadIdx.y == 0) {
-        int* bar = w.sync + SYNC_BAR + 32 * t.xcc;
-        atomicAdd(bar, 1);
-        sh[0] = spin_ge(bar, t.size * (q + 1), w.sync + SYNC_ERR, w.timeout_ticks) ? 1 : 0;
-    }
-    __syncthreads();
-    const bool ok = sh[0] != 0;
-    __syncthreads();
-    return ok;
-}
-
-// position of a workgroup in its team's work list: (segment s, unit u); units of a segment = chunks x team groups
-struct Cursor { int s, u; };
-
-template <bool BWD, class Args>
-__device__ __forceinline__ void walk_body(Args& a, const WalkArgs& w, double* red, int* sh, const Segment* segs /* LDS copy */) {
-    const int lane = threadIdx.x;
-    const int wave = uniform(threadIdx.y);
-    const size_t ld = (size_t)a.ld;
-    Team t;
-    if (!team_join(w, sh, t)) return;
-    // groups of this team: slots index, index + nteams, ... < gact
-    const int gact = a.sel.list ? uniform(*a.sel.count) : a.ld / 64;
-    const int ng = gact > t.index ? (gact - t.index + t.nteams - 1) / t.nteams : 0;
-    if (ng == 0) return;                                       // a team without groups shares no data and no barrier
-    const bool prof = w.prof && t.index == 0 && t.rank == 0 && wave == 0 && lane == 0;
-    auto units = [&](int s) { return uniform(segs[s].nchunks) * ng; };
-    auto normalise = [&](Cursor& c) {                          // first segment at or after c.s that holds a unit for this rank
-        while (c.s < w.n_seg && c.u >= units(c.s)) { ++c.s; c.u = t.rank; }
-    };
-    auto rec_index = [&](const Cursor& c) {
-        const int chunk = c.u / ng;
-        if (uniform(segs[c.s].wpi) == 0) return (size_t)uniform(segs[c.s].rec_base) + (size_t)chunk;     // chain task: one record
-        return (size_t)uniform(segs[c.s].rec_base) + ((size_t)chunk * 16 + wave) * uniform(segs[c.s].rpw);
-    };
-    // cursor of the unit this workgroup executes next, and the (prefetched) first record of this wave in it
-    Cursor cur{0, t.rank};
-    normalise(cur);
-    RecS nxt{};
-    if (cur.s < w.n_seg) nxt = load_rec(a.rec, rec_index(cur));
-    int barriers = 0;
-    for (int s = 0; s < w.n_seg; ++s) {
-        if (prof && (s == 0 || segs[s - 1].last)) w.prof[3 * (segs[s].level - 1)] = wall_clock64();
-        while (cur.s == s) {
-            const RecS r = nxt;
-            const size_t ri = rec_index(cur);
-            const int gs = cur.u % ng;
-            const int wpi = uniform(segs[s].wpi), rpw = uniform(segs[s].rpw);
-            Cursor nx{cur.s, cur.u + t.size};
-            normalise(nx);
-            if (nx.s < w.n_seg) nxt = load_rec(a.rec, rec_index(nx));      // prefetch: static tables, safe across barriers
-            const int slot = t.index + gs * t.nteams;
-            const int g = a.sel.list ? uniform(a.sel.list[slot]) : slot;
-            if (!(a.sel.flags && !a.sel.flags[g])) {
-                const size_t b = (size_t)min(g * 64 + lane, a.lanes - 1);
-                if constexpr (BWD) {
-                    if (wpi == 0) bwd_chain_task(a, red, r, wave, lane, b, ld);
-                    else bwd_chunk(a, red, r, ri, rpw, wpi, wave, lane, b, ld);
-                } else fact_chunk(a, red, r, ri, rpw, wpi, wave, lane, b, ld);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u * NT < nload) {
+                const int r = d[u].y >> 8, c = d[u].y & 255;
+                lds_put(F, r, c, fp, v[u]);
+                if ((unsigned)d[u].x >> 28 & 2) lds_put(F, c, r, fp, Blk{v[u].v00, v[u].v10, v[u].v01, v[u].v11});   // symmetric plans: Lh(c,r) = U(r,c)'
             }
-            cur = nx;
-        }
-        if (segs[s].last) {
-            if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); w.prof[3 * (segs[s].level - 1) + 1] = wall_clock64(); }
-            if (s + 1 < w.n_seg && !team_barrier(w, sh, t, barriers++)) return;
-            if (prof) w.prof[3 * (segs[s].level - 1) + 2] = wall_clock64();
         }
     }
-}
-
-constexpr int WALK_MAX_SEG = 1024;      // segment table staged in LDS (32 bytes each)
-
-__device__ __forceinline__ void stage_segments(const Segment* g, Segment* l, int n) {
-    const int tid = threadIdx.y * 64 + threadIdx.x;
-    const int4* src = (const int4*)g;
-    int4* dst = (int4*)l;
-    for (int i = tid; i < 2 * n; i += 1024) dst[i] = src[i];
+    for (int q = tid; q < m; q += NT) Y[q] = load_vec(a.W, (size_t)(k0 + q), b, ld);
     __syncthreads();
+    // ---- extend-add of the children's update matrices (two children may hit the same block: one after the other)
+    const int* cd = td + h[10];
+    for (int ch = 0; ch < nchild; ++ch) {
+        const int coff = uniform(cd[0]), ce = uniform(cd[1]);
+        const int* cmap = cd + 2;
+        const double* C = stk + coff;
+        const int cl = lane < ce ? cmap[lane] : 0;
+        for (int ca = wave; ca < ce; ca += 2 * NW) {
+            const int ca2 = ca + NW;
+            const int r0 = uniform(cmap[ca]), r1 = uniform(cmap[ca2 < ce ? ca2 : ca]);
+            double2 s0{0.0, 0.0}, s1{0.0, 0.0}, s2{0.0, 0.0}, s3{0.0, 0.0};
+            if (lane < ce) {
+                const double2* p = (const double2*)(C + ((size_t)ca * ce + lane) * 4);
+                s0 = p[0]; s1 = p[1];
+                if (ca2 < ce) { const double2* p2 = (const double2*)(C + ((size_t)ca2 * ce + lane) * 4); s2 = p2[0]; s3 = p2[1]; }
+                Blk t = lds_blk(F, r0, cl, fp);
+                lds_put(F, r0, cl, fp, Blk{t.v00 + s0.x, t.v01 + s0.y, t.v10 + s1.x, t.v11 + s1.y});
+                if (ca2 < ce) {
+                    t = lds_blk(F, r1, cl, fp);
+                    lds_put(F, r1, cl, fp, Blk{t.v00 + s2.x, t.v01 + s2.y, t.v10 + s3.x, t.v11 + s3.y});
+                }
+            }
+        }
+        if (tid < ce) {
+            const double2 v = ((const double2*)(C + (size_t)ce * ce * 4))[tid];
+            double2 y = Y[cmap[tid]];
+            y.x += v.x; y.y += v.y;
+            Y[cmap[tid]] = y;
+        }
+        __syncthreads();
+        cd += 2 + ce;
+    }
+    if (tid == 0) lds_put(F, 0, 0, fp, factor_diag(lds_blk(F, 0, 0, fp), a.status + b));
+    __syncthreads();
+    // ---- pivot steps
+    const unsigned char* lists = (const unsigned char*)(L + 3 * m);
+    for (int q = 0; q < m; ++q) {
+        const int s = uniform(L[3 * q]), lo = uniform(L[3 * q + 1]), lg = uniform(L[3 * q + 2]);
+        const unsigned char* lst = lists + lo;
+        const int bcol = lane & ((1 << lg) - 1), ar = lane >> lg, rpp = 64 >> lg;
+        const Blk D = lds_blk(F, q, q, fp);
+        double z00 = 0.0, z10 = 0.0, z01 = 0.0, z11 = 0.0;
+        int ib = 0;
+        if (bcol < s) {                                          // column operand D^-1 U(q, ib), once per lane and step
+            ib = lst[bcol];
+            const Blk U = lds_blk(F, q, ib, fp);
+            dsolve(D, U.v00, U.v10, z00, z10);
+            dsolve(D, U.v01, U.v11, z01, z11);
+        } else if (bcol == s) {                                  // the rhs column: D^-1 y_q
+            const double2 y = Y[q];
+            dsolve(D, y.x, y.y, z00, z10);
+        }
+        for (int a0 = wave * rpp + ar; a0 < s; a0 += NW * rpp) {
+            const int ia = lst[a0];
+            const Blk Lb = lds_blk(F, ia, q, fp);
+            if (bcol < s) {
+                Blk t = lds_blk(F, ia, ib, fp);
+                t.v00 -= Lb.v00 * z00 + Lb.v01 * z10;
+                t.v01 -= Lb.v00 * z01 + Lb.v01 * z11;
+                t.v10 -= Lb.v10 * z00 + Lb.v11 * z10;
+                t.v11 -= Lb.v10 * z01 + Lb.v11 * z11;
+                if (a0 == 0 && bcol == 0 && q + 1 < m) t = factor_diag(t, a.status + b);     // D(q+1) is final: the next pivot
+                lds_put(F, ia, ib, fp, t);
+            } else if (bcol == s) {
+                double2 y = Y[ia];
+                y.x -= Lb.v00 * z00 + Lb.v01 * z10;
+                y.y -= Lb.v10 * z00 + Lb.v11 * z10;
+                Y[ia] = y;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- store
+    for (int i = tid; i < nload; i += NT) {
+        const int2 d = ll[i];
+        const Blk v = lds_blk(F, d.y >> 8, d.y & 255, fp);
+        store_blk(a.X, (size_t)(d.x & 0x0fffffff), b, ld, v.v00, v.v01, v.v10, v.v11);
+    }
+    for (int q = tid; q < m; q += NT) { const double2 y = Y[q]; store_vec(a.W, (size_t)(k0 + q), b, ld, y.x, y.y); }
+    if (e > 0) {
+        double* out = stk + h[4];
+        for (int ca = wave; ca < e; ca += NW)
+            if (lane < e) {
+                const Blk v = lds_blk(F, m + ca, m + lane, fp);
+                double2* p = (double2*)(out + ((size_t)ca * e + lane) * 4);
+                p[0] = double2{v.v00, v.v01}; p[1] = double2{v.v10, v.v11};
+            }
+        if (tid < e) ((double2*)(out + (size_t)e * e * 4))[tid] = Y[m + tid];
+    }
 }
-
-constexpr int WALK_RED = CHAIN_LDS_D2 * 2;      // doubles: covers the factor partial sums (16*256) and the chain staging
-
-__global__ __launch_bounds__(1024) void k_fact_walk(FactArgs a, WalkArgs w) {
-    extern __shared__ __attribute__((aligned(16))) double red[];   // WALK_RED doubles | 16 ints | segments
-    int* sh = (int*)(red + WALK_RED);
-    Segment* segs = (Segment*)(sh + 16);
-    stage_segments(a.seg, segs, w.n_seg);
-    walk_body<false>(a, w, red, sh, segs);
-}
-
-__global__ __launch_bounds__(1024) void k_bwd_walk(BwdArgs a, WalkArgs w) {
-    extern __shared__ __attribute__((aligned(16))) double red[];   // WALK_RED doubles | 16 ints | segments
-    int* sh = (int*)(red + WALK_RED);
-    Segment* segs = (Segment*)(sh + 16);
-    stage_segments(a.seg, segs, w.n_seg);
-    walk_body<true>(a, w, red, sh, segs);
-}
-
-size_t walk_lds(int n_seg) { return WALK_RED * sizeof(double) + 64 + (size_t)n_seg * sizeof(Segment); }
 
 // per-level launch table: segment ranges and chunk totals
 void level_launches(const std::vector<Segment>& segs, std::vector<DevLaunch>& out) {
@@ -653,9 +663,6 @@ void level_launches(const std::vector<Segment>& segs, std::vector<DevLaunch>& ou
     }
 }
 
-std::mutex g_walk_mu;
-hipEvent_t g_walk_ev[64] = {};
-
 }  // namespace
 
 std::mutex& capture_mutex() {
@@ -675,110 +682,56 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, int policy
         upload(&fwd_rec, S.fwd_rec, error, st) || upload(&fwd_seg, S.fwd_seg, error, st))
         return 2;
     JG_HIP(hipFuncSetAttribute((const void*)k_bwd_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CHAIN_LDS_D2 * sizeof(double2))));
+    if (!S.top_launch.empty()) {
+        if (upload(&top_task, S.top_task, error, st) || upload(&top_data, S.top_data, error, st)) return 2;
+        int lds1 = 0, lds4 = 0;
+        for (const TopLaunch& L : S.top_launch) (L.waves == 1 ? lds1 : lds4) = std::max(L.waves == 1 ? lds1 : lds4, L.lds_bytes);
+        if (lds1) JG_HIP(hipFuncSetAttribute((const void*)k_fact_top<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
+        if (lds4) JG_HIP(hipFuncSetAttribute((const void*)k_fact_top<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4));
+        const size_t sb = (size_t)std::max<long long>(S.top_stack, 2) * ld * sizeof(double);
+        JG_HIP(hipMalloc((void**)&top_stack, sb));
+        JG_HIP(sync_fill(top_stack, 0, sb, st));
+    }
     JG_HIP(hipMalloc((void**)&X, factor_bytes()));
     JG_HIP(sync_fill(X, 0, factor_bytes(), st));
     JG_HIP(hipMalloc((void**)&W, (size_t)n * 2 * ld * sizeof(double)));
     JG_HIP(sync_fill(W, 0, (size_t)n * 2 * ld * sizeof(double), st));
     JG_HIP(hipMalloc((void**)&status, (size_t)ld * sizeof(int)));
     JG_HIP(sync_fill(status, 0, (size_t)ld * sizeof(int), st));
-    JG_HIP(hipMalloc((void**)&sync, (SYNC_WORDS + 1) * sizeof(int)));
-    JG_HIP(sync_fill(sync, 0, (SYNC_WORDS + 1) * sizeof(int), st));
     JG_HIP(hipGetDevice(&device));
-    int cus = 0;
-    JG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-    walk_grid = cus;                                   // one 16-wave workgroup per CU: all co-resident by construction
-    if (getenv("JG_WALK_PROFILE")) {
-        JG_HIP(hipMalloc((void**)&prof, (size_t)S.n_fact_levels * 3 * sizeof(long long)));
-        JG_HIP(sync_fill(prof, 0, (size_t)S.n_fact_levels * 3 * sizeof(long long), st));
-    }
-    // The walker is OPT-IN (JG_WALKER=1).  Measured on MI355X (ACTIVSg10k): its barrier costs 0.6-0.8 us against ~2 us
-    // for a kernel boundary, but binding a scenario group to ONE XCD caps the group at 32 CUs x 64 B/clk of L1 fill,
-    // and a level's cost is set by exactly that (one item's update list = up to 540 KB through one CU): 3.8 ms per
-    // factorisation against 1.5 ms (64 scenarios) / 4.3 against 2.7 ms (512) for the per-level launches, which spread
-    // every level over all 256 CUs.
-    const char* env = getenv("JG_WALKER");
-    walker = false;
-    const bool fits = (int)S.fact_seg.size() <= WALK_MAX_SEG && (int)S.bwd_seg.size() <= WALK_MAX_SEG;
-    if (env && env[0] == '1' && walk_grid > 0 && fits) {
-        JG_HIP(hipFuncSetAttribute((const void*)k_fact_walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds(WALK_MAX_SEG)));
-        JG_HIP(hipFuncSetAttribute((const void*)k_bwd_walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds(WALK_MAX_SEG)));
-        // census: can every workgroup of a walk become resident and do the XCD teams form?  (a walk with no segments)
-        FactArgs a{};
-        a.seg = fact_seg; a.ld = ld; a.lanes = ld;
-        WalkArgs w{0, sync, 5000000LL /* 50 ms */, nullptr};
-        hipLaunchKernelGGL(k_fact_walk, dim3(walk_grid), dim3(64, 16), walk_lds(0), st, a, w);
-        JG_HIP(hipStreamSynchronize(st));
-        int h[SYNC_TEAM + 16];
-        JG_HIP(sync_copy(h, sync, sizeof(h), hipMemcpyDeviceToHost, st));
-        int members = 0;
-        for (int x = 0; x < 16; ++x) members += h[SYNC_TEAM + x];
-        walker = h[SYNC_ERR] == 0 && h[SYNC_REG] == walk_grid && members == walk_grid;
-        JG_HIP(sync_fill(sync, 0, (SYNC_WORDS + 1) * sizeof(int), st));
-    }
     return 0;
 }
 
 void Engine::destroy() {
-    if (prof) {
-        const int nl = S.n_fact_levels;
-        std::vector<long long> t((size_t)nl * 3);
-        if (hipMemcpy(t.data(), prof, t.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess && nl > 0 && t[0]) {
-            fprintf(stderr, "[jg walk profile] level | work_us barrier_us\n");
-            for (int l = 0; l < nl; ++l)
-                fprintf(stderr, "[jg walk profile] %3d | %7.2f %7.2f\n", l, (t[3 * l + 1] - t[3 * l]) * 0.01,
-                        l + 1 < nl ? (t[3 * l + 2] - t[3 * l + 1]) * 0.01 : 0.0);
-            fprintf(stderr, "[jg walk profile] total %.2f us\n", (t[3 * (size_t)nl - 2] - t[0]) * 0.01);
-        }
-        hipFree(prof); prof = nullptr;
-    }
-    hipFree(fact_rec); hipFree(bwd_rec); hipFree(fact_seg); hipFree(bwd_seg); hipFree(bwd_chain); hipFree(sync);
+    hipFree(fact_rec); hipFree(bwd_rec); hipFree(fact_seg); hipFree(bwd_seg); hipFree(bwd_chain);
     hipFree(fwd_rec); hipFree(fwd_seg); fwd_rec = nullptr; fwd_seg = nullptr;
     hipFree(sel_rec); hipFree(sel_seg); hipFree(Zs); sel_rec = nullptr; sel_seg = nullptr; Zs = nullptr;
+    hipFree(top_task); hipFree(top_data); hipFree(top_stack); top_task = nullptr; top_data = nullptr; top_stack = nullptr;
     bwd_chain = nullptr;
     hipFree(X); hipFree(W); hipFree(status);
-    fact_rec = bwd_rec = nullptr; fact_seg = bwd_seg = nullptr; sync = nullptr; status = nullptr;
+    fact_rec = bwd_rec = nullptr; fact_seg = bwd_seg = nullptr; status = nullptr;
     X = W = nullptr;
 }
 
-// Walks of different handles form ONE chain per process: wait for the previous walk's event, enqueue, record the
-// event again -- atomically with respect to other host threads (the mutex is held from begin to end; use WalkTurn).
-void Engine::serialize_begin(hipStream_t st) {
-    if (!walker || device < 0 || device >= 64) return;
-    g_walk_mu.lock();
-    if (g_walk_ev[device]) hipStreamWaitEvent(st, g_walk_ev[device], 0);
-}
-
-void Engine::serialize_end(hipStream_t st) {
-    if (!walker || device < 0 || device >= 64) return;
-    if (g_walk_ev[device] || hipEventCreateWithFlags(&g_walk_ev[device], hipEventDisableTiming) == hipSuccess) hipEventRecord(g_walk_ev[device], st);
-    else g_walk_ev[device] = nullptr;
-    g_walk_mu.unlock();
-}
-
-int Engine::walk_status(hipStream_t st) {
-    if (!walker) return 0;
-    int e = 0;
-    JG_HIP(hipMemcpyAsync(&e, sync + SYNC_WORDS, sizeof(int), hipMemcpyDeviceToHost, st));
-    JG_HIP(hipStreamSynchronize(st));
-    if (e) { error = "persistent level walk stalled (a workgroup never became resident: is another process using this GPU?); set JG_WALKER=0"; return 2; }
-    return 0;
-}
-
-int Engine::factor(hipStream_t st, const double* A, const double* rhs, const GroupSel& sel, int mode) {
+int Engine::factor(hipStream_t st, const double* A, const double* rhs, const GroupSel& sel) {
     if (!S.inplace && !A) { error = "factor: no source matrix"; return 1; }
     FactArgs a{fact_rec, fact_seg, S.inplace ? X : A, rhs, X, W, status, sel, ld, 0, lanes > 0 ? lanes : ld, 0, 0, 1, 1};
-    if (walker && mode != 1) {
-        WalkArgs w{(int)S.fact_seg.size(), sync, 100000000LL /* 1 s */, prof};
-        JG_HIP(hipMemsetAsync(sync, 0, SYNC_WORDS * sizeof(int), st));
-        hipLaunchKernelGGL(k_fact_walk, dim3(walk_grid), dim3(64, 16), walk_lds(w.n_seg), st, a, w);
-        JG_HIP(hipGetLastError());
-        return 0;
-    }
     const int gs = group_stride(ld / 64);
     for (const DevLaunch& L : fact) {
         a.seg_begin = L.seg_begin;
         { const Segment& g = S.fact_seg[L.seg_begin]; a.s0_base = g.rec_base; a.s0_nchunks = g.nchunks; a.s0_wpi = g.wpi; a.s0_rpw = g.rpw; }
         hipLaunchKernelGGL(k_fact_level, dim3((unsigned)L.grid * (16 / FACT_WAVES) * gs, L.nseg), dim3(64, FACT_WAVES), FACT_WAVES * 256 * sizeof(double), st, a);
+    }
+    // the top of the elimination tree: multifrontal tasks, one workgroup per (task, scenario), launch = (task level, class)
+    if (!S.top_launch.empty()) {
+        TopArgs t{top_task, top_data, X, W, top_stack, status, sel, std::max<long long>(S.top_stack, 2), ld, a.lanes, 0, 0, 64};
+        if (ld == 64 && t.lanes < 64) t.lpg = t.lanes;
+        for (const TopLaunch& L : S.top_launch) {
+            t.task_begin = L.task_begin; t.ntasks = L.ntasks;
+            const dim3 grid((unsigned)L.ntasks * t.lpg * gs);
+            if (L.waves == 1) hipLaunchKernelGGL(k_fact_top<1>, grid, dim3(64), (size_t)L.lds_bytes, st, t);
+            else hipLaunchKernelGGL(k_fact_top<4>, grid, dim3(256), (size_t)L.lds_bytes, st, t);
+        }
     }
     JG_HIP(hipGetLastError());
     return 0;
@@ -839,15 +792,8 @@ int Engine::set_shared_matrix(hipStream_t st, const double* blocks_host) {
     return 0;
 }
 
-int Engine::backsolve(hipStream_t st, double* out, const StateUpdate& upd, const GroupSel& sel, int mode) {
+int Engine::backsolve(hipStream_t st, double* out, const StateUpdate& upd, const GroupSel& sel) {
     BwdArgs a{bwd_rec, bwd_seg, bwd_chain, X, W, out, sel, upd, ld, 0, lanes > 0 ? lanes : ld, 0, 0, 1, 1};
-    if (walker && mode != 1) {
-        WalkArgs w{(int)S.bwd_seg.size(), sync, 100000000LL /* 1 s */, nullptr};
-        JG_HIP(hipMemsetAsync(sync, 0, SYNC_WORDS * sizeof(int), st));
-        hipLaunchKernelGGL(k_bwd_walk, dim3(walk_grid), dim3(64, 16), walk_lds(w.n_seg), st, a, w);
-        JG_HIP(hipGetLastError());
-        return 0;
-    }
     const int gs = group_stride(ld / 64);
     for (const DevLaunch& L : bwd) {
         a.seg_begin = L.seg_begin;

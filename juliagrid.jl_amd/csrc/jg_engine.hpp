@@ -130,11 +130,8 @@ struct Engine {
     double* W = nullptr;           // [n][2][ld] pivot order: y after factor(), x after backsolve()
     int* status = nullptr;         // [ld] bit 2 set on zero / non-finite pivot
     std::vector<DevLaunch> fact, bwd, fwd, selv;
-    // persistent level walker (one launch per factorisation / per backward sweep, see jg_engine.hip)
-    int* sync = nullptr;           // registration / team census / barrier counters / error word, zeroed before every walk
-    int walk_grid = 0;             // workgroups of a walk = CUs of the device (all must be co-resident)
-    bool walker = false;           // census passed and JG_WALKER != 0
-    long long* prof = nullptr;     // JG_WALK_PROFILE: per-level timestamps of one workgroup of the last factor walk
+    Rec* top_task = nullptr; int* top_data = nullptr;          // multifrontal top (jg_symbolic.hpp): task headers, task data
+    double* top_stack = nullptr;                               // update matrices of the tasks, scenario-major [ld][S.top_stack]
     int device = 0;
     std::string error;
 
@@ -143,9 +140,8 @@ struct Engine {
     // A: block values in the caller's CSR order [nnz][4][ld]; rhs: [n][2][ld] original block order.
     // Computes A = Lh inv(D) U and y = (Lh inv(D))^-1 rhs in the same launches.
     // sel: which 64-scenario groups take part (workgroups of the others exit at once).
-    // mode: 0 = persistent walker when available, 1 = one launch per dependency level.
     // In-place engines (policy bit 0) ignore A: the caller has assembled into X (entry S.src_entry[p] for its block p).
-    int factor(hipStream_t st, const double* A, const double* rhs, const GroupSel& sel, int mode = 0);
+    int factor(hipStream_t st, const double* A, const double* rhs, const GroupSel& sel);
     // y = (Lh inv(D))^-1 rhs with the factor of the last factor() call (solve many right-hand sides with one factorisation).
     int forward(hipStream_t st, const double* rhs, const GroupSel& sel);
     // Zs = A^-1 on the upper factor pattern + diagonal (same entry numbering as X) for a SYMMETRIC matrix, from the factor
@@ -155,22 +151,8 @@ struct Engine {
     // replicated over every scenario; fill-in entries need nothing.
     int set_shared_matrix(hipStream_t st, const double* blocks_host);
     // x = U^-1 D y, scattered to original order into out [n][2][ld]; optional fused state update.
-    int backsolve(hipStream_t st, double* out, const StateUpdate& upd, const GroupSel& sel, int mode = 0);
+    int backsolve(hipStream_t st, double* out, const StateUpdate& upd, const GroupSel& sel);
     size_t factor_bytes() const { return (size_t)S.n_entries * 4 * ld * sizeof(double); }
-    // 0 ok; 2 + error text when a walk stalled (a workgroup never became resident, e.g. another process holds CUs)
-    int walk_status(hipStream_t st);
-    // scope of one enqueue of walks on `st` (serialize_begin ... serialize_end even on early returns)
-    struct WalkTurn {
-        Engine& e; hipStream_t st;
-        WalkTurn(Engine& e_, hipStream_t st_) : e(e_), st(st_) { e.serialize_begin(st); }
-        ~WalkTurn() { e.serialize_end(st); }
-        WalkTurn(const WalkTurn&) = delete;
-        WalkTurn& operator=(const WalkTurn&) = delete;
-    };
-    // Walks of different handles must not overlap on one device (each needs every CU): the owner brackets whatever
-    // it submits (graph launch or direct calls) with these; they chain the streams through one per-device event.
-    void serialize_begin(hipStream_t st);
-    void serialize_end(hipStream_t st);
 };
 
 #define JG_HIP(expr)                                                                      \

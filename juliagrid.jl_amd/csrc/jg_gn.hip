@@ -521,7 +521,7 @@ int launch_increment(jg_gn* h, const int* group) {
                            h->d_inc, h->d_res, h->d_rho, h->m, h->slack0, h->ld);
         launch_gain(h, true);
         if (int rc = h->eng.forward(h->stream, h->d_rhs2, jg::GroupSel{group})) return failg(rc, h->eng.error);
-        if (int rc = h->eng.backsolve(h->stream, h->d_inc2, none, jg::GroupSel{group}, 1)) return failg(rc, h->eng.error);
+        if (int rc = h->eng.backsolve(h->stream, h->d_inc2, none, jg::GroupSel{group})) return failg(rc, h->eng.error);
         hipLaunchKernelGGL(k_gn_add, dim3(h->nchunk, h->ld / 64), dim3(64, 4), 0, h->stream, h->d_inc, h->d_inc2, h->n, h->ld);
     }
     hipLaunchKernelGGL(k_gn_norm, dim3(h->nchunk, h->ld / 64), dim3(64, 4), 0, h->stream, h->d_inc, h->d_part, h->n, h->slack0, h->ld);
@@ -795,7 +795,7 @@ void jg_gn_destroy(jg_gn* h) {
 int jg_gn_dims(jg_gn* h, int64_t* dims) {
     if (!h || !dims) return failg(1, "jg_gn_dims: bad argument");
     dims[0] = h->m; dims[1] = h->nnzH; dims[2] = (int64_t)h->gi_col.size(); dims[3] = h->eng.S.n_entries;
-    dims[4] = h->eng.S.n_sched_terms; dims[5] = (int64_t)h->eng.fact.size(); dims[6] = (int64_t)h->eng.bwd.size();
+    dims[4] = h->eng.S.n_sched_terms; dims[5] = (int64_t)(h->eng.fact.size() + h->eng.S.top_launch.size()); dims[6] = (int64_t)h->eng.bwd.size();
     dims[7] = h->nslots;
     return 0;
 }
@@ -872,7 +872,6 @@ int jg_gn_increment(jg_gn* h, double* maxinc) {
     if (int rc = set_device(h)) return rc;
     GN_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
     {
-        jg::Engine::WalkTurn turn(h->eng, h->stream);
         if (int rc = launch_increment(h, nullptr)) return rc;
     }
     launch_check(h, 0);
@@ -920,13 +919,11 @@ int jg_gn_run(jg_gn* h, int64_t max_iter, double tol, int32_t* iters, int32_t* s
     GN_HIP(hipMemsetAsync(h->d_group, 0xff, (size_t)(h->ld / 64) * sizeof(int), h->stream));
     for (int64_t it = 0; it <= max_iter; ++it) {                                   // :1303
         {
-            jg::Engine::WalkTurn turn(h->eng, h->stream);
             GN_HIP(hipGraphLaunch(h->exec, h->stream));
         }
         GN_HIP(hipStreamSynchronize(h->stream));
         if (*h->h_counter == 0) break;
     }
-    if (int rc = h->eng.walk_status(h->stream)) return failg(rc, h->eng.error);
     if (iters) GN_HIP(jg::sync_copy(iters, h->d_iters, (size_t)h->batch * 4, hipMemcpyDeviceToHost, h->stream));
     if (status) GN_HIP(jg::sync_copy(status, h->d_status, (size_t)h->batch * 4, hipMemcpyDeviceToHost, h->stream));
     return 0;
@@ -1041,7 +1038,6 @@ int jg_gn_residual_test(jg_gn* h, double* max_nres, int32_t* index) {
     }
     GN_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
     {
-        jg::Engine::WalkTurn turn(h->eng, h->stream);
         launch_rows(h);                                              // residual and Jacobian at the CURRENT state
         launch_gain(h);
         if (int rc = h->eng.factor(h->stream, nullptr, h->d_rhs, jg::GroupSel{})) return failg(rc, h->eng.error);

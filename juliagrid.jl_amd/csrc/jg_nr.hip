@@ -730,7 +730,7 @@ void jg_nr_destroy(jg_nr* h) {
 int jg_nr_dims(jg_nr* h, int64_t* dims) {
     if (!h || !dims) return fail(1, "jg_nr_dims: bad argument");
     dims[0] = h->dimJ; dims[1] = h->nnzJ; dims[2] = h->eng.S.n_entries; dims[3] = h->eng.S.n_sched_terms;
-    dims[4] = (int64_t)h->eng.fact.size();
+    dims[4] = (int64_t)(h->eng.fact.size() + h->eng.S.top_launch.size());      // dependent launches of one factorisation
     dims[5] = (int64_t)h->eng.bwd.size();
     return 0;
 }
@@ -889,7 +889,6 @@ int jg_nr_solve(jg_nr* h) {
     if (!h->jac_valid) launch_assemble(h);
     NR_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
     {
-        jg::Engine::WalkTurn turn(h->eng, h->stream);
         if (int rc = h->eng.factor(h->stream, nullptr, h->d_F, jg::GroupSel{})) return fail(rc, h->eng.error);
         jg::StateUpdate upd{h->d_va, h->d_vm, h->d_flags, nullptr, -1.0};
         if (int rc = h->eng.backsolve(h->stream, h->d_inc, upd, jg::GroupSel{})) return fail(rc, h->eng.error);
@@ -897,7 +896,6 @@ int jg_nr_solve(jg_nr* h) {
     hipLaunchKernelGGL(k_add_iter, dim3((h->ld + 255) / 256), dim3(256), 0, h->stream, h->d_iters, h->ld);
     NR_HIP(hipGetLastError());
     NR_HIP(hipStreamSynchronize(h->stream));
-    if (int rc = h->eng.walk_status(h->stream)) return fail(rc, h->eng.error);
     h->jac_valid = false;
     std::vector<int> st(h->ld);
     NR_HIP(jg::sync_copy(st.data(), h->eng.status, (size_t)h->ld * 4, hipMemcpyDeviceToHost, h->stream));
@@ -939,7 +937,6 @@ int jg_nr_run(jg_nr* h, int64_t max_iter, double tol, int32_t* iters, int32_t* s
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (trace) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, h->stream); }
         {
-            jg::Engine::WalkTurn turn(h->eng, h->stream);
             NR_HIP(hipGraphLaunch(h->execB, h->stream));                       // solve!, then mismatch! and the verdict on the new state
         }
         if (trace) hipEventRecord(e1, h->stream);
@@ -956,7 +953,6 @@ int jg_nr_run(jg_nr* h, int64_t max_iter, double tol, int32_t* iters, int32_t* s
     launch_compact(h, 1);                                                      // lanes back to their home order
     NR_HIP(hipGetLastError());
     NR_HIP(hipStreamSynchronize(h->stream));
-    if (int rc = h->eng.walk_status(h->stream)) return fail(rc, h->eng.error);
     h->jac_valid = false;
     if (iters) NR_HIP(jg::sync_copy(iters, h->d_iters, (size_t)h->batch * 4, hipMemcpyDeviceToHost, h->stream));
     if (status) NR_HIP(jg::sync_copy(status, h->d_status, (size_t)h->batch * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1034,7 +1030,7 @@ static int fast_half(jg_nr* h, int pass) {
     if (pass == 2) launch_assemble(h, jg::GroupSel{}, false, nullptr, 2);
     if (int rc = h->eng.forward(h->stream, h->d_R, jg::GroupSel{})) return fail(rc, h->eng.error);
     jg::StateUpdate upd{h->d_va, h->d_vm, h->d_flags, h->fast_mask, +1.0};            // theta += / V += (:946-950, 966-970)
-    if (int rc = h->eng.backsolve(h->stream, h->d_inc2[pass - 1], upd, jg::GroupSel{}, 1)) return fail(rc, h->eng.error);
+    if (int rc = h->eng.backsolve(h->stream, h->d_inc2[pass - 1], upd, jg::GroupSel{})) return fail(rc, h->eng.error);
     return 0;
 }
 
@@ -1055,7 +1051,7 @@ int jg_nr_fast_setup(jg_nr* h, const double* bp, const double* bq) {
     }
     NR_HIP(jg::sync_fill(h->d_R, 0, vec, h->stream));
     NR_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
-    if (int rc = h->eng.factor(h->stream, nullptr, h->d_R, jg::GroupSel{}, 1)) return fail(rc, h->eng.error);   // ONCE (lu(jacobian), :? utility.jl:470-476)
+    if (int rc = h->eng.factor(h->stream, nullptr, h->d_R, jg::GroupSel{})) return fail(rc, h->eng.error);   // ONCE (lu(jacobian), :? utility.jl:470-476)
     NR_HIP(hipStreamSynchronize(h->stream));
     std::vector<int> st(h->ld);
     NR_HIP(jg::sync_copy(st.data(), h->eng.status, (size_t)h->ld * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1159,11 +1155,6 @@ int jg_nr_set_branches(jg_nr* h, int64_t nb, const int64_t* from, const int64_t*
         f[k] = (int)(from[k] - 1); t[k] = (int)(to[k] - 1);
     }
     NR_HIP(hipStreamSynchronize(h->stream));
-    hipFree(h->d_R); hipFree(h->d_inc2[0]); hipFree(h->d_inc2[1]);
-    if (h->execFA) hipGraphExecDestroy(h->execFA);
-    if (h->execFB) hipGraphExecDestroy(h->execFB);
-    if (h->graphFA) hipGraphDestroy(h->graphFA);
-    if (h->graphFB) hipGraphDestroy(h->graphFB);
     hipFree(h->d_bfrom); hipFree(h->d_bto); hipFree(h->d_bstatus); hipFree(h->d_bparam);
     h->d_bfrom = h->d_bto = nullptr; h->d_bstatus = nullptr; h->d_bparam = nullptr;
     std::string err;
@@ -1263,7 +1254,6 @@ int jg_nr_time_kernel(jg_nr* h, int kernel, int reps, double* mean_ms) {
     jg::StateUpdate none{};
     NR_HIP(hipStreamSynchronize(h->stream));
     {
-        jg::Engine::WalkTurn turn(h->eng, h->stream);
         NR_HIP(hipEventRecord(e0, h->stream));
         for (int r = 0; r < reps; ++r) {
             if (kernel == 0) launch_assemble(h);

@@ -12,6 +12,7 @@
 namespace jg {
 
 void build_tables(BlockSymbolic& S);
+void build_top(BlockSymbolic& S, int top_level, int soft_cap);
 
 namespace {
 
@@ -190,6 +191,132 @@ void build_replay(const std::vector<int>& level, const std::vector<int>& work, i
 
 }  // namespace
 
+// Top tasks (jg_symbolic.hpp): choose the pivots, cut them into chains, level the chain tree, emit headers + data.
+void build_top(BlockSymbolic& S, int top_level, int soft_cap) {
+    const int n = S.n;
+    S.top_level = 0; S.top_task.clear(); S.top_data.clear(); S.top_launch.clear(); S.top_stack = 0; S.top_terms = 0;
+    S.top_task_of.assign(n, -1);
+    if (top_level <= 0 || top_level >= 255) return;
+    auto ssize = [&](int k) { return S.u_ptr[k + 1] - S.u_ptr[k]; };
+    auto parent = [&](int k) { return ssize(k) ? S.u_col[S.u_ptr[k]] : -1; };
+    std::vector<char> top(n, 0);
+    int ntop = 0;
+    for (int k = 0; k < n; ++k) if (S.e_level[S.diag[k]] >= top_level) { top[k] = 1; ++ntop; if (ssize(k) + 1 > TOP_FRONT_MAX) return; }
+    if (ntop == 0) return;
+    struct Task { int k0, m, e, parent, level, waves, stack; std::vector<int> kids; };
+    std::vector<Task> tasks;
+    for (int k = n - 1; k >= 0; --k) {
+        if (!top[k] || S.top_task_of[k] >= 0) continue;
+        Task t{};
+        t.e = ssize(k);
+        const int cap = std::max(std::min(8, TOP_FRONT_MAX - t.e), soft_cap - t.e);
+        int m = 1;
+        while (k - m >= 0 && top[k - m] && parent(k - m) == k - m + 1 && m < cap) ++m;
+        t.k0 = k - m + 1; t.m = m; t.parent = -1; t.level = 1; t.stack = -1;
+        for (int q = t.k0; q <= k; ++q) S.top_task_of[q] = (int)tasks.size();
+        tasks.push_back(t);
+    }
+    const int nt = (int)tasks.size();
+    // tasks were created from the root down: a child has a larger index than its parent
+    for (int t = nt - 1; t >= 0; --t) {
+        const int p = parent(tasks[t].k0 + tasks[t].m - 1);
+        if (p >= 0) { tasks[t].parent = S.top_task_of[p]; tasks[tasks[t].parent].kids.push_back(t); tasks[tasks[t].parent].level = std::max(tasks[tasks[t].parent].level, tasks[t].level + 1); }
+    }
+    long long stack = 0;
+    for (Task& t : tasks) {
+        const int f = t.m + t.e;
+        t.waves = f <= 12 ? 1 : 4;
+        if (t.e > 0) { t.stack = (int)stack; stack += (long long)t.e * t.e * 4 + (long long)t.e * 2; }
+        for (int q = 0; q < t.m; ++q) { const long long s = ssize(t.k0 + q); S.top_terms += s * (s + 1); }
+    }
+    if (stack >= (1LL << 31)) { S.top_task_of.assign(n, -1); return; }
+    S.top_stack = stack;
+    S.top_level = top_level;
+    // launch order: level-major, then by class (waves)
+    std::vector<int> order(nt);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        if (tasks[a].level != tasks[b].level) return tasks[a].level < tasks[b].level;
+        if (tasks[a].waves != tasks[b].waves) return tasks[a].waves < tasks[b].waves;
+        return tasks[a].k0 < tasks[b].k0;
+    });
+    const bool sym = S.symmetric != 0;
+    S.top_task.resize(nt);
+    for (int oi = 0; oi < nt; ++oi) {
+        const Task& t = tasks[order[oi]];
+        const int m = t.m, e = t.e, k1 = t.k0 + m - 1;
+        auto local = [&](const Task& tt, int pivot) {           // front index of a pivot in task tt, -1 if outside
+            if (pivot >= tt.k0 && pivot < tt.k0 + tt.m) return pivot - tt.k0;
+            const int kl = tt.k0 + tt.m - 1;
+            const int* b = S.u_col.data() + S.u_ptr[kl];
+            const int* en = S.u_col.data() + S.u_ptr[kl + 1];
+            const int* p = std::lower_bound(b, en, pivot);
+            return (p != en && *p == pivot) ? tt.m + (int)(p - b) : -1;
+        };
+        Rec h{};
+        const int base = (int)S.top_data.size();
+        // step table + struct lists (bytes)
+        std::vector<int> tab(3 * m);
+        std::vector<unsigned char> lists;
+        for (int q = 0; q < m; ++q) {
+            const int k = t.k0 + q, s = ssize(k);
+            int lg = 0;
+            while ((1 << lg) < s + 1) ++lg;
+            tab[3 * q] = s; tab[3 * q + 1] = (int)lists.size(); tab[3 * q + 2] = lg;
+            for (int p = S.u_ptr[k]; p < S.u_ptr[k + 1]; ++p) lists.push_back((unsigned char)local(t, S.u_col[p]));
+        }
+        while (lists.size() % 4) lists.push_back(0);
+        S.top_data.insert(S.top_data.end(), tab.begin(), tab.end());
+        for (size_t i = 0; i < lists.size(); i += 4) S.top_data.push_back((int)(lists[i] | lists[i + 1] << 8 | lists[i + 2] << 16 | (unsigned)lists[i + 3] << 24));
+        const int nlist = (int)S.top_data.size() - base;
+        if (S.top_data.size() & 1) S.top_data.push_back(0);      // the load list is read as int2
+        const int load_off = (int)S.top_data.size() - base;
+        int nload = 0;
+        auto bottom_terms = [&](int en) {                        // does the entry have a level item (jg build_tables)?
+            for (int x = S.t_ptr[en]; x < S.t_ptr[en + 1]; ++x) if (S.top_task_of[S.e_col[S.t_a[x]]] < 0) return true;
+            return false;
+        };
+        auto add_entry = [&](int en, int r, int c) {
+            int flags = 0;
+            if (!bottom_terms(en) && (S.e_src[en] < 0)) flags |= 1;                 // nothing was ever written there: starts from zero
+            if (sym && r != c) flags |= 2;
+            S.top_data.push_back(en | flags << 28); S.top_data.push_back(r << 8 | c);
+            ++nload;
+        };
+        for (int q = 0; q < m; ++q) {
+            const int k = t.k0 + q;
+            add_entry(S.diag[k], q, q);
+            for (int p = S.u_ptr[k]; p < S.u_ptr[k + 1]; ++p) {
+                const int j = S.u_col[p], lj = local(t, j);
+                add_entry(S.u_ent[p], q, lj);
+                if (!sym) add_entry(find_in_row(S, j, k), lj, q);
+            }
+        }
+        const int child_off = (int)S.top_data.size() - base;
+        for (int c : t.kids) {
+            const Task& ct = tasks[c];
+            const int kl = ct.k0 + ct.m - 1;
+            S.top_data.push_back(ct.stack); S.top_data.push_back(ct.e);
+            for (int p = S.u_ptr[kl]; p < S.u_ptr[kl + 1]; ++p) S.top_data.push_back(local(t, S.u_col[p]));
+        }
+        (void)k1;
+        h.w[0] = m; h.w[1] = e; h.w[2] = t.k0; h.w[3] = base; h.w[4] = t.stack; h.w[5] = nload; h.w[6] = (int)t.kids.size();
+        h.w[7] = (m + e) | 1; h.w[8] = nlist; h.w[9] = load_off; h.w[10] = child_off; h.w[11] = t.level; h.w[12] = t.waves;
+        S.top_task[oi] = h;
+        if (S.top_launch.empty() || S.top_launch.back().level != t.level || S.top_launch.back().waves != t.waves)
+            S.top_launch.push_back(TopLaunch{oi, 0, t.waves, 0, t.level});
+        TopLaunch& L = S.top_launch.back();
+        L.ntasks++;
+        const int f = m + e, fp = f | 1;
+        const int lds = f * fp * 32 + f * 16 + nlist * 4 + 64;
+        L.lds_bytes = std::max(L.lds_bytes, lds);
+    }
+    // top_task_of must name the header position
+    std::vector<int> pos(nt);
+    for (int oi = 0; oi < nt; ++oi) pos[order[oi]] = oi;
+    for (int k = 0; k < n; ++k) if (S.top_task_of[k] >= 0) S.top_task_of[k] = pos[S.top_task_of[k]];
+}
+
 void build_tables(BlockSymbolic& S) {
     const int nE = S.n_entries, n = S.n;
     // factorisation + fused forward elimination
@@ -198,23 +325,55 @@ void build_tables(BlockSymbolic& S) {
     // names U(k,i) with the TRANSPOSE bit (bit 30) where it would read Lh(i,k).  Half the update terms.
     const bool sym = S.symmetric != 0;
     auto lower_operand = [&](int e) { return sym ? (find_in_row(S, S.e_col[e], S.e_row[e]) | 1 << 30) : e; };
+    // Top tasks (jg_symbolic.hpp): an item of a task-owned entry / rhs row keeps only the terms of BOTTOM pivots, stores the
+    // partial sum raw, and is levelled on those terms alone; the terms of task pivots are executed inside the tasks.
+    const bool has_top = !S.top_task.empty();
+    auto in_top = [&](int k) { return has_top && S.top_task_of[k] >= 0; };
+    auto owner = [&](int e) { return std::min(S.e_row[e], S.e_col[e]); };
+    std::vector<int> ft_ptr(nE + n + 1, 0), ft_idx;              // scheduled term ids per item (entries: into t_*, rows: into l_*)
+    ft_idx.reserve((size_t)S.n_terms + S.l_ptr[n]);
     for (int e = 0; e < nE; ++e) {
-        level[e] = S.e_level[e]; work[e] = S.t_ptr[e + 1] - S.t_ptr[e];
+        const bool top = in_top(owner(e));
+        int lev = top ? 0 : S.e_level[e];
+        for (int t = S.t_ptr[e]; t < S.t_ptr[e + 1]; ++t) {
+            if (top && in_top(S.e_col[S.t_a[t]])) continue;
+            ft_idx.push_back(t);
+            if (top) lev = std::max(lev, 1 + std::max(S.e_level[S.t_a[t]], std::max(S.e_level[S.t_d[t]], S.e_level[S.t_b[t]])));
+        }
+        ft_ptr[e + 1] = (int)ft_idx.size();
+        work[e] = ft_ptr[e + 1] - ft_ptr[e];
+        if (top && work[e] == 0 && !S.inplace && S.e_src[e] >= 0) lev = 1;           // copy of the caller's block
+        level[e] = lev;
         if (S.inplace && work[e] == 0 && S.e_row[e] != S.e_col[e] && S.e_src[e] >= 0) level[e] = 0;   // already in place
+        if (top && work[e] == 0 && (S.inplace || S.e_src[e] < 0)) level[e] = 0;      // in place already / starts from zero inside its task
         if (sym && S.e_row[e] > S.e_col[e]) level[e] = 0;
     }
-    for (int r = 0; r < n; ++r) { level[nE + r] = S.y_level[r]; work[nE + r] = S.l_ptr[r + 1] - S.l_ptr[r]; }
+    for (int r = 0; r < n; ++r) {
+        const bool top = in_top(r);
+        int lev = top ? 1 : S.y_level[r];
+        for (int p = S.l_ptr[r]; p < S.l_ptr[r + 1]; ++p) {
+            const int c = S.l_col[p];
+            if (top && in_top(c)) continue;
+            ft_idx.push_back(p);
+            if (top) lev = std::max(lev, 1 + std::max(S.y_level[c], std::max(S.e_level[S.l_ent[p]], S.e_level[S.diag[c]])));
+        }
+        ft_ptr[nE + r + 1] = (int)ft_idx.size();
+        work[nE + r] = ft_ptr[nE + r + 1] - ft_ptr[nE + r];
+        level[nE + r] = lev;
+    }
     auto fill_fact = [&](int it, int sub, int wpi, int rpw, Rec* r) {
-        int kind, id, src, t0, t1;
+        int kind, id, src;
         if (it < nE) {
             kind = S.e_row[it] == S.e_col[it] ? 2 : (S.e_row[it] > S.e_col[it] ? 1 : 0);
-            id = it; src = S.e_src[it] < 0 ? -1 : (S.inplace ? it : S.e_src[it]); t0 = S.t_ptr[it]; t1 = S.t_ptr[it + 1];
+            if (in_top(owner(it))) kind = 0;                     // partial sum of a task-owned entry: stored raw
+            id = it; src = S.e_src[it] < 0 ? -1 : (S.inplace ? it : S.e_src[it]);
         } else {
-            kind = 3; id = it - nE; src = S.perm[id]; t0 = S.l_ptr[id]; t1 = S.l_ptr[id + 1];
+            kind = 3; id = it - nE; src = S.perm[id];
         }
         for (int j = 0; j < rpw; ++j) { r[j].w[0] = kind; r[j].w[1] = id; r[j].w[2] = src; r[j].w[3] = 0; }
         int q = 0;
-        for (int t = t0 + sub; t < t1; t += wpi, ++q) {
+        for (int f = ft_ptr[it] + sub; f < ft_ptr[it + 1]; f += wpi, ++q) {
+            const int t = ft_idx[f];
             Rec& x = r[q / FACT_T];
             const int s = 4 + 3 * (q % FACT_T);
             if (it < nE) { x.w[s] = lower_operand(S.t_a[t]); x.w[s + 1] = S.t_d[t]; x.w[s + 2] = S.t_b[t]; }
@@ -222,11 +381,11 @@ void build_tables(BlockSymbolic& S) {
             x.w[3]++;
         }
     };
-    S.n_sched_terms = 0;
+    S.n_sched_terms = S.top_terms;
     for (int it = 0; it < nE + n; ++it) if (level[it] > 0) S.n_sched_terms += work[it];
     build_replay(level, work, FACT_T, S.fact_seg, S.fact_rec, S.n_fact_levels, fill_fact, NoExtra(), 0, FACT_WAVES);
     // forward elimination ALONE (factor once, solve many: fast decoupled power flow): the rhs rows only, levelled on
-    // each other (every factor entry is final)
+    // each other (every factor entry is final); all terms, no tasks
     {
         std::vector<int> flevel(nE + n, 0), fwork(nE + n, 0);
         for (int r = 0; r < n; ++r) {
@@ -234,7 +393,18 @@ void build_tables(BlockSymbolic& S) {
             for (int p = S.l_ptr[r]; p < S.l_ptr[r + 1]; ++p) l = std::max(l, flevel[nE + S.l_col[p]] + 1);
             flevel[nE + r] = l; fwork[nE + r] = S.l_ptr[r + 1] - S.l_ptr[r];
         }
-        build_replay(flevel, fwork, FACT_T, S.fwd_seg, S.fwd_rec, S.n_fwd_levels, fill_fact, NoExtra(), 0, FACT_WAVES);
+        auto fill_fwd = [&](int it, int sub, int wpi, int rpw, Rec* r) {
+            const int id = it - nE;
+            for (int j = 0; j < rpw; ++j) { r[j].w[0] = 3; r[j].w[1] = id; r[j].w[2] = S.perm[id]; r[j].w[3] = 0; }
+            int q = 0;
+            for (int t = S.l_ptr[id] + sub; t < S.l_ptr[id + 1]; t += wpi, ++q) {
+                Rec& x = r[q / FACT_T];
+                const int s = 4 + 3 * (q % FACT_T);
+                x.w[s] = lower_operand(S.l_ent[t]); x.w[s + 1] = S.diag[S.l_col[t]]; x.w[s + 2] = S.l_col[t];
+                x.w[3]++;
+            }
+        };
+        build_replay(flevel, fwork, FACT_T, S.fwd_seg, S.fwd_rec, S.n_fwd_levels, fill_fwd, NoExtra(), 0, FACT_WAVES);
     }
     // backward sweep: chains of a supernode go to ONE workgroup each (CHAIN_MAX_ROWS), the other rows stay wave records
     std::vector<int> uw(n);
@@ -345,6 +515,7 @@ void build_selected_inverse(BlockSymbolic& S) {
 int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic& S) {
     S = BlockSymbolic();
     S.inplace = policy & 1;
+    constexpr int TOP_LEVEL_DEFAULT = 12, TOP_FRONT_SOFT = 32;
     S.symmetric = (policy >> 1) & 1;
     S.n = n;
     if (n <= 0) return 1;
@@ -491,6 +662,14 @@ int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic&
     for (int r = n - 1; r >= 0; --r)
         for (int p = S.u_ptr[r]; p < S.u_ptr[r + 1]; ++p) S.bwd_level[r] = std::max(S.bwd_level[r], S.bwd_level[S.u_col[p]] + 1);
 
+    {
+        int top_level = (policy >> 8) & 0xff, soft = (policy >> 16) & 0xff;
+        if (const char* e = getenv("JG_TOP_LEVEL")) top_level = atoi(e);
+        if (const char* e = getenv("JG_TOP_FRONT")) soft = atoi(e);
+        if (top_level == 0) top_level = TOP_LEVEL_DEFAULT;
+        if (soft <= 0) soft = TOP_FRONT_SOFT;
+        build_top(S, top_level, std::min(soft, TOP_FRONT_MAX));
+    }
     build_tables(S);
     return 0;
 }

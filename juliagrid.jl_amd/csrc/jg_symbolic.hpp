@@ -47,6 +47,29 @@ constexpr int BWD_T = 6;    // BwdRec:  {k, bus, diag, nterms, (u_ent, u_col) x 
 constexpr int CHAIN_MAX_ROWS = 32, CHAIN_MAX_EXT = 72;
 struct Rec { int w[16]; };
 
+// ---- multifrontal TOP of the elimination tree ---------------------------------------------------------------------
+// Above a dependency level the tree is a handful of long chains with few items per level: per-level launches there cost a
+// kernel boundary + a cold record fetch + a round of operand loads each (7.7 us at 64 scenarios, 9-20 us at 512) for a
+// handful of blocks.  Those pivots are factorised by TOP TASKS instead: a task = consecutive pivots k0 .. k0+m-1 that
+// form a path of the tree (parent(k) = k + 1), worked on by ONE workgroup PER SCENARIO with the dense front
+// (m pivots + e external rows/columns, e = |struct(last pivot)|) in LDS -- lanes run across the front, a pivot step is an
+// LDS round trip + one workgroup barrier (~0.15 us) instead of a launch.  Tasks talk multifrontally: a task leaves its
+// e x e update matrix (+ update vector of the fused forward elimination) on a scenario-major stack, its parent task adds
+// it into its own front (extend-add), so the 3-block-reads-per-term pull of the level kernel disappears for every term
+// whose pivot is in a task (half to three quarters of all terms on transmission grids).
+// Contributions of BOTTOM pivots (all others) to task-owned entries still arrive through level items: those items carry
+// only the bottom terms of the entry and store the partial sum raw (also for diagonal blocks).
+//   header (one 64-byte record per task, level-major / class-major order):
+//     w0 m, w1 e, w2 k0, w3 offset of the task's data in top_data, w4 stack offset of its update matrix (doubles, -1: root),
+//     w5 owned entries (load / store list), w6 children, w7 front pitch in blocks (odd), w8 ints of the step table + lists,
+//     w9 offset of the load list, w10 offset of the child records (both relative to w3)
+//   data: step table m x {s, byte offset of the list, log2 of the column width}; struct lists as bytes (local front indices,
+//     ascending; the first one is the next pivot of the chain); load list n x {entry | flags << 28, row << 8 | col}
+//     (flag 1: starts from zero -- fill-in without bottom terms; flag 2: also mirrored into (col,row) transposed -- symmetric
+//     plans store the upper triangle only); child records {stack offset, e_c, map[e_c] child external -> local index}
+constexpr int TOP_FRONT_MAX = 64;       // m + e of a task (LDS: 65 * 64 * 32 B = 130 KiB); also bounds the column width of a step
+struct TopLaunch { int task_begin, ntasks, waves, lds_bytes, level; };
+
 struct BlockSymbolic {
     int n = 0;
     std::vector<int> perm;              // perm[k]  = original block index eliminated k-th
@@ -86,11 +109,21 @@ struct BlockSymbolic {
     std::vector<Segment> sel_seg;       // selected inverse (built on demand: build_selected_inverse)
     std::vector<Rec> sel_rec;
     int n_sel_levels = 0;
+    // multifrontal top (see TopLaunch): empty when the plan has no top tasks
+    int top_level = 0;                  // pivots whose diagonal becomes final at this level or later belong to top tasks (0: none)
+    std::vector<int> top_task_of;       // [n] task index of a pivot, -1 = bottom pivot
+    std::vector<Rec> top_task;          // task headers, launch order
+    std::vector<int> top_data;
+    std::vector<TopLaunch> top_launch;
+    long long top_stack = 0;            // doubles per scenario on the update stack
+    long long top_terms = 0;            // update terms executed inside tasks
 };
 
 // pattern: CSR (rowptr[n+1], col[nnz]) 0-based, must contain the diagonal and be structurally
 // symmetric. policy bit 0: in-place factor storage (see BlockSymbolic::inplace); bit 1: symmetric VALUES (LDL' by
 // reading U(k,i)' for Lh(i,k): half the update terms; only the blocks on and above the diagonal must be assembled).
+// policy bits 8-15: dependency level from which pivots go to top tasks (0 = default, 255 = no top tasks); bits 16-23: soft
+// cap of a task's front (0 = default).
 // Returns 0, or 1 on a malformed pattern.
 int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic& out);
 // Replay tables of the selected inverse of a SYMMETRIC matrix on the factor pattern (see jg_symbolic.cpp); idempotent.

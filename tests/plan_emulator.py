@@ -1,6 +1,6 @@
 """numpy replay of the static block-LU / triangular-solve replay tables (TEST INFRASTRUCTURE).
 
-Mirrors what the HIP kernels (k_fact_level / k_bwd_level and the persistent walker) do for ONE scenario:
+Mirrors what the HIP kernels (k_fact_level / k_fact_top / k_bwd_level) do for ONE scenario:
 it walks the very tables the device reads (segment -> chunk -> wave -> 64-byte record, jg_symbolic.hpp)
 and asserts that every value a record reads was produced in an EARLIER dependency level (all items of a
 level run concurrently on the device): a race detector for the schedule.  Not used by the product.
@@ -46,6 +46,7 @@ class Replay:
         self.symmetric = symmetric      # policy bit 1: only the upper entries are scheduled (LDL' through transposed reads)
         self.fseg, self.frec = plan.replay_tables("fact")
         self.bseg, self.brec = plan.replay_tables("bwd")
+        self.thdr, self.tdata, self.tlaunch, self.task_of, self.tinfo = plan.top_tables()
 
     @staticmethod
     def _waves(seg, rec):
@@ -63,11 +64,15 @@ class Replay:
         X = np.zeros((nE, 2, 2))
         Y = np.zeros((self.n, 2))
         level_of = np.full(nE + self.n, -1)      # level at which an entry / rhs row becomes final (-1: never yet)
+        partial = np.zeros(nE + self.n, dtype=bool)          # task-owned items that hold their bottom terms only
+        part_level = np.zeros(nE + self.n, dtype=int)
         if self.inplace:
             has = self.e_src >= 0
             X[has] = A[self.e_src[has]]
             work = np.diff(self.t_ptr)
             untouched = has & (work == 0) & (self.e_row != self.e_col)
+            if self.task_of.size:                           # task-owned entries become final inside their task
+                untouched &= self.task_of[np.minimum(self.e_row, self.e_col)] < 0
             level_of[:nE][untouched] = 0         # already final before the first level
         acc, meta = {}, {}
 
@@ -75,13 +80,22 @@ class Replay:
             for key, (lev, kind, ident) in meta.items():
                 v = acc[key]
                 if kind == 3:
-                    assert level_of[nE + ident] < 0, f"rhs row {ident} scheduled twice"
+                    assert level_of[nE + ident] < 0 and not partial[nE + ident], f"rhs row {ident} scheduled twice"
                     Y[ident] = v
-                    level_of[nE + ident] = lev
+                    if self.task_of.size and self.task_of[ident] >= 0:
+                        partial[nE + ident] = True
+                        part_level[nE + ident] = lev
+                    else:
+                        level_of[nE + ident] = lev
                 else:
-                    assert level_of[ident] < 0, f"entry {ident} scheduled twice"
+                    assert level_of[ident] < 0 and not partial[ident], f"entry {ident} scheduled twice"
                     X[ident] = dfactor(v) if kind == 2 else v
-                    level_of[ident] = lev
+                    if self._top_owned(ident):                   # bottom terms only, stored raw: final inside its task
+                        assert kind != 2, "a task-owned diagonal block must not be factorised by a level item"
+                        partial[ident] = True
+                        part_level[ident] = lev
+                    else:
+                        level_of[ident] = lev
             acc.clear()
             meta.clear()
 
@@ -124,16 +138,144 @@ class Replay:
         for r in self.frec:
             if r[0] >= 0:
                 terms_seen += int(r[3])
+        terms_seen += self._top_tasks(X, Y, level_of, partial, part_level, (current or 0))
         work = np.diff(self.t_ptr)
         if self.symmetric:
             lower = self.e_row > self.e_col
             assert (level_of[:nE][lower] <= 0).all(), "a symmetric plan must not schedule the lower entries"
-            assert terms_seen == int(work[~lower].sum()) + int(self.l_ptr[-1])
+            # inside a task the elimination runs on the full (mirrored) front: both triangles of its terms are executed
+            in_task = self.task_of[self.e_col[self.p.get("t_a")]] >= 0 if self.task_of.size else np.zeros(int(self.t_ptr[-1]), dtype=bool)
+            ent = np.repeat(np.arange(nE), work)
+            assert terms_seen == int((~lower[ent] | in_task).sum()) + int(self.l_ptr[-1])
             assert (level_of[:nE][~lower] >= 0).all() and (level_of[nE:] >= 0).all()
         else:
             assert terms_seen == int(self.t_ptr[-1]) + int(self.l_ptr[-1]), "update terms lost or duplicated in the records"
             assert (level_of >= 0).all(), "items missing from the factorisation schedule"
         return X, Y
+
+    def _top_owned(self, e):
+        return self.task_of.size > 0 and self.task_of[min(self.e_row[e], self.e_col[e])] >= 0
+
+    def _top_tasks(self, X, Y, level_of, partial, part_level, bottom_levels):
+        """Replays the multifrontal top (jg_symbolic.hpp, k_fact_top): per launch, per task: load the owned entries into a dense
+        front, extend-add the children's update matrices, eliminate the chain's pivots (struct lists), store.  Asserts that
+        everything a task reads exists before its launch.  Returns the update terms executed."""
+        hdr, data, launches = self.thdr, self.tdata, self.tlaunch
+        nE = self.nE
+        if hdr.shape[0] == 0:
+            assert not partial.any()
+            return 0
+        stack = np.full(int(self.tinfo[1]), np.nan)
+        stack_level = {}
+        seen_tasks = 0
+        terms = 0
+        done_pivot = np.zeros(self.n, dtype=bool)
+        prev = (0, 0)
+        for li, (tb, ntk, waves, lds, tlevel) in enumerate(launches):
+            assert (tlevel, waves) > prev and tb == seen_tasks, "launches out of order"
+            prev = (tlevel, waves)
+            lev = bottom_levels + tlevel
+            results = []
+            for ti in range(tb, tb + ntk):
+                m, e, k0, base, soff, nload, nchild, fp, nlist, load_off, child_off, tl, tw = (int(v) for v in hdr[ti][:13])
+                f = m + e
+                assert tl == tlevel and tw == waves and fp == (f | 1) and 1 <= m and f <= 64
+                assert f * fp * 32 + f * 16 + nlist * 4 + 64 <= lds <= 160 * 1024
+                assert np.all(self.task_of[k0:k0 + m] == ti)
+                F = np.full((f, f, 2, 2), np.nan)
+                Fy = np.full((f, 2), np.nan)
+                F[m:, m:] = 0.0
+                Fy[m:] = 0.0
+                ll = data[base + load_off: base + load_off + 2 * nload].reshape(nload, 2)
+                owned = []
+                for w0, w1 in ll:
+                    ent, fl, r, c = int(w0) & 0x0fffffff, int(w0) >> 28, int(w1) >> 8, int(w1) & 255
+                    assert min(r, c) < m and (self.e_row[ent], self.e_col[ent]) == (self._piv(k0, m, e, r), self._piv(k0, m, e, c))
+                    assert level_of[ent] < 0, "a task-owned entry was finished by somebody else"
+                    if fl & 1:
+                        assert not partial[ent] and self.e_src[ent] < 0
+                        v = np.zeros((2, 2))
+                    else:
+                        assert partial[ent] or (self.inplace and self.e_src[ent] >= 0), "task loads an entry nobody wrote"
+                        v = X[ent].copy()
+                    F[r, c] = v
+                    if fl & 2:
+                        assert self.symmetric and r < c
+                        F[c, r] = v.T
+                    owned.append((ent, r, c))
+                for q in range(m):
+                    assert partial[nE + k0 + q]
+                    Fy[q] = Y[k0 + q]
+                cd = base + child_off
+                for _ in range(nchild):
+                    coff, ce = int(data[cd]), int(data[cd + 1])
+                    cmap = data[cd + 2: cd + 2 + ce]
+                    assert stack_level[coff] < (tlevel, 0), "child task in the same or a later launch level"
+                    C = stack[coff: coff + ce * ce * 4].reshape(ce, ce, 2, 2)
+                    Cv = stack[coff + ce * ce * 4: coff + ce * ce * 4 + ce * 2].reshape(ce, 2)
+                    assert len(set(cmap.tolist())) == ce and cmap.min() >= 0 and cmap.max() < f
+                    F[np.ix_(cmap, cmap)] += C
+                    Fy[cmap] += Cv
+                    cd += 2 + ce
+                tab = data[base: base + 3 * m].reshape(m, 3)
+                lists = data[base + 3 * m: base + nlist].view(np.uint8)
+                F[0, 0] = dfactor(F[0, 0])
+                for q in range(m):
+                    s, lo, lg = (int(v) for v in tab[q])
+                    lst = lists[lo: lo + s].astype(int)
+                    assert (1 << lg) >= s + 1 and (lg == 0 or (1 << (lg - 1)) < s + 1) and s + 1 <= 64
+                    k = k0 + q
+                    want = [self._loc(k0, m, e, int(c)) for c in self.p.get("u_col")[self.u_ptr[k]: self.u_ptr[k + 1]]]
+                    assert lst.tolist() == want and (q + 1 == m or (s > 0 and lst[0] == q + 1))
+                    D = F[q, q]
+                    yq = dsolve(D, Fy[q])
+                    for b in lst:
+                        Z = np.stack([dsolve(D, F[q, b][:, 0]), dsolve(D, F[q, b][:, 1])], axis=1)
+                        for a in lst:
+                            F[a, b] = F[a, b] - F[a, q] @ Z
+                            terms += 1
+                    for a in lst:
+                        Fy[a] = Fy[a] - F[a, q] @ yq
+                        terms += 1
+                    if q + 1 < m:
+                        F[q + 1, q + 1] = dfactor(F[q + 1, q + 1])
+                assert not np.isnan(F[m:, m:]).any() and not np.isnan(Fy).any()
+                results.append((ti, owned, F, Fy, k0, m, e, soff))
+            for ti, owned, F, Fy, k0, m, e, soff in results:             # tasks of one launch are independent of each other
+                for ent, r, c in owned:
+                    assert not np.isnan(F[r, c]).any(), "a task stores an entry of its front that was never written"
+                    X[ent] = F[r, c]
+                    level_of[ent] = lev
+                    partial[ent] = False
+                for q in range(m):
+                    Y[k0 + q] = Fy[q]
+                    level_of[nE + k0 + q] = lev
+                    partial[nE + k0 + q] = False
+                    done_pivot[k0 + q] = True
+                if e > 0:
+                    assert soff >= 0
+                    stack[soff: soff + e * e * 4] = F[m:, m:].reshape(-1)
+                    stack[soff + e * e * 4: soff + e * e * 4 + e * 2] = Fy[m:].reshape(-1)
+                    stack_level[soff] = (tlevel, 0)
+                else:
+                    assert soff == -1
+            seen_tasks += ntk
+        assert seen_tasks == hdr.shape[0] and not partial.any()
+        assert np.array_equal(done_pivot, self.task_of >= 0)
+        return terms
+
+    def _front_ext(self, k0, m):
+        kl = k0 + m - 1
+        return self.p.get("u_col")[self.u_ptr[kl]: self.u_ptr[kl + 1]]
+
+    def _piv(self, k0, m, e, loc):
+        return k0 + loc if loc < m else int(self._front_ext(k0, m)[loc - m])
+
+    def _loc(self, k0, m, e, piv):
+        if k0 <= piv < k0 + m:
+            return piv - k0
+        ext = self._front_ext(k0, m).tolist()
+        return m + ext.index(piv)
 
     def backsolve(self, X, Y):
         """Replays the backward tables: wave-record rows and CHAIN tasks (segments with wpi == 0: consecutive pivots of a

@@ -89,8 +89,29 @@ def test_plan_structure_invariants(jg):
     lead = np.concatenate([np.arange(b, b + c * 16 * r, r * w) for b, c, w, r in seg[:, :4]])   # first record of each leader wave
     lead = lead[rec[lead, 0] >= 0]
     ids = np.where(rec[lead, 0] == 3, e_row.size + rec[lead, 1], rec[lead, 1])
-    assert sorted(ids.tolist()) == list(range(e_row.size + Y.n))
-    assert rec[rec[:, 0] >= 0, 3].sum() == t_ptr[-1] + plan.get("l_ptr")[-1]
+    # multifrontal top: task-owned fill-in without a term of a bottom pivot starts from zero inside its task (no level item);
+    # the terms of task pivots run inside the tasks
+    hdr, tdata, launches, task_of, info = plan.top_tables()
+    assert hdr.shape[0] > 20 and info[0] > 0 and (task_of >= 0).sum() > 200
+    ent = np.repeat(np.arange(e_row.size), np.diff(t_ptr))
+    bottom_term = task_of[e_col[t_a]] < 0
+    has_bottom = np.zeros(e_row.size, dtype=bool)
+    has_bottom[ent[bottom_term]] = True
+    skipped = (task_of[np.minimum(e_row, e_col)] >= 0) & ~has_bottom & (e_src < 0)
+    assert sorted(ids.tolist()) == sorted(np.flatnonzero(~skipped).tolist() + list(range(e_row.size, e_row.size + Y.n)))
+    l_ptr, l_col = plan.get("l_ptr"), plan.get("l_col")
+    lrow = np.repeat(np.arange(Y.n), np.diff(l_ptr))
+    rhs_bottom = (task_of[l_col] < 0).sum()
+    assert np.all(task_of[lrow[task_of[l_col] >= 0]] >= 0)                                         # a task pivot only feeds task rows
+    assert rec[rec[:, 0] >= 0, 3].sum() == bottom_term.sum() + rhs_bottom
+    u_ptr = plan.get("u_ptr")
+    s_top = np.diff(u_ptr)[task_of >= 0].astype(np.int64)
+    assert info[2] == (s_top * (s_top + 1)).sum() == (~bottom_term).sum() + (l_ptr[-1] - rhs_bottom)
+    assert seg[-1, 4] <= info[0] and launches[-1, 4] + seg[-1, 4] < 40                              # 84 dependent launches before
+    # no top tasks on request: the pure level schedule
+    plan0 = jg._lib.Plan(Y.n, Y.colptr - 1, Y.rowval - 1, policy=255 << 8)
+    seg0, rec0 = plan0.replay_tables("fact")
+    assert plan0.top_tables()[0].shape[0] == 0 and seg0[-1, 4] == lev.max() and rec0[rec0[:, 0] >= 0, 3].sum() == t_ptr[-1] + l_ptr[-1]
     seg, rec = plan.replay_tables("bwd")
     rows_seg = seg[seg[:, 2] > 0]
     lead = np.concatenate([np.arange(b, b + c * 16 * r, r * w) for b, c, w, r in rows_seg[:, :4]])
@@ -107,10 +128,12 @@ def test_plan_structure_invariants(jg):
     seg1, rec1 = plan1.replay_tables("fact")
     lead1 = np.concatenate([np.arange(b, b + c * 16 * r, r * w) for b, c, w, r in seg1[:, :4]])
     lead1 = lead1[rec1[lead1, 0] >= 0]
-    skipped = (e_src >= 0) & (np.diff(t_ptr) == 0) & (e_row != e_col)
+    top_owned = task_of[np.minimum(e_row, e_col)] >= 0
+    skipped = np.where(top_owned, ~has_bottom, (e_src >= 0) & (np.diff(t_ptr) == 0) & (e_row != e_col))   # task-owned: only partial sums are scheduled
     assert lead1.size == e_row.size + Y.n - skipped.sum() and skipped.sum() > 20000
     ent1 = rec1[lead1][rec1[lead1, 0] != 3]
     assert not np.any(skipped[ent1[:, 1]])
+    assert not np.any(top_owned[ent1[ent1[:, 0] == 2, 1]])                   # no level item factorises a task-owned diagonal block
     assert np.all(ent1[ent1[:, 2] >= 0, 2] == ent1[ent1[:, 2] >= 0, 1])       # src names the entry itself
 
 
@@ -202,7 +225,7 @@ def test_selected_inverse_replay_matches_dense_inverse(jg, name, symmetric):
     assert seg[-1, 4] == 2 * plan.get("bwd_level").max()
 
 
-def _solve_with_plan(jg, n, edges, rng, symmetric=False):
+def _solve_with_plan(jg, n, edges, rng, symmetric=False, top=0):
     adj = {(i, i) for i in range(n)} | {(a, b) for a, b in edges} | {(b, a) for a, b in edges}
     rowptr, col = [0], []
     for i in range(n):
@@ -223,7 +246,7 @@ def _solve_with_plan(jg, n, edges, rng, symmetric=False):
         dense = (dense + dense.T) / 2
     dense += np.diag(np.abs(dense).sum(axis=1) + 1.0)
     A = np.array([dense[2 * i:2 * i + 2, 2 * col[p]:2 * col[p] + 2] for i in range(n) for p in range(rowptr[i], rowptr[i + 1])])
-    plan = jg._lib.Plan(n, rowptr, col, policy=3 if symmetric else 1)
+    plan = jg._lib.Plan(n, rowptr, col, policy=(3 if symmetric else 1) | top)
     assert sorted(plan.get("perm")) == list(range(n))
     rp = Replay(plan, inplace=True, symmetric=symmetric)
     rhs = rng.standard_normal((n, 2))
@@ -231,6 +254,27 @@ def _solve_with_plan(jg, n, edges, rng, symmetric=False):
     x = rp.backsolve(X, Yf)
     assert np.abs(x.reshape(-1) - np.linalg.solve(dense, rhs.reshape(-1))).max() <= 1e-11
     return plan
+
+
+@pytest.mark.parametrize("symmetric", [False, True])
+@pytest.mark.parametrize("top_level,soft", [(1, 4), (2, 8), (2, 64), (3, 16)])
+def test_top_tasks_on_small_and_random_graphs(jg, symmetric, top_level, soft):
+    """The multifrontal top pushed down to the leaves (every pivot / every pivot above level 1 or 2 in a task; fronts cut at
+    4, 8, 16 and 64 blocks): chains, extend-add maps, partial level items and the update stack must stay consistent."""
+    rng = np.random.default_rng(100 * top_level + soft)
+    cases = [(1, []), (2, [(0, 1)]), (12, [(i, i + 1) for i in range(11)]), (9, [(0, i) for i in range(1, 9)]),
+             (8, [(i, j) for i in range(8) for j in range(i + 1, 8)]),
+             (20, [(i, i + 1) for i in range(0, 19)] + [(i, i + 10) for i in range(10)]),
+             (40, [(i, j) for i in range(40) for j in range(i + 1, min(i + 4, 40))])]
+    for _ in range(6):
+        n = int(rng.integers(20, 90))
+        m = int(rng.integers(n, 3 * n))
+        cases.append((n, [tuple(sorted(rng.choice(n, 2, replace=False))) for _ in range(m)]))
+    ntasks = 0
+    for n, edges in cases:
+        plan = _solve_with_plan(jg, n, edges, rng, symmetric, top=top_level << 8 | soft << 16)
+        ntasks += plan.top_tables()[0].shape[0]
+    assert ntasks > 30
 
 
 @pytest.mark.parametrize("symmetric", [False, True])
