@@ -153,6 +153,6 @@ class Plan:
         return self.get(base).reshape(-1, 8), self.get(base + 1).reshape(-1, 16)
 
     def top_tables(self):
-        """Multifrontal top (jg_symbolic.hpp): task headers [t,16], task data, launches [l,5] = task_begin, ntasks, waves,
-        lds_bytes, level; task of each pivot; (top_level, stack doubles per scenario, terms inside tasks)."""
-        return self.get(70).reshape(-1, 16), self.get(71), self.get(72).reshape(-1, 5), self.get(73), self.get(74)
+        """Multifrontal top (jg_symbolic.hpp): task headers [t,16], task data, launches [l,4] = task_begin, ntasks, class,
+        level; task of each pivot; (top_level, stack doubles per scenario, terms inside tasks)."""
+        return self.get(70).reshape(-1, 16), self.get(71), self.get(72).reshape(-1, 4), self.get(73), self.get(74)

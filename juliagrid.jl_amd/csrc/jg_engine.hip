@@ -464,183 +464,262 @@ __global__ __launch_bounds__(64 * FACT_WAVES, 4) void k_sel_level(SelArgs a) {  
     }
 }
 
-// ---- multifrontal top (jg_symbolic.hpp): one workgroup per (task, scenario), dense front in LDS -------------------------
+// ---- multifrontal top (jg_symbolic.hpp): one workgroup per (task, scenario), dense front in registers ------------------
 // The pivots above BlockSymbolic::top_level are not level items: a TASK owns a chain of consecutive pivots k0 .. k0+m-1
-// (parent(k) = k + 1) and its front of f = m + e block rows / columns (e = |struct(last pivot)|).  Lanes run across the front
-// of ONE scenario (the level kernels run 64 scenarios across the lanes): a pivot step is LDS reads + 2x2 block FMAs + one
-// workgroup barrier, not a kernel boundary with cold caches.
-//   load:   owned entries (rows / columns of the chain) from the batch-minor factor storage -- they hold the assembled value
-//           plus the terms of bottom pivots (level items) --, the rhs rows, the children's update matrices from the stack;
-//   steps:  for pivot q: F(i,j) -= F(i,q) D(q)^-1 F(q,j) over struct(q)^2 (+ the rhs column), the lane that finishes
-//           D(q+1) factorises it in place (2x2 LU with partial pivoting, as fact_finish);
-//   store:  U, unscaled Lh, factored D, y back to the batch-minor storage (the backward sweep, the forward-only sweep and the
-//           selected inverse read them there), the e x e update matrix + update vector to the scenario-major stack.
-// Same arithmetic per term as term3(), terms of an entry in ascending pivot order => bitwise run-to-run determinism.
+// (parent(k) = k + 1) and its front of f = m + e block rows / columns (e = |struct(last pivot)|) plus the rhs as column f.
+// Lanes run across the front of ONE scenario (the level kernels run 64 scenarios across the lanes).
+//   Where the front lives.  A first version kept it in LDS and updated it row by row: a pivot step then moves struct^2 blocks
+//   through the LDS pipe (reads at 256 B/clk, writes at ~80 B/clk, half-empty lanes) -- measured 1 700 - 2 900 clocks per step
+//   whatever the wave roles were.  Now thread (i mod 16, c mod 16) of a 16 x 16 grid OWNS block (i, c) in registers
+//   (CLS x CLS blocks per thread) and LDS only carries what a step broadcasts: the pivot row, the pivot column, the pivot.
+//   bulk threads (waves 0-3), step q:  z_c = D(q)^-1 U(q, c) for their columns, F(i, c) -= L(i, q) z_c for their blocks with
+//                        i, c > q (dense: blocks outside the pattern are zero and stay zero); the owners of row q + 1 and of
+//                        column q + 1 publish them for the next step.
+//   pivot wave (wave 4): keeps its own copy of the chain's diagonal blocks (lane k: S(k,k)), applies the same update to them
+//                        from the published row / column, factorises D(q + 1) (2x2 LU with partial pivoting, every lane the same
+//                        copy: no divergence) and publishes it -- the only chain that links consecutive steps runs beside the
+//                        bulk update instead of behind it.
+// One workgroup barrier per step.  Load and store go straight between the batch-minor factor storage and the registers (entry
+// map of the task); children's update blocks are pulled from the scenario-major stack by the thread that owns the target.
+// Terms of an entry are applied in ascending pivot order => bitwise run-to-run determinism.
 struct TopArgs {
     const Rec* task; const int* data;
     double* X; double* W; double* stack; int* status; GroupSel sel;
     long long stack_stride;        // doubles per scenario
+    long long* prof;               // JG_TOP_PROFILE: [task][8] wall-clock stamps of scenario 0 (start, loaded, children, steps, stored), else null
     int ld, lanes, task_begin, ntasks, lpg;   // lpg: scenarios per 64-lane group that get a workgroup (64, or the real count of a single small group)
 };
 
-__device__ __forceinline__ Blk lds_blk(const double* F, int r, int c, int fp) {
-    const double2* p = (const double2*)(F + ((size_t)r * fp + c) * 4);
-    const double2 r0 = p[0], r1 = p[1];
-    return Blk{r0.x, r0.y, r1.x, r1.y};
+// 1 / x without the IEEE division sequence (v_rcp_f64 + two Newton steps: 5 dependent operations instead of ~14; the result
+// is within an ulp or two, which only perturbs the stored pivot factors at rounding level -- the factorisation stays the
+// exact product of what is stored).  0 -> inf -> NaN and NaN -> NaN, both caught by the pivot check.
+__device__ __forceinline__ double rcp_fast(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
 }
-__device__ __forceinline__ void lds_put(double* F, int r, int c, int fp, const Blk& v) {
-    double2* p = (double2*)(F + ((size_t)r * fp + c) * 4);
-    p[0] = double2{v.v00, v.v01}; p[1] = double2{v.v10, v.v11};
-}
-// 2x2 LU with in-block partial pivoting, stored form of fact_finish
-__device__ __forceinline__ Blk factor_diag(const Blk& c, int* status) {
+// 2x2 LU with in-block partial pivoting in the stored form of fact_finish.  The pivot sits on the dependent chain of every
+// chain step, so the two reciprocals are independent here: u22 = det / u11 with det = o22 u11 - o21 u12 (same backward
+// error as o22 - (o21 / u11) u12: one rounded product in front of the subtraction either way).
+__device__ __forceinline__ Blk factor_diag(const Blk& c, int& bad) {   // bad: sticky flag, reported once at the end of the task
     const bool sw = fabs(c.v10) > fabs(c.v00);
     const double u11 = sw ? c.v10 : c.v00, u12 = sw ? c.v11 : c.v01;
     const double o21 = sw ? c.v00 : c.v10, o22 = sw ? c.v01 : c.v11;
-    const double iu11 = 1.0 / u11;
+    const double det = fma(o22, u11, -(o21 * u12));
+    const double iu11 = rcp_fast(u11), idet = rcp_fast(det);
     const double l = o21 * iu11;
-    const double u22 = o22 - l * u12;
-    const double iu22 = 1.0 / u22;
-    if (!(fabs(u11) > 0.0) || !(fabs(u22) > 0.0) || !(fabs(iu11) < 1.0e300) || !(fabs(iu22) < 1.0e300)) atomicOr(status, 4);
+    const double iu22 = u11 * idet;
+    bad |= (!(fabs(u11) > 0.0) || !(fabs(det) > 0.0) || !(fabs(iu11) < 1.0e300) || !(fabs(iu22) < 1.0e300)) ? 1 : 0;
     return Blk{iu11, u12, sw ? l + 4.0 : l, iu22};
 }
 
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void k_fact_top(TopArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr int NT = 64 * NW;
+__device__ __forceinline__ Blk lds_get(const double* base, int k) {
+    const double2* p = (const double2*)(base + (size_t)k * 4);
+    const double2 r0 = p[0], r1 = p[1];
+    return Blk{r0.x, r0.y, r1.x, r1.y};
+}
+__device__ __forceinline__ void lds_set(double* base, int k, const Blk& v) {
+    double2* p = (double2*)(base + (size_t)k * 4);
+    p[0] = double2{v.v00, v.v01}; p[1] = double2{v.v10, v.v11};
+}
+__device__ __forceinline__ Blk zero_blk() { return Blk{0.0, 0.0, 0.0, 0.0}; }
+// c -= l * z
+__device__ __forceinline__ void blk_sub(Blk& c, const Blk& l, const Blk& z) {
+    c.v00 = fma(-l.v01, z.v10, fma(-l.v00, z.v00, c.v00));
+    c.v01 = fma(-l.v01, z.v11, fma(-l.v00, z.v01, c.v01));
+    c.v10 = fma(-l.v11, z.v10, fma(-l.v10, z.v00, c.v10));
+    c.v11 = fma(-l.v11, z.v11, fma(-l.v10, z.v01, c.v11));
+}
+
+constexpr int TOP_THREADS = 320;        // 16 x 16 bulk threads + the pivot wave
+
+template <int CLS>
+__global__ __launch_bounds__(TOP_THREADS) void k_fact_top(TopArgs a) {
+    __shared__ __attribute__((aligned(16))) double Dbuf[2][4];         // factorised pivot of the current / next step
+    __shared__ __attribute__((aligned(16))) double Ubuf[2][64 * 4];    // pivot row  U(q, c)
+    __shared__ __attribute__((aligned(16))) double Lbuf[2][64 * 4];    // pivot column Lh(i, q)
+    __shared__ __attribute__((aligned(16))) double Dini[64 * 4];       // the chain's diagonal blocks as loaded (for the pivot wave)
     int grp, x;
     if (!map_block(a.sel, a.ld, a.ntasks * a.lpg, grp, x)) return;
     const int ti = x / a.lpg;
     const int bb = grp * 64 + (x - ti * a.lpg);
     if (bb >= a.lanes) return;                                   // padding lanes of the last group: no scenario, no work
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = uniform(tid >> 6);
+    const bool pivot_wave = tid >= 256;
+    const int lane = tid & 63;
+    const int gi = (tid >> 4) & 15, gj = tid & 15;               // bulk thread: row / column class on the 16 x 16 grid
+    const bool prof = a.prof && bb == 0 && tid == 0;
+    long long* pt = a.prof + (size_t)(a.task_begin + ti) * 8;
+    if (prof) pt[0] = wall_clock64();
     const RecS h = load_rec(a.task, (size_t)a.task_begin + ti);
-    const int m = h[0], e = h[1], k0 = h[2], nload = h[5], nchild = h[6], fp = h[7], nlist = h[8];
+    const int m = h[0], e = h[1], k0 = h[2], nchild = h[5], fprime = h[11];
+    const int f = fprime - 1;
     const int* td = a.data + h[3];
-    const int f = m + e;
-    double* F = lds;                                             // [f][fp] blocks of 4 doubles
-    double2* Y = (double2*)(F + (size_t)f * fp * 4);             // [f] rhs column
-    int* L = (int*)(Y + f);                                      // step table + struct lists
     const size_t b = (size_t)bb, ld = (size_t)a.ld;
     double* stk = a.stack + b * (size_t)a.stack_stride;
+    int bad = 0;
+    Blk T[CLS][CLS];
+    int code[CLS][CLS];
+    Blk mydiag{0.0, 0.0, 0.0, 0.0};                              // pivot wave, lane k < m: S(k,k), later the factorised D(k)
 
-    // ---- load
-    for (int i = tid; i < nlist; i += NT) L[i] = td[i];
-    for (int r = m + wave; r < f; r += NW)
-        if (lane < e) lds_put(F, r, m + lane, fp, Blk{0.0, 0.0, 0.0, 0.0});
-    if (tid < e) Y[m + tid] = double2{0.0, 0.0};
-    const int2* ll = (const int2*)(td + h[9]);
-    for (int i0 = tid; i0 < nload; i0 += 4 * NT) {              // four gathers in flight per lane
-        int2 d[4]; Blk v[4];
+    if (!pivot_wave) {
+        // ---- load: entry map, then every gather of the thread in flight together
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int i = i0 + u * NT; d[u] = ll[i < nload ? i : i0]; }
+        for (int r = 0; r < CLS; ++r)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            v[u] = Blk{0.0, 0.0, 0.0, 0.0};
-            if (i0 + u * NT < nload && !((unsigned)d[u].x >> 28 & 1)) v[u] = load_blk(a.X, (size_t)(d[u].x & 0x0fffffff), b, ld);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (i0 + u * NT < nload) {
-                const int r = d[u].y >> 8, c = d[u].y & 255;
-                lds_put(F, r, c, fp, v[u]);
-                if ((unsigned)d[u].x >> 28 & 2) lds_put(F, c, r, fp, Blk{v[u].v00, v[u].v10, v[u].v01, v[u].v11});   // symmetric plans: Lh(c,r) = U(r,c)'
+            for (int c = 0; c < CLS; ++c) {
+                const int i = r * 16 + gi, j = c * 16 + gj;
+                code[r][c] = (i < f && j < fprime) ? td[i * fprime + j] : -1;
             }
+#pragma unroll
+        for (int r = 0; r < CLS; ++r)
+#pragma unroll
+            for (int c = 0; c < CLS; ++c) {
+                const int cd = code[r][c];
+                Blk v{0.0, 0.0, 0.0, 0.0};
+                if (cd == -2) { const double2 y = load_vec(a.W, (size_t)(k0 + r * 16 + gi), b, ld); v.v00 = y.x; v.v10 = y.y; }
+                else if (cd >= 0 && !((cd >> 28) & 1)) {
+                    v = load_blk(a.X, (size_t)(cd & 0x0fffffff), b, ld);
+                    if ((cd >> 28) & 2) { const double s = v.v01; v.v01 = v.v10; v.v10 = s; }        // symmetric plans: Lh(i,c) = U(c,i)'
+                }
+                T[r][c] = v;
+            }
+        if (prof) pt[1] = wall_clock64();
+        // ---- extend-add: every thread pulls what the children left for its blocks (child order fixed => deterministic)
+        const int* cd = td + h[7];
+        for (int ch = 0; ch < nchild; ++ch) {
+            const int coff = cd[0], ce = cd[1];
+            const int* inv = cd + 2;
+            const double* C = stk + coff;
+            int ri[CLS], cj[CLS];
+#pragma unroll
+            for (int r = 0; r < CLS; ++r) { const int i = r * 16 + gi; ri[r] = i < f ? inv[i] : -1; }
+#pragma unroll
+            for (int c = 0; c < CLS; ++c) { const int j = c * 16 + gj; cj[c] = j < fprime ? inv[j] : -1; }
+#pragma unroll
+            for (int r = 0; r < CLS; ++r)
+#pragma unroll
+                for (int c = 0; c < CLS; ++c)
+                    if (ri[r] >= 0 && cj[c] >= 0) {
+                        const double2* p = (const double2*)(C + ((size_t)ri[r] * (ce + 1) + cj[c]) * 4);
+                        const double2 s0 = p[0], s1 = p[1];
+                        T[r][c].v00 += s0.x; T[r][c].v01 += s0.y; T[r][c].v10 += s1.x; T[r][c].v11 += s1.y;
+                    }
+            cd += 2 + fprime;
         }
+        if (prof) pt[2] = wall_clock64();
+        // ---- publish step 0: row 0, column 0, the chain's diagonal blocks; thread 0 factorises D(0).
+        // What is published is what the step needs and ZERO elsewhere (row: columns <= q, column: rows <= q), so the bulk update
+        // below runs without a single predicate: a finished block sees L = 0 or z = 0 and keeps its value.
+        const Blk zero{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < CLS; ++r)
+#pragma unroll
+            for (int c = 0; c < CLS; ++c) {
+                const int i = r * 16 + gi, j = c * 16 + gj;
+                if (i == 0) lds_set(Ubuf[0], j, j > 0 ? T[r][c] : zero);
+                if (j == 0) lds_set(Lbuf[0], i, i > 0 ? T[r][c] : zero);
+                if (i == j && i < m) lds_set(Dini, i, T[r][c]);
+            }
+        if (tid == 0) lds_set(Dbuf[0], 0, factor_diag(T[0][0], bad));
     }
-    for (int q = tid; q < m; q += NT) Y[q] = load_vec(a.W, (size_t)(k0 + q), b, ld);
     __syncthreads();
-    // ---- extend-add of the children's update matrices (two children may hit the same block: one after the other)
-    const int* cd = td + h[10];
-    for (int ch = 0; ch < nchild; ++ch) {
-        const int coff = uniform(cd[0]), ce = uniform(cd[1]);
-        const int* cmap = cd + 2;
-        const double* C = stk + coff;
-        const int cl = lane < ce ? cmap[lane] : 0;
-        for (int ca = wave; ca < ce; ca += 2 * NW) {
-            const int ca2 = ca + NW;
-            const int r0 = uniform(cmap[ca]), r1 = uniform(cmap[ca2 < ce ? ca2 : ca]);
-            double2 s0{0.0, 0.0}, s1{0.0, 0.0}, s2{0.0, 0.0}, s3{0.0, 0.0};
-            if (lane < ce) {
-                const double2* p = (const double2*)(C + ((size_t)ca * ce + lane) * 4);
-                s0 = p[0]; s1 = p[1];
-                if (ca2 < ce) { const double2* p2 = (const double2*)(C + ((size_t)ca2 * ce + lane) * 4); s2 = p2[0]; s3 = p2[1]; }
-                Blk t = lds_blk(F, r0, cl, fp);
-                lds_put(F, r0, cl, fp, Blk{t.v00 + s0.x, t.v01 + s0.y, t.v10 + s1.x, t.v11 + s1.y});
-                if (ca2 < ce) {
-                    t = lds_blk(F, r1, cl, fp);
-                    lds_put(F, r1, cl, fp, Blk{t.v00 + s2.x, t.v01 + s2.y, t.v10 + s3.x, t.v11 + s3.y});
+    if (pivot_wave) {
+        if (lane < m) mydiag = lds_get(Dini, lane);
+        if (lane == 0) mydiag = lds_get(Dbuf[0], 0);
+    }
+    // ---- pivot steps.  Straight-line bulk code: the pivot is the same block for every lane, so the row swap of its 2x2 LU is
+    // folded into the ADDRESS of the two halves of U(q, c) (scalar), finished blocks see zeros (no predicates, no skipping).
+    for (int q = 0; q < m; ++q) {
+        const int cur = q & 1, nxt = cur ^ 1;
+        Blk D = lds_get(Dbuf[cur], 0);
+        const int sw = uniform(D.v10 > 2.0 ? 1 : 0);
+        const double dl = D.v10 - 4.0 * sw;
+        auto zcol = [&](const double* ub, int k) {               // z = D^-1 U(q, k): rows of U read in pivot order
+            const double2* p = (const double2*)(ub + (size_t)k * 4);
+            const double2 a0 = p[sw], a1 = p[sw ^ 1];
+            Blk z;
+            z.v10 = (a1.x - dl * a0.x) * D.v11; z.v00 = (a0.x - D.v01 * z.v10) * D.v00;
+            z.v11 = (a1.y - dl * a0.y) * D.v11; z.v01 = (a0.y - D.v01 * z.v11) * D.v00;
+            return z;
+        };
+        if (!pivot_wave) {
+            Blk z[CLS], Lq[CLS];
+#pragma unroll
+            for (int c = 0; c < CLS; ++c) z[c] = zcol(Ubuf[cur], c * 16 + gj);
+#pragma unroll
+            for (int r = 0; r < CLS; ++r) Lq[r] = lds_get(Lbuf[cur], r * 16 + gi);
+#pragma unroll
+            for (int r = 0; r < CLS; ++r)
+#pragma unroll
+                for (int c = 0; c < CLS; ++c) blk_sub(T[r][c], Lq[r], z[c]);
+            if (q + 1 < m) {                     // the next pivot row / column leave their owners
+                // classes before the pivot's are finished (zeros), classes after it go out as they are (both uniform); only the
+                // pivot's own class needs a per-lane select
+                const int rq = (q + 1) >> 4, tq = (q + 1) & 15;
+                if (gi == tq) {
+#pragma unroll
+                    for (int r = 0; r < CLS; ++r)
+                        if (r == rq) {
+#pragma unroll
+                            for (int c = 0; c < CLS; ++c) {
+                                if (c < rq) lds_set(Ubuf[nxt], c * 16 + gj, zero_blk());
+                                else if (c > rq) lds_set(Ubuf[nxt], c * 16 + gj, T[r][c]);
+                                else lds_set(Ubuf[nxt], c * 16 + gj, gj > tq ? T[r][c] : zero_blk());
+                            }
+                        }
+                }
+                if (gj == tq) {
+#pragma unroll
+                    for (int c = 0; c < CLS; ++c)
+                        if (c == rq) {
+#pragma unroll
+                            for (int r = 0; r < CLS; ++r) {
+                                if (r < rq) lds_set(Lbuf[nxt], r * 16 + gi, zero_blk());
+                                else if (r > rq) lds_set(Lbuf[nxt], r * 16 + gi, T[r][c]);
+                                else lds_set(Lbuf[nxt], r * 16 + gi, gi > tq ? T[r][c] : zero_blk());
+                            }
+                        }
                 }
             }
-        }
-        if (tid < ce) {
-            const double2 v = ((const double2*)(C + (size_t)ce * ce * 4))[tid];
-            double2 y = Y[cmap[tid]];
-            y.x += v.x; y.y += v.y;
-            Y[cmap[tid]] = y;
-        }
-        __syncthreads();
-        cd += 2 + ce;
-    }
-    if (tid == 0) lds_put(F, 0, 0, fp, factor_diag(lds_blk(F, 0, 0, fp), a.status + b));
-    __syncthreads();
-    // ---- pivot steps
-    const unsigned char* lists = (const unsigned char*)(L + 3 * m);
-    for (int q = 0; q < m; ++q) {
-        const int s = uniform(L[3 * q]), lo = uniform(L[3 * q + 1]), lg = uniform(L[3 * q + 2]);
-        const unsigned char* lst = lists + lo;
-        const int bcol = lane & ((1 << lg) - 1), ar = lane >> lg, rpp = 64 >> lg;
-        const Blk D = lds_blk(F, q, q, fp);
-        double z00 = 0.0, z10 = 0.0, z01 = 0.0, z11 = 0.0;
-        int ib = 0;
-        if (bcol < s) {                                          // column operand D^-1 U(q, ib), once per lane and step
-            ib = lst[bcol];
-            const Blk U = lds_blk(F, q, ib, fp);
-            dsolve(D, U.v00, U.v10, z00, z10);
-            dsolve(D, U.v01, U.v11, z01, z11);
-        } else if (bcol == s) {                                  // the rhs column: D^-1 y_q
-            const double2 y = Y[q];
-            dsolve(D, y.x, y.y, z00, z10);
-        }
-        for (int a0 = wave * rpp + ar; a0 < s; a0 += NW * rpp) {
-            const int ia = lst[a0];
-            const Blk Lb = lds_blk(F, ia, q, fp);
-            if (bcol < s) {
-                Blk t = lds_blk(F, ia, ib, fp);
-                t.v00 -= Lb.v00 * z00 + Lb.v01 * z10;
-                t.v01 -= Lb.v00 * z01 + Lb.v01 * z11;
-                t.v10 -= Lb.v10 * z00 + Lb.v11 * z10;
-                t.v11 -= Lb.v10 * z01 + Lb.v11 * z11;
-                if (a0 == 0 && bcol == 0 && q + 1 < m) t = factor_diag(t, a.status + b);     // D(q+1) is final: the next pivot
-                lds_put(F, ia, ib, fp, t);
-            } else if (bcol == s) {
-                double2 y = Y[ia];
-                y.x -= Lb.v00 * z00 + Lb.v01 * z10;
-                y.y -= Lb.v10 * z00 + Lb.v11 * z10;
-                Y[ia] = y;
-            }
+        } else if (q + 1 < m) {
+            // lane k: S(k,k) -= Lh(k,q) D(q)^-1 U(q,k) (lanes <= q see zeros); the block of lane q + 1 is then final
+            const Blk z = zcol(Ubuf[cur], lane), Lk = lds_get(Lbuf[cur], lane);
+            blk_sub(mydiag, Lk, z);
+            auto bc = [&](double v) {
+                const int lo = __builtin_amdgcn_readlane(__double2loint(v), q + 1), hi = __builtin_amdgcn_readlane(__double2hiint(v), q + 1);
+                return __hiloint2double(hi, lo);
+            };
+            const Blk dn = factor_diag(Blk{bc(mydiag.v00), bc(mydiag.v01), bc(mydiag.v10), bc(mydiag.v11)}, bad);
+            if (lane == q + 1) { mydiag = dn; lds_set(Dbuf[nxt], 0, dn); }
         }
         __syncthreads();
     }
+    if (prof) pt[3] = wall_clock64();
     // ---- store
-    for (int i = tid; i < nload; i += NT) {
-        const int2 d = ll[i];
-        const Blk v = lds_blk(F, d.y >> 8, d.y & 255, fp);
-        store_blk(a.X, (size_t)(d.x & 0x0fffffff), b, ld, v.v00, v.v01, v.v10, v.v11);
-    }
-    for (int q = tid; q < m; q += NT) { const double2 y = Y[q]; store_vec(a.W, (size_t)(k0 + q), b, ld, y.x, y.y); }
-    if (e > 0) {
-        double* out = stk + h[4];
-        for (int ca = wave; ca < e; ca += NW)
-            if (lane < e) {
-                const Blk v = lds_blk(F, m + ca, m + lane, fp);
-                double2* p = (double2*)(out + ((size_t)ca * e + lane) * 4);
-                p[0] = double2{v.v00, v.v01}; p[1] = double2{v.v10, v.v11};
+    if (!pivot_wave) {
+        double* out = e > 0 ? stk + h[4] : nullptr;
+#pragma unroll
+        for (int r = 0; r < CLS; ++r)
+#pragma unroll
+            for (int c = 0; c < CLS; ++c) {
+                const int i = r * 16 + gi, j = c * 16 + gj;
+                const int cd = code[r][c];
+                const Blk& v = T[r][c];
+                if (cd == -2) store_vec(a.W, (size_t)(k0 + i), b, ld, v.v00, v.v10);
+                else if (cd >= 0 && !((cd >> 28) & 4)) store_blk(a.X, (size_t)(cd & 0x0fffffff), b, ld, v.v00, v.v01, v.v10, v.v11);
+                else if (i >= m && i < f && j >= m && j < fprime) {                              // update matrix | vector: scenario-major stack
+                    double2* p = (double2*)(out + ((size_t)(i - m) * (e + 1) + (j - m)) * 4);
+                    p[0] = double2{v.v00, v.v01}; p[1] = double2{v.v10, v.v11};
+                }
             }
-        if (tid < e) ((double2*)(out + (size_t)e * e * 4))[tid] = Y[m + tid];
+        if (tid == 0 && bad) atomicOr(a.status + b, 4);
+    } else {
+        if (lane < m) store_blk(a.X, (size_t)td[h[8] + lane], b, ld, mydiag.v00, mydiag.v01, mydiag.v10, mydiag.v11);
+        if (bad && lane == 0) atomicOr(a.status + b, 4);
     }
+    if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pt[4] = wall_clock64(); }
 }
 
 // per-level launch table: segment ranges and chunk totals
@@ -684,13 +763,13 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, int policy
     JG_HIP(hipFuncSetAttribute((const void*)k_bwd_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CHAIN_LDS_D2 * sizeof(double2))));
     if (!S.top_launch.empty()) {
         if (upload(&top_task, S.top_task, error, st) || upload(&top_data, S.top_data, error, st)) return 2;
-        int lds1 = 0, lds4 = 0;
-        for (const TopLaunch& L : S.top_launch) (L.waves == 1 ? lds1 : lds4) = std::max(L.waves == 1 ? lds1 : lds4, L.lds_bytes);
-        if (lds1) JG_HIP(hipFuncSetAttribute((const void*)k_fact_top<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
-        if (lds4) JG_HIP(hipFuncSetAttribute((const void*)k_fact_top<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4));
         const size_t sb = (size_t)std::max<long long>(S.top_stack, 2) * ld * sizeof(double);
         JG_HIP(hipMalloc((void**)&top_stack, sb));
         JG_HIP(sync_fill(top_stack, 0, sb, st));
+        if (getenv("JG_TOP_PROFILE")) {
+            JG_HIP(hipMalloc((void**)&top_prof, S.top_task.size() * 8 * sizeof(long long)));
+            JG_HIP(sync_fill(top_prof, 0, S.top_task.size() * 8 * sizeof(long long), st));
+        }
     }
     JG_HIP(hipMalloc((void**)&X, factor_bytes()));
     JG_HIP(sync_fill(X, 0, factor_bytes(), st));
@@ -703,6 +782,21 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, int policy
 }
 
 void Engine::destroy() {
+    if (top_prof) {                                              // phase times of every task (scenario 0, last factorisation)
+        std::vector<long long> t(S.top_task.size() * 8);
+        if (hipMemcpy(t.data(), top_prof, t.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess) {
+            fprintf(stderr, "[jg top profile] task level class m e | load children steps store total (us) | us per step\n");
+            for (size_t i = 0; i < S.top_task.size(); ++i) {
+                const long long* p = &t[i * 8];
+                if (!p[0]) continue;
+                const Rec& h = S.top_task[i];
+                fprintf(stderr, "[jg top profile] %3zu %2d %d %2d %2d | %6.2f %6.2f %6.2f %6.2f %7.2f | %5.3f", i, h.w[10], h.w[9], h.w[0], h.w[1],
+                        (p[1] - p[0]) * 0.01, (p[2] - p[1]) * 0.01, (p[3] - p[2]) * 0.01, (p[4] - p[3]) * 0.01, (p[4] - p[0]) * 0.01, (p[3] - p[2]) * 0.01 / h.w[0]);
+                fprintf(stderr, "\n");
+            }
+        }
+        hipFree(top_prof); top_prof = nullptr;
+    }
     hipFree(fact_rec); hipFree(bwd_rec); hipFree(fact_seg); hipFree(bwd_seg); hipFree(bwd_chain);
     hipFree(fwd_rec); hipFree(fwd_seg); fwd_rec = nullptr; fwd_seg = nullptr;
     hipFree(sel_rec); hipFree(sel_seg); hipFree(Zs); sel_rec = nullptr; sel_seg = nullptr; Zs = nullptr;
@@ -724,13 +818,14 @@ int Engine::factor(hipStream_t st, const double* A, const double* rhs, const Gro
     }
     // the top of the elimination tree: multifrontal tasks, one workgroup per (task, scenario), launch = (task level, class)
     if (!S.top_launch.empty()) {
-        TopArgs t{top_task, top_data, X, W, top_stack, status, sel, std::max<long long>(S.top_stack, 2), ld, a.lanes, 0, 0, 64};
+        TopArgs t{top_task, top_data, X, W, top_stack, status, sel, std::max<long long>(S.top_stack, 2), top_prof, ld, a.lanes, 0, 0, 64};
         if (ld == 64 && t.lanes < 64) t.lpg = t.lanes;
         for (const TopLaunch& L : S.top_launch) {
             t.task_begin = L.task_begin; t.ntasks = L.ntasks;
             const dim3 grid((unsigned)L.ntasks * t.lpg * gs);
-            if (L.waves == 1) hipLaunchKernelGGL(k_fact_top<1>, grid, dim3(64), (size_t)L.lds_bytes, st, t);
-            else hipLaunchKernelGGL(k_fact_top<4>, grid, dim3(256), (size_t)L.lds_bytes, st, t);
+            if (L.cls == 2) hipLaunchKernelGGL(k_fact_top<2>, grid, dim3(TOP_THREADS), 0, st, t);
+            else if (L.cls == 3) hipLaunchKernelGGL(k_fact_top<3>, grid, dim3(TOP_THREADS), 0, st, t);
+            else hipLaunchKernelGGL(k_fact_top<4>, grid, dim3(TOP_THREADS), 0, st, t);
         }
     }
     JG_HIP(hipGetLastError());

@@ -132,6 +132,7 @@ struct Engine {
     std::vector<DevLaunch> fact, bwd, fwd, selv;
     Rec* top_task = nullptr; int* top_data = nullptr;          // multifrontal top (jg_symbolic.hpp): task headers, task data
     double* top_stack = nullptr;                               // update matrices of the tasks, scenario-major [ld][S.top_stack]
+    long long* top_prof = nullptr;                             // JG_TOP_PROFILE: per-task phase stamps (printed by destroy)
     int device = 0;
     std::string error;
 

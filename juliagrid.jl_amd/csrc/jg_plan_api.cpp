@@ -30,7 +30,7 @@ void jg_plan_destroy(jg_plan* p) { delete p; }
 //        60 fact segments (x8), 61 fact wave records (x16), 62 bwd segments, 63 bwd records, 64 src_entry (device replay tables)
 //        18 bwd_level (row-wise), 19 chain_level (level of the backward chain / row a pivot belongs to), 65 backward chain task data, 66 / 67 forward-only segments / records,
 //        68 / 69 selected-inverse segments / records
-//        70 top-task headers (x16), 71 top-task data, 72 top launches (x5: task_begin, ntasks, waves, lds_bytes, level),
+//        70 top-task headers (x16), 71 top-task data, 72 top launches (x4: task_begin, ntasks, class, level),
 //        73 task of each pivot (-1: bottom), 74 {top_level, stack doubles per scenario (low 31 bits), top terms (low 31 bits)}
 // out == NULL returns the length.
 int64_t jg_plan_export(jg_plan* p, int which, int32_t* out, int64_t cap) {
@@ -60,7 +60,7 @@ int64_t jg_plan_export(jg_plan* p, int which, int32_t* out, int64_t cap) {
         case 69: tmp.assign((const int*)S.sel_rec.data(), (const int*)S.sel_rec.data() + S.sel_rec.size() * 16); v = &tmp; break;
         case 70: tmp.assign((const int*)S.top_task.data(), (const int*)S.top_task.data() + S.top_task.size() * 16); v = &tmp; break;
         case 71: v = &S.top_data; break;
-        case 72: tmp.assign((const int*)S.top_launch.data(), (const int*)S.top_launch.data() + S.top_launch.size() * 5); v = &tmp; break;
+        case 72: tmp.assign((const int*)S.top_launch.data(), (const int*)S.top_launch.data() + S.top_launch.size() * 4); v = &tmp; break;
         case 73: v = &S.top_task_of; break;
         case 74: tmp = {S.top_level, (int)(S.top_stack & 0x7fffffff), (int)(S.top_terms & 0x7fffffff)}; v = &tmp; break;
         default: return -1;

@@ -203,7 +203,7 @@ void build_top(BlockSymbolic& S, int top_level, int soft_cap) {
     int ntop = 0;
     for (int k = 0; k < n; ++k) if (S.e_level[S.diag[k]] >= top_level) { top[k] = 1; ++ntop; if (ssize(k) + 1 > TOP_FRONT_MAX) return; }
     if (ntop == 0) return;
-    struct Task { int k0, m, e, parent, level, waves, stack; std::vector<int> kids; };
+    struct Task { int k0, m, e, parent, level, cls, stack; std::vector<int> kids; };
     std::vector<Task> tasks;
     for (int k = n - 1; k >= 0; --k) {
         if (!top[k] || S.top_task_of[k] >= 0) continue;
@@ -224,27 +224,27 @@ void build_top(BlockSymbolic& S, int top_level, int soft_cap) {
     }
     long long stack = 0;
     for (Task& t : tasks) {
-        const int f = t.m + t.e;
-        t.waves = f <= 12 ? 1 : 4;
-        if (t.e > 0) { t.stack = (int)stack; stack += (long long)t.e * t.e * 4 + (long long)t.e * 2; }
+        const int fprime = t.m + t.e + 1;                        // front rows / columns + the rhs column
+        t.cls = fprime <= 32 ? 2 : (fprime <= 48 ? 3 : 4);       // blocks per thread and dimension on the 16 x 16 thread grid
+        if (t.e > 0) { t.stack = (int)stack; stack += (long long)t.e * (t.e + 1) * 4; }       // e x (e + 1) blocks: update matrix | update vector
         for (int q = 0; q < t.m; ++q) { const long long s = ssize(t.k0 + q); S.top_terms += s * (s + 1); }
     }
     if (stack >= (1LL << 31)) { S.top_task_of.assign(n, -1); return; }
     S.top_stack = stack;
     S.top_level = top_level;
-    // launch order: level-major, then by class (waves)
+    // launch order: level-major; ONE launch per level, compiled for the widest front of the level (a dependent launch costs more
+    // than the registers a narrow front leaves unused in a wide kernel: the top levels hold a handful of tasks)
     std::vector<int> order(nt);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
         if (tasks[a].level != tasks[b].level) return tasks[a].level < tasks[b].level;
-        if (tasks[a].waves != tasks[b].waves) return tasks[a].waves < tasks[b].waves;
         return tasks[a].k0 < tasks[b].k0;
     });
     const bool sym = S.symmetric != 0;
     S.top_task.resize(nt);
     for (int oi = 0; oi < nt; ++oi) {
         const Task& t = tasks[order[oi]];
-        const int m = t.m, e = t.e, k1 = t.k0 + m - 1;
+        const int m = t.m, e = t.e, f = m + e, fprime = f + 1;
         auto local = [&](const Task& tt, int pivot) {           // front index of a pivot in task tt, -1 if outside
             if (pivot >= tt.k0 && pivot < tt.k0 + tt.m) return pivot - tt.k0;
             const int kl = tt.k0 + tt.m - 1;
@@ -255,61 +255,57 @@ void build_top(BlockSymbolic& S, int top_level, int soft_cap) {
         };
         Rec h{};
         const int base = (int)S.top_data.size();
-        // step table + struct lists (bytes)
-        std::vector<int> tab(3 * m);
-        std::vector<unsigned char> lists;
-        for (int q = 0; q < m; ++q) {
-            const int k = t.k0 + q, s = ssize(k);
-            int lg = 0;
-            while ((1 << lg) < s + 1) ++lg;
-            tab[3 * q] = s; tab[3 * q + 1] = (int)lists.size(); tab[3 * q + 2] = lg;
-            for (int p = S.u_ptr[k]; p < S.u_ptr[k + 1]; ++p) lists.push_back((unsigned char)local(t, S.u_col[p]));
-        }
-        while (lists.size() % 4) lists.push_back(0);
-        S.top_data.insert(S.top_data.end(), tab.begin(), tab.end());
-        for (size_t i = 0; i < lists.size(); i += 4) S.top_data.push_back((int)(lists[i] | lists[i + 1] << 8 | lists[i + 2] << 16 | (unsigned)lists[i + 3] << 24));
-        const int nlist = (int)S.top_data.size() - base;
-        if (S.top_data.size() & 1) S.top_data.push_back(0);      // the load list is read as int2
-        const int load_off = (int)S.top_data.size() - base;
-        int nload = 0;
-        auto bottom_terms = [&](int en) {                        // does the entry have a level item (jg build_tables)?
+        // entry map of the front, [f][f + 1]: what thread-slot (r, c) loads before and stores after the elimination
+        //   -1 nothing (outside the pattern, or the update matrix / vector: starts from zero, leaves through the stack)
+        //   -2 rhs row of pivot r (column f): loaded from and stored to the rhs storage
+        //   entry | flags << 28: flag 1 starts from zero (fill-in that no bottom pivot touches), 2 read transposed (symmetric plans
+        //   keep the upper triangle only: slot (r, c), r > c, reads entry (c, r)), 4 not stored by the slot's thread (the
+        //   transposed copies; the diagonal blocks of the chain, which leave through the pivot wave in factorised form)
+        auto bottom_terms = [&](int en) {                        // does the entry have a level item (build_tables)?
             for (int x = S.t_ptr[en]; x < S.t_ptr[en + 1]; ++x) if (S.top_task_of[S.e_col[S.t_a[x]]] < 0) return true;
             return false;
         };
-        auto add_entry = [&](int en, int r, int c) {
-            int flags = 0;
-            if (!bottom_terms(en) && (S.e_src[en] < 0)) flags |= 1;                 // nothing was ever written there: starts from zero
-            if (sym && r != c) flags |= 2;
-            S.top_data.push_back(en | flags << 28); S.top_data.push_back(r << 8 | c);
-            ++nload;
+        std::vector<int> emap((size_t)f * fprime, -1);
+        auto put = [&](int en, int r, int c) {
+            int flags = (!bottom_terms(en) && S.e_src[en] < 0) ? 1 : 0;
+            if (r == c) flags |= 4;
+            emap[(size_t)r * fprime + c] = en | flags << 28;
+            if (sym && r != c) emap[(size_t)c * fprime + r] = en | (flags | 2 | 4) << 28;
         };
+        std::vector<int> dent(m);
         for (int q = 0; q < m; ++q) {
             const int k = t.k0 + q;
-            add_entry(S.diag[k], q, q);
+            dent[q] = S.diag[k];
+            put(S.diag[k], q, q);
+            emap[(size_t)q * fprime + f] = -2;
             for (int p = S.u_ptr[k]; p < S.u_ptr[k + 1]; ++p) {
                 const int j = S.u_col[p], lj = local(t, j);
-                add_entry(S.u_ent[p], q, lj);
-                if (!sym) add_entry(find_in_row(S, j, k), lj, q);
+                put(S.u_ent[p], q, lj);
+                if (!sym) put(find_in_row(S, j, k), lj, q);
             }
         }
+        S.top_data.insert(S.top_data.end(), emap.begin(), emap.end());
+        const int dent_off = (int)S.top_data.size() - base;
+        S.top_data.insert(S.top_data.end(), dent.begin(), dent.end());
+        // child records {stack offset, e_c, inv[f + 1]}: inv[x] = row / column of front index x in the child's update matrix,
+        // -1 if the child does not reach it; inv[f] = e_c (the child's update vector is column e_c of its stack block)
         const int child_off = (int)S.top_data.size() - base;
         for (int c : t.kids) {
             const Task& ct = tasks[c];
             const int kl = ct.k0 + ct.m - 1;
             S.top_data.push_back(ct.stack); S.top_data.push_back(ct.e);
-            for (int p = S.u_ptr[kl]; p < S.u_ptr[kl + 1]; ++p) S.top_data.push_back(local(t, S.u_col[p]));
+            std::vector<int> inv(fprime, -1);
+            int idx = 0;
+            for (int p = S.u_ptr[kl]; p < S.u_ptr[kl + 1]; ++p) inv[local(t, S.u_col[p])] = idx++;
+            inv[f] = ct.e;
+            S.top_data.insert(S.top_data.end(), inv.begin(), inv.end());
         }
-        (void)k1;
-        h.w[0] = m; h.w[1] = e; h.w[2] = t.k0; h.w[3] = base; h.w[4] = t.stack; h.w[5] = nload; h.w[6] = (int)t.kids.size();
-        h.w[7] = (m + e) | 1; h.w[8] = nlist; h.w[9] = load_off; h.w[10] = child_off; h.w[11] = t.level; h.w[12] = t.waves;
+        h.w[0] = m; h.w[1] = e; h.w[2] = t.k0; h.w[3] = base; h.w[4] = t.stack; h.w[5] = (int)t.kids.size();
+        h.w[6] = 0; h.w[7] = child_off; h.w[8] = dent_off; h.w[9] = t.cls; h.w[10] = t.level; h.w[11] = fprime;
         S.top_task[oi] = h;
-        if (S.top_launch.empty() || S.top_launch.back().level != t.level || S.top_launch.back().waves != t.waves)
-            S.top_launch.push_back(TopLaunch{oi, 0, t.waves, 0, t.level});
-        TopLaunch& L = S.top_launch.back();
-        L.ntasks++;
-        const int f = m + e, fp = f | 1;
-        const int lds = f * fp * 32 + f * 16 + nlist * 4 + 64;
-        L.lds_bytes = std::max(L.lds_bytes, lds);
+        if (S.top_launch.empty() || S.top_launch.back().level != t.level) S.top_launch.push_back(TopLaunch{oi, 0, t.cls, t.level});
+        S.top_launch.back().ntasks++;
+        S.top_launch.back().cls = std::max(S.top_launch.back().cls, t.cls);
     }
     // top_task_of must name the header position
     std::vector<int> pos(nt);
@@ -515,7 +511,7 @@ void build_selected_inverse(BlockSymbolic& S) {
 int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic& S) {
     S = BlockSymbolic();
     S.inplace = policy & 1;
-    constexpr int TOP_LEVEL_DEFAULT = 12, TOP_FRONT_SOFT = 32;
+    constexpr int TOP_LEVEL_MIN = 6, TOP_NARROW = 384, TOP_FRONT_SOFT = 24;
     S.symmetric = (policy >> 1) & 1;
     S.n = n;
     if (n <= 0) return 1;
@@ -666,7 +662,23 @@ int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic&
         int top_level = (policy >> 8) & 0xff, soft = (policy >> 16) & 0xff;
         if (const char* e = getenv("JG_TOP_LEVEL")) top_level = atoi(e);
         if (const char* e = getenv("JG_TOP_FRONT")) soft = atoi(e);
-        if (top_level == 0) top_level = TOP_LEVEL_DEFAULT;
+        if (top_level == 0) {
+            // default: the multifrontal top starts where the level schedule gets narrow -- the first dependency level from which
+            // no level holds more than TOP_NARROW items (entries + rhs rows), but not below level TOP_LEVEL_MIN.  Measured on
+            // ACTIVSg10k (84 levels): top from level 27-30 is the optimum at 64 AND at 512 scenarios (from level 12: +5 % at 64,
+            // +35 % at 512 -- a task needs a workgroup per scenario, the level kernel only a wave per 64).
+            int narrow = TOP_NARROW;
+            if (const char* e = getenv("JG_TOP_ITEMS")) narrow = atoi(e);
+            int nlev = 0;
+            for (int e = 0; e < S.n_entries; ++e) nlev = std::max(nlev, S.e_level[e]);
+            for (int r = 0; r < n; ++r) nlev = std::max(nlev, S.y_level[r]);
+            std::vector<int> cnt(nlev + 2, 0);
+            for (int e = 0; e < S.n_entries; ++e) if (!(S.symmetric && S.e_row[e] > S.e_col[e])) cnt[S.e_level[e]]++;
+            for (int r = 0; r < n; ++r) cnt[S.y_level[r]]++;
+            top_level = nlev + 1;
+            while (top_level > TOP_LEVEL_MIN && cnt[top_level - 1] <= narrow) --top_level;
+            if (top_level > nlev - 2) top_level = 255;           // nothing worth a task
+        }
         if (soft <= 0) soft = TOP_FRONT_SOFT;
         build_top(S, top_level, std::min(soft, TOP_FRONT_MAX));
     }

@@ -51,24 +51,22 @@ struct Rec { int w[16]; };
 // Above a dependency level the tree is a handful of long chains with few items per level: per-level launches there cost a
 // kernel boundary + a cold record fetch + a round of operand loads each (7.7 us at 64 scenarios, 9-20 us at 512) for a
 // handful of blocks.  Those pivots are factorised by TOP TASKS instead: a task = consecutive pivots k0 .. k0+m-1 that
-// form a path of the tree (parent(k) = k + 1), worked on by ONE workgroup PER SCENARIO with the dense front
-// (m pivots + e external rows/columns, e = |struct(last pivot)|) in LDS -- lanes run across the front, a pivot step is an
-// LDS round trip + one workgroup barrier (~0.15 us) instead of a launch.  Tasks talk multifrontally: a task leaves its
-// e x e update matrix (+ update vector of the fused forward elimination) on a scenario-major stack, its parent task adds
-// it into its own front (extend-add), so the 3-block-reads-per-term pull of the level kernel disappears for every term
-// whose pivot is in a task (half to three quarters of all terms on transmission grids).
+// form a path of the tree (parent(k) = k + 1), worked on by ONE workgroup PER SCENARIO -- lanes run across the dense front
+// (m pivots + e external rows / columns, e = |struct(last pivot)|, + the rhs as one more column), which lives in the
+// REGISTERS of a 16 x 16 thread grid (thread (i mod 16, c mod 16) owns block (i, c): `cls` x `cls` blocks per thread); a
+// pivot step publishes the next pivot row / column through LDS and costs one workgroup barrier (jg_engine.hip: k_fact_top).
+// Tasks talk multifrontally: a task leaves its e x (e + 1) update matrix | vector on a scenario-major stack, its parent adds
+// it into its own front (extend-add), so the 3-block-reads-per-term pull of the level kernel disappears for every term whose
+// pivot is in a task (half to three quarters of all terms on transmission grids).
 // Contributions of BOTTOM pivots (all others) to task-owned entries still arrive through level items: those items carry
 // only the bottom terms of the entry and store the partial sum raw (also for diagonal blocks).
-//   header (one 64-byte record per task, level-major / class-major order):
-//     w0 m, w1 e, w2 k0, w3 offset of the task's data in top_data, w4 stack offset of its update matrix (doubles, -1: root),
-//     w5 owned entries (load / store list), w6 children, w7 front pitch in blocks (odd), w8 ints of the step table + lists,
-//     w9 offset of the load list, w10 offset of the child records (both relative to w3)
-//   data: step table m x {s, byte offset of the list, log2 of the column width}; struct lists as bytes (local front indices,
-//     ascending; the first one is the next pivot of the chain); load list n x {entry | flags << 28, row << 8 | col}
-//     (flag 1: starts from zero -- fill-in without bottom terms; flag 2: also mirrored into (col,row) transposed -- symmetric
-//     plans store the upper triangle only); child records {stack offset, e_c, map[e_c] child external -> local index}
-constexpr int TOP_FRONT_MAX = 64;       // m + e of a task (LDS: 65 * 64 * 32 B = 130 KiB); also bounds the column width of a step
-struct TopLaunch { int task_begin, ntasks, waves, lds_bytes, level; };
+//   header (one 64-byte record per task; level-major; a launch = one level, compiled for its widest front):
+//     w0 m, w1 e, w2 k0, w3 offset of the task's data in top_data, w4 stack offset of its update block (doubles, -1: root),
+//     w5 children, w7 offset of the child records, w8 offset of the diagonal entries (both relative to w3), w9 class
+//     (2, 3, 4: the front has at most 16 class rows and columns), w10 task level, w11 f + 1
+//   data: entry map [f][f + 1] (see build_top), diagonal entries [m], child records {stack offset, e_c, inv[f + 1]}
+constexpr int TOP_FRONT_MAX = 63;       // m + e of a task: 64 columns with the rhs = class 4 on the 16 x 16 thread grid
+struct TopLaunch { int task_begin, ntasks, cls, level; };
 
 struct BlockSymbolic {
     int n = 0;

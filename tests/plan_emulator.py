@@ -157,9 +157,10 @@ class Replay:
         return self.task_of.size > 0 and self.task_of[min(self.e_row[e], self.e_col[e])] >= 0
 
     def _top_tasks(self, X, Y, level_of, partial, part_level, bottom_levels):
-        """Replays the multifrontal top (jg_symbolic.hpp, k_fact_top): per launch, per task: load the owned entries into a dense
-        front, extend-add the children's update matrices, eliminate the chain's pivots (struct lists), store.  Asserts that
-        everything a task reads exists before its launch.  Returns the update terms executed."""
+        """Replays the multifrontal top (jg_symbolic.hpp, k_fact_top): per launch, per task: the entry map fills the dense
+        front (+ rhs column), the children's update blocks are pulled from the stack through their inverse maps, the chain's
+        pivots are eliminated densely (blocks outside the pattern are zero and stay zero), owned entries go back, the update
+        block goes to the stack.  Asserts that everything a task reads exists before its launch.  Returns the update terms."""
         hdr, data, launches = self.thdr, self.tdata, self.tlaunch
         nE = self.nE
         if hdr.shape[0] == 0:
@@ -170,93 +171,112 @@ class Replay:
         seen_tasks = 0
         terms = 0
         done_pivot = np.zeros(self.n, dtype=bool)
-        prev = (0, 0)
-        for li, (tb, ntk, waves, lds, tlevel) in enumerate(launches):
-            assert (tlevel, waves) > prev and tb == seen_tasks, "launches out of order"
-            prev = (tlevel, waves)
+        prev = 0
+        u_col = self.p.get("u_col")
+        for li, (tb, ntk, cls, tlevel) in enumerate(launches):
+            assert tlevel > prev and tb == seen_tasks and cls in (2, 3, 4), "launches out of order"
+            prev = tlevel
             lev = bottom_levels + tlevel
             results = []
             for ti in range(tb, tb + ntk):
-                m, e, k0, base, soff, nload, nchild, fp, nlist, load_off, child_off, tl, tw = (int(v) for v in hdr[ti][:13])
+                m, e, k0, base, soff, nchild, _, child_off, dent_off, tcls, tl, fprime = (int(v) for v in hdr[ti][:12])
                 f = m + e
-                assert tl == tlevel and tw == waves and fp == (f | 1) and 1 <= m and f <= 64
-                assert f * fp * 32 + f * 16 + nlist * 4 + 64 <= lds <= 160 * 1024
+                assert tl == tlevel and tcls <= cls and fprime == f + 1 <= 16 * tcls and (tcls == 2 or fprime > 16 * (tcls - 1)) and m >= 1
                 assert np.all(self.task_of[k0:k0 + m] == ti)
-                F = np.full((f, f, 2, 2), np.nan)
-                Fy = np.full((f, 2), np.nan)
-                F[m:, m:] = 0.0
-                Fy[m:] = 0.0
-                ll = data[base + load_off: base + load_off + 2 * nload].reshape(nload, 2)
-                owned = []
-                for w0, w1 in ll:
-                    ent, fl, r, c = int(w0) & 0x0fffffff, int(w0) >> 28, int(w1) >> 8, int(w1) & 255
-                    assert min(r, c) < m and (self.e_row[ent], self.e_col[ent]) == (self._piv(k0, m, e, r), self._piv(k0, m, e, c))
-                    assert level_of[ent] < 0, "a task-owned entry was finished by somebody else"
-                    if fl & 1:
-                        assert not partial[ent] and self.e_src[ent] < 0
-                        v = np.zeros((2, 2))
-                    else:
-                        assert partial[ent] or (self.inplace and self.e_src[ent] >= 0), "task loads an entry nobody wrote"
-                        v = X[ent].copy()
-                    F[r, c] = v
-                    if fl & 2:
-                        assert self.symmetric and r < c
-                        F[c, r] = v.T
-                    owned.append((ent, r, c))
+                ext = self._front_ext(k0, m)
+                assert ext.size == e
+                piv = np.concatenate([np.arange(k0, k0 + m), ext])
+                F = np.zeros((f, fprime, 2, 2))
+                emap = data[base: base + f * fprime].reshape(f, fprime)
+                owned, seen = [], set()
+                for r in range(f):
+                    for c in range(fprime):
+                        cd = int(emap[r, c])
+                        if cd == -1:
+                            assert (r >= m and (c >= m)) or (c < f and min(r, c) < m), "only the update block and pattern holes are unmapped"
+                            continue
+                        if cd == -2:
+                            assert c == f and r < m and partial[nE + k0 + r]
+                            F[r, c, :, 0] = Y[k0 + r]
+                            continue
+                        ent, fl = cd & 0x0fffffff, cd >> 28
+                        assert min(r, c) < m and c < f
+                        rr, cc = (c, r) if fl & 2 else (r, c)
+                        assert (self.e_row[ent], self.e_col[ent]) == (piv[rr], piv[cc])
+                        assert bool(fl & 2) == (self.symmetric and r > c) and (not (fl & 2) or fl & 4)
+                        assert bool(fl & 4) == (r == c or bool(fl & 2))
+                        assert level_of[ent] < 0, "a task-owned entry was finished by somebody else"
+                        if fl & 1:
+                            assert not partial[ent] and self.e_src[ent] < 0
+                            v = np.zeros((2, 2))
+                        else:
+                            assert partial[ent] or (self.inplace and self.e_src[ent] >= 0), "task loads an entry nobody wrote"
+                            v = X[ent].copy()
+                        F[r, c] = v.T if fl & 2 else v
+                        if not (fl & 2):
+                            assert ent not in seen
+                            seen.add(ent)
+                            if not (fl & 4):
+                                owned.append((ent, r, c))
+                # every pattern entry of the chain's rows / columns is mapped
                 for q in range(m):
-                    assert partial[nE + k0 + q]
-                    Fy[q] = Y[k0 + q]
+                    k = k0 + q
+                    assert self.diag[k] in seen
+                    want = set(int(x) for x in self.p.get("u_ent")[self.u_ptr[k]: self.u_ptr[k + 1]])
+                    assert want <= seen
+                dent = data[base + dent_off: base + dent_off + m]
+                assert np.array_equal(dent, self.diag[k0:k0 + m])
                 cd = base + child_off
                 for _ in range(nchild):
                     coff, ce = int(data[cd]), int(data[cd + 1])
-                    cmap = data[cd + 2: cd + 2 + ce]
-                    assert stack_level[coff] < (tlevel, 0), "child task in the same or a later launch level"
-                    C = stack[coff: coff + ce * ce * 4].reshape(ce, ce, 2, 2)
-                    Cv = stack[coff + ce * ce * 4: coff + ce * ce * 4 + ce * 2].reshape(ce, 2)
-                    assert len(set(cmap.tolist())) == ce and cmap.min() >= 0 and cmap.max() < f
-                    F[np.ix_(cmap, cmap)] += C
-                    Fy[cmap] += Cv
-                    cd += 2 + ce
-                tab = data[base: base + 3 * m].reshape(m, 3)
-                lists = data[base + 3 * m: base + nlist].view(np.uint8)
-                F[0, 0] = dfactor(F[0, 0])
+                    inv = data[cd + 2: cd + 2 + fprime]
+                    assert stack_level[coff] < tlevel, "child task in the same or a later launch level"
+                    C = stack[coff: coff + ce * (ce + 1) * 4].reshape(ce, ce + 1, 2, 2)
+                    assert inv[f] == ce and sorted(inv[:f][inv[:f] >= 0].tolist()) == list(range(ce))
+                    for r in np.flatnonzero(inv[:f] >= 0):
+                        for c in np.flatnonzero(inv >= 0):
+                            F[r, c] += C[inv[r], inv[c]]
+                    cd += 2 + fprime
+                D = [None] * m
+                D[0] = dfactor(F[0, 0])
                 for q in range(m):
-                    s, lo, lg = (int(v) for v in tab[q])
-                    lst = lists[lo: lo + s].astype(int)
-                    assert (1 << lg) >= s + 1 and (lg == 0 or (1 << (lg - 1)) < s + 1) and s + 1 <= 64
                     k = k0 + q
-                    want = [self._loc(k0, m, e, int(c)) for c in self.p.get("u_col")[self.u_ptr[k]: self.u_ptr[k + 1]]]
-                    assert lst.tolist() == want and (q + 1 == m or (s > 0 and lst[0] == q + 1))
-                    D = F[q, q]
-                    yq = dsolve(D, Fy[q])
-                    for b in lst:
-                        Z = np.stack([dsolve(D, F[q, b][:, 0]), dsolve(D, F[q, b][:, 1])], axis=1)
-                        for a in lst:
-                            F[a, b] = F[a, b] - F[a, q] @ Z
-                            terms += 1
-                    for a in lst:
-                        Fy[a] = Fy[a] - F[a, q] @ yq
-                        terms += 1
+                    s = int(self.u_ptr[k + 1] - self.u_ptr[k])
+                    loc = [self._loc(k0, m, e, int(c)) for c in u_col[self.u_ptr[k]: self.u_ptr[k + 1]]]
+                    assert q + 1 == m or (s > 0 and loc[0] == q + 1)
+                    Z = np.zeros((fprime, 2, 2))
+                    for c in range(q + 1, fprime):
+                        Z[c] = np.stack([dsolve(D[q], F[q, c][:, 0]), dsolve(D[q], F[q, c][:, 1])], axis=1)
+                    # blocks outside struct(q) are exactly zero: the dense update touches only struct(q) x (struct(q) + rhs)
+                    nzr = [i for i in range(q + 1, f) if np.any(F[i, q] != 0)]
+                    nzc = [c for c in range(q + 1, f) if np.any(F[q, c] != 0)]
+                    assert set(nzr) <= set(loc) and set(nzc) <= set(loc)
+                    for i in range(q + 1, f):
+                        for c in range(q + 1, fprime):
+                            F[i, c] = F[i, c] - F[i, q] @ Z[c]
+                    terms += s * (s + 1)
                     if q + 1 < m:
-                        F[q + 1, q + 1] = dfactor(F[q + 1, q + 1])
-                assert not np.isnan(F[m:, m:]).any() and not np.isnan(Fy).any()
-                results.append((ti, owned, F, Fy, k0, m, e, soff))
-            for ti, owned, F, Fy, k0, m, e, soff in results:             # tasks of one launch are independent of each other
+                        D[q + 1] = dfactor(F[q + 1, q + 1])
+                assert not np.isnan(F).any()
+                results.append((ti, owned, F, D, k0, m, e, soff, dent))
+            for ti, owned, F, D, k0, m, e, soff, dent in results:             # tasks of one launch are independent of each other
+                f = m + e
                 for ent, r, c in owned:
-                    assert not np.isnan(F[r, c]).any(), "a task stores an entry of its front that was never written"
                     X[ent] = F[r, c]
                     level_of[ent] = lev
                     partial[ent] = False
                 for q in range(m):
-                    Y[k0 + q] = Fy[q]
+                    X[dent[q]] = D[q]
+                    level_of[dent[q]] = lev
+                    partial[dent[q]] = False
+                    Y[k0 + q] = F[q, f, :, 0]
                     level_of[nE + k0 + q] = lev
                     partial[nE + k0 + q] = False
                     done_pivot[k0 + q] = True
                 if e > 0:
                     assert soff >= 0
-                    stack[soff: soff + e * e * 4] = F[m:, m:].reshape(-1)
-                    stack[soff + e * e * 4: soff + e * e * 4 + e * 2] = Fy[m:].reshape(-1)
-                    stack_level[soff] = (tlevel, 0)
+                    stack[soff: soff + e * (e + 1) * 4] = F[m:, m:].reshape(-1)
+                    stack_level[soff] = tlevel
                 else:
                     assert soff == -1
             seen_tasks += ntk

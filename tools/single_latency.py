@@ -16,5 +16,5 @@ for _ in range(7):
     jg.powerFlow_(an, fetch=False)
     ts.append(time.perf_counter() - t0)
 it = np.atleast_1d(an.method.iteration)
-print(case, "batch", batch, "walker", os.environ.get("JG_WALKER", "0"), "ms/solve %.3f" % (1e3 * np.median(ts)), "iterations", int(it[0]),
+print(case, "batch", batch, "ms/solve %.3f" % (1e3 * np.median(ts)), "iterations", int(it[0]),
       "kernels asm %.4f fact %.4f bwd %.4f" % tuple(an.time_kernel(k, 10) for k in (0, 1, 2)))
