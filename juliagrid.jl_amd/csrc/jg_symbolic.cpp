@@ -160,8 +160,8 @@ void build_replay(const std::vector<int>& level, const std::vector<int>& work, i
         std::vector<int>& it = by[l];
         const size_t seg0 = segs.size();
         std::stable_sort(it.begin(), it.end(), [&](int x, int y) { return work[x] > work[y]; });   // heaviest first
-        const bool wide = it.size() >= 2048;                      // wide levels already fill the chip: do not split lists
-        auto wpi_of = [&](int i) { return std::min(wide ? 2 : max_wpi, pow2ceil(std::max(1, (work[i] + T - 1) / T))); };
+        const bool wide = it.size() >= 2048;                      // wide levels already fill the chip: do not split short lists
+        auto wpi_of = [&](int i) { return std::min(wide && work[i] <= 4 * T ? 2 : max_wpi, pow2ceil(std::max(1, (work[i] + T - 1) / T))); };
         size_t p = 0;
         while (p < it.size()) {
             const int wpi = wpi_of(it[p]);
@@ -667,7 +667,8 @@ int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic&
             // no level holds more than TOP_NARROW items (entries + rhs rows), but not below level TOP_LEVEL_MIN.  Measured on
             // ACTIVSg10k (84 levels): top from level 27-30 is the optimum at 64 AND at 512 scenarios (from level 12: +5 % at 64,
             // +35 % at 512 -- a task needs a workgroup per scenario, the level kernel only a wave per 64).
-            int narrow = TOP_NARROW;
+            int narrow = ((policy >> 24) & 0x7f) * 8;             // the owner knows its batch: a task costs a workgroup per scenario
+            if (narrow == 0) narrow = TOP_NARROW;
             if (const char* e = getenv("JG_TOP_ITEMS")) narrow = atoi(e);
             int nlev = 0;
             for (int e = 0; e < S.n_entries; ++e) nlev = std::max(nlev, S.e_level[e]);

@@ -120,8 +120,9 @@ struct BlockSymbolic {
 // pattern: CSR (rowptr[n+1], col[nnz]) 0-based, must contain the diagonal and be structurally
 // symmetric. policy bit 0: in-place factor storage (see BlockSymbolic::inplace); bit 1: symmetric VALUES (LDL' by
 // reading U(k,i)' for Lh(i,k): half the update terms; only the blocks on and above the diagonal must be assembled).
-// policy bits 8-15: dependency level from which pivots go to top tasks (0 = default, 255 = no top tasks); bits 16-23: soft
-// cap of a task's front (0 = default).
+// policy bits 8-15: dependency level from which pivots go to top tasks (0 = default: where the level schedule gets narrow,
+// 255 = no top tasks); bits 16-23: soft cap of a task's front (0 = default); bits 24-30: what "narrow" means, in units of 8
+// items per level (0 = default).
 // Returns 0, or 1 on a malformed pattern.
 int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic& out);
 // Replay tables of the selected inverse of a SYMMETRIC matrix on the factor pattern (see jg_symbolic.cpp); idempotent.
