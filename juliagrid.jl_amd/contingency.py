@@ -103,6 +103,9 @@ class ContingencyPipeline:
         self.handles = [newtonRaphson(system, batch=self.batch, device=device, max_patch=4) for _ in range(max(1, int(inflight)))]
         if start is not None:
             self.setStart(*start)
+        else:                                            # default restart point of every solve: the start newtonRaphson() built
+            for an in self.handles:
+                an.snapshot_voltage()
 
     def setStart(self, magnitude, angle):
         """Start point of every solve (e.g. the base-case solution), kept in HBM."""

@@ -498,7 +498,7 @@ void launch_compact(jg_nr* h, int restore, bool report = false) {
         };
         add(h->d_vm, h->n, 1); add(h->d_va, h->n, 1); add(h->d_p, h->n, 1); add(h->d_q, h->n, 1);
         if (h->mp > 0) { add(h->d_pdg, h->mp, 1); add(h->d_pdb, h->mp, 1); }
-        if (restore) { add(h->d_F, h->n, 2); add(h->d_inc, h->n, 2); }
+        add(h->d_inc, h->n, 2);                    // a finished scenario keeps ITS last increment (method.increment) wherever its lane goes
         if ((size_t)off * sizeof(double) <= h->eng.factor_bytes()) {      // always, except for grids of a handful of buses
             const dim3 grid((unsigned)std::min(max_rows, 1024), gy.x, (unsigned)na);
             hipLaunchKernelGGL(k_lanes_move, grid, block, 0, h->stream, ls, tmp, h->d_dest, h->d_cflags, h->ld, 0);
@@ -518,7 +518,7 @@ void launch_compact(jg_nr* h, int restore, bool report = false) {
     };
     permute(h->d_vm, h->n); permute(h->d_va, h->n); permute(h->d_p, h->n); permute(h->d_q, h->n);
     if (h->mp > 0) { permute(h->d_pdg, h->mp); permute(h->d_pdb, h->mp); }
-    if (restore) { permute2(h->d_F, h->n); permute2(h->d_inc, h->n); }
+    permute2(h->d_inc, h->n);
 }
 
 int build_graphs(jg_nr* h) {
@@ -872,6 +872,7 @@ int jg_nr_set_ybus(jg_nr* h, const double* y_reim, const double* yt_reim) {
 
 int jg_nr_mismatch(jg_nr* h, double* max_p, double* max_q) {
     if (!h) return fail(1, "jg_nr_mismatch: bad argument");
+    if (h->fast) return fail(1, "jg_nr_mismatch: this handle runs fast Newton-Raphson (its factor storage holds B', B''); use jg_nr_fast_mismatch");
     if (int rc = set_device(h)) return rc;
     launch_assemble(h);
     launch_check(h, 0);
@@ -885,6 +886,7 @@ int jg_nr_mismatch(jg_nr* h, double* max_p, double* max_q) {
 
 int jg_nr_solve(jg_nr* h) {
     if (!h) return fail(1, "jg_nr_solve: bad argument");
+    if (h->fast) return fail(1, "jg_nr_solve: this handle runs fast Newton-Raphson; use jg_nr_fast_solve");
     if (int rc = set_device(h)) return rc;
     if (!h->jac_valid) launch_assemble(h);
     NR_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
@@ -905,6 +907,7 @@ int jg_nr_solve(jg_nr* h) {
 
 int jg_nr_run(jg_nr* h, int64_t max_iter, double tol, int32_t* iters, int32_t* status) {
     if (!h || max_iter < 0 || !(tol > 0.0)) return fail(1, "jg_nr_run: bad argument");
+    if (h->fast) return fail(1, "jg_nr_run: this handle runs fast Newton-Raphson; use jg_nr_fast_run");
     const double t_enter = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
     if (int rc = set_device(h)) return rc;
     if (int rc = build_graphs(h)) return rc;
@@ -951,6 +954,8 @@ int jg_nr_run(jg_nr* h, int64_t max_iter, double tol, int32_t* iters, int32_t* s
     }
     const double t_loop = now_us();
     launch_compact(h, 1);                                                      // lanes back to their home order
+    if (h->ld > 64) launch_assemble(h, jg::GroupSel{}, false);                 // method.mismatch of every scenario at its final state (groups that
+                                                                               // dropped out early held other scenarios' rows after a compaction)
     NR_HIP(hipGetLastError());
     NR_HIP(hipStreamSynchronize(h->stream));
     h->jac_valid = false;
@@ -996,6 +1001,7 @@ int jg_nr_get_increment(jg_nr* h, double* incr) {
 
 int jg_nr_get_jacobian(jg_nr* h, double* nzval) {
     if (!h || !nzval) return fail(1, "jg_nr_get_jacobian: bad argument");
+    if (h->fast) return fail(1, "jg_nr_get_jacobian: this handle runs fast Newton-Raphson: the factor storage holds the factorised B', B'', assembling the full Jacobian there would destroy them");
     if (int rc = set_device(h)) return rc;
     if (!h->jac_valid) { launch_assemble(h); h->jac_valid = true; }      // Jacobian at the current state
     NR_HIP(hipStreamSynchronize(h->stream));
@@ -1238,6 +1244,7 @@ int jg_nr_bus_injection(jg_nr* h, double* inj_pq) {
 
 int jg_nr_time_kernel(jg_nr* h, int kernel, int reps, double* mean_ms) {
     if (!h || reps < 1 || !mean_ms || kernel < 0 || kernel > 3) return fail(1, "jg_nr_time_kernel: bad argument");
+    if (h->fast && kernel < 2) return fail(1, "jg_nr_time_kernel: assembly / factorisation timing would overwrite the constant factor of a fast Newton-Raphson handle");
     if (int rc = set_device(h)) return rc;
     BranchArgs ba{};
     if (kernel == 3) {                                           // power!/current! branch kernel, all seven outputs
@@ -1267,6 +1274,7 @@ int jg_nr_time_kernel(jg_nr* h, int kernel, int reps, double* mean_ms) {
     float ms = 0.f;
     NR_HIP(hipEventElapsedTime(&ms, e0, e1));
     hipEventDestroy(e0); hipEventDestroy(e1);
+    if (kernel == 1) h->jac_valid = false;                       // the factor storage no longer holds the Jacobian
     *mean_ms = (double)ms / reps;
     return 0;
 }

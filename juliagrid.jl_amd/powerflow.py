@@ -127,6 +127,8 @@ class AcPowerFlow:
     @property
     def jacobian(self):
         """analysis.method.jacobian: CSC with the reference's pattern; nzval [nnzJ] (or [batch, nnzJ])."""
+        if getattr(self.method, "fast", False):
+            raise RuntimeError("a fast Newton-Raphson analysis keeps the factorised B', B'' on the device, not the full Jacobian")
         v = np.zeros((self.batch, self.dims["nnzJ"]))
         _lib.check(_lib.lib().jg_nr_get_jacobian(self._h, v))
         return CscMatrix(self.dims["dimJ"], self.method._jcolptr, self.method._jrowval, self._shape(v))

@@ -48,9 +48,11 @@ class PowerSystem:
             shunt=NS(conductance=t["bus_gs"].astype(np.float64), susceptance=t["bus_bs"].astype(np.float64)),
             voltage=NS(magnitude=t["bus_vm"].astype(np.float64), angle=t["bus_va"].astype(np.float64)),
         )
-        # slack = first type-3 bus (load.jl:155-160); none -> bus 1 (load.jl:434-437)
+        # slack: the HDF5 loader stops at the FIRST type-3 bus (load.jl:155-160), the MATPOWER loader keeps the LAST one
+        # (load.jl:429-431); none -> bus 1 (load.jl:434-437)
         s = np.flatnonzero(self.bus.layout.type == 3)
-        self.bus.layout.slack = int(s[0]) + 1 if s.size else 1
+        pick = -1 if t.get("slack_rule") is not None and str(np.asarray(t["slack_rule"]).reshape(-1)[0]) == "last" else 0
+        self.bus.layout.slack = int(s[pick]) + 1 if s.size else 1
         self.branch = NS(
             number=nb,
             layout=NS(from_=t["br_from"].astype(np.int64), to=t["br_to"].astype(np.int64),
@@ -141,6 +143,7 @@ def _matpower_tables(path: str) -> dict:
         gen_bus=np.array([lab[int(r[0])] for r in gen]), gen_status=col(gen, 7).astype(np.int8),
         gen_pg=col(gen, 1) * binv, gen_qg=col(gen, 2) * binv, gen_vg=col(gen, 5),
         gen_qmax=col(gen, 3) * binv, gen_qmin=col(gen, 4) * binv,
+        slack_rule=np.array(["last"]),
     )
 
 

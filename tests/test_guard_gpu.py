@@ -1,0 +1,174 @@
+"""Numeric-failure paths of the batched Newton-Raphson solver (the device keeps a STATIC pivot order; the reference's
+UMFPACK / KLU pivot and raise SingularException, /root/reference/src/backend/utility.jl:470-484, and the reference's loop
+treats non-convergence as a status, acPowerFlow.jl:1414-1423):
+
+  * a bridge outage islands part of the grid: the island's Jacobian is singular, its last pivot block cancels to rounding level
+    (not to an exact zero) -- the scenario must come back with status 3, the other scenarios of the batch untouched;
+  * a NaN in one scenario's state must end in status 3 for that scenario only (k_check);
+  * close to the nose point (load scaled up until the oracle's pivoting LU needs most of its 20 iterations) the static-pivot
+    factorisation must follow the oracle iteration for iteration.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _island_bridges(jg, s, min_size=3):
+    """Bridge branches whose removal cuts off at least `min_size` buses without the slack, largest island first."""
+    n = s.bus.number
+    f, t = s.branch.layout.from_ - 1, s.branch.layout.to - 1
+    on = np.flatnonzero(s.branch.layout.status == 1)
+    out = []
+    for k in np.flatnonzero(jg.bridges(s)):
+        adj = [[] for _ in range(n)]
+        for b in on:
+            if b != k:
+                adj[f[b]].append(t[b])
+                adj[t[b]].append(f[b])
+        seen = np.zeros(n, dtype=bool)
+        stack = [int(s.bus.layout.slack) - 1]
+        seen[stack[0]] = True
+        while stack:
+            v = stack.pop()
+            for u in adj[v]:
+                if not seen[u]:
+                    seen[u] = True
+                    stack.append(int(u))
+        cut = int(n - seen.sum())
+        if cut >= min_size:
+            out.append((cut, int(k) + 1))
+    return [lab for _, lab in sorted(out, reverse=True)]
+
+
+@pytest.mark.parametrize("name", ["case118", "case1354pegase", "case_ACTIVSg10k"])
+def test_bridge_outage_is_reported_not_solved(jg, oracle, name):
+    t = load_case(name)
+    s = jg.powerSystem(t)
+    bad = _island_bridges(jg, s)[:2]
+    if not bad:
+        pytest.skip("grid has no bridge that cuts off three buses")
+    good = [int(x) for x in jg.outageList(s, 3, seed=7)]
+    labels = [bad[0], good[0], 0, good[1]] + bad[1:] + [good[2]]
+    an = jg.contingencyAnalysis(s, labels)
+    jg.powerFlow_(an, iteration=20, tolerance=1e-8)
+    ref = jg.contingencyAnalysis(s, [lab for lab in labels if lab not in bad])
+    jg.powerFlow_(ref, iteration=20, tolerance=1e-8)
+    keep = [i for i, lab in enumerate(labels) if lab not in bad]
+    for i, lab in enumerate(labels):
+        if lab in bad:
+            assert an.status[i] == 3, f"islanding outage of branch {lab} came back with status {an.status[i]}"
+    # the healthy scenarios of the batch do not notice their neighbours: bitwise the batch without them
+    assert np.array_equal(an.status[keep], ref.status) and np.array_equal(an.method.iteration[keep], ref.method.iteration)
+    assert np.array_equal(an.voltage.magnitude[keep], ref.voltage.magnitude) and np.array_equal(an.voltage.angle[keep], ref.voltage.angle)
+    osys = oracle.OracleSystem(t)
+    o = oracle.OracleNR(osys)
+    ptr, dy = jg.outagePatch(s, good[0])
+    for p, d in zip(ptr, dy):
+        o.add_ybus(p - 1, d)
+    st = o.power_flow(iteration=20, tolerance=1e-8)
+    assert an.status[1] == st
+    if st == 0:
+        vm, va = o.voltage()
+        assert an.method.iteration[1] == o.iteration
+        assert np.abs(an.voltage.magnitude[1] - vm).max() <= 1e-8 and np.abs(an.voltage.angle[1] - va).max() <= 1e-8
+
+
+@pytest.mark.parametrize("name,batch", [("case118", 3), ("case1354pegase", 70)])
+def test_nan_state_ends_in_status_3_for_that_scenario_only(jg, name, batch):
+    s = jg.powerSystem(load_case(name))
+    clean = jg.newtonRaphson(s, batch=batch)
+    jg.powerFlow_(clean)
+    an = jg.newtonRaphson(s, batch=batch)
+    vm = np.tile(an.voltage.magnitude[0], (batch, 1))
+    va = np.tile(an.voltage.angle[0], (batch, 1))
+    hit = [1, batch - 1] if batch > 3 else [1]
+    for b in hit:
+        vm[b, 5 + b % 7] = np.nan
+    jg.powerflow._push_voltage(an, vm, va)
+    jg.powerFlow_(an)
+    ok = [b for b in range(batch) if b not in hit]
+    assert all(an.status[b] == 3 for b in hit)
+    assert np.array_equal(an.status[ok], clean.status[ok]) and np.array_equal(an.method.iteration[ok], clean.method.iteration[ok])
+    assert np.array_equal(an.voltage.magnitude[ok], clean.voltage.magnitude[ok])
+
+
+@pytest.mark.parametrize("name", ["case14", "case30test", "case118", "case300", "case1354pegase"])
+def test_static_pivots_follow_the_pivoting_oracle_towards_the_nose_point(jg, oracle, name):
+    """Demand and generation scaled up in steps of 5 % until the oracle stops converging; the three heaviest loadings that
+    still have a solution (the Jacobian is closest to singular there) in one batch: iteration counts equal, V / theta 1e-8."""
+    t = load_case(name)
+    s = jg.powerSystem(t)
+    osys = oracle.OracleSystem(t)
+
+    def oracle_run(scale):
+        o = oracle.OracleNR(osys)
+        o.set_power(osys.ps * scale, osys.qs, osys.pd * scale, osys.qd * scale)
+        return o, o.power_flow(iteration=20, tolerance=1e-8)
+
+    scale, solved = 1.0, []
+    while scale < 6.0:
+        o, st = oracle_run(scale)
+        if st != 0:
+            break
+        solved.append((scale, o))
+        scale = round(scale + 0.05, 2)
+    assert len(solved) >= 3
+    pick = solved[-3:]
+    an = jg.newtonRaphson(s, batch=len(pick))
+    sc = np.array([p[0] for p in pick])[:, None]
+    jg.setInjection_(an, (s.bus.supply.active[None, :] - s.bus.demand.active[None, :]) * sc,
+                     s.bus.supply.reactive[None, :] - s.bus.demand.reactive[None, :] * sc)
+    jg.powerFlow_(an, iteration=20, tolerance=1e-8)
+    for b, (scl, o) in enumerate(pick):
+        assert an.status[b] == 0 and an.method.iteration[b] == o.iteration, f"scale {scl}: {an.method.iteration[b]} vs {o.iteration} iterations"
+        vm, va = o.voltage()
+        assert np.abs(an.voltage.magnitude[b] - vm).max() <= 1e-8 and np.abs(an.voltage.angle[b] - va).max() <= 1e-8
+    assert max(o.iteration for _, o in pick) >= 5          # the heaviest loading needs more iterations than the base case
+
+
+def test_fast_newton_raphson_survives_post_processing(jg):
+    """fastNewtonRaphsonBX -> powerFlow! -> power! (uploads the branch tables) -> setInitialPoint! -> powerFlow!: the second
+    solve repeats the first (the branch upload used to free the fast solver's buffers), and the full Jacobian of a fast
+    analysis is refused instead of silently overwriting the factorised B', B''."""
+    s = jg.powerSystem(load_case("case30test"))
+    an = jg.fastNewtonRaphsonBX(s)
+    jg.powerFlow_(an, iteration=100, tolerance=1e-8)
+    it1, vm1, va1 = int(an.method.iteration), an.voltage.magnitude.copy(), an.voltage.angle.copy()
+    jg.power_(an)
+    with pytest.raises(RuntimeError):
+        an.jacobian
+    jg.setInitialPoint_(an)
+    jg.powerFlow_(an, iteration=100, tolerance=1e-8)
+    assert an.status == 0 and int(an.method.iteration) == it1
+    assert np.array_equal(an.voltage.magnitude, vm1) and np.array_equal(an.voltage.angle, va1)
+    an.close()
+
+
+def test_mismatch_and_increment_belong_to_their_scenario_after_compaction(jg, oracle):
+    """Batch of 200 outage scenarios of case1354pegase (lanes are compacted while the batch iterates): method.mismatch is the
+    mismatch of every scenario's FINAL state, method.increment the last increment of THAT scenario (oracle, same outage)."""
+    t = load_case("case1354pegase")
+    s = jg.powerSystem(t)
+    labels = [int(x) for x in jg.outageList(s, 200, seed=11)]
+    an = jg.contingencyAnalysis(s, labels)
+    jg.powerFlow_(an, iteration=20, tolerance=1e-8)
+    assert len(set(an.method.iteration.tolist())) > 1            # scenarios finish in different iterations
+    f = an.mismatch
+    conv = an.status == 0
+    assert np.abs(f[conv]).max() < 1e-8
+    osys = oracle.OracleSystem(t)
+    inc = an.increment
+    for sc in (0, 63, 64, 65, 130, 199):
+        o = oracle.OracleNR(osys)
+        ptr, dy = jg.outagePatch(s, labels[sc])
+        for p, d in zip(ptr, dy):
+            o.add_ybus(p - 1, d)
+        st = o.power_flow(iteration=20, tolerance=1e-8)
+        assert st == an.status[sc]
+        if st == 0:
+            _, f_ref, inc_ref = o.vectors()
+            assert np.abs(inc[sc] - inc_ref).max() <= 1e-9 * max(1.0, np.abs(inc_ref).max()) + 1e-12
+            assert np.abs(f[sc] - f_ref).max() <= 1e-9
