@@ -109,14 +109,15 @@ __device__ __forceinline__ void fact_record(const FactArgs& a, const RecS& r, in
 // Pivot guard of the static schedule.  The reference's solvers pivot (UMFPACK / KLU threshold pivoting,
 // /root/reference/src/backend/utility.jl:470-484) and raise SingularException; here the pivot ORDER is fixed, so a pivot block
 // that cancels to rounding level must be caught, not divided by: a diagonal block whose 2x2 LU has a pivot below
-// PIVOT_EPS x (largest entry the block started from) marks the scenario (status bit 2 -> per-scenario status 3 in
-// k_check / k_gn_check).  A Jacobian of an islanded sub-grid (bridge outage: no slack in the island) ends exactly there:
+// PIVOT_EPS x (largest entry ITS ROW of the block started from) marks the scenario (status bit 2 -> per-scenario status 3
+// in k_check / k_gn_check).  Row-wise, because the two rows of a block may live on very different scales (gain matrices:
+// a slack angle row of 1 beside a PMU-weighted magnitude row of 1e10) and only cancellation is a defect.  A Jacobian of an islanded sub-grid (bridge outage: no slack in the island) ends exactly there:
 // its last block is a difference of equal numbers, ~1e-16 of what went in, not an exact zero.
 constexpr double PIVOT_EPS = 0x1p-36;       // 1.5e-11: far below any legitimate Schur complement of a power grid, far above rounding
 
-__device__ __forceinline__ double blk_max(const Blk& c) { return fmax(fmax(fabs(c.v00), fabs(c.v01)), fmax(fabs(c.v10), fabs(c.v11))); }
+__device__ __forceinline__ double2 row_max(const Blk& c) { return double2{fmax(fabs(c.v00), fabs(c.v01)), fmax(fabs(c.v10), fabs(c.v11))}; }
 
-__device__ __forceinline__ void fact_finish(const FactArgs& a, int kind, int id, size_t b, size_t ld, const Blk& c, double ref) {
+__device__ __forceinline__ void fact_finish(const FactArgs& a, int kind, int id, size_t b, size_t ld, const Blk& c, double2 ref) {
     if (kind == 3) {
         store_vec(a.W, (size_t)id, b, ld, c.v00, c.v01);
         return;
@@ -129,8 +130,8 @@ __device__ __forceinline__ void fact_finish(const FactArgs& a, int kind, int id,
         const double l = o21 * iu11;
         const double u22 = o22 - l * u12;
         const double iu22 = 1.0 / u22;
-        const double floor = PIVOT_EPS * ref;
-        if (!(fabs(u11) > floor) || !(fabs(u22) > floor) || !(fabs(iu11) < 1.0e300) || !(fabs(iu22) < 1.0e300)) atomicOr(a.status + b, 4);
+        const double f1 = PIVOT_EPS * (sw ? ref.y : ref.x), f2 = PIVOT_EPS * (sw ? ref.x : ref.y);
+        if (!(fabs(u11) > f1) || !(fabs(u22) > f2) || !(fabs(iu11) < 1.0e300) || !(fabs(iu22) < 1.0e300)) atomicOr(a.status + b, 4);
         store_blk(a.X, (size_t)id, b, ld, iu11, u12, sw ? l + 4.0 : l, iu22);
     } else {
         store_blk(a.X, (size_t)id, b, ld, c.v00, c.v01, c.v10, c.v11);
@@ -144,12 +145,12 @@ __device__ __forceinline__ void fact_chunk(const FactArgs& a, double* red, const
     const int sub = wave & (wpi - 1);
     const int kind = rec_word(first, 0), id = rec_word(first, 1), src = rec_word(first, 2);
     Blk c{0.0, 0.0, 0.0, 0.0};
-    double ref = 0.0;                                           // what a diagonal block started from (pivot guard)
+    double2 ref{0.0, 0.0};                                      // what the rows of a diagonal block started from (pivot guard)
     if (kind >= 0) {
         if (sub == 0) {
             if (kind == 3) { const double2 f = load_vec(a.rhs, (size_t)src, b, ld); c.v00 = f.x; c.v01 = f.y; }
             else if (src >= 0) c = load_blk(a.A, (size_t)src, b, ld);
-            ref = blk_max(c);
+            ref = row_max(c);
         }
         // long lists: the wave's next record is requested before the current one is consumed (the tables are static)
         RecS cur = first;
@@ -214,7 +215,7 @@ __device__ __forceinline__ double2 bwd_finish(const BwdArgs& a, const Blk& d, do
     double x0, x1;
     dsolve(d, y0, y1, x0, x1);
     store_vec(a.W, (size_t)k, b, ld, x0, x1);
-    store_vec(a.out, (size_t)bus, b, ld, x0, x1);
+    if (!a.upd.va || p.act) store_vec(a.out, (size_t)bus, b, ld, x0, x1);      // a finished scenario keeps its last increment
     if (a.upd.va) {
         if (p.act && (p.fl & 1)) a.upd.va[(size_t)bus * ld + b] = p.va + a.upd.sign * x0;
         if (p.act && (p.fl & 2)) a.upd.vm[(size_t)bus * ld + b] = p.vm + a.upd.sign * x1;
@@ -515,7 +516,7 @@ __device__ __forceinline__ double rcp_fast(double x) {
 // 2x2 LU with in-block partial pivoting in the stored form of fact_finish.  The pivot sits on the dependent chain of every
 // chain step, so the two reciprocals are independent here: u22 = det / u11 with det = o22 u11 - o21 u12 (same backward
 // error as o22 - (o21 / u11) u12: one rounded product in front of the subtraction either way).
-__device__ __forceinline__ Blk factor_diag(const Blk& c, int& bad, double ref) {   // bad: sticky flag, reported once at the end of the task; ref: pivot guard
+__device__ __forceinline__ Blk factor_diag(const Blk& c, int& bad, double2 ref) {   // bad: sticky flag, reported once at the end of the task; ref: pivot guard
     const bool sw = fabs(c.v10) > fabs(c.v00);
     const double u11 = sw ? c.v10 : c.v00, u12 = sw ? c.v11 : c.v01;
     const double o21 = sw ? c.v00 : c.v10, o22 = sw ? c.v01 : c.v11;
@@ -523,8 +524,8 @@ __device__ __forceinline__ Blk factor_diag(const Blk& c, int& bad, double ref) {
     const double iu11 = rcp_fast(u11), idet = rcp_fast(det);
     const double l = o21 * iu11;
     const double iu22 = u11 * idet;
-    const double floor = PIVOT_EPS * ref;
-    bad |= (!(fabs(u11) > floor) || !(fabs(det) > floor * fabs(u11)) || !(fabs(iu11) < 1.0e300) || !(fabs(iu22) < 1.0e300)) ? 1 : 0;
+    const double f1 = PIVOT_EPS * (sw ? ref.y : ref.x), f2 = PIVOT_EPS * (sw ? ref.x : ref.y);
+    bad |= (!(fabs(u11) > f1) || !(fabs(det) > f2 * fabs(u11)) || !(fabs(iu11) < 1.0e300) || !(fabs(iu22) < 1.0e300)) ? 1 : 0;
     return Blk{iu11, u12, sw ? l + 4.0 : l, iu22};
 }
 
@@ -636,12 +637,12 @@ __global__ __launch_bounds__(TOP_THREADS) void k_fact_top(TopArgs a) {
                 if (j == 0) lds_set(Lbuf[0], i, i > 0 ? T[r][c] : zero);
                 if (i == j && i < m) lds_set(Dini, i, T[r][c]);
             }
-        if (tid == 0) lds_set(Dbuf[0], 0, factor_diag(T[0][0], bad, blk_max(T[0][0])));
+        if (tid == 0) lds_set(Dbuf[0], 0, factor_diag(T[0][0], bad, row_max(T[0][0])));
     }
     __syncthreads();
-    double myref = 0.0;                                          // pivot wave, lane k: largest entry S(k,k) entered the task with
+    double2 myref{0.0, 0.0};                                     // pivot wave, lane k: row maxima S(k,k) entered the task with
     if (pivot_wave) {
-        if (lane < m) { mydiag = lds_get(Dini, lane); myref = blk_max(mydiag); }
+        if (lane < m) { mydiag = lds_get(Dini, lane); myref = row_max(mydiag); }
         if (lane == 0) mydiag = lds_get(Dbuf[0], 0);
     }
     // ---- pivot steps.  Straight-line bulk code: the pivot is the same block for every lane, so the row swap of its 2x2 LU is
@@ -706,7 +707,7 @@ __global__ __launch_bounds__(TOP_THREADS) void k_fact_top(TopArgs a) {
                 const int lo = __builtin_amdgcn_readlane(__double2loint(v), q + 1), hi = __builtin_amdgcn_readlane(__double2hiint(v), q + 1);
                 return __hiloint2double(hi, lo);
             };
-            const Blk dn = factor_diag(Blk{bc(mydiag.v00), bc(mydiag.v01), bc(mydiag.v10), bc(mydiag.v11)}, bad, bc(myref));
+            const Blk dn = factor_diag(Blk{bc(mydiag.v00), bc(mydiag.v01), bc(mydiag.v10), bc(mydiag.v11)}, bad, double2{bc(myref.x), bc(myref.y)});
             if (lane == q + 1) { mydiag = dn; lds_set(Dbuf[nxt], 0, dn); }
         }
         __syncthreads();
