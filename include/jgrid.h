@@ -72,6 +72,10 @@ int jg_nr_restore_voltage(jg_nr* h);
  * vm_dev/va_dev are device pointers, [batch][n] doubles, written on the handle's stream and
  * synchronised before return. */
 int jg_nr_get_voltage_device(jg_nr* h, double* vm_dev, double* va_dev);
+/* The whole result of a batch as ONE device buffer, [batch][2 n + 2] doubles per scenario: V[n] | theta[n] | iterations |
+ * status (the analysis.voltage / method.iteration a caller of powerFlow! reads, src/powerFlow/acPowerFlow.jl:1389-1433) --
+ * the record a sharded screen gathers with a single collective. */
+int jg_nr_pack_results_device(jg_nr* h, double* dst_dev);
 
 /*
  * Per-scenario Ybus edit on top of the shared base matrix -- what acNodalUpdate!

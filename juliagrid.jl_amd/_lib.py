@@ -48,6 +48,7 @@ def lib():
         "jg_nr_snapshot_voltage": [VP],
         "jg_nr_restore_voltage": [VP],
         "jg_nr_get_voltage_device": [VP, VP, VP],
+        "jg_nr_pack_results_device": [VP, VP],
         "jg_nr_patch_ybus": [VP, C.c_int64, C.c_int64, I64P, F64P],
         "jg_nr_patch_ybus_batch": [VP, C.c_int64, C.c_int64, C.c_int64, I64P, F64P],
         "jg_nr_set_ybus": [VP, F64P, F64P],

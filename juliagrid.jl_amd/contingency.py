@@ -174,20 +174,21 @@ class ContingencyPipeline:
         return it, st
 
 
-def gatherResults(dist, iterations, status, magnitude=None, angle=None):
-    """Final gather of a sharded batch: every rank contributes its contiguous block of
-    scenarios; returns the global arrays in scenario order on every rank.  `dist` is an initialised
-    torch.distributed module (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests);
-    tensors must live on the backend's device.  This is the ONLY collective of the path."""
+def gatherResults(dist, packed):
+    """Final gather of a sharded batch: ONE collective.  `packed` is this rank's [scenarios, 2 n + 2] result block
+    (AcPowerFlow.pack_results_device: V | theta | iterations | status); every rank contributes its contiguous block of
+    scenarios and receives the global block in scenario order.  `dist` is an initialised torch.distributed module (backend
+    "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests); the tensor must live on the backend's device.
+    Returns (iterations, status, magnitude, angle) views of the gathered block."""
     import torch
     world = dist.get_world_size()
-    out = []
-    for t in (iterations, status, magnitude, angle):
-        if t is None:
-            out.append(None)
-            continue
-        t = t.contiguous()
-        g = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(g, t)
-        out.append(g)
-    return tuple(out)
+    packed = packed.contiguous()
+    g = torch.empty((world * packed.shape[0], packed.shape[1]), dtype=packed.dtype, device=packed.device)
+    dist.all_gather_into_tensor(g, packed)
+    return unpackResults(g)
+
+
+def unpackResults(g):
+    """(iterations, status, magnitude, angle) of a [scenarios, 2 n + 2] result block."""
+    n = (g.shape[1] - 2) // 2
+    return g[:, 2 * n].long(), g[:, 2 * n + 1].long(), g[:, :n], g[:, n:2 * n]

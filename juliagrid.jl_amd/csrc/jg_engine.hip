@@ -770,7 +770,7 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, int policy
     // Where the multifrontal top starts depends on the batch: a top task occupies a workgroup per scenario (~10 us + ~1 us per
     // pivot), a level launch a wave per 64 scenarios.  Up to 128 scenarios every level that holds fewer than ~400 items is
     // cheaper as tasks (latency regime); at 512 only the levels with at most ~4 parallel chains are (measured, ACTIVSg10k).
-    if (!(policy >> 16)) policy |= ld_ >= 256 ? (47 << 16 | (144 / 8) << 24) : (24 << 16 | (384 / 8) << 24);
+    if (!(policy >> 16)) policy |= ld_ >= 256 ? (47 << 16 | (280 / 8) << 24) : (24 << 16 | (384 / 8) << 24);
     if (analyze(n, rowptr, col, policy, S)) { error = "block pattern must be structurally symmetric with a full diagonal"; return 1; }
     ld = ld_;
     level_launches(S.fact_seg, fact);

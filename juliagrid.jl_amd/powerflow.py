@@ -149,6 +149,10 @@ class AcPowerFlow:
         """Write [batch, n] voltages into caller-owned DEVICE buffers (raw pointers)."""
         _lib.check(_lib.lib().jg_nr_get_voltage_device(self._h, C.c_void_p(vm_ptr), C.c_void_p(va_ptr)))
 
+    def pack_results_device(self, dst_ptr: int):
+        """[batch, 2 n + 2] result records (V | theta | iterations | status) into a caller-owned DEVICE buffer."""
+        _lib.check(_lib.lib().jg_nr_pack_results_device(self._h, C.c_void_p(dst_ptr)))
+
     def time_kernel(self, kernel: int, reps: int = 10) -> float:
         ms = C.c_double(0.0)
         _lib.check(_lib.lib().jg_nr_time_kernel(self._h, int(kernel), int(reps), C.byref(ms)))

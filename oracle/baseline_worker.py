@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One host process of bench.py's all-cores CPU baseline (TEST / MEASUREMENT INFRASTRUCTURE, not the product).
 
-  python oracle/baseline_worker.py <case> <first> <count> <seed> <total>
+  python oracle/baseline_worker.py <case> <first> <count> <seed> <total> [cpu]
 
 Runs the oracle's serial contingency loop (the reference's own loop) over scenarios
 [first, first + count) of the seeded outage list and prints one JSON line {iters, done, seconds} (loop only: the
@@ -20,6 +20,11 @@ sys.path.insert(0, ROOT)
 
 def main():
     case, first, count, seed, total = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    if len(sys.argv) > 6 and hasattr(os, "sched_setaffinity"):       # one worker per core, pinned
+        try:
+            os.sched_setaffinity(0, {int(sys.argv[6])})
+        except OSError:
+            pass
     from oracle import oracle as O
     import juliagrid.jl_amd as jg                     # host model only (outage list / Ybus patches); no GPU call is made
     if case == "case9241synth":

@@ -50,10 +50,16 @@ WORKER = textwrap.dedent("""
     status = (ids % 3 == 0).to(torch.int32)
     vm = (ids[:, None] * 10 + torch.arange(n)[None, :]).to(torch.float64)
     va = -vm
-    g_it, g_st, g_vm, g_va = jg.gatherResults(dist, iters, status, vm, va)
+    packed = torch.cat([vm, va, iters[:, None].double(), status[:, None].double()], dim=1)      # the record jg_nr_pack_results_device writes
+    calls = []
+    real = dist.all_gather_into_tensor
+    dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    g_it, g_st, g_vm, g_va = jg.gatherResults(dist, packed)
+    dist.all_gather_into_tensor = real
+    assert len(calls) == 1                                   # ONE collective for the whole result (SURVEY 8e)
     all_ids = torch.arange(total)
-    assert torch.equal(g_it, (all_ids % 4 + 2).to(torch.int32))
-    assert torch.equal(g_st, (all_ids % 3 == 0).to(torch.int32))
+    assert torch.equal(g_it, (all_ids % 4 + 2).long())
+    assert torch.equal(g_st, (all_ids % 3 == 0).long())
     assert torch.equal(g_vm, (all_ids[:, None] * 10 + torch.arange(n)[None, :]).to(torch.float64))
     assert torch.equal(g_va, -g_vm)
     # whole-job accounting used by bench.py: sum of iterations, max of times
