@@ -1,112 +1,249 @@
-# JuliaGridHIP.jl -- thin ccall shim that plugs libjgrid_hip.so (include/jgrid.h) behind JuliaGrid's own
-# newtonRaphson()/mismatch!()/solve!()/powerFlow!() surface.  Written against JuliaGrid v0.6.2; it has
-# NOT been executed (no Julia toolchain in the build containers) -- see INTEGRATION.md.
+# JuliaGridHIP.jl -- ccall shim that plugs libjgrid_hip.so (include/jgrid.h) behind JuliaGrid's own
+# newtonRaphson() / mismatch!() / solve!() / powerFlow!() and gaussNewton() / increment!() / solve!() / stateEstimation!()
+# surface.  Written against JuliaGrid v0.6.2; it has NOT been executed (no Julia toolchain in the build containers) --
+# see INTEGRATION.md for the one-token patch of the reference it needs and for how every row below maps to the C ABI.
 #
-# Reference seams (paths relative to the JuliaGrid checkout):
-#   tag types            src/definition/analysis.jl:36-99      (LU/KLU/QR <: Normal <: WlsMethod)
-#   NewtonRaphson{T}     src/definition/analysis.jl:154-164    (field `factorization::FactorSparse`)
-#   newtonRaphson        src/powerFlow/acPowerFlow.jl:39-87
-#   mismatch!/solve!     src/powerFlow/acPowerFlow.jl:645-685, 793-911
-#   powerFlow!           src/powerFlow/acPowerFlow.jl:1389-1433   (unchanged: it only calls mismatch!/solve!)
+# The analyses are the REFERENCE'S OWN structs, parametrised by a new solver tag:
+#     AcPowerFlow{NewtonRaphson{HIP}}          (src/definition/analysis.jl:154-164, 252-258)
+#     AcStateEstimation{GaussNewton{HIP}}      (src/definition/analysis.jl:532-545, 643-650)
+# so the reference's generic loops powerFlow! (src/powerFlow/acPowerFlow.jl:1389-1433) and stateEstimation!
+# (src/stateEstimation/acStateEstimation.jl:1286-1329), its printing, power!/current! and every reader of
+# analysis.voltage.{magnitude,angle} / analysis.method.{jacobian,mismatch,increment,residual,iteration} work unchanged;
+# what dispatches here are the methods that do numerics.
+#
+#   reference method (file:line)                                        -> C ABI
+#   newtonRaphson(system, T)             acPowerFlow.jl:39-87           -> jg_nr_create, jg_nr_set_injection, jg_nr_set_voltage
+#   mismatch!(analysis)                  acPowerFlow.jl:645-685         -> jg_nr_mismatch, jg_nr_get_mismatch
+#   solve!(analysis)                     acPowerFlow.jl:793-911         -> jg_nr_solve, jg_nr_get_increment, jg_nr_get_voltage
+#   powerFlow!(analysis)  (fused)        acPowerFlow.jl:1389-1433       -> jg_nr_run, jg_nr_get_voltage, jg_nr_get_iteration
+#   setInitialPoint!(analysis)           acPowerFlow.jl:1226-1249       -> jg_nr_set_voltage
+#   updateBus!/Branch!/Generator!        bus.jl:286, branch.jl:453, generator.jl:382 -> jg_nr_set_injection, jg_nr_set_ybus
+#   gaussNewton(monitoring, T)           acStateEstimation.jl:43-75     -> jg_gn_create, jg_gn_set_measurement, jg_gn_set_voltage
+#   increment!(analysis)                 acStateEstimation.jl:878-904   -> jg_gn_increment, jg_gn_get_increment, jg_gn_get_residual
+#   solve!(analysis)                     acStateEstimation.jl:1035-1047 -> jg_gn_solve, jg_gn_get_voltage
+#   stateEstimation!(analysis) (fused)   acStateEstimation.jl:1286-1329 -> jg_gn_run, jg_gn_get_voltage
+#   setInitialPoint!(analysis)           acStateEstimation.jl:1071      -> jg_gn_set_voltage
+#   update<Meter>!(analysis; ...)        measurement/*.jl               -> jg_gn_set_status, jg_gn_set_measurement
+#   residualTest!(analysis)  (numerics)  badData.jl:181-311             -> jg_gn_residual_test
 module JuliaGridHIP
 
 using JuliaGrid
 using SparseArrays
+import JuliaGrid: newtonRaphson, gaussNewton, mismatch!, solve!, increment!, powerFlow!, stateEstimation!, setInitialPoint!,
+                  updateBus!, updateBranch!, updateGenerator!,
+                  updateVoltmeter!, updateAmmeter!, updateWattmeter!, updateVarmeter!, updatePmu!,
+                  AcPowerFlow, AcStateEstimation, NewtonRaphson, GaussNewton, PowerSystem, Measurement, LU
 
 const lib = get(ENV, "JGRID_HIP_LIB", "libjgrid_hip.so")
 
-struct HIP <: JuliaGrid.Normal end          # the new factorization tag
+"""
+    HIP <: Normal
 
-mutable struct HipHandle                    # stands in for `factorization` (widen FactorSparse, INTEGRATION.md)
+Solver tag: `newtonRaphson(system, HIP)`, `gaussNewton(monitoring, HIP)`.  `GaussNewton{T <: WlsMethod}` accepts it as it
+is; `NewtonRaphson{T <: Union{LU, KLU, QR}}` needs its bound widened to `T <: Normal` (INTEGRATION.md, one token).
+"""
+struct HIP <: JuliaGrid.Normal end
+
+# The structs type their `factorization` field with the FactorSparse union; the device factor lives behind the C handle, so the
+# field keeps an (unused) LU placeholder and the handle is found through the method object.
+JuliaGrid.selectFactorization(::Type{HIP}) = JuliaGrid.selectFactorization(LU)
+
+mutable struct Handle
     ptr::Ptr{Cvoid}
-    function HipHandle(p)
-        h = new(p)
-        finalizer(x -> ccall((:jg_nr_destroy, lib), Cvoid, (Ptr{Cvoid},), x.ptr), h)
+    kind::Symbol                                  # :nr | :gn
+    function Handle(p, kind)
+        h = new(p, kind)
+        finalizer(h) do x
+            x.ptr == C_NULL && return
+            x.kind === :nr ? ccall((:jg_nr_destroy, lib), Cvoid, (Ptr{Cvoid},), x.ptr) :
+                             ccall((:jg_gn_destroy, lib), Cvoid, (Ptr{Cvoid},), x.ptr)
+            x.ptr = C_NULL
+        end
         return h
     end
 end
+const HANDLES = WeakKeyDict{Any, Handle}()        # analysis.method (a mutable struct) -> device handle
+handle(analysis) = HANDLES[analysis.method].ptr
 
 check(rc) = rc == 0 ? nothing :
     throw(ErrorException(unsafe_string(ccall((:jg_last_error, lib), Cstring, ()))))
 
-reim_interleaved(z::Vector{ComplexF64}) = collect(reinterpret(Float64, z))
+reim(z::AbstractVector{ComplexF64}) = collect(reinterpret(Float64, z))
+
+const HipPowerFlow = AcPowerFlow{NewtonRaphson{HIP}}
+const HipStateEstimation = AcStateEstimation{GaussNewton{HIP}}
+
+# ------------------------------------------------------------------------------------------------------------------
+# Newton-Raphson AC power flow
+# ------------------------------------------------------------------------------------------------------------------
+function pushInjection!(analysis::HipPowerFlow)
+    bus = analysis.system.bus
+    p = bus.supply.active .- bus.demand.active
+    q = bus.supply.reactive .- bus.demand.reactive
+    check(ccall((:jg_nr_set_injection, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64), handle(analysis), p, q, 0))
+end
+
+pushVoltage!(analysis::HipPowerFlow) =
+    check(ccall((:jg_nr_set_voltage, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64),
+        handle(analysis), analysis.voltage.magnitude, analysis.voltage.angle, 0))
+
+pullVoltage!(analysis::HipPowerFlow) =
+    check(ccall((:jg_nr_get_voltage, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}),
+        handle(analysis), analysis.voltage.magnitude, analysis.voltage.angle))
+
+function pushYbus!(analysis::HipPowerFlow)
+    ac = analysis.system.model.ac
+    check(ccall((:jg_nr_set_ybus, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}),
+        handle(analysis), reim(ac.nodalMatrix.nzval), reim(ac.nodalMatrixTranspose.nzval)))
+end
 
 """
-    newtonRaphson(system, HIP; batch = 1, device = 0)
+    newtonRaphson(system, HIP; device = 0)
 
-Same set-up as `newtonRaphson(system, LU)` (bus-type normalisation, start voltages, index maps), with
-the Jacobian pattern, symbolic analysis and all per-iteration numerics living on the GPU.
+Same set-up as `newtonRaphson(system, LU)` (bus-type normalisation, start voltages, index maps: done by the reference itself),
+with the Jacobian pattern, the symbolic analysis and all per-iteration numerics on the GPU.  One scenario, like every
+analysis of the reference; batches go through `NewtonRaphsonBatch`.
 """
-function JuliaGrid.newtonRaphson(system::PowerSystem, ::Type{HIP}; batch::Int = 1, device::Int = 0)
-    analysis = newtonRaphson(system, LU)                      # host bookkeeping, maps, containers
+function newtonRaphson(system::PowerSystem, ::Type{HIP}; device::Int = 0)
+    base = newtonRaphson(system, LU)                          # host bookkeeping of the reference: maps, containers, start point
+    m = base.method
+    method = NewtonRaphson{HIP}(m.jacobian, m.mismatch, m.increment, JuliaGrid.selectFactorization(HIP), m.pq, m.pvpq, m.pcount,
+        m.signature, 0)
+    analysis = AcPowerFlow(base.voltage, base.power, base.current, method, system)
     ac = system.model.ac
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:jg_nr_create, lib), Cint,
         (Ref{Ptr{Cvoid}}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int8}, Int64, Int64, Int64, Cint),
         h, system.bus.number, ac.nodalMatrix.colptr, ac.nodalMatrix.rowval,
-        reim_interleaved(ac.nodalMatrix.nzval), reim_interleaved(ac.nodalMatrixTranspose.nzval),
-        system.bus.layout.type, system.bus.layout.slack, batch, batch == 1 ? 0 : 4, device))
-    handle = HipHandle(h[])
-    p = system.bus.supply.active .- system.bus.demand.active
-    q = system.bus.supply.reactive .- system.bus.demand.reactive
-    check(ccall((:jg_nr_set_injection, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64), handle.ptr, p, q, 0))
-    check(ccall((:jg_nr_set_voltage, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64),
-        handle.ptr, analysis.voltage.magnitude, analysis.voltage.angle, 0))
-    return HipPowerFlow(analysis, handle)
+        reim(ac.nodalMatrix.nzval), reim(ac.nodalMatrixTranspose.nzval),
+        system.bus.layout.type, system.bus.layout.slack, 1, 0, device))
+    HANDLES[method] = Handle(h[], :nr)
+    pushInjection!(analysis)
+    pushVoltage!(analysis)
+    return analysis
 end
 
-struct HipPowerFlow                          # AcPowerFlow{NewtonRaphson{HIP}} once the unions are widened
-    base::AcPowerFlow
-    handle::HipHandle
+function staleCheck(analysis::HipPowerFlow)                  # acPowerFlow.jl:802-811
+    rev, sig = analysis.system.model.revision, analysis.method.signature
+    (rev.topology != sig.topology || rev.type != sig.type) && JuliaGrid.errorTypeConversion()
+    if sig.acPattern != -1 && rev.acPattern != sig.acPattern  # addBranch!/dropZeros! changed the Ybus pattern: new handle
+        throw(ErrorException("The Ybus pattern changed; build a new analysis with newtonRaphson(system, HIP)."))
+    end
+    sig.acPattern = rev.acPattern
 end
 
-function JuliaGrid.mismatch!(a::HipPowerFlow)                # acPowerFlow.jl:645-685
+function mismatch!(analysis::HipPowerFlow)                   # acPowerFlow.jl:645-685
     maxp = Ref(0.0); maxq = Ref(0.0)
-    check(ccall((:jg_nr_mismatch, lib), Cint, (Ptr{Cvoid}, Ref{Float64}, Ref{Float64}), a.handle.ptr, maxp, maxq))
+    check(ccall((:jg_nr_mismatch, lib), Cint, (Ptr{Cvoid}, Ref{Float64}, Ref{Float64}), handle(analysis), maxp, maxq))
+    check(ccall((:jg_nr_get_mismatch, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), handle(analysis), analysis.method.mismatch))
     return maxp[], maxq[]
 end
 
-function JuliaGrid.solve!(a::HipPowerFlow)                   # acPowerFlow.jl:793-911
-    rev, sig = a.base.system.model.revision, a.base.method.signature
-    (rev.topology != sig.topology || rev.type != sig.type) && JuliaGrid.errorTypeConversion()
-    check(ccall((:jg_nr_solve, lib), Cint, (Ptr{Cvoid},), a.handle.ptr))
-    check(ccall((:jg_nr_get_voltage, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}),
-        a.handle.ptr, a.base.voltage.magnitude, a.base.voltage.angle))
-    a.base.method.iteration += 1
+function solve!(analysis::HipPowerFlow)                      # acPowerFlow.jl:793-911
+    staleCheck(analysis)
+    check(ccall((:jg_nr_solve, lib), Cint, (Ptr{Cvoid},), handle(analysis)))     # code 3 = singular Jacobian -> ErrorException
+    check(ccall((:jg_nr_get_increment, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), handle(analysis), analysis.method.increment))
+    pullVoltage!(analysis)
+    analysis.method.iteration += 1
     return nothing
 end
 
-function JuliaGrid.powerFlow!(a::HipPowerFlow; iteration::Int64 = 20, tolerance::Float64 = 1e-8)
-    iters = Ref{Int32}(0); status = Ref{Int32}(0)            # acPowerFlow.jl:1389-1433, fused on the device
-    check(ccall((:jg_nr_run, lib), Cint, (Ptr{Cvoid}, Int64, Float64, Ref{Int32}, Ref{Int32}),
-        a.handle.ptr, iteration, tolerance, iters, status))
-    check(ccall((:jg_nr_get_voltage, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}),
-        a.handle.ptr, a.base.voltage.magnitude, a.base.voltage.angle))
-    a.base.method.iteration = iters[]
+"method.jacobian at the current state, in the reference's CSC order (only when somebody looks: it stays on the device)"
+function jacobian!(analysis::HipPowerFlow)
+    check(ccall((:jg_nr_get_jacobian, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), handle(analysis), analysis.method.jacobian.nzval))
+    return analysis.method.jacobian
+end
+
+"""
+    powerFlow!(analysis::AcPowerFlow{NewtonRaphson{HIP}}; iteration, tolerance, power, current)
+
+The reference's loop (acPowerFlow.jl:1389-1433) with the same accounting, run on the device without a host round trip per
+iteration.  The generic `powerFlow!` of the reference also works on this analysis (it only calls `mismatch!` / `solve!`).
+"""
+function powerFlow!(analysis::HipPowerFlow; iteration::Int64 = 20, tolerance::Float64 = 1e-8, power::Bool = false,
+                    current::Bool = false, verbose::Int64 = 0)
+    staleCheck(analysis)
+    iters = Vector{Int32}(undef, 1); status = Vector{Int32}(undef, 1)
+    check(ccall((:jg_nr_run, lib), Cint, (Ptr{Cvoid}, Int64, Float64, Ptr{Int32}, Ptr{Int32}),
+        handle(analysis), iteration, tolerance, iters, status))
+    pullVoltage!(analysis)
+    check(ccall((:jg_nr_get_mismatch, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), handle(analysis), analysis.method.mismatch))
+    check(ccall((:jg_nr_get_increment, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), handle(analysis), analysis.method.increment))
+    analysis.method.iteration = iters[1]
+    status[1] == 3 && throw(ErrorException("The Jacobian is singular."))        # SingularException of the reference's lu!
+    power && JuliaGrid.power!(analysis)
+    current && JuliaGrid.current!(analysis)
     return nothing
 end
 
-function JuliaGrid.setInitialPoint!(a::HipPowerFlow)         # acPowerFlow.jl:1226-1249
-    setInitialPoint!(a.base)
-    check(ccall((:jg_nr_set_voltage, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64),
-        a.handle.ptr, a.base.voltage.magnitude, a.base.voltage.angle, 0))
+function setInitialPoint!(analysis::HipPowerFlow)            # acPowerFlow.jl:1226-1249
+    invoke(setInitialPoint!, Tuple{AcPowerFlow}, analysis)
+    pushVoltage!(analysis)
 end
 
-function JuliaGrid.updateBranch!(a::HipPowerFlow; label, kwargs...)   # branch.jl:453-459
-    updateBranch!(a.base; label, kwargs...)
-    ac = a.base.system.model.ac
-    check(ccall((:jg_nr_set_ybus, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}),
-        a.handle.ptr, reim_interleaved(ac.nodalMatrix.nzval), reim_interleaved(ac.nodalMatrixTranspose.nzval)))
+function setInitialPoint!(target::HipPowerFlow, source::JuliaGrid.AC)   # acPowerFlow.jl:1281-1295
+    invoke(setInitialPoint!, Tuple{AcPowerFlow, JuliaGrid.AC}, target, source)
+    pushVoltage!(target)
 end
 
-# Batched N-1 screening (no counterpart in the reference, which loops updateBranch!/powerFlow! per outage,
-# branch.jl:453-459): scenario s of a batched analysis = base grid with branch labels[s] out of service, expressed as the
-# 4 Ybus edits acNodalUpdate! would make (model.jl:93-101); one upload for the whole batch.
-function setOutages!(a::HipPowerFlow, labels::Vector{Int64})
-    ac, Y = a.base.system.model.ac, a.base.system.model.ac.nodalMatrix
-    lay = a.base.system.branch.layout
-    ptr = zeros(Int64, 4, length(labels)); dy = zeros(Float64, 2, 4, length(labels))
-    position(r, c) = (p = searchsortedfirst(view(Y.rowval, Y.colptr[c]:(Y.colptr[c + 1] - 1)), r); Y.colptr[c] + p - 1)
+function updateBus!(analysis::HipPowerFlow; label, kwargs...)           # bus.jl:286-298
+    invoke(updateBus!, Tuple{AcPowerFlow}, analysis; label, kwargs...)
+    pushInjection!(analysis); pushYbus!(analysis)                       # demand / shunt edits
+    pushVoltage!(analysis)                                              # magnitude / angle keywords
+end
+
+function updateBranch!(analysis::HipPowerFlow; label, kwargs...)        # branch.jl:453-459 (pattern kept: stored zeros, model.jl:70-71)
+    invoke(updateBranch!, Tuple{JuliaGrid.PowerFlow}, analysis; label, kwargs...)
+    pushYbus!(analysis)
+end
+
+function updateGenerator!(analysis::HipPowerFlow; label, kwargs...)     # generator.jl:382-388
+    invoke(updateGenerator!, Tuple{JuliaGrid.PowerFlow}, analysis; label, kwargs...)
+    pushInjection!(analysis)
+    pushVoltage!(analysis)
+end
+
+# ---- batched scenarios (no counterpart in the reference, which loops updateBranch!/powerFlow! per outage, SURVEY.md 3.5) ----
+"""
+    NewtonRaphsonBatch(system, batch; device = 0, maxPatch = 4)
+
+`batch` scenarios of one grid that share the Ybus pattern: per-scenario injections, start points and up to `maxPatch` Ybus
+edits (an outage = the 4 edits acNodalUpdate! makes, model.jl:93-101).  Results are [n, batch] matrices / [batch] vectors.
+"""
+mutable struct NewtonRaphsonBatch
+    system::PowerSystem
+    batch::Int
+    handle::Handle
+    magnitude::Matrix{Float64}
+    angle::Matrix{Float64}
+    iteration::Vector{Int32}
+    status::Vector{Int32}                          # 0 converged, 1 iteration limit, 3 numeric failure (singular Jacobian / NaN)
+end
+
+function NewtonRaphsonBatch(system::PowerSystem, batch::Int; device::Int = 0, maxPatch::Int = 4)
+    base = newtonRaphson(system, LU)
+    ac = system.model.ac
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:jg_nr_create, lib), Cint,
+        (Ref{Ptr{Cvoid}}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int8}, Int64, Int64, Int64, Cint),
+        h, system.bus.number, ac.nodalMatrix.colptr, ac.nodalMatrix.rowval, reim(ac.nodalMatrix.nzval),
+        reim(ac.nodalMatrixTranspose.nzval), system.bus.layout.type, system.bus.layout.slack, batch, maxPatch, device))
+    b = NewtonRaphsonBatch(system, batch, Handle(h[], :nr), zeros(system.bus.number, batch), zeros(system.bus.number, batch),
+        zeros(Int32, batch), zeros(Int32, batch))
+    bus = system.bus
+    check(ccall((:jg_nr_set_injection, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64), b.handle.ptr,
+        bus.supply.active .- bus.demand.active, bus.supply.reactive .- bus.demand.reactive, 0))
+    check(ccall((:jg_nr_set_voltage, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64), b.handle.ptr,
+        base.voltage.magnitude, base.voltage.angle, 0))
+    return b
+end
+
+"scenario s (1-based) = base grid with branch labels[s] out of service (0: base case); one upload for the whole batch"
+function setOutages!(b::NewtonRaphsonBatch, labels::Vector{Int64})
+    length(labels) == b.batch || throw(DimensionMismatch("one label per scenario"))
+    ac, Y, lay = b.system.model.ac, b.system.model.ac.nodalMatrix, b.system.branch.layout
+    ptr = zeros(Int64, 4, b.batch); dy = zeros(Float64, 2, 4, b.batch)
+    position(r, c) = Y.colptr[c] + searchsortedfirst(view(Y.rowval, Y.colptr[c]:(Y.colptr[c + 1] - 1)), r) - 1
     for (s, k) in enumerate(labels)
         k == 0 && continue
         i, j = lay.from[k], lay.to[k]
@@ -116,16 +253,186 @@ function setOutages!(a::HipPowerFlow, labels::Vector{Int64})
         end
     end
     check(ccall((:jg_nr_patch_ybus_batch, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Float64}),
-        a.handle.ptr, 0, length(labels), 4, ptr, dy))
+        b.handle.ptr, 0, b.batch, 4, ptr, dy))
 end
 
-# residualTest!(analysis; threshold) -- badData.jl:181-311: the numeric part on the device (gain, its factor, the selected
-# inverse on the factor pattern, normalised residuals, arg-max); returns (maxNormalizedResidual, index) and leaves the
-# label / status bookkeeping of the reference untouched (it follows from `index` exactly as in badData.jl:225-300).
-function largestNormalizedResidual(handle::HipHandle)
-    mx = Ref(0.0); idx = Ref{Int32}(0)
-    check(ccall((:jg_gn_residual_test, lib), Cint, (Ptr{Cvoid}, Ref{Float64}, Ref{Int32}), handle.ptr, mx, idx))
-    return mx[], Int64(idx[])
+function powerFlow!(b::NewtonRaphsonBatch; iteration::Int64 = 20, tolerance::Float64 = 1e-8)
+    check(ccall((:jg_nr_run, lib), Cint, (Ptr{Cvoid}, Int64, Float64, Ptr{Int32}, Ptr{Int32}),
+        b.handle.ptr, iteration, tolerance, b.iteration, b.status))              # [batch] outputs
+    check(ccall((:jg_nr_get_voltage, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}),
+        b.handle.ptr, b.magnitude, b.angle))                                     # [batch][n] row-major = [n, batch] column-major
+    return nothing
 end
+
+# ------------------------------------------------------------------------------------------------------------------
+# Gauss-Newton WLS state estimation
+# ------------------------------------------------------------------------------------------------------------------
+# Type code of every Jacobian row BEFORE status masking, in acWLS's row order (acStateEstimation.jl:135-235): the library
+# rebuilds the H pattern from (code, index) and needs the code of a masked row as well (se.type holds status * code).
+function typeCodes(monitoring::Measurement)
+    volt, amp, watt, var, pmu = monitoring.voltmeter, monitoring.ammeter, monitoring.wattmeter, monitoring.varmeter, monitoring.pmu
+    code = Int8[]; status = Int8[]; corr = Int64[]
+    for i = 1:volt.number
+        push!(code, 1); push!(status, volt.magnitude.status[i])
+    end
+    for i = 1:amp.number
+        sq, from = amp.layout.square[i], amp.layout.from[i]
+        push!(code, sq ? (from ? 4 : 5) : (from ? 2 : 3)); push!(status, amp.magnitude.status[i])
+    end
+    for i = 1:watt.number
+        push!(code, watt.layout.bus[i] ? 6 : (watt.layout.from[i] ? 7 : 8)); push!(status, watt.active.status[i])
+    end
+    for i = 1:var.number
+        push!(code, var.layout.bus[i] ? 9 : (var.layout.from[i] ? 10 : 11)); push!(status, var.reactive.status[i])
+    end
+    for i = 1:pmu.number
+        sm, sa, from = pmu.magnitude.status[i], pmu.angle.status[i], pmu.layout.from[i]
+        if pmu.layout.polar[i]
+            if pmu.layout.bus[i]
+                append!(code, (12, 13))
+            else
+                append!(code, (pmu.layout.square[i] ? (from ? 4 : 5) : (from ? 2 : 3), from ? 14 : 15))
+            end
+            append!(status, (sm, sa))
+        else
+            pmu.layout.correlated[i] && push!(corr, length(code) + 1)
+            append!(code, pmu.layout.bus[i] ? (16, 17) : (from ? (18, 20) : (19, 21)))
+            append!(status, (sm * sa, sm * sa))
+        end
+    end
+    return code, status, corr
+end
+
+function pushMeasurement!(analysis::HipStateEstimation)       # se.mean, se.precision (diagonal + W[r, r+1] of correlated pairs)
+    se = analysis.method
+    _, _, corr = typeCodes(analysis.monitoring)
+    W = se.precision
+    wdiag = [W[r, r] for r = 1:length(se.mean)]
+    woff = Float64[W[r, r + 1] for r in corr]
+    check(ccall((:jg_gn_set_measurement, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Int64),
+        handle(analysis), se.mean, wdiag, isempty(woff) ? [0.0] : woff, 0, 0))
+end
+
+function pushStatus!(analysis::HipStateEstimation)            # update<Meter>!(...; status, square): se.type = status * code
+    code, status, _ = typeCodes(analysis.monitoring)
+    check(ccall((:jg_gn_set_status, lib), Cint, (Ptr{Cvoid}, Ptr{Int8}, Ptr{Int8}), handle(analysis), status, code))
+end
+
+pushVoltage!(analysis::HipStateEstimation) =
+    check(ccall((:jg_gn_set_voltage, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64),
+        handle(analysis), analysis.voltage.magnitude, analysis.voltage.angle, 0))
+
+pullVoltage!(analysis::HipStateEstimation) =
+    check(ccall((:jg_gn_get_voltage, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}),
+        handle(analysis), analysis.voltage.magnitude, analysis.voltage.angle))
+
+"""
+    gaussNewton(monitoring, HIP; device = 0)
+
+`gaussNewton(monitoring, LU)` of the reference builds the model (acWLS: type, index, range, mean, precision, Jacobian pattern);
+the device gets what acWLS derived, row by row, and rebuilds pattern, gain pattern and symbolic analysis from it.
+"""
+function gaussNewton(monitoring::Measurement, ::Type{HIP}; device::Int = 0)
+    base = gaussNewton(monitoring, LU)
+    m = base.method
+    method = GaussNewton{HIP}(m.jacobian, m.precision, m.mean, m.residual, m.increment, JuliaGrid.selectFactorization(HIP),
+        m.type, m.index, m.range, m.signature, 0.0, 0)
+    system = monitoring.system
+    analysis = AcStateEstimation(base.voltage, base.power, base.current, method, system, monitoring)
+    ac, br = system.model.ac, system.branch
+    code, status, corr = typeCodes(monitoring)
+    param = Matrix{Float64}(undef, 6, br.number)                          # [nb][6] row-major
+    for k = 1:br.number
+        param[:, k] .= (real(ac.admittance[k]), imag(ac.admittance[k]), br.parameter.conductance[k],
+                        br.parameter.susceptance[k], br.parameter.turnsRatio[k], br.parameter.shiftAngle[k])
+    end
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:jg_gn_create, lib), Cint,
+        (Ref{Ptr{Cvoid}}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64},
+         Int64, Int64, Ptr{Int8}, Ptr{Int8}, Ptr{Int64}, Int64, Ptr{Int64}, Int64, Cint),
+        h, system.bus.number, ac.nodalMatrix.colptr, ac.nodalMatrix.rowval, reim(ac.nodalMatrix.nzval),
+        reim(ac.nodalMatrixTranspose.nzval), br.number, br.layout.from, br.layout.to, param,
+        system.bus.layout.slack, length(code), code, status, m.index, length(corr), isempty(corr) ? Int64[0] : corr, 1, device))
+    HANDLES[method] = Handle(h[], :gn)
+    pushMeasurement!(analysis)
+    pushVoltage!(analysis)
+    return analysis
+end
+
+function increment!(analysis::HipStateEstimation)             # acStateEstimation.jl:878-904
+    se = analysis.method
+    maxInc = Vector{Float64}(undef, 1)
+    check(ccall((:jg_gn_increment, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), handle(analysis), maxInc))   # code 3: singular gain
+    check(ccall((:jg_gn_get_increment, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), handle(analysis), se.increment))
+    check(ccall((:jg_gn_get_residual, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), handle(analysis), se.residual))
+    se.signature[:pattern] = 0
+    return maxInc[1]
+end
+
+function solve!(analysis::HipStateEstimation)                 # acStateEstimation.jl:1035-1047
+    check(ccall((:jg_gn_solve, lib), Cint, (Ptr{Cvoid},), handle(analysis)))
+    pullVoltage!(analysis)
+    analysis.method.iteration += 1
+    return nothing
+end
+
+"method.jacobian (H, m x 2n) at the current state in the reference's CSC order, on request"
+function jacobian!(analysis::HipStateEstimation)
+    check(ccall((:jg_gn_get_jacobian, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), handle(analysis), analysis.method.jacobian.nzval))
+    return analysis.method.jacobian
+end
+
+"""
+    stateEstimation!(analysis::AcStateEstimation{GaussNewton{HIP}}; iteration, tolerance, power, current)
+
+The reference's loop (acStateEstimation.jl:1286-1329) fused on the device; the generic `stateEstimation!` works as well.
+"""
+function stateEstimation!(analysis::HipStateEstimation; iteration::Int64 = 40, tolerance::Float64 = 1e-8, power::Bool = false,
+                          current::Bool = false, verbose::Int64 = 0)
+    se = analysis.method
+    iters = Vector{Int32}(undef, 1); status = Vector{Int32}(undef, 1)
+    check(ccall((:jg_gn_run, lib), Cint, (Ptr{Cvoid}, Int64, Float64, Ptr{Int32}, Ptr{Int32}),
+        handle(analysis), iteration, tolerance, iters, status))
+    pullVoltage!(analysis)
+    check(ccall((:jg_gn_get_increment, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), handle(analysis), se.increment))
+    check(ccall((:jg_gn_get_residual, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), handle(analysis), se.residual))
+    se.iteration = iters[1]
+    se.signature[:pattern] = 0
+    status[1] == 3 && throw(ErrorException("The gain matrix is singular."))
+    power && JuliaGrid.power!(analysis)
+    current && JuliaGrid.current!(analysis)
+    return nothing
+end
+
+function setInitialPoint!(analysis::HipStateEstimation)       # acStateEstimation.jl:1071-1077
+    invoke(setInitialPoint!, Tuple{AcStateEstimation}, analysis)
+    pushVoltage!(analysis)
+end
+
+# update<Meter>!(analysis; label, ...): the reference updates the monitoring container AND se.mean / se.precision / se.type of
+# the analysis (measurement/*.jl: _update<Meter>!); the new values and masks follow to the device.  The Jacobian pattern stays.
+for (fn, T) in ((:updateVoltmeter!, :AcStateEstimation), (:updateAmmeter!, :AcStateEstimation), (:updateVarmeter!, :AcStateEstimation),
+                (:updateWattmeter!, :(Union{AcStateEstimation, JuliaGrid.DcStateEstimation})), (:updatePmu!, :(JuliaGrid.StateEstimation)))
+    @eval function $fn(analysis::HipStateEstimation; label, kwargs...)
+        invoke($fn, Tuple{$T}, analysis; label, kwargs...)
+        pushStatus!(analysis)
+        pushMeasurement!(analysis)
+    end
+end
+
+"""
+    largestNormalizedResidual(analysis) -> (value, row)
+
+Numeric part of residualTest! (badData.jl:181-311) on the device: gain and its factor at the current state, selected inverse on
+the factor pattern, normalised residuals, arg-max.  The label / status bookkeeping follows from `row` exactly as in
+badData.jl:225-300.
+"""
+function largestNormalizedResidual(analysis::HipStateEstimation)
+    mx = Vector{Float64}(undef, 1); idx = Vector{Int32}(undef, 1)
+    check(ccall((:jg_gn_residual_test, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int32}), handle(analysis), mx, idx))
+    return mx[1], Int64(idx[1])
+end
+
+export HIP, NewtonRaphsonBatch, setOutages!, jacobian!, largestNormalizedResidual
 
 end # module
