@@ -311,3 +311,53 @@ def test_change_of_the_slack_bus(jg):
     assert an.status == 0
     assert np.abs(an.voltage.magnitude - g["newtonRaphson_voltageMagnitude"]).max() <= 1e-8
     assert np.abs(an.voltage.angle - g["newtonRaphson_voltageAngle"]).max() <= 1e-8
+
+
+def test_headline_configuration_at_its_own_size(jg, oracle):
+    """The bench's configuration (BASELINE configs 3 / 5): case_ACTIVSg10k, 512 outage scenarios per batch, 3 batches in flight
+    through ContingencyPipeline, lanes compacted while a batch iterates.  Per scenario the pipeline returns bitwise what ONE
+    handle returns for the same batch; scenarios that finish in different iterations -- among them lanes the compaction moved --
+    equal the oracle solving that outage alone (iteration count, V, theta to 1e-8)."""
+    t = load_case("case_ACTIVSg10k")
+    s = jg.powerSystem(t)
+    base = jg.newtonRaphson(s)
+    jg.powerFlow_(base)
+    start = (base.voltage.magnitude.copy(), base.voltage.angle.copy())
+    base.close()
+    labels = [int(x) for x in jg.outageList(s, 3 * 512, seed=512)]
+    jobs = [labels[i:i + 512] for i in range(0, len(labels), 512)]
+    pipe = jg.ContingencyPipeline(s, 512, inflight=3, start=start)
+    got = {}
+    res = pipe.run(jobs, iteration=20, tolerance=1e-8,
+                   on_done=lambda j, h: got.__setitem__(j, (h._pull_voltage(), h.voltage.magnitude.copy(), h.voltage.angle.copy())))
+    one = jg.ContingencyPipeline(s, 512, inflight=1, start=start)
+    for j, job in enumerate(jobs):
+        ref = one.run([job], fetch=True)[0]
+        assert np.array_equal(ref[0], res[j][0]) and np.array_equal(ref[1], res[j][1])
+        assert np.array_equal(one.handles[0].voltage.magnitude, got[j][1]) and np.array_equal(one.handles[0].voltage.angle, got[j][2])
+    one.close()
+    it, st = res[0]
+    assert (st == 0).sum() >= 508 and len(set(it[st == 0].tolist())) >= 2
+    # scenarios of every iteration count that occurs; late finishers sit in lanes the compaction moved (they are packed to the front)
+    picks = []
+    for v in sorted(set(it[st == 0].tolist())):
+        idx = np.flatnonzero((it == v) & (st == 0))
+        picks += [int(idx[0]), int(idx[-1])]
+    late = np.flatnonzero((it == it[st == 0].max()) & (st == 0))
+    picks += [int(x) for x in late[:3]] + [5, 300, 511]
+    picks = sorted(set(picks))
+    assert len(picks) >= 8 and max(picks) >= 64
+    osys = oracle.OracleSystem(t)
+    for sc in picks:
+        o = oracle.OracleNR(osys)
+        ptr, dy = jg.outagePatch(s, jobs[0][sc])
+        for p, d in zip(ptr, dy):
+            o.add_ybus(p - 1, d)
+        o.set_voltage(*start)
+        stat = o.power_flow(iteration=20, tolerance=1e-8)
+        assert stat == st[sc]
+        if stat == 0:
+            vm, va = o.voltage()
+            assert it[sc] == o.iteration
+            assert np.abs(got[0][1][sc] - vm).max() <= 1e-8 and np.abs(got[0][2][sc] - va).max() <= 1e-8
+    pipe.close()
