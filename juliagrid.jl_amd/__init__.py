@@ -4,10 +4,11 @@ Host-side mirror of the JuliaGrid interface for the hot path only (see DESIGN.md
 in libjgrid_hip.so (hand-written HIP for gfx950) through the C ABI of include/jgrid.h.
 """
 from .system import PowerSystem, CscMatrix, powerSystem, acModel_          # noqa: F401
+from .system import addBranch_ as addBranchSystem_, dropZeros_ as dropZerosSystem_   # noqa: F401
 from .system import (updateBranch_ as updateBranchSystem_, updateBus_ as updateBusSystem_,   # noqa: F401
                      updateGenerator_ as updateGeneratorSystem_)
 from .powerflow import (AcPowerFlow, newtonRaphson, fastNewtonRaphsonBX, fastNewtonRaphsonXB, mismatch_, solve_, powerFlow_, setInitialPoint_,   # noqa: F401
-                        updateBranch_, updateBus_, updateGenerator_, setOutage_, setOutages_, setInjection_, outagePatch, initializeACPowerFlow, power_, current_, reactiveLimit_, adjustAngle_)
+                        updateBranch_, updateBus_, updateGenerator_, addBranch_, dropZeros_, setOutage_, setOutages_, setInjection_, outagePatch, initializeACPowerFlow, power_, current_, reactiveLimit_, adjustAngle_)
 from .contingency import bridges, outageList, shard, contingencyAnalysis, gatherResults, unpackResults, ContingencyPipeline   # noqa: F401
 from .measurement import (Measurement, measurement, ems, addVoltmeter_, addAmmeter_, addWattmeter_, addVarmeter_,   # noqa: F401
                           addPmu_, exactQuantities)
@@ -27,5 +28,5 @@ __all__ = [
     "updateVoltmeter_", "updateAmmeter_", "updateWattmeter_", "updateVarmeter_", "updatePmu_",
     "outagePatch", "initializeACPowerFlow", "bridges", "outageList", "shard", "contingencyAnalysis", "gatherResults", "unpackResults",
     "WlsMethod", "Normal", "LU", "KLU", "QR", "LDLt", "LL", "Orthogonal", "PetersWilkinson",
-    "pegaseShaped", "case9241synth", "ContingencyPipeline", "setOutages_", "power_", "current_", "reactiveLimit_", "adjustAngle_",
+    "addBranch_", "dropZeros_", "addBranchSystem_", "dropZerosSystem_", "pegaseShaped", "case9241synth", "ContingencyPipeline", "setOutages_", "power_", "current_", "reactiveLimit_", "adjustAngle_",
 ]

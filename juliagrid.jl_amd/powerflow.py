@@ -66,9 +66,23 @@ class AcPowerFlow:
     """AcPowerFlow{NewtonRaphson{HIP}} (src/definition/analysis.jl:154-164, 252-258)."""
 
     def __init__(self, system: PowerSystem, batch: int, device: int, max_patch: int):
-        L = _lib.lib()
         self.system = system
         self.batch = int(batch)
+        self._device, self._max_patch = int(device), int(max_patch)
+        self._injection = None                                           # per-scenario injections set by the caller (kept for a rebuild)
+        self._h = None
+        self._create()
+        self.voltage = NS(magnitude=None, angle=None)
+        self.power = NS(injection=None, supply=None, shunt=None, from_=None, to=None, charging=None, series=None, generator=None)
+        self.current = NS(injection=None, from_=None, to=None, series=None)
+        self._outage_labels = np.zeros(self.batch, dtype=np.int64)     # branch out of service per scenario (0 = none)
+        self._branches_on_device = False
+        self.status = None
+
+    def _create(self):
+        """jg_nr_create from the system's CURRENT nodal matrix: newtonJacobian (maps, pattern), symbolic analysis, upload."""
+        L = _lib.lib()
+        system, device, max_patch = self.system, self._device, self._max_patch
         ac = system.model.ac
         Y, YT = ac.nodalMatrix, ac.nodalMatrixTranspose
         n = system.bus.number
@@ -84,14 +98,10 @@ class AcPowerFlow:
         jcolptr = np.zeros(self.dims["dimJ"] + 1, dtype=np.int64)
         jrowval = np.zeros(self.dims["nnzJ"], dtype=np.int64)
         _lib.check(L.jg_nr_get_maps(self._h, pq, pvpq, pcount, jcolptr, jrowval))
-        self.method = NS(pq=pq, pvpq=pvpq, pcount=pcount, iteration=0, _jcolptr=jcolptr, _jrowval=jrowval,
-                         signature=NS(topology=system.model.revision.topology, type=system.model.revision.type))
-        self.voltage = NS(magnitude=None, angle=None)
-        self.power = NS(injection=None, supply=None, shunt=None, from_=None, to=None, charging=None, series=None, generator=None)
-        self.current = NS(injection=None, from_=None, to=None, series=None)
-        self._outage_labels = np.zeros(self.batch, dtype=np.int64)     # branch out of service per scenario (0 = none)
-        self._branches_on_device = False
-        self.status = None
+        keep = getattr(self, "method", None)
+        self.method = NS(pq=pq, pvpq=pvpq, pcount=pcount, iteration=0 if keep is None else keep.iteration, _jcolptr=jcolptr, _jrowval=jrowval,
+                         signature=NS(topology=system.model.revision.topology, type=system.model.revision.type,
+                                      acPattern=system.model.revision.acPattern))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -180,6 +190,7 @@ def setInjection_(an: AcPowerFlow, active=None, reactive=None):
     q = np.ascontiguousarray(q, dtype=np.float64)
     stride = 0 if p.ndim == 1 else bus.number
     _lib.check(_lib.lib().jg_nr_set_injection(an._h, p.reshape(-1), q.reshape(-1), stride))
+    an._injection = None if active is None and reactive is None else (p.copy(), q.copy())
 
 
 def newtonRaphson(system: PowerSystem, batch: int = 1, device: int = 0, max_patch: int | None = None) -> AcPowerFlow:
@@ -294,6 +305,8 @@ def fastNewtonRaphsonXB(system: PowerSystem, batch: int = 1, device: int = 0) ->
 
 def mismatch_(an: AcPowerFlow):
     """mismatch!(analysis) -> (max|f_P|, max|f_Q|); arrays of length batch when batch > 1."""
+    if an.system.model.revision.acPattern != an.method.signature.acPattern:
+        _rebuild(an)                                              # the device copy of Ybus has the old pattern
     p = np.zeros(an.batch)
     q = np.zeros(an.batch)
     fn = _lib.lib().jg_nr_fast_mismatch if getattr(an.method, "fast", False) else _lib.lib().jg_nr_mismatch
@@ -301,10 +314,40 @@ def mismatch_(an: AcPowerFlow):
     return (float(p[0]), float(q[0])) if an.batch == 1 else (p, q)
 
 
+def _rebuild(an: AcPowerFlow):
+    """The Ybus pattern changed under a live analysis (addBranch! between buses that had no entry, dropZeros!): the reference
+    rebuilds the Jacobian and factorises from scratch on the next solve! (acPowerFlow.jl:806-811, 890-897).  Here the handle
+    is rebuilt -- new maps, new symbolic analysis -- and the state of the analysis moves over: voltages, injections, outages."""
+    vm, va = np.zeros((an.batch, an.system.bus.number)), np.zeros((an.batch, an.system.bus.number))
+    _lib.check(_lib.lib().jg_nr_get_voltage(an._h, vm, va))
+    old = an.method
+    fast = getattr(old, "fast", False)
+    _lib.lib().jg_nr_destroy(an._h)
+    an._h = None
+    an._create()
+    if fast:                                                     # the fast method's own containers (B', B'', its numbering) stay
+        for k, v in vars(old).items():
+            if not hasattr(an.method, k):
+                setattr(an.method, k, v)
+    inj = an._injection
+    if inj is not None:
+        setInjection_(an, *inj)
+    else:
+        setInjection_(an)
+    _push_voltage(an, vm, va)
+    an._branches_on_device = False
+    if np.any(an._outage_labels):
+        setOutages_(an, [int(x) for x in an._outage_labels])
+    if fast:
+        _refresh_fast(an)
+
+
 def _check_signature(an: AcPowerFlow):
     rev, sig = an.system.model.revision, an.method.signature
     if rev.topology != sig.topology or rev.type != sig.type:     # acPowerFlow.jl:802-804
         raise RuntimeError("The power flow model cannot be reused due to required bus type conversion.")
+    if rev.acPattern != sig.acPattern:                            # acPowerFlow.jl:806-811
+        _rebuild(an)
 
 
 def solve_(an: AcPowerFlow):
@@ -345,6 +388,8 @@ def setInitialPoint_(an: AcPowerFlow, source=None):
 
 
 def _upload_ybus(an: AcPowerFlow):
+    if an.system.model.revision.acPattern != an.method.signature.acPattern:
+        return                                                    # new pattern: the next solve rebuilds the device model (_rebuild)
     ac = an.system.model.ac
     _lib.check(_lib.lib().jg_nr_set_ybus(an._h, _reim(ac.nodalMatrix.nzval), _reim(ac.nodalMatrixTranspose.nzval)))
 
@@ -360,11 +405,35 @@ def updateBranch_(an: AcPowerFlow, label: int, status: int | None = None, **para
     _refresh_fast(an)
 
 
+def addBranch_(an: AcPowerFlow, **kwargs) -> int:
+    """addBranch!(analysis; from, to, ...) (branch.jl:182-188): the branch joins the system; if its buses had no Ybus entry yet the
+    pattern revision moves and the next mismatch! / solve! / powerFlow! rebuilds the device model (acPowerFlow.jl:806-811)."""
+    rev, sig = an.system.model.revision, an.method.signature
+    if rev.type != sig.type:                                      # errorTypeConversion (branch.jl:190-192)
+        raise RuntimeError("The power flow model cannot be reused due to required bus type conversion.")
+    from .system import addBranch_ as _add
+    label = _add(an.system, **kwargs)
+    if rev.acPattern == sig.acPattern:
+        _upload_ybus(an)                                          # same pattern: new values only
+        _refresh_fast(an)
+    an._branches_on_device = False
+    sig.topology = rev.topology                                   # syncTopology!
+    return label
+
+
+def dropZeros_(an: AcPowerFlow) -> None:
+    """dropZeros!(system, system.model.ac) under a live analysis (model.jl:342-352)."""
+    from .system import dropZeros_ as _drop
+    _drop(an.system)
+
+
 def _refresh_fast(an: AcPowerFlow):
     """fast Newton-Raphson keeps two CONSTANT matrices: after a change of the grid they are rebuilt and refactorised
     (the reference patches them entry by entry and calls lu! again, acPowerFlow.jl:476-537)."""
     if not getattr(an.method, "fast", False):
         return
+    if an.system.model.revision.acPattern != an.method.signature.acPattern:
+        return                                                    # _rebuild refreshes them on the new pattern
     P, Q, _, _, bp, bq = _fast_model(an.system, an.method.bx)
     _lib.check(_lib.lib().jg_nr_fast_setup(an._h, np.ascontiguousarray(bp), np.ascontiguousarray(bq)))
     an.method.active.jacobian, an.method.reactive.jacobian = P, Q

@@ -108,6 +108,20 @@ class CscMatrix:
             raise KeyError("The sparse matrix pattern does not contain the requested entry.")
         return p
 
+    def has(self, row, col):
+        lo, hi = self.colptr[col - 1] - 1, self.colptr[col] - 1
+        p = lo + int(np.searchsorted(self.rowval[lo:hi], row))
+        return p < hi and self.rowval[p] == row
+
+    def insert(self, row, col):
+        """A[row, col] += x on an absent entry of a SparseMatrixCSC: a structural entry (value 0) at its sorted place."""
+        lo, hi = self.colptr[col - 1] - 1, self.colptr[col] - 1
+        p = lo + int(np.searchsorted(self.rowval[lo:hi], row))
+        self.rowval = np.insert(self.rowval, p, row)
+        self.nzval = np.insert(self.nzval, p, 0)
+        self.colptr = self.colptr.copy()
+        self.colptr[col:] += 1
+
     def toscipy(self):
         import scipy.sparse as sp
         return sp.csc_matrix((self.nzval, self.rowval - 1, self.colptr - 1), shape=(self.n, self.n))
@@ -286,6 +300,73 @@ def _ac_nodal_update(system: PowerSystem, k: int, sign: float) -> None:
     system.model.revision.acModel += 1
 
 
+def _ensure_pair(system: PowerSystem, i: int, j: int) -> None:
+    """Structural entries (i,j) and (j,i) of Ybus and of its transpose copy; a new one changes the pattern (model.jl:103-107)."""
+    ac = system.model.ac
+    grew = False
+    for A in (ac.nodalMatrix, ac.nodalMatrixTranspose):
+        for r, c in ((i, j), (j, i)):
+            if not A.has(r, c):
+                A.insert(r, c)
+                grew = True
+    if grew:
+        system.model.revision.acPattern += 1
+
+
+def addBranch_(system: PowerSystem, from_: int, to: int, resistance: float = 0.0, reactance: float = 0.0, conductance: float = 0.0,
+               susceptance: float = 0.0, turnsRatio: float = 1.0, shiftAngle: float = 0.0, status: int = 1) -> int:
+    """addBranch!(system; from, to, ...) (branch.jl:79-167), per-unit / radian inputs, bus LABELS for from / to.
+    Returns the new branch label (its 1-based index).  On a built AC model an in-service branch enters the nodal matrix like
+    acNodalUpdate! does it (model.jl:81-110): a pair of buses that had no entry yet grows the pattern (acPattern revision)."""
+    if from_ == to:
+        raise ValueError("Invalid value for from or to keywords.")
+    if resistance == 0.0 and reactance == 0.0:
+        raise ValueError("At least one of resistance or reactance is required.")
+    if status not in (0, 1):
+        raise ValueError("The status must be 0 or 1.")
+    try:
+        i, j = system.bus.label[int(from_)], system.bus.label[int(to)]
+    except KeyError as e:
+        raise KeyError(f"The bus label {e.args[0]} that has been specified does not exist.") from None
+    br = system.branch
+    lay, par = br.layout, br.parameter
+    lay.from_ = np.append(lay.from_, i)
+    lay.to = np.append(lay.to, j)
+    lay.status = np.append(lay.status, np.int8(status))
+    for name, v in (("resistance", resistance), ("reactance", reactance), ("conductance", conductance), ("susceptance", susceptance),
+                    ("turnsRatio", turnsRatio), ("shiftAngle", shiftAngle)):
+        setattr(par, name, np.append(getattr(par, name), float(v)))
+    br.number += 1
+    k = br.number - 1
+    ac = system.model.ac
+    if ac.nodalMatrix is not None:
+        for name in ("admittance", "nodalFromFrom", "nodalFromTo", "nodalToTo", "nodalToFrom"):          # acPushZeros!
+            setattr(ac, name, np.append(getattr(ac, name), 0j))
+        if status == 1:
+            y, yff, yft, ytt, ytf = _branch_two_port(*(np.array([getattr(par, nm)[k]]) for nm in
+                                                       ("resistance", "reactance", "conductance", "susceptance", "turnsRatio", "shiftAngle")))
+            ac.admittance[k], ac.nodalFromFrom[k], ac.nodalFromTo[k], ac.nodalToTo[k], ac.nodalToFrom[k] = y[0], yff[0], yft[0], ytt[0], ytf[0]
+            _ensure_pair(system, i, j)
+            _ac_nodal_update(system, k, +1.0)
+    system.model.revision.topology += 1                                                                     # topologyChanged!
+    return br.number
+
+
+def dropZeros_(system: PowerSystem) -> None:
+    """dropZeros!(system, system.model.ac) (model.jl:342-352): stored zeros of Ybus (out-of-service branches) leave the pattern;
+    if any did, the pattern revision moves and every analysis rebuilds its Jacobian on its next solve."""
+    ac = system.model.ac
+    before = ac.nodalMatrix.nnz
+    for A in (ac.nodalMatrix, ac.nodalMatrixTranspose):
+        keep = A.nzval != 0
+        col_of = np.repeat(np.arange(A.n), np.diff(A.colptr))
+        colptr = np.zeros(A.n + 1, dtype=np.int64)
+        np.add.at(colptr, col_of[keep] + 1, 1)
+        A.colptr, A.rowval, A.nzval = np.cumsum(colptr) + 1, A.rowval[keep], A.nzval[keep]
+    if ac.nodalMatrix.nnz != before:
+        system.model.revision.acPattern += 1
+
+
 def updateBranch_(system: PowerSystem, label: int, status: int | None = None, resistance=None, reactance=None,
                   conductance=None, susceptance=None, turnsRatio=None, shiftAngle=None) -> None:
     """updateBranch!(system; label, status, resistance, reactance, conductance, susceptance, turnsRatio, shiftAngle)
@@ -319,6 +400,7 @@ def updateBranch_(system: PowerSystem, label: int, status: int | None = None, re
                                                  par.turnsRatio[k:k + 1], par.shiftAngle[k:k + 1])
         ac.admittance[k], ac.nodalFromFrom[k], ac.nodalFromTo[k] = y[0], yff[0], yft[0]
         ac.nodalToTo[k], ac.nodalToFrom[k] = ytt[0], ytf[0]
+        _ensure_pair(system, int(system.branch.layout.from_[k]), int(system.branch.layout.to[k]))      # after dropZeros!: the entry comes back
         _ac_nodal_update(system, k, +1.0)
     system.branch.layout.status[k] = new
     if new != old:

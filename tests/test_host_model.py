@@ -145,3 +145,39 @@ def test_update_bus_type_and_slack_rules(jg):
     assert s.model.revision.type == rev[0] + 2 and s.model.revision.slack == rev[1] + 2
     jg.updateBusSystem_(s, label=3, type=3)                       # no change, no new revision
     assert s.model.revision.type == rev[0] + 2
+
+
+def test_add_branch_and_drop_zeros_keep_the_model_equal_to_a_fresh_one(jg, oracle):
+    """addBranch! / dropZeros! / updateBranch! on a built AC model (branch.jl:79-167, model.jl:81-110, 342-352): values equal the
+    model built from scratch out of the edited tables; the pattern revision moves exactly when the pattern does."""
+    from test_reusing_pf_gpu import _tables_of
+    s = jg.powerSystem(load_case("case14test"))
+    jg.acModel_(s)
+    rev = s.model.revision
+
+    def same_as_fresh():
+        f = jg.powerSystem(_tables_of(s))
+        jg.acModel_(f)
+        a, b = s.model.ac, f.model.ac
+        assert np.abs(a.nodalMatrix.toscipy().toarray() - b.nodalMatrix.toscipy().toarray()).max() < 1e-14
+        assert np.abs(a.nodalMatrixTranspose.toscipy().toarray() - b.nodalMatrix.toscipy().toarray().T).max() < 1e-14
+        return b.nodalMatrix.nnz
+
+    p0, nnz0 = rev.acPattern, s.model.ac.nodalMatrix.nnz
+    jg.addBranchSystem_(s, from_=2, to=3, resistance=0.02, reactance=0.35)           # parallel to an existing branch: same pattern
+    assert rev.acPattern == p0 and s.model.ac.nodalMatrix.nnz == nnz0 == same_as_fresh()
+    jg.addBranchSystem_(s, from_=11, to=12, reactance=0.12, turnsRatio=0.95, shiftAngle=-0.17)
+    assert rev.acPattern == p0 + 1 and s.model.ac.nodalMatrix.nnz == nnz0 + 2 == same_as_fresh()
+    jg.addBranchSystem_(s, from_=16, to=7, resistance=0.01, reactance=0.23, status=0)   # out of service: no entry (branch.jl:143-150)
+    assert rev.acPattern == p0 + 1 and s.model.ac.nodalMatrix.nnz == nnz0 + 2
+    jg.updateBranchSystem_(s, label=s.branch.number, status=1)                          # ... until it goes into service
+    assert rev.acPattern == p0 + 2 and s.model.ac.nodalMatrix.nnz == nnz0 + 4 == same_as_fresh()
+    jg.updateBranchSystem_(s, label=s.branch.number, status=0)
+    assert s.model.ac.nodalMatrix.nnz == nnz0 + 4                                        # stored zeros stay (model.jl:70-71) ...
+    jg.dropZerosSystem_(s)
+    assert s.model.ac.nodalMatrix.nnz < nnz0 + 4 and rev.acPattern == p0 + 3             # ... until dropZeros!
+    same_as_fresh()
+    with pytest.raises(ValueError):
+        jg.addBranchSystem_(s, from_=2, to=2, reactance=0.1)
+    with pytest.raises(ValueError):
+        jg.addBranchSystem_(s, from_=2, to=3)

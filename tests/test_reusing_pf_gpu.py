@@ -32,7 +32,7 @@ def _tables_of(s):
         gen_qmax=s.generator.capability.maxReactive.copy())
 
 
-def _reuse_check(jg, oracle, an, make, fast=None):
+def _reuse_check(jg, oracle, an, make, fast=None, same_pattern=True):
     fresh = make(jg.powerSystem(_tables_of(an.system)))
     jg.powerFlow_(fresh, iteration=100, tolerance=1e-10)
     jg.setInitialPoint_(an)
@@ -45,8 +45,9 @@ def _reuse_check(jg, oracle, an, make, fast=None):
         o = oracle.OracleNR(osys)
         assert o.power_flow(100, 1e-10) == 0
     else:
-        assert np.allclose(an.method.active.jacobian.nzval, fresh.method.active.jacobian.nzval, rtol=1e-13, atol=0)
-        assert np.allclose(an.method.reactive.jacobian.nzval, fresh.method.reactive.jacobian.nzval, rtol=1e-13, atol=0)
+        if same_pattern:                                         # (after dropZeros! a fresh model stores zeros the reused one dropped)
+            assert np.allclose(an.method.active.jacobian.nzval, fresh.method.active.jacobian.nzval, rtol=1e-13, atol=0)
+            assert np.allclose(an.method.reactive.jacobian.nzval, fresh.method.reactive.jacobian.nzval, rtol=1e-13, atol=0)
         o = oracle.OracleFastNR(osys, bx=fast)
         assert o.power_flow(100, 1e-10) == 0
     vm, va = o.voltage() if fast is None else (o.vm, o.va)
@@ -122,3 +123,60 @@ def test_generator_status_and_type_conversion(jg, oracle):
         jg.updateGenerator_(an, label=single[0][0], status=0)
     assert s.generator.layout.status[single[0][0] - 1] == 1      # refused before the system was touched
     an.close()
+
+
+ADD_STEPS = [                                                    # reusing.jl:40-50: new branches, some between buses with no Ybus entry yet
+    dict(from_=2, to=3, resistance=0.02, reactance=0.35),
+    dict(from_=3, to=5, resistance=0.02, reactance=0.35, conductance=0.001),
+    dict(from_=11, to=12, reactance=0.12, turnsRatio=0.95, shiftAngle=-0.17),
+    dict(from_=16, to=7, resistance=0.01, reactance=0.23, susceptance=0.1),
+]
+
+
+@pytest.mark.parametrize("kind", ["nr", "bx"])
+def test_pattern_changing_edits_rebuild_the_model(jg, oracle, kind):
+    """addBranch!(analysis; ...) and dropZeros! on a live analysis (test/powerFlow/reusing.jl:40-50, test/powerFlow/analysis.jl:100-109;
+    acPowerFlow.jl:806-811): when the Ybus pattern changes the next solve rebuilds maps, pattern and symbolic analysis, and the
+    analysis keeps answering like a fresh one."""
+    make = {"nr": jg.newtonRaphson, "bx": jg.fastNewtonRaphsonBX}[kind]
+    fast = None if kind == "nr" else True
+    s = jg.powerSystem(load_case("case14test"))
+    an = make(s)
+    _reuse_check(jg, oracle, an, make, fast)
+    pattern = [s.model.revision.acPattern]
+    for kw in ADD_STEPS:
+        jg.addBranch_(an, **kw)
+        pattern.append(s.model.revision.acPattern)
+        _reuse_check(jg, oracle, an, make, fast)
+    assert pattern[-1] > pattern[0] and len(set(pattern)) < len(pattern)      # some additions grew the pattern, some did not
+    nnz_j = an.dims["nnzJ"]
+    jg.updateBranch_(an, label=5, status=0)
+    jg.dropZeros_(an)                                            # the stored zeros of the branches out of service leave Ybus
+    _reuse_check(jg, oracle, an, make, fast, same_pattern=False)
+    assert an.dims["nnzJ"] < nnz_j                               # the Jacobian pattern followed
+    jg.updateBranch_(an, label=5, status=1)                      # ... and the entries come back with the branch
+    _reuse_check(jg, oracle, an, make, fast, same_pattern=False)
+    assert an.dims["nnzJ"] <= nnz_j                              # (a model built from scratch stores the zeros of the other branch out of service again)
+    an.close()
+
+
+def test_batched_analysis_survives_a_pattern_change(jg, oracle):
+    """A batch with per-scenario outages and injections: after addBranch! between two unconnected buses the rebuilt handle still
+    holds every scenario's outage (re-expressed on the new pattern), injections and state."""
+    s = jg.powerSystem(load_case("case118"))
+    labels = [int(x) for x in jg.outageList(s, 6, seed=3)] + [0]
+    an = jg.contingencyAnalysis(s, labels)
+    scale = np.linspace(0.9, 1.1, len(labels))[:, None]
+    jg.setInjection_(an, (s.bus.supply.active - s.bus.demand.active)[None, :] * scale, (s.bus.supply.reactive - s.bus.demand.reactive)[None, :] * scale)
+    f, t = int(s.branch.layout.from_[0]), 60
+    Y = s.model.ac.nodalMatrix
+    assert not Y.has(f, t)
+    inv = {v: k for k, v in s.bus.label.items()}
+    jg.addBranch_(an, from_=inv[f], to=inv[t], resistance=0.01, reactance=0.2)
+    jg.powerFlow_(an, iteration=30, tolerance=1e-10)
+    assert np.all(an.status == 0)
+    fresh_sys = jg.powerSystem(_tables_of(s))
+    fresh = jg.contingencyAnalysis(fresh_sys, labels)
+    jg.setInjection_(fresh, (s.bus.supply.active - s.bus.demand.active)[None, :] * scale, (s.bus.supply.reactive - s.bus.demand.reactive)[None, :] * scale)
+    jg.powerFlow_(fresh, iteration=30, tolerance=1e-10)
+    assert np.abs(an.voltage.magnitude - fresh.voltage.magnitude).max() < 1e-8 and np.abs(an.voltage.angle - fresh.voltage.angle).max() < 1e-8
