@@ -99,6 +99,13 @@ int jg_nr_mismatch(jg_nr* h, double* max_p, double* max_q);
 /* solve!(analysis) -- acPowerFlow.jl:793-911: Jacobian fill, refactorization, solve, state update,
  * iteration += 1, for every scenario. */
 int jg_nr_solve(jg_nr* h);
+/* Guard of the static-pivot factorisation, opt-in.  mode 1: every Newton step (jg_nr_solve and the steps of jg_nr_run) is followed
+ * by ONE step of iterative refinement, rho = f - J d, d += J^-1 rho, before the state moves -- what the reference gets from
+ * UMFPACK's solve behind ldiv! (src/backend/utility.jl:576-586; UMFPACK refines by default, KLU does not).  J d is formed from
+ * Ybus and the state (the factor has overwritten J); costs one more pass over the rows, a forward-only and a backward sweep
+ * (~ +45 % per iteration).  Independent of the mode a pivot block that cancels to rounding level marks its scenario (status 3).
+ * mode 0 (default): no refinement -- Newton's iteration corrects a rounding-level error of one step in the next. */
+int jg_nr_set_refine(jg_nr* h, int mode);
 /* powerFlow!(analysis; iteration, tolerance) -- acPowerFlow.jl:1389-1433, per scenario, with the
  * reference's loop accounting.  iters/status: [batch]; status 0 converged, 1 iteration limit,
  * 3 numeric failure. */

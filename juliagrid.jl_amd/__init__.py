@@ -7,7 +7,7 @@ from .system import PowerSystem, CscMatrix, powerSystem, acModel_          # noq
 from .system import addBranch_ as addBranchSystem_, dropZeros_ as dropZerosSystem_   # noqa: F401
 from .system import (updateBranch_ as updateBranchSystem_, updateBus_ as updateBusSystem_,   # noqa: F401
                      updateGenerator_ as updateGeneratorSystem_)
-from .powerflow import (AcPowerFlow, newtonRaphson, fastNewtonRaphsonBX, fastNewtonRaphsonXB, mismatch_, solve_, powerFlow_, setInitialPoint_,   # noqa: F401
+from .powerflow import (AcPowerFlow, newtonRaphson, fastNewtonRaphsonBX, fastNewtonRaphsonXB, mismatch_, solve_, powerFlow_, setInitialPoint_, setRefinement_,   # noqa: F401
                         updateBranch_, updateBus_, updateGenerator_, addBranch_, dropZeros_, setOutage_, setOutages_, setInjection_, outagePatch, initializeACPowerFlow, power_, current_, reactiveLimit_, adjustAngle_)
 from .contingency import bridges, outageList, shard, contingencyAnalysis, gatherResults, unpackResults, ContingencyPipeline   # noqa: F401
 from .measurement import (Measurement, measurement, ems, addVoltmeter_, addAmmeter_, addWattmeter_, addVarmeter_,   # noqa: F401
@@ -22,7 +22,7 @@ from . import _lib                                                           # n
 
 __all__ = [
     "PowerSystem", "CscMatrix", "powerSystem", "acModel_", "updateBranchSystem_", "updateBusSystem_", "updateGeneratorSystem_", "updateBus_", "updateGenerator_", "AcPowerFlow", "newtonRaphson", "fastNewtonRaphsonBX", "fastNewtonRaphsonXB",
-    "mismatch_", "solve_", "powerFlow_", "setInitialPoint_", "updateBranch_", "setOutage_", "setInjection_",
+    "mismatch_", "solve_", "powerFlow_", "setInitialPoint_", "setRefinement_", "updateBranch_", "setOutage_", "setInjection_",
     "Measurement", "measurement", "ems", "addVoltmeter_", "addAmmeter_", "addWattmeter_", "addVarmeter_", "addPmu_",
     "exactQuantities", "AcStateEstimation", "PmuStateEstimation", "pmuStateEstimation", "gaussNewton", "incrementSE_", "solveSE_", "stateEstimation_", "setNoise_", "residualTest_", "normalizedResidual", "chiTest",
     "updateVoltmeter_", "updateAmmeter_", "updateWattmeter_", "updateVarmeter_", "updatePmu_",

@@ -54,6 +54,7 @@ def lib():
         "jg_nr_set_ybus": [VP, F64P, F64P],
         "jg_nr_mismatch": [VP, F64P, F64P],
         "jg_nr_solve": [VP],
+        "jg_nr_set_refine": [VP, C.c_int],
         "jg_nr_run": [VP, C.c_int64, C.c_double, I32P, I32P],
         "jg_nr_get_mismatch": [VP, F64P],
         "jg_nr_get_increment": [VP, F64P],

@@ -173,6 +173,86 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(AsmArgs a) {
     }
 }
 
+// ---- iterative refinement of the Newton step (opt-in, jg_nr_set_refine) ------------------------------------------------
+// The reference's default solver refines: UMFPACK's solve runs up to two steps of iterative refinement behind `ldiv!`
+// (/root/reference/src/backend/utility.jl:576-586 -> umfpack_solve, UMFPACK_IRSTEP = 2), which is what covers a weak pivot
+// of ITS threshold pivoting.  The device keeps a static pivot order, so the same guard is offered here: after the first solve
+//   rho = f - J d         (this kernel: J is NOT stored -- the factor overwrote it -- so the product is formed from Ybus
+//                          and the unchanged state with the same sincos terms the assembly uses, one pass over the rows)
+//   d  += J^-1 rho        (forward-only sweep + backward sweep on the factor that is already there), then x -= d.
+struct RefineArgs {
+    const int* rowptr; const int* colm; const double2* GB; const int* rowtype;
+    const double* vm; const double* va;
+    const int* ppos; const double* pdg; const double* pdb;
+    const double* F; const double* inc; double* R; jg::GroupSel sel;
+    int n; int ld; int mp; int nchunk; int lanes;
+};
+
+template <int MP>
+__global__ __launch_bounds__(64 * ASM_WAVES) void k_refine_residual(RefineArgs a) {
+    int grp, bx;
+    if (!jg::map_block(a.sel, a.ld, a.nchunk, grp, bx)) return;
+    const int lane = threadIdx.x;
+    const int wave = uniform(threadIdx.y);
+    const size_t ld = (size_t)a.ld;
+    const size_t b = (size_t)min(grp * 64 + lane, a.lanes - 1);
+    int ppos[MP > 0 ? MP : 1];
+#pragma unroll
+    for (int m = 0; m < MP; ++m) ppos[m] = a.ppos[(size_t)m * ld + b];
+    const int r0 = bx * ASM_ROWS, r1 = min(r0 + ASM_ROWS, a.n);
+    for (int i = r0 + wave; i < r1; i += ASM_WAVES) {
+        const int p0 = uniform(a.rowptr[i]), p1 = uniform(a.rowptr[i + 1]);
+        const int ti = (int)((unsigned)uniform(a.rowtype[i]));
+        const double vi = a.vm[(size_t)i * ld + b], thi = a.va[(size_t)i * ld + b];
+        const double2 f = jg::load_vec(a.F, (size_t)i, b, ld);
+        const double2 di = jg::load_vec(a.inc, (size_t)i, b, ld);
+        double s1 = 0.0, s2 = 0.0, gii = 0.0, bii = 0.0, rp = f.x, rq = f.y;
+        for (int p = p0; p < p1; ++p) {
+            const int cm = uniform(a.colm[p]);
+            const int j = cm & 0xffffff, mk = cm >> 24;
+            double2 gb = a.GB[p];
+#pragma unroll
+            for (int m = 0; m < MP; ++m)
+                if (ppos[m] == p) { gb.x += a.pdg[(size_t)m * ld + b]; gb.y += a.pdb[(size_t)m * ld + b]; }
+            const double vj = a.vm[(size_t)j * ld + b];
+            double s, c;
+            sincos(thi - a.va[(size_t)j * ld + b], &s, &c);
+            const double ac = gb.x * c + gb.y * s, ad = gb.x * s - gb.y * c;
+            s1 += vj * ac;
+            s2 += vj * ad;
+            if (j == i) { gii = gb.x; bii = gb.y; continue; }
+            const double2 dj = jg::load_vec(a.inc, (size_t)j, b, ld);
+            rp -= ((mk & 1) ? vi * vj * ad : 0.0) * dj.x + ((mk & 2) ? vi * ac : 0.0) * dj.y;
+            rq -= ((mk & 4) ? -(vi * vj) * ac : 0.0) * dj.x + ((mk & 8) ? vi * ad : 0.0) * dj.y;
+        }
+        double d00 = -vi * s2 - bii * (vi * vi), d01 = s1 + gii * vi, d10 = vi * s1 - gii * (vi * vi), d11 = s2 - bii * vi;
+        if (ti == 3) { d00 = 1.0; d01 = 0.0; d10 = 0.0; d11 = 1.0; }
+        else if (ti == 2) { d01 = 0.0; d10 = 0.0; d11 = 1.0; }
+        rp -= d00 * di.x + d01 * di.y;
+        rq -= d10 * di.x + d11 * di.y;
+        jg::store_vec(a.R, (size_t)i, b, ld, rp, rq);
+    }
+}
+
+// d = d1 + d2 (kept as method.increment), then x -= d on the state components of the scenarios still iterating
+__global__ void k_refine_apply(double* inc, const double* inc2, double* va, double* vm, const signed char* flags, const int* active,
+                               const jg::GroupSel sel, int n, int ld, int lanes) {
+    int grp, bx;
+    if (!jg::map_block(sel, ld, (n + 15) / 16, grp, bx)) return;
+    const int i = bx * 16 + threadIdx.y;
+    if (i >= n) return;
+    const int lb = grp * 64 + threadIdx.x;
+    if (lb >= lanes) return;
+    const size_t b = (size_t)lb, l = (size_t)ld;
+    if (active && !active[b]) return;
+    const double2 d1 = jg::load_vec(inc, (size_t)i, b, l), d2 = jg::load_vec(inc2, (size_t)i, b, l);
+    const double dx = d1.x + d2.x, dy = d1.y + d2.y;
+    jg::store_vec(inc, (size_t)i, b, l, dx, dy);
+    const int fl = flags[i];
+    if (fl & 1) va[(size_t)i * l + b] -= dx;
+    if (fl & 2) vm[(size_t)i * l + b] -= dy;
+}
+
 // ---- post-processing: power!/current! branch quantities (acAnalysis.jl:66-81, 688-701) -------------------------
 struct BranchArgs {
     const int* from; const int* to; const signed char* status; const double* param;   // param [nb][16], see jgrid.h
@@ -441,6 +521,7 @@ struct jg_nr {
     double* d_vm0 = nullptr; double* d_va0 = nullptr;   // snapshot of the start point
     int* d_active = nullptr; int* d_iters = nullptr; int* d_status = nullptr; int* d_counter = nullptr; int* d_group = nullptr;
     int* d_lid = nullptr; int* d_dest = nullptr; int* d_cflags = nullptr; int* d_itmp = nullptr; int* d_glist = nullptr;   // scenario compaction
+    bool refine = false;                              // one step of iterative refinement per Newton step (jg_nr_set_refine)
     bool fast = false;                                // fast decoupled mode (jg_nr_fast_setup): constant B', B'' factorised once
     double* d_R = nullptr;                            // rhs of the half-iterations
     double* d_inc2[2] = {nullptr, nullptr};           // increments of the theta / V half-iterations
@@ -541,6 +622,30 @@ void launch_compact(jg_nr* h, int restore, bool report = false) {
     permute2(h->d_inc, h->n);
 }
 
+// solve! numerics on the groups of `sel`: factorise the Jacobian that is in place, solve, update the state (active: nullable)
+int newton_step(jg_nr* h, const jg::GroupSel& sel, const int* active) {
+    if (int rc = h->eng.factor(h->stream, nullptr, h->d_F, sel)) return rc;
+    if (!h->refine) {
+        jg::StateUpdate upd{h->d_va, h->d_vm, h->d_flags, active, -1.0};
+        return h->eng.backsolve(h->stream, h->d_inc, upd, sel);
+    }
+    jg::StateUpdate none{};
+    if (int rc = h->eng.backsolve(h->stream, h->d_inc, none, sel)) return rc;
+    RefineArgs a{h->d_rowptr, h->d_col, h->d_GB, h->d_rowtype, h->d_vm, h->d_va, h->d_ppos, h->d_pdg, h->d_pdb,
+                 h->d_F, h->d_inc, h->d_R, sel, h->n, h->ld, h->mp, h->nchunk, h->batch};
+    dim3 grid((unsigned)h->nchunk * jg::group_stride(h->ld / 64)), block(64, ASM_WAVES);
+    switch (h->mp) {
+        case 0: hipLaunchKernelGGL((k_refine_residual<0>), grid, block, 0, h->stream, a); break;
+        case 4: hipLaunchKernelGGL((k_refine_residual<4>), grid, block, 0, h->stream, a); break;
+        default: hipLaunchKernelGGL((k_refine_residual<8>), grid, block, 0, h->stream, a); break;
+    }
+    if (int rc = h->eng.forward(h->stream, h->d_R, sel)) return rc;
+    if (int rc = h->eng.backsolve(h->stream, h->d_inc2[0], none, sel)) return rc;
+    hipLaunchKernelGGL(k_refine_apply, dim3((unsigned)((h->n + 15) / 16) * jg::group_stride(h->ld / 64)), dim3(64, 16), 0, h->stream,
+                       h->d_inc, h->d_inc2[0], h->d_va, h->d_vm, h->d_flags, active, sel, h->n, h->ld, h->batch);
+    return 0;
+}
+
 int build_graphs(jg_nr* h) {
     if (h->execA) return 0;
     std::lock_guard<std::mutex> lk(jg::capture_mutex());
@@ -562,9 +667,7 @@ int build_graphs(jg_nr* h) {
     NR_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     // graph B: one iteration on the packed lanes (factorise the Jacobian that is already in place, solve, update), then the
     // verdict on the new state
-    int rc = h->eng.factor(h->stream, nullptr, h->d_F, active_groups(h));
-    jg::StateUpdate upd{h->d_va, h->d_vm, h->d_flags, h->d_active, -1.0};
-    if (!rc) rc = h->eng.backsolve(h->stream, h->d_inc, upd, active_groups(h));
+    int rc = newton_step(h, active_groups(h), h->d_active);
     verdict();
     hipError_t e = hipStreamEndCapture(h->stream, &h->graphB);
     if (rc) return fail(rc, h->eng.error);
@@ -923,11 +1026,7 @@ int jg_nr_solve(jg_nr* h) {
     if (int rc = set_device(h)) return rc;
     if (!h->jac_valid) launch_assemble(h);
     NR_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
-    {
-        if (int rc = h->eng.factor(h->stream, nullptr, h->d_F, jg::GroupSel{})) return fail(rc, h->eng.error);
-        jg::StateUpdate upd{h->d_va, h->d_vm, h->d_flags, nullptr, -1.0};
-        if (int rc = h->eng.backsolve(h->stream, h->d_inc, upd, jg::GroupSel{})) return fail(rc, h->eng.error);
-    }
+    if (int rc = newton_step(h, jg::GroupSel{}, nullptr)) return fail(rc, h->eng.error);
     hipLaunchKernelGGL(k_add_iter, dim3((h->ld + 255) / 256), dim3(256), 0, h->stream, h->d_iters, h->ld);
     NR_HIP(hipGetLastError());
     NR_HIP(hipStreamSynchronize(h->stream));
@@ -935,6 +1034,28 @@ int jg_nr_solve(jg_nr* h) {
     std::vector<int> st(h->ld);
     NR_HIP(jg::sync_copy(st.data(), h->eng.status, (size_t)h->ld * 4, hipMemcpyDeviceToHost, h->stream));
     for (int b = 0; b < h->batch; ++b) if (st[b] & 4) return fail(3, "jg_nr_solve: zero or non-finite pivot (singular Jacobian)");
+    return 0;
+}
+
+int jg_nr_set_refine(jg_nr* h, int mode) {
+    if (!h || mode < 0 || mode > 1) return fail(1, "jg_nr_set_refine: bad argument");
+    if (h->fast) return fail(1, "jg_nr_set_refine: fast Newton-Raphson solves with constant matrices");
+    if (int rc = set_device(h)) return rc;
+    NR_HIP(hipStreamSynchronize(h->stream));
+    if (mode && !h->d_R) {
+        const size_t vec = (size_t)h->n * 2 * h->ld * 8;
+        NR_HIP(hipMalloc((void**)&h->d_R, vec));
+        NR_HIP(hipMalloc((void**)&h->d_inc2[0], vec));
+        NR_HIP(jg::sync_fill(h->d_R, 0, vec, h->stream));
+        NR_HIP(jg::sync_fill(h->d_inc2[0], 0, vec, h->stream));
+    }
+    if ((mode != 0) != h->refine) {                              // the iteration graph is captured for one mode
+        if (h->execB) { hipGraphExecDestroy(h->execB); h->execB = nullptr; }
+        if (h->graphB) { hipGraphDestroy(h->graphB); h->graphB = nullptr; }
+        if (h->execA) { hipGraphExecDestroy(h->execA); h->execA = nullptr; }
+        if (h->graphA) { hipGraphDestroy(h->graphA); h->graphA = nullptr; }
+    }
+    h->refine = mode != 0;
     return 0;
 }
 
@@ -1083,11 +1204,10 @@ int jg_nr_fast_setup(jg_nr* h, const double* bp, const double* bq) {
     // (engine block q sits at row = the column that pointer q belongs to, col = rowval[q]; tperm[p of (r, c)] = pointer of (c, r))
     if (int rc = h->eng.set_shared_matrix(h->stream, blk.data())) return fail(rc, h->eng.error);
     const size_t vec = (size_t)h->n * 2 * h->ld * 8;
-    if (!h->d_R) {
-        NR_HIP(hipMalloc((void**)&h->d_R, vec));
-        NR_HIP(hipMalloc((void**)&h->d_inc2[0], vec));
-        NR_HIP(hipMalloc((void**)&h->d_inc2[1], vec));
-    }
+    if (h->refine) return fail(1, "jg_nr_fast_setup: the handle is set up for refined full Newton-Raphson steps");
+    if (!h->d_R) NR_HIP(hipMalloc((void**)&h->d_R, vec));
+    if (!h->d_inc2[0]) NR_HIP(hipMalloc((void**)&h->d_inc2[0], vec));
+    if (!h->d_inc2[1]) NR_HIP(hipMalloc((void**)&h->d_inc2[1], vec));
     NR_HIP(jg::sync_fill(h->d_R, 0, vec, h->stream));
     NR_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
     if (int rc = h->eng.factor(h->stream, nullptr, h->d_R, jg::GroupSel{})) return fail(rc, h->eng.error);   // ONCE (lu(jacobian), :? utility.jl:470-476)

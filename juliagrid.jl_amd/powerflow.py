@@ -193,7 +193,14 @@ def setInjection_(an: AcPowerFlow, active=None, reactive=None):
     an._injection = None if active is None and reactive is None else (p.copy(), q.copy())
 
 
-def newtonRaphson(system: PowerSystem, batch: int = 1, device: int = 0, max_patch: int | None = None) -> AcPowerFlow:
+def setRefinement_(an: AcPowerFlow, on: bool = True):
+    """One step of iterative refinement behind every Newton step (what UMFPACK's solve does for the reference's default LU tag,
+    utility.jl:576-586); off by default."""
+    _lib.check(_lib.lib().jg_nr_set_refine(an._h, 1 if on else 0))
+    an._refine = bool(on)
+
+
+def newtonRaphson(system: PowerSystem, batch: int = 1, device: int = 0, max_patch: int | None = None, refine: bool = False) -> AcPowerFlow:
     """newtonRaphson(system) (acPowerFlow.jl:39-87). Mutates bus types / slack like the reference."""
     if system.bus.layout.slack == 0:
         raise RuntimeError("The slack bus is missing.")
@@ -205,6 +212,8 @@ def newtonRaphson(system: PowerSystem, batch: int = 1, device: int = 0, max_patc
     an = AcPowerFlow(system, batch, device, max_patch)
     setInjection_(an)
     _push_voltage(an, vm, va)
+    if refine:
+        setRefinement_(an, True)
     return an
 
 
@@ -330,6 +339,8 @@ def _rebuild(an: AcPowerFlow):
             if not hasattr(an.method, k):
                 setattr(an.method, k, v)
     inj = an._injection
+    if getattr(an, "_refine", False):
+        setRefinement_(an, True)
     if inj is not None:
         setInjection_(an, *inj)
     else:

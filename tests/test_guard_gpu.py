@@ -173,3 +173,43 @@ def test_mismatch_and_increment_belong_to_their_scenario_after_compaction(jg, or
             assert an.method.iteration[sc] == o.iteration
             assert np.abs(inc[sc] - inc_ref).max() <= 1e-9 * max(1.0, np.abs(inc_ref).max()) + 1e-12
             assert np.abs(f[sc]).max() < 1e-8 and np.abs(f_ref).max() < 1e-8      # both at their converged state (they differ by J x 1e-10)
+
+
+@pytest.mark.parametrize("name", ["case118", "case1354pegase", "case_ACTIVSg10k"])
+def test_refined_newton_step(jg, oracle, name):
+    """jg_nr_set_refine: one step of iterative refinement behind the static-pivot solve (the reference's UMFPACK solve refines).
+    The refined first Newton increment is at least as close to the pivoting oracle's as the plain one and good to 1e-11; the
+    refined iteration reaches the same solution in the same number of iterations, alone and in a compacted batch."""
+    t = load_case(name)
+    s = jg.powerSystem(t)
+    o = oracle.OracleNR(oracle.OracleSystem(t))
+    o.mismatch()
+    o.solve()
+    _, _, inc_ref = o.vectors()
+    scale = max(1.0, np.abs(inc_ref).max())
+    err = {}
+    for refine in (False, True):
+        an = jg.newtonRaphson(jg.powerSystem(t), refine=refine)
+        jg.mismatch_(an)
+        jg.solve_(an)
+        err[refine] = np.abs(an.increment - inc_ref).max() / scale
+        an.close()
+    assert err[True] <= 1e-11 and err[True] <= 2.0 * err[False] + 1e-15
+    plain = jg.newtonRaphson(jg.powerSystem(t))
+    jg.powerFlow_(plain)
+    labels = [int(x) for x in jg.outageList(s, 150, seed=2)]
+    for batch_labels in (None, labels):
+        a = jg.newtonRaphson(jg.powerSystem(t), refine=True) if batch_labels is None else jg.contingencyAnalysis(s, batch_labels)
+        b = None
+        if batch_labels is not None:
+            jg.setRefinement_(a, True)
+            b = jg.contingencyAnalysis(s, batch_labels)
+            jg.powerFlow_(b)
+        jg.powerFlow_(a)
+        if batch_labels is None:
+            assert a.status == 0 and a.method.iteration == plain.method.iteration
+            assert np.abs(a.voltage.magnitude - plain.voltage.magnitude).max() < 1e-9
+        else:
+            assert np.array_equal(a.status, b.status) and np.array_equal(a.method.iteration, b.method.iteration)
+            ok = a.status == 0
+            assert np.abs(a.voltage.magnitude[ok] - b.voltage.magnitude[ok]).max() < 1e-8 and np.abs(a.voltage.angle[ok] - b.voltage.angle[ok]).max() < 1e-8
