@@ -21,8 +21,8 @@ def load(path):
 
 
 def short(name):
-    for k in ("k_assemble", "k_fact_level", "k_bwd_level", "k_fact_walk", "k_bwd_walk", "k_check", "k_compact", "k_lane_permute", "k_lane_copy", "k_lanes_move",
-              "k_gn_rows", "k_gn_gain"):
+    for k in ("k_assemble", "k_fact_level", "k_fact_top", "k_bwd_level", "k_check", "k_compact", "k_lane_permute", "k_lane_copy", "k_lanes_move",
+              "k_gn_rows", "k_gn_gain", "k_gn_hdelta", "k_gn_norm", "k_gn_update", "k_sel_level", "k_gn_project"):
         if k in name:
             if k == "k_assemble":
                 return "k_assemble<jac>" if "true" in name or "ELb1" in name else "k_assemble<mismatch>"
@@ -42,9 +42,9 @@ def main(fetch_csv, write_csv, n, ld, solves, out_json, grid="case_ACTIVSg10k"):
         cw = sorted(v[0] for v in w[key] if v[0] > 1000)
         cal_f_raw = Counter(round(x) for x in cf).most_common(1)[0][0] * 1024.0
         cal_w_raw = Counter(round(x) for x in cw).most_common(1)[0][0] * 1024.0
-    else:                                        # k_lanes_move: the restore at the end of a run moves V, theta, P, Q (n rows each), the
-        key = [k for k in f if "k_lanes_move" in k][0]    # patch values (2 x 4 rows) and mismatch + increment (2n doubles per lane each)
-        known = (8 * n + 2 * 4) * ld * 8         # read and written by each of its two launches
+    else:                                        # k_lanes_move: the restore at the end of a run moves these arrays, read and written by each
+        key = [k for k in f if "k_lanes_move" in k][0]    # of its two launches
+        known = (6 * n + 2 * 4) * ld * 8         # V, theta, P, Q (n rows each), patch values (2 x 4 rows), increment (2n doubles per lane)
         # of the two launches the copy-back is the clean one (whole lines on both sides; the scatter writes permuted lanes)
         cal_f_raw = min(v[0] for v in f[key] if v[0] > 0.5 * max(x[0] for x in f[key])) * 1024.0
         cal_w_raw = min(v[0] for v in w[key] if v[0] > 0.5 * max(x[0] for x in w[key])) * 1024.0
@@ -64,11 +64,11 @@ def main(fetch_csv, write_csv, n, ld, solves, out_json, grid="case_ACTIVSg10k"):
            "calibration": check, "grid": grid, "batch_ld": ld, "solves": solves, "per_kernel_total": agg}
     per = {}
     for k, a in agg.items():
-        div = {"k_fact_level": solves, "k_bwd_level": solves, "k_fact_walk": solves, "k_bwd_walk": solves}.get(k, a["launches"] if a["launches"] else 1)
+        div = {"k_fact_level": solves, "k_fact_top": solves, "k_bwd_level": solves}.get(k, a["launches"] if a["launches"] else 1)
         per[k] = (a["fetch"] + a["write"]) / div
-    per["k_fwd+k_bwd"] = per.get("k_bwd_level", 0.0) + per.get("k_bwd_walk", 0.0)
+    per["k_fwd+k_bwd"] = per.get("k_bwd_level", 0.0)
     per["k_assemble"] = per.get("k_assemble<jac>", 0.0)
-    per["k_lu"] = per["k_fact"] = per.get("k_fact_level", 0.0) + per.get("k_fact_walk", 0.0)
+    per["k_lu"] = per["k_fact"] = per.get("k_fact_level", 0.0) + per.get("k_fact_top", 0.0)       # one factorisation: level launches + top tasks
     res["traffic_per_logical_launch"] = per          # one assembly pass / one factorisation (all levels) / one backward sweep
     json.dump(res, open(out_json, "w"), indent=1)
     for k, a in sorted(agg.items()):

@@ -16,9 +16,8 @@ import juliagrid.jl_amd as jg  # noqa: E402
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-with np.load(os.path.join(ROOT, "tests", "golden", "cases", "case_ACTIVSg10k.npz")) as z:
-    t = {k: z[k] for k in z.files}
-s = jg.powerSystem(t)
+case = sys.argv[3] if len(sys.argv) > 3 else "case_ACTIVSg10k"
+s = jg.powerSystem(case)
 an = jg.contingencyAnalysis(s, jg.outageList(s, batch, seed=512))     # ONE handle: every dispatch belongs to the batch
 jg.powerFlow_(an, iteration=iters, fetch=False)
 print("dims", an.dims, "solves", iters, "iterations", int(np.sum(an.method.iteration)))

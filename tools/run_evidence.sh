@@ -1,18 +1,34 @@
 #!/bin/bash
 # Every number the round's documents quote, in one call on the GPU box (repo root): tools/run_evidence.sh <tag>
 # Writes under gpurun_out/ only; copy what is to be judged into profiles/.
-TAG=${1:-r01}
+TAG=${1:-r02}
 REPO=$(pwd)
 export TMPDIR=/tmp
 python bench.py > gpurun_out/bench_${TAG}.json 2> gpurun_out/bench_${TAG}.err
-python bench.py --case case9241synth --steps 12 --warmup 3 > gpurun_out/bench_9241_${TAG}.json 2> gpurun_out/bench_9241_${TAG}.err
-python bench.py --case case1354pegase --steps 12 --warmup 3 --no-cpu > gpurun_out/bench_1354_${TAG}.json 2> gpurun_out/bench_1354_${TAG}.err
+python bench.py --case case9241synth --steps 24 --warmup 3 --no-se > gpurun_out/bench_9241_${TAG}.json 2> gpurun_out/bench_9241_${TAG}.err
+python bench.py --case case1354pegase --steps 24 --warmup 3 --no-se > gpurun_out/bench_1354_${TAG}.json 2> gpurun_out/bench_1354_${TAG}.err
 python tools/bench_se.py > gpurun_out/bench_se_${TAG}.json 2> gpurun_out/bench_se_${TAG}.err
-tools/run_profiles.sh ${TAG} > gpurun_out/run_profiles_${TAG}.log 2>&1
+# strong-scaling shards on one GPU: what a rank of an N-GPU run does (512 / N scenarios per step, more steps in flight)
+for cfg in "256 6" "128 12" "64 12" "64 24"; do set -- $cfg
+  python bench.py --batch $1 --inflight $2 --steps 96 --no-cpu --no-se 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(json.dumps({'scenarios_per_step': $1, 'steps_in_flight': $2, 'value': j['value'], 'ms_per_step': j['ms_per_step'], 'kernels_ms': {k: v['ms'] for k, v in j['kernels'].items()}}))"
+done > gpurun_out/bench_shards_${TAG}.jsonl
+JG_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 24 --no-cpu --no-se > gpurun_out/bench_gloo2_${TAG}.json 2> gpurun_out/bench_gloo2_${TAG}.err
 cd /tmp
+rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_${TAG} -o b --output-format csv -- python $REPO/bench.py --steps 12 --warmup 2 --no-cpu --no-se > $REPO/gpurun_out/prof_${TAG}_bench.json 2> $REPO/gpurun_out/prof_${TAG}_bench.err
 rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_${TAG}_iso -o k --output-format csv -- python $REPO/tools/time_kernels.py 512 case_ACTIVSg10k 20 > $REPO/gpurun_out/prof_${TAG}_iso.txt 2>&1
-rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_${TAG}_se -o s --output-format csv -- python $REPO/tools/time_se.py 256 > $REPO/gpurun_out/prof_${TAG}_se.txt 2>&1
+rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_${TAG}_iso64 -o k --output-format csv -- python $REPO/tools/time_kernels.py 64 case_ACTIVSg10k 20 > $REPO/gpurun_out/prof_${TAG}_iso64.txt 2>&1
+rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_${TAG}_9241 -o k --output-format csv -- python $REPO/tools/time_kernels.py 512 case9241synth 20 > $REPO/gpurun_out/prof_${TAG}_9241.txt 2>&1
+rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_${TAG}_se -o s --output-format csv -- python $REPO/tools/time_se.py 512 > $REPO/gpurun_out/prof_${TAG}_se.txt 2>&1
 cd $REPO
+tools/run_pmc.sh ${TAG} 512 2 case_ACTIVSg10k > gpurun_out/run_pmc_${TAG}.log 2>&1
+tools/run_pmc.sh ${TAG}_9241 512 2 case9241synth > gpurun_out/run_pmc_${TAG}_9241.log 2>&1
+cd /tmp
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace -d $REPO/gpurun_out/pmc_${TAG}_se_$C -o p --output-format csv -- python $REPO/tools/profile_se.py 512 2 > $REPO/gpurun_out/pmc_${TAG}_se_$C.log 2>&1
+done
+cd $REPO
+python tools/pmc_se_summary.py gpurun_out/pmc_${TAG}_se_FETCH_SIZE/p_counter_collection.csv gpurun_out/pmc_${TAG}_se_WRITE_SIZE/p_counter_collection.csv 2 gpurun_out/pmc_${TAG}_se.json > gpurun_out/run_pmc_${TAG}_se.log 2>&1
 for c in case1354pegase case9241synth case_ACTIVSg10k; do python tools/single_latency.py $c 1 2>&1 | tail -1; done > gpurun_out/single_${TAG}.txt
-tail -n 3 gpurun_out/run_profiles_${TAG}.log
-cut -c1-400 gpurun_out/bench_${TAG}.json
+tail -n 4 gpurun_out/run_pmc_${TAG}.log gpurun_out/run_pmc_${TAG}_9241.log gpurun_out/run_pmc_${TAG}_se.log
+cat gpurun_out/bench_shards_${TAG}.jsonl gpurun_out/single_${TAG}.txt
+cut -c1-300 gpurun_out/bench_${TAG}.json
