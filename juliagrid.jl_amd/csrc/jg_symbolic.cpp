@@ -673,11 +673,13 @@ int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic&
             int nlev = 0;
             for (int e = 0; e < S.n_entries; ++e) nlev = std::max(nlev, S.e_level[e]);
             for (int r = 0; r < n; ++r) nlev = std::max(nlev, S.y_level[r]);
-            std::vector<int> cnt(nlev + 2, 0);
+            int chains = (policy >> 4) & 0xf;                     // ... and at most this many pivots (parallel chains) per level (0: any)
+            if (const char* e = getenv("JG_TOP_CHAINS")) chains = atoi(e);
+            std::vector<int> cnt(nlev + 2, 0), piv(nlev + 2, 0);
             for (int e = 0; e < S.n_entries; ++e) if (!(S.symmetric && S.e_row[e] > S.e_col[e])) cnt[S.e_level[e]]++;
-            for (int r = 0; r < n; ++r) cnt[S.y_level[r]]++;
+            for (int r = 0; r < n; ++r) { cnt[S.y_level[r]]++; piv[S.e_level[S.diag[r]]]++; }
             top_level = nlev + 1;
-            while (top_level > TOP_LEVEL_MIN && cnt[top_level - 1] <= narrow) --top_level;
+            while (top_level > TOP_LEVEL_MIN && cnt[top_level - 1] <= narrow && (chains == 0 || piv[top_level - 1] <= chains)) --top_level;
             if (top_level > nlev - 2) top_level = 255;           // nothing worth a task
         }
         if (soft <= 0) soft = TOP_FRONT_SOFT;

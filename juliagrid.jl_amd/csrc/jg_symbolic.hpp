@@ -122,7 +122,7 @@ struct BlockSymbolic {
 // reading U(k,i)' for Lh(i,k): half the update terms; only the blocks on and above the diagonal must be assembled).
 // policy bits 8-15: dependency level from which pivots go to top tasks (0 = default: where the level schedule gets narrow,
 // 255 = no top tasks); bits 16-23: soft cap of a task's front (0 = default); bits 24-30: what "narrow" means, in units of 8
-// items per level (0 = default).
+// items per level (0 = default); bits 4-7: at most this many pivots per level in the top (0 = any).
 // Returns 0, or 1 on a malformed pattern.
 int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic& out);
 // Replay tables of the selected inverse of a SYMMETRIC matrix on the factor pattern (see jg_symbolic.cpp); idempotent.

@@ -4,6 +4,8 @@
 TAG=${1:-r02}
 REPO=$(pwd)
 export TMPDIR=/tmp
+tools/run_pmc.sh ${TAG} 512 2 case_ACTIVSg10k > gpurun_out/run_pmc_${TAG}.log 2>&1
+cp gpurun_out/pmc_${TAG}.json profiles/pmc_traffic.json        # bench.py reads roofline.traffic from here (grid and batch must match)
 python bench.py > gpurun_out/bench_${TAG}.json 2> gpurun_out/bench_${TAG}.err
 python bench.py --case case9241synth --steps 24 --warmup 3 --no-se > gpurun_out/bench_9241_${TAG}.json 2> gpurun_out/bench_9241_${TAG}.err
 python bench.py --case case1354pegase --steps 24 --warmup 3 --no-se > gpurun_out/bench_1354_${TAG}.json 2> gpurun_out/bench_1354_${TAG}.err
@@ -12,7 +14,7 @@ python tools/bench_se.py > gpurun_out/bench_se_${TAG}.json 2> gpurun_out/bench_s
 for cfg in "256 6" "128 12" "64 12" "64 24"; do set -- $cfg
   python bench.py --batch $1 --inflight $2 --steps 96 --no-cpu --no-se 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(json.dumps({'scenarios_per_step': $1, 'steps_in_flight': $2, 'value': j['value'], 'ms_per_step': j['ms_per_step'], 'kernels_ms': {k: v['ms'] for k, v in j['kernels'].items()}}))"
 done > gpurun_out/bench_shards_${TAG}.jsonl
-JG_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 24 --no-cpu --no-se > gpurun_out/bench_gloo2_${TAG}.json 2> gpurun_out/bench_gloo2_${TAG}.err
+JG_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 24 --no-cpu --no-se 2> gpurun_out/bench_gloo2_${TAG}.err | grep '^{' > gpurun_out/bench_gloo2_${TAG}.json
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_${TAG} -o b --output-format csv -- python $REPO/bench.py --steps 12 --warmup 2 --no-cpu --no-se > $REPO/gpurun_out/prof_${TAG}_bench.json 2> $REPO/gpurun_out/prof_${TAG}_bench.err
 rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_${TAG}_iso -o k --output-format csv -- python $REPO/tools/time_kernels.py 512 case_ACTIVSg10k 20 > $REPO/gpurun_out/prof_${TAG}_iso.txt 2>&1
@@ -20,7 +22,6 @@ rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_${TAG}_iso64 -o k --ou
 rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_${TAG}_9241 -o k --output-format csv -- python $REPO/tools/time_kernels.py 512 case9241synth 20 > $REPO/gpurun_out/prof_${TAG}_9241.txt 2>&1
 rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_${TAG}_se -o s --output-format csv -- python $REPO/tools/time_se.py 512 > $REPO/gpurun_out/prof_${TAG}_se.txt 2>&1
 cd $REPO
-tools/run_pmc.sh ${TAG} 512 2 case_ACTIVSg10k > gpurun_out/run_pmc_${TAG}.log 2>&1
 tools/run_pmc.sh ${TAG}_9241 512 2 case9241synth > gpurun_out/run_pmc_${TAG}_9241.log 2>&1
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
