@@ -769,10 +769,10 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, int policy
     if (ld_ <= 0 || ld_ % 64) { error = "batch leading dimension must be a positive multiple of 64"; return 1; }
     // Where the multifrontal top starts depends on the batch: a top task occupies a workgroup per scenario (~10 us + ~1 us per
     // pivot), a level launch a wave per 64 scenarios.  Up to 128 scenarios every level that holds fewer than ~400 items is
-    // cheaper as tasks (latency regime); from 256 on only the levels with a few parallel chains are (< ~100 items; measured at
-    // 512 scenarios: case1354pegase 0.190 -> 0.159 ms, 9241-bus grid 0.853 -> 0.761, ACTIVSg10k 1.60 -> 1.46; with the
-    // small-batch threshold 0.221 / 0.849 / 1.62).
-    if (!(policy >> 16)) policy |= ld_ >= 256 ? (47 << 16 | (96 / 8) << 24) : (24 << 16 | (384 / 8) << 24);
+    // cheaper as tasks (latency regime); from 256 on only the levels with at most 4 pivots -- parallel chains -- are (measured
+    // at 512 scenarios: case1354pegase 0.190 -> 0.154 ms, 9241-bus grid 0.853 -> 0.777, ACTIVSg10k 1.60 -> 1.46 with 40
+    // launches instead of 84; with the small-batch threshold 0.221 / 0.849 / 1.62).
+    if (!(policy >> 16)) policy |= ld_ >= 256 ? (47 << 16 | (280 / 8) << 24 | 4 << 4) : (24 << 16 | (384 / 8) << 24);
     if (analyze(n, rowptr, col, policy, S)) { error = "block pattern must be structurally symmetric with a full diagonal"; return 1; }
     ld = ld_;
     level_launches(S.fact_seg, fact);
