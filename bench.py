@@ -15,10 +15,15 @@ N > 1, gather them with ONE RCCL all-gather.  Scenarios shard contiguously acros
       GPU at N = 8); at N = 1 this is the 512-scenario batch on one GPU.
   --scaling weak: `--batch` scenarios PER GPU.
 
-`--inflight` steps are in flight per GPU at once (ContingencyPipeline: one handle, HIP stream and host thread each): a single
-batch leaves most of the chip idle during the narrow dependency levels of the sparse LU and during its straggler
-iterations.  Default: 3 at 512 scenarios per GPU, more for smaller shards (the scenarios in flight per GPU stay ~1 536, at
-most 12 steps).  Every step is a full, independent solve and all K steps complete inside the timed region.
+`--merge` M: a rank solves its shares of M consecutive steps in ONE device batch of M x (scenarios per GPU) lanes (default
+under strong scaling: as many as bring the shard back to 512 lanes -- M = 8 at N = 8, M = 1 at N = 1).  The scenarios of a
+job are independent; how a rank groups its K x (512 / N) scenario solves into launches does not change the work, and the
+collective then carries the records of M steps at once.
+
+`--inflight` device batches are in flight per GPU at once (ContingencyPipeline: one handle, HIP stream and host thread each): a
+single batch leaves most of the chip idle during the narrow dependency levels of the sparse LU and during its straggler
+iterations.  Default: 3 at 512 lanes, more for smaller device batches (the scenarios in flight per GPU stay ~1 536, at
+most 12 batches).  Every step is a full, independent solve and all K steps complete inside the timed region.
 
 value = total Newton-Raphson iterations (sum over all scenarios, all ranks, all K steps) / seconds; inputs are resident in HBM
 when the timed region starts.  The JSON line also carries `roofline` (the factorisation: algorithmic bytes / HIP-event time /
@@ -267,6 +272,8 @@ def main():
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--case", default="case_ACTIVSg10k", help="case_ACTIVSg10k (the metric's 10k-bus grid) | case9241synth | any fixture")
     ap.add_argument("--inflight", type=int, default=0, help="steps in flight per GPU (0: 3 at 512 scenarios per GPU, more for smaller shards)")
+    ap.add_argument("--merge", type=int, default=0, help="steps solved together in one device batch per GPU (0: as many as bring a shard back to "
+                    "512 lanes under strong scaling, i.e. 8 at 64 scenarios per GPU; 1: every step its own device batch)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--no-se", action="store_true", help="skip the config4_se object")
     args = ap.parse_args()
@@ -329,21 +336,35 @@ def main():
     B = hi - lo                                                          # scenarios of this rank per step
     if B < 1:
         raise SystemExit(f"rank {rank}: no scenarios ({total} scenarios over {world} ranks)")
-    inflight = args.inflight if args.inflight > 0 else max(3, min(12, 1536 // B))
+    # Device batch: under strong scaling a rank's share of a step shrinks with N (64 scenarios at N = 8), and the path is at its best
+    # around 512 scenarios per launch.  The scenarios of a job are independent, so a rank solves its shares of M
+    # consecutive steps together in ONE handle of M x B lanes (M = 512 // B): the same K x `total` scenarios are solved inside the
+    # timed region, in wider launches, and the ONE collective then carries the records of M steps.  --merge 1 switches it off.
+    b_max = -(-total // world)
+    if args.merge > 0:
+        merge = args.merge
+    elif args.scaling == "strong" and 512 // b_max > 1:
+        m_max = min(512 // b_max, args.steps)         # at most 512 lanes; among the upper half, the M that leaves the fewest spare lanes in
+        merge = min(range(max(1, (m_max + 1) // 2), m_max + 1), key=lambda m: (-(-args.steps // m) * m - args.steps, -m))   # the last batch
+    else:
+        merge = 1
+    merge = max(1, min(merge, args.steps))
+    lanes = B * merge
+    inflight = args.inflight if args.inflight > 0 else max(3, min(12, 1536 // lanes))
     cand = jg.outageList(system, 2 * total, seed=512)
-    pipe = jg.ContingencyPipeline(system, B, inflight=inflight, device=local, start=(vm0, va0))
+    pipe = jg.ContingencyPipeline(system, lanes, inflight=inflight, device=local, start=(vm0, va0))
     it_pre, st_pre = pipe.screen(cand, iteration=20, tolerance=1e-8)
     solvable = np.flatnonzero(st_pre == 0)
     if solvable.size < total:
         raise SystemExit(f"only {solvable.size} of {cand.size} candidate contingencies have a power flow")
     excluded = int(np.sum(st_pre[:solvable[total - 1] + 1] != 0))
     chosen = cand[solvable[:total]]
-    labels = chosen[lo:hi]
+    labels = np.tile(chosen[lo:hi], merge)            # lane m * B + s = scenario s of the m-th step of the device batch
     for h in pipe.handles:
         jg.setOutages_(h, labels)                     # the scenarios stay resident: a step re-solves them from the start point
     an = pipe.handles[0]
     n = system.bus.number
-    packed = [torch.empty((B, 2 * n + 2), dtype=torch.float64, device="cuda") for _ in pipe.handles]
+    packed = [torch.empty((lanes, 2 * n + 2), dtype=torch.float64, device="cuda") for _ in pipe.handles]
 
     def deliver(job, h):                              # caller's thread, step order: result record of the step, then the ONE collective
         buf = packed[job % len(packed)]
@@ -356,8 +377,10 @@ def main():
                 jg.gatherResults(dist, buf.cpu())
 
     def run(steps):
-        out = pipe.run([None] * steps, iteration=20, tolerance=1e-8, on_done=deliver)
-        return int(sum(int(np.sum(it)) for it, _ in out)), out[-1][1]
+        jobs = -(-steps // merge)                     # device batches; the last one may hold fewer real steps: its spare lanes are
+        out = pipe.run([None] * jobs, iteration=20, tolerance=1e-8, on_done=deliver)      # solved (and timed) but not counted
+        real = [min(merge, steps - j * merge) * B for j in range(jobs)]
+        return int(sum(int(np.sum(it[:r])) for (it, _), r in zip(out, real))), out[-1][1][:B]
 
     def fence():
         if world > 1:
@@ -431,8 +454,11 @@ def main():
                        "grid": args.case, "buses": n, "batch_per_gpu": B, "scenarios_per_step": total, "dimJ": d["dimJ"], "nnzJ": d["nnzJ"],
                        "lu_blocks_2x2": d["lu_blocks"], "lu_terms": d["lu_terms"],
                        "launches_per_iteration": 2 + d["lu_launches"] + d["solve_launches"],
-                       "steps_in_flight_per_gpu": len(pipe.handles),
-                       "parallelism": f"scenario-sharded x{world}, one RCCL all-gather of the packed results per step",
+                       "steps_per_device_batch": merge, "lanes_per_device_batch": lanes,
+                       "device_batches_in_flight_per_gpu": len(pipe.handles),
+                       "steps_in_flight_per_gpu": len(pipe.handles) * merge,
+                       "parallelism": f"scenario-sharded x{world}, one RCCL all-gather of the packed results per device batch "
+                                      f"({merge} step(s) of {B} scenarios per GPU)",
                        "scenario_selection": f"the first {total} solvable contingencies of a seeded shuffle of the non-bridge branches; "
                                              f"{excluded} candidate(s) without a power flow skipped"},
             "scenarios_per_s": nsc / dt,

@@ -10,9 +10,10 @@ python bench.py > gpurun_out/bench_${TAG}.json 2> gpurun_out/bench_${TAG}.err
 python bench.py --case case9241synth --steps 24 --warmup 3 --no-se > gpurun_out/bench_9241_${TAG}.json 2> gpurun_out/bench_9241_${TAG}.err
 python bench.py --case case1354pegase --steps 24 --warmup 3 --no-se > gpurun_out/bench_1354_${TAG}.json 2> gpurun_out/bench_1354_${TAG}.err
 python tools/bench_se.py > gpurun_out/bench_se_${TAG}.json 2> gpurun_out/bench_se_${TAG}.err
-# strong-scaling shards on one GPU: what a rank of an N-GPU run does (512 / N scenarios per step, more steps in flight)
-for cfg in "256 6" "128 12" "64 12" "64 24"; do set -- $cfg
-  python bench.py --batch $1 --inflight $2 --steps 96 --no-cpu --no-se 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(json.dumps({'scenarios_per_step': $1, 'steps_in_flight': $2, 'value': j['value'], 'ms_per_step': j['ms_per_step'], 'kernels_ms': {k: v['ms'] for k, v in j['kernels'].items()}}))"
+# strong-scaling shards on one GPU: what a rank of an N-GPU run does (512 / N scenarios per step).  First every step as its own
+# device batch (--merge 1, more batches in flight), then the default: the rank's shares of M steps solved as one 512-lane batch
+for cfg in "256 6 1" "128 12 1" "64 12 1" "64 24 1" "256 3 2" "128 3 4" "64 3 8"; do set -- $cfg
+  python bench.py --batch $1 --inflight $2 --merge $3 --steps 96 --no-cpu --no-se 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(json.dumps({'scenarios_per_step': $1, 'steps_per_device_batch': $3, 'device_batches_in_flight': $2, 'value': j['value'], 'ms_per_step': j['ms_per_step'], 'kernels_ms': {k: v['ms'] for k, v in j['kernels'].items()}}))"
 done > gpurun_out/bench_shards_${TAG}.jsonl
 JG_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 24 --no-cpu --no-se 2> gpurun_out/bench_gloo2_${TAG}.err | grep '^{' > gpurun_out/bench_gloo2_${TAG}.json
 cd /tmp
