@@ -274,6 +274,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=0, help="steps in flight per GPU (0: 3 at 512 scenarios per GPU, more for smaller shards)")
     ap.add_argument("--merge", type=int, default=0, help="steps solved together in one device batch per GPU (0: as many as bring a shard back to "
                     "512 lanes under strong scaling, i.e. 8 at 64 scenarios per GPU; 1: every step its own device batch)")
+    ap.add_argument("--pool", type=int, default=256, help="lanes of the straggler pool (0: every batch finishes its own stragglers in lockstep)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--no-se", action="store_true", help="skip the config4_se object")
     args = ap.parse_args()
@@ -352,9 +353,11 @@ def main():
     lanes = B * merge
     inflight = args.inflight if args.inflight > 0 else max(3, min(12, 1536 // lanes))
     cand = jg.outageList(system, 2 * total, seed=512)
-    pipe = jg.ContingencyPipeline(system, lanes, inflight=inflight, device=local, start=(vm0, va0))
+    pipe = jg.ContingencyPipeline(system, lanes, inflight=inflight, device=local, start=(vm0, va0), pool=args.pool)
     it_pre, st_pre = pipe.screen(cand, iteration=20, tolerance=1e-8)
     solvable = np.flatnonzero(st_pre == 0)
+    if os.environ.get("JG_BENCH_PROBE_UNIFORM"):        # probe only: scenarios that all need the same number of iterations (no stragglers)
+        solvable = np.flatnonzero((st_pre == 0) & (it_pre == int(os.environ["JG_BENCH_PROBE_UNIFORM"])))
     if solvable.size < total:
         raise SystemExit(f"only {solvable.size} of {cand.size} candidate contingencies have a power flow")
     excluded = int(np.sum(st_pre[:solvable[total - 1] + 1] != 0))
@@ -364,21 +367,24 @@ def main():
         jg.setOutages_(h, labels)                     # the scenarios stay resident: a step re-solves them from the start point
     an = pipe.handles[0]
     n = system.bus.number
-    packed = [torch.empty((lanes, 2 * n + 2), dtype=torch.float64, device="cuda") for _ in pipe.handles]
+    # result records: a ring the pipeline fills (the batch's own scenarios when its main phase ends, its stragglers when their pool
+    # has finished them); a record is reused only after its job has been delivered
+    ring = len(pipe.handles) + (12 if pipe.pools else 0)
+    packed = [torch.empty((lanes, 2 * n + 2), dtype=torch.float64, device="cuda") for _ in range(ring)]
 
-    def deliver(job, h):                              # caller's thread, step order: result record of the step, then the ONE collective
-        buf = packed[job % len(packed)]
-        h.pack_results_device(buf.data_ptr())
+    def deliver(job, h):                              # caller's thread, job order: the record is complete -> the ONE collective
         if world > 1:
+            buf = packed[job % ring]
             if cdev == "cuda":
                 jg.gatherResults(dist, buf)
-                torch.cuda.current_stream().synchronize()   # the record is rewritten when this handle finishes its next step
+                torch.cuda.current_stream().synchronize()
             else:
                 jg.gatherResults(dist, buf.cpu())
 
     def run(steps):
         jobs = -(-steps // merge)                     # device batches; the last one may hold fewer real steps: its spare lanes are
-        out = pipe.run([None] * jobs, iteration=20, tolerance=1e-8, on_done=deliver)      # solved (and timed) but not counted
+        out = pipe.run([None] * jobs, iteration=20, tolerance=1e-8, on_done=deliver,      # solved (and timed) but not counted
+                       record=lambda j: packed[j % ring].data_ptr(), records=ring)
         real = [min(merge, steps - j * merge) * B for j in range(jobs)]
         return int(sum(int(np.sum(it[:r])) for (it, _), r in zip(out, real))), out[-1][1][:B]
 
@@ -456,6 +462,7 @@ def main():
                        "launches_per_iteration": 2 + d["lu_launches"] + d["solve_launches"],
                        "steps_per_device_batch": merge, "lanes_per_device_batch": lanes,
                        "device_batches_in_flight_per_gpu": len(pipe.handles),
+                       "straggler_pool_lanes": pipe.pools[0].handle.batch if pipe.pools else 0,
                        "steps_in_flight_per_gpu": len(pipe.handles) * merge,
                        "parallelism": f"scenario-sharded x{world}, one RCCL all-gather of the packed results per device batch "
                                       f"({merge} step(s) of {B} scenarios per GPU)",

@@ -110,6 +110,26 @@ int jg_nr_set_refine(jg_nr* h, int mode);
  * reference's loop accounting.  iters/status: [batch]; status 0 converged, 1 iteration limit,
  * 3 numeric failure. */
 int jg_nr_run(jg_nr* h, int64_t max_iter, double tol, int32_t* iters, int32_t* status);
+/* Straggler hand-off between batches of the same grid (no counterpart in the reference, which has no batch: its loop runs one
+ * scenario at a time, acPowerFlow.jl:1389-1433).  A batch advances in lockstep until its slowest scenario is done; the last
+ * iterations of 512 N-1 scenarios run on a few dozen of them at the latency of a full pass.  A pipeline of batches therefore
+ * stops a batch once at most defer_at (<= 64) scenarios are active, moves those into a POOL handle that collects the stragglers of
+ * several batches, and finishes them together:
+ *   jg_nr_run_defer   jg_nr_run that returns as soon as <= defer_at scenarios are active (n_left of them; 0: the batch is done);
+ *                     the handle is PAUSED: lanes packed, results not yet in home order.  Handles of one lane group never pause.
+ *   jg_nr_move_lanes  the active scenarios of the paused handle src (state, injections, Ybus patch, iteration count) continue in
+ *                     lanes dst_lane0.. of dst; home[i] = the scenario (lane of src) that went to lane dst_lane0 + i, count of them;
+ *                     in src they end with status 4 (deferred).  Same grid, same device, dst must not be running.
+ *   jg_nr_finish      ends a paused run: lanes home, iters / status [batch] (deferred scenarios: status 4).
+ *   jg_nr_resume      runs the scenarios in lanes [0, lanes) of a pool to the end, each with the iteration count it arrived with
+ *                     (per-scenario results are bitwise those of an undisturbed batch: lanes never interact); iters / status [lanes].
+ *   jg_nr_pack_rows_device  V | theta | iterations | status of lanes lane0 .. lane0 + count - 1 into rows rows[i] of a result
+ *                     record [.][2 n + 2] in device memory (the record jg_nr_pack_results_device writes for the batch they left). */
+int jg_nr_run_defer(jg_nr* h, int64_t max_iter, double tol, int64_t defer_at, int32_t* n_left);
+int jg_nr_move_lanes(jg_nr* dst, int64_t dst_lane0, jg_nr* src, int32_t* home, int32_t* count);
+int jg_nr_finish(jg_nr* h, int32_t* iters, int32_t* status);
+int jg_nr_resume(jg_nr* h, int64_t lanes, int64_t max_iter, double tol, int32_t* iters, int32_t* status);
+int jg_nr_pack_rows_device(jg_nr* h, double* dst_dev, int64_t lane0, int64_t count, const int32_t* rows);
 
 /* analysis.method.{mismatch,increment,jacobian.nzval} in the reference's own ordering
  * (rows/cols pvpq then pq; CSC of newtonJacobian).  [batch][dimJ] / [batch][nnzJ]. */

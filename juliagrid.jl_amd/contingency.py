@@ -86,21 +86,46 @@ def contingencyAnalysis(system: PowerSystem, labels, device: int = 0) -> AcPower
     return an
 
 
+class _Pool:
+    """A handle that collects the stragglers of several batches (ContingencyPipeline, straggler hand-off)."""
+
+    def __init__(self, handle):
+        self.handle = handle
+        self.fill = 0
+        self.routes = []                    # (job, scenario numbers in the job's batch, first lane in the pool)
+        self.idle = threading.Event()
+        self.idle.set()
+        self.queued = False
+
+
 class ContingencyPipeline:
     """`inflight` batches of the same grid in flight on one GPU, each on its own handle, HIP stream and host thread.
 
-    Why: the sparse LU replays ~100 dependency levels per iteration and most of them occupy a fraction of the chip for
-    a few microseconds (latency bound), and the last iterations of a batch run on the few scenarios that have not
-    converged yet.  A second and third batch fill those holes: kernels of different streams run concurrently.  Measured
-    on MI355X, case_ACTIVSg10k, 512 scenarios per batch: 131k NR iterations/s with 1 batch in flight, 215k with 3.
+    Why: the sparse LU replays dozens of dependency levels per iteration and most of them occupy a fraction of the chip for
+    a few microseconds (latency bound).  A second and third batch fill those holes: kernels of different streams run
+    concurrently.  Measured on MI355X, case_ACTIVSg10k, 512 scenarios per batch: 131k NR iterations/s with 1 batch in flight,
+    215k with 3.
 
-    jobs are processed in order; `on_done(job, analysis)` (optional) is called on the CALLER's thread in job order while
-    the batch's results are still resident (this is where a sharded run issues its RCCL gather: collectives must be
-    issued in the same order on every rank)."""
+    Straggler hand-off (`pool` > 0): a batch advances in lockstep, so its last iterations run on the few scenarios that have
+    not converged yet (36 of 512 N-1 scenarios of case_ACTIVSg10k need a 4th iteration, one a 5th) at the latency of a full
+    pass.  With a pool, a batch stops as soon as at most `defer_at` (<= 64) scenarios are active; those move -- state,
+    injections, outage patch, iteration count -- into a pool handle of `pool` lanes that collects the stragglers of several
+    batches and finishes them together, while the batch's handle starts its next job.  Lanes never interact, so every
+    scenario's result is bitwise what an undisturbed batch gives.
 
-    def __init__(self, system: PowerSystem, batch: int, inflight: int = 3, device: int = 0, start=None):
+    jobs are processed in order; `on_done(job, analysis)` (optional) is called on the CALLER's thread in job order (this is
+    where a sharded run issues its RCCL gather: collectives must be issued in the same order on every rank).  Without a pool
+    the batch's results are still resident in `analysis` at that point.  With a pool the handle may already be running its next
+    job: results are delivered through `record` (see run)."""
+
+    def __init__(self, system: PowerSystem, batch: int, inflight: int = 3, device: int = 0, start=None, pool: int = 0, defer_at: int = 64):
         self.system, self.batch = system, int(batch)
         self.handles = [newtonRaphson(system, batch=self.batch, device=device, max_patch=4) for _ in range(max(1, int(inflight)))]
+        self.defer_at = max(0, min(64, int(defer_at)))
+        self.pools = []
+        if pool and self.batch > 64 and self.defer_at > 0:
+            lanes = max(2 * self.defer_at, -(-int(pool) // 64) * 64)
+            self.pools = [_Pool(newtonRaphson(system, batch=lanes, device=device, max_patch=4)) for _ in range(2)]
         if start is not None:
             self.setStart(*start)
         else:                                            # default restart point of every solve: the start newtonRaphson() built
@@ -112,54 +137,158 @@ class ContingencyPipeline:
         for an in self.handles:
             _push_voltage(an, magnitude, angle)
             an.snapshot_voltage()
+        for p in self.pools:                             # idle pool lanes compute along in their lane group: give them a sane state
+            _push_voltage(p.handle, magnitude, angle)
 
     def close(self):
         for an in self.handles:
             an.close()
-        self.handles = []
+        for p in self.pools:
+            p.handle.close()
+        self.handles, self.pools = [], []
 
-    def run(self, jobs, iteration: int = 20, tolerance: float = 1e-8, on_done=None, fetch: bool = False):
+    def run(self, jobs, iteration: int = 20, tolerance: float = 1e-8, on_done=None, fetch: bool = False, record=None, records: int = 0):
         """jobs: sequence of label lists (one batch each; None = keep the handle's current outages).
-        Returns per-job (iterations, status) arrays."""
+        record: optional callable job -> DEVICE pointer of a [batch, 2 n + 2] float64 buffer; the job's result record
+        (V | theta | iterations | status per scenario) is complete in it when on_done(job, .) is called.  The caller owns a
+        ring of `records` such buffers (record(j) and record(j + records) may be the same memory): job j + records is not
+        written before on_done(j) has returned.  Returns per-job (iterations, status) arrays."""
         jobs = list(jobs)
-        results = [None] * len(jobs)
-        done = [threading.Event() for _ in jobs]
-        released = [threading.Event() for _ in jobs]
+        nj = len(jobs)
+        results = [None] * nj
+        main_done = [threading.Event() for _ in jobs]
+        pool_done = [None] * nj                                   # Event of the jobs that handed scenarios to a pool
+        released = [threading.Event() for _ in jobs]              # the handle of job j may start job j + nh
+        delivered = [threading.Event() for _ in jobs]             # on_done(j) has returned
         nh = len(self.handles)
+        use_pool = bool(self.pools)
+        if use_pool and on_done is not None and record is None:
+            raise ValueError("a pipeline with a straggler pool delivers results through `record`")
+        ring = int(records) if (record is not None and records) else 0
         errors = []
+        lock = threading.Lock()
+        state = {"fill": 0}                                       # index of the pool that is being filled
+        import queue
+        flush_q = queue.Queue()
+
+        def submit(p):                                            # under `lock`
+            if p.fill > 0 and not p.queued:
+                p.queued = True
+                p.idle.clear()
+                flush_q.put(p)
+
+        def flush_filling():
+            with lock:
+                submit(self.pools[state["fill"]])
+
+        def pool_worker():
+            try:
+                while True:
+                    p = flush_q.get()
+                    if p is None:
+                        return
+                    it, st = p.handle.resume(p.fill, iteration, tolerance)
+                    for j, home, off in p.routes:
+                        main_done[j].wait()                       # the batch's own record / arrays are written first
+                        if errors:
+                            break
+                        results[j][0][home] = it[off:off + home.size]
+                        results[j][1][home] = st[off:off + home.size]
+                        if record is not None:
+                            p.handle.pack_rows_device(record(j), off, home)
+                        pool_done[j].set()
+                    p.routes = []                                 # no lock: a worker may hold it while it waits for this pool; submit() sees
+                    p.fill = 0                                    # either queued (skips) or an empty pool (skips)
+                    p.queued = False
+                    p.idle.set()
+            except BaseException as e:
+                errors.append(e)
+                for ev in main_done + delivered + [x for x in pool_done if x is not None]:
+                    ev.set()
+                for p in self.pools:
+                    p.idle.set()
 
         def worker(k):
             try:
-                for j in range(k, len(jobs), nh):
+                for j in range(k, nj, nh):
                     if j - nh >= 0:
-                        released[j - nh].wait()                  # the caller has consumed this handle's previous results
+                        released[j - nh].wait()
+                    if ring and j - ring >= 0 and not delivered[j - ring].is_set():
+                        if use_pool:
+                            flush_filling()                       # what the caller is waiting for may sit in the pool that is filling
+                        delivered[j - ring].wait()
+                    if errors:
+                        return
                     an = self.handles[k]
                     if jobs[j] is not None:
                         labels = [int(x) if x else 0 for x in jobs[j]]
                         setOutages_(an, labels + [0] * (self.batch - len(labels)))
                     an.restore_voltage()
-                    powerFlow_(an, iteration=iteration, tolerance=tolerance, fetch=fetch)
+                    if use_pool:
+                        left = an.run_defer(iteration, tolerance, self.defer_at)
+                        if left > 0:
+                            with lock:
+                                p = self.pools[state["fill"]]
+                                if p.queued or p.fill + left > p.handle.batch:
+                                    submit(p)
+                                    state["fill"] ^= 1
+                                    p = self.pools[state["fill"]]
+                                p.idle.wait()                     # the other pool has long finished in a steady pipeline
+                                if errors:
+                                    return
+                                home = p.handle.take_lanes(an, p.fill)
+                                pool_done[j] = threading.Event()
+                                p.routes.append((j, home, p.fill))
+                                p.fill += home.size
+                        an.finish()
+                        if fetch:
+                            an._pull_voltage()
+                    else:
+                        powerFlow_(an, iteration=iteration, tolerance=tolerance, fetch=fetch)
                     results[j] = (np.array(an.method.iteration), np.array(an.status))
-                    done[j].set()
+                    if record is not None:
+                        an.pack_results_device(record(j))
+                    main_done[j].set()
+                    if use_pool or record is not None and on_done is None:
+                        released[j].set()                         # nothing of this job lives in the handle any more
+                if use_pool:
+                    flush_filling()                               # this worker adds nothing more
             except BaseException as e:                             # surface in the caller, never hang it
                 errors.append(e)
-                for ev in done:
+                for ev in main_done + delivered + released + [x for x in pool_done if x is not None]:
                     ev.set()
+                for p in self.pools:
+                    p.idle.set()
 
         threads = [threading.Thread(target=worker, args=(k,), daemon=True) for k in range(nh)]
+        pthread = threading.Thread(target=pool_worker, daemon=True) if use_pool else None
+        if pthread:
+            pthread.start()
         for t in threads:
             t.start()
-        for j in range(len(jobs)):
-            done[j].wait()
+        for j in range(nj):
+            main_done[j].wait()
+            if not errors and pool_done[j] is not None:
+                if j == nj - 1 or all(main_done[i].is_set() for i in range(j, nj)):
+                    flush_filling()                               # nobody is left to fill the pool
+                while not pool_done[j].wait(0.05):
+                    if errors:
+                        break
+                    if all(ev.is_set() for ev in main_done):
+                        flush_filling()
             if errors:
-                for ev in released:
+                for ev in released + delivered:
                     ev.set()
                 break
             if on_done is not None:
                 on_done(j, self.handles[j % nh])
+            delivered[j].set()
             released[j].set()
         for t in threads:
             t.join()
+        if pthread:
+            flush_q.put(None)
+            pthread.join()
         if errors:
             raise errors[0]
         return results

@@ -493,6 +493,52 @@ __global__ void k_pack_tail(const int* iters, const int* status, double* dst, in
     if (b < batch) { dst[(size_t)b * stride + off] = (double)iters[b]; dst[(size_t)b * stride + off + 1] = (double)status[b]; }
 }
 
+// ---- straggler hand-off (jg_nr_move_lanes): the scenarios of a paused batch that are still active -- all inside its first
+// lane group -- continue in another handle of the same grid (a pool that collects the stragglers of several batches).
+// k_move_plan (one wave): pool lane of every active position, the per-lane integers, the home lane of each moved scenario; the
+// source lanes become inactive with status 4 (deferred).  k_move_rows: the per-lane rows (V, theta, P, Q, patch values).
+struct MovePlanArgs {
+    int* s_active; int* s_iters; int* s_status; const int* s_lid; const int* s_ppos; int s_ld;
+    int* d_active; int* d_iters; int* d_status; int* d_lu; int* d_ppos; int d_ld;
+    int* map; int* home; int* count; int mp; int lane0; int cap;
+};
+__global__ __launch_bounds__(64) void k_move_plan(MovePlanArgs a) {
+    const int p = threadIdx.x;
+    const bool act = a.s_active[p] != 0;
+    const unsigned long long m = __ballot(act);
+    const int r = __popcll(m & ((1ull << p) - 1ull));
+    const int total = __popcll(m);
+    const bool fits = a.lane0 + total <= a.cap;
+    if (p == 0) a.count[0] = fits ? total : -1;
+    a.map[p] = -1;
+    if (!act || !fits) return;
+    const int d = a.lane0 + r;
+    a.map[p] = d;
+    a.home[r] = a.s_lid[p];
+    a.d_active[d] = 1; a.d_iters[d] = a.s_iters[p]; a.d_status[d] = 1; a.d_lu[d] = 0;
+    for (int k = 0; k < a.mp; ++k) a.d_ppos[(size_t)k * a.d_ld + d] = a.s_ppos[(size_t)k * a.s_ld + p];
+    a.s_active[p] = 0; a.s_status[p] = 4;
+}
+struct MoveRowsArgs { const double* src[6]; double* dst[6]; int rows[6]; int s_ld; int d_ld; const int* map; };
+__global__ __launch_bounds__(256) void k_move_rows(MoveRowsArgs a) {
+    const int p = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int d = a.map[p];
+    if (d < 0) return;
+    const int arr = blockIdx.y;
+    const double* s = a.src[arr];
+    double* t = a.dst[arr];
+    for (int r = blockIdx.x * 4 + sub; r < a.rows[arr]; r += gridDim.x * 4) t[(size_t)r * a.d_ld + d] = s[(size_t)r * a.s_ld + p];
+}
+// rows of a result record [.][stride] <- V | theta | iterations | status of lanes lane0 .. lane0 + count - 1 (rows[i] = record row)
+__global__ __launch_bounds__(256) void k_pack_rows(const double* vm, const double* va, const int* iters, const int* status, const int* rows,
+                                                   double* dst, int n, int ld, int lane0, long long stride) {
+    const int i = blockIdx.y;
+    const int b = lane0 + i;
+    double* out = dst + (size_t)rows[i] * stride;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) { out[j] = vm[(size_t)j * ld + b]; out[n + j] = va[(size_t)j * ld + b]; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[2 * n] = (double)iters[b]; out[2 * n + 1] = (double)status[b]; }
+}
+
 __global__ void k_add_iter(int* iters, int n) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < n) iters[b] += 1;
@@ -535,6 +581,10 @@ struct jg_nr {
     hipGraph_t graphA = nullptr, graphB = nullptr;
     hipGraphExec_t execA = nullptr, execB = nullptr;
     bool jac_valid = false;
+    bool f_stale = false;            // d_F does not hold every scenario's final mismatch yet (see run_finish)
+    bool paused = false;             // jg_nr_run_defer stopped with scenarios still active (lanes compacted, not yet sent home)
+    int* d_move = nullptr;           // straggler hand-off: map[64] | home[64] | count[1] (device), home/count mirrored in h_move (pinned)
+    int* h_move = nullptr;
     int* h_counter = nullptr;        // pinned
     int* h_counter_dev = nullptr;    // its device alias
 };
@@ -829,6 +879,7 @@ void jg_nr_destroy(jg_nr* h) {
     if (!h) return;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->d_move) { hipFree(h->d_move); hipHostFree(h->h_move); }
     if (h->execA) hipGraphExecDestroy(h->execA);
     if (h->execB) hipGraphExecDestroy(h->execB);
     if (h->graphA) hipGraphDestroy(h->graphA);
@@ -1015,6 +1066,7 @@ int jg_nr_mismatch(jg_nr* h, double* max_p, double* max_q) {
     NR_HIP(hipGetLastError());
     NR_HIP(hipStreamSynchronize(h->stream));
     h->jac_valid = true;
+    h->f_stale = false;
     if (max_p) NR_HIP(jg::sync_copy(max_p, h->d_normp, (size_t)h->batch * 8, hipMemcpyDeviceToHost, h->stream));
     if (max_q) NR_HIP(jg::sync_copy(max_q, h->d_normq, (size_t)h->batch * 8, hipMemcpyDeviceToHost, h->stream));
     return 0;
@@ -1059,69 +1111,177 @@ int jg_nr_set_refine(jg_nr* h, int mode) {
     return 0;
 }
 
-int jg_nr_run(jg_nr* h, int64_t max_iter, double tol, int32_t* iters, int32_t* status) {
-    if (!h || max_iter < 0 || !(tol > 0.0)) return fail(1, "jg_nr_run: bad argument");
-    if (h->fast) return fail(1, "jg_nr_run: this handle runs fast Newton-Raphson; use jg_nr_fast_run");
-    const double t_enter = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
-    if (int rc = set_device(h)) return rc;
+namespace {
+
+// Start of a batched solve: every real scenario active, lanes in home order, all groups in use.  keep_iters: the lanes carry
+// their iteration counts (a pool of moved scenarios, jg_nr_resume).
+int run_setup(jg_nr* h, int64_t max_iter, double tol, int lanes, bool keep_iters) {
     if (int rc = build_graphs(h)) return rc;
     const double params[2] = {tol, (double)max_iter};
     NR_HIP(hipMemcpyAsync(h->d_params, params, sizeof(params), hipMemcpyHostToDevice, h->stream));
-    NR_HIP(hipMemsetAsync(h->d_iters, 0, (size_t)h->ld * 4, h->stream));      // acPowerFlow.jl:1401
-    NR_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
-    {   // every real scenario starts active, lanes in home order, all groups in use
-        std::vector<int> act(h->ld, 0), lid(h->ld);
-        for (int b = 0; b < h->ld; ++b) { act[b] = b < h->batch; lid[b] = b; }
-        const int cf[4] = {0, h->batch, h->ld / 64, h->ld / 64};
-        NR_HIP(hipMemcpyAsync(h->d_active, act.data(), (size_t)h->ld * 4, hipMemcpyHostToDevice, h->stream));
-        NR_HIP(hipMemcpyAsync(h->d_lid, lid.data(), (size_t)h->ld * 4, hipMemcpyHostToDevice, h->stream));
-        NR_HIP(hipMemcpyAsync(h->d_cflags, cf, sizeof(cf), hipMemcpyHostToDevice, h->stream));
-        std::vector<int> grp(h->ld / 64, 1), gl(h->ld / 64);
-        for (size_t g = 0; g < gl.size(); ++g) gl[g] = (int)g;
-        NR_HIP(hipMemcpyAsync(h->d_group, grp.data(), grp.size() * 4, hipMemcpyHostToDevice, h->stream));
-        NR_HIP(hipMemcpyAsync(h->d_glist, gl.data(), gl.size() * 4, hipMemcpyHostToDevice, h->stream));
-        NR_HIP(hipStreamSynchronize(h->stream));
+    if (!keep_iters) {
+        NR_HIP(hipMemsetAsync(h->d_iters, 0, (size_t)h->ld * 4, h->stream));      // acPowerFlow.jl:1401
+        NR_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
     }
+    std::vector<int> act(h->ld, 0), lid(h->ld);
+    for (int b = 0; b < h->ld; ++b) { act[b] = b < lanes; lid[b] = b; }
+    const int cf[4] = {0, lanes, h->ld / 64, h->ld / 64};
+    if (!keep_iters) NR_HIP(hipMemcpyAsync(h->d_active, act.data(), (size_t)h->ld * 4, hipMemcpyHostToDevice, h->stream));
+    NR_HIP(hipMemcpyAsync(h->d_lid, lid.data(), (size_t)h->ld * 4, hipMemcpyHostToDevice, h->stream));
+    NR_HIP(hipMemcpyAsync(h->d_cflags, cf, sizeof(cf), hipMemcpyHostToDevice, h->stream));
+    std::vector<int> grp(h->ld / 64, 1), gl(h->ld / 64);
+    for (size_t g = 0; g < gl.size(); ++g) gl[g] = (int)g;
+    NR_HIP(hipMemcpyAsync(h->d_group, grp.data(), grp.size() * 4, hipMemcpyHostToDevice, h->stream));
+    NR_HIP(hipMemcpyAsync(h->d_glist, gl.data(), gl.size() * 4, hipMemcpyHostToDevice, h->stream));
+    NR_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// The iteration loop: one graph per iteration until no scenario is active (the iteration limit itself is kept on the device,
+// k_check) -- or, defer_at > 0, until at most defer_at (<= 64) scenarios are: they then sit in the first lane group.
+int run_loop(jg_nr* h, int64_t max_iter, int defer_at) {
     const bool trace = getenv("JG_TRACE") != nullptr;
     auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t_setup = now_us();
-    if (trace) fprintf(stderr, "[jg_nr_run] setup %.1f us\n", t_setup - t_enter);
-    NR_HIP(hipGraphLaunch(h->execA, h->stream));                               // acPowerFlow.jl:1406: mismatch!, verdict
-    NR_HIP(hipStreamSynchronize(h->stream));
-    if (trace) fprintf(stderr, "[jg_nr_run] start point: %d scenarios active, %.1f us\n", *h->h_counter, now_us() - t_setup);
-    for (int64_t it = 0; it <= max_iter && *h->h_counter != 0; ++it) {          // the iteration limit itself is kept on the device (k_check)
+    for (int64_t it = 0; it <= max_iter && *h->h_counter != 0; ++it) {
+        if (defer_at > 0 && *h->h_counter <= defer_at) break;
         const double tc = now_us();
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (trace) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, h->stream); }
-        {
-            NR_HIP(hipGraphLaunch(h->execB, h->stream));                       // solve!, then mismatch! and the verdict on the new state
-        }
+        NR_HIP(hipGraphLaunch(h->execB, h->stream));                           // solve!, then mismatch! and the verdict on the new state
         if (trace) hipEventRecord(e1, h->stream);
         NR_HIP(hipStreamSynchronize(h->stream));
-        if (trace) { float ms = 0.f; hipEventElapsedTime(&ms, e0, e1); fprintf(stderr, "[jg_nr_run] graph on the device: %.1f us\n", 1e3 * ms); hipEventDestroy(e0); hipEventDestroy(e1); }
         if (trace) {
+            float ms = 0.f; hipEventElapsedTime(&ms, e0, e1); fprintf(stderr, "[jg_nr_run] graph on the device: %.1f us\n", 1e3 * ms); hipEventDestroy(e0); hipEventDestroy(e1);
             int cf[4];
             jg::sync_copy(cf, h->d_cflags, sizeof(cf), hipMemcpyDeviceToHost, h->stream);
             fprintf(stderr, "[jg_nr_run] iteration %lld: %.1f us, %d scenarios still active, %d of %d lane groups in use%s\n", (long long)it + 1,
                     now_us() - tc, *h->h_counter, cf[2], h->ld / 64, cf[0] ? " (compacted)" : "");
         }
     }
-    const double t_loop = now_us();
+    return 0;
+}
+
+// End of a batched solve: lanes back to their home order, method.mismatch of every scenario at its final state, outputs.
+int run_finish(jg_nr* h, int32_t* iters, int32_t* status) {
     launch_compact(h, 1);                                                      // lanes back to their home order
-    if (h->ld > 64) launch_assemble(h, jg::GroupSel{}, false);                 // method.mismatch of every scenario at its final state (groups that
-                                                                               // dropped out early held other scenarios' rows after a compaction)
+    h->f_stale = h->ld > 64;                                                   // method.mismatch of every scenario at its final state: groups that dropped
+                                                                               // out early hold other scenarios' rows after a compaction -- one mismatch-only
+                                                                               // pass, run when jg_nr_get_mismatch asks for it (0.1 ms per batch of 512)
     NR_HIP(hipGetLastError());
     NR_HIP(hipStreamSynchronize(h->stream));
     h->jac_valid = false;
+    h->paused = false;
     if (iters) NR_HIP(jg::sync_copy(iters, h->d_iters, (size_t)h->batch * 4, hipMemcpyDeviceToHost, h->stream));
     if (status) NR_HIP(jg::sync_copy(status, h->d_status, (size_t)h->batch * 4, hipMemcpyDeviceToHost, h->stream));
-    if (trace) fprintf(stderr, "[jg_nr_run] tail %.1f us, total %.1f us\n", now_us() - t_loop, now_us() - t_enter);
+    return 0;
+}
+
+}  // namespace
+
+int jg_nr_run(jg_nr* h, int64_t max_iter, double tol, int32_t* iters, int32_t* status) {
+    if (!h || max_iter < 0 || !(tol > 0.0)) return fail(1, "jg_nr_run: bad argument");
+    if (h->fast) return fail(1, "jg_nr_run: this handle runs fast Newton-Raphson; use jg_nr_fast_run");
+    if (int rc = set_device(h)) return rc;
+    if (int rc = run_setup(h, max_iter, tol, h->batch, false)) return rc;
+    NR_HIP(hipGraphLaunch(h->execA, h->stream));                               // acPowerFlow.jl:1406: mismatch!, verdict
+    NR_HIP(hipStreamSynchronize(h->stream));
+    if (int rc = run_loop(h, max_iter, 0)) return rc;
+    return run_finish(h, iters, status);
+}
+
+int jg_nr_run_defer(jg_nr* h, int64_t max_iter, double tol, int64_t defer_at, int32_t* n_left) {
+    if (!h || max_iter < 0 || !(tol > 0.0) || defer_at < 0 || defer_at > 64 || !n_left) return fail(1, "jg_nr_run_defer: bad argument (defer_at in 0..64)");
+    if (h->fast) return fail(1, "jg_nr_run_defer: this handle runs fast Newton-Raphson");
+    if (int rc = set_device(h)) return rc;
+    if (int rc = run_setup(h, max_iter, tol, h->batch, false)) return rc;
+    NR_HIP(hipGraphLaunch(h->execA, h->stream));
+    NR_HIP(hipStreamSynchronize(h->stream));
+    if (int rc = run_loop(h, max_iter, h->ld > 64 ? (int)defer_at : 0)) return rc;   // one lane group: lanes are never packed, nothing to hand off
+    *n_left = *h->h_counter;
+    h->paused = true;
+    return 0;
+}
+
+int jg_nr_finish(jg_nr* h, int32_t* iters, int32_t* status) {
+    if (!h || !h->paused) return fail(1, "jg_nr_finish: the handle is not paused (jg_nr_run_defer)");
+    if (int rc = set_device(h)) return rc;
+    return run_finish(h, iters, status);
+}
+
+int jg_nr_move_lanes(jg_nr* dst, int64_t dst_lane0, jg_nr* src, int32_t* home, int32_t* count) {
+    if (!dst || !src || dst == src || !home || !count || dst_lane0 < 0) return fail(1, "jg_nr_move_lanes: bad argument");
+    if (!src->paused) return fail(1, "jg_nr_move_lanes: the source is not paused (jg_nr_run_defer)");
+    if (dst->device != src->device || dst->n != src->n || dst->nnz != src->nnz || dst->mp != src->mp || dst->fast || src->fast)
+        return fail(1, "jg_nr_move_lanes: the two handles must hold the same grid on the same device");
+    if (int rc = set_device(dst)) return rc;
+    for (jg_nr* h : {dst, src})
+        if (!h->d_move) {
+            NR_HIP(hipMalloc((void**)&h->d_move, 129 * sizeof(int)));
+            NR_HIP(hipHostMalloc((void**)&h->h_move, 65 * sizeof(int)));
+        }
+    NR_HIP(hipStreamSynchronize(src->stream));
+    int* map = dst->d_move; int* d_home = dst->d_move + 64; int* d_count = dst->d_move + 128;
+    MovePlanArgs pa{src->d_active, src->d_iters, src->d_status, src->d_lid, src->d_ppos, src->ld,
+                    dst->d_active, dst->d_iters, dst->d_status, dst->eng.status, dst->d_ppos, dst->ld,
+                    map, d_home, d_count, src->mp, (int)dst_lane0, dst->batch};
+    hipLaunchKernelGGL(k_move_plan, dim3(1), dim3(64), 0, dst->stream, pa);
+    MoveRowsArgs ra{};
+    int na = 0;
+    auto add = [&](const double* s, double* t, int rows) { ra.src[na] = s; ra.dst[na] = t; ra.rows[na] = rows; ++na; };
+    add(src->d_vm, dst->d_vm, src->n); add(src->d_va, dst->d_va, src->n); add(src->d_p, dst->d_p, src->n); add(src->d_q, dst->d_q, src->n);
+    if (src->mp > 0) { add(src->d_pdg, dst->d_pdg, src->mp); add(src->d_pdb, dst->d_pdb, src->mp); }
+    ra.s_ld = src->ld; ra.d_ld = dst->ld; ra.map = map;
+    hipLaunchKernelGGL(k_move_rows, dim3((unsigned)std::min((src->n + 3) / 4, 1024), (unsigned)na), dim3(256), 0, dst->stream, ra);
+    NR_HIP(hipGetLastError());
+    NR_HIP(hipMemcpyAsync(dst->h_move, d_home, 65 * sizeof(int), hipMemcpyDeviceToHost, dst->stream));
+    NR_HIP(hipStreamSynchronize(dst->stream));
+    const int c = dst->h_move[64];
+    if (c < 0) return fail(1, "jg_nr_move_lanes: the destination has not enough free lanes");
+    for (int i = 0; i < c; ++i) home[i] = dst->h_move[i];
+    *count = c;
+    *src->h_counter = 0;
+    dst->jac_valid = false;
+    return 0;
+}
+
+int jg_nr_resume(jg_nr* h, int64_t lanes, int64_t max_iter, double tol, int32_t* iters, int32_t* status) {
+    if (!h || lanes < 0 || lanes > h->batch || max_iter < 0 || !(tol > 0.0)) return fail(1, "jg_nr_resume: bad argument");
+    if (h->fast) return fail(1, "jg_nr_resume: this handle runs fast Newton-Raphson");
+    if (int rc = set_device(h)) return rc;
+    // lanes [0, lanes) hold moved scenarios (active, their iteration counts with them); the others are idle
+    if (int rc = run_setup(h, max_iter, tol, (int)lanes, true)) return rc;
+    if (lanes < h->ld) {
+        NR_HIP(hipMemsetAsync(h->d_active + lanes, 0, (size_t)(h->ld - lanes) * 4, h->stream));
+        NR_HIP(hipMemsetAsync(h->eng.status + lanes, 0, (size_t)(h->ld - lanes) * 4, h->stream));
+        NR_HIP(hipMemsetD32Async((hipDeviceptr_t)(h->d_iters + lanes), (int)max_iter, (size_t)(h->ld - lanes), h->stream));   // idle lanes: at the limit, never picked up by a verdict
+    }
+    launch_compact(h, 0, true);                                                // groups in use (the lanes are already packed)
+    launch_assemble(h, active_groups(h), true);                                // the Jacobian of the state they arrived with; NO verdict:
+    NR_HIP(hipStreamSynchronize(h->stream));                                   // theirs was taken (and counted) where they came from
+    if (int rc = run_loop(h, max_iter, 0)) return rc;
+    h->paused = true;
+    if (int rc = run_finish(h, nullptr, nullptr)) return rc;
+    if (iters) NR_HIP(jg::sync_copy(iters, h->d_iters, (size_t)lanes * 4, hipMemcpyDeviceToHost, h->stream));
+    if (status) NR_HIP(jg::sync_copy(status, h->d_status, (size_t)lanes * 4, hipMemcpyDeviceToHost, h->stream));
+    return 0;
+}
+
+int jg_nr_pack_rows_device(jg_nr* h, double* dst_dev, int64_t lane0, int64_t count, const int32_t* rows) {
+    if (!h || !dst_dev || !rows || lane0 < 0 || count < 0 || lane0 + count > h->batch || count > h->ld) return fail(1, "jg_nr_pack_rows_device: bad argument");
+    if (count == 0) return 0;
+    if (int rc = set_device(h)) return rc;
+    NR_HIP(hipMemcpyAsync(h->d_itmp, rows, (size_t)count * 4, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)std::min((h->n + 255) / 256, 64), (unsigned)count), dim3(256), 0, h->stream,
+                       h->d_vm, h->d_va, h->d_iters, h->d_status, h->d_itmp, dst_dev, h->n, h->ld, (int)lane0, 2LL * h->n + 2);
+    NR_HIP(hipGetLastError());
+    NR_HIP(hipStreamSynchronize(h->stream));
     return 0;
 }
 
 int jg_nr_get_mismatch(jg_nr* h, double* mism) {
     if (!h || !mism) return fail(1, "jg_nr_get_mismatch: bad argument");
     if (int rc = set_device(h)) return rc;
+    if (h->f_stale) { launch_assemble(h, jg::GroupSel{}, false); NR_HIP(hipGetLastError()); h->f_stale = false; }
     NR_HIP(hipStreamSynchronize(h->stream));
     std::vector<double> t((size_t)h->n * 2 * h->batch);
     if (int rc = get_bus_array(h, h->d_F, t.data(), 2)) return rc;

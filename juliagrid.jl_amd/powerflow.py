@@ -163,6 +163,43 @@ class AcPowerFlow:
         """[batch, 2 n + 2] result records (V | theta | iterations | status) into a caller-owned DEVICE buffer."""
         _lib.check(_lib.lib().jg_nr_pack_results_device(self._h, C.c_void_p(dst_ptr)))
 
+    # ---- straggler hand-off (jgrid.h: jg_nr_run_defer ...): used by ContingencyPipeline, not part of the reference's surface
+    def run_defer(self, iteration: int = 20, tolerance: float = 1e-8, defer_at: int = 64) -> int:
+        """powerFlow! that pauses once at most `defer_at` scenarios are active; returns how many are left (0: done).
+        Follow with pool.take_lanes(self, ...) (if any are left) and self.finish()."""
+        _check_signature(self)
+        left = C.c_int32(0)
+        _lib.check(_lib.lib().jg_nr_run_defer(self._h, int(iteration), float(tolerance), int(defer_at), C.byref(left)))
+        return int(left.value)
+
+    def finish(self):
+        """Ends a paused run: method.iteration / status of every scenario (4 = handed to a pool)."""
+        it = np.zeros(self.batch, dtype=np.int32)
+        st = np.zeros(self.batch, dtype=np.int32)
+        _lib.check(_lib.lib().jg_nr_finish(self._h, it, st))
+        self.method.iteration = int(it[0]) if self.batch == 1 else it
+        self.status = int(st[0]) if self.batch == 1 else st
+
+    def take_lanes(self, src: "AcPowerFlow", lane0: int) -> np.ndarray:
+        """The still-active scenarios of the paused analysis `src` continue in lanes lane0.. of this one; returns their
+        scenario numbers in `src` (0-based), in lane order."""
+        home = np.zeros(64, dtype=np.int32)
+        count = C.c_int32(0)
+        _lib.check(_lib.lib().jg_nr_move_lanes(self._h, int(lane0), src._h, home, C.byref(count)))
+        return home[:count.value].copy()
+
+    def resume(self, lanes: int, iteration: int = 20, tolerance: float = 1e-8):
+        """Runs the scenarios in lanes [0, lanes) to the end; returns (iterations, status) of those lanes."""
+        it = np.zeros(max(lanes, 1), dtype=np.int32)
+        st = np.zeros(max(lanes, 1), dtype=np.int32)
+        _lib.check(_lib.lib().jg_nr_resume(self._h, int(lanes), int(iteration), float(tolerance), it, st))
+        return it[:lanes], st[:lanes]
+
+    def pack_rows_device(self, dst_ptr: int, lane0: int, rows):
+        """Result records of lanes lane0 .. lane0 + len(rows) - 1 into rows `rows` of a [., 2 n + 2] DEVICE record."""
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        _lib.check(_lib.lib().jg_nr_pack_rows_device(self._h, C.c_void_p(dst_ptr), int(lane0), int(rows.size), rows))
+
     def time_kernel(self, kernel: int, reps: int = 10) -> float:
         ms = C.c_double(0.0)
         _lib.check(_lib.lib().jg_nr_time_kernel(self._h, int(kernel), int(reps), C.byref(ms)))

@@ -1,0 +1,69 @@
+"""ContingencyPipeline with a straggler pool (jg_nr_run_defer / jg_nr_move_lanes / jg_nr_resume / jg_nr_pack_rows_device):
+every scenario's result -- iteration count, status, V, theta -- is BITWISE what the lockstep pipeline gives; scenarios without a
+power flow and scenarios that never leave their batch are covered."""
+import numpy as np
+import pytest
+
+from conftest import load_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _records(torch, count, lanes, n):
+    return [torch.full((lanes, 2 * n + 2), -7.0, dtype=torch.float64, device="cuda") for _ in range(count)]
+
+
+@pytest.mark.parametrize("name,batch,njobs,pool", [("case1354pegase", 192, 7, 128), ("case1354pegase", 128, 5, 64),
+                                                  ("case_ACTIVSg10k", 512, 4, 256)])
+def test_pool_is_bitwise_the_lockstep_pipeline(jg, name, batch, njobs, pool):
+    import torch
+    s = jg.powerSystem(load_case(name))
+    n = s.bus.number
+    base = jg.newtonRaphson(s)
+    jg.powerFlow_(base)
+    start = (base.voltage.magnitude.copy(), base.voltage.angle.copy())
+    labels = jg.outageList(s, batch * njobs, seed=3)
+    jobs = [labels[i * batch:(i + 1) * batch] for i in range(njobs)]
+    jobs[-1] = jobs[-1][:batch - 5]                                   # a ragged last job (padded with base-case lanes)
+    out = {}
+    for mode in ("lockstep", "pool"):
+        pipe = jg.ContingencyPipeline(s, batch, inflight=3, start=start, pool=pool if mode == "pool" else 0)
+        assert bool(pipe.pools) == (mode == "pool")
+        ring = 4 if mode == "pool" else njobs
+        rec = _records(torch, ring, batch, n)
+        seen = []
+
+        def on_done(j, an, rec=rec, ring=ring, seen=seen):
+            seen.append((j, rec[j % ring].clone()))        # the library synchronised its own stream after writing the record
+            torch.cuda.current_stream().synchronize()      # (no device-wide sync: another worker may be capturing its graphs)
+
+        res = pipe.run(jobs, iteration=20, tolerance=1e-8, on_done=on_done, record=lambda j: rec[j % ring].data_ptr(), records=ring)
+        assert [j for j, _ in seen] == list(range(njobs))
+        out[mode] = (res, [r.cpu().numpy() for _, r in seen])
+        pipe.close()
+    moved = 0
+    for j in range(njobs):
+        (it_a, st_a), (it_b, st_b) = out["lockstep"][0][j], out["pool"][0][j]
+        assert np.array_equal(it_a, it_b) and np.array_equal(st_a, st_b)
+        assert not np.any(st_b == 4)                                  # nothing is left "deferred"
+        ra, rb = out["lockstep"][1][j], out["pool"][1][j]
+        assert np.array_equal(ra, rb)                                 # V | theta | iterations | status, bitwise
+        assert np.array_equal(rb[:, 2 * n], it_b.astype(float)) and np.array_equal(rb[:, 2 * n + 1], st_b.astype(float))
+        moved += int(np.sum(it_b > np.median(it_b)))
+    assert moved > 0                                                  # some scenarios did need more iterations than their batch
+
+
+def test_pool_handles_scenarios_without_a_power_flow(jg):
+    """An islanding outage (status 3) and a scenario that runs into the iteration limit end with the right status whether they
+    finish in their batch or in the pool; screen() works with a pool (no records)."""
+    s = jg.powerSystem(load_case("case1354pegase"))
+    good = [int(x) for x in jg.outageList(s, 300, seed=5)]
+    br = np.flatnonzero(jg.bridges(s) & (s.branch.layout.status == 1)) + 1
+    labels = good[:100] + [int(br[0])] + good[100:200] + [int(br[1])] + good[200:]
+    a = jg.ContingencyPipeline(s, 128, inflight=2)
+    b = jg.ContingencyPipeline(s, 128, inflight=2, pool=128)
+    it_a, st_a = a.screen(labels, iteration=6, tolerance=1e-8)
+    it_b, st_b = b.screen(labels, iteration=6, tolerance=1e-8)
+    a.close(); b.close()
+    assert np.array_equal(it_a, it_b) and np.array_equal(st_a, st_b)
+    assert set(np.unique(st_a)) <= {0, 1, 3} and st_a[100] != 0 and st_a[201] != 0
