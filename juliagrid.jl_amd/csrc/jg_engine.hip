@@ -568,7 +568,7 @@ __global__ __launch_bounds__(TOP_THREADS) void k_fact_top(TopArgs a) {
     long long* pt = a.prof + (size_t)(a.task_begin + ti) * 8;
     if (prof) pt[0] = wall_clock64();
     const RecS h = load_rec(a.task, (size_t)a.task_begin + ti);
-    const int m = h[0], e = h[1], k0 = h[2], nchild = h[5], fprime = h[11];
+    const int m = h[0], e = h[1], nchild = h[5], fprime = h[11];
     const int f = fprime - 1;
     const int* td = a.data + h[3];
     const size_t b = (size_t)bb, ld = (size_t)a.ld;
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(TOP_THREADS) void k_fact_top(TopArgs a) {
             for (int c = 0; c < CLS; ++c) {
                 const int cd = code[r][c];
                 Blk v{0.0, 0.0, 0.0, 0.0};
-                if (cd == -2) { const double2 y = load_vec(a.W, (size_t)(k0 + r * 16 + gi), b, ld); v.v00 = y.x; v.v10 = y.y; }
+                if (cd <= -2) { const double2 y = load_vec(a.W, (size_t)(-(cd + 2)), b, ld); v.v00 = y.x; v.v10 = y.y; }
                 else if (cd >= 0 && !((cd >> 28) & 1)) {
                     v = load_blk(a.X, (size_t)(cd & 0x0fffffff), b, ld);
                     if ((cd >> 28) & 2) { const double s = v.v01; v.v01 = v.v10; v.v10 = s; }        // symmetric plans: Lh(i,c) = U(c,i)'
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(TOP_THREADS) void k_fact_top(TopArgs a) {
                 const int i = r * 16 + gi, j = c * 16 + gj;
                 const int cd = code[r][c];
                 const Blk& v = T[r][c];
-                if (cd == -2) store_vec(a.W, (size_t)(k0 + i), b, ld, v.v00, v.v10);
+                if (cd <= -2) store_vec(a.W, (size_t)(-(cd + 2)), b, ld, v.v00, v.v10);
                 else if (cd >= 0 && !((cd >> 28) & 4)) store_blk(a.X, (size_t)(cd & 0x0fffffff), b, ld, v.v00, v.v01, v.v10, v.v11);
                 else if (i >= m && i < f && j >= m && j < fprime) {                              // update matrix | vector: scenario-major stack
                     double2* p = (double2*)(out + ((size_t)(i - m) * (e + 1) + (j - m)) * 4);

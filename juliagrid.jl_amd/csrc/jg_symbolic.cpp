@@ -12,7 +12,7 @@
 namespace jg {
 
 void build_tables(BlockSymbolic& S);
-void build_top(BlockSymbolic& S, int top_level, int soft_cap);
+void build_top(BlockSymbolic& S, int top_level, int soft_cap, int struct_min);
 
 namespace {
 
@@ -191,8 +191,12 @@ void build_replay(const std::vector<int>& level, const std::vector<int>& work, i
 
 }  // namespace
 
-// Top tasks (jg_symbolic.hpp): choose the pivots, cut them into chains, level the chain tree, emit headers + data.
-void build_top(BlockSymbolic& S, int top_level, int soft_cap) {
+// Top tasks (jg_symbolic.hpp): choose the pivots, cut them into tasks, level the task tree, emit headers + data.
+// A task is a CONNECTED piece of the elimination tree with one root: the root, then -- while the front has room -- pivots whose
+// parent is already in the task, largest pivot number first (the supernode child of a pivot is its largest child, so a chain is
+// followed to its end before siblings are taken).  Its front holds the task's pivots in ascending order, then struct(root);
+// the elimination is dense over that front (a block outside a pivot's structure is an exact zero and stays one).
+void build_top(BlockSymbolic& S, int top_level, int soft_cap, int struct_min) {
     const int n = S.n;
     S.top_level = 0; S.top_task.clear(); S.top_data.clear(); S.top_launch.clear(); S.top_stack = 0; S.top_terms = 0;
     S.top_task_of.assign(n, -1);
@@ -201,25 +205,37 @@ void build_top(BlockSymbolic& S, int top_level, int soft_cap) {
     auto parent = [&](int k) { return ssize(k) ? S.u_col[S.u_ptr[k]] : -1; };
     std::vector<char> top(n, 0);
     int ntop = 0;
-    for (int k = 0; k < n; ++k) if (S.e_level[S.diag[k]] >= top_level) { top[k] = 1; ++ntop; if (ssize(k) + 1 > TOP_FRONT_MAX) return; }
+    for (int k = 0; k < n; ++k) if (S.e_level[S.diag[k]] >= top_level) top[k] = 1;
+    // fronts of struct_min blocks and more go to the tasks wherever they sit in the tree, and so do their ancestors (a task hands
+    // its update matrix to the task of its parent): per (pivot, scenario) a task step costs the same whatever the front, a
+    // level item costs per update term, and the two cross near 13 blocks
+    if (struct_min > 0) {
+        for (int k = 0; k < n; ++k) if (ssize(k) >= struct_min) top[k] = 1;
+        for (int k = 0; k < n; ++k) if (top[k] && parent(k) >= 0) top[parent(k)] = 1;
+    }
+    for (int k = 0; k < n; ++k) if (top[k]) { ++ntop; if (ssize(k) + 1 > TOP_FRONT_MAX) return; }
     if (ntop == 0) return;
-    struct Task { int k0, m, e, parent, level, cls, stack; std::vector<int> kids; };
+    struct Task { std::vector<int> piv; int m, e, parent, level, cls, stack; std::vector<int> kids; int root() const { return piv.back(); } };
     std::vector<Task> tasks;
+    std::vector<int> sub(n, 1);                                  // subtree sizes: the descendants of k are k - sub[k] + 1 .. k - 1 (postorder)
+    for (int k = 0; k < n; ++k) if (parent(k) >= 0) sub[parent(k)] += sub[k];
     for (int k = n - 1; k >= 0; --k) {
         if (!top[k] || S.top_task_of[k] >= 0) continue;
         Task t{};
         t.e = ssize(k);
         const int cap = std::max(std::min(8, TOP_FRONT_MAX - t.e), soft_cap - t.e);
-        int m = 1;
-        while (k - m >= 0 && top[k - m] && parent(k - m) == k - m + 1 && m < cap) ++m;
-        t.k0 = k - m + 1; t.m = m; t.parent = -1; t.level = 1; t.stack = -1;
-        for (int q = t.k0; q <= k; ++q) S.top_task_of[q] = (int)tasks.size();
+        const int id = (int)tasks.size();
+        t.piv.push_back(k); S.top_task_of[k] = id;
+        for (int q = k - 1; q > k - sub[k] && (int)t.piv.size() < cap; --q)
+            if (top[q] && S.top_task_of[q] < 0 && S.top_task_of[parent(q)] == id) { t.piv.push_back(q); S.top_task_of[q] = id; }
+        std::reverse(t.piv.begin(), t.piv.end());
+        t.m = (int)t.piv.size(); t.parent = -1; t.level = 1; t.stack = -1;
         tasks.push_back(t);
     }
     const int nt = (int)tasks.size();
     // tasks were created from the root down: a child has a larger index than its parent
     for (int t = nt - 1; t >= 0; --t) {
-        const int p = parent(tasks[t].k0 + tasks[t].m - 1);
+        const int p = parent(tasks[t].root());
         if (p >= 0) { tasks[t].parent = S.top_task_of[p]; tasks[tasks[t].parent].kids.push_back(t); tasks[tasks[t].parent].level = std::max(tasks[tasks[t].parent].level, tasks[t].level + 1); }
     }
     long long stack = 0;
@@ -227,7 +243,7 @@ void build_top(BlockSymbolic& S, int top_level, int soft_cap) {
         const int fprime = t.m + t.e + 1;                        // front rows / columns + the rhs column
         t.cls = fprime <= 32 ? 2 : (fprime <= 48 ? 3 : 4);       // blocks per thread and dimension on the 16 x 16 thread grid
         if (t.e > 0) { t.stack = (int)stack; stack += (long long)t.e * (t.e + 1) * 4; }       // e x (e + 1) blocks: update matrix | update vector
-        for (int q = 0; q < t.m; ++q) { const long long s = ssize(t.k0 + q); S.top_terms += s * (s + 1); }
+        for (int k : t.piv) { const long long s = ssize(k); S.top_terms += s * (s + 1); }
     }
     if (stack >= (1LL << 31)) { S.top_task_of.assign(n, -1); return; }
     S.top_stack = stack;
@@ -238,7 +254,7 @@ void build_top(BlockSymbolic& S, int top_level, int soft_cap) {
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
         if (tasks[a].level != tasks[b].level) return tasks[a].level < tasks[b].level;
-        return tasks[a].k0 < tasks[b].k0;
+        return tasks[a].root() < tasks[b].root();
     });
     const bool sym = S.symmetric != 0;
     S.top_task.resize(nt);
@@ -246,8 +262,9 @@ void build_top(BlockSymbolic& S, int top_level, int soft_cap) {
         const Task& t = tasks[order[oi]];
         const int m = t.m, e = t.e, f = m + e, fprime = f + 1;
         auto local = [&](const Task& tt, int pivot) {           // front index of a pivot in task tt, -1 if outside
-            if (pivot >= tt.k0 && pivot < tt.k0 + tt.m) return pivot - tt.k0;
-            const int kl = tt.k0 + tt.m - 1;
+            const auto it = std::lower_bound(tt.piv.begin(), tt.piv.end(), pivot);
+            if (it != tt.piv.end() && *it == pivot) return (int)(it - tt.piv.begin());
+            const int kl = tt.root();
             const int* b = S.u_col.data() + S.u_ptr[kl];
             const int* en = S.u_col.data() + S.u_ptr[kl + 1];
             const int* p = std::lower_bound(b, en, pivot);
@@ -257,7 +274,7 @@ void build_top(BlockSymbolic& S, int top_level, int soft_cap) {
         const int base = (int)S.top_data.size();
         // entry map of the front, [f][f + 1]: what thread-slot (r, c) loads before and stores after the elimination
         //   -1 nothing (outside the pattern, or the update matrix / vector: starts from zero, leaves through the stack)
-        //   -2 rhs row of pivot r (column f): loaded from and stored to the rhs storage
+        //   -(2 + k) rhs row of pivot k (column f of the pivot's front row): loaded from and stored to the rhs storage
         //   entry | flags << 28: flag 1 starts from zero (fill-in that no bottom pivot touches), 2 read transposed (symmetric plans
         //   keep the upper triangle only: slot (r, c), r > c, reads entry (c, r)), 4 not stored by the slot's thread (the
         //   transposed copies; the diagonal blocks of the chain, which leave through the pivot wave in factorised form)
@@ -274,10 +291,10 @@ void build_top(BlockSymbolic& S, int top_level, int soft_cap) {
         };
         std::vector<int> dent(m);
         for (int q = 0; q < m; ++q) {
-            const int k = t.k0 + q;
+            const int k = t.piv[q];
             dent[q] = S.diag[k];
             put(S.diag[k], q, q);
-            emap[(size_t)q * fprime + f] = -2;
+            emap[(size_t)q * fprime + f] = -(2 + k);
             for (int p = S.u_ptr[k]; p < S.u_ptr[k + 1]; ++p) {
                 const int j = S.u_col[p], lj = local(t, j);
                 put(S.u_ent[p], q, lj);
@@ -292,7 +309,7 @@ void build_top(BlockSymbolic& S, int top_level, int soft_cap) {
         const int child_off = (int)S.top_data.size() - base;
         for (int c : t.kids) {
             const Task& ct = tasks[c];
-            const int kl = ct.k0 + ct.m - 1;
+            const int kl = ct.root();
             S.top_data.push_back(ct.stack); S.top_data.push_back(ct.e);
             std::vector<int> inv(fprime, -1);
             int idx = 0;
@@ -300,8 +317,10 @@ void build_top(BlockSymbolic& S, int top_level, int soft_cap) {
             inv[f] = ct.e;
             S.top_data.insert(S.top_data.end(), inv.begin(), inv.end());
         }
-        h.w[0] = m; h.w[1] = e; h.w[2] = t.k0; h.w[3] = base; h.w[4] = t.stack; h.w[5] = (int)t.kids.size();
-        h.w[6] = 0; h.w[7] = child_off; h.w[8] = dent_off; h.w[9] = t.cls; h.w[10] = t.level; h.w[11] = fprime;
+        const int piv_off = (int)S.top_data.size() - base;
+        S.top_data.insert(S.top_data.end(), t.piv.begin(), t.piv.end());
+        h.w[0] = m; h.w[1] = e; h.w[2] = t.root(); h.w[3] = base; h.w[4] = t.stack; h.w[5] = (int)t.kids.size();
+        h.w[6] = piv_off; h.w[7] = child_off; h.w[8] = dent_off; h.w[9] = t.cls; h.w[10] = t.level; h.w[11] = fprime;
         S.top_task[oi] = h;
         if (S.top_launch.empty() || S.top_launch.back().level != t.level) S.top_launch.push_back(TopLaunch{oi, 0, t.cls, t.level});
         S.top_launch.back().ntasks++;
@@ -683,7 +702,9 @@ int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic&
             if (top_level > nlev - 2) top_level = 255;           // nothing worth a task
         }
         if (soft <= 0) soft = TOP_FRONT_SOFT;
-        build_top(S, top_level, std::min(soft, TOP_FRONT_MAX));
+        int struct_min = 0;
+        if (const char* e = getenv("JG_TOP_STRUCT")) struct_min = atoi(e);
+        build_top(S, top_level, std::min(soft, TOP_FRONT_MAX), struct_min);
     }
     build_tables(S);
     return 0;

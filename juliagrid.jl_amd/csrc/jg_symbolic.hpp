@@ -50,9 +50,10 @@ struct Rec { int w[16]; };
 // ---- multifrontal TOP of the elimination tree ---------------------------------------------------------------------
 // Above a dependency level the tree is a handful of long chains with few items per level: per-level launches there cost a
 // kernel boundary + a cold record fetch + a round of operand loads each (7.7 us at 64 scenarios, 9-20 us at 512) for a
-// handful of blocks.  Those pivots are factorised by TOP TASKS instead: a task = consecutive pivots k0 .. k0+m-1 that
-// form a path of the tree (parent(k) = k + 1), worked on by ONE workgroup PER SCENARIO -- lanes run across the dense front
-// (m pivots + e external rows / columns, e = |struct(last pivot)|, + the rhs as one more column), which lives in the
+// handful of blocks.  Those pivots are factorised by TOP TASKS instead: a task = a connected piece of the tree with one root
+// (a path k0 .. k0+m-1 with parent(k) = k + 1 first; siblings and their descendants while the front has room), worked on by
+// ONE workgroup PER SCENARIO -- lanes run across the dense front
+// (m pivots in ascending order + e external rows / columns, e = |struct(root)|, + the rhs as one more column), which lives in the
 // REGISTERS of a 16 x 16 thread grid (thread (i mod 16, c mod 16) owns block (i, c): `cls` x `cls` blocks per thread); a
 // pivot step publishes the next pivot row / column through LDS and costs one workgroup barrier (jg_engine.hip: k_fact_top).
 // Tasks talk multifrontally: a task leaves its e x (e + 1) update matrix | vector on a scenario-major stack, its parent adds
@@ -61,10 +62,10 @@ struct Rec { int w[16]; };
 // Contributions of BOTTOM pivots (all others) to task-owned entries still arrive through level items: those items carry
 // only the bottom terms of the entry and store the partial sum raw (also for diagonal blocks).
 //   header (one 64-byte record per task; level-major; a launch = one level, compiled for its widest front):
-//     w0 m, w1 e, w2 k0, w3 offset of the task's data in top_data, w4 stack offset of its update block (doubles, -1: root),
-//     w5 children, w7 offset of the child records, w8 offset of the diagonal entries (both relative to w3), w9 class
-//     (2, 3, 4: the front has at most 16 class rows and columns), w10 task level, w11 f + 1
-//   data: entry map [f][f + 1] (see build_top), diagonal entries [m], child records {stack offset, e_c, inv[f + 1]}
+//     w0 m, w1 e, w2 root pivot, w3 offset of the task's data in top_data, w4 stack offset of its update block (doubles, -1: root),
+//     w5 children, w6 offset of the pivot list, w7 offset of the child records, w8 offset of the diagonal entries (all relative
+//     to w3), w9 class (2, 3, 4: the front has at most 16 class rows and columns), w10 task level, w11 f + 1
+//   data: entry map [f][f + 1] (see build_top), diagonal entries [m], child records {stack offset, e_c, inv[f + 1]}, pivots [m]
 constexpr int TOP_FRONT_MAX = 63;       // m + e of a task: 64 columns with the rhs = class 4 on the 16 x 16 thread grid
 struct TopLaunch { int task_begin, ntasks, cls, level; };
 

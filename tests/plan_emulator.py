@@ -179,13 +179,17 @@ class Replay:
             lev = bottom_levels + tlevel
             results = []
             for ti in range(tb, tb + ntk):
-                m, e, k0, base, soff, nchild, _, child_off, dent_off, tcls, tl, fprime = (int(v) for v in hdr[ti][:12])
+                m, e, root, base, soff, nchild, piv_off, child_off, dent_off, tcls, tl, fprime = (int(v) for v in hdr[ti][:12])
                 f = m + e
+                tp = data[base + piv_off: base + piv_off + m].astype(np.int64)          # the task's pivots, ascending, the root last
+                assert np.all(np.diff(tp) > 0) and tp[-1] == root
+                par = [int(u_col[self.u_ptr[k]]) if self.u_ptr[k + 1] > self.u_ptr[k] else -1 for k in tp]
+                assert all(pk in set(tp.tolist()) for pk in par[:-1]), "a task is a connected piece of the elimination tree"
                 assert tl == tlevel and tcls <= cls and fprime == f + 1 <= 16 * tcls and (tcls == 2 or fprime > 16 * (tcls - 1)) and m >= 1
-                assert np.all(self.task_of[k0:k0 + m] == ti)
-                ext = self._front_ext(k0, m)
+                assert np.all(self.task_of[tp] == ti) and np.sum(self.task_of == ti) == m
+                ext = self._front_ext(root)
                 assert ext.size == e
-                piv = np.concatenate([np.arange(k0, k0 + m), ext])
+                piv = np.concatenate([tp, ext])
                 F = np.zeros((f, fprime, 2, 2))
                 emap = data[base: base + f * fprime].reshape(f, fprime)
                 owned, seen = [], set()
@@ -195,9 +199,9 @@ class Replay:
                         if cd == -1:
                             assert (r >= m and (c >= m)) or (c < f and min(r, c) < m), "only the update block and pattern holes are unmapped"
                             continue
-                        if cd == -2:
-                            assert c == f and r < m and partial[nE + k0 + r]
-                            F[r, c, :, 0] = Y[k0 + r]
+                        if cd <= -2:
+                            assert c == f and r < m and -(cd + 2) == tp[r] and partial[nE + tp[r]]
+                            F[r, c, :, 0] = Y[tp[r]]
                             continue
                         ent, fl = cd & 0x0fffffff, cd >> 28
                         assert min(r, c) < m and c < f
@@ -220,12 +224,12 @@ class Replay:
                                 owned.append((ent, r, c))
                 # every pattern entry of the chain's rows / columns is mapped
                 for q in range(m):
-                    k = k0 + q
+                    k = int(tp[q])
                     assert self.diag[k] in seen
                     want = set(int(x) for x in self.p.get("u_ent")[self.u_ptr[k]: self.u_ptr[k + 1]])
                     assert want <= seen
                 dent = data[base + dent_off: base + dent_off + m]
-                assert np.array_equal(dent, self.diag[k0:k0 + m])
+                assert np.array_equal(dent, self.diag[tp])
                 cd = base + child_off
                 for _ in range(nchild):
                     coff, ce = int(data[cd]), int(data[cd + 1])
@@ -240,10 +244,10 @@ class Replay:
                 D = [None] * m
                 D[0] = dfactor(F[0, 0])
                 for q in range(m):
-                    k = k0 + q
+                    k = int(tp[q])
                     s = int(self.u_ptr[k + 1] - self.u_ptr[k])
-                    loc = [self._loc(k0, m, e, int(c)) for c in u_col[self.u_ptr[k]: self.u_ptr[k + 1]]]
-                    assert q + 1 == m or (s > 0 and loc[0] == q + 1)
+                    loc = [self._loc(tp, root, int(c)) for c in u_col[self.u_ptr[k]: self.u_ptr[k + 1]]]
+                    assert q + 1 == m or (s > 0 and min(loc) > q)
                     Z = np.zeros((fprime, 2, 2))
                     for c in range(q + 1, fprime):
                         Z[c] = np.stack([dsolve(D[q], F[q, c][:, 0]), dsolve(D[q], F[q, c][:, 1])], axis=1)
@@ -258,8 +262,8 @@ class Replay:
                     if q + 1 < m:
                         D[q + 1] = dfactor(F[q + 1, q + 1])
                 assert not np.isnan(F).any()
-                results.append((ti, owned, F, D, k0, m, e, soff, dent))
-            for ti, owned, F, D, k0, m, e, soff, dent in results:             # tasks of one launch are independent of each other
+                results.append((ti, owned, F, D, tp, m, e, soff, dent))
+            for ti, owned, F, D, tp, m, e, soff, dent in results:             # tasks of one launch are independent of each other
                 f = m + e
                 for ent, r, c in owned:
                     X[ent] = F[r, c]
@@ -269,10 +273,10 @@ class Replay:
                     X[dent[q]] = D[q]
                     level_of[dent[q]] = lev
                     partial[dent[q]] = False
-                    Y[k0 + q] = F[q, f, :, 0]
-                    level_of[nE + k0 + q] = lev
-                    partial[nE + k0 + q] = False
-                    done_pivot[k0 + q] = True
+                    Y[tp[q]] = F[q, f, :, 0]
+                    level_of[nE + tp[q]] = lev
+                    partial[nE + tp[q]] = False
+                    done_pivot[tp[q]] = True
                 if e > 0:
                     assert soff >= 0
                     stack[soff: soff + e * (e + 1) * 4] = F[m:, m:].reshape(-1)
@@ -284,18 +288,15 @@ class Replay:
         assert np.array_equal(done_pivot, self.task_of >= 0)
         return terms
 
-    def _front_ext(self, k0, m):
-        kl = k0 + m - 1
-        return self.p.get("u_col")[self.u_ptr[kl]: self.u_ptr[kl + 1]]
+    def _front_ext(self, root):
+        return self.p.get("u_col")[self.u_ptr[root]: self.u_ptr[root + 1]]
 
-    def _piv(self, k0, m, e, loc):
-        return k0 + loc if loc < m else int(self._front_ext(k0, m)[loc - m])
-
-    def _loc(self, k0, m, e, piv):
-        if k0 <= piv < k0 + m:
-            return piv - k0
-        ext = self._front_ext(k0, m).tolist()
-        return m + ext.index(piv)
+    def _loc(self, tp, root, piv):
+        hit = np.flatnonzero(tp == piv)
+        if hit.size:
+            return int(hit[0])
+        ext = self._front_ext(root).tolist()
+        return len(tp) + ext.index(piv)
 
     def backsolve(self, X, Y):
         """Replays the backward tables: wave-record rows and CHAIN tasks (segments with wpi == 0: consecutive pivots of a
