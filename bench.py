@@ -344,9 +344,8 @@ def main():
     b_max = -(-total // world)
     if args.merge > 0:
         merge = args.merge
-    elif args.scaling == "strong" and 512 // b_max > 1:
-        m_max = min(512 // b_max, args.steps)         # at most 512 lanes; among the upper half, the M that leaves the fewest spare lanes in
-        merge = min(range(max(1, (m_max + 1) // 2), m_max + 1), key=lambda m: (-(-args.steps // m) * m - args.steps, -m))   # the last batch
+    elif args.scaling == "strong":
+        merge = jg.deviceBatching(b_max, args.steps, 512)   # at most 512 lanes; the count that leaves the fewest spare lanes in the last batch
     else:
         merge = 1
     merge = max(1, min(merge, args.steps))

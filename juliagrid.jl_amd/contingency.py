@@ -78,6 +78,17 @@ def shard(count: int, rank: int, world: int) -> tuple[int, int]:
     return lo, min(lo + per, count)
 
 
+def deviceBatching(share: int, steps: int, lanes: int = 512) -> int:
+    """How many consecutive steps a rank solves together as one device batch (strong scaling: a rank's share of a step shrinks
+    with the number of ranks, the path is at its best around `lanes` scenarios per launch).  At most lanes // share steps; among
+    the upper half of that range the count that leaves the fewest spare lanes in the last batch of a run of `steps` steps,
+    the larger one on a tie.  1 when the share already fills the lanes."""
+    m_max = min(max(1, lanes // max(1, int(share))), max(1, int(steps)))
+    if m_max <= 1:
+        return 1
+    return min(range(max(1, (m_max + 1) // 2), m_max + 1), key=lambda m: (-(-steps // m) * m - steps, -m))
+
+
 def contingencyAnalysis(system: PowerSystem, labels, device: int = 0) -> AcPowerFlow:
     """Batched analysis with scenario s = outage of branch labels[s] (None / 0 = base case)."""
     labels = list(labels)

@@ -25,6 +25,20 @@ def test_shard_is_a_contiguous_partition(jg):
             assert max(hi - lo for lo, hi in blocks) - min(hi - lo for lo, hi in blocks if hi > lo or True) <= -(-count // world)
 
 
+def test_device_batching_of_a_shrinking_share(jg):
+    """bench.py --merge: steps per device batch under strong scaling (512 scenarios per step over N ranks, K steps)."""
+    assert jg.deviceBatching(512, 48) == 1 and jg.deviceBatching(700, 48) == 1            # N = 1: a step already fills the lanes
+    assert jg.deviceBatching(256, 48) == 2 and jg.deviceBatching(128, 48) == 4 and jg.deviceBatching(64, 48) == 8
+    assert jg.deviceBatching(64, 20) == 5                                                  # 4 batches of 5 steps, no spare lanes
+    assert jg.deviceBatching(64, 3) == 3 and jg.deviceBatching(64, 1) == 1
+    for share in (64, 100, 171, 256):
+        for steps in (1, 5, 7, 20, 24, 96):
+            m = jg.deviceBatching(share, steps)
+            assert 1 <= m <= max(1, min(512 // share, steps)) and m * share <= max(512, share)
+            spare = -(-steps // m) * m - steps
+            assert all(spare <= -(-steps // q) * q - steps for q in range(max(1, (min(512 // share, steps) + 1) // 2), min(512 // share, steps) + 1))
+
+
 def test_outage_list_is_seeded_and_avoids_bridges(jg):
     s = jg.powerSystem(load_case("case118"))
     a = jg.outageList(s, 40, seed=512)

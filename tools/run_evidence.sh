@@ -7,6 +7,9 @@ export TMPDIR=/tmp
 tools/run_pmc.sh ${TAG} 512 2 case_ACTIVSg10k > gpurun_out/run_pmc_${TAG}.log 2>&1
 cp gpurun_out/pmc_${TAG}.json profiles/pmc_traffic.json        # bench.py reads roofline.traffic from here (grid and batch must match)
 python bench.py > gpurun_out/bench_${TAG}.json 2> gpurun_out/bench_${TAG}.err
+# the same line without the straggler pool (every batch finishes its own stragglers), and with scenarios that all take 3 iterations
+python bench.py --pool 0 --no-cpu --no-se 2>/dev/null | grep '^{' > gpurun_out/bench_nopool_${TAG}.json
+JG_BENCH_PROBE_UNIFORM=3 python bench.py --pool 0 --no-cpu --no-se 2>/dev/null | grep '^{' > gpurun_out/bench_uniform3_${TAG}.json
 python bench.py --case case9241synth --steps 24 --warmup 3 --no-se > gpurun_out/bench_9241_${TAG}.json 2> gpurun_out/bench_9241_${TAG}.err
 python bench.py --case case1354pegase --steps 24 --warmup 3 --no-se > gpurun_out/bench_1354_${TAG}.json 2> gpurun_out/bench_1354_${TAG}.err
 python tools/bench_se.py > gpurun_out/bench_se_${TAG}.json 2> gpurun_out/bench_se_${TAG}.err
