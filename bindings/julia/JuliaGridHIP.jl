@@ -264,6 +264,42 @@ function powerFlow!(b::NewtonRaphsonBatch; iteration::Int64 = 20, tolerance::Flo
     return nothing
 end
 
+# ---- straggler hand-off between batches (jgrid.h: jg_nr_run_defer ...): a pipeline of batches stops a batch once <= deferAt
+# scenarios are active, moves them into a POOL batch that collects the stragglers of several batches, and finishes them together
+# (what ContingencyPipeline(pool = ...) does on the Python side; a Julia driver runs batches from Threads.@spawn tasks).
+"runs until at most `deferAt` (<= 64) scenarios are still active; returns their number (0: the batch is done).  Follow with
+moveLanes!(pool, lane0, b) if any are left, then finish!(b)."
+function powerFlowDefer!(b::NewtonRaphsonBatch; iteration::Int64 = 20, tolerance::Float64 = 1e-8, deferAt::Int64 = 64)
+    left = Ref{Int32}(0)
+    check(ccall((:jg_nr_run_defer, lib), Cint, (Ptr{Cvoid}, Int64, Float64, Int64, Ref{Int32}),
+        b.handle.ptr, iteration, tolerance, deferAt, left))
+    return Int(left[])
+end
+
+"the still-active scenarios of the paused batch `src` continue in lanes lane0 + 1, ... of `pool`; returns their (1-based)
+scenario numbers in `src`, in lane order; in `src` they end with status 4 (deferred)"
+function moveLanes!(pool::NewtonRaphsonBatch, lane0::Int, src::NewtonRaphsonBatch)
+    home = zeros(Int32, 64); count = Ref{Int32}(0)
+    check(ccall((:jg_nr_move_lanes, lib), Cint, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Int32}, Ref{Int32}),
+        pool.handle.ptr, lane0, src.handle.ptr, home, count))
+    return Int.(home[1:count[]]) .+ 1
+end
+
+"ends a paused run: iteration / status of every scenario (4 = handed to a pool), voltages of the others"
+function finish!(b::NewtonRaphsonBatch)
+    check(ccall((:jg_nr_finish, lib), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}), b.handle.ptr, b.iteration, b.status))
+    check(ccall((:jg_nr_get_voltage, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), b.handle.ptr, b.magnitude, b.angle))
+    return nothing
+end
+
+"runs the scenarios in lanes 1:lanes of a pool to the end, each with the iteration count it arrived with"
+function resume!(pool::NewtonRaphsonBatch, lanes::Int; iteration::Int64 = 20, tolerance::Float64 = 1e-8)
+    check(ccall((:jg_nr_resume, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Float64, Ptr{Int32}, Ptr{Int32}),
+        pool.handle.ptr, lanes, iteration, tolerance, pool.iteration, pool.status))    # first `lanes` entries are written
+    check(ccall((:jg_nr_get_voltage, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), pool.handle.ptr, pool.magnitude, pool.angle))
+    return nothing
+end
+
 # ------------------------------------------------------------------------------------------------------------------
 # Gauss-Newton WLS state estimation
 # ------------------------------------------------------------------------------------------------------------------
@@ -433,6 +469,6 @@ function largestNormalizedResidual(analysis::HipStateEstimation)
     return mx[1], Int64(idx[1])
 end
 
-export HIP, NewtonRaphsonBatch, setOutages!, jacobian!, largestNormalizedResidual
+export HIP, NewtonRaphsonBatch, setOutages!, powerFlowDefer!, moveLanes!, finish!, resume!, jacobian!, largestNormalizedResidual
 
 end # module
