@@ -129,7 +129,7 @@ class Plan:
     """Device-free symbolic analysis (schedule export for tests)."""
 
     NAMES = dict(perm=0, e_row=1, e_col=2, e_src=3, t_ptr=4, t_a=5, t_b=6, e_level=7, e_diag=8, diag=9,
-                 l_ptr=10, l_ent=11, l_col=12, u_ptr=13, u_ent=14, u_col=15, t_d=16, y_level=17, bwd_level=18, chain_level=19, src_entry=64, bwd_chain=65)
+                 l_ptr=10, l_ent=11, l_col=12, u_ptr=13, u_ent=14, u_col=15, t_d=16, y_level=17, bwd_level=18, chain_level=19, src_entry=64, bwd_chain=65, pre_pivot=75)
 
     def __init__(self, n, rowptr, col, policy=0):
         self.h = VP()
@@ -156,7 +156,7 @@ class Plan:
     def replay_tables(self, kind):
         """Device replay tables (jg_symbolic.hpp): segments [n,8] = rec_base, nchunks, wpi, rpw, level, last, items, -;
         wave records [m,16]."""
-        base = {"fact": 60, "bwd": 62, "fwd": 66, "sel": 68}[kind]
+        base = {"fact": 60, "bwd": 62, "fwd": 66, "sel": 68, "pre": 76}[kind]
         return self.get(base).reshape(-1, 8), self.get(base + 1).reshape(-1, 16)
 
     def top_tables(self):

@@ -113,9 +113,7 @@ __device__ __forceinline__ void fact_record(const FactArgs& a, const RecS& r, in
 // in k_check / k_gn_check).  Row-wise, because the two rows of a block may live on very different scales (gain matrices:
 // a slack angle row of 1 beside a PMU-weighted magnitude row of 1e10) and only cancellation is a defect.  A Jacobian of an islanded sub-grid (bridge outage: no slack in the island) ends exactly there:
 // its last block is a difference of equal numbers, ~1e-16 of what went in, not an exact zero.
-constexpr double PIVOT_EPS = 0x1p-36;       // 1.5e-11: far below any legitimate Schur complement of a power grid, far above rounding
-
-__device__ __forceinline__ double2 row_max(const Blk& c) { return double2{fmax(fabs(c.v00), fabs(c.v01)), fmax(fabs(c.v10), fabs(c.v11))}; }
+// (PIVOT_EPS, row_max and the 2x2 LU itself -- diag_lu -- live in jg_engine.hpp: a producer of a prefactor plan uses them too.)
 
 __device__ __forceinline__ void fact_finish(const FactArgs& a, int kind, int id, size_t b, size_t ld, const Blk& c, double2 ref) {
     if (kind == 3) {
@@ -123,16 +121,10 @@ __device__ __forceinline__ void fact_finish(const FactArgs& a, int kind, int id,
         return;
     }
     if (kind == 2) {                            // diagonal block: 2x2 LU with in-block partial pivoting
-        const bool sw = fabs(c.v10) > fabs(c.v00);
-        const double u11 = sw ? c.v10 : c.v00, u12 = sw ? c.v11 : c.v01;
-        const double o21 = sw ? c.v00 : c.v10, o22 = sw ? c.v01 : c.v11;
-        const double iu11 = 1.0 / u11;
-        const double l = o21 * iu11;
-        const double u22 = o22 - l * u12;
-        const double iu22 = 1.0 / u22;
-        const double f1 = PIVOT_EPS * (sw ? ref.y : ref.x), f2 = PIVOT_EPS * (sw ? ref.x : ref.y);
-        if (!(fabs(u11) > f1) || !(fabs(u22) > f2) || !(fabs(iu11) < 1.0e300) || !(fabs(iu22) < 1.0e300)) atomicOr(a.status + b, 4);
-        store_blk(a.X, (size_t)id, b, ld, iu11, u12, sw ? l + 4.0 : l, iu22);
+        bool bad;
+        const Blk f = diag_lu(c, ref, bad);
+        if (bad) atomicOr(a.status + b, 4);
+        store_blk(a.X, (size_t)id, b, ld, f.v00, f.v01, f.v10, f.v11);
     } else {
         store_blk(a.X, (size_t)id, b, ld, c.v00, c.v01, c.v10, c.v11);
     }
@@ -776,8 +768,14 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, int policy
     if (analyze(n, rowptr, col, policy, S)) { error = "block pattern must be structurally symmetric with a full diagonal"; return 1; }
     ld = ld_;
     level_launches(S.fact_seg, fact);
+    level_launches(S.pre_seg, pre);
     level_launches(S.bwd_seg, bwd);
     level_launches(S.fwd_seg, fwd);
+    {
+        std::vector<int> prow(n, 0);                             // by ORIGINAL block index: pivot + 1 where the producer finishes D and y
+        for (int k = 0; k < n; ++k) if (S.prefactor && S.pre_pivot[k]) prow[S.perm[k]] = k + 1;
+        if (upload(&pre_rec, S.pre_rec, error, st) || upload(&pre_seg, S.pre_seg, error, st) || upload(&pre_row, prow, error, st)) return 2;
+    }
     if (upload(&fact_rec, S.fact_rec, error, st) || upload(&bwd_rec, S.bwd_rec, error, st) || upload(&fact_seg, S.fact_seg, error, st) ||
         upload(&bwd_seg, S.bwd_seg, error, st) || upload(&bwd_chain, S.bwd_chain, error, st) ||
         upload(&fwd_rec, S.fwd_rec, error, st) || upload(&fwd_seg, S.fwd_seg, error, st))
@@ -819,20 +817,29 @@ void Engine::destroy() {
         }
         hipFree(top_prof); top_prof = nullptr;
     }
-    hipFree(fact_rec); hipFree(bwd_rec); hipFree(fact_seg); hipFree(bwd_seg); hipFree(bwd_chain);
+    hipFree(fact_rec); hipFree(bwd_rec); hipFree(fact_seg); hipFree(bwd_seg); hipFree(bwd_chain); hipFree(pre_rec); hipFree(pre_seg); hipFree(pre_row);
     hipFree(fwd_rec); hipFree(fwd_seg); fwd_rec = nullptr; fwd_seg = nullptr;
     hipFree(sel_rec); hipFree(sel_seg); hipFree(Zs); sel_rec = nullptr; sel_seg = nullptr; Zs = nullptr;
     hipFree(top_task); hipFree(top_data); hipFree(top_stack); top_task = nullptr; top_data = nullptr; top_stack = nullptr;
     bwd_chain = nullptr;
     hipFree(X); hipFree(W); hipFree(status);
-    fact_rec = bwd_rec = nullptr; fact_seg = bwd_seg = nullptr; status = nullptr;
+    fact_rec = bwd_rec = nullptr; fact_seg = bwd_seg = nullptr; status = nullptr; pre_rec = nullptr; pre_seg = nullptr; pre_row = nullptr;
     X = W = nullptr;
 }
 
-int Engine::factor(hipStream_t st, const double* A, const double* rhs, const GroupSel& sel) {
+int Engine::factor(hipStream_t st, const double* A, const double* rhs, const GroupSel& sel, bool level0_done) {
     if (!S.inplace && !A) { error = "factor: no source matrix"; return 1; }
     FactArgs a{fact_rec, fact_seg, S.inplace ? X : A, rhs, X, W, status, sel, ld, 0, lanes > 0 ? lanes : ld, 0, 0, 1, 1};
     const int gs = group_stride(ld / 64);
+    if (!level0_done && !pre.empty()) {                          // prefactor plan, plain blocks from the producer: its level 0 first
+        FactArgs p = a;
+        p.rec = pre_rec; p.seg = pre_seg;
+        for (const DevLaunch& L : pre) {
+            p.seg_begin = L.seg_begin;
+            { const Segment& g = S.pre_seg[L.seg_begin]; p.s0_base = g.rec_base; p.s0_nchunks = g.nchunks; p.s0_wpi = g.wpi; p.s0_rpw = g.rpw; }
+            hipLaunchKernelGGL(k_fact_level, dim3((unsigned)L.grid * (16 / FACT_WAVES) * gs, L.nseg), dim3(64, FACT_WAVES), FACT_WAVES * 256 * sizeof(double), st, p);
+        }
+    }
     for (const DevLaunch& L : fact) {
         a.seg_begin = L.seg_begin;
         { const Segment& g = S.fact_seg[L.seg_begin]; a.s0_base = g.rec_base; a.s0_nchunks = g.nchunks; a.s0_wpi = g.wpi; a.s0_rpw = g.rpw; }

@@ -88,6 +88,36 @@ __device__ __forceinline__ void store_vec(double* base, size_t item, size_t b, s
     *(double2*)(base + (item * ld + b) * 2) = double2{v0, v1};
 }
 
+// A diagonal block whose eliminated form is smaller than PIVOT_EPS x (largest entry ITS ROW of the block started from) marks the
+// scenario (status bit 2 -> per-scenario status 3): a block that cancelled to rounding level is the signature of a structurally
+// singular matrix (an islanding outage) under a static pivot order.  Row-wise because a gain block mixes |V|- and theta-scaled rows.
+constexpr double PIVOT_EPS = 0x1p-36;       // 1.5e-11: far below any legitimate Schur complement of a power grid, far above rounding
+__device__ __forceinline__ double2 row_max(const Blk& c) { return double2{fmax(fabs(c.v00), fabs(c.v01)), fmax(fabs(c.v10), fabs(c.v11))}; }
+// 1 / x without the IEEE division sequence (v_rcp_f64 + two Newton steps: 5 dependent operations and 3 registers instead of ~14
+// and a dozen; the result is within an ulp or two, which only perturbs the stored pivot factors at rounding level -- the
+// factorisation stays the exact product of what is stored).  0 -> inf -> NaN and NaN -> NaN, both caught by the pivot check.
+__device__ __forceinline__ double rcp_nr(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+// 2x2 LU with in-block partial pivoting in the stored form {1/u11, u12, l (+ 4 if the rows were swapped), 1/u22}: what a
+// diagonal item of the level kernels stores, and what a producer stores for the pivots of a prefactor plan (same arithmetic:
+// the two paths are bitwise interchangeable).
+__device__ __forceinline__ Blk diag_lu(const Blk& c, double2 ref, bool& bad) {
+    const bool sw = fabs(c.v10) > fabs(c.v00);
+    const double u11 = sw ? c.v10 : c.v00, u12 = sw ? c.v11 : c.v01;
+    const double o21 = sw ? c.v00 : c.v10, o22 = sw ? c.v01 : c.v11;
+    const double iu11 = rcp_nr(u11);
+    const double l = o21 * iu11;
+    const double u22 = o22 - l * u12;
+    const double iu22 = rcp_nr(u22);
+    const double f1 = PIVOT_EPS * (sw ? ref.y : ref.x), f2 = PIVOT_EPS * (sw ? ref.x : ref.y);
+    bad = !(fabs(u11) > f1) || !(fabs(u22) > f2) || !(fabs(iu11) < 1.0e300) || !(fabs(iu22) < 1.0e300);
+    return Blk{iu11, u12, sw ? l + 4.0 : l, iu22};
+}
+
 // blockIdx.x -> (scenario group g, chunk x) of an nx-chunk launch; false: nothing to do for this workgroup.
 // The group list and its length sit on the critical path of EVERY level launch (a workgroup cannot fetch its record before it
 // knows its group), so they are read through the scalar cache, the count and the first eight list entries in parallel (the
@@ -122,6 +152,7 @@ struct Engine {
     int lanes = 0;                 // real scenarios (<= ld; set by the owner, default ld): lanes beyond alias the last real one,
                                    // so a small batch moves 8 bytes per load instruction instead of 512
     Rec* fact_rec = nullptr; Rec* bwd_rec = nullptr;           // wave records (jg_symbolic.hpp), replay order
+    Rec* pre_rec = nullptr; Segment* pre_seg = nullptr; int* pre_row = nullptr;   // level 0 of a prefactor plan (jg_symbolic.hpp); pre_row: device, [n]
     Segment* fact_seg = nullptr; Segment* bwd_seg = nullptr;
     Rec* sel_rec = nullptr; Segment* sel_seg = nullptr; double* Zs = nullptr;   // selected inverse (allocated on first use)
     Rec* fwd_rec = nullptr; Segment* fwd_seg = nullptr;          // forward elimination alone (factor once, solve many)
@@ -129,7 +160,7 @@ struct Engine {
     double* X = nullptr;           // factor values [n_entries][4][ld]: U, unscaled Lh, factored diagonal blocks
     double* W = nullptr;           // [n][2][ld] pivot order: y after factor(), x after backsolve()
     int* status = nullptr;         // [ld] bit 2 set on zero / non-finite pivot
-    std::vector<DevLaunch> fact, bwd, fwd, selv;
+    std::vector<DevLaunch> fact, bwd, fwd, selv, pre;
     Rec* top_task = nullptr; int* top_data = nullptr;          // multifrontal top (jg_symbolic.hpp): task headers, task data
     double* top_stack = nullptr;                               // update matrices of the tasks, scenario-major [ld][S.top_stack]
     long long* top_prof = nullptr;                             // JG_TOP_PROFILE: per-task phase stamps (printed by destroy)
@@ -142,7 +173,9 @@ struct Engine {
     // Computes A = Lh inv(D) U and y = (Lh inv(D))^-1 rhs in the same launches.
     // sel: which 64-scenario groups take part (workgroups of the others exit at once).
     // In-place engines (policy bit 0) ignore A: the caller has assembled into X (entry S.src_entry[p] for its block p).
-    int factor(hipStream_t st, const double* A, const double* rhs, const GroupSel& sel);
+    // level0_done (plans with policy bit 2 only): the producer has stored the diagonal blocks of S.pre_pivot FACTORISED (diag_lu below)
+    // and written their rhs rows into W (pre_row: pivot + 1 per ORIGINAL block index, 0 elsewhere); otherwise the PRE tables run first.
+    int factor(hipStream_t st, const double* A, const double* rhs, const GroupSel& sel, bool level0_done = false);
     // y = (Lh inv(D))^-1 rhs with the factor of the last factor() call (solve many right-hand sides with one factorisation).
     int forward(hipStream_t st, const double* rhs, const GroupSel& sel);
     // Zs = A^-1 on the upper factor pattern + diagonal (same entry numbering as X) for a SYMMETRIC matrix, from the factor

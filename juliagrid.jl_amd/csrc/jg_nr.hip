@@ -53,9 +53,17 @@ struct AsmArgs {
     double* R; int fd_mode;    // fast decoupled passes (acPowerFlow.jl:687-730, 952-962): 1 = mismatches / V, R = (f_P, 0); 2 = R = (0, f_Q)
     int n; int ld; int mp; int nchunk; int lanes;
     const int* only_if;        // nullable: the launch does nothing unless *only_if != 0 (re-assembly after a lane compaction)
+    double* W; int* lu_status; // (lu_status: unused by the kernel -- an atomic there costs 14 VGPRs and a wave per SIMD; a singular level-0 block
+                               // turns the row's mismatch into NaN instead, which k_check reports as status 3)
+                               // level 0 of the engine's prefactor plan (jg_symbolic.hpp): where rowtype carries (pivot + 1) << 2 the diagonal block
+                               // leaves FACTORISED and the mismatch row is also written as the rhs row W[pivot]
 };
 
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ void store_vec_nt(double* base, size_t item, size_t b, size_t ld, double v0, double v1) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store(d2{v0, v1}, (d2*)(base + (item * ld + b) * 2));
+}
 
 // Fused mismatch + Jacobian assembly. blockDim (64, ASM_WAVES); 1-D grid, scenario group fastest (jg::map_block:
 // a group's V/theta gathers stay in one XCD's L2).
@@ -78,7 +86,8 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(AsmArgs a) {
     const int r1 = min(r0 + ASM_ROWS, a.n);
     for (int i = r0 + wave; i < r1; i += ASM_WAVES) {
         const int p0 = uniform(a.rowptr[i]), p1 = uniform(a.rowptr[i + 1]);
-        const int ti = (int)((unsigned)uniform(a.rowtype[i]));
+        const int tfull = (int)((unsigned)uniform(a.rowtype[i]));   // bus type | (pivot + 1) << 2 where this pass also finishes the plan's level 0
+        const int ti = tfull & 3, pre = tfull >> 2;
         const double vi = a.vm[(size_t)i * ld + b];
         const double thi = a.va[(size_t)i * ld + b];
         const double pinj = a.p[(size_t)i * ld + b], qinj = a.q[(size_t)i * ld + b];   // issued early, used after the row
@@ -145,13 +154,22 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(AsmArgs a) {
         if (ti == 3) { d00 = 1.0; d01 = 0.0; d10 = 0.0; d11 = 1.0; fp = 0.0; fq = 0.0; }
         else if (ti == 2) { d01 = 0.0; d10 = 0.0; d11 = 1.0; fq = 0.0; }
         if (JAC) {
+            if (pre) {                                     // nobody updates this block: its 2x2 LU is the factorisation's whole work on it
+                const jg::Blk raw{d00, d01, d10, d11};
+                bool bad;
+                const jg::Blk f = jg::diag_lu(raw, jg::row_max(raw), bad);
+                if (bad) fp = __builtin_nan("");           // a singular block marks its scenario through the mismatch (k_check: NaN -> status 3)
+                d00 = f.v00; d01 = f.v01; d10 = f.v10; d11 = f.v11;
+                store_vec_nt(a.W, (size_t)pre - 1, b, ld, fp, fq);   // nontemporal like every other store of this pass: a plain store here
+                                                                       // cost 0.09 ms per pass at 512 scenarios (the V / theta gathers lost their L2 lines)
+            }
             jg::store_blk_nt(a.A, (size_t)pd, b, ld, d00, d01, d10, d11);
         }
         if (!JAC && a.fd_mode) {
             if (a.fd_mode == 1) { jg::store_vec(a.F, (size_t)i, b, ld, fp, fq); jg::store_vec(a.R, (size_t)i, b, ld, fp, 0.0); }
             else jg::store_vec(a.R, (size_t)i, b, ld, 0.0, fq);
         } else {
-            jg::store_vec(a.F, (size_t)i, b, ld, fp, fq);
+            store_vec_nt(a.F, (size_t)i, b, ld, fp, fq);
         }
         // NaN-propagating max: a NaN mismatch must not look converged
         const double afp = fabs(fp), afq = fabs(fq);
@@ -558,7 +576,7 @@ struct jg_nr {
     std::vector<int> tperm;          // Ybus CSC pointer -> block CSR index of the same (row, col)
     std::vector<int64_t> jmap;       // Jacobian CSC nz -> (factor entry holding the block)*4 + component
     // device
-    int* d_rowptr = nullptr; int* d_col = nullptr; double* d_G = nullptr; double* d_B = nullptr; double2* d_GB = nullptr; int* d_rowtype = nullptr;
+    int* d_rowptr = nullptr; int* d_col = nullptr; double* d_G = nullptr; double* d_B = nullptr; double2* d_GB = nullptr; int* d_rowtype = nullptr; int* d_rowtype_pre = nullptr;   // _pre: type | (pivot + 1) << 2 for the pivots of the plan's level 0
     signed char* d_type = nullptr; signed char* d_flags = nullptr;
     double* d_vm = nullptr; double* d_va = nullptr; double* d_p = nullptr; double* d_q = nullptr;
     int* d_ppos = nullptr; double* d_pdg = nullptr; double* d_pdb = nullptr;
@@ -581,6 +599,7 @@ struct jg_nr {
     hipGraph_t graphA = nullptr, graphB = nullptr;
     hipGraphExec_t execA = nullptr, execB = nullptr;
     bool jac_valid = false;
+    bool level0_done = false;        // the Jacobian in the factor storage came from an assembly that finished the plan's level 0
     bool f_stale = false;            // d_F does not hold every scenario's final mismatch yet (see run_finish)
     bool paused = false;             // jg_nr_run_defer stopped with scenarios still active (lanes compacted, not yet sent home)
     int* d_move = nullptr;           // straggler hand-off: map[64] | home[64] | count[1] (device), home/count mirrored in h_move (pinned)
@@ -595,9 +614,15 @@ int set_device(jg_nr* h) { NR_HIP(hipSetDevice(h->device)); return 0; }
 
 jg::GroupSel active_groups(jg_nr* h) { return jg::GroupSel{nullptr, h->d_glist, h->d_cflags + 3}; }
 
-void launch_assemble(jg_nr* h, const jg::GroupSel& sel = jg::GroupSel{}, bool jac = true, double* pq_out = nullptr, int fd_mode = 0, const int* only_if = nullptr) {
-    AsmArgs a{h->d_rowptr, h->d_col, h->d_GB, h->d_rowtype, h->d_dst, h->d_vm, h->d_va, h->d_p, h->d_q,
-              h->d_ppos, h->d_pdg, h->d_pdb, h->eng.X, h->d_F, h->d_part, pq_out, sel, fd_mode ? h->d_R : nullptr, fd_mode, h->n, h->ld, h->mp, h->nchunk, h->batch, only_if};
+// level0: the assembly also finishes level 0 of the engine's plan (factorised diagonal blocks + rhs rows of the pivots nobody
+// updates); the factorisation that follows must be told (h->level0_done).  Plain assemblies (getters, jg_nr_mismatch) leave it off.
+void launch_assemble(jg_nr* h, const jg::GroupSel& sel = jg::GroupSel{}, bool jac = true, double* pq_out = nullptr, int fd_mode = 0, const int* only_if = nullptr,
+                     bool level0 = false) {
+    const bool pre = jac && level0 && h->eng.S.prefactor && h->d_rowtype_pre;
+    AsmArgs a{h->d_rowptr, h->d_col, h->d_GB, pre ? h->d_rowtype_pre : h->d_rowtype, h->d_dst, h->d_vm, h->d_va, h->d_p, h->d_q,
+              h->d_ppos, h->d_pdg, h->d_pdb, h->eng.X, h->d_F, h->d_part, pq_out, sel, fd_mode ? h->d_R : nullptr, fd_mode, h->n, h->ld, h->mp, h->nchunk, h->batch, only_if,
+              h->eng.W, h->eng.status};
+    if (jac && !only_if) h->level0_done = pre;
     dim3 grid((unsigned)h->nchunk * jg::group_stride(h->ld / 64)), block(64, ASM_WAVES);
     if (jac) {
         switch (h->mp) {
@@ -674,7 +699,7 @@ void launch_compact(jg_nr* h, int restore, bool report = false) {
 
 // solve! numerics on the groups of `sel`: factorise the Jacobian that is in place, solve, update the state (active: nullable)
 int newton_step(jg_nr* h, const jg::GroupSel& sel, const int* active) {
-    if (int rc = h->eng.factor(h->stream, nullptr, h->d_F, sel)) return rc;
+    if (int rc = h->eng.factor(h->stream, nullptr, h->d_F, sel, h->level0_done)) return rc;
     if (!h->refine) {
         jg::StateUpdate upd{h->d_va, h->d_vm, h->d_flags, active, -1.0};
         return h->eng.backsolve(h->stream, h->d_inc, upd, sel);
@@ -705,10 +730,10 @@ int build_graphs(jg_nr* h) {
     // still-active lanes.  A compaction moves lanes (and stages them in the factor storage), so the assembly is repeated
     // on the packed lanes -- a launch that returns at once unless the compaction flag is set.
     auto verdict = [&]() {
-        launch_assemble(h, active_groups(h), true);
+        launch_assemble(h, active_groups(h), true, nullptr, 0, nullptr, true);
         launch_check(h, 1, h->d_group);
         launch_compact(h, 0, true);                    // also reports the number of active scenarios to the host word
-        if (h->ld > 64) launch_assemble(h, active_groups(h), true, nullptr, 0, h->d_cflags);
+        if (h->ld > 64) launch_assemble(h, active_groups(h), true, nullptr, 0, h->d_cflags, true);
     };
     // graph A: the verdict on the start point
     verdict();
@@ -866,9 +891,15 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
         jg_nr_destroy(h); return fail(2, "jg_nr_create: pinned allocation failed");
     }
     if (hipHostGetDevicePointer((void**)&h->h_counter_dev, h->h_counter, 0) != hipSuccess) { jg_nr_destroy(h); return fail(2, "jg_nr_create: pinned host word is not device-visible"); }
-    rc = h->eng.create(n, rp.data(), cl.data(), h->ld, 1, h->stream);          // in place: the assembly kernel writes into the factor storage
+    // in place: the assembly kernel writes into the factor storage; bit 2: it also finishes the plan's level 0 (jg_symbolic.hpp: prefactor)
+    rc = h->eng.create(n, rp.data(), cl.data(), h->ld, getenv("JG_NO_PREFACTOR") ? 1 : 1 | 4, h->stream);
     if (rc) { std::string m = h->eng.error; jg_nr_destroy(h); return fail(rc, m); }
     if (jg::upload(&h->d_dst, h->eng.S.src_entry, err, h->stream)) { jg_nr_destroy(h); return fail(2, err); }
+    if (h->eng.S.prefactor) {                            // the row table of the assemblies that also finish the plan's level 0
+        std::vector<int> rt(type, type + n);
+        for (int k = 0; k < (int)n; ++k) if (h->eng.S.pre_pivot[k]) rt[h->eng.S.perm[k]] |= (k + 1) << 2;
+        if (jg::upload(&h->d_rowtype_pre, rt, err, h->stream)) { jg_nr_destroy(h); return fail(2, err); }
+    }
     h->eng.lanes = h->batch;
     for (int64_t k = 0; k < h->nnzJ; ++k) h->jmap[k] = (int64_t)h->eng.S.src_entry[h->jmap[k] >> 2] * 4 + (h->jmap[k] & 3);
     *out = h;
@@ -891,7 +922,7 @@ void jg_nr_destroy(jg_nr* h) {
     if (h->graphFA) hipGraphDestroy(h->graphFA);
     if (h->graphFB) hipGraphDestroy(h->graphFB);
     hipFree(h->d_bfrom); hipFree(h->d_bto); hipFree(h->d_bstatus); hipFree(h->d_bparam); hipFree(h->d_outage); hipFree(h->d_post);
-    hipFree(h->d_rowptr); hipFree(h->d_col); hipFree(h->d_G); hipFree(h->d_B); hipFree(h->d_GB); hipFree(h->d_rowtype); hipFree(h->d_type); hipFree(h->d_flags);
+    hipFree(h->d_rowptr); hipFree(h->d_col); hipFree(h->d_G); hipFree(h->d_B); hipFree(h->d_GB); hipFree(h->d_rowtype); hipFree(h->d_rowtype_pre); hipFree(h->d_type); hipFree(h->d_flags);
     hipFree(h->d_vm); hipFree(h->d_va); hipFree(h->d_p); hipFree(h->d_q); hipFree(h->d_ppos); hipFree(h->d_pdg);
     hipFree(h->d_pdb); hipFree(h->d_dst); hipFree(h->d_F); hipFree(h->d_inc); hipFree(h->d_part); hipFree(h->d_normp);
     hipFree(h->d_normq); hipFree(h->d_params); hipFree(h->d_active); hipFree(h->d_iters); hipFree(h->d_status);
@@ -1256,7 +1287,7 @@ int jg_nr_resume(jg_nr* h, int64_t lanes, int64_t max_iter, double tol, int32_t*
         NR_HIP(hipMemsetD32Async((hipDeviceptr_t)(h->d_iters + lanes), (int)max_iter, (size_t)(h->ld - lanes), h->stream));   // idle lanes: at the limit, never picked up by a verdict
     }
     launch_compact(h, 0, true);                                                // groups in use (the lanes are already packed)
-    launch_assemble(h, active_groups(h), true);                                // the Jacobian of the state they arrived with; NO verdict:
+    launch_assemble(h, active_groups(h), true, nullptr, 0, nullptr, true);     // the Jacobian of the state they arrived with; NO verdict:
     NR_HIP(hipStreamSynchronize(h->stream));                                   // theirs was taken (and counted) where they came from
     if (int rc = run_loop(h, max_iter, 0)) return rc;
     h->paused = true;
@@ -1576,8 +1607,8 @@ int jg_nr_time_kernel(jg_nr* h, int kernel, int reps, double* mean_ms) {
     {
         NR_HIP(hipEventRecord(e0, h->stream));
         for (int r = 0; r < reps; ++r) {
-            if (kernel == 0) launch_assemble(h);
-            else if (kernel == 1) { if (int rc = h->eng.factor(h->stream, nullptr, h->d_F, jg::GroupSel{})) return fail(rc, h->eng.error); }
+            if (kernel == 0) launch_assemble(h, jg::GroupSel{}, true, nullptr, 0, nullptr, true);     // as the iteration runs it
+            else if (kernel == 1) { if (int rc = h->eng.factor(h->stream, nullptr, h->d_F, jg::GroupSel{}, h->eng.S.prefactor != 0)) return fail(rc, h->eng.error); }
             else if (kernel == 3) hipLaunchKernelGGL(k_branch_quantities, dim3((h->nb + 15) / 16, h->ld / 64), dim3(64, 16), 0, h->stream, ba);
             else { if (int rc = h->eng.backsolve(h->stream, h->d_inc, none, jg::GroupSel{})) return fail(rc, h->eng.error); }
         }

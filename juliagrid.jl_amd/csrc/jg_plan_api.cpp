@@ -63,6 +63,9 @@ int64_t jg_plan_export(jg_plan* p, int which, int32_t* out, int64_t cap) {
         case 72: tmp.assign((const int*)S.top_launch.data(), (const int*)S.top_launch.data() + S.top_launch.size() * 4); v = &tmp; break;
         case 73: v = &S.top_task_of; break;
         case 74: tmp = {S.top_level, (int)(S.top_stack & 0x7fffffff), (int)(S.top_terms & 0x7fffffff)}; v = &tmp; break;
+        case 75: tmp.assign(S.pre_pivot.begin(), S.pre_pivot.end()); v = &tmp; break;
+        case 76: tmp.assign((const int*)S.pre_seg.data(), (const int*)S.pre_seg.data() + S.pre_seg.size() * 8); v = &tmp; break;
+        case 77: tmp.assign((const int*)S.pre_rec.data(), (const int*)S.pre_rec.data() + S.pre_rec.size() * 16); v = &tmp; break;
         default: return -1;
     }
     if (!out) return (int64_t)v->size();

@@ -399,6 +399,17 @@ void build_tables(BlockSymbolic& S) {
     S.n_sched_terms = S.top_terms;
     for (int it = 0; it < nE + n; ++it) if (level[it] > 0) S.n_sched_terms += work[it];
     build_replay(level, work, FACT_T, S.fact_seg, S.fact_rec, S.n_fact_levels, fill_fact, NoExtra(), 0, FACT_WAVES);
+    // level 0 of a prefactor plan as tables of its own (for producers that deliver plain blocks): D(k) and y_k of the pivots
+    // nobody updates
+    S.pre_pivot.assign(n, 0); S.pre_seg.clear(); S.pre_rec.clear(); S.n_pre_levels = 0;
+    if (S.prefactor) {
+        std::vector<int> plevel(nE + n, 0), pwork(nE + n, 0);
+        for (int k = 0; k < n; ++k)
+            if (!in_top(k) && work[S.diag[k]] == 0 && S.e_level[S.diag[k]] == 0 && work[nE + k] == 0) {
+                S.pre_pivot[k] = 1; plevel[S.diag[k]] = 1; plevel[nE + k] = 1;
+            }
+        build_replay(plevel, pwork, FACT_T, S.pre_seg, S.pre_rec, S.n_pre_levels, fill_fact, NoExtra(), 0, FACT_WAVES);
+    }
     // forward elimination ALONE (factor once, solve many: fast decoupled power flow): the rhs rows only, levelled on
     // each other (every factor entry is final); all terms, no tasks
     {
@@ -532,6 +543,7 @@ int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic&
     S.inplace = policy & 1;
     constexpr int TOP_LEVEL_MIN = 6, TOP_NARROW = 384, TOP_FRONT_SOFT = 24;
     S.symmetric = (policy >> 1) & 1;
+    S.prefactor = ((policy >> 2) & 1) && S.inplace;
     S.n = n;
     if (n <= 0) return 1;
     // adjacency without the diagonal; verify structural symmetry and diagonal presence
@@ -637,11 +649,13 @@ int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic&
         for (int k = 0; k < n; ++k) {
             const std::vector<int>& s = strct[k];
             const int d = S.diag[k];
-            S.e_level[d] = acc[d] + 1;
+            // level 0 (policy bit 2): entries the producer leaves final -- no update terms and present in its pattern
+            auto lvl = [&](int e) { return (S.prefactor && S.t_ptr[e + 1] == S.t_ptr[e] && S.e_src[e] >= 0) ? 0 : acc[e] + 1; };
+            S.e_level[d] = lvl(d);
             for (int j : s) {
                 const int u = find_in_row(S, k, j), l = find_in_row(S, j, k);
-                S.e_level[u] = acc[u] + 1;
-                S.e_level[l] = acc[l] + 1;
+                S.e_level[u] = lvl(u);
+                S.e_level[l] = lvl(l);
             }
             for (int i : s) {
                 const int li = std::max(S.e_level[find_in_row(S, i, k)], S.e_level[d]);
@@ -667,7 +681,7 @@ int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic&
             else if (c > r) { S.u_ent[up] = e; S.u_col[up++] = c; }
         }
     }
-    S.y_level.assign(n, 1);
+    S.y_level.assign(n, S.prefactor ? 0 : 1);                 // a row without lower entries: y_k = rhs_k, written by the producer
     S.bwd_level.assign(n, 1);
     for (int r = 0; r < n; ++r)
         for (int p = S.l_ptr[r]; p < S.l_ptr[r + 1]; ++p) {

@@ -99,6 +99,16 @@ struct BlockSymbolic {
     // are not scheduled; FactRec.src then names the entry itself.
     int inplace = 0;
     int symmetric = 0;                  // policy bit 1: the matrix is symmetric, Lh(i,k) = U(k,i)' is read through the upper entry
+    // policy bit 2 ("the producer finishes level 0", in-place plans only): a pivot whose diagonal block receives no update term
+    // -- no earlier pivot touches it: the leaves of the elimination tree, half of the pivots of a transmission grid -- needs
+    // nothing from the factorisation but the 2x2 LU of its block as assembled and y_k = rhs_k.  A producer that has the block
+    // in registers anyway (the Jacobian assembly) stores it FACTORISED and writes y_k itself (pre_pivot names those pivots);
+    // those items then sit at dependency level 0, every other level moves down by one, and the first (widest) level launch
+    // disappears.  For producers that deliver plain blocks the same items form the PRE tables, run ahead of level 1
+    // (Engine::factor(..., level0_done = false)).
+    int prefactor = 0;
+    std::vector<char> pre_pivot;        // [n] pivot k: D(k) and y_k are level-0 items
+    std::vector<Segment> pre_seg; std::vector<Rec> pre_rec; int n_pre_levels = 0;
     std::vector<int> src_entry;         // [nnz of the caller's pattern] -> entry id
     std::vector<Segment> fact_seg, bwd_seg, fwd_seg;    // fwd: the forward elimination alone (rhs rows of the fact tables)
     std::vector<Rec> fact_rec, bwd_rec, fwd_rec;

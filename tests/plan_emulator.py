@@ -34,8 +34,11 @@ class Replay:
     """inplace=True mirrors policy bit 0: the caller's blocks already sit in the factor storage and
     off-diagonal entries without update terms are not scheduled at all."""
 
-    def __init__(self, plan, inplace=False, symmetric=False):
+    def __init__(self, plan, inplace=False, symmetric=False, prefactor=False, producer=True):
+        """prefactor mirrors policy bit 2: the pivots nobody updates (pre_pivot) are level-0 items -- finished by the producer
+        (producer=True: their diagonal blocks arrive factorised, their rhs rows are in place) or by the plan's PRE tables."""
         self.p = plan
+        self.prefactor, self.producer = prefactor, producer
         g = plan.get
         self.perm, self.e_row, self.e_col, self.e_src = g("perm"), g("e_row"), g("e_col"), g("e_src")
         self.t_ptr, self.diag = g("t_ptr"), g("diag")
@@ -74,6 +77,19 @@ class Replay:
             if self.task_of.size:                           # task-owned entries become final inside their task
                 untouched &= self.task_of[np.minimum(self.e_row, self.e_col)] < 0
             level_of[:nE][untouched] = 0         # already final before the first level
+        pre = self.p.get("pre_pivot").astype(bool) if self.prefactor else np.zeros(self.n, dtype=bool)
+        assert self.prefactor or not pre.any()
+        if self.prefactor:
+            work = np.diff(self.t_ptr)
+            lcount = np.diff(self.l_ptr)
+            assert np.array_equal(pre, (work[self.diag] == 0) & (lcount == 0) & ((self.task_of < 0) if self.task_of.size else True)), \
+                "level 0 = the pivots whose diagonal block and rhs row receive no term"
+            if self.producer:                    # what the Jacobian assembly does for these pivots
+                for k in np.flatnonzero(pre):
+                    X[self.diag[k]] = dfactor(X[self.diag[k]])
+                    Y[k] = rhs[self.perm[k]]
+                    level_of[self.diag[k]] = 0
+                    level_of[nE + k] = 0
         acc, meta = {}, {}
 
         def flush():                              # the level is complete: its items become final together
@@ -100,7 +116,11 @@ class Replay:
             meta.clear()
 
         current = None
-        for level, key, sub, recs in self._waves(self.fseg, self.frec):
+        tables = [(lv, k, sb, rc) for lv, k, sb, rc in self._waves(self.fseg, self.frec)]
+        if self.prefactor and not self.producer:             # plain blocks: the PRE tables run ahead of level 1, as level 0
+            pseg, prec = self.p.replay_tables("pre")
+            tables = [(0, ("pre",) + k, sb, rc) for lv, k, sb, rc in self._waves(pseg, prec)] + tables
+        for level, key, sub, recs in tables:
             if level != current:
                 assert current is None or level > current, "segments out of level order"
                 flush()

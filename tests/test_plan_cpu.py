@@ -18,13 +18,18 @@ def _oracle_jacobian(oracle, name):
     return s, a, J, f0, inc
 
 
-@pytest.mark.parametrize("inplace", [False, True])
+@pytest.mark.parametrize("inplace", [False, True, "producer finishes level 0", "pre tables"])
 @pytest.mark.parametrize("name", ["case14test", "case30test", "case118", "case1354pegase"])
 def test_schedule_replay_matches_oracle_increment(jg, oracle, name, inplace):
     s, a, J, f0, inc = _oracle_jacobian(oracle, name)
     rowptr, col, A = block_jacobian_from_csc(s.n, s.colptr, s.rowval, a.type, a.pq, a.pvpq, a.jcolptr, a.jrowval, J)
-    plan = jg._lib.Plan(s.n, rowptr, col, policy=1 if inplace else 0)
-    rp = Replay(plan, inplace=inplace)
+    pre = isinstance(inplace, str)                            # policy bit 2: level 0 by the producer / by the plan's PRE tables
+    plan = jg._lib.Plan(s.n, rowptr, col, policy=(1 | 4) if pre else (1 if inplace else 0))
+    rp = Replay(plan, inplace=bool(inplace), prefactor=pre, producer=inplace == "producer finishes level 0")
+    if pre:
+        plain = jg._lib.Plan(s.n, rowptr, col, policy=1)
+        assert plan.get("e_level").max() == plain.get("e_level").max() - 1      # every level moved down by one
+        assert plan.get("pre_pivot").sum() > s.n // 4
     rhs = np.zeros((s.n, 2))
     for i in range(s.n):
         if a.pvpq[i]:
@@ -225,7 +230,7 @@ def test_selected_inverse_replay_matches_dense_inverse(jg, name, symmetric):
     assert seg[-1, 4] == 2 * plan.get("bwd_level").max()
 
 
-def _solve_with_plan(jg, n, edges, rng, symmetric=False, top=0):
+def _solve_with_plan(jg, n, edges, rng, symmetric=False, top=0, prefactor=None):
     adj = {(i, i) for i in range(n)} | {(a, b) for a, b in edges} | {(b, a) for a, b in edges}
     rowptr, col = [0], []
     for i in range(n):
@@ -246,9 +251,10 @@ def _solve_with_plan(jg, n, edges, rng, symmetric=False, top=0):
         dense = (dense + dense.T) / 2
     dense += np.diag(np.abs(dense).sum(axis=1) + 1.0)
     A = np.array([dense[2 * i:2 * i + 2, 2 * col[p]:2 * col[p] + 2] for i in range(n) for p in range(rowptr[i], rowptr[i + 1])])
-    plan = jg._lib.Plan(n, rowptr, col, policy=(3 if symmetric else 1) | top)
+    pre = prefactor is not None
+    plan = jg._lib.Plan(n, rowptr, col, policy=(3 if symmetric else 1) | (4 if pre else 0) | top)
     assert sorted(plan.get("perm")) == list(range(n))
-    rp = Replay(plan, inplace=True, symmetric=symmetric)
+    rp = Replay(plan, inplace=True, symmetric=symmetric, prefactor=pre, producer=bool(prefactor))
     rhs = rng.standard_normal((n, 2))
     X, Yf = rp.factor(A, rhs)
     x = rp.backsolve(X, Yf)
@@ -275,10 +281,11 @@ def test_top_tasks_on_small_and_random_graphs(jg, monkeypatch, symmetric, top_le
         m = int(rng.integers(n, 3 * n))
         cases.append((n, [tuple(sorted(rng.choice(n, 2, replace=False))) for _ in range(m)]))
     ntasks = 0
-    for n, edges in cases:
-        plan = _solve_with_plan(jg, n, edges, rng, symmetric, top=top_level << 8 | soft << 16)
+    for ci, (n, edges) in enumerate(cases):
+        # unsymmetric plans also with policy bit 2: level 0 finished by the producer (even cases) or by the PRE tables (odd)
+        plan = _solve_with_plan(jg, n, edges, rng, symmetric, top=top_level << 8 | soft << 16, prefactor=None if symmetric else ci % 2 == 0)
         ntasks += plan.top_tables()[0].shape[0]
-    assert ntasks > 10
+    assert ntasks > 5              # (a prefactor plan has one level less: fewer pivots above a given top level)
 
 
 @pytest.mark.parametrize("symmetric", [False, True])
