@@ -521,6 +521,9 @@ __device__ __forceinline__ Blk factor_diag(const Blk& c, int& bad, double2 ref) 
     return Blk{iu11, u12, sw ? l + 4.0 : l, iu22};
 }
 
+__device__ __forceinline__ double uniform_d(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
 __device__ __forceinline__ Blk lds_get(const double* base, int k) {
     const double2* p = (const double2*)(base + (size_t)k * 4);
     const double2 r0 = p[0], r1 = p[1];
@@ -542,7 +545,7 @@ __device__ __forceinline__ void blk_sub(Blk& c, const Blk& l, const Blk& z) {
 constexpr int TOP_THREADS = 320;        // 16 x 16 bulk threads + the pivot wave
 
 template <int CLS>
-__global__ __launch_bounds__(TOP_THREADS) void k_fact_top(TopArgs a) {
+__global__ __launch_bounds__(TOP_THREADS) __attribute__((amdgpu_waves_per_eu(CLS == 4 ? 2 : 4))) void k_fact_top(TopArgs a) {
     __shared__ __attribute__((aligned(16))) double Dbuf[2][4];         // factorised pivot of the current / next step
     __shared__ __attribute__((aligned(16))) double Ubuf[2][64 * 4];    // pivot row  U(q, c)
     __shared__ __attribute__((aligned(16))) double Lbuf[2][64 * 4];    // pivot column Lh(i, q)
@@ -567,11 +570,16 @@ __global__ __launch_bounds__(TOP_THREADS) void k_fact_top(TopArgs a) {
     double* stk = a.stack + b * (size_t)a.stack_stride;
     int bad = 0;
     Blk T[CLS][CLS];
-    int code[CLS][CLS];
-    Blk mydiag{0.0, 0.0, 0.0, 0.0};                              // pivot wave, lane k < m: S(k,k), later the factorised D(k)
+    // The pivot wave owns no part of the front: its state lives in the registers the bulk threads use for T (a variable of its
+    // own would stay allocated in every wave through the step loop -- 12 of the 128 registers that let two workgroups share a CU)
+    Blk& mydiag = T[0][0];                                       // pivot wave, lane k < m: S(k,k), later the factorised D(k)
+    double& myref_x = T[0][1].v00; double& myref_y = T[0][1].v01;   // pivot wave, lane k: row maxima S(k,k) entered the task with
+    if (pivot_wave) { mydiag = Blk{0.0, 0.0, 0.0, 0.0}; myref_x = 0.0; myref_y = 0.0; }
 
     if (!pivot_wave) {
-        // ---- load: entry map, then every gather of the thread in flight together
+        // ---- load: entry map, then every gather of the thread in flight together (the map is read again for the store: nine
+        // registers that would otherwise live through the step loop)
+        int code[CLS][CLS];
 #pragma unroll
         for (int r = 0; r < CLS; ++r)
 #pragma unroll
@@ -632,9 +640,8 @@ __global__ __launch_bounds__(TOP_THREADS) void k_fact_top(TopArgs a) {
         if (tid == 0) lds_set(Dbuf[0], 0, factor_diag(T[0][0], bad, row_max(T[0][0])));
     }
     __syncthreads();
-    double2 myref{0.0, 0.0};                                     // pivot wave, lane k: row maxima S(k,k) entered the task with
     if (pivot_wave) {
-        if (lane < m) { mydiag = lds_get(Dini, lane); myref = row_max(mydiag); }
+        if (lane < m) { mydiag = lds_get(Dini, lane); const double2 rm = row_max(mydiag); myref_x = rm.x; myref_y = rm.y; }
         if (lane == 0) mydiag = lds_get(Dbuf[0], 0);
     }
     // ---- pivot steps.  Straight-line bulk code: the pivot is the same block for every lane, so the row swap of its 2x2 LU is
@@ -642,6 +649,7 @@ __global__ __launch_bounds__(TOP_THREADS) void k_fact_top(TopArgs a) {
     for (int q = 0; q < m; ++q) {
         const int cur = q & 1, nxt = cur ^ 1;
         Blk D = lds_get(Dbuf[cur], 0);
+        D = Blk{uniform_d(D.v00), uniform_d(D.v01), uniform_d(D.v10), uniform_d(D.v11)};   // the same block in every lane: scalar registers
         const int sw = uniform(D.v10 > 2.0 ? 1 : 0);
         const double dl = D.v10 - 4.0 * sw;
         auto zcol = [&](const double* ub, int k) {               // z = D^-1 U(q, k): rows of U read in pivot order
@@ -653,15 +661,15 @@ __global__ __launch_bounds__(TOP_THREADS) void k_fact_top(TopArgs a) {
             return z;
         };
         if (!pivot_wave) {
-            Blk z[CLS], Lq[CLS];
-#pragma unroll
-            for (int c = 0; c < CLS; ++c) z[c] = zcol(Ubuf[cur], c * 16 + gj);
+            Blk Lq[CLS];
 #pragma unroll
             for (int r = 0; r < CLS; ++r) Lq[r] = lds_get(Lbuf[cur], r * 16 + gi);
 #pragma unroll
-            for (int r = 0; r < CLS; ++r)
+            for (int c = 0; c < CLS; ++c) {
+                const Blk z = zcol(Ubuf[cur], c * 16 + gj);
 #pragma unroll
-                for (int c = 0; c < CLS; ++c) blk_sub(T[r][c], Lq[r], z[c]);
+                for (int r = 0; r < CLS; ++r) blk_sub(T[r][c], Lq[r], z);
+            }
             if (q + 1 < m) {                     // the next pivot row / column leave their owners
                 // classes before the pivot's are finished (zeros), classes after it go out as they are (both uniform); only the
                 // pivot's own class needs a per-lane select
@@ -699,7 +707,7 @@ __global__ __launch_bounds__(TOP_THREADS) void k_fact_top(TopArgs a) {
                 const int lo = __builtin_amdgcn_readlane(__double2loint(v), q + 1), hi = __builtin_amdgcn_readlane(__double2hiint(v), q + 1);
                 return __hiloint2double(hi, lo);
             };
-            const Blk dn = factor_diag(Blk{bc(mydiag.v00), bc(mydiag.v01), bc(mydiag.v10), bc(mydiag.v11)}, bad, double2{bc(myref.x), bc(myref.y)});
+            const Blk dn = factor_diag(Blk{bc(mydiag.v00), bc(mydiag.v01), bc(mydiag.v10), bc(mydiag.v11)}, bad, double2{bc(myref_x), bc(myref_y)});
             if (lane == q + 1) { mydiag = dn; lds_set(Dbuf[nxt], 0, dn); }
         }
         __syncthreads();
@@ -713,7 +721,7 @@ __global__ __launch_bounds__(TOP_THREADS) void k_fact_top(TopArgs a) {
 #pragma unroll
             for (int c = 0; c < CLS; ++c) {
                 const int i = r * 16 + gi, j = c * 16 + gj;
-                const int cd = code[r][c];
+                const int cd = (i < f && j < fprime) ? td[i * fprime + j] : -1;
                 const Blk& v = T[r][c];
                 if (cd <= -2) store_vec(a.W, (size_t)(-(cd + 2)), b, ld, v.v00, v.v10);
                 else if (cd >= 0 && !((cd >> 28) & 4)) store_blk(a.X, (size_t)(cd & 0x0fffffff), b, ld, v.v00, v.v01, v.v10, v.v11);

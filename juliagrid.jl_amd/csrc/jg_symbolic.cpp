@@ -148,7 +148,8 @@ struct NoExtra { void operator()(int, std::vector<Segment>&, std::vector<Rec>&) 
 // `extra(level, segs, recs)` may append further segments of that level (backward chains); extra_levels = highest level it uses
 template <class Fill, class Extra = NoExtra>
 void build_replay(const std::vector<int>& level, const std::vector<int>& work, int T, std::vector<Segment>& segs,
-                  std::vector<Rec>& recs, int& n_levels, Fill fill, Extra extra = Extra(), int extra_levels = 0, int max_wpi = 16) {
+                  std::vector<Rec>& recs, int& n_levels, Fill fill, Extra extra = Extra(), int extra_levels = 0, int max_wpi = 16,
+                  const std::vector<long long>* locality = nullptr) {
     const int n_items = (int)level.size();
     int nlev = extra_levels;
     for (int i = 0; i < n_items; ++i) nlev = std::max(nlev, level[i]);
@@ -159,9 +160,17 @@ void build_replay(const std::vector<int>& level, const std::vector<int>& work, i
     for (int l = 1; l <= nlev; ++l) {
         std::vector<int>& it = by[l];
         const size_t seg0 = segs.size();
-        std::stable_sort(it.begin(), it.end(), [&](int x, int y) { return work[x] > work[y]; });   // heaviest first
         const bool wide = it.size() >= 2048;                      // wide levels already fill the chip: do not split short lists
         auto wpi_of = [&](int i) { return std::min(wide && work[i] <= 4 * T ? 2 : max_wpi, pow2ceil(std::max(1, (work[i] + T - 1) / T))); };
+        if (locality)                                             // segments by waves per item (widest first); inside a segment the items
+                                                                  // that share operands sit next to each other (same workgroup, same moment)
+            std::stable_sort(it.begin(), it.end(), [&](int x, int y) {
+                const int wx = wpi_of(x), wy = wpi_of(y);
+                if (wx != wy) return wx > wy;
+                return (*locality)[x] < (*locality)[y];
+            });
+        else
+            std::stable_sort(it.begin(), it.end(), [&](int x, int y) { return work[x] > work[y]; });   // heaviest first
         size_t p = 0;
         while (p < it.size()) {
             const int wpi = wpi_of(it[p]);
@@ -171,7 +180,9 @@ void build_replay(const std::vector<int>& level, const std::vector<int>& work, i
             sg.rec_base = (int)recs.size(); sg.wpi = wpi; sg.level = l; sg.items = (int)(q - p);
             const int slots = 16 / wpi;
             sg.nchunks = (sg.items + slots - 1) / slots;
-            sg.rpw = std::max(1, ((work[it[p]] + wpi - 1) / wpi + T - 1) / T);
+            int wmax = 0;
+            for (size_t x = p; x < q; ++x) wmax = std::max(wmax, work[it[x]]);
+            sg.rpw = std::max(1, ((wmax + wpi - 1) / wpi + T - 1) / T);
             sg.last = 0;
             recs.resize(recs.size() + (size_t)sg.nchunks * 16 * sg.rpw);
             for (int c = 0; c < sg.nchunks; ++c)
@@ -398,7 +409,18 @@ void build_tables(BlockSymbolic& S) {
     };
     S.n_sched_terms = S.top_terms;
     for (int it = 0; it < nE + n; ++it) if (level[it] > 0) S.n_sched_terms += work[it];
-    build_replay(level, work, FACT_T, S.fact_seg, S.fact_rec, S.n_fact_levels, fill_fact, NoExtra(), 0, FACT_WAVES);
+    // Item order inside a level: everything that becomes final with pivot p = min(row, col) together -- U(p, .) and y_p share
+    // Lh(p, k) and D(k) of every term, Lh(., p) share U(k, p) and D(k) -- so the waves of a workgroup (and the workgroups that run
+    // at the same moment on an XCD) ask for the same operand blocks while they are still in L1 / L2.  JG_ITEM_ORDER=0: heaviest first.
+    std::vector<long long> loc(nE + n);
+    for (int e = 0; e < nE; ++e) {
+        const int r = S.e_row[e], c = S.e_col[e], p = std::min(r, c);
+        loc[e] = ((long long)p << 33) | ((long long)(r > c ? 1 : 0) << 32) | (long long)(r > c ? r : c);
+    }
+    for (int r = 0; r < n; ++r) loc[nE + r] = ((long long)r << 33) | 0xffffffffLL;      // y_p right after U(p, .)
+    const char* io = getenv("JG_ITEM_ORDER");
+    const std::vector<long long>* locp = (io && atoi(io) == 0) ? nullptr : &loc;
+    build_replay(level, work, FACT_T, S.fact_seg, S.fact_rec, S.n_fact_levels, fill_fact, NoExtra(), 0, FACT_WAVES, locp);
     // level 0 of a prefactor plan as tables of its own (for producers that deliver plain blocks): D(k) and y_k of the pivots
     // nobody updates
     S.pre_pivot.assign(n, 0); S.pre_seg.clear(); S.pre_rec.clear(); S.n_pre_levels = 0;
