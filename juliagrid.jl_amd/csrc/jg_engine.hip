@@ -559,9 +559,15 @@ __global__ __launch_bounds__(TOP_THREADS) __attribute__((amdgpu_waves_per_eu(CLS
     const bool pivot_wave = tid >= 256;
     const int lane = tid & 63;
     const int gi = (tid >> 4) & 15, gj = tid & 15;               // bulk thread: row / column class on the 16 x 16 grid
-    const bool prof = a.prof && bb == 0 && tid == 0;
-    long long* pt = a.prof + (size_t)(a.task_begin + ti) * 8;
-    if (prof) pt[0] = wall_clock64();
+    const bool prof = a.prof && tid == 0;                        // every scenario: the host prints scenario 0 and the spread over the batch
+    long long* pt = a.prof + ((size_t)(a.task_begin + ti) * a.ld + bb) * 8;
+    if (prof) {
+        pt[0] = wall_clock64();
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        pt[5] = (long long)((xcc & 0xf) << 16 | ((hw >> 13) & 0x7) << 8 | ((hw >> 8) & 0xf));      // XCC | SE | CU
+    }
     const RecS h = load_rec(a.task, (size_t)a.task_begin + ti);
     const int m = h[0], e = h[1], nchild = h[5], fprime = h[11];
     const int f = fprime - 1;
@@ -795,8 +801,8 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, int policy
         JG_HIP(hipMalloc((void**)&top_stack, sb));
         JG_HIP(sync_fill(top_stack, 0, sb, st));
         if (getenv("JG_TOP_PROFILE")) {
-            JG_HIP(hipMalloc((void**)&top_prof, S.top_task.size() * 8 * sizeof(long long)));
-            JG_HIP(sync_fill(top_prof, 0, S.top_task.size() * 8 * sizeof(long long), st));
+            JG_HIP(hipMalloc((void**)&top_prof, S.top_task.size() * ld * 8 * sizeof(long long)));
+            JG_HIP(sync_fill(top_prof, 0, S.top_task.size() * ld * 8 * sizeof(long long), st));
         }
     }
     JG_HIP(hipMalloc((void**)&X, factor_bytes()));
@@ -811,15 +817,26 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, int policy
 
 void Engine::destroy() {
     if (top_prof) {                                              // phase times of every task (scenario 0, last factorisation)
-        std::vector<long long> t(S.top_task.size() * 8);
+        std::vector<long long> t(S.top_task.size() * ld * 8);
         if (hipMemcpy(t.data(), top_prof, t.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess) {
-            fprintf(stderr, "[jg top profile] task level class m e | load children steps store total (us) | us per step\n");
+            fprintf(stderr, "[jg top profile] task level class m e | load children steps store total (us) | us per step | batch: workgroups, start spread, "
+                            "total min / median / max, first start -> last end, CUs used, most workgroups on one CU\n");
             for (size_t i = 0; i < S.top_task.size(); ++i) {
-                const long long* p = &t[i * 8];
+                const long long* p = &t[i * ld * 8];
                 if (!p[0]) continue;
                 const Rec& h = S.top_task[i];
                 fprintf(stderr, "[jg top profile] %3zu %2d %d %2d %2d | %6.2f %6.2f %6.2f %6.2f %7.2f | %5.3f", i, h.w[10], h.w[9], h.w[0], h.w[1],
                         (p[1] - p[0]) * 0.01, (p[2] - p[1]) * 0.01, (p[3] - p[2]) * 0.01, (p[4] - p[3]) * 0.01, (p[4] - p[0]) * 0.01, (p[3] - p[2]) * 0.01 / h.w[0]);
+                std::vector<long long> st0, tot; long long e1 = 0; std::vector<int> cu;
+                for (int b = 0; b < ld; ++b) { const long long* q = p + (size_t)b * 8; if (q[0] && q[4]) { st0.push_back(q[0]); tot.push_back(q[4] - q[0]); e1 = std::max(e1, q[4]); cu.push_back((int)q[5]); } }
+                if (!st0.empty()) {
+                    const long long s0 = *std::min_element(st0.begin(), st0.end()), s1 = *std::max_element(st0.begin(), st0.end());
+                    std::sort(tot.begin(), tot.end()); std::sort(cu.begin(), cu.end());
+                    int ncu = 0, most = 0, run = 0;
+                    for (size_t x = 0; x < cu.size(); ++x) { if (x == 0 || cu[x] != cu[x - 1]) { ++ncu; run = 0; } most = std::max(most, ++run); }
+                    fprintf(stderr, " | %zu %6.2f  %6.2f / %6.2f / %6.2f  %7.2f  %d %d", st0.size(), (s1 - s0) * 0.01, tot.front() * 0.01, tot[tot.size() / 2] * 0.01, tot.back() * 0.01,
+                            (e1 - s0) * 0.01, ncu, most);
+                }
                 fprintf(stderr, "\n");
             }
         }

@@ -16,7 +16,6 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -839,28 +838,7 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
     // ---- device upload ----------------------------------------------------------------------
     int rc = set_device(h);
     if (rc) { delete h; return rc; }
-    {
-        // JG_CU_PARTS=n[,mode] (experiment): handle number i of the process gets a stream whose queue may only use partition i % n of the
-        // CUs (mask bit b -> XCD b % 8, CU b / 8 of it).  mode 0: a slice of every XCD; mode 1: whole XCDs.
-        static std::atomic<int> created{0};
-        const char* e = getenv("JG_CU_PARTS");
-        const int parts = e ? atoi(e) : 0;
-        hipError_t se;
-        if (parts > 1) {
-            const int mode = strchr(e, ',') ? atoi(strchr(e, ',') + 1) : 0;
-            const int me = created.fetch_add(1) % parts;
-            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int b = 0; b < 256; ++b) {
-                const int xcd = b % 8, cu = b / 8;
-                const bool mine = mode == 1 ? (xcd * parts / 8 == me) : (cu * parts / 32 == me);
-                if (mine) mask[b / 32] |= 1u << (b % 32);
-            }
-            se = hipExtStreamCreateWithCUMask(&h->stream, 8, mask);
-        } else {
-            se = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
-        }
-        if (se != hipSuccess) { delete h; return fail(2, "jg_nr_create: stream creation failed"); }
-    }
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(2, "jg_nr_create: stream creation failed"); }
     std::vector<int> rp(n + 1), cl(nnz);
     std::vector<double> G(nnz), B(nnz);
     for (int i = 0; i <= n; ++i) rp[i] = (int)(colptr[i] - 1);
