@@ -652,8 +652,9 @@ __global__ __launch_bounds__(TOP_THREADS) __attribute__((amdgpu_waves_per_eu(CLS
     }
     // ---- pivot steps.  Straight-line bulk code: the pivot is the same block for every lane, so the row swap of its 2x2 LU is
     // folded into the ADDRESS of the two halves of U(q, c) (scalar), finished blocks see zeros (no predicates, no skipping).
-    for (int q = 0; q < m; ++q) {
-        const int cur = q & 1, nxt = cur ^ 1;
+    for (int qv = 0; qv < m; ++qv) {
+        const int q = uniform(qv);                               // the step number is wave-uniform: which row / column class publishes, the
+        const int cur = q & 1, nxt = cur ^ 1;                    // LDS buffer in use and the lane of the next pivot are scalar decisions
         Blk D = lds_get(Dbuf[cur], 0);
         D = Blk{uniform_d(D.v00), uniform_d(D.v01), uniform_d(D.v10), uniform_d(D.v11)};   // the same block in every lane: scalar registers
         const int sw = uniform(D.v10 > 2.0 ? 1 : 0);
