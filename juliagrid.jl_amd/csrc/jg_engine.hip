@@ -544,8 +544,13 @@ __device__ __forceinline__ void blk_sub(Blk& c, const Blk& l, const Blk& z) {
 
 constexpr int TOP_THREADS = 320;        // 16 x 16 bulk threads + the pivot wave
 
-template <int CLS>
-__global__ __launch_bounds__(TOP_THREADS) __attribute__((amdgpu_waves_per_eu(CLS == 4 ? 2 : 4))) void k_fact_top(TopArgs a) {
+// PW = false: no pivot wave (256 threads).  The thread that owns the diagonal block of the NEXT pivot factorises it right after its
+// own update of that block and publishes it; the arithmetic is the pivot wave's, block for block, so both variants give the same bits.
+// A 5-wave workgroup puts two waves on one SIMD, which caps a CU at 2 (CLS = 3) or 1 (CLS = 4) workgroups; four waves sit one
+// per SIMD: 4 resp. 2 workgroups.  A lone workgroup (small batches) is faster WITH the pivot wave (its chain runs beside the bulk
+// update), so the launch picks the variant by its size (Engine::factor).
+template <int CLS, bool PW>
+__global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves_per_eu(CLS == 4 ? 2 : 4))) void k_fact_top(TopArgs a) {
     __shared__ __attribute__((aligned(16))) double Dbuf[2][4];         // factorised pivot of the current / next step
     __shared__ __attribute__((aligned(16))) double Ubuf[2][64 * 4];    // pivot row  U(q, c)
     __shared__ __attribute__((aligned(16))) double Lbuf[2][64 * 4];    // pivot column Lh(i, q)
@@ -556,7 +561,7 @@ __global__ __launch_bounds__(TOP_THREADS) __attribute__((amdgpu_waves_per_eu(CLS
     const int bb = grp * 64 + (x - ti * a.lpg);
     if (bb >= a.lanes) return;                                   // padding lanes of the last group: no scenario, no work
     const int tid = threadIdx.x;
-    const bool pivot_wave = tid >= 256;
+    const bool pivot_wave = PW && tid >= 256;
     const int lane = tid & 63;
     const int gi = (tid >> 4) & 15, gj = tid & 15;               // bulk thread: row / column class on the 16 x 16 grid
     const bool prof = a.prof && tid == 0;                        // every scenario: the host prints scenario 0 and the spread over the batch
@@ -643,7 +648,11 @@ __global__ __launch_bounds__(TOP_THREADS) __attribute__((amdgpu_waves_per_eu(CLS
                 if (j == 0) lds_set(Lbuf[0], i, i > 0 ? T[r][c] : zero);
                 if (i == j && i < m) lds_set(Dini, i, T[r][c]);
             }
-        if (tid == 0) lds_set(Dbuf[0], 0, factor_diag(T[0][0], bad, row_max(T[0][0])));
+        if (tid == 0) {
+            const Blk d0 = factor_diag(T[0][0], bad, row_max(T[0][0]));
+            lds_set(Dbuf[0], 0, d0);
+            if (!PW) T[0][0] = d0;                               // without a pivot wave the owner keeps the factorised block for the store
+        }
     }
     __syncthreads();
     if (pivot_wave) {
@@ -681,6 +690,16 @@ __global__ __launch_bounds__(TOP_THREADS) __attribute__((amdgpu_waves_per_eu(CLS
                 // classes before the pivot's are finished (zeros), classes after it go out as they are (both uniform); only the
                 // pivot's own class needs a per-lane select
                 const int rq = (q + 1) >> 4, tq = (q + 1) & 15;
+                if (!PW && gi == tq && gj == tq) {               // the owner of S(q+1, q+1): final now, factorised here
+                    const Blk ini = lds_get(Dini, q + 1);
+#pragma unroll
+                    for (int r = 0; r < CLS; ++r)
+                        if (r == rq) {
+                            const Blk dn = factor_diag(T[r][r], bad, row_max(ini));
+                            lds_set(Dbuf[nxt], 0, dn);
+                            T[r][r] = dn;                        // later steps see L = 0 for this row: it stays what it is
+                        }
+                }
                 if (gi == tq) {
 #pragma unroll
                     for (int r = 0; r < CLS; ++r)
@@ -731,13 +750,13 @@ __global__ __launch_bounds__(TOP_THREADS) __attribute__((amdgpu_waves_per_eu(CLS
                 const int cd = (i < f && j < fprime) ? td[i * fprime + j] : -1;
                 const Blk& v = T[r][c];
                 if (cd <= -2) store_vec(a.W, (size_t)(-(cd + 2)), b, ld, v.v00, v.v10);
-                else if (cd >= 0 && !((cd >> 28) & 4)) store_blk(a.X, (size_t)(cd & 0x0fffffff), b, ld, v.v00, v.v01, v.v10, v.v11);
+                else if (cd >= 0 && (!((cd >> 28) & 4) || (!PW && i == j && i < m))) store_blk(a.X, (size_t)(cd & 0x0fffffff), b, ld, v.v00, v.v01, v.v10, v.v11);
                 else if (i >= m && i < f && j >= m && j < fprime) {                              // update matrix | vector: scenario-major stack
                     double2* p = (double2*)(out + ((size_t)(i - m) * (e + 1) + (j - m)) * 4);
                     p[0] = double2{v.v00, v.v01}; p[1] = double2{v.v10, v.v11};
                 }
             }
-        if (tid == 0 && bad) atomicOr(a.status + b, 4);
+        if ((PW ? tid == 0 : true) && bad) atomicOr(a.status + b, 4);
     } else {
         if (lane < m) store_blk(a.X, (size_t)td[h[8] + lane], b, ld, mydiag.v00, mydiag.v01, mydiag.v10, mydiag.v11);
         if (bad && lane == 0) atomicOr(a.status + b, 4);
@@ -878,9 +897,21 @@ int Engine::factor(hipStream_t st, const double* A, const double* rhs, const Gro
         for (const TopLaunch& L : S.top_launch) {
             t.task_begin = L.task_begin; t.ntasks = L.ntasks;
             const dim3 grid((unsigned)L.ntasks * t.lpg * gs);
-            if (L.cls == 2) hipLaunchKernelGGL(k_fact_top<2>, grid, dim3(TOP_THREADS), 0, st, t);
-            else if (L.cls == 3) hipLaunchKernelGGL(k_fact_top<3>, grid, dim3(TOP_THREADS), 0, st, t);
-            else hipLaunchKernelGGL(k_fact_top<4>, grid, dim3(TOP_THREADS), 0, st, t);
+            // More workgroups than the CUs can hold WITH a pivot wave (1 per CU at CLS = 4, 2 at CLS = 3, 3 at CLS = 2): the 4-wave
+            // variant, of which a CU holds twice as many; else the pivot-wave variant, whose step is 15 % shorter (measured at 512
+            // scenarios: 0.86 against 1.02 us per step with two workgroups on a CU).
+            static const int pw_env = getenv("JG_TOP_PW") ? atoi(getenv("JG_TOP_PW")) : -1;
+            const long long wgs = (long long)L.ntasks * std::min<long long>(t.lanes, (long long)t.lpg * (ld / 64));
+            const bool pw = pw_env >= 0 ? pw_env != 0 : wgs <= 256 * (L.cls == 4 ? 1 : (L.cls == 3 ? 2 : 3));
+            if (pw) {
+                if (L.cls == 2) hipLaunchKernelGGL((k_fact_top<2, true>), grid, dim3(TOP_THREADS), 0, st, t);
+                else if (L.cls == 3) hipLaunchKernelGGL((k_fact_top<3, true>), grid, dim3(TOP_THREADS), 0, st, t);
+                else hipLaunchKernelGGL((k_fact_top<4, true>), grid, dim3(TOP_THREADS), 0, st, t);
+            } else {
+                if (L.cls == 2) hipLaunchKernelGGL((k_fact_top<2, false>), grid, dim3(256), 0, st, t);
+                else if (L.cls == 3) hipLaunchKernelGGL((k_fact_top<3, false>), grid, dim3(256), 0, st, t);
+                else hipLaunchKernelGGL((k_fact_top<4, false>), grid, dim3(256), 0, st, t);
+            }
         }
     }
     JG_HIP(hipGetLastError());
