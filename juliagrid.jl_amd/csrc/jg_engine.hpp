@@ -106,12 +106,13 @@ __device__ __forceinline__ double rcp_nr(double x) {
 // diagonal item of the level kernels stores, and what a producer stores for the pivots of a prefactor plan (same arithmetic:
 // the two paths are bitwise interchangeable).
 __device__ __forceinline__ Blk diag_lu(const Blk& c, double2 ref, bool& bad) {
+#pragma clang fp contract(off)                  // two kernels inline this: what is fused is written as fma(), nothing else may be (l + 4.0 was)
     const bool sw = fabs(c.v10) > fabs(c.v00);
     const double u11 = sw ? c.v10 : c.v00, u12 = sw ? c.v11 : c.v01;
     const double o21 = sw ? c.v00 : c.v10, o22 = sw ? c.v01 : c.v11;
     const double iu11 = rcp_nr(u11);
     const double l = o21 * iu11;
-    const double u22 = o22 - l * u12;
+    const double u22 = fma(-l, u12, o22);      // explicit: the assembly kernel and the level kernel must contract the same way
     const double iu22 = rcp_nr(u22);
     const double f1 = PIVOT_EPS * (sw ? ref.y : ref.x), f2 = PIVOT_EPS * (sw ? ref.x : ref.y);
     bad = !(fabs(u11) > f1) || !(fabs(u22) > f2) || !(fabs(iu11) < 1.0e300) || !(fabs(iu22) < 1.0e300);

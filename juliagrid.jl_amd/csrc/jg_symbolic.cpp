@@ -734,7 +734,8 @@ int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic&
             for (int e = 0; e < S.n_entries; ++e) if (!(S.symmetric && S.e_row[e] > S.e_col[e])) cnt[S.e_level[e]]++;
             for (int r = 0; r < n; ++r) { cnt[S.y_level[r]]++; piv[S.e_level[S.diag[r]]]++; }
             top_level = nlev + 1;
-            while (top_level > TOP_LEVEL_MIN && cnt[top_level - 1] <= narrow && (chains == 0 || piv[top_level - 1] <= chains)) --top_level;
+            const int level_min = TOP_LEVEL_MIN - (S.prefactor ? 1 : 0);    // a prefactor plan numbers the same levels one lower: same pivots in the top
+            while (top_level > level_min && cnt[top_level - 1] <= narrow && (chains == 0 || piv[top_level - 1] <= chains)) --top_level;
             if (top_level > nlev - 2) top_level = 255;           // nothing worth a task
         }
         if (soft <= 0) soft = TOP_FRONT_SOFT;

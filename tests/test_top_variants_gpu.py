@@ -1,0 +1,50 @@
+"""The two shapes of the multifrontal top kernel (k_fact_top with a pivot wave / with the owner of the next diagonal block
+factorising it, jg_engine.hip) and the two ways level 0 of a prefactor plan gets done (by the Jacobian assembly / by the plan's PRE
+tables) must give the same BITS: which one runs depends on the size of a launch, and a scenario's result may not depend on the
+batch it was solved in.  The variants are process-wide switches (environment), so each one runs in a process of its own."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r"""
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+sys.path.insert(0, {root!r} + "/tests")
+from conftest import load_case
+import juliagrid.jl_amd as jg
+s = jg.powerSystem(load_case({case!r}))
+an = jg.contingencyAnalysis(s, jg.outageList(s, {batch}, seed=11))
+jg.powerFlow_(an, iteration=20, tolerance=1e-8)
+h = hashlib.sha256()
+for a in (np.asarray(an.method.iteration), np.asarray(an.voltage.magnitude), np.asarray(an.voltage.angle)):
+    h.update(np.ascontiguousarray(a).tobytes())
+print("DIGEST", h.hexdigest(), int(np.sum(an.method.iteration)))
+an.close()
+"""
+
+
+def _run(case, batch, **env):
+    e = dict(os.environ)
+    e.update({k: str(v) for k, v in env.items()})
+    out = subprocess.run([sys.executable, "-c", SCRIPT.format(root=ROOT, case=case, batch=batch)], env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("DIGEST")][-1].split()
+    return line[1], int(line[2])
+
+
+@pytest.mark.parametrize("case,batch", [("case1354pegase", 70), ("case_ACTIVSg10k", 130)])
+def test_top_kernel_variants_and_level0_routes_give_the_same_bits(case, batch):
+    ref, iters = _run(case, batch)                                   # the build's own choice per launch
+    assert iters >= 3 * batch
+    assert _run(case, batch, JG_TOP_PW=1)[0] == ref                  # every top launch with the pivot wave
+    assert _run(case, batch, JG_TOP_PW=0)[0] == ref                  # every top launch without
+    assert _run(case, batch, JG_NO_PREFACTOR=1)[0] == ref            # plain plan: the level kernel factorises the leaf blocks
+    assert _run(case, batch, JG_ITEM_ORDER=0)[0] == ref              # items of a level dealt heaviest first
