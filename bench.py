@@ -266,7 +266,7 @@ def se_config4(jg, case="case9241synth", batch=512, steps=12, warmup=2, inflight
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--steps", type=int, default=240)       # 1.4 s of timed region at 512 scenarios per step
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=512, help="scenarios per step (strong scaling: in total; weak: per GPU)")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")

@@ -161,7 +161,14 @@ void build_replay(const std::vector<int>& level, const std::vector<int>& work, i
         std::vector<int>& it = by[l];
         const size_t seg0 = segs.size();
         const bool wide = it.size() >= 2048;                      // wide levels already fill the chip: do not split short lists
-        auto wpi_of = [&](int i) { return std::min(wide && work[i] <= 4 * T ? 2 : max_wpi, pow2ceil(std::max(1, (work[i] + T - 1) / T))); };
+        // ... and at most 4 waves share a long list there (the level that brings the bottom's terms to the top-owned entries holds
+        // thousands of 20- to 70-term items: 26 112 workgroups at 8 waves per item, 139 us; 13 056 at 4, 117 us; at 2: 138 us)
+        static const int wide_cap = getenv("JG_WIDE_WPI") ? atoi(getenv("JG_WIDE_WPI")) : 4;
+        auto wpi_of = [&](int i) {
+            int cap = wide && work[i] <= 4 * T ? 2 : max_wpi;
+            if (wide && wide_cap > 0) cap = std::min(cap, wide_cap);
+            return std::min(cap, pow2ceil(std::max(1, (work[i] + T - 1) / T)));
+        };
         if (locality)                                             // segments by waves per item (widest first); inside a segment the items
                                                                   // that share operands sit next to each other (same workgroup, same moment)
             std::stable_sort(it.begin(), it.end(), [&](int x, int y) {
