@@ -270,7 +270,10 @@ int jg_gn_time_kernel(jg_gn* h, int kernel, int reps, double* mean_ms);
  * Symbolic analysis only (no device needed): the static schedule that replaces the symbolic half
  * of `lu`/`klu` (src/backend/utility.jl:470-476, 486-492).  Used by the CPU test-suite to replay
  * and race-check the schedule.  pattern: 0-based int32 block CSR, structurally symmetric, full
- * diagonal.  jg_plan_export(which): see csrc/jg_plan_api.cpp; out == NULL returns the length.
+ * diagonal.  policy: bit 0 in-place factor storage, bit 1 symmetric values (LDL'), bit 2 the producer finishes level 0 (the
+ * leaf pivots: factorised diagonal blocks + rhs rows; csrc/jg_symbolic.hpp), bits 4-7 / 8-15 / 16-23 / 24-30 where the
+ * multifrontal top starts and how large its fronts get (0 = defaults).  jg_plan_export(which): see csrc/jg_plan_api.cpp;
+ * out == NULL returns the length.
  * ------------------------------------------------------------------------------------------- */
 typedef struct jg_plan jg_plan;
 int jg_plan_create(jg_plan** p, int64_t n, const int32_t* rowptr, const int32_t* col, int policy);
