@@ -297,7 +297,10 @@ def main():
     cdev = "cuda" if backend == "nccl" else "cpu"      # where the tensors of the collectives live
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    force_dist = world == 1 and bool(os.environ.get("JG_BENCH_FORCE_DIST"))   # probe: a 1-rank RCCL group, so that the collective path
+    if force_dist:                                                             # (init, all_gather_into_tensor on device records) runs on a 1-GPU box
+        os.environ.setdefault("MASTER_PORT", "29531"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -372,7 +375,7 @@ def main():
     packed = [torch.empty((lanes, 2 * n + 2), dtype=torch.float64, device="cuda") for _ in range(ring)]
 
     def deliver(job, h):                              # caller's thread, job order: the record is complete -> the ONE collective
-        if world > 1:
+        if world > 1 or force_dist:
             buf = packed[job % ring]
             if cdev == "cuda":
                 jg.gatherResults(dist, buf)
@@ -388,7 +391,7 @@ def main():
         return int(sum(int(np.sum(it[:r])) for (it, _), r in zip(out, real))), out[-1][1][:B]
 
     def fence():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -507,7 +510,7 @@ def main():
         print(json.dumps(line))
     else:
         pipe.close()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

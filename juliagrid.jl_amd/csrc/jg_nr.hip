@@ -328,10 +328,18 @@ __global__ __launch_bounds__(1024) void k_check(CheckArgs a) {
     const int b = blockIdx.x * 64 + lane;
     if (a.mode == 1 && a.group && !a.group[blockIdx.x]) return;   // finished group: assembly was skipped, keep its verdict
     double mp = 0.0, mq = 0.0;
-    for (int c = wave; c < a.nchunk; c += 16) {
-        const double x = a.part[((size_t)c * 2) * a.ld + b], y = a.part[((size_t)c * 2 + 1) * a.ld + b];
-        mp = (x > mp || x != x) ? x : mp;
-        mq = (y > mq || y != y) ? y : mq;
+    for (int c0 = wave; c0 < a.nchunk; c0 += 64) {                // four chunks per trip: eight loads in flight (625 chunks on a 10 000-bus
+        double x[4], y[4];                                        // grid were 39 dependent round trips per wave, 26 us per verdict)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = min(c0 + 16 * u, a.nchunk - 1);         // a repeated chunk changes no maximum
+            x[u] = a.part[((size_t)c * 2) * a.ld + b]; y[u] = a.part[((size_t)c * 2 + 1) * a.ld + b];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            mp = (x[u] > mp || x[u] != x[u]) ? x[u] : mp;
+            mq = (y[u] > mq || y[u] != y[u]) ? y[u] : mq;
+        }
     }
     red[0][wave][lane] = mp;
     red[1][wave][lane] = mq;
