@@ -376,24 +376,33 @@ struct CompactArgs {
                                // a store from this kernel instead of a memset node and a 4-byte copy node per iteration, ~20 us each)
 };
 
+// inclusive scan over the 1024 threads of the workgroup: shuffles inside a wave, the 16 wave totals through LDS (two barriers; the
+// Hillis-Steele loop it replaces had twenty and made the verdict of a single instance 12 us long)
+__device__ __forceinline__ int block_scan_1024(int v, int* wsum, int t, int& total) {
+    const int lane = t & 63, w = t >> 6;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    int off = 0;
+    total = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const int q = wsum[k]; off += k < w ? q : 0; total += q; }
+    __syncthreads();
+    return x + off;
+}
+
 __global__ __launch_bounds__(1024) void k_compact(CompactArgs a) {
-    __shared__ int scan[1024];
+    __shared__ int wsum[16];
     const int t = threadIdx.x;
     const int ld = a.ld, ngroups = ld / 64;
     const int per = (ld + 1023) / 1024;
     const int b0 = t * per, b1 = min(b0 + per, ld);
     int cnt = 0;
     for (int b = b0; b < b1; ++b) cnt += a.active[b] != 0;
-    scan[t] = cnt;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {                    // inclusive Hillis-Steele scan
-        const int v = t >= off ? scan[t - off] : 0;
-        __syncthreads();
-        scan[t] += v;
-        __syncthreads();
-    }
-    const int n_active = scan[1023];
-    const int before = scan[t] - cnt;                             // active lanes in front of this thread's chunk
+    int n_active;
+    (void)block_scan_1024(cnt, wsum, t, n_active);
     const int groups_new = (n_active + 63) / 64;
     const int groups_cur = a.flags[2];
     const bool permute = a.restore ? true : (n_active > 0 && groups_new < groups_cur);
@@ -419,23 +428,15 @@ __global__ __launch_bounds__(1024) void k_compact(CompactArgs a) {
         // Minimal moves: an active lane inside the leading groups_new groups stays where it is; the k-th active lane behind them
         // swaps with the k-th inactive lane inside them.  (A stable partition shifted almost every lane: 1 GB of lane rows per
         // compaction of 512 scenarios of a 10 000-bus grid, and again for the way home; 37 stragglers of 512 now move 64 lanes.)
-        (void)before;
         const int L = groups_new * 64;
         int holes = 0, outs = 0;
         for (int b = b0; b < b1; ++b) { const bool act = a.active[b] != 0; holes += (b < L && !act); outs += (b >= L && act); a.dest[b] = b; }
-        __syncthreads();                                          // (scan[] was read above)
-        scan[t] = holes | outs << 16;                             // both counts in one scan: ld < 65 536
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            const int v = t >= off ? scan[t - off] : 0;
-            __syncthreads();
-            scan[t] += v;
-            __syncthreads();
-        }
-        int hr = (scan[t] & 0xffff) - holes, orank = (scan[t] >> 16) - outs;   // holes / outside actives in front of this thread's chunk
+        int both;
+        const int incl = block_scan_1024(holes | outs << 16, wsum, t, both);   // both counts in one scan: ld < 65 536
+        int hr = (incl & 0xffff) - holes, orank = (incl >> 16) - outs;         // holes / outside actives in front of this thread's chunk
         int* hole_at = a.tmp;                                     // [k] position of the k-th hole, [ld / 2 + k] of the k-th outside active lane
         int* out_at = a.tmp + ld / 2;
-        const int n_out = scan[1023] >> 16;                       // <= min(L, ld - L) <= ld / 2; the leading groups hold at least as many holes
+        const int n_out = both >> 16;                             // <= min(L, ld - L) <= ld / 2; the leading groups hold at least as many holes
         for (int b = b0; b < b1; ++b) {
             const bool act = a.active[b] != 0;
             if (b < L && !act) { if (hr < n_out) hole_at[hr] = b; ++hr; }
