@@ -328,15 +328,16 @@ __global__ __launch_bounds__(1024) void k_check(CheckArgs a) {
     const int b = blockIdx.x * 64 + lane;
     if (a.mode == 1 && a.group && !a.group[blockIdx.x]) return;   // finished group: assembly was skipped, keep its verdict
     double mp = 0.0, mq = 0.0;
-    for (int c0 = wave; c0 < a.nchunk; c0 += 64) {                // four chunks per trip: eight loads in flight (625 chunks on a 10 000-bus
-        double x[4], y[4];                                        // grid were 39 dependent round trips per wave, 26 us per verdict)
+    constexpr int CU = 8;
+    for (int c0 = wave; c0 < a.nchunk; c0 += 16 * CU) {           // eight chunks per trip: sixteen loads in flight (625 chunks on a 10 000-bus
+        double x[CU], y[CU];                                      // grid were 39 dependent round trips per wave, 26 us per verdict)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < CU; ++u) {
             const int c = min(c0 + 16 * u, a.nchunk - 1);         // a repeated chunk changes no maximum
             x[u] = a.part[((size_t)c * 2) * a.ld + b]; y[u] = a.part[((size_t)c * 2 + 1) * a.ld + b];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < CU; ++u) {
             mp = (x[u] > mp || x[u] != x[u]) ? x[u] : mp;
             mq = (y[u] > mq || y[u] != y[u]) ? y[u] : mq;
         }
