@@ -42,6 +42,13 @@ def main(fetch_csv, write_csv, n, ld, solves, out_json, grid="case_ACTIVSg10k"):
         cw = sorted(v[0] for v in w[key] if v[0] > 1000)
         cal_f_raw = Counter(round(x) for x in cf).most_common(1)[0][0] * 1024.0
         cal_w_raw = Counter(round(x) for x in cw).most_common(1)[0][0] * 1024.0
+    elif any("copyBuffer" in k for k in f) and any(v[0] * 1024.0 > 0.4 * n * ld * 8 for k in f if "copyBuffer" in k for v in f[k]):
+        # device-to-device copies of V / theta at the end of tools/profile_kernels.py (snapshot + restore: four launches of n x ld x 8
+        # bytes read and written).  (The lane movers used before only touch the lanes that change place since the minimal-move compaction.)
+        key = [k for k in f if "copyBuffer" in k][0]
+        known = n * ld * 8
+        cal_f_raw = Counter(round(v[0]) for v in f[key] if v[0] * 1024.0 > 0.4 * known).most_common(1)[0][0] * 1024.0
+        cal_w_raw = Counter(round(v[0]) for v in w[key] if v[0] * 1024.0 > 0.8 * known).most_common(1)[0][0] * 1024.0
     else:                                        # k_lanes_move: the restore at the end of a run moves these arrays, read and written by each
         key = [k for k in f if "k_lanes_move" in k][0]    # of its two launches
         known = (6 * n + 2 * 4) * ld * 8         # V, theta, P, Q (n rows each), patch values (2 x 4 rows), increment (2n doubles per lane)

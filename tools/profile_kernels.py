@@ -20,4 +20,8 @@ case = sys.argv[3] if len(sys.argv) > 3 else "case_ACTIVSg10k"
 s = jg.powerSystem(case)
 an = jg.contingencyAnalysis(s, jg.outageList(s, batch, seed=512))     # ONE handle: every dispatch belongs to the batch
 jg.powerFlow_(an, iteration=iters, fetch=False)
+# calibration launches for the PMC passes (tools/pmc_summary.py): device-to-device copies of KNOWN size -- V and theta, n x ld x 8
+# bytes each, read once and written once
+an.snapshot_voltage()
+an.restore_voltage()
 print("dims", an.dims, "solves", iters, "iterations", int(np.sum(an.method.iteration)))
