@@ -802,6 +802,7 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, int policy
     // 0.358 / 0.339 / 0.337 / 0.344 ms at 64, the 9241-bus grid 0.213 / 0.202 / 0.207 / 0.217), 24 on small ones (case1354pegase 0.088 / 0.094 / ...)
     // large batches: the top starts where a level holds at most 384 items and 8 pivots on the large grids (ACTIVSg10k at 512 scenarios: 1.279 -> 1.241 ms
     // against 280 items / 4 pivots, which the small grids keep: case1354pegase 0.148 against 0.160 ms; the 9241-bus grid does not care)
+    if (!(policy >> 16) && ld_ >= 256 && !getenv("JG_TOP_NOSPLIT")) policy |= 8;
     if (!(policy >> 16)) policy |= ld_ >= 256 ? (n >= 4000 ? (47 << 16 | (384 / 8) << 24 | 8 << 4) : (47 << 16 | (280 / 8) << 24 | 4 << 4))
                                               : ((n >= 4000 ? 26 : 24) << 16 | (384 / 8) << 24);
     if (analyze(n, rowptr, col, policy, S)) { error = "block pattern must be structurally symmetric with a full diagonal"; return 1; }

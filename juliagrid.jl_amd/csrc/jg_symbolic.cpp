@@ -270,8 +270,12 @@ void build_top(BlockSymbolic& S, int top_level, int soft_cap, int struct_min) {
     // than the registers a narrow front leaves unused in a wide kernel: the top levels hold a handful of tasks)
     std::vector<int> order(nt);
     std::iota(order.begin(), order.end(), 0);
+    // (policy bit 3, large batches: a level's tasks of different classes go to launches of their own -- eight tasks x 512 scenarios are
+    // 4 096 workgroups, and the six of them with small fronts then run the 71-register kernel, seven to a CU instead of four)
+    const bool split = S.top_split != 0;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
         if (tasks[a].level != tasks[b].level) return tasks[a].level < tasks[b].level;
+        if (split && tasks[a].cls != tasks[b].cls) return tasks[a].cls < tasks[b].cls;
         return tasks[a].root() < tasks[b].root();
     });
     const bool sym = S.symmetric != 0;
@@ -340,7 +344,8 @@ void build_top(BlockSymbolic& S, int top_level, int soft_cap, int struct_min) {
         h.w[0] = m; h.w[1] = e; h.w[2] = t.root(); h.w[3] = base; h.w[4] = t.stack; h.w[5] = (int)t.kids.size();
         h.w[6] = piv_off; h.w[7] = child_off; h.w[8] = dent_off; h.w[9] = t.cls; h.w[10] = t.level; h.w[11] = fprime;
         S.top_task[oi] = h;
-        if (S.top_launch.empty() || S.top_launch.back().level != t.level) S.top_launch.push_back(TopLaunch{oi, 0, t.cls, t.level});
+        if (S.top_launch.empty() || S.top_launch.back().level != t.level || (split && S.top_launch.back().cls != t.cls))
+            S.top_launch.push_back(TopLaunch{oi, 0, t.cls, t.level});
         S.top_launch.back().ntasks++;
         S.top_launch.back().cls = std::max(S.top_launch.back().cls, t.cls);
     }
@@ -573,6 +578,7 @@ int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic&
     constexpr int TOP_LEVEL_MIN = 6, TOP_NARROW = 384, TOP_FRONT_SOFT = 24;
     S.symmetric = (policy >> 1) & 1;
     S.prefactor = ((policy >> 2) & 1) && S.inplace;
+    S.top_split = (policy >> 3) & 1;
     S.n = n;
     if (n <= 0) return 1;
     // adjacency without the diagonal; verify structural symmetry and diagonal presence

@@ -107,6 +107,7 @@ struct BlockSymbolic {
     // disappears.  For producers that deliver plain blocks the same items form the PRE tables, run ahead of level 1
     // (Engine::factor(..., level0_done = false)).
     int prefactor = 0;
+    int top_split = 0;                  // policy bit 3: one top launch per (task level, class) instead of one per level
     std::vector<char> pre_pivot;        // [n] pivot k: D(k) and y_k are level-0 items
     std::vector<Segment> pre_seg; std::vector<Rec> pre_rec; int n_pre_levels = 0;
     std::vector<int> src_entry;         // [nnz of the caller's pattern] -> entry id
@@ -131,6 +132,7 @@ struct BlockSymbolic {
 // pattern: CSR (rowptr[n+1], col[nnz]) 0-based, must contain the diagonal and be structurally
 // symmetric. policy bit 0: in-place factor storage (see BlockSymbolic::inplace); bit 1: symmetric VALUES (LDL' by
 // reading U(k,i)' for Lh(i,k): half the update terms; only the blocks on and above the diagonal must be assembled).
+// policy bit 3: top launches per (level, class) (large batches).
 // policy bits 8-15: dependency level from which pivots go to top tasks (0 = default: where the level schedule gets narrow,
 // 255 = no top tasks); bits 16-23: soft cap of a task's front (0 = default); bits 24-30: what "narrow" means, in units of 8
 // items per level (0 = default); bits 4-7: at most this many pivots per level in the top (0 = any).

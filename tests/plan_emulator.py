@@ -194,7 +194,7 @@ class Replay:
         prev = 0
         u_col = self.p.get("u_col")
         for li, (tb, ntk, cls, tlevel) in enumerate(launches):
-            assert tlevel > prev and tb == seen_tasks and cls in (2, 3, 4), "launches out of order"
+            assert tlevel >= prev and tb == seen_tasks and cls in (2, 3, 4), "launches out of order"   # (policy bit 3: a level may take one launch per class)
             prev = tlevel
             lev = bottom_levels + tlevel
             results = []

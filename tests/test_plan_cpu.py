@@ -283,7 +283,8 @@ def test_top_tasks_on_small_and_random_graphs(jg, monkeypatch, symmetric, top_le
     ntasks = 0
     for ci, (n, edges) in enumerate(cases):
         # unsymmetric plans also with policy bit 2: level 0 finished by the producer (even cases) or by the PRE tables (odd)
-        plan = _solve_with_plan(jg, n, edges, rng, symmetric, top=top_level << 8 | soft << 16, prefactor=None if symmetric else ci % 2 == 0)
+        # every third case with policy bit 3: one top launch per (level, class)
+        plan = _solve_with_plan(jg, n, edges, rng, symmetric, top=top_level << 8 | soft << 16 | (8 if ci % 3 == 0 else 0), prefactor=None if symmetric else ci % 2 == 0)
         ntasks += plan.top_tables()[0].shape[0]
     assert ntasks > 5              # (a prefactor plan has one level less: fewer pivots above a given top level)
 
