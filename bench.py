@@ -330,6 +330,15 @@ def main():
         jg.powerFlow_(base, fetch=False)
         t_single.append(time.perf_counter() - t0)
     base.close()
+    # The first handle of a process also pays the HIP context and the load of the library's code object.  What ONE MORE analysis of the
+    # same grid costs (what a reference user pays per newtonRaphson() call) is measured on a second handle:
+    t0 = time.perf_counter()
+    again = jg.newtonRaphson(jg.powerSystem(tables), batch=1, device=local)
+    t_create2 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    jg.powerFlow_(again)
+    t_first2 = time.perf_counter() - t0
+    again.close()
 
     # Scenario selection (untimed, identical on every rank): the first scenarios of a seeded shuffle of the non-bridge branches
     # THAT HAVE A POWER FLOW.  A contingency without a solution runs to the iteration limit (20 iterations for one lane while the
@@ -480,9 +489,12 @@ def main():
             "converged_fraction": conv_total / total,
             "single_instance": {"ms_per_solve": 1e3 * float(np.median(t_single)), "iterations": base_iters,
                                 "ms_per_iteration": 1e3 * float(np.median(t_single)) / max(base_iters, 1),
-                                "setup_ms": 1e3 * (t_create + t_first) - 1e3 * float(np.median(t_single)),
-                                "setup_what": f"newtonRaphson() {1e3 * t_create:.1f} ms (symbolic analysis of the block LU on the host, replay tables, "
-                                              f"upload) + first powerFlow!() {1e3 * t_first:.1f} ms (hipGraph capture) - one warm solve"},
+                                "setup_ms": 1e3 * (t_create2 + t_first2) - 1e3 * float(np.median(t_single)),
+                                "setup_what": f"a further analysis in a warm process: newtonRaphson() {1e3 * t_create2:.1f} ms (symbolic analysis of the block LU "
+                                              f"on the host, replay tables, upload) + first powerFlow!() {1e3 * t_first2:.1f} ms (hipGraph capture) - one warm solve",
+                                "setup_first_in_process_ms": 1e3 * (t_create + t_first) - 1e3 * float(np.median(t_single)),
+                                "setup_first_what": f"the first analysis of the process (HIP context, code object load on top): newtonRaphson() {1e3 * t_create:.1f} ms "
+                                                    f"+ first powerFlow!() {1e3 * t_first:.1f} ms - one warm solve"},
             "roofline": roofline,
             "kernels": kern,
         }

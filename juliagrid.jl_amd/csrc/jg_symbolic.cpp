@@ -3,6 +3,7 @@
 #include "jg_symbolic.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <iterator>
 #include <queue>
 #include <cstdio>
@@ -600,8 +601,14 @@ int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic&
             if (!std::binary_search(adj[j].begin(), adj[j].end(), i)) return 1;
 
     std::vector<std::vector<int>> strct;
+    const bool timing = getenv("JG_PLAN_TIMING") != nullptr;
+    auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = tnow();
+    auto lap = [&](const char* what) { if (timing) { const double t = tnow(); fprintf(stderr, "[jg plan] %-28s %8.1f ms\n", what, t - t0); t0 = t; } };
     elimination_order(n, adj, S.perm, strct);
+    lap("elimination order");
     postorder(S.perm, strct);
+    lap("postorder");
     S.iperm.assign(n, 0);
     for (int k = 0; k < n; ++k) S.iperm[S.perm[k]] = k;
     for (int k = 0; k < n; ++k) {
@@ -754,9 +761,12 @@ int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic&
         if (soft <= 0) soft = TOP_FRONT_SOFT;
         int struct_min = 0;
         if (const char* e = getenv("JG_TOP_STRUCT")) struct_min = atoi(e);
+        lap("fill pattern, terms, levels");
         build_top(S, top_level, std::min(soft, TOP_FRONT_MAX), struct_min);
+        lap("top tasks");
     }
     build_tables(S);
+    lap("replay tables");
     return 0;
 }
 
