@@ -528,15 +528,18 @@ __global__ void k_to_scenario_major(const double* src, double* dst, int n, int l
 
 // [n][ld] batch-minor -> column block `off` of a scenario-major result record [batch][stride] (the packed result of a batch:
 // V | theta | iterations | status per scenario, one buffer for the one gather of a sharded run)
-__global__ void k_pack_bus(const double* src, double* dst, int n, int ld, int batch, long long stride, int off) {
-    __shared__ double tile[32][33];
-    const int i0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
-    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+// (64 x 64 tiles: a wave reads and writes 512 contiguous bytes; both arrays of a record in one launch, blockIdx.z)
+__global__ __launch_bounds__(512) void k_pack_bus(const double* vm, const double* va, double* dst, int n, int ld, int batch, long long stride) {
+    __shared__ double tile[64][65];
+    const double* src = blockIdx.z ? va : vm;
+    const int off = blockIdx.z ? n : 0;
+    const int i0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+    for (int r = threadIdx.y; r < 64; r += blockDim.y) {
         const int i = i0 + r, b = b0 + threadIdx.x;
         tile[r][threadIdx.x] = (i < n && b < ld) ? src[(size_t)i * ld + b] : 0.0;
     }
     __syncthreads();
-    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    for (int r = threadIdx.y; r < 64; r += blockDim.y) {
         const int b = b0 + r, i = i0 + threadIdx.x;
         if (b < batch && i < n) dst[(size_t)b * stride + off + i] = tile[threadIdx.x][r];
     }
@@ -1051,9 +1054,8 @@ int jg_nr_pack_results_device(jg_nr* h, double* dst_dev) {
     if (!h || !dst_dev) return fail(1, "jg_nr_pack_results_device: bad argument");
     if (int rc = set_device(h)) return rc;
     const long long stride = 2LL * h->n + 2;
-    dim3 grid((h->n + 31) / 32, (h->ld + 31) / 32), block(32, 8);
-    hipLaunchKernelGGL(k_pack_bus, grid, block, 0, h->stream, h->d_vm, dst_dev, h->n, h->ld, h->batch, stride, 0);
-    hipLaunchKernelGGL(k_pack_bus, grid, block, 0, h->stream, h->d_va, dst_dev, h->n, h->ld, h->batch, stride, h->n);
+    dim3 grid((h->n + 63) / 64, (h->ld + 63) / 64, 2), block(64, 8);
+    hipLaunchKernelGGL(k_pack_bus, grid, block, 0, h->stream, h->d_vm, h->d_va, dst_dev, h->n, h->ld, h->batch, stride);
     hipLaunchKernelGGL(k_pack_tail, dim3((h->batch + 255) / 256), dim3(256), 0, h->stream, h->d_iters, h->d_status, dst_dev, h->batch, stride, 2 * h->n);
     NR_HIP(hipGetLastError());
     NR_HIP(hipStreamSynchronize(h->stream));
