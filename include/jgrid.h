@@ -272,11 +272,12 @@ int jg_gn_time_kernel(jg_gn* h, int kernel, int reps, double* mean_ms);
  * and race-check the schedule.  pattern: 0-based int32 block CSR, structurally symmetric, full
  * diagonal.  policy: bit 0 in-place factor storage, bit 1 symmetric values (LDL'), bit 2 the producer finishes level 0 (the
  * leaf pivots: factorised diagonal blocks + rhs rows; csrc/jg_symbolic.hpp), bits 4-7 / 8-15 / 16-23 / 24-30 where the
- * multifrontal top starts and how large its fronts get (0 = defaults).  jg_plan_export(which): see csrc/jg_plan_api.cpp;
+ * multifrontal top starts and how large its fronts get (0 = defaults), bits 32-39 / 40-47 / 48 the grouped tasks below the
+ * top (csrc/jg_symbolic.hpp: "mid").  jg_plan_export(which): see csrc/jg_plan_api.cpp;
  * out == NULL returns the length.
  * ------------------------------------------------------------------------------------------- */
 typedef struct jg_plan jg_plan;
-int jg_plan_create(jg_plan** p, int64_t n, const int32_t* rowptr, const int32_t* col, int policy);
+int jg_plan_create(jg_plan** p, int64_t n, const int32_t* rowptr, const int32_t* col, int64_t policy);
 void jg_plan_destroy(jg_plan* p);
 int64_t jg_plan_export(jg_plan* p, int which, int32_t* out, int64_t cap);
 

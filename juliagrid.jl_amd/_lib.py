@@ -98,7 +98,7 @@ def lib():
         "jg_gn_get_increment": [VP, F64P],
         "jg_gn_get_iteration": [VP, I32P],
         "jg_gn_time_kernel": [VP, C.c_int, C.c_int, C.POINTER(C.c_double)],
-        "jg_plan_create": [C.POINTER(VP), C.c_int64, I32P, I32P, C.c_int],
+        "jg_plan_create": [C.POINTER(VP), C.c_int64, I32P, I32P, C.c_int64],
     }
     for name, args in sig.items():
         f = getattr(L, name)
@@ -161,5 +161,6 @@ class Plan:
 
     def top_tables(self):
         """Multifrontal top (jg_symbolic.hpp): task headers [t,16], task data, launches [l,4] = task_begin, ntasks, class,
-        level; task of each pivot; (top_level, stack doubles per scenario, terms inside tasks)."""
-        return self.get(70).reshape(-1, 16), self.get(71), self.get(72).reshape(-1, 4), self.get(73), self.get(74)
+        level, grouped, wg_begin, nwg, -; task of each pivot; (top_level, stack doubles per scenario, terms inside tasks).
+        Workgroup map of the grouped launches: get(78)."""
+        return self.get(70).reshape(-1, 16), self.get(71), self.get(72).reshape(-1, 8), self.get(73), self.get(74)

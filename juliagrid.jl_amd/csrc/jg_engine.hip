@@ -491,10 +491,20 @@ __global__ __launch_bounds__(64 * FACT_WAVES, 4) void k_sel_level(SelArgs a) {  
 struct TopArgs {
     const Rec* task; const int* data;
     double* X; double* W; double* stack; int* status; GroupSel sel;
-    long long stack_stride;        // doubles per scenario
+    long long stack_stride;        // doubles per scenario of the scenario-major stack (class 0)
+    long long sbase[3], sstride[3];   // the stacks by interleave class (1 / 4 / 16 scenarios): first double, doubles per scenario
     long long* prof;               // JG_TOP_PROFILE: [task][8] wall-clock stamps of scenario 0 (start, loaded, children, steps, stored), else null
     int ld, lanes, task_begin, ntasks, lpg;   // lpg: scenarios per 64-lane group that get a workgroup (64, or the real count of a single small group)
+    const int* wgmap; int wg_begin, nwg;      // grouped launches (k_fact_grp): workgroup x of a group -> task << 8 | scenario block
 };
+
+// Where scenario b keeps 16-byte unit q of a task's update block: the block is interleaved over the 2^lg scenarios that share a workgroup
+// of the PARENT task (lg = 0: scenario-major, what a workgroup per scenario reads; jg_symbolic.hpp).  off: the block's offset in doubles.
+__device__ __forceinline__ double2* stack_unit(const TopArgs& a, size_t b, int off, int lg) {
+    const long long base = lg == 0 ? a.sbase[0] : (lg == 2 ? a.sbase[1] : a.sbase[2]);
+    const long long stride = lg == 0 ? a.sstride[0] : (lg == 2 ? a.sstride[1] : a.sstride[2]);
+    return (double2*)(a.stack + base) + ((((b >> lg) * (size_t)(stride >> 1) + (size_t)(off >> 1)) << lg) + (b & ((1u << lg) - 1)));
+}
 
 // 1 / x without the IEEE division sequence (v_rcp_f64 + two Newton steps: 5 dependent operations instead of ~14; the result
 // is within an ulp or two, which only perturbs the stored pivot factors at rounding level -- the factorisation stays the
@@ -741,7 +751,8 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
     if (prof) pt[3] = wall_clock64();
     // ---- store
     if (!pivot_wave) {
-        double* out = e > 0 ? stk + h[4] : nullptr;
+        const int lgo = h[12];                                   // scenario interleave of the update block: that of the parent's workgroup
+        double2* out = e > 0 ? stack_unit(a, b, h[4], lgo) : nullptr;
 #pragma unroll
         for (int r = 0; r < CLS; ++r)
 #pragma unroll
@@ -752,8 +763,8 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
                 if (cd <= -2) store_vec(a.W, (size_t)(-(cd + 2)), b, ld, v.v00, v.v10);
                 else if (cd >= 0 && (!((cd >> 28) & 4) || (!PW && i == j && i < m))) store_blk(a.X, (size_t)(cd & 0x0fffffff), b, ld, v.v00, v.v01, v.v10, v.v11);
                 else if (i >= m && i < f && j >= m && j < fprime) {                              // update matrix | vector: scenario-major stack
-                    double2* p = (double2*)(out + ((size_t)(i - m) * (e + 1) + (j - m)) * 4);
-                    p[0] = double2{v.v00, v.v01}; p[1] = double2{v.v10, v.v11};
+                    double2* p = out + ((((size_t)(i - m) * (e + 1) + (j - m)) * 2) << lgo);
+                    p[0] = double2{v.v00, v.v01}; p[(size_t)1 << lgo] = double2{v.v10, v.v11};
                 }
             }
         if ((PW ? tid == 0 : true) && bad) atomicOr(a.status + b, 4);
@@ -762,6 +773,183 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
         if (bad && lane == 0) atomicOr(a.status + b, 4);
     }
     if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pt[4] = wall_clock64(); }
+}
+
+// ---- grouped tasks (jg_symbolic.hpp): one workgroup per (task, G consecutive scenarios), G = 4 or 16 ---------------------------------
+// The same elimination as k_fact_top<CLS, false> -- dense front in registers, pivot row / column / pivot through LDS, one barrier per
+// pivot, the owner of the next diagonal block factorises it -- on G thread grids of T x T (T = 8 / 4) instead of one of 16 x 16:
+// thread (g, gi, gj), g fastest, owns blocks (r T + gi, c T + gj) of scenario bb0 + g.  A load / store instruction of the gather covers
+// G x 16 contiguous bytes of the batch-minor storage (one scenario per workgroup: 16 of every 1 024), the children's update blocks are
+// interleaved over the same G scenarios, and a pivot step of the workgroup advances G scenarios.  The pivot differs from lane to lane
+// here, so the row swap of its 2x2 LU is a select, not an address.  Geometry (G, T) comes from the task header: one kernel instance
+// serves every grouped task of a level.
+template <int CLS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_fact_grp(TopArgs a) {
+    __shared__ __attribute__((aligned(16))) double Dbuf[2][16 * 4];     // [buffer][scenario]: factorised pivot of the current / next step
+    __shared__ __attribute__((aligned(16))) double Ubuf[2][256 * 4];    // [buffer][front column x G + scenario]: pivot row U(q, c)
+    __shared__ __attribute__((aligned(16))) double Lbuf[2][256 * 4];    // pivot column Lh(i, q)
+    __shared__ __attribute__((aligned(16))) double Dref[256 * 2];       // [pivot x G + scenario]: row maxima of the chain's diagonal blocks as they entered the task
+    int grp, x;
+    if (!map_block(a.sel, a.ld, a.nwg, grp, x)) return;
+    const int wm = ((CIntPtr)a.wgmap)[a.wg_begin + x];
+    const int ti = wm >> 8;
+    const RecS h = load_rec(a.task, (size_t)ti);
+    const int m = h[0], e = h[1], nchild = h[5], fprime = h[11], lgo = h[12], lg = h[13];
+    const int f = fprime - 1;
+    const int lt = 4 - (lg >> 1);
+    const int bb0 = grp * 64 + ((wm & 255) << lg);
+    if (bb0 >= a.lanes) return;                                  // padding scenarios of the last group
+    const int tid = threadIdx.x;
+    const int g = tid & ((1 << lg) - 1), gj = (tid >> lg) & ((1 << lt) - 1), gi = tid >> (lg + lt);
+    const bool live = bb0 + g < a.lanes;                         // threads of a padding scenario compute on the last real one and store nothing
+    const size_t b = (size_t)min(bb0 + g, a.lanes - 1), ld = (size_t)a.ld;
+    const int* td = a.data + h[3];
+    int bad = 0;
+    Blk T[CLS][CLS];
+    // ---- load: entry map, then every gather of the thread in flight together
+    {
+        int code[CLS][CLS];
+#pragma unroll
+        for (int r = 0; r < CLS; ++r)
+#pragma unroll
+            for (int c = 0; c < CLS; ++c) {
+                const int i = (r << lt) + gi, j = (c << lt) + gj;
+                code[r][c] = (i < f && j < fprime) ? td[i * fprime + j] : -1;
+            }
+#pragma unroll
+        for (int r = 0; r < CLS; ++r)
+#pragma unroll
+            for (int c = 0; c < CLS; ++c) {
+                const int cd = code[r][c];
+                Blk v{0.0, 0.0, 0.0, 0.0};
+                if (cd <= -2) { const double2 y = load_vec(a.W, (size_t)(-(cd + 2)), b, ld); v.v00 = y.x; v.v10 = y.y; }
+                else if (cd >= 0 && !((cd >> 28) & 1)) {
+                    v = load_blk(a.X, (size_t)(cd & 0x0fffffff), b, ld);
+                    if ((cd >> 28) & 2) { const double s = v.v01; v.v01 = v.v10; v.v10 = s; }        // symmetric plans: Lh(i,c) = U(c,i)'
+                }
+                T[r][c] = v;
+            }
+    }
+    // ---- extend-add: the children's update blocks, interleaved over the scenarios of THIS workgroup (child order fixed => deterministic)
+    {
+        const int* cd = td + h[7];
+        for (int ch = 0; ch < nchild; ++ch) {
+            const int coff = cd[0], ce = cd[1];
+            const int* inv = cd + 2;
+            const double2* C = stack_unit(a, b, coff, lg);
+            int ri[CLS], cj[CLS];
+#pragma unroll
+            for (int r = 0; r < CLS; ++r) { const int i = (r << lt) + gi; ri[r] = i < f ? inv[i] : -1; }
+#pragma unroll
+            for (int c = 0; c < CLS; ++c) { const int j = (c << lt) + gj; cj[c] = j < fprime ? inv[j] : -1; }
+#pragma unroll
+            for (int r = 0; r < CLS; ++r)
+#pragma unroll
+                for (int c = 0; c < CLS; ++c)
+                    if (ri[r] >= 0 && cj[c] >= 0) {
+                        const double2* p = C + ((((size_t)ri[r] * (ce + 1) + cj[c]) * 2) << lg);
+                        const double2 s0 = p[0], s1 = p[(size_t)1 << lg];
+                        T[r][c].v00 += s0.x; T[r][c].v01 += s0.y; T[r][c].v10 += s1.x; T[r][c].v11 += s1.y;
+                    }
+            cd += 2 + fprime;
+        }
+    }
+    // ---- publish step 0 (zeros where the step must not touch: row: columns <= q, column: rows <= q)
+#pragma unroll
+    for (int r = 0; r < CLS; ++r)
+#pragma unroll
+        for (int c = 0; c < CLS; ++c) {
+            const int i = (r << lt) + gi, j = (c << lt) + gj;
+            if (i == 0) lds_set(Ubuf[0], (j << lg) + g, j > 0 ? T[r][c] : zero_blk());
+            if (j == 0) lds_set(Lbuf[0], (i << lg) + g, i > 0 ? T[r][c] : zero_blk());
+            if (i == j && i < m) *(double2*)(Dref + (size_t)((i << lg) + g) * 2) = row_max(T[r][c]);
+        }
+    if (gi == 0 && gj == 0) {
+        const Blk d0 = factor_diag(T[0][0], bad, row_max(T[0][0]));
+        lds_set(Dbuf[0], g, d0);
+        T[0][0] = d0;
+    }
+    __syncthreads();
+    // ---- pivot steps
+    for (int qv = 0; qv < m; ++qv) {
+        const int q = uniform(qv);
+        const int cur = q & 1, nxt = cur ^ 1;
+        const Blk D = lds_get(Dbuf[cur], g);
+        const bool sw = D.v10 > 2.0;
+        const double dl = sw ? D.v10 - 4.0 : D.v10;
+        Blk Lq[CLS];
+#pragma unroll
+        for (int r = 0; r < CLS; ++r) Lq[r] = lds_get(Lbuf[cur], ((((r << lt) + gi)) << lg) + g);
+#pragma unroll
+        for (int c = 0; c < CLS; ++c) {
+            const double2* p = (const double2*)(Ubuf[cur] + (size_t)((((c << lt) + gj) << lg) + g) * 4);
+            const double2 r0 = p[0], r1 = p[1];
+            const double2 a0 = sw ? r1 : r0, a1 = sw ? r0 : r1;  // z = D^-1 U(q, c): rows of U in pivot order
+            Blk z;
+            z.v10 = (a1.x - dl * a0.x) * D.v11; z.v00 = (a0.x - D.v01 * z.v10) * D.v00;
+            z.v11 = (a1.y - dl * a0.y) * D.v11; z.v01 = (a0.y - D.v01 * z.v11) * D.v00;
+#pragma unroll
+            for (int r = 0; r < CLS; ++r) blk_sub(T[r][c], Lq[r], z);
+        }
+        if (q + 1 < m) {
+            const int rq = (q + 1) >> lt, tq = (q + 1) & ((1 << lt) - 1);
+            if (gi == tq && gj == tq) {                          // the owner of S(q+1, q+1): final now, factorised here
+                const double2 ref = *(const double2*)(Dref + (size_t)(((q + 1) << lg) + g) * 2);
+#pragma unroll
+                for (int r = 0; r < CLS; ++r)
+                    if (r == rq) {
+                        const Blk dn = factor_diag(T[r][r], bad, ref);
+                        lds_set(Dbuf[nxt], g, dn);
+                        T[r][r] = dn;
+                    }
+            }
+            if (gi == tq) {
+#pragma unroll
+                for (int r = 0; r < CLS; ++r)
+                    if (r == rq) {
+#pragma unroll
+                        for (int c = 0; c < CLS; ++c) {
+                            const int slot = (((c << lt) + gj) << lg) + g;
+                            if (c < rq) lds_set(Ubuf[nxt], slot, zero_blk());
+                            else if (c > rq) lds_set(Ubuf[nxt], slot, T[r][c]);
+                            else lds_set(Ubuf[nxt], slot, gj > tq ? T[r][c] : zero_blk());
+                        }
+                    }
+            }
+            if (gj == tq) {
+#pragma unroll
+                for (int c = 0; c < CLS; ++c)
+                    if (c == rq) {
+#pragma unroll
+                        for (int r = 0; r < CLS; ++r) {
+                            const int slot = (((r << lt) + gi) << lg) + g;
+                            if (r < rq) lds_set(Lbuf[nxt], slot, zero_blk());
+                            else if (r > rq) lds_set(Lbuf[nxt], slot, T[r][c]);
+                            else lds_set(Lbuf[nxt], slot, gi > tq ? T[r][c] : zero_blk());
+                        }
+                    }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- store
+    if (!live) return;
+    double2* out = e > 0 ? stack_unit(a, b, h[4], lgo) : nullptr;
+#pragma unroll
+    for (int r = 0; r < CLS; ++r)
+#pragma unroll
+        for (int c = 0; c < CLS; ++c) {
+            const int i = (r << lt) + gi, j = (c << lt) + gj;
+            const int cd = (i < f && j < fprime) ? td[i * fprime + j] : -1;
+            const Blk& v = T[r][c];
+            if (cd <= -2) store_vec(a.W, (size_t)(-(cd + 2)), b, ld, v.v00, v.v10);
+            else if (cd >= 0 && (!((cd >> 28) & 4) || (i == j && i < m))) store_blk(a.X, (size_t)(cd & 0x0fffffff), b, ld, v.v00, v.v01, v.v10, v.v11);
+            else if (i >= m && i < f && j >= m && j < fprime) {                              // update matrix | vector
+                double2* p = out + ((((size_t)(i - m) * (e + 1) + (j - m)) * 2) << lgo);
+                p[0] = double2{v.v00, v.v01}; p[(size_t)1 << lgo] = double2{v.v10, v.v11};
+            }
+        }
+    if (bad) atomicOr(a.status + b, 4);
 }
 
 // per-level launch table: segment ranges and chunk totals
@@ -791,7 +979,7 @@ std::mutex& capture_mutex() {
     return m;
 }
 
-int Engine::create(int n, const int* rowptr, const int* col, int ld_, int policy, hipStream_t st) {
+int Engine::create(int n, const int* rowptr, const int* col, int ld_, long long policy, hipStream_t st) {
     if (ld_ <= 0 || ld_ % 64) { error = "batch leading dimension must be a positive multiple of 64"; return 1; }
     // Where the multifrontal top starts depends on the batch: a top task occupies a workgroup per scenario (~10 us + ~1 us per
     // pivot), a level launch a wave per 64 scenarios.  Up to 128 scenarios every level that holds fewer than ~400 items is
@@ -802,8 +990,9 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, int policy
     // 0.358 / 0.339 / 0.337 / 0.344 ms at 64, the 9241-bus grid 0.213 / 0.202 / 0.207 / 0.217), 24 on small ones (case1354pegase 0.088 / 0.094 / ...)
     // large batches: the top starts where a level holds at most 384 items and 8 pivots on the large grids (ACTIVSg10k at 512 scenarios: 1.279 -> 1.241 ms
     // against 280 items / 4 pivots, which the small grids keep: case1354pegase 0.148 against 0.160 ms; the 9241-bus grid does not care)
-    if (!(policy >> 16) && ld_ >= 256 && !getenv("JG_TOP_NOSPLIT")) policy |= 8;
-    if (!(policy >> 16)) policy |= ld_ >= 256 ? (n >= 4000 ? (47 << 16 | (384 / 8) << 24 | 8 << 4) : (47 << 16 | (280 / 8) << 24 | 4 << 4))
+    const bool defaults = !((policy >> 16) & 0x7fff);
+    if (defaults && ld_ >= 256 && !getenv("JG_TOP_NOSPLIT")) policy |= 8;
+    if (defaults) policy |= ld_ >= 256 ? (n >= 4000 ? (47 << 16 | (384 / 8) << 24 | 8 << 4) : (47 << 16 | (280 / 8) << 24 | 4 << 4))
                                               : ((n >= 4000 ? 26 : 24) << 16 | (384 / 8) << 24);
     if (analyze(n, rowptr, col, policy, S)) { error = "block pattern must be structurally symmetric with a full diagonal"; return 1; }
     ld = ld_;
@@ -822,8 +1011,8 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, int policy
         return 2;
     JG_HIP(hipFuncSetAttribute((const void*)k_bwd_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CHAIN_LDS_D2 * sizeof(double2))));
     if (!S.top_launch.empty()) {
-        if (upload(&top_task, S.top_task, error, st) || upload(&top_data, S.top_data, error, st)) return 2;
-        const size_t sb = (size_t)std::max<long long>(S.top_stack, 2) * ld * sizeof(double);
+        if (upload(&top_task, S.top_task, error, st) || upload(&top_data, S.top_data, error, st) || upload(&top_wgmap, S.top_wgmap, error, st)) return 2;
+        const size_t sb = (size_t)(std::max<long long>(S.top_stack_cls[0], 2) + S.top_stack_cls[1] + S.top_stack_cls[2]) * ld * sizeof(double);
         JG_HIP(hipMalloc((void**)&top_stack, sb));
         JG_HIP(sync_fill(top_stack, 0, sb, st));
         if (getenv("JG_TOP_PROFILE")) {
@@ -871,7 +1060,7 @@ void Engine::destroy() {
     hipFree(fact_rec); hipFree(bwd_rec); hipFree(fact_seg); hipFree(bwd_seg); hipFree(bwd_chain); hipFree(pre_rec); hipFree(pre_seg); hipFree(pre_row);
     hipFree(fwd_rec); hipFree(fwd_seg); fwd_rec = nullptr; fwd_seg = nullptr;
     hipFree(sel_rec); hipFree(sel_seg); hipFree(Zs); sel_rec = nullptr; sel_seg = nullptr; Zs = nullptr;
-    hipFree(top_task); hipFree(top_data); hipFree(top_stack); top_task = nullptr; top_data = nullptr; top_stack = nullptr;
+    hipFree(top_task); hipFree(top_data); hipFree(top_stack); hipFree(top_wgmap); top_task = nullptr; top_data = nullptr; top_stack = nullptr; top_wgmap = nullptr;
     bwd_chain = nullptr;
     hipFree(X); hipFree(W); hipFree(status);
     fact_rec = bwd_rec = nullptr; fact_seg = bwd_seg = nullptr; status = nullptr; pre_rec = nullptr; pre_seg = nullptr; pre_row = nullptr;
@@ -898,10 +1087,17 @@ int Engine::factor(hipStream_t st, const double* A, const double* rhs, const Gro
     }
     // the top of the elimination tree: multifrontal tasks, one workgroup per (task, scenario), launch = (task level, class)
     if (!S.top_launch.empty()) {
-        TopArgs t{top_task, top_data, X, W, top_stack, status, sel, std::max<long long>(S.top_stack, 2), top_prof, ld, a.lanes, 0, 0, 64};
+        const long long s0 = std::max<long long>(S.top_stack_cls[0], 2);
+        TopArgs t{top_task, top_data, X, W, top_stack, status, sel, s0, {0, s0 * ld, (s0 + S.top_stack_cls[1]) * ld}, {s0, S.top_stack_cls[1], S.top_stack_cls[2]},
+                  top_prof, ld, a.lanes, 0, 0, 64, top_wgmap, 0, 0};
         if (ld == 64 && t.lanes < 64) t.lpg = t.lanes;
         for (const TopLaunch& L : S.top_launch) {
             t.task_begin = L.task_begin; t.ntasks = L.ntasks;
+            if (L.grouped) {                                     // every grouped task of the level: 4 or 16 scenarios per workgroup
+                t.wg_begin = L.wg_begin; t.nwg = L.nwg;
+                hipLaunchKernelGGL((k_fact_grp<4>), dim3((unsigned)L.nwg * gs), dim3(256), 0, st, t);
+                continue;
+            }
             const dim3 grid((unsigned)L.ntasks * t.lpg * gs);
             // More workgroups than the CUs can hold WITH a pivot wave (1 per CU at CLS = 4, 2 at CLS = 3, 3 at CLS = 2): the 4-wave
             // variant, of which a CU holds twice as many; else the pivot-wave variant, whose step is 15 % shorter (measured at 512

@@ -163,12 +163,13 @@ struct Engine {
     int* status = nullptr;         // [ld] bit 2 set on zero / non-finite pivot
     std::vector<DevLaunch> fact, bwd, fwd, selv, pre;
     Rec* top_task = nullptr; int* top_data = nullptr;          // multifrontal top (jg_symbolic.hpp): task headers, task data
+    int* top_wgmap = nullptr;                                  // workgroup map of the grouped launches
     double* top_stack = nullptr;                               // update matrices of the tasks, scenario-major [ld][S.top_stack]
     long long* top_prof = nullptr;                             // JG_TOP_PROFILE: per-task phase stamps (printed by destroy)
     int device = 0;
     std::string error;
 
-    int create(int n, const int* rowptr, const int* col, int ld_, int policy, hipStream_t st);   // st: the owner's stream (setup copies)
+    int create(int n, const int* rowptr, const int* col, int ld_, long long policy, hipStream_t st);   // st: the owner's stream (setup copies)
     void destroy();
     // A: block values in the caller's CSR order [nnz][4][ld]; rhs: [n][2][ld] original block order.
     // Computes A = Lh inv(D) U and y = (Lh inv(D))^-1 rhs in the same launches.

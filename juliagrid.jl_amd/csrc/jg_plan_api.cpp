@@ -14,10 +14,10 @@ struct jg_plan {
 
 extern "C" {
 
-int jg_plan_create(jg_plan** out, int64_t n, const int32_t* rowptr, const int32_t* col, int policy) {
+int jg_plan_create(jg_plan** out, int64_t n, const int32_t* rowptr, const int32_t* col, int64_t policy) {
     if (!out || !rowptr || !col || n < 1) return 1;
     jg_plan* p = new jg_plan();
-    if (jg::analyze((int)n, rowptr, col, policy, p->S)) { delete p; return 1; }
+    if (jg::analyze((int)n, rowptr, col, (long long)policy, p->S)) { delete p; return 1; }
     *out = p;
     return 0;
 }
@@ -30,8 +30,9 @@ void jg_plan_destroy(jg_plan* p) { delete p; }
 //        60 fact segments (x8), 61 fact wave records (x16), 62 bwd segments, 63 bwd records, 64 src_entry (device replay tables)
 //        18 bwd_level (row-wise), 19 chain_level (level of the backward chain / row a pivot belongs to), 65 backward chain task data, 66 / 67 forward-only segments / records,
 //        68 / 69 selected-inverse segments / records
-//        70 top-task headers (x16), 71 top-task data, 72 top launches (x4: task_begin, ntasks, class, level),
-//        73 task of each pivot (-1: bottom), 74 {top_level, stack doubles per scenario (low 31 bits), top terms (low 31 bits)}
+//        70 top-task headers (x16), 71 top-task data, 72 top launches (x8: task_begin, ntasks, class, level, grouped, wg_begin, nwg, -),
+//        78 workgroup map of the grouped launches (task << 8 | scenario block),
+//        73 task of each pivot (-1: bottom), 74 {top_level, stack doubles per scenario (low 31 bits), top terms (low 31 bits), stack doubles per interleave class x3}
 // out == NULL returns the length.
 int64_t jg_plan_export(jg_plan* p, int which, int32_t* out, int64_t cap) {
     if (!p) return -1;
@@ -60,9 +61,10 @@ int64_t jg_plan_export(jg_plan* p, int which, int32_t* out, int64_t cap) {
         case 69: tmp.assign((const int*)S.sel_rec.data(), (const int*)S.sel_rec.data() + S.sel_rec.size() * 16); v = &tmp; break;
         case 70: tmp.assign((const int*)S.top_task.data(), (const int*)S.top_task.data() + S.top_task.size() * 16); v = &tmp; break;
         case 71: v = &S.top_data; break;
-        case 72: tmp.assign((const int*)S.top_launch.data(), (const int*)S.top_launch.data() + S.top_launch.size() * 4); v = &tmp; break;
+        case 72: tmp.assign((const int*)S.top_launch.data(), (const int*)S.top_launch.data() + S.top_launch.size() * 8); v = &tmp; break;
+        case 78: v = &S.top_wgmap; break;
         case 73: v = &S.top_task_of; break;
-        case 74: tmp = {S.top_level, (int)(S.top_stack & 0x7fffffff), (int)(S.top_terms & 0x7fffffff)}; v = &tmp; break;
+        case 74: tmp = {S.top_level, (int)(S.top_stack & 0x7fffffff), (int)(S.top_terms & 0x7fffffff), (int)S.top_stack_cls[0], (int)S.top_stack_cls[1], (int)S.top_stack_cls[2]}; v = &tmp; break;
         case 75: tmp.assign(S.pre_pivot.begin(), S.pre_pivot.end()); v = &tmp; break;
         case 76: tmp.assign((const int*)S.pre_seg.data(), (const int*)S.pre_seg.data() + S.pre_seg.size() * 8); v = &tmp; break;
         case 77: tmp.assign((const int*)S.pre_rec.data(), (const int*)S.pre_rec.data() + S.pre_rec.size() * 16); v = &tmp; break;

@@ -13,7 +13,8 @@
 namespace jg {
 
 void build_tables(BlockSymbolic& S);
-void build_top(BlockSymbolic& S, int top_level, int soft_cap, int struct_min);
+constexpr int NO_TOP_LEVEL = 0x7fffffff;
+void build_top(BlockSymbolic& S, int top_level, int soft_cap, int struct_min, int mid_mmin, int mid_strict);
 
 namespace {
 
@@ -215,16 +216,19 @@ void build_replay(const std::vector<int>& level, const std::vector<int>& work, i
 // parent is already in the task, largest pivot number first (the supernode child of a pivot is its largest child, so a chain is
 // followed to its end before siblings are taken).  Its front holds the task's pivots in ascending order, then struct(root);
 // the elimination is dense over that front (a block outside a pivot's structure is an exact zero and stays one).
-void build_top(BlockSymbolic& S, int top_level, int soft_cap, int struct_min) {
+// mid_mmin > 0: GROUPED tasks (jg_symbolic.hpp) -- a task's front is capped by the geometry it will run with (15 rows at 16 scenarios per
+// workgroup, 31 at 4, soft_cap at one), the smallest one that still leaves room for mid_mmin pivots (or for every task pivot of the root's
+// subtree if there are fewer); mid_strict: pivots that would fit a smaller geometry are not absorbed (they form tasks of their own).
+void build_top(BlockSymbolic& S, int top_level, int soft_cap, int struct_min, int mid_mmin, int mid_strict) {
     const int n = S.n;
-    S.top_level = 0; S.top_task.clear(); S.top_data.clear(); S.top_launch.clear(); S.top_stack = 0; S.top_terms = 0;
+    S.top_level = 0; S.top_task.clear(); S.top_data.clear(); S.top_launch.clear(); S.top_stack = 0; S.top_terms = 0; S.top_wgmap.clear();
     S.top_task_of.assign(n, -1);
-    if (top_level <= 0 || top_level >= 255) return;
+    if (top_level <= 0 || (top_level == NO_TOP_LEVEL && struct_min <= 0)) return;   // NO_TOP_LEVEL: no pivot goes to a task for its level
     auto ssize = [&](int k) { return S.u_ptr[k + 1] - S.u_ptr[k]; };
     auto parent = [&](int k) { return ssize(k) ? S.u_col[S.u_ptr[k]] : -1; };
     std::vector<char> top(n, 0);
     int ntop = 0;
-    for (int k = 0; k < n; ++k) if (S.e_level[S.diag[k]] >= top_level) top[k] = 1;
+    if (top_level != NO_TOP_LEVEL) for (int k = 0; k < n; ++k) if (S.e_level[S.diag[k]] >= top_level) top[k] = 1;
     // fronts of struct_min blocks and more go to the tasks wherever they sit in the tree, and so do their ancestors (a task hands
     // its update matrix to the task of its parent): per (pivot, scenario) a task step costs the same whatever the front, a
     // level item costs per update term, and the two cross near 13 blocks
@@ -234,19 +238,29 @@ void build_top(BlockSymbolic& S, int top_level, int soft_cap, int struct_min) {
     }
     for (int k = 0; k < n; ++k) if (top[k]) { ++ntop; if (ssize(k) + 1 > TOP_FRONT_MAX) return; }
     if (ntop == 0) return;
-    struct Task { std::vector<int> piv; int m, e, parent, level, cls, stack; std::vector<int> kids; int root() const { return piv.back(); } };
+    struct Task { std::vector<int> piv; int m, e, parent, level, cls, stack, lg; std::vector<int> kids; int root() const { return piv.back(); } };
     std::vector<Task> tasks;
     std::vector<int> sub(n, 1);                                  // subtree sizes: the descendants of k are k - sub[k] + 1 .. k - 1 (postorder)
     for (int k = 0; k < n; ++k) if (parent(k) >= 0) sub[parent(k)] += sub[k];
+    std::vector<int> tsub(n, 0);                                 // task pivots in the subtree of k
+    for (int k = 0; k < n; ++k) { if (top[k]) tsub[k]++; if (parent(k) >= 0) tsub[parent(k)] += tsub[k]; }
+    const int gcap[3] = {15, 31, soft_cap};                      // front rows a geometry holds (16 / 4 / 1 scenarios per workgroup)
     for (int k = n - 1; k >= 0; --k) {
         if (!top[k] || S.top_task_of[k] >= 0) continue;
         Task t{};
         t.e = ssize(k);
-        const int cap = std::max(std::min(8, TOP_FRONT_MAX - t.e), soft_cap - t.e);
+        int cap = std::max(std::min(8, TOP_FRONT_MAX - t.e), soft_cap - t.e), lowcap = 0;
+        if (mid_mmin > 0) {
+            const int need = std::max(1, std::min(tsub[k], mid_mmin));
+            int geo = 2;
+            for (int g = 0; g < 2 && geo == 2; ++g) if (gcap[g] - t.e >= need) geo = g;
+            if (geo < 2) cap = gcap[geo] - t.e;
+            lowcap = geo ? gcap[geo - 1] : 0;
+        }
         const int id = (int)tasks.size();
         t.piv.push_back(k); S.top_task_of[k] = id;
         for (int q = k - 1; q > k - sub[k] && (int)t.piv.size() < cap; --q)
-            if (top[q] && S.top_task_of[q] < 0 && S.top_task_of[parent(q)] == id) { t.piv.push_back(q); S.top_task_of[q] = id; }
+            if (top[q] && S.top_task_of[q] < 0 && S.top_task_of[parent(q)] == id && !(mid_strict && ssize(q) + 1 <= lowcap)) { t.piv.push_back(q); S.top_task_of[q] = id; }
         std::reverse(t.piv.begin(), t.piv.end());
         t.m = (int)t.piv.size(); t.parent = -1; t.level = 1; t.stack = -1;
         tasks.push_back(t);
@@ -261,11 +275,21 @@ void build_top(BlockSymbolic& S, int top_level, int soft_cap, int struct_min) {
     for (Task& t : tasks) {
         const int fprime = t.m + t.e + 1;                        // front rows / columns + the rhs column
         t.cls = fprime <= 32 ? 2 : (fprime <= 48 ? 3 : 4);       // blocks per thread and dimension on the 16 x 16 thread grid
-        if (t.e > 0) { t.stack = (int)stack; stack += (long long)t.e * (t.e + 1) * 4; }       // e x (e + 1) blocks: update matrix | update vector
+        t.lg = 0;
+        static const int nogroup = getenv("JG_MID_NOGROUP") ? atoi(getenv("JG_MID_NOGROUP")) : 0;   // experiments: 1 = every task one scenario per workgroup, 2 = no 16-scenario geometry
+        if (mid_mmin > 0 && fprime <= 32 && nogroup != 1 && !(nogroup == 3 && (t.root() & 1))) { t.lg = fprime <= 16 && nogroup != 2 ? 4 : 2; t.cls = 4; }   // grouped: 16 / 4 scenarios per workgroup, 4 x 4 blocks per thread
+
         for (int k : t.piv) { const long long s = ssize(k); S.top_terms += s * (s + 1); }
     }
+    // update blocks: e x (e + 1) blocks (update matrix | update vector) on the stack of the interleave class of the PARENT's workgroup
+    // (blocks of different interleaves cannot share one address space: a class is a stack of its own)
+    long long cstack[3] = {0, 0, 0};
+    for (Task& t : tasks)
+        if (t.e > 0) { long long& cs = cstack[t.parent >= 0 ? tasks[t.parent].lg >> 1 : 0]; t.stack = (int)cs; cs += (long long)t.e * (t.e + 1) * 4; }
+    stack = cstack[0] + cstack[1] + cstack[2];
     if (stack >= (1LL << 31)) { S.top_task_of.assign(n, -1); return; }
     S.top_stack = stack;
+    for (int c = 0; c < 3; ++c) S.top_stack_cls[c] = cstack[c];
     S.top_level = top_level;
     // launch order: level-major; ONE launch per level, compiled for the widest front of the level (a dependent launch costs more
     // than the registers a narrow front leaves unused in a wide kernel: the top levels hold a handful of tasks)
@@ -276,6 +300,8 @@ void build_top(BlockSymbolic& S, int top_level, int soft_cap, int struct_min) {
     const bool split = S.top_split != 0;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
         if (tasks[a].level != tasks[b].level) return tasks[a].level < tasks[b].level;
+        if ((tasks[a].lg > 0) != (tasks[b].lg > 0)) return tasks[a].lg > 0;             // the grouped tasks of a level: one launch, the longest first
+        if (tasks[a].lg > 0 && tasks[a].m != tasks[b].m) return tasks[a].m > tasks[b].m;
         if (split && tasks[a].cls != tasks[b].cls) return tasks[a].cls < tasks[b].cls;
         return tasks[a].root() < tasks[b].root();
     });
@@ -344,11 +370,19 @@ void build_top(BlockSymbolic& S, int top_level, int soft_cap, int struct_min) {
         S.top_data.insert(S.top_data.end(), t.piv.begin(), t.piv.end());
         h.w[0] = m; h.w[1] = e; h.w[2] = t.root(); h.w[3] = base; h.w[4] = t.stack; h.w[5] = (int)t.kids.size();
         h.w[6] = piv_off; h.w[7] = child_off; h.w[8] = dent_off; h.w[9] = t.cls; h.w[10] = t.level; h.w[11] = fprime;
+        h.w[12] = t.parent >= 0 ? tasks[t.parent].lg : 0; h.w[13] = t.lg;
         S.top_task[oi] = h;
-        if (S.top_launch.empty() || S.top_launch.back().level != t.level || (split && S.top_launch.back().cls != t.cls))
-            S.top_launch.push_back(TopLaunch{oi, 0, t.cls, t.level});
+        const int grouped = t.lg > 0 ? 1 : 0;
+        if (S.top_launch.empty() || S.top_launch.back().level != t.level || S.top_launch.back().grouped != grouped ||
+            (!grouped && split && S.top_launch.back().cls != t.cls))
+            S.top_launch.push_back(TopLaunch{oi, 0, t.cls, t.level, grouped, (int)S.top_wgmap.size(), 0, 0});
         S.top_launch.back().ntasks++;
         S.top_launch.back().cls = std::max(S.top_launch.back().cls, t.cls);
+        if (grouped) {
+            const int blocks = 64 >> t.lg;                       // workgroups of this task per 64-scenario group
+            for (int b = 0; b < blocks; ++b) S.top_wgmap.push_back(oi << 8 | b);
+            S.top_launch.back().nwg += blocks;
+        }
     }
     // top_task_of must name the header position
     std::vector<int> pos(nt);
@@ -573,8 +607,9 @@ void build_selected_inverse(BlockSymbolic& S) {
     }, NoExtra(), 0, FACT_WAVES);
 }
 
-int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic& S) {
+int analyze(int n, const int* rowptr, const int* col, long long policy64, BlockSymbolic& S) {
     S = BlockSymbolic();
+    const int policy = (int)(policy64 & 0x7fffffff);
     S.inplace = policy & 1;
     constexpr int TOP_LEVEL_MIN = 6, TOP_NARROW = 384, TOP_FRONT_SOFT = 24;
     S.symmetric = (policy >> 1) & 1;
@@ -756,13 +791,17 @@ int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic&
             top_level = nlev + 1;
             const int level_min = TOP_LEVEL_MIN - (S.prefactor ? 1 : 0);    // a prefactor plan numbers the same levels one lower: same pivots in the top
             while (top_level > level_min && cnt[top_level - 1] <= narrow && (chains == 0 || piv[top_level - 1] <= chains)) --top_level;
-            if (top_level > nlev - 2) top_level = 255;           // nothing worth a task
-        }
+            if (top_level > nlev - 2) top_level = NO_TOP_LEVEL;  // nothing worth a task
+        } else if (top_level >= 255) top_level = NO_TOP_LEVEL;   // policy / environment: no top by level
         if (soft <= 0) soft = TOP_FRONT_SOFT;
-        int struct_min = 0;
+        int struct_min = 0, mid_mmin = 0, mid_strict = (int)((policy64 >> 48) & 1);
         if (const char* e = getenv("JG_TOP_STRUCT")) struct_min = atoi(e);
+        if (const int mid = (int)((policy64 >> 32) & 0xff)) { struct_min = mid; mid_mmin = (int)((policy64 >> 40) & 0xff); if (!mid_mmin) mid_mmin = 6; }
+        if (const char* e = getenv("JG_MID_STRUCT")) { struct_min = atoi(e); mid_mmin = struct_min > 0 ? std::max(mid_mmin, 6) : 0; }
+        if (const char* e = getenv("JG_MID_MMIN")) { if (mid_mmin) mid_mmin = std::max(1, atoi(e)); }
+        if (const char* e = getenv("JG_MID_STRICT")) mid_strict = atoi(e);
         lap("fill pattern, terms, levels");
-        build_top(S, top_level, std::min(soft, TOP_FRONT_MAX), struct_min);
+        build_top(S, top_level, std::min(soft, TOP_FRONT_MAX), struct_min, mid_mmin, mid_strict);
         lap("top tasks");
     }
     build_tables(S);

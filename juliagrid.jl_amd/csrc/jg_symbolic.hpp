@@ -64,10 +64,21 @@ struct Rec { int w[16]; };
 //   header (one 64-byte record per task; level-major; a launch = one level, compiled for its widest front):
 //     w0 m, w1 e, w2 root pivot, w3 offset of the task's data in top_data, w4 stack offset of its update block (doubles, -1: root),
 //     w5 children, w6 offset of the pivot list, w7 offset of the child records, w8 offset of the diagonal entries (all relative
-//     to w3), w9 class (2, 3, 4: the front has at most 16 class rows and columns), w10 task level, w11 f + 1
+//     to w3), w9 class (2, 3, 4: the front has at most 16 class rows and columns), w10 task level, w11 f + 1,
+//     w12 log2 of the scenario interleave of the task's update block on the stack (= w13 of its parent), w13 log2 G of the task's own
+//     geometry (below)
 //   data: entry map [f][f + 1] (see build_top), diagonal entries [m], child records {stack offset, e_c, inv[f + 1]}, pivots [m]
+// GROUPED tasks (plans with a "mid" policy, large batches).  One workgroup per scenario is the right shape for the dense top (fronts of
+// 30-60 block rows), but a (task, scenario) workgroup costs ~10 us + ~1 us per pivot whatever its front, and its loads touch 16 bytes
+// of every 1 KiB line of the batch-minor storage.  Below the top the fronts are small (5-30 block rows) and there are many of them, so
+// a workgroup takes G = 4 or 16 CONSECUTIVE scenarios there: the 256 threads form G grids of T x T threads (T = 8 / 4: fronts of up
+// to 31 / 15 block rows at 4 x 4 blocks per thread), a load instruction covers G x 16 contiguous bytes, and a pivot step of the
+// workgroup advances G scenarios (k_fact_grp).  Tasks of all geometries exchange update blocks through the same stack; the block of
+// a task is interleaved over the G scenarios of its PARENT's workgroup ([scenario / G][stack][scenario % G] in 16-byte units), so the
+// extend-add of a grouped task is coalesced as well.  A launch of grouped tasks holds every G > 1 task of one task level: workgroup x
+// of a 64-scenario group finds its (task, scenario block) in top_wgmap.
 constexpr int TOP_FRONT_MAX = 63;       // m + e of a task: 64 columns with the rhs = class 4 on the 16 x 16 thread grid
-struct TopLaunch { int task_begin, ntasks, cls, level; };
+struct TopLaunch { int task_begin, ntasks, cls, level, grouped, wg_begin, nwg, pad; };   // grouped: wgmap[wg_begin .. wg_begin + nwg) = task << 8 | scenario block
 
 struct BlockSymbolic {
     int n = 0;
@@ -125,7 +136,9 @@ struct BlockSymbolic {
     std::vector<Rec> top_task;          // task headers, launch order
     std::vector<int> top_data;
     std::vector<TopLaunch> top_launch;
-    long long top_stack = 0;            // doubles per scenario on the update stack
+    std::vector<int> top_wgmap;         // grouped launches: workgroup -> (task, scenario block of its 64-scenario group)
+    long long top_stack = 0;            // doubles per scenario on the update stacks
+    long long top_stack_cls[3] = {0, 0, 0};   // ... of the blocks interleaved over 1 / 4 / 16 scenarios (a task's w4 is an offset inside its class)
     long long top_terms = 0;            // update terms executed inside tasks
 };
 
@@ -136,8 +149,12 @@ struct BlockSymbolic {
 // policy bits 8-15: dependency level from which pivots go to top tasks (0 = default: where the level schedule gets narrow,
 // 255 = no top tasks); bits 16-23: soft cap of a task's front (0 = default); bits 24-30: what "narrow" means, in units of 8
 // items per level (0 = default); bits 4-7: at most this many pivots per level in the top (0 = any).
+// policy bits 32-39 ("mid", 0 = off): pivots with at least this many neighbours at elimination -- and their ancestors -- go to tasks
+// wherever they sit in the tree, and tasks get a geometry by the size of their front (GROUPED tasks, above); bits 40-47: a task's
+// geometry is chosen so that it can take at least this many pivots (0 = default 6); bit 48: a task only absorbs pivots that need
+// its geometry (smaller fronts form tasks of their own below it).
 // Returns 0, or 1 on a malformed pattern.
-int analyze(int n, const int* rowptr, const int* col, int policy, BlockSymbolic& out);
+int analyze(int n, const int* rowptr, const int* col, long long policy, BlockSymbolic& out);
 // Replay tables of the selected inverse of a SYMMETRIC matrix on the factor pattern (see jg_symbolic.cpp); idempotent.
 void build_selected_inverse(BlockSymbolic& S);
 // entry id of block (r, c) in pivot numbering, -1 if outside the factor pattern

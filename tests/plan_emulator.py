@@ -186,26 +186,40 @@ class Replay:
         if hdr.shape[0] == 0:
             assert not partial.any()
             return 0
-        stack = np.full(int(self.tinfo[1]), np.nan)
+        stacks = [np.full(int(self.tinfo[3 + c]), np.nan) for c in range(3)]     # one stack per interleave class (1 / 4 / 16 scenarios)
+        assert int(self.tinfo[1]) == sum(int(self.tinfo[3 + c]) for c in range(3))
         stack_level = {}
         seen_tasks = 0
         terms = 0
         done_pivot = np.zeros(self.n, dtype=bool)
         prev = 0
         u_col = self.p.get("u_col")
-        for li, (tb, ntk, cls, tlevel) in enumerate(launches):
+        wgmap = self.p.get(78)
+        geom_of_stack = {}                                    # stack offset of a task's update block -> log2 of its scenario interleave
+        for li, (tb, ntk, cls, tlevel, grouped, wgb, nwg, _pad) in enumerate(launches):
             assert tlevel >= prev and tb == seen_tasks and cls in (2, 3, 4), "launches out of order"   # (policy bit 3: a level may take one launch per class)
             prev = tlevel
             lev = bottom_levels + tlevel
             results = []
+            if grouped:                                      # every (task, scenario block) of the launch exactly once in its workgroup map
+                want = sorted((ti << 8) | b for ti in range(tb, tb + ntk) for b in range(64 >> int(hdr[ti][13])))
+                assert sorted(int(v) for v in wgmap[wgb: wgb + nwg]) == want, "workgroup map of a grouped launch"
+            else:
+                assert nwg == 0
             for ti in range(tb, tb + ntk):
-                m, e, root, base, soff, nchild, piv_off, child_off, dent_off, tcls, tl, fprime = (int(v) for v in hdr[ti][:12])
+                m, e, root, base, soff, nchild, piv_off, child_off, dent_off, tcls, tl, fprime, lgo, lg = (int(v) for v in hdr[ti][:14])
                 f = m + e
+                assert (lg > 0) == bool(grouped) and lg in (0, 2, 4) and lgo in (0, 2, 4)
+                if soff >= 0:
+                    assert (lgo, soff) not in geom_of_stack
+                    geom_of_stack[(lgo, soff)] = lgo
                 tp = data[base + piv_off: base + piv_off + m].astype(np.int64)          # the task's pivots, ascending, the root last
                 assert np.all(np.diff(tp) > 0) and tp[-1] == root
                 par = [int(u_col[self.u_ptr[k]]) if self.u_ptr[k + 1] > self.u_ptr[k] else -1 for k in tp]
                 assert all(pk in set(tp.tolist()) for pk in par[:-1]), "a task is a connected piece of the elimination tree"
-                assert tl == tlevel and tcls <= cls and fprime == f + 1 <= 16 * tcls and (tcls == 2 or fprime > 16 * (tcls - 1)) and m >= 1
+                tgrid = 16 >> (lg // 2)                       # threads per front dimension: 16 / 8 / 4 at 1 / 4 / 16 scenarios per workgroup
+                assert tl == tlevel and tcls <= cls and fprime == f + 1 <= tgrid * tcls and m >= 1
+                assert (tcls == 4 and (lg == 2 or fprime <= 16)) if lg else (tcls == 2 or fprime > 16 * (tcls - 1))
                 assert np.all(self.task_of[tp] == ti) and np.sum(self.task_of == ti) == m
                 ext = self._front_ext(root)
                 assert ext.size == e
@@ -254,8 +268,9 @@ class Replay:
                 for _ in range(nchild):
                     coff, ce = int(data[cd]), int(data[cd + 1])
                     inv = data[cd + 2: cd + 2 + fprime]
-                    assert stack_level[coff] < tlevel, "child task in the same or a later launch level"
-                    C = stack[coff: coff + ce * (ce + 1) * 4].reshape(ce, ce + 1, 2, 2)
+                    assert stack_level[(lg, coff)] < tlevel, "child task in the same or a later launch level"     # KeyError: the child left its
+                    C = stacks[lg >> 1][coff: coff + ce * (ce + 1) * 4].reshape(ce, ce + 1, 2, 2)                # block in another interleave
+                    assert not np.isnan(C).any(), "update blocks of one interleave class overlap"
                     assert inv[f] == ce and sorted(inv[:f][inv[:f] >= 0].tolist()) == list(range(ce))
                     for r in np.flatnonzero(inv[:f] >= 0):
                         for c in np.flatnonzero(inv >= 0):
@@ -282,8 +297,8 @@ class Replay:
                     if q + 1 < m:
                         D[q + 1] = dfactor(F[q + 1, q + 1])
                 assert not np.isnan(F).any()
-                results.append((ti, owned, F, D, tp, m, e, soff, dent))
-            for ti, owned, F, D, tp, m, e, soff, dent in results:             # tasks of one launch are independent of each other
+                results.append((ti, owned, F, D, tp, m, e, soff, dent, lgo))
+            for ti, owned, F, D, tp, m, e, soff, dent, lgo in results:             # tasks of one launch are independent of each other
                 f = m + e
                 for ent, r, c in owned:
                     X[ent] = F[r, c]
@@ -299,8 +314,9 @@ class Replay:
                     done_pivot[tp[q]] = True
                 if e > 0:
                     assert soff >= 0
-                    stack[soff: soff + e * (e + 1) * 4] = F[m:, m:].reshape(-1)
-                    stack_level[soff] = tlevel
+                    assert np.isnan(stacks[lgo >> 1][soff: soff + e * (e + 1) * 4]).all(), "update blocks of one interleave class overlap"
+                    stacks[lgo >> 1][soff: soff + e * (e + 1) * 4] = F[m:, m:].reshape(-1)
+                    stack_level[(lgo, soff)] = tlevel
                 else:
                     assert soff == -1
             seen_tasks += ntk

@@ -290,6 +290,33 @@ def test_top_tasks_on_small_and_random_graphs(jg, monkeypatch, symmetric, top_le
 
 
 @pytest.mark.parametrize("symmetric", [False, True])
+@pytest.mark.parametrize("mid,mmin,strict,top_level,soft", [(1, 1, 0, 2, 47), (2, 3, 0, 3, 47), (3, 6, 1, 6, 40), (2, 6, 0, 255, 63), (1, 2, 1, 1, 24)])
+def test_grouped_tasks_on_small_and_random_graphs(jg, symmetric, mid, mmin, strict, top_level, soft):
+    """Plans with a "mid" policy (jg_symbolic.hpp): pivots with `mid` neighbours at elimination and their ancestors go to tasks, a
+    task's front is capped by its geometry (15 / 31 rows at 16 / 4 scenarios per workgroup, else one scenario per workgroup), update
+    blocks are interleaved for the parent's workgroup, and the grouped tasks of a level form one launch with a workgroup map.  The
+    replay checks every map and solves a system through the tables."""
+    rng = np.random.default_rng(7 * mid + mmin)
+    cases = [(2, [(0, 1)]), (12, [(i, i + 1) for i in range(11)]), (9, [(0, i) for i in range(1, 9)]),
+             (24, [(i, j) for i in range(24) for j in range(i + 1, 24)]),                 # dense: a chain of 24 pivots, fronts beyond 16
+             (40, [(i, j) for i in range(40) for j in range(i + 1, 40)]),                 # ... and beyond 32: all three geometries in one chain
+             (60, [(i, j) for i in range(60) for j in range(i + 1, min(i + 6, 60))])]
+    for _ in range(6):
+        n = int(rng.integers(30, 120))
+        m = int(rng.integers(n, 4 * n))
+        cases.append((n, [tuple(sorted(rng.choice(n, 2, replace=False))) for _ in range(m)]))
+    geoms = set()
+    for ci, (n, edges) in enumerate(cases):
+        policy = top_level << 8 | soft << 16 | (8 if ci % 2 else 0) | mid << 32 | mmin << 40 | strict << 48
+        plan = _solve_with_plan(jg, n, edges, rng, symmetric, top=policy, prefactor=None if symmetric else ci % 2 == 0)
+        hdr, _, launches = plan.top_tables()[:3]
+        geoms |= set(int(v) for v in hdr[:, 13])
+        for tb, ntk, cls, lvl, grouped, wgb, nwg, _ in launches:
+            assert all((int(hdr[t, 13]) > 0) == bool(grouped) for t in range(tb, tb + ntk))
+    assert geoms >= {0, 2, 4}
+
+
+@pytest.mark.parametrize("symmetric", [False, True])
 def test_ordering_and_tables_on_degenerate_graphs(jg, symmetric):
     """One bus, isolated buses, islands, a path, a star, a complete graph, a ladder, random sparse graphs: the greedy
     minimum-fill / height ordering and every replay table must stay valid (checked by replaying a solve)."""

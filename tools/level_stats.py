@@ -35,6 +35,6 @@ for lv in np.unique(seg[:, 4]):
     print(f"{lv:5d} {len(sg):5d} {items:6d} {wgs:8d} {terms:8d} {mx:6d}   {kinds.tolist()}")
 print("scheduled terms in levels:", tot)
 tasks, data, launches = plan.top_tables()[:3]
-print("top launches (task_begin, ntasks, cls, level):", launches.tolist() if hasattr(launches, "tolist") else launches)
+print("top launches (task_begin, ntasks, cls, level, grouped, wg_begin, nwg, -):", launches.tolist() if hasattr(launches, "tolist") else launches)
 for t in tasks:
-    print("  task m=%d e=%d root=%d cls=%d level=%d" % (t[0], t[1], t[2], t[9], t[10]))
+    print("  task m=%d e=%d root=%d cls=%d level=%d G=%d" % (t[0], t[1], t[2], t[9], t[10], 1 << t[13]))
