@@ -805,6 +805,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     const size_t b = (size_t)min(bb0 + g, a.lanes - 1), ld = (size_t)a.ld;
     const int* td = a.data + h[3];
     int bad = 0;
+    const bool prof = a.prof && tid == 0;                        // JG_TOP_PROFILE: phase stamps of the workgroup's first scenario
+    long long* pt = a.prof + ((size_t)ti * a.ld + bb0) * 8;
+    if (prof) pt[0] = wall_clock64();
     Blk T[CLS][CLS];
     // ---- load: entry map, then every gather of the thread in flight together
     {
@@ -830,6 +833,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 T[r][c] = v;
             }
     }
+    if (prof) pt[1] = wall_clock64();
     // ---- extend-add: the children's update blocks, interleaved over the scenarios of THIS workgroup (child order fixed => deterministic)
     {
         const int* cd = td + h[7];
@@ -854,6 +858,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             cd += 2 + fprime;
         }
     }
+    if (prof) pt[2] = wall_clock64();
     // ---- publish step 0 (zeros where the step must not touch: row: columns <= q, column: rows <= q)
 #pragma unroll
     for (int r = 0; r < CLS; ++r)
@@ -932,6 +937,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         }
         __syncthreads();
     }
+    if (prof) pt[3] = wall_clock64();
     // ---- store
     if (!live) return;
     double2* out = e > 0 ? stack_unit(a, b, h[4], lgo) : nullptr;
@@ -950,6 +956,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             }
         }
     if (bad) atomicOr(a.status + b, 4);
+    if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pt[4] = wall_clock64(); pt[5] = 0; }
 }
 
 // per-level launch table: segment ranges and chunk totals
