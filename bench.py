@@ -285,6 +285,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N`: run it the way the driver runs it -- one rank per GPU under torch.distributed.run on
+        # this node -- and hand its output and exit code through (rank 0 prints the one JSON line)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
@@ -383,10 +394,21 @@ def main():
     ring = len(pipe.handles) + (12 if pipe.pools else 0)
     packed = [torch.empty((lanes, 2 * n + 2), dtype=torch.float64, device="cuda") for _ in range(ring)]
 
+    # JG_BENCH_GATHER=abi: the collective through the library's own C ABI (jg_comm_*: ncclAllGather of librccl, csrc/jg_comm.cpp) instead of
+    # torch.distributed -- what a Julia host calls; rank 0 draws the communicator id, torch only ships its 128 bytes
+    comm = gathered = None
+    if (world > 1 or force_dist) and os.environ.get("JG_BENCH_GATHER") == "abi" and cdev == "cuda":
+        uid = torch.from_numpy(jg._lib.Comm.unique_id() if rank == 0 else np.zeros(jg._lib.COMM_ID_BYTES, dtype=np.uint8)).cuda()
+        dist.broadcast(uid, src=0)
+        comm = jg._lib.Comm(rank, world, uid.cpu().numpy(), device=local)
+        gathered = torch.empty((world * lanes, 2 * n + 2), dtype=torch.float64, device="cuda")
+
     def deliver(job, h):                              # caller's thread, job order: the record is complete -> the ONE collective
         if world > 1 or force_dist:
             buf = packed[job % ring]
-            if cdev == "cuda":
+            if comm is not None:
+                comm.allgather_device(buf.data_ptr(), gathered.data_ptr(), buf.numel())
+            elif cdev == "cuda":
                 jg.gatherResults(dist, buf)
                 torch.cuda.current_stream().synchronize()
             else:
@@ -479,6 +501,7 @@ def main():
                        "device_batches_in_flight_per_gpu": len(pipe.handles),
                        "straggler_pool_lanes": pipe.pools[0].handle.batch if pipe.pools else 0,
                        "steps_in_flight_per_gpu": len(pipe.handles) * merge,
+                       "gather": "abi" if comm is not None else "torch.distributed",
                        "parallelism": f"scenario-sharded x{world}, one RCCL all-gather of the packed results per device batch "
                                       f"({merge} step(s) of {B} scenarios per GPU)",
                        "scenario_selection": f"the first {total} solvable contingencies of a seeded shuffle of the non-bridge branches; "

@@ -267,6 +267,30 @@ int jg_gn_get_normalized_residual(jg_gn* h, double* nres);
 int jg_gn_time_kernel(jg_gn* h, int kernel, int reps, double* mean_ms);
 
 /* ---------------------------------------------------------------------------------------------
+ * Sharded contingency screen: the final gather.  Scenarios are independent, a rank (one process per GPU) solves a
+ * contiguous block of them, and ONE collective -- ncclAllGather of RCCL over xGMI -- hands every rank the result record of the whole
+ * screen in scenario order.  The reference has no counterpart: its user-level loop runs the scenarios one after the other in one
+ * process (src/powerSystem/branch.jl:453-459: updateBranch!(...; status = 0), powerFlow!, updateBranch!(...; status = 1)).
+ *   jg_comm_unique_id  rank 0 draws the 128-byte id of a communicator; the HOST ships it to the other ranks (MPI, a file, a socket)
+ *   jg_comm_create     collective over the `world` ranks: rank's communicator on HIP device `device`
+ *   jg_nr_allgather_results  packs the handle's record ([batch][2 n + 2]: V | theta | iterations | status, jg_nr_pack_results_device)
+ *                      into block `rank` of dst_dev [world x batch][2 n + 2] (device memory of the caller) and gathers in place on
+ *                      the handle's stream; every rank must call it with the same batch.  Returns after the stream has drained.
+ *   jg_comm_allgather_device  the same collective for a record that is already packed (a ContingencyPipeline fills its records
+ *                      itself): count doubles per rank, recv_dev [world][count]; send_dev may be recv_dev + rank * count.
+ * librccl is bound at run time on the first call (csrc/jg_comm.cpp); return code 2 with jg_last_error() when it is missing.
+ * ------------------------------------------------------------------------------------------- */
+#define JG_COMM_ID_BYTES 128
+typedef struct jg_comm jg_comm;
+int jg_comm_unique_id(uint8_t* id);
+int jg_comm_create(jg_comm** c, int64_t rank, int64_t world, const uint8_t* id, int device);
+void jg_comm_destroy(jg_comm* c);
+int jg_comm_rank(const jg_comm* c);
+int jg_comm_world(const jg_comm* c);
+int jg_comm_allgather_device(jg_comm* c, const double* send_dev, double* recv_dev, int64_t count);
+int jg_nr_allgather_results(jg_nr* h, jg_comm* c, double* dst_dev);
+
+/* ---------------------------------------------------------------------------------------------
  * Symbolic analysis only (no device needed): the static schedule that replaces the symbolic half
  * of `lu`/`klu` (src/backend/utility.jl:470-476, 486-492).  Used by the CPU test-suite to replay
  * and race-check the schedule.  pattern: 0-based int32 block CSR, structurally symmetric, full

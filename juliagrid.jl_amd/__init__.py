@@ -9,7 +9,7 @@ from .system import (updateBranch_ as updateBranchSystem_, updateBus_ as updateB
                      updateGenerator_ as updateGeneratorSystem_)
 from .powerflow import (AcPowerFlow, newtonRaphson, fastNewtonRaphsonBX, fastNewtonRaphsonXB, mismatch_, solve_, powerFlow_, setInitialPoint_, setRefinement_,   # noqa: F401
                         updateBranch_, updateBus_, updateGenerator_, addBranch_, dropZeros_, setOutage_, setOutages_, setInjection_, outagePatch, initializeACPowerFlow, power_, current_, reactiveLimit_, adjustAngle_)
-from .contingency import bridges, outageList, shard, deviceBatching, contingencyAnalysis, gatherResults, unpackResults, ContingencyPipeline   # noqa: F401
+from .contingency import bridges, outageList, shard, deviceBatching, contingencyAnalysis, gatherResults, gatherResultsDevice, unpackResults, ContingencyPipeline   # noqa: F401
 from .measurement import (Measurement, measurement, ems, addVoltmeter_, addAmmeter_, addWattmeter_, addVarmeter_,   # noqa: F401
                           addPmu_, exactQuantities)
 from .stateestimation import (WlsMethod, Normal, LU, KLU, QR, LDLt, LL, Orthogonal, PetersWilkinson,   # noqa: F401
@@ -26,7 +26,7 @@ __all__ = [
     "Measurement", "measurement", "ems", "addVoltmeter_", "addAmmeter_", "addWattmeter_", "addVarmeter_", "addPmu_",
     "exactQuantities", "AcStateEstimation", "PmuStateEstimation", "pmuStateEstimation", "gaussNewton", "incrementSE_", "solveSE_", "stateEstimation_", "setNoise_", "residualTest_", "normalizedResidual", "chiTest",
     "updateVoltmeter_", "updateAmmeter_", "updateWattmeter_", "updateVarmeter_", "updatePmu_",
-    "outagePatch", "initializeACPowerFlow", "bridges", "outageList", "shard", "deviceBatching", "contingencyAnalysis", "gatherResults", "unpackResults",
+    "outagePatch", "initializeACPowerFlow", "bridges", "outageList", "shard", "deviceBatching", "contingencyAnalysis", "gatherResults", "gatherResultsDevice", "unpackResults",
     "WlsMethod", "Normal", "LU", "KLU", "QR", "LDLt", "LL", "Orthogonal", "PetersWilkinson",
     "addBranch_", "dropZeros_", "addBranchSystem_", "dropZerosSystem_", "pegaseShaped", "case9241synth", "ContingencyPipeline", "setOutages_", "power_", "current_", "reactiveLimit_", "adjustAngle_",
 ]

@@ -15,6 +15,7 @@ I64P = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
 I32P = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 I8P = np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")
 F64P = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+U8P = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 VP = C.c_void_p
 
 _lib = None
@@ -99,6 +100,12 @@ def lib():
         "jg_gn_get_iteration": [VP, I32P],
         "jg_gn_time_kernel": [VP, C.c_int, C.c_int, C.POINTER(C.c_double)],
         "jg_plan_create": [C.POINTER(VP), C.c_int64, I32P, I32P, C.c_int64],
+        "jg_comm_unique_id": [U8P],
+        "jg_comm_create": [C.POINTER(VP), C.c_int64, C.c_int64, U8P, C.c_int],
+        "jg_comm_rank": [VP],
+        "jg_comm_world": [VP],
+        "jg_comm_allgather_device": [VP, VP, VP, C.c_int64],
+        "jg_nr_allgather_results": [VP, VP, VP],
     }
     for name, args in sig.items():
         f = getattr(L, name)
@@ -108,6 +115,8 @@ def lib():
     L.jg_nr_destroy.restype = None
     L.jg_gn_destroy.argtypes = [VP]
     L.jg_gn_destroy.restype = None
+    L.jg_comm_destroy.argtypes = [VP]
+    L.jg_comm_destroy.restype = None
     L.jg_plan_destroy.argtypes = [VP]
     L.jg_plan_destroy.restype = None
     L.jg_plan_export.argtypes = [VP, C.c_int, VP, C.c_int64]
@@ -164,3 +173,33 @@ class Plan:
         level, grouped, wg_begin, nwg, -; task of each pivot; (top_level, stack doubles per scenario, terms inside tasks).
         Workgroup map of the grouped launches: get(78)."""
         return self.get(70).reshape(-1, 16), self.get(71), self.get(72).reshape(-1, 8), self.get(73), self.get(74)
+
+
+COMM_ID_BYTES = 128
+
+
+class Comm:
+    """RCCL communicator of a sharded screen behind the C ABI (include/jgrid.h: jg_comm_*).  Rank 0 draws `Comm.unique_id()`, the host
+    ships the 128 bytes to every rank (any channel), every rank calls Comm(rank, world, id, device) -- a collective."""
+
+    @staticmethod
+    def unique_id():
+        out = np.zeros(COMM_ID_BYTES, dtype=np.uint8)
+        check(lib().jg_comm_unique_id(out))
+        return out
+
+    def __init__(self, rank, world, uid, device=0):
+        self.h = VP()
+        check(lib().jg_comm_create(C.byref(self.h), int(rank), int(world), np.ascontiguousarray(uid, dtype=np.uint8), int(device)))
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+
+    def allgather_device(self, send_ptr, recv_ptr, count):
+        """count doubles per rank from device pointer send_ptr into recv_ptr [world][count] (send may alias its own block of recv)."""
+        check(lib().jg_comm_allgather_device(self.h, VP(int(send_ptr)), VP(int(recv_ptr)), int(count)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().jg_comm_destroy(self.h)
+            self.h = None
+
+    __del__ = close

@@ -5,7 +5,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["jg_symbolic.cpp", "jg_plan_api.cpp", "jg_engine.hip", "jg_nr.hip", "jg_gn.hip"]
+SOURCES = ["jg_symbolic.cpp", "jg_plan_api.cpp", "jg_comm.cpp", "jg_engine.hip", "jg_nr.hip", "jg_gn.hip"]
 LIB = os.path.join(HERE, "libjgrid_hip.so")
 
 
@@ -29,7 +29,7 @@ def build(force=False, verbose=False):
         return LIB
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-value", "-Wno-unused-result", "-Wno-pass-failed"] + os.environ.get("JG_EXTRA_HIPCC_FLAGS", "").split() + ["-o", LIB + ".tmp"] + srcs
+           "-Wno-unused-value", "-Wno-unused-result", "-Wno-pass-failed"] + os.environ.get("JG_EXTRA_HIPCC_FLAGS", "").split() + ["-o", LIB + ".tmp"] + srcs + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

@@ -328,6 +328,14 @@ def gatherResults(dist, packed):
     return unpackResults(g)
 
 
+def gatherResultsDevice(an: AcPowerFlow, comm, out_ptr: int):
+    """The same gather through the C ABI alone (jg_nr_allgather_results: pack + ncclAllGather of RCCL on the handle's stream): `comm` is a
+    juliagrid.jl_amd._lib.Comm, `out_ptr` a device pointer to [world x batch][2 n + 2] doubles owned by the caller.  Every rank calls
+    it with the same batch; on return the record of the whole screen is in scenario order on every rank."""
+    from . import _lib
+    _lib.check(_lib.lib().jg_nr_allgather_results(an._h, comm.h, _lib.VP(int(out_ptr))))
+
+
 def unpackResults(g):
     """(iterations, status, magnitude, angle) of a [scenarios, 2 n + 2] result block."""
     n = (g.shape[1] - 2) // 2

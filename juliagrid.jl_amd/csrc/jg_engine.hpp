@@ -23,6 +23,12 @@
 namespace jg {
 
 void set_last_error(const std::string& msg);   // thread-local text behind jg_last_error()
+}
+struct jg_comm;
+namespace jg {
+int comm_allgather(jg_comm* c, const double* send, double* recv, size_t count, hipStream_t st);   // jg_comm.cpp: ncclAllGather on st, not synchronised
+int comm_rank(const jg_comm* c);
+int comm_device(const jg_comm* c);
 std::mutex& capture_mutex();                   // one graph capture at a time per process (host threads must not interleave captures)
 
 // one per-level launch: grid.y walks the level's segments (at most one per wpi class 1, 2, 4, 8, 16)

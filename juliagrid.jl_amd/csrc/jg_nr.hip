@@ -1062,6 +1062,22 @@ int jg_nr_pack_results_device(jg_nr* h, double* dst_dev) {
     return 0;
 }
 
+int jg_nr_allgather_results(jg_nr* h, jg_comm* c, double* dst_dev) {
+    if (!h || !c || !dst_dev) return fail(1, "jg_nr_allgather_results: bad argument");
+    if (jg::comm_device(c) != h->device) return fail(1, "jg_nr_allgather_results: communicator and handle live on different devices");
+    if (int rc = set_device(h)) return rc;
+    const long long stride = 2LL * h->n + 2;
+    const size_t count = (size_t)h->batch * stride;
+    double* mine = dst_dev + (size_t)jg::comm_rank(c) * count;   // in-place all-gather: this rank's record sits in its own block
+    dim3 grid((h->n + 63) / 64, (h->ld + 63) / 64, 2), block(64, 8);
+    hipLaunchKernelGGL(k_pack_bus, grid, block, 0, h->stream, h->d_vm, h->d_va, mine, h->n, h->ld, h->batch, stride);
+    hipLaunchKernelGGL(k_pack_tail, dim3((h->batch + 255) / 256), dim3(256), 0, h->stream, h->d_iters, h->d_status, mine, h->batch, stride, 2 * h->n);
+    NR_HIP(hipGetLastError());
+    if (int rc = jg::comm_allgather(c, mine, dst_dev, count, h->stream)) return rc;
+    NR_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 int jg_nr_patch_ybus(jg_nr* h, int64_t scenario, int64_t k, const int64_t* ptr, const double* dy) {
     if (!h || scenario < 0 || scenario >= h->batch || k < 0 || k > h->mp || (k > 0 && (!ptr || !dy)))
         return fail(1, "jg_nr_patch_ybus: bad argument (scenario / entry count beyond max_patch)");

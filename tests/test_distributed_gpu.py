@@ -1,0 +1,67 @@
+"""The N > 1 machinery on the 1-GPU box: the RCCL gather behind the C ABI (a 1-rank communicator: init, pack, ncclAllGather, record
+bit-equal to the packed one), and bench.py started the way the driver starts it -- plain `python bench.py --gpus N` -- with two ranks
+sharing the GPU over gloo (control flow, sharding, strong-scaling accounting) and with a 1-rank RCCL group (device records through
+all_gather_into_tensor)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+def test_allgather_through_the_c_abi_equals_the_packed_record(jg):
+    import torch
+    s = jg.powerSystem(load_case("case118"))
+    an = jg.contingencyAnalysis(s, jg.outageList(s, 70, seed=3))
+    jg.powerFlow_(an, iteration=20, tolerance=1e-8)
+    n = s.bus.number
+    packed = torch.zeros((70, 2 * n + 2), dtype=torch.float64, device="cuda")
+    jg._lib.check(jg._lib.lib().jg_nr_pack_results_device(an._h, jg._lib.VP(packed.data_ptr())))
+    comm = jg._lib.Comm(0, 1, jg._lib.Comm.unique_id(), device=0)
+    assert jg._lib.lib().jg_comm_rank(comm.h) == 0 and jg._lib.lib().jg_comm_world(comm.h) == 1
+    out = torch.full((70, 2 * n + 2), np.nan, dtype=torch.float64, device="cuda")
+    jg.gatherResultsDevice(an, comm, out.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(out, packed)
+    it, st, vm, va = jg.unpackResults(out)
+    assert np.array_equal(it.cpu().numpy(), np.asarray(an.method.iteration)) and np.array_equal(st.cpu().numpy(), np.asarray(an.status))
+    assert np.array_equal(vm.cpu().numpy(), np.asarray(an.voltage.magnitude))
+    # a record that is already packed (what a ContingencyPipeline delivers), out of place
+    out2 = torch.empty_like(out)
+    comm.allgather_device(packed.data_ptr(), out2.data_ptr(), packed.numel())
+    assert torch.equal(out2, packed)
+    comm.close()
+    an.close()
+
+
+def _bench(args, **env):
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None); e.pop("RANK", None); e.pop("LOCAL_RANK", None)
+    e.update({k: str(v) for k, v in env.items()})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints ONE JSON line"
+    return json.loads(lines[0])
+
+
+def test_bench_starts_by_itself_with_two_ranks():
+    """`python bench.py --gpus 2` without a launcher: it re-executes itself under torch.distributed.run; two ranks share the one GPU
+    over gloo (JG_BENCH_BACKEND: the measured configuration is RCCL), 512 scenarios per step sharded 256 + 256."""
+    d = _bench(["--gpus", "2", "--steps", "4", "--warmup", "1", "--no-cpu", "--no-se"], JG_BENCH_BACKEND="gloo")
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 4
+    assert d["config"]["scenarios_per_step"] == 512 and d["config"]["batch_per_gpu"] == 256
+    assert d["value"] > 0 and d["converged_fraction"] == 1.0
+
+
+def test_bench_with_a_one_rank_rccl_group():
+    d = _bench(["--steps", "4", "--warmup", "1", "--no-cpu", "--no-se"], JG_BENCH_FORCE_DIST="1")
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["converged_fraction"] == 1.0
+    d2 = _bench(["--steps", "4", "--warmup", "1", "--no-cpu", "--no-se"], JG_BENCH_FORCE_DIST="1", JG_BENCH_GATHER="abi")
+    assert d2["config"].get("gather") == "abi" and d2["converged_fraction"] == 1.0

@@ -48,3 +48,46 @@ def test_top_kernel_variants_and_level0_routes_give_the_same_bits(case, batch):
     assert _run(case, batch, JG_TOP_PW=0)[0] == ref                  # every top launch without
     assert _run(case, batch, JG_NO_PREFACTOR=1)[0] == ref            # plain plan: the level kernel factorises the leaf blocks
     assert _run(case, batch, JG_ITEM_ORDER=0)[0] == ref              # items of a level dealt heaviest first
+
+
+SCRIPT_STATE = r"""
+import sys
+import numpy as np
+sys.path.insert(0, {root!r})
+sys.path.insert(0, {root!r} + "/tests")
+from conftest import load_case
+import juliagrid.jl_amd as jg
+s = jg.powerSystem(load_case({case!r}))
+an = jg.contingencyAnalysis(s, jg.outageList(s, {batch}, seed=11))
+jg.powerFlow_(an, iteration=20, tolerance=1e-8)
+np.savez({out!r}, it=np.asarray(an.method.iteration), st=np.asarray(an.status), vm=np.asarray(an.voltage.magnitude), va=np.asarray(an.voltage.angle))
+an.close()
+"""
+
+
+@pytest.mark.parametrize("case,batch,env", [
+    ("case118", 70, dict(JG_TOP_LEVEL=1, JG_MID_STRUCT=1, JG_MID_MMIN=1)),                       # every pivot in a grouped task
+    ("case118", 70, dict(JG_TOP_LEVEL=1, JG_MID_STRUCT=1, JG_MID_MMIN=1, JG_MID_NOGROUP=3)),     # ... mixed with one-scenario tasks (all three update stacks)
+    ("case1354pegase", 300, dict(JG_MID_STRUCT=3, JG_MID_MMIN=4)),
+    ("case_ACTIVSg10k", 130, dict(JG_MID_STRUCT=8, JG_MID_MMIN=4)),
+    ("case_ACTIVSg10k", 512, dict(JG_MID_STRUCT=13, JG_MID_MMIN=4, JG_MID_STRICT=1)),
+])
+def test_grouped_tasks_match_the_default_plan(tmp_path, case, batch, env):
+    """Plans with grouped tasks below the top (k_fact_grp: 4 or 16 scenarios per workgroup, jg_symbolic.hpp "mid" policy; opt-in) against
+    the default plan: equal iteration counts and status, V / theta to 1e-9 (another summation order, not another algorithm)."""
+    outs = []
+    for i, e in enumerate((dict(), env)):
+        out = str(tmp_path / f"r{i}.npz")
+        ee = dict(os.environ)
+        ee.update({k: str(v) for k, v in e.items()})
+        r = subprocess.run([sys.executable, "-c", SCRIPT_STATE.format(root=ROOT, case=case, batch=batch, out=out)], env=ee, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        import numpy as np
+        with np.load(out) as z:
+            outs.append({k: z[k] for k in z.files})
+    a, b = outs
+    import numpy as np
+    assert np.array_equal(a["it"], b["it"]) and np.array_equal(a["st"], b["st"])
+    ok = a["st"] == 0
+    assert ok.sum() >= 0.9 * batch
+    assert np.abs(a["vm"] - b["vm"])[ok].max() < 1e-9 and np.abs(a["va"] - b["va"])[ok].max() < 1e-9
