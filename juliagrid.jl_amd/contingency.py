@@ -136,6 +136,10 @@ class ContingencyPipeline:
         self.pools = []
         if pool and self.batch > 64 and self.defer_at > 0:
             lanes = max(2 * self.defer_at, -(-int(pool) // 64) * 64)
+            # the engine picks its plan (where the multifrontal top starts, front caps: another summation order) by the side of 256 lanes
+            # a handle is on (Engine::create): the pool must sit on the same side as the batches it serves, or a straggler that finishes
+            # there would no longer be bitwise the scenario of a lockstep batch
+            lanes = max(lanes, 256) if -(-self.batch // 64) * 64 >= 256 else min(lanes, 192)
             self.pools = [_Pool(newtonRaphson(system, batch=lanes, device=device, max_patch=4)) for _ in range(2)]
         if start is not None:
             self.setStart(*start)

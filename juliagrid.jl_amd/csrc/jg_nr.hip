@@ -1162,6 +1162,7 @@ int jg_nr_solve(jg_nr* h) {
     if (h->fast) return fail(1, "jg_nr_solve: this handle runs fast Newton-Raphson; use jg_nr_fast_solve");
     if (int rc = set_device(h)) return rc;
     if (!h->jac_valid) launch_assemble(h);
+    h->f_stale = false;                                          // method.mismatch = the mismatch this step started from, for every scenario
     NR_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
     if (int rc = newton_step(h, jg::GroupSel{}, nullptr)) return fail(rc, h->eng.error);
     hipLaunchKernelGGL(k_add_iter, dim3((h->ld + 255) / 256), dim3(256), 0, h->stream, h->d_iters, h->ld);
@@ -1672,7 +1673,8 @@ int jg_nr_time_kernel(jg_nr* h, int kernel, int reps, double* mean_ms) {
     float ms = 0.f;
     NR_HIP(hipEventElapsedTime(&ms, e0, e1));
     hipEventDestroy(e0); hipEventDestroy(e1);
-    if (kernel == 1) h->jac_valid = false;                       // the factor storage no longer holds the Jacobian
+    if (kernel <= 1) h->jac_valid = false;                       // the factor storage no longer holds the plain Jacobian (kernel 0 runs the
+                                                                 // prefactoring assembly: leaf diagonal blocks leave as 2x2 LU factors)
     *mean_ms = (double)ms / reps;
     return 0;
 }

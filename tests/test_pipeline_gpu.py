@@ -14,7 +14,9 @@ def _records(torch, count, lanes, n):
 
 
 @pytest.mark.parametrize("name,batch,njobs,pool", [("case1354pegase", 192, 7, 128), ("case1354pegase", 128, 5, 64),
-                                                  ("case_ACTIVSg10k", 512, 4, 256)])
+                                                  ("case_ACTIVSg10k", 512, 4, 256),
+                                                  ("case1354pegase", 512, 3, 128),       # pool request on the other side of the 256-lane plan
+                                                  ("case1354pegase", 320, 3, 64)])       # threshold than its batches: the pipeline moves it over
 def test_pool_is_bitwise_the_lockstep_pipeline(jg, name, batch, njobs, pool):
     import torch
     s = jg.powerSystem(load_case(name))

@@ -1,0 +1,130 @@
+"""Gauss-Newton kernels against the C oracle AT BASELINE SCALE and ON NOISY READINGS: the config-4 set on the
+9241-bus grid (96 723 rows) with one noisy realisation, and a case1354pegase set that holds every measurement type code 1 .. 21.
+  * se.type / index / range, H pattern ............................ bit-exact
+  * H and residual at the same state .............................. 1e-12 relative to the largest entry, at the flat start AND at
+                                                                    the second iterate (the oracle is moved to the device's state)
+  * Gauss-Newton increment ........................................ 1e-8 relative
+  * stateEstimation!: iteration counts equal, V / theta ........... 1e-8
+Reference: src/stateEstimation/acStateEstimation.jl:261-583, 878-904; test/stateEstimation/analysis.jl:203-298."""
+import numpy as np
+import pytest
+
+from conftest import load_case
+from test_reusing_gpu import _table_of
+from test_se_gpu import _mirror, _system_like
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_system(oracle, tables):
+    osys = oracle.OracleSystem(tables)
+    opf = oracle.OracleNR(osys)
+    assert opf.power_flow(iteration=30, tolerance=1e-11) == 0
+    vm, va = opf.voltage()
+    osys.type = opf.type.copy(); osys.slack = opf.slack           # the power flow normalises bus types like newtonRaphson(system)
+    return osys, vm, va
+
+
+def _compare_at_state(an, gn, jg, tag):
+    """increment! on both sides at the SAME state: H, residual, objective, increment."""
+    mx = jg.incrementSE_(an)
+    mo = gn.increment()
+    v = gn.vectors()
+    H = an.jacobian.nzval
+    assert np.abs(H - v["jacobian"]).max() <= 1e-12 * np.abs(v["jacobian"]).max(), tag
+    assert np.abs(an.residual - v["residual"]).max() <= 1e-12 * max(1.0, np.abs(v["residual"]).max()), tag
+    assert abs(an.objective - gn.objective) <= 1e-9 * max(1.0, gn.objective), tag
+    assert np.abs(an.increment - v["increment"]).max() <= 1e-8 * max(1.0, np.abs(v["increment"]).max()), tag
+    assert abs(mx - mo) <= 1e-8 * max(1.0, mo), tag
+
+
+def _check_model(an, gn):
+    assert np.array_equal(an.method.type, gn.type)
+    assert np.array_equal(an.method.index, gn.index)
+    assert np.array_equal(an.method.range, gn.range)
+    J = an.jacobian
+    assert np.array_equal(J.colptr, gn.hcolptr) and np.array_equal(J.rowval, gn.hrowval)
+
+
+def _noisy(mon, rng):
+    """z + sigma N(0, 1) on every raw meter quantity of the container, in place (measurement/utility.jl:70-73 with noise = true)."""
+    for g in (mon.voltmeter.magnitude, mon.ammeter.magnitude, mon.wattmeter.active, mon.varmeter.reactive, mon.pmu.magnitude, mon.pmu.angle):
+        g.mean[:] = g.mean + np.sqrt(g.variance) * rng.standard_normal(g.mean.size)
+
+
+def test_config4_noisy_realisation_against_the_oracle(jg, oracle):
+    from juliagrid.jl_amd.synthetic import case9241synth
+    tables = case9241synth()
+    s = jg.powerSystem({k: np.array(v) for k, v in tables.items()})
+    pf = jg.newtonRaphson(s)
+    jg.powerFlow_(pf, tolerance=1e-11)
+    assert pf.status == 0
+    mon = jg.measurement(s)
+    jg.addVoltmeter_(mon, pf); jg.addWattmeter_(mon, pf); jg.addVarmeter_(mon, pf)
+    jg.addPmu_(mon, pf, buses=range(1, s.bus.number + 1, 10), statusTo=-1, minMagnitude=1e-6)
+    _noisy(mon, np.random.Generator(np.random.PCG64(4)))
+    n = s.bus.number
+    an = jg.gaussNewton(mon)
+    assert 0.9e5 <= an.dims["m"] <= 1.05e5
+    osys, _, _ = _oracle_system(oracle, {k: np.array(v) for k, v in tables.items()})
+    gn = oracle.OracleGN(osys, _table_of(oracle, mon), np.ones(n), np.zeros(n))
+    _check_model(an, gn)
+    an.setVoltage(np.ones(n), np.zeros(n))
+    _compare_at_state(an, gn, jg, "flat start")
+    jg.solveSE_(an)                                               # second iterate: the device's own state, handed to the oracle
+    gn.set_voltage(np.asarray(an.voltage.magnitude), np.asarray(an.voltage.angle))
+    _compare_at_state(an, gn, jg, "second iterate")
+    # the whole estimation from the flat start on both sides
+    an.setVoltage(np.ones(n), np.zeros(n))
+    jg.stateEstimation_(an, iteration=40, tolerance=1e-8)
+    gn2 = oracle.OracleGN(osys, _table_of(oracle, mon), np.ones(n), np.zeros(n))
+    assert gn2.state_estimation(40, 1e-8) == 0 and an.status == 0
+    assert gn2.iteration == an.method.iteration
+    v = gn2.vectors()
+    assert np.abs(an.voltage.magnitude - v["magnitude"]).max() <= 1e-8 and np.abs(an.voltage.angle - v["angle"]).max() <= 1e-8
+    an.close(); pf.close()
+
+
+def test_every_type_code_on_case1354pegase_with_noise(jg, oracle):
+    """Voltmeters (1), ammeters plain and squared (2-5), wattmeters (6-8), varmeters (9-11), polar PMUs incl. squared current
+    magnitudes (12-15 and 4, 5), rectangular PMUs uncorrelated and correlated (16-21): every type code of acWLS in ONE noisy set."""
+    t = load_case("case1354pegase")
+    osys, vm, va = _oracle_system(oracle, t)
+    tab = oracle.MeterTable()
+    oracle.add_from_power_flow(tab, osys, vm, va, "voltmeter")
+    oracle.add_from_power_flow(tab, osys, vm, va, "ammeter", variance=1e-4)
+    oracle.add_from_power_flow(tab, osys, vm, va, "ammeter", variance=1e-4, square=True)
+    oracle.add_from_power_flow(tab, osys, vm, va, "wattmeter")
+    oracle.add_from_power_flow(tab, osys, vm, va, "varmeter")
+    oracle.add_from_power_flow(tab, osys, vm, va, "pmu", polar=True)
+    oracle.add_from_power_flow(tab, osys, vm, va, "pmu", bus=False, polar=True, square=True)
+    oracle.add_from_power_flow(tab, osys, vm, va, "pmu")
+    oracle.add_from_power_flow(tab, osys, vm, va, "pmu", correlated=True)
+    rng = np.random.Generator(np.random.PCG64(4))
+    rows = []
+    for (kind, loc, index, m1, v1, s1, m2, v2, s2, fl) in tab.rows:
+        m1 = m1 + np.sqrt(v1) * rng.standard_normal()
+        if kind == 5:
+            m2 = m2 + np.sqrt(v2) * rng.standard_normal()
+        if kind in (2, 5) and m1 <= 0:                             # a magnitude reading stays positive
+            m1 = abs(m1) + 1e-9
+        rows.append((kind, loc, index, float(m1), v1, s1, float(m2), v2, s2, fl))
+    tab.rows = rows
+    s = _system_like(jg, t, osys)
+    n = s.bus.number
+    an = jg.gaussNewton(_mirror(jg, s, tab))
+    gn = oracle.OracleGN(osys, tab, np.ones(n), np.zeros(n))
+    assert set(int(c) for c in np.unique(gn.type)) >= set(range(1, 22)), sorted(np.unique(gn.type))
+    _check_model(an, gn)
+    an.setVoltage(np.ones(n), np.zeros(n))
+    _compare_at_state(an, gn, jg, "flat start")
+    jg.solveSE_(an)
+    gn.set_voltage(np.asarray(an.voltage.magnitude), np.asarray(an.voltage.angle))
+    _compare_at_state(an, gn, jg, "second iterate")
+    an.setVoltage(np.ones(n), np.zeros(n))
+    jg.stateEstimation_(an, iteration=40, tolerance=1e-8)
+    gn2 = oracle.OracleGN(osys, tab, np.ones(n), np.zeros(n))
+    assert gn2.state_estimation(40, 1e-8) == 0 and an.status == 0 and gn2.iteration == an.method.iteration
+    v = gn2.vectors()
+    assert np.abs(an.voltage.magnitude - v["magnitude"]).max() <= 1e-8 and np.abs(an.voltage.angle - v["angle"]).max() <= 1e-8
+    an.close()
