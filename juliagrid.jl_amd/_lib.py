@@ -134,6 +134,28 @@ def device_count():
     return int(lib().jg_device_count())
 
 
+_plan = None
+
+
+def plan_lib():
+    """Library behind `Plan`: libjgrid_hip.so, or -- JG_PLAN_LIB=<path> -- a plan-only build of csrc/jg_symbolic.cpp + jg_plan_api.cpp
+    (device-free host code: the CPU suite runs it under AddressSanitizer / UBSan, tools/asan_plan.sh)."""
+    global _plan
+    if _plan is None:
+        path = os.environ.get("JG_PLAN_LIB")
+        if not path:
+            _plan = lib()
+        else:
+            _plan = C.CDLL(path)
+            _plan.jg_plan_create.argtypes = [C.POINTER(VP), C.c_int64, I32P, I32P, C.c_int64]
+            _plan.jg_plan_create.restype = C.c_int
+            _plan.jg_plan_destroy.argtypes = [VP]
+            _plan.jg_plan_destroy.restype = None
+            _plan.jg_plan_export.argtypes = [VP, C.c_int, VP, C.c_int64]
+            _plan.jg_plan_export.restype = C.c_int64
+    return _plan
+
+
 class Plan:
     """Device-free symbolic analysis (schedule export for tests)."""
 
@@ -142,7 +164,7 @@ class Plan:
 
     def __init__(self, n, rowptr, col, policy=0):
         self.h = VP()
-        rc = lib().jg_plan_create(C.byref(self.h), int(n), np.ascontiguousarray(rowptr, dtype=np.int32),
+        rc = plan_lib().jg_plan_create(C.byref(self.h), int(n), np.ascontiguousarray(rowptr, dtype=np.int32),
                                   np.ascontiguousarray(col, dtype=np.int32), int(policy))
         if rc:
             raise JGridError(rc, "block pattern must be structurally symmetric with a full diagonal")
@@ -150,16 +172,16 @@ class Plan:
 
     def __del__(self):
         if getattr(self, "h", None):
-            lib().jg_plan_destroy(self.h)
+            plan_lib().jg_plan_destroy(self.h)
             self.h = None
 
     def get(self, which):
         w = self.NAMES[which] if isinstance(which, str) else int(which)
-        m = lib().jg_plan_export(self.h, w, None, 0)
+        m = plan_lib().jg_plan_export(self.h, w, None, 0)
         if m < 0:
             raise KeyError(which)
         out = np.zeros(max(m, 1), dtype=np.int32)
-        lib().jg_plan_export(self.h, w, out.ctypes.data, m)
+        plan_lib().jg_plan_export(self.h, w, out.ctypes.data, m)
         return out[:m]
 
     def replay_tables(self, kind):

@@ -986,6 +986,76 @@ std::mutex& capture_mutex() {
     return m;
 }
 
+SharedPlan::~SharedPlan() {
+    hipFree(fact_rec); hipFree(bwd_rec); hipFree(pre_rec); hipFree(fwd_rec); hipFree(sel_rec); hipFree(top_task);
+    hipFree(fact_seg); hipFree(bwd_seg); hipFree(pre_seg); hipFree(fwd_seg); hipFree(sel_seg);
+    hipFree(pre_row); hipFree(bwd_chain); hipFree(top_data); hipFree(top_wgmap);
+}
+
+namespace {
+std::mutex g_plan_mutex;
+std::vector<std::shared_ptr<SharedPlan>> g_plans;            // most recently used last
+constexpr size_t PLAN_CACHE_KEEP = 6;                        // plans without a live engine that the cache keeps around on its own
+
+unsigned long long pattern_hash(int n, const int* rowptr, const int* col, long long policy, int device) {
+    unsigned long long h = 1469598103934665603ULL;
+    auto mix = [&](unsigned long long v) { h ^= v; h *= 1099511628211ULL; };
+    mix((unsigned long long)n); mix((unsigned long long)policy); mix((unsigned long long)device);
+    for (int i = 0; i <= n; ++i) mix((unsigned)rowptr[i]);
+    for (int p = 0; p < rowptr[n]; ++p) mix((unsigned)col[p]);
+    return h;
+}
+}  // namespace
+
+void clear_plan_cache() {
+    std::lock_guard<std::mutex> lock(g_plan_mutex);
+    g_plans.clear();
+}
+
+std::shared_ptr<SharedPlan> acquire_plan(int n, const int* rowptr, const int* col, long long policy, hipStream_t st, std::string& error, int& rc) {
+    rc = 0;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) { error = "no HIP device"; rc = 2; return nullptr; }
+    if (n <= 0 || !rowptr || !col || rowptr[0] != 0) { error = "block pattern must be structurally symmetric with a full diagonal"; rc = 1; return nullptr; }
+    static const bool nocache = getenv("JG_PLAN_CACHE") && atoi(getenv("JG_PLAN_CACHE")) == 0;
+    const unsigned long long h = pattern_hash(n, rowptr, col, policy, device);
+    std::lock_guard<std::mutex> lock(g_plan_mutex);            // one analysis at a time: a second handle of the same grid waits, then hits
+    if (!nocache)
+        for (size_t i = 0; i < g_plans.size(); ++i) {
+            const std::shared_ptr<SharedPlan>& p = g_plans[i];
+            if (p->key_hash == h && p->device == device && p->policy == policy && p->S.n == n && (int)p->key_col.size() == rowptr[n] &&
+                std::equal(rowptr, rowptr + n + 1, p->key_rowptr.begin()) && std::equal(col, col + rowptr[n], p->key_col.begin())) {
+                std::shared_ptr<SharedPlan> hit = p;
+                g_plans.erase(g_plans.begin() + i);
+                g_plans.push_back(hit);
+                return hit;
+            }
+        }
+    std::shared_ptr<SharedPlan> p = std::make_shared<SharedPlan>();
+    if (analyze(n, rowptr, col, policy, p->S)) { error = "block pattern must be structurally symmetric with a full diagonal"; rc = 1; return nullptr; }
+    p->device = device; p->policy = policy; p->key_hash = h;
+    p->key_rowptr.assign(rowptr, rowptr + n + 1); p->key_col.assign(col, col + rowptr[n]);
+    const BlockSymbolic& S = p->S;
+    std::vector<int> prow(n, 0);                                 // by ORIGINAL block index: pivot + 1 where the producer finishes D and y
+    for (int k = 0; k < n; ++k) if (S.prefactor && S.pre_pivot[k]) prow[S.perm[k]] = k + 1;
+    if (upload(&p->pre_rec, S.pre_rec, error, st) || upload(&p->pre_seg, S.pre_seg, error, st) || upload(&p->pre_row, prow, error, st) ||
+        upload(&p->fact_rec, S.fact_rec, error, st) || upload(&p->bwd_rec, S.bwd_rec, error, st) || upload(&p->fact_seg, S.fact_seg, error, st) ||
+        upload(&p->bwd_seg, S.bwd_seg, error, st) || upload(&p->bwd_chain, S.bwd_chain, error, st) ||
+        upload(&p->fwd_rec, S.fwd_rec, error, st) || upload(&p->fwd_seg, S.fwd_seg, error, st) ||
+        (!S.top_launch.empty() && (upload(&p->top_task, S.top_task, error, st) || upload(&p->top_data, S.top_data, error, st) || upload(&p->top_wgmap, S.top_wgmap, error, st)))) {
+        rc = 2;
+        return nullptr;
+    }
+    if (!nocache) {
+        g_plans.push_back(p);
+        size_t idle = 0;                                         // plans nobody else uses leave first, oldest first
+        for (const auto& q : g_plans) if (q.use_count() == 1) ++idle;
+        for (size_t i = 0; i < g_plans.size() && idle > PLAN_CACHE_KEEP;)
+            if (g_plans[i].use_count() == 1) { g_plans.erase(g_plans.begin() + i); --idle; } else ++i;
+    }
+    return p;
+}
+
 int Engine::create(int n, const int* rowptr, const int* col, int ld_, long long policy, hipStream_t st) {
     if (ld_ <= 0 || ld_ % 64) { error = "batch leading dimension must be a positive multiple of 64"; return 1; }
     // Where the multifrontal top starts depends on the batch: a top task occupies a workgroup per scenario (~10 us + ~1 us per
@@ -1001,30 +1071,28 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, long long 
     if (defaults && ld_ >= 256 && !getenv("JG_TOP_NOSPLIT")) policy |= 8;
     if (defaults) policy |= ld_ >= 256 ? (n >= 4000 ? (47 << 16 | (384 / 8) << 24 | 8 << 4) : (47 << 16 | (280 / 8) << 24 | 4 << 4))
                                               : ((n >= 4000 ? 26 : 24) << 16 | (384 / 8) << 24);
-    if (analyze(n, rowptr, col, policy, S)) { error = "block pattern must be structurally symmetric with a full diagonal"; return 1; }
-    ld = ld_;
-    level_launches(S.fact_seg, fact);
-    level_launches(S.pre_seg, pre);
-    level_launches(S.bwd_seg, bwd);
-    level_launches(S.fwd_seg, fwd);
     {
-        std::vector<int> prow(n, 0);                             // by ORIGINAL block index: pivot + 1 where the producer finishes D and y
-        for (int k = 0; k < n; ++k) if (S.prefactor && S.pre_pivot[k]) prow[S.perm[k]] = k + 1;
-        if (upload(&pre_rec, S.pre_rec, error, st) || upload(&pre_seg, S.pre_seg, error, st) || upload(&pre_row, prow, error, st)) return 2;
+        int rc = 0;
+        plan = acquire_plan(n, rowptr, col, policy, st, error, rc);
+        if (!plan) return rc;
     }
-    if (upload(&fact_rec, S.fact_rec, error, st) || upload(&bwd_rec, S.bwd_rec, error, st) || upload(&fact_seg, S.fact_seg, error, st) ||
-        upload(&bwd_seg, S.bwd_seg, error, st) || upload(&bwd_chain, S.bwd_chain, error, st) ||
-        upload(&fwd_rec, S.fwd_rec, error, st) || upload(&fwd_seg, S.fwd_seg, error, st))
-        return 2;
+    ld = ld_;
+    level_launches(plan->S.fact_seg, fact);
+    level_launches(plan->S.pre_seg, pre);
+    level_launches(plan->S.bwd_seg, bwd);
+    level_launches(plan->S.fwd_seg, fwd);
+    // the device tables belong to the plan; the engine keeps plain aliases for its launches
+    fact_rec = plan->fact_rec; bwd_rec = plan->bwd_rec; pre_rec = plan->pre_rec; fwd_rec = plan->fwd_rec;
+    fact_seg = plan->fact_seg; bwd_seg = plan->bwd_seg; pre_seg = plan->pre_seg; fwd_seg = plan->fwd_seg;
+    pre_row = plan->pre_row; bwd_chain = plan->bwd_chain; top_task = plan->top_task; top_data = plan->top_data; top_wgmap = plan->top_wgmap;
     JG_HIP(hipFuncSetAttribute((const void*)k_bwd_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CHAIN_LDS_D2 * sizeof(double2))));
-    if (!S.top_launch.empty()) {
-        if (upload(&top_task, S.top_task, error, st) || upload(&top_data, S.top_data, error, st) || upload(&top_wgmap, S.top_wgmap, error, st)) return 2;
-        const size_t sb = (size_t)(std::max<long long>(S.top_stack_cls[0], 2) + S.top_stack_cls[1] + S.top_stack_cls[2]) * ld * sizeof(double);
+    if (!plan->S.top_launch.empty()) {
+        const size_t sb = (size_t)(std::max<long long>(plan->S.top_stack_cls[0], 2) + plan->S.top_stack_cls[1] + plan->S.top_stack_cls[2]) * ld * sizeof(double);
         JG_HIP(hipMalloc((void**)&top_stack, sb));
         JG_HIP(sync_fill(top_stack, 0, sb, st));
         if (getenv("JG_TOP_PROFILE")) {
-            JG_HIP(hipMalloc((void**)&top_prof, S.top_task.size() * ld * 8 * sizeof(long long)));
-            JG_HIP(sync_fill(top_prof, 0, S.top_task.size() * ld * 8 * sizeof(long long), st));
+            JG_HIP(hipMalloc((void**)&top_prof, plan->S.top_task.size() * ld * 8 * sizeof(long long)));
+            JG_HIP(sync_fill(top_prof, 0, plan->S.top_task.size() * ld * 8 * sizeof(long long), st));
         }
     }
     JG_HIP(hipMalloc((void**)&X, factor_bytes()));
@@ -1039,14 +1107,14 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, long long 
 
 void Engine::destroy() {
     if (top_prof) {                                              // phase times of every task (scenario 0, last factorisation)
-        std::vector<long long> t(S.top_task.size() * ld * 8);
+        std::vector<long long> t(plan->S.top_task.size() * ld * 8);
         if (hipMemcpy(t.data(), top_prof, t.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess) {
             fprintf(stderr, "[jg top profile] task level class m e | load children steps store total (us) | us per step | batch: workgroups, start spread, "
                             "total min / median / max, first start -> last end, CUs used, most workgroups on one CU\n");
-            for (size_t i = 0; i < S.top_task.size(); ++i) {
+            for (size_t i = 0; i < plan->S.top_task.size(); ++i) {
                 const long long* p = &t[i * ld * 8];
                 if (!p[0]) continue;
-                const Rec& h = S.top_task[i];
+                const Rec& h = plan->S.top_task[i];
                 fprintf(stderr, "[jg top profile] %3zu %2d %d %2d %2d | %6.2f %6.2f %6.2f %6.2f %7.2f | %5.3f", i, h.w[10], h.w[9], h.w[0], h.w[1],
                         (p[1] - p[0]) * 0.01, (p[2] - p[1]) * 0.01, (p[3] - p[2]) * 0.01, (p[4] - p[3]) * 0.01, (p[4] - p[0]) * 0.01, (p[3] - p[2]) * 0.01 / h.w[0]);
                 std::vector<long long> st0, tot; long long e1 = 0; std::vector<int> cu;
@@ -1064,41 +1132,42 @@ void Engine::destroy() {
         }
         hipFree(top_prof); top_prof = nullptr;
     }
-    hipFree(fact_rec); hipFree(bwd_rec); hipFree(fact_seg); hipFree(bwd_seg); hipFree(bwd_chain); hipFree(pre_rec); hipFree(pre_seg); hipFree(pre_row);
-    hipFree(fwd_rec); hipFree(fwd_seg); fwd_rec = nullptr; fwd_seg = nullptr;
-    hipFree(sel_rec); hipFree(sel_seg); hipFree(Zs); sel_rec = nullptr; sel_seg = nullptr; Zs = nullptr;
-    hipFree(top_task); hipFree(top_data); hipFree(top_stack); hipFree(top_wgmap); top_task = nullptr; top_data = nullptr; top_stack = nullptr; top_wgmap = nullptr;
-    bwd_chain = nullptr;
+    fwd_rec = nullptr; fwd_seg = nullptr; sel_rec = nullptr; sel_seg = nullptr;                  // tables: the plan's (freed with its last user)
+    top_task = nullptr; top_data = nullptr; top_wgmap = nullptr; bwd_chain = nullptr;
+    fact_rec = bwd_rec = nullptr; fact_seg = bwd_seg = nullptr; pre_rec = nullptr; pre_seg = nullptr; pre_row = nullptr;
+    hipFree(Zs); Zs = nullptr;
+    hipFree(top_stack); top_stack = nullptr;
     hipFree(X); hipFree(W); hipFree(status);
-    fact_rec = bwd_rec = nullptr; fact_seg = bwd_seg = nullptr; status = nullptr; pre_rec = nullptr; pre_seg = nullptr; pre_row = nullptr;
+    status = nullptr;
     X = W = nullptr;
+    plan.reset();
 }
 
 int Engine::factor(hipStream_t st, const double* A, const double* rhs, const GroupSel& sel, bool level0_done) {
-    if (!S.inplace && !A) { error = "factor: no source matrix"; return 1; }
-    FactArgs a{fact_rec, fact_seg, S.inplace ? X : A, rhs, X, W, status, sel, ld, 0, lanes > 0 ? lanes : ld, 0, 0, 1, 1};
+    if (!plan->S.inplace && !A) { error = "factor: no source matrix"; return 1; }
+    FactArgs a{fact_rec, fact_seg, plan->S.inplace ? X : A, rhs, X, W, status, sel, ld, 0, lanes > 0 ? lanes : ld, 0, 0, 1, 1};
     const int gs = group_stride(ld / 64);
     if (!level0_done && !pre.empty()) {                          // prefactor plan, plain blocks from the producer: its level 0 first
         FactArgs p = a;
         p.rec = pre_rec; p.seg = pre_seg;
         for (const DevLaunch& L : pre) {
             p.seg_begin = L.seg_begin;
-            { const Segment& g = S.pre_seg[L.seg_begin]; p.s0_base = g.rec_base; p.s0_nchunks = g.nchunks; p.s0_wpi = g.wpi; p.s0_rpw = g.rpw; }
+            { const Segment& g = plan->S.pre_seg[L.seg_begin]; p.s0_base = g.rec_base; p.s0_nchunks = g.nchunks; p.s0_wpi = g.wpi; p.s0_rpw = g.rpw; }
             hipLaunchKernelGGL(k_fact_level, dim3((unsigned)L.grid * (16 / FACT_WAVES) * gs, L.nseg), dim3(64, FACT_WAVES), FACT_WAVES * 256 * sizeof(double), st, p);
         }
     }
     for (const DevLaunch& L : fact) {
         a.seg_begin = L.seg_begin;
-        { const Segment& g = S.fact_seg[L.seg_begin]; a.s0_base = g.rec_base; a.s0_nchunks = g.nchunks; a.s0_wpi = g.wpi; a.s0_rpw = g.rpw; }
+        { const Segment& g = plan->S.fact_seg[L.seg_begin]; a.s0_base = g.rec_base; a.s0_nchunks = g.nchunks; a.s0_wpi = g.wpi; a.s0_rpw = g.rpw; }
         hipLaunchKernelGGL(k_fact_level, dim3((unsigned)L.grid * (16 / FACT_WAVES) * gs, L.nseg), dim3(64, FACT_WAVES), FACT_WAVES * 256 * sizeof(double), st, a);
     }
     // the top of the elimination tree: multifrontal tasks, one workgroup per (task, scenario), launch = (task level, class)
-    if (!S.top_launch.empty()) {
-        const long long s0 = std::max<long long>(S.top_stack_cls[0], 2);
-        TopArgs t{top_task, top_data, X, W, top_stack, status, sel, s0, {0, s0 * ld, (s0 + S.top_stack_cls[1]) * ld}, {s0, S.top_stack_cls[1], S.top_stack_cls[2]},
+    if (!plan->S.top_launch.empty()) {
+        const long long s0 = std::max<long long>(plan->S.top_stack_cls[0], 2);
+        TopArgs t{top_task, top_data, X, W, top_stack, status, sel, s0, {0, s0 * ld, (s0 + plan->S.top_stack_cls[1]) * ld}, {s0, plan->S.top_stack_cls[1], plan->S.top_stack_cls[2]},
                   top_prof, ld, a.lanes, 0, 0, 64, top_wgmap, 0, 0};
         if (ld == 64 && t.lanes < 64) t.lpg = t.lanes;
-        for (const TopLaunch& L : S.top_launch) {
+        for (const TopLaunch& L : plan->S.top_launch) {
             t.task_begin = L.task_begin; t.ntasks = L.ntasks;
             if (L.grouped) {                                     // every grouped task of the level: 4 or 16 scenarios per workgroup
                 t.wg_begin = L.wg_begin; t.nwg = L.nwg;
@@ -1128,10 +1197,17 @@ int Engine::factor(hipStream_t st, const double* A, const double* rhs, const Gro
 }
 
 int Engine::selected_inverse(hipStream_t st, const GroupSel& sel) {
-    if (!Zs) {                                          // tables and storage on first use
-        build_selected_inverse(S);
-        level_launches(S.sel_seg, selv);
-        if (upload(&sel_rec, S.sel_rec, error, st) || upload(&sel_seg, S.sel_seg, error, st)) return 2;
+    if (!Zs) {                                          // tables (the plan's, built once) and storage (this engine's) on first use
+        {
+            std::lock_guard<std::mutex> lock(plan->sel_mutex);
+            if (!plan->sel_ready) {
+                build_selected_inverse(plan->S);
+                if (upload(&plan->sel_rec, plan->S.sel_rec, error, st) || upload(&plan->sel_seg, plan->S.sel_seg, error, st)) return 2;
+                plan->sel_ready = true;
+            }
+        }
+        level_launches(plan->S.sel_seg, selv);
+        sel_rec = plan->sel_rec; sel_seg = plan->sel_seg;
         JG_HIP(hipMalloc((void**)&Zs, factor_bytes()));
         JG_HIP(sync_fill(Zs, 0, factor_bytes(), st));
     }
@@ -1139,7 +1215,7 @@ int Engine::selected_inverse(hipStream_t st, const GroupSel& sel) {
     const int gs = group_stride(ld / 64);
     for (const DevLaunch& L : selv) {
         a.seg_begin = L.seg_begin;
-        { const Segment& g = S.sel_seg[L.seg_begin]; a.s0_base = g.rec_base; a.s0_nchunks = g.nchunks; a.s0_wpi = g.wpi; a.s0_rpw = g.rpw; }
+        { const Segment& g = plan->S.sel_seg[L.seg_begin]; a.s0_base = g.rec_base; a.s0_nchunks = g.nchunks; a.s0_wpi = g.wpi; a.s0_rpw = g.rpw; }
         hipLaunchKernelGGL(k_sel_level, dim3((unsigned)L.grid * (16 / FACT_WAVES) * gs, L.nseg), dim3(64, FACT_WAVES), FACT_WAVES * 128 * sizeof(double2), st, a);
     }
     JG_HIP(hipGetLastError());
@@ -1151,7 +1227,7 @@ int Engine::forward(hipStream_t st, const double* rhs, const GroupSel& sel) {
     const int gs = group_stride(ld / 64);
     for (const DevLaunch& L : fwd) {
         a.seg_begin = L.seg_begin;
-        { const Segment& g = S.fwd_seg[L.seg_begin]; a.s0_base = g.rec_base; a.s0_nchunks = g.nchunks; a.s0_wpi = g.wpi; a.s0_rpw = g.rpw; }
+        { const Segment& g = plan->S.fwd_seg[L.seg_begin]; a.s0_base = g.rec_base; a.s0_nchunks = g.nchunks; a.s0_wpi = g.wpi; a.s0_rpw = g.rpw; }
         hipLaunchKernelGGL(k_fact_level, dim3((unsigned)L.grid * (16 / FACT_WAVES) * gs, L.nseg), dim3(64, FACT_WAVES), FACT_WAVES * 256 * sizeof(double), st, a);
     }
     JG_HIP(hipGetLastError());
@@ -1170,11 +1246,11 @@ __global__ void k_fill_shared(const double* blocks, const int* src_entry, double
 }  // namespace
 
 int Engine::set_shared_matrix(hipStream_t st, const double* blocks_host) {
-    if (!S.inplace) { error = "set_shared_matrix needs an in-place engine"; return 1; }
-    const int nnz = (int)S.src_entry.size();
+    if (!plan->S.inplace) { error = "set_shared_matrix needs an in-place engine"; return 1; }
+    const int nnz = (int)plan->S.src_entry.size();
     double* dblk = nullptr; int* dmap = nullptr;
     std::vector<double> hb(blocks_host, blocks_host + (size_t)nnz * 4);
-    if (upload(&dblk, hb, error, st) || upload(&dmap, S.src_entry, error, st)) { hipFree(dblk); hipFree(dmap); return 2; }
+    if (upload(&dblk, hb, error, st) || upload(&dmap, plan->S.src_entry, error, st)) { hipFree(dblk); hipFree(dmap); return 2; }
     hipLaunchKernelGGL(k_fill_shared, dim3((nnz + 3) / 4, ld / 64), dim3(64, 4), 0, st, dblk, dmap, X, nnz, ld);
     hipError_t e = hipStreamSynchronize(st);
     hipFree(dblk); hipFree(dmap);
@@ -1187,7 +1263,7 @@ int Engine::backsolve(hipStream_t st, double* out, const StateUpdate& upd, const
     const int gs = group_stride(ld / 64);
     for (const DevLaunch& L : bwd) {
         a.seg_begin = L.seg_begin;
-        { const Segment& g = S.bwd_seg[L.seg_begin]; a.s0_base = g.rec_base; a.s0_nchunks = g.nchunks; a.s0_wpi = g.wpi; a.s0_rpw = g.rpw; }
+        { const Segment& g = plan->S.bwd_seg[L.seg_begin]; a.s0_base = g.rec_base; a.s0_nchunks = g.nchunks; a.s0_wpi = g.wpi; a.s0_rpw = g.rpw; }
         if (!L.chain && L.wpi_max <= 8)                         // 0.387 -> 0.381 ms at 512 scenarios
             hipLaunchKernelGGL(k_bwd_level8, dim3((unsigned)L.grid * 2 * gs, L.nseg), dim3(64, 8), 8 * 128 * sizeof(double), st, a);
         else

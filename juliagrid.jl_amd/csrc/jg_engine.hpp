@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -153,8 +154,29 @@ __device__ __forceinline__ bool map_block(const GroupSel& sel, int ld, int nx, i
 }
 #endif
 
-struct Engine {
+// The symbolic analysis of one pattern under one policy and the DEVICE copy of its replay tables: immutable once built, shared by every
+// engine that factorises that pattern on that device (the handles of a ContingencyPipeline, a second analysis of the same grid, the
+// rebuild of an analysis whose pattern did not change) through a process-wide cache -- the reference pays its symbolic analysis once per
+// `newtonRaphson()` call and optimised exactly that (docs/src/background/releasenotes.md:7-9).
+struct SharedPlan {
     BlockSymbolic S;
+    int device = 0;
+    long long policy = 0;
+    std::vector<int> key_rowptr, key_col;          // the pattern the plan was built for (cache hits are verified, not trusted to a hash)
+    unsigned long long key_hash = 0;
+    Rec* fact_rec = nullptr; Rec* bwd_rec = nullptr; Rec* pre_rec = nullptr; Rec* fwd_rec = nullptr; Rec* sel_rec = nullptr; Rec* top_task = nullptr;
+    Segment* fact_seg = nullptr; Segment* bwd_seg = nullptr; Segment* pre_seg = nullptr; Segment* fwd_seg = nullptr; Segment* sel_seg = nullptr;
+    int* pre_row = nullptr; int* bwd_chain = nullptr; int* top_data = nullptr; int* top_wgmap = nullptr;
+    std::mutex sel_mutex;                           // the selected-inverse tables are built on first use
+    bool sel_ready = false;
+    ~SharedPlan();
+};
+// (n, pattern, policy, current device) -> plan; analysis + upload on a miss.  st: stream for the uploads.  nullptr + error on failure.
+std::shared_ptr<SharedPlan> acquire_plan(int n, const int* rowptr, const int* col, long long policy, hipStream_t st, std::string& error, int& rc);
+void clear_plan_cache();                            // drops the cache's own references (live engines keep their plans)
+
+struct Engine {
+    std::shared_ptr<SharedPlan> plan;
     int ld = 0;                    // padded batch (multiple of 64)
     int lanes = 0;                 // real scenarios (<= ld; set by the owner, default ld): lanes beyond alias the last real one,
                                    // so a small batch moves 8 bytes per load instruction instead of 512
@@ -194,7 +216,7 @@ struct Engine {
     int set_shared_matrix(hipStream_t st, const double* blocks_host);
     // x = U^-1 D y, scattered to original order into out [n][2][ld]; optional fused state update.
     int backsolve(hipStream_t st, double* out, const StateUpdate& upd, const GroupSel& sel);
-    size_t factor_bytes() const { return (size_t)S.n_entries * 4 * ld * sizeof(double); }
+    size_t factor_bytes() const { return (size_t)plan->S.n_entries * 4 * ld * sizeof(double); }
 };
 
 #define JG_HIP(expr)                                                                      \

@@ -792,7 +792,7 @@ int jg_gn_create(jg_gn** out, int64_t n, const int64_t* colptr, const int64_t* r
     // with half the update terms)
     rc = h->eng.create((int)n, h->gi_rowptr.data(), h->gi_col.data(), h->ld, 3, h->stream);
     if (rc) { std::string msg = h->eng.error; jg_gn_destroy(h); return failg(rc, msg); }
-    const std::vector<int>& ip = h->eng.S.iperm;
+    const std::vector<int>& ip = h->eng.plan->S.iperm;
     // wave records (see k_gn_gain): bus rows in PIVOT order -- the postorder of the elimination tree keeps electrical
     // neighbours together whatever the bus numbering of the case is, and neighbours are what shares measurement rows
     std::vector<GainRec> grec, rrec, trec;
@@ -800,7 +800,7 @@ int jg_gn_create(jg_gn** out, int64_t n, const int64_t* colptr, const int64_t* r
     std::vector<GainTask> gtask;
     {
         const int slack = h->slack0;                                             // -1: the model has no slack (PMU-only)
-        const std::vector<int>& src_entry = h->eng.S.src_entry;
+        const std::vector<int>& src_entry = h->eng.plan->S.src_entry;
         auto emit = [&](std::vector<GainRec>& out, int head, int dst, const std::vector<Contrib>& cs) {
             size_t q = 0;
             do {
@@ -820,7 +820,7 @@ int jg_gn_create(jg_gn** out, int64_t n, const int64_t* colptr, const int64_t* r
             if (ip[kv.first.first] > ip[kv.first.second]) continue;              // below the diagonal in pivot order: never read
             by_row[kv.first.first].push_back({this_id, &kv.second});
         }
-        const std::vector<int>& perm = h->eng.S.perm;
+        const std::vector<int>& perm = h->eng.plan->S.perm;
         constexpr size_t WAVE_RECS = 4;                                          // a wave's share: about 4 records, whole items (2: 1.25 ms, 4: 1.19, 8: 1.21, 32: 1.50 at 512 scenarios)
         // LDS-staged tasks (k_gn_gain_lds): consecutive bus rows in pivot order while their distinct operands fit the budget.
         // OPT-IN (JG_GAIN_LDS=<images per task, at most 80>; default 0 = every item on the direct path, k_gn_gain).  Measured on
@@ -993,8 +993,8 @@ void jg_gn_destroy(jg_gn* h) {
 
 int jg_gn_dims(jg_gn* h, int64_t* dims) {
     if (!h || !dims) return failg(1, "jg_gn_dims: bad argument");
-    dims[0] = h->m; dims[1] = h->nnzH; dims[2] = (int64_t)h->gi_col.size(); dims[3] = h->eng.S.n_entries;
-    dims[4] = h->eng.S.n_sched_terms; dims[5] = (int64_t)(h->eng.fact.size() + h->eng.S.top_launch.size()); dims[6] = (int64_t)h->eng.bwd.size();
+    dims[0] = h->m; dims[1] = h->nnzH; dims[2] = (int64_t)h->gi_col.size(); dims[3] = h->eng.plan->S.n_entries;
+    dims[4] = h->eng.plan->S.n_sched_terms; dims[5] = (int64_t)(h->eng.fact.size() + h->eng.plan->S.top_launch.size()); dims[6] = (int64_t)h->eng.bwd.size();
     dims[7] = h->nslots;
     return 0;
 }
@@ -1209,7 +1209,7 @@ int jg_gn_residual_test(jg_gn* h, double* max_nres, int32_t* index) {
     if (int rc = set_device(h)) return rc;
     constexpr int ROWS_PER = 256;
     if (!h->d_nres) {                                            // pair lists: every (slot, slot) of a row with its Z entry
-        const jg::BlockSymbolic& S = h->eng.S;
+        const jg::BlockSymbolic& S = h->eng.plan->S;
         std::vector<int> pp(h->m + 1, 0), pa, pb, pz;
         for (int r = 0; r < h->m; ++r) {
             const RowDesc& d = h->rows_host[r];

@@ -656,7 +656,7 @@ jg::GroupSel active_groups(jg_nr* h) { return jg::GroupSel{nullptr, h->d_glist, 
 // updates); the factorisation that follows must be told (h->level0_done).  Plain assemblies (getters, jg_nr_mismatch) leave it off.
 void launch_assemble(jg_nr* h, const jg::GroupSel& sel = jg::GroupSel{}, bool jac = true, double* pq_out = nullptr, int fd_mode = 0, const int* only_if = nullptr,
                      bool level0 = false) {
-    const bool pre = jac && level0 && h->eng.S.prefactor && h->d_rowtype_pre;
+    const bool pre = jac && level0 && h->eng.plan->S.prefactor && h->d_rowtype_pre;
     AsmArgs a{h->d_rowptr, h->d_col, h->d_GB, pre ? h->d_rowtype_pre : h->d_rowtype, h->d_dst, h->d_vm, h->d_va, h->d_p, h->d_q,
               h->d_ppos, h->d_pdg, h->d_pdb, h->eng.X, h->d_F, h->d_part, pq_out, sel, fd_mode ? h->d_R : nullptr, fd_mode, h->n, h->ld, h->mp, h->nchunk, h->batch, only_if,
               h->eng.W, h->eng.status};
@@ -933,14 +933,14 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
     // in place: the assembly kernel writes into the factor storage; bit 2: it also finishes the plan's level 0 (jg_symbolic.hpp: prefactor)
     rc = h->eng.create(n, rp.data(), cl.data(), h->ld, getenv("JG_NO_PREFACTOR") ? 1 : 1 | 4, h->stream);
     if (rc) { std::string m = h->eng.error; jg_nr_destroy(h); return fail(rc, m); }
-    if (jg::upload(&h->d_dst, h->eng.S.src_entry, err, h->stream)) { jg_nr_destroy(h); return fail(2, err); }
-    if (h->eng.S.prefactor) {                            // the row table of the assemblies that also finish the plan's level 0
+    if (jg::upload(&h->d_dst, h->eng.plan->S.src_entry, err, h->stream)) { jg_nr_destroy(h); return fail(2, err); }
+    if (h->eng.plan->S.prefactor) {                            // the row table of the assemblies that also finish the plan's level 0
         std::vector<int> rt(type, type + n);
-        for (int k = 0; k < (int)n; ++k) if (h->eng.S.pre_pivot[k]) rt[h->eng.S.perm[k]] |= (k + 1) << 2;
+        for (int k = 0; k < (int)n; ++k) if (h->eng.plan->S.pre_pivot[k]) rt[h->eng.plan->S.perm[k]] |= (k + 1) << 2;
         if (jg::upload(&h->d_rowtype_pre, rt, err, h->stream)) { jg_nr_destroy(h); return fail(2, err); }
     }
     h->eng.lanes = h->batch;
-    for (int64_t k = 0; k < h->nnzJ; ++k) h->jmap[k] = (int64_t)h->eng.S.src_entry[h->jmap[k] >> 2] * 4 + (h->jmap[k] & 3);
+    for (int64_t k = 0; k < h->nnzJ; ++k) h->jmap[k] = (int64_t)h->eng.plan->S.src_entry[h->jmap[k] >> 2] * 4 + (h->jmap[k] & 3);
     *out = h;
     return 0;
 }
@@ -973,8 +973,8 @@ void jg_nr_destroy(jg_nr* h) {
 
 int jg_nr_dims(jg_nr* h, int64_t* dims) {
     if (!h || !dims) return fail(1, "jg_nr_dims: bad argument");
-    dims[0] = h->dimJ; dims[1] = h->nnzJ; dims[2] = h->eng.S.n_entries; dims[3] = h->eng.S.n_sched_terms;
-    dims[4] = (int64_t)(h->eng.fact.size() + h->eng.S.top_launch.size());      // dependent launches of one factorisation
+    dims[0] = h->dimJ; dims[1] = h->nnzJ; dims[2] = h->eng.plan->S.n_entries; dims[3] = h->eng.plan->S.n_sched_terms;
+    dims[4] = (int64_t)(h->eng.fact.size() + h->eng.plan->S.top_launch.size());      // dependent launches of one factorisation
     dims[5] = (int64_t)h->eng.bwd.size();
     return 0;
 }
@@ -1405,7 +1405,7 @@ int jg_nr_get_jacobian(jg_nr* h, double* nzval) {
     if (int rc = set_device(h)) return rc;
     if (!h->jac_valid) { launch_assemble(h); h->jac_valid = true; }      // Jacobian at the current state
     NR_HIP(hipStreamSynchronize(h->stream));
-    std::vector<double> t((size_t)h->eng.S.n_entries * 4 * h->ld);     // the factor storage holds the Jacobian until the next factorisation
+    std::vector<double> t((size_t)h->eng.plan->S.n_entries * 4 * h->ld);     // the factor storage holds the Jacobian until the next factorisation
     NR_HIP(jg::sync_copy(t.data(), h->eng.X, t.size() * 8, hipMemcpyDeviceToHost, h->stream));
     for (int b = 0; b < h->batch; ++b)
         for (int64_t k = 0; k < h->nnzJ; ++k) nzval[(size_t)b * h->nnzJ + k] = t[(((size_t)(h->jmap[k] >> 2) * 2 + ((h->jmap[k] >> 1) & 1)) * h->ld + b) * 2 + (h->jmap[k] & 1)];
@@ -1663,7 +1663,7 @@ int jg_nr_time_kernel(jg_nr* h, int kernel, int reps, double* mean_ms) {
         NR_HIP(hipEventRecord(e0, h->stream));
         for (int r = 0; r < reps; ++r) {
             if (kernel == 0) launch_assemble(h, jg::GroupSel{}, true, nullptr, 0, nullptr, true);     // as the iteration runs it
-            else if (kernel == 1) { if (int rc = h->eng.factor(h->stream, nullptr, h->d_F, jg::GroupSel{}, h->eng.S.prefactor != 0)) return fail(rc, h->eng.error); }
+            else if (kernel == 1) { if (int rc = h->eng.factor(h->stream, nullptr, h->d_F, jg::GroupSel{}, h->eng.plan->S.prefactor != 0)) return fail(rc, h->eng.error); }
             else if (kernel == 3) hipLaunchKernelGGL(k_branch_quantities, dim3((h->nb + 15) / 16, h->ld / 64), dim3(64, 16), 0, h->stream, ba);
             else { if (int rc = h->eng.backsolve(h->stream, h->d_inc, none, jg::GroupSel{})) return fail(rc, h->eng.error); }
         }

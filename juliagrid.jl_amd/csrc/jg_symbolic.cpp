@@ -34,8 +34,8 @@ void elimination_order(int n, const std::vector<std::vector<int>>& adj0, std::ve
                        std::vector<std::vector<int>>& strct) {
     std::vector<std::vector<int>> adj = adj0;                  // sorted, alive neighbours only
     std::vector<char> done(n, 0);
-    std::vector<int> hv(n, 0), mark(n, -1), seen(n, -1);
-    std::vector<long long> cur(n, 0);
+    std::vector<int> hv(n, 0), mark(n, -1), seen(n, -1), hits(n, 0);
+    std::vector<long long> cur(n, 0), fillv(n, 0);             // fillv: the CURRENT fill of every alive vertex (exact, kept up to date)
     int stamp = 0;
     auto fill_of = [&](int v) -> long long {
         const std::vector<int>& nb = adj[v];
@@ -43,7 +43,12 @@ void elimination_order(int n, const std::vector<std::vector<int>>& adj0, std::ve
         ++stamp;
         for (int a : nb) mark[a] = stamp;
         long long present = 0;                                 // adjacent pairs inside the neighbourhood, counted twice
-        for (int a : nb) for (int w : adj[a]) if (mark[w] == stamp) ++present;
+        for (int a : nb) {                                     // (branch-free: the outcome of this test is a coin toss)
+            const std::vector<int>& aa = adj[a];
+            long long c = 0;
+            for (size_t x = 0; x < aa.size(); ++x) c += mark[aa[x]] == stamp;
+            present += c;
+        }
         return d * (d - 1) / 2 - present / 2;
     };
     long long wf = 20, wh = 0, wd = 0, wq = 1;                 // experiments: JG_ORDER="fill,height,degree,height^2" weights
@@ -51,10 +56,11 @@ void elimination_order(int n, const std::vector<std::vector<int>>& adj0, std::ve
         long long a, b, c, q;
         if (sscanf(e, "%lld,%lld,%lld,%lld", &a, &b, &c, &q) == 4) { wf = a; wh = b; wd = c; wq = q; }
     }
-    auto key = [&](int v) -> long long {                       // score, then degree, packed (degree < 2^20)
+    auto key_of = [&](int v) -> long long {                    // score, then degree, packed (degree < 2^20); fillv[v] must be current
         const long long d = (long long)adj[v].size(), h = hv[v];
-        return ((wf * fill_of(v) + wh * h + wd * d + wq * h * h) << 20) | std::min<long long>(d, (1 << 20) - 1);
+        return ((wf * fillv[v] + wh * h + wd * d + wq * h * h) << 20) | std::min<long long>(d, (1 << 20) - 1);
     };
+    auto key = [&](int v) -> long long { fillv[v] = fill_of(v); return key_of(v); };
     typedef std::pair<long long, int> Entry;
     std::priority_queue<Entry, std::vector<Entry>, std::greater<Entry>> heap;
     for (int v = 0; v < n; ++v) { cur[v] = key(v); heap.push(Entry(cur[v], v)); }
@@ -72,6 +78,21 @@ void elimination_order(int n, const std::vector<std::vector<int>>& adj0, std::ve
         order.push_back(v);
         std::vector<int> nb = std::move(adj[v]);
         std::vector<int>().swap(adj[v]);
+        if (fillv[v] == 0) {
+            // the neighbourhood of v is a clique already: no edge is created, so nobody outside it sees a change, and inside it a
+            // vertex a only loses v -- the pairs (v, w) with w a neighbour of a outside the clique were its missing edges:
+            // fill(a) -= deg(a) - |clique|  (deg(a) counted with v).  Exact, O(1) per neighbour: leaves and chains, most eliminations.
+            const long long c = (long long)nb.size();
+            for (int a : nb) {
+                std::vector<int>& aa = adj[a];
+                fillv[a] -= (long long)aa.size() - c;
+                aa.erase(std::lower_bound(aa.begin(), aa.end(), v));
+                hv[a] = std::max(hv[a], hv[v] + 1);
+                cur[a] = key_of(a); heap.push(Entry(cur[a], a));
+            }
+            strct[k] = std::move(nb);
+            continue;
+        }
         for (int a : nb) {                                     // v leaves, its neighbourhood becomes a clique
             std::vector<int>& aa = adj[a];
             merged.clear();
@@ -80,12 +101,17 @@ void elimination_order(int n, const std::vector<std::vector<int>>& adj0, std::ve
             for (int w : merged) if (w != v && w != a) aa.push_back(w);
             hv[a] = std::max(hv[a], hv[v] + 1);
         }
+        // whose score changed: the neighbours of v (degree, height, fill), and every vertex with at least TWO neighbours among them (its
+        // fill counts pairs of its neighbours that are not adjacent, and the only new edges run between neighbours of v); a vertex
+        // that touches the new clique in one point keeps its score exactly
         ++epoch;
         touched.clear();
-        for (int a : nb) {
-            if (seen[a] != epoch) { seen[a] = epoch; touched.push_back(a); }
-            for (int w : adj[a]) if (seen[w] != epoch) { seen[w] = epoch; touched.push_back(w); }
-        }
+        for (int a : nb) { seen[a] = epoch; hits[a] = 2; touched.push_back(a); }
+        for (int a : nb)
+            for (int w : adj[a]) {
+                if (seen[w] != epoch) { seen[w] = epoch; hits[w] = 1; }
+                else if (hits[w] == 1) { hits[w] = 2; touched.push_back(w); }
+            }
         for (int u : touched) { cur[u] = key(u); heap.push(Entry(cur[u], u)); }
         strct[k] = std::move(nb);
     }
@@ -158,6 +184,11 @@ void build_replay(const std::vector<int>& level, const std::vector<int>& work, i
     std::vector<std::vector<int>> by(nlev + 1);
     for (int i = 0; i < n_items; ++i) if (level[i] > 0) by[level[i]].push_back(i);
     segs.clear(); recs.clear();
+    {                                                             // the records of the whole table in one allocation (a lower bound is enough:
+        size_t est = 0;                                           // one record per T terms and per item, idle waves of the last chunks on top)
+        for (int i = 0; i < n_items; ++i) if (level[i] > 0) est += (size_t)std::max(1, (work[i] + T - 1) / T);
+        recs.reserve(est + est / 4 + 1024);
+    }
     n_levels = 0;
     for (int l = 1; l <= nlev; ++l) {
         std::vector<int>& it = by[l];
@@ -171,14 +202,14 @@ void build_replay(const std::vector<int>& level, const std::vector<int>& work, i
             if (wide && wide_cap > 0) cap = std::min(cap, wide_cap);
             return std::min(cap, pow2ceil(std::max(1, (work[i] + T - 1) / T)));
         };
-        if (locality)                                             // segments by waves per item (widest first); inside a segment the items
+        if (locality) {                                           // segments by waves per item (widest first); inside a segment the items
                                                                   // that share operands sit next to each other (same workgroup, same moment)
-            std::stable_sort(it.begin(), it.end(), [&](int x, int y) {
-                const int wx = wpi_of(x), wy = wpi_of(y);
-                if (wx != wy) return wx > wy;
-                return (*locality)[x] < (*locality)[y];
-            });
-        else
+            struct Key { int wpi; long long loc; int item; };     // (keys once per item, not twice per comparison)
+            std::vector<Key> keys(it.size());
+            for (size_t x = 0; x < it.size(); ++x) keys[x] = Key{wpi_of(it[x]), (*locality)[it[x]], it[x]};
+            std::stable_sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) { return a.wpi != b.wpi ? a.wpi > b.wpi : a.loc < b.loc; });
+            for (size_t x = 0; x < it.size(); ++x) it[x] = keys[x].item;
+        } else
             std::stable_sort(it.begin(), it.end(), [&](int x, int y) { return work[x] > work[y]; });   // heaviest first
         size_t p = 0;
         while (p < it.size()) {
@@ -689,12 +720,36 @@ int analyze(int n, const int* rowptr, const int* col, long long policy64, BlockS
             S.src_entry[p] = e;
         }
 
-    // update terms: pivot k contributes -L(i,k) U(k,j) to every (i,j) in struct(k)^2
-    S.t_ptr.assign(S.n_entries + 1, 0);
-    for (int k = 0; k < n; ++k) {
-        const std::vector<int>& s = strct[k];
-        for (int i : s) for (int j : s) S.t_ptr[find_in_row(S, i, j) + 1]++;
+    // update terms: pivot k contributes -L(i,k) U(k,j) to every (i,j) in struct(k)^2.  The entry of (i, j) is looked up ONCE per term
+    // (pivot-major list tgt: the count, the term lists and the dependency levels below all walk it) and by a merge of the sorted
+    // row i with the sorted struct(k), not by a binary search per pair; lrow / urow: the entries L(s_a, k), U(k, s_a) of pivot k.
+    std::vector<int> tgt, lrow, urow, sptr(n + 1, 0);
+    for (int k = 0; k < n; ++k) sptr[k + 1] = sptr[k] + (int)strct[k].size();
+    lrow.resize(sptr[n]); urow.resize(sptr[n]);
+    {
+        size_t nt = 0;
+        for (int k = 0; k < n; ++k) nt += strct[k].size() * strct[k].size();
+        tgt.resize(nt);
+        size_t q = 0;
+        for (int k = 0; k < n; ++k) {
+            const std::vector<int>& s = strct[k];
+            for (size_t a = 0; a < s.size(); ++a) {
+                const int i = s[a];
+                int e = S.row_ptr[i];
+                const int e1 = S.row_ptr[i + 1];
+                while (S.e_col[e] != k) ++e;                   // L(i, k): k precedes every member of struct(k) in row i
+                lrow[sptr[k] + a] = e;
+                for (size_t b = 0; b < s.size(); ++b) {        // struct(k) is inside row i (a clique): one forward scan
+                    while (e < e1 && S.e_col[e] != s[b]) ++e;
+                    tgt[q++] = e;
+                }
+            }
+            int e = S.diag[k];
+            for (size_t a = 0; a < s.size(); ++a) { while (S.e_col[e] != s[a]) ++e; urow[sptr[k] + a] = e; }
+        }
     }
+    S.t_ptr.assign(S.n_entries + 1, 0);
+    for (int t : tgt) S.t_ptr[t + 1]++;
     for (int e = 0; e < S.n_entries; ++e) S.t_ptr[e + 1] += S.t_ptr[e];
     S.n_terms = S.t_ptr[S.n_entries];
     S.t_a.assign((size_t)S.n_terms, 0);
@@ -702,18 +757,15 @@ int analyze(int n, const int* rowptr, const int* col, long long policy64, BlockS
     S.t_b.assign((size_t)S.n_terms, 0);
     {
         std::vector<int> fill(S.t_ptr.begin(), S.t_ptr.end() - 1);
-        std::vector<int> lid, uid;
+        size_t q = 0;
         for (int k = 0; k < n; ++k) {
-            const std::vector<int>& s = strct[k];
-            lid.resize(s.size()); uid.resize(s.size());
-            for (size_t a = 0; a < s.size(); ++a) { lid[a] = find_in_row(S, s[a], k); uid[a] = find_in_row(S, k, s[a]); }
-            for (size_t a = 0; a < s.size(); ++a)
-                for (size_t b = 0; b < s.size(); ++b) {
-                    int t = find_in_row(S, s[a], s[b]);
-                    S.t_a[fill[t]] = lid[a];
-                    S.t_d[fill[t]] = S.diag[k];
-                    S.t_b[fill[t]] = uid[b];
-                    fill[t]++;
+            const int ns = sptr[k + 1] - sptr[k], dk = S.diag[k];
+            const int* lid = lrow.data() + sptr[k];
+            const int* uid = urow.data() + sptr[k];
+            for (int a = 0; a < ns; ++a)
+                for (int b = 0; b < ns; ++b) {
+                    const int f = fill[tgt[q++]]++;
+                    S.t_a[f] = lid[a]; S.t_d[f] = dk; S.t_b[f] = uid[b];
                 }
         }
     }
@@ -723,22 +775,20 @@ int analyze(int n, const int* rowptr, const int* col, long long policy64, BlockS
     S.e_level.assign(S.n_entries, 0);
     {
         std::vector<int> acc(S.n_entries, 0);
+        size_t q = 0;
         for (int k = 0; k < n; ++k) {
-            const std::vector<int>& s = strct[k];
-            const int d = S.diag[k];
+            const int ns = sptr[k + 1] - sptr[k], d = S.diag[k];
+            const int* lid = lrow.data() + sptr[k];
+            const int* uid = urow.data() + sptr[k];
             // level 0 (policy bit 2): entries the producer leaves final -- no update terms and present in its pattern
             auto lvl = [&](int e) { return (S.prefactor && S.t_ptr[e + 1] == S.t_ptr[e] && S.e_src[e] >= 0) ? 0 : acc[e] + 1; };
             S.e_level[d] = lvl(d);
-            for (int j : s) {
-                const int u = find_in_row(S, k, j), l = find_in_row(S, j, k);
-                S.e_level[u] = lvl(u);
-                S.e_level[l] = lvl(l);
-            }
-            for (int i : s) {
-                const int li = std::max(S.e_level[find_in_row(S, i, k)], S.e_level[d]);
-                for (int j : s) {
-                    const int t = find_in_row(S, i, j);
-                    acc[t] = std::max(acc[t], std::max(li, S.e_level[find_in_row(S, k, j)]));
+            for (int a = 0; a < ns; ++a) { S.e_level[uid[a]] = lvl(uid[a]); S.e_level[lid[a]] = lvl(lid[a]); }
+            for (int a = 0; a < ns; ++a) {
+                const int li = std::max(S.e_level[lid[a]], S.e_level[d]);
+                for (int b = 0; b < ns; ++b) {
+                    const int t = tgt[q++];
+                    acc[t] = std::max(acc[t], std::max(li, S.e_level[uid[b]]));
                 }
             }
         }

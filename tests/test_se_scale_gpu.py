@@ -25,17 +25,50 @@ def _oracle_system(oracle, tables):
     return osys, vm, va
 
 
-def _compare_at_state(an, gn, jg, tag):
-    """increment! on both sides at the SAME state: H, residual, objective, increment."""
+def _normal_equations(gn, v, slack):
+    """gain = H' W H with the slack angle column removed and gain[slack, slack] = 1, rhs = H' W r (acStateEstimation.jl:878-904), in
+    scipy sparse f64, from the ORACLE's H, W and residual."""
+    import scipy.sparse as sp
+    n2 = gn.hcolptr.size - 1
+    H = sp.csc_matrix((v["jacobian"], gn.hrowval - 1, gn.hcolptr - 1), shape=(gn.m, n2)).tocsr()
+    W = sp.diags(gn.wdiag).tolil()
+    for r in np.flatnonzero(gn.woff):                              # 2x2 blocks of correlated PMUs: woff[r] couples rows r and r + 1
+        W[r, r + 1] = W[r + 1, r] = gn.woff[r]
+    W = W.tocsr()
+    keep = np.ones(n2); keep[slack - 1] = 0.0
+    Hs = H @ sp.diags(keep)
+    G = (Hs.T @ W @ Hs).tolil()
+    G[slack - 1, slack - 1] = 1.0
+    b = Hs.T @ (W @ v["residual"])
+    return G.tocsr(), b
+
+
+def _backward_error(G, b, x):
+    r = G @ x - b
+    return np.abs(r).max() / (abs(G).sum(axis=1).max() * np.abs(x).max() + np.abs(b).max())
+
+
+def _compare_at_state(an, gn, jg, tag, slack, inc_tol=1e-8):
+    """increment! on both sides at the SAME state: H, residual, objective to 1e-12; the increment to inc_tol.  On a gain matrix
+    whose condition number times the unit roundoff exceeds inc_tol (config 4 from the flat start: PMU weights 1e8 beside 1e4) two
+    backward-stable solvers need not agree any closer than that -- there the statement is the one a solver can be held to: the
+    device's increment solves the oracle's normal equations with a backward error of rounding size, no worse than the oracle's own."""
     mx = jg.incrementSE_(an)
     mo = gn.increment()
     v = gn.vectors()
     H = an.jacobian.nzval
     assert np.abs(H - v["jacobian"]).max() <= 1e-12 * np.abs(v["jacobian"]).max(), tag
-    assert np.abs(an.residual - v["residual"]).max() <= 1e-12 * max(1.0, np.abs(v["residual"]).max()), tag
+    # a residual is z - h(x) and h sums terms of the size of the row's partials (|Y| reaches 1e4 on low-impedance branches): its rounding
+    # scales with those terms, not with the difference that is left
+    assert np.abs(an.residual - v["residual"]).max() <= 1e-12 * max(1.0, np.abs(v["residual"]).max(), np.abs(v["jacobian"]).max()), tag
     assert abs(an.objective - gn.objective) <= 1e-9 * max(1.0, gn.objective), tag
-    assert np.abs(an.increment - v["increment"]).max() <= 1e-8 * max(1.0, np.abs(v["increment"]).max()), tag
-    assert abs(mx - mo) <= 1e-8 * max(1.0, mo), tag
+    G, b = _normal_equations(gn, v, slack)
+    be_dev, be_orc = _backward_error(G, b, np.asarray(an.increment)), _backward_error(G, b, v["increment"])
+    diff = np.abs(an.increment - v["increment"]).max() / max(1.0, np.abs(v["increment"]).max())
+    print(f"[{tag}] increment: device vs oracle {diff:.2e}; backward error device {be_dev:.2e}, oracle {be_orc:.2e}")
+    assert be_dev <= 1e-13 and be_dev <= 10 * be_orc + 1e-15, (tag, be_dev, be_orc)
+    assert diff <= inc_tol, (tag, diff)
+    assert abs(mx - mo) <= inc_tol * max(1.0, mo), tag
 
 
 def _check_model(an, gn):
@@ -49,7 +82,8 @@ def _check_model(an, gn):
 def _noisy(mon, rng):
     """z + sigma N(0, 1) on every raw meter quantity of the container, in place (measurement/utility.jl:70-73 with noise = true)."""
     for g in (mon.voltmeter.magnitude, mon.ammeter.magnitude, mon.wattmeter.active, mon.varmeter.reactive, mon.pmu.magnitude, mon.pmu.angle):
-        g.mean[:] = g.mean + np.sqrt(g.variance) * rng.standard_normal(g.mean.size)
+        mean = np.asarray(g.mean, dtype=float)
+        g.mean[:] = list(mean + np.sqrt(np.asarray(g.variance, dtype=float)) * rng.standard_normal(mean.size))
 
 
 def test_config4_noisy_realisation_against_the_oracle(jg, oracle):
@@ -70,10 +104,11 @@ def test_config4_noisy_realisation_against_the_oracle(jg, oracle):
     gn = oracle.OracleGN(osys, _table_of(oracle, mon), np.ones(n), np.zeros(n))
     _check_model(an, gn)
     an.setVoltage(np.ones(n), np.zeros(n))
-    _compare_at_state(an, gn, jg, "flat start")
+    # (measured: the two increments differ by 7e-5 from the flat start -- cond(gain) ~ 1e11 -- with backward errors of ~1e-17 on both sides)
+    _compare_at_state(an, gn, jg, "flat start", osys.slack, inc_tol=1e-3)
     jg.solveSE_(an)                                               # second iterate: the device's own state, handed to the oracle
     gn.set_voltage(np.asarray(an.voltage.magnitude), np.asarray(an.voltage.angle))
-    _compare_at_state(an, gn, jg, "second iterate")
+    _compare_at_state(an, gn, jg, "second iterate", osys.slack, inc_tol=1e-3)
     # the whole estimation from the flat start on both sides
     an.setVoltage(np.ones(n), np.zeros(n))
     jg.stateEstimation_(an, iteration=40, tolerance=1e-8)
@@ -103,6 +138,8 @@ def test_every_type_code_on_case1354pegase_with_noise(jg, oracle):
     rng = np.random.Generator(np.random.PCG64(4))
     rows = []
     for (kind, loc, index, m1, v1, s1, m2, v2, s2, fl) in tab.rows:
+        if kind in (2, 5) and loc != 0 and m1 < 5e-2:             # no current meter on a branch that carries (almost) no current: its squared
+            continue                                               # reading has variance 4 z^2 sigma^2 -> 0 (errorVariance in the reference too)
         m1 = m1 + np.sqrt(v1) * rng.standard_normal()
         if kind == 5:
             m2 = m2 + np.sqrt(v2) * rng.standard_normal()
@@ -112,18 +149,21 @@ def test_every_type_code_on_case1354pegase_with_noise(jg, oracle):
     tab.rows = rows
     s = _system_like(jg, t, osys)
     n = s.bus.number
+    # start: the case's stored voltages (what gaussNewton(monitoring) takes, acStateEstimation.jl:43-75).  Not the flat start: a branch
+    # without charging carries no current there and the partials of a current MAGNITUDE divide by it -- in the reference too
+    v0, a0 = np.asarray(t["bus_vm"], dtype=float), np.asarray(t["bus_va"], dtype=float)
     an = jg.gaussNewton(_mirror(jg, s, tab))
-    gn = oracle.OracleGN(osys, tab, np.ones(n), np.zeros(n))
+    gn = oracle.OracleGN(osys, tab, v0, a0)
     assert set(int(c) for c in np.unique(gn.type)) >= set(range(1, 22)), sorted(np.unique(gn.type))
     _check_model(an, gn)
-    an.setVoltage(np.ones(n), np.zeros(n))
-    _compare_at_state(an, gn, jg, "flat start")
+    an.setVoltage(v0, a0)
+    _compare_at_state(an, gn, jg, "stored start", osys.slack, inc_tol=1e-5)
     jg.solveSE_(an)
     gn.set_voltage(np.asarray(an.voltage.magnitude), np.asarray(an.voltage.angle))
-    _compare_at_state(an, gn, jg, "second iterate")
-    an.setVoltage(np.ones(n), np.zeros(n))
+    _compare_at_state(an, gn, jg, "second iterate", osys.slack, inc_tol=1e-5)
+    an.setVoltage(v0, a0)
     jg.stateEstimation_(an, iteration=40, tolerance=1e-8)
-    gn2 = oracle.OracleGN(osys, tab, np.ones(n), np.zeros(n))
+    gn2 = oracle.OracleGN(osys, tab, v0, a0)
     assert gn2.state_estimation(40, 1e-8) == 0 and an.status == 0 and gn2.iteration == an.method.iteration
     v = gn2.vectors()
     assert np.abs(an.voltage.magnitude - v["magnitude"]).max() <= 1e-8 and np.abs(an.voltage.angle - v["angle"]).max() <= 1e-8
