@@ -29,6 +29,12 @@ typedef struct jg_gn jg_gn;
 const char* jg_last_error(void);
 /* Number of visible HIP devices (<0 on runtime failure). */
 int jg_device_count(void);
+/* Engines that factorise the same block pattern under the same plan policy on the same device share ONE symbolic analysis and ONE
+ * device copy of its replay tables through a process-wide cache (csrc/jg_engine.hpp: SharedPlan; the reference redoes its symbolic
+ * factorisation in every newtonRaphson() / gaussNewton() call).  jg_plan_cache_clear drops the cache's own references -- live handles keep
+ * their plans -- so that the next jg_*_create pays a full analysis again (benchmarks measure that cost with it).  JG_PLAN_CACHE=0 in the
+ * environment switches the cache off. */
+void jg_plan_cache_clear(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Newton-Raphson AC power flow

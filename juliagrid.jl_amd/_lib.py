@@ -115,6 +115,8 @@ def lib():
     L.jg_nr_destroy.restype = None
     L.jg_gn_destroy.argtypes = [VP]
     L.jg_gn_destroy.restype = None
+    L.jg_plan_cache_clear.argtypes = []
+    L.jg_plan_cache_clear.restype = None
     L.jg_comm_destroy.argtypes = [VP]
     L.jg_comm_destroy.restype = None
     L.jg_plan_destroy.argtypes = [VP]

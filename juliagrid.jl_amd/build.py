@@ -29,7 +29,7 @@ def build(force=False, verbose=False):
         return LIB
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-value", "-Wno-unused-result", "-Wno-pass-failed"] + os.environ.get("JG_EXTRA_HIPCC_FLAGS", "").split() + ["-o", LIB + ".tmp"] + srcs + ["-ldl"]
+           "-Wno-unused-value", "-Wno-unused-result", "-Wno-pass-failed"] + os.environ.get("JG_EXTRA_HIPCC_FLAGS", "").split() + ["-o", LIB + ".tmp"] + srcs + ["-ldl", "-pthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

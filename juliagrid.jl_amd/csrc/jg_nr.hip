@@ -619,6 +619,7 @@ struct jg_nr {
     double* d_vm = nullptr; double* d_va = nullptr; double* d_p = nullptr; double* d_q = nullptr;
     int* d_ppos = nullptr; double* d_pdg = nullptr; double* d_pdb = nullptr;
     int* d_dst = nullptr; double* d_F = nullptr; double* d_inc = nullptr; double* d_part = nullptr;
+    double* d_stage = nullptr; size_t stage_bytes = 0;           // host rows on their way to a [n][ld] array (put_bus_array)
     double* d_normp = nullptr; double* d_normq = nullptr; double* d_params = nullptr;
     double* d_vm0 = nullptr; double* d_va0 = nullptr;   // snapshot of the start point
     int* d_active = nullptr; int* d_iters = nullptr; int* d_status = nullptr; int* d_counter = nullptr; int* d_group = nullptr;
@@ -684,13 +685,46 @@ void launch_check(jg_nr* h, int mode, const int* group = nullptr) {
 }
 
 // host [batch][n] (or one [n] broadcast) -> device [n][ld]
-int put_bus_array(jg_nr* h, double* dst, const double* src, int64_t stride) {
-    std::vector<double> t((size_t)h->n * h->ld, 0.0);
-    for (int b = 0; b < h->ld; ++b) {
-        const double* s = src + (size_t)(b < h->batch ? b : h->batch - 1) * (size_t)stride;   // pad with last scenario
-        for (int i = 0; i < h->n; ++i) t[(size_t)i * h->ld + b] = s[i];
+// [rows][n] (scenario-major, as the host hands it over; rows = 1: one row for every scenario) -> dst [n][ld]; lanes beyond the batch
+// repeat the last scenario.  64 x 64 tiles through LDS: contiguous reads along the bus index, contiguous writes along the lanes.
+__global__ __launch_bounds__(512) void k_spread_bus(const double* src, double* dst, int n, int ld, int batch, int rows) {
+    __shared__ double tile[64][65];
+    const int i0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+    for (int r = threadIdx.y; r < 64; r += blockDim.y) {
+        const int b = min(min(b0 + r, batch - 1), rows - 1), i = i0 + threadIdx.x;
+        tile[r][threadIdx.x] = i < n ? src[(size_t)b * n + i] : 0.0;
     }
-    NR_HIP(jg::sync_copy(dst, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    __syncthreads();
+    for (int r = threadIdx.y; r < 64; r += blockDim.y) {
+        const int i = i0 + r, b = b0 + threadIdx.x;
+        if (i < n && b < ld) dst[(size_t)i * ld + b] = tile[threadIdx.x][r];
+    }
+}
+
+// host [batch][n] (stride n) or [n] (stride 0: every scenario the same) -> device [n][ld].  The rows go up as they are (80 KB for one row
+// of a 10 000-bus grid; the host-side transposition to [n][ld] that used to happen here moved 5 MB per array even for one scenario) and
+// a kernel spreads them over the lanes.
+int put_bus_array(jg_nr* h, double* dst, const double* src, int64_t stride) {
+    const int rows = stride == 0 ? 1 : h->batch;
+    if (stride != 0 && stride != h->n) {                         // a caller's own row pitch: the general (slow) way
+        std::vector<double> t((size_t)h->n * h->ld, 0.0);
+        for (int b = 0; b < h->ld; ++b) {
+            const double* s = src + (size_t)(b < h->batch ? b : h->batch - 1) * (size_t)stride;   // pad with last scenario
+            for (int i = 0; i < h->n; ++i) t[(size_t)i * h->ld + b] = s[i];
+        }
+        NR_HIP(jg::sync_copy(dst, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        return 0;
+    }
+    const size_t need = (size_t)rows * h->n * sizeof(double);
+    if (need > h->stage_bytes) {
+        hipFree(h->d_stage); h->d_stage = nullptr; h->stage_bytes = 0;
+        NR_HIP(hipMalloc((void**)&h->d_stage, need));
+        h->stage_bytes = need;
+    }
+    NR_HIP(hipMemcpyAsync(h->d_stage, src, need, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_spread_bus, dim3((h->n + 63) / 64, h->ld / 64), dim3(64, 8), 0, h->stream, (const double*)h->d_stage, dst, h->n, h->ld, h->batch, rows);
+    NR_HIP(hipGetLastError());
+    NR_HIP(hipStreamSynchronize(h->stream));
     return 0;
 }
 
@@ -794,6 +828,8 @@ int build_graphs(jg_nr* h) {
 extern "C" {
 
 const char* jg_last_error(void) { return g_error.c_str(); }
+
+void jg_plan_cache_clear(void) { jg::clear_plan_cache(); }
 
 int jg_device_count(void) {
     int c = 0;
@@ -955,6 +991,7 @@ void jg_nr_destroy(jg_nr* h) {
     if (h->graphA) hipGraphDestroy(h->graphA);
     if (h->graphB) hipGraphDestroy(h->graphB);
     h->eng.destroy();
+    hipFree(h->d_stage);
     hipFree(h->d_R); hipFree(h->d_inc2[0]); hipFree(h->d_inc2[1]);
     if (h->execFA) hipGraphExecDestroy(h->execFA);
     if (h->execFB) hipGraphExecDestroy(h->execFB);

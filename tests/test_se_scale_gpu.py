@@ -56,11 +56,28 @@ def _compare_at_state(an, gn, jg, tag, slack, inc_tol=1e-8):
     mx = jg.incrementSE_(an)
     mo = gn.increment()
     v = gn.vectors()
-    H = an.jacobian.nzval
-    assert np.abs(H - v["jacobian"]).max() <= 1e-12 * np.abs(v["jacobian"]).max(), tag
+    J = an.jacobian
+    H, hmax = J.nzval, np.abs(v["jacobian"]).max()
+    # Rows of current MAGNITUDE and ANGLE (type codes 2-5, 14, 15): the reference's own formulas (equations.jl:279-458) form
+    # I^2 = A Vi^2 + B Vj^2 - 2 Vi Vj (C cos - D sin) from terms of size (|y| V)^2 -- 1e6 .. 1e9 on case1354pegase -- that cancel down to
+    # I^2 ~ 1e-2: a one-ulp difference in a term (the oracle is plain C without contraction, the device fuses multiply-adds) comes out
+    # amplified by (|y| V / I)^2 in h and once more through the division by I in its partials.  Measured (tools/se_dbg.py): types
+    # 2 / 3 |dH| 1.4e-3 at |H| 2.5e3, |dh| 2.8e-8; types 4 / 5 3.7e-9 / 1.0e-8; types 14 / 15 6e-7 at 5e4; every other type code <= 4e-12
+    # at |H| ~ 1e4.  So: 1e-12 of the largest entry everywhere else, 1e-6 of the row's own scale on the current rows.
+    cur = np.isin(gn.type, (2, 3, 4, 5, 14, 15))
+    ent_cur = cur[J.rowval - 1]
+    dH = np.abs(H - v["jacobian"])
+    assert dH[~ent_cur].max() <= 1e-12 * hmax, tag
+    if ent_cur.any():
+        rowmax = np.zeros(gn.m)
+        np.maximum.at(rowmax, J.rowval - 1, np.abs(v["jacobian"]))
+        assert (dH[ent_cur] <= 1e-6 * rowmax[J.rowval - 1][ent_cur]).all(), tag
     # a residual is z - h(x) and h sums terms of the size of the row's partials (|Y| reaches 1e4 on low-impedance branches): its rounding
     # scales with those terms, not with the difference that is left
-    assert np.abs(an.residual - v["residual"]).max() <= 1e-12 * max(1.0, np.abs(v["residual"]).max(), np.abs(v["jacobian"]).max()), tag
+    dr = np.abs(an.residual - v["residual"])
+    assert dr[~cur].max() <= 1e-12 * max(1.0, np.abs(v["residual"]).max(), hmax), tag
+    if cur.any():
+        assert dr[cur].max() <= 1e-6, tag
     assert abs(an.objective - gn.objective) <= 1e-9 * max(1.0, gn.objective), tag
     G, b = _normal_equations(gn, v, slack)
     be_dev, be_orc = _backward_error(G, b, np.asarray(an.increment)), _backward_error(G, b, v["increment"])
