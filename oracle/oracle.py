@@ -29,10 +29,35 @@ def build(force=False):
     return so
 
 
+def build_fast():
+    """A second build of the same sources for the cpu_baseline legs of bench.py ONLY: `-O3 -march=native`, contraction allowed -- the
+    parity checks keep the `-O2 -ffp-contract=off` build.  Compiled on the box it runs on (the flags are per CPU): the file name
+    carries a hash of the CPU's model and flags, so a copy that travelled from another machine is never loaded."""
+    import hashlib
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu = "".join(l for l in f if l.startswith(("model name", "flags")))[:20000]
+    except OSError:
+        cpu = "unknown"
+    tag = hashlib.sha1(cpu.encode()).hexdigest()[:10]
+    out = os.path.join(_HERE, "_fast")
+    os.makedirs(out, exist_ok=True)
+    so = os.path.join(out, f"libjg_oracle_fast_{tag}.so")
+    srcs = [os.path.join(_HERE, f) for f in ("jg_oracle.c", "jg_oracle_se.c")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-std=c99", "-shared", "-o", so + ".tmp"] + srcs + ["-lm"])
+        os.replace(so + ".tmp", so)
+    return so
+
+
+FAST_BUILD = False          # True once lib() has loaded the -O3 -march=native build (JG_ORACLE_FAST=1: bench.py's baseline legs)
+
+
 def lib():
-    global _LIB
+    global _LIB, FAST_BUILD
     if _LIB is None:
-        L = C.CDLL(build())
+        FAST_BUILD = os.environ.get("JG_ORACLE_FAST") == "1"
+        L = C.CDLL(build_fast() if FAST_BUILD else build())
         L.jgo_ac_model.restype = C.c_int64
         L.jgo_ac_model.argtypes = [C.c_int64, C.c_int64, I64P, I64P, I8P] + [F64P] * 8 + [I64P, I64P] + [F64P] * 5
         L.jgo_initialize_ac_power_flow.restype = C.c_int64
