@@ -1036,8 +1036,35 @@ int jg_nr_set_voltage(jg_nr* h, const double* vm, const double* va, int64_t stri
     return 0;
 }
 
+// device [n][ld] -> device [batch][n] (64 x 64 tiles: contiguous on both sides)
+__global__ __launch_bounds__(512) void k_gather_bus(const double* src, double* dst, int n, int ld, int batch) {
+    __shared__ double tile[64][65];
+    const int i0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+    for (int r = threadIdx.y; r < 64; r += blockDim.y) {
+        const int i = i0 + r, b = b0 + threadIdx.x;
+        tile[r][threadIdx.x] = (i < n && b < ld) ? src[(size_t)i * ld + b] : 0.0;
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 64; r += blockDim.y) {
+        const int b = b0 + r, i = i0 + threadIdx.x;
+        if (b < batch && i < n) dst[(size_t)b * n + i] = tile[threadIdx.x][r];
+    }
+}
+
 static int get_bus_array(jg_nr* h, const double* src, double* dst, int comps) {
     // device [n][ld][comps] -> host [batch][n*comps]
+    if (comps == 1) {                                            // transposed on the device, then ONE copy of exactly the rows asked for
+        const size_t need = (size_t)h->batch * h->n * sizeof(double);
+        if (need > h->stage_bytes) {
+            hipFree(h->d_stage); h->d_stage = nullptr; h->stage_bytes = 0;
+            NR_HIP(hipMalloc((void**)&h->d_stage, need));
+            h->stage_bytes = need;
+        }
+        hipLaunchKernelGGL(k_gather_bus, dim3((h->n + 63) / 64, h->ld / 64), dim3(64, 8), 0, h->stream, src, h->d_stage, h->n, h->ld, h->batch);
+        NR_HIP(hipGetLastError());
+        NR_HIP(jg::sync_copy(dst, h->d_stage, need, hipMemcpyDeviceToHost, h->stream));
+        return 0;
+    }
     const size_t rows = (size_t)h->n * comps;
     std::vector<double> t(rows * h->ld);
     NR_HIP(jg::sync_copy(t.data(), src, t.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -72,7 +72,7 @@ int64_t jg_plan_export(jg_plan* p, int which, int32_t* out, int64_t cap) {
     }
     if (!out) return (int64_t)v->size();
     if ((int64_t)v->size() > cap) return -1;
-    std::memcpy(out, v->data(), v->size() * sizeof(int));
+    if (!v->empty()) std::memcpy(out, v->data(), v->size() * sizeof(int));     // (an empty vector may hand out a null pointer: UBSan, tools/asan_plan.sh)
     return (int64_t)v->size();
 }
 

@@ -214,7 +214,11 @@ def _push_voltage(an: AcPowerFlow, vm, va):
     if vm.ndim == 2 and vm.shape[0] != an.batch:
         raise ValueError("voltage batch dimension mismatch")
     _lib.check(_lib.lib().jg_nr_set_voltage(an._h, vm.reshape(-1), va.reshape(-1), stride))
-    an._pull_voltage()
+    # the host mirror is what was just sent (no read-back: 82 MB and a host-side transposition for 512 scenarios of a 10 000-bus grid)
+    if vm.ndim == 1 and an.batch > 1:
+        an.voltage.magnitude, an.voltage.angle = np.broadcast_to(vm, (an.batch, n)).copy(), np.broadcast_to(va, (an.batch, n)).copy()
+    else:
+        an.voltage.magnitude, an.voltage.angle = an._shape(vm.reshape(an.batch, n).copy()), an._shape(va.reshape(an.batch, n).copy())
 
 
 def setInjection_(an: AcPowerFlow, active=None, reactive=None):

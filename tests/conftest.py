@@ -46,9 +46,10 @@ def jg():
     # torch ships its own copy of the HIP runtime under the same soname: when a process uses both torch and libjgrid_hip.so,
     # torch has to be imported first so that both bind to ONE runtime (bench.py does the same); loading ours first and torch
     # later leaves torch without devices ("No HIP GPUs are available").
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    if not os.environ.get("JG_PLAN_LIB"):            # (a sanitizer run of the plan code preloads libasan: torch does not survive that)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     import juliagrid.jl_amd as jg
     return jg
