@@ -157,3 +157,48 @@ def pegaseShaped(n=9241, nb=16049, ng=1445, seed=9241, load_scale=0.2):
 def case9241synth():
     """The grid standing in for case9241pegase in BASELINE.json's configurations."""
     return pegaseShaped(**PEGASE9241)
+
+
+def tiledGrid(tables, copies, slack_active=None, seed=0, jitter=0.005, tie_x=0.05):
+    """A grid of `copies` x n buses built from a solved case: `copies` instances of `tables`, the slack bus of instance c tied to the
+    slack bus of instance c + 1 by one line (x = tie_x pu), ONE slack (instance 0; the other former slack buses become PV buses whose
+    unit produces `slack_active` = the slack's active OUTPUT in the solved single case, pu -- the caller computes it, e.g. from
+    power!(analysis) -- so that the ties carry next to nothing and the stored voltages stay a good start), branch reactances jittered by
+    +-`jitter` (seeded) so that the instances are not bit-identical.  Stands in for the reference's 25 000 / 70 000 / 82 000-bus datasets
+    (docs/src/examples/powerSystemDatasets.md:13-15: not shipped, `.MISSING_LARGE_BLOBS`): same table layout, sizes beyond 10 000 buses
+    for the symbolic analysis, the int32 tables and the memory plan."""
+    t = {k: np.array(v) for k, v in tables.items()}
+    n, nb, ng = t["bus_type"].size, t["br_from"].size, t["gen_bus"].size
+    slack = int(np.flatnonzero(t["bus_type"] == 3)[0]) + 1
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = {"base_power": t["base_power"].copy()}
+    for k in t:
+        if k.startswith("bus_"):
+            out[k] = np.tile(t[k], copies)
+    for c in range(1, copies):
+        out["bus_type"][c * n + slack - 1] = 2
+    br = {k: np.tile(t[k], copies) for k in t if k.startswith("br_")}
+    off_b = np.repeat(np.arange(copies) * n, nb)
+    br["br_from"] = br["br_from"] + off_b
+    br["br_to"] = br["br_to"] + off_b
+    br["br_x"] = br["br_x"] * (1.0 + jitter * (2.0 * rng.random(copies * nb) - 1.0))
+    ties = copies - 1
+    tie = {"br_from": np.array([c * n + slack for c in range(ties)], dtype=np.int64),
+           "br_to": np.array([(c + 1) * n + slack for c in range(ties)], dtype=np.int64),
+           "br_status": np.ones(ties, dtype=np.int8), "br_r": np.full(ties, 0.1 * tie_x), "br_x": np.full(ties, tie_x),
+           "br_g": np.zeros(ties), "br_b": np.zeros(ties), "br_tap": np.ones(ties), "br_shift": np.zeros(ties)}
+    for k in br:
+        out[k] = np.concatenate([br[k], tie[k].astype(br[k].dtype)])
+    gen = {k: np.tile(t[k], copies) for k in t if k.startswith("gen_")}
+    gen["gen_bus"] = gen["gen_bus"] + np.repeat(np.arange(copies) * n, ng)
+    if slack_active is not None:                      # the units on a former slack bus now hold the output the slack had in the solved case
+        on = np.flatnonzero((t["gen_bus"] == slack) & (t["gen_status"] == 1))
+        if on.size:
+            share = np.full(on.size, float(slack_active) / on.size)
+            for c in range(1, copies):
+                gen["gen_pg"][c * ng + on] = share
+    out.update(gen)
+    for k in t:
+        if k not in out:
+            out[k] = np.tile(t[k], copies) if np.ndim(t[k]) and t[k].size in (n, nb, ng) else t[k].copy()
+    return out

@@ -52,3 +52,25 @@ def test_factor_structure_is_grid_like(jg):
     front = np.diff(plan.get("u_ptr")).max()
     assert 15 <= front <= 80
     assert plan.get("e_row").size <= 3 * Y.nnz
+
+
+def test_tiled_grid_shape_and_determinism(oracle):
+    """tiledGrid: 7 tied instances of case_ACTIVSg10k (stands in for the reference's 70 000-bus dataset): table sizes, one slack, the
+    ties, seeded jitter, and the acceptance rule of every stand-in -- the oracle's Newton-Raphson converges from the stored start."""
+    from conftest import load_case
+    from juliagrid.jl_amd.synthetic import tiledGrid
+    t = load_case("case_ACTIVSg10k")
+    o = oracle.OracleNR(oracle.OracleSystem(t))
+    assert o.power_flow() == 0
+    vm, va = o.voltage()
+    slack = int(np.flatnonzero(t["bus_type"] == 3)[0])
+    p_slack = oracle.exact_quantities(oracle.OracleSystem(t), vm, va)[1][slack, 0] + t["bus_pd"][slack]
+    a = tiledGrid(t, 7, slack_active=p_slack)
+    b = tiledGrid(t, 7, slack_active=p_slack)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    n, nb, ng = t["bus_type"].size, t["br_from"].size, t["gen_bus"].size
+    assert a["bus_type"].size == 7 * n and a["br_from"].size == 7 * nb + 6 and a["gen_bus"].size == 7 * ng
+    assert int(np.sum(a["bus_type"] == 3)) == 1 and a["br_from"].max() <= 7 * n and a["gen_bus"].max() <= 7 * n
+    assert not np.array_equal(a["br_x"][:nb], a["br_x"][nb:2 * nb])            # instances are not bit-identical
+    big = oracle.OracleNR(oracle.OracleSystem(a))
+    assert big.power_flow(iteration=20, tolerance=1e-8) == 0 and big.iteration <= 10
