@@ -559,12 +559,22 @@ constexpr int TOP_THREADS = 320;        // 16 x 16 bulk threads + the pivot wave
 // A 5-wave workgroup puts two waves on one SIMD, which caps a CU at 2 (CLS = 3) or 1 (CLS = 4) workgroups; four waves sit one
 // per SIMD: 4 resp. 2 workgroups.  A lone workgroup (small batches) is faster WITH the pivot wave (its chain runs beside the bulk
 // update), so the launch picks the variant by its size (Engine::factor).
-template <int CLS, bool PW>
-__global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves_per_eu(CLS == 4 ? 2 : 4))) void k_fact_top(TopArgs a) {
+// FUSE (no pivot wave): TWO pivots per barrier.  Besides row / column / factorised block of pivot q the owners publish the row and
+// column of pivot q + 1 and its diagonal block as they stand BEFORE pivot q is applied; every thread then forms, for its own rows and
+// columns, L(i, q+1) = L0(i, q+1) - L(i, q) z_q(q+1), U(q+1, c) = U0(q+1, c) - L(q+1, q) z_q(c) and the factorised D(q+1) itself -- the
+// very operations, in the very order, that the owners of those blocks perform in the one-pivot step (same bits) -- and applies both
+// pivots to its blocks.  A third more arithmetic per pivot, half the barriers and half the publish / read round trips: the step is
+// bound by those, not by the arithmetic.
+template <int CLS, bool PW, bool FUSE = false>
+__global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves_per_eu(CLS == 4 || (FUSE && CLS == 3) ? 2 : 4))) void k_fact_top(TopArgs a) {
+    static_assert(!(PW && FUSE), "the fused step has no pivot wave");
     __shared__ __attribute__((aligned(16))) double Dbuf[2][4];         // factorised pivot of the current / next step
     __shared__ __attribute__((aligned(16))) double Ubuf[2][64 * 4];    // pivot row  U(q, c)
     __shared__ __attribute__((aligned(16))) double Lbuf[2][64 * 4];    // pivot column Lh(i, q)
     __shared__ __attribute__((aligned(16))) double Dini[64 * 4];       // the chain's diagonal blocks as loaded (for the pivot wave)
+    __shared__ __attribute__((aligned(16))) double U1buf[FUSE ? 2 : 1][FUSE ? 64 * 4 : 4];   // FUSE: row / column / diagonal block of the pair's
+    __shared__ __attribute__((aligned(16))) double L1buf[FUSE ? 2 : 1][FUSE ? 64 * 4 : 4];   // SECOND pivot, not yet touched by the first
+    __shared__ __attribute__((aligned(16))) double Sbuf[2][4];
     int grp, x;
     if (!map_block(a.sel, a.ld, a.ntasks * a.lpg, grp, x)) return;
     const int ti = x / a.lpg;
@@ -657,6 +667,11 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
                 if (i == 0) lds_set(Ubuf[0], j, j > 0 ? T[r][c] : zero);
                 if (j == 0) lds_set(Lbuf[0], i, i > 0 ? T[r][c] : zero);
                 if (i == j && i < m) lds_set(Dini, i, T[r][c]);
+                if (FUSE) {
+                    if (i == 1) lds_set(U1buf[0], j, j > 1 ? T[r][c] : zero);
+                    if (j == 1) lds_set(L1buf[0], i, i > 1 ? T[r][c] : zero);
+                    if (i == 1 && j == 1) lds_set(Sbuf[0], 0, T[r][c]);
+                }
             }
         if (tid == 0) {
             const Blk d0 = factor_diag(T[0][0], bad, row_max(T[0][0]));
@@ -669,11 +684,116 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
         if (lane < m) { mydiag = lds_get(Dini, lane); const double2 rm = row_max(mydiag); myref_x = rm.x; myref_y = rm.y; }
         if (lane == 0) mydiag = lds_get(Dbuf[0], 0);
     }
+    int q_done = 0;                                              // pivots finished by fused steps
+    if constexpr (FUSE) {
+        for (int qv = 0; qv + 1 < m; qv += 2) {
+            const int q = uniform(qv), q1 = q + 1;
+            const int cur = (q >> 1) & 1, nxt = cur ^ 1;
+            Blk D = lds_get(Dbuf[cur], 0);
+            D = Blk{uniform_d(D.v00), uniform_d(D.v01), uniform_d(D.v10), uniform_d(D.v11)};
+            const int sw = uniform(D.v10 > 2.0 ? 1 : 0);
+            const double dl = D.v10 - 4.0 * sw;
+            auto zcol = [&](const double* ub, int k) {           // z = D(q)^-1 U(q, k)
+                const double2* p = (const double2*)(ub + (size_t)k * 4);
+                const double2 a0 = p[sw], a1 = p[sw ^ 1];
+                Blk z;
+                z.v10 = (a1.x - dl * a0.x) * D.v11; z.v00 = (a0.x - D.v01 * z.v10) * D.v00;
+                z.v11 = (a1.y - dl * a0.y) * D.v11; z.v01 = (a0.y - D.v01 * z.v11) * D.v00;
+                return z;
+            };
+            // what the owners of row / column / diagonal q + 1 would do in step q: here every thread does it for itself
+            const Blk zq1 = zcol(Ubuf[cur], q1);                 // z_q(q + 1)
+            const Blk Lq1q = lds_get(Lbuf[cur], q1);             // Lh(q + 1, q)
+            Blk S1 = lds_get(Sbuf[cur], 0);
+            blk_sub(S1, Lq1q, zq1);
+            int bad1 = 0;
+            const Blk D1 = factor_diag(S1, bad1, row_max(lds_get(Dini, q1)));
+            const int rq1 = q1 >> 4, tq1 = q1 & 15;
+            if (gi == tq1 && gj == tq1) bad |= bad1;             // reported once, by the owner of the block
+            const bool sw1 = D1.v10 > 2.0;
+            const double dl1 = sw1 ? D1.v10 - 4.0 : D1.v10;
+            Blk Lq[CLS], L1[CLS];
+#pragma unroll
+            for (int r = 0; r < CLS; ++r) {
+                Lq[r] = lds_get(Lbuf[cur], r * 16 + gi);
+                L1[r] = lds_get(L1buf[cur], r * 16 + gi);
+                blk_sub(L1[r], Lq[r], zq1);
+                if (r * 16 + gi <= q1) L1[r] = zero_blk();       // rows up to q + 1 are finished for pivot q + 1
+            }
+#pragma unroll
+            for (int c = 0; c < CLS; ++c) {
+                const Blk z = zcol(Ubuf[cur], c * 16 + gj);
+                Blk U1 = lds_get(U1buf[cur], c * 16 + gj);
+                blk_sub(U1, Lq1q, z);
+                if (c * 16 + gj <= q1) U1 = zero_blk();
+                const double a0x = sw1 ? U1.v10 : U1.v00, a0y = sw1 ? U1.v11 : U1.v01, a1x = sw1 ? U1.v00 : U1.v10, a1y = sw1 ? U1.v01 : U1.v11;
+                Blk z1;                                          // z_{q+1}(c) = D(q + 1)^-1 U(q + 1, c)
+                z1.v10 = (a1x - dl1 * a0x) * D1.v11; z1.v00 = (a0x - D1.v01 * z1.v10) * D1.v00;
+                z1.v11 = (a1y - dl1 * a0y) * D1.v11; z1.v01 = (a0y - D1.v01 * z1.v11) * D1.v00;
+#pragma unroll
+                for (int r = 0; r < CLS; ++r) { blk_sub(T[r][c], Lq[r], z); blk_sub(T[r][c], L1[r], z1); }
+            }
+            // the owner of S(q+1, q+1) keeps the factorised block for the store
+            if (gi == tq1 && gj == tq1) {
+#pragma unroll
+                for (int r = 0; r < CLS; ++r) if (r == rq1) T[r][r] = D1;
+            }
+            q_done = q + 2;
+            if (q + 2 < m) {                                     // the next pair leaves its owners: pivot q + 2 final, pivot q + 3 as it stands
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const int p = q + 2 + w;
+                    if (p < m) {
+                        const int rp = p >> 4, tp = p & 15;
+                        double* ub = w ? U1buf[nxt] : Ubuf[nxt];
+                        double* lb = w ? L1buf[nxt] : Lbuf[nxt];
+                        if (gi == tp && gj == tp) {
+#pragma unroll
+                            for (int r = 0; r < CLS; ++r)
+                                if (r == rp) {
+                                    if (w == 0) {
+                                        const Blk dn = factor_diag(T[r][r], bad, row_max(lds_get(Dini, p)));
+                                        lds_set(Dbuf[nxt], 0, dn);
+                                        T[r][r] = dn;
+                                    } else lds_set(Sbuf[nxt], 0, T[r][r]);
+                                }
+                        }
+                        if (gi == tp) {
+#pragma unroll
+                            for (int r = 0; r < CLS; ++r)
+                                if (r == rp) {
+#pragma unroll
+                                    for (int c = 0; c < CLS; ++c) {
+                                        if (c < rp) lds_set(ub, c * 16 + gj, zero_blk());
+                                        else if (c > rp) lds_set(ub, c * 16 + gj, T[r][c]);
+                                        else lds_set(ub, c * 16 + gj, gj > tp ? T[r][c] : zero_blk());
+                                    }
+                                }
+                        }
+                        if (gj == tp) {
+#pragma unroll
+                            for (int c = 0; c < CLS; ++c)
+                                if (c == rp) {
+#pragma unroll
+                                    for (int r = 0; r < CLS; ++r) {
+                                        if (r < rp) lds_set(lb, r * 16 + gi, zero_blk());
+                                        else if (r > rp) lds_set(lb, r * 16 + gi, T[r][c]);
+                                        else lds_set(lb, r * 16 + gi, gi > tp ? T[r][c] : zero_blk());
+                                    }
+                                }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
     // ---- pivot steps.  Straight-line bulk code: the pivot is the same block for every lane, so the row swap of its 2x2 LU is
     // folded into the ADDRESS of the two halves of U(q, c) (scalar), finished blocks see zeros (no predicates, no skipping).
-    for (int qv = 0; qv < m; ++qv) {
+    // (after fused steps: the one pivot an odd chain has left; its row / column / block sit in the buffers of the pair it would have led)
+    for (int qv = q_done; qv < m; ++qv) {
         const int q = uniform(qv);                               // the step number is wave-uniform: which row / column class publishes, the
-        const int cur = q & 1, nxt = cur ^ 1;                    // LDS buffer in use and the lane of the next pivot are scalar decisions
+        const int cur = FUSE ? (q >> 1) & 1 : q & 1, nxt = cur ^ 1;   // LDS buffer in use and the lane of the next pivot are scalar decisions
         Blk D = lds_get(Dbuf[cur], 0);
         D = Blk{uniform_d(D.v00), uniform_d(D.v01), uniform_d(D.v10), uniform_d(D.v11)};   // the same block in every lane: scalar registers
         const int sw = uniform(D.v10 > 2.0 ? 1 : 0);
@@ -1181,7 +1301,12 @@ int Engine::factor(hipStream_t st, const double* A, const double* rhs, const Gro
             static const int pw_env = getenv("JG_TOP_PW") ? atoi(getenv("JG_TOP_PW")) : -1;
             const long long wgs = (long long)L.ntasks * std::min<long long>(t.lanes, (long long)t.lpg * (ld / 64));
             const bool pw = pw_env >= 0 ? pw_env != 0 : wgs <= 256 * (L.cls == 4 ? 1 : (L.cls == 3 ? 2 : 3));
-            if (pw) {
+            static const int fuse_env = getenv("JG_TOP_FUSE") ? atoi(getenv("JG_TOP_FUSE")) : 0;
+            if (fuse_env && L.cls <= 3) {                        // two pivots per barrier (k_fact_top<CLS, false, true>; at 4 x 4 blocks per thread
+                                                                 // the second pivot's row / column do not fit the register file beside the front)
+                if (L.cls == 2) hipLaunchKernelGGL((k_fact_top<2, false, true>), grid, dim3(256), 0, st, t);
+                else hipLaunchKernelGGL((k_fact_top<3, false, true>), grid, dim3(256), 0, st, t);
+            } else if (pw) {
                 if (L.cls == 2) hipLaunchKernelGGL((k_fact_top<2, true>), grid, dim3(TOP_THREADS), 0, st, t);
                 else if (L.cls == 3) hipLaunchKernelGGL((k_fact_top<3, true>), grid, dim3(TOP_THREADS), 0, st, t);
                 else hipLaunchKernelGGL((k_fact_top<4, true>), grid, dim3(TOP_THREADS), 0, st, t);

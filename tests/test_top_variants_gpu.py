@@ -48,6 +48,8 @@ def test_top_kernel_variants_and_level0_routes_give_the_same_bits(case, batch):
     assert _run(case, batch, JG_TOP_PW=0)[0] == ref                  # every top launch without
     assert _run(case, batch, JG_NO_PREFACTOR=1)[0] == ref            # plain plan: the level kernel factorises the leaf blocks
     assert _run(case, batch, JG_ITEM_ORDER=0)[0] == ref              # items of a level dealt heaviest first
+    assert _run(case, batch, JG_TOP_FUSE=1)[0] == ref                # two pivots per barrier: every thread redoes what the owners of the
+                                                                     # second pivot's row / column / block do, operation for operation
 
 
 SCRIPT_STATE = r"""
