@@ -469,6 +469,64 @@ function largestNormalizedResidual(analysis::HipStateEstimation)
     return mx[1], Int64(idx[1])
 end
 
-export HIP, NewtonRaphsonBatch, setOutages!, powerFlowDefer!, moveLanes!, finish!, resume!, jacobian!, largestNormalizedResidual
+# ---- sharded contingency screen: the ONE collective behind the C ABI (jgrid.h: jg_comm_*, jg_nr_allgather_results) --------------
+# One Julia process per GPU.  Rank 0 draws the communicator id, the HOST ships its 128 bytes to the other ranks (MPI.bcast, a file,
+# a socket -- the library does not care), every rank creates its communicator (a collective), solves its contiguous block of the
+# scenario list and receives the record of the whole screen with ONE ncclAllGather of RCCL over xGMI.
+const COMM_ID_BYTES = 128
+
+"id of a new communicator (rank 0 calls this and ships the bytes to every rank)"
+function commUniqueId()
+    id = Vector{UInt8}(undef, COMM_ID_BYTES)
+    check(ccall((:jg_comm_unique_id, lib), Cint, (Ptr{UInt8},), id))
+    return id
+end
+
+mutable struct Comm
+    ptr::Ptr{Cvoid}
+    rank::Int
+    world::Int
+    device::Int
+    function Comm(rank::Int, world::Int, id::Vector{UInt8}; device::Int = 0)
+        length(id) == COMM_ID_BYTES || throw(DimensionMismatch("communicator id: $COMM_ID_BYTES bytes"))
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:jg_comm_create, lib), Cint, (Ptr{Ptr{Cvoid}}, Int64, Int64, Ptr{UInt8}, Cint), h, rank, world, id, device))
+        c = new(h[], rank, world, device)
+        finalizer(x -> (x.ptr == C_NULL || ccall((:jg_comm_destroy, lib), Cvoid, (Ptr{Cvoid},), x.ptr); x.ptr = C_NULL), c)
+        return c
+    end
+end
+
+"contiguous block of scenarios owned by `rank` of `world` (0-based rank; 1-based inclusive range): SURVEY 8(e)"
+function shard(count::Int, rank::Int, world::Int)
+    per, extra = divrem(count, world)
+    lo = rank * per + min(rank, extra)
+    return (lo + 1):(lo + per + (rank < extra ? 1 : 0))
+end
+
+"""
+    contingencyAnalysis(system, labels, comm; iteration = 20, tolerance = 1e-8, record)
+
+N-1 screen of `labels` (branch labels, 0 = base case) sharded over the ranks of `comm`: this rank solves `labels[shard(...)]` as one
+batch on its GPU (every rank must hold the same number of scenarios: pad with 0), then ONE all-gather hands every rank the record of
+the whole screen.  `record` is DEVICE memory of the caller for `world * batch` rows of `2n + 2` doubles (V | theta | iterations |
+status per scenario, scenario order), e.g. an AMDGPU.jl `ROCArray{Float64}`; pass its pointer.  Replaces the reference's serial
+user-level loop (src/powerSystem/branch.jl:453-459: updateBranch!(...; status = 0) -> powerFlow! -> updateBranch!(...; status = 1)).
+"""
+function contingencyAnalysis(system::PowerSystem, labels::Vector{Int64}, comm::Comm; iteration::Int64 = 20, tolerance::Float64 = 1e-8,
+                             record::Ptr{Float64})
+    mine = labels[shard(length(labels), comm.rank, comm.world)]
+    b = NewtonRaphsonBatch(system, length(mine); device = comm.device)
+    setOutages!(b, mine)
+    check(ccall((:jg_nr_run, lib), Cint, (Ptr{Cvoid}, Int64, Float64, Ptr{Int32}, Ptr{Int32}), b.handle.ptr, iteration, tolerance, b.iteration, b.status))
+    check(ccall((:jg_nr_allgather_results, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}), b.handle.ptr, comm.ptr, record))
+    return b
+end
+
+"drops the library's cached symbolic analyses (live analyses keep theirs): the next newtonRaphson(system, HIP) pays a full analysis again"
+clearPlanCache() = ccall((:jg_plan_cache_clear, lib), Cvoid, ())
+
+export HIP, NewtonRaphsonBatch, setOutages!, powerFlowDefer!, moveLanes!, finish!, resume!, jacobian!, largestNormalizedResidual,
+       commUniqueId, Comm, shard, contingencyAnalysis, clearPlanCache
 
 end # module

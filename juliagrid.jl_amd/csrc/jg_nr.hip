@@ -253,7 +253,7 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_refine_residual(RefineArgs a
 }
 
 // d = d1 + d2 (kept as method.increment), then x -= d on the state components of the scenarios still iterating
-__global__ void k_refine_apply(double* inc, const double* inc2, double* va, double* vm, const signed char* flags, const int* active,
+__global__ void k_refine_apply(double* inc, const double* inc1, const double* inc2, double* va, double* vm, const signed char* flags, const int* active,
                                const jg::GroupSel sel, int n, int ld, int lanes) {
     int grp, bx;
     if (!jg::map_block(sel, ld, (n + 15) / 16, grp, bx)) return;
@@ -263,7 +263,7 @@ __global__ void k_refine_apply(double* inc, const double* inc2, double* va, doub
     if (lb >= lanes) return;
     const size_t b = (size_t)lb, l = (size_t)ld;
     if (active && !active[b]) return;
-    const double2 d1 = jg::load_vec(inc, (size_t)i, b, l), d2 = jg::load_vec(inc2, (size_t)i, b, l);
+    const double2 d1 = jg::load_vec(inc1, (size_t)i, b, l), d2 = jg::load_vec(inc2, (size_t)i, b, l);
     const double dx = d1.x + d2.x, dy = d1.y + d2.y;
     jg::store_vec(inc, (size_t)i, b, l, dx, dy);
     const int fl = flags[i];
@@ -776,10 +776,12 @@ int newton_step(jg_nr* h, const jg::GroupSel& sel, const int* active) {
         jg::StateUpdate upd{h->d_va, h->d_vm, h->d_flags, active, -1.0};
         return h->eng.backsolve(h->stream, h->d_inc, upd, sel);
     }
+    // the plain solve goes to a scratch vector: method.increment (d_inc) is written for ACTIVE scenarios only, by k_refine_apply -- a
+    // finished scenario of an active lane group keeps its last increment, as without refinement
     jg::StateUpdate none{};
-    if (int rc = h->eng.backsolve(h->stream, h->d_inc, none, sel)) return rc;
+    if (int rc = h->eng.backsolve(h->stream, h->d_inc2[1], none, sel)) return rc;
     RefineArgs a{h->d_rowptr, h->d_col, h->d_GB, h->d_rowtype, h->d_vm, h->d_va, h->d_ppos, h->d_pdg, h->d_pdb,
-                 h->d_F, h->d_inc, h->d_R, sel, h->n, h->ld, h->mp, h->nchunk, h->batch};
+                 h->d_F, h->d_inc2[1], h->d_R, sel, h->n, h->ld, h->mp, h->nchunk, h->batch};
     dim3 grid((unsigned)h->nchunk * jg::group_stride(h->ld / 64)), block(64, ASM_WAVES);
     switch (h->mp) {
         case 0: hipLaunchKernelGGL((k_refine_residual<0>), grid, block, 0, h->stream, a); break;
@@ -789,7 +791,7 @@ int newton_step(jg_nr* h, const jg::GroupSel& sel, const int* active) {
     if (int rc = h->eng.forward(h->stream, h->d_R, sel)) return rc;
     if (int rc = h->eng.backsolve(h->stream, h->d_inc2[0], none, sel)) return rc;
     hipLaunchKernelGGL(k_refine_apply, dim3((unsigned)((h->n + 15) / 16) * jg::group_stride(h->ld / 64)), dim3(64, 16), 0, h->stream,
-                       h->d_inc, h->d_inc2[0], h->d_va, h->d_vm, h->d_flags, active, sel, h->n, h->ld, h->batch);
+                       h->d_inc, h->d_inc2[1], h->d_inc2[0], h->d_va, h->d_vm, h->d_flags, active, sel, h->n, h->ld, h->batch);
     return 0;
 }
 
@@ -1248,8 +1250,10 @@ int jg_nr_set_refine(jg_nr* h, int mode) {
         const size_t vec = (size_t)h->n * 2 * h->ld * 8;
         NR_HIP(hipMalloc((void**)&h->d_R, vec));
         NR_HIP(hipMalloc((void**)&h->d_inc2[0], vec));
+        if (!h->d_inc2[1]) NR_HIP(hipMalloc((void**)&h->d_inc2[1], vec));
         NR_HIP(jg::sync_fill(h->d_R, 0, vec, h->stream));
         NR_HIP(jg::sync_fill(h->d_inc2[0], 0, vec, h->stream));
+        NR_HIP(jg::sync_fill(h->d_inc2[1], 0, vec, h->stream));
     }
     if ((mode != 0) != h->refine) {                              // the iteration graph is captured for one mode
         if (h->execB) { hipGraphExecDestroy(h->execB); h->execB = nullptr; }
