@@ -189,12 +189,13 @@ class Plan:
     def replay_tables(self, kind):
         """Device replay tables (jg_symbolic.hpp): segments [n,8] = rec_base, nchunks, wpi, rpw, level, last, items, -;
         wave records [m,16]."""
-        base = {"fact": 60, "bwd": 62, "fwd": 66, "sel": 68, "pre": 76}[kind]
+        base = {"fact": 60, "bwd": 62, "fwd": 66, "sel": 68, "pre": 76, "bwdj": 79}[kind]
         return self.get(base).reshape(-1, 8), self.get(base + 1).reshape(-1, 16)
 
     def top_tables(self):
         """Multifrontal top (jg_symbolic.hpp): task headers [t,16], task data, launches [l,4] = task_begin, ntasks, class,
-        level, grouped, wg_begin, nwg, -; task of each pivot; (top_level, stack doubles per scenario, terms inside tasks).
+        level, grouped, wg_begin, nwg, -; task of each pivot; (top_level, stack doubles per scenario, terms inside tasks, stack doubles per
+        interleave class x 3, Jordan plan, blocks of Jordan rows).
         Workgroup map of the grouped launches: get(78)."""
         return self.get(70).reshape(-1, 16), self.get(71), self.get(72).reshape(-1, 8), self.get(73), self.get(74)
 

@@ -565,9 +565,16 @@ constexpr int TOP_THREADS = 320;        // 16 x 16 bulk threads + the pivot wave
 // very operations, in the very order, that the owners of those blocks perform in the one-pivot step (same bits) -- and applies both
 // pivots to its blocks.  A third more arithmetic per pivot, half the barriers and half the publish / read round trips: the step is
 // bound by those, not by the arithmetic.
-template <int CLS, bool PW, bool FUSE = false>
+// JORDAN (jg_symbolic.hpp: Jordan rows): the column of the next pivot is published with the blocks of the FINISHED pivot rows as they
+// stand instead of zeros, so the bulk update -- which touches every block of the grid anyway -- also eliminates column q from the rows
+// above it: rows i < q get row_i -= U(i,q) D(q)^-1 row_q over the columns c > q (the row of pivot q is published with zeros up to
+// column q, so nothing left of it moves: the diagonal blocks, Lh and the in-task multipliers U(i,q) stay what they are).  After the
+// last step a pivot row holds J(i, ext) and y'_i; the rows leave for their own region behind the factor entries.  Same step, same
+// barrier count, no extra arithmetic issued.
+template <int CLS, bool PW, bool FUSE = false, bool JORDAN = false>
 __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves_per_eu(CLS == 4 || (FUSE && CLS == 3) ? 2 : 4))) void k_fact_top(TopArgs a) {
     static_assert(!(PW && FUSE), "the fused step has no pivot wave");
+    static_assert(!(JORDAN && FUSE), "the fused step keeps plain rows");
     __shared__ __attribute__((aligned(16))) double Dbuf[2][4];         // factorised pivot of the current / next step
     __shared__ __attribute__((aligned(16))) double Ubuf[2][64 * 4];    // pivot row  U(q, c)
     __shared__ __attribute__((aligned(16))) double Lbuf[2][64 * 4];    // pivot column Lh(i, q)
@@ -848,9 +855,9 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
                         if (c == rq) {
 #pragma unroll
                             for (int r = 0; r < CLS; ++r) {
-                                if (r < rq) lds_set(Lbuf[nxt], r * 16 + gi, zero_blk());
+                                if (r < rq) lds_set(Lbuf[nxt], r * 16 + gi, JORDAN ? T[r][c] : zero_blk());     // JORDAN: the rows above lose column q + 1 too
                                 else if (r > rq) lds_set(Lbuf[nxt], r * 16 + gi, T[r][c]);
-                                else lds_set(Lbuf[nxt], r * 16 + gi, gi > tq ? T[r][c] : zero_blk());
+                                else lds_set(Lbuf[nxt], r * 16 + gi, (JORDAN ? gi != tq : gi > tq) ? T[r][c] : zero_blk());
                             }
                         }
                 }
@@ -873,6 +880,7 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
     if (!pivot_wave) {
         const int lgo = h[12];                                   // scenario interleave of the update block: that of the parent's workgroup
         double2* out = e > 0 ? stack_unit(a, b, h[4], lgo) : nullptr;
+        const int jb = JORDAN ? h[14] : -1;                      // Jordan rows: block jb + i e + (j - m) for pivot row i, external column j
 #pragma unroll
         for (int r = 0; r < CLS; ++r)
 #pragma unroll
@@ -880,7 +888,8 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
                 const int i = r * 16 + gi, j = c * 16 + gj;
                 const int cd = (i < f && j < fprime) ? td[i * fprime + j] : -1;
                 const Blk& v = T[r][c];
-                if (cd <= -2) store_vec(a.W, (size_t)(-(cd + 2)), b, ld, v.v00, v.v10);
+                if (JORDAN && i < m && j >= m && j < f) store_blk(a.X, (size_t)(jb + i * e + (j - m)), b, ld, v.v00, v.v01, v.v10, v.v11);
+                else if (cd <= -2) store_vec(a.W, (size_t)(-(cd + 2)), b, ld, v.v00, v.v10);
                 else if (cd >= 0 && (!((cd >> 28) & 4) || (!PW && i == j && i < m))) store_blk(a.X, (size_t)(cd & 0x0fffffff), b, ld, v.v00, v.v01, v.v10, v.v11);
                 else if (i >= m && i < f && j >= m && j < fprime) {                              // update matrix | vector: scenario-major stack
                     double2* p = out + ((((size_t)(i - m) * (e + 1) + (j - m)) * 2) << lgo);
@@ -1110,6 +1119,7 @@ SharedPlan::~SharedPlan() {
     hipFree(fact_rec); hipFree(bwd_rec); hipFree(pre_rec); hipFree(fwd_rec); hipFree(sel_rec); hipFree(top_task);
     hipFree(fact_seg); hipFree(bwd_seg); hipFree(pre_seg); hipFree(fwd_seg); hipFree(sel_seg);
     hipFree(pre_row); hipFree(bwd_chain); hipFree(top_data); hipFree(top_wgmap);
+    hipFree(bwdj_rec); hipFree(bwdj_seg);
 }
 
 namespace {
@@ -1161,6 +1171,7 @@ std::shared_ptr<SharedPlan> acquire_plan(int n, const int* rowptr, const int* co
     if (upload(&p->pre_rec, S.pre_rec, error, st) || upload(&p->pre_seg, S.pre_seg, error, st) || upload(&p->pre_row, prow, error, st) ||
         upload(&p->fact_rec, S.fact_rec, error, st) || upload(&p->bwd_rec, S.bwd_rec, error, st) || upload(&p->fact_seg, S.fact_seg, error, st) ||
         upload(&p->bwd_seg, S.bwd_seg, error, st) || upload(&p->bwd_chain, S.bwd_chain, error, st) ||
+        (S.jordan && (upload(&p->bwdj_rec, S.bwdj_rec, error, st) || upload(&p->bwdj_seg, S.bwdj_seg, error, st))) ||
         upload(&p->fwd_rec, S.fwd_rec, error, st) || upload(&p->fwd_seg, S.fwd_seg, error, st) ||
         (!S.top_launch.empty() && (upload(&p->top_task, S.top_task, error, st) || upload(&p->top_data, S.top_data, error, st) || upload(&p->top_wgmap, S.top_wgmap, error, st)))) {
         rc = 2;
@@ -1200,7 +1211,9 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, long long 
     level_launches(plan->S.fact_seg, fact);
     level_launches(plan->S.pre_seg, pre);
     level_launches(plan->S.bwd_seg, bwd);
+    level_launches(plan->S.bwdj_seg, bwdj);
     level_launches(plan->S.fwd_seg, fwd);
+    jordan = plan->S.jordan && !(getenv("JG_JORDAN") && atoi(getenv("JG_JORDAN")) == 0);
     // the device tables belong to the plan; the engine keeps plain aliases for its launches
     fact_rec = plan->fact_rec; bwd_rec = plan->bwd_rec; pre_rec = plan->pre_rec; fwd_rec = plan->fwd_rec;
     fact_seg = plan->fact_seg; bwd_seg = plan->bwd_seg; pre_seg = plan->pre_seg; fwd_seg = plan->fwd_seg;
@@ -1289,6 +1302,7 @@ int Engine::factor(hipStream_t st, const double* A, const double* rhs, const Gro
         if (ld == 64 && t.lanes < 64) t.lpg = t.lanes;
         for (const TopLaunch& L : plan->S.top_launch) {
             t.task_begin = L.task_begin; t.ntasks = L.ntasks;
+            const bool jordan = this->jordan && plan->S.jordan;
             if (L.grouped) {                                     // every grouped task of the level: 4 or 16 scenarios per workgroup
                 t.wg_begin = L.wg_begin; t.nwg = L.nwg;
                 hipLaunchKernelGGL((k_fact_grp<4>), dim3((unsigned)L.nwg * gs), dim3(256), 0, st, t);
@@ -1302,7 +1316,17 @@ int Engine::factor(hipStream_t st, const double* A, const double* rhs, const Gro
             const long long wgs = (long long)L.ntasks * std::min<long long>(t.lanes, (long long)t.lpg * (ld / 64));
             const bool pw = pw_env >= 0 ? pw_env != 0 : wgs <= 256 * (L.cls == 4 ? 1 : (L.cls == 3 ? 2 : 3));
             static const int fuse_env = getenv("JG_TOP_FUSE") ? atoi(getenv("JG_TOP_FUSE")) : 0;
-            if (fuse_env && L.cls <= 3) {                        // two pivots per barrier (k_fact_top<CLS, false, true>; at 4 x 4 blocks per thread
+            if (jordan) {                                        // Jordan rows (jg_symbolic.hpp); the plain sweep's tables would read garbage after this
+                if (pw) {
+                    if (L.cls == 2) hipLaunchKernelGGL((k_fact_top<2, true, false, true>), grid, dim3(TOP_THREADS), 0, st, t);
+                    else if (L.cls == 3) hipLaunchKernelGGL((k_fact_top<3, true, false, true>), grid, dim3(TOP_THREADS), 0, st, t);
+                    else hipLaunchKernelGGL((k_fact_top<4, true, false, true>), grid, dim3(TOP_THREADS), 0, st, t);
+                } else {
+                    if (L.cls == 2) hipLaunchKernelGGL((k_fact_top<2, false, false, true>), grid, dim3(256), 0, st, t);
+                    else if (L.cls == 3) hipLaunchKernelGGL((k_fact_top<3, false, false, true>), grid, dim3(256), 0, st, t);
+                    else hipLaunchKernelGGL((k_fact_top<4, false, false, true>), grid, dim3(256), 0, st, t);
+                }
+            } else if (fuse_env && L.cls <= 3) {                        // two pivots per barrier (k_fact_top<CLS, false, true>; at 4 x 4 blocks per thread
                                                                  // the second pivot's row / column do not fit the register file beside the front)
                 if (L.cls == 2) hipLaunchKernelGGL((k_fact_top<2, false, true>), grid, dim3(256), 0, st, t);
                 else hipLaunchKernelGGL((k_fact_top<3, false, true>), grid, dim3(256), 0, st, t);
@@ -1384,11 +1408,13 @@ int Engine::set_shared_matrix(hipStream_t st, const double* blocks_host) {
 }
 
 int Engine::backsolve(hipStream_t st, double* out, const StateUpdate& upd, const GroupSel& sel) {
-    BwdArgs a{bwd_rec, bwd_seg, bwd_chain, X, W, out, sel, upd, ld, 0, lanes > 0 ? lanes : ld, 0, 0, 1, 1};
+    // jordan: the last factor() left Jordan rows (the flag must not change between a factorisation and its solves)
+    BwdArgs a{jordan ? plan->bwdj_rec : bwd_rec, jordan ? plan->bwdj_seg : bwd_seg, bwd_chain, X, W, out, sel, upd, ld, 0, lanes > 0 ? lanes : ld, 0, 0, 1, 1};
     const int gs = group_stride(ld / 64);
-    for (const DevLaunch& L : bwd) {
+    const std::vector<Segment>& segs = jordan ? plan->S.bwdj_seg : plan->S.bwd_seg;
+    for (const DevLaunch& L : (jordan ? bwdj : bwd)) {
         a.seg_begin = L.seg_begin;
-        { const Segment& g = plan->S.bwd_seg[L.seg_begin]; a.s0_base = g.rec_base; a.s0_nchunks = g.nchunks; a.s0_wpi = g.wpi; a.s0_rpw = g.rpw; }
+        { const Segment& g = segs[L.seg_begin]; a.s0_base = g.rec_base; a.s0_nchunks = g.nchunks; a.s0_wpi = g.wpi; a.s0_rpw = g.rpw; }
         if (!L.chain && L.wpi_max <= 8)                         // 0.387 -> 0.381 ms at 512 scenarios
             hipLaunchKernelGGL(k_bwd_level8, dim3((unsigned)L.grid * 2 * gs, L.nseg), dim3(64, 8), 8 * 128 * sizeof(double), st, a);
         else

@@ -167,6 +167,7 @@ struct SharedPlan {
     Rec* fact_rec = nullptr; Rec* bwd_rec = nullptr; Rec* pre_rec = nullptr; Rec* fwd_rec = nullptr; Rec* sel_rec = nullptr; Rec* top_task = nullptr;
     Segment* fact_seg = nullptr; Segment* bwd_seg = nullptr; Segment* pre_seg = nullptr; Segment* fwd_seg = nullptr; Segment* sel_seg = nullptr;
     int* pre_row = nullptr; int* bwd_chain = nullptr; int* top_data = nullptr; int* top_wgmap = nullptr;
+    Rec* bwdj_rec = nullptr; Segment* bwdj_seg = nullptr;    // Jordan plans: the backward sweep over Jordan rows (jg_symbolic.hpp)
     std::mutex sel_mutex;                           // the selected-inverse tables are built on first use
     bool sel_ready = false;
     ~SharedPlan();
@@ -189,7 +190,12 @@ struct Engine {
     double* X = nullptr;           // factor values [n_entries][4][ld]: U, unscaled Lh, factored diagonal blocks
     double* W = nullptr;           // [n][2][ld] pivot order: y after factor(), x after backsolve()
     int* status = nullptr;         // [ld] bit 2 set on zero / non-finite pivot
-    std::vector<DevLaunch> fact, bwd, fwd, selv, pre;
+    std::vector<DevLaunch> fact, bwd, bwdj, fwd, selv, pre;
+    // Jordan plans (policy bit 49): factor() leaves Jordan rows for the pivots of the top tasks and backsolve() sweeps over them (one
+    // backward level per task level instead of a sequential chain per task).  false: plain rows and the chain tables -- what
+    // forward() + backsolve() need (the forward elimination of another right-hand side produces y, not the y' Jordan rows go with).
+    // Read by factor() and backsolve() at launch time: change it only between a backsolve and the next factorisation.
+    bool jordan = false;
     Rec* top_task = nullptr; int* top_data = nullptr;          // multifrontal top (jg_symbolic.hpp): task headers, task data
     int* top_wgmap = nullptr;                                  // workgroup map of the grouped launches
     double* top_stack = nullptr;                               // update matrices of the tasks, scenario-major [ld][S.top_stack]
@@ -216,7 +222,7 @@ struct Engine {
     int set_shared_matrix(hipStream_t st, const double* blocks_host);
     // x = U^-1 D y, scattered to original order into out [n][2][ld]; optional fused state update.
     int backsolve(hipStream_t st, double* out, const StateUpdate& upd, const GroupSel& sel);
-    size_t factor_bytes() const { return (size_t)plan->S.n_entries * 4 * ld * sizeof(double); }
+    size_t factor_bytes() const { return ((size_t)plan->S.n_entries + (size_t)plan->S.n_jordan) * 4 * ld * sizeof(double); }   // Jordan rows sit behind the entries
 };
 
 #define JG_HIP(expr)                                                                      \

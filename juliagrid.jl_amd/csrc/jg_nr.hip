@@ -969,7 +969,9 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
     }
     if (hipHostGetDevicePointer((void**)&h->h_counter_dev, h->h_counter, 0) != hipSuccess) { jg_nr_destroy(h); return fail(2, "jg_nr_create: pinned host word is not device-visible"); }
     // in place: the assembly kernel writes into the factor storage; bit 2: it also finishes the plan's level 0 (jg_symbolic.hpp: prefactor)
-    rc = h->eng.create(n, rp.data(), cl.data(), h->ld, getenv("JG_NO_PREFACTOR") ? 1 : 1 | 4, h->stream);
+    // bit 49: Jordan rows for the pivots of the top tasks (jg_symbolic.hpp): the backward sweep over the top of the tree is a handful of
+    // plain levels instead of sequential chains (refined steps and fast Newton-Raphson switch the engine back: Engine::jordan)
+    rc = h->eng.create(n, rp.data(), cl.data(), h->ld, (getenv("JG_NO_PREFACTOR") ? 1LL : 1LL | 4) | 1LL << 49, h->stream);
     if (rc) { std::string m = h->eng.error; jg_nr_destroy(h); return fail(rc, m); }
     if (jg::upload(&h->d_dst, h->eng.plan->S.src_entry, err, h->stream)) { jg_nr_destroy(h); return fail(2, err); }
     if (h->eng.plan->S.prefactor) {                            // the row table of the assemblies that also finish the plan's level 0
@@ -1262,6 +1264,8 @@ int jg_nr_set_refine(jg_nr* h, int mode) {
         if (h->graphA) { hipGraphDestroy(h->graphA); h->graphA = nullptr; }
     }
     h->refine = mode != 0;
+    // a refined step runs forward() + backsolve() on the factor of the step: plain rows (Engine::jordan); back on when refinement goes off
+    h->eng.jordan = !h->refine && h->eng.plan->S.jordan && !(getenv("JG_JORDAN") && atoi(getenv("JG_JORDAN")) == 0);
     return 0;
 }
 
@@ -1524,6 +1528,7 @@ int jg_nr_fast_setup(jg_nr* h, const double* bp, const double* bq) {
     if (!h->d_inc2[1]) NR_HIP(hipMalloc((void**)&h->d_inc2[1], vec));
     NR_HIP(jg::sync_fill(h->d_R, 0, vec, h->stream));
     NR_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
+    h->eng.jordan = false;                                       // factor once, then forward() + backsolve() per half iteration: plain rows
     if (int rc = h->eng.factor(h->stream, nullptr, h->d_R, jg::GroupSel{})) return fail(rc, h->eng.error);   // ONCE (lu(jacobian), :? utility.jl:470-476)
     NR_HIP(hipStreamSynchronize(h->stream));
     std::vector<int> st(h->ld);

@@ -32,7 +32,8 @@ void jg_plan_destroy(jg_plan* p) { delete p; }
 //        68 / 69 selected-inverse segments / records
 //        70 top-task headers (x16), 71 top-task data, 72 top launches (x8: task_begin, ntasks, class, level, grouped, wg_begin, nwg, -),
 //        78 workgroup map of the grouped launches (task << 8 | scenario block),
-//        73 task of each pivot (-1: bottom), 74 {top_level, stack doubles per scenario (low 31 bits), top terms (low 31 bits), stack doubles per interleave class x3}
+//        73 task of each pivot (-1: bottom), 74 {top_level, stack doubles per scenario (low 31 bits), top terms (low 31 bits), stack doubles per interleave class x3,
+//        Jordan plan (0 / 1), blocks of Jordan rows behind the factor entries}, 79 / 80 backward segments / records over Jordan rows
 // out == NULL returns the length.
 int64_t jg_plan_export(jg_plan* p, int which, int32_t* out, int64_t cap) {
     if (!p) return -1;
@@ -64,7 +65,9 @@ int64_t jg_plan_export(jg_plan* p, int which, int32_t* out, int64_t cap) {
         case 72: tmp.assign((const int*)S.top_launch.data(), (const int*)S.top_launch.data() + S.top_launch.size() * 8); v = &tmp; break;
         case 78: v = &S.top_wgmap; break;
         case 73: v = &S.top_task_of; break;
-        case 74: tmp = {S.top_level, (int)(S.top_stack & 0x7fffffff), (int)(S.top_terms & 0x7fffffff), (int)S.top_stack_cls[0], (int)S.top_stack_cls[1], (int)S.top_stack_cls[2]}; v = &tmp; break;
+        case 74: tmp = {S.top_level, (int)(S.top_stack & 0x7fffffff), (int)(S.top_terms & 0x7fffffff), (int)S.top_stack_cls[0], (int)S.top_stack_cls[1], (int)S.top_stack_cls[2], S.jordan, S.n_jordan}; v = &tmp; break;
+        case 79: tmp.assign((const int*)S.bwdj_seg.data(), (const int*)S.bwdj_seg.data() + S.bwdj_seg.size() * 8); v = &tmp; break;
+        case 80: tmp.assign((const int*)S.bwdj_rec.data(), (const int*)S.bwdj_rec.data() + S.bwdj_rec.size() * 16); v = &tmp; break;
         case 75: tmp.assign(S.pre_pivot.begin(), S.pre_pivot.end()); v = &tmp; break;
         case 76: tmp.assign((const int*)S.pre_seg.data(), (const int*)S.pre_seg.data() + S.pre_seg.size() * 8); v = &tmp; break;
         case 77: tmp.assign((const int*)S.pre_rec.data(), (const int*)S.pre_rec.data() + S.pre_rec.size() * 16); v = &tmp; break;

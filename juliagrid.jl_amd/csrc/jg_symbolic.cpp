@@ -255,6 +255,8 @@ void build_top(BlockSymbolic& S, int top_level, int soft_cap, int struct_min, in
     const int n = S.n;
     S.top_level = 0; S.top_task.clear(); S.top_data.clear(); S.top_launch.clear(); S.top_stack = 0; S.top_terms = 0; S.top_wgmap.clear();
     S.top_task_of.assign(n, -1);
+    const bool want_jordan = S.jordan != 0;                      // granted below if the plan has tasks and none of them is grouped
+    S.jordan = 0; S.n_jordan = 0;
     if (top_level <= 0 || (top_level == NO_TOP_LEVEL && struct_min <= 0)) return;   // NO_TOP_LEVEL: no pivot goes to a task for its level
     auto ssize = [&](int k) { return S.u_ptr[k + 1] - S.u_ptr[k]; };
     auto parent = [&](int k) { return ssize(k) ? S.u_col[S.u_ptr[k]] : -1; };
@@ -403,6 +405,8 @@ void build_top(BlockSymbolic& S, int top_level, int soft_cap, int struct_min, in
         h.w[0] = m; h.w[1] = e; h.w[2] = t.root(); h.w[3] = base; h.w[4] = t.stack; h.w[5] = (int)t.kids.size();
         h.w[6] = piv_off; h.w[7] = child_off; h.w[8] = dent_off; h.w[9] = t.cls; h.w[10] = t.level; h.w[11] = fprime;
         h.w[12] = t.parent >= 0 ? tasks[t.parent].lg : 0; h.w[13] = t.lg;
+        h.w[14] = -1;
+        if (want_jordan && e > 0) { h.w[14] = S.n_entries + S.n_jordan; S.n_jordan += m * e; }     // Jordan rows: [m][e] blocks behind the factor entries
         S.top_task[oi] = h;
         const int grouped = t.lg > 0 ? 1 : 0;
         if (S.top_launch.empty() || S.top_launch.back().level != t.level || S.top_launch.back().grouped != grouped ||
@@ -415,6 +419,12 @@ void build_top(BlockSymbolic& S, int top_level, int soft_cap, int struct_min, in
             for (int b = 0; b < blocks; ++b) S.top_wgmap.push_back(oi << 8 | b);
             S.top_launch.back().nwg += blocks;
         }
+    }
+    if (want_jordan) {
+        bool plain = !S.symmetric;                               // (symmetric plans read U(k,i)' for Lh(i,k) and feed the selected inverse: U stays U)
+        for (const Task& t : tasks) if (t.lg > 0) plain = false;
+        if (plain) S.jordan = 1;
+        else { S.n_jordan = 0; for (Rec& h : S.top_task) h.w[14] = -1; }
     }
     // top_task_of must name the header position
     std::vector<int> pos(nt);
@@ -535,70 +545,87 @@ void build_tables(BlockSymbolic& S) {
         };
         build_replay(flevel, fwork, FACT_T, S.fwd_seg, S.fwd_rec, S.n_fwd_levels, fill_fwd, NoExtra(), 0, FACT_WAVES);
     }
-    // backward sweep: chains of a supernode go to ONE workgroup each (CHAIN_MAX_ROWS), the other rows stay wave records
-    std::vector<int> uw(n);
-    for (int r = 0; r < n; ++r) uw[r] = S.u_ptr[r + 1] - S.u_ptr[r];
-    std::vector<int> cstart, clen;                           // chains in ascending pivot order
-    std::vector<int> chain_of(n);
-    for (int k = 0; k < n;) {
-        int e = k;
-        while (e + 1 < n && e + 1 - k < CHAIN_MAX_ROWS && uw[e] >= 1 && S.u_col[S.u_ptr[e]] == e + 1 && uw[e] == uw[e + 1] + 1) ++e;
-        if (uw[e] > CHAIN_MAX_EXT) e = k;                    // too many external columns for the LDS staging: plain rows
-        for (int r = k; r <= e; ++r) chain_of[r] = (int)cstart.size();
-        cstart.push_back(k); clen.push_back(e - k + 1);
-        k = e + 1;
-    }
-    const int nc = (int)cstart.size();
-    std::vector<int> clevel(nc, 1);
-    for (int c = nc - 1; c >= 0; --c) {
-        const int last = cstart[c] + clen[c] - 1;
-        for (int p = S.u_ptr[last]; p < S.u_ptr[last + 1]; ++p) clevel[c] = std::max(clevel[c], clevel[chain_of[S.u_col[p]]] + 1);
-    }
-    S.chain_level.assign(n, 0);
-    std::vector<int> row_level(n, 0);
-    int max_level = 0;
-    std::vector<std::vector<int>> chains_at;
-    for (int c = 0; c < nc; ++c) {
-        max_level = std::max(max_level, clevel[c]);
-        for (int r = cstart[c]; r < cstart[c] + clen[c]; ++r) S.chain_level[r] = clevel[c];
-        if (clen[c] == 1) row_level[cstart[c]] = clevel[c];
-    }
-    chains_at.assign(max_level + 1, {});
-    for (int c = 0; c < nc; ++c) if (clen[c] > 1) chains_at[clevel[c]].push_back(c);
+    // backward sweep: chains of a supernode go to ONE workgroup each (CHAIN_MAX_ROWS), the other rows stay wave records.
+    // Built once for plain rows and, in Jordan plans, once more for Jordan rows (jg_symbolic.hpp): there a pivot of a top task is a plain
+    // wave-record row over the EXTERNAL columns of its task (entries w14 + i e + c), never part of a chain.
     S.bwd_chain.clear();
-    build_replay(row_level, uw, BWD_T, S.bwd_seg, S.bwd_rec, S.n_bwd_levels, [&](int k, int sub, int wpi, int rpw, Rec* r) {
-        for (int j = 0; j < rpw; ++j) { r[j].w[0] = k; r[j].w[1] = S.perm[k]; r[j].w[2] = S.diag[k]; r[j].w[3] = 0; }
-        int q = 0;
-        for (int p = S.u_ptr[k] + sub; p < S.u_ptr[k + 1]; p += wpi, ++q) {
-            Rec& x = r[q / BWD_T];
-            const int s = 4 + 2 * (q % BWD_T);
-            x.w[s] = S.u_ent[p]; x.w[s + 1] = S.u_col[p];
-            x.w[3]++;
+    auto build_bwd = [&](bool jordan, std::vector<Segment>& out_seg, std::vector<Rec>& out_rec, int& out_levels, std::vector<int>* chain_level_out) {
+        std::vector<int> jrow(n, -1), jroot(n, -1);              // Jordan: first block of the pivot's row, root of its task (whose U row names ext(task))
+        if (jordan)
+            for (const Rec& h : S.top_task) {
+                const int* piv = S.top_data.data() + h.w[3] + h.w[6];
+                for (int q = 0; q < h.w[0]; ++q) { jrow[piv[q]] = h.w[14] >= 0 ? h.w[14] + q * h.w[1] : 0; jroot[piv[q]] = h.w[2]; }
+            }
+        auto is_j = [&](int r) { return jroot[r] >= 0; };
+        auto cols_of = [&](int r) { return is_j(r) ? jroot[r] : r; };    // the pivot whose U row lists the columns row r depends on
+        std::vector<int> uw(n);
+        for (int r = 0; r < n; ++r) { const int c = cols_of(r); uw[r] = S.u_ptr[c + 1] - S.u_ptr[c]; }
+        std::vector<int> cstart, clen;                           // chains in ascending pivot order
+        std::vector<int> chain_of(n);
+        for (int k = 0; k < n;) {
+            int e = k;
+            if (!is_j(k))
+                while (e + 1 < n && !is_j(e + 1) && e + 1 - k < CHAIN_MAX_ROWS && uw[e] >= 1 && S.u_col[S.u_ptr[e]] == e + 1 && uw[e] == uw[e + 1] + 1) ++e;
+            if (uw[e] > CHAIN_MAX_EXT) e = k;                    // too many external columns for the LDS staging: plain rows
+            for (int r = k; r <= e; ++r) chain_of[r] = (int)cstart.size();
+            cstart.push_back(k); clen.push_back(e - k + 1);
+            k = e + 1;
         }
-    }, [&](int l, std::vector<Segment>& segs, std::vector<Rec>& recs) {
-        const std::vector<int>& cs = chains_at[l];
-        if (cs.empty()) return;
-        Segment sg{};
-        sg.rec_base = (int)recs.size(); sg.nchunks = (int)cs.size(); sg.wpi = 0; sg.rpw = 1; sg.level = l; sg.last = 0; sg.items = 0;
-        for (int c : cs) {
-            const int b = clen[c], first = cstart[c], last = first + b - 1;
-            const int nE = uw[last];
-            Rec r{};
-            r.w[0] = b; r.w[1] = nE; r.w[2] = (int)S.bwd_chain.size();
-            int wpr = 1;
-            while (wpr * 2 * b <= 16) wpr *= 2;              // waves per row in the external phase
-            r.w[3] = wpr;
-            recs.push_back(r);
-            sg.items += b;
-            for (int p = 0; p < b; ++p) { S.bwd_chain.push_back(first + p); S.bwd_chain.push_back(S.perm[first + p]); S.bwd_chain.push_back(S.diag[first + p]); }
-            for (int q = 0; q < nE; ++q) S.bwd_chain.push_back(S.u_col[S.u_ptr[last] + q]);
-            for (int p = 0; p < b; ++p)
-                for (int q = 0; q < nE; ++q) S.bwd_chain.push_back(find_in_row(S, first + p, S.u_col[S.u_ptr[last] + q]));
-            for (int p = 0; p < b; ++p)
-                for (int c2 = 0; c2 < b; ++c2) S.bwd_chain.push_back(c2 > p ? find_in_row(S, first + p, first + c2) : -1);
+        const int nc = (int)cstart.size();
+        std::vector<int> clevel(nc, 1);
+        for (int c = nc - 1; c >= 0; --c) {
+            const int last = cols_of(cstart[c] + clen[c] - 1);
+            for (int p = S.u_ptr[last]; p < S.u_ptr[last + 1]; ++p) clevel[c] = std::max(clevel[c], clevel[chain_of[S.u_col[p]]] + 1);
         }
-        segs.push_back(sg);
-    }, max_level);
+        std::vector<int> row_level(n, 0);
+        int max_level = 0;
+        std::vector<std::vector<int>> chains_at;
+        for (int c = 0; c < nc; ++c) {
+            max_level = std::max(max_level, clevel[c]);
+            if (chain_level_out) for (int r = cstart[c]; r < cstart[c] + clen[c]; ++r) (*chain_level_out)[r] = clevel[c];
+            if (clen[c] == 1) row_level[cstart[c]] = clevel[c];
+        }
+        chains_at.assign(max_level + 1, {});
+        for (int c = 0; c < nc; ++c) if (clen[c] > 1) chains_at[clevel[c]].push_back(c);
+        build_replay(row_level, uw, BWD_T, out_seg, out_rec, out_levels, [&](int k, int sub, int wpi, int rpw, Rec* r) {
+            for (int j = 0; j < rpw; ++j) { r[j].w[0] = k; r[j].w[1] = S.perm[k]; r[j].w[2] = S.diag[k]; r[j].w[3] = 0; }
+            const int c = cols_of(k);
+            int q = 0;
+            for (int t = sub; t < uw[k]; t += wpi, ++q) {
+                Rec& x = r[q / BWD_T];
+                const int s = 4 + 2 * (q % BWD_T);
+                x.w[s] = is_j(k) ? jrow[k] + t : S.u_ent[S.u_ptr[k] + t]; x.w[s + 1] = S.u_col[S.u_ptr[c] + t];
+                x.w[3]++;
+            }
+        }, [&](int l, std::vector<Segment>& segs, std::vector<Rec>& recs) {
+            const std::vector<int>& cs = chains_at[l];
+            if (cs.empty()) return;
+            Segment sg{};
+            sg.rec_base = (int)recs.size(); sg.nchunks = (int)cs.size(); sg.wpi = 0; sg.rpw = 1; sg.level = l; sg.last = 0; sg.items = 0;
+            for (int c : cs) {
+                const int b = clen[c], first = cstart[c], last = first + b - 1;
+                const int nE = uw[last];
+                Rec r{};
+                r.w[0] = b; r.w[1] = nE; r.w[2] = (int)S.bwd_chain.size();
+                int wpr = 1;
+                while (wpr * 2 * b <= 16) wpr *= 2;              // waves per row in the external phase
+                r.w[3] = wpr;
+                recs.push_back(r);
+                sg.items += b;
+                for (int p = 0; p < b; ++p) { S.bwd_chain.push_back(first + p); S.bwd_chain.push_back(S.perm[first + p]); S.bwd_chain.push_back(S.diag[first + p]); }
+                for (int q = 0; q < nE; ++q) S.bwd_chain.push_back(S.u_col[S.u_ptr[last] + q]);
+                for (int p = 0; p < b; ++p)
+                    for (int q = 0; q < nE; ++q) S.bwd_chain.push_back(find_in_row(S, first + p, S.u_col[S.u_ptr[last] + q]));
+                for (int p = 0; p < b; ++p)
+                    for (int c2 = 0; c2 < b; ++c2) S.bwd_chain.push_back(c2 > p ? find_in_row(S, first + p, first + c2) : -1);
+            }
+            segs.push_back(sg);
+        }, max_level);
+    };
+    S.chain_level.assign(n, 0);
+    build_bwd(false, S.bwd_seg, S.bwd_rec, S.n_bwd_levels, &S.chain_level);
+    S.bwdj_seg.clear(); S.bwdj_rec.clear(); S.n_bwdj_levels = 0;
+    if (S.jordan) build_bwd(true, S.bwdj_seg, S.bwdj_rec, S.n_bwdj_levels, nullptr);
 }
 
 // Selected inverse Z = A^-1 on the pattern of the factor (Takahashi recursion, for a SYMMETRIC matrix: only the upper part
@@ -649,6 +676,7 @@ int analyze(int n, const int* rowptr, const int* col, long long policy64, BlockS
     S.symmetric = (policy >> 1) & 1;
     S.prefactor = ((policy >> 2) & 1) && S.inplace;
     S.top_split = (policy >> 3) & 1;
+    S.jordan = (int)((policy64 >> 49) & 1);                       // a request here; build_top grants it
     S.n = n;
     if (n <= 0) return 1;
     // adjacency without the diagonal; verify structural symmetry and diagonal presence

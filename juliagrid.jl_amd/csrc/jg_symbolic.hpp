@@ -66,7 +66,7 @@ struct Rec { int w[16]; };
 //     w5 children, w6 offset of the pivot list, w7 offset of the child records, w8 offset of the diagonal entries (all relative
 //     to w3), w9 class (2, 3, 4: the front has at most 16 class rows and columns), w10 task level, w11 f + 1,
 //     w12 log2 of the scenario interleave of the task's update block on the stack (= w13 of its parent), w13 log2 G of the task's own
-//     geometry (below)
+//     geometry (below), w14 first block of the task's JORDAN rows in the factor storage (-1: none; below)
 //   data: entry map [f][f + 1] (see build_top), diagonal entries [m], child records {stack offset, e_c, inv[f + 1]}, pivots [m]
 // GROUPED tasks (plans with a "mid" policy, large batches).  One workgroup per scenario is the right shape for the dense top (fronts of
 // 30-60 block rows), but a (task, scenario) workgroup costs ~10 us + ~1 us per pivot whatever its front, and its loads touch 16 bytes
@@ -77,6 +77,19 @@ struct Rec { int w[16]; };
 // a task is interleaved over the G scenarios of its PARENT's workgroup ([scenario / G][stack][scenario % G] in 16-byte units), so the
 // extend-add of a grouped task is coalesced as well.  A launch of grouped tasks holds every G > 1 task of one task level: workgroup x
 // of a 64-scenario group finds its (task, scenario block) in top_wgmap.
+// JORDAN rows (plans with policy bit 49, unsymmetric, no grouped tasks).  The backward sweep over the top used to be the one sequential
+// piece left in the solve: a chain of m pivots is m dependent steps (one workgroup barrier each, jg_engine.hip: bwd_chain_task), and the
+// top of a transmission grid is ~120 pivots deep.  A task has its pivot rows in registers anyway, so it eliminates each pivot column
+// ABOVE the diagonal as well (Gauss-Jordan inside the task: rows i < q get  row_i -= U(i,q) D(q)^-1 row_q  in the very bulk update that
+// serves the rows below, which touches every block of the thread grid whether it needs to or not).  What leaves the task for pivot row
+// i is then  J(i, .) = the row over the EXTERNAL columns of the front only  and  y'_i, with
+//     x_i = D(i)^-1 (y'_i - sum_{c in ext(task)} J(i,c) x_c):
+// every row of a task depends on pivots of ANCESTOR tasks only, the rows of a task are one backward level of plain wave records, and the
+// depth of the sweep over the top falls from its pivots to its task levels.  J is dense (m x e blocks per task) where U(i, ext) is not,
+// so it lives behind the factor entries: block w14 + i * e + c with w14 >= n_entries.  The in-task triangle of U keeps the multipliers U(i,q) as
+// they stood when column q was eliminated.  L, D and the update matrices are untouched: the forward elimination of another right-hand
+// side (Engine::forward) still produces y, not y' -- users of that path (iterative refinement, fast Newton-Raphson) switch the engine
+// back to the plain sweep (Engine::jordan = false: plain rows from the tasks, the chain tables below).
 constexpr int TOP_FRONT_MAX = 63;       // m + e of a task: 64 columns with the rhs = class 4 on the 16 x 16 thread grid
 struct TopLaunch { int task_begin, ntasks, cls, level, grouped, wg_begin, nwg, pad; };   // grouped: wgmap[wg_begin .. wg_begin + nwg) = task << 8 | scenario block
 
@@ -124,6 +137,11 @@ struct BlockSymbolic {
     std::vector<int> src_entry;         // [nnz of the caller's pattern] -> entry id
     std::vector<Segment> fact_seg, bwd_seg, fwd_seg;    // fwd: the forward elimination alone (rhs rows of the fact tables)
     std::vector<Rec> fact_rec, bwd_rec, fwd_rec;
+    int jordan = 0;                     // policy bit 49 and the plan qualifies: the top tasks can leave Jordan rows (see TopLaunch)
+    int n_jordan = 0;                   // blocks of Jordan rows behind the n_entries factor entries
+    std::vector<Segment> bwdj_seg;      // the backward sweep over Jordan rows (top pivots: wave records over ext(task); chains only below the top)
+    std::vector<Rec> bwdj_rec;
+    int n_bwdj_levels = 0;
     std::vector<int> bwd_chain;         // chain task data (see CHAIN_MAX_ROWS)
     std::vector<int> chain_level;       // [n] backward level of the chain (or single row) a pivot belongs to
     int n_fact_levels = 0, n_bwd_levels = 0, n_fwd_levels = 0;
@@ -153,6 +171,7 @@ struct BlockSymbolic {
 // wherever they sit in the tree, and tasks get a geometry by the size of their front (GROUPED tasks, above); bits 40-47: a task's
 // geometry is chosen so that it can take at least this many pivots (0 = default 6); bit 48: a task only absorbs pivots that need
 // its geometry (smaller fronts form tasks of their own below it).
+// policy bit 49: Jordan rows for the pivots of the top tasks + a second set of backward tables over them (see TOP_FRONT_MAX above).
 // Returns 0, or 1 on a malformed pattern.
 int analyze(int n, const int* rowptr, const int* col, long long policy, BlockSymbolic& out);
 // Replay tables of the selected inverse of a SYMMETRIC matrix on the factor pattern (see jg_symbolic.cpp); idempotent.

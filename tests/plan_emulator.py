@@ -34,10 +34,13 @@ class Replay:
     """inplace=True mirrors policy bit 0: the caller's blocks already sit in the factor storage and
     off-diagonal entries without update terms are not scheduled at all."""
 
-    def __init__(self, plan, inplace=False, symmetric=False, prefactor=False, producer=True):
+    def __init__(self, plan, inplace=False, symmetric=False, prefactor=False, producer=True, jordan=False):
         """prefactor mirrors policy bit 2: the pivots nobody updates (pre_pivot) are level-0 items -- finished by the producer
-        (producer=True: their diagonal blocks arrive factorised, their rhs rows are in place) or by the plan's PRE tables."""
+        (producer=True: their diagonal blocks arrive factorised, their rhs rows are in place) or by the plan's PRE tables.
+        jordan mirrors Engine::jordan on a plan with policy bit 49: the top tasks eliminate above the diagonal too and leave Jordan rows
+        behind the factor entries; the backward sweep walks the "bwdj" tables."""
         self.p = plan
+        self.jordan = jordan
         self.prefactor, self.producer = prefactor, producer
         g = plan.get
         self.perm, self.e_row, self.e_col, self.e_src = g("perm"), g("e_row"), g("e_col"), g("e_src")
@@ -50,6 +53,10 @@ class Replay:
         self.fseg, self.frec = plan.replay_tables("fact")
         self.bseg, self.brec = plan.replay_tables("bwd")
         self.thdr, self.tdata, self.tlaunch, self.task_of, self.tinfo = plan.top_tables()
+        self.n_jordan = int(self.tinfo[7]) if self.tinfo.size > 7 else 0
+        if jordan:
+            assert self.tinfo.size > 7 and int(self.tinfo[6]) == 1, "not a Jordan plan"
+            self.bseg, self.brec = plan.replay_tables("bwdj")
 
     @staticmethod
     def _waves(seg, rec):
@@ -64,14 +71,15 @@ class Replay:
         """A: [nnz_blocks,2,2] caller CSR order; rhs [n,2] original order.
         Returns X [nE,2,2] (U, unscaled Lh, factored diagonal blocks) and y [n,2] (pivot order)."""
         nE = self.nE
-        X = np.zeros((nE, 2, 2))
+        X = np.zeros((nE + self.n_jordan, 2, 2))                # Jordan rows sit behind the factor entries
+        X[nE:] = np.nan
         Y = np.zeros((self.n, 2))
         level_of = np.full(nE + self.n, -1)      # level at which an entry / rhs row becomes final (-1: never yet)
         partial = np.zeros(nE + self.n, dtype=bool)          # task-owned items that hold their bottom terms only
         part_level = np.zeros(nE + self.n, dtype=int)
         if self.inplace:
             has = self.e_src >= 0
-            X[has] = A[self.e_src[has]]
+            X[:nE][has] = A[self.e_src[has]]
             work = np.diff(self.t_ptr)
             untouched = has & (work == 0) & (self.e_row != self.e_col)
             if self.task_of.size:                           # task-owned entries become final inside their task
@@ -208,7 +216,12 @@ class Replay:
                 assert nwg == 0
             for ti in range(tb, tb + ntk):
                 m, e, root, base, soff, nchild, piv_off, child_off, dent_off, tcls, tl, fprime, lgo, lg = (int(v) for v in hdr[ti][:14])
+                jbase = int(hdr[ti][14])
                 f = m + e
+                if self.tinfo.size > 7 and int(self.tinfo[6]):
+                    assert (jbase >= nE and jbase + m * e <= nE + self.n_jordan and lg == 0) if e > 0 else jbase == -1
+                else:
+                    assert jbase == -1
                 assert (lg > 0) == bool(grouped) and lg in (0, 2, 4) and lgo in (0, 2, 4)
                 if soff >= 0:
                     assert (lgo, soff) not in geom_of_stack
@@ -293,17 +306,26 @@ class Replay:
                     for i in range(q + 1, f):
                         for c in range(q + 1, fprime):
                             F[i, c] = F[i, c] - F[i, q] @ Z[c]
+                    if self.jordan:                          # ... and above the diagonal: rows of finished pivots lose column q
+                        for i in range(q):
+                            for c in range(q + 1, fprime):
+                                F[i, c] = F[i, c] - F[i, q] @ Z[c]
                     terms += s * (s + 1)
                     if q + 1 < m:
                         D[q + 1] = dfactor(F[q + 1, q + 1])
                 assert not np.isnan(F).any()
-                results.append((ti, owned, F, D, tp, m, e, soff, dent, lgo))
-            for ti, owned, F, D, tp, m, e, soff, dent, lgo in results:             # tasks of one launch are independent of each other
+                results.append((ti, owned, F, D, tp, m, e, soff, dent, lgo, jbase))
+            for ti, owned, F, D, tp, m, e, soff, dent, lgo, jbase in results:      # tasks of one launch are independent of each other
                 f = m + e
                 for ent, r, c in owned:
                     X[ent] = F[r, c]
+                    if self.jordan and r < m and c >= m:     # U(pivot, external): superseded by the Jordan row, not stored by the task
+                        X[ent] = np.nan
                     level_of[ent] = lev
                     partial[ent] = False
+                if self.jordan and e > 0:
+                    assert np.isnan(X[jbase: jbase + m * e]).all(), "Jordan rows of two tasks overlap"
+                    X[jbase: jbase + m * e] = F[:m, m:f].reshape(m * e, 2, 2)
                 for q in range(m):
                     X[dent[q]] = D[q]
                     level_of[dent[q]] = lev
@@ -388,6 +410,13 @@ class Replay:
                         for t in range(int(r[3])):
                             ent, col = int(r[4 + 2 * t]), int(r[5 + 2 * t])
                             assert 0 <= level_of[col] < level, "bwd schedule race"
+                            if ent >= self.nE:                   # Jordan row: block (local pivot, external column) of the pivot's task
+                                h = self.thdr[self.task_of[k]]
+                                tpv = self.tdata[int(h[3]) + int(h[6]): int(h[3]) + int(h[6]) + int(h[0])]
+                                q, il = (ent - int(h[14])) % int(h[1]), (ent - int(h[14])) // int(h[1])
+                                assert self.jordan and tpv[il] == k and self._front_ext(int(h[2]))[q] == col
+                            else:
+                                assert self.e_row[ent] == k and self.e_col[ent] == col and not (self.jordan and self.task_of[k] >= 0)
                             part -= X[ent] @ W[col]
                             terms += 1
                     if sub == 0:
@@ -402,7 +431,15 @@ class Replay:
             for key, (kk, bus, dg) in meta.items():
                 level_of[kk] = level
         assert (level_of >= 0).all(), "rows missing from the backward schedule"
-        assert terms == int(self.u_ptr[-1]), "U terms lost or duplicated in the records"
+        if self.jordan:                                      # a task pivot has one term per external column of its task instead of its U row
+            want = 0
+            for k in range(self.n):
+                kk = int(self.thdr[self.task_of[k]][2]) if self.task_of[k] >= 0 else k
+                want += int(self.u_ptr[kk + 1] - self.u_ptr[kk])
+            assert terms == want, "terms lost or duplicated in the Jordan records"
+        else:
+            assert terms == int(self.u_ptr[-1]), "U terms lost or duplicated in the records"
+        assert not np.isnan(out).any()
         return out
 
     def selected_inverse(self, X):

@@ -18,14 +18,18 @@ def _oracle_jacobian(oracle, name):
     return s, a, J, f0, inc
 
 
-@pytest.mark.parametrize("inplace", [False, True, "producer finishes level 0", "pre tables"])
+@pytest.mark.parametrize("inplace", [False, True, "producer finishes level 0", "pre tables", "producer finishes level 0, Jordan rows"])
 @pytest.mark.parametrize("name", ["case14test", "case30test", "case118", "case1354pegase"])
 def test_schedule_replay_matches_oracle_increment(jg, oracle, name, inplace):
     s, a, J, f0, inc = _oracle_jacobian(oracle, name)
     rowptr, col, A = block_jacobian_from_csc(s.n, s.colptr, s.rowval, a.type, a.pq, a.pvpq, a.jcolptr, a.jrowval, J)
     pre = isinstance(inplace, str)                            # policy bit 2: level 0 by the producer / by the plan's PRE tables
-    plan = jg._lib.Plan(s.n, rowptr, col, policy=(1 | 4) if pre else (1 if inplace else 0))
-    rp = Replay(plan, inplace=bool(inplace), prefactor=pre, producer=inplace == "producer finishes level 0")
+    jordan = pre and "Jordan" in inplace                      # policy bit 49: what jg_nr_create asks for (granted where the plan has top tasks)
+    plan = jg._lib.Plan(s.n, rowptr, col, policy=((1 | 4) if pre else (1 if inplace else 0)) | (1 << 49 if jordan else 0))
+    if jordan:
+        jordan = bool(plan.top_tables()[4][6])
+        assert jordan == (plan.top_tables()[0].shape[0] > 0) and (jordan or s.n < 100)
+    rp = Replay(plan, inplace=bool(inplace), prefactor=pre, producer=pre and inplace.startswith("producer finishes level 0"), jordan=jordan)
     if pre:
         plain = jg._lib.Plan(s.n, rowptr, col, policy=1)
         assert plan.get("e_level").max() == plain.get("e_level").max() - 1      # every level moved down by one
@@ -259,6 +263,16 @@ def _solve_with_plan(jg, n, edges, rng, symmetric=False, top=0, prefactor=None):
     X, Yf = rp.factor(A, rhs)
     x = rp.backsolve(X, Yf)
     assert np.abs(x.reshape(-1) - np.linalg.solve(dense, rhs.reshape(-1))).max() <= 1e-11
+    if plan.top_tables()[4][6]:                                 # a Jordan plan carries both sweeps: the same system through the Jordan rows
+        rj = Replay(plan, inplace=True, symmetric=symmetric, prefactor=pre, producer=bool(prefactor), jordan=True)
+        Xj, Yj = rj.factor(A, rhs)
+        xj = rj.backsolve(Xj, Yj)
+        assert np.abs(xj.reshape(-1) - np.linalg.solve(dense, rhs.reshape(-1))).max() <= 1e-11
+        nE = plan.get("e_row").size
+        keep = ~np.isnan(Xj[:nE]).any(axis=(1, 2))
+        lower_or_diag = plan.get("e_row") >= plan.get("e_col")
+        assert np.array_equal(Xj[:nE][lower_or_diag], X[:nE][lower_or_diag]), "Lh and D are untouched by the Jordan elimination"
+        assert keep[lower_or_diag].all()
     return plan
 
 
@@ -287,6 +301,50 @@ def test_top_tasks_on_small_and_random_graphs(jg, monkeypatch, symmetric, top_le
         plan = _solve_with_plan(jg, n, edges, rng, symmetric, top=top_level << 8 | soft << 16 | (8 if ci % 3 == 0 else 0), prefactor=None if symmetric else ci % 2 == 0)
         ntasks += plan.top_tables()[0].shape[0]
     assert ntasks > 5              # (a prefactor plan has one level less: fewer pivots above a given top level)
+
+
+@pytest.mark.parametrize("top_level,soft", [(1, 4), (1, 63), (2, 8), (3, 16), (6, 24)])
+def test_jordan_rows_on_small_and_random_graphs(jg, top_level, soft):
+    """Plans with policy bit 49 (jg_symbolic.hpp: Jordan rows): the top tasks eliminate above the diagonal as well, the pivots of a
+    task become ONE backward level of wave records over the task's external columns, chains only exist below the top.  Replayed both
+    ways (plain sweep and Jordan sweep of the same plan) against a dense solve; a symmetric plan must refuse the bit."""
+    rng = np.random.default_rng(31 * top_level + soft)
+    cases = [(2, [(0, 1)]), (12, [(i, i + 1) for i in range(11)]), (9, [(0, i) for i in range(1, 9)]),
+             (8, [(i, j) for i in range(8) for j in range(i + 1, 8)]),
+             (24, [(i, j) for i in range(24) for j in range(i + 1, 24)]),
+             (20, [(i, i + 1) for i in range(0, 19)] + [(i, i + 10) for i in range(10)]),
+             (40, [(i, j) for i in range(40) for j in range(i + 1, min(i + 4, 40))])]
+    for _ in range(8):
+        n = int(rng.integers(20, 100))
+        m = int(rng.integers(n, 3 * n))
+        cases.append((n, [tuple(sorted(rng.choice(n, 2, replace=False))) for _ in range(m)]))
+    granted = 0
+    for ci, (n, edges) in enumerate(cases):
+        policy = top_level << 8 | soft << 16 | (8 if ci % 3 == 0 else 0) | 1 << 49
+        plan = _solve_with_plan(jg, n, edges, rng, False, top=policy, prefactor=ci % 2 == 0)
+        hdr, _, _, task_of, info = plan.top_tables()
+        assert int(info[6]) == (1 if hdr.shape[0] else 0)
+        if not info[6]:
+            continue
+        granted += 1
+        # every pivot of a task sits in ONE backward level of the Jordan tables, and no chain task holds a task pivot
+        seg, rec = plan.replay_tables("bwdj")
+        chain = plan.get("bwd_chain")
+        level_of_row = {}
+        for base, nchunks, wpi, rpw, level, *_ in seg:
+            if wpi == 0:
+                for t in range(nchunks):
+                    nb, nE, off, _ = (int(v) for v in rec[base + t][:4])
+                    assert all(task_of[int(k)] < 0 for k in chain[off: off + 3 * nb: 3])
+                continue
+            for r in rec[base: base + nchunks * 16 * rpw]:
+                if r[0] >= 0:
+                    level_of_row[int(r[0])] = int(level)
+        for t in range(hdr.shape[0]):
+            assert len({level_of_row[int(k)] for k in np.flatnonzero(task_of == t)}) == 1
+    assert granted > 8
+    sym = _solve_with_plan(jg, 40, [(i, j) for i in range(40) for j in range(i + 1, min(i + 4, 40))], rng, True, top=2 << 8 | 16 << 16 | 1 << 49)
+    assert sym.top_tables()[0].shape[0] > 0 and int(sym.top_tables()[4][6]) == 0 and int(sym.top_tables()[4][7]) == 0
 
 
 @pytest.mark.parametrize("symmetric", [False, True])
