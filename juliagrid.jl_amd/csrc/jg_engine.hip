@@ -311,6 +311,81 @@ __device__ __forceinline__ void bwd_chain_task(const BwdArgs& a, double* lds, co
     __syncthreads();
 }
 
+// A SMALL chain (jg_symbolic.hpp: at most CHAIN_SMALL_ROWS rows, every chain below the top): the same two phases on eight waves with
+// everything a row needs in the registers of ITS wave.  Wave p * wpr owns row p: its right-hand side, diagonal block, state-update
+// operands and the in-chain blocks U(k_p, k_c) (requested CHAIN_PF steps ahead) -- all asked for before the first use, together with the
+// external blocks, so the task is ONE round trip to memory, a reduction of the partial sums and nb - 1 barriers of an 8-wave workgroup
+// (the general task stages x_E and the sums in LDS: four dependent round trips and 16-wave barriers, ~13 us against ~6 for a 7-row chain).
+// Waves beyond 8 (the 16-wave kernel) only keep the barriers company.  LDS: part[8] | xc[2] (double2 per lane each).
+constexpr int CHAIN_SMALL_LDS_D2 = (8 + 2) * 64;
+__device__ __forceinline__ void bwd_chain_small(const BwdArgs& a, double* lds, const RecS& rec, int wave, int lane, size_t b, size_t ld) {
+    const int nb = rec[0], nE = rec[1], wpr = rec[3];
+    CIntPtr rows = (CIntPtr)a.chain + rec[2];
+    CIntPtr ecol = rows + 3 * nb;
+    CIntPtr uext = ecol + nE;
+    CIntPtr uin = uext + nb * nE;
+    double2* part = (double2*)lds;
+    double2* xc = part + 8 * 64;
+    const int p = wave / wpr, sub = wave & (wpr - 1);
+    const bool live = wave < 8 && p < nb, owner = live && sub == 0;
+    UpdPre up{0, false, 0.0, 0.0};
+    double y0 = 0.0, y1 = 0.0;
+    Blk d{0.0, 0.0, 0.0, 0.0};
+    int k = 0, bus = 0;
+    Blk mb[CHAIN_PF];
+    auto request = [&](int c, Blk& m) { if (owner && c > p) m = load_blk(a.X, (size_t)uin[p * nb + c], b, ld); };
+    if (owner) {
+        k = rows[3 * p]; bus = rows[3 * p + 1];
+        up = upd_prefetch(a, bus, b, ld);
+        const double2 y = load_vec(a.W, (size_t)k, b, ld); y0 = y.x; y1 = y.y;
+        d = load_blk(a.X, (size_t)rows[3 * p + 2], b, ld);
+    }
+#pragma unroll
+    for (int s = 0; s < CHAIN_PF; ++s) request(nb - 1 - s, mb[s]);
+    // ---- phase A: the external columns of row p, dealt over its wpr waves
+    if (live) {
+        const int len = (nE + wpr - 1) / wpr;
+        const int q1 = min(sub * len + len, nE);
+        for (int q = sub * len; q < q1; q += 4) {
+            Blk m[4]; double2 x[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (q + t < q1) { m[t] = load_blk(a.X, (size_t)uext[p * nE + q + t], b, ld); x[t] = load_vec(a.W, (size_t)ecol[q + t], b, ld); }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (q + t < q1) {
+                    y0 -= m[t].v00 * x[t].x + m[t].v01 * x[t].y;
+                    y1 -= m[t].v10 * x[t].x + m[t].v11 * x[t].y;
+                }
+        }
+    }
+    if (wpr > 1) {                                               // uniform across the workgroup
+        if (live && sub != 0) part[wave * 64 + lane] = double2{y0, y1};
+        __syncthreads();
+        if (owner) for (int w = 1; w < wpr; ++w) { const double2 t = part[(wave + w) * 64 + lane]; y0 += t.x; y1 += t.y; }
+    }
+    // ---- phase B: from the last pivot up, one barrier per pivot (none after the first row's)
+    for (int c0 = nb - 1; c0 >= 0; c0 -= CHAIN_PF) {
+#pragma unroll
+        for (int s = 0; s < CHAIN_PF; ++s) {
+            const int c = c0 - s;
+            if (c >= 0) {                                        // uniform across the workgroup
+                double2* slot = xc + (c & 1) * 64;
+                if (owner && p == c) slot[lane] = bwd_finish(a, d, y0, y1, k, bus, b, ld, up);
+                if (c > 0) {
+                    __syncthreads();
+                    if (owner && p < c) {
+                        const double2 x = slot[lane];
+                        y0 -= mb[s].v00 * x.x + mb[s].v01 * x.y;
+                        y1 -= mb[s].v10 * x.x + mb[s].v11 * x.y;
+                    }
+                    request(c - CHAIN_PF, mb[s]);
+                }
+            }
+        }
+    }
+}
+
 // One chunk of a backward segment: x_k = Dinv_k (y_k - sum_c U(k,c) x_c), scattered to original order; optional fused
 // state update (Newton-Raphson: V/theta -= increment on active scenarios).
 __device__ __forceinline__ void bwd_chunk(const BwdArgs& a, double* red, const RecS& first, size_t rec_index, int rpw, int wpi,
@@ -358,14 +433,15 @@ __device__ __forceinline__ void level_body(const Args& a, double* red) {
         base = sg[0]; nchunks = sg[1]; wpi = sg[2]; rpw = sg[3];
     }
     int grp, bx;
-    if (!map_block(a.sel, a.ld, BWD ? nchunks * (16 / BW) : nchunks * (16 / FACT_WAVES), grp, bx)) return;
+    if (!map_block(a.sel, a.ld, BWD ? (wpi <= 0 ? nchunks : nchunks * (16 / BW)) : nchunks * (16 / FACT_WAVES), grp, bx)) return;
     const int lane = threadIdx.x;
     const int wave = uniform(threadIdx.y);
     const size_t ld = (size_t)a.ld;
     const size_t b = (size_t)min(grp * 64 + lane, a.lanes - 1);
     if constexpr (BWD) {
-        if (wpi == 0) {                                          // chain segment: one task (one record) per workgroup
-            bwd_chain_task(a, red, load_rec(a.rec, (size_t)base + bx), wave, lane, b, ld);
+        if (wpi <= 0) {                                          // chain segment: one task (one record) per workgroup
+            if (wpi < 0) bwd_chain_small(a, red, load_rec(a.rec, (size_t)base + bx), wave, lane, b, ld);
+            else if constexpr (BW == 16) bwd_chain_task(a, red, load_rec(a.rec, (size_t)base + bx), wave, lane, b, ld);
             return;
         }
     }
@@ -1416,7 +1492,7 @@ int Engine::backsolve(hipStream_t st, double* out, const StateUpdate& upd, const
         a.seg_begin = L.seg_begin;
         { const Segment& g = segs[L.seg_begin]; a.s0_base = g.rec_base; a.s0_nchunks = g.nchunks; a.s0_wpi = g.wpi; a.s0_rpw = g.rpw; }
         if (!L.chain && L.wpi_max <= 8)                         // 0.387 -> 0.381 ms at 512 scenarios
-            hipLaunchKernelGGL(k_bwd_level8, dim3((unsigned)L.grid * 2 * gs, L.nseg), dim3(64, 8), 8 * 128 * sizeof(double), st, a);
+            hipLaunchKernelGGL(k_bwd_level8, dim3((unsigned)L.grid * 2 * gs, L.nseg), dim3(64, 8), CHAIN_SMALL_LDS_D2 * sizeof(double2), st, a);
         else
         hipLaunchKernelGGL(k_bwd_level, dim3((unsigned)L.grid * gs, L.nseg), dim3(64, 16),
                            L.chain ? (size_t)CHAIN_LDS_D2 * sizeof(double2) : 16 * 128 * sizeof(double), st, a);

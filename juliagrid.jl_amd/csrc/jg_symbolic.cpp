@@ -598,17 +598,20 @@ void build_tables(BlockSymbolic& S) {
                 x.w[3]++;
             }
         }, [&](int l, std::vector<Segment>& segs, std::vector<Rec>& recs) {
-            const std::vector<int>& cs = chains_at[l];
-            if (cs.empty()) return;
+            static const bool no_small = getenv("JG_CHAIN_SMALL") && atoi(getenv("JG_CHAIN_SMALL")) == 0;     // experiments: every chain a general task
+            for (int small = 0; small < 2; ++small) {            // the general tasks (wpi 0), then the small ones (wpi -1, jg_symbolic.hpp)
+            std::vector<int> cs;
+            for (int c : chains_at[l]) if ((clen[c] <= CHAIN_SMALL_ROWS && !no_small) == (small != 0)) cs.push_back(c);
+            if (cs.empty()) continue;
             Segment sg{};
-            sg.rec_base = (int)recs.size(); sg.nchunks = (int)cs.size(); sg.wpi = 0; sg.rpw = 1; sg.level = l; sg.last = 0; sg.items = 0;
+            sg.rec_base = (int)recs.size(); sg.nchunks = (int)cs.size(); sg.wpi = small ? -1 : 0; sg.rpw = 1; sg.level = l; sg.last = 0; sg.items = 0;
             for (int c : cs) {
                 const int b = clen[c], first = cstart[c], last = first + b - 1;
                 const int nE = uw[last];
                 Rec r{};
                 r.w[0] = b; r.w[1] = nE; r.w[2] = (int)S.bwd_chain.size();
                 int wpr = 1;
-                while (wpr * 2 * b <= 16) wpr *= 2;              // waves per row in the external phase
+                while (wpr * 2 * b <= (small ? 8 : 16)) wpr *= 2;   // waves per row in the external phase
                 r.w[3] = wpr;
                 recs.push_back(r);
                 sg.items += b;
@@ -620,6 +623,7 @@ void build_tables(BlockSymbolic& S) {
                     for (int c2 = 0; c2 < b; ++c2) S.bwd_chain.push_back(c2 > p ? find_in_row(S, first + p, first + c2) : -1);
             }
             segs.push_back(sg);
+            }
         }, max_level);
     };
     S.chain_level.assign(n, 0);

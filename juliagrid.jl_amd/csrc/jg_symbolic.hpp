@@ -44,7 +44,11 @@ constexpr int BWD_T = 6;    // BwdRec:  {k, bus, diag, nterms, (u_ent, u_col) x 
 // of kernel launches.  A chain segment has wpi = 0 and ONE record per task: {b, nE, off, wpr}; at bwd_chain[off]:
 //   rows[b] x {pivot, original block index, diagonal entry} | ecol[nE] external columns (pivots) |
 //   uext[b][nE] entries U(row, ecol) | uin[b][b] entries U(row p, row c) for c > p (else -1)
-constexpr int CHAIN_MAX_ROWS = 32, CHAIN_MAX_EXT = 72;
+// SMALL chains (at most CHAIN_SMALL_ROWS rows: every chain below the top; segment wpi = -1, same task data, wpr = 8 / pow2ceil(b)): eight
+// waves, wave p * wpr owns row p -- its sum, its diagonal block and its in-chain blocks stay in registers, the external columns are read
+// straight from the solution vector, LDS only carries the partial sums and x_c.  A third of the latency of the general task, and a level
+// whose chains are all small runs the 8-wave kernel (two workgroups per CU) instead of the 16-wave one with 125 KB of LDS.
+constexpr int CHAIN_MAX_ROWS = 32, CHAIN_MAX_EXT = 72, CHAIN_SMALL_ROWS = 8;
 struct Rec { int w[16]; };
 
 // ---- multifrontal TOP of the elimination tree ---------------------------------------------------------------------

@@ -365,10 +365,13 @@ class Replay:
         chain = self.p.get("bwd_chain")
         terms = 0
         for si, (base, nchunks, wpi, rpw, level, _last, _items, _pad) in enumerate(self.bseg):
-            if wpi == 0:
+            if wpi <= 0:                                     # chain tasks: general (wpi 0, 16 waves) or small (wpi -1, 8 waves, at most 8 rows)
                 for t in range(nchunks):
                     nb, nE, off, wpr = (int(v) for v in self.brec[base + t][:4])
-                    assert 2 <= nb <= 32 and nE <= 72 and wpr in (1, 2, 4, 8) and (wpr == 1 or wpr * nb <= 16)
+                    if wpi == 0:
+                        assert 2 <= nb <= 32 and nE <= 72 and wpr in (1, 2, 4, 8) and (wpr == 1 or wpr * nb <= 16)
+                    else:
+                        assert wpi == -1 and 2 <= nb <= 8 and nE <= 72 and wpr in (1, 2, 4) and wpr * nb <= 8 and (wpr == 4 or 2 * wpr * nb > 8)
                     rows = chain[off:off + 3 * nb].reshape(nb, 3)
                     ecol = chain[off + 3 * nb: off + 3 * nb + nE]
                     uext = chain[off + 3 * nb + nE: off + 3 * nb + nE + nb * nE].reshape(nb, nE)

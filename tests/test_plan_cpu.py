@@ -86,9 +86,9 @@ def test_plan_structure_invariants(jg):
         base, nchunks, wpi, rpw, level, last = (seg[:, k] for k in range(6))
         assert np.all(np.diff(level) >= 0) and last[-1] == 1
         assert np.all(last[:-1] == (level[1:] > level[:-1]))
-        assert np.all(np.isin(wpi, [0, 1, 2, 4, 8, 16])) and (kind == "bwd" or np.all(wpi > 0))     # wpi 0 = backward chain tasks
+        assert np.all(np.isin(wpi, [-1, 0, 1, 2, 4, 8, 16])) and (kind == "bwd" or np.all(wpi > 0))     # wpi 0 / -1 = backward chain tasks (general / small)
         for l in np.unique(level):
-            assert np.unique(wpi[level == l]).size == (level == l).sum() <= 6
+            assert np.unique(wpi[level == l]).size == (level == l).sum() <= 7
         count = np.where(wpi > 0, nchunks * 16 * rpw, nchunks)                                      # one record per chain task
         assert base[0] == 0 and np.all(base[1:] == base[:-1] + count[:-1])
         assert rec.shape[0] == base[-1] + count[-1]
@@ -127,7 +127,7 @@ def test_plan_structure_invariants(jg):
     lead = lead[rec[lead, 0] >= 0]
     chain = plan.get("bwd_chain")
     in_chains = []
-    for b, c in seg[seg[:, 2] == 0][:, :2]:
+    for b, c in seg[seg[:, 2] <= 0][:, :2]:
         for nb, nE, off, wpr in rec[b:b + c, :4]:
             in_chains += chain[off:off + 3 * nb:3].tolist()
     assert sorted(rec[lead, 0].tolist() + in_chains) == list(range(Y.n))                            # every pivot exactly once
@@ -332,7 +332,7 @@ def test_jordan_rows_on_small_and_random_graphs(jg, top_level, soft):
         chain = plan.get("bwd_chain")
         level_of_row = {}
         for base, nchunks, wpi, rpw, level, *_ in seg:
-            if wpi == 0:
+            if wpi <= 0:
                 for t in range(nchunks):
                     nb, nE, off, _ = (int(v) for v in rec[base + t][:4])
                     assert all(task_of[int(k)] < 0 for k in chain[off: off + 3 * nb: 3])
