@@ -790,7 +790,9 @@ int jg_gn_create(jg_gn** out, int64_t n, const int64_t* colptr, const int64_t* r
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return failg(2, "jg_gn_create: stream creation failed"); }
     // in place (k_gn_gain writes into the factor storage) + symmetric (the factorisation reads U(k,i)' for Lh(i,k): LDL'
     // with half the update terms)
-    rc = h->eng.create((int)n, h->gi_rowptr.data(), h->gi_col.data(), h->ld, 3, h->stream);
+    // bit 49: Jordan rows for the pivots of the top tasks (jg_symbolic.hpp).  What reads the in-task triangle of U -- the forward elimination
+    // of the orthogonal method, the selected inverse of the bad-data test -- factorises with Engine::jordan off (below).
+    rc = h->eng.create((int)n, h->gi_rowptr.data(), h->gi_col.data(), h->ld, 3 | 1LL << 49, h->stream);
     if (rc) { std::string msg = h->eng.error; jg_gn_destroy(h); return failg(rc, msg); }
     const std::vector<int>& ip = h->eng.plan->S.iperm;
     // wave records (see k_gn_gain): bus rows in PIVOT order -- the postorder of the elimination tree keeps electrical
@@ -1015,6 +1017,7 @@ int jg_gn_set_method(jg_gn* h, int method) {
         h->exec = nullptr; h->graph = nullptr;
     }
     h->method = method;
+    h->eng.jordan = method == 0 && h->eng.plan->S.jordan && !(getenv("JG_JORDAN") && atoi(getenv("JG_JORDAN")) == 0);   // method 1 runs forward() on the factor
     return 0;
 }
 
@@ -1239,7 +1242,11 @@ int jg_gn_residual_test(jg_gn* h, double* max_nres, int32_t* index) {
     {
         launch_rows(h);                                              // residual and Jacobian at the CURRENT state
         launch_gain(h);
-        if (int rc = h->eng.factor(h->stream, nullptr, h->d_rhs, jg::GroupSel{})) return failg(rc, h->eng.error);
+        const bool jordan = h->eng.jordan;
+        h->eng.jordan = false;                                       // the selected inverse walks U itself: plain rows from the tasks
+        const int rcf = h->eng.factor(h->stream, nullptr, h->d_rhs, jg::GroupSel{});
+        h->eng.jordan = jordan;                                      // (the next increment factorises again before it solves)
+        if (rcf) return failg(rcf, h->eng.error);
         if (int rc = h->eng.selected_inverse(h->stream, jg::GroupSel{})) return failg(rc, h->eng.error);
     }
     ProjArgs a{h->d_pair_ptr, h->d_pa, h->d_pb, h->d_pz, h->d_slot_bus, h->d_Hs, h->eng.Zs, h->d_res, h->d_w, h->d_nres, h->m, h->slack0, h->ld};
@@ -1277,7 +1284,7 @@ int jg_gn_time_kernel(jg_gn* h, int kernel, int reps, double* mean_ms) {
         else if (kernel == 1) launch_gain(h);
         else if (kernel == 2) { if (int rc = h->eng.factor(h->stream, nullptr, h->d_rhs, jg::GroupSel{})) return failg(rc, h->eng.error); }
         else if (kernel == 3) { if (int rc = h->eng.backsolve(h->stream, h->d_inc, none, jg::GroupSel{})) return failg(rc, h->eng.error); }
-        else { if (int rc = h->eng.selected_inverse(h->stream, jg::GroupSel{})) return failg(rc, h->eng.error); }
+        else { if (int rc = h->eng.selected_inverse(h->stream, jg::GroupSel{})) return failg(rc, h->eng.error); }    // (timing only: whatever the storage holds)
     }
     GN_HIP(hipEventRecord(e1, h->stream));
     GN_HIP(hipEventSynchronize(e1));

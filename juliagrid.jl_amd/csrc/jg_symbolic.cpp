@@ -421,7 +421,10 @@ void build_top(BlockSymbolic& S, int top_level, int soft_cap, int struct_min, in
         }
     }
     if (want_jordan) {
-        bool plain = !S.symmetric;                               // (symmetric plans read U(k,i)' for Lh(i,k) and feed the selected inverse: U stays U)
+        // (symmetric plans too: a task mirrors its front from the upper entries, eliminates the full front and stores the upper part -- the
+        // Jordan rows are upper blocks.  The in-task triangle then holds multipliers, not U: whoever reads U(k,i)' as Lh(i,k) of a TASK pivot
+        // -- the forward elimination alone, the selected inverse -- factorises with Engine::jordan off.)
+        bool plain = true;
         for (const Task& t : tasks) if (t.lg > 0) plain = false;
         if (plain) S.jordan = 1;
         else { S.n_jordan = 0; for (Rec& h : S.top_task) h.w[14] = -1; }

@@ -81,7 +81,7 @@ struct Rec { int w[16]; };
 // a task is interleaved over the G scenarios of its PARENT's workgroup ([scenario / G][stack][scenario % G] in 16-byte units), so the
 // extend-add of a grouped task is coalesced as well.  A launch of grouped tasks holds every G > 1 task of one task level: workgroup x
 // of a 64-scenario group finds its (task, scenario block) in top_wgmap.
-// JORDAN rows (plans with policy bit 49, unsymmetric, no grouped tasks).  The backward sweep over the top used to be the one sequential
+// JORDAN rows (plans with policy bit 49, no grouped tasks).  The backward sweep over the top used to be the one sequential
 // piece left in the solve: a chain of m pivots is m dependent steps (one workgroup barrier each, jg_engine.hip: bwd_chain_task), and the
 // top of a transmission grid is ~120 pivots deep.  A task has its pivot rows in registers anyway, so it eliminates each pivot column
 // ABOVE the diagonal as well (Gauss-Jordan inside the task: rows i < q get  row_i -= U(i,q) D(q)^-1 row_q  in the very bulk update that

@@ -343,8 +343,12 @@ def test_jordan_rows_on_small_and_random_graphs(jg, top_level, soft):
         for t in range(hdr.shape[0]):
             assert len({level_of_row[int(k)] for k in np.flatnonzero(task_of == t)}) == 1
     assert granted > 8
-    sym = _solve_with_plan(jg, 40, [(i, j) for i in range(40) for j in range(i + 1, min(i + 4, 40))], rng, True, top=2 << 8 | 16 << 16 | 1 << 49)
-    assert sym.top_tables()[0].shape[0] > 0 and int(sym.top_tables()[4][6]) == 0 and int(sym.top_tables()[4][7]) == 0
+    # symmetric plans (LDL' through transposed reads of the upper entries) carry Jordan rows as well; a plan with grouped tasks does not
+    for ci, (n, edges) in enumerate(cases):
+        sym = _solve_with_plan(jg, n, edges, rng, True, top=top_level << 8 | soft << 16 | (8 if ci % 3 == 0 else 0) | 1 << 49)
+        assert int(sym.top_tables()[4][6]) == (1 if sym.top_tables()[0].shape[0] else 0)
+    grp = _solve_with_plan(jg, 40, [(i, j) for i in range(40) for j in range(i + 1, min(i + 4, 40))], rng, False, top=2 << 8 | 16 << 16 | 1 << 49 | 1 << 32 | 1 << 40)
+    assert grp.top_tables()[0].shape[0] > 0 and int(grp.top_tables()[4][6]) == 0 and int(grp.top_tables()[4][7]) == 0
 
 
 @pytest.mark.parametrize("symmetric", [False, True])
