@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libjgrid_hip.so")
+LIB_PATH = os.environ.get("JG_LIB") or os.path.join(HERE, "libjgrid_hip.so")     # JG_LIB: another build of the same library (A/B experiments)
 
 I64P = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
 I32P = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")

@@ -93,3 +93,52 @@ def test_grouped_tasks_match_the_default_plan(tmp_path, case, batch, env):
     ok = a["st"] == 0
     assert ok.sum() >= 0.9 * batch
     assert np.abs(a["vm"] - b["vm"])[ok].max() < 1e-9 and np.abs(a["va"] - b["va"])[ok].max() < 1e-9
+
+
+def _state(tmp_path, tag, case, batch, env):
+    import numpy as np
+    out = str(tmp_path / f"{tag}.npz")
+    ee = dict(os.environ)
+    ee.update({k: str(v) for k, v in env.items()})
+    r = subprocess.run([sys.executable, "-c", SCRIPT_STATE.format(root=ROOT, case=case, batch=batch, out=out)], env=ee, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    with np.load(out) as z:
+        return {k: z[k] for k in z.files}
+
+
+@pytest.mark.parametrize("case,batch", [("case118", 70), ("case1354pegase", 300), ("case_ACTIVSg10k", 130), ("case_ACTIVSg10k", 512)])
+def test_jordan_rows_and_small_chains_match_the_plain_backward_sweep(tmp_path, case, batch):
+    """Round 3: the top tasks eliminate above the diagonal as well and leave Jordan rows (the backward sweep over the top is one plain level
+    per task level instead of sequential chains: jg_symbolic.hpp), and the chains below the top run as 8-wave tasks.  Both change the order
+    of a handful of additions, not the algorithm: against the plain sweep (JG_JORDAN=0) and the general chain tasks (JG_CHAIN_SMALL=0) the
+    iteration counts and status are equal and V / theta agree to 1e-10."""
+    import numpy as np
+    ref = _state(tmp_path, "ref", case, batch, dict())
+    ok = ref["st"] == 0
+    assert ok.sum() >= 0.9 * batch
+    for tag, env in (("plain", dict(JG_JORDAN=0)), ("general", dict(JG_CHAIN_SMALL=0)), ("both", dict(JG_JORDAN=0, JG_CHAIN_SMALL=0))):
+        b = _state(tmp_path, tag, case, batch, env)
+        assert np.array_equal(ref["it"], b["it"]) and np.array_equal(ref["st"], b["st"]), tag
+        assert np.abs(ref["vm"] - b["vm"])[ok].max() < 1e-10 and np.abs(ref["va"] - b["va"])[ok].max() < 1e-10, tag
+
+
+def test_refined_steps_switch_the_engine_back_to_plain_rows():
+    """Iterative refinement runs forward() + backsolve() on the factor of the step: the forward elimination of another right-hand side gives
+    y, not the y' Jordan rows go with, so jg_nr_set_refine turns Engine::jordan off (and on again when refinement goes off).  A handle that
+    refined and stopped refining must give the bits of one that never did."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_case
+    import juliagrid.jl_amd as jg
+    s = jg.powerSystem(load_case("case1354pegase"))
+    plain = jg.newtonRaphson(s)
+    jg.powerFlow_(plain)
+    once = jg.newtonRaphson(s, refine=True)
+    jg.powerFlow_(once)
+    assert np.array_equal(once.method.iteration, plain.method.iteration)
+    assert np.abs(once.voltage.magnitude - plain.voltage.magnitude).max() < 1e-10 and np.abs(once.voltage.angle - plain.voltage.angle).max() < 1e-10
+    jg.powerflow.setRefinement_(once, False)
+    jg.setInitialPoint_(once)
+    jg.powerFlow_(once)
+    assert np.array_equal(once.voltage.magnitude, plain.voltage.magnitude) and np.array_equal(once.voltage.angle, plain.voltage.angle)
+    plain.close(); once.close()
