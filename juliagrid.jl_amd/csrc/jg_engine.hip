@@ -628,6 +628,11 @@ __device__ __forceinline__ void blk_sub(Blk& c, const Blk& l, const Blk& z) {
     c.v11 = fma(-l.v11, z.v11, fma(-l.v10, z.v01, c.v11));
 }
 
+// TIMING PROBES of a pivot step (compile with -DJG_PROBE_TOP=1: the next pivot's row / column are not published, =2: one block update per
+// thread instead of CLS x CLS; wrong numbers -- tools/level_bound_probe.sh): what a step is made of.
+#ifndef JG_PROBE_TOP
+#define JG_PROBE_TOP 0
+#endif
 constexpr int TOP_THREADS = 320;        // 16 x 16 bulk threads + the pivot wave
 
 // PW = false: no pivot wave (256 threads).  The thread that owns the diagonal block of the NEXT pivot factorises it right after its
@@ -897,9 +902,9 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
             for (int c = 0; c < CLS; ++c) {
                 const Blk z = zcol(Ubuf[cur], c * 16 + gj);
 #pragma unroll
-                for (int r = 0; r < CLS; ++r) blk_sub(T[r][c], Lq[r], z);
+                for (int r = 0; r < CLS; ++r) if (JG_PROBE_TOP != 2 || (r == 0 && c == 0)) blk_sub(T[r][c], Lq[r], z);
             }
-            if (q + 1 < m) {                     // the next pivot row / column leave their owners
+            if (q + 1 < m && JG_PROBE_TOP != 1) {                     // the next pivot row / column leave their owners
                 // classes before the pivot's are finished (zeros), classes after it go out as they are (both uniform); only the
                 // pivot's own class needs a per-lane select
                 const int rq = (q + 1) >> 4, tq = (q + 1) & 15;

@@ -497,6 +497,12 @@ void build_tables(BlockSymbolic& S) {
             if (it < nE) { x.w[s] = lower_operand(S.t_a[t]); x.w[s + 1] = S.t_d[t]; x.w[s + 2] = S.t_b[t]; }
             else { x.w[s] = lower_operand(S.l_ent[t]); x.w[s + 1] = S.diag[S.l_col[t]]; x.w[s + 2] = S.l_col[t]; }
             x.w[3]++;
+            // TIMING PROBES (JG_PROBE_LOADS, wrong numbers -- tools/level_bound_probe.sh): what does a level launch wait for?
+            // 1: no update term at all (what is left: dispatch, record, the item's own block in and out, reduction);  2: every operand of a
+            // term is its pivot block (the same loads issued, all served from cache: no miss traffic)
+            static const int probe = getenv("JG_PROBE_LOADS") ? atoi(getenv("JG_PROBE_LOADS")) : 0;
+            if (probe == 1) x.w[3] = 0;
+            if (probe == 2 && it < nE) { x.w[s] = x.w[s + 1]; x.w[s + 2] = x.w[s + 1]; }
         }
     };
     S.n_sched_terms = S.top_terms;
