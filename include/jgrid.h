@@ -112,6 +112,12 @@ int jg_nr_solve(jg_nr* h);
  * (~ +45 % per iteration).  Independent of the mode a pivot block that cancels to rounding level marks its scenario (status 3).
  * mode 0 (default): no refinement -- Newton's iteration corrects a rounding-level error of one step in the next. */
 int jg_nr_set_refine(jg_nr* h, int mode);
+/* Performance hint, no counterpart in the reference (one analysis at a time).  mode 1: this handle is one of SEVERAL batches in flight on
+ * its GPU (a pipeline of contingency batches): the multifrontal top of the factorisation always runs its 4-wave kernel variant, which
+ * leaves room on a CU for the workgroups of the other batches (+2-3 % throughput with three 512-scenario batches in flight, -0.6 % for a
+ * handle that runs alone).  Results are bitwise the same either way (tests/test_top_variants_gpu.py).  mode 0 (default): by the size of
+ * each launch. */
+int jg_nr_set_shared(jg_nr* h, int mode);
 /* powerFlow!(analysis; iteration, tolerance) -- acPowerFlow.jl:1389-1433, per scenario, with the
  * reference's loop accounting.  iters/status: [batch]; status 0 converged, 1 iteration limit,
  * 3 numeric failure. */
@@ -305,7 +311,8 @@ int jg_nr_allgather_results(jg_nr* h, jg_comm* c, double* dst_dev);
  * diagonal.  policy: bit 0 in-place factor storage, bit 1 symmetric values (LDL'), bit 2 the producer finishes level 0 (the
  * leaf pivots: factorised diagonal blocks + rhs rows; csrc/jg_symbolic.hpp), bits 4-7 / 8-15 / 16-23 / 24-30 where the
  * multifrontal top starts and how large its fronts get (0 = defaults), bits 32-39 / 40-47 / 48 the grouped tasks below the
- * top (csrc/jg_symbolic.hpp: "mid").  jg_plan_export(which): see csrc/jg_plan_api.cpp;
+ * top (csrc/jg_symbolic.hpp: "mid"), bit 49 Jordan rows for the pivots of the top tasks + the backward tables over them (what
+ * jg_nr_create / jg_gn_create ask for; csrc/jg_symbolic.hpp).  jg_plan_export(which): see csrc/jg_plan_api.cpp;
  * out == NULL returns the length.
  * ------------------------------------------------------------------------------------------- */
 typedef struct jg_plan jg_plan;

@@ -56,6 +56,7 @@ def lib():
         "jg_nr_mismatch": [VP, F64P, F64P],
         "jg_nr_solve": [VP],
         "jg_nr_set_refine": [VP, C.c_int],
+        "jg_nr_set_shared": [VP, C.c_int],
         "jg_nr_run": [VP, C.c_int64, C.c_double, I32P, I32P],
         "jg_nr_run_defer": [VP, C.c_int64, C.c_double, C.c_int64, C.POINTER(C.c_int32)],
         "jg_nr_move_lanes": [VP, C.c_int64, VP, I32P, C.POINTER(C.c_int32)],

@@ -14,6 +14,7 @@ import numpy as np
 
 import threading
 
+from . import _lib
 from .powerflow import AcPowerFlow, newtonRaphson, powerFlow_, setOutage_, setOutages_, _push_voltage
 from .system import PowerSystem
 
@@ -141,6 +142,9 @@ class ContingencyPipeline:
             # there would no longer be bitwise the scenario of a lockstep batch
             lanes = max(lanes, 256) if -(-self.batch // 64) * 64 >= 256 else min(lanes, 192)
             self.pools = [_Pool(newtonRaphson(system, batch=lanes, device=device, max_patch=4)) for _ in range(2)]
+        if len(self.handles) + len(self.pools) > 1:      # several batches share the GPU: the top launches leave room for the others' workgroups
+            for an in self.handles + [p.handle for p in self.pools]:
+                _lib.check(_lib.lib().jg_nr_set_shared(an._h, 1))
         if start is not None:
             self.setStart(*start)
         else:                                            # default restart point of every solve: the start newtonRaphson() built

@@ -1395,7 +1395,9 @@ int Engine::factor(hipStream_t st, const double* A, const double* rhs, const Gro
             // scenarios: 0.86 against 1.02 us per step with two workgroups on a CU).
             static const int pw_env = getenv("JG_TOP_PW") ? atoi(getenv("JG_TOP_PW")) : -1;
             const long long wgs = (long long)L.ntasks * std::min<long long>(t.lanes, (long long)t.lpg * (ld / 64));
-            const bool pw = pw_env >= 0 ? pw_env != 0 : wgs <= 256 * (L.cls == 4 ? 1 : (L.cls == 3 ? 2 : 3));
+            // (shared: the handle is one of several batches in flight on this GPU -- a CU with two 4-wave top workgroups still has room for a level
+            // workgroup of another batch, with 5-wave ones it has not: +2-3 % on the 512 x 3 pipeline, -0.6 % on a lone factorisation; same bits)
+            const bool pw = pw_env >= 0 ? pw_env != 0 : (!shared && wgs <= 256 * (L.cls == 4 ? 1 : (L.cls == 3 ? 2 : 3)));
             static const int fuse_env = getenv("JG_TOP_FUSE") ? atoi(getenv("JG_TOP_FUSE")) : 0;
             if (jordan) {                                        // Jordan rows (jg_symbolic.hpp); the plain sweep's tables would read garbage after this
                 if (pw) {

@@ -196,6 +196,7 @@ struct Engine {
     // forward() + backsolve() need (the forward elimination of another right-hand side produces y, not the y' Jordan rows go with).
     // Read by factor() and backsolve() at launch time: change it only between a backsolve and the next factorisation.
     bool jordan = false;
+    bool shared = false;           // hint (jg_nr_set_shared): other batches are in flight on this GPU -- the top launches take the 4-wave variant (same bits)
     Rec* top_task = nullptr; int* top_data = nullptr;          // multifrontal top (jg_symbolic.hpp): task headers, task data
     int* top_wgmap = nullptr;                                  // workgroup map of the grouped launches
     double* top_stack = nullptr;                               // update matrices of the tasks, scenario-major [ld][S.top_stack]

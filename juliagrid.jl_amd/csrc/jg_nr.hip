@@ -1269,6 +1269,20 @@ int jg_nr_set_refine(jg_nr* h, int mode) {
     return 0;
 }
 
+int jg_nr_set_shared(jg_nr* h, int mode) {
+    if (!h || mode < 0 || mode > 1) return fail(1, "jg_nr_set_shared: bad argument");
+    if (int rc = set_device(h)) return rc;
+    NR_HIP(hipStreamSynchronize(h->stream));
+    if ((mode != 0) != h->eng.shared) {                          // the iteration graph holds the launches of the other choice
+        if (h->execB) { hipGraphExecDestroy(h->execB); h->execB = nullptr; }
+        if (h->graphB) { hipGraphDestroy(h->graphB); h->graphB = nullptr; }
+        if (h->execA) { hipGraphExecDestroy(h->execA); h->execA = nullptr; }
+        if (h->graphA) { hipGraphDestroy(h->graphA); h->graphA = nullptr; }
+    }
+    h->eng.shared = mode != 0;
+    return 0;
+}
+
 namespace {
 
 // Start of a batched solve: every real scenario active, lanes in home order, all groups in use.  keep_iters: the lanes carry

@@ -122,14 +122,12 @@ def test_jordan_rows_and_small_chains_match_the_plain_backward_sweep(tmp_path, c
         assert np.abs(ref["vm"] - b["vm"])[ok].max() < 1e-10 and np.abs(ref["va"] - b["va"])[ok].max() < 1e-10, tag
 
 
-def test_refined_steps_switch_the_engine_back_to_plain_rows():
+def test_refined_steps_switch_the_engine_back_to_plain_rows(jg):
     """Iterative refinement runs forward() + backsolve() on the factor of the step: the forward elimination of another right-hand side gives
     y, not the y' Jordan rows go with, so jg_nr_set_refine turns Engine::jordan off (and on again when refinement goes off).  A handle that
     refined and stopped refining must give the bits of one that never did."""
     import numpy as np
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import load_case
-    import juliagrid.jl_amd as jg
     s = jg.powerSystem(load_case("case1354pegase"))
     plain = jg.newtonRaphson(s)
     jg.powerFlow_(plain)
@@ -142,3 +140,19 @@ def test_refined_steps_switch_the_engine_back_to_plain_rows():
     jg.powerFlow_(once)
     assert np.array_equal(once.voltage.magnitude, plain.voltage.magnitude) and np.array_equal(once.voltage.angle, plain.voltage.angle)
     plain.close(); once.close()
+
+
+def test_shared_device_hint_keeps_the_bits(jg):
+    """jg_nr_set_shared (a pipeline's handles: every top launch takes the 4-wave kernel variant) is a performance hint: same bits."""
+    import numpy as np
+    from conftest import load_case
+    s = jg.powerSystem(load_case("case_ACTIVSg10k"))
+    labels = jg.outageList(s, 130, seed=11)
+    a = jg.contingencyAnalysis(s, labels)
+    b = jg.contingencyAnalysis(s, labels)
+    jg._lib.check(jg._lib.lib().jg_nr_set_shared(b._h, 1))
+    for an in (a, b):
+        jg.powerFlow_(an, iteration=20, tolerance=1e-8)
+    assert np.array_equal(a.method.iteration, b.method.iteration)
+    assert np.array_equal(a.voltage.magnitude, b.voltage.magnitude) and np.array_equal(a.voltage.angle, b.voltage.angle)
+    a.close(); b.close()
