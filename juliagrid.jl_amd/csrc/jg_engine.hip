@@ -660,6 +660,7 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
     __shared__ __attribute__((aligned(16))) double Ubuf[2][64 * 4];    // pivot row  U(q, c)
     __shared__ __attribute__((aligned(16))) double Lbuf[2][64 * 4];    // pivot column Lh(i, q)
     __shared__ __attribute__((aligned(16))) double Dini[64 * 4];       // the chain's diagonal blocks as loaded (for the pivot wave)
+    __shared__ __attribute__((aligned(16))) double Dref[64 * 2];       // pivot guard: row maxima of those blocks BEFORE the children's update matrices came in
     __shared__ __attribute__((aligned(16))) double U1buf[FUSE ? 2 : 1][FUSE ? 64 * 4 : 4];   // FUSE: row / column / diagonal block of the pair's
     __shared__ __attribute__((aligned(16))) double L1buf[FUSE ? 2 : 1][FUSE ? 64 * 4 : 4];   // SECOND pivot, not yet touched by the first
     __shared__ __attribute__((aligned(16))) double Sbuf[2][4];
@@ -718,6 +719,10 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
                     if ((cd >> 28) & 2) { const double s = v.v01; v.v01 = v.v10; v.v10 = s; }        // symmetric plans: Lh(i,c) = U(c,i)'
                 }
                 T[r][c] = v;
+                // what the guard compares a pivot with: the block as it entered the task -- a pivot that the children's update matrices (or the
+                // task's own steps) cancel to rounding level is the signature of an island whose root sits in the top (taken after
+                // the extend-add the reference scale was the cancelled value itself)
+                if (r == c && gi == gj && r * 16 + gi < m) *(double2*)(Dref + (size_t)(r * 16 + gi) * 2) = row_max(v);
             }
         if (prof) pt[1] = wall_clock64();
         // ---- extend-add: every thread pulls what the children left for its blocks (child order fixed => deterministic)
@@ -762,14 +767,14 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
                 }
             }
         if (tid == 0) {
-            const Blk d0 = factor_diag(T[0][0], bad, row_max(T[0][0]));
+            const Blk d0 = factor_diag(T[0][0], bad, *(const double2*)Dref);
             lds_set(Dbuf[0], 0, d0);
             if (!PW) T[0][0] = d0;                               // without a pivot wave the owner keeps the factorised block for the store
         }
     }
     __syncthreads();
     if (pivot_wave) {
-        if (lane < m) { mydiag = lds_get(Dini, lane); const double2 rm = row_max(mydiag); myref_x = rm.x; myref_y = rm.y; }
+        if (lane < m) { mydiag = lds_get(Dini, lane); const double2 rm = *(const double2*)(Dref + (size_t)lane * 2); myref_x = rm.x; myref_y = rm.y; }
         if (lane == 0) mydiag = lds_get(Dbuf[0], 0);
     }
     int q_done = 0;                                              // pivots finished by fused steps
@@ -795,7 +800,7 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
             Blk S1 = lds_get(Sbuf[cur], 0);
             blk_sub(S1, Lq1q, zq1);
             int bad1 = 0;
-            const Blk D1 = factor_diag(S1, bad1, row_max(lds_get(Dini, q1)));
+            const Blk D1 = factor_diag(S1, bad1, *(const double2*)(Dref + (size_t)q1 * 2));
             const int rq1 = q1 >> 4, tq1 = q1 & 15;
             if (gi == tq1 && gj == tq1) bad |= bad1;             // reported once, by the owner of the block
             const bool sw1 = D1.v10 > 2.0;
@@ -840,7 +845,7 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
                             for (int r = 0; r < CLS; ++r)
                                 if (r == rp) {
                                     if (w == 0) {
-                                        const Blk dn = factor_diag(T[r][r], bad, row_max(lds_get(Dini, p)));
+                                        const Blk dn = factor_diag(T[r][r], bad, *(const double2*)(Dref + (size_t)p * 2));
                                         lds_set(Dbuf[nxt], 0, dn);
                                         T[r][r] = dn;
                                     } else lds_set(Sbuf[nxt], 0, T[r][r]);
@@ -909,11 +914,11 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
                 // pivot's own class needs a per-lane select
                 const int rq = (q + 1) >> 4, tq = (q + 1) & 15;
                 if (!PW && gi == tq && gj == tq) {               // the owner of S(q+1, q+1): final now, factorised here
-                    const Blk ini = lds_get(Dini, q + 1);
+                    const double2 ref = *(const double2*)(Dref + (size_t)(q + 1) * 2);
 #pragma unroll
                     for (int r = 0; r < CLS; ++r)
                         if (r == rq) {
-                            const Blk dn = factor_diag(T[r][r], bad, row_max(ini));
+                            const Blk dn = factor_diag(T[r][r], bad, ref);
                             lds_set(Dbuf[nxt], 0, dn);
                             T[r][r] = dn;                        // later steps see L = 0 for this row: it stays what it is
                         }

@@ -213,3 +213,37 @@ def test_refined_newton_step(jg, oracle, name):
             assert np.array_equal(a.status, b.status) and np.array_equal(a.method.iteration, b.method.iteration)
             ok = a.status == 0
             assert np.abs(a.voltage.magnitude[ok] - b.voltage.magnitude[ok]).max() < 1e-8 and np.abs(a.voltage.angle[ok] - b.voltage.angle[ok]).max() < 1e-8
+
+
+@pytest.mark.parametrize("copies,batch", [(3, 6), (4, 70)])
+def test_island_whose_root_pivot_sits_in_the_top_tasks(jg, copies, batch):
+    """the guard of k_fact_top took its reference scale AFTER the children's update matrices had come in, so a pivot that those
+    cancel -- the last pivot of an island as large as a whole sub-grid, whose root sits in the multifrontal top -- was compared with itself.
+    Instances of case1354pegase tied slack to slack by single lines: the outage of a tie cuts off one or more whole instances without a slack
+    bus.  Those scenarios must come back with status 3, their neighbours in the batch bitwise untouched."""
+    from juliagrid.jl_amd.synthetic import tiledGrid
+    t = load_case("case1354pegase")
+    one = jg.newtonRaphson(jg.powerSystem(t))
+    jg.powerFlow_(one)
+    jg.power_(one)
+    slack = int(np.flatnonzero(np.asarray(one.system.bus.layout.type) == 3)[0])
+    p_slack = float(np.asarray(one.power.supply.active).reshape(-1)[slack])
+    one.close()
+    s = jg.powerSystem(tiledGrid(t, copies, slack_active=p_slack))
+    nb = s.branch.number
+    ties = [nb - (copies - 1) + c + 1 for c in range(copies - 1)]          # the tie lines are the last branches (1-based labels)
+    assert all(jg.bridges(s)[k - 1] for k in ties)
+    good = [int(x) for x in jg.outageList(s, batch - len(ties), seed=5)]
+    labels = good[:2] + [ties[0]] + good[2:-1] + ties[1:] + good[-1:]
+    an = jg.contingencyAnalysis(s, labels)
+    jg.powerFlow_(an, iteration=20, tolerance=1e-8)
+    ref = jg.contingencyAnalysis(s, [lab for lab in labels if lab not in ties])
+    jg.powerFlow_(ref, iteration=20, tolerance=1e-8)
+    keep = [i for i, lab in enumerate(labels) if lab not in ties]
+    for i, lab in enumerate(labels):
+        if lab in ties:
+            assert an.status[i] == 3, f"the outage of tie {lab} came back with status {an.status[i]} after {an.method.iteration[i]} iterations"
+    assert (ref.status == 0).sum() >= len(keep) - 2
+    assert np.array_equal(an.status[keep], ref.status) and np.array_equal(an.method.iteration[keep], ref.method.iteration)
+    assert np.array_equal(an.voltage.magnitude[keep], ref.voltage.magnitude) and np.array_equal(an.voltage.angle[keep], ref.voltage.angle)
+    an.close(); ref.close()
