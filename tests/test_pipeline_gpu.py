@@ -69,3 +69,58 @@ def test_pool_handles_scenarios_without_a_power_flow(jg):
     a.close(); b.close()
     assert np.array_equal(it_a, it_b) and np.array_equal(st_a, st_b)
     assert set(np.unique(st_a)) <= {0, 1, 3} and st_a[100] != 0 and st_a[201] != 0
+
+
+def test_bench_default_pipeline_ends_at_the_oracle(jg, oracle):
+    """The configuration bench.py times by default -- case_ACTIVSg10k, 512 outage scenarios per batch, THREE batches in flight, a straggler
+    pool of 256 lanes, results delivered as packed device records -- checked straight against the oracle (it was covered
+    transitively only, pool == lockstep and lockstep == oracle).  Picked from the packed record of a job: every scenario that finished in
+    the pool (it needed more iterations than its batch ran in lockstep), and a handful that never left their batch."""
+    import torch
+    t = load_case("case_ACTIVSg10k")
+    s = jg.powerSystem(t)
+    n = s.bus.number
+    base = jg.newtonRaphson(s)
+    jg.powerFlow_(base)
+    start = (base.voltage.magnitude.copy(), base.voltage.angle.copy())
+    base.close()
+    labels = [int(x) for x in jg.outageList(s, 4 * 512, seed=512)]
+    jobs = [labels[i:i + 512] for i in range(0, len(labels), 512)]
+    pipe = jg.ContingencyPipeline(s, 512, inflight=3, start=start, pool=256)
+    assert len(pipe.handles) == 3 and pipe.pools
+    ring = 4
+    rec = _records(torch, ring, 512, n)
+    seen = {}
+
+    def on_done(j, an):
+        seen[j] = rec[j % ring].clone()
+        torch.cuda.current_stream().synchronize()
+
+    res = pipe.run(jobs, iteration=20, tolerance=1e-8, on_done=on_done, record=lambda j: rec[j % ring].data_ptr(), records=ring)
+    pipe.close()
+    osys = oracle.OracleSystem(t)
+    checked_pool = 0
+    for j in (0, 3):                                                  # the first job and the last one (its stragglers empty the pool at the end)
+        r = seen[j].cpu().numpy()
+        it, st = res[j]
+        assert np.array_equal(r[:, 2 * n], it.astype(float)) and np.array_equal(r[:, 2 * n + 1], st.astype(float))
+        ok = st == 0
+        assert ok.sum() >= 500
+        lock = int(np.median(it[ok]))                                 # what the batch ran in lockstep: later finishers went through the pool
+        late = np.flatnonzero(ok & (it > lock))
+        assert late.size > 0
+        picks = sorted(set([int(x) for x in late[:6]] + [0, 77, 300, 511]))
+        for sc in picks:
+            o = oracle.OracleNR(osys)
+            ptr, dy = jg.outagePatch(s, jobs[j][sc])
+            for p, d in zip(ptr, dy):
+                o.add_ybus(p - 1, d)
+            o.set_voltage(*start)
+            stat = o.power_flow(iteration=20, tolerance=1e-8)
+            assert stat == st[sc]
+            if stat == 0:
+                vm, va = o.voltage()
+                assert it[sc] == o.iteration
+                assert np.abs(r[sc, :n] - vm).max() <= 1e-8 and np.abs(r[sc, n:2 * n] - va).max() <= 1e-8
+                checked_pool += int(it[sc] > lock)
+    assert checked_pool >= 4
