@@ -1016,7 +1016,7 @@ int jg_nr_dims(jg_nr* h, int64_t* dims) {
     if (!h || !dims) return fail(1, "jg_nr_dims: bad argument");
     dims[0] = h->dimJ; dims[1] = h->nnzJ; dims[2] = h->eng.plan->S.n_entries; dims[3] = h->eng.plan->S.n_sched_terms;
     dims[4] = (int64_t)(h->eng.fact.size() + h->eng.plan->S.top_launch.size());      // dependent launches of one factorisation
-    dims[5] = (int64_t)h->eng.bwd.size();
+    dims[5] = (int64_t)(h->eng.jordan ? h->eng.bwdj.size() : h->eng.bwd.size());     // ... of the backward sweep the handle runs (Jordan rows or plain)
     return 0;
 }
 
