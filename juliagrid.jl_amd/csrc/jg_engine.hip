@@ -1286,7 +1286,11 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, long long 
     // against 280 items / 4 pivots, which the small grids keep: case1354pegase 0.148 against 0.160 ms; the 9241-bus grid does not care)
     const bool defaults = !((policy >> 16) & 0x7fff);
     if (defaults && ld_ >= 256 && !getenv("JG_TOP_NOSPLIT")) policy |= 8;
-    if (defaults) policy |= ld_ >= 256 ? (n >= 4000 ? (47 << 16 | (384 / 8) << 24 | 8 << 4) : (47 << 16 | (280 / 8) << 24 | 4 << 4))
+    // round 3 (the top launches got cheaper: Jordan rows, 4-wave variant where it pays): on the large grids a large batch starts the top where a level
+    // holds at most 12 pivots, whatever its item count (narrow = 127: no limit) -- ACTIVSg10k: level 22 instead of 27, 1.236 -> 1.213 ms at 512
+    // scenarios, three interleaved runs each; the 9241-bus grid does not care
+    static const bool top_r02 = getenv("JG_TOP_R02") != nullptr;     // the rule of round 2 (384 items, 8 pivots)
+    if (defaults) policy |= ld_ >= 256 ? (n >= 4000 ? (top_r02 ? (47 << 16 | (384 / 8) << 24 | 8 << 4) : (47 << 16 | 127 << 24 | 12 << 4)) : (47 << 16 | (280 / 8) << 24 | 4 << 4))
                                               : ((n >= 4000 ? 26 : 24) << 16 | (384 / 8) << 24);
     {
         int rc = 0;

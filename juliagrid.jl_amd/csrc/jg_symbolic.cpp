@@ -873,6 +873,7 @@ int analyze(int n, const int* rowptr, const int* col, long long policy64, BlockS
             // +35 % at 512 -- a task needs a workgroup per scenario, the level kernel only a wave per 64).
             int narrow = ((policy >> 24) & 0x7f) * 8;             // the owner knows its batch: a task costs a workgroup per scenario
             if (narrow == 0) narrow = TOP_NARROW;
+            if (narrow == 127 * 8) narrow = 0x7fffffff;           // 127: no item limit (the pivots-per-level limit decides)
             if (const char* e = getenv("JG_TOP_ITEMS")) narrow = atoi(e);
             int nlev = 0;
             for (int e = 0; e < S.n_entries; ++e) nlev = std::max(nlev, S.e_level[e]);

@@ -12,7 +12,7 @@ ld = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 s = jg.powerSystem(case)
 jg.acModel_(s)
 Y = s.model.ac.nodalMatrix
-policy = 1 | 4 | (((47 << 16 | (384 // 8) << 24 | 8 << 4) if Y.n >= 4000 else (47 << 16 | (280 // 8) << 24 | 4 << 4)) if ld >= 256 else ((26 if Y.n >= 4000 else 24) << 16 | (384 // 8) << 24))
+policy = 1 | 4 | (((47 << 16 | 127 << 24 | 12 << 4) if Y.n >= 4000 else (47 << 16 | (280 // 8) << 24 | 4 << 4)) if ld >= 256 else ((26 if Y.n >= 4000 else 24) << 16 | (384 // 8) << 24))
 plan = jg._lib.Plan(Y.n, Y.colptr - 1, Y.rowval - 1, policy=policy)
 seg, rec = plan.replay_tables("fact")
 print("level  segs  items  wgs(8 waves)  terms  max_terms_item  kinds(U/L, D, rhs, partial)")
