@@ -1290,8 +1290,14 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, long long 
     // holds at most 12 pivots, whatever its item count (narrow = 127: no limit) -- ACTIVSg10k: level 22 instead of 27, 1.236 -> 1.213 ms at 512
     // scenarios, three interleaved runs each; the 9241-bus grid does not care
     static const bool top_r02 = getenv("JG_TOP_R02") != nullptr;     // the rule of round 2 (384 items, 8 pivots)
+    // a handful of scenarios (the owner sets `lanes` before create: a single power flow, up to 32 scenarios) of an unsymmetric matrix: the top starts as
+    // low as the level schedule allows (no item limit) -- a task costs one workgroup per REAL scenario, and since the Jordan rows the pivots of the top
+    // are the cheap ones of the backward sweep as well.  ACTIVSg10k, one scenario: factorisation 0.283 -> 0.244 ms, backward sweep 0.104 -> 0.060,
+    // 2.04 -> 1.67 ms per solve (9241-bus grid 1.76 -> 1.58); 32 scenarios 0.419 -> 0.363; from 64 scenarios on and for the gain matrices (whose
+    // factorisation loses what their sweep wins) the threshold stays 384 items.
+    const bool tiny = !top_r02 && ld_ == 64 && lanes > 0 && lanes <= 32 && !(policy & 2);
     if (defaults) policy |= ld_ >= 256 ? (n >= 4000 ? (top_r02 ? (47 << 16 | (384 / 8) << 24 | 8 << 4) : (47 << 16 | 127 << 24 | 12 << 4)) : (47 << 16 | (280 / 8) << 24 | 4 << 4))
-                                              : ((n >= 4000 ? 26 : 24) << 16 | (384 / 8) << 24);
+                                              : ((n >= 4000 ? 26 : 24) << 16 | (tiny ? 127 : 384 / 8) << 24);
     {
         int rc = 0;
         plan = acquire_plan(n, rowptr, col, policy, st, error, rc);

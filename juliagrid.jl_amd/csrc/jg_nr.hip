@@ -971,6 +971,7 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
     // in place: the assembly kernel writes into the factor storage; bit 2: it also finishes the plan's level 0 (jg_symbolic.hpp: prefactor)
     // bit 49: Jordan rows for the pivots of the top tasks (jg_symbolic.hpp): the backward sweep over the top of the tree is a handful of
     // plain levels instead of sequential chains (refined steps and fast Newton-Raphson switch the engine back: Engine::jordan)
+    h->eng.lanes = h->batch;                                    // (known before the plan is chosen: a handful of scenarios gets a deeper top)
     rc = h->eng.create(n, rp.data(), cl.data(), h->ld, (getenv("JG_NO_PREFACTOR") ? 1LL : 1LL | 4) | 1LL << 49, h->stream);
     if (rc) { std::string m = h->eng.error; jg_nr_destroy(h); return fail(rc, m); }
     if (jg::upload(&h->d_dst, h->eng.plan->S.src_entry, err, h->stream)) { jg_nr_destroy(h); return fail(2, err); }

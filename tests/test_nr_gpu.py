@@ -229,9 +229,16 @@ def test_full_size_batch_properties(jg, oracle):
     assert (an.status == 0).sum() >= B - 4
     assert np.array_equal(an.voltage.magnitude[0], an.voltage.magnitude[B - 2])
     assert np.array_equal(an.voltage.angle[0], an.voltage.angle[B - 2])
+    # a scenario's result does not depend on the batch it is solved in -- bitwise within a plan class (33 - 255 lanes here: Engine::create), to
+    # rounding across classes (a handle for up to 32 scenarios starts its multifrontal top lower: another summation order)
+    alone = jg.newtonRaphson(jg.powerSystem(t), batch=33)
+    jg.powerFlow_(alone)
+    assert np.array_equal(alone.voltage.magnitude[0], an.voltage.magnitude[B - 1]) and np.array_equal(alone.voltage.angle[0], an.voltage.angle[B - 1])
+    assert alone.method.iteration[0] == an.method.iteration[B - 1]
+    alone.close()
     single = jg.newtonRaphson(jg.powerSystem(t))
     jg.powerFlow_(single)
-    assert np.array_equal(single.voltage.magnitude, an.voltage.magnitude[B - 1])
+    assert np.abs(single.voltage.magnitude - an.voltage.magnitude[B - 1]).max() <= 1e-12 and np.abs(single.voltage.angle - an.voltage.angle[B - 1]).max() <= 1e-12
     assert single.method.iteration == an.method.iteration[B - 1]
     osys = oracle.OracleSystem(t)
     for sc in (0, 17, 63, 64, 100, B - 1):
