@@ -1296,8 +1296,11 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, long long 
     // 2.04 -> 1.67 ms per solve (9241-bus grid 1.76 -> 1.58); 32 scenarios 0.419 -> 0.363; from 64 scenarios on and for the gain matrices (whose
     // factorisation loses what their sweep wins) the threshold stays 384 items.
     const bool tiny = !top_r02 && ld_ == 64 && lanes > 0 && lanes <= 32 && !(policy & 2);
+    // one lane group with more than 32 scenarios, large grids: the top starts where a level holds at most 36 pivots, whatever its item count (ACTIVSg10k at 64
+    // scenarios: level 12 instead of 17, factorisation + backward sweep 0.466 -> 0.417 ms; the 9241-bus grid 0.283 -> 0.29; two lane groups and more: no difference)
+    const bool lane64 = !top_r02 && ld_ == 64 && !tiny && n >= 4000 && !(policy & 2);
     if (defaults) policy |= ld_ >= 256 ? (n >= 4000 ? (top_r02 ? (47 << 16 | (384 / 8) << 24 | 8 << 4) : (47 << 16 | 127 << 24 | 12 << 4)) : (47 << 16 | (280 / 8) << 24 | 4 << 4))
-                                              : ((n >= 4000 ? 26 : 24) << 16 | (tiny ? 127 : 384 / 8) << 24);
+                                              : ((n >= 4000 ? 26 : 24) << 16 | (tiny || lane64 ? 127 : 384 / 8) << 24 | (lane64 ? 15 << 4 : 0));
     {
         int rc = 0;
         plan = acquire_plan(n, rowptr, col, policy, st, error, rc);

@@ -878,7 +878,8 @@ int analyze(int n, const int* rowptr, const int* col, long long policy64, BlockS
             int nlev = 0;
             for (int e = 0; e < S.n_entries; ++e) nlev = std::max(nlev, S.e_level[e]);
             for (int r = 0; r < n; ++r) nlev = std::max(nlev, S.y_level[r]);
-            int chains = (policy >> 4) & 0xf;                     // ... and at most this many pivots (parallel chains) per level (0: any)
+            int chains = (policy >> 4) & 0xf;                     // ... and at most this many pivots (parallel chains) per level (0: any;
+            if (chains >= 13) chains = chains == 13 ? 18 : (chains == 14 ? 24 : 36);   // 13 / 14 / 15 stand for 18 / 24 / 36)
             if (const char* e = getenv("JG_TOP_CHAINS")) chains = atoi(e);
             std::vector<int> cnt(nlev + 2, 0), piv(nlev + 2, 0);
             for (int e = 0; e < S.n_entries; ++e) if (!(S.symmetric && S.e_row[e] > S.e_col[e])) cnt[S.e_level[e]]++;

@@ -170,7 +170,7 @@ struct BlockSymbolic {
 // policy bit 3: top launches per (level, class) (large batches).
 // policy bits 8-15: dependency level from which pivots go to top tasks (0 = default: where the level schedule gets narrow,
 // 255 = no top tasks); bits 16-23: soft cap of a task's front (0 = default); bits 24-30: what "narrow" means, in units of 8
-// items per level (0 = default, 127 = no limit); bits 4-7: at most this many pivots per level in the top (0 = any).
+// items per level (0 = default, 127 = no limit); bits 4-7: at most this many pivots per level in the top (0 = any; 13 / 14 / 15 = 18 / 24 / 36).
 // policy bits 32-39 ("mid", 0 = off): pivots with at least this many neighbours at elimination -- and their ancestors -- go to tasks
 // wherever they sit in the tree, and tasks get a geometry by the size of their front (GROUPED tasks, above); bits 40-47: a task's
 // geometry is chosen so that it can take at least this many pivots (0 = default 6); bit 48: a task only absorbs pivots that need

@@ -229,9 +229,9 @@ def test_full_size_batch_properties(jg, oracle):
     assert (an.status == 0).sum() >= B - 4
     assert np.array_equal(an.voltage.magnitude[0], an.voltage.magnitude[B - 2])
     assert np.array_equal(an.voltage.angle[0], an.voltage.angle[B - 2])
-    # a scenario's result does not depend on the batch it is solved in -- bitwise within a plan class (33 - 255 lanes here: Engine::create), to
+    # a scenario's result does not depend on the batch it is solved in -- bitwise within a plan class (65 - 255 scenarios here: Engine::create), to
     # rounding across classes (a handle for up to 32 scenarios starts its multifrontal top lower: another summation order)
-    alone = jg.newtonRaphson(jg.powerSystem(t), batch=33)
+    alone = jg.newtonRaphson(jg.powerSystem(t), batch=65)
     jg.powerFlow_(alone)
     assert np.array_equal(alone.voltage.magnitude[0], an.voltage.magnitude[B - 1]) and np.array_equal(alone.voltage.angle[0], an.voltage.angle[B - 1])
     assert alone.method.iteration[0] == an.method.iteration[B - 1]
