@@ -1288,7 +1288,7 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, long long 
     if (defaults && ld_ >= 256 && !getenv("JG_TOP_NOSPLIT")) policy |= 8;
     // round 3 (the top launches got cheaper: Jordan rows, 4-wave variant where it pays): on the large grids a large batch starts the top where a level
     // holds at most 12 pivots, whatever its item count (narrow = 127: no limit) -- ACTIVSg10k: level 22 instead of 27, 1.236 -> 1.213 ms at 512
-    // scenarios, three interleaved runs each; the 9241-bus grid does not care
+    // scenarios, three interleaved runs each; the 9241-bus grid does not care; symmetric plans -- the Gauss-Newton gain -- keep the rule of round 2: 2.96 against 2.99 ms for factorisation + sweep
     static const bool top_r02 = getenv("JG_TOP_R02") != nullptr;     // the rule of round 2 (384 items, 8 pivots)
     // a handful of scenarios (the owner sets `lanes` before create: a single power flow, up to 32 scenarios) of an unsymmetric matrix: the top starts as
     // low as the level schedule allows (no item limit) -- a task costs one workgroup per REAL scenario, and since the Jordan rows the pivots of the top
@@ -1299,7 +1299,7 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, long long 
     // one lane group with more than 32 scenarios, large grids: the top starts where a level holds at most 36 pivots, whatever its item count (ACTIVSg10k at 64
     // scenarios: level 12 instead of 17, factorisation + backward sweep 0.466 -> 0.417 ms; the 9241-bus grid 0.283 -> 0.29; two lane groups and more: no difference)
     const bool lane64 = !top_r02 && ld_ == 64 && !tiny && n >= 4000 && !(policy & 2);
-    if (defaults) policy |= ld_ >= 256 ? (n >= 4000 ? (top_r02 ? (47 << 16 | (384 / 8) << 24 | 8 << 4) : (47 << 16 | 127 << 24 | 12 << 4)) : (47 << 16 | (280 / 8) << 24 | 4 << 4))
+    if (defaults) policy |= ld_ >= 256 ? (n >= 4000 ? (top_r02 || (policy & 2) ? (47 << 16 | (384 / 8) << 24 | 8 << 4) : (47 << 16 | 127 << 24 | 12 << 4)) : (47 << 16 | (280 / 8) << 24 | 4 << 4))
                                               : ((n >= 4000 ? 26 : 24) << 16 | (tiny || lane64 ? 127 : 384 / 8) << 24 | (lane64 ? 15 << 4 : 0));
     {
         int rc = 0;
