@@ -628,6 +628,268 @@ __device__ __forceinline__ void blk_sub(Blk& c, const Blk& l, const Blk& z) {
     c.v11 = fma(-l.v11, z.v11, fma(-l.v10, z.v01, c.v11));
 }
 
+// ---- executor 1b: factorisation TASKS (jg_symbolic.hpp, plans with policy bit 50) ------------------------------------------------
+// One 8-wave workgroup per task.  A wave first stages its share of the task's shared operands -- Lh(p,k) D(k)^-1 for row items, D(k)^-1 U(k,p)
+// for column items -- into LDS slots, with the operand loads of its first item record already in flight; after ONE workgroup barrier every
+// update term is one block from memory, one block from LDS and eight multiply-adds.  Split items (wpi > 1) meet in a TK_BAR round.
+// LDS: slots [TASK_SLOTS][2][64] double2 | partial sums [8][2][64] double2 = 76 KiB: two workgroups per CU, as k_fact_level.
+constexpr int TASK_LDS_D2 = (TASK_SLOTS + TASK_WAVES) * 128;
+
+// The memory operands of a record are requested with hand-placed instructions: `global_load_dwordx4 dst, lane offset, scalar base` back to back
+// and ONE `s_waitcnt vmcnt(0)` before the first use.  Left to the compiler, every operand's pair of loads was fenced by waits of its own (it reuses
+// the destination registers of one load as address registers of the next and drains the queue before each address computation: rocprof showed a task's
+// six operands arriving in six consecutive round trips; the wave records of k_fact_level suffer from the same thing in pairs).  The compiler does not count
+// these loads: its own waits can only be earlier than needed (loads return in order), never later.
+typedef double d2v __attribute__((ext_vector_type(2)));
+struct BlkV { d2v r0, r1; };
+__device__ __forceinline__ void gload16(d2v& dst, const void* base, unsigned off) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory");   // "memory": the compiler must not move its stores across (the waits count them)
+}
+// Every request of the wave has arrived.  `stores`: store instructions that were issued AFTER those requests and may stay in flight (the results
+// of the previous round leave behind the next round's requests: loads and stores share the counter and complete in order, so waiting for the
+// loads of a round must not mean waiting for the stores of the round before).  A lower bound is safe, a larger count is not.
+__device__ __forceinline__ void task_wait_all(BlkV (&m)[TASK_T], BlkV& own, int stores) {
+    static_assert(TASK_T == 6, "operand list of the wait");
+    switch (stores) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    }
+    // no instruction: ties the values to the wait (volatile statements keep their order; nothing that uses them is scheduled ahead of it)
+    asm volatile("" : "+v"(m[0].r0), "+v"(m[0].r1), "+v"(m[1].r0), "+v"(m[1].r1), "+v"(m[2].r0), "+v"(m[2].r1),
+                      "+v"(m[3].r0), "+v"(m[3].r1), "+v"(m[4].r0), "+v"(m[4].r1), "+v"(m[5].r0), "+v"(m[5].r1), "+v"(own.r0), "+v"(own.r1));
+}
+// the staging operands have arrived, the `later` requests issued after them (the record's memory operands) may still be in flight
+__device__ __forceinline__ void task_wait_stage(BlkV (&A)[TASK_STAGE], BlkV (&D)[TASK_STAGE], int later) {
+    static_assert(TASK_STAGE == 2, "operand list of the wait");
+    switch (later) {                                             // (the count is an immediate of the instruction)
+        case 0: asm volatile("s_waitcnt vmcnt(0)"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)"); break;
+        default: asm volatile("s_waitcnt vmcnt(12)"); break;
+    }
+    // no instruction: ties the values to the waits above (volatile statements keep their order; with the operands on every case the compiler
+    // copied all sixteen registers in each of them)
+    asm volatile("" : "+v"(A[0].r0), "+v"(A[0].r1), "+v"(A[1].r0), "+v"(A[1].r1), "+v"(D[0].r0), "+v"(D[0].r1), "+v"(D[1].r0), "+v"(D[1].r1));
+}
+
+// The memory operands of a record (and the item's own block with its first record) are requested with hand-placed instructions -- `global_load_dwordx4
+// dst, lane offset, scalar base`, back to back -- and waited for with ONE `s_waitcnt` before the first use.  Left to the compiler, every operand's pair
+// of loads was fenced by waits of its own (it reuses the destination registers of one load as address registers of the next and drains the queue before
+// each address computation: a task's six operands arrived in six consecutive round trips; the wave records of k_fact_level suffer from the same thing in
+// pairs).  Returns the number of requests it issued for memory operands.
+__device__ __forceinline__ int task_issue(const FactArgs& a, const RecS& q, size_t b, size_t ld, BlkV& own, BlkV (&m)[TASK_T]) {
+    const int h = rec_word(q, 0), kind = h & TK_KIND;
+    if (kind == 7) return 0;
+    const unsigned off = (unsigned)b * 16u;
+    if ((h & TK_FIRST) && ((h >> 8) & 7) == 0 && rec_word(q, 2) >= 0) {   // the owner starts from the item's block / rhs row (a rhs row: the second half re-reads the first)
+        const int src = rec_word(q, 2);
+        const char* p = kind == 3 ? (const char*)a.rhs + (size_t)src * ld * 16 : (const char*)a.A + (size_t)src * ld * 32;
+        gload16(own.r0, p, off);
+        gload16(own.r1, p + (kind == 3 ? 0 : ld * 16), off);
+    }
+#pragma unroll
+    for (int t = 0; t < TASK_T; ++t) asm volatile("" : "=v"(m[t].r0), "=v"(m[t].r1));   // no instruction: what the registers held before this record is dead
+                                                                                          // (else the compiler carries -- and copies -- it for the operands the record does not have)
+    if (h & TK_DIRECT) return 0;
+    const int nt = rec_word(q, 3) & 0xff;
+    // one code path for blocks and for the 2-vectors of a rhs row: no branch per load
+    const char* const src = kind == 3 ? (const char*)a.W : (const char*)a.X;
+    const size_t row = kind == 3 ? ld * 16 : ld * 32, half = kind == 3 ? 0 : ld * 16;
+#pragma unroll
+    for (int t = 0; t < TASK_T; ++t)
+        if (t < nt) {
+            const char* p = src + (size_t)(rec_word(q, 4 + t) & 0xffffff) * row;
+            gload16(m[t].r0, p, off);
+            gload16(m[t].r1, p + half, off);
+        }
+    return 2 * nt;
+}
+
+// the arithmetic of a record (after its requests have arrived); returns true if the wave has an item to finish (task_finish)
+__device__ __forceinline__ bool task_consume(const FactArgs& a, const RecS& q, size_t b, size_t ld, int wave, int lane, const double2* slots, double2* scratch,
+                                             Blk& c, BlkV& own, BlkV (&m)[TASK_T], int stores, double2& ref) {
+    const int h = rec_word(q, 0), kind = h & TK_KIND, sub = (h >> 8) & 7, wpi = (h >> 12) & 15;
+    const bool last = (h & TK_LAST) != 0;
+    if (kind != 7) {
+        const int nt = rec_word(q, 3) & 0xff;
+        task_wait_all(m, own, stores);                           // every request of the record has arrived
+        if (h & TK_FIRST) {
+            if (sub == 0 && rec_word(q, 2) >= 0) c = Blk{own.r0.x, own.r0.y, own.r1.x, own.r1.y};
+            else c = Blk{0.0, 0.0, 0.0, 0.0};
+        }
+        if (h & TK_DIRECT) {                                     // terms whose shared operand found no slot (rare): three operands each, left to the compiler
+            Blk l[TASK_DIRECT_T], d[TASK_DIRECT_T], u[TASK_DIRECT_T];
+#pragma unroll
+            for (int t = 0; t < TASK_DIRECT_T; ++t)
+                if (t < nt) {
+                    const int ia = rec_word(q, 4 + 3 * t);
+                    l[t] = load_blk(a.X, (size_t)(ia & 0x3fffffff), b, ld);
+                    if (ia >> 30) { const double x = l[t].v01; l[t].v01 = l[t].v10; l[t].v10 = x; }
+                    d[t] = load_blk(a.X, (size_t)rec_word(q, 5 + 3 * t), b, ld);
+                    if (kind == 3) { const double2 w = load_vec(a.W, (size_t)rec_word(q, 6 + 3 * t), b, ld); u[t] = Blk{w.x, 0.0, w.y, 0.0}; }
+                    else u[t] = load_blk(a.X, (size_t)rec_word(q, 6 + 3 * t), b, ld);
+                }
+#pragma unroll
+            for (int t = 0; t < TASK_DIRECT_T; ++t)
+                if (t < nt) {
+                    if (kind == 3) {
+                        double z0, z1;
+                        dsolve(d[t], u[t].v00, u[t].v10, z0, z1);
+                        c = Blk{c.v00 - (l[t].v00 * z0 + l[t].v01 * z1), c.v01 - (l[t].v10 * z0 + l[t].v11 * z1), c.v10, c.v11};
+                    } else term3(c, l[t], d[t], u[t]);
+                }
+        } else if (kind == 3) {                                  // y -= [Lh D^-1] y_c
+#pragma unroll
+            for (int t = 0; t < TASK_T; ++t)
+                if (t < nt) {
+                    const double2* p = slots + (size_t)(rec_word(q, 4 + t) >> 24) * 128 + lane;
+                    const double2 s0 = p[0], s1 = p[64];
+                    c = Blk{fma(-s0.y, m[t].r0.y, fma(-s0.x, m[t].r0.x, c.v00)), fma(-s1.y, m[t].r0.y, fma(-s1.x, m[t].r0.x, c.v01)), c.v10, c.v11};
+                }
+        } else if (h & TK_SIDE) {                                // c -= Lh(i,k) [D^-1 U]
+#pragma unroll
+            for (int t = 0; t < TASK_T; ++t)
+                if (t < nt) {
+                    const double2* p = slots + (size_t)(rec_word(q, 4 + t) >> 24) * 128 + lane;
+                    const double2 s0 = p[0], s1 = p[64];
+                    c.v00 = fma(-m[t].r0.y, s1.x, fma(-m[t].r0.x, s0.x, c.v00));
+                    c.v01 = fma(-m[t].r0.y, s1.y, fma(-m[t].r0.x, s0.y, c.v01));
+                    c.v10 = fma(-m[t].r1.y, s1.x, fma(-m[t].r1.x, s0.x, c.v10));
+                    c.v11 = fma(-m[t].r1.y, s1.y, fma(-m[t].r1.x, s0.y, c.v11));
+                }
+        } else {                                                 // c -= [Lh D^-1] U(k,j)
+#pragma unroll
+            for (int t = 0; t < TASK_T; ++t)
+                if (t < nt) {
+                    const double2* p = slots + (size_t)(rec_word(q, 4 + t) >> 24) * 128 + lane;
+                    const double2 s0 = p[0], s1 = p[64];
+                    c.v00 = fma(-s0.y, m[t].r1.x, fma(-s0.x, m[t].r0.x, c.v00));
+                    c.v01 = fma(-s0.y, m[t].r1.y, fma(-s0.x, m[t].r0.y, c.v01));
+                    c.v10 = fma(-s1.y, m[t].r1.x, fma(-s1.x, m[t].r0.x, c.v10));
+                    c.v11 = fma(-s1.y, m[t].r1.y, fma(-s1.x, m[t].r0.y, c.v11));
+                }
+        }
+    }
+    if (h & TK_BAR) {                                            // uniform across the workgroup (the tables mark the round for every wave)
+        const bool split = kind != 7 && last && wpi > 1;
+        if (split && sub != 0) { double2* p = scratch + (size_t)wave * 128 + lane; p[0] = double2{c.v00, c.v01}; p[64] = double2{c.v10, c.v11}; }
+        __syncthreads();
+        if (split && sub == 0)
+            for (int w = 1; w < wpi; ++w) {
+                const double2* p = scratch + (size_t)(wave + w) * 128 + lane;
+                const double2 h0 = p[0], h1 = p[64];
+                c.v00 += h0.x; c.v01 += h0.y; c.v10 += h1.x; c.v11 += h1.y;
+            }
+        __syncthreads();
+    }
+    if (kind != 7 && last && sub == 0) {
+        // pivot guard: the row maxima of the block as it was loaded -- still in `own` (taken now: the next round's requests may overwrite it)
+        const bool had = rec_word(q, 2) >= 0;
+        ref = double2{had ? fmax(fabs(own.r0.x), fabs(own.r0.y)) : 0.0, had ? fmax(fabs(own.r1.x), fabs(own.r1.y)) : 0.0};
+        return true;
+    }
+    return false;
+}
+
+// the slots this wave stages for its task: the staging entries of one record (at most TASK_STAGE).  Requests first ...
+__device__ __forceinline__ void task_stage_issue(const FactArgs& a, const RecS& s, size_t b, size_t ld, BlkV (&A)[TASK_STAGE], BlkV (&D)[TASK_STAGE]) {
+    const int ns = rec_word(s, 3) >> 8;
+    const unsigned off = (unsigned)b * 16u;
+#pragma unroll
+    for (int u = 0; u < TASK_STAGE; ++u)
+        if (u < ns) {
+            const char* pa = (const char*)a.X + (size_t)(rec_word(s, 10 + 3 * u) & 0xffffff) * ld * 32;
+            const char* pd = (const char*)a.X + (size_t)rec_word(s, 11 + 3 * u) * ld * 32;
+            gload16(A[u].r0, pa, off); gload16(A[u].r1, pa + ld * 16, off);
+            gload16(D[u].r0, pd, off); gload16(D[u].r1, pd + ld * 16, off);
+        }
+}
+// ... then (after task_wait_stage) the multiplication by the pivot block and the write into the slot
+__device__ __forceinline__ void task_stage_write(const RecS& s, int lane, double2* slots, const BlkV (&A)[TASK_STAGE], const BlkV (&D)[TASK_STAGE]) {
+    const int ns = rec_word(s, 3) >> 8;
+#pragma unroll
+    for (int u = 0; u < TASK_STAGE; ++u)
+        if (u < ns) {
+            const int aw = rec_word(s, 10 + 3 * u);
+            const bool tr = (aw >> 30) & 1;
+            const Blk x{A[u].r0.x, tr ? A[u].r1.x : A[u].r0.y, tr ? A[u].r0.y : A[u].r1.x, A[u].r1.y};
+            const Blk d{D[u].r0.x, D[u].r0.y, D[u].r1.x, D[u].r1.y};
+            const bool sw = d.v10 > 2.0;
+            const double l = sw ? d.v10 - 4.0 : d.v10;
+            Blk o;
+            if ((aw >> 29) & 1) {                                // x D^-1, row by row: z U_d = x, y L_d = z, columns swapped back
+                const double z1 = x.v00 * d.v00, w1 = x.v10 * d.v00;
+                const double z2 = (x.v01 - z1 * d.v01) * d.v11, w2 = (x.v11 - w1 * d.v01) * d.v11;
+                const double y1 = z1 - z2 * l, v1 = w1 - w2 * l;
+                o = sw ? Blk{z2, y1, w2, v1} : Blk{y1, z2, v1, w2};
+            } else {                                             // D^-1 x, column by column
+                dsolve(d, x.v00, x.v10, o.v00, o.v10);
+                dsolve(d, x.v01, x.v11, o.v01, o.v11);
+            }
+            double2* p = slots + (size_t)rec_word(s, 12 + 3 * u) * 128 + lane;
+            p[0] = double2{o.v00, o.v01}; p[64] = double2{o.v10, o.v11};
+        }
+}
+
+__global__ __launch_bounds__(64 * TASK_WAVES, 4) void k_fact_task(FactArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double red[];
+    double2* const slots = (double2*)red;
+    double2* const scratch = slots + TASK_SLOTS * 128;
+    int base = a.s0_base, ntasks = a.s0_nchunks, spw = a.s0_wpi, rpw = a.s0_rpw;
+    if (blockIdx.y != 0) {
+        const SegS sg = ((SegPtr)a.seg)[a.seg_begin + blockIdx.y];
+        base = sg[0]; ntasks = sg[1]; spw = sg[2]; rpw = sg[3];
+    }
+    int grp, bx;
+    if (!map_block(a.sel, a.ld, ntasks, grp, bx)) return;
+    const int lane = threadIdx.x;
+    const int wave = uniform(threadIdx.y);
+    const size_t ld = (size_t)a.ld;
+    const size_t b = (size_t)min(grp * 64 + lane, a.lanes - 1);
+    const size_t ri = (size_t)base + ((size_t)bx * TASK_WAVES + wave) * rpw;
+    RecS r = load_rec(a.rec, ri);
+    Blk c{0.0, 0.0, 0.0, 0.0};
+    BlkV m[TASK_T], own{d2v{0.0, 0.0}, d2v{0.0, 0.0}};
+    RecS nxt = r;
+    if (rpw > 1) nxt = load_rec(a.rec, ri + 1);                  // the tables are static: the next record is requested before this one is consumed
+    {   // ---- first round: the slots are staged with the round's own operands already in flight
+        BlkV A[TASK_STAGE], D[TASK_STAGE];
+#pragma unroll
+        for (int u = 0; u < TASK_STAGE; ++u) asm volatile("" : "=v"(A[u].r0), "=v"(A[u].r1), "=v"(D[u].r0), "=v"(D[u].r1));
+        task_stage_issue(a, r, b, ld, A, D);
+        const int later = task_issue(a, r, b, ld, own, m);
+        task_wait_stage(A, D, later);
+        task_stage_write(r, lane, slots, A, D);
+        for (int i = 1; i < spw; ++i) {                          // tasks of more than 16 slots (rare): the next batch once the registers are free
+            const RecS s = i == 1 ? nxt : load_rec(a.rec, ri + i);
+            task_stage_issue(a, s, b, ld, A, D);
+            task_wait_stage(A, D, 0);
+            task_stage_write(s, lane, slots, A, D);
+        }
+        __syncthreads();
+    }
+    // Rounds, software-pipelined by one: the requests of round j + 1 are issued BEFORE the results of round j are stored, so the wait of round j + 1
+    // leaves those stores in flight (stores = how many were issued behind the requests: 2 per block, 1 per rhs row, at least).
+    int stores = 0;
+    for (int j = 0; j < rpw; ++j) {
+        double2 ref{0.0, 0.0};
+        const bool fin = task_consume(a, r, b, ld, wave, lane, slots, scratch, c, own, m, stores, ref);
+        const int kind = rec_word(r, 0) & TK_KIND, id = rec_word(r, 1);
+        if (j + 1 < rpw) {
+            const RecS cur = nxt;
+            if (j + 2 < rpw) nxt = load_rec(a.rec, ri + j + 2);
+            task_issue(a, cur, b, ld, own, m);
+            r = cur;
+        }
+        stores = 0;
+        if (fin) { fact_finish(a, kind, id, b, ld, c, ref); stores = kind == 3 ? 1 : 2; }
+    }
+}
+
 // TIMING PROBES of a pivot step (compile with -DJG_PROBE_TOP=1: the next pivot's row / column are not published, =2: one block update per
 // thread instead of CLS x CLS; wrong numbers -- tools/level_bound_probe.sh): what a step is made of.
 #ifndef JG_PROBE_TOP
@@ -1286,6 +1548,12 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, long long 
     // against 280 items / 4 pivots, which the small grids keep: case1354pegase 0.148 against 0.160 ms; the 9241-bus grid does not care)
     const bool defaults = !((policy >> 16) & 0x7fff);
     if (defaults && ld_ >= 256 && !getenv("JG_TOP_NOSPLIT")) policy |= 8;
+    // round 4: large batches factorise the bottom of the tree in TASKS (jg_symbolic.hpp: shared operands of a pivot row / column staged in LDS, one
+    // block load per update term instead of three).  JG_ROW_TASKS=0: the wave records of round 3; =2: tasks for every batch size.
+    {
+        static const int tasks_env = getenv("JG_ROW_TASKS") ? atoi(getenv("JG_ROW_TASKS")) : 1;
+        if (defaults && !((policy >> 32) & 0xff) && (tasks_env == 2 || (tasks_env == 1 && ld_ >= 256))) policy |= 1LL << 50;
+    }
     // round 3 (the top launches got cheaper: Jordan rows, 4-wave variant where it pays): on the large grids a large batch starts the top where a level
     // holds at most 12 pivots, whatever its item count (narrow = 127: no limit) -- ACTIVSg10k: level 22 instead of 27, 1.236 -> 1.213 ms at 512
     // scenarios, three interleaved runs each; the 9241-bus grid does not care; symmetric plans -- the Gauss-Newton gain -- keep the rule of round 2: 2.96 against 2.99 ms for factorisation + sweep
@@ -1318,6 +1586,7 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, long long 
     fact_seg = plan->fact_seg; bwd_seg = plan->bwd_seg; pre_seg = plan->pre_seg; fwd_seg = plan->fwd_seg;
     pre_row = plan->pre_row; bwd_chain = plan->bwd_chain; top_task = plan->top_task; top_data = plan->top_data; top_wgmap = plan->top_wgmap;
     JG_HIP(hipFuncSetAttribute((const void*)k_bwd_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CHAIN_LDS_D2 * sizeof(double2))));
+    JG_HIP(hipFuncSetAttribute((const void*)k_fact_task, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(TASK_LDS_D2 * sizeof(double2))));
     if (!plan->S.top_launch.empty()) {
         const size_t sb = (size_t)(std::max<long long>(plan->S.top_stack_cls[0], 2) + plan->S.top_stack_cls[1] + plan->S.top_stack_cls[2]) * ld * sizeof(double);
         JG_HIP(hipMalloc((void**)&top_stack, sb));
@@ -1391,7 +1660,10 @@ int Engine::factor(hipStream_t st, const double* A, const double* rhs, const Gro
     for (const DevLaunch& L : fact) {
         a.seg_begin = L.seg_begin;
         { const Segment& g = plan->S.fact_seg[L.seg_begin]; a.s0_base = g.rec_base; a.s0_nchunks = g.nchunks; a.s0_wpi = g.wpi; a.s0_rpw = g.rpw; }
-        hipLaunchKernelGGL(k_fact_level, dim3((unsigned)L.grid * (16 / FACT_WAVES) * gs, L.nseg), dim3(64, FACT_WAVES), FACT_WAVES * 256 * sizeof(double), st, a);
+        if (plan->S.fact_tasks)                                  // TASKS (jg_symbolic.hpp): a workgroup per task, not per 8 item waves
+            hipLaunchKernelGGL(k_fact_task, dim3((unsigned)L.grid * gs, L.nseg), dim3(64, TASK_WAVES), TASK_LDS_D2 * sizeof(double2), st, a);
+        else
+            hipLaunchKernelGGL(k_fact_level, dim3((unsigned)L.grid * (16 / FACT_WAVES) * gs, L.nseg), dim3(64, FACT_WAVES), FACT_WAVES * 256 * sizeof(double), st, a);
     }
     // the top of the elimination tree: multifrontal tasks, one workgroup per (task, scenario), launch = (task level, class)
     if (!plan->S.top_launch.empty()) {

@@ -75,24 +75,32 @@ __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirs
 
 // 2x2 block / 2-vector of one scenario: two (one) 16-byte accesses
 struct Blk { double v00, v01, v10, v11; };
+// Addresses are formed as (wave-uniform base of the item) + (32-bit byte offset of the lane): the item index comes from a record in scalar
+// registers, so the base is scalar arithmetic and every access of a wave shares ONE offset register (global_load ... v_off, s[base] instead of a
+// 64-bit address pair computed per access on the vector ALU).  A batch row is at most 2^32 bytes: ld < 2^28 scenarios.
 __device__ __forceinline__ Blk load_blk(const double* base, size_t item, size_t b, size_t ld) {
-    const double2* p = (const double2*)base + item * 2 * ld + b;
-    const double2 r0 = p[0], r1 = p[ld];
+    const char* p = (const char*)base + item * ld * 32;
+    const unsigned off = (unsigned)b * 16u;
+    const double2 r0 = *(const double2*)(p + off), r1 = *(const double2*)(p + ld * 16 + off);
     return Blk{r0.x, r0.y, r1.x, r1.y};
 }
 __device__ __forceinline__ void store_blk(double* base, size_t item, size_t b, size_t ld, double v00, double v01, double v10, double v11) {
-    double2* p = (double2*)base + item * 2 * ld + b;
-    p[0] = double2{v00, v01}; p[ld] = double2{v10, v11};
+    char* p = (char*)base + item * ld * 32;
+    const unsigned off = (unsigned)b * 16u;
+    *(double2*)(p + off) = double2{v00, v01}; *(double2*)(p + ld * 16 + off) = double2{v10, v11};
 }
 __device__ __forceinline__ void store_blk_nt(double* base, size_t item, size_t b, size_t ld, double v00, double v01, double v10, double v11) {
     typedef double d2 __attribute__((ext_vector_type(2)));
-    d2* p = (d2*)base + item * 2 * ld + b;       // write-once stream: nontemporal, two 16-byte stores of 1 KiB per wave each
-    __builtin_nontemporal_store(d2{v00, v01}, p);
-    __builtin_nontemporal_store(d2{v10, v11}, p + ld);
+    char* p = (char*)base + item * ld * 32;       // write-once stream: nontemporal, two 16-byte stores of 1 KiB per wave each
+    const unsigned off = (unsigned)b * 16u;
+    __builtin_nontemporal_store(d2{v00, v01}, (d2*)(p + off));
+    __builtin_nontemporal_store(d2{v10, v11}, (d2*)(p + ld * 16 + off));
 }
-__device__ __forceinline__ double2 load_vec(const double* base, size_t item, size_t b, size_t ld) { return *(const double2*)(base + (item * ld + b) * 2); }
+__device__ __forceinline__ double2 load_vec(const double* base, size_t item, size_t b, size_t ld) {
+    return *(const double2*)((const char*)base + item * ld * 16 + (unsigned)b * 16u);
+}
 __device__ __forceinline__ void store_vec(double* base, size_t item, size_t b, size_t ld, double v0, double v1) {
-    *(double2*)(base + (item * ld + b) * 2) = double2{v0, v1};
+    *(double2*)((char*)base + item * ld * 16 + (unsigned)b * 16u) = double2{v0, v1};
 }
 
 // A diagonal block whose eliminated form is smaller than PIVOT_EPS x (largest entry ITS ROW of the block started from) marks the

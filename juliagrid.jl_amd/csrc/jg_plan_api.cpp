@@ -33,7 +33,8 @@ void jg_plan_destroy(jg_plan* p) { delete p; }
 //        70 top-task headers (x16), 71 top-task data, 72 top launches (x8: task_begin, ntasks, class, level, grouped, wg_begin, nwg, -),
 //        78 workgroup map of the grouped launches (task << 8 | scenario block),
 //        73 task of each pivot (-1: bottom), 74 {top_level, stack doubles per scenario (low 31 bits), top terms (low 31 bits), stack doubles per interleave class x3,
-//        Jordan plan (0 / 1), blocks of Jordan rows behind the factor entries}, 79 / 80 backward segments / records over Jordan rows
+//        Jordan plan (0 / 1), blocks of Jordan rows behind the factor entries, factorisation tables are TASKS (0 / 1: policy bit 50, jg_symbolic.hpp),
+//        rounds a task is filled up to, operands staged by the tasks, terms of task items in three-operand form}, 79 / 80 backward segments / records over Jordan rows
 // out == NULL returns the length.
 int64_t jg_plan_export(jg_plan* p, int which, int32_t* out, int64_t cap) {
     if (!p) return -1;
@@ -65,7 +66,8 @@ int64_t jg_plan_export(jg_plan* p, int which, int32_t* out, int64_t cap) {
         case 72: tmp.assign((const int*)S.top_launch.data(), (const int*)S.top_launch.data() + S.top_launch.size() * 8); v = &tmp; break;
         case 78: v = &S.top_wgmap; break;
         case 73: v = &S.top_task_of; break;
-        case 74: tmp = {S.top_level, (int)(S.top_stack & 0x7fffffff), (int)(S.top_terms & 0x7fffffff), (int)S.top_stack_cls[0], (int)S.top_stack_cls[1], (int)S.top_stack_cls[2], S.jordan, S.n_jordan}; v = &tmp; break;
+        case 74: tmp = {S.top_level, (int)(S.top_stack & 0x7fffffff), (int)(S.top_terms & 0x7fffffff), (int)S.top_stack_cls[0], (int)S.top_stack_cls[1], (int)S.top_stack_cls[2], S.jordan, S.n_jordan,
+                        S.fact_tasks, S.task_rounds, (int)S.n_staged, (int)S.n_direct_terms}; v = &tmp; break;
         case 79: tmp.assign((const int*)S.bwdj_seg.data(), (const int*)S.bwdj_seg.data() + S.bwdj_seg.size() * 8); v = &tmp; break;
         case 80: tmp.assign((const int*)S.bwdj_rec.data(), (const int*)S.bwdj_rec.data() + S.bwdj_rec.size() * 16); v = &tmp; break;
         case 75: tmp.assign(S.pre_pivot.begin(), S.pre_pivot.end()); v = &tmp; break;

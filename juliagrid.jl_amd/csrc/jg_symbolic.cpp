@@ -519,7 +519,191 @@ void build_tables(BlockSymbolic& S) {
     const char* io = getenv("JG_ITEM_ORDER");
     const std::vector<long long>* locp = (io && atoi(io) == 0) ? nullptr : &loc;
     // the factorisation tables are two thirds of this function's time and independent of the others: they get a thread of their own
-    std::thread fact_thread([&] { build_replay(level, work, FACT_T, S.fact_seg, S.fact_rec, S.n_fact_levels, fill_fact, NoExtra(), 0, FACT_WAVES, locp); });
+    // Plans with policy bit 50: the same items, levels and terms as TASKS (jg_symbolic.hpp) -- runs of items in the pivot order of their level
+    // share a workgroup that stages their common operands, premultiplied by the pivot block, in LDS.
+    auto build_fact_tasks = [&] {
+        struct Term { int mem, slot, a, d, b; };                   // slot -1: no slot left, the term keeps the three-operand form
+        struct TItem { int it, kind, side, wpi, rps; std::vector<Term> terms; };
+        const int T = TASK_T, W = TASK_WAVES;
+        const int rmax = std::max(1, S.task_rounds);
+        int nlev = 0;
+        for (int i = 0; i < nE + n; ++i) nlev = std::max(nlev, level[i]);
+        std::vector<std::vector<int>> by(nlev + 1);
+        for (int i = 0; i < nE + n; ++i) if (level[i] > 0) by[level[i]].push_back(i);
+        S.fact_seg.clear(); S.fact_rec.clear(); S.n_fact_levels = 0; S.n_staged = 0; S.n_direct_terms = 0;
+        std::vector<int> slot_stamp(nE, -1), slot_idx(nE, 0);     // staged operand (an entry) -> slot of the task being filled
+        int stamp = 0;
+        auto side_of = [&](int it) { return it < nE && S.e_row[it] > S.e_col[it] ? 1 : 0; };
+        auto group_of = [&](int it) -> long long { return it < nE ? ((long long)std::min(S.e_row[it], S.e_col[it]) << 1 | side_of(it)) : ((long long)(it - nE) << 1); };
+        auto term_of = [&](int it, int f, int& a, int& d, int& b) {
+            const int t = ft_idx[f];
+            if (it < nE) { a = lower_operand(S.t_a[t]); d = S.t_d[t]; b = S.t_b[t]; }
+            else { a = lower_operand(S.l_ent[t]); d = S.diag[S.l_col[t]]; b = S.l_col[t]; }
+        };
+        auto shares_of = [&](int it) { return std::min(W, pow2ceil(std::max(1, (work[it] + T - 1) / T))); };
+        struct Task { std::vector<TItem> items; std::vector<int> skey, sd; int shares = 0; };
+        for (int l = 1; l <= nlev; ++l) {
+            std::vector<int>& its = by[l];
+            if (its.empty()) continue;
+            std::stable_sort(its.begin(), its.end(), [&](int x, int y) { return loc[x] < loc[y]; });
+            std::vector<Task> tasks;
+            Task cur;
+            ++stamp;
+            auto close = [&] { if (!cur.items.empty()) { tasks.push_back(std::move(cur)); cur = Task(); ++stamp; } };
+            auto new_keys = [&](size_t g0, size_t g1) {             // staged operands the items [g0, g1) would add to the current task
+                int nk = 0;
+                std::vector<int> seen;
+                for (size_t x = g0; x < g1; ++x) {
+                    const int it = its[x];
+                    for (int f = ft_ptr[it]; f < ft_ptr[it + 1]; ++f) {
+                        int a, d, b; term_of(it, f, a, d, b);
+                        const int key = (side_of(it) ? b : a) & 0x3fffffff;
+                        if (slot_stamp[key] != stamp && slot_stamp[key] != -2 - stamp) { slot_stamp[key] = -2 - stamp; seen.push_back(key); ++nk; }
+                    }
+                }
+                for (int k : seen) slot_stamp[k] = -1;
+                return nk;
+            };
+            auto add_item = [&](int it) {
+                TItem ti{};
+                ti.it = it; ti.side = side_of(it);
+                if (it < nE) { ti.kind = S.e_row[it] == S.e_col[it] ? 2 : 0; if (in_top(owner(it))) ti.kind = 0; } else ti.kind = 3;
+                for (int f = ft_ptr[it]; f < ft_ptr[it + 1]; ++f) {
+                    Term tm{};
+                    term_of(it, f, tm.a, tm.d, tm.b);
+                    const int keyw = ti.side ? tm.b : tm.a;         // the shared operand (with its transpose bit)
+                    const int key = keyw & 0x3fffffff;
+                    tm.mem = ti.side ? tm.a : tm.b;
+                    if (slot_stamp[key] == stamp) tm.slot = slot_idx[key];
+                    else if ((int)cur.skey.size() < TASK_SLOTS) {
+                        slot_stamp[key] = stamp; slot_idx[key] = (int)cur.skey.size(); tm.slot = slot_idx[key];
+                        cur.skey.push_back(keyw | (ti.side ? 0 : 1 << 29)); cur.sd.push_back(tm.d);
+                    } else tm.slot = -1;
+                    ti.terms.push_back(tm);
+                }
+                ti.wpi = shares_of(it);
+                cur.shares += ti.wpi;
+                cur.items.push_back(std::move(ti));
+            };
+            for (size_t x = 0; x < its.size();) {
+                size_t y = x;
+                int sh = 0;
+                while (y < its.size() && group_of(its[y]) == group_of(its[x])) sh += shares_of(its[y++]);
+                const int nk = new_keys(x, y);
+                if ((int)cur.skey.size() + nk <= TASK_SLOTS && cur.shares + sh <= W * rmax) { for (; x < y; ++x) add_item(its[x]); continue; }
+                close();
+                const int nk0 = new_keys(x, y);
+                if (nk0 <= TASK_SLOTS && sh <= W * rmax) { for (; x < y; ++x) add_item(its[x]); continue; }
+                for (; x < y; ++x) {                              // a row / column too large for one task: item by item
+                    const int it = its[x];
+                    if (!cur.items.empty() && ((int)cur.skey.size() + new_keys(x, x + 1) > TASK_SLOTS || cur.shares + shares_of(it) > W * rmax)) close();
+                    add_item(it);
+                }
+            }
+            close();
+            // lay every task out: shares -> (wave, round); records
+            struct Laid { int spw, rounds; std::vector<Rec> recs; };   // recs: [wave][rounds]
+            std::vector<Laid> laid(tasks.size());
+            for (size_t ti = 0; ti < tasks.size(); ++ti) {
+                Task& tk = tasks[ti];
+                for (TItem& it : tk.items) {                      // records a share needs: staged terms T per record, direct ones 4 per record
+                    int rps = 1;
+                    for (int sub = 0; sub < it.wpi; ++sub) {
+                        int ns = 0, nd = 0;
+                        for (size_t q = sub; q < it.terms.size(); q += it.wpi) (it.terms[q].slot >= 0 ? ns : nd)++;
+                        rps = std::max(rps, (ns + T - 1) / T + (nd + TASK_DIRECT_T - 1) / TASK_DIRECT_T);
+                    }
+                    it.rps = rps;
+                }
+                std::vector<int> order(tk.items.size());
+                std::iota(order.begin(), order.end(), 0);
+                std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+                    if (tk.items[x].wpi != tk.items[y].wpi) return tk.items[x].wpi > tk.items[y].wpi;
+                    return tk.items[x].rps > tk.items[y].rps;
+                });
+                int h[TASK_WAVES] = {0, 0, 0, 0, 0, 0, 0, 0};
+                struct Place { int item, wave, round; };
+                std::vector<Place> places;
+                for (int oi : order) {
+                    const TItem& it = tk.items[oi];
+                    int best = 0, bh = 0x7fffffff;
+                    for (int w0 = 0; w0 + it.wpi <= W; w0 += it.wpi) {
+                        int mh = 0;
+                        for (int w = w0; w < w0 + it.wpi; ++w) mh = std::max(mh, h[w]);
+                        if (mh < bh) { bh = mh; best = w0; }
+                    }
+                    places.push_back(Place{oi, best, bh});
+                    for (int w = best; w < best + it.wpi; ++w) h[w] = bh + it.rps;
+                }
+                int rounds = 1;
+                for (int w = 0; w < W; ++w) rounds = std::max(rounds, h[w]);
+                const int nslot = (int)tk.skey.size();
+                const int spw = std::max(1, ((nslot + W - 1) / W + TASK_STAGE - 1) / TASK_STAGE);   // leading rounds whose records carry staging entries
+                rounds = std::max(rounds, spw);
+                std::vector<char> bar(rounds, 0);
+                for (const Place& pl : places) if (tk.items[pl.item].wpi > 1) bar[pl.round + tk.items[pl.item].rps - 1] = 1;
+                Laid& L = laid[ti];
+                L.spw = spw; L.rounds = rounds;
+                L.recs.assign((size_t)W * rounds, Rec{});
+                for (int w = 0; w < W; ++w)
+                    for (int r = 0; r < rounds; ++r) L.recs[(size_t)w * rounds + r].w[0] = 7 | (bar[r] ? TK_BAR : 0);
+                for (int s = 0; s < nslot; ++s) {
+                    const int w = s % W, q = s / W;
+                    Rec& r = L.recs[(size_t)w * rounds + q / TASK_STAGE];
+                    const int u = q % TASK_STAGE;
+                    r.w[10 + 3 * u] = tk.skey[s]; r.w[11 + 3 * u] = tk.sd[s]; r.w[12 + 3 * u] = s;
+                    r.w[3] = (u + 1) << 8;
+                }
+                S.n_staged += nslot;
+                for (const Place& pl : places) {
+                    const TItem& it = tk.items[pl.item];
+                    const int id = it.it < nE ? it.it : it.it - nE;
+                    const int src = it.it < nE ? (S.e_src[it.it] < 0 ? -1 : (S.inplace ? it.it : S.e_src[it.it])) : S.perm[id];
+                    for (int sub = 0; sub < it.wpi; ++sub) {
+                        std::vector<const Term*> st, dr;
+                        for (size_t q = sub; q < it.terms.size(); q += it.wpi) (it.terms[q].slot >= 0 ? st : dr).push_back(&it.terms[q]);
+                        size_t si = 0, di = 0;
+                        for (int j = 0; j < it.rps; ++j) {
+                            Rec& r = L.recs[(size_t)(pl.wave + sub) * rounds + pl.round + j];
+                            int w0 = it.kind | (r.w[0] & TK_BAR) | (it.side ? TK_SIDE : 0) | sub << 8 | it.wpi << 12;
+                            if (j == 0) w0 |= TK_FIRST;
+                            if (j == it.rps - 1) w0 |= TK_LAST;
+                            r.w[1] = id; r.w[2] = src;
+                            int nt = 0;
+                            if (si < st.size()) {
+                                for (int q = 0; q < T && si < st.size(); ++q, ++si) { r.w[4 + q] = st[si]->mem | st[si]->slot << 24; ++nt; }
+                            } else if (di < dr.size()) {
+                                w0 |= TK_DIRECT;
+                                for (int q = 0; q < TASK_DIRECT_T && di < dr.size(); ++q, ++di) { r.w[4 + 3 * q] = dr[di]->a; r.w[5 + 3 * q] = dr[di]->d; r.w[6 + 3 * q] = dr[di]->b; ++nt; S.n_direct_terms++; }
+                            }
+                            r.w[3] |= nt;
+                            r.w[0] = w0;
+                        }
+                    }
+                }
+            }
+            // segments: the tasks of the level by shape, in task order
+            const size_t seg0 = S.fact_seg.size();
+            std::vector<char> done(tasks.size(), 0);
+            for (size_t t0 = 0; t0 < tasks.size(); ++t0) {
+                if (done[t0]) continue;
+                Segment sg{};
+                sg.rec_base = (int)S.fact_rec.size(); sg.wpi = laid[t0].spw; sg.rpw = laid[t0].rounds; sg.level = l; sg.last = 0; sg.nchunks = 0; sg.items = 0;
+                for (size_t t = t0; t < tasks.size(); ++t)
+                    if (!done[t] && laid[t].spw == laid[t0].spw && laid[t].rounds == laid[t0].rounds) {
+                        done[t] = 1;
+                        S.fact_rec.insert(S.fact_rec.end(), laid[t].recs.begin(), laid[t].recs.end());
+                        sg.nchunks++; sg.items += (int)tasks[t].items.size();
+                    }
+                S.fact_seg.push_back(sg);
+            }
+            if (S.fact_seg.size() > seg0) { S.fact_seg.back().last = 1; ++S.n_fact_levels; }
+        }
+    };
+    std::thread fact_thread([&] {
+        if (S.fact_tasks) build_fact_tasks();
+        else build_replay(level, work, FACT_T, S.fact_seg, S.fact_rec, S.n_fact_levels, fill_fact, NoExtra(), 0, FACT_WAVES, locp);
+    });
     struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } join_fact{fact_thread};
     // level 0 of a prefactor plan as tables of its own (for producers that deliver plain blocks): D(k) and y_k of the pivots
     // nobody updates
@@ -690,6 +874,10 @@ int analyze(int n, const int* rowptr, const int* col, long long policy64, BlockS
     S.prefactor = ((policy >> 2) & 1) && S.inplace;
     S.top_split = (policy >> 3) & 1;
     S.jordan = (int)((policy64 >> 49) & 1);                       // a request here; build_top grants it
+    S.fact_tasks = (int)((policy64 >> 50) & 1);
+    S.task_rounds = (int)((policy64 >> 51) & 7);
+    if (const char* e = getenv("JG_TASK_ROUNDS")) S.task_rounds = atoi(e);
+    if (S.task_rounds <= 0) S.task_rounds = 3;
     S.n = n;
     if (n <= 0) return 1;
     // adjacency without the diagonal; verify structural symmetry and diagonal presence
@@ -900,6 +1088,7 @@ int analyze(int n, const int* rowptr, const int* col, long long policy64, BlockS
         build_top(S, top_level, std::min(soft, TOP_FRONT_MAX), struct_min, mid_mmin, mid_strict);
         lap("top tasks");
     }
+    if (S.n_entries + S.n_jordan >= (1 << 24)) S.fact_tasks = 0;   // a task term packs (entry | slot << 24)
     build_tables(S);
     lap("replay tables");
     return 0;

@@ -39,6 +39,29 @@ constexpr int FACT_T = 4;
 // 1.79 -> 1.59 ms (512 scenarios), 0.68 -> 0.64 ms (64); 4-wave workgroups: 1.59 / 0.80 ms (long lists get too few waves).
 constexpr int FACT_WAVES = 8;   // FactRec: {kind, id, src, nterms, (a, d, b) x 4}; kind -1 = idle wave
 constexpr int BWD_T = 6;    // BwdRec:  {k, bus, diag, nterms, (u_ent, u_col) x 6}; k -1 = idle wave
+// ---- factorisation TASKS (plans with policy bit 50, round 4) --------------------------------------------------------------
+// A level item pulls three operand blocks per update term -- Lh(i,k), D(k), U(k,j) -- through the vector memory pipe of its CU, and that
+// pipe (one 1 KiB wave-load per 16 clocks), not HBM, is what the level launches of a large batch wait for.  But the items that
+// become final with pivot p share operands: every term of D(p), U(p, .) and y_p with pivot k reads the SAME Lh(p,k) and D(k), every term of
+// Lh(., p) the same U(k,p) and D(k).  A TASK is one 8-wave workgroup that owns a run of such items (whole pivot rows / columns, in the pivot order
+// of the level): it first STAGES the shared operands of its items in LDS, already multiplied by the pivot block --
+//     row items    (side 0):  slot = Lh(p,k) D(k)^-1      (right solve on the stored 2x2 LU), a term is  c -= slot * U(k,j)   resp.  slot * y_k
+//     column items (side 1):  slot = D(k)^-1 U(k,p)       (left solve),                        a term is  c -= Lh(i,k) * slot
+// -- two block loads per staged operand, once per task; after that a term costs ONE block load from memory, one block read from LDS
+// (256 B/clk against 64 for the vector memory pipe) and 8 multiply-adds: no dsolve per term.  What is stored does not change (A = Lh D^-1 U,
+// unscaled): the top tasks, the backward sweep, the forward-only tables and the selected inverse read the same factor as before.
+// Tables: a segment holds the tasks of one level with the same shape (R rounds of one record per wave, the first spw of them carry staging
+// entries: Segment::rpw = R, Segment::wpi = spw); record index = seg.rec_base + ((task * 8 + wave) * rpw + j).  ONE record format:
+//   w0 = kind (0 entry stored raw, 2 diagonal block, 3 rhs row, 7 no item) | TK_FIRST | TK_LAST | TK_BAR | TK_SIDE | TK_DIRECT | sub << 8 | wpi << 12,
+//   w1 id, w2 src, w3 = terms | staging entries << 8,
+//   w4 .. w9   TASK_T x (memory operand | slot << 24)      or, TK_DIRECT, 2 x (a, d, b) as in a FactRec (terms whose shared operand found no
+//              slot: rows with more than TASK_SLOTS lower entries)
+//   w10 .. w15 TASK_STAGE x (operand entry | transpose << 30 | right-solve << 29, pivot entry, slot): what THIS wave stages before the task's barrier
+//   An item of more than TASK_T terms is dealt over wpi = 2, 4, 8 neighbouring waves (shares end in the same round; TK_BAR marks that round for
+//   EVERY wave of the task: partial sums meet in LDS, fixed order); a share of more than one record continues in the wave's next round
+//   (TK_FIRST / TK_LAST bracket it).
+constexpr int TASK_WAVES = 8, TASK_SLOTS = 30, TASK_T = 6, TASK_STAGE = 2, TASK_DIRECT_T = 2;
+constexpr int TK_KIND = 7, TK_FIRST = 8, TK_LAST = 16, TK_BAR = 32, TK_SIDE = 64, TK_DIRECT = 128;
 // Backward CHAINS: consecutive pivots k..k+b-1 of one supernode (each the parent of the previous, nested structure)
 // are solved by ONE workgroup in one launch -- the dense in-chain triangle is a sequence of workgroup barriers, not
 // of kernel launches.  A chain segment has wpi = 0 and ONE record per task: {b, nE, off, wpr}; at bwd_chain[off]:
@@ -141,6 +164,10 @@ struct BlockSymbolic {
     std::vector<int> src_entry;         // [nnz of the caller's pattern] -> entry id
     std::vector<Segment> fact_seg, bwd_seg, fwd_seg;    // fwd: the forward elimination alone (rhs rows of the fact tables)
     std::vector<Rec> fact_rec, bwd_rec, fwd_rec;
+    int fact_tasks = 0;                 // policy bit 50: fact_seg / fact_rec hold factorisation TASKS (above), not wave records of single items
+    int task_rounds = 0;                // ... and a task is filled up to this many rounds of 8 shares
+    long long n_staged = 0;             // operands staged by the tasks (statistics)
+    long long n_direct_terms = 0;       // terms of task items that kept the three-operand form
     int jordan = 0;                     // policy bit 49 and the plan qualifies: the top tasks can leave Jordan rows (see TopLaunch)
     int n_jordan = 0;                   // blocks of Jordan rows behind the n_entries factor entries
     std::vector<Segment> bwdj_seg;      // the backward sweep over Jordan rows (top pivots: wave records over ext(task); chains only below the top)
@@ -176,6 +203,7 @@ struct BlockSymbolic {
 // geometry is chosen so that it can take at least this many pivots (0 = default 6); bit 48: a task only absorbs pivots that need
 // its geometry (smaller fronts form tasks of their own below it).
 // policy bit 49: Jordan rows for the pivots of the top tasks + a second set of backward tables over them (see TOP_FRONT_MAX above).
+// policy bit 50: the factorisation tables are TASKS (see TASK_WAVES above); bits 51-53: rounds a task is filled up to (0 = default 3).
 // Returns 0, or 1 on a malformed pattern.
 int analyze(int n, const int* rowptr, const int* col, long long policy, BlockSymbolic& out);
 // Replay tables of the selected inverse of a SYMMETRIC matrix on the factor pattern (see jg_symbolic.cpp); idempotent.

@@ -30,6 +30,16 @@ def dsolve(F, R):
     return np.array([y1, y2])
 
 
+def dsolve_right(F, r):
+    """r D^-1 for a row vector r (what a task stages for its row items: Lh(p,k) D(k)^-1 row by row)."""
+    sw = F[1, 0] > 2.0
+    l = F[1, 0] - 4.0 if sw else F[1, 0]
+    z1 = r[0] * F[0, 0]
+    z2 = (r[1] - z1 * F[0, 1]) * F[1, 1]
+    y1 = z1 - z2 * l
+    return np.array([z2, y1]) if sw else np.array([y1, z2])
+
+
 class Replay:
     """inplace=True mirrors policy bit 0: the caller's blocks already sit in the factor storage and
     off-diagonal entries without update terms are not scheduled at all."""
@@ -54,6 +64,7 @@ class Replay:
         self.bseg, self.brec = plan.replay_tables("bwd")
         self.thdr, self.tdata, self.tlaunch, self.task_of, self.tinfo = plan.top_tables()
         self.n_jordan = int(self.tinfo[7]) if self.tinfo.size > 7 else 0
+        self.fact_tasks = bool(self.tinfo.size > 8 and int(self.tinfo[8]))
         if jordan:
             assert self.tinfo.size > 7 and int(self.tinfo[6]) == 1, "not a Jordan plan"
             self.bseg, self.brec = plan.replay_tables("bwdj")
@@ -124,7 +135,7 @@ class Replay:
             meta.clear()
 
         current = None
-        tables = [(lv, k, sb, rc) for lv, k, sb, rc in self._waves(self.fseg, self.frec)]
+        tables = [] if self.fact_tasks else [(lv, k, sb, rc) for lv, k, sb, rc in self._waves(self.fseg, self.frec)]
         if self.prefactor and not self.producer:             # plain blocks: the PRE tables run ahead of level 1, as level 0
             pseg, prec = self.p.replay_tables("pre")
             tables = [(0, ("pre",) + k, sb, rc) for lv, k, sb, rc in self._waves(pseg, prec)] + tables
@@ -162,10 +173,21 @@ class Replay:
                         part -= La @ dsolve(X[d], X[b])
             acc[key] = acc[key] + part            # the leader (sub 0) comes first and seeds the accumulator
         flush()
-        terms_seen = 0
-        for r in self.frec:
-            if r[0] >= 0:
-                terms_seen += int(r[3])
+        if self.fact_tasks:                                   # policy bit 50: the same items as TASKS (jg_symbolic.hpp, k_fact_task)
+            for si, (base, ntasks, spw, rpw, level, _last, _items, _pad) in enumerate(self.fseg):
+                if level != current:
+                    assert current is None or level > current, "segments out of level order"
+                    flush()
+                    current = level
+                for c in range(ntasks):
+                    self._task(si, c, self.frec[base + c * 8 * rpw: base + (c + 1) * 8 * rpw].reshape(8, rpw, 16), spw, level, A, rhs, X, Y, level_of, acc, meta)
+            flush()
+            terms_seen = int((self.frec[self.frec[:, 0] & 7 != 7, 3] & 0xff).sum())
+        else:
+            terms_seen = 0
+            for r in self.frec:
+                if r[0] >= 0:
+                    terms_seen += int(r[3])
         terms_seen += self._top_tasks(X, Y, level_of, partial, part_level, (current or 0))
         work = np.diff(self.t_ptr)
         if self.symmetric:
@@ -180,6 +202,104 @@ class Replay:
             assert terms_seen == int(self.t_ptr[-1]) + int(self.l_ptr[-1]), "update terms lost or duplicated in the records"
             assert (level_of >= 0).all(), "items missing from the factorisation schedule"
         return X, Y
+
+    def _task(self, si, c, recs, spw, level, A, rhs, X, Y, level_of, acc, meta):
+        """One factorisation TASK (jg_symbolic.hpp): recs [8 waves][rpw][16].  Staging records first (shared operands premultiplied by their
+        pivot block into slots), then rounds of item records; shares of a split item meet at the end of a TK_BAR round."""
+        nE = self.nE
+        FIRST, LAST, BAR, SIDE, DIRECT = 8, 16, 32, 64, 128
+        rpw = recs.shape[1]
+        slots = {}
+        assert 1 <= spw <= rpw
+        for w in range(8):
+            for j in range(rpw):
+                r = recs[w, j]
+                nst = int(r[3]) >> 8
+                assert 0 <= nst <= 2 and (nst == 0 or j < spw), "staging entries sit in the first spw records of a wave"
+                for u in range(nst):
+                    aw, d, sl = int(r[10 + 3 * u]), int(r[11 + 3 * u]), int(r[12 + 3 * u])
+                    a, tr, right = aw & ((1 << 24) - 1), (aw >> 30) & 1, (aw >> 29) & 1
+                    assert sl not in slots and 0 <= sl < 30 and sl % 8 == w, "slot staged twice / by the wrong wave"
+                    assert 0 <= level_of[a] < level and 0 <= level_of[d] < level, "LU schedule race (staged operand)"
+                    Aa = X[a].T if tr else X[a]
+                    if right:                                 # Lh(p,k) D(k)^-1: the solve runs over the ROWS of the operand
+                        slots[sl] = (np.stack([dsolve_right(X[d], Aa[0]), dsolve_right(X[d], Aa[1])], axis=0), a, d, 0)
+                    else:                                     # D(k)^-1 U(k,p)
+                        slots[sl] = (np.stack([dsolve(X[d], Aa[:, 0]), dsolve(X[d], Aa[:, 1])], axis=1), a, d, 1)
+        assert sorted(slots) == list(range(len(slots))), "slots are numbered without holes"
+        state = [None] * 8                                    # per wave: (kind, ident, sub, wpi, value, first round)
+        for rd in range(rpw):
+            bar = [int(recs[w, rd, 0]) & BAR for w in range(8)]
+            assert len(set(bar)) == 1, "TK_BAR must mark a round for every wave"
+            done = {}
+            for w in range(8):
+                r = recs[w, rd]
+                h = int(r[0])
+                kind = h & 7
+                if kind == 7:
+                    assert state[w] is None and int(r[3]) & 0xff == 0, "idle record inside a share"
+                    continue
+                assert kind in (0, 2, 3)
+                ident, src, nt, sub, wpi, side = int(r[1]), int(r[2]), int(r[3]) & 0xff, (h >> 8) & 7, (h >> 12) & 15, 1 if h & SIDE else 0
+                assert wpi in (1, 2, 4, 8) and sub < wpi and (w - sub) % wpi == 0, "shares of an item sit in neighbouring, aligned waves"
+                if h & FIRST:
+                    assert state[w] is None
+                    if sub == 0:
+                        if kind == 3:
+                            v = np.array(rhs[src], dtype=float)
+                        elif src >= 0:
+                            v = (X[src] if self.inplace else A[src]).copy()
+                            assert not self.inplace or src == ident
+                        else:
+                            v = np.zeros((2, 2))
+                    else:
+                        v = np.zeros(2) if kind == 3 else np.zeros((2, 2))
+                    state[w] = [kind, ident, sub, wpi, v]
+                st = state[w]
+                assert st is not None and st[:4] == [kind, ident, sub, wpi], "continuation record of another item"
+                assert not (kind == 3 and side), "a rhs row is a row item"
+                for t in range(nt):
+                    if h & DIRECT:
+                        assert t < 2
+                        a, d, b = (int(v) for v in r[4 + 3 * t: 7 + 3 * t])
+                        tr, a = a >> 30, a & ((1 << 30) - 1)
+                        assert 0 <= level_of[a] < level and 0 <= level_of[d] < level, "LU schedule race"
+                        La = X[a].T if tr else X[a]
+                        if kind == 3:
+                            assert 0 <= level_of[nE + b] < level, "forward schedule race"
+                            st[4] = st[4] - La @ dsolve(X[d], Y[b])
+                        else:
+                            assert 0 <= level_of[b] < level, "LU schedule race"
+                            st[4] = st[4] - La @ dsolve(X[d], X[b])
+                    else:
+                        assert t < 6
+                        word = int(r[4 + t])
+                        mem, sl = word & ((1 << 24) - 1), word >> 24
+                        S, sa, sd, sside = slots[sl]
+                        assert sside == side, "a row item reads a column slot"
+                        if kind == 3:
+                            assert 0 <= level_of[nE + mem] < level, "forward schedule race"
+                            st[4] = st[4] - S @ Y[mem]
+                        else:
+                            assert 0 <= level_of[mem] < level, "LU schedule race"
+                            st[4] = st[4] - (X[mem] @ S if side else S @ X[mem])
+                if h & LAST:
+                    assert wpi == 1 or bar[w], "the last round of a split item is a TK_BAR round"
+                    done[w] = st
+                    state[w] = None
+            for w, st in sorted(done.items()):                # owners collect their shares in wave order (fixed order on the device)
+                kind, ident, sub, wpi, v = st
+                if sub != 0:
+                    assert (w - sub) in done and done[w - sub][:2] == [kind, ident], "share without its owner in the same round"
+                    continue
+                for x in range(1, wpi):
+                    assert (w + x) in done and done[w + x][:4] == [kind, ident, x, wpi], "shares of an item must end in the same round"
+                    v = v + done[w + x][4]
+                key = (si, c, w, rd)
+                assert key not in meta
+                meta[key] = (level, kind, ident)
+                acc[key] = v
+        assert all(s is None for s in state), "a share without its last record"
 
     def _top_owned(self, e):
         return self.task_of.size > 0 and self.task_of[min(self.e_row[e], self.e_col[e])] >= 0

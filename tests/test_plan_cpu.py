@@ -18,18 +18,28 @@ def _oracle_jacobian(oracle, name):
     return s, a, J, f0, inc
 
 
-@pytest.mark.parametrize("inplace", [False, True, "producer finishes level 0", "pre tables", "producer finishes level 0, Jordan rows"])
+@pytest.mark.parametrize("inplace", [False, True, "producer finishes level 0", "pre tables", "producer finishes level 0, Jordan rows",
+                                     "producer finishes level 0, Jordan rows, tasks", "pre tables, tasks", "tasks", "tasks of one round"])
 @pytest.mark.parametrize("name", ["case14test", "case30test", "case118", "case1354pegase"])
 def test_schedule_replay_matches_oracle_increment(jg, oracle, name, inplace):
     s, a, J, f0, inc = _oracle_jacobian(oracle, name)
     rowptr, col, A = block_jacobian_from_csc(s.n, s.colptr, s.rowval, a.type, a.pq, a.pvpq, a.jcolptr, a.jrowval, J)
     pre = isinstance(inplace, str)                            # policy bit 2: level 0 by the producer / by the plan's PRE tables
     jordan = pre and "Jordan" in inplace                      # policy bit 49: what jg_nr_create asks for (granted where the plan has top tasks)
-    plan = jg._lib.Plan(s.n, rowptr, col, policy=((1 | 4) if pre else (1 if inplace else 0)) | (1 << 49 if jordan else 0))
+    tasks = isinstance(inplace, str) and "tasks" in inplace   # policy bit 50: the factorisation tables as TASKS (shared operands staged in LDS)
+    pre = pre and ("level 0" in inplace or "pre tables" in inplace)
+    plan = jg._lib.Plan(s.n, rowptr, col, policy=((1 | 4) if pre else (1 if inplace else 0)) | (1 << 49 if jordan else 0) | (1 << 50 if tasks else 0) |
+                        (1 << 51 if tasks and "one round" in inplace else 0))
+    assert bool(plan.top_tables()[4][8]) == tasks
     if jordan:
         jordan = bool(plan.top_tables()[4][6])
         assert jordan == (plan.top_tables()[0].shape[0] > 0) and (jordan or s.n < 100)
     rp = Replay(plan, inplace=bool(inplace), prefactor=pre, producer=pre and inplace.startswith("producer finishes level 0"), jordan=jordan)
+    if tasks and s.n > 1000:                                  # sharing pays: fewer staged operands than terms, (almost) no three-operand term left
+        info = plan.top_tables()[4]
+        seg, rec = plan.replay_tables("fact")
+        terms = (rec[rec[:, 0] & 7 != 7, 3] & 0xff).sum()
+        assert 0 < info[10] < 0.6 * terms and info[11] < 0.02 * terms
     if pre:
         plain = jg._lib.Plan(s.n, rowptr, col, policy=1)
         assert plan.get("e_level").max() == plain.get("e_level").max() - 1      # every level moved down by one
@@ -187,12 +197,14 @@ def test_replay_is_stable_on_ill_conditioned_gain(jg, oracle):
                 col.append(j)
                 A.append(blk)
         rowptr.append(len(col))
-    rp = Replay(jg._lib.Plan(n, np.array(rowptr), np.array(col)))
-    X, Y = rp.factor(np.array(A), rb.reshape(n, 2))
-    x = rp.backsolve(X, Y)
-    xs = np.concatenate([x[:, 0], x[:, 1]])
-    assert np.abs(xs - dx).max() <= 1e-6 * np.abs(dx).max()       # ~ cond * eps
-    assert np.abs(xs - v["increment"]).max() <= 1e-6 * np.abs(dx).max()
+    for policy in (0, 1 << 50):                                   # wave records; tasks (a staged operand is Lh D^-1 through the stored 2x2 LU: a right solve, not an inverse)
+        rp = Replay(jg._lib.Plan(n, np.array(rowptr), np.array(col), policy=policy))
+        assert rp.fact_tasks == bool(policy)
+        X, Y = rp.factor(np.array(A), rb.reshape(n, 2))
+        x = rp.backsolve(X, Y)
+        xs = np.concatenate([x[:, 0], x[:, 1]])
+        assert np.abs(xs - dx).max() <= 1e-6 * np.abs(dx).max()       # ~ cond * eps
+        assert np.abs(xs - v["increment"]).max() <= 1e-6 * np.abs(dx).max()
 
 
 @pytest.mark.parametrize("symmetric", [False, True])
@@ -273,6 +285,12 @@ def _solve_with_plan(jg, n, edges, rng, symmetric=False, top=0, prefactor=None):
         lower_or_diag = plan.get("e_row") >= plan.get("e_col")
         assert np.array_equal(Xj[:nE][lower_or_diag], X[:nE][lower_or_diag]), "Lh and D are untouched by the Jordan elimination"
         assert keep[lower_or_diag].all()
+    if not (top >> 50) & 1:                                     # ... and through the factorisation TASKS of the same policy (bit 50), filled to 1, 2, 3 rounds
+        rounds = 1 + (n + len(edges)) % 3
+        tp = _solve_with_plan(jg, n, edges, np.random.default_rng(n), symmetric, top | 1 << 50 | rounds << 51, prefactor)
+        assert int(tp.top_tables()[4][8]) == 1 and int(tp.top_tables()[4][9]) == rounds
+        for name in ("perm", "e_row", "e_col", "t_ptr", "e_level"):
+            assert np.array_equal(tp.get(name), plan.get(name)), "the tasks change the tables of the factorisation, not the analysis"
     return plan
 
 

@@ -9,7 +9,7 @@ def load(path):
     rows = []
     for r in csv.DictReader(open(path)):
         n = r["Kernel_Name"]
-        if "k_fact_level" in n or "k_fact_top" in n or "k_assemble" in n:
+        if "k_fact_level" in n or "k_fact_task" in n or "k_fact_top" in n or "k_assemble" in n:
             rows.append((int(r["Dispatch_Id"]), "asm" if "k_assemble" in n else ("top" if "k_fact_top" in n else "lvl"), float(r["Counter_Value"]),
                          int(r["Grid_Size"]) // int(r["Workgroup_Size"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     rows.sort()
