@@ -500,20 +500,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def region():
+        """EXACTLY args.steps steps between two fences (barrier + device synchronise); the time is the MAX over ranks."""
+        fence()
+        t0 = time.perf_counter()
+        it, st = run(args.steps)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, it, st
+
     run(args.warmup)
-    fence()
-    t0 = time.perf_counter()
-    iters_local, last_status = run(args.steps)
-    fence()
-    dt = time.perf_counter() - t0
+    # The timed region is K steps as given.  At the driver's K = 20 that is 0.12 s at N = 1 and ~15 ms at N = 8 (VERDICT r03): one region is
+    # mostly the fill and drain of the batches in flight plus whatever the box does in that instant.  So the SAME region -- K steps, fenced on
+    # both sides, max over ranks -- is repeated until about a second has been timed (every rank takes the count from the max-reduced first
+    # region: same number of collectives everywhere) and the line reports the MEDIAN region; min / max travel with it.
+    dt0, iters_local, last_status = region()
+    repeats = max(3, min(int(os.environ.get("JG_BENCH_MAX_REPEATS", "50")), int(np.ceil(float(os.environ.get("JG_BENCH_MIN_SECONDS", "1.0")) / max(dt0, 1e-6)))))
+    regions = [dt0]
+    for _ in range(repeats - 1):
+        dtr, it_r, last_status = region()
+        assert it_r == iters_local, "the same scenarios take the same iterations in every region"
+        regions.append(dtr)
+    dt = float(np.median(regions))
 
     conv_local = int(np.sum(last_status == 0))
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         cnt = torch.tensor([iters_local, conv_local], dtype=torch.int64, device=cdev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        dt = float(tt.item())
         iters_total, conv_total = int(cnt[0].item()), int(cnt[1].item())
     else:
         iters_total, conv_total = iters_local, conv_local
@@ -565,6 +582,8 @@ def main():
             "metric": "NR iterations/sec (batched N-1 AC power flow, 10k-bus grid)",
             "value": iters_total / dt, "unit": "NR iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "region_repeats": len(regions), "region_ms_min": 1e3 * float(np.min(regions)), "region_ms_median": 1e3 * dt, "region_ms_max": 1e3 * float(np.max(regions)),
+            "region_what": f"the K = {args.steps}-step region (fenced on both sides, max over ranks) repeated {len(regions)} times; value and ms_per_step are its MEDIAN",
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.case} batched N-1 contingency Newton-Raphson, {total} scenarios per step "
                                    f"({B} per GPU), start = base-case solution, tol 1e-8, max 20 iterations",
@@ -575,6 +594,11 @@ def main():
                        "device_batches_in_flight_per_gpu": len(pipe.handles),
                        "straggler_pool_lanes": pipe.pools[0].handle.batch if pipe.pools else 0,
                        "steps_in_flight_per_gpu": len(pipe.handles) * merge,
+                       "device_batches_per_region": -(-args.steps // merge),
+                       "pipeline_steady_state": bool(-(-args.steps // merge) >= 3 * len(pipe.handles)),
+                       "pipeline_note": ("a region holds at least three rounds of the batches in flight" if -(-args.steps // merge) >= 3 * len(pipe.handles) else
+                                         f"a region is {-(-args.steps // merge)} device batch(es) with {len(pipe.handles)} in flight: it measures the fill and drain of the pipeline, "
+                                         "not its steady state -- more --steps per region (or --merge 1 for narrower batches) changes that, the K of the caller is kept as given"),
                        "gather": "abi" if comm is not None else "torch.distributed",
                        "parallelism": f"scenario-sharded x{world}, one RCCL all-gather of the packed results per device batch "
                                       f"({merge} step(s) of {B} scenarios per GPU)",

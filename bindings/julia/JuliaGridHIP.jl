@@ -238,7 +238,6 @@ function NewtonRaphsonBatch(system::PowerSystem, batch::Int; device::Int = 0, ma
     return b
 end
 
-"scenario s (1-based) = base grid with branch labels[s] out of service (0: base case); one upload for the whole batch"
 """
     shareDevice!(batch, on = true)
 
@@ -248,6 +247,7 @@ leaves room on a compute unit for the other batches' workgroups.  Results are bi
 shareDevice!(b::NewtonRaphsonBatch, on::Bool = true) =
     check(ccall((:jg_nr_set_shared, lib), Cint, (Ptr{Cvoid}, Cint), b.handle.ptr, on ? 1 : 0))
 
+"scenario s (1-based) = base grid with branch labels[s] out of service (0: base case); one upload for the whole batch"
 function setOutages!(b::NewtonRaphsonBatch, labels::Vector{Int64})
     length(labels) == b.batch || throw(DimensionMismatch("one label per scenario"))
     ac, Y, lay = b.system.model.ac, b.system.model.ac.nodalMatrix, b.system.branch.layout

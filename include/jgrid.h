@@ -134,9 +134,9 @@ int jg_nr_run(jg_nr* h, int64_t max_iter, double tol, int32_t* iters, int32_t* s
  *                     in src they end with status 4 (deferred).  Same grid, same device, dst must not be running.
  *   jg_nr_finish      ends a paused run: lanes home, iters / status [batch] (deferred scenarios: status 4).
  *   jg_nr_resume      runs the scenarios in lanes [0, lanes) of a pool to the end, each with the iteration count it arrived with
- *                     (per-scenario results are bitwise those of an undisturbed batch: lanes never interact -- provided the pool
- *                     handle runs the same factorisation plan, i.e. its batch lies on the same side of 256 scenarios as the
- *                     batch the scenarios came from; the plan depends on the batch a handle was created for); iters / status [lanes].
+ *                     (per-scenario results are bitwise those of an undisturbed batch: lanes never interact, and jg_nr_move_lanes refuses
+ *                     a pool that runs another factorisation plan than the batch -- the plan depends on the CLASS of batch a handle was
+ *                     created for: at most 32 scenarios, 33-64, 65-255, 256 and more); iters / status [lanes].
  *   jg_nr_pack_rows_device  V | theta | iterations | status of lanes lane0 .. lane0 + count - 1 into rows rows[i] of a result
  *                     record [.][2 n + 2] in device memory (the record jg_nr_pack_results_device writes for the batch they left). */
 int jg_nr_run_defer(jg_nr* h, int64_t max_iter, double tol, int64_t defer_at, int32_t* n_left);

@@ -37,6 +37,13 @@ def lib():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    if not os.environ.get("JG_LIB") and not os.environ.get("JG_ALLOW_STALE"):
+        # the library must have been built from the sources that lie next to it (content hash written by build.py beside the .so): a stale
+        # binary would pass or fail tests for code that is not in the tree
+        from . import build as _build
+        if _build.needs_build():
+            raise ImportError(f"{LIB_PATH} was not built from the current csrc/ + include/jgrid.h (content hash differs or is missing): rebuild with "
+                              "`python -c 'import __graft_entry__ as g; g.build()'`, or set JG_ALLOW_STALE=1 to load it anyway")
     L = C.CDLL(LIB_PATH)
     L.jg_last_error.restype = C.c_char_p
     L.jg_device_count.restype = C.c_int

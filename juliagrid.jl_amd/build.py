@@ -16,16 +16,40 @@ def hipcc():
     raise RuntimeError("hipcc not found (need ROCm to build libjgrid_hip.so)")
 
 
+def source_hash():
+    """SHA-256 over the sources the library is built from (csrc/*, include/jgrid.h), the compiler flags and this script's command shape."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(HERE, "..", "include", "jgrid.h")]
+    for f in files:
+        if os.path.isfile(f):
+            h.update(os.path.basename(f).encode() + b"\0")
+            with open(f, "rb") as fh:
+                h.update(fh.read())
+            h.update(b"\0")
+    h.update(" ".join(SOURCES).encode())
+    h.update(os.environ.get("JG_EXTRA_HIPCC_FLAGS", "").encode())
+    return h.hexdigest()
+
+
+def stamp_path():
+    return LIB + ".sha256"
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    """The decision rests on CONTENT, not on modification times (the git-ignored .so travels prebuilt to the GPU box and a push
+    leaves whatever mtimes it leaves): the hash of the sources the library was built from is stored beside it."""
+    if not os.path.exists(LIB) or not os.path.exists(stamp_path()):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "jgrid.h")]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    with open(stamp_path()) as fh:
+        return fh.read().strip() != source_hash()
 
 
 def build(force=False, verbose=False):
+    want = source_hash()
     if not force and not needs_build():
+        if verbose or os.environ.get("JG_BUILD_VERBOSE"):
+            print(f"[jgrid build] up to date: {LIB} was built from sources {want[:12]}")
         return LIB
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
@@ -34,6 +58,10 @@ def build(force=False, verbose=False):
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
     os.replace(LIB + ".tmp", LIB)
+    with open(stamp_path(), "w") as fh:
+        fh.write(want + "\n")
+    if verbose or os.environ.get("JG_BUILD_VERBOSE"):
+        print(f"[jgrid build] rebuilt {LIB} from sources {want[:12]}")
     return LIB
 
 

@@ -140,7 +140,9 @@ class ContingencyPipeline:
             # the engine picks its plan (where the multifrontal top starts, front caps: another summation order) by the side of 256 lanes
             # a handle is on (Engine::create): the pool must sit on the same side as the batches it serves, or a straggler that finishes
             # there would no longer be bitwise the scenario of a lockstep batch
-            lanes = max(lanes, 256) if -(-self.batch // 64) * 64 >= 256 else min(lanes, 192)
+            # (there are more classes than two -- up to 32 scenarios, one lane group, 65-255, 256 and more -- and a pool of 64 lanes
+            # beside batches of 128 / 192 would run the one-lane-group plan; jg_nr_move_lanes now refuses a hand-off between different plans)
+            lanes = max(lanes, 256) if -(-self.batch // 64) * 64 >= 256 else min(max(lanes, 128), 192)
             self.pools = [_Pool(newtonRaphson(system, batch=lanes, device=device, max_patch=4)) for _ in range(2)]
         if len(self.handles) + len(self.pools) > 1:      # several batches share the GPU: the top launches leave room for the others' workgroups
             for an in self.handles + [p.handle for p in self.pools]:

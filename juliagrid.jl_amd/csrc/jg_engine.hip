@@ -72,35 +72,61 @@ typedef const RecS __attribute__((address_space(4)))* RecPtr;
 __device__ __forceinline__ RecS load_rec(const Rec* base, size_t index) { return ((RecPtr)base)[index]; }
 __device__ __forceinline__ int rec_word(const RecS& r, int k) { return r[k]; }
 
-// one record of a factorisation item: up to FACT_T update terms, every operand load issued before the first use
+// Hand-placed requests: `global_load_dwordx4 dst, lane offset, scalar base` (the item index of every operand comes from a record in scalar
+// registers).  hipcc fences loads that sit behind a branch on a run-time count -- `if (t < nt) load` -- with waits of their own: it reuses the
+// destination registers of one load as address registers of the next and drains (part of) the queue before each address computation, so the
+// operands of a record arrived one term after the other (rocprof, round 4; cdna_hip_programming.md lists the same trap).  Requests written this way
+// go out back to back; ONE s_waitcnt, tied to the destination registers by its operands, stands before the first use.  The compiler does not count
+// these loads: its own waits can only come earlier than needed (loads return in order), never later.
+typedef double d2v __attribute__((ext_vector_type(2)));
+struct BlkV { d2v r0, r1; };
+__device__ __forceinline__ void gload16(d2v& dst, const void* base, unsigned off) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory");   // "memory": the compiler must not move its stores across (the waits count them)
+}
+
+// one record of a factorisation item: up to FACT_T update terms, every operand requested before the first use (nothing in the request loop
+// uses a loaded value: the transposition of a symmetric plan's operand is a select at the point of use; a rhs row's 2-vector is requested like a
+// block whose second half re-reads the first: one kind of request, no branch)
 __device__ __forceinline__ void fact_record(const FactArgs& a, const RecS& r, int kind, size_t b, size_t ld, Blk& c) {
+    static_assert(FACT_T == 4, "operand list of the wait");
     const int nt = rec_word(r, 3);
-    Blk l[FACT_T], d[FACT_T], u[FACT_T];
+    BlkV l[FACT_T], d[FACT_T], u[FACT_T];
+#pragma unroll
+    for (int t = 0; t < FACT_T; ++t) asm volatile("" : "=v"(l[t].r0), "=v"(l[t].r1), "=v"(d[t].r0), "=v"(d[t].r1), "=v"(u[t].r0), "=v"(u[t].r1));   // (no instruction)
+    const char* const usrc = kind == 3 ? (const char*)a.W : (const char*)a.X;
+    const size_t urow = kind == 3 ? ld * 16 : ld * 32, uhalf = kind == 3 ? 0 : ld * 16;
+    const unsigned off = (unsigned)b * 16u;
 #pragma unroll
     for (int t = 0; t < FACT_T; ++t) {
         if (t < nt) {
-            const int ia = rec_word(r, 4 + 3 * t);              // bit 30: read the block transposed (symmetric matrices: Lh(i,k) = U(k,i)')
-            l[t] = load_blk(a.X, (size_t)(ia & 0x3fffffff), b, ld);
-            if (ia >> 30) { const double x = l[t].v01; l[t].v01 = l[t].v10; l[t].v10 = x; }
-            d[t] = load_blk(a.X, (size_t)rec_word(r, 5 + 3 * t), b, ld);
-            if (kind == 3) {
-                const double2 w = load_vec(a.W, (size_t)rec_word(r, 6 + 3 * t), b, ld);
-                u[t].v00 = w.x; u[t].v10 = w.y; u[t].v01 = 0.0; u[t].v11 = 0.0;
-            } else {
-                u[t] = load_blk(a.X, (size_t)rec_word(r, 6 + 3 * t), b, ld);
-            }
+            const char* pl = (const char*)a.X + (size_t)(rec_word(r, 4 + 3 * t) & 0x3fffffff) * ld * 32;
+            const char* pd = (const char*)a.X + (size_t)rec_word(r, 5 + 3 * t) * ld * 32;
+            const char* pu = usrc + (size_t)rec_word(r, 6 + 3 * t) * urow;
+            gload16(l[t].r0, pl, off); gload16(l[t].r1, pl + ld * 16, off);
+            gload16(d[t].r0, pd, off); gload16(d[t].r1, pd + ld * 16, off);
+            gload16(u[t].r0, pu, off); gload16(u[t].r1, pu + uhalf, off);
         }
+    }
+    if (nt > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" : "+v"(l[0].r0), "+v"(l[0].r1), "+v"(d[0].r0), "+v"(d[0].r1), "+v"(u[0].r0), "+v"(u[0].r1),
+                          "+v"(l[1].r0), "+v"(l[1].r1), "+v"(d[1].r0), "+v"(d[1].r1), "+v"(u[1].r0), "+v"(u[1].r1));
+        asm volatile("" : "+v"(l[2].r0), "+v"(l[2].r1), "+v"(d[2].r0), "+v"(d[2].r1), "+v"(u[2].r0), "+v"(u[2].r1),
+                          "+v"(l[3].r0), "+v"(l[3].r1), "+v"(d[3].r0), "+v"(d[3].r1), "+v"(u[3].r0), "+v"(u[3].r1));
     }
 #pragma unroll
     for (int t = 0; t < FACT_T; ++t) {
         if (t < nt) {
-            if (kind == 3) {          // y -= Lh(a) * D(d)^-1 * y_c
+            const bool tr = (rec_word(r, 4 + 3 * t) >> 30) != 0;  // bit 30: read the block transposed (symmetric matrices: Lh(i,k) = U(k,i)')
+            const Blk lt{l[t].r0.x, tr ? l[t].r1.x : l[t].r0.y, tr ? l[t].r0.y : l[t].r1.x, l[t].r1.y};
+            const Blk dt{d[t].r0.x, d[t].r0.y, d[t].r1.x, d[t].r1.y};
+            if (kind == 3) {          // y -= Lh(a) * D(d)^-1 * y_c   (y_c = the first half of u)
                 double z0, z1;
-                dsolve(d[t], u[t].v00, u[t].v10, z0, z1);
-                c.v00 -= l[t].v00 * z0 + l[t].v01 * z1;
-                c.v01 -= l[t].v10 * z0 + l[t].v11 * z1;
+                dsolve(dt, u[t].r0.x, u[t].r0.y, z0, z1);
+                c.v00 -= lt.v00 * z0 + lt.v01 * z1;
+                c.v01 -= lt.v10 * z0 + lt.v11 * z1;
             } else {
-                term3(c, l[t], d[t], u[t]);
+                term3(c, lt, dt, Blk{u[t].r0.x, u[t].r0.y, u[t].r1.x, u[t].r1.y});
             }
         }
     }
@@ -475,26 +501,39 @@ struct SelArgs {
     int s0_base, s0_nchunks, s0_wpi, s0_rpw;
 };
 
-// T += U(i,k) * Z(k,j)   (Z entry read transposed when bit 30 of its id is set)
+// T += U(i,k) * Z(k,j)   (Z entry read transposed when bit 30 of its id is set); hand-placed requests, one wait (see gload16)
 __device__ __forceinline__ void sel_record(const SelArgs& a, const RecS& r, size_t b, size_t ld, Blk& t) {
+    static_assert(BWD_T == 6, "operand list of the wait");
     const int nt = rec_word(r, 3);
-    Blk u[BWD_T], z[BWD_T];
+    BlkV u[BWD_T], z[BWD_T];
+#pragma unroll
+    for (int q = 0; q < BWD_T; ++q) asm volatile("" : "=v"(u[q].r0), "=v"(u[q].r1), "=v"(z[q].r0), "=v"(z[q].r1));   // (no instruction)
+    const unsigned off = (unsigned)b * 16u;
 #pragma unroll
     for (int q = 0; q < BWD_T; ++q) {
         if (q < nt) {
-            u[q] = load_blk(a.X, (size_t)rec_word(r, 4 + 2 * q), b, ld);
-            z[q] = load_blk(a.Z, (size_t)(rec_word(r, 5 + 2 * q) & 0x3fffffff), b, ld);
+            const char* pu = (const char*)a.X + (size_t)rec_word(r, 4 + 2 * q) * ld * 32;
+            const char* pz = (const char*)a.Z + (size_t)(rec_word(r, 5 + 2 * q) & 0x3fffffff) * ld * 32;
+            gload16(u[q].r0, pu, off); gload16(u[q].r1, pu + ld * 16, off);
+            gload16(z[q].r0, pz, off); gload16(z[q].r1, pz + ld * 16, off);
         }
+    }
+    if (nt > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" : "+v"(u[0].r0), "+v"(u[0].r1), "+v"(z[0].r0), "+v"(z[0].r1), "+v"(u[1].r0), "+v"(u[1].r1), "+v"(z[1].r0), "+v"(z[1].r1),
+                          "+v"(u[2].r0), "+v"(u[2].r1), "+v"(z[2].r0), "+v"(z[2].r1));
+        asm volatile("" : "+v"(u[3].r0), "+v"(u[3].r1), "+v"(z[3].r0), "+v"(z[3].r1), "+v"(u[4].r0), "+v"(u[4].r1), "+v"(z[4].r0), "+v"(z[4].r1),
+                          "+v"(u[5].r0), "+v"(u[5].r1), "+v"(z[5].r0), "+v"(z[5].r1));
     }
 #pragma unroll
     for (int q = 0; q < BWD_T; ++q) {
         if (q < nt) {
             const bool tr = (rec_word(r, 5 + 2 * q) >> 30) & 1;
-            const double z01 = tr ? z[q].v10 : z[q].v01, z10 = tr ? z[q].v01 : z[q].v10;
-            t.v00 += u[q].v00 * z[q].v00 + u[q].v01 * z10;
-            t.v01 += u[q].v00 * z01 + u[q].v01 * z[q].v11;
-            t.v10 += u[q].v10 * z[q].v00 + u[q].v11 * z10;
-            t.v11 += u[q].v10 * z01 + u[q].v11 * z[q].v11;
+            const double z00 = z[q].r0.x, z11 = z[q].r1.y, z01 = tr ? z[q].r1.x : z[q].r0.y, z10 = tr ? z[q].r0.y : z[q].r1.x;
+            t.v00 += u[q].r0.x * z00 + u[q].r0.y * z10;
+            t.v01 += u[q].r0.x * z01 + u[q].r0.y * z11;
+            t.v10 += u[q].r1.x * z00 + u[q].r1.y * z10;
+            t.v11 += u[q].r1.x * z01 + u[q].r1.y * z11;
         }
     }
 }
@@ -640,11 +679,6 @@ constexpr int TASK_LDS_D2 = (TASK_SLOTS + TASK_WAVES) * 128;
 // the destination registers of one load as address registers of the next and drains the queue before each address computation: rocprof showed a task's
 // six operands arriving in six consecutive round trips; the wave records of k_fact_level suffer from the same thing in pairs).  The compiler does not count
 // these loads: its own waits can only be earlier than needed (loads return in order), never later.
-typedef double d2v __attribute__((ext_vector_type(2)));
-struct BlkV { d2v r0, r1; };
-__device__ __forceinline__ void gload16(d2v& dst, const void* base, unsigned off) {
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory");   // "memory": the compiler must not move its stores across (the waits count them)
-}
 // Every request of the wave has arrived.  `stores`: store instructions that were issued AFTER those requests and may stay in flight (the results
 // of the previous round leave behind the next round's requests: loads and stores share the counter and complete in order, so waiting for the
 // loads of a round must not mean waiting for the stores of the round before).  A lower bound is safe, a larger count is not.

@@ -1386,6 +1386,12 @@ int jg_nr_move_lanes(jg_nr* dst, int64_t dst_lane0, jg_nr* src, int32_t* home, i
     if (!src->paused) return fail(1, "jg_nr_move_lanes: the source is not paused (jg_nr_run_defer)");
     if (dst->device != src->device || dst->n != src->n || dst->nnz != src->nnz || dst->mp != src->mp || dst->fast || src->fast)
         return fail(1, "jg_nr_move_lanes: the two handles must hold the same grid on the same device");
+    //  the factorisation plan -- where the top starts, front caps, tasks or wave records: the summation order -- is chosen by the class of
+    // batch a handle was created for (Engine::create: up to 32 scenarios, one lane group, 65-255, 256 and more).  A straggler that finishes under another
+    // plan is no longer bitwise the scenario of a lockstep batch, silently: refuse the hand-off instead.
+    if (dst->eng.plan && src->eng.plan && dst->eng.plan->policy != src->eng.plan->policy)
+        return fail(1, "jg_nr_move_lanes: the pool runs another factorisation plan than the batch (create both for the same class of batch: "
+                       "at most 32 scenarios, 33-64, 65-255, 256 and more)");
     if (int rc = set_device(dst)) return rc;
     for (jg_nr* h : {dst, src})
         if (!h->d_move) {

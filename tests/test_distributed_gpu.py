@@ -54,14 +54,35 @@ def _bench(args, **env):
 def test_bench_starts_by_itself_with_two_ranks():
     """`python bench.py --gpus 2` without a launcher: it re-executes itself under torch.distributed.run; two ranks share the one GPU
     over gloo (JG_BENCH_BACKEND: the measured configuration is RCCL), 512 scenarios per step sharded 256 + 256."""
-    d = _bench(["--gpus", "2", "--steps", "4", "--warmup", "1", "--no-cpu", "--no-se"], JG_BENCH_BACKEND="gloo")
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 4
+    d = _bench(["--gpus", "2", "--steps", "4", "--warmup", "1", "--no-cpu", "--no-se"], JG_BENCH_BACKEND="gloo", JG_BENCH_MAX_REPEATS="3")
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 4 and d["region_repeats"] == 3
     assert d["config"]["scenarios_per_step"] == 512 and d["config"]["batch_per_gpu"] == 256
     assert d["value"] > 0 and d["converged_fraction"] == 1.0
 
 
 def test_bench_with_a_one_rank_rccl_group():
-    d = _bench(["--steps", "4", "--warmup", "1", "--no-cpu", "--no-se"], JG_BENCH_FORCE_DIST="1")
+    d = _bench(["--steps", "4", "--warmup", "1", "--no-cpu", "--no-se"], JG_BENCH_FORCE_DIST="1", JG_BENCH_MAX_REPEATS="3")
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["converged_fraction"] == 1.0
-    d2 = _bench(["--steps", "4", "--warmup", "1", "--no-cpu", "--no-se"], JG_BENCH_FORCE_DIST="1", JG_BENCH_GATHER="abi")
+    d2 = _bench(["--steps", "4", "--warmup", "1", "--no-cpu", "--no-se"], JG_BENCH_FORCE_DIST="1", JG_BENCH_GATHER="abi", JG_BENCH_MAX_REPEATS="3")
     assert d2["config"].get("gather") == "abi" and d2["converged_fraction"] == 1.0
+
+
+def test_bench_at_the_drivers_flags_with_four_ranks():
+    """The driver's command shape for N = 4 (`--steps 20 --warmup 3`), four ranks sharing the one GPU over gloo: 512 scenarios sharded 4 x 128, a
+    rank solves its shares of 4 steps as one 512-lane device batch; the K-step region is repeated and the line carries the median and the spread,
+    and says whether a region reaches the steady state of the pipeline (5 device batches with 3 in flight: it does not)."""
+    d = _bench(["--gpus", "4", "--steps", "20", "--warmup", "3", "--no-cpu", "--no-se"], JG_BENCH_BACKEND="gloo", JG_BENCH_MAX_REPEATS="4")
+    assert d["n_gpus"] == 4 and d["steps"] == 20 and d["warmup"] == 3 and d["scaling"] == "strong"
+    assert d["config"]["batch_per_gpu"] == 128 and d["config"]["lanes_per_device_batch"] == 512 and d["config"]["steps_per_device_batch"] == 4
+    assert 3 <= d["region_repeats"] <= 4 and d["region_ms_min"] <= d["region_ms_median"] <= d["region_ms_max"]
+    assert abs(d["ms_per_step"] * d["steps"] - d["region_ms_median"]) < 1e-6 * d["region_ms_median"]
+    assert d["config"]["device_batches_per_region"] == 5 and d["config"]["pipeline_steady_state"] is False
+    assert d["value"] > 0 and d["converged_fraction"] == 1.0
+
+
+def test_bench_region_statistics_at_one_gpu():
+    """N = 1 at the driver's flags: 20 device batches per region with three in flight (steady state), the region repeated until ~1 s is timed."""
+    d = _bench(["--steps", "20", "--warmup", "3", "--no-cpu", "--no-se"])
+    assert d["n_gpus"] == 1 and d["region_repeats"] >= 3 and d["config"]["pipeline_steady_state"] is True
+    assert d["region_ms_max"] < 1.5 * d["region_ms_min"], "regions of the same work on an otherwise idle GPU"
+    assert d["region_repeats"] * d["region_ms_median"] > 500.0 or d["region_repeats"] == 50

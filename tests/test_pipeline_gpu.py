@@ -55,6 +55,44 @@ def test_pool_is_bitwise_the_lockstep_pipeline(jg, name, batch, njobs, pool):
     assert moved > 0                                                  # some scenarios did need more iterations than their batch
 
 
+def test_pool_of_a_mid_size_batch_keeps_its_plan_class(jg):
+    """batches of 128 / 192 lanes with defer_at <= 32 and a small pool request used to get a 64-lane pool, which on a grid of
+    4 000 buses and more runs the one-lane-group plan (another summation order): stragglers were no longer bitwise the lockstep scenarios, with
+    no error.  The pool is now clamped into the class of its batches, and jg_nr_move_lanes refuses a hand-off between different plans."""
+    import torch
+    s = jg.powerSystem(load_case("case_ACTIVSg10k"))
+    n = s.bus.number
+    base = jg.newtonRaphson(s)
+    jg.powerFlow_(base)
+    start = (base.voltage.magnitude.copy(), base.voltage.angle.copy())
+    base.close()
+    labels = jg.outageList(s, 2 * 192, seed=11)
+    jobs = [labels[:192], labels[192:]]
+    out = {}
+    for mode, pool in (("lockstep", 0), ("pool", 64)):
+        pipe = jg.ContingencyPipeline(s, 192, inflight=2, start=start, pool=pool, defer_at=32)
+        if pool:
+            assert pipe.pools and 128 <= pipe.pools[0].handle.batch <= 192, "a pool beside 192-lane batches stays in their class"
+        rec = _records(torch, 2, 192, n)
+        res = pipe.run(jobs, iteration=20, tolerance=1e-8, on_done=lambda j, an: torch.cuda.current_stream().synchronize(),
+                       record=lambda j: rec[j % 2].data_ptr(), records=2)
+        out[mode] = (res, [r.cpu().numpy().copy() for r in rec])
+        pipe.close()
+    for j in range(2):
+        assert np.array_equal(out["lockstep"][0][j][0], out["pool"][0][j][0]) and np.array_equal(out["lockstep"][1][j], out["pool"][1][j])
+    # the refusal itself: a paused 192-lane batch and a 64-lane handle of the same grid
+    big = jg.contingencyAnalysis(s, labels[:192])
+    small = jg.newtonRaphson(s, batch=64, max_patch=4)
+    left = jg._lib.C.c_int32(0)
+    jg._lib.check(jg._lib.lib().jg_nr_run_defer(big._h, 20, 1e-8, 64, jg._lib.C.byref(left)))
+    if left.value > 0:
+        home = np.zeros(64, dtype=np.int32)
+        cnt = jg._lib.C.c_int32(0)
+        rc = jg._lib.lib().jg_nr_move_lanes(small._h, 0, big._h, home, jg._lib.C.byref(cnt))
+        assert rc == 1 and b"another factorisation plan" in jg._lib.lib().jg_last_error()
+    big.close(); small.close()
+
+
 def test_pool_handles_scenarios_without_a_power_flow(jg):
     """An islanding outage (status 3) and a scenario that runs into the iteration limit end with the right status whether they
     finish in their batch or in the pool; screen() works with a pool (no records)."""
