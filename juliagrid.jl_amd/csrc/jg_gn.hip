@@ -59,6 +59,11 @@ constexpr int GN_ROWS = 16;     // measurement rows per workgroup (4 waves x 4)
 // value and partials of one branch measurement; i = from, j = to (equations.jl:147-547)
 __device__ __forceinline__ void branch_row(int ty, const BranchP& p, double Vi, double Vj, double thi, double thj,
                                            double& h, double& ti, double& vi, double& tj, double& vj) {
+    // No contraction into fused multiply-adds here.  The reference's formulas for a current magnitude form I^2 = A Vi^2 + B Vj^2 - 2 Vi Vj (C cos -+ D sin)
+    // from terms of size (|y| V)^2 -- 1e6 .. 1e9 -- that cancel to ~1e-2 (equations.jl:279-458); Julia does not contract, and a fused term differs from
+    // the reference's by one rounding that the cancellation amplifies to 6e-7 of the row's scale in H.  Measured with the library built both ways
+    // (tools/se_contract_probe.sh, profiles/r04_se_contract_probe.txt): rows of type 2 / 3 |dH| 1.4e-3 -> 7e-13, types 14 / 15 6e-7 -> 7e-8 at |H| 1e4.
+#pragma clang fp contract(off)
     const double g = p.g, b = p.b, gs = p.gs, bs = p.bs, tv = p.tinv;
     if (ty >= 18) {                                   // rectangular current phasors (types 18-21)
         double si, ci, sj, cj, A, B;

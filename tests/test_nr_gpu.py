@@ -212,6 +212,43 @@ def test_batched_injections_match_oracle(jg, oracle):
         assert np.abs(an.voltage.angle[b] - va).max() <= 1e-8
 
 
+def test_monte_carlo_injections_at_config2_scale(jg, oracle):
+    """SURVEY 8(d) config 2 / north_star "Monte-Carlo instances": B = 512 load-perturbed copies of case1354pegase in ONE handle -- every scenario its
+    own demand (each bus's active and reactive demand scaled by an independent N(1, 0.05^2) draw, PCG64(1354): what a user loop over updateBus!(;
+    active, reactive) does, bus.jl:286-298, :314-323), shared topology.  Sixteen lanes -- the first and last of each lane group among them -- against the
+    oracle solving that scenario alone: equal iteration counts, V / theta 1e-8; every scenario converges; two scenarios with the same draw are bitwise
+    equal (lanes do not interact)."""
+    t = load_case("case1354pegase")
+    s = jg.powerSystem(t)
+    B, n = 512, s.bus.number
+    an = jg.newtonRaphson(s, batch=B)
+    rng = np.random.Generator(np.random.PCG64(1354))
+    fp = 1.0 + 0.05 * rng.standard_normal((B, n))
+    fq = 1.0 + 0.05 * rng.standard_normal((B, n))
+    fp[B - 1], fq[B - 1] = fp[3], fq[3]                               # a duplicate of scenario 3 in another lane group
+    pd = s.bus.demand.active[None, :] * fp
+    qd = s.bus.demand.reactive[None, :] * fq
+    jg.setInjection_(an, s.bus.supply.active[None, :] - pd, s.bus.supply.reactive[None, :] - qd)
+    jg.powerFlow_(an)
+    assert (an.status == 0).all()
+    assert len(set(int(i) for i in an.method.iteration)) >= 1 and an.method.iteration.max() <= 8
+    assert np.array_equal(an.voltage.magnitude[3], an.voltage.magnitude[B - 1]) and np.array_equal(an.voltage.angle[3], an.voltage.angle[B - 1])
+    assert np.abs(an.voltage.magnitude[0] - an.voltage.magnitude[1]).max() > 1e-6, "the scenarios are different power flows"
+    osys = oracle.OracleSystem(t)
+    lanes = [0, 1, 63, 64, 127, 128, 200, 255, 256, 300, 383, 384, 447, 448, 510, 511]
+    worst = 0.0
+    for b in lanes:
+        o = oracle.OracleNR(osys)
+        o.set_power(osys.ps, osys.qs, pd[b], qd[b])
+        assert o.power_flow() == 0
+        assert an.method.iteration[b] == o.iteration, b
+        vm, va = o.voltage()
+        worst = max(worst, np.abs(an.voltage.magnitude[b] - vm).max(), np.abs(an.voltage.angle[b] - va).max())
+    print(f"[monte carlo 512 x case1354pegase] {len(lanes)} lanes against the oracle: max |dV|, |dtheta| {worst:.2e}; iterations {np.bincount(an.method.iteration).tolist()}")
+    assert worst <= 1e-8
+    an.close()
+
+
 def test_full_size_batch_properties(jg, oracle):
     """BASELINE config 5 shape on one GPU (ACTIVSg10k, 128 outage scenarios): size-independent
     properties -- every converged scenario satisfies the power-flow equations when its state is
