@@ -3,7 +3,9 @@
 #include "jg_symbolic.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <type_traits>
 #include <iterator>
 #include <queue>
 #include <thread>
@@ -68,6 +70,7 @@ void elimination_order(int n, const std::vector<std::vector<int>>& adj0, std::ve
     order.clear(); order.reserve(n);
     strct.assign(n, {});
     std::vector<int> merged, touched;
+    std::vector<std::pair<int, int>> newedge;
     int epoch = 0;
     while (!heap.empty()) {
         const Entry top = heap.top();
@@ -94,6 +97,15 @@ void elimination_order(int n, const std::vector<std::vector<int>>& adj0, std::ve
             strct[k] = std::move(nb);
             continue;
         }
+        // the edges the elimination creates: pairs of neighbours of v that are not adjacent yet (fillv[v] of them)
+        newedge.clear();
+        ++epoch;
+        for (int a : nb) seen[a] = epoch;                      // seen == epoch: member of the new clique
+        for (int a : nb) {
+            ++stamp;
+            for (int w : adj[a]) mark[w] = stamp;
+            for (int x : nb) if (x > a && mark[x] != stamp) newedge.push_back(std::make_pair(a, x));
+        }
         for (int a : nb) {                                     // v leaves, its neighbourhood becomes a clique
             std::vector<int>& aa = adj[a];
             merged.clear();
@@ -102,18 +114,23 @@ void elimination_order(int n, const std::vector<std::vector<int>>& adj0, std::ve
             for (int w : merged) if (w != v && w != a) aa.push_back(w);
             hv[a] = std::max(hv[a], hv[v] + 1);
         }
-        // whose score changed: the neighbours of v (degree, height, fill), and every vertex with at least TWO neighbours among them (its
-        // fill counts pairs of its neighbours that are not adjacent, and the only new edges run between neighbours of v); a vertex
-        // that touches the new clique in one point keeps its score exactly
-        ++epoch;
+        // Whose score changed.  A vertex OUTSIDE the new clique keeps its neighbourhood; its fill counts the pairs of its neighbours that are not
+        // adjacent, and the only pairs that became adjacent are the new edges: fill(u) -= 1 for every new edge (a, x) with u a common neighbour of
+        // a and x -- exact, and a few list intersections per elimination (the greedy choice keeps fill(v) small) where the first build recomputed
+        // the fill of every vertex with two neighbours in the clique from scratch (round 4: 19 -> 9 ms of the analysis of the 10 000-bus grid,
+        // same order bit for bit).  The members of the clique (degree, height, neighbourhood all changed) are recomputed.
         touched.clear();
-        for (int a : nb) { seen[a] = epoch; hits[a] = 2; touched.push_back(a); }
-        for (int a : nb)
-            for (int w : adj[a]) {
-                if (seen[w] != epoch) { seen[w] = epoch; hits[w] = 1; }
-                else if (hits[w] == 1) { hits[w] = 2; touched.push_back(w); }
-            }
-        for (int u : touched) { cur[u] = key(u); heap.push(Entry(cur[u], u)); }
+        for (const std::pair<int, int>& e : newedge) {
+            ++stamp;
+            for (int w : adj[e.first]) mark[w] = stamp;
+            for (int u : adj[e.second])
+                if (mark[u] == stamp && seen[u] != epoch) {
+                    fillv[u] -= 1;
+                    if (hits[u] != -epoch) { hits[u] = -epoch; touched.push_back(u); }
+                }
+        }
+        for (int u : touched) { cur[u] = key_of(u); heap.push(Entry(cur[u], u)); }
+        for (int a : nb) { cur[a] = key(a); heap.push(Entry(cur[a], a)); }
         strct[k] = std::move(nb);
     }
 }
@@ -191,13 +208,19 @@ void build_replay(const std::vector<int>& level, const std::vector<int>& work, i
         recs.reserve(est + est / 4 + 1024);
     }
     n_levels = 0;
-    for (int l = 1; l <= nlev; ++l) {
+    static const int wide_cap = getenv("JG_WIDE_WPI") ? atoi(getenv("JG_WIDE_WPI")) : 4;
+    constexpr bool has_extra = !std::is_same<Extra, NoExtra>::value;
+    int nthreads = 1;
+    if (n_items >= 4096) {
+        const int hw = (int)std::max(1u, std::min(4u, std::thread::hardware_concurrency()));
+        if (!has_extra && nlev >= 8) nthreads = hw;
+    }
+    // one level: its segments and records into `lsegs` / `lrecs` (rec_base relative to lrecs)
+    auto do_level = [&](int l, std::vector<Segment>& lsegs, std::vector<Rec>& lrecs) {
         std::vector<int>& it = by[l];
-        const size_t seg0 = segs.size();
         const bool wide = it.size() >= 2048;                      // wide levels already fill the chip: do not split short lists
         // ... and at most 4 waves share a long list there (the level that brings the bottom's terms to the top-owned entries holds
         // thousands of 20- to 70-term items: 26 112 workgroups at 8 waves per item, 139 us; 13 056 at 4, 117 us; at 2: 138 us)
-        static const int wide_cap = getenv("JG_WIDE_WPI") ? atoi(getenv("JG_WIDE_WPI")) : 4;
         auto wpi_of = [&](int i) {
             int cap = wide && work[i] <= 4 * T ? 2 : max_wpi;
             if (wide && wide_cap > 0) cap = std::min(cap, wide_cap);
@@ -218,24 +241,64 @@ void build_replay(const std::vector<int>& level, const std::vector<int>& work, i
             size_t q = p;
             while (q < it.size() && wpi_of(it[q]) == wpi) ++q;
             Segment sg{};
-            sg.rec_base = (int)recs.size(); sg.wpi = wpi; sg.level = l; sg.items = (int)(q - p);
+            sg.rec_base = (int)lrecs.size(); sg.wpi = wpi; sg.level = l; sg.items = (int)(q - p);
             const int slots = 16 / wpi;
             sg.nchunks = (sg.items + slots - 1) / slots;
             int wmax = 0;
             for (size_t x = p; x < q; ++x) wmax = std::max(wmax, work[it[x]]);
             sg.rpw = std::max(1, ((wmax + wpi - 1) / wpi + T - 1) / T);
             sg.last = 0;
-            recs.resize(recs.size() + (size_t)sg.nchunks * 16 * sg.rpw);
-            for (int c = 0; c < sg.nchunks; ++c)
-                for (int w = 0; w < 16; ++w) {
-                    const size_t idx = p + (size_t)c * slots + w / wpi;
-                    Rec* r = &recs[sg.rec_base + ((size_t)c * 16 + w) * sg.rpw];
-                    for (int j = 0; j < sg.rpw; ++j) { for (int k = 0; k < 16; ++k) r[j].w[k] = 0; r[j].w[0] = -1; }
-                    if (idx < q) fill(it[idx], w % wpi, wpi, sg.rpw, r);
-                }
-            segs.push_back(sg);
+            lrecs.resize(lrecs.size() + (size_t)sg.nchunks * 16 * sg.rpw);
+            auto chunks = [&](int c0, int c1) {
+                for (int c = c0; c < c1; ++c)
+                    for (int w = 0; w < 16; ++w) {
+                        const size_t idx = p + (size_t)c * slots + w / wpi;
+                        Rec* r = &lrecs[sg.rec_base + ((size_t)c * 16 + w) * sg.rpw];
+                        for (int j = 0; j < sg.rpw; ++j) { for (int k = 0; k < 16; ++k) r[j].w[k] = 0; r[j].w[0] = -1; }
+                        if (idx < q) fill(it[idx], w % wpi, wpi, sg.rpw, r);
+                    }
+            };
+            chunks(0, sg.nchunks);
+            lsegs.push_back(sg);
             p = q;
         }
+    };
+    const bool rtiming = getenv("JG_PLAN_TIMING") != nullptr;
+    auto rnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double r0 = rnow();
+    if (nthreads > 1) {
+        // levels are independent of each other (round 4: the analysis is what a cold power flow waits for): a few threads take them in turn,
+        // the tables are stitched together in level order -- the result is the sequential one bit for bit
+        std::vector<std::vector<Segment>> lsegs(nlev + 1);
+        std::vector<std::vector<Rec>> lrecs(nlev + 1);
+        std::atomic<int> next{1};
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; ++t)
+            pool.emplace_back([&] { for (int l = next.fetch_add(1); l <= nlev; l = next.fetch_add(1)) do_level(l, lsegs[l], lrecs[l]); });
+        for (std::thread& t : pool) t.join();
+        const double r1 = rnow();
+        size_t total = 0;
+        for (int l = 1; l <= nlev; ++l) total += lrecs[l].size();
+        recs.reserve(total);
+        for (int l = 1; l <= nlev; ++l) {
+            const int base = (int)recs.size();
+            for (Segment sg : lsegs[l]) { sg.rec_base += base; segs.push_back(sg); }
+            recs.insert(recs.end(), lrecs[l].begin(), lrecs[l].end());
+            if (!lsegs[l].empty()) { segs.back().last = 1; ++n_levels; }
+        }
+        if (rtiming) fprintf(stderr, "[jg plan]     replay of %d items, %d levels: levels %.1f ms on %d threads, stitched %.1f ms\n", n_items, nlev, r1 - r0, nthreads, rnow() - r1);
+        return;
+    }
+    for (int l = 1; l <= nlev; ++l) {
+        const size_t seg0 = segs.size();
+        std::vector<Segment> lsegs;
+        const size_t base = recs.size();
+        {
+            std::vector<Rec> lrecs;                               // (a level's records straight behind the table: one copy, as before)
+            do_level(l, lsegs, lrecs);
+            recs.insert(recs.end(), lrecs.begin(), lrecs.end());
+        }
+        for (Segment sg : lsegs) { sg.rec_base += (int)base; segs.push_back(sg); }
         extra(l, segs, recs);
         if (segs.size() > seg0) { segs.back().last = 1; ++n_levels; }
     }
@@ -700,14 +763,19 @@ void build_tables(BlockSymbolic& S) {
             if (S.fact_seg.size() > seg0) { S.fact_seg.back().last = 1; ++S.n_fact_levels; }
         }
     };
+    const bool timing = getenv("JG_PLAN_TIMING") != nullptr;
+    auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tb0 = tnow();
     std::thread fact_thread([&] {
         if (S.fact_tasks) build_fact_tasks();
         else build_replay(level, work, FACT_T, S.fact_seg, S.fact_rec, S.n_fact_levels, fill_fact, NoExtra(), 0, FACT_WAVES, locp);
+        if (timing) fprintf(stderr, "[jg plan]   factorisation tables done at %6.1f ms\n", tnow() - tb0);
     });
     struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } join_fact{fact_thread};
     // level 0 of a prefactor plan as tables of its own (for producers that deliver plain blocks): D(k) and y_k of the pivots
-    // nobody updates
+    // nobody updates -- and the forward-only tables: a thread of their own as well (round 4: the analysis is what a cold power flow waits for)
     S.pre_pivot.assign(n, 0); S.pre_seg.clear(); S.pre_rec.clear(); S.n_pre_levels = 0;
+    std::thread side_thread([&] {
     if (S.prefactor) {
         std::vector<int> plevel(nE + n, 0), pwork(nE + n, 0);
         for (int k = 0; k < n; ++k)
@@ -738,6 +806,10 @@ void build_tables(BlockSymbolic& S) {
         };
         build_replay(flevel, fwork, FACT_T, S.fwd_seg, S.fwd_rec, S.n_fwd_levels, fill_fwd, NoExtra(), 0, FACT_WAVES);
     }
+        if (timing) fprintf(stderr, "[jg plan]   pre + forward tables done at   %6.1f ms\n", tnow() - tb0);
+    });
+    Join join_side{side_thread};
+    if (timing) fprintf(stderr, "[jg plan]   term lists of the items at      %6.1f ms\n", tnow() - tb0);
     // backward sweep: chains of a supernode go to ONE workgroup each (CHAIN_MAX_ROWS), the other rows stay wave records.
     // Built once for plain rows and, in Jordan plans, once more for Jordan rows (jg_symbolic.hpp): there a pivot of a top task is a plain
     // wave-record row over the EXTERNAL columns of its task (entries w14 + i e + c), never part of a chain.
@@ -822,7 +894,9 @@ void build_tables(BlockSymbolic& S) {
     S.chain_level.assign(n, 0);
     build_bwd(false, S.bwd_seg, S.bwd_rec, S.n_bwd_levels, &S.chain_level);
     S.bwdj_seg.clear(); S.bwdj_rec.clear(); S.n_bwdj_levels = 0;
+    if (timing) fprintf(stderr, "[jg plan]   backward tables done at        %6.1f ms\n", tnow() - tb0);
     if (S.jordan) build_bwd(true, S.bwdj_seg, S.bwdj_rec, S.n_bwdj_levels, nullptr);
+    if (timing) fprintf(stderr, "[jg plan]   Jordan backward tables done at %6.1f ms\n", tnow() - tb0);
 }
 
 // Selected inverse Z = A^-1 on the pattern of the factor (Takahashi recursion, for a SYMMETRIC matrix: only the upper part
@@ -940,6 +1014,7 @@ int analyze(int n, const int* rowptr, const int* col, long long policy64, BlockS
     for (int e = 0; e < S.n_entries; ++e)
         if (S.e_row[e] > S.e_col[e]) S.e_diag[e] = S.diag[S.e_col[e]];
 
+    lap("  row patterns");
     // source positions in the caller's block CSR
     S.e_src.assign(S.n_entries, -1);
     S.src_entry.assign(rowptr[n], -1);
@@ -952,6 +1027,7 @@ int analyze(int n, const int* rowptr, const int* col, long long policy64, BlockS
             S.src_entry[p] = e;
         }
 
+    lap("  source map");
     // update terms: pivot k contributes -L(i,k) U(k,j) to every (i,j) in struct(k)^2.  The entry of (i, j) is looked up ONCE per term
     // (pivot-major list tgt: the count, the term lists and the dependency levels below all walk it) and by a merge of the sorted
     // row i with the sorted struct(k), not by a binary search per pair; lrow / urow: the entries L(s_a, k), U(k, s_a) of pivot k.
@@ -980,6 +1056,7 @@ int analyze(int n, const int* rowptr, const int* col, long long policy64, BlockS
             for (size_t a = 0; a < s.size(); ++a) { while (S.e_col[e] != s[a]) ++e; urow[sptr[k] + a] = e; }
         }
     }
+    lap("  term targets");
     S.t_ptr.assign(S.n_entries + 1, 0);
     for (int t : tgt) S.t_ptr[t + 1]++;
     for (int e = 0; e < S.n_entries; ++e) S.t_ptr[e + 1] += S.t_ptr[e];
@@ -1002,6 +1079,7 @@ int analyze(int n, const int* rowptr, const int* col, long long policy64, BlockS
         }
     }
 
+    lap("  term lists");
     // entry dependency levels (pivots ascending: all sources of pivot-k entries have smaller pivots);
     // D(k), U(k,.) and Lh(.,k) have no mutual dependency, so one level per pivot "generation"
     S.e_level.assign(S.n_entries, 0);
@@ -1026,6 +1104,7 @@ int analyze(int n, const int* rowptr, const int* col, long long policy64, BlockS
         }
     }
 
+    lap("  entry levels");
     // triangular-solve row lists and levels
     S.l_ptr.assign(n + 1, 0);
     S.u_ptr.assign(n + 1, 0);
