@@ -24,15 +24,23 @@
 #   stateEstimation!(analysis) (fused)   acStateEstimation.jl:1286-1329 -> jg_gn_run, jg_gn_get_voltage
 #   setInitialPoint!(analysis)           acStateEstimation.jl:1071      -> jg_gn_set_voltage
 #   update<Meter>!(analysis; ...)        measurement/*.jl               -> jg_gn_set_status, jg_gn_set_measurement
-#   residualTest!(analysis)  (numerics)  badData.jl:181-311             -> jg_gn_residual_test
+#   residualTest!(analysis)  (numerics)  badData.jl:181-311             -> jg_gn_residual_test, jg_gn_get_normalized_residual
+#   fastNewtonRaphsonBX/XB(system, T)    acPowerFlow.jl:215-537         -> jg_nr_create, jg_nr_fast_setup
+#   mismatch!/solve!/powerFlow! (fast)   acPowerFlow.jl:687-730, 913-983 -> jg_nr_fast_mismatch, jg_nr_fast_solve, jg_nr_fast_run, jg_nr_fast_get_increment
+#   power!(analysis), current!(analysis) postprocessing/acAnalysis.jl:30-169, 672-704 -> jg_nr_set_branches, jg_nr_bus_injection, jg_nr_branch_quantities
+#   gaussNewton(monitoring, HIPOrthogonal)  (Orthogonal / PetersWilkinson rows) acStateEstimation.jl:906-971 -> jg_gn_set_method
+#   pmuStateEstimation(monitoring, T), solve!  pmuStateEstimation.jl:43-177, 369-399 -> jg_gn_create (codes 22-27), jg_gn_increment, jg_gn_solve
+#   chiTest(analysis)                    badData.jl:948-995             -> jg_gn_evaluate, jg_gn_get_residual (se.objective)
 module JuliaGridHIP
 
 using JuliaGrid
 using SparseArrays
-import JuliaGrid: newtonRaphson, gaussNewton, mismatch!, solve!, increment!, powerFlow!, stateEstimation!, setInitialPoint!,
+import JuliaGrid: newtonRaphson, fastNewtonRaphsonBX, fastNewtonRaphsonXB, gaussNewton, pmuStateEstimation, mismatch!, solve!, increment!,
+                  powerFlow!, stateEstimation!, setInitialPoint!, power!, current!, chiTest,
                   updateBus!, updateBranch!, updateGenerator!,
                   updateVoltmeter!, updateAmmeter!, updateWattmeter!, updateVarmeter!, updatePmu!,
-                  AcPowerFlow, AcStateEstimation, NewtonRaphson, GaussNewton, PowerSystem, Measurement, LU
+                  AcPowerFlow, AcStateEstimation, PmuStateEstimation, NewtonRaphson, FastNewtonRaphson, FastNewtonRaphsonModel, GaussNewton, WLS,
+                  PowerSystem, Measurement, LU
 
 const lib = get(ENV, "JGRID_HIP_LIB", "libjgrid_hip.so")
 
@@ -44,9 +52,20 @@ is; `NewtonRaphson{T <: Union{LU, KLU, QR}}` needs its bound widened to `T <: No
 """
 struct HIP <: JuliaGrid.Normal end
 
+"""
+    HIPOrthogonal <: WlsMethod
+
+`gaussNewton(monitoring, HIPOrthogonal)` / `pmuStateEstimation(monitoring, HIPOrthogonal)`: what the `Orthogonal` and `PetersWilkinson` tags of
+the reference are for (acStateEstimation.jl:906-971: an increment whose error does not carry the squared condition number of the gain matrix), on the
+device: the corrected semi-normal equations on the factor the engine holds (`jg_gn_set_method(h, 1)`, include/jgrid.h).  Diagonal precision only, as
+in the reference (`sqrtPrecision!`).
+"""
+struct HIPOrthogonal <: JuliaGrid.WlsMethod end
+
 # The structs type their `factorization` field with the FactorSparse union; the device factor lives behind the C handle, so the
 # field keeps an (unused) LU placeholder and the handle is found through the method object.
 JuliaGrid.selectFactorization(::Type{HIP}) = JuliaGrid.selectFactorization(LU)
+JuliaGrid.selectFactorization(::Type{HIPOrthogonal}) = JuliaGrid.selectFactorization(LU)
 
 mutable struct Handle
     ptr::Ptr{Cvoid}
@@ -70,28 +89,32 @@ check(rc) = rc == 0 ? nothing :
 
 reim(z::AbstractVector{ComplexF64}) = collect(reinterpret(Float64, z))
 
+const HipTag = Union{HIP, HIPOrthogonal}
 const HipPowerFlow = AcPowerFlow{NewtonRaphson{HIP}}
-const HipStateEstimation = AcStateEstimation{GaussNewton{HIP}}
+const HipFastPowerFlow = AcPowerFlow{FastNewtonRaphson{HIP}}          # needs `FastNewtonRaphson{T <: Normal}` / `FastNewtonRaphsonModel{T <: Normal}` (INTEGRATION.md)
+const HipAnyPowerFlow = Union{HipPowerFlow, HipFastPowerFlow}
+const HipStateEstimation = Union{AcStateEstimation{GaussNewton{HIP}}, AcStateEstimation{GaussNewton{HIPOrthogonal}}}
+const HipPmuStateEstimation = Union{PmuStateEstimation{WLS{HIP}}, PmuStateEstimation{WLS{HIPOrthogonal}}}
 
 # ------------------------------------------------------------------------------------------------------------------
 # Newton-Raphson AC power flow
 # ------------------------------------------------------------------------------------------------------------------
-function pushInjection!(analysis::HipPowerFlow)
+function pushInjection!(analysis::HipAnyPowerFlow)
     bus = analysis.system.bus
     p = bus.supply.active .- bus.demand.active
     q = bus.supply.reactive .- bus.demand.reactive
     check(ccall((:jg_nr_set_injection, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64), handle(analysis), p, q, 0))
 end
 
-pushVoltage!(analysis::HipPowerFlow) =
+pushVoltage!(analysis::HipAnyPowerFlow) =
     check(ccall((:jg_nr_set_voltage, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64),
         handle(analysis), analysis.voltage.magnitude, analysis.voltage.angle, 0))
 
-pullVoltage!(analysis::HipPowerFlow) =
+pullVoltage!(analysis::HipAnyPowerFlow) =
     check(ccall((:jg_nr_get_voltage, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}),
         handle(analysis), analysis.voltage.magnitude, analysis.voltage.angle))
 
-function pushYbus!(analysis::HipPowerFlow)
+function pushYbus!(analysis::HipAnyPowerFlow)
     ac = analysis.system.model.ac
     check(ccall((:jg_nr_set_ybus, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}),
         handle(analysis), reim(ac.nodalMatrix.nzval), reim(ac.nodalMatrixTranspose.nzval)))
@@ -123,7 +146,7 @@ function newtonRaphson(system::PowerSystem, ::Type{HIP}; device::Int = 0)
     return analysis
 end
 
-function staleCheck(analysis::HipPowerFlow)                  # acPowerFlow.jl:802-811
+function staleCheck(analysis::HipAnyPowerFlow)                  # acPowerFlow.jl:802-811
     rev, sig = analysis.system.model.revision, analysis.method.signature
     (rev.topology != sig.topology || rev.type != sig.type) && JuliaGrid.errorTypeConversion()
     if sig.acPattern != -1 && rev.acPattern != sig.acPattern  # addBranch!/dropZeros! changed the Ybus pattern: new handle
@@ -171,8 +194,143 @@ function powerFlow!(analysis::HipPowerFlow; iteration::Int64 = 20, tolerance::Fl
     check(ccall((:jg_nr_get_increment, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), handle(analysis), analysis.method.increment))
     analysis.method.iteration = iters[1]
     status[1] == 3 && throw(ErrorException("The Jacobian is singular."))        # SingularException of the reference's lu!
-    power && JuliaGrid.power!(analysis)
-    current && JuliaGrid.current!(analysis)
+    power && power!(analysis)
+    current && current!(analysis)
+    return nothing
+end
+
+# ---- fast Newton-Raphson BX / XB (acPowerFlow.jl:215-537): the two constant matrices go to the device as values per stored Ybus entry and
+# ---- are factorised there once; an iteration is two forward / backward sweeps on the device
+function fastModel(system::PowerSystem, bx::Bool, device::Int)
+    base = bx ? fastNewtonRaphsonBX(system, LU) : fastNewtonRaphsonXB(system, LU)     # B', B'', numbering, start point: the reference's own set-up
+    m = base.method
+    act = FastNewtonRaphsonModel{HIP}(m.active.jacobian, m.active.mismatch, m.active.increment, JuliaGrid.selectFactorization(HIP))
+    rea = FastNewtonRaphsonModel{HIP}(m.reactive.jacobian, m.reactive.mismatch, m.reactive.increment, JuliaGrid.selectFactorization(HIP))
+    method = FastNewtonRaphson{HIP}(act, rea, m.pq, m.pvpq, m.signature, bx, 0)
+    analysis = AcPowerFlow(base.voltage, base.power, base.current, method, system)
+    ac, bus = system.model.ac, system.bus
+    Y = ac.nodalMatrix
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:jg_nr_create, lib), Cint,
+        (Ref{Ptr{Cvoid}}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int8}, Int64, Int64, Int64, Cint),
+        h, bus.number, Y.colptr, Y.rowval, reim(Y.nzval), reim(ac.nodalMatrixTranspose.nzval), bus.layout.type, bus.layout.slack, 1, 0, device))
+    HANDLES[method] = Handle(h[], :nr)
+    pushFast!(analysis)
+    pushInjection!(analysis)
+    pushVoltage!(analysis)
+    return analysis
+end
+
+"B'[pvpq r, pvpq c] and B''[pq r, pq c] at every stored Ybus entry (r, c); identity on the diagonal / zero elsewhere outside the reduced matrices"
+function pushFast!(analysis::HipFastPowerFlow)
+    system, m = analysis.system, analysis.method
+    Y, typ, slack = system.model.ac.nodalMatrix, system.bus.layout.type, system.bus.layout.slack
+    bp = zeros(nnz(Y)); bq = zeros(nnz(Y))
+    for c = 1:system.bus.number, p = Y.colptr[c]:(Y.colptr[c + 1] - 1)
+        r = Y.rowval[p]
+        bp[p] = (typ[r] != 3 && c != slack) ? m.active.jacobian[m.pvpq[r], m.pvpq[c]] : (r == c ? 1.0 : 0.0)
+        bq[p] = (typ[r] == 1 && typ[c] == 1) ? m.reactive.jacobian[m.pq[r], m.pq[c]] : (r == c ? 1.0 : 0.0)
+    end
+    check(ccall((:jg_nr_fast_setup, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), handle(analysis), bp, bq))
+end
+
+fastNewtonRaphsonBX(system::PowerSystem, ::Type{HIP}; device::Int = 0) = fastModel(system, true, device)
+fastNewtonRaphsonXB(system::PowerSystem, ::Type{HIP}; device::Int = 0) = fastModel(system, false, device)
+
+function mismatch!(analysis::HipFastPowerFlow)               # acPowerFlow.jl:687-730
+    m = analysis.method
+    maxp = Ref(0.0); maxq = Ref(0.0)
+    check(ccall((:jg_nr_fast_mismatch, lib), Cint, (Ptr{Cvoid}, Ref{Float64}, Ref{Float64}), handle(analysis), maxp, maxq))
+    both = Vector{Float64}(undef, length(m.active.mismatch) + length(m.reactive.mismatch))       # [active.mismatch | reactive.mismatch]
+    check(ccall((:jg_nr_get_mismatch, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), handle(analysis), both))
+    m.active.mismatch .= view(both, 1:length(m.active.mismatch))
+    m.reactive.mismatch .= view(both, (length(m.active.mismatch) + 1):length(both))
+    return maxp[], maxq[]
+end
+
+function pullFastIncrement!(analysis::HipFastPowerFlow)
+    m = analysis.method
+    both = Vector{Float64}(undef, length(m.active.increment) + length(m.reactive.increment))     # [active.increment | reactive.increment]
+    check(ccall((:jg_nr_fast_get_increment, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), handle(analysis), both))
+    m.active.increment .= view(both, 1:length(m.active.increment))
+    m.reactive.increment .= view(both, (length(m.active.increment) + 1):length(both))
+end
+
+function solve!(analysis::HipFastPowerFlow)                  # acPowerFlow.jl:913-983
+    staleCheck(analysis)
+    check(ccall((:jg_nr_fast_solve, lib), Cint, (Ptr{Cvoid},), handle(analysis)))
+    pullFastIncrement!(analysis)
+    pullVoltage!(analysis)
+    analysis.method.iteration += 1
+    return nothing
+end
+
+function powerFlow!(analysis::HipFastPowerFlow; iteration::Int64 = 20, tolerance::Float64 = 1e-8, power::Bool = false,
+                    current::Bool = false, verbose::Int64 = 0)
+    staleCheck(analysis)
+    iters = Vector{Int32}(undef, 1); status = Vector{Int32}(undef, 1)
+    check(ccall((:jg_nr_fast_run, lib), Cint, (Ptr{Cvoid}, Int64, Float64, Ptr{Int32}, Ptr{Int32}),
+        handle(analysis), iteration, tolerance, iters, status))
+    pullVoltage!(analysis)
+    pullFastIncrement!(analysis)
+    analysis.method.iteration = iters[1]
+    status[1] == 3 && throw(ErrorException("The Jacobian is singular."))
+    power && power!(analysis)
+    current && current!(analysis)
+    return nothing
+end
+
+# ---- power!(analysis) / current!(analysis) (postprocessing/acAnalysis.jl:30-169, 672-704): the Ybus row walk (injections) and the branch formulas run on
+# ---- the device at the state the handle holds; the O(n) bus / generator bookkeeping is the reference's own (its power! runs first, the device
+# ---- quantities then replace what it computed for injections and branches)
+const BRANCHES = WeakKeyDict{Any, Bool}()                    # analysis.method -> the branch table is on the device
+
+function pushBranches!(analysis::HipAnyPowerFlow)
+    get(BRANCHES, analysis.method, false) && return
+    system = analysis.system
+    ac, br = system.model.ac, system.branch
+    nb = br.number
+    param = zeros(16, nb)                                     # [nb][16] row-major (jgrid.h: jg_nr_set_branches)
+    for k = 1:nb
+        tij = (1.0 / br.parameter.turnsRatio[k]) * cis(-br.parameter.shiftAngle[k])      # acAnalysis.jl:846-851
+        for (c, z) in enumerate((ac.nodalFromFrom[k], ac.nodalFromTo[k], ac.nodalToFrom[k], ac.nodalToTo[k], ac.admittance[k], tij))
+            param[2c - 1, k] = real(z); param[2c, k] = imag(z)
+        end
+        param[13, k] = br.parameter.conductance[k]; param[14, k] = br.parameter.susceptance[k]; param[15, k] = 1.0 / br.parameter.turnsRatio[k]
+    end
+    check(ccall((:jg_nr_set_branches, lib), Cint, (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Int8}, Ptr{Float64}),
+        handle(analysis), nb, br.layout.from, br.layout.to, Int8.(br.layout.status), param))
+    BRANCHES[analysis.method] = true
+end
+
+function power!(analysis::HipAnyPowerFlow)
+    invoke(power!, Tuple{AcPowerFlow}, analysis)              # containers, shunt, supply, generator allocation: the reference's bookkeeping
+    pushBranches!(analysis)
+    n, nb, pw = analysis.system.bus.number, analysis.system.branch.number, analysis.power
+    inj = Matrix{Float64}(undef, 2, n)                        # [n][2] row-major
+    check(ccall((:jg_nr_bus_injection, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), handle(analysis), inj))
+    pw.injection.active .= view(inj, 1, :); pw.injection.reactive .= view(inj, 2, :)
+    from = Matrix{Float64}(undef, 2, nb); to = similar(from); series = similar(from); charging = similar(from)
+    check(ccall((:jg_nr_branch_quantities, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        handle(analysis), from, to, series, charging, C_NULL, C_NULL, C_NULL))
+    for (dst, src) in ((pw.from, from), (pw.to, to), (pw.series, series), (pw.charging, charging))
+        dst.active .= view(src, 1, :); dst.reactive .= view(src, 2, :)
+    end
+    return nothing
+end
+
+function current!(analysis::HipAnyPowerFlow)
+    invoke(current!, Tuple{JuliaGrid.AC}, analysis)           # containers + injection currents (O(n) from the injections)
+    pushBranches!(analysis)
+    nb, cu = analysis.system.branch.number, analysis.current
+    from = Matrix{Float64}(undef, 2, nb); to = similar(from); series = similar(from)
+    check(ccall((:jg_nr_branch_quantities, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        handle(analysis), C_NULL, C_NULL, C_NULL, C_NULL, from, to, series))
+    for (dst, src) in ((cu.from, from), (cu.to, to), (cu.series, series))
+        dst.magnitude .= view(src, 1, :); dst.angle .= view(src, 2, :)
+    end
     return nothing
 end
 
@@ -195,6 +353,7 @@ end
 function updateBranch!(analysis::HipPowerFlow; label, kwargs...)        # branch.jl:453-459 (pattern kept: stored zeros, model.jl:70-71)
     invoke(updateBranch!, Tuple{JuliaGrid.PowerFlow}, analysis; label, kwargs...)
     pushYbus!(analysis)
+    delete!(BRANCHES, analysis.method)                                  # the branch table of power! / current! goes up again on the next call
 end
 
 function updateGenerator!(analysis::HipPowerFlow; label, kwargs...)     # generator.jl:382-388
@@ -218,6 +377,7 @@ mutable struct NewtonRaphsonBatch
     angle::Matrix{Float64}
     iteration::Vector{Int32}
     status::Vector{Int32}                          # 0 converged, 1 iteration limit, 3 numeric failure (singular Jacobian / NaN)
+    outage::Vector{Int64}                          # branch out of service per scenario (0: none), for branchQuantities
 end
 
 function NewtonRaphsonBatch(system::PowerSystem, batch::Int; device::Int = 0, maxPatch::Int = 4)
@@ -229,7 +389,7 @@ function NewtonRaphsonBatch(system::PowerSystem, batch::Int; device::Int = 0, ma
         h, system.bus.number, ac.nodalMatrix.colptr, ac.nodalMatrix.rowval, reim(ac.nodalMatrix.nzval),
         reim(ac.nodalMatrixTranspose.nzval), system.bus.layout.type, system.bus.layout.slack, batch, maxPatch, device))
     b = NewtonRaphsonBatch(system, batch, Handle(h[], :nr), zeros(system.bus.number, batch), zeros(system.bus.number, batch),
-        zeros(Int32, batch), zeros(Int32, batch))
+        zeros(Int32, batch), zeros(Int32, batch), zeros(Int64, batch))
     bus = system.bus
     check(ccall((:jg_nr_set_injection, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64), b.handle.ptr,
         bus.supply.active .- bus.demand.active, bus.supply.reactive .- bus.demand.reactive, 0))
@@ -263,6 +423,8 @@ function setOutages!(b::NewtonRaphsonBatch, labels::Vector{Int64})
     end
     check(ccall((:jg_nr_patch_ybus_batch, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Float64}),
         b.handle.ptr, 0, b.batch, 4, ptr, dy))
+    b.outage .= labels
+    return nothing
 end
 
 function powerFlow!(b::NewtonRaphsonBatch; iteration::Int64 = 20, tolerance::Float64 = 1e-8)
@@ -271,6 +433,40 @@ function powerFlow!(b::NewtonRaphsonBatch; iteration::Int64 = 20, tolerance::Flo
     check(ccall((:jg_nr_get_voltage, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}),
         b.handle.ptr, b.magnitude, b.angle))                                     # [batch][n] row-major = [n, batch] column-major
     return nothing
+end
+
+"""
+    branchQuantities(batch; currents = false) -> (from, to, series, charging) | (from, to, series)
+
+`power!` / `current!` of the branches for EVERY scenario of the batch at its current state (acAnalysis.jl:898-931), each `[2, nb, batch]`
+(active | reactive resp. magnitude | angle); the branch that is out of service in a scenario (`setOutages!`) reads zero there.
+"""
+function branchQuantities(b::NewtonRaphsonBatch; currents::Bool = false)
+    system = b.system
+    ac, br = system.model.ac, system.branch
+    nb = br.number
+    param = zeros(16, nb)
+    for k = 1:nb
+        tij = (1.0 / br.parameter.turnsRatio[k]) * cis(-br.parameter.shiftAngle[k])
+        for (c, z) in enumerate((ac.nodalFromFrom[k], ac.nodalFromTo[k], ac.nodalToFrom[k], ac.nodalToTo[k], ac.admittance[k], tij))
+            param[2c - 1, k] = real(z); param[2c, k] = imag(z)
+        end
+        param[13, k] = br.parameter.conductance[k]; param[14, k] = br.parameter.susceptance[k]; param[15, k] = 1.0 / br.parameter.turnsRatio[k]
+    end
+    check(ccall((:jg_nr_set_branches, lib), Cint, (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Int8}, Ptr{Float64}),
+        b.handle.ptr, nb, br.layout.from, br.layout.to, Int8.(br.layout.status), param))
+    check(ccall((:jg_nr_set_outage_labels, lib), Cint, (Ptr{Cvoid}, Ptr{Int64}), b.handle.ptr, b.outage))
+    out = [Array{Float64}(undef, 2, nb, b.batch) for _ = 1:(currents ? 3 : 4)]
+    if currents
+        check(ccall((:jg_nr_branch_quantities, lib), Cint,
+            (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+            b.handle.ptr, C_NULL, C_NULL, C_NULL, C_NULL, out[1], out[2], out[3]))
+    else
+        check(ccall((:jg_nr_branch_quantities, lib), Cint,
+            (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+            b.handle.ptr, out[1], out[2], out[3], out[4], C_NULL, C_NULL, C_NULL))
+    end
+    return Tuple(out)
 end
 
 # ---- straggler hand-off between batches (jgrid.h: jg_nr_run_defer ...): a pipeline of batches stops a batch once <= deferAt
@@ -377,10 +573,10 @@ pullVoltage!(analysis::HipStateEstimation) =
 `gaussNewton(monitoring, LU)` of the reference builds the model (acWLS: type, index, range, mean, precision, Jacobian pattern);
 the device gets what acWLS derived, row by row, and rebuilds pattern, gain pattern and symbolic analysis from it.
 """
-function gaussNewton(monitoring::Measurement, ::Type{HIP}; device::Int = 0)
+function gaussNewton(monitoring::Measurement, ::Type{T}; device::Int = 0) where {T <: HipTag}
     base = gaussNewton(monitoring, LU)
     m = base.method
-    method = GaussNewton{HIP}(m.jacobian, m.precision, m.mean, m.residual, m.increment, JuliaGrid.selectFactorization(HIP),
+    method = GaussNewton{T}(m.jacobian, m.precision, m.mean, m.residual, m.increment, JuliaGrid.selectFactorization(T),
         m.type, m.index, m.range, m.signature, 0.0, 0)
     system = monitoring.system
     analysis = AcStateEstimation(base.voltage, base.power, base.current, method, system, monitoring)
@@ -399,17 +595,28 @@ function gaussNewton(monitoring::Measurement, ::Type{HIP}; device::Int = 0)
         reim(ac.nodalMatrixTranspose.nzval), br.number, br.layout.from, br.layout.to, param,
         system.bus.layout.slack, length(code), code, status, m.index, length(corr), isempty(corr) ? Int64[0] : corr, 1, device))
     HANDLES[method] = Handle(h[], :gn)
+    if T === HIPOrthogonal                                                # the Orthogonal / PetersWilkinson rows: corrected semi-normal equations;
+        check(ccall((:jg_gn_set_method, lib), Cint, (Ptr{Cvoid}, Cint), h[], 1))   # returns 1 (-> ErrorException) on correlated PMUs, like the reference
+    end
     pushMeasurement!(analysis)
     pushVoltage!(analysis)
     return analysis
 end
 
-function increment!(analysis::HipStateEstimation)             # acStateEstimation.jl:878-904
+"se.residual from the device and se.objective = r' W r (equations.jl:689-698: what chiTest reads, badData.jl:948-961)"
+function pullResidual!(analysis::HipStateEstimation)
+    se = analysis.method
+    check(ccall((:jg_gn_get_residual, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), handle(analysis), se.residual))
+    se.objective = transpose(se.residual) * (se.precision * se.residual)
+    return nothing
+end
+
+function increment!(analysis::HipStateEstimation)             # acStateEstimation.jl:878-904 (HIPOrthogonal: :906-971)
     se = analysis.method
     maxInc = Vector{Float64}(undef, 1)
     check(ccall((:jg_gn_increment, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), handle(analysis), maxInc))   # code 3: singular gain
     check(ccall((:jg_gn_get_increment, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), handle(analysis), se.increment))
-    check(ccall((:jg_gn_get_residual, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), handle(analysis), se.residual))
+    pullResidual!(analysis)
     se.signature[:pattern] = 0
     return maxInc[1]
 end
@@ -440,10 +647,90 @@ function stateEstimation!(analysis::HipStateEstimation; iteration::Int64 = 40, t
         handle(analysis), iteration, tolerance, iters, status))
     pullVoltage!(analysis)
     check(ccall((:jg_gn_get_increment, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), handle(analysis), se.increment))
-    check(ccall((:jg_gn_get_residual, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), handle(analysis), se.residual))
+    pullResidual!(analysis)
     se.iteration = iters[1]
     se.signature[:pattern] = 0
     status[1] == 3 && throw(ErrorException("The gain matrix is singular."))
+    power && JuliaGrid.power!(analysis)
+    current && JuliaGrid.current!(analysis)
+    return nothing
+end
+
+"""
+    chiTest(analysis::AcStateEstimation{GaussNewton{HIP}}; confidence = 0.95)
+
+badData.jl:948-961 reads `se.objective`; here the residual (and with it the objective) is first re-evaluated on the device AT THE CURRENT STATE
+(`jg_gn_evaluate`: after the last `solve!` the device holds the residual of the state before that step), then the reference's own test runs.
+"""
+function chiTest(analysis::HipStateEstimation; confidence::Float64 = 0.95)
+    check(ccall((:jg_gn_evaluate, lib), Cint, (Ptr{Cvoid},), handle(analysis)))
+    pullResidual!(analysis)
+    return invoke(chiTest, Tuple{AcStateEstimation{<:GaussNewton}}, analysis; confidence)
+end
+
+"all normalised residuals of the last largestNormalizedResidual / residualTest! call (badData.jl:289-311), one per Jacobian row"
+function normalizedResiduals(analysis::HipStateEstimation)
+    out = Vector{Float64}(undef, length(analysis.method.mean))
+    check(ccall((:jg_gn_get_normalized_residual, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), handle(analysis), out))
+    return out
+end
+
+# ---- pmuStateEstimation(monitoring, HIP) (pmuStateEstimation.jl:43-177): the LINEAR model z = H [Re V; Im V] + u.  The device runs it as one
+# ---- Gauss-Newton step of linear rows (type codes 22-27, no slack) from the zero state: gain H' W H, block LU, solve (:369-399)
+function pmuStateEstimation(monitoring::Measurement, ::Type{T}; device::Int = 0) where {T <: HipTag}
+    base = pmuStateEstimation(monitoring, LU)                  # coefficient, precision, mean, inservice: the reference's pmuEstimationWls
+    m = base.method
+    method = WLS{T}(m.coefficient, m.precision, m.mean, JuliaGrid.selectFactorization(T), m.index, m.number, m.inservice, m.signature)
+    system, pmu = monitoring.system, monitoring.pmu
+    analysis = PmuStateEstimation(base.voltage, base.power, base.current, method, system, monitoring)
+    ac, br = system.model.ac, system.branch
+    code = Int8[]; status = Int8[]; index = Int64[]; corr = Int64[]
+    for i = 1:pmu.number                                       # two rows (Re, Im) per device, in device order
+        pmu.layout.correlated[i] && push!(corr, length(code) + 1)
+        append!(code, pmu.layout.bus[i] ? (22, 23) : (pmu.layout.from[i] ? (24, 25) : (26, 27)))
+        on = Int8(pmu.magnitude.status[i] * pmu.angle.status[i])
+        append!(status, (on, on)); append!(index, (pmu.layout.index[i], pmu.layout.index[i]))
+    end
+    T === HIPOrthogonal && !isempty(corr) && throw(ErrorException("A non-diagonal precision matrix prevents the use of the select method."))
+    param = Matrix{Float64}(undef, 6, br.number)
+    for k = 1:br.number
+        param[:, k] .= (real(ac.admittance[k]), imag(ac.admittance[k]), br.parameter.conductance[k],
+                        br.parameter.susceptance[k], br.parameter.turnsRatio[k], br.parameter.shiftAngle[k])
+    end
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:jg_gn_create, lib), Cint,
+        (Ref{Ptr{Cvoid}}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64},
+         Int64, Int64, Ptr{Int8}, Ptr{Int8}, Ptr{Int64}, Int64, Ptr{Int64}, Int64, Cint),
+        h, system.bus.number, ac.nodalMatrix.colptr, ac.nodalMatrix.rowval, reim(ac.nodalMatrix.nzval),
+        reim(ac.nodalMatrixTranspose.nzval), br.number, br.layout.from, br.layout.to, param,
+        0, length(code), code, status, index, length(corr), isempty(corr) ? Int64[0] : corr, 1, device))     # slack = 0: every variable is estimated
+    HANDLES[method] = Handle(h[], :gn)
+    T === HIPOrthogonal && check(ccall((:jg_gn_set_method, lib), Cint, (Ptr{Cvoid}, Cint), h[], 1))
+    W = method.precision
+    wdiag = [W[r, r] for r = 1:length(method.mean)]
+    woff = Float64[W[r, r + 1] for r in corr]
+    check(ccall((:jg_gn_set_measurement, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Int64),
+        h[], method.mean, wdiag, isempty(woff) ? [0.0] : woff, 0, 0))
+    return analysis
+end
+
+function solve!(analysis::HipPmuStateEstimation)              # pmuStateEstimation.jl:369-399
+    n = analysis.system.bus.number
+    zero = zeros(n)
+    check(ccall((:jg_gn_set_voltage, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64), handle(analysis), zero, zero, 0))
+    maxInc = Vector{Float64}(undef, 1)
+    check(ccall((:jg_gn_increment, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), handle(analysis), maxInc))    # residual = z at the zero state: H'WH, H'Wz
+    check(ccall((:jg_gn_solve, lib), Cint, (Ptr{Cvoid},), handle(analysis)))
+    im = Vector{Float64}(undef, n); re = Vector{Float64}(undef, n)
+    check(ccall((:jg_gn_get_voltage, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), handle(analysis), im, re))   # the state arrays hold (Im V, Re V)
+    resize!(analysis.voltage.magnitude, n); resize!(analysis.voltage.angle, n)
+    analysis.voltage.magnitude .= hypot.(re, im)
+    analysis.voltage.angle .= atan.(im, re)
+    return nothing
+end
+
+function stateEstimation!(analysis::HipPmuStateEstimation; power::Bool = false, current::Bool = false, verbose::Int64 = 0)
+    solve!(analysis)
     power && JuliaGrid.power!(analysis)
     current && JuliaGrid.current!(analysis)
     return nothing
@@ -535,7 +822,110 @@ end
 "drops the library's cached symbolic analyses (live analyses keep theirs): the next newtonRaphson(system, HIP) pays a full analysis again"
 clearPlanCache() = ccall((:jg_plan_cache_clear, lib), Cvoid, ())
 
-export HIP, NewtonRaphsonBatch, setOutages!, powerFlowDefer!, moveLanes!, finish!, resume!, jacobian!, largestNormalizedResidual,
-       commUniqueId, Comm, shard, contingencyAnalysis, clearPlanCache
+# ---- the rest of the ABI: sizes, maps, device-resident start points and records, the optional guard (include/jgrid.h) -------------------------
+"number of HIP devices the library sees"
+deviceCount() = Int(ccall((:jg_device_count, lib), Cint, ()))
+
+"(dimJ, nnz(J), blocks of L + D + U, update terms, launches per factorisation, launches per backward sweep)"
+function dims(analysis::HipAnyPowerFlow)
+    d = Vector{Int64}(undef, 6)
+    check(ccall((:jg_nr_dims, lib), Cint, (Ptr{Cvoid}, Ptr{Int64}), handle(analysis), d))
+    return d
+end
+"(m, nnz(H), gain blocks, blocks of L + D + U, update terms, factor launches, backward launches, H slots)"
+function dims(analysis::Union{HipStateEstimation, HipPmuStateEstimation})
+    d = Vector{Int64}(undef, 8)
+    check(ccall((:jg_gn_dims, lib), Cint, (Ptr{Cvoid}, Ptr{Int64}), handle(analysis), d))
+    return d
+end
+
+"one step of iterative refinement behind every Newton step (what UMFPACK's solve does behind ldiv!, utility.jl:576-586); off by default"
+setRefinement!(analysis::HipPowerFlow, on::Bool = true) =
+    check(ccall((:jg_nr_set_refine, lib), Cint, (Ptr{Cvoid}, Cint), handle(analysis), on ? 1 : 0))
+
+"pq, pvpq, pcount and the CSC pattern of the Jacobian as the DEVICE built them (bit-exact copies of newtonJacobian's, acPowerFlow.jl:89-175)"
+function deviceMaps(analysis::HipPowerFlow)
+    n, d = analysis.system.bus.number, dims(analysis)
+    pq = Vector{Int64}(undef, n); pvpq = Vector{Int64}(undef, n); pcount = Vector{Int64}(undef, n)
+    colptr = Vector{Int64}(undef, d[1] + 1); rowval = Vector{Int64}(undef, d[2])
+    check(ccall((:jg_nr_get_maps, lib), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}),
+        handle(analysis), pq, pvpq, pcount, colptr, rowval))
+    return pq, pvpq, pcount, colptr, rowval
+end
+"se.type and the CSC pattern of H as the device built them (bit-exact copies of acWLS's, acStateEstimation.jl:77-259)"
+function deviceMaps(analysis::HipStateEstimation)
+    d = dims(analysis)
+    type = Vector{Int8}(undef, d[1]); colptr = Vector{Int64}(undef, 2 * analysis.system.bus.number + 1); rowval = Vector{Int64}(undef, d[2])
+    check(ccall((:jg_gn_get_maps, lib), Cint, (Ptr{Cvoid}, Ptr{Int8}, Ptr{Int64}, Ptr{Int64}), handle(analysis), type, colptr, rowval))
+    return type, colptr, rowval
+end
+
+"scenario s (1-based) of a batch: branch `label` out of service (0: back to the base grid) -- the four edits acNodalUpdate! makes, model.jl:93-101"
+function setOutage!(b::NewtonRaphsonBatch, s::Int, label::Int64)
+    ac, Y, lay = b.system.model.ac, b.system.model.ac.nodalMatrix, b.system.branch.layout
+    position(r, c) = Y.colptr[c] + searchsortedfirst(view(Y.rowval, Y.colptr[c]:(Y.colptr[c + 1] - 1)), r) - 1
+    ptr = zeros(Int64, 4); dy = zeros(Float64, 2, 4)
+    if label != 0
+        i, j = lay.from[label], lay.to[label]
+        ptr .= (position(i, i), position(j, j), position(i, j), position(j, i))
+        for (m, v) in enumerate((ac.nodalFromFrom[label], ac.nodalToTo[label], ac.nodalFromTo[label], ac.nodalToFrom[label]))
+            dy[1, m], dy[2, m] = -real(v), -imag(v)
+        end
+    end
+    check(ccall((:jg_nr_patch_ybus, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Float64}), b.handle.ptr, s - 1, label == 0 ? 0 : 4, ptr, dy))
+    b.outage[s] = label
+    return nothing
+end
+
+"keeps the current voltages of every scenario inside HBM / brings them back (the start point of a Monte-Carlo or benchmark loop without a PCIe round trip)"
+snapshotVoltage!(b::NewtonRaphsonBatch) = check(ccall((:jg_nr_snapshot_voltage, lib), Cint, (Ptr{Cvoid},), b.handle.ptr))
+restoreVoltage!(b::NewtonRaphsonBatch) = check(ccall((:jg_nr_restore_voltage, lib), Cint, (Ptr{Cvoid},), b.handle.ptr))
+snapshotVoltage!(analysis::HipStateEstimation) = check(ccall((:jg_gn_snapshot_voltage, lib), Cint, (Ptr{Cvoid},), handle(analysis)))
+restoreVoltage!(analysis::HipStateEstimation) = check(ccall((:jg_gn_restore_voltage, lib), Cint, (Ptr{Cvoid},), handle(analysis)))
+
+"method.iteration of every scenario, straight from the device"
+function iterations(b::NewtonRaphsonBatch)
+    check(ccall((:jg_nr_get_iteration, lib), Cint, (Ptr{Cvoid}, Ptr{Int32}), b.handle.ptr, b.iteration))
+    return b.iteration
+end
+function iterations(analysis::HipStateEstimation)
+    it = Vector{Int32}(undef, 1)
+    check(ccall((:jg_gn_get_iteration, lib), Cint, (Ptr{Cvoid}, Ptr{Int32}), handle(analysis), it))
+    return Int(it[1])
+end
+
+"V and theta of every scenario into DEVICE buffers of the caller ([n, batch] each, e.g. AMDGPU.jl arrays: pass their pointers)"
+voltageDevice!(b::NewtonRaphsonBatch, magnitude::Ptr{Float64}, angle::Ptr{Float64}) =
+    check(ccall((:jg_nr_get_voltage_device, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), b.handle.ptr, magnitude, angle))
+"the result record of the batch (V | theta | iterations | status per scenario, [2n + 2, batch]) into a DEVICE buffer of the caller: the operand of the one gather"
+packResults!(b::NewtonRaphsonBatch, record::Ptr{Float64}) =
+    check(ccall((:jg_nr_pack_results_device, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), b.handle.ptr, record))
+"rows `rows` (0-based) of a record another batch owns <- lanes lane0 + 1 : lane0 + length(rows) of this pool (jg_nr_pack_rows_device)"
+packRows!(pool::NewtonRaphsonBatch, record::Ptr{Float64}, lane0::Int, rows::Vector{Int32}) =
+    check(ccall((:jg_nr_pack_rows_device, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Int32}), pool.handle.ptr, record, lane0, length(rows), rows))
+
+"the collective for a record that is already packed: `count` doubles per rank from device pointer `send` into `recv` [count, world]"
+allgatherDevice(comm::Comm, send::Ptr{Float64}, recv::Ptr{Float64}, count::Int) =
+    check(ccall((:jg_comm_allgather_device, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64), comm.ptr, send, recv, count))
+commRank(comm::Comm) = Int(ccall((:jg_comm_rank, lib), Cint, (Ptr{Cvoid},), comm.ptr))
+commWorld(comm::Comm) = Int(ccall((:jg_comm_world, lib), Cint, (Ptr{Cvoid},), comm.ptr))
+
+"mean milliseconds of `reps` executions of one kernel group on the handle's stream (HIP events): 0 assembly, 1 factorisation, 2 backward sweep, 3 branch post-processing"
+function timeKernel(analysis::HipAnyPowerFlow, kernel::Int, reps::Int = 10)
+    ms = Ref(0.0)
+    check(ccall((:jg_nr_time_kernel, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ref{Float64}), handle(analysis), kernel, reps, ms))
+    return ms[]
+end
+"... of a state estimation: 0 measurement rows, 1 gain + rhs gather, 2 factorisation, 3 backward sweep, 4 selected inverse"
+function timeKernel(analysis::HipStateEstimation, kernel::Int, reps::Int = 10)
+    ms = Ref(0.0)
+    check(ccall((:jg_gn_time_kernel, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ref{Float64}), handle(analysis), kernel, reps, ms))
+    return ms[]
+end
+
+export HIP, HIPOrthogonal, NewtonRaphsonBatch, setOutages!, shareDevice!, branchQuantities, powerFlowDefer!, moveLanes!, finish!, resume!, jacobian!,
+       largestNormalizedResidual, normalizedResiduals, commUniqueId, Comm, shard, contingencyAnalysis, clearPlanCache,
+       deviceCount, dims, setRefinement!, deviceMaps, setOutage!, snapshotVoltage!, restoreVoltage!, iterations, voltageDevice!, packResults!, packRows!,
+       allgatherDevice, commRank, commWorld, timeKernel
 
 end # module
