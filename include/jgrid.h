@@ -291,7 +291,8 @@ int jg_gn_time_kernel(jg_gn* h, int kernel, int reps, double* mean_ms);
  *                      into block `rank` of dst_dev [world x batch][2 n + 2] (device memory of the caller) and gathers in place on
  *                      the handle's stream; every rank must call it with the same batch.  Returns after the stream has drained.
  *   jg_comm_allgather_device  the same collective for a record that is already packed (a ContingencyPipeline fills its records
- *                      itself): count doubles per rank, recv_dev [world][count]; send_dev may be recv_dev + rank * count.
+ *                      itself): count doubles per rank, recv_dev [world][count]; send_dev may be recv_dev + rank * count.  The gather runs on the
+ *                      communicator's own stream: whatever produced send_dev must have been synchronised before the call; it returns when done.
  * librccl is bound at run time on the first call (csrc/jg_comm.cpp); return code 2 with jg_last_error() when it is missing.
  * ------------------------------------------------------------------------------------------- */
 #define JG_COMM_ID_BYTES 128

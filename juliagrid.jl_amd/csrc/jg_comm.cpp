@@ -7,7 +7,18 @@
 // copy that is already mapped wins (RTLD_NOLOAD first), exactly as for the HIP runtime.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+
+// The five entry points of RCCL this file binds, declared here (the library is bound at run time so that a host without RCCL can still
+// run single-GPU analyses -- a hard #include <rccl/rccl.h> made the BUILD depend on its headers all the same).  The ABI of these has been stable
+// since NCCL 2.0: an opaque communicator pointer, a 128-byte id passed by value, int-sized enums (ncclSuccess = 0; ncclFloat64 = ncclDouble = 8).
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+}
+static const ncclResult_t ncclSuccess = 0;
+static const ncclDataType_t ncclDouble = 8;
 
 #include <cstring>
 #include <mutex>
@@ -102,6 +113,9 @@ void jg_comm_destroy(jg_comm* c) {
 int jg_comm_rank(const jg_comm* c) { return c ? c->rank : -1; }
 int jg_comm_world(const jg_comm* c) { return c ? c->world : -1; }
 
+// Precondition: the collective runs on the communicator's PRIVATE stream, which is not ordered against whatever stream produced
+// send_dev -- the producer must have been synchronised (a ContingencyPipeline's record is complete, and its stream synchronised, before on_done
+// hands it over; jg_nr_allgather_results needs no such care: it gathers on the handle's own stream).  The call returns after the gather has completed.
 int jg_comm_allgather_device(jg_comm* c, const double* send_dev, double* recv_dev, int64_t count) {
     if (!c || !send_dev || !recv_dev || count < 1) return failc(1, "jg_comm_allgather_device: bad argument");
     if (hipSetDevice(c->device) != hipSuccess) return failc(2, "jg_comm_allgather_device: device");

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <mutex>
 
 namespace jg {
@@ -1342,6 +1343,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                     if ((cd >> 28) & 2) { const double s = v.v01; v.v01 = v.v10; v.v10 = s; }        // symmetric plans: Lh(i,c) = U(c,i)'
                 }
                 T[r][c] = v;
+                // pivot guard (as in k_fact_top): what a pivot is compared with is its block as it ENTERED the task, before the children's
+                // update matrices come in -- taken after the extend-add the reference scale of an island's root was the cancelled value itself
+                const int i = (r << lt) + gi, j = (c << lt) + gj;
+                if (i == j && i < m) *(double2*)(Dref + (size_t)((i << lg) + g) * 2) = row_max(v);
             }
     }
     if (prof) pt[1] = wall_clock64();
@@ -1378,10 +1383,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             const int i = (r << lt) + gi, j = (c << lt) + gj;
             if (i == 0) lds_set(Ubuf[0], (j << lg) + g, j > 0 ? T[r][c] : zero_blk());
             if (j == 0) lds_set(Lbuf[0], (i << lg) + g, i > 0 ? T[r][c] : zero_blk());
-            if (i == j && i < m) *(double2*)(Dref + (size_t)((i << lg) + g) * 2) = row_max(T[r][c]);
         }
     if (gi == 0 && gj == 0) {
-        const Blk d0 = factor_diag(T[0][0], bad, row_max(T[0][0]));
+        const Blk d0 = factor_diag(T[0][0], bad, *(const double2*)(Dref + (size_t)g * 2));      // (written by this very thread in the load loop)
         lds_set(Dbuf[0], g, d0);
         T[0][0] = d0;
     }
@@ -1505,8 +1509,12 @@ SharedPlan::~SharedPlan() {
 }
 
 namespace {
-std::mutex g_plan_mutex;
-std::vector<std::shared_ptr<SharedPlan>> g_plans;            // most recently used last
+//  The cache is a deliberately LEAKED heap object: idle plans would otherwise be destroyed -- ~17 hipFree each -- during static
+// destruction at process exit or dlclose, when the HIP runtime (torch ships its own copy; unload order is not ours) may already be gone.
+std::mutex& plan_mutex() { static std::mutex* m = new std::mutex(); return *m; }
+std::vector<std::shared_ptr<SharedPlan>>& plans() { static auto* v = new std::vector<std::shared_ptr<SharedPlan>>(); return *v; }   // most recently used last
+#define g_plan_mutex plan_mutex()
+#define g_plans plans()
 constexpr size_t PLAN_CACHE_KEEP = 6;                        // plans without a live engine that the cache keeps around on its own
 
 unsigned long long pattern_hash(int n, const int* rowptr, const int* col, long long policy, int device) {
@@ -1531,18 +1539,40 @@ std::shared_ptr<SharedPlan> acquire_plan(int n, const int* rowptr, const int* co
     if (n <= 0 || !rowptr || !col || rowptr[0] != 0) { error = "block pattern must be structurally symmetric with a full diagonal"; rc = 1; return nullptr; }
     static const bool nocache = getenv("JG_PLAN_CACHE") && atoi(getenv("JG_PLAN_CACHE")) == 0;
     const unsigned long long h = pattern_hash(n, rowptr, col, policy, device);
-    std::lock_guard<std::mutex> lock(g_plan_mutex);            // one analysis at a time: a second handle of the same grid waits, then hits
-    if (!nocache)
-        for (size_t i = 0; i < g_plans.size(); ++i) {
-            const std::shared_ptr<SharedPlan>& p = g_plans[i];
-            if (p->key_hash == h && p->device == device && p->policy == policy && p->S.n == n && (int)p->key_col.size() == rowptr[n] &&
-                std::equal(rowptr, rowptr + n + 1, p->key_rowptr.begin()) && std::equal(col, col + rowptr[n], p->key_col.begin())) {
-                std::shared_ptr<SharedPlan> hit = p;
-                g_plans.erase(g_plans.begin() + i);
-                g_plans.push_back(hit);
-                return hit;
+    //  The lock covers the look-up and the publication, NOT the analysis: creates of different patterns (other grids, other devices, other
+    // threads) run side by side; a second handle of the SAME key waits for the first one's analysis, then hits.
+    struct Pending { unsigned long long hash; long long policy; int device, n; };
+    static std::vector<Pending>* pending = new std::vector<Pending>();
+    static std::condition_variable* pending_cv = new std::condition_variable();
+    auto is_pending = [&] { for (const Pending& q : *pending) if (q.hash == h && q.policy == policy && q.device == device && q.n == n) return true; return false; };
+    std::unique_lock<std::mutex> lock(g_plan_mutex);
+    for (;;) {
+        if (!nocache)
+            for (size_t i = 0; i < g_plans.size(); ++i) {
+                const std::shared_ptr<SharedPlan>& p = g_plans[i];
+                if (p->key_hash == h && p->device == device && p->policy == policy && p->S.n == n && (int)p->key_col.size() == rowptr[n] &&
+                    std::equal(rowptr, rowptr + n + 1, p->key_rowptr.begin()) && std::equal(col, col + rowptr[n], p->key_col.begin())) {
+                    std::shared_ptr<SharedPlan> hit = p;
+                    g_plans.erase(g_plans.begin() + i);
+                    g_plans.push_back(hit);
+                    return hit;
+                }
             }
+        if (nocache || !is_pending()) break;
+        pending_cv->wait(lock);
+    }
+    if (!nocache) pending->push_back(Pending{h, policy, device, n});
+    lock.unlock();
+    struct Done {                                                // whatever way the analysis ends: the key is no longer pending
+        std::unique_lock<std::mutex>& lock; std::vector<Pending>* pending; std::condition_variable* cv; unsigned long long h; long long policy; int device, n; bool armed;
+        ~Done() {
+            if (!armed) return;
+            if (!lock.owns_lock()) lock.lock();
+            for (size_t i = 0; i < pending->size(); ++i)
+                if ((*pending)[i].hash == h && (*pending)[i].policy == policy && (*pending)[i].device == device && (*pending)[i].n == n) { pending->erase(pending->begin() + i); break; }
+            cv->notify_all();
         }
+    } done{lock, pending, pending_cv, h, policy, device, n, !nocache};
     std::shared_ptr<SharedPlan> p = std::make_shared<SharedPlan>();
     if (analyze(n, rowptr, col, policy, p->S)) { error = "block pattern must be structurally symmetric with a full diagonal"; rc = 1; return nullptr; }
     p->device = device; p->policy = policy; p->key_hash = h;
@@ -1560,6 +1590,7 @@ std::shared_ptr<SharedPlan> acquire_plan(int n, const int* rowptr, const int* co
         return nullptr;
     }
     if (!nocache) {
+        lock.lock();
         g_plans.push_back(p);
         size_t idle = 0;                                         // plans nobody else uses leave first, oldest first
         for (const auto& q : g_plans) if (q.use_count() == 1) ++idle;
@@ -1758,7 +1789,10 @@ int Engine::selected_inverse(hipStream_t st, const GroupSel& sel) {
             std::lock_guard<std::mutex> lock(plan->sel_mutex);
             if (!plan->sel_ready) {
                 build_selected_inverse(plan->S);
-                if (upload(&plan->sel_rec, plan->S.sel_rec, error, st) || upload(&plan->sel_seg, plan->S.sel_seg, error, st)) return 2;
+                if (upload(&plan->sel_rec, plan->S.sel_rec, error, st) || upload(&plan->sel_seg, plan->S.sel_seg, error, st)) {
+                    hipFree(plan->sel_rec); hipFree(plan->sel_seg); plan->sel_rec = nullptr; plan->sel_seg = nullptr;   // a retry starts clean
+                    return 2;
+                }
                 plan->sel_ready = true;
             }
         }
