@@ -543,9 +543,11 @@ def main():
         # group of 10 backward sweeps -- must not become the per-launch figure)
         def timed(kernel, reps):
             return float(np.median([an.time_kernel(kernel, reps) for _ in range(5)]))
-        t_asm = timed(0, 8)
-        t_lu = timed(1, 4)
-        t_sol = timed(2, 4)
+        # (repetitions: the first launches of a group run on a chip that has just been idle -- 4 / 8 / 20 assemblies per group measure
+        # 0.156 / 0.144 / 0.137 ms per launch on the same handle; the groups are long enough that this start-up does not set the figure)
+        t_asm = timed(0, 24)
+        t_lu = timed(1, 8)
+        t_sol = timed(2, 12)
         kern = {
             "assembly": {"ms": t_asm, "bytes": ab["assembly"], "launches": 1},
             "lu": {"ms": t_lu, "bytes": ab["lu"], "launches": d["lu_launches"]},

@@ -1,16 +1,19 @@
 #!/usr/bin/env python3
 """Per-launch L2-miss traffic of ONE factorisation from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE):
-python tools/pmc_levels.py <fetch_csv> <write_csv> [which factorisation, default 1 (0 = the first)]
+python tools/pmc_levels.py <fetch_csv> <write_csv> [which factorisation, default 1 (0 = the first)] [separator kernel, default k_assemble; k_gn_gain for the gain]
 FETCH_SIZE in KiB x 2 (gfx950 half-count, profiles/README.md), WRITE_SIZE in KiB."""
 import csv, sys
+
+
+SEP = sys.argv[4] if len(sys.argv) > 4 else "k_assemble"
 
 
 def load(path):
     rows = []
     for r in csv.DictReader(open(path)):
         n = r["Kernel_Name"]
-        if "k_fact_level" in n or "k_fact_task" in n or "k_fact_top" in n or "k_assemble" in n:
-            rows.append((int(r["Dispatch_Id"]), "asm" if "k_assemble" in n else ("top" if "k_fact_top" in n else "lvl"), float(r["Counter_Value"]),
+        if "k_fact_level" in n or "k_fact_task" in n or "k_fact_top" in n or SEP in n:
+            rows.append((int(r["Dispatch_Id"]), "asm" if SEP in n else ("top" if "k_fact_top" in n else "lvl"), float(r["Counter_Value"]),
                          int(r["Grid_Size"]) // int(r["Workgroup_Size"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     rows.sort()
     # cut into factorisations: an assembly launch separates them

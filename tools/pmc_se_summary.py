@@ -18,7 +18,7 @@ def load(path):
 
 
 def short(name):
-    for k in ("k_gn_rows", "k_gn_gain", "k_gn_norm", "k_gn_update", "k_gn_check", "k_fact_level", "k_fact_top", "k_bwd_level"):
+    for k in ("k_gn_rows", "k_gn_gain", "k_gn_norm", "k_gn_update", "k_gn_check", "k_fact_level", "k_fact_task", "k_fact_top", "k_bwd_level"):
         if k in name:
             return k
     return None
