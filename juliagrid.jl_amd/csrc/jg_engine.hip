@@ -79,11 +79,7 @@ __device__ __forceinline__ int rec_word(const RecS& r, int k) { return r[k]; }
 // operands of a record arrived one term after the other (rocprof, round 4; cdna_hip_programming.md lists the same trap).  Requests written this way
 // go out back to back; ONE s_waitcnt, tied to the destination registers by its operands, stands before the first use.  The compiler does not count
 // these loads: its own waits can only come earlier than needed (loads return in order), never later.
-typedef double d2v __attribute__((ext_vector_type(2)));
-struct BlkV { d2v r0, r1; };
-__device__ __forceinline__ void gload16(d2v& dst, const void* base, unsigned off) {
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory");   // "memory": the compiler must not move its stores across (the waits count them)
-}
+// (d2v, BlkV, gload16, gload8: jg_engine.hpp)
 
 // one record of a factorisation item: up to FACT_T update terms, every operand requested before the first use (nothing in the request loop
 // uses a loaded value: the transposition of a symmetric plan's operand is a select at the point of use; a rhs row's 2-vector is requested like a
@@ -108,7 +104,7 @@ __device__ __forceinline__ void fact_record(const FactArgs& a, const RecS& r, in
             gload16(u[t].r0, pu, off); gload16(u[t].r1, pu + uhalf, off);
         }
     }
-    if (nt > 0) {
+    {                                                            // (unconditional: a wait behind a second test of the count is a path no static check can follow)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("" : "+v"(l[0].r0), "+v"(l[0].r1), "+v"(d[0].r0), "+v"(d[0].r1), "+v"(u[0].r0), "+v"(u[0].r1),
                           "+v"(l[1].r0), "+v"(l[1].r1), "+v"(d[1].r0), "+v"(d[1].r1), "+v"(u[1].r0), "+v"(u[1].r1));
@@ -519,7 +515,7 @@ __device__ __forceinline__ void sel_record(const SelArgs& a, const RecS& r, size
             gload16(z[q].r0, pz, off); gload16(z[q].r1, pz + ld * 16, off);
         }
     }
-    if (nt > 0) {
+    {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("" : "+v"(u[0].r0), "+v"(u[0].r1), "+v"(z[0].r0), "+v"(z[0].r1), "+v"(u[1].r0), "+v"(u[1].r1), "+v"(z[1].r0), "+v"(z[1].r1),
                           "+v"(u[2].r0), "+v"(u[2].r1), "+v"(z[2].r0), "+v"(z[2].r1));
@@ -680,34 +676,19 @@ constexpr int TASK_LDS_D2 = (TASK_SLOTS + TASK_WAVES) * 128;
 // the destination registers of one load as address registers of the next and drains the queue before each address computation: rocprof showed a task's
 // six operands arriving in six consecutive round trips; the wave records of k_fact_level suffer from the same thing in pairs).  The compiler does not count
 // these loads: its own waits can only be earlier than needed (loads return in order), never later.
-// Every request of the wave has arrived.  `stores`: store instructions that were issued AFTER those requests and may stay in flight (the results
-// of the previous round leave behind the next round's requests: loads and stores share the counter and complete in order, so waiting for the
-// loads of a round must not mean waiting for the stores of the round before).  A lower bound is safe, a larger count is not.
-__device__ __forceinline__ void task_wait_all(BlkV (&m)[TASK_T], BlkV& own, int stores) {
+// Every request of the wave has arrived: ONE wait, tied to the destination registers by the operands of an instruction-less statement (volatile
+// statements keep their order; nothing that uses the values is scheduled ahead of the wait).  Counted waits -- vmcnt(n) that leave the stores of the
+// previous round or the operands behind the staging loads in flight -- were built and measured against this: 1.150 / 1.153 against 1.146 / 1.153 ms
+// per factorisation, no difference, and a count that depends on the path taken cannot be checked statically (tools/check_asm_loads.py).
+__device__ __forceinline__ void task_wait_all(BlkV (&m)[TASK_T], BlkV& own) {
     static_assert(TASK_T == 6, "operand list of the wait");
-    switch (stores) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    }
-    // no instruction: ties the values to the wait (volatile statements keep their order; nothing that uses them is scheduled ahead of it)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("" : "+v"(m[0].r0), "+v"(m[0].r1), "+v"(m[1].r0), "+v"(m[1].r1), "+v"(m[2].r0), "+v"(m[2].r1),
                       "+v"(m[3].r0), "+v"(m[3].r1), "+v"(m[4].r0), "+v"(m[4].r1), "+v"(m[5].r0), "+v"(m[5].r1), "+v"(own.r0), "+v"(own.r1));
 }
-// the staging operands have arrived, the `later` requests issued after them (the record's memory operands) may still be in flight
-__device__ __forceinline__ void task_wait_stage(BlkV (&A)[TASK_STAGE], BlkV (&D)[TASK_STAGE], int later) {
+__device__ __forceinline__ void task_wait_stage(BlkV (&A)[TASK_STAGE], BlkV (&D)[TASK_STAGE]) {
     static_assert(TASK_STAGE == 2, "operand list of the wait");
-    switch (later) {                                             // (the count is an immediate of the instruction)
-        case 0: asm volatile("s_waitcnt vmcnt(0)"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)"); break;
-        case 10: asm volatile("s_waitcnt vmcnt(10)"); break;
-        default: asm volatile("s_waitcnt vmcnt(12)"); break;
-    }
-    // no instruction: ties the values to the waits above (volatile statements keep their order; with the operands on every case the compiler
-    // copied all sixteen registers in each of them)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("" : "+v"(A[0].r0), "+v"(A[0].r1), "+v"(A[1].r0), "+v"(A[1].r1), "+v"(D[0].r0), "+v"(D[0].r1), "+v"(D[1].r0), "+v"(D[1].r1));
 }
 
@@ -715,10 +696,10 @@ __device__ __forceinline__ void task_wait_stage(BlkV (&A)[TASK_STAGE], BlkV (&D)
 // dst, lane offset, scalar base`, back to back -- and waited for with ONE `s_waitcnt` before the first use.  Left to the compiler, every operand's pair
 // of loads was fenced by waits of its own (it reuses the destination registers of one load as address registers of the next and drains the queue before
 // each address computation: a task's six operands arrived in six consecutive round trips; the wave records of k_fact_level suffer from the same thing in
-// pairs).  Returns the number of requests it issued for memory operands.
-__device__ __forceinline__ int task_issue(const FactArgs& a, const RecS& q, size_t b, size_t ld, BlkV& own, BlkV (&m)[TASK_T]) {
+// pairs).
+__device__ __forceinline__ void task_issue(const FactArgs& a, const RecS& q, size_t b, size_t ld, BlkV& own, BlkV (&m)[TASK_T]) {
     const int h = rec_word(q, 0), kind = h & TK_KIND;
-    if (kind == 7) return 0;
+    if (kind == 7) return;
     const unsigned off = (unsigned)b * 16u;
     if ((h & TK_FIRST) && ((h >> 8) & 7) == 0 && rec_word(q, 2) >= 0) {   // the owner starts from the item's block / rhs row (a rhs row: the second half re-reads the first)
         const int src = rec_word(q, 2);
@@ -729,7 +710,7 @@ __device__ __forceinline__ int task_issue(const FactArgs& a, const RecS& q, size
 #pragma unroll
     for (int t = 0; t < TASK_T; ++t) asm volatile("" : "=v"(m[t].r0), "=v"(m[t].r1));   // no instruction: what the registers held before this record is dead
                                                                                           // (else the compiler carries -- and copies -- it for the operands the record does not have)
-    if (h & TK_DIRECT) return 0;
+    if (h & TK_DIRECT) return;
     const int nt = rec_word(q, 3) & 0xff;
     // one code path for blocks and for the 2-vectors of a rhs row: no branch per load
     const char* const src = kind == 3 ? (const char*)a.W : (const char*)a.X;
@@ -741,17 +722,16 @@ __device__ __forceinline__ int task_issue(const FactArgs& a, const RecS& q, size
             gload16(m[t].r0, p, off);
             gload16(m[t].r1, p + half, off);
         }
-    return 2 * nt;
 }
 
 // the arithmetic of a record (after its requests have arrived); returns true if the wave has an item to finish (task_finish)
 __device__ __forceinline__ bool task_consume(const FactArgs& a, const RecS& q, size_t b, size_t ld, int wave, int lane, const double2* slots, double2* scratch,
-                                             Blk& c, BlkV& own, BlkV (&m)[TASK_T], int stores, double2& ref) {
+                                             Blk& c, BlkV& own, BlkV (&m)[TASK_T], double2& ref) {
     const int h = rec_word(q, 0), kind = h & TK_KIND, sub = (h >> 8) & 7, wpi = (h >> 12) & 15;
     const bool last = (h & TK_LAST) != 0;
+    task_wait_all(m, own);                                       // every request of the record has arrived (unconditional: idle records wait for nothing)
     if (kind != 7) {
         const int nt = rec_word(q, 3) & 0xff;
-        task_wait_all(m, own, stores);                           // every request of the record has arrived
         if (h & TK_FIRST) {
             if (sub == 0 && rec_word(q, 2) >= 0) c = Blk{own.r0.x, own.r0.y, own.r1.x, own.r1.y};
             else c = Blk{0.0, 0.0, 0.0, 0.0};
@@ -896,32 +876,28 @@ __global__ __launch_bounds__(64 * TASK_WAVES, 4) void k_fact_task(FactArgs a) {
 #pragma unroll
         for (int u = 0; u < TASK_STAGE; ++u) asm volatile("" : "=v"(A[u].r0), "=v"(A[u].r1), "=v"(D[u].r0), "=v"(D[u].r1));
         task_stage_issue(a, r, b, ld, A, D);
-        const int later = task_issue(a, r, b, ld, own, m);
-        task_wait_stage(A, D, later);
+        task_issue(a, r, b, ld, own, m);                         // the round's own operands travel with the staging loads: ONE round trip
+        task_wait_stage(A, D);
         task_stage_write(r, lane, slots, A, D);
         for (int i = 1; i < spw; ++i) {                          // tasks of more than 16 slots (rare): the next batch once the registers are free
             const RecS s = i == 1 ? nxt : load_rec(a.rec, ri + i);
             task_stage_issue(a, s, b, ld, A, D);
-            task_wait_stage(A, D, 0);
+            task_wait_stage(A, D);
             task_stage_write(s, lane, slots, A, D);
         }
         __syncthreads();
     }
-    // Rounds, software-pipelined by one: the requests of round j + 1 are issued BEFORE the results of round j are stored, so the wait of round j + 1
-    // leaves those stores in flight (stores = how many were issued behind the requests: 2 per block, 1 per rhs row, at least).
-    int stores = 0;
     for (int j = 0; j < rpw; ++j) {
         double2 ref{0.0, 0.0};
-        const bool fin = task_consume(a, r, b, ld, wave, lane, slots, scratch, c, own, m, stores, ref);
+        const bool fin = task_consume(a, r, b, ld, wave, lane, slots, scratch, c, own, m, ref);
         const int kind = rec_word(r, 0) & TK_KIND, id = rec_word(r, 1);
-        if (j + 1 < rpw) {
+        if (j + 1 < rpw) {                                       // the next round's requests leave before this round's result is factorised and stored
             const RecS cur = nxt;
             if (j + 2 < rpw) nxt = load_rec(a.rec, ri + j + 2);
             task_issue(a, cur, b, ld, own, m);
             r = cur;
         }
-        stores = 0;
-        if (fin) { fact_finish(a, kind, id, b, ld, c, ref); stores = kind == 3 ? 1 : 2; }
+        if (fin) fact_finish(a, kind, id, b, ld, c, ref);
     }
 }
 

@@ -103,6 +103,17 @@ __device__ __forceinline__ void store_vec(double* base, size_t item, size_t b, s
     *(double2*)((char*)base + item * ld * 16 + (unsigned)b * 16u) = double2{v0, v1};
 }
 
+// Hand-placed requests (jg_engine.hip: fact_record explains why): `global_load_dwordx4 / x2  dst, lane offset, scalar base`.  The base must be
+// wave-uniform (it lands in a scalar register pair); the caller waits with an explicit s_waitcnt tied to the destinations.
+typedef double d2v __attribute__((ext_vector_type(2)));
+struct BlkV { d2v r0, r1; };
+__device__ __forceinline__ void gload16(d2v& dst, const void* base, unsigned off) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory");   // "memory": the compiler must not move its stores across (the waits count them)
+}
+__device__ __forceinline__ void gload8(double& dst, const void* base, unsigned off) {
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory");
+}
+
 // A diagonal block whose eliminated form is smaller than PIVOT_EPS x (largest entry ITS ROW of the block started from) marks the
 // scenario (status bit 2 -> per-scenario status 3): a block that cancelled to rounding level is the signature of a structurally
 // singular matrix (an islanding outage) under a static pivot order.  Row-wise because a gain block mixes |V|- and theta-scaled rows.

@@ -261,25 +261,53 @@ __global__ __launch_bounds__(256) void k_gn_gain(GainArgs a) {
         if (r + 1 < r1) nxt = ((GRecPtr)a.rec)[r + 1];
         const int head = cur[0], n = cur[2];
         const bool is_rhs = head & 1;
-        double wt[GAIN_T], x0[GAIN_T], x1[GAIN_T], y0[GAIN_T], y1[GAIN_T];
+        // Hand-placed requests, one wait (jg_engine.hpp: gload16; round 4).  The first build chose between three kinds of load per term behind
+        // run-time branches -- residual row, second slot, or none where both slots are the same -- and hipcc waited for every single load before
+        // it requested the next one (rocprof ISA: `global_load ...; s_waitcnt vmcnt(0)` per operand): a record's operands arrived one by one.
+        static_assert(GAIN_T == 4, "operand list of the wait");
+        double wt[GAIN_T], yr[GAIN_T];
+        jg::d2v xa[GAIN_T], xb[GAIN_T];
+        const unsigned off8 = (unsigned)b * 8u, off16 = (unsigned)b * 16u;
 #pragma unroll
         for (int t = 0; t < GAIN_T; ++t) {
-            if (t < n) {
-                wt[t] = a.w[(size_t)cur[4 + 3 * t] * ld + b];
-                const double2 pa = jg::load_vec(a.Hs, (size_t)cur[5 + 3 * t], b, ld);
-                x0[t] = pa.x; x1[t] = pa.y;
-                if (is_rhs) { y0[t] = a.res[(size_t)cur[6 + 3 * t] * ld + b]; y1[t] = 0.0; }
-                else if (cur[6 + 3 * t] == cur[5 + 3 * t]) { y0[t] = pa.x; y1[t] = pa.y; }     // diagonal blocks: the same slot on both sides (half of all block terms)
-                else { const double2 pb = jg::load_vec(a.Hs, (size_t)cur[6 + 3 * t], b, ld); y0[t] = pb.x; y1[t] = pb.y; }
-            }
+            // ONE statement per term, its three kinds of right-hand operand behind SCALAR branches inside it (mode 0: the same slot on both sides -- half of
+            // all block terms --, 1: a residual, 2: a second slot): every destination is defined by exactly one statement on every path.  With the
+            // choice written as C++ branches around separate requests the compiler merged the alternatives into one register tuple and COPIED a
+            // register whose load was still in flight (tools/check_asm_loads.py found it; the pmu case of tests/test_se_gpu.py failed on it).
+            const int mode = t < n ? (is_rhs ? 1 : (cur[6 + 3 * t] != cur[5 + 3 * t] ? 2 : 0)) : 3;
+            const char* pw = (const char*)a.w + (size_t)cur[4 + 3 * t] * ld * 8;
+            const char* px = (const char*)a.Hs + (size_t)cur[5 + 3 * t] * ld * 16;
+            const char* py = (mode == 1 ? (const char*)a.res + (size_t)cur[6 + 3 * t] * ld * 8 : (const char*)a.Hs + (size_t)cur[6 + 3 * t] * ld * 16);
+            asm volatile("s_cmp_eq_u32 %9, 3\n\t"
+                         "s_cbranch_scc1 2f\n\t"
+                         "global_load_dwordx2 %0, %4, %6\n\t"
+                         "global_load_dwordx4 %1, %5, %7\n\t"
+                         "s_cmp_eq_u32 %9, 0\n\t"
+                         "s_cbranch_scc1 2f\n\t"
+                         "s_cmp_eq_u32 %9, 1\n\t"
+                         "s_cbranch_scc1 1f\n\t"
+                         "global_load_dwordx4 %3, %5, %8\n\t"
+                         "s_branch 2f\n"
+                         "1:\n\t"
+                         "global_load_dwordx2 %2, %4, %8\n"
+                         "2:"
+                         : "=v"(wt[t]), "=v"(xa[t]), "=v"(yr[t]), "=v"(xb[t])
+                         : "v"(off8), "v"(off16), "s"(pw), "s"(px), "s"(py), "s"(mode)
+                         : "memory", "scc");
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" : "+v"(wt[0]), "+v"(yr[0]), "+v"(xa[0]), "+v"(xb[0]), "+v"(wt[1]), "+v"(yr[1]), "+v"(xa[1]), "+v"(xb[1]),
+                          "+v"(wt[2]), "+v"(yr[2]), "+v"(xa[2]), "+v"(xb[2]), "+v"(wt[3]), "+v"(yr[3]), "+v"(xa[3]), "+v"(xb[3]));
 #pragma unroll
         for (int t = 0; t < GAIN_T; ++t) {
             if (t < n) {
-                if (is_rhs) { const double rr = wt[t] * y0[t]; g00 += x0[t] * rr; g01 += x1[t] * rr; }
+                const double x0 = xa[t].x, x1 = xa[t].y;
+                if (is_rhs) { const double rr = wt[t] * yr[t]; g00 += x0 * rr; g01 += x1 * rr; }
                 else {
-                    const double at = wt[t] * x0[t], av = wt[t] * x1[t];
-                    g00 += at * y0[t]; g01 += at * y1[t]; g10 += av * y0[t]; g11 += av * y1[t];
+                    const bool same = cur[6 + 3 * t] == cur[5 + 3 * t];
+                    const double y0 = same ? x0 : xb[t].x, y1 = same ? x1 : xb[t].y;
+                    const double at = wt[t] * x0, av = wt[t] * x1;
+                    g00 += at * y0; g01 += at * y1; g10 += av * y0; g11 += av * y1;
                 }
             }
         }
@@ -338,17 +366,26 @@ __global__ __launch_bounds__(64 * GAIN_LDS_WAVES, 2) void k_gn_gain_lds(GainLdsA
     GRecS cur = ((GRecPtr)a.rec)[r];                                             // the wave's first record travels while the images are staged (the table ends with a pad record)
     constexpr int SU = 8;                                                        // independent slot loads per wave and trip
     for (int e0 = wave * SU; e0 < n_stage; e0 += GAIN_LDS_WAVES * SU) {
-        i4 d[SU]; double2 hv[SU]; double wt[SU];
+        static_assert(SU == 8, "operand list of the wait");
+        i4 d[SU]; jg::d2v hv[SU]; double wt[SU];
 #pragma unroll
-        for (int u = 0; u < SU; ++u) if (e0 + u < n_stage) {
-            d[u] = st[e0 + u];
-            hv[u] = jg::load_vec(a.Hs, (size_t)d[u][0], b, ld);
-            wt[u] = d[u][1] >= 0 ? a.w[(size_t)d[u][1] * ld + b] : 0.0;
+        for (int u = 0; u < SU; ++u) d[u] = st[min(e0 + u, n_stage - 1)];          // the stage entries first (scalar loads, all in flight together)
+#pragma unroll
+        for (int u = 0; u < SU; ++u) asm volatile("" : "=v"(hv[u]), "=v"(wt[u]));
+        const unsigned off8 = (unsigned)b * 8u, off16 = (unsigned)b * 16u;
+#pragma unroll
+        for (int u = 0; u < SU; ++u) if (e0 + u < n_stage) {                        // hand-placed requests, one wait (jg_engine.hpp: gload16)
+            jg::gload16(hv[u], (const char*)a.Hs + (size_t)d[u][0] * ld * 16, off16);
+            if (d[u][1] >= 0) jg::gload8(wt[u], (const char*)a.w + (size_t)d[u][1] * ld * 8, off8);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" : "+v"(hv[0]), "+v"(wt[0]), "+v"(hv[1]), "+v"(wt[1]), "+v"(hv[2]), "+v"(wt[2]), "+v"(hv[3]), "+v"(wt[3]),
+                          "+v"(hv[4]), "+v"(wt[4]), "+v"(hv[5]), "+v"(wt[5]), "+v"(hv[6]), "+v"(wt[6]), "+v"(hv[7]), "+v"(wt[7]));
 #pragma unroll
         for (int u = 0; u < SU; ++u) if (e0 + u < n_stage) {
-            if (d[u][3] >= 0) img[d[u][3] * 64 + lane] = hv[u];
-            if (d[u][2] >= 0) img[d[u][2] * 64 + lane] = double2{wt[u] * hv[u].x, wt[u] * hv[u].y};
+            const double w = d[u][1] >= 0 ? wt[u] : 0.0;
+            if (d[u][3] >= 0) img[d[u][3] * 64 + lane] = double2{hv[u].x, hv[u].y};
+            if (d[u][2] >= 0) img[d[u][2] * 64 + lane] = double2{w * hv[u].x, w * hv[u].y};
         }
     }
     __syncthreads();

@@ -276,8 +276,12 @@ def test_staged_and_direct_gain_gather_agree(jg, oracle, monkeypatch, budget):
         out[mode] = (inc, an.voltage.magnitude.copy(), an.voltage.angle.copy())
         an.close()
     scale = max(1.0, np.abs(out["0"][0]).max())
-    for mode in ("80", budget):          # the increment to the tolerance the oracle parity uses, the converged estimate to 1e-8
-        assert np.abs(out[mode][0] - out["0"][0]).max() <= 1e-8 * scale
+    for mode in ("80", budget):          # the converged estimate to 1e-8; the first increment from the flat start to cond(gain) x eps: the two gathers add
+        # the same terms in another association (w h' * h against w * h' h), and on this gain matrix (cond ~ 1e11, tests/test_se_scale_gpu.py) a last-bit
+        # difference of an entry moves the increment by cond x eps (measured 6e-5 here, 2e-5 .. 7e-5 device against oracle in test_se_scale_gpu.py, whose
+        # bound of 1e-3 this takes over) -- round 3 asked for 1e-8 and passed only while both paths happened to round alike
+        d = np.abs(out[mode][0] - out["0"][0]).max()
+        assert d <= 1e-3 * scale, (mode, d)
         assert np.abs(out[mode][1] - out["0"][1]).max() <= 1e-8 and np.abs(out[mode][2] - out["0"][2]).max() <= 1e-8
 
 
