@@ -469,6 +469,30 @@ function branchQuantities(b::NewtonRaphsonBatch; currents::Bool = false)
     return Tuple(out)
 end
 
+"""
+    screenSummary(batch; rating = nothing, record = nothing) -> Matrix [10, batch]
+
+Contingency screen summary on the device (jgrid.h: jg_nr_screen): per scenario the worst branch loading against `rating` (pu of apparent power per branch,
+0 = no limit) and its branch, the largest apparent power at a branch end and its branch, the lowest / highest voltage magnitude and their buses,
+iterations, status -- what the user loop of branch.jl:453-459 reads off power!(analysis) after every powerFlow!, reduced where the states are.
+`record`: a DEVICE pointer for `10 * batch` doubles instead (the operand of `allgatherDevice` in a sharded screen).
+"""
+function screenSummary(b::NewtonRaphsonBatch; rating::Union{Nothing, Vector{Float64}} = nothing, record::Union{Nothing, Ptr{Float64}} = nothing)
+    branchQuantities(b; currents = true)                      # uploads the branch table and the outage labels (and is cheap: three outputs)
+    if rating === nothing
+        check(ccall((:jg_nr_set_screen, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), b.handle.ptr, C_NULL))
+    else
+        check(ccall((:jg_nr_set_screen, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), b.handle.ptr, rating))
+    end
+    if record !== nothing
+        check(ccall((:jg_nr_screen_device, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), b.handle.ptr, record))
+        return nothing
+    end
+    rec = Matrix{Float64}(undef, 10, b.batch)
+    check(ccall((:jg_nr_screen, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), b.handle.ptr, rec))
+    return rec
+end
+
 # ---- straggler hand-off between batches (jgrid.h: jg_nr_run_defer ...): a pipeline of batches stops a batch once <= deferAt
 # scenarios are active, moves them into a POOL batch that collects the stragglers of several batches, and finishes them together
 # (what ContingencyPipeline(pool = ...) does on the Python side; a Julia driver runs batches from Threads.@spawn tasks).
@@ -923,7 +947,7 @@ function timeKernel(analysis::HipStateEstimation, kernel::Int, reps::Int = 10)
     return ms[]
 end
 
-export HIP, HIPOrthogonal, NewtonRaphsonBatch, setOutages!, shareDevice!, branchQuantities, powerFlowDefer!, moveLanes!, finish!, resume!, jacobian!,
+export HIP, HIPOrthogonal, NewtonRaphsonBatch, setOutages!, shareDevice!, branchQuantities, screenSummary, powerFlowDefer!, moveLanes!, finish!, resume!, jacobian!,
        largestNormalizedResidual, normalizedResiduals, commUniqueId, Comm, shard, contingencyAnalysis, clearPlanCache,
        deviceCount, dims, setRefinement!, deviceMaps, setOutage!, snapshotVoltage!, restoreVoltage!, iterations, voltageDevice!, packResults!, packRows!,
        allgatherDevice, commRank, commWorld, timeKernel

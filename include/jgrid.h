@@ -192,6 +192,22 @@ int jg_nr_branch_quantities(jg_nr* h, double* from_pq, double* to_pq, double* se
                             double* from_i, double* to_i, double* series_i);
 int jg_nr_bus_injection(jg_nr* h, double* inj_pq);
 
+/*
+ * Contingency screen summary on the device (the next widening of the path) -- what a user of the reference reads off power!(analysis)
+ * after every powerFlow! of the outage loop (src/powerSystem/branch.jl:453-459 + postprocessing/acAnalysis.jl:30-169), reduced per scenario so that
+ * a sharded screen gathers 10 doubles per scenario instead of its 2 n + 2 state record.  For every scenario at its CURRENT state:
+ *   rec[b][0] worst loading  max_k max(|S_ij|, |S_ji|) / rating[k]  over the in-service branches with rating[k] > 0 (0 if none), rec[b][1] its branch (1-based, 0: none)
+ *   rec[b][2] largest apparent power at a branch end max(|S_ij|, |S_ji|) (pu; PijQij / PjiQji, :898-904), rec[b][3] its branch
+ *   rec[b][4] lowest voltage magnitude, rec[b][5] its bus (1-based); rec[b][6] highest, rec[b][7] its bus
+ *   rec[b][8] method.iteration, rec[b][9] status (0 converged, 1 iteration limit, 3 numeric failure) of the last jg_nr_run
+ * Ties go to the lowest index.  The branch that is out of service in a scenario (jg_nr_set_outage_labels) does not count there.
+ * jg_nr_set_screen: rating [nb] in pu of apparent power (branch.flow.maxFromBus / maxToBus of type 2, src/powerSystem/branch.jl:29-37), 0 = no limit, NULL = none;
+ *   needs jg_nr_set_branches.  jg_nr_screen: rec [batch][10] to the host; jg_nr_screen_device: into a device buffer (the operand of jg_comm_allgather_device).
+ */
+int jg_nr_set_screen(jg_nr* h, const double* rating);
+int jg_nr_screen(jg_nr* h, double* rec);
+int jg_nr_screen_device(jg_nr* h, double* rec_dev);
+
 /* Measurement hooks (HIP events on the handle's own stream).
  * kernel: 0 fused mismatch+Jacobian assembly, 1 LU refactorization + fused forward elimination (all
  * launches), 2 backward sweep (no state update), 3 power!/current! branch kernel (all outputs).  Returns the mean

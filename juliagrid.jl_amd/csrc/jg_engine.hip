@@ -1486,7 +1486,7 @@ SharedPlan::~SharedPlan() {
 
 namespace {
 //  The cache is a deliberately LEAKED heap object: idle plans would otherwise be destroyed -- ~17 hipFree each -- during static
-// destruction at process exit or dlclose, when the HIP runtime (torch ships its own copy; unload order is not ours) may already be gone.
+// destruction at process exit or dlclose, when the HIP runtime (Python ML frameworks ship their own copy; unload order is not ours) may already be gone.
 std::mutex& plan_mutex() { static std::mutex* m = new std::mutex(); return *m; }
 std::vector<std::shared_ptr<SharedPlan>>& plans() { static auto* v = new std::vector<std::shared_ptr<SharedPlan>>(); return *v; }   // most recently used last
 #define g_plan_mutex plan_mutex()

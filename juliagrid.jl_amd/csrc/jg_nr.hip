@@ -314,6 +314,90 @@ __global__ __launch_bounds__(1024) void k_branch_quantities(BranchArgs a) {
     if (a.series_i) jg::store_vec(a.series_i, (size_t)k, b, ld, z * hypot(isr, isi), on ? atan2(isi, isr) : 0.0);
 }
 
+// ---- contingency screen summary (SURVEY 8f "next"; jgrid.h: jg_nr_screen): worst branch loading, largest flow, lowest / highest voltage per scenario
+// Partial maxima per (chunk of 256 branches resp. 1024 buses, scenario), then one reduction per scenario.  Ties go to the lowest index (fixed order).
+struct ScreenArgs {
+    const int* from; const int* to; const signed char* status; const double* param; const double* rating;   // rating [nb] or null
+    const double* vm; const double* va; const int* outage;
+    double* part;                  // [chunks][4][ld]: branch chunks {loading, its branch, flow, its branch}, then bus chunks {vmin, its bus, vmax, its bus}
+    const int* iters; const int* status_sc;
+    double* rec;                   // [batch][10]
+    int nb, n, ld, lanes, bchunks, vchunks;
+};
+constexpr int SCREEN_BR = 256, SCREEN_BUS = 1024;
+
+__global__ __launch_bounds__(1024) void k_screen_partial(ScreenArgs a) {
+    typedef const double __attribute__((address_space(4)))* CDbl;
+    typedef const int __attribute__((address_space(4)))* CInt;
+    __shared__ double red[16][4][64];
+    const int lane = threadIdx.x, wave = uniform(threadIdx.y);
+    const size_t ld = (size_t)a.ld;
+    const size_t b = (size_t)min((int)blockIdx.y * 64 + lane, a.lanes - 1);
+    const int c = blockIdx.x;
+    double m0, i0, m1, i1;
+    if (c < a.bchunks) {                                         // branches: apparent power at both ends (PijQij, PjiQji: acAnalysis.jl:898-904)
+        m0 = 0.0; i0 = 0.0; m1 = 0.0; i1 = 0.0;
+        const int k0 = c * SCREEN_BR + wave * (SCREEN_BR / 16);
+        for (int k = k0; k < min(k0 + SCREEN_BR / 16, a.nb); ++k) {
+            if (a.status[k] != 1) continue;
+            CDbl p = (CDbl)a.param + (size_t)k * 16;
+            const int i = ((CInt)a.from)[k], j = ((CInt)a.to)[k];
+            const bool on = a.outage[b] != k + 1;
+            const double Vi = a.vm[(size_t)i * ld + b], Vj = a.vm[(size_t)j * ld + b];
+            double si, ci, sj, cj;
+            sincos(a.va[(size_t)i * ld + b], &si, &ci);
+            sincos(a.va[(size_t)j * ld + b], &sj, &cj);
+            const double vir = Vi * ci, vii = Vi * si, vjr = Vj * cj, vji = Vj * sj;
+            const double ifr = vir * p[0] - vii * p[1] + vjr * p[2] - vji * p[3], ifi = vir * p[1] + vii * p[0] + vjr * p[3] + vji * p[2];
+            const double itr = vir * p[4] - vii * p[5] + vjr * p[6] - vji * p[7], iti = vir * p[5] + vii * p[4] + vjr * p[7] + vji * p[6];
+            const double sf = hypot(vir * ifr + vii * ifi, vii * ifr - vir * ifi), st = hypot(vjr * itr + vji * iti, vji * itr - vjr * iti);
+            const double s = on ? fmax(sf, st) : 0.0;
+            if (s > m1) { m1 = s; i1 = (double)(k + 1); }
+            const double r = a.rating ? ((CDbl)a.rating)[k] : 0.0;
+            if (r > 0.0 && s / r > m0) { m0 = s / r; i0 = (double)(k + 1); }
+        }
+    } else {                                                     // buses: lowest and highest voltage magnitude
+        m0 = 1.0e300; i0 = 0.0; m1 = -1.0e300; i1 = 0.0;
+        const int v0 = (c - a.bchunks) * SCREEN_BUS + wave * (SCREEN_BUS / 16);
+        for (int i = v0; i < min(v0 + SCREEN_BUS / 16, a.n); ++i) {
+            const double v = a.vm[(size_t)i * ld + b];
+            if (v < m0) { m0 = v; i0 = (double)(i + 1); }
+            if (v > m1) { m1 = v; i1 = (double)(i + 1); }
+        }
+    }
+    red[wave][0][lane] = m0; red[wave][1][lane] = i0; red[wave][2][lane] = m1; red[wave][3][lane] = i1;
+    __syncthreads();
+    if (wave != 0) return;
+    const bool lo = c >= a.bchunks;                              // the first pair of a bus chunk is a MINIMUM
+    for (int w = 1; w < 16; ++w) {                               // ascending index order: a strict comparison keeps the lowest index on ties
+        const double x0 = red[w][0][lane], x1 = red[w][2][lane];
+        if (lo ? x0 < m0 : x0 > m0) { m0 = x0; i0 = red[w][1][lane]; }
+        if (x1 > m1) { m1 = x1; i1 = red[w][3][lane]; }
+    }
+    double* q = a.part + (size_t)c * 4 * ld + b;
+    q[0] = m0; q[ld] = i0; q[2 * ld] = m1; q[3 * ld] = i1;
+}
+
+__global__ __launch_bounds__(64) void k_screen_final(ScreenArgs a) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= a.lanes) return;
+    const size_t ld = (size_t)a.ld;
+    double load = 0.0, lidx = 0.0, flow = 0.0, fidx = 0.0, vmin = 1.0e300, vminidx = 0.0, vmax = -1.0e300, vmaxidx = 0.0;
+    for (int c = 0; c < a.bchunks; ++c) {
+        const double* q = a.part + (size_t)c * 4 * ld + b;
+        if (q[0] > load) { load = q[0]; lidx = q[ld]; }
+        if (q[2 * ld] > flow) { flow = q[2 * ld]; fidx = q[3 * ld]; }
+    }
+    for (int c = a.bchunks; c < a.bchunks + a.vchunks; ++c) {
+        const double* q = a.part + (size_t)c * 4 * ld + b;
+        if (q[0] < vmin) { vmin = q[0]; vminidx = q[ld]; }
+        if (q[2 * ld] > vmax) { vmax = q[2 * ld]; vmaxidx = q[3 * ld]; }
+    }
+    double* r = a.rec + (size_t)b * 10;
+    r[0] = load; r[1] = lidx; r[2] = flow; r[3] = fidx; r[4] = vmin; r[5] = vminidx; r[6] = vmax; r[7] = vmaxidx;
+    r[8] = (double)a.iters[b]; r[9] = (double)a.status_sc[b];
+}
+
 struct CheckArgs {
     const double* part; int nchunk; int ld; int batch;
     const double* params;      // [0] tolerance, [1] max iterations
@@ -633,6 +717,7 @@ struct jg_nr {
     int nb = 0;                                       // post-processing (jg_nr_set_branches)
     int* d_bfrom = nullptr; int* d_bto = nullptr; signed char* d_bstatus = nullptr; double* d_bparam = nullptr; int* d_outage = nullptr;
     double* d_post = nullptr; size_t post_bytes = 0;  // staging for branch / bus quantities, grown on demand
+    double* d_rating = nullptr; double* d_screen = nullptr; double* d_screc = nullptr;   // contingency screen: ratings [nb], partial maxima, the record [batch][10]
     jg::Engine eng;
     hipStream_t stream = nullptr;
     hipGraph_t graphA = nullptr, graphB = nullptr;
@@ -1003,6 +1088,7 @@ void jg_nr_destroy(jg_nr* h) {
     if (h->graphFA) hipGraphDestroy(h->graphFA);
     if (h->graphFB) hipGraphDestroy(h->graphFB);
     hipFree(h->d_bfrom); hipFree(h->d_bto); hipFree(h->d_bstatus); hipFree(h->d_bparam); hipFree(h->d_outage); hipFree(h->d_post);
+    hipFree(h->d_rating); hipFree(h->d_screen); hipFree(h->d_screc);
     hipFree(h->d_rowptr); hipFree(h->d_col); hipFree(h->d_G); hipFree(h->d_B); hipFree(h->d_GB); hipFree(h->d_rowtype); hipFree(h->d_rowtype_pre); hipFree(h->d_type); hipFree(h->d_flags);
     hipFree(h->d_vm); hipFree(h->d_va); hipFree(h->d_p); hipFree(h->d_q); hipFree(h->d_ppos); hipFree(h->d_pdg);
     hipFree(h->d_pdb); hipFree(h->d_dst); hipFree(h->d_F); hipFree(h->d_inc); hipFree(h->d_part); hipFree(h->d_normp);
@@ -1733,6 +1819,51 @@ int jg_nr_bus_injection(jg_nr* h, double* inj_pq) {
     NR_HIP(hipStreamSynchronize(h->stream));
     h->jac_valid = false;
     return get_pairs(h, h->d_post, inj_pq, (size_t)h->n);
+}
+
+int jg_nr_set_screen(jg_nr* h, const double* rating) {
+    if (!h) return fail(1, "jg_nr_set_screen: bad argument");
+    if (!h->d_bparam) return fail(1, "jg_nr_set_screen: call jg_nr_set_branches first");
+    if (int rc = set_device(h)) return rc;
+    hipFree(h->d_rating); h->d_rating = nullptr;
+    if (rating) {
+        for (int k = 0; k < h->nb; ++k) if (!(rating[k] >= 0.0)) return fail(1, "jg_nr_set_screen: a rating is negative or not a number (0 = no limit)");
+        std::string err;
+        if (jg::upload(&h->d_rating, std::vector<double>(rating, rating + h->nb), err, h->stream)) return fail(2, err);
+    }
+    return 0;
+}
+
+static int screen_launch(jg_nr* h) {
+    if (!h->d_bparam) return fail(1, "jg_nr_screen: call jg_nr_set_branches first");
+    const int bchunks = (h->nb + SCREEN_BR - 1) / SCREEN_BR, vchunks = (h->n + SCREEN_BUS - 1) / SCREEN_BUS;
+    if (!h->d_screen) {
+        NR_HIP(hipMalloc((void**)&h->d_screen, (size_t)(bchunks + vchunks) * 4 * h->ld * sizeof(double)));
+        NR_HIP(hipMalloc((void**)&h->d_screc, (size_t)h->ld * 10 * sizeof(double)));
+    }
+    ScreenArgs a{h->d_bfrom, h->d_bto, h->d_bstatus, h->d_bparam, h->d_rating, h->d_vm, h->d_va, h->d_outage, h->d_screen, h->d_iters, h->d_status,
+                 h->d_screc, h->nb, h->n, h->ld, h->batch, bchunks, vchunks};
+    hipLaunchKernelGGL(k_screen_partial, dim3(bchunks + vchunks, h->ld / 64), dim3(64, 16), 0, h->stream, a);
+    hipLaunchKernelGGL(k_screen_final, dim3(h->ld / 64), dim3(64), 0, h->stream, a);
+    NR_HIP(hipGetLastError());
+    return 0;
+}
+
+int jg_nr_screen(jg_nr* h, double* rec) {
+    if (!h || !rec) return fail(1, "jg_nr_screen: bad argument");
+    if (int rc = set_device(h)) return rc;
+    if (int rc = screen_launch(h)) return rc;
+    NR_HIP(jg::sync_copy(rec, h->d_screc, (size_t)h->batch * 10 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    return 0;
+}
+
+int jg_nr_screen_device(jg_nr* h, double* rec_dev) {
+    if (!h || !rec_dev) return fail(1, "jg_nr_screen_device: bad argument");
+    if (int rc = set_device(h)) return rc;
+    if (int rc = screen_launch(h)) return rc;
+    NR_HIP(hipMemcpyAsync(rec_dev, h->d_screc, (size_t)h->batch * 10 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    NR_HIP(hipStreamSynchronize(h->stream));
+    return 0;
 }
 
 int jg_nr_time_kernel(jg_nr* h, int kernel, int reps, double* mean_ms) {

@@ -674,6 +674,37 @@ def current_(an: AcPowerFlow):
     cur.from_, cur.to, cur.series = _ns2(an, fi, names), _ns2(an, ti, names), _ns2(an, si, names)
 
 
+def screenSummary_(an: AcPowerFlow, rating=None, device_record: int | None = None):
+    """Contingency screen summary on the device (include/jgrid.h: jg_nr_screen): per scenario the worst branch loading against `rating`
+    (pu of apparent power per branch, 0 / None = no limit) and its branch, the largest apparent power at a branch end and its branch, the lowest and the
+    highest voltage magnitude and their buses, iterations and status -- what a user of the reference reads off power!(analysis) after every powerFlow! of
+    the outage loop (branch.jl:453-459), reduced where the states are.  device_record: DEVICE pointer of a [batch, 10] float64 buffer to fill instead
+    (the operand of the one gather of a sharded screen); else a namespace of arrays ([batch]; scalars for batch 1) comes back."""
+    L = _lib.lib()
+    if not an._branches_on_device:
+        _upload_branches(an)
+    _lib.check(L.jg_nr_set_outage_labels(an._h, np.ascontiguousarray(an._outage_labels, dtype=np.int64)))
+    if rating is not None:
+        r = np.ascontiguousarray(np.asarray(rating, dtype=np.float64))
+        if r.shape != (an.system.branch.number,):
+            raise ValueError("rating: one value per branch")
+        _lib.check(L.jg_nr_set_screen(an._h, r.ctypes.data))
+        an._screen_rating = r
+    elif getattr(an, "_screen_rating", None) is not None:
+        _lib.check(L.jg_nr_set_screen(an._h, None))
+        an._screen_rating = None
+    if device_record is not None:
+        _lib.check(L.jg_nr_screen_device(an._h, _lib.VP(int(device_record))))
+        return None
+    rec = np.zeros((an.batch, 10))
+    _lib.check(L.jg_nr_screen(an._h, rec))
+    one = an.batch == 1
+    f = (lambda x: x[0]) if one else (lambda x: x)
+    return NS(loading=f(rec[:, 0]), loadingBranch=f(rec[:, 1].astype(np.int64)), flow=f(rec[:, 2]), flowBranch=f(rec[:, 3].astype(np.int64)),
+              minMagnitude=f(rec[:, 4]), minBus=f(rec[:, 5].astype(np.int64)), maxMagnitude=f(rec[:, 6]), maxBus=f(rec[:, 7].astype(np.int64)),
+              iteration=f(rec[:, 8].astype(np.int32)), status=f(rec[:, 9].astype(np.int32)))
+
+
 def reactiveLimit_(an: AcPowerFlow):
     """reactiveLimit!(analysis) (src/powerFlow/acPowerFlow.jl:1081-1155), single-scenario analyses: generator outputs
     from power! on the device, then the reference's bookkeeping on the PowerSystem container -- a generator whose

@@ -1,0 +1,80 @@
+"""Contingency screen summary on the device (the next widening of the path; include/jgrid.h: jg_nr_screen): per scenario the worst branch
+loading and its branch, the largest apparent power at a branch end and its branch, lowest / highest voltage and their buses, iterations, status -- against
+the oracle's restatement of power! (src/postprocessing/acAnalysis.jl:898-904) evaluated on that scenario's own state with its branch switched off; against
+the device's own power!; through a device record (the operand of the one gather of a sharded screen)."""
+import numpy as np
+import pytest
+
+from conftest import load_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_summary(oracle, t, label, vm, va, rating):
+    t2 = {k: np.array(v) for k, v in t.items()}
+    if label:
+        t2["br_status"][label - 1] = 0
+    ref = oracle.power_and_current(oracle.OracleSystem(t2), vm, va)
+    s = np.maximum(np.hypot(ref["from_"][0], ref["from_"][1]), np.hypot(ref["to"][0], ref["to"][1]))
+    on = np.asarray(t2["br_status"]) == 1
+    s = np.where(on, s, 0.0)
+    kf = int(np.argmax(s))
+    load = np.where((rating > 0) & on, s / np.where(rating > 0, rating, 1.0), 0.0)
+    kl = int(np.argmax(load))
+    return (float(load[kl]), kl + 1 if load[kl] > 0 else 0, float(s[kf]), kf + 1, float(vm.min()), int(np.argmin(vm)) + 1, float(vm.max()), int(np.argmax(vm)) + 1)
+
+
+@pytest.mark.parametrize("name,batch", [("case118", 6), ("case1354pegase", 70), ("case_ACTIVSg10k", 130)])
+def test_summary_matches_the_oracle(jg, oracle, name, batch):
+    t = load_case(name)
+    s = jg.powerSystem(t)
+    labels = [int(x) for x in jg.outageList(s, batch - 1, seed=7)] + [0]
+    an = jg.contingencyAnalysis(s, labels)
+    jg.powerFlow_(an)
+    nb = s.branch.number
+    rng = np.random.Generator(np.random.PCG64(nb))
+    base = jg.newtonRaphson(jg.powerSystem(t))
+    jg.powerFlow_(base)
+    jg.power_(base)
+    flow0 = np.maximum(np.hypot(base.power.from_.active, base.power.from_.reactive), np.hypot(base.power.to.active, base.power.to.reactive))
+    rating = np.where(rng.random(nb) < 0.8, (1.0 + rng.random(nb)) * np.maximum(flow0, 0.05), 0.0)     # every fifth branch has no limit
+    base.close()
+    out = jg.screenSummary_(an, rating=rating)
+    assert np.array_equal(out.iteration, an.method.iteration) and np.array_equal(out.status, an.status)
+    checked = 0
+    for sc in list(range(0, batch, max(1, batch // 9))) + [batch - 1]:
+        if an.status[sc] != 0:
+            continue
+        ref = _oracle_summary(oracle, t, labels[sc], an.voltage.magnitude[sc], an.voltage.angle[sc], rating)
+        got = (out.loading[sc], out.loadingBranch[sc], out.flow[sc], out.flowBranch[sc], out.minMagnitude[sc], out.minBus[sc], out.maxMagnitude[sc], out.maxBus[sc])
+        assert abs(got[0] - ref[0]) <= 1e-11 * max(1.0, ref[0]) and abs(got[2] - ref[2]) <= 1e-11 * max(1.0, ref[2]), (sc, got, ref)
+        assert got[4] == ref[4] and got[6] == ref[6] and (got[5], got[7]) == (ref[5], ref[7]), (sc, got, ref)
+        assert (got[1], got[3]) == (ref[1], ref[3]), (sc, got, ref)
+        checked += 1
+    assert checked >= 5
+    # against the device's own power!: the summary is a reduction of exactly those numbers
+    jg.power_(an)
+    f = np.maximum(np.hypot(an.power.from_.active, an.power.from_.reactive), np.hypot(an.power.to.active, an.power.to.reactive))
+    assert np.abs(out.flow - f.max(axis=1)).max() <= 1e-12 * max(1.0, f.max()) and np.array_equal(out.flowBranch, f.argmax(axis=1) + 1)
+    # without ratings: no loading, everything else unchanged
+    none = jg.screenSummary_(an)
+    assert np.all(none.loading == 0.0) and np.all(none.loadingBranch == 0) and np.array_equal(none.flow, out.flow) and np.array_equal(none.minBus, out.minBus)
+    an.close()
+
+
+def test_summary_into_a_device_record(jg):
+    """The record a sharded screen gathers: 10 doubles per scenario in a device buffer of the caller, bit-equal to the host record."""
+    import torch
+    s = jg.powerSystem(load_case("case1354pegase"))
+    labels = [int(x) for x in jg.outageList(s, 200, seed=3)]
+    an = jg.contingencyAnalysis(s, labels)
+    jg.powerFlow_(an)
+    rating = np.full(s.branch.number, 2.5)
+    host = jg.screenSummary_(an, rating=rating)
+    rec = torch.full((200, 10), -1.0, dtype=torch.float64, device="cuda")
+    jg.screenSummary_(an, rating=rating, device_record=rec.data_ptr())
+    r = rec.cpu().numpy()
+    assert np.array_equal(r[:, 0], host.loading) and np.array_equal(r[:, 1], host.loadingBranch.astype(float)) and np.array_equal(r[:, 4], host.minMagnitude)
+    assert np.array_equal(r[:, 8], an.method.iteration.astype(float)) and np.array_equal(r[:, 9], an.status.astype(float))
+    assert (2 * s.bus.number + 2) / 10 > 250, "the gather shrinks by the ratio of the state record to the summary"
+    an.close()
