@@ -594,8 +594,11 @@ void build_tables(BlockSymbolic& S) {
         std::vector<std::vector<int>> by(nlev + 1);
         for (int i = 0; i < nE + n; ++i) if (level[i] > 0) by[level[i]].push_back(i);
         S.fact_seg.clear(); S.fact_rec.clear(); S.n_fact_levels = 0; S.n_staged = 0; S.n_direct_terms = 0;
-        std::vector<int> slot_stamp(nE, -1), slot_idx(nE, 0);     // staged operand (an entry) -> slot of the task being filled
-        int stamp = 0;
+        // the levels are independent of each other: each is laid out into tables of its own (by several threads: the 512-scenario plan of a
+        // 10 000-bus grid is 48 ms of this on one), stitched in level order afterwards
+        struct LevelOut { std::vector<Segment> segs; std::vector<Rec> recs; long long staged = 0, direct = 0; };
+        struct Scratch { std::vector<int> slot_stamp, slot_idx; int stamp = 0; };   // staged operand (an entry) -> slot of the task being filled
+        std::vector<LevelOut> outs(nlev + 1);
         auto side_of = [&](int it) { return it < nE && S.e_row[it] > S.e_col[it] ? 1 : 0; };
         auto group_of = [&](int it) -> long long { return it < nE ? ((long long)std::min(S.e_row[it], S.e_col[it]) << 1 | side_of(it)) : ((long long)(it - nE) << 1); };
         auto term_of = [&](int it, int f, int& a, int& d, int& b) {
@@ -605,9 +608,10 @@ void build_tables(BlockSymbolic& S) {
         };
         auto shares_of = [&](int it) { return std::min(W, pow2ceil(std::max(1, (work[it] + T - 1) / T))); };
         struct Task { std::vector<TItem> items; std::vector<int> skey, sd; int shares = 0; };
-        for (int l = 1; l <= nlev; ++l) {
+        auto do_level = [&](int l, Scratch& sc, LevelOut& out) {
+            std::vector<int>& slot_stamp = sc.slot_stamp; std::vector<int>& slot_idx = sc.slot_idx; int& stamp = sc.stamp;
             std::vector<int>& its = by[l];
-            if (its.empty()) continue;
+            if (its.empty()) return;
             std::stable_sort(its.begin(), its.end(), [&](int x, int y) { return loc[x] < loc[y]; });
             std::vector<Task> tasks;
             Task cur;
@@ -717,7 +721,7 @@ void build_tables(BlockSymbolic& S) {
                     r.w[10 + 3 * u] = tk.skey[s]; r.w[11 + 3 * u] = tk.sd[s]; r.w[12 + 3 * u] = s;
                     r.w[3] = (u + 1) << 8;
                 }
-                S.n_staged += nslot;
+                out.staged += nslot;
                 for (const Place& pl : places) {
                     const TItem& it = tk.items[pl.item];
                     const int id = it.it < nE ? it.it : it.it - nE;
@@ -737,7 +741,7 @@ void build_tables(BlockSymbolic& S) {
                                 for (int q = 0; q < T && si < st.size(); ++q, ++si) { r.w[4 + q] = st[si]->mem | st[si]->slot << 24; ++nt; }
                             } else if (di < dr.size()) {
                                 w0 |= TK_DIRECT;
-                                for (int q = 0; q < TASK_DIRECT_T && di < dr.size(); ++q, ++di) { r.w[4 + 3 * q] = dr[di]->a; r.w[5 + 3 * q] = dr[di]->d; r.w[6 + 3 * q] = dr[di]->b; ++nt; S.n_direct_terms++; }
+                                for (int q = 0; q < TASK_DIRECT_T && di < dr.size(); ++q, ++di) { r.w[4 + 3 * q] = dr[di]->a; r.w[5 + 3 * q] = dr[di]->d; r.w[6 + 3 * q] = dr[di]->b; ++nt; out.direct++; }
                             }
                             r.w[3] |= nt;
                             r.w[0] = w0;
@@ -745,22 +749,51 @@ void build_tables(BlockSymbolic& S) {
                     }
                 }
             }
-            // segments: the tasks of the level by shape, in task order
-            const size_t seg0 = S.fact_seg.size();
+            // segments: the tasks of the level by shape, in task order (rec_base: relative to the level's records until the stitch)
             std::vector<char> done(tasks.size(), 0);
             for (size_t t0 = 0; t0 < tasks.size(); ++t0) {
                 if (done[t0]) continue;
                 Segment sg{};
-                sg.rec_base = (int)S.fact_rec.size(); sg.wpi = laid[t0].spw; sg.rpw = laid[t0].rounds; sg.level = l; sg.last = 0; sg.nchunks = 0; sg.items = 0;
+                sg.rec_base = (int)out.recs.size(); sg.wpi = laid[t0].spw; sg.rpw = laid[t0].rounds; sg.level = l; sg.last = 0; sg.nchunks = 0; sg.items = 0;
                 for (size_t t = t0; t < tasks.size(); ++t)
                     if (!done[t] && laid[t].spw == laid[t0].spw && laid[t].rounds == laid[t0].rounds) {
                         done[t] = 1;
-                        S.fact_rec.insert(S.fact_rec.end(), laid[t].recs.begin(), laid[t].recs.end());
+                        out.recs.insert(out.recs.end(), laid[t].recs.begin(), laid[t].recs.end());
                         sg.nchunks++; sg.items += (int)tasks[t].items.size();
                     }
-                S.fact_seg.push_back(sg);
+                out.segs.push_back(sg);
             }
-            if (S.fact_seg.size() > seg0) { S.fact_seg.back().last = 1; ++S.n_fact_levels; }
+            if (!out.segs.empty()) out.segs.back().last = 1;
+        };
+        // heaviest level first, levels handed out through a counter: the result does not depend on who laid out which level
+        std::vector<int> lorder;
+        for (int l = 1; l <= nlev; ++l) if (!by[l].empty()) lorder.push_back(l);
+        std::stable_sort(lorder.begin(), lorder.end(), [&](int x, int y) { return by[x].size() > by[y].size(); });
+        int nthr = (int)std::max<size_t>(1, std::min<size_t>({(size_t)8, lorder.size(), (size_t)std::max(1u, std::thread::hardware_concurrency() / 2), (size_t)(nE + n) / 8192 + 1}));
+        if (const char* e = getenv("JG_PLAN_THREADS")) nthr = std::max(1, std::min(16, atoi(e)));     // tests: the tables must not depend on it
+        std::atomic<size_t> next{0};
+        auto worker = [&] {
+            Scratch sc; sc.slot_stamp.assign(nE, -1); sc.slot_idx.assign(nE, 0);
+            for (size_t q = next++; q < lorder.size(); q = next++) {
+                const auto t0 = std::chrono::steady_clock::now();
+                do_level(lorder[q], sc, outs[lorder[q]]);
+                if (getenv("JG_PLAN_TIMING_LEVELS")) fprintf(stderr, "[jg plan]     level %d: %zu items %.2f ms\n", lorder[q], by[lorder[q]].size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+            }
+        };
+        {
+            std::vector<std::thread> pool;
+            for (int t = 1; t < nthr; ++t) pool.emplace_back(worker);
+            worker();
+            for (std::thread& t : pool) t.join();
+        }
+        for (int l = 1; l <= nlev; ++l) {
+            LevelOut& o = outs[l];
+            if (o.segs.empty()) continue;
+            const int base = (int)S.fact_rec.size();
+            for (Segment& sg : o.segs) { sg.rec_base += base; S.fact_seg.push_back(sg); }
+            S.fact_rec.insert(S.fact_rec.end(), o.recs.begin(), o.recs.end());
+            S.n_staged += o.staged; S.n_direct_terms += o.direct;
+            ++S.n_fact_levels;
         }
     };
     const bool timing = getenv("JG_PLAN_TIMING") != nullptr;

@@ -421,3 +421,21 @@ def test_ordering_and_tables_on_degenerate_graphs(jg, symmetric):
         if n == 12 and len(edges) == 11:                                                 # path: the height penalty trades a little fill
             assert plan.get("e_row").size <= 12 + 22 + 12                                # for a shallower tree (dissection, not a chain)
             assert plan.replay_tables("fact")[0][-1, 4] < 12
+
+
+def test_task_tables_do_not_depend_on_the_threads_that_built_them(jg, monkeypatch):
+    """The factorisation tasks of a plan are laid out level by level on several host threads (round 4: 48 ms on one for the 512-scenario
+    plan of the 10 000-bus grid); who built which level must not show in the tables."""
+    s = jg.powerSystem("case_ACTIVSg10k")
+    jg.acModel_(s)
+    Y = s.model.ac.nodalMatrix
+    policy = 1 | 4 | (47 << 16 | 127 << 24 | 12 << 4) | 1 << 49 | 1 << 50
+    tables = []
+    for thr in ("1", "3", "8"):
+        monkeypatch.setenv("JG_PLAN_THREADS", thr)
+        plan = jg._lib.Plan(Y.n, Y.colptr - 1, Y.rowval - 1, policy=policy)
+        seg, rec = plan.replay_tables("fact")
+        tables.append((seg.copy(), rec.copy(), plan.get(74).copy()))
+    for seg, rec, meta in tables[1:]:
+        assert np.array_equal(seg, tables[0][0]) and np.array_equal(rec, tables[0][1]) and np.array_equal(meta, tables[0][2])
+    assert len(tables[0][1]) > 10000
