@@ -13,6 +13,7 @@
 #include "jg_engine.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <condition_variable>
@@ -1554,6 +1555,7 @@ std::shared_ptr<SharedPlan> acquire_plan(int n, const int* rowptr, const int* co
     p->device = device; p->policy = policy; p->key_hash = h;
     p->key_rowptr.assign(rowptr, rowptr + n + 1); p->key_col.assign(col, col + rowptr[n]);
     const BlockSymbolic& S = p->S;
+    const double tu0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
     std::vector<int> prow(n, 0);                                 // by ORIGINAL block index: pivot + 1 where the producer finishes D and y
     for (int k = 0; k < n; ++k) if (S.prefactor && S.pre_pivot[k]) prow[S.perm[k]] = k + 1;
     if (upload(&p->pre_rec, S.pre_rec, error, st) || upload(&p->pre_seg, S.pre_seg, error, st) || upload(&p->pre_row, prow, error, st) ||
@@ -1565,6 +1567,7 @@ std::shared_ptr<SharedPlan> acquire_plan(int n, const int* rowptr, const int* co
         rc = 2;
         return nullptr;
     }
+    if (getenv("JG_PLAN_TIMING")) fprintf(stderr, "[jg engine]   table upload %6.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - tu0);
     if (!nocache) {
         lock.lock();
         g_plans.push_back(p);
@@ -1610,11 +1613,15 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, long long 
     const bool lane64 = !top_r02 && ld_ == 64 && !tiny && n >= 4000 && !(policy & 2);
     if (defaults) policy |= ld_ >= 256 ? (n >= 4000 ? (top_r02 || (policy & 2) ? (47 << 16 | (384 / 8) << 24 | 8 << 4) : (47 << 16 | 127 << 24 | 12 << 4)) : (47 << 16 | (280 / 8) << 24 | 4 << 4))
                                               : ((n >= 4000 ? 26 : 24) << 16 | (tiny || lane64 ? 127 : 384 / 8) << 24 | (lane64 ? 15 << 4 : 0));
+    const bool timing = getenv("JG_PLAN_TIMING") != nullptr;
+    auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double te0 = tnow();
     {
         int rc = 0;
         plan = acquire_plan(n, rowptr, col, policy, st, error, rc);
         if (!plan) return rc;
     }
+    if (timing) fprintf(stderr, "[jg engine] plan (analysis or cache hit, table upload) %6.1f ms\n", tnow() - te0);
     ld = ld_;
     level_launches(plan->S.fact_seg, fact);
     level_launches(plan->S.pre_seg, pre);
@@ -1644,6 +1651,7 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, long long 
     JG_HIP(hipMalloc((void**)&status, (size_t)ld * sizeof(int)));
     JG_HIP(sync_fill(status, 0, (size_t)ld * sizeof(int), st));
     JG_HIP(hipGetDevice(&device));
+    if (timing) fprintf(stderr, "[jg engine] + factor storage, stacks               %6.1f ms\n", tnow() - te0);
     return 0;
 }
 

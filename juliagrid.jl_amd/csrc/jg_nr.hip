@@ -23,6 +23,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/jgrid.h"
@@ -700,6 +701,7 @@ struct jg_nr {
     // device
     int* d_rowptr = nullptr; int* d_col = nullptr; double* d_G = nullptr; double* d_B = nullptr; double2* d_GB = nullptr; int* d_rowtype = nullptr; int* d_rowtype_pre = nullptr;   // _pre: type | (pivot + 1) << 2 for the pivots of the plan's level 0
     signed char* d_type = nullptr; signed char* d_flags = nullptr;
+    void* d_arena = nullptr;                   // one allocation behind the per-handle state below (jg_nr_create)
     double* d_vm = nullptr; double* d_va = nullptr; double* d_p = nullptr; double* d_q = nullptr;
     int* d_ppos = nullptr; double* d_pdg = nullptr; double* d_pdb = nullptr;
     int* d_dst = nullptr; double* d_F = nullptr; double* d_inc = nullptr; double* d_part = nullptr;
@@ -934,6 +936,7 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
     int ndev = 0;
     NR_HIP(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(1, "jg_nr_create: no such HIP device");
+    const double tc0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
     jg_nr* h = new jg_nr();
     h->n = (int)n; h->batch = (int)batch; h->ld = (int)((batch + 63) / 64 * 64);
     h->mp = max_patch == 0 ? 0 : (max_patch <= 4 ? 4 : 8);
@@ -943,15 +946,39 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
     h->rowval.assign(rowval, rowval + h->nnz);
     h->type.assign(type, type + n);
     const int nnz = h->nnz;
+    if (n >= (1 << 24)) { delete h; return fail(1, "jg_nr_create: more than 2^24 buses"); }
+    for (int c = 0; c < n; ++c) {
+        if (colptr[c + 1] < colptr[c] || colptr[c] < 1 || colptr[c + 1] - 1 > nnz) { delete h; return fail(1, "jg_nr_create: malformed column pointers"); }
+        for (int64_t p = colptr[c] - 1; p < colptr[c + 1] - 1; ++p)
+            if (rowval[p] < 1 || rowval[p] > n) { delete h; return fail(1, "jg_nr_create: row index out of range"); }
+    }
+    // The symbolic analysis of the block LU (or its look-up in the plan cache), the upload of its tables and the factor storage need the pattern
+    // and nothing else: they run on a thread of their own while this one builds the reference's maps, uploads the model and allocates the state
+    // (round 4: what a first power flow on a grid waits for is the analysis -- 19 of 30 ms on the 10 000-bus grid -- not analysis + the rest).
+    int rc = set_device(h);
+    if (rc) { delete h; return rc; }
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(2, "jg_nr_create: stream creation failed"); }
+    std::vector<int> rp(n + 1), cl(nnz);
+    for (int i = 0; i <= n; ++i) rp[i] = (int)(colptr[i] - 1);
+    for (int p = 0; p < nnz; ++p) cl[p] = (int)(rowval[p] - 1);
+    // in place: the assembly kernel writes into the factor storage; bit 2: it also finishes the plan's level 0 (jg_symbolic.hpp: prefactor)
+    // bit 49: Jordan rows for the pivots of the top tasks (jg_symbolic.hpp): the backward sweep over the top of the tree is a handful of
+    // plain levels instead of sequential chains (refined steps and fast Newton-Raphson switch the engine back: Engine::jordan)
+    h->eng.lanes = h->batch;                                    // (known before the plan is chosen: a handful of scenarios gets a deeper top)
+    int eng_rc = 0;
+    std::thread eng_thread([&] {
+        if (hipSetDevice(h->device) != hipSuccess) { h->eng.error = "hipSetDevice failed on the analysis thread"; eng_rc = 2; return; }
+        eng_rc = h->eng.create((int)n, rp.data(), cl.data(), h->ld, (getenv("JG_NO_PREFACTOR") ? 1LL : 1LL | 4) | 1LL << 49, h->stream);
+    });
+    struct JoinEng { std::thread& t; ~JoinEng() { if (t.joinable()) t.join(); } } join_eng{eng_thread};     // every early return waits for it before the handle goes
     // transpose permutation of the (structurally symmetric) pattern: tperm[p of (r,c)] = pointer of (c,r)
     h->tperm.assign(nnz, -1);
     for (int c = 0; c < n; ++c)
         for (int64_t p = colptr[c] - 1; p < colptr[c + 1] - 1; ++p) {
             const int64_t r = rowval[p] - 1;
-            if (r < 0 || r >= n) { delete h; return fail(1, "jg_nr_create: row index out of range"); }
             int64_t lo = colptr[r] - 1, hi = colptr[r + 1] - 2, q = -1;
             while (lo <= hi) { int64_t m = (lo + hi) >> 1; if (rowval[m] - 1 < c) lo = m + 1; else if (rowval[m] - 1 > c) hi = m - 1; else { q = m; break; } }
-            if (q < 0) { delete h; return fail(1, "jg_nr_create: Ybus pattern is not structurally symmetric"); }
+            if (q < 0) { eng_thread.join(); jg_nr_destroy(h); return fail(1, "jg_nr_create: Ybus pattern is not structurally symmetric"); }
             h->tperm[p] = (int)q;
         }
     // ---- newtonJacobian (acPowerFlow.jl:89-175), integer only -------------------------------
@@ -998,14 +1025,8 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
         }
     }
     // ---- device upload ----------------------------------------------------------------------
-    int rc = set_device(h);
-    if (rc) { delete h; return rc; }
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(2, "jg_nr_create: stream creation failed"); }
-    std::vector<int> rp(n + 1), cl(nnz);
     std::vector<double> G(nnz), B(nnz);
-    for (int i = 0; i <= n; ++i) rp[i] = (int)(colptr[i] - 1);
-    for (int p = 0; p < nnz; ++p) { cl[p] = (int)(rowval[p] - 1); G[p] = yt_reim[2 * p]; B[p] = yt_reim[2 * p + 1]; }
-    if (n >= (1 << 24)) { delete h; return fail(1, "jg_nr_create: more than 2^24 buses"); }
+    for (int p = 0; p < nnz; ++p) { G[p] = yt_reim[2 * p]; B[p] = yt_reim[2 * p + 1]; }
     std::vector<int> colm(nnz);                 // column | existence mask of the 2x2 block entries (row i, col j types)
     for (int i = 0; i < n; ++i)
         for (int p = rp[i]; p < rp[i + 1]; ++p) {
@@ -1018,7 +1039,7 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
     // consistency of the two value arrays the reference keeps (T1): yT[p] must equal y[tperm[p]]
     for (int p = 0; p < nnz; ++p)
         if (y_reim[2 * (size_t)h->tperm[p]] != yt_reim[2 * p] || y_reim[2 * (size_t)h->tperm[p] + 1] != yt_reim[2 * p + 1]) {
-            delete h; return fail(4, "jg_nr_create: nodalMatrix and nodalMatrixTranspose disagree (stale model)");
+            eng_thread.join(); jg_nr_destroy(h); return fail(4, "jg_nr_create: nodalMatrix and nodalMatrixTranspose disagree (stale model)");
         }
     std::vector<signed char> flags(n);
     for (int i = 0; i < n; ++i) flags[i] = (signed char)((type[i] != 3 ? 1 : 0) | (type[i] == 1 ? 2 : 0));
@@ -1026,39 +1047,41 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
     std::vector<signed char> tp(type, type + n);
     if (jg::upload(&h->d_rowptr, rp, err, h->stream) || jg::upload(&h->d_col, colm, err, h->stream) || jg::upload(&h->d_G, G, err, h->stream) ||
         jg::upload(&h->d_B, B, err, h->stream) || jg::upload(&h->d_GB, GBv, err, h->stream) || jg::upload(&h->d_rowtype, std::vector<int>(type, type + n), err, h->stream) || jg::upload(&h->d_type, tp, err, h->stream) || jg::upload(&h->d_flags, flags, err, h->stream)) {
-        jg_nr_destroy(h); return fail(2, err);
+        eng_thread.join(); jg_nr_destroy(h); return fail(2, err);
     }
     h->nchunk = (h->n + ASM_ROWS - 1) / ASM_ROWS;
     const size_t ld = h->ld;
-    auto dmalloc = [&](void** p, size_t bytes) -> bool {
-        if (hipMalloc(p, bytes) != hipSuccess) return false;
-        return jg::sync_fill(*p, 0, bytes, h->stream) == hipSuccess;
-    };
+    // the per-handle state as ONE allocation and ONE fill (round 4: 23 x (hipMalloc + fill + stream synchronisation) were 2 of the 4 ms a handle on a
+    // cached plan costs); every array starts on a 256-byte boundary
     const size_t mpn = h->mp > 0 ? h->mp : 1;
-    bool ok = dmalloc((void**)&h->d_vm, n * ld * 8) && dmalloc((void**)&h->d_va, n * ld * 8) &&
-              dmalloc((void**)&h->d_p, n * ld * 8) && dmalloc((void**)&h->d_q, n * ld * 8) &&
-              dmalloc((void**)&h->d_ppos, mpn * ld * 4) && dmalloc((void**)&h->d_pdg, mpn * ld * 8) &&
-              dmalloc((void**)&h->d_pdb, mpn * ld * 8) &&
-              dmalloc((void**)&h->d_F, n * 2 * ld * 8) && dmalloc((void**)&h->d_inc, n * 2 * ld * 8) &&
-              dmalloc((void**)&h->d_part, (size_t)h->nchunk * 2 * ld * 8) && dmalloc((void**)&h->d_normp, ld * 8) &&
-              dmalloc((void**)&h->d_normq, ld * 8) && dmalloc((void**)&h->d_params, 2 * 8) &&
-              dmalloc((void**)&h->d_active, ld * 4) && dmalloc((void**)&h->d_iters, ld * 4) &&
-              dmalloc((void**)&h->d_status, ld * 4) && dmalloc((void**)&h->d_counter, 4) &&
-              dmalloc((void**)&h->d_group, (ld / 64) * 4) && dmalloc((void**)&h->d_lid, ld * 4) &&
-              dmalloc((void**)&h->d_dest, ld * 4) && dmalloc((void**)&h->d_cflags, 16) && dmalloc((void**)&h->d_itmp, ld * 4) &&
-              dmalloc((void**)&h->d_glist, std::max<size_t>(ld / 64, 8) * 4);    // map_block reads the first eight entries in one scalar load
-    if (!ok) { jg_nr_destroy(h); return fail(2, "jg_nr_create: device allocation failed"); }
+    struct Part { void** p; size_t bytes; };
+    const Part parts[] = {
+        {(void**)&h->d_vm, n * ld * 8}, {(void**)&h->d_va, n * ld * 8}, {(void**)&h->d_p, n * ld * 8}, {(void**)&h->d_q, n * ld * 8},
+        {(void**)&h->d_ppos, mpn * ld * 4}, {(void**)&h->d_pdg, mpn * ld * 8}, {(void**)&h->d_pdb, mpn * ld * 8},
+        {(void**)&h->d_F, n * 2 * ld * 8}, {(void**)&h->d_inc, n * 2 * ld * 8}, {(void**)&h->d_part, (size_t)h->nchunk * 2 * ld * 8},
+        {(void**)&h->d_normp, ld * 8}, {(void**)&h->d_normq, ld * 8}, {(void**)&h->d_params, 2 * 8}, {(void**)&h->d_active, ld * 4},
+        {(void**)&h->d_iters, ld * 4}, {(void**)&h->d_status, ld * 4}, {(void**)&h->d_counter, 4}, {(void**)&h->d_group, (ld / 64) * 4},
+        {(void**)&h->d_lid, ld * 4}, {(void**)&h->d_dest, ld * 4}, {(void**)&h->d_cflags, 16}, {(void**)&h->d_itmp, ld * 4},
+        {(void**)&h->d_glist, std::max<size_t>(ld / 64, 8) * 4}};    // map_block reads the first eight entries in one scalar load
+    size_t arena_bytes = 0;
+    for (const Part& q : parts) arena_bytes += (q.bytes + 255) / 256 * 256;
+    bool ok = hipMalloc((void**)&h->d_arena, arena_bytes) == hipSuccess && jg::sync_fill(h->d_arena, 0, arena_bytes, h->stream) == hipSuccess;
+    if (ok) {
+        size_t off = 0;
+        for (const Part& q : parts) { *q.p = (char*)h->d_arena + off; off += (q.bytes + 255) / 256 * 256; }
+    }
+    if (!ok) { eng_thread.join(); jg_nr_destroy(h); return fail(2, "jg_nr_create: device allocation failed"); }
     if (jg::sync_fill(h->d_ppos, 0xff, mpn * ld * 4, h->stream) != hipSuccess ||     // -1 = no patch
         hipHostMalloc((void**)&h->h_counter, sizeof(int)) != hipSuccess) {
-        jg_nr_destroy(h); return fail(2, "jg_nr_create: pinned allocation failed");
+        eng_thread.join(); jg_nr_destroy(h); return fail(2, "jg_nr_create: pinned allocation failed");
     }
-    if (hipHostGetDevicePointer((void**)&h->h_counter_dev, h->h_counter, 0) != hipSuccess) { jg_nr_destroy(h); return fail(2, "jg_nr_create: pinned host word is not device-visible"); }
-    // in place: the assembly kernel writes into the factor storage; bit 2: it also finishes the plan's level 0 (jg_symbolic.hpp: prefactor)
-    // bit 49: Jordan rows for the pivots of the top tasks (jg_symbolic.hpp): the backward sweep over the top of the tree is a handful of
-    // plain levels instead of sequential chains (refined steps and fast Newton-Raphson switch the engine back: Engine::jordan)
-    h->eng.lanes = h->batch;                                    // (known before the plan is chosen: a handful of scenarios gets a deeper top)
-    rc = h->eng.create(n, rp.data(), cl.data(), h->ld, (getenv("JG_NO_PREFACTOR") ? 1LL : 1LL | 4) | 1LL << 49, h->stream);
-    if (rc) { std::string m = h->eng.error; jg_nr_destroy(h); return fail(rc, m); }
+    if (hipHostGetDevicePointer((void**)&h->h_counter_dev, h->h_counter, 0) != hipSuccess) { eng_thread.join(); jg_nr_destroy(h); return fail(2, "jg_nr_create: pinned host word is not device-visible"); }
+    const bool timing = getenv("JG_PLAN_TIMING") != nullptr;
+    auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    if (timing) fprintf(stderr, "[jg nr create] maps, model upload, state arena done at %6.1f ms\n", tnow() - tc0);
+    eng_thread.join();
+    if (timing) fprintf(stderr, "[jg nr create] engine joined at                        %6.1f ms\n", tnow() - tc0);
+    if (eng_rc) { std::string m = h->eng.error; jg_nr_destroy(h); return fail(eng_rc, m); }
     if (jg::upload(&h->d_dst, h->eng.plan->S.src_entry, err, h->stream)) { jg_nr_destroy(h); return fail(2, err); }
     if (h->eng.plan->S.prefactor) {                            // the row table of the assemblies that also finish the plan's level 0
         std::vector<int> rt(type, type + n);
@@ -1067,6 +1090,7 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
     }
     h->eng.lanes = h->batch;
     for (int64_t k = 0; k < h->nnzJ; ++k) h->jmap[k] = (int64_t)h->eng.plan->S.src_entry[h->jmap[k] >> 2] * 4 + (h->jmap[k] & 3);
+    if (timing) fprintf(stderr, "[jg nr create] done at                                 %6.1f ms\n", tnow() - tc0);
     *out = h;
     return 0;
 }
@@ -1090,10 +1114,9 @@ void jg_nr_destroy(jg_nr* h) {
     hipFree(h->d_bfrom); hipFree(h->d_bto); hipFree(h->d_bstatus); hipFree(h->d_bparam); hipFree(h->d_outage); hipFree(h->d_post);
     hipFree(h->d_rating); hipFree(h->d_screen); hipFree(h->d_screc);
     hipFree(h->d_rowptr); hipFree(h->d_col); hipFree(h->d_G); hipFree(h->d_B); hipFree(h->d_GB); hipFree(h->d_rowtype); hipFree(h->d_rowtype_pre); hipFree(h->d_type); hipFree(h->d_flags);
-    hipFree(h->d_vm); hipFree(h->d_va); hipFree(h->d_p); hipFree(h->d_q); hipFree(h->d_ppos); hipFree(h->d_pdg);
-    hipFree(h->d_pdb); hipFree(h->d_dst); hipFree(h->d_F); hipFree(h->d_inc); hipFree(h->d_part); hipFree(h->d_normp);
-    hipFree(h->d_normq); hipFree(h->d_params); hipFree(h->d_active); hipFree(h->d_iters); hipFree(h->d_status);
-    hipFree(h->d_counter); hipFree(h->d_vm0); hipFree(h->d_va0); hipFree(h->d_group); hipFree(h->d_lid); hipFree(h->d_dest); hipFree(h->d_cflags); hipFree(h->d_itmp); hipFree(h->d_glist);
+    hipFree(h->d_arena);                                         // V, theta, P, Q, patches, mismatch, increment, norms, lane bookkeeping: one allocation (jg_nr_create)
+    hipFree(h->d_dst);
+    hipFree(h->d_vm0); hipFree(h->d_va0);
     if (h->h_counter) hipHostFree(h->h_counter);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;

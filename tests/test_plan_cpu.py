@@ -8,6 +8,13 @@ from conftest import load_case
 from plan_emulator import Replay, block_jacobian_from_csc
 
 
+@pytest.fixture(autouse=True)
+def _order_check(monkeypatch):
+    """Every plan of this module is built with JG_ORDER_CHECK: each incrementally updated fill count of the min-fill ordering is compared with
+    a recount (jg_symbolic.cpp: elimination_order; a disagreement fails the plan)."""
+    monkeypatch.setenv("JG_ORDER_CHECK", "1")
+
+
 def _oracle_jacobian(oracle, name):
     s = oracle.OracleSystem(load_case(name))
     a = oracle.OracleNR(s)
