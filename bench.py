@@ -564,7 +564,7 @@ def main():
             k["GBps"] = k["bytes"] / (k["ms"] * 1e-3) / 1e9
             k["frac"] = k["GBps"] / HBM_PEAK_GBS
         dom = max(kern, key=lambda k: kern[k]["ms"])
-        names = {"assembly": "k_assemble", "lu": "k_fact_level + k_fact_top (one factorisation)", "solve": "k_bwd_level (one backward sweep)"}
+        names = {"assembly": "k_assemble", "lu": "k_fact_task + k_fact_top (one factorisation: task launches of the bottom levels -- k_fact_level where a plan keeps wave records -- and the multifrontal top)", "solve": "k_bwd_level (one backward sweep)"}
         # HBM bytes per logical launch from the committed PMC passes (profiles/pmc_traffic.json: FETCH_SIZE x2 +
         # WRITE_SIZE, calibrated on a kernel of known byte count); only valid for the grid and batch it was collected at
         traffic = None

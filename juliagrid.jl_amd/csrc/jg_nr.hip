@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -957,7 +958,6 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
     // (round 4: what a first power flow on a grid waits for is the analysis -- 19 of 30 ms on the 10 000-bus grid -- not analysis + the rest).
     int rc = set_device(h);
     if (rc) { delete h; return rc; }
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(2, "jg_nr_create: stream creation failed"); }
     std::vector<int> rp(n + 1), cl(nnz);
     for (int i = 0; i <= n; ++i) rp[i] = (int)(colptr[i] - 1);
     for (int p = 0; p < nnz; ++p) cl[p] = (int)(rowval[p] - 1);
@@ -966,8 +966,11 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
     // plain levels instead of sequential chains (refined steps and fast Newton-Raphson switch the engine back: Engine::jordan)
     h->eng.lanes = h->batch;                                    // (known before the plan is chosen: a handful of scenarios gets a deeper top)
     int eng_rc = 0;
+    std::atomic<int> stream_state{0};                           // 1: h->stream exists, -1: its creation failed (the analysis thread creates it first)
     std::thread eng_thread([&] {
-        if (hipSetDevice(h->device) != hipSuccess) { h->eng.error = "hipSetDevice failed on the analysis thread"; eng_rc = 2; return; }
+        if (hipSetDevice(h->device) != hipSuccess) { h->eng.error = "hipSetDevice failed on the analysis thread"; eng_rc = 2; stream_state = -1; return; }
+        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { h->eng.error = "jg_nr_create: stream creation failed"; eng_rc = 2; stream_state = -1; return; }
+        stream_state = 1;
         eng_rc = h->eng.create((int)n, rp.data(), cl.data(), h->ld, (getenv("JG_NO_PREFACTOR") ? 1LL : 1LL | 4) | 1LL << 49, h->stream);
     });
     struct JoinEng { std::thread& t; ~JoinEng() { if (t.joinable()) t.join(); } } join_eng{eng_thread};     // every early return waits for it before the handle goes
@@ -1025,6 +1028,9 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
         }
     }
     // ---- device upload ----------------------------------------------------------------------
+    while (stream_state.load() == 0) std::this_thread::yield();
+    if (stream_state.load() < 0) { eng_thread.join(); std::string m = h->eng.error; jg_nr_destroy(h); return fail(2, m); }
+    if (getenv("JG_PLAN_TIMING")) fprintf(stderr, "[jg nr create] reference maps done at                  %6.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - tc0);
     std::vector<double> G(nnz), B(nnz);
     for (int p = 0; p < nnz; ++p) { G[p] = yt_reim[2 * p]; B[p] = yt_reim[2 * p + 1]; }
     std::vector<int> colm(nnz);                 // column | existence mask of the 2x2 block entries (row i, col j types)

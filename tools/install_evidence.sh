@@ -25,8 +25,10 @@ cp $G/pmc_${T}_se.json $P/${R}_pmc_se_9241.json
 grep -v "^calibration\|^{" $G/run_pmc_$T.log > $P/${R}_pmc_b512_per_kernel.txt; grep "^calibration\|^{" $G/run_pmc_$T.log >> $P/${R}_pmc_b512_per_kernel.txt
 grep -v "^calibration\|^{" $G/run_pmc_${T}_9241.log > $P/${R}_pmc_9241_b512_per_kernel.txt; grep "^calibration\|^{" $G/run_pmc_${T}_9241.log >> $P/${R}_pmc_9241_b512_per_kernel.txt
 cp $G/run_pmc_${T}_se.log $P/${R}_pmc_se_9241_per_kernel.txt
-for f in setup mid_sweep mid13_launches mid13_task_profile default_launches default_bwd_launches top_fuse mid_se jordan pipeline_variants level_bound_probe; do [ -f $G/${f}_$T.txt ] && cp $G/${f}_$T.txt $P/${R}_${f}.txt; done
+for f in setup mid_sweep mid13_launches mid13_task_profile default_launches default_bwd_launches top_fuse mid_se jordan pipeline_variants level_bound_probe tasks_ab top_task_profile; do [ -f $G/${f}_$T.txt ] && cp $G/${f}_$T.txt $P/${R}_${f}.txt; done
 line $G/bench_25k_$T.json $P/${R}_bench_nr_synth25k_b512.json
 line $G/bench_70k_$T.json $P/${R}_bench_nr_tiled70k_b512.json
 line $G/bench_abi_gather_$T.json $P/${R}_bench_b512_abi_gather_1rank.json
+[ -f $G/bench_240_$T.json ] && line $G/bench_240_$T.json $P/${R}_bench_b512_240steps.json
+[ -f $G/bench_20_$T.json ] && line $G/bench_20_$T.json $P/${R}_bench_b512_driver_flags.json
 git status --short $P | head -60

@@ -21,7 +21,7 @@ def load(path):
 
 
 def short(name):
-    for k in ("k_assemble", "k_fact_level", "k_fact_top", "k_bwd_level", "k_check", "k_compact", "k_lane_permute", "k_lane_copy", "k_lanes_move",
+    for k in ("k_assemble", "k_fact_level", "k_fact_task", "k_fact_top", "k_bwd_level", "k_check", "k_compact", "k_lane_permute", "k_lane_copy", "k_lanes_move",
               "k_gn_rows", "k_gn_gain", "k_gn_hdelta", "k_gn_norm", "k_gn_update", "k_sel_level", "k_gn_project"):
         if k in name:
             if k == "k_assemble":
@@ -71,11 +71,11 @@ def main(fetch_csv, write_csv, n, ld, solves, out_json, grid="case_ACTIVSg10k"):
            "calibration": check, "grid": grid, "batch_ld": ld, "solves": solves, "per_kernel_total": agg}
     per = {}
     for k, a in agg.items():
-        div = {"k_fact_level": solves, "k_fact_top": solves, "k_bwd_level": solves}.get(k, a["launches"] if a["launches"] else 1)
+        div = {"k_fact_level": solves, "k_fact_task": solves, "k_fact_top": solves, "k_bwd_level": solves}.get(k, a["launches"] if a["launches"] else 1)
         per[k] = (a["fetch"] + a["write"]) / div
     per["k_fwd+k_bwd"] = per.get("k_bwd_level", 0.0)
     per["k_assemble"] = per.get("k_assemble<jac>", 0.0)
-    per["k_lu"] = per["k_fact"] = per.get("k_fact_level", 0.0) + per.get("k_fact_top", 0.0)       # one factorisation: level launches + top tasks
+    per["k_lu"] = per["k_fact"] = per.get("k_fact_level", 0.0) + per.get("k_fact_task", 0.0) + per.get("k_fact_top", 0.0)       # one factorisation: level launches (wave records or tasks) + top tasks
     res["traffic_per_logical_launch"] = per          # one assembly pass / one factorisation (all levels) / one backward sweep
     json.dump(res, open(out_json, "w"), indent=1)
     for k, a in sorted(agg.items()):

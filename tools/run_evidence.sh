@@ -34,26 +34,21 @@ done
 cd $REPO
 python tools/pmc_se_summary.py gpurun_out/pmc_${TAG}_se_FETCH_SIZE/p_counter_collection.csv gpurun_out/pmc_${TAG}_se_WRITE_SIZE/p_counter_collection.csv 2 gpurun_out/pmc_${TAG}_se.json > gpurun_out/run_pmc_${TAG}_se.log 2>&1
 for c in case1354pegase case9241synth case_ACTIVSg10k; do python tools/single_latency.py $c 1 2>&1 | tail -1; done > gpurun_out/single_${TAG}.txt
-# round 3: set-up cost (cold / cached plan, pipeline construction), grids beyond 10 000 buses, the ABI gather, the experiments that did not pay
+# set-up cost (cold / cached plan, pipeline construction), grids beyond 10 000 buses, the ABI gather, the experiments that did not pay
 python tools/setup_profile.py 2>&1 | grep -v amdgpu.ids > gpurun_out/setup_${TAG}.txt
 python bench.py --case synth25k --steps 24 --warmup 2 --no-se 2> gpurun_out/bench_25k_${TAG}.err | grep '^{' > gpurun_out/bench_25k_${TAG}.json
 python bench.py --case tiled70k --steps 12 --warmup 2 --no-se 2> gpurun_out/bench_70k_${TAG}.err | grep '^{' > gpurun_out/bench_70k_${TAG}.json
 JG_BENCH_FORCE_DIST=1 JG_BENCH_GATHER=abi python bench.py --steps 96 --no-cpu --no-se 2>/dev/null | grep '^{' > gpurun_out/bench_abi_gather_${TAG}.json
-MID_CFGS="13,4,0 10,6,0 8,4,0 5,4,0 8,4,1" bash tools/mid_sweep.sh case_ACTIVSg10k 512 > gpurun_out/mid_sweep_${TAG}.txt 2>&1
-(export JG_MID_STRUCT=13 JG_MID_MMIN=4; bash tools/trace_levels.sh 512 case_ACTIVSg10k > /dev/null 2>&1; cp gpurun_out/lt_512_fact.txt gpurun_out/mid13_launches_${TAG}.txt; bash tools/top_profile.sh 512 > gpurun_out/mid13_task_profile_${TAG}.txt 2>&1)
 bash tools/trace_levels.sh 512 case_ACTIVSg10k > /dev/null 2>&1; cp gpurun_out/lt_512_fact.txt gpurun_out/default_launches_${TAG}.txt; cp gpurun_out/lt_512_bwd.txt gpurun_out/default_bwd_launches_${TAG}.txt
-for b in 512 64 1; do echo "batch $b: default, then JG_TOP_FUSE=1 (two pivots per barrier)"; python tools/time_kernels.py $b case_ACTIVSg10k 20 | tail -1; JG_TOP_FUSE=1 python tools/time_kernels.py $b case_ACTIVSg10k 20 | tail -1; done > gpurun_out/top_fuse_${TAG}.txt 2>&1
-for c in "" "13 4" "20 4" "26 4"; do set -- $c; echo "SE gain factorisation, JG_MID_STRUCT=${1:-off}"; ( [ -n "$1" ] && export JG_MID_STRUCT=$1 JG_MID_MMIN=$2; python tools/time_se.py 512 2>&1 | grep "rows " | tail -1 ); done > gpurun_out/mid_se_${TAG}.txt 2>&1
-# round 3, second half: Jordan rows + small chains against the plain backward sweep, the pipeline with one top-kernel variant, the timing probes
-for cfg in "1 1" "0 1" "1 0" "0 0"; do set -- $cfg
-  for b in 512 64; do echo "JG_JORDAN=$1 JG_CHAIN_SMALL=$2 $(JG_JORDAN=$1 JG_CHAIN_SMALL=$2 python tools/time_kernels.py $b case_ACTIVSg10k 20 2>&1 | tail -1)"; done
-  for c in case1354pegase case9241synth case_ACTIVSg10k; do echo "JG_JORDAN=$1 JG_CHAIN_SMALL=$2 $(JG_JORDAN=$1 JG_CHAIN_SMALL=$2 python tools/single_latency.py $c 1 2>&1 | tail -1)"; done
-  echo "JG_JORDAN=$1 JG_CHAIN_SMALL=$2 $(JG_JORDAN=$1 JG_CHAIN_SMALL=$2 python tools/time_se.py 512 2>&1 | grep 'rows ' | tail -1)"
-done > gpurun_out/jordan_${TAG}.txt 2>&1
-for v in "JG_X=0" "JG_TOP_PW=0" "JG_TOP_PW=1" "JG_JORDAN=0 JG_CHAIN_SMALL=0"; do
+# round 4: the driver's flags against a long region, the factorisation as tasks against the wave records of round 3, the top tasks' phases
+python bench.py --steps 240 --warmup 3 --no-cpu --no-se 2>/dev/null | grep '^{' > gpurun_out/bench_240_${TAG}.json
+python bench.py --steps 20 --warmup 2 --no-cpu --no-se 2>/dev/null | grep '^{' > gpurun_out/bench_20_${TAG}.json
+for v in "JG_ROW_TASKS=1" "JG_ROW_TASKS=0"; do
+  echo "$v $(env $v python tools/time_kernels.py 512 case_ACTIVSg10k 20 2>&1 | tail -1)"
+  echo "$v $(env $v python tools/time_se.py 512 2>&1 | grep 'rows ' | tail -1)"
   env $v python bench.py --no-cpu --no-se --steps 240 --warmup 3 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', round(d['value']), 'NR it/s', round(d['ms_per_step'], 3), 'ms per step; isolated kernels ms', {k: round(v['ms'], 4) for k, v in d['kernels'].items()})"
-done > gpurun_out/pipeline_variants_${TAG}.txt 2>&1
-bash tools/level_bound_probe.sh > gpurun_out/level_bound_probe_${TAG}.txt 2>&1
+done > gpurun_out/tasks_ab_${TAG}.txt 2>&1
+bash tools/top_profile.sh 512 > gpurun_out/top_task_profile_${TAG}.txt 2>&1
 # raw traces are large: the summaries above are what is kept
 find gpurun_out -name "*.csv" -size +4M -delete; find gpurun_out -name "*.db" -delete; rm -rf gpurun_out/lt_512
 tail -n 4 gpurun_out/run_pmc_${TAG}.log gpurun_out/run_pmc_${TAG}_9241.log gpurun_out/run_pmc_${TAG}_se.log
