@@ -338,6 +338,10 @@ def main():
     ap.add_argument("--merge", type=int, default=0, help="steps solved together in one device batch per GPU (0: as many as bring a shard back to "
                     "512 lanes under strong scaling, i.e. 8 at 64 scenarios per GPU; 1: every step its own device batch)")
     ap.add_argument("--pool", type=int, default=256, help="lanes of the straggler pool (0: every batch finishes its own stragglers in lockstep)")
+    ap.add_argument("--record", choices=("state", "summary"), default="state",
+                    help="what a device batch delivers and a sharded run gathers per scenario: the state record V | theta | iterations | status "
+                         "(2 n + 2 doubles: SURVEY 8(e), the default) or the contingency screen summary (10 doubles: worst loading, largest flow, "
+                         "voltage extremes, iterations, status -- jg_nr_screen)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--no-se", action="store_true", help="skip the config4_se object")
     args = ap.parse_args()
@@ -396,6 +400,12 @@ def main():
     assert base.status == 0
     base_iters = int(base.method.iteration)
     vm0, va0 = base.voltage.magnitude.copy(), base.voltage.angle.copy()
+    screen_rating = None
+    if args.record == "summary":
+        jg.power_(base)
+        sf = np.hypot(base.power.from_.active, base.power.from_.reactive)
+        st_ = np.hypot(base.power.to.active, base.power.to.reactive)
+        screen_rating = np.maximum(1.2 * np.maximum(sf, st_), 0.05)
     # single-instance latency (BASELINE config 2/3 "ms/solve"): the SAME handle again from the case's start point (warm: what the
     # reference's reused analysis is); what a first solve pays on top is reported as setup_ms
     t_single = []
@@ -475,7 +485,11 @@ def main():
     # result records: a ring the pipeline fills (the batch's own scenarios when its main phase ends, its stragglers when their pool
     # has finished them); a record is reused only after its job has been delivered
     ring = len(pipe.handles) + (12 if pipe.pools else 0)
-    packed = [torch.empty((lanes, 2 * n + 2), dtype=torch.float64, device="cuda") for _ in range(ring)]
+    summary = args.record == "summary"
+    width = 10 if summary else 2 * n + 2
+    if summary:                                       # ratings of the screen: the case holds none -- 1.2 x the base-case flow of every branch, floor 0.05 pu
+        pipe.setRating(screen_rating)
+    packed = [torch.empty((lanes, width), dtype=torch.float64, device="cuda") for _ in range(ring)]
 
     # JG_BENCH_GATHER=abi: the collective through the library's own C ABI (jg_comm_*: ncclAllGather of librccl, csrc/jg_comm.cpp) instead of
     # torch.distributed -- what a Julia host calls; rank 0 draws the communicator id, torch only ships its 128 bytes
@@ -484,7 +498,7 @@ def main():
         uid = torch.from_numpy(jg._lib.Comm.unique_id() if rank == 0 else np.zeros(jg._lib.COMM_ID_BYTES, dtype=np.uint8)).cuda()
         dist.broadcast(uid, src=0)
         comm = jg._lib.Comm(rank, world, uid.cpu().numpy(), device=local)
-        gathered = torch.empty((world * lanes, 2 * n + 2), dtype=torch.float64, device="cuda")
+        gathered = torch.empty((world * lanes, width), dtype=torch.float64, device="cuda")
 
     def deliver(job, h):                              # caller's thread, job order: the record is complete -> the ONE collective
         if world > 1 or force_dist:
@@ -500,7 +514,7 @@ def main():
     def run(steps):
         jobs = -(-steps // merge)                     # device batches; the last one may hold fewer real steps: its spare lanes are
         out = pipe.run([None] * jobs, iteration=20, tolerance=1e-8, on_done=deliver,      # solved (and timed) but not counted
-                       record=lambda j: packed[j % ring].data_ptr(), records=ring)
+                       record=lambda j: packed[j % ring].data_ptr(), records=ring, summary=summary)
         real = [min(merge, steps - j * merge) * B for j in range(jobs)]
         return int(sum(int(np.sum(it[:r])) for (it, _), r in zip(out, real))), out[-1][1][:B]
 
@@ -611,6 +625,9 @@ def main():
                                          f"a region is {-(-args.steps // merge)} device batch(es) with {len(pipe.handles)} in flight: it measures the fill and drain of the pipeline, "
                                          "not its steady state -- more --steps per region (or --merge 1 for narrower batches) changes that, the K of the caller is kept as given"),
                        "gather": "abi" if comm is not None else "torch.distributed",
+                       "record": ("screen summary, 10 doubles per scenario (jg_nr_screen: worst loading against 1.2 x the base-case flows, largest flow, voltage extremes, "
+                                  "iterations, status), reduced on the device by the handle that finished the scenario") if summary else
+                                 f"state record, 2 n + 2 = {2 * n + 2} doubles per scenario (V | theta | iterations | status)",
                        "parallelism": f"scenario-sharded x{world}, one RCCL all-gather of the packed results per device batch "
                                       f"({merge} step(s) of {B} scenarios per GPU)",
                        "scenario_selection": f"the first {total} solvable contingencies of a seeded shuffle of the non-bridge branches; "

@@ -927,6 +927,10 @@ packResults!(b::NewtonRaphsonBatch, record::Ptr{Float64}) =
 "rows `rows` (0-based) of a record another batch owns <- lanes lane0 + 1 : lane0 + length(rows) of this pool (jg_nr_pack_rows_device)"
 packRows!(pool::NewtonRaphsonBatch, record::Ptr{Float64}, lane0::Int, rows::Vector{Int32}) =
     check(ccall((:jg_nr_pack_rows_device, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Int32}), pool.handle.ptr, record, lane0, length(rows), rows))
+"rows `rows` (0-based) of a screen-summary record ([10, .] doubles, screenSummary) another batch owns <- the summaries of lanes lane0 + 1 : lane0 + length(rows)
+of this pool (jg_nr_screen_rows_device); the pool's branch table, ratings and outage labels must be set (screenSummary / setOutage! on the pool)"
+screenRows!(pool::NewtonRaphsonBatch, record::Ptr{Float64}, lane0::Int, rows::Vector{Int32}) =
+    check(ccall((:jg_nr_screen_rows_device, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Int32}), pool.handle.ptr, record, lane0, length(rows), rows))
 
 "the collective for a record that is already packed: `count` doubles per rank from device pointer `send` into `recv` [count, world]"
 allgatherDevice(comm::Comm, send::Ptr{Float64}, recv::Ptr{Float64}, count::Int) =

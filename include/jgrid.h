@@ -203,10 +203,13 @@ int jg_nr_bus_injection(jg_nr* h, double* inj_pq);
  * Ties go to the lowest index.  The branch that is out of service in a scenario (jg_nr_set_outage_labels) does not count there.
  * jg_nr_set_screen: rating [nb] in pu of apparent power (branch.flow.maxFromBus / maxToBus of type 2, src/powerSystem/branch.jl:29-37), 0 = no limit, NULL = none;
  *   needs jg_nr_set_branches.  jg_nr_screen: rec [batch][10] to the host; jg_nr_screen_device: into a device buffer (the operand of jg_comm_allgather_device).
+ * jg_nr_screen_rows_device: the summaries of lanes lane0 .. lane0 + count - 1 into rows rows[0 .. count) of a [.][10] device record (a pool handle returns the
+ *   stragglers it finished to the record of the batch they came from, like jg_nr_pack_rows_device does for the state record).
  */
 int jg_nr_set_screen(jg_nr* h, const double* rating);
 int jg_nr_screen(jg_nr* h, double* rec);
 int jg_nr_screen_device(jg_nr* h, double* rec_dev);
+int jg_nr_screen_rows_device(jg_nr* h, double* rec_dev, int64_t lane0, int64_t count, const int32_t* rows);
 
 /* Measurement hooks (HIP events on the handle's own stream).
  * kernel: 0 fused mismatch+Jacobian assembly, 1 LU refactorization + fused forward elimination (all

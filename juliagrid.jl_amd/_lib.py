@@ -88,6 +88,7 @@ def lib():
         "jg_nr_set_screen": [VP, VP],
         "jg_nr_screen": [VP, F64P],
         "jg_nr_screen_device": [VP, VP],
+        "jg_nr_screen_rows_device": [VP, VP, C.c_int64, C.c_int64, I32P],
         "jg_gn_create": [C.POINTER(VP), C.c_int64, I64P, I64P, F64P, F64P, C.c_int64, I64P, I64P, F64P, C.c_int64, C.c_int64,
                          I8P, I8P, I64P, C.c_int64, I64P, C.c_int64, C.c_int],
         "jg_gn_dims": [VP, I64P],

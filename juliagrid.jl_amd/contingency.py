@@ -168,12 +168,28 @@ class ContingencyPipeline:
             p.handle.close()
         self.handles, self.pools = [], []
 
-    def run(self, jobs, iteration: int = 20, tolerance: float = 1e-8, on_done=None, fetch: bool = False, record=None, records: int = 0):
+    def setRating(self, rating):
+        """Branch ratings (pu of apparent power, 0 = no limit) of the screen summaries (`run(..., summary=True)`), on every handle."""
+        from .powerflow import _upload_branches
+        r = None if rating is None else np.ascontiguousarray(np.asarray(rating, dtype=np.float64))
+        if r is not None and r.shape != (self.system.branch.number,):
+            raise ValueError("rating: one value per branch")
+        for an in self.handles + [p.handle for p in self.pools]:
+            if not an._branches_on_device:
+                _upload_branches(an)
+            _lib.check(_lib.lib().jg_nr_set_screen(an._h, None if r is None else r.ctypes.data))
+            an._screen_rating = r
+
+    def run(self, jobs, iteration: int = 20, tolerance: float = 1e-8, on_done=None, fetch: bool = False, record=None, records: int = 0,
+            summary: bool = False):
         """jobs: sequence of label lists (one batch each; None = keep the handle's current outages).
         record: optional callable job -> DEVICE pointer of a [batch, 2 n + 2] float64 buffer; the job's result record
         (V | theta | iterations | status per scenario) is complete in it when on_done(job, .) is called.  The caller owns a
         ring of `records` such buffers (record(j) and record(j + records) may be the same memory): job j + records is not
-        written before on_done(j) has returned.  Returns per-job (iterations, status) arrays."""
+        written before on_done(j) has returned.  Returns per-job (iterations, status) arrays.
+        summary: the record is the SCREEN SUMMARY instead ([batch, 10] float64 per job: powerflow.screenSummary_ -- worst branch loading against
+        setRating's limits, largest flow, voltage extremes, iterations, status), reduced on the device by the handle that finished the scenario:
+        what a sharded screen gathers is 80 bytes per scenario, not 16 n + 16."""
         jobs = list(jobs)
         nj = len(jobs)
         results = [None] * nj
@@ -216,7 +232,10 @@ class ContingencyPipeline:
                         results[j][0][home] = it[off:off + home.size]
                         results[j][1][home] = st[off:off + home.size]
                         if record is not None:
-                            p.handle.pack_rows_device(record(j), off, home)
+                            if summary:
+                                p.handle.screen_rows_device(record(j), off, home)
+                            else:
+                                p.handle.pack_rows_device(record(j), off, home)
                         pool_done[j].set()
                     p.routes = []                                 # no lock: a worker may hold it while it waits for this pool; submit() sees
                     p.fill = 0                                    # either queued (skips) or an empty pool (skips)
@@ -258,6 +277,7 @@ class ContingencyPipeline:
                                 if errors:
                                     return
                                 home = p.handle.take_lanes(an, p.fill)
+                                p.handle._outage_labels[p.fill:p.fill + home.size] = an._outage_labels[home]     # (the screen summary leaves the branch that is out aside)
                                 pool_done[j] = threading.Event()
                                 p.routes.append((j, home, p.fill))
                                 p.fill += home.size
@@ -268,7 +288,10 @@ class ContingencyPipeline:
                         powerFlow_(an, iteration=iteration, tolerance=tolerance, fetch=fetch)
                     results[j] = (np.array(an.method.iteration), np.array(an.status))
                     if record is not None:
-                        an.pack_results_device(record(j))
+                        if summary:
+                            an.screen_device(record(j))
+                        else:
+                            an.pack_results_device(record(j))
                     main_done[j].set()
                     if use_pool or record is not None and on_done is None:
                         released[j].set()                         # nothing of this job lives in the handle any more

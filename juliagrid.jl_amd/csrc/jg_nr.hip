@@ -1895,6 +1895,26 @@ int jg_nr_screen_device(jg_nr* h, double* rec_dev) {
     return 0;
 }
 
+// rows of a summary record from a range of lanes (the stragglers a pool finished: jg_nr_pack_rows_device's counterpart)
+__global__ void k_screen_rows(const double* screc, const int* rows, double* dst, int lane0, int count) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count * 10) return;
+    const int i = t / 10, c = t - i * 10;
+    dst[(size_t)rows[i] * 10 + c] = screc[(size_t)(lane0 + i) * 10 + c];
+}
+
+int jg_nr_screen_rows_device(jg_nr* h, double* rec_dev, int64_t lane0, int64_t count, const int32_t* rows) {
+    if (!h || !rec_dev || !rows || lane0 < 0 || count < 0 || lane0 + count > h->batch) return fail(1, "jg_nr_screen_rows_device: bad argument");
+    if (count == 0) return 0;
+    if (int rc = set_device(h)) return rc;
+    if (int rc = screen_launch(h)) return rc;
+    NR_HIP(hipMemcpyAsync(h->d_itmp, rows, (size_t)count * 4, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_screen_rows, dim3((unsigned)((count * 10 + 255) / 256)), dim3(256), 0, h->stream, h->d_screc, h->d_itmp, rec_dev, (int)lane0, (int)count);
+    NR_HIP(hipGetLastError());
+    NR_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 int jg_nr_time_kernel(jg_nr* h, int kernel, int reps, double* mean_ms) {
     if (!h || reps < 1 || !mean_ms || kernel < 0 || kernel > 3) return fail(1, "jg_nr_time_kernel: bad argument");
     if (h->fast && kernel < 2) return fail(1, "jg_nr_time_kernel: assembly / factorisation timing would overwrite the constant factor of a fast Newton-Raphson handle");

@@ -200,6 +200,23 @@ class AcPowerFlow:
         rows = np.ascontiguousarray(rows, dtype=np.int32)
         _lib.check(_lib.lib().jg_nr_pack_rows_device(self._h, C.c_void_p(dst_ptr), int(lane0), int(rows.size), rows))
 
+    def screen_device(self, dst_ptr: int):
+        """[batch, 10] screen summaries (screenSummary_; ratings as last set) into a caller-owned DEVICE buffer."""
+        L = _lib.lib()
+        if not self._branches_on_device:
+            _upload_branches(self)
+        _lib.check(L.jg_nr_set_outage_labels(self._h, np.ascontiguousarray(self._outage_labels, dtype=np.int64)))
+        _lib.check(L.jg_nr_screen_device(self._h, C.c_void_p(dst_ptr)))
+
+    def screen_rows_device(self, dst_ptr: int, lane0: int, rows):
+        """Screen summaries (screenSummary_) of lanes lane0 .. lane0 + len(rows) - 1 into rows `rows` of a [., 10] DEVICE record."""
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        L = _lib.lib()
+        if not self._branches_on_device:
+            _upload_branches(self)
+        _lib.check(L.jg_nr_set_outage_labels(self._h, np.ascontiguousarray(self._outage_labels, dtype=np.int64)))
+        _lib.check(L.jg_nr_screen_rows_device(self._h, C.c_void_p(dst_ptr), int(lane0), int(rows.size), rows))
+
     def time_kernel(self, kernel: int, reps: int = 10) -> float:
         ms = C.c_double(0.0)
         _lib.check(_lib.lib().jg_nr_time_kernel(self._h, int(kernel), int(reps), C.byref(ms)))

@@ -86,3 +86,12 @@ def test_bench_region_statistics_at_one_gpu():
     assert d["n_gpus"] == 1 and d["region_repeats"] >= 3 and d["config"]["pipeline_steady_state"] is True
     assert d["region_ms_max"] < 1.5 * d["region_ms_min"], "regions of the same work on an otherwise idle GPU"
     assert d["region_repeats"] * d["region_ms_median"] > 500.0 or d["region_repeats"] == 50
+
+
+def test_bench_gathers_screen_summaries_with_two_ranks():
+    """`--record summary`: a device batch delivers the 10-double screen summary per scenario (reduced on the device, stragglers' rows by their pool handle)
+    and that is what the ranks gather -- 80 bytes per scenario instead of 16 n + 16; two ranks over gloo, and one rank through the C ABI's RCCL gather."""
+    d = _bench(["--gpus", "2", "--steps", "4", "--warmup", "1", "--no-cpu", "--no-se", "--record", "summary"], JG_BENCH_BACKEND="gloo", JG_BENCH_MAX_REPEATS="3")
+    assert d["n_gpus"] == 2 and d["config"]["record"].startswith("screen summary") and d["value"] > 0 and d["converged_fraction"] == 1.0
+    d1 = _bench(["--steps", "4", "--warmup", "1", "--no-cpu", "--no-se", "--record", "summary"], JG_BENCH_FORCE_DIST="1", JG_BENCH_GATHER="abi", JG_BENCH_MAX_REPEATS="3")
+    assert d1["config"]["record"].startswith("screen summary") and d1["config"].get("gather") == "abi" and d1["converged_fraction"] == 1.0

@@ -78,3 +78,55 @@ def test_summary_into_a_device_record(jg):
     assert np.array_equal(r[:, 8], an.method.iteration.astype(float)) and np.array_equal(r[:, 9], an.status.astype(float))
     assert (2 * s.bus.number + 2) / 10 > 250, "the gather shrinks by the ratio of the state record to the summary"
     an.close()
+
+
+@pytest.mark.parametrize("name,batch,njobs,pool", [("case1354pegase", 192, 4, 128), ("case_ACTIVSg10k", 512, 3, 256)])
+def test_pipeline_delivers_summary_records(jg, name, batch, njobs, pool):
+    """ContingencyPipeline.run(summary=True): the record of a job is [batch, 10] screen summaries, the stragglers' rows written by the pool handle that
+    finished them (jg_nr_screen_rows_device) -- bitwise what the lockstep pipeline and a plain batch + screenSummary_ give."""
+    import torch
+    t = load_case(name)
+    s = jg.powerSystem(t)
+    base = jg.newtonRaphson(s)
+    jg.powerFlow_(base)
+    start = (base.voltage.magnitude.copy(), base.voltage.angle.copy())
+    jg.power_(base)
+    flow0 = np.maximum(np.hypot(base.power.from_.active, base.power.from_.reactive), np.hypot(base.power.to.active, base.power.to.reactive))
+    rating = np.maximum(1.1 * flow0, 0.05)
+    base.close()
+    labels = jg.outageList(s, batch * njobs, seed=5)
+    jobs = [labels[i * batch:(i + 1) * batch] for i in range(njobs)]
+    out = {}
+    for mode in ("lockstep", "pool"):
+        pipe = jg.ContingencyPipeline(s, batch, inflight=3, start=start, pool=pool if mode == "pool" else 0)
+        pipe.setRating(rating)
+        ring = 4 if mode == "pool" else njobs
+        rec = [torch.zeros((batch, 10), dtype=torch.float64, device="cuda") for _ in range(ring)]
+        seen = []
+
+        def on_done(j, an, rec=rec, ring=ring, seen=seen):
+            seen.append(rec[j % ring].clone())
+            torch.cuda.current_stream().synchronize()
+
+        res = pipe.run(jobs, iteration=20, tolerance=1e-8, on_done=on_done, record=lambda j: rec[j % ring].data_ptr(), records=ring, summary=True)
+        out[mode] = (res, [r.cpu().numpy() for r in seen])
+        pipe.close()
+    moved = 0
+    for j in range(njobs):
+        ra, rb = out["lockstep"][1][j], out["pool"][1][j]
+        assert np.array_equal(ra, rb)
+        it, st = out["pool"][0][j]
+        assert np.array_equal(rb[:, 8], it.astype(float)) and np.array_equal(rb[:, 9], st.astype(float)) and not np.any(st == 4)
+        moved += int(np.sum(it > np.median(it)))
+    assert moved > 0
+    # job 0 as a plain batch from the case's own start point: the converged states agree to the solver's tolerance, so do the summaries
+    an = jg.contingencyAnalysis(s, jobs[0])
+    jg.powerFlow_(an)
+    ref = jg.screenSummary_(an, rating=rating)
+    r0 = out["pool"][1][0]
+    ok = ref.status == 0
+    assert np.array_equal(r0[:, 9], ref.status.astype(float))
+    assert np.abs(r0[:, 0][ok] - ref.loading[ok]).max() <= 1e-6 * max(1.0, ref.loading[ok].max())
+    assert np.abs(r0[:, 2][ok] - ref.flow[ok]).max() <= 1e-6 * max(1.0, ref.flow[ok].max())
+    assert np.abs(r0[:, 4][ok] - ref.minMagnitude[ok]).max() <= 1e-6 and np.abs(r0[:, 6][ok] - ref.maxMagnitude[ok]).max() <= 1e-6
+    an.close()
