@@ -24,6 +24,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -967,12 +968,14 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
     h->eng.lanes = h->batch;                                    // (known before the plan is chosen: a handful of scenarios gets a deeper top)
     int eng_rc = 0;
     std::atomic<int> stream_state{0};                           // 1: h->stream exists, -1: its creation failed (the analysis thread creates it first)
-    std::thread eng_thread([&] {
+    auto eng_work = [&] {
         if (hipSetDevice(h->device) != hipSuccess) { h->eng.error = "hipSetDevice failed on the analysis thread"; eng_rc = 2; stream_state = -1; return; }
         if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { h->eng.error = "jg_nr_create: stream creation failed"; eng_rc = 2; stream_state = -1; return; }
         stream_state = 1;
         eng_rc = h->eng.create((int)n, rp.data(), cl.data(), h->ld, (getenv("JG_NO_PREFACTOR") ? 1LL : 1LL | 4) | 1LL << 49, h->stream);
-    });
+    };
+    std::thread eng_thread;
+    try { eng_thread = std::thread(eng_work); } catch (const std::system_error&) { eng_work(); }     // no thread to be had: the analysis first, then the rest
     struct JoinEng { std::thread& t; ~JoinEng() { if (t.joinable()) t.join(); } } join_eng{eng_thread};     // every early return waits for it before the handle goes
     // transpose permutation of the (structurally symmetric) pattern: tperm[p of (r,c)] = pointer of (c,r)
     h->tperm.assign(nnz, -1);
@@ -981,7 +984,7 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
             const int64_t r = rowval[p] - 1;
             int64_t lo = colptr[r] - 1, hi = colptr[r + 1] - 2, q = -1;
             while (lo <= hi) { int64_t m = (lo + hi) >> 1; if (rowval[m] - 1 < c) lo = m + 1; else if (rowval[m] - 1 > c) hi = m - 1; else { q = m; break; } }
-            if (q < 0) { eng_thread.join(); jg_nr_destroy(h); return fail(1, "jg_nr_create: Ybus pattern is not structurally symmetric"); }
+            if (q < 0) { if (eng_thread.joinable()) eng_thread.join(); jg_nr_destroy(h); return fail(1, "jg_nr_create: Ybus pattern is not structurally symmetric"); }
             h->tperm[p] = (int)q;
         }
     // ---- newtonJacobian (acPowerFlow.jl:89-175), integer only -------------------------------
@@ -1029,7 +1032,7 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
     }
     // ---- device upload ----------------------------------------------------------------------
     while (stream_state.load() == 0) std::this_thread::yield();
-    if (stream_state.load() < 0) { eng_thread.join(); std::string m = h->eng.error; jg_nr_destroy(h); return fail(2, m); }
+    if (stream_state.load() < 0) { if (eng_thread.joinable()) eng_thread.join(); std::string m = h->eng.error; jg_nr_destroy(h); return fail(2, m); }
     if (getenv("JG_PLAN_TIMING")) fprintf(stderr, "[jg nr create] reference maps done at                  %6.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - tc0);
     std::vector<double> G(nnz), B(nnz);
     for (int p = 0; p < nnz; ++p) { G[p] = yt_reim[2 * p]; B[p] = yt_reim[2 * p + 1]; }
@@ -1045,7 +1048,7 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
     // consistency of the two value arrays the reference keeps (T1): yT[p] must equal y[tperm[p]]
     for (int p = 0; p < nnz; ++p)
         if (y_reim[2 * (size_t)h->tperm[p]] != yt_reim[2 * p] || y_reim[2 * (size_t)h->tperm[p] + 1] != yt_reim[2 * p + 1]) {
-            eng_thread.join(); jg_nr_destroy(h); return fail(4, "jg_nr_create: nodalMatrix and nodalMatrixTranspose disagree (stale model)");
+            if (eng_thread.joinable()) eng_thread.join(); jg_nr_destroy(h); return fail(4, "jg_nr_create: nodalMatrix and nodalMatrixTranspose disagree (stale model)");
         }
     std::vector<signed char> flags(n);
     for (int i = 0; i < n; ++i) flags[i] = (signed char)((type[i] != 3 ? 1 : 0) | (type[i] == 1 ? 2 : 0));
@@ -1053,7 +1056,7 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
     std::vector<signed char> tp(type, type + n);
     if (jg::upload(&h->d_rowptr, rp, err, h->stream) || jg::upload(&h->d_col, colm, err, h->stream) || jg::upload(&h->d_G, G, err, h->stream) ||
         jg::upload(&h->d_B, B, err, h->stream) || jg::upload(&h->d_GB, GBv, err, h->stream) || jg::upload(&h->d_rowtype, std::vector<int>(type, type + n), err, h->stream) || jg::upload(&h->d_type, tp, err, h->stream) || jg::upload(&h->d_flags, flags, err, h->stream)) {
-        eng_thread.join(); jg_nr_destroy(h); return fail(2, err);
+        if (eng_thread.joinable()) eng_thread.join(); jg_nr_destroy(h); return fail(2, err);
     }
     h->nchunk = (h->n + ASM_ROWS - 1) / ASM_ROWS;
     const size_t ld = h->ld;
@@ -1076,16 +1079,16 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
         size_t off = 0;
         for (const Part& q : parts) { *q.p = (char*)h->d_arena + off; off += (q.bytes + 255) / 256 * 256; }
     }
-    if (!ok) { eng_thread.join(); jg_nr_destroy(h); return fail(2, "jg_nr_create: device allocation failed"); }
+    if (!ok) { if (eng_thread.joinable()) eng_thread.join(); jg_nr_destroy(h); return fail(2, "jg_nr_create: device allocation failed"); }
     if (jg::sync_fill(h->d_ppos, 0xff, mpn * ld * 4, h->stream) != hipSuccess ||     // -1 = no patch
         hipHostMalloc((void**)&h->h_counter, sizeof(int)) != hipSuccess) {
-        eng_thread.join(); jg_nr_destroy(h); return fail(2, "jg_nr_create: pinned allocation failed");
+        if (eng_thread.joinable()) eng_thread.join(); jg_nr_destroy(h); return fail(2, "jg_nr_create: pinned allocation failed");
     }
-    if (hipHostGetDevicePointer((void**)&h->h_counter_dev, h->h_counter, 0) != hipSuccess) { eng_thread.join(); jg_nr_destroy(h); return fail(2, "jg_nr_create: pinned host word is not device-visible"); }
+    if (hipHostGetDevicePointer((void**)&h->h_counter_dev, h->h_counter, 0) != hipSuccess) { if (eng_thread.joinable()) eng_thread.join(); jg_nr_destroy(h); return fail(2, "jg_nr_create: pinned host word is not device-visible"); }
     const bool timing = getenv("JG_PLAN_TIMING") != nullptr;
     auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     if (timing) fprintf(stderr, "[jg nr create] maps, model upload, state arena done at %6.1f ms\n", tnow() - tc0);
-    eng_thread.join();
+    if (eng_thread.joinable()) eng_thread.join();
     if (timing) fprintf(stderr, "[jg nr create] engine joined at                        %6.1f ms\n", tnow() - tc0);
     if (eng_rc) { std::string m = h->eng.error; jg_nr_destroy(h); return fail(eng_rc, m); }
     if (jg::upload(&h->d_dst, h->eng.plan->S.src_entry, err, h->stream)) { jg_nr_destroy(h); return fail(2, err); }

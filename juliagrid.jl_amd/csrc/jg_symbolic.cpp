@@ -8,6 +8,7 @@
 #include <type_traits>
 #include <iterator>
 #include <queue>
+#include <system_error>
 #include <thread>
 #include <cstdio>
 #include <cstdlib>
@@ -260,6 +261,12 @@ int find_in_row(const BlockSymbolic& S, int r, int c) {
 
 int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
+// A helper thread where the host can give one (std::thread throws when it cannot: the C ABI above must never see that) -- else the work runs right here.
+template <class F>
+std::thread spawn_or_run(F&& f) {
+    try { return std::thread(f); } catch (const std::system_error&) { f(); return std::thread(); }
+}
+
 // Levels -> segments -> chunks -> wave records.  `level[i]` (1-based; 0 = not scheduled) and `work[i]` (terms) per item;
 // `emit(item, first_term_slot q0, stride, out)` fills one wave's records.
 struct NoExtra { void operator()(int, std::vector<Segment>&, std::vector<Rec>&) const {} };
@@ -346,9 +353,10 @@ void build_replay(const std::vector<int>& level, const std::vector<int>& work, i
         std::vector<std::vector<Rec>> lrecs(nlev + 1);
         std::atomic<int> next{1};
         std::vector<std::thread> pool;
-        for (int t = 0; t < nthreads; ++t)
-            pool.emplace_back([&] { for (int l = next.fetch_add(1); l <= nlev; l = next.fetch_add(1)) do_level(l, lsegs[l], lrecs[l]); });
-        for (std::thread& t : pool) t.join();
+        auto take = [&] { for (int l = next.fetch_add(1); l <= nlev; l = next.fetch_add(1)) do_level(l, lsegs[l], lrecs[l]); };
+        for (int t = 1; t < nthreads; ++t) pool.push_back(spawn_or_run(take));
+        take();
+        for (std::thread& t : pool) if (t.joinable()) t.join();
         const double r1 = rnow();
         size_t total = 0;
         for (int l = 1; l <= nlev; ++l) total += lrecs[l].size();
@@ -855,9 +863,9 @@ void build_tables(BlockSymbolic& S) {
         };
         {
             std::vector<std::thread> pool;
-            for (int t = 1; t < nthr; ++t) pool.emplace_back(worker);
+            for (int t = 1; t < nthr; ++t) pool.push_back(spawn_or_run(worker));
             worker();
-            for (std::thread& t : pool) t.join();
+            for (std::thread& t : pool) if (t.joinable()) t.join();
         }
         for (int l = 1; l <= nlev; ++l) {
             LevelOut& o = outs[l];
@@ -872,7 +880,7 @@ void build_tables(BlockSymbolic& S) {
     const bool timing = getenv("JG_PLAN_TIMING") != nullptr;
     auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tb0 = tnow();
-    std::thread fact_thread([&] {
+    std::thread fact_thread = spawn_or_run([&] {
         if (S.fact_tasks) build_fact_tasks();
         else build_replay(level, work, FACT_T, S.fact_seg, S.fact_rec, S.n_fact_levels, fill_fact, NoExtra(), 0, FACT_WAVES, locp);
         if (timing) fprintf(stderr, "[jg plan]   factorisation tables done at %6.1f ms\n", tnow() - tb0);
@@ -881,7 +889,7 @@ void build_tables(BlockSymbolic& S) {
     // level 0 of a prefactor plan as tables of its own (for producers that deliver plain blocks): D(k) and y_k of the pivots
     // nobody updates -- and the forward-only tables: a thread of their own as well (round 4: the analysis is what a cold power flow waits for)
     S.pre_pivot.assign(n, 0); S.pre_seg.clear(); S.pre_rec.clear(); S.n_pre_levels = 0;
-    std::thread side_thread([&] {
+    std::thread side_thread = spawn_or_run([&] {
     if (S.prefactor) {
         std::vector<int> plevel(nE + n, 0), pwork(nE + n, 0);
         for (int k = 0; k < n; ++k)
