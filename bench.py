@@ -66,7 +66,7 @@ def load_tables(jg, case):
     if case == "synth25k":                       # stand-ins for the reference's 25 000 / 70 000-bus datasets (not shipped): tests/test_big_grids_gpu.py
         from juliagrid.jl_amd.synthetic import pegaseShaped
         return {k: np.array(v) for k, v in pegaseShaped(n=25000, nb=int(25000 * 16049 / 9241), ng=int(25000 * 1445 / 9241), seed=25000, load_scale=0.1).items()}
-    if case == "tiled70k":
+    if case in ("tiled70k", "tiled90k"):         # (tiled90k: nine instances tied to the first one -- for the 82 000-bus set)
         from juliagrid.jl_amd.synthetic import tiledGrid
         t = load_tables(jg, "case_ACTIVSg10k")
         one = jg.newtonRaphson(jg.powerSystem(t))
@@ -75,7 +75,7 @@ def load_tables(jg, case):
         slack = int(np.flatnonzero(np.asarray(one.system.bus.layout.type) == 3)[0])
         p_slack = float(np.asarray(one.power.supply.active).reshape(-1)[slack])
         one.close()
-        return tiledGrid(t, 7, slack_active=p_slack)
+        return tiledGrid(t, 9, slack_active=p_slack, star=True) if case == "tiled90k" else tiledGrid(t, 7, slack_active=p_slack)
     with np.load(os.path.join(ROOT, "tests", "golden", "cases", case + ".npz")) as z:
         return {k: z[k] for k in z.files}
 

@@ -159,7 +159,7 @@ def case9241synth():
     return pegaseShaped(**PEGASE9241)
 
 
-def tiledGrid(tables, copies, slack_active=None, seed=0, jitter=0.005, tie_x=0.05):
+def tiledGrid(tables, copies, slack_active=None, seed=0, jitter=0.005, tie_x=0.05, star=False):
     """A grid of `copies` x n buses built from a solved case: `copies` instances of `tables`, the slack bus of instance c tied to the
     slack bus of instance c + 1 by one line (x = tie_x pu), ONE slack (instance 0; the other former slack buses become PV buses whose
     unit produces `slack_active` = the slack's active OUTPUT in the solved single case, pu -- the caller computes it, e.g. from
@@ -183,7 +183,7 @@ def tiledGrid(tables, copies, slack_active=None, seed=0, jitter=0.005, tie_x=0.0
     br["br_to"] = br["br_to"] + off_b
     br["br_x"] = br["br_x"] * (1.0 + jitter * (2.0 * rng.random(copies * nb) - 1.0))
     ties = copies - 1
-    tie = {"br_from": np.array([c * n + slack for c in range(ties)], dtype=np.int64),
+    tie = {"br_from": np.array([(0 if star else c) * n + slack for c in range(ties)], dtype=np.int64),     # star: every instance tied to instance 0, else a chain
            "br_to": np.array([(c + 1) * n + slack for c in range(ties)], dtype=np.int64),
            "br_status": np.ones(ties, dtype=np.int8), "br_r": np.full(ties, 0.1 * tie_x), "br_x": np.full(ties, tie_x),
            "br_g": np.zeros(ties), "br_b": np.zeros(ties), "br_tap": np.ones(ties), "br_shift": np.zeros(ties)}

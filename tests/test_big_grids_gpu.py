@@ -2,6 +2,7 @@
 (docs/src/examples/powerSystemDatasets.md:13-15) that it does not ship.  Stand-ins of that size, both seeded:
   * 25 000 buses   juliagrid.jl_amd.synthetic.pegaseShaped(n = 25 000)           (the generator behind case9241synth)
   * 70 000 buses   juliagrid.jl_amd.synthetic.tiledGrid(case_ACTIVSg10k, 7)      (seven tied instances of the shipped 10k grid)
+  * 90 000 buses   tiledGrid(case_ACTIVSg10k, 9, star = True)                    (for the 82 000-bus set: nine instances tied to the first one)
 Checked: the oracle converges; single-instance NR parity on the GPU (iteration count equal, V / theta 1e-8); a 512-scenario N-1 batch
 fits and runs (symbolic analysis, int32 tables, top-task caps, memory at that size), spot-checked against the oracle."""
 import numpy as np
@@ -23,10 +24,10 @@ def big_tables(oracle, which):
     vm, va = o.voltage()
     slack = int(np.flatnonzero(t["bus_type"] == 3)[0])
     p_slack = oracle.exact_quantities(oracle.OracleSystem(t), vm, va)[1][slack, 0] + t["bus_pd"][slack]
-    return tiledGrid(t, 7, slack_active=p_slack)
+    return tiledGrid(t, 9, slack_active=p_slack, star=True) if which == "tiled90k" else tiledGrid(t, 7, slack_active=p_slack)
 
 
-@pytest.mark.parametrize("which,n", [("synth25k", 25000), ("tiled70k", 70000)])
+@pytest.mark.parametrize("which,n", [("synth25k", 25000), ("tiled70k", 70000), ("tiled90k", 90000)])
 def test_single_instance_and_batch_on_a_big_grid(jg, oracle, which, n):
     t = big_tables(oracle, which)
     assert t["bus_type"].size == n
