@@ -902,7 +902,7 @@ __global__ __launch_bounds__(64 * TASK_WAVES, 4) void k_fact_task(FactArgs a) {
     }
 }
 
-// TIMING PROBES of a pivot step (compile with -DJG_PROBE_TOP=1: the next pivot's row / column are not published, =2: one block update per
+// TIMING PROBES of a pivot step (compile with -DJG_PROBE_TOP=1: the next pivot's row / column are not published, =3: the bulk threads take the published row as D^-1 U(q, .) -- no pivot read, no solve --, =2: one block update per
 // thread instead of CLS x CLS; wrong numbers -- tools/level_bound_probe.sh): what a step is made of.
 #ifndef JG_PROBE_TOP
 #define JG_PROBE_TOP 0
@@ -1161,7 +1161,7 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
     for (int qv = q_done; qv < m; ++qv) {
         const int q = uniform(qv);                               // the step number is wave-uniform: which row / column class publishes, the
         const int cur = FUSE ? (q >> 1) & 1 : q & 1, nxt = cur ^ 1;   // LDS buffer in use and the lane of the next pivot are scalar decisions
-        Blk D = lds_get(Dbuf[cur], 0);
+        Blk D = (JG_PROBE_TOP == 3 && !pivot_wave) ? Blk{1.0, 0.0, 0.0, 1.0} : lds_get(Dbuf[cur], 0);     // (probe 3: what a published D^-1 U(q, .) would save)
         D = Blk{uniform_d(D.v00), uniform_d(D.v01), uniform_d(D.v10), uniform_d(D.v11)};   // the same block in every lane: scalar registers
         const int sw = uniform(D.v10 > 2.0 ? 1 : 0);
         const double dl = D.v10 - 4.0 * sw;
@@ -1179,7 +1179,7 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
             for (int r = 0; r < CLS; ++r) Lq[r] = lds_get(Lbuf[cur], r * 16 + gi);
 #pragma unroll
             for (int c = 0; c < CLS; ++c) {
-                const Blk z = zcol(Ubuf[cur], c * 16 + gj);
+                const Blk z = JG_PROBE_TOP == 3 ? lds_get(Ubuf[cur], c * 16 + gj) : zcol(Ubuf[cur], c * 16 + gj);
 #pragma unroll
                 for (int r = 0; r < CLS; ++r) if (JG_PROBE_TOP != 2 || (r == 0 && c == 0)) blk_sub(T[r][c], Lq[r], z);
             }
