@@ -368,6 +368,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    # stdout carries the ONE JSON line and nothing else: whatever a library writes to file descriptor 1 while the bench runs (RCCL prints a version
+    # banner through C stdio when a communicator is born) goes to stderr; the real stdout comes back for the line at the very end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     # JG_BENCH_BACKEND=gloo: dry run of the N > 1 control flow on a box with fewer GPUs than ranks (ranks share the
     # devices round-robin, collectives go through host memory).  The measured configuration is always nccl = RCCL.
     backend = os.environ.get("JG_BENCH_BACKEND", "nccl")
@@ -688,12 +693,18 @@ def main():
                                       "cpu_baseline": se.get("cpu_baseline"), "speedup_vs_cpu_baseline": se.get("speedup_vs_cpu_baseline")}
             except Exception as e:                      # the NR line is the contract; the SE object must never break it
                 line["config4_se"] = {"error": repr(e)}
-        print(json.dumps(line))
     else:
         pipe.close()
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # (the banner sits in the C stdio buffer -- stdout is a pipe -- until it is flushed: before the descriptor is handed back)
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(real_stdout, 1)
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
