@@ -682,10 +682,12 @@ void build_tables(BlockSymbolic& S) {
         std::vector<LevelOut> outs(nlev + 1);
         auto side_of = [&](int it) { return it < nE && S.e_row[it] > S.e_col[it] ? 1 : 0; };
         auto group_of = [&](int it) -> long long { return it < nE ? ((long long)std::min(S.e_row[it], S.e_col[it]) << 1 | side_of(it)) : ((long long)(it - nE) << 1); };
+        // TIMING PROBES (JG_PROBE_LOADS, wrong numbers -- as in fill_fact above): 1: no update term at all; 2: every operand of a term is its pivot block
+        static const int probe = getenv("JG_PROBE_LOADS") ? atoi(getenv("JG_PROBE_LOADS")) : 0;
         auto term_of = [&](int it, int f, int& a, int& d, int& b) {
             const int t = ft_idx[f];
-            if (it < nE) { a = lower_operand(S.t_a[t]); d = S.t_d[t]; b = S.t_b[t]; }
-            else { a = lower_operand(S.l_ent[t]); d = S.diag[S.l_col[t]]; b = S.l_col[t]; }
+            if (it < nE) { a = lower_operand(S.t_a[t]); d = S.t_d[t]; b = S.t_b[t]; if (probe == 2) { a = d; b = d; } }
+            else { a = lower_operand(S.l_ent[t]); d = S.diag[S.l_col[t]]; b = S.l_col[t]; if (probe == 2) a = d; }
         };
         auto shares_of = [&](int it) { return std::min(W, pow2ceil(std::max(1, (work[it] + T - 1) / T))); };
         struct Task { std::vector<TItem> items; std::vector<int> skey, sd; int shares = 0; };
@@ -703,7 +705,7 @@ void build_tables(BlockSymbolic& S) {
                 std::vector<int> seen;
                 for (size_t x = g0; x < g1; ++x) {
                     const int it = its[x];
-                    for (int f = ft_ptr[it]; f < ft_ptr[it + 1]; ++f) {
+                    for (int f = ft_ptr[it]; f < (probe == 1 ? ft_ptr[it] : ft_ptr[it + 1]); ++f) {
                         int a, d, b; term_of(it, f, a, d, b);
                         const int key = (side_of(it) ? b : a) & 0x3fffffff;
                         if (slot_stamp[key] != stamp && slot_stamp[key] != -2 - stamp) { slot_stamp[key] = -2 - stamp; seen.push_back(key); ++nk; }
@@ -716,7 +718,7 @@ void build_tables(BlockSymbolic& S) {
                 TItem ti{};
                 ti.it = it; ti.side = side_of(it);
                 if (it < nE) { ti.kind = S.e_row[it] == S.e_col[it] ? 2 : 0; if (in_top(owner(it))) ti.kind = 0; } else ti.kind = 3;
-                for (int f = ft_ptr[it]; f < ft_ptr[it + 1]; ++f) {
+                for (int f = ft_ptr[it]; f < (probe == 1 ? ft_ptr[it] : ft_ptr[it + 1]); ++f) {
                     Term tm{};
                     term_of(it, f, tm.a, tm.d, tm.b);
                     const int keyw = ti.side ? tm.b : tm.a;         // the shared operand (with its transpose bit)
