@@ -52,9 +52,32 @@ struct RowArgs {
     const double* vm; const double* va; const double* mean;
     double* Hs; double* res;
     int m; int ld;
+    const int* items; int n_items;              // work items of k_gn_rows (below): {row | kind << 28, row, row, row}
 };
 
 constexpr int GN_ROWS = 16;     // measurement rows per workgroup (4 waves x 4)
+#ifndef JG_GN_ITEMS
+#define JG_GN_ITEMS 16
+#endif
+constexpr int GN_ITEMS = JG_GN_ITEMS;   // work items of k_gn_rows per workgroup (4 waves)
+
+// active / reactive power flow at one end of a branch (types 7, 8, 10, 11) from s, c = sin, cos(theta_i - theta_j - shift): the four rows of a branch share
+// them (equations.jl:147-277)
+__device__ __forceinline__ void flow_row(int ty, const BranchP& p, double Vi, double Vj, double s, double c,
+                                         double& h, double& ti, double& vi, double& tj, double& vj) {
+#pragma clang fp contract(off)
+    const double g = p.g, b = p.b, gs = p.gs, bs = p.bs, tv = p.tinv;
+    const double B = tv * g, C = tv * b;
+    if (ty == 7) { const double A = tv * tv * (g + gs);
+        h = A * Vi * Vi - (B * c + C * s) * Vi * Vj; ti = (B * s - C * c) * Vi * Vj; vi = 2 * A * Vi - (B * c + C * s) * Vj; tj = -ti; vj = -(B * c + C * s) * Vi;
+    } else if (ty == 8) { const double A = g + gs;
+        h = A * Vj * Vj - (B * c - C * s) * Vi * Vj; ti = (B * s + C * c) * Vi * Vj; vi = (-B * c + C * s) * Vj; tj = -ti; vj = 2 * A * Vj - (B * c - C * s) * Vi;
+    } else if (ty == 10) { const double A = tv * tv * (b + bs);
+        h = -A * Vi * Vi - (B * s - C * c) * Vi * Vj; ti = -(B * c + C * s) * Vi * Vj; vi = -2 * A * Vi - (B * s - C * c) * Vj; tj = -ti; vj = -(B * s - C * c) * Vi;
+    } else { const double A = b + bs;
+        h = -A * Vj * Vj + (B * s + C * c) * Vi * Vj; ti = (B * c - C * s) * Vi * Vj; vi = (B * s + C * c) * Vj; tj = -ti; vj = -2 * A * Vj + (B * s + C * c) * Vi;
+    }
+}
 
 // value and partials of one branch measurement; i = from, j = to (equations.jl:147-547)
 __device__ __forceinline__ void branch_row(int ty, const BranchP& p, double Vi, double Vj, double thi, double thj,
@@ -83,19 +106,7 @@ __device__ __forceinline__ void branch_row(int ty, const BranchP& p, double Vi, 
     }
     double s, c;
     sincos(thi - thj - p.shift, &s, &c);              // ViVjthetaijState
-    if (ty == 7 || ty == 8 || ty == 10 || ty == 11) {
-        const double B = tv * g, C = tv * b;
-        if (ty == 7) { const double A = tv * tv * (g + gs);
-            h = A * Vi * Vi - (B * c + C * s) * Vi * Vj; ti = (B * s - C * c) * Vi * Vj; vi = 2 * A * Vi - (B * c + C * s) * Vj; tj = -ti; vj = -(B * c + C * s) * Vi;
-        } else if (ty == 8) { const double A = g + gs;
-            h = A * Vj * Vj - (B * c - C * s) * Vi * Vj; ti = (B * s + C * c) * Vi * Vj; vi = (-B * c + C * s) * Vj; tj = -ti; vj = 2 * A * Vj - (B * c - C * s) * Vi;
-        } else if (ty == 10) { const double A = tv * tv * (b + bs);
-            h = -A * Vi * Vi - (B * s - C * c) * Vi * Vj; ti = -(B * c + C * s) * Vi * Vj; vi = -2 * A * Vi - (B * s - C * c) * Vj; tj = -ti; vj = -(B * s - C * c) * Vi;
-        } else { const double A = b + bs;
-            h = -A * Vj * Vj + (B * s + C * c) * Vi * Vj; ti = (B * c - C * s) * Vi * Vj; vi = (B * s + C * c) * Vj; tj = -ti; vj = -2 * A * Vj + (B * s + C * c) * Vi;
-        }
-        return;
-    }
+    if (ty == 7 || ty == 8 || ty == 10 || ty == 11) { flow_row(ty, p, Vi, Vj, s, c, h, ti, vi, tj, vj); return; }
     // current magnitude / squared magnitude / angle: I_ij and I_ji coefficient sets
     const double t2 = tv * tv;
     double A, B, C, D, sg;                           // sg: sign of the D term inside (C cos -/+ D sin)
@@ -127,14 +138,19 @@ __device__ __forceinline__ void branch_row(int ty, const BranchP& p, double Vi, 
     }
 }
 
-// One wave = one measurement row x 64 scenarios.
+// One wave = one WORK ITEM x 64 scenarios.  An item is a measurement row, or rows that share their operands (built once in jg_gn_create):
+//   kind 1  the power-flow rows of ONE branch (wattmeter / varmeter at either end: types 7, 8, 10, 11, up to four rows): V and theta of the two buses are
+//           read once and sin, cos(theta_ij) computed once for all of them -- the reference evaluates every row on its own (acStateEstimation.jl:261-583);
+//   kind 2  active + reactive injection at ONE bus (types 6, 9): one sweep over the bus's Ybus row (V, theta, sin, cos per neighbour) for both rows.
+// Every row keeps its own formulas and the order of its sums, so H and the residual are what the single rows give.  A row that is out of service
+// (type 0) inside a group leaves zeros, as on its own.  BASELINE config 4: 96 723 rows = 34 449 items.
 __global__ __launch_bounds__(256, 4) void k_gn_rows(RowArgs a) {
     const int lane = threadIdx.x;
     const int wave = uniform(threadIdx.y);
     const size_t ld = (size_t)a.ld;
     const size_t b = (size_t)blockIdx.y * 64 + lane;
-    const int r0 = blockIdx.x * GN_ROWS;
-    const int r1 = min(r0 + GN_ROWS, a.m);
+    const int r0 = blockIdx.x * GN_ITEMS;
+    const int r1 = min(r0 + GN_ITEMS, a.n_items);
     // the row table, the slot -> bus map, the branch parameters and Ybus are wave-uniform and immutable within a launch: they come
     // through the scalar cache (constant address space), not as 64 identical vector loads followed by readfirstlane
     typedef const int __attribute__((address_space(4)))* CInt;
@@ -146,7 +162,62 @@ __global__ __launch_bounds__(256, 4) void k_gn_rows(RowArgs a) {
     auto branch = [&](int k) { const i16 raw = ((CBranch)a.br)[k]; BranchP q; __builtin_memcpy(&q, &raw, sizeof(q)); return q; };
     CInt slot_bus = (CInt)a.slot_bus, rowptr = (CInt)a.rowptr, ydiag = (CInt)a.ydiag;
     CDbl Gs = (CDbl)a.G, Bs = (CDbl)a.Bv;
-    for (int r = r0 + wave; r < r1; r += blockDim.y) {
+    for (int pos = r0 + wave; pos < r1; pos += blockDim.y) {
+        const i4 item = ((CInt4)a.items)[pos];
+        const int kind = item[0] >> 28;
+        if (kind == 1) {                               // the flow rows of one branch
+            const i4 first = ((CInt4)a.rows)[item[0] & 0x0fffffff];
+            const BranchP p = branch(first[1]);
+            const int i = p.from, j = p.to;
+            const double Vi = a.vm[(size_t)i * ld + b], thi = a.va[(size_t)i * ld + b];
+            const double Vj = a.vm[(size_t)j * ld + b], thj = a.va[(size_t)j * ld + b];
+            double sn, cs;
+            sincos(thi - thj - p.shift, &sn, &cs);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int rk = k == 0 ? (item[0] & 0x0fffffff) : item[k];
+                if (rk < 0) break;
+                const i4 rd = k == 0 ? first : ((CInt4)a.rows)[rk];
+                double h = 0.0, ti = 0.0, vi = 0.0, tj = 0.0, vj = 0.0, z = 0.0;
+                if (rd[0] != 0) { z = a.mean[(size_t)rk * ld + b]; flow_row(rd[0], p, Vi, Vj, sn, cs, h, ti, vi, tj, vj); }
+                jg::store_vec(a.Hs, (size_t)rd[2], b, ld, ti, vi);
+                jg::store_vec(a.Hs, (size_t)rd[2] + 1, b, ld, tj, vj);
+                a.res[(size_t)rk * ld + b] = z - h;
+            }
+            continue;
+        }
+        if (kind == 2) {                               // active + reactive injection at one bus: slots follow the Ybus row of the bus
+            const int ra = item[0] & 0x0fffffff, rb = item[1];
+            const i4 da = ((CInt4)a.rows)[ra], db = ((CInt4)a.rows)[rb];
+            const bool ona = da[0] != 0, onb = db[0] != 0;
+            const int i = da[1], ns = da[3];
+            const double Vi = a.vm[(size_t)i * ld + b], thi = a.va[(size_t)i * ld + b];
+            const int p0 = rowptr[i];
+            const int pd = ydiag[i];
+            double s1 = 0.0, s2 = 0.0;
+            for (int s = 0; s < ns; ++s) {
+                const int pp = p0 + s;
+                const int j = slot_bus[da[2] + s];
+                const double g = Gs[pp], bb = Bs[pp];
+                const double Vj = a.vm[(size_t)j * ld + b], thj = a.va[(size_t)j * ld + b];
+                double sn, cs;
+                sincos(thi - thj, &sn, &cs);
+                const double ac = g * cs + bb * sn, ad = g * sn - bb * cs;
+                s1 += Vj * ac; s2 += Vj * ad;
+                if (pp != pd) {
+                    jg::store_vec(a.Hs, (size_t)(da[2] + s), b, ld, ona ? Vi * Vj * ad : 0.0, ona ? Vi * ac : 0.0);
+                    jg::store_vec(a.Hs, (size_t)(db[2] + s), b, ld, onb ? -(Vi * Vj) * ac : 0.0, onb ? Vi * ad : 0.0);
+                }
+            }
+            const double gii = Gs[pd], bii = Bs[pd];
+            const int sd = pd - p0;
+            jg::store_vec(a.Hs, (size_t)(da[2] + sd), b, ld, ona ? -Vi * s2 - bii * (Vi * Vi) : 0.0, ona ? s1 + gii * Vi : 0.0);
+            jg::store_vec(a.Hs, (size_t)(db[2] + sd), b, ld, onb ? Vi * s1 - gii * (Vi * Vi) : 0.0, onb ? s2 - bii * Vi : 0.0);
+            a.res[(size_t)ra * ld + b] = ona ? a.mean[(size_t)ra * ld + b] - Vi * s1 : 0.0;
+            a.res[(size_t)rb * ld + b] = onb ? a.mean[(size_t)rb * ld + b] - Vi * s2 : 0.0;
+            continue;
+        }
+        const int r = item[0];
         const i4 rd = ((CInt4)a.rows)[r];
         const int ty = rd[0], idx = rd[1], s0 = rd[2], ns = rd[3];
         // a slot = the 1x2 block (d/dtheta, d/dV) of one (row, bus) pair, interleaved per scenario: one 16-byte store
@@ -601,7 +672,7 @@ struct jg_gn {
     std::vector<int> corr_row;
     int gain_waves = 0, rhs_waves = 0;          // waves of the gain launch / of the rhs-only (correction) launch
     // device
-    RowDesc* d_rows = nullptr; int* d_slot_bus = nullptr; BranchP* d_br = nullptr;
+    RowDesc* d_rows = nullptr; int* d_slot_bus = nullptr; BranchP* d_br = nullptr; int* d_items = nullptr; int n_items = 0;
     int* d_rowptr = nullptr; double* d_G = nullptr; double* d_B = nullptr; int* d_ydiag = nullptr;
     void* d_arena = nullptr;                    // one allocation behind the per-handle state below (jg_gn_create)
     double* d_vm = nullptr; double* d_va = nullptr; double* d_mean = nullptr; double* d_w = nullptr;
@@ -630,8 +701,8 @@ int set_device(jg_gn* h) { GN_HIP(hipSetDevice(h->device)); return 0; }
 
 void launch_rows(jg_gn* h) {
     RowArgs a{h->d_rows, h->d_slot_bus, h->d_br, h->d_rowptr, h->d_G, h->d_B, h->d_ydiag, h->d_vm, h->d_va, h->d_mean,
-              h->d_Hs, h->d_res, h->m, h->ld};
-    hipLaunchKernelGGL(k_gn_rows, dim3((h->m + GN_ROWS - 1) / GN_ROWS, h->ld / 64), dim3(64, 4), 0, h->stream, a);
+              h->d_Hs, h->d_res, h->m, h->ld, h->d_items, h->n_items};
+    hipLaunchKernelGGL(k_gn_rows, dim3((h->n_items + GN_ITEMS - 1) / GN_ITEMS, h->ld / 64), dim3(64, 4), 0, h->stream, a);
 }
 
 void launch_gain(jg_gn* h, bool correction = false) {
@@ -983,6 +1054,40 @@ int jg_gn_create(jg_gn** out, int64_t n, const int64_t* colptr, const int64_t* r
         }
         h->gain_waves = (int)gwave.size() - 1; h->rhs_waves = (int)rwave.size() - 1;
     }
+    // work items of k_gn_rows: rows that share their operands go to one wave (see the kernel).  Grouped by the type CODE of a row (a row that is out of
+    // service later keeps its place and leaves zeros); a group sits where its first row sat, the other rows leave their places.
+    std::vector<int> items;
+    {
+        std::map<int, int> flow_item, inj_item;                                   // branch / bus -> its item
+        std::vector<int> quad;                                                    // 4 ints per item
+        const bool fuse = !(getenv("JG_GN_FUSE") && atoi(getenv("JG_GN_FUSE")) == 0);
+        for (int r = 0; r < m; ++r) {
+            const int c = h->code[r], idx = rows[r].idx;
+            const bool flow = c == 7 || c == 8 || c == 10 || c == 11, inj = c == 6 || c == 9;
+            if (fuse && flow) {
+                auto it = flow_item.find(idx);
+                if (it != flow_item.end()) {
+                    int* q = &quad[(size_t)it->second * 4];
+                    int k = 1;
+                    while (k < 4 && q[k] >= 0) ++k;
+                    if (k < 4) { q[k] = r; q[0] = (q[0] & 0x0fffffff) | 1 << 28; continue; }
+                } else flow_item[idx] = (int)(quad.size() / 4);
+            } else if (fuse && inj) {
+                auto it = inj_item.find(idx);
+                if (it != inj_item.end()) {
+                    int* q = &quad[(size_t)it->second * 4];
+                    const int ra = q[0] & 0x0fffffff;
+                    if (q[1] < 0 && h->code[ra] != c && rows[ra].nslots == rows[r].nslots) {       // one active + one reactive row of the bus, 6 first
+                        if (c == 6) { q[1] = ra; q[0] = r | 2 << 28; } else { q[1] = r; q[0] = ra | 2 << 28; }
+                        continue;
+                    }
+                } else inj_item[idx] = (int)(quad.size() / 4);
+            }
+            quad.insert(quad.end(), {r, -1, -1, -1});
+        }
+        items.swap(quad);
+        h->n_items = (int)(items.size() / 4);
+    }
     // branch parameters
     std::vector<BranchP> br(std::max<int64_t>(nb, 1));
     for (int64_t k = 0; k < nb; ++k) {
@@ -991,7 +1096,7 @@ int jg_gn_create(jg_gn** out, int64_t n, const int64_t* colptr, const int64_t* r
     }
     // ---- device -------------------------------------------------------------------------------------
     std::string err;
-    if (jg::upload(&h->d_rows, rows, err, h->stream) || jg::upload(&h->d_slot_bus, slot_bus, err, h->stream) || jg::upload(&h->d_br, br, err, h->stream) ||
+    if (jg::upload(&h->d_rows, rows, err, h->stream) || jg::upload(&h->d_items, items, err, h->stream) || jg::upload(&h->d_slot_bus, slot_bus, err, h->stream) || jg::upload(&h->d_br, br, err, h->stream) ||
         jg::upload(&h->d_rowptr, rp, err, h->stream) || jg::upload(&h->d_G, G, err, h->stream) || jg::upload(&h->d_B, B, err, h->stream) || jg::upload(&h->d_ydiag, ydiag, err, h->stream) ||
         jg::upload(&h->d_grec, grec, err, h->stream) || jg::upload(&h->d_gwave, gwave, err, h->stream) || jg::upload(&h->d_rrec, rrec, err, h->stream) ||
         jg::upload(&h->d_rwave, rwave, err, h->stream) || jg::upload(&h->d_gtask, gtask, err, h->stream) || jg::upload(&h->d_gstage, gstage, err, h->stream) ||
@@ -1032,7 +1137,7 @@ void jg_gn_destroy(jg_gn* h) {
     if (h->exec) hipGraphExecDestroy(h->exec);
     if (h->graph) hipGraphDestroy(h->graph);
     h->eng.destroy();
-    hipFree(h->d_rows); hipFree(h->d_slot_bus); hipFree(h->d_br); hipFree(h->d_rowptr); hipFree(h->d_G); hipFree(h->d_B); hipFree(h->d_ydiag);
+    hipFree(h->d_rows); hipFree(h->d_items); hipFree(h->d_slot_bus); hipFree(h->d_br); hipFree(h->d_rowptr); hipFree(h->d_G); hipFree(h->d_B); hipFree(h->d_ydiag);
     hipFree(h->d_vm0); hipFree(h->d_va0); hipFree(h->d_rho); hipFree(h->d_rhs2); hipFree(h->d_inc2);
     hipFree(h->d_arena);                                         // V, theta, z, weights, slots, residual, rhs, increment, norms, lane bookkeeping: one allocation (jg_gn_create)
     hipFree(h->d_pair_ptr); hipFree(h->d_pa); hipFree(h->d_pb); hipFree(h->d_pz); hipFree(h->d_nres); hipFree(h->d_amax_v); hipFree(h->d_amax_i);
