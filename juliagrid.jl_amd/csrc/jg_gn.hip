@@ -57,9 +57,9 @@ struct RowArgs {
 
 constexpr int GN_ROWS = 16;     // measurement rows per workgroup (4 waves x 4)
 #ifndef JG_GN_ITEMS
-#define JG_GN_ITEMS 16
+#define JG_GN_ITEMS 32
 #endif
-constexpr int GN_ITEMS = JG_GN_ITEMS;   // work items of k_gn_rows per workgroup (4 waves)
+constexpr int GN_ITEMS = JG_GN_ITEMS;   // work items of k_gn_rows per workgroup (4 waves; 4 / 8 / 16 / 32: 0.83 / 0.77 / 0.70-0.74 / 0.69 ms on config 4)
 
 // active / reactive power flow at one end of a branch (types 7, 8, 10, 11) from s, c = sin, cos(theta_i - theta_j - shift): the four rows of a branch share
 // them (equations.jl:147-277)
