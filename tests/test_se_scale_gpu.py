@@ -211,3 +211,38 @@ def test_every_type_code_on_case1354pegase_with_noise(jg, oracle):
     assert gn2.iteration == an.method.iteration and gn2.iteration <= 12
     assert dv <= 1e-8 and da <= 1e-8
     an.close()
+
+
+def test_rows_switched_off_inside_fused_work_items(jg, oracle):
+    """k_gn_rows evaluates the power-flow rows of a branch (up to four) and the two injection rows of a bus as ONE work item (shared V, theta, sin / cos).
+    Meters switched off AFTER gaussNewton() -- one flow row of a branch, both flow rows of one end, one injection row of a bus, a whole injection pair --
+    must leave zeros and a zero residual in their rows and nothing else changed: H, residual, objective against the oracle at 1e-12, from the same state."""
+    t = load_case("case1354pegase")
+    s = jg.powerSystem(t)
+    pf = jg.newtonRaphson(s)
+    jg.powerFlow_(pf, tolerance=1e-11)
+    mon = jg.measurement(s)
+    jg.addVoltmeter_(mon, pf); jg.addWattmeter_(mon, pf); jg.addVarmeter_(mon, pf)
+    _noisy(mon, np.random.Generator(np.random.PCG64(11)))
+    n, nb = s.bus.number, s.branch.number
+    an = jg.gaussNewton(mon)
+    assert an.dims["m"] == n + 2 * (n + 2 * int((s.branch.layout.status == 1).sum()))
+    # wattmeters / varmeters are numbered: bus injections (n), then from-end and to-end of every in-service branch, interleaved per branch
+    jg.updateWattmeter_(an, n + 1, status=0)              # P at the from-end of the first branch: one row of a group of four
+    jg.updateWattmeter_(an, n + 6, status=0)              # P ...
+    jg.updateVarmeter_(an, n + 6, status=0)               # ... and Q at the same end of the third branch: two rows of a group
+    jg.updateVarmeter_(an, 5, status=0)                   # Q injection at bus 5: one row of a pair
+    jg.updateWattmeter_(an, 9, status=0)
+    jg.updateVarmeter_(an, 9, status=0)                   # both injection rows of bus 9
+    osys, _, _ = _oracle_system(oracle, t)
+    gn = oracle.OracleGN(osys, _table_of(oracle, mon), np.ones(n), np.zeros(n))
+    _check_model(an, gn)
+    assert int((np.asarray(an.method.type) == 0).sum()) == 6
+    vm0, va0 = np.asarray(pf.voltage.magnitude) * 1.01, np.asarray(pf.voltage.angle) + 0.002
+    an.setVoltage(vm0, va0)
+    gn.set_voltage(vm0, va0)
+    _compare_at_state(an, gn, jg, "rows switched off inside groups", osys.slack, inc_tol=1e-6)
+    off = np.flatnonzero(np.asarray(an.method.type) == 0)
+    assert np.all(np.asarray(an.residual)[off] == 0.0)
+    J = an.jacobian
+    assert np.all(J.nzval[np.isin(J.rowval - 1, off)] == 0.0)
