@@ -143,7 +143,7 @@ __device__ __forceinline__ void branch_row(int ty, const BranchP& p, double Vi, 
 //           read once and sin, cos(theta_ij) computed once for all of them -- the reference evaluates every row on its own (acStateEstimation.jl:261-583);
 //   kind 2  active + reactive injection at ONE bus (types 6, 9): one sweep over the bus's Ybus row (V, theta, sin, cos per neighbour) for both rows.
 // Every row keeps its own formulas and the order of its sums, so H and the residual are what the single rows give.  A row that is out of service
-// (type 0) inside a group leaves zeros, as on its own.  BASELINE config 4: 96 723 rows = 34 449 items.
+// (type 0) inside a group leaves zeros, as on its own.  BASELINE config 4: 82 678 of the 96 723 rows are flow or injection rows -> 25 290 groups.
 __global__ __launch_bounds__(256, 4) void k_gn_rows(RowArgs a) {
     const int lane = threadIdx.x;
     const int wave = uniform(threadIdx.y);
