@@ -136,7 +136,9 @@ int jg_nr_run(jg_nr* h, int64_t max_iter, double tol, int32_t* iters, int32_t* s
  *   jg_nr_resume      runs the scenarios in lanes [0, lanes) of a pool to the end, each with the iteration count it arrived with
  *                     (per-scenario results are bitwise those of an undisturbed batch: lanes never interact, and jg_nr_move_lanes refuses
  *                     a pool that runs another factorisation plan than the batch -- the plan depends on the CLASS of batch a handle was
- *                     created for: at most 32 scenarios, 33-64, 65-255, 256 and more); iters / status [lanes].
+ *                     created for, decided by the scenario count PADDED to a multiple of 64 lanes: 64 lanes with at most 32 scenarios,
+ *                     64 lanes (33-64 scenarios), 128 or 192 lanes (65-192), 256 lanes and more (193 scenarios and more: a batch of
+ *                     200 is in the class of 512, not of 192); iters / status [lanes].
  *   jg_nr_pack_rows_device  V | theta | iterations | status of lanes lane0 .. lane0 + count - 1 into rows rows[i] of a result
  *                     record [.][2 n + 2] in device memory (the record jg_nr_pack_results_device writes for the batch they left). */
 int jg_nr_run_defer(jg_nr* h, int64_t max_iter, double tol, int64_t defer_at, int32_t* n_left);
@@ -201,6 +203,9 @@ int jg_nr_bus_injection(jg_nr* h, double* inj_pq);
  *   rec[b][4] lowest voltage magnitude, rec[b][5] its bus (1-based); rec[b][6] highest, rec[b][7] its bus
  *   rec[b][8] method.iteration, rec[b][9] status (0 converged, 1 iteration limit, 3 numeric failure) of the last jg_nr_run
  * Ties go to the lowest index.  The branch that is out of service in a scenario (jg_nr_set_outage_labels) does not count there.
+ * A scenario that ended with status 3 (numeric failure: its state is NaN) delivers NaN in rec[b][0], [2], [4], [6] and index 0 in [1], [3], [5], [7]:
+ * rank by rec[b][9] first -- a diverged contingency must never read as the safest one.
+ * jg_nr_set_branches with another branch count drops an installed rating (it belongs to the table it was given for): call jg_nr_set_screen again.
  * jg_nr_set_screen: rating [nb] in pu of apparent power (branch.flow.maxFromBus / maxToBus of type 2, src/powerSystem/branch.jl:29-37), 0 = no limit, NULL = none;
  *   needs jg_nr_set_branches.  jg_nr_screen: rec [batch][10] to the host; jg_nr_screen_device: into a device buffer (the operand of jg_comm_allgather_device).
  * jg_nr_screen_rows_device: the summaries of lanes lane0 .. lane0 + count - 1 into rows rows[0 .. count) of a [.][10] device record (a pool handle returns the

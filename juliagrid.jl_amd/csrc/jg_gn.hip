@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void k_gn_gain(GainArgs a) {
                          "1:\n\t"
                          "global_load_dwordx2 %2, %4, %8\n"
                          "2:"
-                         : "=v"(wt[t]), "=v"(xa[t]), "=v"(yr[t]), "=v"(xb[t])
+                         : "=&v"(wt[t]), "=&v"(xa[t]), "=&v"(yr[t]), "=&v"(xb[t])     // early clobber: later instructions of the statement still read %4, %5
                          : "v"(off8), "v"(off16), "s"(pw), "s"(px), "s"(py), "s"(mode)
                          : "memory", "scc");
         }

@@ -397,8 +397,13 @@ __global__ __launch_bounds__(64) void k_screen_final(ScreenArgs a) {
         if (q[2 * ld] > vmax) { vmax = q[2 * ld]; vmaxidx = q[3 * ld]; }
     }
     double* r = a.rec + (size_t)b * 10;
+    const int st = a.status_sc[b];
+    if (st == 3) {                                               //  numeric failure: V is NaN, every comparison above was false -- the sentinels would read
+        const double nan = __builtin_nan("");                     // as "nothing overloaded".  The summary of such a scenario is NaN (jgrid.h); rec[8], rec[9] say why.
+        load = flow = vmin = vmax = nan; lidx = fidx = vminidx = vmaxidx = 0.0;
+    }
     r[0] = load; r[1] = lidx; r[2] = flow; r[3] = fidx; r[4] = vmin; r[5] = vminidx; r[6] = vmax; r[7] = vmaxidx;
-    r[8] = (double)a.iters[b]; r[9] = (double)a.status_sc[b];
+    r[8] = (double)a.iters[b]; r[9] = (double)st;
 }
 
 struct CheckArgs {
@@ -1505,11 +1510,11 @@ int jg_nr_move_lanes(jg_nr* dst, int64_t dst_lane0, jg_nr* src, int32_t* home, i
     if (dst->device != src->device || dst->n != src->n || dst->nnz != src->nnz || dst->mp != src->mp || dst->fast || src->fast)
         return fail(1, "jg_nr_move_lanes: the two handles must hold the same grid on the same device");
     //  the factorisation plan -- where the top starts, front caps, tasks or wave records: the summation order -- is chosen by the class of
-    // batch a handle was created for (Engine::create: up to 32 scenarios, one lane group, 65-255, 256 and more).  A straggler that finishes under another
+    // batch a handle was created for (Engine::create, by the lane count PADDED to a multiple of 64: 64 with at most 32 scenarios, 64, 128 / 192, 256 and more).  A straggler that finishes under another
     // plan is no longer bitwise the scenario of a lockstep batch, silently: refuse the hand-off instead.
     if (dst->eng.plan && src->eng.plan && dst->eng.plan->policy != src->eng.plan->policy)
         return fail(1, "jg_nr_move_lanes: the pool runs another factorisation plan than the batch (create both for the same class of batch: "
-                       "at most 32 scenarios, 33-64, 65-255, 256 and more)");
+                       "1-32 scenarios, 33-64, 65-192, 193 and more = padded lane count 64 with at most 32 scenarios, 64, 128 / 192, 256 and more)");
     if (int rc = set_device(dst)) return rc;
     for (jg_nr* h : {dst, src})
         if (!h->d_move) {
@@ -1782,6 +1787,10 @@ int jg_nr_set_branches(jg_nr* h, int64_t nb, const int64_t* from, const int64_t*
     if (!h->d_outage) {
         NR_HIP(hipMalloc((void**)&h->d_outage, (size_t)h->ld * sizeof(int)));
         NR_HIP(jg::sync_fill(h->d_outage, 0, (size_t)h->ld * sizeof(int), h->stream));
+    }
+    if ((int)nb != h->nb) {                                      //  the screen's partial maxima are sized by the branch count and a rating
+        hipFree(h->d_screen); hipFree(h->d_screc); hipFree(h->d_rating);   // belongs to the branch table it was installed for: both go with the old table
+        h->d_screen = h->d_screc = h->d_rating = nullptr;
     }
     h->nb = (int)nb;
     return 0;

@@ -582,6 +582,14 @@ def _upload_branches(an: AcPowerFlow):
     _lib.check(L.jg_nr_set_branches(an._h, nb, np.ascontiguousarray(lay.from_, dtype=np.int64), np.ascontiguousarray(lay.to, dtype=np.int64),
                                     np.ascontiguousarray(lay.status, dtype=np.int8), np.ascontiguousarray(tab.reshape(-1))))
     an._branches_on_device = True
+    #  a rating belongs to the branch table it was given for: the library drops it when the branch count changes, so it is pushed again
+    # with every new table -- or forgotten here too when it no longer has one value per branch (addBranch_ on an unchanged pattern)
+    r = getattr(an, "_screen_rating", None)
+    if r is not None:
+        if r.shape == (nb,):
+            _lib.check(L.jg_nr_set_screen(an._h, r.ctypes.data))
+        else:
+            an._screen_rating = None
 
 
 def _pairs(an, fn, rows, *slots):

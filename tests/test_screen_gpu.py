@@ -130,3 +130,60 @@ def test_pipeline_delivers_summary_records(jg, name, batch, njobs, pool):
     assert np.abs(r0[:, 2][ok] - ref.flow[ok]).max() <= 1e-6 * max(1.0, ref.flow[ok].max())
     assert np.abs(r0[:, 4][ok] - ref.minMagnitude[ok]).max() <= 1e-6 and np.abs(r0[:, 6][ok] - ref.maxMagnitude[ok]).max() <= 1e-6
     an.close()
+
+
+def test_summary_of_a_failed_scenario_is_not_the_safest_one(jg):
+    """ A scenario that ends with status 3 has NaN voltages: every comparison of the reduction is false and the sentinels (loading 0, lowest voltage
+    1e300) would read as 'nothing overloaded'.  Its summary is NaN with index 0 (include/jgrid.h), its neighbours in the batch are untouched."""
+    from test_guard_gpu import _island_bridges
+    s = jg.powerSystem(load_case("case1354pegase"))
+    bad = _island_bridges(jg, s, 3)[:1]
+    assert bad
+    good = [int(x) for x in jg.outageList(s, 4, seed=11)]
+    labels = good[:2] + bad + good[2:]
+    an = jg.contingencyAnalysis(s, labels)
+    jg.powerFlow_(an)
+    assert an.status[2] == 3 and all(an.status[i] == 0 for i in (0, 1, 3, 4))
+    rating = np.full(s.branch.number, 5.0)
+    out = jg.screenSummary_(an, rating=rating)
+    assert np.isnan(out.loading[2]) and np.isnan(out.flow[2]) and np.isnan(out.minMagnitude[2]) and np.isnan(out.maxMagnitude[2])
+    assert (out.loadingBranch[2], out.flowBranch[2], out.minBus[2], out.maxBus[2]) == (0, 0, 0, 0) and out.status[2] == 3
+    keep = [0, 1, 3, 4]
+    ref = jg.contingencyAnalysis(s, [labels[i] for i in keep])
+    jg.powerFlow_(ref)
+    r = jg.screenSummary_(ref, rating=rating)
+    for name in ("loading", "loadingBranch", "flow", "flowBranch", "minMagnitude", "minBus", "maxMagnitude", "maxBus"):
+        assert np.array_equal(getattr(out, name)[keep], getattr(r, name)), name
+    an.close(); ref.close()
+
+
+def test_summary_follows_a_branch_table_that_grew(jg):
+    """ addBranch!(analysis) on an unchanged Ybus pattern re-uploads a LONGER branch table: the partial maxima of the screen are sized by the
+    branch count (chunks of 256 branches) and an installed rating has the old length.  186 -> 257 branches crosses a chunk boundary: the summary must be the
+    one of a fresh analysis of the grown system, and a rating of the old length must be gone, not read out of bounds."""
+    s = jg.powerSystem(load_case("case118"))
+    labels = [int(x) for x in jg.outageList(s, 5, seed=2)] + [0]
+    an = jg.contingencyAnalysis(s, labels)
+    jg.powerFlow_(an)
+    nb0 = s.branch.number
+    first = jg.screenSummary_(an, rating=np.full(nb0, 3.0))
+    assert np.all(first.loading > 0)
+    inv = {v: k for k, v in s.bus.label.items()}
+    fr, to = s.branch.layout.from_, s.branch.layout.to
+    rev = s.model.revision.acPattern
+    k = 0
+    while s.branch.number <= 256:                                # parallel circuits: the Ybus pattern stays, the branch table grows past a chunk of 256
+        jg.addBranch_(an, from_=inv[int(fr[k])], to=inv[int(to[k])], resistance=0.02, reactance=0.4)
+        k += 1
+    assert s.model.revision.acPattern == rev and s.branch.number == 257
+    jg.powerFlow_(an)
+    assert np.all(an.status == 0)
+    norating = jg.screenSummary_(an, rating=None)                # the old rating (186 values) went with the old table
+    assert np.all(norating.loading == 0.0) and np.all(norating.loadingBranch == 0)
+    rating = np.full(s.branch.number, 3.0)
+    out = jg.screenSummary_(an, rating=rating)
+    jg.power_(an)
+    f = np.maximum(np.hypot(an.power.from_.active, an.power.from_.reactive), np.hypot(an.power.to.active, an.power.to.reactive))
+    assert np.abs(out.flow - f.max(axis=1)).max() <= 1e-12 * max(1.0, f.max()) and np.array_equal(out.flowBranch, f.argmax(axis=1) + 1)
+    assert np.abs(out.loading - f.max(axis=1) / 3.0).max() <= 1e-12 and np.array_equal(out.loadingBranch, out.flowBranch)
+    an.close()

@@ -10,6 +10,11 @@ load while that load may still be in flight:
     state   = {register -> number of vector-memory operations issued after its load}   (minimum over paths)
     s_waitcnt vmcnt(k)  completes every load with at least k younger operations (loads and stores share the counter and complete in order)
 
+Also reported: an asm load whose ADDRESS register is the destination of a load still in flight (an output of a multi-instruction statement that
+was not declared early-clobber may share a register with an input a later instruction of the statement reads), and a block of instructions the walk never
+reaches (the checker would pass vacuously for it).  Numeric local labels of GNU as inside an asm statement (`1:` ... `s_cbranch_scc1 1f`) are resolved
+(`Nf` = the next definition of N, `Nb` = the previous one); a branch whose target is not found falls through conservatively.
+
     python tools/check_asm_loads.py file.s [...]          exit code 1 on a finding
 """
 import re
@@ -66,28 +71,47 @@ def check_kernel(name, body):
         if m:
             ins.append(("label", m.group(1), False)); continue
         ins.append(("ins", s.strip(), in_asm))
-    # basic blocks
-    blocks, cur, names = [], [], {}
+    # basic blocks.  names: label -> block; numeric local labels (GNU as: `1:` may be defined many times) keep every definition in order
+    blocks, cur, names, local_defs = [], [], {}, {}
     for kind, text, asm in ins:
         if kind == "label":
             if cur:
                 blocks.append(cur); cur = []
-            names[text] = len(blocks)
+            if text.isdigit():
+                local_defs.setdefault(text, []).append(len(blocks))
+            else:
+                names[text] = len(blocks)
             continue
         cur.append((text, asm))
         if BRANCH.match(text) or text.startswith("s_endpgm"):
             blocks.append(cur); cur = []
     if cur:
         blocks.append(cur)
+
+    def resolve(target, at):
+        """block index of a branch target seen from block `at`; None if unknown"""
+        if target in names:
+            return names[target]
+        m = re.fullmatch(r"(\d+)([fb])", target)
+        if m and m.group(1) in local_defs:
+            defs = local_defs[m.group(1)]
+            if m.group(2) == "f":
+                nxt = [d for d in defs if d > at]
+                return nxt[0] if nxt else None
+            prv = [d for d in defs if d <= at]
+            return prv[-1] if prv else None
+        return None
+
     succ = []
     for i, b in enumerate(blocks):
         last = b[-1][0] if b else ""
         m = BRANCH.match(last)
         s = []
         if m:
-            if m.group(2) in names:
-                s.append(names[m.group(2)])
-            if m.group(1) != "branch" and i + 1 < len(blocks):
+            tgt = resolve(m.group(2), i)
+            if tgt is not None:
+                s.append(tgt)
+            if (m.group(1) != "branch" or tgt is None) and i + 1 < len(blocks):     # unknown target: fall through (conservative)
                 s.append(i + 1)
         elif not last.startswith("s_endpgm") and i + 1 < len(blocks):
             s.append(i + 1)
@@ -102,10 +126,15 @@ def check_kernel(name, body):
         st = dict(state_in[i])
         for text, asm in blocks[i]:
             if asm and text.startswith("global_load"):
+                parts = text.split(",")
+                addr = regs_of(parts[1]) if len(parts) > 1 else set()          # global_load dst, vaddr, saddr
+                hit = addr & set(st)
+                if hit and (i, text) not in seen_find:
+                    seen_find.add((i, text))
+                    findings.append((name, text + "    [address register]", sorted(hit)))
                 for r in st:
                     st[r] += 1
-                dst = text.split(",")[0]
-                for r in regs_of(dst):
+                for r in regs_of(parts[0]):
                     st[r] = 0
                 continue
             w = re.search(r"vmcnt\((\d+)\)", text) if text.startswith("s_waitcnt") else None
@@ -131,6 +160,9 @@ def check_kernel(name, body):
                         merged[r] = a; changed = True
                 if changed:
                     state_in[j] = merged; work.append(j)
+    for i, b in enumerate(blocks):                              # a block the walk never reached was never analysed: no vacuous 'ok'
+        if state_in[i] is None and any(not t.startswith(("s_endpgm", "s_nop", "s_code_end")) for t, _ in b):
+            findings.append((name, f"unreachable block of {len(b)} instruction(s) starting at: {b[0][0]}", []))
     return findings
 
 
