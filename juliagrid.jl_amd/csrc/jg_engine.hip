@@ -1264,6 +1264,216 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
     if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pt[4] = wall_clock64(); }
 }
 
+// ---- narrow task kernels (round 5): ONE or TWO waves per (task, scenario) ----------------------------------------------------------
+// k_fact_top spreads a front over 256 threads: a pivot step is then ~0.2 us of arithmetic inside ~0.9 us of barrier, LDS round trips and publish
+// code, and a CU holds four scenarios (r04_top_task_profile.txt: 2 560 workgroups of a task level run in two to three rounds).  The step is a chain,
+// so what a launch of MANY tasks needs is more scenarios per CU, and what a chain needs is less synchronisation per step -- both say: fewer
+// threads per scenario.
+//   W1  fronts of class 2 (f + 1 <= 32):  ONE wave per scenario, 8 x 8 thread grid, 4 x 4 blocks per thread.  No workgroup barrier at all: the
+//       pivot row / column / pivot travel through LDS inside the wave (DS operations of a wave execute in order).  A workgroup is TOPW_SPW
+//       independent waves = consecutive scenarios (their gathers touch the same 128-byte lines of the batch-minor storage).
+//   W2  fronts of class 3 (f + 1 <= 48):  TWO waves per scenario, 8 x 16 grid, 6 x 3 blocks per thread, one 2-wave barrier per step.
+// Same elimination as k_fact_top<CLS, false, false, JORDAN>, block for block and term for term in the same order (ascending pivots, the same
+// fma forms, the same 2 x 2 LU): the results are BITWISE those of the wide kernel (tests/test_top_variants_gpu.py compares digests), so a plan
+// may run either.  New here: classes of the thread grid that a step cannot change are skipped with scalar branches -- row classes whose rows are
+// all finished (plain rows; a Jordan step touches the rows above too), column classes left of the pivot, classes beyond the task's own front
+// (a launch is compiled for its class, its fronts are 22 - 31 resp. 32 - 47 rows) -- the wide kernel runs every block of every thread in every step.
+constexpr int TOPW_SPW = 4;             // W1: scenarios (waves) per workgroup
+template <int GRL, int GCL, int CR, int CC, bool JORDAN>
+__global__ __launch_bounds__(((1 << (GRL + GCL)) == 64 ? 64 * TOPW_SPW : (1 << (GRL + GCL)))) __attribute__((amdgpu_waves_per_eu(2))) void k_fact_topw(TopArgs a) {
+    constexpr int GR = 1 << GRL, GC = 1 << GCL, NT = GR * GC, NW = NT / 64, SPW = NW == 1 ? TOPW_SPW : 1;
+    constexpr int NROW = CR * GR, NCOL = CC * GC;
+    static_assert(NT == 64 || NT == 128, "one or two waves per scenario");
+    __shared__ __attribute__((aligned(16))) double Dbuf_[SPW][2][4];
+    __shared__ __attribute__((aligned(16))) double Ubuf_[SPW][2][NCOL * 4];
+    __shared__ __attribute__((aligned(16))) double Lbuf_[SPW][2][NROW * 4];
+    __shared__ __attribute__((aligned(16))) double Dref_[SPW][NROW * 2];
+    int grp, x;
+    const int qpg = (a.lpg + SPW - 1) / SPW;                     // workgroups of a task per 64-lane group
+    if (!map_block(a.sel, a.ld, a.ntasks * qpg, grp, x)) return;
+    const int ti = x / qpg;
+    const int slot = NW == 1 ? uniform((int)threadIdx.y) : 0;    // W1: the wave's scenario inside the workgroup
+    const int s0 = (x - ti * qpg) * SPW + slot;
+    const int bb = grp * 64 + s0;
+    if (s0 >= a.lpg || bb >= a.lanes) return;                    // (W1: waves are independent -- no barrier follows; W2: uniform for the workgroup)
+    double (&Dbuf)[2][4] = Dbuf_[slot]; double (&Ubuf)[2][NCOL * 4] = Ubuf_[slot]; double (&Lbuf)[2][NROW * 4] = Lbuf_[slot]; double (&Dref)[NROW * 2] = Dref_[slot];
+    const int tid = threadIdx.x;
+    const int gi = tid >> GCL, gj = tid & (GC - 1);
+    auto sync = [&] {
+        if constexpr (NW == 1) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+        else __syncthreads();
+    };
+    const bool prof = a.prof && tid == 0;
+    long long* pt = a.prof + ((size_t)(a.task_begin + ti) * a.ld + bb) * 8;
+    if (prof) {
+        pt[0] = wall_clock64();
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        pt[5] = (long long)((xcc & 0xf) << 16 | ((hw >> 13) & 0x7) << 8 | ((hw >> 8) & 0xf));
+    }
+    const RecS h = load_rec(a.task, (size_t)a.task_begin + ti);
+    const int m = h[0], e = h[1], nchild = h[5], fprime = h[11];
+    const int f = fprime - 1;
+    const int re = (f + GR - 1) >> GRL, ce = (fprime + GC - 1) >> GCL;     // thread-grid classes the front reaches
+    const int* td = a.data + h[3];
+    const size_t b = (size_t)bb, ld = (size_t)a.ld;
+    double* stk = a.stack + b * (size_t)a.stack_stride;
+    int bad = 0;
+    Blk T[CR][CC];
+    {   // ---- load: entry map, then every gather of the thread in flight together
+        int code[CR][CC];
+#pragma unroll
+        for (int r = 0; r < CR; ++r)
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                const int i = r * GR + gi, j = c * GC + gj;
+                code[r][c] = (i < f && j < fprime) ? td[i * fprime + j] : -1;
+            }
+#pragma unroll
+        for (int r = 0; r < CR; ++r)
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                const int cd = code[r][c];
+                Blk v{0.0, 0.0, 0.0, 0.0};
+                if (cd <= -2) { const double2 y = load_vec(a.W, (size_t)(-(cd + 2)), b, ld); v.v00 = y.x; v.v10 = y.y; }
+                else if (cd >= 0 && !((cd >> 28) & 1)) {
+                    v = load_blk(a.X, (size_t)(cd & 0x0fffffff), b, ld);
+                    if ((cd >> 28) & 2) { const double sw = v.v01; v.v01 = v.v10; v.v10 = sw; }      // symmetric plans: Lh(i,c) = U(c,i)'
+                }
+                T[r][c] = v;
+                const int i = r * GR + gi, j = c * GC + gj;
+                if (i == j && i < m) *(double2*)(Dref + (size_t)i * 2) = row_max(v);                  // pivot guard: the block as it entered the task
+            }
+    }
+    if (prof) pt[1] = wall_clock64();
+    {   // ---- extend-add (child order fixed => deterministic)
+        const int* cd = td + h[7];
+        for (int ch = 0; ch < nchild; ++ch) {
+            const int coff = cd[0], cen = cd[1];
+            const int* inv = cd + 2;
+            const double* C = stk + coff;
+            int ri[CR], cj[CC];
+#pragma unroll
+            for (int r = 0; r < CR; ++r) { const int i = r * GR + gi; ri[r] = i < f ? inv[i] : -1; }
+#pragma unroll
+            for (int c = 0; c < CC; ++c) { const int j = c * GC + gj; cj[c] = j < fprime ? inv[j] : -1; }
+#pragma unroll
+            for (int r = 0; r < CR; ++r)
+#pragma unroll
+                for (int c = 0; c < CC; ++c)
+                    if (ri[r] >= 0 && cj[c] >= 0) {
+                        const double2* p = (const double2*)(C + ((size_t)ri[r] * (cen + 1) + cj[c]) * 4);
+                        const double2 q0 = p[0], q1 = p[1];
+                        T[r][c].v00 += q0.x; T[r][c].v01 += q0.y; T[r][c].v10 += q1.x; T[r][c].v11 += q1.y;
+                    }
+            cd += 2 + fprime;
+        }
+    }
+    if (prof) pt[2] = wall_clock64();
+    // ---- publish step 0 (zeros where a step must not touch: row: columns <= q, column: rows <= q resp. row q itself)
+#pragma unroll
+    for (int r = 0; r < CR; ++r)
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            const int i = r * GR + gi, j = c * GC + gj;
+            if (i == 0) lds_set(Ubuf[0], j, j > 0 ? T[r][c] : zero_blk());
+            if (j == 0) lds_set(Lbuf[0], i, i > 0 ? T[r][c] : zero_blk());
+        }
+    if (tid == 0) {
+        const Blk d0 = factor_diag(T[0][0], bad, *(const double2*)Dref);     // (Dref[0] was written by this very thread)
+        lds_set(Dbuf[0], 0, d0);
+        T[0][0] = d0;
+    }
+    sync();
+    // ---- pivot steps
+    for (int qv = 0; qv < m; ++qv) {
+        const int q = uniform(qv);
+        const int cur = q & 1, nxt = cur ^ 1;
+        Blk D = lds_get(Dbuf[cur], 0);
+        D = Blk{uniform_d(D.v00), uniform_d(D.v01), uniform_d(D.v10), uniform_d(D.v11)};
+        const int sw = uniform(D.v10 > 2.0 ? 1 : 0);
+        const double dl = D.v10 - 4.0 * sw;
+        const int rs = JORDAN ? 0 : (q + 1) >> GRL, cs = (q + 1) >> GCL;       // first classes with a row / column the step can change
+        Blk Lq[CR];
+#pragma unroll
+        for (int r = 0; r < CR; ++r) if (r >= rs && r < re) Lq[r] = lds_get(Lbuf[cur], r * GR + gi);
+#pragma unroll
+        for (int c = 0; c < CC; ++c)
+            if (c >= cs && c < ce) {
+                const double2* p = (const double2*)(Ubuf[cur] + (size_t)(c * GC + gj) * 4);
+                const double2 a0 = p[sw], a1 = p[sw ^ 1];
+                Blk z;                                           // z = D^-1 U(q, c): rows of U read in pivot order
+                z.v10 = (a1.x - dl * a0.x) * D.v11; z.v00 = (a0.x - D.v01 * z.v10) * D.v00;
+                z.v11 = (a1.y - dl * a0.y) * D.v11; z.v01 = (a0.y - D.v01 * z.v11) * D.v00;
+#pragma unroll
+                for (int r = 0; r < CR; ++r) if (r >= rs && r < re) blk_sub(T[r][c], Lq[r], z);
+            }
+        if (q + 1 < m) {                                         // the next pivot row / column / block leave their owners
+            const int rqr = (q + 1) >> GRL, tqr = (q + 1) & (GR - 1), rqc = (q + 1) >> GCL, tqc = (q + 1) & (GC - 1);
+            if (gi == tqr && gj == tqc) {                        // the owner of S(q+1, q+1): final now, factorised here
+                const double2 ref = *(const double2*)(Dref + (size_t)(q + 1) * 2);
+#pragma unroll
+                for (int r = 0; r < CR; ++r)
+#pragma unroll
+                    for (int c = 0; c < CC; ++c)
+                        if (r == rqr && c == rqc) {
+                            const Blk dn = factor_diag(T[r][c], bad, ref);
+                            lds_set(Dbuf[nxt], 0, dn);
+                            T[r][c] = dn;
+                        }
+            }
+            if (gi == tqr) {
+#pragma unroll
+                for (int r = 0; r < CR; ++r)
+                    if (r == rqr) {
+#pragma unroll
+                        for (int c = 0; c < CC; ++c) {
+                            if (c < rqc) lds_set(Ubuf[nxt], c * GC + gj, zero_blk());
+                            else if (c > rqc) lds_set(Ubuf[nxt], c * GC + gj, T[r][c]);
+                            else lds_set(Ubuf[nxt], c * GC + gj, gj > tqc ? T[r][c] : zero_blk());
+                        }
+                    }
+            }
+            if (gj == tqc) {
+#pragma unroll
+                for (int c = 0; c < CC; ++c)
+                    if (c == rqc) {
+#pragma unroll
+                        for (int r = 0; r < CR; ++r) {
+                            if (r < rqr) lds_set(Lbuf[nxt], r * GR + gi, JORDAN ? T[r][c] : zero_blk());     // JORDAN: the rows above lose column q + 1 too
+                            else if (r > rqr) lds_set(Lbuf[nxt], r * GR + gi, T[r][c]);
+                            else lds_set(Lbuf[nxt], r * GR + gi, (JORDAN ? gi != tqr : gi > tqr) ? T[r][c] : zero_blk());
+                        }
+                    }
+            }
+        }
+        sync();
+    }
+    if (prof) pt[3] = wall_clock64();
+    // ---- store
+    const int lgo = h[12];
+    double2* out = e > 0 ? stack_unit(a, b, h[4], lgo) : nullptr;
+    const int jb = JORDAN ? h[14] : -1;
+#pragma unroll
+    for (int r = 0; r < CR; ++r)
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            const int i = r * GR + gi, j = c * GC + gj;
+            const int cd = (i < f && j < fprime) ? td[i * fprime + j] : -1;
+            const Blk& v = T[r][c];
+            if (JORDAN && i < m && j >= m && j < f) store_blk(a.X, (size_t)(jb + i * e + (j - m)), b, ld, v.v00, v.v01, v.v10, v.v11);
+            else if (cd <= -2) store_vec(a.W, (size_t)(-(cd + 2)), b, ld, v.v00, v.v10);
+            else if (cd >= 0 && (!((cd >> 28) & 4) || (i == j && i < m))) store_blk(a.X, (size_t)(cd & 0x0fffffff), b, ld, v.v00, v.v01, v.v10, v.v11);
+            else if (i >= m && i < f && j >= m && j < fprime) {                              // update matrix | vector: scenario-major stack
+                double2* p = out + ((((size_t)(i - m) * (e + 1) + (j - m)) * 2) << lgo);
+                p[0] = double2{v.v00, v.v01}; p[(size_t)1 << lgo] = double2{v.v10, v.v11};
+            }
+        }
+    if (bad) atomicOr(a.status + b, 4);
+    if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pt[4] = wall_clock64(); }
+}
+
 // ---- grouped tasks (jg_symbolic.hpp): one workgroup per (task, G consecutive scenarios), G = 4 or 16 ---------------------------------
 // The same elimination as k_fact_top<CLS, false> -- dense front in registers, pivot row / column / pivot through LDS, one barrier per
 // pivot, the owner of the next diagonal block factorises it -- on G thread grids of T x T (T = 8 / 4) instead of one of 16 x 16:
@@ -1726,6 +1936,25 @@ int Engine::factor(hipStream_t st, const double* A, const double* rhs, const Gro
             if (L.grouped) {                                     // every grouped task of the level: 4 or 16 scenarios per workgroup
                 t.wg_begin = L.wg_begin; t.nwg = L.nwg;
                 hipLaunchKernelGGL((k_fact_grp<4>), dim3((unsigned)L.nwg * gs), dim3(256), 0, st, t);
+                continue;
+            }
+            // round 5: narrow task kernels (k_fact_topw) for the front classes they exist for -- bitwise the results of k_fact_top.  JG_TOPW=1: W1 (class 2), 2: W2
+            // (class 3), 3: both; default 0 = the wide kernel everywhere: MEASURED SLOWER (profiles/r05_topw_ab.txt: factorisation of 512 scenarios 1.164 -> 1.189 ms
+            // with W1, -> 1.317 with W2, a single instance 0.241 -> 0.423 ms).  A lone wave issues one instruction per ~4.5 clocks whatever its kind, so a scenario's
+            // step on ONE wave (16 block updates + their bookkeeping, ~350 instructions at best, 766 as compiled) is slower than the same step spread over the four
+            // SIMDs of a CU, and the register file -- not the thread count -- caps the scenarios a CU holds (a 31-row front is 124 VGPRs x 64 lanes however it is
+            // dealt: 8 waves of W1 against 7 workgroups of k_fact_top<2>).  Kept as a checked experiment (tests/test_top_variants_gpu.py), DESIGN_LOG round 5.
+            static const int topw_env = getenv("JG_TOPW") ? atoi(getenv("JG_TOPW")) : 0;
+            if (L.cls == 2 && (topw_env & 1)) {
+                const dim3 gridw((unsigned)L.ntasks * ((t.lpg + TOPW_SPW - 1) / TOPW_SPW) * gs);
+                if (jordan) hipLaunchKernelGGL((k_fact_topw<3, 3, 4, 4, true>), gridw, dim3(64, TOPW_SPW), 0, st, t);
+                else hipLaunchKernelGGL((k_fact_topw<3, 3, 4, 4, false>), gridw, dim3(64, TOPW_SPW), 0, st, t);
+                continue;
+            }
+            if (L.cls == 3 && (topw_env & 2)) {
+                const dim3 gridw((unsigned)L.ntasks * t.lpg * gs);
+                if (jordan) hipLaunchKernelGGL((k_fact_topw<3, 4, 6, 3, true>), gridw, dim3(128), 0, st, t);
+                else hipLaunchKernelGGL((k_fact_topw<3, 4, 6, 3, false>), gridw, dim3(128), 0, st, t);
                 continue;
             }
             const dim3 grid((unsigned)L.ntasks * t.lpg * gs);

@@ -50,6 +50,18 @@ def test_top_kernel_variants_and_level0_routes_give_the_same_bits(case, batch):
     assert _run(case, batch, JG_ITEM_ORDER=0)[0] == ref              # items of a level dealt heaviest first
     assert _run(case, batch, JG_TOP_FUSE=1)[0] == ref                # two pivots per barrier: every thread redoes what the owners of the
                                                                      # second pivot's row / column / block do, operation for operation
+    assert _run(case, batch, JG_TOPW=3)[0] == ref                    # round 5: the one- / two-wave kernels (opt-in) for the front classes they exist for
+
+
+@pytest.mark.parametrize("case,batch", [("case_ACTIVSg10k", 512), ("case_ACTIVSg10k", 1), ("case9241synth", 256)])
+def test_narrow_top_kernels_give_the_bits_of_the_wide_one(case, batch):
+    """k_fact_topw (one wave per scenario for fronts of class 2, two for class 3; jg_engine.hip) performs the elimination of k_fact_top operation for
+    operation and skips only blocks a step cannot change: same bits, in the plan class of the headline batch, of a single instance and of a 256-lane batch.
+    (Opt-in, JG_TOPW: measured slower than the wide kernel -- profiles/r05_topw_ab.txt -- and kept as a checked experiment.)"""
+    ref, iters = _run(case, batch)
+    assert iters >= 3 * batch
+    for mode in (1, 2, 3):
+        assert _run(case, batch, JG_TOPW=mode)[0] == ref, mode
 
 
 SCRIPT_STATE = r"""
