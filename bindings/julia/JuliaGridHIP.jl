@@ -31,6 +31,8 @@
 #   gaussNewton(monitoring, HIPOrthogonal)  (Orthogonal / PetersWilkinson rows) acStateEstimation.jl:906-971 -> jg_gn_set_method
 #   pmuStateEstimation(monitoring, T), solve!  pmuStateEstimation.jl:43-177, 369-399 -> jg_gn_create (codes 22-27), jg_gn_increment, jg_gn_solve
 #   chiTest(analysis)                    badData.jl:948-995             -> jg_gn_evaluate, jg_gn_get_residual (se.objective)
+#   Monte-Carlo batch (user loop over add<Meter>!(noise = true) + stateEstimation!, measurement/utility.jl:70-73) -> jg_gn_run on a batch,
+#                                        jg_gn_get_objective, jg_gn_pack_results_device, jg_gn_allgather_results
 module JuliaGridHIP
 
 using JuliaGrid
@@ -843,6 +845,94 @@ function contingencyAnalysis(system::PowerSystem, labels::Vector{Int64}, comm::C
     return b
 end
 
+# ---- sharded Monte-Carlo state estimation (jgrid.h: jg_gn_pack_results_device, jg_gn_allgather_results) ---------------------------------
+"""
+    GaussNewtonBatch(monitoring, batch; device = 0)
+
+`batch` noisy realisations of ONE measurement set (the reference draws a realisation inside `add<Meter>!(...; noise = true)`,
+src/measurement/utility.jl:70-73, and estimates them one after the other, acStateEstimation.jl:1286-1329): same rows, type codes and Jacobian
+pattern, per-realisation means and precisions.  Results are [n, batch] matrices / [batch] vectors.
+"""
+mutable struct GaussNewtonBatch
+    monitoring::Measurement
+    batch::Int
+    handle::Handle
+    rows::Int
+    magnitude::Matrix{Float64}
+    angle::Matrix{Float64}
+    iteration::Vector{Int32}
+    status::Vector{Int32}                          # 0 converged, 1 iteration limit, 3 singular gain matrix
+    objective::Vector{Float64}                     # se.objective = r' W r per realisation (equations.jl:689-698)
+end
+
+function GaussNewtonBatch(monitoring::Measurement, batch::Int; device::Int = 0)
+    base = gaussNewton(monitoring, LU)
+    m = base.method
+    system = monitoring.system
+    ac, br = system.model.ac, system.branch
+    code, status, corr = typeCodes(monitoring)
+    param = Matrix{Float64}(undef, 6, br.number)
+    for k = 1:br.number
+        param[:, k] .= (real(ac.admittance[k]), imag(ac.admittance[k]), br.parameter.conductance[k],
+                        br.parameter.susceptance[k], br.parameter.turnsRatio[k], br.parameter.shiftAngle[k])
+    end
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:jg_gn_create, lib), Cint,
+        (Ref{Ptr{Cvoid}}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64},
+         Int64, Int64, Ptr{Int8}, Ptr{Int8}, Ptr{Int64}, Int64, Ptr{Int64}, Int64, Cint),
+        h, system.bus.number, ac.nodalMatrix.colptr, ac.nodalMatrix.rowval, reim(ac.nodalMatrix.nzval),
+        reim(ac.nodalMatrixTranspose.nzval), br.number, br.layout.from, br.layout.to, param,
+        system.bus.layout.slack, length(code), code, status, m.index, length(corr), isempty(corr) ? Int64[0] : corr, batch, device))
+    b = GaussNewtonBatch(monitoring, batch, Handle(h[], :gn), length(code), zeros(system.bus.number, batch), zeros(system.bus.number, batch),
+        zeros(Int32, batch), zeros(Int32, batch), zeros(batch))
+    W = m.precision
+    wdiag = [W[r, r] for r = 1:length(m.mean)]
+    woff = Float64[W[r, r + 1] for r in corr]
+    check(ccall((:jg_gn_set_measurement, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Int64),
+        b.handle.ptr, m.mean, wdiag, isempty(woff) ? [0.0] : woff, 0, 0))
+    check(ccall((:jg_gn_set_voltage, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64), b.handle.ptr,
+        base.voltage.magnitude, base.voltage.angle, 0))
+    return b
+end
+
+"se.mean and the diagonal (+ pair terms `woff` [pairs, batch]) of se.precision per realisation: [rows, batch] each (acStateEstimation.jl:135-236)"
+function setRealisations!(b::GaussNewtonBatch, mean::Matrix{Float64}, wdiag::Matrix{Float64}, woff::Matrix{Float64} = zeros(1, b.batch))
+    size(mean) == (b.rows, b.batch) && size(wdiag) == (b.rows, b.batch) || throw(DimensionMismatch("[rows, batch] means and precisions"))
+    check(ccall((:jg_gn_set_measurement, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Int64),
+        b.handle.ptr, mean, wdiag, woff, b.rows, size(woff, 1)))
+end
+
+"stateEstimation!(analysis; iteration, tolerance) for every realisation of the batch (acStateEstimation.jl:1286-1329), then voltages and objectives"
+function stateEstimation!(b::GaussNewtonBatch; iteration::Int64 = 40, tolerance::Float64 = 1e-8, fetch::Bool = true)
+    check(ccall((:jg_gn_run, lib), Cint, (Ptr{Cvoid}, Int64, Float64, Ptr{Int32}, Ptr{Int32}), b.handle.ptr, iteration, tolerance, b.iteration, b.status))
+    if fetch
+        check(ccall((:jg_gn_get_voltage, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), b.handle.ptr, b.magnitude, b.angle))
+        check(ccall((:jg_gn_get_objective, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), b.handle.ptr, b.objective))
+    end
+    return nothing
+end
+
+"the batch's result record (magnitude | angle | iterations | status | objective per realisation, [2n + 3, batch]) into a DEVICE buffer of the caller"
+packResults!(b::GaussNewtonBatch, record::Ptr{Float64}) =
+    check(ccall((:jg_gn_pack_results_device, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), b.handle.ptr, record))
+
+"""
+    monteCarloEstimation(monitoring, mean, wdiag, comm; iteration = 40, tolerance = 1e-8, record)
+
+Noisy realisations (columns of `mean` / `wdiag`, [rows, realisations]) sharded over the ranks of `comm`: this rank estimates its contiguous block as one batch
+(every rank the same count), then ONE all-gather hands every rank the record of all realisations: `record` = DEVICE memory for `world * batch` rows
+of `2n + 3` doubles (magnitude | angle | iterations | status | objective).
+"""
+function monteCarloEstimation(monitoring::Measurement, mean::Matrix{Float64}, wdiag::Matrix{Float64}, comm::Comm; iteration::Int64 = 40,
+                              tolerance::Float64 = 1e-8, record::Ptr{Float64})
+    mine = shard(size(mean, 2), comm.rank, comm.world)
+    b = GaussNewtonBatch(monitoring, length(mine); device = comm.device)
+    setRealisations!(b, mean[:, mine], wdiag[:, mine])
+    stateEstimation!(b; iteration, tolerance, fetch = false)
+    check(ccall((:jg_gn_allgather_results, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}), b.handle.ptr, comm.ptr, record))
+    return b
+end
+
 "drops the library's cached symbolic analyses (live analyses keep theirs): the next newtonRaphson(system, HIP) pays a full analysis again"
 clearPlanCache() = ccall((:jg_plan_cache_clear, lib), Cvoid, ())
 
@@ -954,6 +1044,6 @@ end
 export HIP, HIPOrthogonal, NewtonRaphsonBatch, setOutages!, shareDevice!, branchQuantities, screenSummary, powerFlowDefer!, moveLanes!, finish!, resume!, jacobian!,
        largestNormalizedResidual, normalizedResiduals, commUniqueId, Comm, shard, contingencyAnalysis, clearPlanCache,
        deviceCount, dims, setRefinement!, deviceMaps, setOutage!, snapshotVoltage!, restoreVoltage!, iterations, voltageDevice!, packResults!, packRows!,
-       allgatherDevice, commRank, commWorld, timeKernel
+       allgatherDevice, commRank, commWorld, timeKernel, GaussNewtonBatch, setRealisations!, monteCarloEstimation
 
 end # module

@@ -286,6 +286,20 @@ int jg_gn_get_jacobian(jg_gn* h, double* nzval);
 int jg_gn_get_residual(jg_gn* h, double* residual);
 int jg_gn_get_increment(jg_gn* h, double* increment);
 int jg_gn_get_iteration(jg_gn* h, int32_t* iters);
+/* se.objective = r' W r at the residual the handle holds (the last increment! / evaluate: after stateEstimation! the residual of every scenario at its
+ * final state) -- src/backend/equations.jl:689-698 incl. the cross terms of correlated PMU pairs --, reduced on the device in a fixed order; [batch]. */
+int jg_gn_get_objective(jg_gn* h, double* objective);
+/*
+ * Sharded Monte-Carlo state estimation (SURVEY.md 8e for the Gauss-Newton side): noisy realisations of one measurement set are independent scenarios
+ * (the reference draws them in add<Meter>!(...; noise = true), src/measurement/utility.jl:70-73, and estimates them one after the other,
+ * acStateEstimation.jl:1286-1329); a rank estimates a contiguous block of them and ONE collective hands every rank the whole result.
+ *   jg_gn_pack_results_device  the handle's record after jg_gn_run into device memory of the caller: [batch][2 n + 3] =
+ *                              magnitude[n] | angle[n] | method.iteration | status | se.objective  per realisation (the state arrays as jg_gn_get_voltage
+ *                              returns them; bitwise the getters' values).  Returns after the stream has drained.
+ *   jg_gn_allgather_results    packs into block `rank` of dst_dev [world x batch][2 n + 3] and gathers in place (ncclAllGather of RCCL on the handle's
+ *                              stream); every rank calls it with the same batch.
+ */
+int jg_gn_pack_results_device(jg_gn* h, double* dst_dev);
 /* residualTest!(analysis) -- src/stateEstimation/badData.jl:119-311, the numeric part, per scenario: residual, Jacobian,
  * gain and its factor at the CURRENT state, selected inverse of the gain on its factor pattern (replaces
  * takahashiCholeskyLower / selectedInverse, :536-637), c = rowProjection (:289-311), normalised residuals
@@ -328,6 +342,7 @@ int jg_comm_rank(const jg_comm* c);
 int jg_comm_world(const jg_comm* c);
 int jg_comm_allgather_device(jg_comm* c, const double* send_dev, double* recv_dev, int64_t count);
 int jg_nr_allgather_results(jg_nr* h, jg_comm* c, double* dst_dev);
+int jg_gn_allgather_results(jg_gn* h, jg_comm* c, double* dst_dev);
 
 /* ---------------------------------------------------------------------------------------------
  * Symbolic analysis only (no device needed): the static schedule that replaces the symbolic half

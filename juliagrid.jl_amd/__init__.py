@@ -16,6 +16,7 @@ from .stateestimation import (WlsMethod, Normal, LU, KLU, QR, LDLt, LL, Orthogon
                               AcStateEstimation, PmuStateEstimation, pmuStateEstimation, gaussNewton, increment_ as incrementSE_, solve_ as solveSE_,   # noqa: F401
                               stateEstimation_, setNoise_, residualTest_, normalizedResidual, chiTest,
                               updateVoltmeter_, updateAmmeter_, updateWattmeter_, updateVarmeter_, updatePmu_)
+from .montecarlo import MonteCarloPipeline, gatherEstimates, gatherEstimatesDevice, unpackEstimates   # noqa: F401
 from .synthetic import pegaseShaped, case9241synth                          # noqa: F401
 from . import powerflow, stateestimation   # noqa: F401
 from . import _lib                                                           # noqa: F401
@@ -28,5 +29,5 @@ __all__ = [
     "updateVoltmeter_", "updateAmmeter_", "updateWattmeter_", "updateVarmeter_", "updatePmu_",
     "outagePatch", "initializeACPowerFlow", "bridges", "outageList", "shard", "deviceBatching", "contingencyAnalysis", "gatherResults", "gatherResultsDevice", "unpackResults",
     "WlsMethod", "Normal", "LU", "KLU", "QR", "LDLt", "LL", "Orthogonal", "PetersWilkinson",
-    "addBranch_", "dropZeros_", "addBranchSystem_", "dropZerosSystem_", "pegaseShaped", "case9241synth", "ContingencyPipeline", "setOutages_", "power_", "current_", "screenSummary_", "reactiveLimit_", "adjustAngle_",
+    "addBranch_", "dropZeros_", "addBranchSystem_", "dropZerosSystem_", "pegaseShaped", "case9241synth", "ContingencyPipeline", "MonteCarloPipeline", "gatherEstimates", "gatherEstimatesDevice", "unpackEstimates", "setOutages_", "power_", "current_", "screenSummary_", "reactiveLimit_", "adjustAngle_",
 ]

@@ -110,6 +110,9 @@ def lib():
         "jg_gn_get_residual": [VP, F64P],
         "jg_gn_get_increment": [VP, F64P],
         "jg_gn_get_iteration": [VP, I32P],
+        "jg_gn_get_objective": [VP, F64P],
+        "jg_gn_pack_results_device": [VP, VP],
+        "jg_gn_allgather_results": [VP, VP, VP],
         "jg_gn_time_kernel": [VP, C.c_int, C.c_int, C.POINTER(C.c_double)],
         "jg_plan_create": [C.POINTER(VP), C.c_int64, I32P, I32P, C.c_int64],
         "jg_comm_unique_id": [U8P],

@@ -534,6 +534,65 @@ __global__ __launch_bounds__(256) void k_gn_add(double* inc, const double* cor, 
     }
 }
 
+// ---- the result record of a sharded Monte-Carlo run (jgrid.h: jg_gn_pack_results_device) --------------------------------------------------
+// se.objective = r' W r at the residual of the last increment! (equations.jl:689-698), per scenario, reduced where the residuals are: a noisy
+// realisation's residual is 96 723 doubles, its objective one.  Two launches with a FIXED summation order (bitwise run-to-run): a wave sums OBJ_WROWS
+// consecutive rows in row order, the sixteen waves of a workgroup meet in LDS in wave order, the chunks are added in chunk order, then the cross
+// terms 2 r_a r_b W_ab of the correlated PMU pairs in pair order.
+constexpr int OBJ_WROWS = 128, OBJ_ROWS = 16 * OBJ_WROWS;
+__global__ __launch_bounds__(1024) void k_gn_obj_partial(const double* res, const double* w, double* part, int m, int ld, int lanes) {
+    __shared__ double red[16][64];
+    const int lane = threadIdx.x, wave = threadIdx.y;
+    const size_t b = (size_t)min((int)blockIdx.y * 64 + lane, lanes - 1);
+    const int r0 = blockIdx.x * OBJ_ROWS + wave * OBJ_WROWS, r1 = min(r0 + OBJ_WROWS, m);
+    double acc = 0.0;
+    for (int r = r0; r < r1; r += 4) {                                   // four rows in flight, added in row order
+        double x[4], y[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int q = min(r + u, m - 1); x[u] = res[(size_t)q * ld + b]; y[u] = w[(size_t)q * ld + b]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (r + u < r1) acc += x[u] * x[u] * y[u];
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+        for (int k = 1; k < 16; ++k) acc += red[k][lane];
+        part[(size_t)blockIdx.x * ld + blockIdx.y * 64 + lane] = acc;
+    }
+}
+__global__ __launch_bounds__(64) void k_gn_obj_final(const double* part, int chunks, const double* res, const double* woff, const int* corr_row, int ncorr,
+                                                     double* obj, int ld, int lanes) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= lanes) return;
+    double acc = 0.0;
+    for (int c = 0; c < chunks; ++c) acc += part[(size_t)c * ld + b];
+    for (int q = 0; q < ncorr; ++q) {                                    // the cross term sits on the pair's second row in the reference (:694-698)
+        const int r = corr_row[q];
+        acc += 2.0 * res[(size_t)r * ld + b] * res[(size_t)(r + 1) * ld + b] * woff[(size_t)q * ld + b];
+    }
+    obj[b] = acc;
+}
+// [n][ld] rows -> the scenario-major record (the transpose kernel of the power-flow record, jg_nr.hip: k_pack_bus): z = 0 magnitudes, 1 angles
+__global__ __launch_bounds__(512) void k_gn_pack_bus(const double* vm, const double* va, double* dst, int n, int ld, int batch, long long stride) {
+    __shared__ double tile[64][65];
+    const double* src = blockIdx.z ? va : vm;
+    const int off = blockIdx.z ? n : 0;
+    const int i0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+    for (int r = threadIdx.y; r < 64; r += blockDim.y) {
+        const int i = i0 + r, b = b0 + threadIdx.x;
+        tile[r][threadIdx.x] = (i < n && b < ld) ? src[(size_t)i * ld + b] : 0.0;
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 64; r += blockDim.y) {
+        const int b = b0 + r, i = i0 + threadIdx.x;
+        if (b < batch && i < n) dst[(size_t)b * stride + off + i] = tile[threadIdx.x][r];
+    }
+}
+__global__ void k_gn_pack_tail(const int* iters, const int* status, const double* obj, double* dst, int batch, long long stride, int off) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < batch) { double* q = dst + (size_t)b * stride + off; q[0] = (double)iters[b]; q[1] = (double)status[b]; q[2] = obj[b]; }
+}
+
 // max |increment| per scenario (partial per bus chunk); forces increment[slack theta] = 0 (:899)
 __global__ __launch_bounds__(256) void k_gn_norm(double* inc, double* part, int n, int slack, int ld) {
     __shared__ double red[4][64];
@@ -689,6 +748,8 @@ struct jg_gn {
     int method = 0;                                     // jg_gn_set_method: 0 normal equations, 1 + one least-squares correction pass
     double* d_rho = nullptr; double* d_rhs2 = nullptr; double* d_inc2 = nullptr;   // correction pass (allocated by jg_gn_set_method)
     int* d_active = nullptr; int* d_iters = nullptr; int* d_status = nullptr; int* d_counter = nullptr; int* d_group = nullptr;
+    double* d_obj = nullptr; double* d_objpart = nullptr; int* d_corr = nullptr; int obj_chunks = 0;   // objective per scenario (first use: jg_gn_get_objective / jg_gn_pack_results_device)
+    bool ran = false;                                   // d_iters / d_status hold the verdicts of a stateEstimation! run
     jg::Engine eng;
     hipStream_t stream = nullptr;
     hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
@@ -1142,6 +1203,7 @@ void jg_gn_destroy(jg_gn* h) {
     hipFree(h->d_arena);                                         // V, theta, z, weights, slots, residual, rhs, increment, norms, lane bookkeeping: one allocation (jg_gn_create)
     hipFree(h->d_pair_ptr); hipFree(h->d_pa); hipFree(h->d_pb); hipFree(h->d_pz); hipFree(h->d_nres); hipFree(h->d_amax_v); hipFree(h->d_amax_i);
     hipFree(h->d_bad_v); hipFree(h->d_bad_i);
+    hipFree(h->d_obj); hipFree(h->d_objpart); hipFree(h->d_corr);
     hipFree(h->d_grec); hipFree(h->d_gwave); hipFree(h->d_rrec); hipFree(h->d_rwave); hipFree(h->d_gtask); hipFree(h->d_gstage); hipFree(h->d_trec);
     if (h->h_counter) hipHostFree(h->h_counter);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -1281,8 +1343,65 @@ int jg_gn_run(jg_gn* h, int64_t max_iter, double tol, int32_t* iters, int32_t* s
         GN_HIP(hipStreamSynchronize(h->stream));
         if (*h->h_counter == 0) break;
     }
+    h->ran = true;
     if (iters) GN_HIP(jg::sync_copy(iters, h->d_iters, (size_t)h->batch * 4, hipMemcpyDeviceToHost, h->stream));
     if (status) GN_HIP(jg::sync_copy(status, h->d_status, (size_t)h->batch * 4, hipMemcpyDeviceToHost, h->stream));
+    return 0;
+}
+
+namespace {
+// se.objective of every scenario from the residual the handle holds, into d_obj (stream-ordered, not synchronised)
+int launch_objective(jg_gn* h) {
+    if (!h->d_obj) {
+        h->obj_chunks = (h->m + OBJ_ROWS - 1) / OBJ_ROWS;
+        GN_HIP(hipMalloc((void**)&h->d_obj, (size_t)h->ld * 8));
+        GN_HIP(hipMalloc((void**)&h->d_objpart, (size_t)h->obj_chunks * h->ld * 8));
+        std::string err;
+        if (jg::upload(&h->d_corr, h->corr_row, err, h->stream)) return failg(2, err);
+    }
+    hipLaunchKernelGGL(k_gn_obj_partial, dim3(h->obj_chunks, h->ld / 64), dim3(64, 16), 0, h->stream, h->d_res, h->d_w, h->d_objpart, h->m, h->ld, h->batch);
+    hipLaunchKernelGGL(k_gn_obj_final, dim3(h->ld / 64), dim3(64), 0, h->stream, h->d_objpart, h->obj_chunks, h->d_res, h->d_w + (size_t)h->m * h->ld, h->d_corr, h->ncorr,
+                       h->d_obj, h->ld, h->batch);
+    GN_HIP(hipGetLastError());
+    return 0;
+}
+int launch_pack(jg_gn* h, double* dst) {
+    if (int rc = launch_objective(h)) return rc;
+    const long long stride = 2LL * h->n + 3;
+    hipLaunchKernelGGL(k_gn_pack_bus, dim3((h->n + 63) / 64, (h->ld + 63) / 64, 2), dim3(64, 8), 0, h->stream, h->d_vm, h->d_va, dst, h->n, h->ld, h->batch, stride);
+    hipLaunchKernelGGL(k_gn_pack_tail, dim3((h->batch + 255) / 256), dim3(256), 0, h->stream, h->d_iters, h->d_status, h->d_obj, dst, h->batch, stride, 2 * h->n);
+    GN_HIP(hipGetLastError());
+    return 0;
+}
+}  // namespace
+
+int jg_gn_get_objective(jg_gn* h, double* objective) {
+    if (!h || !objective) return failg(1, "jg_gn_get_objective: bad argument");
+    if (int rc = set_device(h)) return rc;
+    if (int rc = launch_objective(h)) return rc;
+    GN_HIP(jg::sync_copy(objective, h->d_obj, (size_t)h->batch * 8, hipMemcpyDeviceToHost, h->stream));
+    return 0;
+}
+
+int jg_gn_pack_results_device(jg_gn* h, double* dst_dev) {
+    if (!h || !dst_dev) return failg(1, "jg_gn_pack_results_device: bad argument");
+    if (!h->ran) return failg(1, "jg_gn_pack_results_device: no stateEstimation! run on this handle yet (jg_gn_run): iterations and status are undefined");
+    if (int rc = set_device(h)) return rc;
+    if (int rc = launch_pack(h, dst_dev)) return rc;
+    GN_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int jg_gn_allgather_results(jg_gn* h, jg_comm* c, double* dst_dev) {
+    if (!h || !c || !dst_dev) return failg(1, "jg_gn_allgather_results: bad argument");
+    if (!h->ran) return failg(1, "jg_gn_allgather_results: no stateEstimation! run on this handle yet (jg_gn_run)");
+    if (jg::comm_device(c) != h->device) return failg(1, "jg_gn_allgather_results: communicator and handle live on different devices");
+    if (int rc = set_device(h)) return rc;
+    const size_t count = (size_t)h->batch * (2 * (size_t)h->n + 3);
+    double* mine = dst_dev + (size_t)jg::comm_rank(c) * count;    // in-place all-gather: this rank's record sits in its own block
+    if (int rc = launch_pack(h, mine)) return rc;
+    if (int rc = jg::comm_allgather(c, mine, dst_dev, count, h->stream)) return rc;
+    GN_HIP(hipStreamSynchronize(h->stream));
     return 0;
 }
 

@@ -270,6 +270,18 @@ class AcStateEstimation:
             obj = obj + 2.0 * np.sum(res[:, r0] * res[:, r0 + 1] * wo, axis=1)
         return float(obj[0]) if self.batch == 1 else obj
 
+    def objectiveDevice(self):
+        """se.objective per scenario, reduced on the device in a fixed order (jg_gn_get_objective): what the result record carries.  `objective`
+        above sums the pulled residuals on the host -- [batch, m] doubles over PCIe; both follow equations.jl:689-698 and agree to rounding."""
+        o = np.zeros(self.batch)
+        _lib.check(_lib.lib().jg_gn_get_objective(self._h, o))
+        return float(o[0]) if self.batch == 1 else o
+
+    def pack_results_device(self, ptr: int):
+        """The result record of the last stateEstimation_ -- magnitude | angle | iterations | status | objective per scenario, [batch, 2 n + 3] float64 --
+        into DEVICE memory of the caller (the operand of the one gather of a sharded Monte-Carlo run)."""
+        _lib.check(_lib.lib().jg_gn_pack_results_device(self._h, _lib.VP(int(ptr))))
+
     def time_kernel(self, kernel: int, reps: int = 10) -> float:
         ms = C.c_double(0.0)
         _lib.check(_lib.lib().jg_gn_time_kernel(self._h, int(kernel), int(reps), C.byref(ms)))

@@ -101,3 +101,53 @@ def test_two_rank_gloo_gather(tmp_path):
             break
     assert out.returncode == 0, out.stdout + out.stderr
     assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+
+
+WORKER_SE = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, {root!r})
+    import numpy as np, torch, torch.distributed as dist
+    import juliagrid.jl_amd as jg
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    B, n = 5, 4
+    total = B * world
+    lo, hi = jg.shard(total, rank, world)
+    ids = torch.arange(lo, hi)
+    vm = (ids[:, None] * 7 + torch.arange(n)[None, :]).to(torch.float64)
+    va = -0.5 * vm
+    iters = (ids % 3 + 4).double()
+    status = (ids % 5 == 0).double()
+    obj = (ids * 1000 + 0.25).double()
+    packed = torch.cat([vm, va, iters[:, None], status[:, None], obj[:, None]], dim=1)      # the record jg_gn_pack_results_device writes: [B, 2 n + 3]
+    calls = []
+    real = dist.all_gather_into_tensor
+    dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    g_it, g_st, g_obj, g_vm, g_va = jg.gatherEstimates(dist, packed)
+    dist.all_gather_into_tensor = real
+    assert len(calls) == 1                                   # ONE collective for the whole Monte-Carlo result
+    all_ids = torch.arange(total)
+    assert torch.equal(g_it, (all_ids % 3 + 4).long()) and torch.equal(g_st, (all_ids % 5 == 0).long())
+    assert torch.equal(g_obj, (all_ids * 1000 + 0.25).double())
+    assert torch.equal(g_vm, (all_ids[:, None] * 7 + torch.arange(n)[None, :]).to(torch.float64)) and torch.equal(g_va, -0.5 * g_vm)
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.stdout.write("rank %d ok" % rank + chr(10))
+    sys.stdout.flush()
+""")
+
+
+def test_two_rank_gloo_gather_of_estimation_records(tmp_path):
+    """The Monte-Carlo side of SURVEY 8(e): realisations shard contiguously, ONE all-gather of the [., 2 n + 3] record (magnitude | angle | iterations |
+    status | objective) gives every rank the whole study in realisation order."""
+    script = tmp_path / "worker_se.py"
+    script.write_text(WORKER_SE.format(root=ROOT))
+    for attempt in range(3):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                              "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"], str(script)],
+                             capture_output=True, text=True, timeout=300, env=env)
+        if out.returncode == 0 or "AssertionError" in out.stderr:
+            break
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
