@@ -326,6 +326,222 @@ def se_config4(jg, case="case9241synth", batch=512, steps=12, warmup=2, inflight
     return line
 
 
+def make_gather(jg, torch, dist, rank, world, local, cdev, force_dist, lanes, width):
+    """The ONE collective of a device batch.  Default for N > 1 on the GPU: the library's own C ABI (jg_comm_*: ncclAllGather of librccl,
+    csrc/jg_comm.cpp) -- what a Julia host calls; rank 0 draws the communicator id and torch.distributed only ships its 128 bytes.  JG_BENCH_GATHER=torch
+    (or a communicator that cannot be built: no librccl) falls back to torch.distributed.all_gather_into_tensor.  Returns (deliver(buf), label, close)."""
+    if not (world > 1 or force_dist):
+        return (lambda buf: None), "none (one rank)", (lambda: None)
+    want = os.environ.get("JG_BENCH_GATHER", "abi" if world > 1 else "torch")
+    comm = gathered = None
+    note = ""
+    if want == "abi" and cdev == "cuda":
+        ok = torch.ones(1, dtype=torch.int32, device="cuda")
+        try:
+            uid = torch.from_numpy(jg._lib.Comm.unique_id() if rank == 0 else np.zeros(jg._lib.COMM_ID_BYTES, dtype=np.uint8)).cuda()
+        except Exception as e:                        # librccl could not be bound on rank 0: every rank must take the same path
+            uid = torch.zeros(jg._lib.COMM_ID_BYTES, dtype=torch.uint8, device="cuda"); ok[0] = 0; note = repr(e)
+        dist.broadcast(uid, src=0)
+        dist.broadcast(ok, src=0)
+        if int(ok.item()):
+            try:
+                comm = jg._lib.Comm(rank, world, uid.cpu().numpy(), device=local)
+            except Exception as e:
+                note = repr(e); comm = None
+            good = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(good, op=dist.ReduceOp.MIN)
+            if not int(good.item()):
+                if comm is not None:
+                    comm.close()
+                comm = None
+        if comm is not None:
+            gathered = torch.empty((world * lanes, width), dtype=torch.float64, device="cuda")
+
+    def deliver(buf):
+        if comm is not None:
+            comm.allgather_device(buf.data_ptr(), gathered.data_ptr(), buf.numel())
+        elif cdev == "cuda":
+            g = torch.empty((world * buf.shape[0], buf.shape[1]), dtype=buf.dtype, device=buf.device)
+            dist.all_gather_into_tensor(g, buf.contiguous())
+            torch.cuda.current_stream().synchronize()
+        else:
+            b = buf.cpu()
+            g = torch.empty((world * b.shape[0], b.shape[1]), dtype=b.dtype)
+            dist.all_gather_into_tensor(g, b.contiguous())
+
+    label = "abi" if comm is not None else ("torch.distributed" + (f" (C-ABI communicator unavailable: {note})" if want == "abi" and cdev == "cuda" and note else ""))
+    return deliver, label, (lambda: comm.close() if comm is not None else None)
+
+
+def timed_regions(torch, dist, world, force_dist, cdev, run, steps):
+    """The K-step region (fenced on both sides, max over ranks), repeated until about a second has been timed; (regions, iterations of one region, last status)."""
+    def fence():
+        if world > 1 or force_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def region():
+        fence()
+        t0 = time.perf_counter()
+        it, st = run(steps)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, it, st
+
+    dt0, iters_local, last_status = region()
+    repeats = max(3, min(int(os.environ.get("JG_BENCH_MAX_REPEATS", "50")), int(np.ceil(float(os.environ.get("JG_BENCH_MIN_SECONDS", "1.0")) / max(dt0, 1e-6)))))
+    regions = [dt0]
+    for _ in range(repeats - 1):
+        dtr, it_r, last_status = region()
+        assert it_r == iters_local, "the same scenarios take the same iterations in every region"
+        regions.append(dtr)
+    return regions, iters_local, last_status
+
+
+def predicted_from_shards(workload, world, total):
+    """What ONE rank's share of this N-GPU run does on one GPU (profiles/bench_shards.json, written by tools/run_evidence.sh on the last box that measured it):
+    N x that rate is the strong-scaling prediction the line carries beside the measurement (the pool has one GPU per box: the 1 -> 8 curve itself
+    is the driver's to measure)."""
+    path = os.path.join(ROOT, "profiles", "bench_shards.json")
+    if world < 2 or not os.path.exists(path):
+        return None
+    try:
+        rows = [r for r in json.load(open(path)).get(workload, []) if r.get("merged") and r["scenarios_per_step"] * world == total]
+        if not rows:
+            return None
+        r = rows[-1]
+        return {"value": world * r["value"], "per_gpu_value": r["value"], "from": "profiles/bench_shards.json",
+                "what": f"{world} x the rate ONE GPU reaches on a rank's share ({r['scenarios_per_step']} scenarios per step, {r['steps_per_device_batch']} steps per device batch, "
+                        f"{r['device_batches_in_flight']} in flight), measured {r.get('measured', 'earlier')}; no gather, no host contention"}
+    except Exception:
+        return None
+
+
+def workload_se(jg, torch, dist, args, rank, local, world, cdev, force_dist):
+    """--workload se: BASELINE config 4 as a sharded Monte-Carlo run.  One step = `--batch` noisy realisations (strong scaling: in total) of the config-4
+    measurement set, each estimated from the flat start by stateEstimation! (tol 1e-8, max 40); a rank estimates its contiguous share, a device batch packs
+    its record (magnitude | angle | iterations | status | objective per realisation, jg_gn_pack_results_device) and ONE all-gather carries it."""
+    case = args.case if args.case != "case_ACTIVSg10k" else "case9241synth"
+    s = jg.powerSystem(load_tables(jg, case))
+    pf = jg.newtonRaphson(s, device=local)
+    jg.powerFlow_(pf, tolerance=1e-11)
+    assert pf.status == 0
+    mon = jg.measurement(s)
+    jg.addVoltmeter_(mon, pf, variance=1e-4)
+    jg.addWattmeter_(mon, pf, variance=1e-4)
+    jg.addVarmeter_(mon, pf, variance=1e-4)
+    jg.addPmu_(mon, pf, buses=range(1, s.bus.number + 1, 10), statusTo=-1, minMagnitude=1e-6)
+    n = s.bus.number
+    total = args.batch if args.scaling == "strong" else args.batch * world
+    lo, hi = jg.shard(total, rank, world)
+    B = hi - lo
+    if B < 1:
+        raise SystemExit(f"rank {rank}: no realisations ({total} over {world} ranks)")
+    b_max = -(-total // world)
+    merge = args.merge if args.merge > 0 else (jg.deviceBatching(b_max, args.steps, 512) if args.scaling == "strong" else 1)
+    merge = max(1, min(merge, args.steps))
+    lanes = B * merge
+    inflight = args.inflight if args.inflight > 0 else 2
+    t0 = time.perf_counter()
+    pipe = jg.MonteCarloPipeline(mon, lanes, inflight=inflight, device=local)
+    t_pipe = time.perf_counter() - t0
+    for k, h in enumerate(pipe.handles):              # the realisations stay resident (a step re-estimates them from the flat start): seeds differ by handle and rank
+        jg.setNoise_(h, np.random.Generator(np.random.PCG64(4 + k + 1000 * rank)), scale=1.0)
+    an = pipe.handles[0]
+    width = pipe.record_width
+    ring = len(pipe.handles)
+    packed = [torch.empty((lanes, width), dtype=torch.float64, device="cuda") for _ in range(ring)]
+    gather, gather_label, gather_close = make_gather(jg, torch, dist, rank, world, local, cdev, force_dist, lanes, width)
+
+    def run(steps):
+        jobs = -(-steps // merge)
+        out = pipe.run([None] * jobs, iteration=40, tolerance=1e-8, on_done=lambda j, h: gather(packed[j % ring]),
+                       record=lambda j: packed[j % ring].data_ptr(), records=ring)
+        real = [min(merge, steps - j * merge) * B for j in range(jobs)]
+        return int(sum(int(np.sum(it[:r])) for (it, _), r in zip(out, real))), out[-1][1][:B]
+
+    run(args.warmup)
+    regions, iters_local, last_status = timed_regions(torch, dist, world, force_dist, cdev, run, args.steps)
+    dt = float(np.median(regions))
+    jobs_per_region = -(-args.steps // merge)
+    steady = jobs_per_region >= 3 * len(pipe.handles)
+    steady_extra = None
+    if not steady:                                    # K as given measures fill + drain of the pipeline: ALSO a region long enough for its steady state
+        ks = 3 * len(pipe.handles) * merge
+        rs, it_s, _ = timed_regions(torch, dist, world, force_dist, cdev, run, ks)
+        steady_extra = (ks, float(np.median(rs)), it_s)
+    conv_local = int(np.sum(last_status == 0))
+    counts = [iters_local, conv_local] + ([steady_extra[2]] if steady_extra else [])
+    if world > 1:
+        cnt = torch.tensor(counts, dtype=torch.int64, device=cdev)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        counts = [int(x) for x in cnt.tolist()]
+    line = None
+    if rank == 0:
+        d = an.dims
+        L = an.batch
+        algo = {"rows": L * (16 * d["slots"] + 16 * d["m"] + 16 * n), "gain": L * (16 * d["slots"] + 8 * d["m"] + 32 * d["gain_blocks"] + 16 * n),
+                "factor": L * (64 * ((d["lu_blocks"] + n) // 2)), "backward": L * (32 * ((d["lu_blocks"] + n) // 2) + 64 * n)}
+        kern = {}
+        for k, name in enumerate(("rows", "gain", "factor", "backward")):
+            ms = float(np.median([an.time_kernel(k, 6 if name == "factor" else 12) for _ in range(5)]))
+            kern[name] = {"ms": ms, "bytes": algo[name], "GBps": algo[name] / ms / 1e6, "frac": algo[name] / ms / 1e6 / HBM_PEAK_GBS}
+        dom = max(kern, key=lambda k: kern[k]["ms"])
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic_se.json")
+        if os.path.exists(pmc):
+            try:
+                pj = json.load(open(pmc))
+                if int(pj.get("batch_ld", 0)) == L and pj.get("grid") == case:
+                    for kk in kern:
+                        kern[kk]["hbm_traffic_bytes_pmc"] = pj["traffic_per_increment"].get(kk)
+                    traffic = pj["traffic_per_increment"].get(dom)
+            except Exception:
+                traffic = None
+        nsc = total * args.steps
+        line = {
+            "metric": "GN iterations/sec (sharded Monte-Carlo WLS state estimation, PMU + legacy, 9241-bus PEGASE-shaped grid)",
+            "value": counts[0] / dt, "unit": "GN iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "region_repeats": len(regions), "region_ms_min": 1e3 * float(np.min(regions)), "region_ms_median": 1e3 * dt, "region_ms_max": 1e3 * float(np.max(regions)),
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{case} Gauss-Newton WLS state estimation (BASELINE config 4), {total} noisy realisations per step ({B} per GPU), flat start, tol 1e-8, max 40",
+                       "grid": case, "buses": n, "rows": d["m"], "nnzH": d["nnzH"], "gain_blocks": d["gain_blocks"], "lu_blocks": d["lu_blocks"], "lu_terms": d["lu_terms"],
+                       "factor_launches": d["factor_launches"], "backward_launches": d["backward_launches"],
+                       "batch_per_gpu": B, "scenarios_per_step": total, "steps_per_device_batch": merge, "lanes_per_device_batch": lanes,
+                       "device_batches_in_flight_per_gpu": len(pipe.handles), "device_batches_per_region": jobs_per_region, "pipeline_steady_state": bool(steady),
+                       "gather": gather_label, "record": f"magnitude | angle | iterations | status | objective, 2 n + 3 = {width} doubles per realisation",
+                       "parallelism": f"realisation-sharded x{world}, one all-gather of the packed record per device batch"},
+            "scenarios_per_s": nsc / dt, "ms_per_solve_batched": 1e3 * dt / nsc, "iterations_per_scenario": counts[0] / nsc,
+            "converged_fraction": counts[1] / total, "pipeline_construction_ms": 1e3 * t_pipe,
+            "roofline": {"bound": "hbm", "kernel": {"rows": "k_gn_rows", "gain": "k_gn_gain", "factor": "k_fact_task + k_fact_top (symmetric plan)", "backward": "k_bwd_level"}[dom],
+                         "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["frac"], "traffic": traffic,
+                         "algorithmic_bytes": kern[dom]["bytes"]},
+            "kernels": kern,
+        }
+        if steady_extra:
+            ks, dts, _ = steady_extra
+            line["value_steady"] = counts[2] / dts
+            line["steady_steps"] = ks
+            line["steady_ms_per_step"] = 1e3 * dts / ks
+            line["steady_what"] = (f"the K = {args.steps}-step region is {jobs_per_region} device batch(es) with {len(pipe.handles)} in flight (fill + drain); value_steady is the same "
+                                   f"measurement over {ks} steps (three rounds of the batches in flight).  value, ms_per_step: the K of the caller, unchanged")
+        pred = predicted_from_shards("se", world, total)
+        if pred:
+            line["predicted"] = pred
+        if world == 1 and not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline_se(jg, s, case, pf, budget_s=10.0)
+            line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
+    gather_close()
+    pipe.close()
+    pf.close()
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -342,6 +558,9 @@ def main():
                     help="what a device batch delivers and a sharded run gathers per scenario: the state record V | theta | iterations | status "
                          "(2 n + 2 doubles: SURVEY 8(e), the default) or the contingency screen summary (10 doubles: worst loading, largest flow, "
                          "voltage extremes, iterations, status -- jg_nr_screen)")
+    ap.add_argument("--workload", choices=("nr", "se"), default="nr",
+                    help="nr: batched N-1 Newton-Raphson (the headline metric); se: BASELINE config 4 as a sharded Monte-Carlo run -- `--batch` noisy realisations "
+                         "per step of the PMU + legacy measurement set on the 9241-bus grid, Gauss-Newton WLS, the same line shape (GN iterations/s)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--no-se", action="store_true", help="skip the config4_se object")
     args = ap.parse_args()
@@ -391,6 +610,19 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # RCCL over xGMI
         else:
             dist.init_process_group(backend)
+
+    if args.workload == "se":
+        line = workload_se(jg, torch, dist, args, rank, local, world, cdev, force_dist)
+        if world > 1 or force_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            import ctypes
+            sys.stdout.flush()
+            ctypes.CDLL(None).fflush(None)
+            os.dup2(real_stdout, 1)
+            print(json.dumps(line), flush=True)
+        return
 
     tables = load_tables(jg, args.case)
 
@@ -496,25 +728,11 @@ def main():
         pipe.setRating(screen_rating)
     packed = [torch.empty((lanes, width), dtype=torch.float64, device="cuda") for _ in range(ring)]
 
-    # JG_BENCH_GATHER=abi: the collective through the library's own C ABI (jg_comm_*: ncclAllGather of librccl, csrc/jg_comm.cpp) instead of
-    # torch.distributed -- what a Julia host calls; rank 0 draws the communicator id, torch only ships its 128 bytes
-    comm = gathered = None
-    if (world > 1 or force_dist) and os.environ.get("JG_BENCH_GATHER") == "abi" and cdev == "cuda":
-        uid = torch.from_numpy(jg._lib.Comm.unique_id() if rank == 0 else np.zeros(jg._lib.COMM_ID_BYTES, dtype=np.uint8)).cuda()
-        dist.broadcast(uid, src=0)
-        comm = jg._lib.Comm(rank, world, uid.cpu().numpy(), device=local)
-        gathered = torch.empty((world * lanes, width), dtype=torch.float64, device="cuda")
+    # the ONE collective of a device batch (make_gather: the library's own C ABI by default for N > 1, torch.distributed as the fallback)
+    gather, gather_label, gather_close = make_gather(jg, torch, dist, rank, world, local, cdev, force_dist, lanes, width)
 
     def deliver(job, h):                              # caller's thread, job order: the record is complete -> the ONE collective
-        if world > 1 or force_dist:
-            buf = packed[job % ring]
-            if comm is not None:
-                comm.allgather_device(buf.data_ptr(), gathered.data_ptr(), buf.numel())
-            elif cdev == "cuda":
-                jg.gatherResults(dist, buf)
-                torch.cuda.current_stream().synchronize()
-            else:
-                jg.gatherResults(dist, buf.cpu())
+        gather(packed[job % ring])
 
     def run(steps):
         jobs = -(-steps // merge)                     # device batches; the last one may hold fewer real steps: its spare lanes are
@@ -523,37 +741,26 @@ def main():
         real = [min(merge, steps - j * merge) * B for j in range(jobs)]
         return int(sum(int(np.sum(it[:r])) for (it, _), r in zip(out, real))), out[-1][1][:B]
 
-    def fence():
-        if world > 1 or force_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def region():
-        """EXACTLY args.steps steps between two fences (barrier + device synchronise); the time is the MAX over ranks."""
-        fence()
-        t0 = time.perf_counter()
-        it, st = run(args.steps)
-        fence()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-        return dt, it, st
-
     run(args.warmup)
     # The timed region is K steps as given.  At the driver's K = 20 that is 0.12 s at N = 1 and ~15 ms at N = 8 (VERDICT r03): one region is
     # mostly the fill and drain of the batches in flight plus whatever the box does in that instant.  So the SAME region -- K steps, fenced on
     # both sides, max over ranks -- is repeated until about a second has been timed (every rank takes the count from the max-reduced first
-    # region: same number of collectives everywhere) and the line reports the MEDIAN region; min / max travel with it.
-    dt0, iters_local, last_status = region()
-    repeats = max(3, min(int(os.environ.get("JG_BENCH_MAX_REPEATS", "50")), int(np.ceil(float(os.environ.get("JG_BENCH_MIN_SECONDS", "1.0")) / max(dt0, 1e-6)))))
-    regions = [dt0]
-    for _ in range(repeats - 1):
-        dtr, it_r, last_status = region()
-        assert it_r == iters_local, "the same scenarios take the same iterations in every region"
-        regions.append(dtr)
+    # region: same number of collectives everywhere) and the line reports the MEDIAN region; min / max travel with it (timed_regions).
+    regions, iters_local, last_status = timed_regions(torch, dist, world, force_dist, cdev, run, args.steps)
     dt = float(np.median(regions))
+    #  when the K-step region cannot reach the pipeline's steady state (N = 8 at K = 20: 4 device batches, all in flight at once) the line
+    # ALSO carries the same measurement over three rounds of the batches in flight -- value_steady; value stays the K of the caller
+    jobs_per_region = -(-args.steps // merge)
+    steady = jobs_per_region >= 3 * len(pipe.handles)
+    steady_extra = None
+    if not steady:
+        ks = 3 * len(pipe.handles) * merge
+        rs, it_s, _ = timed_regions(torch, dist, world, force_dist, cdev, run, ks)
+        steady_extra = [ks, float(np.median(rs)), it_s]
+        if world > 1:
+            c2 = torch.tensor([it_s], dtype=torch.int64, device=cdev)
+            dist.all_reduce(c2, op=dist.ReduceOp.SUM)
+            steady_extra[2] = int(c2.item())
 
     conv_local = int(np.sum(last_status == 0))
     if world > 1:
@@ -629,7 +836,7 @@ def main():
                        "pipeline_note": ("a region holds at least three rounds of the batches in flight" if -(-args.steps // merge) >= 3 * len(pipe.handles) else
                                          f"a region is {-(-args.steps // merge)} device batch(es) with {len(pipe.handles)} in flight: it measures the fill and drain of the pipeline, "
                                          "not its steady state -- more --steps per region (or --merge 1 for narrower batches) changes that, the K of the caller is kept as given"),
-                       "gather": "abi" if comm is not None else "torch.distributed",
+                       "gather": gather_label,
                        "record": ("screen summary, 10 doubles per scenario (jg_nr_screen: worst loading against 1.2 x the base-case flows, largest flow, voltage extremes, "
                                   "iterations, status), reduced on the device by the handle that finished the scenario") if summary else
                                  f"state record, 2 n + 2 = {2 * n + 2} doubles per scenario (V | theta | iterations | status)",
@@ -656,6 +863,17 @@ def main():
             "roofline": roofline,
             "kernels": kern,
         }
+        if steady_extra:
+            ks, dts, its = steady_extra
+            line["value_steady"] = its / dts
+            line["steady_steps"] = ks
+            line["steady_ms_per_step"] = 1e3 * dts / ks
+            line["steady_what"] = (f"the K = {args.steps}-step region is {jobs_per_region} device batch(es) with {len(pipe.handles)} in flight (fill + drain of the pipeline); "
+                                   f"value_steady is the same measurement over {ks} steps (three rounds of the batches in flight).  value, ms_per_step: the K of the caller, unchanged")
+        pred = predicted_from_shards("nr", world, total)
+        if pred:
+            line["predicted"] = pred
+        gather_close()
         pipe.close()
         try:
             hbm = hbm_measured_gbps(torch)
@@ -694,6 +912,7 @@ def main():
             except Exception as e:                      # the NR line is the contract; the SE object must never break it
                 line["config4_se"] = {"error": repr(e)}
     else:
+        gather_close()
         pipe.close()
     if world > 1 or force_dist:
         dist.barrier()

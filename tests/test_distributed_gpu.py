@@ -95,3 +95,33 @@ def test_bench_gathers_screen_summaries_with_two_ranks():
     assert d["n_gpus"] == 2 and d["config"]["record"].startswith("screen summary") and d["value"] > 0 and d["converged_fraction"] == 1.0
     d1 = _bench(["--steps", "4", "--warmup", "1", "--no-cpu", "--no-se", "--record", "summary"], JG_BENCH_FORCE_DIST="1", JG_BENCH_GATHER="abi", JG_BENCH_MAX_REPEATS="3")
     assert d1["config"]["record"].startswith("screen summary") and d1["config"].get("gather") == "abi" and d1["converged_fraction"] == 1.0
+
+
+def test_bench_at_the_drivers_flags_with_eight_ranks():
+    """ The driver's command shape for the 8-GPU run -- `--gpus 8 --steps 20 --warmup 5` -- as a dry run: eight ranks share the one GPU over gloo.
+    512 scenarios shard 8 x 64; deviceBatching(64, 20) = 5 steps per device batch = 320 lanes, 4 device batches per region, all in flight at once: the K-step
+    region cannot reach the pipeline's steady state, so the line ALSO carries value_steady (three rounds of the batches in flight); value keeps the caller's K."""
+    d = _bench(["--gpus", "8", "--steps", "20", "--warmup", "5", "--no-cpu", "--no-se"], JG_BENCH_BACKEND="gloo", JG_BENCH_MAX_REPEATS="3", JG_BENCH_MIN_SECONDS="0.2")
+    assert d["n_gpus"] == 8 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "strong"
+    c = d["config"]
+    assert c["batch_per_gpu"] == 64 and c["steps_per_device_batch"] == 5 and c["lanes_per_device_batch"] == 320 and c["device_batches_per_region"] == 4
+    assert c["pipeline_steady_state"] is False and c["gather"].startswith("torch.distributed")
+    assert d["value"] > 0 and d["converged_fraction"] == 1.0
+    assert d["value_steady"] > 0 and d["steady_steps"] == 3 * c["device_batches_in_flight_per_gpu"] * 5
+    assert abs(d["ms_per_step"] * 20 - d["region_ms_median"]) < 1e-6 * d["region_ms_median"]
+
+
+def test_bench_state_estimation_workload_sharded():
+    """`--workload se`: BASELINE config 4 as a sharded Monte-Carlo run with the NR line's shape -- two ranks over gloo (128 + 128 realisations of the 9241-bus
+    set's little brother would hide nothing: the real grid, a small batch), and one rank through the C ABI's RCCL gather of the [., 2 n + 3] record."""
+    d = _bench(["--workload", "se", "--gpus", "2", "--batch", "256", "--steps", "2", "--warmup", "1", "--no-cpu"], JG_BENCH_BACKEND="gloo", JG_BENCH_MAX_REPEATS="3",
+               JG_BENCH_MIN_SECONDS="0.1")
+    assert d["n_gpus"] == 2 and d["unit"] == "GN iterations/s" and d["scaling"] == "strong" and d["dtype"] == "f64"
+    c = d["config"]
+    assert c["batch_per_gpu"] == 128 and c["scenarios_per_step"] == 256 and c["rows"] > 90000 and "config 4" in c["workload"]
+    assert d["value"] > 0 and d["converged_fraction"] == 1.0 and 4.0 <= d["iterations_per_scenario"] <= 12.0
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and set(d["kernels"]) == {"rows", "gain", "factor", "backward"}
+    assert d["value_steady"] > 0                                       # one device batch per region: fill + drain
+    d1 = _bench(["--workload", "se", "--batch", "256", "--steps", "4", "--warmup", "1", "--no-cpu"], JG_BENCH_FORCE_DIST="1", JG_BENCH_GATHER="abi",
+                JG_BENCH_MAX_REPEATS="3", JG_BENCH_MIN_SECONDS="0.1")
+    assert d1["n_gpus"] == 1 and d1["config"]["gather"] == "abi" and d1["converged_fraction"] == 1.0 and d1["config"]["record"].startswith("magnitude | angle")
