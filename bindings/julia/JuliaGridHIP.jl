@@ -991,6 +991,17 @@ function setOutage!(b::NewtonRaphsonBatch, s::Int, label::Int64)
     return nothing
 end
 
+"""
+    fastPatch!(batch, scenario0, ptr, dbp, dbq)
+
+Fast Newton-Raphson under batched outages (jg_nr_fast_patch_batch): scenarios `scenario0 + 1 : scenario0 + size(ptr, 2)` keep the shared B', B'' of
+`jg_nr_fast_setup` plus the edits `dbp`, `dbq` ([k, count], k <= 4) at the stored Ybus pointers `ptr` ([k, count], 1-based, 0 = unused); the batch is
+factorised once.  What `_updateBranch!(::AcPowerFlow{<:FastNewtonRaphson})` (branch.jl:477) does entry by entry for one scenario at a time.
+"""
+fastPatch!(b::NewtonRaphsonBatch, scenario0::Int, ptr::Matrix{Int64}, dbp::Matrix{Float64}, dbq::Matrix{Float64}) =
+    check(ccall((:jg_nr_fast_patch_batch, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}),
+        b.handle.ptr, scenario0, size(ptr, 2), size(ptr, 1), ptr, dbp, dbq))
+
 "keeps the current voltages of every scenario inside HBM / brings them back (the start point of a Monte-Carlo or benchmark loop without a PCIe round trip)"
 snapshotVoltage!(b::NewtonRaphsonBatch) = check(ccall((:jg_nr_snapshot_voltage, lib), Cint, (Ptr{Cvoid},), b.handle.ptr))
 restoreVoltage!(b::NewtonRaphsonBatch) = check(ccall((:jg_nr_restore_voltage, lib), Cint, (Ptr{Cvoid},), b.handle.ptr))
@@ -1044,6 +1055,6 @@ end
 export HIP, HIPOrthogonal, NewtonRaphsonBatch, setOutages!, shareDevice!, branchQuantities, screenSummary, powerFlowDefer!, moveLanes!, finish!, resume!, jacobian!,
        largestNormalizedResidual, normalizedResiduals, commUniqueId, Comm, shard, contingencyAnalysis, clearPlanCache,
        deviceCount, dims, setRefinement!, deviceMaps, setOutage!, snapshotVoltage!, restoreVoltage!, iterations, voltageDevice!, packResults!, packRows!,
-       allgatherDevice, commRank, commWorld, timeKernel, GaussNewtonBatch, setRealisations!, monteCarloEstimation
+       allgatherDevice, commRank, commWorld, timeKernel, GaussNewtonBatch, setRealisations!, monteCarloEstimation, fastPatch!
 
 end # module

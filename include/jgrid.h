@@ -168,6 +168,14 @@ int jg_nr_get_iteration(jg_nr* h, int32_t* iters);
  *   [active.mismatch | reactive.mismatch], jg_nr_fast_get_increment [active.increment | reactive.increment].
  */
 int jg_nr_fast_setup(jg_nr* h, const double* bp, const double* bq);
+/* Fast Newton-Raphson under BATCHED outages -- _updateBranch!(::AcPowerFlow{<:FastNewtonRaphson}), src/powerSystem/branch.jl:477 with
+ * fastNewtonJacobian! / Pijtheta*, QijV* (acPowerFlow.jl:416-537): the reference edits the entries of B' and B'' a branch touches and refactorises.
+ * Here scenario scenario0 + s keeps the shared matrices of jg_nr_fast_setup plus up to k <= 4 edits: ptr [count][k] 1-based pointers into the stored
+ * Ybus pattern (0 = unused slot), dbp / dbq [count][k] what is ADDED to B' / B'' at that entry (0 where the entry is not in the reduced matrix).
+ * Replaces the edits of those scenarios, keeps the others', then rebuilds and factorises the whole batch ONCE; the iterations are solves only.
+ * The Ybus side of the same outage (the mismatches) is jg_nr_patch_ybus_batch.  A scenario whose edited matrix is singular comes back from
+ * jg_nr_fast_run with status 3; jg_nr_fast_setup drops all edits. */
+int jg_nr_fast_patch_batch(jg_nr* h, int64_t scenario0, int64_t count, int64_t k, const int64_t* ptr, const double* dbp, const double* dbq);
 int jg_nr_fast_mismatch(jg_nr* h, double* max_p, double* max_q);
 int jg_nr_fast_solve(jg_nr* h);
 int jg_nr_fast_run(jg_nr* h, int64_t max_iter, double tol, int32_t* iters, int32_t* status);

@@ -110,6 +110,7 @@ def lib():
         "jg_gn_get_residual": [VP, F64P],
         "jg_gn_get_increment": [VP, F64P],
         "jg_gn_get_iteration": [VP, I32P],
+        "jg_nr_fast_patch_batch": [VP, C.c_int64, C.c_int64, C.c_int64, I64P, F64P, F64P],
         "jg_gn_get_objective": [VP, F64P],
         "jg_gn_pack_results_device": [VP, VP],
         "jg_gn_allgather_results": [VP, VP, VP],

@@ -90,10 +90,17 @@ def deviceBatching(share: int, steps: int, lanes: int = 512) -> int:
     return min(range(max(1, (m_max + 1) // 2), m_max + 1), key=lambda m: (-(-steps // m) * m - steps, -m))
 
 
-def contingencyAnalysis(system: PowerSystem, labels, device: int = 0) -> AcPowerFlow:
-    """Batched analysis with scenario s = outage of branch labels[s] (None / 0 = base case)."""
+def contingencyAnalysis(system: PowerSystem, labels, device: int = 0, method: str = "nr") -> AcPowerFlow:
+    """Batched analysis with scenario s = outage of branch labels[s] (None / 0 = base case).  method: "nr" Newton-Raphson, "bx" / "xb" fast
+    Newton-Raphson (constant matrices with per-scenario edits, ONE factorisation for the batch: jg_nr_fast_patch_batch)."""
     labels = list(labels)
-    an = newtonRaphson(system, batch=len(labels), device=device, max_patch=4)
+    if method in ("bx", "xb"):
+        from .powerflow import fastNewtonRaphsonBX, fastNewtonRaphsonXB
+        an = (fastNewtonRaphsonBX if method == "bx" else fastNewtonRaphsonXB)(system, batch=len(labels), device=device, max_patch=4)
+    elif method == "nr":
+        an = newtonRaphson(system, batch=len(labels), device=device, max_patch=4)
+    else:
+        raise ValueError("method: nr | bx | xb")
     setOutages_(an, [int(lab) if lab else 0 for lab in labels])
     return an
 

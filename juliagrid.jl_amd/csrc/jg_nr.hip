@@ -719,6 +719,8 @@ struct jg_nr {
     int* d_lid = nullptr; int* d_dest = nullptr; int* d_cflags = nullptr; int* d_itmp = nullptr; int* d_glist = nullptr;   // scenario compaction
     bool refine = false;                              // one step of iterative refinement per Newton step (jg_nr_set_refine)
     bool fast = false;                                // fast decoupled mode (jg_nr_fast_setup): constant B', B'' factorised once
+    std::vector<double> fast_blk;                     // ... the shared block matrix diag(B', B'') as set up [nnz][4] (engine block order)
+    std::vector<int> fp_entry; std::vector<double> fp_dp, fp_dq;   // per-scenario edits of B' / B'' (jg_nr_fast_patch_batch): [FAST_MP][batch] factor entry (-1: none), deltas
     double* d_R = nullptr;                            // rhs of the half-iterations
     double* d_inc2[2] = {nullptr, nullptr};           // increments of the theta / V half-iterations
     const int* fast_mask = nullptr;                   // scenarios that take the update (nullptr: all)
@@ -1647,6 +1649,44 @@ int jg_nr_get_iteration(jg_nr* h, int32_t* iters) {
 }
 
 // ---- fast decoupled Newton-Raphson (fastNewtonRaphsonBX / XB, acPowerFlow.jl:215-537, 687-730, 913-983) ---------------
+constexpr int FAST_MP = 4;                            // edits per scenario: a branch touches (i,i), (j,j), (i,j), (j,i) of B' and of B''
+// X[entry] += diag(dp, dq) for the scenario of the lane: the matrices of a batch differ from the shared ones in a handful of entries
+__global__ void k_fast_patch(double* X, const int* entry, const double* dp, const double* dq, int ld, int batch) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+    if (b >= batch) return;
+    const int e = entry[(size_t)m * batch + b];
+    if (e < 0) return;
+    double* x = X + ((size_t)e * 2 * ld + b) * 2;                 // block row 0: (v00, v01); block row 1 sits ld * 2 doubles further
+    x[0] += dp[(size_t)m * batch + b];
+    x[(size_t)ld * 2 + 1] += dq[(size_t)m * batch + b];
+}
+
+// shared matrices + every scenario's edits into the factor storage, then ONE factorisation for the whole batch (fastNewtonRaphson factorises
+// once per matrix, acPowerFlow.jl:923-927; after updateBranch! the reference calls lu! again, :476-537).  A scenario whose B' or B'' is singular
+// (an islanding outage) keeps status bit 2 in eng.status: jg_nr_fast_run reports it as status 3, its neighbours are untouched.
+static int fast_refactor(jg_nr* h) {
+    if (int rc = h->eng.set_shared_matrix(h->stream, h->fast_blk.data())) return fail(rc, h->eng.error);
+    bool any = false;
+    for (int e : h->fp_entry) any = any || e >= 0;
+    if (any) {
+        int* d_e = nullptr; double* d_p = nullptr; double* d_q = nullptr;
+        std::string err;
+        if (jg::upload(&d_e, h->fp_entry, err, h->stream) || jg::upload(&d_p, h->fp_dp, err, h->stream) || jg::upload(&d_q, h->fp_dq, err, h->stream)) {
+            hipFree(d_e); hipFree(d_p); hipFree(d_q);
+            return fail(2, err);
+        }
+        hipLaunchKernelGGL(k_fast_patch, dim3((h->batch + 255) / 256, FAST_MP), dim3(256), 0, h->stream, h->eng.X, d_e, d_p, d_q, h->ld, h->batch);
+        hipError_t e = hipStreamSynchronize(h->stream);
+        hipFree(d_e); hipFree(d_p); hipFree(d_q);
+        NR_HIP(e);
+    }
+    NR_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
+    h->eng.jordan = false;                                       // factor once, then forward() + backsolve() per half iteration: plain rows
+    if (int rc = h->eng.factor(h->stream, nullptr, h->d_R, jg::GroupSel{})) return fail(rc, h->eng.error);   // ONCE (lu(jacobian), utility.jl:470-476)
+    NR_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 static int fast_half(jg_nr* h, int pass) {
     // pass 1: rhs = (f_P / V, 0) is already in d_R (written by the mismatch pass); pass 2: Q mismatches at the new angles first
     if (pass == 2) launch_assemble(h, jg::GroupSel{}, false, nullptr, 2);
@@ -1661,26 +1701,44 @@ int jg_nr_fast_setup(jg_nr* h, const double* bp, const double* bq) {
     if (int rc = set_device(h)) return rc;
     NR_HIP(hipStreamSynchronize(h->stream));
     // block (r, c) of the shared matrix = diag(B'[r,c], B''[r,c]); the caller pads slack / PV rows and columns with identity
-    std::vector<double> blk((size_t)h->nnz * 4, 0.0);
-    for (int p = 0; p < h->nnz; ++p) { blk[(size_t)h->tperm[p] * 4] = bp[p]; blk[(size_t)h->tperm[p] * 4 + 3] = bq[p]; }
-    // (engine block q sits at row = the column that pointer q belongs to, col = rowval[q]; tperm[p of (r, c)] = pointer of (c, r))
-    if (int rc = h->eng.set_shared_matrix(h->stream, blk.data())) return fail(rc, h->eng.error);
-    const size_t vec = (size_t)h->n * 2 * h->ld * 8;
     if (h->refine) return fail(1, "jg_nr_fast_setup: the handle is set up for refined full Newton-Raphson steps");
+    h->fast_blk.assign((size_t)h->nnz * 4, 0.0);
+    for (int p = 0; p < h->nnz; ++p) { h->fast_blk[(size_t)h->tperm[p] * 4] = bp[p]; h->fast_blk[(size_t)h->tperm[p] * 4 + 3] = bq[p]; }
+    // (engine block q sits at row = the column that pointer q belongs to, col = rowval[q]; tperm[p of (r, c)] = pointer of (c, r))
+    h->fp_entry.assign((size_t)FAST_MP * h->batch, -1); h->fp_dp.assign((size_t)FAST_MP * h->batch, 0.0); h->fp_dq.assign((size_t)FAST_MP * h->batch, 0.0);   // new matrices: no edits
+    const size_t vec = (size_t)h->n * 2 * h->ld * 8;
     if (!h->d_R) NR_HIP(hipMalloc((void**)&h->d_R, vec));
     if (!h->d_inc2[0]) NR_HIP(hipMalloc((void**)&h->d_inc2[0], vec));
     if (!h->d_inc2[1]) NR_HIP(hipMalloc((void**)&h->d_inc2[1], vec));
     NR_HIP(jg::sync_fill(h->d_R, 0, vec, h->stream));
-    NR_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
-    h->eng.jordan = false;                                       // factor once, then forward() + backsolve() per half iteration: plain rows
-    if (int rc = h->eng.factor(h->stream, nullptr, h->d_R, jg::GroupSel{})) return fail(rc, h->eng.error);   // ONCE (lu(jacobian), :? utility.jl:470-476)
-    NR_HIP(hipStreamSynchronize(h->stream));
+    if (int rc = fast_refactor(h)) return rc;
     std::vector<int> st(h->ld);
     NR_HIP(jg::sync_copy(st.data(), h->eng.status, (size_t)h->ld * 4, hipMemcpyDeviceToHost, h->stream));
     for (int b = 0; b < h->batch; ++b) if (st[b] & 4) return fail(3, "jg_nr_fast_setup: zero or non-finite pivot (singular B matrix)");
     h->fast = true;
     h->jac_valid = false;
     return 0;
+}
+
+int jg_nr_fast_patch_batch(jg_nr* h, int64_t scenario0, int64_t count, int64_t k, const int64_t* ptr, const double* dbp, const double* dbq) {
+    if (!h || !h->fast) return fail(1, "jg_nr_fast_patch_batch: call jg_nr_fast_setup first");
+    if (scenario0 < 0 || count < 1 || scenario0 + count > h->batch || k < 0 || k > FAST_MP || (k > 0 && (!ptr || !dbp || !dbq)))
+        return fail(1, "jg_nr_fast_patch_batch: bad argument (scenario range / more than 4 entries per scenario)");
+    if (int rc = set_device(h)) return rc;
+    NR_HIP(hipStreamSynchronize(h->stream));
+    const jg::BlockSymbolic& S = h->eng.plan->S;
+    for (int64_t sc = 0; sc < count; ++sc)
+        for (int m = 0; m < FAST_MP; ++m) {
+            const size_t at = (size_t)m * h->batch + scenario0 + sc;
+            h->fp_entry[at] = -1; h->fp_dp[at] = 0.0; h->fp_dq[at] = 0.0;
+            if (m >= k || ptr[sc * k + m] == 0) continue;
+            const int64_t p = ptr[sc * k + m];
+            if (p < 1 || p > h->nnz) return fail(1, "jg_nr_fast_patch_batch: pointer out of range");
+            for (int mm = 0; mm < m; ++mm) if (ptr[sc * k + mm] == p) return fail(1, "jg_nr_fast_patch_batch: duplicate pointer");
+            h->fp_entry[at] = S.src_entry[h->tperm[p - 1]];
+            h->fp_dp[at] = dbp[sc * k + m]; h->fp_dq[at] = dbq[sc * k + m];
+        }
+    return fast_refactor(h);
 }
 
 int jg_nr_fast_mismatch(jg_nr* h, double* max_p, double* max_q) {
@@ -1749,7 +1807,8 @@ int jg_nr_fast_run(jg_nr* h, int64_t max_iter, double tol, int32_t* iters, int32
     const double params[2] = {tol, (double)max_iter};
     NR_HIP(hipMemcpyAsync(h->d_params, params, sizeof(params), hipMemcpyHostToDevice, h->stream));
     NR_HIP(hipMemsetAsync(h->d_iters, 0, (size_t)h->ld * 4, h->stream));
-    NR_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
+    // (eng.status is NOT cleared: nothing is factorised inside this loop -- the pivot flags of the batch's ONE factorisation, jg_nr_fast_setup /
+    // jg_nr_fast_patch_batch, are what the verdict of a scenario with a singular B' or B'' must see)
     {
         std::vector<int> act(h->ld, 0);
         for (int b = 0; b < h->batch; ++b) act[b] = 1;

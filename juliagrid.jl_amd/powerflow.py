@@ -342,13 +342,39 @@ def _fast_model(system: PowerSystem, bx: bool):
     return P, Q, pq, pvpq, bp, bq
 
 
-def _fast_newton_raphson(system: PowerSystem, bx: bool, batch: int, device: int) -> AcPowerFlow:
+def fastOutagePatch(system: PowerSystem, label: int, bx: bool):
+    """What `updateBranch!(analysis::AcPowerFlow{<:FastNewtonRaphson}; label, status = 0)` takes out of the two constant matrices
+    (_updateBranch!, branch.jl:477; Pijtheta*, QijV*, acPowerFlow.jl:476-537 -- the terms fastNewtonJacobian! put in, :416-447) as
+    (1-based pointers into the stored Ybus pattern in outagePatch's order (i,i), (j,j), (i,j), (j,i); deltas of B'; deltas of B''), zero where an
+    entry is not in the reduced matrix (slack row / column of B', PV and slack buses in B'')."""
+    k = int(label) - 1
+    bus, br, ac = system.bus, system.branch, system.model.ac
+    typ, slack, par, Y = bus.layout.type, bus.layout.slack, br.parameter, ac.nodalMatrix
+    i, j = int(br.layout.from_[k]) - 1, int(br.layout.to[k]) - 1
+    bsi, tinv = 0.5 * par.susceptance[k], 1.0 / par.turnsRatio[k]
+    sn, cs = np.sin(par.shiftAngle[k]), np.cos(par.shiftAngle[k])
+    y = ac.admittance[k]
+    if bx:
+        bmk, A, B = -1.0 / par.reactance[k], y.real, y.imag
+    else:
+        bmk, A, B = y.imag, 0.0, -1.0 / par.reactance[k]
+    den = cs * cs + sn * sn
+    ni, nj = i != slack - 1, j != slack - 1
+    qi, qj = typ[i] == 1, typ[j] == 1
+    qA, qB, qC = -bmk * tinv, (bmk + bsi) * tinv ** 2, bmk + bsi
+    ptr = np.array([Y.position(i + 1, i + 1), Y.position(j + 1, j + 1), Y.position(i + 1, j + 1), Y.position(j + 1, i + 1)], dtype=np.int64) + 1
+    dbp = -np.array([B / den if ni else 0.0, B if nj else 0.0, (-A * sn - B * cs) / den if ni and nj else 0.0, (A * sn - B * cs) / den if ni and nj else 0.0])
+    dbq = -np.array([qB if qi else 0.0, qC if qj else 0.0, qA if qi and qj else 0.0, qA if qi and qj else 0.0])
+    return ptr, dbp, dbq
+
+
+def _fast_newton_raphson(system: PowerSystem, bx: bool, batch: int, device: int, max_patch: int = 0) -> AcPowerFlow:
     if system.bus.layout.slack == 0:
         raise RuntimeError("The slack bus is missing.")
     if system.model.ac.nodalMatrix is None:
         acModel_(system)
     vm, va = initializeACPowerFlow(system)
-    an = AcPowerFlow(system, batch, device, 0)
+    an = AcPowerFlow(system, batch, device, max_patch)
     P, Q, pq, pvpq, bp, bq = _fast_model(system, bx)
     _lib.check(_lib.lib().jg_nr_fast_setup(an._h, np.ascontiguousarray(bp), np.ascontiguousarray(bq)))
     an.method.fast, an.method.bx = True, bool(bx)
@@ -360,14 +386,15 @@ def _fast_newton_raphson(system: PowerSystem, bx: bool, batch: int, device: int)
     return an
 
 
-def fastNewtonRaphsonBX(system: PowerSystem, batch: int = 1, device: int = 0) -> AcPowerFlow:
-    """fastNewtonRaphsonBX(system) (acPowerFlow.jl:215-217, 259-336): both constant matrices factorised once on the device."""
-    return _fast_newton_raphson(system, True, batch, device)
+def fastNewtonRaphsonBX(system: PowerSystem, batch: int = 1, device: int = 0, max_patch: int = 0) -> AcPowerFlow:
+    """fastNewtonRaphsonBX(system) (acPowerFlow.jl:215-217, 259-336): both constant matrices factorised once on the device.
+    max_patch = 4: a batch whose scenarios carry branch outages (setOutages_: per-scenario edits of Ybus AND of B', B'')."""
+    return _fast_newton_raphson(system, True, batch, device, max_patch)
 
 
-def fastNewtonRaphsonXB(system: PowerSystem, batch: int = 1, device: int = 0) -> AcPowerFlow:
+def fastNewtonRaphsonXB(system: PowerSystem, batch: int = 1, device: int = 0, max_patch: int = 0) -> AcPowerFlow:
     """fastNewtonRaphsonXB(system) (acPowerFlow.jl:255-257)."""
-    return _fast_newton_raphson(system, False, batch, device)
+    return _fast_newton_raphson(system, False, batch, device, max_patch)
 
 
 def mismatch_(an: AcPowerFlow):
@@ -506,6 +533,8 @@ def _refresh_fast(an: AcPowerFlow):
     P, Q, _, _, bp, bq = _fast_model(an.system, an.method.bx)
     _lib.check(_lib.lib().jg_nr_fast_setup(an._h, np.ascontiguousarray(bp), np.ascontiguousarray(bq)))
     an.method.active.jacobian, an.method.reactive.jacobian = P, Q
+    if np.any(an._outage_labels):                                # new shared matrices drop the scenarios' edits (jg_nr_fast_setup): put them back
+        setOutages_(an, [int(x) for x in an._outage_labels])
 
 
 def updateBus_(an: AcPowerFlow, label: int, **kwargs):
@@ -546,6 +575,8 @@ def outagePatch(system: PowerSystem, label: int):
 def setOutage_(an: AcPowerFlow, scenario: int, label: int | None):
     """Scenario `scenario` of a batched analysis = base grid with branch `label` out of service
     (None restores the base grid)."""
+    if getattr(an.method, "fast", False):                        # Ybus AND the two constant matrices: one path (setOutages_)
+        return setOutages_(an, [int(label) if label else 0], int(scenario))
     if label is None:
         _lib.check(_lib.lib().jg_nr_patch_ybus(an._h, int(scenario), 0, np.zeros(1, dtype=np.int64), np.zeros(2)))
         an._outage_labels[int(scenario)] = 0
@@ -566,6 +597,15 @@ def setOutages_(an: AcPowerFlow, labels, scenario0: int = 0):
             ptr[s], dy[s] = outagePatch(an.system, int(lab))
     _lib.check(_lib.lib().jg_nr_patch_ybus_batch(an._h, int(scenario0), len(labels), 4, ptr.reshape(-1), _reim(dy.reshape(-1))))
     an._outage_labels[scenario0:scenario0 + len(labels)] = [int(lab) if lab else 0 for lab in labels]
+    if getattr(an.method, "fast", False):
+        # fast Newton-Raphson: the outage also leaves the two constant matrices (branch.jl:477); every scenario keeps the shared B', B'' plus its own
+        # (at most) 4 + 4 edits, and the batch is factorised ONCE -- the iterations stay forward / backward sweeps
+        fptr = np.zeros((len(labels), 4), dtype=np.int64)
+        dbp, dbq = np.zeros((len(labels), 4)), np.zeros((len(labels), 4))
+        for s, lab in enumerate(labels):
+            if lab:
+                fptr[s], dbp[s], dbq[s] = fastOutagePatch(an.system, int(lab), an.method.bx)
+        _lib.check(_lib.lib().jg_nr_fast_patch_batch(an._h, int(scenario0), len(labels), 4, fptr.reshape(-1), dbp.reshape(-1), dbq.reshape(-1)))
 
 
 # ---- post-processing (N2): power!(analysis) / current!(analysis) for every scenario of the batch ------------------
