@@ -402,6 +402,51 @@ def timed_regions(torch, dist, world, force_dist, cdev, run, steps):
     return regions, iters_local, last_status
 
 
+def live_pmc_traffic(case, batch, n):
+    """roofline.traffic measured IN THIS RUN when rocprofv3 is on the box (VERDICT r04): two separate `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE;
+    kernel-trace only, as MI355X_MICROARCH.md prescribes) of tools/profile_kernels.py -- one handle of the bench's batch, two solves -- summarised by
+    tools/pmc_summary.py (KiB units, FETCH_SIZE doubled on gfx950, calibrated on a device copy of known size).  None when rocprofv3 is missing, switched
+    off (JG_BENCH_LIVE_PMC=0) or fails: the caller falls back to the committed profiles/pmc_traffic.json and says so."""
+    import shutil
+    import subprocess
+    import tempfile
+    if os.environ.get("JG_BENCH_LIVE_PMC", "1") == "0" or not shutil.which("rocprofv3"):
+        return None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import pmc_summary
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+                env.pop(k, None)
+            for c in ("FETCH_SIZE", "WRITE_SIZE"):
+                r = subprocess.run(["rocprofv3", "--pmc", c, "--kernel-trace", "-d", os.path.join(td, c), "-o", "p", "--output-format", "csv", "--",
+                                    sys.executable, os.path.join(ROOT, "tools", "profile_kernels.py"), str(batch), "2", case],
+                                   cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+                if r.returncode != 0:
+                    return None
+
+            def csv_of(c):
+                for dp, _, fs in os.walk(os.path.join(td, c)):
+                    for f in fs:
+                        if f.endswith("counter_collection.csv"):
+                            return os.path.join(dp, f)
+                return None
+            fc, wc = csv_of("FETCH_SIZE"), csv_of("WRITE_SIZE")
+            if not fc or not wc:
+                return None
+            out = os.path.join(td, "pmc.json")
+            real = sys.stdout
+            sys.stdout = open(os.devnull, "w")
+            try:
+                pmc_summary.main(fc, wc, n, batch, 2, out, case)
+            finally:
+                sys.stdout.close(); sys.stdout = real
+            return json.load(open(out))
+    except Exception:
+        return None
+
+
 def predicted_from_shards(workload, world, total):
     """What ONE rank's share of this N-GPU run does on one GPU (profiles/bench_shards.json, written by tools/run_evidence.sh on the last box that measured it):
     N x that rate is the strong-scaling prediction the line carries beside the measurement (the pool has one GPU per box: the 1 -> 8 curve itself
@@ -796,10 +841,14 @@ def main():
         # HBM bytes per logical launch from the committed PMC passes (profiles/pmc_traffic.json: FETCH_SIZE x2 +
         # WRITE_SIZE, calibrated on a kernel of known byte count); only valid for the grid and batch it was collected at
         traffic = None
+        traffic_source = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        pj_live = live_pmc_traffic(args.case, an.batch, n) if (world == 1 and not args.no_cpu) else None
+        if pj_live is not None or os.path.exists(pmc):
             try:
-                pj = json.load(open(pmc))
+                pj = pj_live if pj_live is not None else json.load(open(pmc))
+                traffic_source = ("two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of tools/profile_kernels.py inside this bench run" if pj_live is not None
+                                  else "profiles/pmc_traffic.json (committed: the same two passes on an earlier box; rocprofv3 not run in this bench run)")
                 if int(pj.get("batch_ld", 0)) == an.batch and pj.get("grid") == args.case:
                     key = {"assembly": "k_assemble", "lu": "k_fact", "solve": "k_fwd+k_bwd"}[dom]
                     traffic = pj["traffic_per_logical_launch"].get(key)
@@ -811,7 +860,7 @@ def main():
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": names[dom], "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": kern[dom]["frac"], "traffic": traffic,
+                    "unit": "GB/s", "frac": kern[dom]["frac"], "traffic": traffic, "traffic_source": traffic_source if traffic is not None else None,
                     "per_launch_ms": kern[dom]["ms"] / kern[dom]["launches"], "launches": kern[dom]["launches"],
                     "algorithmic_bytes": kern[dom]["bytes"]}
         nsc = total * args.steps
