@@ -447,6 +447,48 @@ def live_pmc_traffic(case, batch, n):
         return None
 
 
+def live_pmc_traffic_se(batch):
+    """The same for the state-estimation kernels: two `rocprofv3 --pmc` passes of tools/profile_se.py (config 4, ONE handle, three increments), summarised by
+    tools/pmc_se_summary.py into bytes per Gauss-Newton increment: {"rows", "gain", "factor", "backward"} or None."""
+    import shutil
+    import subprocess
+    import tempfile
+    if os.environ.get("JG_BENCH_LIVE_PMC", "1") == "0" or not shutil.which("rocprofv3"):
+        return None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import pmc_se_summary
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+                env.pop(k, None)
+            found = {}
+            for c in ("FETCH_SIZE", "WRITE_SIZE"):
+                r = subprocess.run(["rocprofv3", "--pmc", c, "--kernel-trace", "-d", os.path.join(td, c), "-o", "p", "--output-format", "csv", "--",
+                                    sys.executable, os.path.join(ROOT, "tools", "profile_se.py"), str(batch), "2"],
+                                   cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+                if r.returncode != 0:
+                    return None
+                for dp, _, fs in os.walk(os.path.join(td, c)):
+                    for f in fs:
+                        if f.endswith("counter_collection.csv"):
+                            found[c] = os.path.join(dp, f)
+            if len(found) != 2:
+                return None
+            out = os.path.join(td, "pmc.json")
+            real = sys.stdout
+            sys.stdout = open(os.devnull, "w")
+            try:
+                pmc_se_summary.main(found["FETCH_SIZE"], found["WRITE_SIZE"], 2, out)
+            finally:
+                sys.stdout.close(); sys.stdout = real
+            t = json.load(open(out))["traffic"]
+            tot = lambda k: float(t[k]["fetch_bytes"] + t[k]["write_bytes"]) if k in t else None
+            return {"rows": tot("k_gn_rows"), "gain": tot("k_gn_gain"), "factor": tot("factor"), "backward": tot("k_bwd_level")}
+    except Exception:
+        return None
+
+
 def predicted_from_shards(workload, world, total):
     """What ONE rank's share of this N-GPU run does on one GPU (profiles/bench_shards.json, written by tools/run_evidence.sh on the last box that measured it):
     N x that rate is the strong-scaling prediction the line carries beside the measurement (the pool has one GPU per box: the 1 -> 8 curve itself
@@ -536,17 +578,23 @@ def workload_se(jg, torch, dist, args, rank, local, world, cdev, force_dist):
             ms = float(np.median([an.time_kernel(k, 6 if name == "factor" else 12) for _ in range(5)]))
             kern[name] = {"ms": ms, "bytes": algo[name], "GBps": algo[name] / ms / 1e6, "frac": algo[name] / ms / 1e6 / HBM_PEAK_GBS}
         dom = max(kern, key=lambda k: kern[k]["ms"])
-        traffic = None
+        traffic = traffic_source = None
+        live = live_pmc_traffic_se(L) if (world == 1 and not args.no_cpu and case == "case9241synth") else None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic_se.json")
-        if os.path.exists(pmc):
-            try:
+        try:
+            per = None
+            if live is not None:
+                per, traffic_source = live, "two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of tools/profile_se.py inside this bench run"
+            elif os.path.exists(pmc):
                 pj = json.load(open(pmc))
                 if int(pj.get("batch_ld", 0)) == L and pj.get("grid") == case:
-                    for kk in kern:
-                        kern[kk]["hbm_traffic_bytes_pmc"] = pj["traffic_per_increment"].get(kk)
-                    traffic = pj["traffic_per_increment"].get(dom)
-            except Exception:
-                traffic = None
+                    per, traffic_source = pj["traffic_per_increment"], "profiles/pmc_traffic_se.json (committed: the same two passes on an earlier box)"
+            if per:
+                for kk in kern:
+                    kern[kk]["hbm_traffic_bytes_pmc"] = per.get(kk)
+                traffic = per.get(dom)
+        except Exception:
+            traffic = None
         nsc = total * args.steps
         line = {
             "metric": "GN iterations/sec (sharded Monte-Carlo WLS state estimation, PMU + legacy, 9241-bus PEGASE-shaped grid)",
@@ -565,7 +613,7 @@ def workload_se(jg, torch, dist, args, rank, local, world, cdev, force_dist):
             "converged_fraction": counts[1] / total, "pipeline_construction_ms": 1e3 * t_pipe,
             "roofline": {"bound": "hbm", "kernel": {"rows": "k_gn_rows", "gain": "k_gn_gain", "factor": "k_fact_task + k_fact_top (symmetric plan)", "backward": "k_bwd_level"}[dom],
                          "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["frac"], "traffic": traffic,
-                         "algorithmic_bytes": kern[dom]["bytes"]},
+                         "traffic_source": traffic_source if traffic is not None else None, "algorithmic_bytes": kern[dom]["bytes"]},
             "kernels": kern,
         }
         if steady_extra:

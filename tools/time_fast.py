@@ -33,3 +33,20 @@ for _ in range(4):
     ts.append(time.perf_counter() - t0)
 it = np.atleast_1d(nr.method.iteration)
 print(case, "batch", batch, "Newton-Raphson: ms/solve %.2f, iterations max %d" % (1e3 * np.median(ts), it.max()))
+# round 5: fast Newton-Raphson under BATCHED outages (per-scenario B', B'': one factorisation per batch, then sweeps only)
+labels = [int(x) for x in jg.outageList(s, batch, seed=512)]
+t0 = time.perf_counter()
+fo = jg.contingencyAnalysis(s, labels, method="xb")
+t_make = time.perf_counter() - t0
+t0 = time.perf_counter()
+jg.setOutages_(fo, labels)                                   # Ybus patches + 4 + 4 edits of B', B'' per scenario + ONE factorisation of the batch
+t_patch = time.perf_counter() - t0
+ts = []
+for _ in range(4):
+    jg.setInitialPoint_(fo)
+    t0 = time.perf_counter()
+    jg.powerFlow_(fo, iteration=100, fetch=False)
+    ts.append(time.perf_counter() - t0)
+it = np.atleast_1d(fo.method.iteration)
+print(case, "batch", batch, "fast XB under %d outages: analysis %.1f ms, patch + refactor %.2f ms, ms/solve %.2f, iterations max %d mean %.1f, ms per iteration %.3f, converged %d/%d"
+      % (batch, 1e3 * t_make, 1e3 * t_patch, 1e3 * np.median(ts), it.max(), it.mean(), 1e3 * np.median(ts) / max(it.max(), 1), int(np.sum(np.atleast_1d(fo.status) == 0)), batch))
