@@ -151,3 +151,22 @@ def test_two_rank_gloo_gather_of_estimation_records(tmp_path):
             break
     assert out.returncode == 0, out.stdout + out.stderr
     assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+
+
+def test_predicted_value_of_an_n_gpu_run_comes_from_the_shard_emulation():
+    """bench.py: the N > 1 line carries `predicted` = N x what ONE GPU reaches on a rank's share (profiles/bench_shards.json, the one-rank emulation of the
+    strong-scaling shares merged to 512-lane device batches) -- the pool has one GPU per box, the 1 -> 8 curve itself is the driver's to measure."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("_bench", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    shards = json.load(open(os.path.join(ROOT, "profiles", "bench_shards.json")))
+    assert b.predicted_from_shards("nr", 1, 512) is None                       # N = 1 is measured, not predicted
+    for wl in ("nr", "se"):
+        for world in (2, 4, 8):
+            row = [r for r in shards[wl] if r["scenarios_per_step"] * world == 512][-1]
+            p = b.predicted_from_shards(wl, world, 512)
+            assert p["per_gpu_value"] == row["value"] and abs(p["value"] - world * row["value"]) < 1e-9 * p["value"]
+            assert 0.8 * shards[wl][0]["value"] < row["value"] < 1.2 * shards[wl][0]["value"], "a rank's merged share runs at about the N = 1 rate"
+    assert b.predicted_from_shards("nr", 3, 512) is None                       # no measured share for that N
