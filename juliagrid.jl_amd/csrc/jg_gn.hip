@@ -26,6 +26,8 @@
 #include <map>
 #include <set>
 #include <string>
+#include <thread>
+#include <chrono>
 #include <vector>
 
 #include "../../include/jgrid.h"
@@ -1336,13 +1338,30 @@ int jg_gn_run(jg_gn* h, int64_t max_iter, double tol, int32_t* iters, int32_t* s
     GN_HIP(hipMemsetAsync(h->d_iters, 0, (size_t)h->ld * 4, h->stream));          // acStateEstimation.jl:1298
     GN_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
     GN_HIP(hipMemsetAsync(h->d_group, 0xff, (size_t)(h->ld / 64) * sizeof(int), h->stream));
+    // (round 5, as jg_nr_run: the host arms the pinned word and polls it instead of paying a stream synchronise per iteration; JG_POLL=0 switches it off)
+    static const bool poll = !(getenv("JG_POLL") && atoi(getenv("JG_POLL")) == 0);
     for (int64_t it = 0; it <= max_iter; ++it) {                                   // :1303
-        {
-            GN_HIP(hipGraphLaunch(h->exec, h->stream));
-        }
-        GN_HIP(hipStreamSynchronize(h->stream));
+        if (poll) *(volatile int*)h->h_counter = -1;
+        GN_HIP(hipGraphLaunch(h->exec, h->stream));
+        if (poll) {
+            volatile int* w = (volatile int*)h->h_counter;
+            const auto t0 = std::chrono::steady_clock::now();
+            bool fell_back = false;
+            for (long spins = 0; *w == -1; ++spins) {
+                if ((spins & 63) == 63) {
+                    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+                    if (us > 2.0e6) { fell_back = true; break; }
+                    if (us > 200.0) std::this_thread::yield();
+                }
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            }
+            if (fell_back) GN_HIP(hipStreamSynchronize(h->stream));
+        } else GN_HIP(hipStreamSynchronize(h->stream));
         if (*h->h_counter == 0) break;
     }
+    GN_HIP(hipStreamSynchronize(h->stream));
     h->ran = true;
     if (iters) GN_HIP(jg::sync_copy(iters, h->d_iters, (size_t)h->batch * 4, hipMemcpyDeviceToHost, h->stream));
     if (status) GN_HIP(jg::sync_copy(status, h->d_status, (size_t)h->batch * 4, hipMemcpyDeviceToHost, h->stream));

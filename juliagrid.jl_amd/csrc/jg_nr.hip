@@ -1435,6 +1435,29 @@ int run_setup(jg_nr* h, int64_t max_iter, double tol, int lanes, bool keep_iters
     return 0;
 }
 
+// The host learns the verdict of an iteration from ONE pinned word the verdict kernel stores into (k_compact: host_count).  Waiting for it with
+// hipStreamSynchronize costs a wake-up of ~20 us per iteration -- a tenth of a single instance's iteration; round 5: the host ARMS the word (-1) before
+// the launch and polls it (bounded spin, then yields; hipStreamSynchronize after 2 s as the safety net).  The next graph is then launched while the tail of
+// the previous one (the predicated re-assembly of a compaction) still runs -- stream order keeps them apart.  JG_POLL=0: the synchronise of round 4.
+static bool poll_enabled() { static const bool on = !(getenv("JG_POLL") && atoi(getenv("JG_POLL")) == 0); return on; }
+static void arm_verdict(jg_nr* h) { if (poll_enabled()) *(volatile int*)h->h_counter = -1; }
+static hipError_t wait_verdict(jg_nr* h) {
+    if (!poll_enabled()) return hipStreamSynchronize(h->stream);
+    volatile int* w = (volatile int*)h->h_counter;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long spins = 0; *w == -1; ++spins) {
+        if ((spins & 63) == 63) {
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            if (us > 2.0e6) return hipStreamSynchronize(h->stream);          // something is wrong (or very slow): the blocking wait reports it
+            if (us > 200.0) std::this_thread::yield();                        // a long batched iteration: give the core away between looks
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    return hipSuccess;
+}
+
 // The iteration loop: one graph per iteration until no scenario is active (the iteration limit itself is kept on the device,
 // k_check) -- or, defer_at > 0, until at most defer_at (<= 64) scenarios are: they then sit in the first lane group.
 int run_loop(jg_nr* h, int64_t max_iter, int defer_at) {
@@ -1445,9 +1468,10 @@ int run_loop(jg_nr* h, int64_t max_iter, int defer_at) {
         const double tc = now_us();
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (trace) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, h->stream); }
+        if (!trace) arm_verdict(h);
         NR_HIP(hipGraphLaunch(h->execB, h->stream));                           // solve!, then mismatch! and the verdict on the new state
         if (trace) hipEventRecord(e1, h->stream);
-        NR_HIP(hipStreamSynchronize(h->stream));
+        NR_HIP(trace ? hipStreamSynchronize(h->stream) : wait_verdict(h));
         if (trace) {
             float ms = 0.f; hipEventElapsedTime(&ms, e0, e1); fprintf(stderr, "[jg_nr_run] graph on the device: %.1f us\n", 1e3 * ms); hipEventDestroy(e0); hipEventDestroy(e1);
             int cf[4];
@@ -1481,8 +1505,9 @@ int jg_nr_run(jg_nr* h, int64_t max_iter, double tol, int32_t* iters, int32_t* s
     if (h->fast) return fail(1, "jg_nr_run: this handle runs fast Newton-Raphson; use jg_nr_fast_run");
     if (int rc = set_device(h)) return rc;
     if (int rc = run_setup(h, max_iter, tol, h->batch, false)) return rc;
+    arm_verdict(h);
     NR_HIP(hipGraphLaunch(h->execA, h->stream));                               // acPowerFlow.jl:1406: mismatch!, verdict
-    NR_HIP(hipStreamSynchronize(h->stream));
+    NR_HIP(wait_verdict(h));
     if (int rc = run_loop(h, max_iter, 0)) return rc;
     return run_finish(h, iters, status);
 }
@@ -1492,8 +1517,9 @@ int jg_nr_run_defer(jg_nr* h, int64_t max_iter, double tol, int64_t defer_at, in
     if (h->fast) return fail(1, "jg_nr_run_defer: this handle runs fast Newton-Raphson");
     if (int rc = set_device(h)) return rc;
     if (int rc = run_setup(h, max_iter, tol, h->batch, false)) return rc;
+    arm_verdict(h);
     NR_HIP(hipGraphLaunch(h->execA, h->stream));
-    NR_HIP(hipStreamSynchronize(h->stream));
+    NR_HIP(wait_verdict(h));
     if (int rc = run_loop(h, max_iter, h->ld > 64 ? (int)defer_at : 0)) return rc;   // one lane group: lanes are never packed, nothing to hand off
     *n_left = *h->h_counter;
     h->paused = true;
