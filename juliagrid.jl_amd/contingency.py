@@ -189,7 +189,9 @@ class ContingencyPipeline:
 
     def run(self, jobs, iteration: int = 20, tolerance: float = 1e-8, on_done=None, fetch: bool = False, record=None, records: int = 0,
             summary: bool = False):
-        """jobs: sequence of label lists (one batch each; None = keep the handle's current outages).
+        """jobs: sequence of label lists (one batch each; None = keep the handle's current outages), or dicts {"labels": [...], "active": P, "reactive": Q}
+        for Monte-Carlo jobs: net injections supply - demand per scenario ([batch, n], or [n] for all) -- the independent instances the north star names beside
+        contingencies; a pool receives a straggler's injections with its state (jg_nr_move_lanes).
         record: optional callable job -> DEVICE pointer of a [batch, 2 n + 2] float64 buffer; the job's result record
         (V | theta | iterations | status per scenario) is complete in it when on_done(job, .) is called.  The caller owns a
         ring of `records` such buffers (record(j) and record(j + records) may be the same memory): job j + records is not
@@ -267,8 +269,16 @@ class ContingencyPipeline:
                     if errors:
                         return
                     an = self.handles[k]
-                    if jobs[j] is not None:
-                        labels = [int(x) if x else 0 for x in jobs[j]]
+                    job = jobs[j]
+                    if isinstance(job, dict):                     # a Monte-Carlo job: per-scenario injections (load / generation variations), outages optional
+                        if job.get("labels") is not None:
+                            labels = [int(x) if x else 0 for x in job["labels"]]
+                            setOutages_(an, labels + [0] * (self.batch - len(labels)))
+                        if job.get("active") is not None or job.get("reactive") is not None:
+                            from .powerflow import setInjection_
+                            setInjection_(an, job.get("active"), job.get("reactive"))
+                    elif job is not None:
+                        labels = [int(x) if x else 0 for x in job]
                         setOutages_(an, labels + [0] * (self.batch - len(labels)))
                     an.restore_voltage()
                     if use_pool:

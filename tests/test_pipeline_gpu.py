@@ -162,3 +162,49 @@ def test_bench_default_pipeline_ends_at_the_oracle(jg, oracle):
                 assert np.abs(r[sc, :n] - vm).max() <= 1e-8 and np.abs(r[sc, n:2 * n] - va).max() <= 1e-8
                 checked_pool += int(it[sc] > lock)
     assert checked_pool >= 4
+
+
+def test_monte_carlo_injection_jobs_through_the_pipeline(jg, oracle):
+    """Jobs that carry per-scenario injections (load variations: the Monte-Carlo instances of the north star) instead of outage labels: three jobs on two handles
+    with a straggler pool and a ring of device records; every job's record is bitwise the record of a plain batch with the same injections, samples agree with the oracle."""
+    import torch
+    t = load_case("case1354pegase")
+    s = jg.powerSystem(t)
+    n, B = s.bus.number, 192
+    base = jg.newtonRaphson(s)
+    jg.powerFlow_(base)
+    start = (base.voltage.magnitude.copy(), base.voltage.angle.copy())
+    base.close()
+    rng = np.random.default_rng(17)
+    jobs = []
+    for _ in range(3):
+        scale = 1.0 + 0.05 * rng.standard_normal((B, 1))
+        jobs.append({"active": s.bus.supply.active[None, :] - s.bus.demand.active[None, :] * scale,
+                     "reactive": s.bus.supply.reactive[None, :] - s.bus.demand.reactive[None, :] * scale})
+    pipe = jg.ContingencyPipeline(s, B, inflight=2, start=start, pool=128)
+    ring = [torch.zeros((B, 2 * n + 2), dtype=torch.float64, device="cuda") for _ in range(3)]
+    seen = []
+
+    def on_done(j, an):
+        seen.append(ring[j % 3].clone())
+        torch.cuda.synchronize()
+
+    res = pipe.run(jobs, on_done=on_done, record=lambda j: ring[j % 3].data_ptr(), records=3)
+    pipe.close()
+    ref = jg.newtonRaphson(s, batch=B, max_patch=4)
+    for j, job in enumerate(jobs):
+        jg.setInjection_(ref, job["active"], job["reactive"])
+        jg.powerflow._push_voltage(ref, *start)
+        jg.powerFlow_(ref)
+        rec = torch.zeros((B, 2 * n + 2), dtype=torch.float64, device="cuda")
+        ref.pack_results_device(rec.data_ptr())
+        assert torch.equal(rec, seen[j]), j
+        assert np.array_equal(res[j][0], ref.method.iteration) and np.all(res[j][1] == 0)
+    osys = oracle.OracleSystem(t)
+    o = oracle.OracleNR(osys)
+    o.set_power(osys.ps, osys.qs, s.bus.supply.active - jobs[2]["active"][5], s.bus.supply.reactive - jobs[2]["reactive"][5])
+    o.set_voltage(start[0], start[1])
+    assert o.power_flow() == 0 and o.iteration == ref.method.iteration[5]
+    vm, va = o.voltage()
+    assert np.abs(ref.voltage.magnitude[5] - vm).max() < 1e-8 and np.abs(ref.voltage.angle[5] - va).max() < 1e-8
+    ref.close()
