@@ -536,8 +536,12 @@ def workload_se(jg, torch, dist, args, rank, local, world, cdev, force_dist):
     t0 = time.perf_counter()
     pipe = jg.MonteCarloPipeline(mon, lanes, inflight=inflight, device=local)
     t_pipe = time.perf_counter() - t0
-    for k, h in enumerate(pipe.handles):              # the realisations stay resident (a step re-estimates them from the flat start): seeds differ by handle and rank
-        jg.setNoise_(h, np.random.Generator(np.random.PCG64(4 + k + 1000 * rank)), scale=1.0)
+    # every device batch estimates FRESH realisations, drawn on the device inside the timed region (jg_gn_draw_noise: seed 4, realisation ids unique over jobs and ranks:
+    # what a Monte-Carlo study does; 0.8 GB of se.mean / se.precision rewritten per 512 realisations, ~1 % of a step); JG_BENCH_SE_RESIDENT=1: the realisations of
+    # round 4's config4_se leg stay resident instead (drawn once, on the device)
+    resident = bool(os.environ.get("JG_BENCH_SE_RESIDENT"))
+    for k, h in enumerate(pipe.handles):
+        jg.drawNoise_(h, 4, scale=1.0, first=(k * world + rank) * lanes)
     an = pipe.handles[0]
     width = pipe.record_width
     ring = len(pipe.handles)
@@ -546,7 +550,8 @@ def workload_se(jg, torch, dist, args, rank, local, world, cdev, force_dist):
 
     def run(steps):
         jobs = -(-steps // merge)
-        out = pipe.run([None] * jobs, iteration=40, tolerance=1e-8, on_done=lambda j, h: gather(packed[j % ring]),
+        work = [None] * jobs if resident else [(4, (j * world + rank) * lanes) for j in range(jobs)]
+        out = pipe.run(work, iteration=40, tolerance=1e-8, on_done=lambda j, h: gather(packed[j % ring]),
                        record=lambda j: packed[j % ring].data_ptr(), records=ring)
         real = [min(merge, steps - j * merge) * B for j in range(jobs)]
         return int(sum(int(np.sum(it[:r])) for (it, _), r in zip(out, real))), out[-1][1][:B]
@@ -608,6 +613,7 @@ def workload_se(jg, torch, dist, args, rank, local, world, cdev, force_dist):
                        "batch_per_gpu": B, "scenarios_per_step": total, "steps_per_device_batch": merge, "lanes_per_device_batch": lanes,
                        "device_batches_in_flight_per_gpu": len(pipe.handles), "device_batches_per_region": jobs_per_region, "pipeline_steady_state": bool(steady),
                        "gather": gather_label, "record": f"magnitude | angle | iterations | status | objective, 2 n + 3 = {width} doubles per realisation",
+                       "realisations": "resident (drawn once on the device)" if resident else "fresh per device batch, drawn on the device inside the timed region (jg_gn_draw_noise)",
                        "parallelism": f"realisation-sharded x{world}, one all-gather of the packed record per device batch"},
             "scenarios_per_s": nsc / dt, "ms_per_solve_batched": 1e3 * dt / nsc, "iterations_per_scenario": counts[0] / nsc,
             "converged_fraction": counts[1] / total, "pipeline_construction_ms": 1e3 * t_pipe,

@@ -902,6 +902,26 @@ function setRealisations!(b::GaussNewtonBatch, mean::Matrix{Float64}, wdiag::Mat
         b.handle.ptr, mean, wdiag, woff, b.rows, size(woff, 1)))
 end
 
+"""
+    setReadings!(b, row, kind, z1, v1, s1, z2, v2, s2);  drawNoise!(b, seed; scale = 1.0, first = 0)
+
+Realisations drawn ON the device (jg_gn_set_readings / jg_gn_draw_noise): the raw readings per device once (first row 1-based, kind of acWLS value rule 0..5 --
+include/jgrid.h --, mean / variance / status of the magnitude-type and of the angle-type quantity), then lane b of the batch becomes realisation `first + b` of `seed`:
+what `add<Meter>!(...; noise = true)` draws (measurement/utility.jl:70-73) and acWLS makes of it (acStateEstimation.jl:135-236), without a byte over PCIe.
+"""
+setReadings!(b::GaussNewtonBatch, row::Vector{Int64}, kind::Vector{Int8}, z1::Vector{Float64}, v1::Vector{Float64}, s1::Vector{Int8},
+             z2::Vector{Float64}, v2::Vector{Float64}, s2::Vector{Int8}) =
+    check(ccall((:jg_gn_set_readings, lib), Cint, (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int8}, Ptr{Float64}, Ptr{Float64}, Ptr{Int8}, Ptr{Float64}, Ptr{Float64}, Ptr{Int8}),
+        b.handle.ptr, length(row), row, kind, z1, v1, s1, z2, v2, s2))
+drawNoise!(b::GaussNewtonBatch, seed::UInt64; scale::Float64 = 1.0, first::Int64 = 0) =
+    check(ccall((:jg_gn_draw_noise, lib), Cint, (Ptr{Cvoid}, UInt64, Float64, Int64), b.handle.ptr, seed, scale, first))
+"se.mean and diag(se.precision) of every realisation as the device holds them: [rows, batch] each (+ the pair terms [pairs, batch])"
+function measurementDevice(b::GaussNewtonBatch, pairs::Int = 0)
+    mean = Matrix{Float64}(undef, b.rows, b.batch); wdiag = similar(mean); woff = Matrix{Float64}(undef, max(pairs, 1), b.batch)
+    check(ccall((:jg_gn_get_measurement, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), b.handle.ptr, mean, wdiag, woff))
+    return mean, wdiag, woff
+end
+
 "stateEstimation!(analysis; iteration, tolerance) for every realisation of the batch (acStateEstimation.jl:1286-1329), then voltages and objectives"
 function stateEstimation!(b::GaussNewtonBatch; iteration::Int64 = 40, tolerance::Float64 = 1e-8, fetch::Bool = true)
     check(ccall((:jg_gn_run, lib), Cint, (Ptr{Cvoid}, Int64, Float64, Ptr{Int32}, Ptr{Int32}), b.handle.ptr, iteration, tolerance, b.iteration, b.status))
@@ -1055,6 +1075,6 @@ end
 export HIP, HIPOrthogonal, NewtonRaphsonBatch, setOutages!, shareDevice!, branchQuantities, screenSummary, powerFlowDefer!, moveLanes!, finish!, resume!, jacobian!,
        largestNormalizedResidual, normalizedResiduals, commUniqueId, Comm, shard, contingencyAnalysis, clearPlanCache,
        deviceCount, dims, setRefinement!, deviceMaps, setOutage!, snapshotVoltage!, restoreVoltage!, iterations, voltageDevice!, packResults!, packRows!,
-       allgatherDevice, commRank, commWorld, timeKernel, GaussNewtonBatch, setRealisations!, monteCarloEstimation, fastPatch!
+       allgatherDevice, commRank, commWorld, timeKernel, GaussNewtonBatch, setRealisations!, monteCarloEstimation, fastPatch!, setReadings!, drawNoise!, measurementDevice
 
 end # module

@@ -273,6 +273,20 @@ int jg_gn_set_method(jg_gn* h, int method);
  * [batch][n_corr] (acStateEstimation.jl:135-236; equations.jl:576-677).  stride 0 broadcasts. */
 int jg_gn_set_measurement(jg_gn* h, const double* mean, const double* wdiag, const double* woff,
                           int64_t batch_stride_m, int64_t batch_stride_corr);
+/* Monte-Carlo realisations drawn ON the device.  The reference draws one inside add<Meter>!(...; noise = true) -- mean + variance^(1/2) * randn,
+ * src/measurement/utility.jl:70-73 -- and acWLS applies its value rules to the noisy readings (acStateEstimation.jl:135-236; squared currents,
+ * rectangular PMUs: equations.jl:576-666).  jg_gn_set_readings (once): the RAW readings per device in acWLS's row order -- row [ndev] 1-based first row,
+ * kind [ndev]: 0 one row, value z; 1 one row, squared current (mean z^2, variance 4 z^2 sigma^2); 2 polar PMU (rows magnitude, angle); 3 polar PMU with
+ * squared current magnitude; 4 / 5 rectangular PMU without / with its 2x2 precision block (5 exactly on the corr_row rows of jg_gn_create);
+ * z1, v1, s1 magnitude (or the single quantity): mean, variance, status; z2, v2, s2 the PMU angle (ignored for kinds 0, 1).
+ * jg_gn_draw_noise: lane b becomes realisation first_realisation + b of `seed`: z + scale * sigma * N(0,1) per raw reading from a counter-based generator
+ * (splitmix64 finaliser + Box-Muller, csrc/jg_gn.hip: k_gn_noise -- the same realisation gets the same numbers on any rank, batch and lane), then the value
+ * rules: se.mean and se.precision of every scenario are rewritten in place, nothing crosses PCIe.  scale 0 restores the noise-free set.  Returns 1 when a
+ * variance comes out zero or not finite (the reference's errorVariance).  jg_gn_get_measurement: se.mean / diag(se.precision) [batch][m], pair terms [batch][n_corr]. */
+int jg_gn_set_readings(jg_gn* h, int64_t ndev, const int64_t* row, const int8_t* kind, const double* z1, const double* v1, const int8_t* s1,
+                       const double* z2, const double* v2, const int8_t* s2);
+int jg_gn_draw_noise(jg_gn* h, uint64_t seed, double scale, int64_t first_realisation);
+int jg_gn_get_measurement(jg_gn* h, double* mean, double* wdiag, double* woff);
 int jg_gn_set_voltage(jg_gn* h, const double* vm, const double* va, int64_t batch_stride);
 int jg_gn_get_voltage(jg_gn* h, double* vm, double* va);
 /* Keep / restore the current state inside HBM (restart of a Monte-Carlo batch from the same start point without a

@@ -14,7 +14,7 @@ from .measurement import (Measurement, measurement, ems, addVoltmeter_, addAmmet
                           addPmu_, exactQuantities)
 from .stateestimation import (WlsMethod, Normal, LU, KLU, QR, LDLt, LL, Orthogonal, PetersWilkinson,   # noqa: F401
                               AcStateEstimation, PmuStateEstimation, pmuStateEstimation, gaussNewton, increment_ as incrementSE_, solve_ as solveSE_,   # noqa: F401
-                              stateEstimation_, setNoise_, residualTest_, normalizedResidual, chiTest,
+                              stateEstimation_, setNoise_, drawNoise_, measurementDevice, residualTest_, normalizedResidual, chiTest,
                               updateVoltmeter_, updateAmmeter_, updateWattmeter_, updateVarmeter_, updatePmu_)
 from .montecarlo import MonteCarloPipeline, gatherEstimates, gatherEstimatesDevice, unpackEstimates   # noqa: F401
 from .synthetic import pegaseShaped, case9241synth                          # noqa: F401
@@ -25,7 +25,7 @@ __all__ = [
     "PowerSystem", "CscMatrix", "powerSystem", "acModel_", "updateBranchSystem_", "updateBusSystem_", "updateGeneratorSystem_", "updateBus_", "updateGenerator_", "AcPowerFlow", "newtonRaphson", "fastNewtonRaphsonBX", "fastNewtonRaphsonXB",
     "mismatch_", "solve_", "powerFlow_", "setInitialPoint_", "setRefinement_", "updateBranch_", "setOutage_", "setInjection_",
     "Measurement", "measurement", "ems", "addVoltmeter_", "addAmmeter_", "addWattmeter_", "addVarmeter_", "addPmu_",
-    "exactQuantities", "AcStateEstimation", "PmuStateEstimation", "pmuStateEstimation", "gaussNewton", "incrementSE_", "solveSE_", "stateEstimation_", "setNoise_", "residualTest_", "normalizedResidual", "chiTest",
+    "exactQuantities", "AcStateEstimation", "PmuStateEstimation", "pmuStateEstimation", "gaussNewton", "incrementSE_", "solveSE_", "stateEstimation_", "setNoise_", "drawNoise_", "measurementDevice", "residualTest_", "normalizedResidual", "chiTest",
     "updateVoltmeter_", "updateAmmeter_", "updateWattmeter_", "updateVarmeter_", "updatePmu_",
     "outagePatch", "fastOutagePatch", "initializeACPowerFlow", "bridges", "outageList", "shard", "deviceBatching", "contingencyAnalysis", "gatherResults", "gatherResultsDevice", "unpackResults",
     "WlsMethod", "Normal", "LU", "KLU", "QR", "LDLt", "LL", "Orthogonal", "PetersWilkinson",

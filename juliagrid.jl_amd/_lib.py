@@ -111,6 +111,9 @@ def lib():
         "jg_gn_get_increment": [VP, F64P],
         "jg_gn_get_iteration": [VP, I32P],
         "jg_nr_fast_patch_batch": [VP, C.c_int64, C.c_int64, C.c_int64, I64P, F64P, F64P],
+        "jg_gn_set_readings": [VP, C.c_int64, I64P, I8P, F64P, F64P, I8P, F64P, F64P, I8P],
+        "jg_gn_draw_noise": [VP, C.c_uint64, C.c_double, C.c_int64],
+        "jg_gn_get_measurement": [VP, F64P, F64P, F64P],
         "jg_gn_get_objective": [VP, F64P],
         "jg_gn_pack_results_device": [VP, VP],
         "jg_gn_allgather_results": [VP, VP, VP],

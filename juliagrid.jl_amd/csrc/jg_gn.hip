@@ -536,6 +536,59 @@ __global__ __launch_bounds__(256) void k_gn_add(double* inc, const double* cor, 
     }
 }
 
+// ---- Monte-Carlo realisations drawn ON the device (jgrid.h: jg_gn_set_readings, jg_gn_draw_noise) -----------------------------------------------
+// The reference draws a realisation inside add<Meter>!(...; noise = true): mean + variance^(1/2) * randn (src/measurement/utility.jl:70-73), and acWLS
+// turns the raw readings into se.mean / se.precision row by row (acStateEstimation.jl:135-236: squared currents mean z^2, variance 4 z^2 sigma^2; rectangular
+// PMUs through variancePmu / covariancePmu + precision!, equations.jl:576-666).  Drawn on the host, 512 realisations of config 4 are 50 M normals and
+// 0.8 GB over PCIe per job; here a wave owns one DEVICE (meter or PMU), its lanes the realisations: two normals per (device, realisation) from a
+// counter-based generator (no state: realisation r of seed s is the same numbers on any rank, in any batch, at any lane), the value rules, coalesced rows out.
+//   u = mix64(ctr), mix64 = the splitmix64 finaliser; ctr = seed + GOLDEN * (2 d + k) ^ realisation * 0xD1B54A32D192ED03;  uniform (0, 1] = ((u >> 11) + 1) 2^-53;
+//   Box-Muller: e1 = sqrt(-2 ln u1) cos(2 pi u2), e2 = ... sin(...).   tests/test_montecarlo_gpu.py restates it in numpy.
+struct NoiseDev { int row, kind, corr, st; double z1, v1, z2, v2; };   // kind 0 plain, 1 squared, 2 polar PMU, 3 polar PMU with squared magnitude, 4 / 5 rectangular PMU (un)correlated; st = st1 | st2 << 1
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
+    return z;
+}
+__global__ __launch_bounds__(1024) void k_gn_noise(const NoiseDev* dev, int ndev, unsigned long long seed, double scale, long long first, double* mean, double* w,
+                                                   int m, int ld, int lanes, int* bad) {
+    const int lane = threadIdx.x, wave = uniform(threadIdx.y);
+    const int d = blockIdx.x * 16 + wave;
+    if (d >= ndev) return;
+    const size_t b = (size_t)min((int)blockIdx.y * 64 + lane, lanes - 1);
+    const NoiseDev q = dev[d];
+    const unsigned long long ctr = (seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(2 * d)) ^ ((unsigned long long)(first + (long long)b) * 0xD1B54A32D192ED03ull);
+    const double u1 = (double)((mix64(ctr) >> 11) + 1ull) * 0x1p-53, u2 = (double)((mix64(ctr + 0x9E3779B97F4A7C15ull) >> 11) + 1ull) * 0x1p-53;
+    const double rad = sqrt(-2.0 * log(u1));
+    double sn, cs;
+    sincos(6.283185307179586476925286766559 * u2, &sn, &cs);
+    const double zz = q.z1 + scale * sqrt(q.v1) * (rad * cs);
+    const double za = q.z2 + scale * sqrt(q.v2) * (rad * sn);
+    const double st1 = (double)(q.st & 1), st2 = (double)((q.st >> 1) & 1);
+    double m0, w0, m1 = 0.0, w1 = 1.0, off = 0.0;
+    if (q.kind == 0 || q.kind == 2) { m0 = st1 * zz; w0 = 1.0 / q.v1; }
+    else if (q.kind == 1 || q.kind == 3) { m0 = st1 * zz * zz; w0 = 1.0 / (4.0 * zz * zz * q.v1); }
+    else {
+        double s, c;
+        sincos(za, &s, &c);
+        const double vre = q.v1 * c * c + q.v2 * (zz * s) * (zz * s), vim = q.v1 * s * s + q.v2 * (zz * c) * (zz * c);
+        const double stt = st1 * st2;
+        m0 = stt * (zz * c); m1 = stt * (zz * s);
+        if (q.kind == 4) { w0 = 1.0 / vre; w1 = 1.0 / vim; }
+        else {                                                    // covariancePmu + precision! (equations.jl:591-666)
+            const double l1i = 1.0 / sqrt(vre), l2 = s * c * (q.v1 - q.v2 * zz * zz) * l1i, l3i2 = 1.0 / (vim - l2 * l2);
+            off = (-l2 * l1i) * l3i2;
+            w0 = (l1i - l2 * off) * l1i; w1 = l3i2;
+        }
+    }
+    if (q.kind == 2 || q.kind == 3) { m1 = st2 * za; w1 = 1.0 / q.v2; }
+    const size_t col = (size_t)blockIdx.y * 64 + lane;            // every lane of the padded batch gets a value (lanes beyond the batch repeat its last realisation)
+    mean[(size_t)q.row * ld + col] = m0; w[(size_t)q.row * ld + col] = w0;
+    bool ok = w0 > 0.0 && w0 < 1.0e300;
+    if (q.kind >= 2) { mean[(size_t)(q.row + 1) * ld + col] = m1; w[(size_t)(q.row + 1) * ld + col] = w1; ok = ok && w1 > 0.0 && w1 < 1.0e300; }
+    if (q.kind == 5) { w[(size_t)(m + q.corr) * ld + col] = off; ok = ok && off == off && fabs(off) < 1.0e300; }
+    if (!ok) atomicOr(bad, 1);                                    // errorVariance: a zero-magnitude squared current / rectangular PMU reading
+}
+
 // ---- the result record of a sharded Monte-Carlo run (jgrid.h: jg_gn_pack_results_device) --------------------------------------------------
 // se.objective = r' W r at the residual of the last increment! (equations.jl:689-698), per scenario, reduced where the residuals are: a noisy
 // realisation's residual is 96 723 doubles, its objective one.  Two launches with a FIXED summation order (bitwise run-to-run): a wave sums OBJ_WROWS
@@ -750,6 +803,7 @@ struct jg_gn {
     int method = 0;                                     // jg_gn_set_method: 0 normal equations, 1 + one least-squares correction pass
     double* d_rho = nullptr; double* d_rhs2 = nullptr; double* d_inc2 = nullptr;   // correction pass (allocated by jg_gn_set_method)
     int* d_active = nullptr; int* d_iters = nullptr; int* d_status = nullptr; int* d_counter = nullptr; int* d_group = nullptr;
+    NoiseDev* d_noise = nullptr; int n_noise = 0; int* d_noise_bad = nullptr;   // raw readings per device (jg_gn_set_readings)
     double* d_obj = nullptr; double* d_objpart = nullptr; int* d_corr = nullptr; int obj_chunks = 0;   // objective per scenario (first use: jg_gn_get_objective / jg_gn_pack_results_device)
     bool ran = false;                                   // d_iters / d_status hold the verdicts of a stateEstimation! run
     jg::Engine eng;
@@ -1205,7 +1259,7 @@ void jg_gn_destroy(jg_gn* h) {
     hipFree(h->d_arena);                                         // V, theta, z, weights, slots, residual, rhs, increment, norms, lane bookkeeping: one allocation (jg_gn_create)
     hipFree(h->d_pair_ptr); hipFree(h->d_pa); hipFree(h->d_pb); hipFree(h->d_pz); hipFree(h->d_nres); hipFree(h->d_amax_v); hipFree(h->d_amax_i);
     hipFree(h->d_bad_v); hipFree(h->d_bad_i);
-    hipFree(h->d_obj); hipFree(h->d_objpart); hipFree(h->d_corr);
+    hipFree(h->d_obj); hipFree(h->d_objpart); hipFree(h->d_corr); hipFree(h->d_noise); hipFree(h->d_noise_bad);
     hipFree(h->d_grec); hipFree(h->d_gwave); hipFree(h->d_rrec); hipFree(h->d_rwave); hipFree(h->d_gtask); hipFree(h->d_gstage); hipFree(h->d_trec);
     if (h->h_counter) hipHostFree(h->h_counter);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -1249,6 +1303,57 @@ int jg_gn_set_measurement(jg_gn* h, const double* mean, const double* wdiag, con
     if (int rc = put_rows(h, h->d_w, wdiag, batch_stride_m, h->m)) return rc;
     if (h->ncorr > 0)
         if (int rc = put_rows(h, h->d_w + (size_t)h->m * h->ld, woff, batch_stride_corr, h->ncorr)) return rc;
+    return 0;
+}
+
+int jg_gn_set_readings(jg_gn* h, int64_t ndev, const int64_t* row, const int8_t* kind, const double* z1, const double* v1, const int8_t* s1,
+                       const double* z2, const double* v2, const int8_t* s2) {
+    if (!h || ndev < 1 || !row || !kind || !z1 || !v1 || !s1 || !z2 || !v2 || !s2) return failg(1, "jg_gn_set_readings: bad argument");
+    if (int rc = set_device(h)) return rc;
+    std::vector<NoiseDev> t((size_t)ndev);
+    std::vector<char> seen((size_t)h->m, 0);
+    std::vector<int> pair_of((size_t)h->m, -1);
+    for (int qn = 0; qn < h->ncorr; ++qn) pair_of[h->corr_row[qn]] = qn;
+    for (int64_t d = 0; d < ndev; ++d) {
+        const int k = kind[d], rows = k >= 2 ? 2 : 1;
+        if (k < 0 || k > 5 || row[d] < 1 || row[d] + rows - 1 > h->m) return failg(1, "jg_gn_set_readings: kind 0..5, rows 1-based inside the model");
+        if (!(v1[d] > 0.0) || (k >= 2 && !(v2[d] > 0.0))) return failg(1, "jg_gn_set_readings: variances must be positive");
+        const int r = (int)row[d] - 1;
+        for (int x = 0; x < rows; ++x) { if (seen[r + x]) return failg(1, "jg_gn_set_readings: two devices claim one row"); seen[r + x] = 1; }
+        if ((k == 5) != (pair_of[r] >= 0)) return failg(1, "jg_gn_set_readings: kind 5 (correlated rectangular PMU) exactly on the rows jg_gn_create got as corr_row");
+        t[d] = NoiseDev{r, k, k == 5 ? pair_of[r] : 0, (s1[d] ? 1 : 0) | (s2[d] ? 2 : 0), z1[d], v1[d], z2[d], k >= 2 ? v2[d] : 1.0};
+    }
+    for (int r = 0; r < h->m; ++r) if (!seen[r]) return failg(1, "jg_gn_set_readings: a row of the model belongs to no device");
+    GN_HIP(hipStreamSynchronize(h->stream));
+    hipFree(h->d_noise); h->d_noise = nullptr;
+    GN_HIP(hipMalloc((void**)&h->d_noise, t.size() * sizeof(NoiseDev)));
+    GN_HIP(jg::sync_copy(h->d_noise, t.data(), t.size() * sizeof(NoiseDev), hipMemcpyHostToDevice, h->stream));
+    if (!h->d_noise_bad) GN_HIP(hipMalloc((void**)&h->d_noise_bad, sizeof(int)));
+    h->n_noise = (int)ndev;
+    return 0;
+}
+
+int jg_gn_draw_noise(jg_gn* h, uint64_t seed, double scale, int64_t first_realisation) {
+    if (!h || !(scale >= 0.0) || first_realisation < 0) return failg(1, "jg_gn_draw_noise: bad argument");
+    if (!h->d_noise) return failg(1, "jg_gn_draw_noise: call jg_gn_set_readings first");
+    if (int rc = set_device(h)) return rc;
+    GN_HIP(hipMemsetAsync(h->d_noise_bad, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_gn_noise, dim3((unsigned)((h->n_noise + 15) / 16), (unsigned)(h->ld / 64)), dim3(64, 16), 0, h->stream, h->d_noise, h->n_noise,
+                       (unsigned long long)seed, scale, (long long)first_realisation, h->d_mean, h->d_w, h->m, h->ld, h->batch, h->d_noise_bad);
+    GN_HIP(hipGetLastError());
+    int bad = 0;
+    GN_HIP(jg::sync_copy(&bad, h->d_noise_bad, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (bad) return failg(1, "jg_gn_draw_noise: the variance of a measurement is zero or not finite (errorVariance): a squared-current / rectangular PMU reading of magnitude zero");
+    return 0;
+}
+
+int jg_gn_get_measurement(jg_gn* h, double* mean, double* wdiag, double* woff) {
+    if (!h || !mean || !wdiag) return failg(1, "jg_gn_get_measurement: bad argument");
+    if (int rc = set_device(h)) return rc;
+    GN_HIP(hipStreamSynchronize(h->stream));
+    if (int rc = get_rows(h, h->d_mean, mean, h->m)) return rc;
+    if (int rc = get_rows(h, h->d_w, wdiag, h->m)) return rc;
+    if (woff && h->ncorr > 0) return get_rows(h, h->d_w + (size_t)h->m * h->ld, woff, h->ncorr);
     return 0;
 }
 

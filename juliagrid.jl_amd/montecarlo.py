@@ -15,7 +15,7 @@ import numpy as np
 
 from . import _lib
 from .measurement import Measurement
-from .stateestimation import AcStateEstimation, gaussNewton, setNoise_, stateEstimation_
+from .stateestimation import AcStateEstimation, drawNoise_, gaussNewton, setNoise_, stateEstimation_
 
 RECORD_TAIL = 3         # iterations | status | objective behind magnitude[n] | angle[n]
 
@@ -24,13 +24,14 @@ class MonteCarloPipeline:
     """`inflight` batches of `batch` realisations each in flight on one GPU: a handle, a HIP stream and a host thread per batch (the narrow
     launches of one batch's factorisation are filled by the others').
 
-    A job is one batch of realisations: an integer SEED (the handle draws z + scale * sigma * N(0,1) per raw reading with PCG64(seed) and applies the
-    acWLS value rules per realisation -- stateestimation.setNoise_) or None (the handle keeps the realisations it holds: a timing loop).  Every job
-    restarts from the pipeline's start point, which stays in HBM.  `on_done(job, analysis)` runs on the CALLER's thread in job order -- where a sharded
+    A job is one batch of realisations: an integer SEED or a pair (seed, first realisation) -- the handle draws realisations first .. first + batch - 1 of
+    that seed ON THE DEVICE (stateestimation.drawNoise_: counter-based generator + the acWLS value rules, nothing over PCIe; a rank of a sharded study passes
+    its own `first`) --, `host_noise=True` draws them with numpy's PCG64(seed) on the host instead (setNoise_: [batch, m] arrays over PCIe), or None (the
+    handle keeps the realisations it holds: a timing loop).  Every job restarts from the pipeline's start point, which stays in HBM.  `on_done(job, analysis)` runs on the CALLER's thread in job order -- where a sharded
     run issues its gather (collectives must be issued in the same order on every rank)."""
 
-    def __init__(self, monitoring: Measurement, batch: int, inflight: int = 2, device: int = 0, start=None, method=None, scale: float = 1.0):
-        self.monitoring, self.batch, self.scale = monitoring, int(batch), float(scale)
+    def __init__(self, monitoring: Measurement, batch: int, inflight: int = 2, device: int = 0, start=None, method=None, scale: float = 1.0, host_noise: bool = False):
+        self.monitoring, self.batch, self.scale, self.host_noise = monitoring, int(batch), float(scale), bool(host_noise)
         kw = {} if method is None else {"method": method}
         self.handles = [gaussNewton(monitoring, batch=self.batch, device=device, **kw) for _ in range(max(1, int(inflight)))]
         n = monitoring.system.bus.number
@@ -71,7 +72,11 @@ class MonteCarloPipeline:
                         return
                     h = self.handles[k]
                     if jobs[j] is not None:
-                        setNoise_(h, np.random.Generator(np.random.PCG64(int(jobs[j]))), scale=self.scale)
+                        seed, first = (jobs[j] if isinstance(jobs[j], (tuple, list)) else (jobs[j], 0))
+                        if self.host_noise:
+                            setNoise_(h, np.random.Generator(np.random.PCG64(int(seed))), scale=self.scale)
+                        else:
+                            drawNoise_(h, int(seed), scale=self.scale, first=int(first))
                     h.restore_voltage()
                     stateEstimation_(h, iteration=iteration, tolerance=tolerance, fetch=False)
                     results[j] = (np.array(h.method.iteration), np.array(h.status))

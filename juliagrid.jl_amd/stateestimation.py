@@ -418,10 +418,50 @@ def gaussNewton(monitoring: Measurement, method=LU, batch: int = 1, device: int 
     return _tagged(AcStateEstimation(monitoring, batch, device), method, "gaussNewton")
 
 
+def _upload_readings(an: AcStateEstimation):
+    """The raw readings per device, once, for jg_gn_draw_noise (include/jgrid.h: jg_gn_set_readings): first row, kind of value rule, z / variance / status."""
+    mon, devs = an.monitoring, an._devs
+    z1, v1, s1, z2, v2, s2 = an._z
+    kind = np.zeros(len(devs), dtype=np.int8)
+    a, p = mon.ammeter, mon.pmu
+    for d, (fam, i) in enumerate(devs):
+        if fam != "p":
+            kind[d] = 1 if (fam == "a" and a.layout.square[i]) else 0
+        elif p.layout.polar[i]:
+            kind[d] = 3 if (p.layout.square[i] and not p.layout.bus[i]) else 2
+        else:
+            kind[d] = 5 if p.layout.correlated[i] else 4
+    _lib.check(_lib.lib().jg_gn_set_readings(an._h, len(devs), np.ascontiguousarray(an._dev_row + 1, dtype=np.int64), kind,
+                                             np.ascontiguousarray(z1), np.ascontiguousarray(v1), np.ascontiguousarray(s1, dtype=np.int8),
+                                             np.ascontiguousarray(z2), np.ascontiguousarray(v2), np.ascontiguousarray(s2, dtype=np.int8)))
+    an._readings_on_device = True
+
+
+def drawNoise_(an: AcStateEstimation, seed: int, scale: float = 1.0, first: int = 0):
+    """Monte-Carlo realisations drawn ON the device (jg_gn_draw_noise): lane b becomes realisation `first + b` of `seed` -- z + scale * sigma * N(0,1) on every raw
+    reading (measurement/utility.jl:70-73) from a counter-based generator, then the acWLS value rules -- without a byte over PCIe; the same (seed, realisation)
+    gives the same numbers on any rank, in any batch, at any lane.  The host containers (method.mean, the precision) are NOT refreshed: read them back with
+    measurementDevice(an) when needed."""
+    if isinstance(an, PmuStateEstimation):
+        raise TypeError("drawNoise_: Gauss-Newton analyses (the linear PMU model keeps its own rows)")
+    if not getattr(an, "_readings_on_device", False):
+        _upload_readings(an)
+    _lib.check(_lib.lib().jg_gn_draw_noise(an._h, int(seed), float(scale), int(first)))
+
+
+def measurementDevice(an: AcStateEstimation):
+    """(se.mean, diag(se.precision), pair terms) of every scenario as the device holds them: [batch, m], [batch, m], [batch, n_corr]."""
+    m, nc = an.dims["m"], int(an.method._corr.size)
+    mean, wd, wo = np.zeros((an.batch, m)), np.zeros((an.batch, m)), np.zeros((an.batch, max(nc, 1)))
+    _lib.check(_lib.lib().jg_gn_get_measurement(an._h, mean, wd, wo))
+    return mean, wd, wo[:, :nc]
+
+
 def setNoise_(an: AcStateEstimation, rng, scale: float = 1.0):
     """Monte-Carlo realisations: scenario b reads z + scale * sigma * N(0,1) on every raw meter quantity
     (what `noise = true` does in add*!, measurement/utility.jl:70-73), then the acWLS value rules are
-    re-applied per scenario (squared currents and rectangular PMUs make mean AND precision depend on z)."""
+    re-applied per scenario (squared currents and rectangular PMUs make mean AND precision depend on z).
+    Host path (numpy generator, [batch, m] arrays over PCIe); drawNoise_ does the same on the device from an integer seed."""
     z1, v1, s1, z2, v2, s2 = an._z
     B = an.batch
     n1 = z1[None, :] + scale * np.sqrt(v1)[None, :] * rng.standard_normal((B, z1.size))

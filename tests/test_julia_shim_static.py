@@ -79,7 +79,7 @@ def _ctype(arg):
 
 
 HANDLE_TYPES = {"jg_nr", "jg_gn", "jg_comm", "jg_plan"}
-SCALARS = {"Cint": "int", "Int64": "int64_t", "Float64": "double", "Int32": "int32_t"}
+SCALARS = {"Cint": "int", "Int64": "int64_t", "Float64": "double", "Int32": "int32_t", "UInt64": "uint64_t"}
 POINTEES = {"Float64": "double", "Int64": "int64_t", "Int32": "int32_t", "Int8": "int8_t", "UInt8": "uint8_t"}
 
 

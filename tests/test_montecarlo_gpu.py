@@ -101,7 +101,7 @@ def test_pipeline_delivers_the_records_of_plain_batches(jg):
     pipe.close()
     ref = jg.gaussNewton(mon, batch=B)
     for j, seed in enumerate(seeds):
-        jg.setNoise_(ref, np.random.Generator(np.random.PCG64(seed)), scale=1.0)
+        jg.drawNoise_(ref, seed)                                  # the pipeline draws its realisations on the device (MonteCarloPipeline(host_noise=False))
         ref.setVoltage(np.ones(n), np.zeros(n))
         jg.stateEstimation_(ref, iteration=40, tolerance=1e-8)
         rec = torch.zeros((B, 2 * n + 3), dtype=torch.float64, device="cuda")
@@ -110,3 +110,97 @@ def test_pipeline_delivers_the_records_of_plain_batches(jg):
         assert np.array_equal(res[j][0], ref.method.iteration) and np.array_equal(res[j][1], ref.status)
     assert not torch.equal(seen[0], seen[1])                      # different seeds, different realisations
     ref.close()
+
+
+# ---- realisations drawn on the device (jg_gn_set_readings / jg_gn_draw_noise) against a numpy restatement of the generator + the host's value rules ----------
+_GOLD, _LANE = 0x9E3779B97F4A7C15, 0xD1B54A32D192ED03
+
+
+def _mix64(z):
+    z = z ^ (z >> np.uint64(30)); z = z * np.uint64(0xBF58476D1CE4E5B9)
+    z = z ^ (z >> np.uint64(27)); z = z * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def _normals(seed, ndev, first, count):
+    """(e1, e2) [count, ndev]: the generator of k_gn_noise (csrc/jg_gn.hip) in numpy uint64 arithmetic: splitmix64 finaliser on a (seed, device, realisation) counter, Box-Muller."""
+    with np.errstate(over="ignore"):
+        d = np.arange(ndev, dtype=np.uint64)[None, :]
+        r = (np.uint64(first) + np.arange(count, dtype=np.uint64))[:, None]
+        ctr = (np.uint64(seed) + np.uint64(_GOLD) * (np.uint64(2) * d)) ^ (r * np.uint64(_LANE))
+        u1 = ((_mix64(ctr) >> np.uint64(11)) + np.uint64(1)).astype(np.float64) * 2.0 ** -53
+        u2 = ((_mix64(ctr + np.uint64(_GOLD)) >> np.uint64(11)) + np.uint64(1)).astype(np.float64) * 2.0 ** -53
+    rad = np.sqrt(-2.0 * np.log(u1))
+    return rad * np.cos(2.0 * np.pi * u2), rad * np.sin(2.0 * np.pi * u2)
+
+
+def _every_value_rule(jg, oracle):
+    t, osys, vm, va = se_case14(oracle)
+    tab = oracle.MeterTable()
+    for fam, kw in (("voltmeter", {}), ("ammeter", {}), ("ammeter", dict(square=True)), ("wattmeter", {}), ("varmeter", {}),
+                    ("pmu", {}), ("pmu", dict(polar=True)), ("pmu", dict(polar=True, square=True)), ("pmu", dict(correlated=True))):
+        oracle.add_from_power_flow(tab, osys, vm, va, fam, **kw)
+    return _mirror(jg, _system_like(jg, t, osys), tab)
+
+
+def test_noise_drawn_on_the_device_follows_the_generator_and_the_value_rules(jg, oracle):
+    """Every kind of value rule (plain, squared current, polar PMU with plain / squared magnitude, rectangular PMU with and without its 2x2 precision block):
+    the device's se.mean / se.precision of 70 realisations against the numpy restatement of its generator pushed through the HOST's rules (stateestimation._wls_values,
+    the restatement of acWLS :135-236) -- 1e-12; realisation r of a seed is the same numbers at any lane of any batch (what lets the ranks of a sharded study draw their own
+    shares); scale 0 is the noise-free set."""
+    mon = _every_value_rule(jg, oracle)
+    B = 70
+    an = jg.gaussNewton(mon, batch=B)
+    base = jg.measurementDevice(an)
+    z1, v1, s1, z2, v2, s2 = an._z
+    kinds = set()
+    jg.drawNoise_(an, 20251001, scale=1.0, first=5)
+    mean, wd, wo = jg.measurementDevice(an)
+    e1, e2 = _normals(20251001, z1.size, 5, B)
+    n1, n2 = z1[None, :] + np.sqrt(v1)[None, :] * e1, z2[None, :] + np.sqrt(v2)[None, :] * e2
+    rm, rw, ro, _ = an._values(an.monitoring, an._devs, an._dev_row, an.dims["m"], n1, v1, s1, n2, v2, s2)
+    assert ro.shape == wo.shape and wo.shape[1] > 0
+    for got, ref in ((mean, rm), (wd, rw), (wo, ro)):
+        assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max(), np.abs(got - ref).max()
+    assert np.abs(mean - base[0]).max() > 1e-4                    # it IS noisy
+    # the same realisations at other lanes of another batch
+    other = jg.gaussNewton(mon, batch=16)
+    jg.drawNoise_(other, 20251001, scale=1.0, first=5 + 30)
+    m2, w2, o2 = jg.measurementDevice(other)
+    assert np.array_equal(m2, mean[30:46]) and np.array_equal(w2, wd[30:46]) and np.array_equal(o2, wo[30:46])
+    jg.drawNoise_(other, 20251002, scale=1.0, first=5 + 30)       # another seed: other numbers
+    assert not np.array_equal(jg.measurementDevice(other)[0], m2)
+    other.close()
+    jg.drawNoise_(an, 1, scale=0.0)
+    back = jg.measurementDevice(an)
+    for got, ref in zip(back, base):                              # (the precision block of a correlated PMU is a difference of close numbers: sincos of the device and of numpy
+        assert np.all(np.abs(got - ref) <= 1e-11 * np.maximum(1.0, np.abs(ref)))   # differ in the last bit and that comes out at 1e-13 relative)
+    an.close()
+
+
+def test_device_noise_is_standard_normal_and_the_estimates_are_consistent(jg):
+    """512 realisations of the config-4-shaped set of case1354pegase drawn on the device: the standardised deviations (mean - z) / sigma of the plain rows have mean 0 and
+    variance 1 (6.6e6 samples: 5 sigma of the sample moments), and the estimation they feed converges with a chi-square objective -- the statistics of a sound generator
+    (badData.jl:948-961 tests se.objective against exactly that distribution)."""
+    s, mon = _config4_like(jg)
+    n, B = s.bus.number, 512
+    an = jg.gaussNewton(mon, batch=B)
+    base, wbase, _ = jg.measurementDevice(an)
+    jg.drawNoise_(an, 7, scale=1.0)
+    mean, wd, _ = jg.measurementDevice(an)
+    plain = np.flatnonzero(np.isin(an.method._code, (1, 6, 7, 8, 9, 10, 11)) & (an.method.type != 0))
+    dev = (mean[:, plain] - base[:, plain]) * np.sqrt(wbase[:, plain])
+    N = dev.size
+    assert abs(dev.mean()) < 5.0 / np.sqrt(N) and abs(dev.var() - 1.0) < 5.0 * np.sqrt(2.0 / N)
+    assert abs(np.mean(dev ** 3)) < 5.0 * np.sqrt(6.0 / N) and abs(np.mean(dev ** 4) - 3.0) < 5.0 * np.sqrt(96.0 / N)
+    c = np.corrcoef(dev[:, :200].T)                               # rows are independent of each other ...
+    assert np.abs(c - np.eye(200)).max() < 6.0 / np.sqrt(B)
+    c = np.corrcoef(dev[:200, :2000])                             # ... and realisations of each other
+    assert np.abs(c - np.eye(200)).max() < 6.0 / np.sqrt(2000)
+    an.setVoltage(np.ones(n), np.zeros(n))
+    jg.stateEstimation_(an, iteration=40, tolerance=1e-8, fetch=False)
+    assert np.all(an.status == 0)
+    dof = an.dims["m"] - (2 * n - 1)
+    obj = an.objectiveDevice()
+    assert abs(obj.mean() - dof) < 5.0 * np.sqrt(2.0 * dof / B), (obj.mean(), dof)
+    an.close()
