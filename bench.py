@@ -422,7 +422,7 @@ def live_pmc_traffic(case, batch, n):
             for c in ("FETCH_SIZE", "WRITE_SIZE"):
                 r = subprocess.run(["rocprofv3", "--pmc", c, "--kernel-trace", "-d", os.path.join(td, c), "-o", "p", "--output-format", "csv", "--",
                                     sys.executable, os.path.join(ROOT, "tools", "profile_kernels.py"), str(batch), "2", case],
-                                   cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+                                   cwd="/tmp", env=env, capture_output=True, text=True, timeout=120)
                 if r.returncode != 0:
                     return None
 
@@ -466,7 +466,7 @@ def live_pmc_traffic_se(batch):
             for c in ("FETCH_SIZE", "WRITE_SIZE"):
                 r = subprocess.run(["rocprofv3", "--pmc", c, "--kernel-trace", "-d", os.path.join(td, c), "-o", "p", "--output-format", "csv", "--",
                                     sys.executable, os.path.join(ROOT, "tools", "profile_se.py"), str(batch), "2"],
-                                   cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+                                   cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
                 if r.returncode != 0:
                     return None
                 for dp, _, fs in os.walk(os.path.join(td, c)):
