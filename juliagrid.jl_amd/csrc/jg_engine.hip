@@ -1264,6 +1264,197 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
     if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pt[4] = wall_clock64(); }
 }
 
+// ---- the top of a SYMMETRIC plan (the Gauss-Newton gain), round 5 ---------------------------------------------------------------------------
+// k_fact_top mirrors a symmetric front from its upper entries and eliminates all of it: twice the gathers, twice the extend-add, twice the block updates and
+// twice the registers of what LDL' needs (class 4 -- fronts of 49 - 63 rows, which only the gain has -- at 198 VGPRs: two workgroups per CU).  Here a thread
+// keeps only its blocks ON AND ABOVE the diagonal (i <= j; the right-hand side is column f): CLS (CLS + 1) / 2 class blocks instead of CLS^2.  The pivot
+// column is the pivot row transposed -- Lh(i, q) = U(q, i)' --, so the owners of row q publish BOTH operands of a step; with Jordan rows the blocks above the
+// pivot, U(i, q) for i < q, come from the owners of column q as before.  Children leave (and parents read) the upper triangle of an update matrix at the
+// offsets of the full one.  No pivot wave, Jordan rows only: what a Gauss-Newton handle runs by default; the plain-row paths (jg_gn_set_method(h, 1), the
+// selected inverse) keep k_fact_top.  Another summation order than the mirrored elimination (whose lower half is not bitwise the transpose of its upper half): results
+// agree to rounding, tests/test_se_*.py hold both against the oracle; JG_TOP_SYM=0 runs the mirrored kernel.
+__device__ __forceinline__ Blk blk_t(const Blk& v) { return Blk{v.v00, v.v10, v.v01, v.v11}; }
+template <int CLS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CLS == 4 ? 3 : 4))) void k_fact_top_sym(TopArgs a) {
+    __shared__ __attribute__((aligned(16))) double Dbuf[2][4];
+    __shared__ __attribute__((aligned(16))) double Ubuf[2][64 * 4];    // pivot row U(q, c), zero for c <= q
+    __shared__ __attribute__((aligned(16))) double Lbuf[2][64 * 4];    // i > q: U(q, i)';  i < q: U(i, q) (Jordan);  i == q and i >= f: zero
+    __shared__ __attribute__((aligned(16))) double Dref[64 * 2];
+    int grp, x;
+    if (!map_block(a.sel, a.ld, a.ntasks * a.lpg, grp, x)) return;
+    const int ti = x / a.lpg;
+    const int bb = grp * 64 + (x - ti * a.lpg);
+    if (bb >= a.lanes) return;
+    const int tid = threadIdx.x;
+    const int gi = (tid >> 4) & 15, gj = tid & 15;
+    const bool prof = a.prof && tid == 0;
+    long long* pt = a.prof + ((size_t)(a.task_begin + ti) * a.ld + bb) * 8;
+    if (prof) {
+        pt[0] = wall_clock64();
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        pt[5] = (long long)((xcc & 0xf) << 16 | ((hw >> 13) & 0x7) << 8 | ((hw >> 8) & 0xf));
+    }
+    const RecS h = load_rec(a.task, (size_t)a.task_begin + ti);
+    const int m = h[0], e = h[1], nchild = h[5], fprime = h[11];
+    const int f = fprime - 1;
+    const int* td = a.data + h[3];
+    const size_t b = (size_t)bb, ld = (size_t)a.ld;
+    double* stk = a.stack + b * (size_t)a.stack_stride;
+    int bad = 0;
+    Blk T[CLS][CLS];                                             // T[r][c] with r <= c only (the others are never named: no registers)
+    {   // ---- load: the upper entries of the front, once each
+        int code[CLS][CLS];
+#pragma unroll
+        for (int r = 0; r < CLS; ++r)
+#pragma unroll
+            for (int c = r; c < CLS; ++c) {
+                const int i = r * 16 + gi, j = c * 16 + gj;
+                code[r][c] = (i <= j && i < f && j < fprime) ? td[i * fprime + j] : -1;
+            }
+#pragma unroll
+        for (int r = 0; r < CLS; ++r)
+#pragma unroll
+            for (int c = r; c < CLS; ++c) {
+                const int cd = code[r][c];
+                Blk v{0.0, 0.0, 0.0, 0.0};
+                if (cd <= -2) { const double2 y = load_vec(a.W, (size_t)(-(cd + 2)), b, ld); v.v00 = y.x; v.v10 = y.y; }
+                else if (cd >= 0 && !((cd >> 28) & 1)) v = load_blk(a.X, (size_t)(cd & 0x0fffffff), b, ld);
+                T[r][c] = v;
+                const int i = r * 16 + gi, j = c * 16 + gj;
+                if (i == j && i < m) *(double2*)(Dref + (size_t)i * 2) = row_max(v);
+            }
+    }
+    if (prof) pt[1] = wall_clock64();
+    {   // ---- extend-add: the upper triangle (+ update vector) of every child's update matrix; front orders are ascending in the pivot number on both
+        // sides, so an upper block of the parent is an upper block of the child
+        const int* cd = td + h[7];
+        for (int ch = 0; ch < nchild; ++ch) {
+            const int coff = cd[0], cen = cd[1];
+            const int* inv = cd + 2;
+            const double* C = stk + coff;
+            int ri[CLS], cj[CLS];
+#pragma unroll
+            for (int r = 0; r < CLS; ++r) { const int i = r * 16 + gi; ri[r] = i < f ? inv[i] : -1; }
+#pragma unroll
+            for (int c = 0; c < CLS; ++c) { const int j = c * 16 + gj; cj[c] = j < fprime ? inv[j] : -1; }
+#pragma unroll
+            for (int r = 0; r < CLS; ++r)
+#pragma unroll
+                for (int c = r; c < CLS; ++c)
+                    if (r * 16 + gi <= c * 16 + gj && ri[r] >= 0 && cj[c] >= 0) {
+                        const double2* p = (const double2*)(C + ((size_t)ri[r] * (cen + 1) + cj[c]) * 4);
+                        const double2 q0 = p[0], q1 = p[1];
+                        T[r][c].v00 += q0.x; T[r][c].v01 += q0.y; T[r][c].v10 += q1.x; T[r][c].v11 += q1.y;
+                    }
+            cd += 2 + fprime;
+        }
+    }
+    if (prof) pt[2] = wall_clock64();
+    // ---- publish step 0: the owners of row 0 write the row and, transposed, the column
+    if (gi == 0) {
+#pragma unroll
+        for (int c = 0; c < CLS; ++c) {
+            const int j = c * 16 + gj;
+            lds_set(Ubuf[0], j, j > 0 ? T[0][c] : zero_blk());
+            lds_set(Lbuf[0], j, (j > 0 && j < f) ? blk_t(T[0][c]) : zero_blk());
+        }
+    }
+    if (tid == 0) {
+        const Blk d0 = factor_diag(T[0][0], bad, *(const double2*)Dref);
+        lds_set(Dbuf[0], 0, d0);
+        T[0][0] = d0;
+    }
+    __syncthreads();
+    // ---- pivot steps
+    for (int qv = 0; qv < m; ++qv) {
+        const int q = uniform(qv);
+        const int cur = q & 1, nxt = cur ^ 1;
+        Blk D = lds_get(Dbuf[cur], 0);
+        D = Blk{uniform_d(D.v00), uniform_d(D.v01), uniform_d(D.v10), uniform_d(D.v11)};
+        const int sw = uniform(D.v10 > 2.0 ? 1 : 0);
+        const double dl = D.v10 - 4.0 * sw;
+        Blk Lq[CLS];
+#pragma unroll
+        for (int r = 0; r < CLS; ++r) Lq[r] = lds_get(Lbuf[cur], r * 16 + gi);
+#pragma unroll
+        for (int c = 0; c < CLS; ++c) {
+            const double2* p = (const double2*)(Ubuf[cur] + (size_t)(c * 16 + gj) * 4);
+            const double2 a0 = p[sw], a1 = p[sw ^ 1];
+            Blk z;
+            z.v10 = (a1.x - dl * a0.x) * D.v11; z.v00 = (a0.x - D.v01 * z.v10) * D.v00;
+            z.v11 = (a1.y - dl * a0.y) * D.v11; z.v01 = (a0.y - D.v01 * z.v11) * D.v00;
+#pragma unroll
+            for (int r = 0; r <= c; ++r) blk_sub(T[r][c], Lq[r], z);     // (a diagonal class also moves the unused blocks below the diagonal: never read, never stored)
+        }
+        if (q + 1 < m) {
+            const int rq = (q + 1) >> 4, tq = (q + 1) & 15;
+            if (gi == tq && gj == tq) {                          // the owner of S(q+1, q+1): final now
+                const double2 ref = *(const double2*)(Dref + (size_t)(q + 1) * 2);
+#pragma unroll
+                for (int r = 0; r < CLS; ++r)
+                    if (r == rq) {
+                        const Blk dn = factor_diag(T[r][r], bad, ref);
+                        lds_set(Dbuf[nxt], 0, dn);
+                        T[r][r] = dn;
+                    }
+            }
+            if (gi == tq) {                                      // the owners of row q + 1: the row, and the column below the pivot as its transpose
+#pragma unroll
+                for (int r = 0; r < CLS; ++r)
+                    if (r == rq) {
+#pragma unroll
+                        for (int c = 0; c < CLS; ++c) {
+                            const int j = c * 16 + gj;
+                            if (c < r) lds_set(Ubuf[nxt], j, zero_blk());                    // (columns left of the pivot's class: finished; their Lbuf entries belong to the Jordan writers)
+                            else {
+                                const bool right = j > q + 1;
+                                lds_set(Ubuf[nxt], j, right ? T[r][c] : zero_blk());
+                                if (j >= q + 1) lds_set(Lbuf[nxt], j, (right && j < f) ? blk_t(T[r][c]) : zero_blk());
+                            }
+                        }
+                    }
+            }
+            if (gj == tq) {                                      // Jordan: the blocks of column q + 1 ABOVE the pivot, U(i, q + 1), i <= q
+#pragma unroll
+                for (int c = 0; c < CLS; ++c)
+                    if (c == rq) {
+#pragma unroll
+                        for (int r = 0; r <= c; ++r) {
+                            const int i = r * 16 + gi;
+                            if (i < q + 1) lds_set(Lbuf[nxt], i, T[r][c]);
+                        }
+                    }
+            }
+        }
+        __syncthreads();
+    }
+    if (prof) pt[3] = wall_clock64();
+    // ---- store (upper blocks only)
+    const int lgo = h[12];
+    double2* out = e > 0 ? stack_unit(a, b, h[4], lgo) : nullptr;
+    const int jb = h[14];
+#pragma unroll
+    for (int r = 0; r < CLS; ++r)
+#pragma unroll
+        for (int c = r; c < CLS; ++c) {
+            const int i = r * 16 + gi, j = c * 16 + gj;
+            if (i > j) continue;
+            const int cd = (i < f && j < fprime) ? td[i * fprime + j] : -1;
+            const Blk& v = T[r][c];
+            if (i < m && j >= m && j < f) store_blk(a.X, (size_t)(jb + i * e + (j - m)), b, ld, v.v00, v.v01, v.v10, v.v11);
+            else if (cd <= -2) store_vec(a.W, (size_t)(-(cd + 2)), b, ld, v.v00, v.v10);
+            else if (cd >= 0 && (!((cd >> 28) & 4) || (i == j && i < m))) store_blk(a.X, (size_t)(cd & 0x0fffffff), b, ld, v.v00, v.v01, v.v10, v.v11);
+            else if (i >= m && i < f && j >= m && j < fprime) {
+                double2* p = out + ((((size_t)(i - m) * (e + 1) + (j - m)) * 2) << lgo);
+                p[0] = double2{v.v00, v.v01}; p[(size_t)1 << lgo] = double2{v.v10, v.v11};
+            }
+        }
+    if (bad) atomicOr(a.status + b, 4);
+    if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pt[4] = wall_clock64(); }
+}
+
 // ---- narrow task kernels (round 5): ONE or TWO waves per (task, scenario) ----------------------------------------------------------
 // k_fact_top spreads a front over 256 threads: a pivot step is then ~0.2 us of arithmetic inside ~0.9 us of barrier, LDS round trips and publish
 // code, and a CU holds four scenarios (r04_top_task_profile.txt: 2 560 workgroups of a task level run in two to three rounds).  The step is a chain,
@@ -1936,6 +2127,15 @@ int Engine::factor(hipStream_t st, const double* A, const double* rhs, const Gro
             if (L.grouped) {                                     // every grouped task of the level: 4 or 16 scenarios per workgroup
                 t.wg_begin = L.wg_begin; t.nwg = L.nwg;
                 hipLaunchKernelGGL((k_fact_grp<4>), dim3((unsigned)L.nwg * gs), dim3(256), 0, st, t);
+                continue;
+            }
+            // round 5: symmetric plans with Jordan rows (the Gauss-Newton gain by default) eliminate the upper triangle only (k_fact_top_sym); JG_TOP_SYM=0: the mirrored front
+            static const bool sym_env = !(getenv("JG_TOP_SYM") && atoi(getenv("JG_TOP_SYM")) == 0);
+            if (plan->S.symmetric && jordan && sym_env) {
+                const dim3 grids((unsigned)L.ntasks * t.lpg * gs);
+                if (L.cls == 2) hipLaunchKernelGGL((k_fact_top_sym<2>), grids, dim3(256), 0, st, t);
+                else if (L.cls == 3) hipLaunchKernelGGL((k_fact_top_sym<3>), grids, dim3(256), 0, st, t);
+                else hipLaunchKernelGGL((k_fact_top_sym<4>), grids, dim3(256), 0, st, t);
                 continue;
             }
             // round 5: narrow task kernels (k_fact_topw) for the front classes they exist for -- bitwise the results of k_fact_top.  JG_TOPW=1: W1 (class 2), 2: W2

@@ -168,3 +168,42 @@ def test_shared_device_hint_keeps_the_bits(jg):
     assert np.array_equal(a.method.iteration, b.method.iteration)
     assert np.array_equal(a.voltage.magnitude, b.voltage.magnitude) and np.array_equal(a.voltage.angle, b.voltage.angle)
     a.close(); b.close()
+
+
+SCRIPT_SE = r"""
+import sys
+import numpy as np
+sys.path.insert(0, {root!r})
+sys.path.insert(0, {root!r} + "/tests")
+import juliagrid.jl_amd as jg
+s = jg.powerSystem({case!r})
+pf = jg.newtonRaphson(s)
+jg.powerFlow_(pf, tolerance=1e-11)
+mon = jg.measurement(s)
+jg.addVoltmeter_(mon, pf, variance=1e-4); jg.addWattmeter_(mon, pf, variance=1e-4); jg.addVarmeter_(mon, pf, variance=1e-4)
+jg.addPmu_(mon, pf, buses=range(1, s.bus.number + 1, 10), statusTo=-1, minMagnitude=1e-6)
+an = jg.gaussNewton(mon, batch={batch})
+jg.drawNoise_(an, 4)
+an.setVoltage(np.ones(s.bus.number), np.zeros(s.bus.number))
+jg.stateEstimation_(an, iteration=40, tolerance=1e-8)
+np.savez({out!r}, it=np.asarray(an.method.iteration), st=np.asarray(an.status), vm=np.asarray(an.voltage.magnitude), va=np.asarray(an.voltage.angle), obj=np.asarray(an.objectiveDevice()))
+"""
+
+
+@pytest.mark.parametrize("case,batch", [("case9241synth", 128), ("case9241synth", 1)])
+def test_symmetric_top_kernel_against_the_mirrored_front(tmp_path, case, batch):
+    """k_fact_top_sym (round 5: the top tasks of the Gauss-Newton gain keep and eliminate the upper triangle only) against k_fact_top on the mirrored front (JG_TOP_SYM=0):
+    another summation order, not another algorithm -- equal iteration counts and status, estimates to 1e-10, objectives to 1e-9 relative on noisy realisations of config 4."""
+    outs = []
+    for mode in (1, 0):
+        out = str(tmp_path / f"sym{mode}.npz")
+        e = dict(os.environ, JG_TOP_SYM=str(mode))
+        r = subprocess.run([sys.executable, "-c", SCRIPT_SE.format(root=ROOT, case=case, batch=batch, out=out)], env=e, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        import numpy as np
+        outs.append(dict(np.load(out)))
+    import numpy as np
+    a, b = outs
+    assert np.array_equal(a["it"], b["it"]) and np.array_equal(a["st"], b["st"]) and np.all(a["st"] == 0)
+    assert np.abs(a["vm"] - b["vm"]).max() <= 1e-10 and np.abs(a["va"] - b["va"]).max() <= 1e-10
+    assert np.abs(a["obj"] - b["obj"]).max() <= 1e-9 * np.abs(b["obj"]).max()
