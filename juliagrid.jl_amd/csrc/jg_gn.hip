@@ -806,6 +806,7 @@ struct jg_gn {
     NoiseDev* d_noise = nullptr; int n_noise = 0; int* d_noise_bad = nullptr;   // raw readings per device (jg_gn_set_readings)
     double* d_obj = nullptr; double* d_objpart = nullptr; int* d_corr = nullptr; int obj_chunks = 0;   // objective per scenario (first use: jg_gn_get_objective / jg_gn_pack_results_device)
     bool ran = false;                                   // d_iters / d_status hold the verdicts of a stateEstimation! run
+    double wait_us = 0.0;                               // running mean of the host's waits for an iteration's verdict (jg_gn_run: polls while this is short)
     jg::Engine eng;
     hipStream_t stream = nullptr;
     hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
@@ -1443,27 +1444,31 @@ int jg_gn_run(jg_gn* h, int64_t max_iter, double tol, int32_t* iters, int32_t* s
     GN_HIP(hipMemsetAsync(h->d_iters, 0, (size_t)h->ld * 4, h->stream));          // acStateEstimation.jl:1298
     GN_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
     GN_HIP(hipMemsetAsync(h->d_group, 0xff, (size_t)(h->ld / 64) * sizeof(int), h->stream));
-    // (round 5, as jg_nr_run: the host arms the pinned word and polls it instead of paying a stream synchronise per iteration; JG_POLL=0 switches it off)
+    // (round 5, as jg_nr_run: while the handle's iterations are SHORT the host arms the pinned word and polls it instead of paying a stream synchronise per
+    // iteration; a long iteration -- config 4 at 512 lanes: 4.4 ms -- blocks as before, see wait_verdict in jg_nr.hip.  JG_POLL=0 switches polling off)
     static const bool poll = !(getenv("JG_POLL") && atoi(getenv("JG_POLL")) == 0);
     for (int64_t it = 0; it <= max_iter; ++it) {                                   // :1303
-        if (poll) *(volatile int*)h->h_counter = -1;
+        const bool spin = poll && h->wait_us <= 800.0;
+        if (spin) *(volatile int*)h->h_counter = -1;
         GN_HIP(hipGraphLaunch(h->exec, h->stream));
-        if (poll) {
+        const auto t0 = std::chrono::steady_clock::now();
+        auto elapsed = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); };
+        bool block = !spin;
+        if (spin) {
             volatile int* w = (volatile int*)h->h_counter;
-            const auto t0 = std::chrono::steady_clock::now();
-            bool fell_back = false;
             for (long spins = 0; *w == -1; ++spins) {
                 if ((spins & 63) == 63) {
-                    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-                    if (us > 2.0e6) { fell_back = true; break; }
-                    if (us > 200.0) std::this_thread::yield();
+                    const double us = elapsed();
+                    if (us > 2.0e6) { block = true; break; }
+                    if (us > 1600.0) std::this_thread::yield();
                 }
 #if defined(__x86_64__)
                 __builtin_ia32_pause();
 #endif
             }
-            if (fell_back) GN_HIP(hipStreamSynchronize(h->stream));
-        } else GN_HIP(hipStreamSynchronize(h->stream));
+        }
+        if (block) GN_HIP(hipStreamSynchronize(h->stream));
+        h->wait_us = 0.5 * h->wait_us + 0.5 * elapsed();
         if (*h->h_counter == 0) break;
     }
     GN_HIP(hipStreamSynchronize(h->stream));

@@ -739,7 +739,7 @@ struct jg_nr {
     bool paused = false;             // jg_nr_run_defer stopped with scenarios still active (lanes compacted, not yet sent home)
     int* d_move = nullptr;           // straggler hand-off: map[64] | home[64] | count[1] (device), home/count mirrored in h_move (pinned)
     int* h_move = nullptr;
-    double wait_us = 0.0;            // how long the host waited for the last verdicts (wait_verdict: sleeps through most of the next one)
+    double wait_us = 0.0;            // how long the host waited for the last verdicts (running mean; wait_verdict: polls the pinned word while this is short)
     int* h_counter = nullptr;        // pinned
     int* h_counter_dev = nullptr;    // its device alias
 };
@@ -1440,23 +1440,27 @@ int run_setup(jg_nr* h, int64_t max_iter, double tol, int lanes, bool keep_iters
 // hipStreamSynchronize costs a wake-up of ~20 us per iteration -- a tenth of a single instance's iteration; round 5: the host ARMS the word (-1) before
 // the launch and polls it (bounded spin, then yields; hipStreamSynchronize after 2 s as the safety net).  The next graph is then launched while the tail of
 // the previous one (the predicated re-assembly of a compaction) still runs -- stream order keeps them apart.  JG_POLL=0: the synchronise of round 4.
+constexpr double POLL_BELOW_US = 800.0;   // a handle whose waits average more than this blocks in hipStreamSynchronize instead
 static bool poll_enabled() { static const bool on = !(getenv("JG_POLL") && atoi(getenv("JG_POLL")) == 0); return on; }
 static void arm_verdict(jg_nr* h) { if (poll_enabled()) *(volatile int*)h->h_counter = -1; }
 static hipError_t wait_verdict(jg_nr* h) {
-    if (!poll_enabled()) return hipStreamSynchronize(h->stream);
-    volatile int* w = (volatile int*)h->h_counter;
     const auto t0 = std::chrono::steady_clock::now();
     auto elapsed = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); };
-    // Iterations of one handle take about as long as the one before: the thread SLEEPS through the first 70 % of that (a pipeline has a host thread per batch in
-    // flight, a node eight ranks of them -- they must not each burn a core for the 1.6 ms of a 512-lane iteration) and spins only for the rest.
-    // (only where an iteration is long: a sleep overshoots by 50 - 200 us -- measured on a single instance of the 10k-bus grid, 366 us per iteration: 1.595 ms per
-    // solve spinning, 1.80 with a nap, 1.656 with the stream synchronise of round 4)
-    if (h->wait_us > 800.0 && *w == -1) std::this_thread::sleep_for(std::chrono::duration<double, std::micro>(0.7 * h->wait_us - 100.0));
+    // Polling pays where an iteration is SHORT (a single instance of the 10k-bus grid: 366 us per iteration; 1.595 ms per solve spinning against 1.656 with the
+    // synchronise).  Where it is long -- a 512-lane batch: 1.6 ms, three of them in flight on a thread each -- the blocking wait is the right one: measured on one
+    // box, interleaved (profiles/r05_poll_ab.txt), the pipeline loses 7 - 10 % to three spinning / napping host threads (254 - 264k against 282 - 287k NR it/s at
+    // the driver's K = 20).  The handle remembers how long its last waits took and picks by that.
+    if (!poll_enabled() || h->wait_us > POLL_BELOW_US) {
+        const hipError_t e = hipStreamSynchronize(h->stream);
+        h->wait_us = 0.5 * h->wait_us + 0.5 * elapsed();
+        return e;
+    }
+    volatile int* w = (volatile int*)h->h_counter;
     for (long spins = 0; *w == -1; ++spins) {
         if ((spins & 63) == 63) {
             const double us = elapsed();
             if (us > 2.0e6) return hipStreamSynchronize(h->stream);          // something is wrong (or very slow): the blocking wait reports it
-            if (us > 3.0 * h->wait_us + 500.0) std::this_thread::yield();     // far beyond the expected time: give the core away between looks
+            if (us > 2.0 * POLL_BELOW_US) std::this_thread::yield();          // longer than anything this branch is meant for (the first wait of a big batch): give the core away between looks
         }
 #if defined(__x86_64__)
         __builtin_ia32_pause();
@@ -1761,14 +1765,19 @@ int jg_nr_fast_patch_batch(jg_nr* h, int64_t scenario0, int64_t count, int64_t k
     if (int rc = set_device(h)) return rc;
     NR_HIP(hipStreamSynchronize(h->stream));
     const jg::BlockSymbolic& S = h->eng.plan->S;
+    for (int64_t sc = 0; sc < count; ++sc)                       // the whole call is checked before a single edit is recorded: a refused call changes nothing
+        for (int64_t m = 0; m < k; ++m) {
+            const int64_t p = ptr[sc * k + m];
+            if (p == 0) continue;
+            if (p < 1 || p > h->nnz) return fail(1, "jg_nr_fast_patch_batch: pointer out of range");
+            for (int64_t mm = 0; mm < m; ++mm) if (ptr[sc * k + mm] == p) return fail(1, "jg_nr_fast_patch_batch: duplicate pointer");
+        }
     for (int64_t sc = 0; sc < count; ++sc)
         for (int m = 0; m < FAST_MP; ++m) {
             const size_t at = (size_t)m * h->batch + scenario0 + sc;
             h->fp_entry[at] = -1; h->fp_dp[at] = 0.0; h->fp_dq[at] = 0.0;
             if (m >= k || ptr[sc * k + m] == 0) continue;
             const int64_t p = ptr[sc * k + m];
-            if (p < 1 || p > h->nnz) return fail(1, "jg_nr_fast_patch_batch: pointer out of range");
-            for (int mm = 0; mm < m; ++mm) if (ptr[sc * k + mm] == p) return fail(1, "jg_nr_fast_patch_batch: duplicate pointer");
             h->fp_entry[at] = S.src_entry[h->tperm[p - 1]];
             h->fp_dp[at] = dbp[sc * k + m]; h->fp_dq[at] = dbq[sc * k + m];
         }

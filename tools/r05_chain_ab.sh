@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: records a round-5 experiment whose code is NOT in the tree any more (the switch it toggles no longer exists): kept as the recipe behind the file of the same name under profiles/
 # chained single-task top launches (JG_TOP_CHAIN=1, default) against one launch per task level (=0)
 cd "$(dirname "$0")/.."; OUT=gpurun_out/r05_chain_ab.txt; : > $OUT
 for rep in 1 2; do for M in 0 1; do

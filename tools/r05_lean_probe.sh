@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: records a round-5 experiment whose code is NOT in the tree any more (the switch it toggles no longer exists): kept as the recipe behind the file of the same name under profiles/
 # probe: k_fact_task at 96 VGPRs (five waves per SIMD: room for another batch's top workgroup beside two task workgroups) and 28 LDS slots, isolated and in the pipeline
 cd "$(dirname "$0")/.."; OUT=gpurun_out/r05_lean_probe.txt; : > $OUT
 for L in "" probe_libs/libjg_slots28.so probe_libs/libjg_lean.so; do
