@@ -344,10 +344,29 @@ def make_gather(jg, torch, dist, rank, world, local, cdev, force_dist, lanes, wi
         dist.broadcast(uid, src=0)
         dist.broadcast(ok, src=0)
         if int(ok.item()):
-            try:
-                comm = jg._lib.Comm(rank, world, uid.cpu().numpy(), device=local)
-            except Exception as e:
-                note = repr(e); comm = None
+            # RCCL through the C ABI has only ever met ONE rank on the build pool (one GPU per box): the communicator is built and tried -- one gather of the
+            # real record size -- on a side thread with a deadline, so that a rendezvous that never completes costs the run its C-ABI gather, not the run
+            import threading
+            box = {}
+            uid_host = uid.cpu().numpy()
+
+            def build_and_try():
+                try:
+                    c = jg._lib.Comm(rank, world, uid_host, device=local)
+                    torch.cuda.set_device(local)
+                    probe = torch.zeros((lanes, width), dtype=torch.float64, device="cuda")
+                    out = torch.empty((world * lanes, width), dtype=torch.float64, device="cuda")
+                    c.allgather_device(probe.data_ptr(), out.data_ptr(), probe.numel())
+                    torch.cuda.synchronize()
+                    box["comm"] = c
+                except Exception as e:
+                    box["error"] = repr(e)
+            th = threading.Thread(target=build_and_try, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("JG_BENCH_COMM_TIMEOUT", "120")))
+            comm = box.get("comm")
+            if comm is None:
+                note = box.get("error", "communicator not ready after JG_BENCH_COMM_TIMEOUT seconds")
             good = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device="cuda")
             dist.all_reduce(good, op=dist.ReduceOp.MIN)
             if not int(good.item()):
