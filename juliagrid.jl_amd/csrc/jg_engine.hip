@@ -2052,6 +2052,7 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, long long 
     JG_HIP(hipMalloc((void**)&status, (size_t)ld * sizeof(int)));
     JG_HIP(sync_fill(status, 0, (size_t)ld * sizeof(int), st));
     JG_HIP(hipGetDevice(&device));
+    probe_part = getenv("JG_PROBE_FACT_PART") ? atoi(getenv("JG_PROBE_FACT_PART")) : 0;
     if (timing) fprintf(stderr, "[jg engine] + factor storage, stacks               %6.1f ms\n", tnow() - te0);
     return 0;
 }
@@ -2108,6 +2109,7 @@ int Engine::factor(hipStream_t st, const double* A, const double* rhs, const Gro
         }
     }
     for (const DevLaunch& L : fact) {
+        if (probe_part == 2) break;
         a.seg_begin = L.seg_begin;
         { const Segment& g = plan->S.fact_seg[L.seg_begin]; a.s0_base = g.rec_base; a.s0_nchunks = g.nchunks; a.s0_wpi = g.wpi; a.s0_rpw = g.rpw; }
         if (plan->S.fact_tasks)                                  // TASKS (jg_symbolic.hpp): a workgroup per task, not per 8 item waves
@@ -2116,7 +2118,7 @@ int Engine::factor(hipStream_t st, const double* A, const double* rhs, const Gro
             hipLaunchKernelGGL(k_fact_level, dim3((unsigned)L.grid * (16 / FACT_WAVES) * gs, L.nseg), dim3(64, FACT_WAVES), FACT_WAVES * 256 * sizeof(double), st, a);
     }
     // the top of the elimination tree: multifrontal tasks, one workgroup per (task, scenario), launch = (task level, class)
-    if (!plan->S.top_launch.empty()) {
+    if (!plan->S.top_launch.empty() && probe_part != 1) {
         const long long s0 = std::max<long long>(plan->S.top_stack_cls[0], 2);
         TopArgs t{top_task, top_data, X, W, top_stack, status, sel, s0, {0, s0 * ld, (s0 + plan->S.top_stack_cls[1]) * ld}, {s0, plan->S.top_stack_cls[1], plan->S.top_stack_cls[2]},
                   top_prof, ld, a.lanes, 0, 0, 64, top_wgmap, 0, 0};

@@ -215,6 +215,7 @@ struct Engine {
     // forward() + backsolve() need (the forward elimination of another right-hand side produces y, not the y' Jordan rows go with).
     // Read by factor() and backsolve() at launch time: change it only between a backsolve and the next factorisation.
     bool jordan = false;
+    int probe_part = 0;            // TIMING PROBE (JG_PROBE_FACT_PART at create: 1 = factor() launches the bottom levels only, 2 = the top only; wrong numbers) -- tools/r05_overlap_probe.py
     bool shared = false;           // hint (jg_nr_set_shared): other batches are in flight on this GPU -- the top launches take the 4-wave variant (same bits)
     Rec* top_task = nullptr; int* top_data = nullptr;          // multifrontal top (jg_symbolic.hpp): task headers, task data
     int* top_wgmap = nullptr;                                  // workgroup map of the grouped launches

@@ -978,6 +978,10 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
     std::atomic<int> stream_state{0};                           // 1: h->stream exists, -1: its creation failed (the analysis thread creates it first)
     auto eng_work = [&] {
         if (hipSetDevice(h->device) != hipSuccess) { h->eng.error = "hipSetDevice failed on the analysis thread"; eng_rc = 2; stream_state = -1; return; }
+        // JG_STREAM_PRIORITY (probe, tools/r05_overlap_probe.py): the handle's stream at that priority (lower = more urgent; hipDeviceGetStreamPriorityRange)
+        if (const char* pr = getenv("JG_STREAM_PRIORITY")) {
+            if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, atoi(pr)) != hipSuccess) { h->eng.error = "jg_nr_create: stream creation failed"; eng_rc = 2; stream_state = -1; return; }
+        } else
         if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { h->eng.error = "jg_nr_create: stream creation failed"; eng_rc = 2; stream_state = -1; return; }
         stream_state = 1;
         eng_rc = h->eng.create((int)n, rp.data(), cl.data(), h->ld, (getenv("JG_NO_PREFACTOR") ? 1LL : 1LL | 4) | 1LL << 49, h->stream);
