@@ -603,6 +603,43 @@ __global__ void k_lanes_move(LaneSet s, double* tmp, const int* dest, const int*
     }
 }
 
+// The same move IN PLACE, one launch (round 5): dest is a permutation of the lanes (k_compact: swaps of a hole with a straggler; restore: every lane to its home), so a
+// workgroup that holds ALL lanes of a row reads what moves, waits for the values, meets at a barrier and writes them to their new lanes -- no staging area, half
+// the traffic and half the launches of the two-pass move (which remains for handles of more than LANES_INPLACE lanes).
+constexpr int LANES_INPLACE = 4096;
+__global__ __launch_bounds__(1024) void k_lanes_permute(LaneSet s, const int* dest, const int* flags, int ld) {
+    if (!flags[0]) return;
+    constexpr int NL = LANES_INPLACE / 1024;
+    const int a = blockIdx.z;
+    const int rows = s.rows[a], E = s.elem[a];
+    int b[NL], d[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) { b[k] = (int)threadIdx.x + k * 1024; d[k] = b[k] < ld ? dest[b[k]] : b[k]; }
+    if (E == 2) {
+        double2* x = (double2*)s.x[a];
+        for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+            double2 v[NL];
+#pragma unroll
+            for (int k = 0; k < NL; ++k) if (d[k] != b[k]) v[k] = x[(size_t)r * ld + b[k]];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the values are HERE before any lane of the row is overwritten
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < NL; ++k) if (d[k] != b[k]) x[(size_t)r * ld + d[k]] = v[k];
+        }
+        return;
+    }
+    double* x = s.x[a];
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+        double v[NL];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) if (d[k] != b[k]) v[k] = x[(size_t)r * ld + b[k]];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NL; ++k) if (d[k] != b[k]) x[(size_t)r * ld + d[k]] = v[k];
+    }
+}
+
 // [n][ld] batch-minor -> [batch][n] scenario-major, tiled through LDS so both sides stay coalesced
 __global__ void k_to_scenario_major(const double* src, double* dst, int n, int ld, int batch) {
     __shared__ double tile[32][33];
@@ -844,6 +881,11 @@ void launch_compact(jg_nr* h, int restore, bool report = false) {
         add(h->d_vm, h->n, 1); add(h->d_va, h->n, 1); add(h->d_p, h->n, 1); add(h->d_q, h->n, 1);
         if (h->mp > 0) { add(h->d_pdg, h->mp, 1); add(h->d_pdb, h->mp, 1); }
         add(h->d_inc, h->n, 2);                    // a finished scenario keeps ITS last increment (method.increment) wherever its lane goes
+        static const bool inplace_env = !(getenv("JG_LANES_INPLACE") && atoi(getenv("JG_LANES_INPLACE")) == 0);
+        if (h->ld <= LANES_INPLACE && inplace_env) {                      // one launch, in place (k_lanes_permute); JG_LANES_INPLACE=0: the two-pass move
+            hipLaunchKernelGGL(k_lanes_permute, dim3((unsigned)std::min(max_rows, 2048), 1, (unsigned)na), dim3((unsigned)std::min(1024, h->ld)), 0, h->stream, ls, h->d_dest, h->d_cflags, h->ld);
+            return;
+        }
         if ((size_t)off * sizeof(double) <= h->eng.factor_bytes()) {      // always, except for grids of a handful of buses
             const dim3 grid((unsigned)std::min(max_rows, 1024), gy.x, (unsigned)na);
             hipLaunchKernelGGL(k_lanes_move, grid, block, 0, h->stream, ls, tmp, h->d_dest, h->d_cflags, h->ld, 0);
