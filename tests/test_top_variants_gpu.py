@@ -207,3 +207,41 @@ def test_symmetric_top_kernel_against_the_mirrored_front(tmp_path, case, batch):
     assert np.array_equal(a["it"], b["it"]) and np.array_equal(a["st"], b["st"]) and np.all(a["st"] == 0)
     assert np.abs(a["vm"] - b["vm"]).max() <= 1e-10 and np.abs(a["va"] - b["va"]).max() <= 1e-10
     assert np.abs(a["obj"] - b["obj"]).max() <= 1e-9 * np.abs(b["obj"]).max()
+
+
+SCRIPT_COMPACT = r"""
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+sys.path.insert(0, {root!r} + "/tests")
+from conftest import load_case
+import juliagrid.jl_amd as jg
+s = jg.powerSystem(load_case({case!r}))
+base = jg.newtonRaphson(s)
+jg.powerFlow_(base, tolerance=1e-10)
+an = jg.contingencyAnalysis(s, jg.outageList(s, {batch}, seed=512))
+jg.contingency._push_voltage(an, base.voltage.magnitude.copy(), base.voltage.angle.copy())          # from the base case's solution: most outages need 3 iterations, some 2 or 4
+jg.powerFlow_(an, iteration=20, tolerance=1e-8)
+h = hashlib.sha256()
+for a in (np.asarray(an.method.iteration), np.asarray(an.status), np.asarray(an.voltage.magnitude), np.asarray(an.voltage.angle), np.asarray(an.increment)):
+    h.update(np.ascontiguousarray(a).tobytes())
+print("DIGEST", h.hexdigest(), int(np.sum(an.method.iteration)), int(np.max(an.method.iteration)) - int(np.min(an.method.iteration)))
+an.close()
+"""
+
+
+@pytest.mark.parametrize("case,batch", [("case_ACTIVSg10k", 200), ("case1354pegase", 512), ("case_ACTIVSg10k", 1100)])
+def test_lane_moves_in_place_give_the_bits_of_the_two_pass_move(case, batch):
+    """Compaction packs the still-active scenarios into the leading lanes.  Round 5 moves the lanes IN PLACE (k_lanes_permute: a workgroup holds every lane of a
+    row; one launch) instead of through a staging area and back (JG_LANES_INPLACE=0): same bits in every per-scenario array that travels -- state, last
+    increment, iteration count, status -- for batches of one, two and five workgroup-widths of lanes (1 100 scenarios: two lanes per thread)."""
+    def run(**env):
+        e = dict(os.environ)
+        e.update({k: str(v) for k, v in env.items()})
+        out = subprocess.run([sys.executable, "-c", SCRIPT_COMPACT.format(root=ROOT, case=case, batch=batch)], env=e, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [l for l in out.stdout.splitlines() if l.startswith("DIGEST")][-1].split()
+        return line[1], int(line[2]), int(line[3])
+    ref, iters, spread = run()
+    assert iters >= 2 * batch and spread >= 1, "scenarios finish after different iteration counts: lanes move"
+    assert run(JG_LANES_INPLACE=0)[0] == ref
