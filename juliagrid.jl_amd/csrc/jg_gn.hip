@@ -867,21 +867,71 @@ void launch_update(jg_gn* h, const int* active) {
     hipLaunchKernelGGL(k_gn_update, dim3(h->nchunk, h->ld / 64), dim3(64, 4), 0, h->stream, h->d_inc, h->d_vm, h->d_va, active, h->n, h->ld);
 }
 
-int put_rows(jg_gn* h, double* dst, const double* src, int64_t stride, int rows) {
-    std::vector<double> t((size_t)rows * h->ld, 0.0);
-    for (int b = 0; b < h->ld; ++b) {
-        const double* s = src + (size_t)(b < h->batch ? b : h->batch - 1) * (size_t)stride;
-        for (int i = 0; i < rows; ++i) t[(size_t)i * h->ld + b] = s[i];
+// host [batch][rows] (stride = rows) or ONE [rows] for every scenario (stride 0) -> device [rows][ld]; lanes beyond the batch repeat the last scenario.
+// The rows go up as the host holds them and a kernel spreads them over the lanes (round 5: the host-side transposition that used to happen here wrote
+// 96 723 x 512 doubles with a stride of 4 KB and uploaded 396 MB even for one shared column -- 0.95 of the 1.4 s a Gauss-Newton handle of config 4 took to build).
+__global__ __launch_bounds__(512) void k_gn_spread_rows(const double* src, double* dst, int rows, int ld, int batch, int src_rows) {
+    __shared__ double tile[64][65];
+    const int i0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+    for (int r = threadIdx.y; r < 64; r += blockDim.y) {
+        const int b = min(min(b0 + r, batch - 1), src_rows - 1), i = i0 + threadIdx.x;
+        tile[r][threadIdx.x] = i < rows ? src[(size_t)b * rows + i] : 0.0;
     }
-    GN_HIP(jg::sync_copy(dst, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    __syncthreads();
+    for (int r = threadIdx.y; r < 64; r += blockDim.y) {
+        const int i = i0 + r, b = b0 + threadIdx.x;
+        if (i < rows && b < ld) dst[(size_t)i * ld + b] = tile[threadIdx.x][r];
+    }
+}
+// device [rows][ld] -> device [batch][rows] (what the host receives)
+__global__ __launch_bounds__(512) void k_gn_collect_rows(const double* src, double* dst, int rows, int ld, int batch) {
+    __shared__ double tile[64][65];
+    const int i0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+    for (int r = threadIdx.y; r < 64; r += blockDim.y) {
+        const int i = i0 + r, b = b0 + threadIdx.x;
+        tile[r][threadIdx.x] = (i < rows && b < ld) ? src[(size_t)i * ld + b] : 0.0;
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 64; r += blockDim.y) {
+        const int b = b0 + r, i = i0 + threadIdx.x;
+        if (b < batch && i < rows) dst[(size_t)b * rows + i] = tile[threadIdx.x][r];
+    }
+}
+
+int put_rows(jg_gn* h, double* dst, const double* src, int64_t stride, int rows) {
+    if (stride != 0 && stride != rows) {                         // a caller's own row pitch: the general (slow) way
+        std::vector<double> t((size_t)rows * h->ld, 0.0);
+        for (int b = 0; b < h->ld; ++b) {
+            const double* s = src + (size_t)(b < h->batch ? b : h->batch - 1) * (size_t)stride;
+            for (int i = 0; i < rows; ++i) t[(size_t)i * h->ld + b] = s[i];
+        }
+        GN_HIP(jg::sync_copy(dst, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        return 0;
+    }
+    const int src_rows = stride == 0 ? 1 : h->batch;
+    const size_t bytes = (size_t)src_rows * rows * sizeof(double);
+    double* stage = nullptr;
+    GN_HIP(hipMalloc((void**)&stage, bytes));
+    hipError_t e = jg::sync_copy(stage, src, bytes, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_gn_spread_rows, dim3((rows + 63) / 64, h->ld / 64), dim3(64, 8), 0, h->stream, (const double*)stage, dst, rows, h->ld, h->batch, src_rows);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    }
+    hipFree(stage);
+    GN_HIP(e);
     return 0;
 }
 
 int get_rows(jg_gn* h, const double* src, double* dst, size_t rows) {
-    std::vector<double> t(rows * h->ld);
-    GN_HIP(jg::sync_copy(t.data(), src, t.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    for (int b = 0; b < h->batch; ++b)
-        for (size_t r = 0; r < rows; ++r) dst[(size_t)b * rows + r] = t[r * h->ld + b];
+    const size_t bytes = (size_t)h->batch * rows * sizeof(double);
+    double* stage = nullptr;
+    GN_HIP(hipMalloc((void**)&stage, bytes));
+    hipLaunchKernelGGL(k_gn_collect_rows, dim3((unsigned)((rows + 63) / 64), h->ld / 64), dim3(64, 8), 0, h->stream, src, stage, (int)rows, h->ld, h->batch);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = jg::sync_copy(dst, stage, bytes, hipMemcpyDeviceToHost, h->stream);
+    hipFree(stage);
+    GN_HIP(e);
     return 0;
 }
 

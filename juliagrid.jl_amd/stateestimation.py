@@ -101,16 +101,25 @@ def _wls_values(mon: Measurement, devs, dev_row, m, z1, v1, s1, z2, v2, s2):
     status = np.zeros(m, dtype=np.int8)
     woff = []
     a, p = mon.ammeter, mon.pmu
+    # the legacy meters (one row each) as whole arrays -- 90 000 of the 92 000 devices of config 4; the formulas of the per-device branch below, element by element
+    fam_of = np.array([f for f, _ in devs])
+    legacy = np.nonzero(fam_of != "p")[0]
+    if legacy.size:
+        rows = np.asarray(dev_row, dtype=np.int64)[legacy]
+        sq = np.zeros(legacy.size, dtype=bool)
+        amm = fam_of[legacy] == "a"
+        if amm.any():
+            sq[amm] = np.asarray(a.layout.square, dtype=bool)[np.array([devs[d][1] for d in legacy[amm]], dtype=np.int64)]
+        zz, var, st = z1[..., legacy], v1[legacy], s1[legacy]
+        status[rows] = st
+        mean[..., rows] = st * np.where(sq, zz ** 2, zz)                       # :138, :149, :163, :177
+        with np.errstate(divide="ignore"):
+            wdiag[..., rows] = 1.0 / np.where(sq, 4.0 * zz ** 2 * var, var)    # varianceSquare
     for d, (fam, i) in enumerate(devs):
+        if fam != "p":
+            continue
         r = int(dev_row[d])
         zz, var, st = z1[..., d], v1[d], int(s1[d])
-        if fam != "p":
-            sq = fam == "a" and a.layout.square[i]
-            status[r] = st
-            mean[..., r] = st * (zz ** 2 if sq else zz)                        # :138, :149, :163, :177
-            with np.errstate(divide="ignore"):
-                wdiag[..., r] = 1.0 / (4.0 * zz ** 2 * var if sq else var)     # varianceSquare
-            continue
         za, vara, sta = z2[..., d], v2[d], int(s2[d])
         if p.layout.polar[i]:
             sq = p.layout.square[i] and not p.layout.bus[i]
