@@ -926,8 +926,13 @@ constexpr int TOP_THREADS = 320;        // 16 x 16 bulk threads + the pivot wave
 // column q, so nothing left of it moves: the diagonal blocks, Lh and the in-task multipliers U(i,q) stay what they are).  After the
 // last step a pivot row holds J(i, ext) and y'_i; the rows leave for their own region behind the factor entries.  Same step, same
 // barrier count, no extra arithmetic issued.
-template <int CLS, bool PW, bool FUSE = false, bool JORDAN = false>
-__global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves_per_eu(CLS == 4 || (FUSE && CLS == 3) ? 2 : 4))) void k_fact_top(TopArgs a) {
+// GL = 5 (round 5, opt-in experiment JG_TOP_G32=1): the front on a 32 x 32 thread grid -- 1 024 threads, CLS = 2 covers every front (<= 63 rows + the right-hand side) with FOUR
+// blocks per thread instead of nine or sixteen; block for block the same operations in the same order => the same bits.  No pivot wave (1 024 threads is the workgroup limit): the
+// owner of the next diagonal block factorises it.  Measured slower than the 16 x 16 grid even for lone workgroups (Engine::factor has the numbers).
+template <int CLS, bool PW, bool FUSE = false, bool JORDAN = false, int GL = 4>
+__global__ __launch_bounds__(PW ? TOP_THREADS : (1 << (2 * GL))) __attribute__((amdgpu_waves_per_eu(GL == 5 ? 4 : (CLS == 4 || (FUSE && CLS == 3) ? 2 : 4)))) void k_fact_top(TopArgs a) {
+    constexpr int G = 1 << GL;
+    static_assert(GL == 4 || (GL == 5 && CLS == 2 && !PW && !FUSE), "the 32 x 32 grid: CLS = 2, no pivot wave, one pivot per barrier");
     static_assert(!(PW && FUSE), "the fused step has no pivot wave");
     static_assert(!(JORDAN && FUSE), "the fused step keeps plain rows");
     __shared__ __attribute__((aligned(16))) double Dbuf[2][4];         // factorised pivot of the current / next step
@@ -944,9 +949,9 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
     const int bb = grp * 64 + (x - ti * a.lpg);
     if (bb >= a.lanes) return;                                   // padding lanes of the last group: no scenario, no work
     const int tid = threadIdx.x;
-    const bool pivot_wave = PW && tid >= 256;
+    const bool pivot_wave = PW && tid >= G * G;
     const int lane = tid & 63;
-    const int gi = (tid >> 4) & 15, gj = tid & 15;               // bulk thread: row / column class on the 16 x 16 grid
+    const int gi = (tid >> GL) & (G - 1), gj = tid & (G - 1);     // bulk thread: row / column class on the G x G grid (16 x 16; 32 x 32 for lone workgroups)
     const bool prof = a.prof && tid == 0;                        // every scenario: the host prints scenario 0 and the spread over the batch
     long long* pt = a.prof + ((size_t)(a.task_begin + ti) * a.ld + bb) * 8;
     if (prof) {
@@ -978,7 +983,7 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
         for (int r = 0; r < CLS; ++r)
 #pragma unroll
             for (int c = 0; c < CLS; ++c) {
-                const int i = r * 16 + gi, j = c * 16 + gj;
+                const int i = r * G + gi, j = c * G + gj;
                 code[r][c] = (i < f && j < fprime) ? td[i * fprime + j] : -1;
             }
 #pragma unroll
@@ -996,7 +1001,7 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
                 // what the guard compares a pivot with: the block as it entered the task -- a pivot that the children's update matrices (or the
                 // task's own steps) cancel to rounding level is the signature of an island whose root sits in the top (taken after
                 // the extend-add the reference scale was the cancelled value itself)
-                if (r == c && gi == gj && r * 16 + gi < m) *(double2*)(Dref + (size_t)(r * 16 + gi) * 2) = row_max(v);
+                if (r == c && gi == gj && r * G + gi < m) *(double2*)(Dref + (size_t)(r * G + gi) * 2) = row_max(v);
             }
         if (prof) pt[1] = wall_clock64();
         // ---- extend-add: every thread pulls what the children left for its blocks (child order fixed => deterministic)
@@ -1007,9 +1012,9 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
             const double* C = stk + coff;
             int ri[CLS], cj[CLS];
 #pragma unroll
-            for (int r = 0; r < CLS; ++r) { const int i = r * 16 + gi; ri[r] = i < f ? inv[i] : -1; }
+            for (int r = 0; r < CLS; ++r) { const int i = r * G + gi; ri[r] = i < f ? inv[i] : -1; }
 #pragma unroll
-            for (int c = 0; c < CLS; ++c) { const int j = c * 16 + gj; cj[c] = j < fprime ? inv[j] : -1; }
+            for (int c = 0; c < CLS; ++c) { const int j = c * G + gj; cj[c] = j < fprime ? inv[j] : -1; }
 #pragma unroll
             for (int r = 0; r < CLS; ++r)
 #pragma unroll
@@ -1030,7 +1035,7 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
         for (int r = 0; r < CLS; ++r)
 #pragma unroll
             for (int c = 0; c < CLS; ++c) {
-                const int i = r * 16 + gi, j = c * 16 + gj;
+                const int i = r * G + gi, j = c * G + gj;
                 if (i == 0) lds_set(Ubuf[0], j, j > 0 ? T[r][c] : zero);
                 if (j == 0) lds_set(Lbuf[0], i, i > 0 ? T[r][c] : zero);
                 if (i == j && i < m) lds_set(Dini, i, T[r][c]);
@@ -1075,24 +1080,24 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
             blk_sub(S1, Lq1q, zq1);
             int bad1 = 0;
             const Blk D1 = factor_diag(S1, bad1, *(const double2*)(Dref + (size_t)q1 * 2));
-            const int rq1 = q1 >> 4, tq1 = q1 & 15;
+            const int rq1 = q1 >> GL, tq1 = q1 & (G - 1);
             if (gi == tq1 && gj == tq1) bad |= bad1;             // reported once, by the owner of the block
             const bool sw1 = D1.v10 > 2.0;
             const double dl1 = sw1 ? D1.v10 - 4.0 : D1.v10;
             Blk Lq[CLS], L1[CLS];
 #pragma unroll
             for (int r = 0; r < CLS; ++r) {
-                Lq[r] = lds_get(Lbuf[cur], r * 16 + gi);
-                L1[r] = lds_get(L1buf[cur], r * 16 + gi);
+                Lq[r] = lds_get(Lbuf[cur], r * G + gi);
+                L1[r] = lds_get(L1buf[cur], r * G + gi);
                 blk_sub(L1[r], Lq[r], zq1);
-                if (r * 16 + gi <= q1) L1[r] = zero_blk();       // rows up to q + 1 are finished for pivot q + 1
+                if (r * G + gi <= q1) L1[r] = zero_blk();       // rows up to q + 1 are finished for pivot q + 1
             }
 #pragma unroll
             for (int c = 0; c < CLS; ++c) {
-                const Blk z = zcol(Ubuf[cur], c * 16 + gj);
-                Blk U1 = lds_get(U1buf[cur], c * 16 + gj);
+                const Blk z = zcol(Ubuf[cur], c * G + gj);
+                Blk U1 = lds_get(U1buf[cur], c * G + gj);
                 blk_sub(U1, Lq1q, z);
-                if (c * 16 + gj <= q1) U1 = zero_blk();
+                if (c * G + gj <= q1) U1 = zero_blk();
                 const double a0x = sw1 ? U1.v10 : U1.v00, a0y = sw1 ? U1.v11 : U1.v01, a1x = sw1 ? U1.v00 : U1.v10, a1y = sw1 ? U1.v01 : U1.v11;
                 Blk z1;                                          // z_{q+1}(c) = D(q + 1)^-1 U(q + 1, c)
                 z1.v10 = (a1x - dl1 * a0x) * D1.v11; z1.v00 = (a0x - D1.v01 * z1.v10) * D1.v00;
@@ -1111,7 +1116,7 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
                 for (int w = 0; w < 2; ++w) {
                     const int p = q + 2 + w;
                     if (p < m) {
-                        const int rp = p >> 4, tp = p & 15;
+                        const int rp = p >> GL, tp = p & (G - 1);
                         double* ub = w ? U1buf[nxt] : Ubuf[nxt];
                         double* lb = w ? L1buf[nxt] : Lbuf[nxt];
                         if (gi == tp && gj == tp) {
@@ -1131,9 +1136,9 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
                                 if (r == rp) {
 #pragma unroll
                                     for (int c = 0; c < CLS; ++c) {
-                                        if (c < rp) lds_set(ub, c * 16 + gj, zero_blk());
-                                        else if (c > rp) lds_set(ub, c * 16 + gj, T[r][c]);
-                                        else lds_set(ub, c * 16 + gj, gj > tp ? T[r][c] : zero_blk());
+                                        if (c < rp) lds_set(ub, c * G + gj, zero_blk());
+                                        else if (c > rp) lds_set(ub, c * G + gj, T[r][c]);
+                                        else lds_set(ub, c * G + gj, gj > tp ? T[r][c] : zero_blk());
                                     }
                                 }
                         }
@@ -1143,9 +1148,9 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
                                 if (c == rp) {
 #pragma unroll
                                     for (int r = 0; r < CLS; ++r) {
-                                        if (r < rp) lds_set(lb, r * 16 + gi, zero_blk());
-                                        else if (r > rp) lds_set(lb, r * 16 + gi, T[r][c]);
-                                        else lds_set(lb, r * 16 + gi, gi > tp ? T[r][c] : zero_blk());
+                                        if (r < rp) lds_set(lb, r * G + gi, zero_blk());
+                                        else if (r > rp) lds_set(lb, r * G + gi, T[r][c]);
+                                        else lds_set(lb, r * G + gi, gi > tp ? T[r][c] : zero_blk());
                                     }
                                 }
                         }
@@ -1176,17 +1181,17 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
         if (!pivot_wave) {
             Blk Lq[CLS];
 #pragma unroll
-            for (int r = 0; r < CLS; ++r) Lq[r] = lds_get(Lbuf[cur], r * 16 + gi);
+            for (int r = 0; r < CLS; ++r) Lq[r] = lds_get(Lbuf[cur], r * G + gi);
 #pragma unroll
             for (int c = 0; c < CLS; ++c) {
-                const Blk z = JG_PROBE_TOP == 3 ? lds_get(Ubuf[cur], c * 16 + gj) : zcol(Ubuf[cur], c * 16 + gj);
+                const Blk z = JG_PROBE_TOP == 3 ? lds_get(Ubuf[cur], c * G + gj) : zcol(Ubuf[cur], c * G + gj);
 #pragma unroll
                 for (int r = 0; r < CLS; ++r) if (JG_PROBE_TOP != 2 || (r == 0 && c == 0)) blk_sub(T[r][c], Lq[r], z);
             }
             if (q + 1 < m && JG_PROBE_TOP != 1) {                     // the next pivot row / column leave their owners
                 // classes before the pivot's are finished (zeros), classes after it go out as they are (both uniform); only the
                 // pivot's own class needs a per-lane select
-                const int rq = (q + 1) >> 4, tq = (q + 1) & 15;
+                const int rq = (q + 1) >> GL, tq = (q + 1) & (G - 1);
                 if (!PW && gi == tq && gj == tq) {               // the owner of S(q+1, q+1): final now, factorised here
                     const double2 ref = *(const double2*)(Dref + (size_t)(q + 1) * 2);
 #pragma unroll
@@ -1203,9 +1208,9 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
                         if (r == rq) {
 #pragma unroll
                             for (int c = 0; c < CLS; ++c) {
-                                if (c < rq) lds_set(Ubuf[nxt], c * 16 + gj, zero_blk());
-                                else if (c > rq) lds_set(Ubuf[nxt], c * 16 + gj, T[r][c]);
-                                else lds_set(Ubuf[nxt], c * 16 + gj, gj > tq ? T[r][c] : zero_blk());
+                                if (c < rq) lds_set(Ubuf[nxt], c * G + gj, zero_blk());
+                                else if (c > rq) lds_set(Ubuf[nxt], c * G + gj, T[r][c]);
+                                else lds_set(Ubuf[nxt], c * G + gj, gj > tq ? T[r][c] : zero_blk());
                             }
                         }
                 }
@@ -1215,9 +1220,9 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
                         if (c == rq) {
 #pragma unroll
                             for (int r = 0; r < CLS; ++r) {
-                                if (r < rq) lds_set(Lbuf[nxt], r * 16 + gi, JORDAN ? T[r][c] : zero_blk());     // JORDAN: the rows above lose column q + 1 too
-                                else if (r > rq) lds_set(Lbuf[nxt], r * 16 + gi, T[r][c]);
-                                else lds_set(Lbuf[nxt], r * 16 + gi, (JORDAN ? gi != tq : gi > tq) ? T[r][c] : zero_blk());
+                                if (r < rq) lds_set(Lbuf[nxt], r * G + gi, JORDAN ? T[r][c] : zero_blk());     // JORDAN: the rows above lose column q + 1 too
+                                else if (r > rq) lds_set(Lbuf[nxt], r * G + gi, T[r][c]);
+                                else lds_set(Lbuf[nxt], r * G + gi, (JORDAN ? gi != tq : gi > tq) ? T[r][c] : zero_blk());
                             }
                         }
                 }
@@ -1245,7 +1250,7 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
         for (int r = 0; r < CLS; ++r)
 #pragma unroll
             for (int c = 0; c < CLS; ++c) {
-                const int i = r * 16 + gi, j = c * 16 + gj;
+                const int i = r * G + gi, j = c * G + gj;
                 const int cd = (i < f && j < fprime) ? td[i * fprime + j] : -1;
                 const Blk& v = T[r][c];
                 if (JORDAN && i < m && j >= m && j < f) store_blk(a.X, (size_t)(jb + i * e + (j - m)), b, ld, v.v00, v.v01, v.v10, v.v11);
@@ -2169,6 +2174,16 @@ int Engine::factor(hipStream_t st, const double* A, const double* rhs, const Gro
             // workgroup of another batch, with 5-wave ones it has not: +2-3 % on the 512 x 3 pipeline, -0.6 % on a lone factorisation; same bits)
             const bool pw = pw_env >= 0 ? pw_env != 0 : (!shared && wgs <= 256 * (L.cls == 4 ? 1 : (L.cls == 3 ? 2 : 3)));
             static const int fuse_env = getenv("JG_TOP_FUSE") ? atoi(getenv("JG_TOP_FUSE")) : 0;
+            // round 5, OPT-IN (JG_TOP_G32=1): the front over 1 024 threads -- four blocks per thread whatever the class, a third of the instructions per wave and step
+            // (k_fact_top<2, false, false, ., 5>; same bits).  MEASURED SLOWER even for the lone workgroups of a single instance (profiles/r05_g32_ab.txt: factorisation 0.242 ->
+            // 0.258 ms on the 10k-bus grid, 0.079 -> 0.102 on case1354pegase): sixteen waves read four times the pivot row / column bytes from the CU's one LDS port (128 KB per
+            // step against 49 KB) and meet at a 16-wave barrier.  With the one- / two-wave kernels (JG_TOPW) this brackets the 16 x 16 grid from both sides.
+            static const int g32_env = getenv("JG_TOP_G32") ? atoi(getenv("JG_TOP_G32")) : 0;
+            if (g32_env > 0 && !(fuse_env && !jordan) && pw_env < 0) {
+                if (jordan) hipLaunchKernelGGL((k_fact_top<2, false, false, true, 5>), grid, dim3(1024), 0, st, t);
+                else hipLaunchKernelGGL((k_fact_top<2, false, false, false, 5>), grid, dim3(1024), 0, st, t);
+                continue;
+            }
             if (jordan) {                                        // Jordan rows (jg_symbolic.hpp); the plain sweep's tables would read garbage after this
                 if (pw) {
                     if (L.cls == 2) hipLaunchKernelGGL((k_fact_top<2, true, false, true>), grid, dim3(TOP_THREADS), 0, st, t);

@@ -51,6 +51,7 @@ def test_top_kernel_variants_and_level0_routes_give_the_same_bits(case, batch):
     assert _run(case, batch, JG_TOP_FUSE=1)[0] == ref                # two pivots per barrier: every thread redoes what the owners of the
                                                                      # second pivot's row / column / block do, operation for operation
     assert _run(case, batch, JG_TOPW=3)[0] == ref                    # round 5: the one- / two-wave kernels (opt-in) for the front classes they exist for
+    assert _run(case, batch, JG_TOP_G32=1)[0] == ref                 # round 5: every front on a 32 x 32 thread grid (opt-in)
 
 
 @pytest.mark.parametrize("case,batch", [("case_ACTIVSg10k", 512), ("case_ACTIVSg10k", 1), ("case9241synth", 256)])
