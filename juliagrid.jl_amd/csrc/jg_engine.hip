@@ -907,6 +907,9 @@ __global__ __launch_bounds__(64 * TASK_WAVES, 4) void k_fact_task(FactArgs a) {
 #ifndef JG_PROBE_TOP
 #define JG_PROBE_TOP 0
 #endif
+#ifndef JG_PROBE_STEP
+#define JG_PROBE_STEP 0                 // TIMING PROBE (-DJG_PROBE_STEP=1 with JG_TOP_PROFILE=1): shader-clock stamps inside the pivot step of thread 0 -- tools/r05_step_probe.sh
+#endif
 constexpr int TOP_THREADS = 320;        // 16 x 16 bulk threads + the pivot wave
 
 // PW = false: no pivot wave (256 threads).  The thread that owns the diagonal block of the NEXT pivot factorises it right after its
@@ -1163,7 +1166,15 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : (1 << (2 * GL))) __attribute__((
     // ---- pivot steps.  Straight-line bulk code: the pivot is the same block for every lane, so the row swap of its 2x2 LU is
     // folded into the ADDRESS of the two halves of U(q, c) (scalar), finished blocks see zeros (no predicates, no skipping).
     // (after fused steps: the one pivot an odd chain has left; its row / column / block sit in the buffers of the pair it would have led)
+#if JG_PROBE_STEP
+    long long ps[5] = {0, 0, 0, 0, 0};                           // read | update | publish | barrier (clocks of thread 0's wave, summed over the steps)
+#define JG_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 0" ::: "memory"); const long long now_ = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); if (k >= 0) ps[k] += now_ - last_; last_ = now_; } while (0)
+    long long last_ = 0;
+#else
+#define JG_STAMP(k) do { } while (0)
+#endif
     for (int qv = q_done; qv < m; ++qv) {
+        JG_STAMP(-1);
         const int q = uniform(qv);                               // the step number is wave-uniform: which row / column class publishes, the
         const int cur = FUSE ? (q >> 1) & 1 : q & 1, nxt = cur ^ 1;   // LDS buffer in use and the lane of the next pivot are scalar decisions
         Blk D = (JG_PROBE_TOP == 3 && !pivot_wave) ? Blk{1.0, 0.0, 0.0, 1.0} : lds_get(Dbuf[cur], 0);     // (probe 3: what a published D^-1 U(q, .) would save)
@@ -1182,16 +1193,42 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : (1 << (2 * GL))) __attribute__((
             Blk Lq[CLS];
 #pragma unroll
             for (int r = 0; r < CLS; ++r) Lq[r] = lds_get(Lbuf[cur], r * G + gi);
+#if JG_PROBE_STEP
+            Blk Uq[CLS];                                         // (probe: the row is read before the stamp, the solve z = D^-1 U(q, .) counts as update)
+#pragma unroll
+            for (int c = 0; c < CLS; ++c) Uq[c] = lds_get(Ubuf[cur], c * G + gj);
+            JG_STAMP(0);
+#endif
 #pragma unroll
             for (int c = 0; c < CLS; ++c) {
+#if JG_PROBE_STEP
+                Blk z;                                           // zcol on the registers read above
+                {
+                    const double a0x = sw ? Uq[c].v10 : Uq[c].v00, a0y = sw ? Uq[c].v11 : Uq[c].v01, a1x = sw ? Uq[c].v00 : Uq[c].v10, a1y = sw ? Uq[c].v01 : Uq[c].v11;
+                    z.v10 = (a1x - dl * a0x) * D.v11; z.v00 = (a0x - D.v01 * z.v10) * D.v00;
+                    z.v11 = (a1y - dl * a0y) * D.v11; z.v01 = (a0y - D.v01 * z.v11) * D.v00;
+                }
+#else
                 const Blk z = JG_PROBE_TOP == 3 ? lds_get(Ubuf[cur], c * G + gj) : zcol(Ubuf[cur], c * G + gj);
+#endif
 #pragma unroll
                 for (int r = 0; r < CLS; ++r) if (JG_PROBE_TOP != 2 || (r == 0 && c == 0)) blk_sub(T[r][c], Lq[r], z);
             }
+#if JG_PROBE_STEP
+            { double sink = 0.0;
+#pragma unroll
+              for (int r = 0; r < CLS; ++r)
+#pragma unroll
+                  for (int c = 0; c < CLS; ++c) sink += T[r][c].v11;
+              asm volatile("" :: "v"(sink)); }                   // the updates have left the pipe
+            JG_STAMP(1);
+#endif
             if (q + 1 < m && JG_PROBE_TOP != 1) {                     // the next pivot row / column leave their owners
                 // classes before the pivot's are finished (zeros), classes after it go out as they are (both uniform); only the
                 // pivot's own class needs a per-lane select
                 const int rq = (q + 1) >> GL, tq = (q + 1) & (G - 1);
+                // (the owner's chain of ~55 dependent instructions BEFORE the row and the column leave: the other order -- their LDS writes travelling while the chain runs --
+                // measured 0.7 % slower at 512 scenarios, profiles/r05_reorder_ab.txt)
                 if (!PW && gi == tq && gj == tq) {               // the owner of S(q+1, q+1): final now, factorised here
                     const double2 ref = *(const double2*)(Dref + (size_t)(q + 1) * 2);
 #pragma unroll
@@ -1238,8 +1275,13 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : (1 << (2 * GL))) __attribute__((
             const Blk dn = factor_diag(Blk{bc(mydiag.v00), bc(mydiag.v01), bc(mydiag.v10), bc(mydiag.v11)}, bad, double2{bc(myref_x), bc(myref_y)});
             if (lane == q + 1) { mydiag = dn; lds_set(Dbuf[nxt], 0, dn); }
         }
+        JG_STAMP(2);
         __syncthreads();
+        JG_STAMP(3);
     }
+#if JG_PROBE_STEP
+    if (prof) { pt[6] = ps[0] << 32 | (ps[1] & 0xffffffffll); pt[7] = ps[2] << 32 | (ps[3] & 0xffffffffll); }
+#endif
     if (prof) pt[3] = wall_clock64();
     // ---- store
     if (!pivot_wave) {
@@ -2084,6 +2126,7 @@ void Engine::destroy() {
                     fprintf(stderr, " | %zu %6.2f  %6.2f / %6.2f / %6.2f  %7.2f  %d %d", st0.size(), (s1 - s0) * 0.01, tot.front() * 0.01, tot[tot.size() / 2] * 0.01, tot.back() * 0.01,
                             (e1 - s0) * 0.01, ncu, most);
                 }
+                if (JG_PROBE_STEP && p[6]) fprintf(stderr, " | step clocks: read %lld update %lld publish %lld barrier %lld", (p[6] >> 32) / h.w[0], (p[6] & 0xffffffffll) / h.w[0], (p[7] >> 32) / h.w[0], (p[7] & 0xffffffffll) / h.w[0]);
                 fprintf(stderr, "\n");
             }
         }
