@@ -107,11 +107,14 @@ __device__ __forceinline__ void store_vec(double* base, size_t item, size_t b, s
 // wave-uniform (it lands in a scalar register pair); the caller waits with an explicit s_waitcnt tied to the destinations.
 typedef double d2v __attribute__((ext_vector_type(2)));
 struct BlkV { d2v r0, r1; };
+#ifndef JG_LOAD_POLICY
+#define JG_LOAD_POLICY ""               // probe builds: -DJG_LOAD_POLICY='" nt"' (streaming), '" sc1"', ...
+#endif
 __device__ __forceinline__ void gload16(d2v& dst, const void* base, unsigned off) {
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory");   // "memory": the compiler must not move its stores across (the waits count them)
+    asm volatile("global_load_dwordx4 %0, %1, %2" JG_LOAD_POLICY : "=v"(dst) : "v"(off), "s"(base) : "memory");   // "memory": the compiler must not move its stores across (the waits count them)
 }
 __device__ __forceinline__ void gload8(double& dst, const void* base, unsigned off) {
-    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory");
+    asm volatile("global_load_dwordx2 %0, %1, %2" JG_LOAD_POLICY : "=v"(dst) : "v"(off), "s"(base) : "memory");
 }
 
 // A diagonal block whose eliminated form is smaller than PIVOT_EPS x (largest entry ITS ROW of the block started from) marks the
