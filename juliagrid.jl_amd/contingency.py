@@ -327,29 +327,36 @@ class ContingencyPipeline:
             pthread.start()
         for t in threads:
             t.start()
-        for j in range(nj):
-            main_done[j].wait()
-            if not errors and pool_done[j] is not None:
-                if j == nj - 1 or all(main_done[i].is_set() for i in range(j, nj)):
-                    flush_filling()                               # nobody is left to fill the pool
-                while not pool_done[j].wait(0.05):
-                    if errors:
-                        break
-                    if all(ev.is_set() for ev in main_done):
-                        flush_filling()
+        try:
+            for j in range(nj):
+                main_done[j].wait()
+                if not errors and pool_done[j] is not None:
+                    if j == nj - 1 or all(main_done[i].is_set() for i in range(j, nj)):
+                        flush_filling()                           # nobody is left to fill the pool
+                    while not pool_done[j].wait(0.05):
+                        if errors:
+                            break
+                        if all(ev.is_set() for ev in main_done):
+                            flush_filling()
+                if errors:
+                    break
+                if on_done is not None:
+                    on_done(j, self.handles[j % nh])
+                delivered[j].set()
+                released[j].set()
+        except BaseException as e:                                 # the caller's own on_done failed: the workers must not wait for deliveries that never come
+            errors.insert(0, e)
+        finally:
             if errors:
-                for ev in released + delivered:
+                for ev in released + delivered + [x for x in pool_done if x is not None]:
                     ev.set()
-                break
-            if on_done is not None:
-                on_done(j, self.handles[j % nh])
-            delivered[j].set()
-            released[j].set()
-        for t in threads:
-            t.join()
-        if pthread:
-            flush_q.put(None)
-            pthread.join()
+                for p in self.pools:
+                    p.idle.set()
+            for t in threads:
+                t.join()
+            if pthread:
+                flush_q.put(None)
+                pthread.join()
         if errors:
             raise errors[0]
         return results

@@ -91,17 +91,22 @@ class MonteCarloPipeline:
         threads = [threading.Thread(target=worker, args=(k,), daemon=True) for k in range(nh)]
         for t in threads:
             t.start()
-        for j in range(nj):
-            done[j].wait()
+        try:
+            for j in range(nj):
+                done[j].wait()
+                if errors:
+                    break
+                if on_done is not None:
+                    on_done(j, self.handles[j % nh])
+                delivered[j].set()
+        except BaseException as e:                                 # the caller's own on_done failed: the workers must not wait for deliveries that never come
+            errors.insert(0, e)
+        finally:
             if errors:
                 for ev in delivered:
                     ev.set()
-                break
-            if on_done is not None:
-                on_done(j, self.handles[j % nh])
-            delivered[j].set()
-        for t in threads:
-            t.join()
+            for t in threads:
+                t.join()
         if errors:
             raise errors[0]
         return results

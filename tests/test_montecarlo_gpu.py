@@ -204,3 +204,29 @@ def test_device_noise_is_standard_normal_and_the_estimates_are_consistent(jg):
     obj = an.objectiveDevice()
     assert abs(obj.mean() - dof) < 5.0 * np.sqrt(2.0 * dof / B), (obj.mean(), dof)
     an.close()
+
+
+def test_a_failing_on_done_surfaces_and_leaves_no_worker_waiting(jg):
+    """The caller's callback raises in the middle of a Monte-Carlo run: run() re-raises that error once its workers have ended, and works afterwards."""
+    import threading
+    s, mon = _config4_like(jg, "case118")
+    pipe = jg.MonteCarloPipeline(mon, 32, inflight=2)
+    box = {}
+
+    def boom(j, h):
+        if j == 1:
+            raise RuntimeError("caller failed on job 1")
+
+    def go():
+        try:
+            pipe.run(list(range(6)), on_done=boom)
+        except BaseException as e:
+            box["e"] = e
+    t = threading.Thread(target=go, daemon=True)
+    t.start()
+    t.join(120)
+    assert not t.is_alive(), "run() hangs after a failing on_done"
+    assert isinstance(box.get("e"), RuntimeError) and "job 1" in str(box["e"])
+    res = pipe.run([7, 8])
+    assert all(int((st == 0).sum()) == 32 for _, st in res)
+    pipe.close()

@@ -208,3 +208,37 @@ def test_monte_carlo_injection_jobs_through_the_pipeline(jg, oracle):
     vm, va = o.voltage()
     assert np.abs(ref.voltage.magnitude[5] - vm).max() < 1e-8 and np.abs(ref.voltage.angle[5] - va).max() < 1e-8
     ref.close()
+
+
+def test_a_failing_on_done_surfaces_and_leaves_no_worker_waiting(jg):
+    """The caller's own callback raises in the middle of a run: run() re-raises THAT error after its workers have ended (none of them may keep waiting
+    for a delivery that never comes), and the pipeline is usable afterwards."""
+    import threading
+    s = jg.powerSystem(load_case("case118"))
+    pipe = jg.ContingencyPipeline(s, 64, inflight=3)
+    labels = [int(x) for x in jg.outageList(s, 64 * 6, seed=5)]
+    jobs = [labels[i:i + 64] for i in range(0, len(labels), 64)]
+    before = threading.active_count()
+
+    def boom(j, h):
+        if j == 2:
+            raise RuntimeError("caller failed on job 2")
+    box = {}
+    t = threading.Thread(target=lambda: box.setdefault("e", _raises(lambda: pipe.run(jobs, on_done=boom))), daemon=True)
+    t.start()
+    t.join(120)
+    assert not t.is_alive(), "run() hangs after a failing on_done"
+    assert isinstance(box["e"], RuntimeError) and "job 2" in str(box["e"])
+    assert threading.active_count() <= before + 1
+    res = pipe.run(jobs[:2])
+    assert all(int((r[1] == 0).sum()) >= 60 for r in res)
+    pipe.close()
+
+
+def _raises(f):
+    try:
+        f()
+    except BaseException as e:
+        return e
+    return None
+
