@@ -621,6 +621,7 @@ def _refresh(an: AcStateEstimation):
     scenario restarts from the container's readings (noise realisations of setNoise_ are dropped)."""
     z = an._raw(an.monitoring)
     an._z = z
+    an._readings_on_device = False                                 # drawNoise_ uploads the new readings / variances / statuses before its next draw
     code = an._layout(an.monitoring)[0]
     mean, wdiag, woff, status = an._values(an.monitoring, an._devs, an._dev_row, an.dims["m"], *z)
     _lib.check(_lib.lib().jg_gn_set_status(an._h, np.ascontiguousarray(status, dtype=np.int8), code))

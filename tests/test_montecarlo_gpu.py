@@ -230,3 +230,25 @@ def test_a_failing_on_done_surfaces_and_leaves_no_worker_waiting(jg):
     res = pipe.run([7, 8])
     assert all(int((st == 0).sum()) == 32 for _, st in res)
     pipe.close()
+
+
+def test_device_noise_follows_a_meter_updated_after_the_first_draw(jg):
+    """updateVoltmeter!(analysis; ...) after realisations were drawn on the device: the next draw starts from the NEW reading, variance and status (the raw
+    readings the device holds are refreshed with the analysis; scale 0 makes the draw the reading itself)."""
+    s, mon = _config4_like(jg, "case118")
+    an = jg.gaussNewton(mon, batch=8)
+    jg.drawNoise_(an, 3, scale=1.0)
+    jg.drawNoise_(an, 3, scale=0.0)
+    base, wbase, _ = jg.measurementDevice(an)
+    jg.updateVoltmeter_(an, label=5, magnitude=1.0321, variance=4e-4)
+    jg.updateWattmeter_(an, label=2, status=0)
+    jg.drawNoise_(an, 3, scale=0.0)
+    mean, wd, _ = jg.measurementDevice(an)
+    rv = int(an._dev_row[4])                                            # voltmeters come first: device 4 = voltmeter 5
+    assert np.all(mean[:, rv] == 1.0321) and np.allclose(wd[:, rv], 1.0 / 4e-4, rtol=1e-15)
+    nv = mon.voltmeter.number + mon.ammeter.number
+    rw = int(an._dev_row[nv + 1])                                       # wattmeter 2
+    assert np.all(mean[:, rw] == 0.0) and np.all(base[:, rw] != 0.0)
+    keep = np.ones(mean.shape[1], dtype=bool); keep[[rv, rw]] = False
+    assert np.array_equal(mean[:, keep], base[:, keep]) and np.array_equal(wd[:, keep], wbase[:, keep])
+    an.close()
