@@ -349,6 +349,8 @@ def fastOutagePatch(system: PowerSystem, label: int, bx: bool):
     entry is not in the reduced matrix (slack row / column of B', PV and slack buses in B'')."""
     k = int(label) - 1
     bus, br, ac = system.bus, system.branch, system.model.ac
+    if int(br.layout.status[k]) != 1:                            # already out of service: fastNewtonJacobian! put nothing in for it (acPowerFlow.jl:416-447), as Ybus holds none of it
+        return np.zeros(4, dtype=np.int64), np.zeros(4), np.zeros(4)
     typ, slack, par, Y = bus.layout.type, bus.layout.slack, br.parameter, ac.nodalMatrix
     i, j = int(br.layout.from_[k]) - 1, int(br.layout.to[k]) - 1
     bsi, tinv = 0.5 * par.susceptance[k], 1.0 / par.turnsRatio[k]

@@ -181,3 +181,20 @@ def test_islanding_outages_in_a_fast_batch_end_like_the_reference(jg, oracle):
         seen.add(bool(singular))
     assert seen == {True, False}, "the three bridges of the fixture cover both endings"
     an.close()
+
+
+@pytest.mark.parametrize("method", ["bx", "xb", "nr"])
+def test_the_outage_of_a_branch_that_is_already_out_changes_nothing(jg, method):
+    """A scenario whose 'outage' names a branch the grid already has out of service: neither Ybus nor B' / B'' hold anything of that branch
+    (acPowerFlow.jl:416-447 skips it), so the lane is bitwise the base case."""
+    t = {k: np.array(v) for k, v in load_case("case118").items()}
+    off = int(jg.outageList(jg.powerSystem(t), 1, seed=9)[0])
+    t["br_status"][off - 1] = 0
+    s = jg.powerSystem(t)
+    an = jg.contingencyAnalysis(s, [off, 0, off], method=method)
+    jg.powerFlow_(an, iteration=100)
+    assert np.all(np.asarray(an.status) == 0)
+    for b in (0, 2):
+        assert np.array_equal(an.voltage.magnitude[b], an.voltage.magnitude[1]) and np.array_equal(an.voltage.angle[b], an.voltage.angle[1])
+        assert an.method.iteration[b] == an.method.iteration[1]
+    an.close()
