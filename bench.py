@@ -520,9 +520,13 @@ def predicted_from_shards(workload, world, total):
         if not rows:
             return None
         r = rows[-1]
-        return {"value": world * r["value"], "per_gpu_value": r["value"], "from": "profiles/bench_shards.json",
-                "what": f"{world} x the rate ONE GPU reaches on a rank's share ({r['scenarios_per_step']} scenarios per step, {r['steps_per_device_batch']} steps per device batch, "
-                        f"{r['device_batches_in_flight']} in flight), measured {r.get('measured', 'earlier')}; no gather, no host contention"}
+        out = {"value": world * r["value"], "per_gpu_value": r["value"], "from": "profiles/bench_shards.json",
+               "what": f"{world} x the rate ONE GPU reaches on a rank's share ({r['scenarios_per_step']} scenarios per step, {r['steps_per_device_batch']} steps per device batch, "
+                       f"{r['device_batches_in_flight']} in flight" + (f", K = {r['steps']} steps per region as the driver runs it" if r.get("steps") else "") +
+                       f"), measured {r.get('measured', 'earlier')}; no gather, no host contention"}
+        if r.get("value_steady"):
+            out["value_steady"] = world * r["value_steady"]
+        return out
     except Exception:
         return None
 
@@ -814,7 +818,7 @@ def main():
     if args.merge > 0:
         merge = args.merge
     elif args.scaling == "strong":
-        merge = jg.deviceBatching(b_max, args.steps, 512)   # at most 512 lanes; the count that leaves the fewest spare lanes in the last batch
+        merge = jg.deviceBatching(b_max, args.steps, 512)   # 512-lane batches with the fewest spare lanes in the last one; a run of at most 1 280 scenarios per rank: one or two wider batches
     else:
         merge = 1
     merge = max(1, min(merge, args.steps))

@@ -84,7 +84,17 @@ def deviceBatching(share: int, steps: int, lanes: int = 512) -> int:
     with the number of ranks, the path is at its best around `lanes` scenarios per launch).  At most lanes // share steps; among
     the upper half of that range the count that leaves the fewest spare lanes in the last batch of a run of `steps` steps,
     the larger one on a tie.  1 when the share already fills the lanes."""
-    m_max = min(max(1, lanes // max(1, int(share))), max(1, int(steps)))
+    share, steps = max(1, int(share)), max(1, int(steps))
+    if share < lanes:
+        # (round 5) a rank whose WHOLE run is a batch or two -- N = 8 at the driver's K = 20: 20 x 64 = 1 280 scenarios -- solves it as ONE batch of up to 5/4 lanes resp.
+        # as TWO batches that are both in flight: measured on one GPU (profiles/r05_n8_shape.txt, 64 scenarios per step, K = 20) 2 x 640 lanes 260k NR it/s, 1 x 1 280
+        # 247k, 5 x 256 242k, 512 + 512 + 256 230k, 4 x 320 (the old choice: no spare lanes) 197k
+        total, wide = share * steps, lanes + lanes // 4
+        if lanes < total <= wide:
+            return steps
+        if wide < total <= 2 * wide:
+            return -(-steps // 2)
+    m_max = min(max(1, lanes // share), steps)
     if m_max <= 1:
         return 1
     return min(range(max(1, (m_max + 1) // 2), m_max + 1), key=lambda m: (-(-steps // m) * m - steps, -m))

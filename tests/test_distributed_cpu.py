@@ -29,11 +29,16 @@ def test_device_batching_of_a_shrinking_share(jg):
     """bench.py --merge: steps per device batch under strong scaling (512 scenarios per step over N ranks, K steps)."""
     assert jg.deviceBatching(512, 48) == 1 and jg.deviceBatching(700, 48) == 1            # N = 1: a step already fills the lanes
     assert jg.deviceBatching(256, 48) == 2 and jg.deviceBatching(128, 48) == 4 and jg.deviceBatching(64, 48) == 8
-    assert jg.deviceBatching(64, 20) == 5                                                  # 4 batches of 5 steps, no spare lanes
+    assert jg.deviceBatching(64, 20) == 10                                                 # round 5: the rank's whole run (1 280 scenarios) as TWO batches, both in flight
+    assert jg.deviceBatching(64, 10) == 10 and jg.deviceBatching(64, 9) == 9               # ... as ONE batch of up to 640 lanes
+    assert jg.deviceBatching(128, 10) == 5 and jg.deviceBatching(128, 20) == 4             # 2 x 640; beyond 1 280 scenarios: 512-lane batches
     assert jg.deviceBatching(64, 3) == 3 and jg.deviceBatching(64, 1) == 1
     for share in (64, 100, 171, 256):
         for steps in (1, 5, 7, 20, 24, 96):
             m = jg.deviceBatching(share, steps)
+            if 512 < share * steps <= 1280:                                                # one batch of up to 640 lanes, or two of them
+                assert m == (steps if share * steps <= 640 else -(-steps // 2)) and m * share <= 640 + share
+                continue
             assert 1 <= m <= max(1, min(512 // share, steps)) and m * share <= max(512, share)
             spare = -(-steps // m) * m - steps
             assert all(spare <= -(-steps // q) * q - steps for q in range(max(1, (min(512 // share, steps) + 1) // 2), min(512 // share, steps) + 1))

@@ -99,15 +99,15 @@ def test_bench_gathers_screen_summaries_with_two_ranks():
 
 def test_bench_at_the_drivers_flags_with_eight_ranks():
     """ The driver's command shape for the 8-GPU run -- `--gpus 8 --steps 20 --warmup 5` -- as a dry run: eight ranks share the one GPU over gloo.
-    512 scenarios shard 8 x 64; deviceBatching(64, 20) = 5 steps per device batch = 320 lanes, 4 device batches per region, all in flight at once: the K-step
+    512 scenarios shard 8 x 64; deviceBatching(64, 20) = 10 steps per device batch = 640 lanes, the rank's whole region as TWO device batches, both in flight: the K-step
     region cannot reach the pipeline's steady state, so the line ALSO carries value_steady (three rounds of the batches in flight); value keeps the caller's K."""
     d = _bench(["--gpus", "8", "--steps", "20", "--warmup", "5", "--no-cpu", "--no-se"], JG_BENCH_BACKEND="gloo", JG_BENCH_MAX_REPEATS="3", JG_BENCH_MIN_SECONDS="0.2")
     assert d["n_gpus"] == 8 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "strong"
     c = d["config"]
-    assert c["batch_per_gpu"] == 64 and c["steps_per_device_batch"] == 5 and c["lanes_per_device_batch"] == 320 and c["device_batches_per_region"] == 4
+    assert c["batch_per_gpu"] == 64 and c["steps_per_device_batch"] == 10 and c["lanes_per_device_batch"] == 640 and c["device_batches_per_region"] == 2
     assert c["pipeline_steady_state"] is False and c["gather"].startswith("torch.distributed")
     assert d["value"] > 0 and d["converged_fraction"] == 1.0
-    assert d["value_steady"] > 0 and d["steady_steps"] == 3 * c["device_batches_in_flight_per_gpu"] * 5
+    assert d["value_steady"] > 0 and d["steady_steps"] == 3 * c["device_batches_in_flight_per_gpu"] * 10
     assert abs(d["ms_per_step"] * 20 - d["region_ms_median"]) < 1e-6 * d["region_ms_median"]
 
 

@@ -12,15 +12,18 @@ python bench.py --case case1354pegase --steps 24 --warmup 3 --no-se --no-cpu 2>/
 python - <<'PY' > gpurun_out/bench_shards_$T.json
 import json, subprocess, sys, datetime
 out = {"nr": [], "se": [], "measured": "round 5, " + datetime.date.today().isoformat() + ", one MI355X of the build pool"}
-for wl, cfgs in (("nr", [(256, 3, 2), (128, 3, 4), (64, 3, 8)]), ("se", [(256, 2, 2), (128, 2, 4), (64, 2, 8)])):
-    for share, infl, merge in cfgs:
-        cmd = [sys.executable, "bench.py", "--workload", wl, "--batch", str(share), "--inflight", str(infl), "--merge", str(merge), "--steps", "96" if wl == "nr" else "24", "--no-cpu", "--no-se"]
+# (the driver's own shape: --steps 20 --warmup 5 with the device batching bench.py picks for that share -- what a rank of the N-GPU run does, fill and drain included)
+for wl in ("nr", "se"):
+    for share in (256, 128, 64):
+        cmd = [sys.executable, "bench.py", "--workload", wl, "--batch", str(share), "--steps", "20", "--warmup", "5", "--no-cpu", "--no-se"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         l = [x for x in r.stdout.splitlines() if x.startswith("{")]
         if not l:
             continue
         j = json.loads(l[-1])
-        out[wl].append({"scenarios_per_step": share, "steps_per_device_batch": merge, "device_batches_in_flight": infl, "merged": True, "value": j["value"],
+        c = j["config"]
+        out[wl].append({"scenarios_per_step": share, "steps": 20, "steps_per_device_batch": c["steps_per_device_batch"], "lanes_per_device_batch": c["lanes_per_device_batch"],
+                        "device_batches_in_flight": c["device_batches_in_flight_per_gpu"], "merged": True, "value": j["value"], "value_steady": j.get("value_steady"),
                         "ms_per_step": j["ms_per_step"], "measured": out["measured"]})
 print(json.dumps(out, indent=1))
 PY
