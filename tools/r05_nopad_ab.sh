@@ -1,3 +1,5 @@
+#!/bin/bash
+# NOTE: probe_libs/libjgrid_nopad.so was a build with 5 - 7 lane groups unpadded (-DJG_GS_NOPAD=1, a switch that is gone: 5 and 6 groups are unpadded by default now, 7 stays padded)
 line() { grep '^{' | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); c=d['config']; print(round(d['value']), round(d['ms_per_step'],3), 'lanes', c['lanes_per_device_batch'], 'value_steady', d.get('value_steady') and round(d['value_steady']))"; }
 for L in "" probe_libs/libjgrid_nopad.so; do
   echo "== lib ${L:-default}"
