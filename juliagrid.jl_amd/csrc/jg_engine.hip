@@ -2146,14 +2146,13 @@ void Engine::destroy() {
 int Engine::factor(hipStream_t st, const double* A, const double* rhs, const GroupSel& sel, bool level0_done) {
     if (!plan->S.inplace && !A) { error = "factor: no source matrix"; return 1; }
     FactArgs a{fact_rec, fact_seg, plan->S.inplace ? X : A, rhs, X, W, status, sel, ld, 0, lanes > 0 ? lanes : ld, 0, 0, 1, 1};
-    const int gs = group_stride(ld / 64);
     if (!level0_done && !pre.empty()) {                          // prefactor plan, plain blocks from the producer: its level 0 first
         FactArgs p = a;
         p.rec = pre_rec; p.seg = pre_seg;
         for (const DevLaunch& L : pre) {
             p.seg_begin = L.seg_begin;
             { const Segment& g = plan->S.pre_seg[L.seg_begin]; p.s0_base = g.rec_base; p.s0_nchunks = g.nchunks; p.s0_wpi = g.wpi; p.s0_rpw = g.rpw; }
-            hipLaunchKernelGGL(k_fact_level, dim3((unsigned)L.grid * (16 / FACT_WAVES) * gs, L.nseg), dim3(64, FACT_WAVES), FACT_WAVES * 256 * sizeof(double), st, p);
+            hipLaunchKernelGGL(k_fact_level, dim3(grid_blocks(ld / 64, (long long)L.grid * (16 / FACT_WAVES)), L.nseg), dim3(64, FACT_WAVES), FACT_WAVES * 256 * sizeof(double), st, p);
         }
     }
     for (const DevLaunch& L : fact) {
@@ -2161,9 +2160,9 @@ int Engine::factor(hipStream_t st, const double* A, const double* rhs, const Gro
         a.seg_begin = L.seg_begin;
         { const Segment& g = plan->S.fact_seg[L.seg_begin]; a.s0_base = g.rec_base; a.s0_nchunks = g.nchunks; a.s0_wpi = g.wpi; a.s0_rpw = g.rpw; }
         if (plan->S.fact_tasks)                                  // TASKS (jg_symbolic.hpp): a workgroup per task, not per 8 item waves
-            hipLaunchKernelGGL(k_fact_task, dim3((unsigned)L.grid * gs, L.nseg), dim3(64, TASK_WAVES), TASK_LDS_D2 * sizeof(double2), st, a);
+            hipLaunchKernelGGL(k_fact_task, dim3(grid_blocks(ld / 64, L.grid), L.nseg), dim3(64, TASK_WAVES), TASK_LDS_D2 * sizeof(double2), st, a);
         else
-            hipLaunchKernelGGL(k_fact_level, dim3((unsigned)L.grid * (16 / FACT_WAVES) * gs, L.nseg), dim3(64, FACT_WAVES), FACT_WAVES * 256 * sizeof(double), st, a);
+            hipLaunchKernelGGL(k_fact_level, dim3(grid_blocks(ld / 64, (long long)L.grid * (16 / FACT_WAVES)), L.nseg), dim3(64, FACT_WAVES), FACT_WAVES * 256 * sizeof(double), st, a);
     }
     // the top of the elimination tree: multifrontal tasks, one workgroup per (task, scenario), launch = (task level, class)
     if (!plan->S.top_launch.empty() && probe_part != 1) {
@@ -2176,13 +2175,13 @@ int Engine::factor(hipStream_t st, const double* A, const double* rhs, const Gro
             const bool jordan = this->jordan && plan->S.jordan;
             if (L.grouped) {                                     // every grouped task of the level: 4 or 16 scenarios per workgroup
                 t.wg_begin = L.wg_begin; t.nwg = L.nwg;
-                hipLaunchKernelGGL((k_fact_grp<4>), dim3((unsigned)L.nwg * gs), dim3(256), 0, st, t);
+                hipLaunchKernelGGL((k_fact_grp<4>), dim3(grid_blocks(ld / 64, L.nwg)), dim3(256), 0, st, t);
                 continue;
             }
             // round 5: symmetric plans with Jordan rows (the Gauss-Newton gain by default) eliminate the upper triangle only (k_fact_top_sym); JG_TOP_SYM=0: the mirrored front
             static const bool sym_env = !(getenv("JG_TOP_SYM") && atoi(getenv("JG_TOP_SYM")) == 0);
             if (plan->S.symmetric && jordan && sym_env) {
-                const dim3 grids((unsigned)L.ntasks * t.lpg * gs);
+                const dim3 grids(grid_blocks(ld / 64, (long long)L.ntasks * t.lpg));
                 if (L.cls == 2) hipLaunchKernelGGL((k_fact_top_sym<2>), grids, dim3(256), 0, st, t);
                 else if (L.cls == 3) hipLaunchKernelGGL((k_fact_top_sym<3>), grids, dim3(256), 0, st, t);
                 else hipLaunchKernelGGL((k_fact_top_sym<4>), grids, dim3(256), 0, st, t);
@@ -2196,18 +2195,18 @@ int Engine::factor(hipStream_t st, const double* A, const double* rhs, const Gro
             // dealt: 8 waves of W1 against 7 workgroups of k_fact_top<2>).  Kept as a checked experiment (tests/test_top_variants_gpu.py), DESIGN_LOG round 5.
             static const int topw_env = getenv("JG_TOPW") ? atoi(getenv("JG_TOPW")) : 0;
             if (L.cls == 2 && (topw_env & 1)) {
-                const dim3 gridw((unsigned)L.ntasks * ((t.lpg + TOPW_SPW - 1) / TOPW_SPW) * gs);
+                const dim3 gridw(grid_blocks(ld / 64, (long long)L.ntasks * ((t.lpg + TOPW_SPW - 1) / TOPW_SPW)));
                 if (jordan) hipLaunchKernelGGL((k_fact_topw<3, 3, 4, 4, true>), gridw, dim3(64, TOPW_SPW), 0, st, t);
                 else hipLaunchKernelGGL((k_fact_topw<3, 3, 4, 4, false>), gridw, dim3(64, TOPW_SPW), 0, st, t);
                 continue;
             }
             if (L.cls == 3 && (topw_env & 2)) {
-                const dim3 gridw((unsigned)L.ntasks * t.lpg * gs);
+                const dim3 gridw(grid_blocks(ld / 64, (long long)L.ntasks * t.lpg));
                 if (jordan) hipLaunchKernelGGL((k_fact_topw<3, 4, 6, 3, true>), gridw, dim3(128), 0, st, t);
                 else hipLaunchKernelGGL((k_fact_topw<3, 4, 6, 3, false>), gridw, dim3(128), 0, st, t);
                 continue;
             }
-            const dim3 grid((unsigned)L.ntasks * t.lpg * gs);
+            const dim3 grid(grid_blocks(ld / 64, (long long)L.ntasks * t.lpg));
             // More workgroups than the CUs can hold WITH a pivot wave (1 per CU at CLS = 4, 2 at CLS = 3, 3 at CLS = 2): the 4-wave
             // variant, of which a CU holds twice as many; else the pivot-wave variant, whose step is 15 % shorter (measured at 512
             // scenarios: 0.86 against 1.02 us per step with two workgroups on a CU).
@@ -2275,11 +2274,10 @@ int Engine::selected_inverse(hipStream_t st, const GroupSel& sel) {
         JG_HIP(sync_fill(Zs, 0, factor_bytes(), st));
     }
     SelArgs a{sel_rec, sel_seg, X, Zs, sel, ld, 0, lanes > 0 ? lanes : ld, 0, 0, 1, 1};
-    const int gs = group_stride(ld / 64);
     for (const DevLaunch& L : selv) {
         a.seg_begin = L.seg_begin;
         { const Segment& g = plan->S.sel_seg[L.seg_begin]; a.s0_base = g.rec_base; a.s0_nchunks = g.nchunks; a.s0_wpi = g.wpi; a.s0_rpw = g.rpw; }
-        hipLaunchKernelGGL(k_sel_level, dim3((unsigned)L.grid * (16 / FACT_WAVES) * gs, L.nseg), dim3(64, FACT_WAVES), FACT_WAVES * 128 * sizeof(double2), st, a);
+        hipLaunchKernelGGL(k_sel_level, dim3(grid_blocks(ld / 64, (long long)L.grid * (16 / FACT_WAVES)), L.nseg), dim3(64, FACT_WAVES), FACT_WAVES * 128 * sizeof(double2), st, a);
     }
     JG_HIP(hipGetLastError());
     return 0;
@@ -2287,11 +2285,10 @@ int Engine::selected_inverse(hipStream_t st, const GroupSel& sel) {
 
 int Engine::forward(hipStream_t st, const double* rhs, const GroupSel& sel) {
     FactArgs a{fwd_rec, fwd_seg, X, rhs, X, W, status, sel, ld, 0, lanes > 0 ? lanes : ld, 0, 0, 1, 1};
-    const int gs = group_stride(ld / 64);
     for (const DevLaunch& L : fwd) {
         a.seg_begin = L.seg_begin;
         { const Segment& g = plan->S.fwd_seg[L.seg_begin]; a.s0_base = g.rec_base; a.s0_nchunks = g.nchunks; a.s0_wpi = g.wpi; a.s0_rpw = g.rpw; }
-        hipLaunchKernelGGL(k_fact_level, dim3((unsigned)L.grid * (16 / FACT_WAVES) * gs, L.nseg), dim3(64, FACT_WAVES), FACT_WAVES * 256 * sizeof(double), st, a);
+        hipLaunchKernelGGL(k_fact_level, dim3(grid_blocks(ld / 64, (long long)L.grid * (16 / FACT_WAVES)), L.nseg), dim3(64, FACT_WAVES), FACT_WAVES * 256 * sizeof(double), st, a);
     }
     JG_HIP(hipGetLastError());
     return 0;
@@ -2324,15 +2321,14 @@ int Engine::set_shared_matrix(hipStream_t st, const double* blocks_host) {
 int Engine::backsolve(hipStream_t st, double* out, const StateUpdate& upd, const GroupSel& sel) {
     // jordan: the last factor() left Jordan rows (the flag must not change between a factorisation and its solves)
     BwdArgs a{jordan ? plan->bwdj_rec : bwd_rec, jordan ? plan->bwdj_seg : bwd_seg, bwd_chain, X, W, out, sel, upd, ld, 0, lanes > 0 ? lanes : ld, 0, 0, 1, 1};
-    const int gs = group_stride(ld / 64);
     const std::vector<Segment>& segs = jordan ? plan->S.bwdj_seg : plan->S.bwd_seg;
     for (const DevLaunch& L : (jordan ? bwdj : bwd)) {
         a.seg_begin = L.seg_begin;
         { const Segment& g = segs[L.seg_begin]; a.s0_base = g.rec_base; a.s0_nchunks = g.nchunks; a.s0_wpi = g.wpi; a.s0_rpw = g.rpw; }
         if (!L.chain && L.wpi_max <= 8)                         // 0.387 -> 0.381 ms at 512 scenarios
-            hipLaunchKernelGGL(k_bwd_level8, dim3((unsigned)L.grid * 2 * gs, L.nseg), dim3(64, 8), CHAIN_SMALL_LDS_D2 * sizeof(double2), st, a);
+            hipLaunchKernelGGL(k_bwd_level8, dim3(grid_blocks(ld / 64, (long long)L.grid * 2), L.nseg), dim3(64, 8), CHAIN_SMALL_LDS_D2 * sizeof(double2), st, a);
         else
-        hipLaunchKernelGGL(k_bwd_level, dim3((unsigned)L.grid * gs, L.nseg), dim3(64, 16),
+        hipLaunchKernelGGL(k_bwd_level, dim3(grid_blocks(ld / 64, L.grid), L.nseg), dim3(64, 16),
                            L.chain ? (size_t)CHAIN_LDS_D2 * sizeof(double2) : 16 * 128 * sizeof(double), st, a);
     }
     JG_HIP(hipGetLastError());

@@ -72,6 +72,18 @@ struct GroupSel {
 __host__ __device__ inline int group_stride(int groups) {
     return groups >= 8 || groups == 5 || groups == 6 || groups == 3 ? groups : (groups <= 1 ? 1 : (groups <= 2 ? 2 : (groups <= 4 ? 4 : 8)));   // (3 groups: a 192-lane pipeline 214k -> 226k NR it/s)
 }
+// BALANCED mapping (round 5, JG_BALANCED_MAP below): every group count that cannot be pinned -- not 1, 2, 4 and no multiple of 8 -- takes the (group, chunk) pairs of a launch in
+// group-major order, cuts that list into EIGHT equal runs and gives run k to the workgroups that land on XCD k (id % 8 == k): every XCD gets the same number of workgroups whatever
+// the count, and a group's operands meet in the one to three L2s its run(s) touch instead of all eight (the rotation) -- 640 lanes = 10 groups is what a rank of the 8-GPU run
+// merges at the driver's K = 20, 5 - 7 groups what a 512-lane batch compacts to.
+#ifndef JG_BALANCED_MAP
+#define JG_BALANCED_MAP 1
+#endif
+__host__ __device__ inline bool groups_balanced(int groups) { return JG_BALANCED_MAP && groups > 2 && groups != 4 && (groups & 7) != 0; }
+// workgroups of a launch of nx chunks per group (host side; the count of a handle's lanes bounds every count its launches can see after compaction)
+__host__ inline unsigned grid_blocks(int groups, long long nx) {
+    return groups_balanced(groups) ? (unsigned)(((long long)groups * nx + 7) / 8 * 8) : (unsigned)(nx * group_stride(groups));
+}
 
 #ifdef __HIPCC__
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -164,12 +176,21 @@ __device__ __forceinline__ bool map_block(const GroupSel& sel, int ld, int nx, i
     int gact = ld / 64;
     SelInt8 first{};
     if (sel.list) { first = *(SelInt8Ptr)sel.list; gact = *(SelIntPtr)sel.count; }
-    const int gs = group_stride(gact);
-    const int slot = id % gs;
-    x = id / gs;
-    if (slot >= gact || x >= nx) return false;
+    int slot;
+    if (groups_balanced(gact)) {
+        const int total = gact * nx, chunk = (total + 7) >> 3;
+        const int j = id >> 3, flat = (id & 7) * chunk + j;
+        if (j >= chunk || flat >= total) return false;
+        slot = flat / nx;
+        x = flat - slot * nx;
+    } else {
+        const int gs = group_stride(gact);
+        slot = id % gs;
+        x = id / gs;
+        if (slot >= gact || x >= nx) return false;
+    }
     if (sel.list) {
-        if (gs <= 8) {
+        if (gact <= 8) {
             g = first[0];
 #pragma unroll
             for (int k = 1; k < 8; ++k) g = slot == k ? first[k] : g;

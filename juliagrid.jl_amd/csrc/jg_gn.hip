@@ -827,10 +827,10 @@ void launch_gain(jg_gn* h, bool correction = false) {
     const int nw = correction ? h->rhs_waves : h->gain_waves;
     GainArgs a{correction ? h->d_rrec : h->d_grec, correction ? h->d_rwave : h->d_gwave, h->d_Hs, correction ? h->d_rho : h->d_res, h->d_w, h->eng.X,
                correction ? h->d_rhs2 : h->d_rhs, nw, h->ld};
-    if (nw > 0) hipLaunchKernelGGL(k_gn_gain, dim3((unsigned)((nw + 3) / 4) * jg::group_stride(h->ld / 64)), dim3(64, 4), 0, h->stream, a);
+    if (nw > 0) hipLaunchKernelGGL(k_gn_gain, dim3(jg::grid_blocks(h->ld / 64, (nw + 3) / 4)), dim3(64, 4), 0, h->stream, a);
     if (!correction && h->gain_tasks > 0) {
         GainLdsArgs t{h->d_gtask, h->d_gstage, h->d_trec, h->d_Hs, h->d_res, h->d_w, h->eng.X, h->d_rhs, h->gain_tasks, h->ld};
-        hipLaunchKernelGGL(k_gn_gain_lds, dim3((unsigned)h->gain_tasks * jg::group_stride(h->ld / 64)), dim3(64, GAIN_LDS_WAVES), (size_t)h->gain_lds_bytes, h->stream, t);
+        hipLaunchKernelGGL(k_gn_gain_lds, dim3(jg::grid_blocks(h->ld / 64, h->gain_tasks)), dim3(64, GAIN_LDS_WAVES), (size_t)h->gain_lds_bytes, h->stream, t);
     }
 }
 

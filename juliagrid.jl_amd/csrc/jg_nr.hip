@@ -796,7 +796,7 @@ void launch_assemble(jg_nr* h, const jg::GroupSel& sel = jg::GroupSel{}, bool ja
               h->d_ppos, h->d_pdg, h->d_pdb, h->eng.X, h->d_F, h->d_part, pq_out, sel, fd_mode ? h->d_R : nullptr, fd_mode, h->n, h->ld, h->mp, h->nchunk, h->batch, only_if,
               h->eng.W, h->eng.status};
     if (jac && !only_if) h->level0_done = pre;
-    dim3 grid((unsigned)h->nchunk * jg::group_stride(h->ld / 64)), block(64, ASM_WAVES);
+    dim3 grid(jg::grid_blocks(h->ld / 64, h->nchunk)), block(64, ASM_WAVES);
     if (jac) {
         switch (h->mp) {
             case 0: hipLaunchKernelGGL((k_assemble<0, true>), grid, block, 0, h->stream, a); break;
@@ -921,7 +921,7 @@ int newton_step(jg_nr* h, const jg::GroupSel& sel, const int* active) {
     if (int rc = h->eng.backsolve(h->stream, h->d_inc2[1], none, sel)) return rc;
     RefineArgs a{h->d_rowptr, h->d_col, h->d_GB, h->d_rowtype, h->d_vm, h->d_va, h->d_ppos, h->d_pdg, h->d_pdb,
                  h->d_F, h->d_inc2[1], h->d_R, sel, h->n, h->ld, h->mp, h->nchunk, h->batch};
-    dim3 grid((unsigned)h->nchunk * jg::group_stride(h->ld / 64)), block(64, ASM_WAVES);
+    dim3 grid(jg::grid_blocks(h->ld / 64, h->nchunk)), block(64, ASM_WAVES);
     switch (h->mp) {
         case 0: hipLaunchKernelGGL((k_refine_residual<0>), grid, block, 0, h->stream, a); break;
         case 4: hipLaunchKernelGGL((k_refine_residual<4>), grid, block, 0, h->stream, a); break;
@@ -929,7 +929,7 @@ int newton_step(jg_nr* h, const jg::GroupSel& sel, const int* active) {
     }
     if (int rc = h->eng.forward(h->stream, h->d_R, sel)) return rc;
     if (int rc = h->eng.backsolve(h->stream, h->d_inc2[0], none, sel)) return rc;
-    hipLaunchKernelGGL(k_refine_apply, dim3((unsigned)((h->n + 15) / 16) * jg::group_stride(h->ld / 64)), dim3(64, 16), 0, h->stream,
+    hipLaunchKernelGGL(k_refine_apply, dim3(jg::grid_blocks(h->ld / 64, (h->n + 15) / 16)), dim3(64, 16), 0, h->stream,
                        h->d_inc, h->d_inc2[1], h->d_inc2[0], h->d_va, h->d_vm, h->d_flags, active, sel, h->n, h->ld, h->batch);
     return 0;
 }
