@@ -354,7 +354,7 @@ def make_gather(jg, torch, dist, rank, world, local, cdev, force_dist, lanes, wi
                 try:
                     c = jg._lib.Comm(rank, world, uid_host, device=local)
                     torch.cuda.set_device(local)
-                    probe = torch.zeros((lanes, width), dtype=torch.float64, device="cuda")
+                    probe = torch.zeros((lanes, width), dtype=torch.float64, device="cuda"); torch.cuda.current_stream().synchronize()   # (the fill runs on torch's stream, the gather on the communicator's)
                     out = torch.empty((world * lanes, width), dtype=torch.float64, device="cuda")
                     c.allgather_device(probe.data_ptr(), out.data_ptr(), probe.numel())
                     torch.cuda.synchronize()

@@ -22,18 +22,21 @@ def test_allgather_through_the_c_abi_equals_the_packed_record(jg):
     jg.powerFlow_(an, iteration=20, tolerance=1e-8)
     n = s.bus.number
     packed = torch.zeros((70, 2 * n + 2), dtype=torch.float64, device="cuda")
+    torch.cuda.current_stream().synchronize()                                    # the fill runs on torch's stream, the library writes on its own: finish it first
     jg._lib.check(jg._lib.lib().jg_nr_pack_results_device(an._h, jg._lib.VP(packed.data_ptr())))
     comm = jg._lib.Comm(0, 1, jg._lib.Comm.unique_id(), device=0)
     assert jg._lib.lib().jg_comm_rank(comm.h) == 0 and jg._lib.lib().jg_comm_world(comm.h) == 1
     out = torch.full((70, 2 * n + 2), np.nan, dtype=torch.float64, device="cuda")
+    torch.cuda.current_stream().synchronize()                                    # the fill runs on torch's stream, the library writes on its own: finish it first
     jg.gatherResultsDevice(an, comm, out.data_ptr())
-    torch.cuda.synchronize()
+    torch.cuda.current_stream().synchronize()
     assert torch.equal(out, packed)
     it, st, vm, va = jg.unpackResults(out)
     assert np.array_equal(it.cpu().numpy(), np.asarray(an.method.iteration)) and np.array_equal(st.cpu().numpy(), np.asarray(an.status))
     assert np.array_equal(vm.cpu().numpy(), np.asarray(an.voltage.magnitude))
     # a record that is already packed (what a ContingencyPipeline delivers), out of place
     out2 = torch.empty_like(out)
+    torch.cuda.current_stream().synchronize()                                    # the fill runs on torch's stream, the library writes on its own: finish it first
     comm.allgather_device(packed.data_ptr(), out2.data_ptr(), packed.numel())
     assert torch.equal(out2, packed)
     comm.close()

@@ -54,6 +54,7 @@ def test_record_is_bitwise_the_getters(jg, batch):
     jg.stateEstimation_(an, iteration=40, tolerance=1e-8)
     assert np.all(an.status == 0) and an.method.iteration.min() >= 3
     rec = torch.full((batch, 2 * n + 3), np.nan, dtype=torch.float64, device="cuda")
+    torch.cuda.current_stream().synchronize()                                    # the fill runs on torch's stream, the library writes on its own: finish it first
     an.pack_results_device(rec.data_ptr())
     r = rec.cpu().numpy()
     it, st, obj, vm, va = (x.cpu().numpy() for x in jg.unpackEstimates(rec))
@@ -67,13 +68,15 @@ def test_record_is_bitwise_the_getters(jg, batch):
     assert 0.8 * dof < obj.mean() < 1.2 * dof
     # bitwise run to run (fixed summation order)
     rec2 = torch.zeros_like(rec)
+    torch.cuda.current_stream().synchronize()                                    # the fill runs on torch's stream, the library writes on its own: finish it first
     an.pack_results_device(rec2.data_ptr())
     assert torch.equal(rec, rec2)
     # the gather through the C ABI with a 1-rank RCCL communicator
     comm = jg._lib.Comm(0, 1, jg._lib.Comm.unique_id(), device=0)
     out = torch.full_like(rec, np.nan)
+    torch.cuda.current_stream().synchronize()                                    # the fill runs on torch's stream, the library writes on its own: finish it first
     jg.gatherEstimatesDevice(an, comm, out.data_ptr())
-    torch.cuda.synchronize()
+    torch.cuda.current_stream().synchronize()
     assert torch.equal(out, rec)
     comm.close()
     an.close()
@@ -88,12 +91,13 @@ def test_pipeline_delivers_the_records_of_plain_batches(jg):
     pipe = jg.MonteCarloPipeline(mon, B, inflight=2)
     assert pipe.record_width == 2 * n + 3
     ring = [torch.zeros((B, 2 * n + 3), dtype=torch.float64, device="cuda") for _ in range(2)]
+    torch.cuda.current_stream().synchronize()                                    # the fill runs on torch's stream, the library writes on its own: finish it first
     seen, order = [], []
 
     def on_done(j, an):
         order.append(j)
         seen.append(ring[j % 2].clone())
-        torch.cuda.synchronize()
+        torch.cuda.current_stream().synchronize()
 
     seeds = [11, 12, 13, 14]
     res = pipe.run(seeds, iteration=40, tolerance=1e-8, on_done=on_done, record=lambda j: ring[j % 2].data_ptr(), records=2)
@@ -105,6 +109,7 @@ def test_pipeline_delivers_the_records_of_plain_batches(jg):
         ref.setVoltage(np.ones(n), np.zeros(n))
         jg.stateEstimation_(ref, iteration=40, tolerance=1e-8)
         rec = torch.zeros((B, 2 * n + 3), dtype=torch.float64, device="cuda")
+        torch.cuda.current_stream().synchronize()                                    # the fill runs on torch's stream, the library writes on its own: finish it first
         ref.pack_results_device(rec.data_ptr())
         assert torch.equal(rec, seen[j]), j
         assert np.array_equal(res[j][0], ref.method.iteration) and np.array_equal(res[j][1], ref.status)

@@ -10,7 +10,9 @@ pytestmark = pytest.mark.gpu
 
 
 def _records(torch, count, lanes, n):
-    return [torch.full((lanes, 2 * n + 2), -7.0, dtype=torch.float64, device="cuda") for _ in range(count)]
+    ring = [torch.full((lanes, 2 * n + 2), -7.0, dtype=torch.float64, device="cuda") for _ in range(count)]
+    torch.cuda.current_stream().synchronize()                                    # the fill runs on torch's stream, the library writes on its own: finish it first
+    return ring
 
 
 @pytest.mark.parametrize("name,batch,njobs,pool", [("case1354pegase", 192, 7, 128), ("case1354pegase", 128, 5, 64),
@@ -183,11 +185,12 @@ def test_monte_carlo_injection_jobs_through_the_pipeline(jg, oracle):
                      "reactive": s.bus.supply.reactive[None, :] - s.bus.demand.reactive[None, :] * scale})
     pipe = jg.ContingencyPipeline(s, B, inflight=2, start=start, pool=128)
     ring = [torch.zeros((B, 2 * n + 2), dtype=torch.float64, device="cuda") for _ in range(3)]
+    torch.cuda.current_stream().synchronize()                                    # the fill runs on torch's stream, the library writes on its own: finish it first
     seen = []
 
     def on_done(j, an):
         seen.append(ring[j % 3].clone())
-        torch.cuda.synchronize()
+        torch.cuda.current_stream().synchronize()
 
     res = pipe.run(jobs, on_done=on_done, record=lambda j: ring[j % 3].data_ptr(), records=3)
     pipe.close()
@@ -197,6 +200,7 @@ def test_monte_carlo_injection_jobs_through_the_pipeline(jg, oracle):
         jg.powerflow._push_voltage(ref, *start)
         jg.powerFlow_(ref)
         rec = torch.zeros((B, 2 * n + 2), dtype=torch.float64, device="cuda")
+        torch.cuda.current_stream().synchronize()                                    # the fill runs on torch's stream, the library writes on its own: finish it first
         ref.pack_results_device(rec.data_ptr())
         assert torch.equal(rec, seen[j]), j
         assert np.array_equal(res[j][0], ref.method.iteration) and np.all(res[j][1] == 0)

@@ -72,6 +72,7 @@ def test_summary_into_a_device_record(jg):
     rating = np.full(s.branch.number, 2.5)
     host = jg.screenSummary_(an, rating=rating)
     rec = torch.full((200, 10), -1.0, dtype=torch.float64, device="cuda")
+    torch.cuda.current_stream().synchronize()                                    # the fill runs on torch's stream, the library writes on its own: finish it first
     jg.screenSummary_(an, rating=rating, device_record=rec.data_ptr())
     r = rec.cpu().numpy()
     assert np.array_equal(r[:, 0], host.loading) and np.array_equal(r[:, 1], host.loadingBranch.astype(float)) and np.array_equal(r[:, 4], host.minMagnitude)
@@ -102,6 +103,7 @@ def test_pipeline_delivers_summary_records(jg, name, batch, njobs, pool):
         pipe.setRating(rating)
         ring = 4 if mode == "pool" else njobs
         rec = [torch.zeros((batch, 10), dtype=torch.float64, device="cuda") for _ in range(ring)]
+        torch.cuda.current_stream().synchronize()                                    # the fill runs on torch's stream, the library writes on its own: finish it first
         seen = []
 
         def on_done(j, an, rec=rec, ring=ring, seen=seen):
