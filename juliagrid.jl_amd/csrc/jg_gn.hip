@@ -807,6 +807,7 @@ struct jg_gn {
     double* d_obj = nullptr; double* d_objpart = nullptr; int* d_corr = nullptr; int obj_chunks = 0;   // objective per scenario (first use: jg_gn_get_objective / jg_gn_pack_results_device)
     bool ran = false;                                   // d_iters / d_status hold the verdicts of a stateEstimation! run
     double wait_us = 0.0;                               // running mean of the host's waits for an iteration's verdict (jg_gn_run: polls while this is short)
+    double* d_stage = nullptr; size_t stage_bytes = 0;  // rows on their way up or down (put_rows / get_rows)
     jg::Engine eng;
     hipStream_t stream = nullptr;
     hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
@@ -898,6 +899,17 @@ __global__ __launch_bounds__(512) void k_gn_collect_rows(const double* src, doub
     }
 }
 
+// the staging area of a handle for rows on their way up or down: grows, is never freed before the handle (a hipFree per call would synchronise the device -- while
+// another host thread of a pipeline may be capturing its hipGraph)
+int stage_room(jg_gn* h, size_t bytes) {
+    if (bytes <= h->stage_bytes) return 0;
+    GN_HIP(hipStreamSynchronize(h->stream));
+    hipFree(h->d_stage); h->d_stage = nullptr; h->stage_bytes = 0;
+    GN_HIP(hipMalloc((void**)&h->d_stage, bytes));
+    h->stage_bytes = bytes;
+    return 0;
+}
+
 int put_rows(jg_gn* h, double* dst, const double* src, int64_t stride, int rows) {
     if (stride != 0 && stride != rows) {                         // a caller's own row pitch: the general (slow) way
         std::vector<double> t((size_t)rows * h->ld, 0.0);
@@ -910,28 +922,20 @@ int put_rows(jg_gn* h, double* dst, const double* src, int64_t stride, int rows)
     }
     const int src_rows = stride == 0 ? 1 : h->batch;
     const size_t bytes = (size_t)src_rows * rows * sizeof(double);
-    double* stage = nullptr;
-    GN_HIP(hipMalloc((void**)&stage, bytes));
-    hipError_t e = jg::sync_copy(stage, src, bytes, hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_gn_spread_rows, dim3((rows + 63) / 64, h->ld / 64), dim3(64, 8), 0, h->stream, (const double*)stage, dst, rows, h->ld, h->batch, src_rows);
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    }
-    hipFree(stage);
-    GN_HIP(e);
+    if (int rc = stage_room(h, bytes)) return rc;
+    GN_HIP(jg::sync_copy(h->d_stage, src, bytes, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_gn_spread_rows, dim3((rows + 63) / 64, h->ld / 64), dim3(64, 8), 0, h->stream, (const double*)h->d_stage, dst, rows, h->ld, h->batch, src_rows);
+    GN_HIP(hipGetLastError());
+    GN_HIP(hipStreamSynchronize(h->stream));
     return 0;
 }
 
 int get_rows(jg_gn* h, const double* src, double* dst, size_t rows) {
     const size_t bytes = (size_t)h->batch * rows * sizeof(double);
-    double* stage = nullptr;
-    GN_HIP(hipMalloc((void**)&stage, bytes));
-    hipLaunchKernelGGL(k_gn_collect_rows, dim3((unsigned)((rows + 63) / 64), h->ld / 64), dim3(64, 8), 0, h->stream, src, stage, (int)rows, h->ld, h->batch);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = jg::sync_copy(dst, stage, bytes, hipMemcpyDeviceToHost, h->stream);
-    hipFree(stage);
-    GN_HIP(e);
+    if (int rc = stage_room(h, bytes)) return rc;
+    hipLaunchKernelGGL(k_gn_collect_rows, dim3((unsigned)((rows + 63) / 64), h->ld / 64), dim3(64, 8), 0, h->stream, src, h->d_stage, (int)rows, h->ld, h->batch);
+    GN_HIP(hipGetLastError());
+    GN_HIP(jg::sync_copy(dst, h->d_stage, bytes, hipMemcpyDeviceToHost, h->stream));
     return 0;
 }
 
@@ -1310,7 +1314,7 @@ void jg_gn_destroy(jg_gn* h) {
     hipFree(h->d_arena);                                         // V, theta, z, weights, slots, residual, rhs, increment, norms, lane bookkeeping: one allocation (jg_gn_create)
     hipFree(h->d_pair_ptr); hipFree(h->d_pa); hipFree(h->d_pb); hipFree(h->d_pz); hipFree(h->d_nres); hipFree(h->d_amax_v); hipFree(h->d_amax_i);
     hipFree(h->d_bad_v); hipFree(h->d_bad_i);
-    hipFree(h->d_obj); hipFree(h->d_objpart); hipFree(h->d_corr); hipFree(h->d_noise); hipFree(h->d_noise_bad);
+    hipFree(h->d_obj); hipFree(h->d_objpart); hipFree(h->d_corr); hipFree(h->d_noise); hipFree(h->d_noise_bad); hipFree(h->d_stage);
     hipFree(h->d_grec); hipFree(h->d_gwave); hipFree(h->d_rrec); hipFree(h->d_rwave); hipFree(h->d_gtask); hipFree(h->d_gstage); hipFree(h->d_trec);
     if (h->h_counter) hipHostFree(h->h_counter);
     if (h->stream) hipStreamDestroy(h->stream);
