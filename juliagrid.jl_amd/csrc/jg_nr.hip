@@ -776,6 +776,7 @@ struct jg_nr {
     bool paused = false;             // jg_nr_run_defer stopped with scenarios still active (lanes compacted, not yet sent home)
     int* d_move = nullptr;           // straggler hand-off: map[64] | home[64] | count[1] (device), home/count mirrored in h_move (pinned)
     int* h_move = nullptr;
+    double host_launch_us = 0.0, host_wait_us = 0.0; long long host_iters = 0;   // JG_HOST_TIMING=1: what the host spent in hipGraphLaunch / waiting per iteration of run_loop
     double wait_us = 0.0;            // how long the host waited for the last verdicts (running mean; wait_verdict: polls the pinned word while this is short)
     int* h_counter = nullptr;        // pinned
     int* h_counter_dev = nullptr;    // its device alias
@@ -1159,6 +1160,9 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
 }
 
 void jg_nr_destroy(jg_nr* h) {
+    if (h && getenv("JG_HOST_TIMING") && h->host_iters > 0)
+        fprintf(stderr, "[jg host timing] %d lanes: %lld iterations, hipGraphLaunch %.1f us, wait for the verdict %.1f us per iteration\n", h->ld, h->host_iters,
+                h->host_launch_us / h->host_iters, h->host_wait_us / h->host_iters);
     if (!h) return;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
@@ -1528,8 +1532,10 @@ int run_loop(jg_nr* h, int64_t max_iter, int defer_at) {
         if (trace) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, h->stream); }
         if (!trace) arm_verdict(h);
         NR_HIP(hipGraphLaunch(h->execB, h->stream));                           // solve!, then mismatch! and the verdict on the new state
+        const double tl = now_us();
         if (trace) hipEventRecord(e1, h->stream);
         NR_HIP(trace ? hipStreamSynchronize(h->stream) : wait_verdict(h));
+        h->host_launch_us += tl - tc; h->host_wait_us += now_us() - tl; h->host_iters += 1;     // JG_HOST_TIMING: printed when the handle goes
         if (trace) {
             float ms = 0.f; hipEventElapsedTime(&ms, e0, e1); fprintf(stderr, "[jg_nr_run] graph on the device: %.1f us\n", 1e3 * ms); hipEventDestroy(e0); hipEventDestroy(e1);
             int cf[4];
