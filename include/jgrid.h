@@ -24,6 +24,7 @@ extern "C" {
 #endif
 
 typedef struct jg_nr jg_nr;
+typedef struct jg_nr_base jg_nr_base;
 typedef struct jg_gn jg_gn;
 
 const char* jg_last_error(void);
@@ -146,6 +147,46 @@ int jg_nr_move_lanes(jg_nr* dst, int64_t dst_lane0, jg_nr* src, int32_t* home, i
 int jg_nr_finish(jg_nr* h, int32_t* iters, int32_t* status);
 int jg_nr_resume(jg_nr* h, int64_t lanes, int64_t max_iter, double tol, int32_t* iters, int32_t* status);
 int jg_nr_pack_rows_device(jg_nr* h, double* dst_dev, int64_t lane0, int64_t count, const int32_t* rows);
+
+/*
+ * The FIRST iteration of a batch whose scenarios all start from one state, on ONE shared factor (compensation method) -- what replaces, for the
+ * user loop of an N-1 screen (src/powerSystem/branch.jl:453-459: updateBranch!(analysis; label, status = 0), setInitialPoint!, powerFlow!), the first
+ * lu! + ldiv! of every scenario (src/powerFlow/acPowerFlow.jl:890-897; src/backend/utility.jl:478-484, 576-586).  At the common start the Jacobian of
+ * scenario s is J_0 + E M_s F' with M_s the change of the <= 4 blocks of the two buses its Ybus edits touch, so its Newton step is
+ *     x_s = J_0^-1 (f_s - E c_s),   c_s = M_s (I + S_s M_s)^-1 F' J_0^-1 f_s,   S_s = the 4 x 4 of J_0^-1 at those buses
+ * -- one factorisation per BASE CASE instead of one per scenario; the batch pays a mismatch pass, a correction of <= 4 numbers per scenario and one
+ * sweep pair whose factor values are shared (scalar loads).  Iterations >= 2 refactorise as before.  Results agree with the refactorising path to
+ * rounding (the step is the same Newton step); a scenario whose 4 x 4 system is singular -- the outage islands a part of the grid -- ends with
+ * status 3, like a cancelled pivot of the batched factorisation.
+ *   jg_nr_base_create   `single`: a handle with batch = 1 whose CURRENT nodal matrix, injections and voltages are the base case and the common
+ *                       start (e.g. its converged power flow).  Factorises its Jacobian once, forms J_0^-1 f_0, the blocks of J_0^-1 on the Ybus
+ *                       pattern and the dense inverse of the top of the elimination tree (top_cap: at most this many pivots there; 0 = default
+ *                       512, < 0 = none: every level a launch).  The base keeps copies: `single` may be reused or destroyed afterwards.
+ *                       rc 3: the base Jacobian is singular.
+ *   jg_nr_base_destroy  releases the caller's reference (the memory goes when the last attached handle lets go).
+ *   jg_nr_attach_base   the scenarios of h may start from this base (same grid, bus types and device; NULL detaches).  jg_nr_set_ybus detaches.
+ *   jg_nr_start_from_base   V, theta of EVERY scenario of h = the base's start (device-side broadcast; replaces jg_nr_restore_voltage in the loop).
+ *   jg_nr_run / jg_nr_run_defer then take the shared-factor iteration BY THEMSELVES when (a) the state is untouched since jg_nr_start_from_base,
+ *                       (b) every scenario's Ybus edits (jg_nr_patch_ybus*) lie in the rows / columns of at most two buses joined by an edited
+ *                       entry -- a branch outage or parameter change, a shunt change --, (c) scenarios with edits keep the base's injections
+ *                       (checked on the device once per jg_nr_set_injection; scenarios WITHOUT edits may have any injections: Monte-Carlo
+ *                       variations solve J_0 x = f_s directly), (d) no refinement (jg_nr_set_refine); otherwise they refactorise as always.
+ *   jg_nr_set_first_iteration   mode 0: always refactorise (the A/B switch of bench.py's value_full_refactor); 1 (default): as above.
+ *   jg_nr_first_iteration_counts   how many runs of h started the one way / the other (NULL: not wanted).
+ *   jg_nr_base_info     info[8] = pivots in the dense top, forward level above which a pivot belongs to it, forward / backward level launches of a
+ *                       sweep pair, the same two without a top (the set-up solver), creation time in microseconds, attached handles.
+ *   jg_nr_base_get      test access: which = 0 J_0^-1 on the Ybus pattern [nnz][4] (row-CSR position (i, j) of the stored pattern: block
+ *                       (theta_i, V_i) x (P_j, Q_j), row-major), 1 J_0^-1 f_0 [n][2], 2 f_0 [n][2], 3 the dense inverse of the top's Schur
+ *                       complement (rows of the leading dimension info reports as cap / (2 pivots)), 4 the compact factor [entries][4].
+ */
+int jg_nr_base_create(jg_nr_base** out, jg_nr* single, int64_t top_cap);
+void jg_nr_base_destroy(jg_nr_base* b);
+int jg_nr_base_info(jg_nr_base* b, int64_t* info);
+int jg_nr_base_get(jg_nr_base* b, int which, double* out, int64_t cap);
+int jg_nr_attach_base(jg_nr* h, jg_nr_base* b);
+int jg_nr_start_from_base(jg_nr* h);
+int jg_nr_set_first_iteration(jg_nr* h, int mode);
+int jg_nr_first_iteration_counts(jg_nr* h, int64_t* compensated, int64_t* refactorised);
 
 /* analysis.method.{mismatch,increment,jacobian.nzval} in the reference's own ordering
  * (rows/cols pvpq then pq; CSC of newtonJacobian).  [batch][dimJ] / [batch][nnzJ]. */

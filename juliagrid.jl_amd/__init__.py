@@ -8,7 +8,8 @@ from .system import addBranch_ as addBranchSystem_, dropZeros_ as dropZerosSyste
 from .system import (updateBranch_ as updateBranchSystem_, updateBus_ as updateBusSystem_,   # noqa: F401
                      updateGenerator_ as updateGeneratorSystem_)
 from .powerflow import (AcPowerFlow, newtonRaphson, fastNewtonRaphsonBX, fastNewtonRaphsonXB, mismatch_, solve_, powerFlow_, setInitialPoint_, setRefinement_,   # noqa: F401
-                        updateBranch_, updateBus_, updateGenerator_, addBranch_, dropZeros_, setOutage_, setOutages_, setInjection_, outagePatch, fastOutagePatch, initializeACPowerFlow, power_, current_, screenSummary_, reactiveLimit_, adjustAngle_)
+                        updateBranch_, updateBus_, updateGenerator_, addBranch_, dropZeros_, setOutage_, setOutages_, setInjection_, outagePatch, fastOutagePatch, initializeACPowerFlow, power_, current_, screenSummary_, reactiveLimit_, adjustAngle_,
+                        BaseCase, startFromBase_, setFirstIteration_, firstIterationCounts)
 from .contingency import bridges, outageList, shard, deviceBatching, contingencyAnalysis, gatherResults, gatherResultsDevice, unpackResults, ContingencyPipeline   # noqa: F401
 from .measurement import (Measurement, measurement, ems, addVoltmeter_, addAmmeter_, addWattmeter_, addVarmeter_,   # noqa: F401
                           addPmu_, exactQuantities)
@@ -30,4 +31,5 @@ __all__ = [
     "outagePatch", "fastOutagePatch", "initializeACPowerFlow", "bridges", "outageList", "shard", "deviceBatching", "contingencyAnalysis", "gatherResults", "gatherResultsDevice", "unpackResults",
     "WlsMethod", "Normal", "LU", "KLU", "QR", "LDLt", "LL", "Orthogonal", "PetersWilkinson",
     "addBranch_", "dropZeros_", "addBranchSystem_", "dropZerosSystem_", "pegaseShaped", "case9241synth", "ContingencyPipeline", "MonteCarloPipeline", "gatherEstimates", "gatherEstimatesDevice", "unpackEstimates", "setOutages_", "power_", "current_", "screenSummary_", "reactiveLimit_", "adjustAngle_",
+    "BaseCase", "startFromBase_", "setFirstIteration_", "firstIterationCounts",
 ]

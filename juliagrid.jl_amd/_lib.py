@@ -125,6 +125,13 @@ def lib():
         "jg_comm_world": [VP],
         "jg_comm_allgather_device": [VP, VP, VP, C.c_int64],
         "jg_nr_allgather_results": [VP, VP, VP],
+        "jg_nr_base_create": [C.POINTER(VP), VP, C.c_int64],
+        "jg_nr_base_info": [VP, I64P],
+        "jg_nr_base_get": [VP, C.c_int, F64P, C.c_int64],
+        "jg_nr_attach_base": [VP, VP],
+        "jg_nr_start_from_base": [VP],
+        "jg_nr_set_first_iteration": [VP, C.c_int],
+        "jg_nr_first_iteration_counts": [VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
     }
     for name, args in sig.items():
         f = getattr(L, name)
@@ -134,6 +141,8 @@ def lib():
     L.jg_nr_destroy.restype = None
     L.jg_gn_destroy.argtypes = [VP]
     L.jg_gn_destroy.restype = None
+    L.jg_nr_base_destroy.argtypes = [VP]
+    L.jg_nr_base_destroy.restype = None
     L.jg_plan_cache_clear.argtypes = []
     L.jg_plan_cache_clear.restype = None
     L.jg_comm_destroy.argtypes = [VP]

@@ -5,7 +5,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["jg_symbolic.cpp", "jg_plan_api.cpp", "jg_comm.cpp", "jg_engine.hip", "jg_nr.hip", "jg_gn.hip"]
+SOURCES = ["jg_symbolic.cpp", "jg_plan_api.cpp", "jg_comm.cpp", "jg_engine.hip", "jg_comp.hip", "jg_nr.hip", "jg_gn.hip"]
 LIB = os.environ.get("JG_LIB_OUT") or os.path.join(HERE, "libjgrid_hip.so")     # JG_LIB_OUT: build a variant somewhere else (JG_EXTRA_HIPCC_FLAGS)
 
 

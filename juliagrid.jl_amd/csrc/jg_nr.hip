@@ -30,6 +30,7 @@
 
 #include "../../include/jgrid.h"
 #include "jg_engine.hpp"
+#include "jg_comp.hpp"
 
 namespace {
 
@@ -780,11 +781,55 @@ struct jg_nr {
     double wait_us = 0.0;            // how long the host waited for the last verdicts (running mean; wait_verdict: polls the pinned word while this is short)
     int* h_counter = nullptr;        // pinned
     int* h_counter_dev = nullptr;    // its device alias
+    // ---- first iteration on a shared factor (jg_comp.hpp; jg_nr_attach_base) ----
+    std::vector<int> csr_row, csr_col;                // Ybus row-CSR position -> (row, column)
+    jg_nr_base* base = nullptr;                       // the base case this handle's scenarios start from (nullptr: none attached)
+    double* d_cw = nullptr;                           // scratch of the shared-factor sweeps [(n + top rows)][ld][2]
+    bool start_is_base = false;                       // V, theta of every lane = the base's start (jg_nr_start_from_base; any other write clears it)
+    int first_mode = 1;                               // jg_nr_set_first_iteration: 1 = compensated when the conditions hold, 0 = always refactorise
+    std::vector<unsigned char> patch_state;           // [batch] 0 no edit, 1 edits within two adjacent buses (compensable), 2 other
+    bool inj_checked = false, inj_equal = false;      // the lanes' injections were compared with the base's / equal it
+    int* d_cmp = nullptr;                             // one word: mismatching injections (inj check)
+    hipGraph_t graphA2 = nullptr, graphC = nullptr;
+    hipGraphExec_t execA2 = nullptr, execC = nullptr;
+    long long first_comp = 0, first_full = 0;         // runs whose first iteration went the one / the other way (jg_nr_first_iteration_counts)
+};
+
+// The base case of a screen: ONE factorisation of the Jacobian at the common start state and what the per-scenario corrections read (jg_comp.hpp).
+struct jg_nr_base {
+    jg::CompBase cb;
+    int n = 0, nnz = 0, device = 0;
+    std::vector<int64_t> colptr, rowval;
+    std::vector<int8_t> type;
+    hipStream_t stream = nullptr;
+    std::atomic<int> refs{1};                         // the creator + every attached handle
+    double create_ms = 0.0;
 };
 
 namespace {
 
 int set_device(jg_nr* h) { NR_HIP(hipSetDevice(h->device)); return 0; }
+
+// What the first iteration on a shared factor may assume of a scenario's Ybus edits (jg_comp.hpp): they lie in the rows / columns of at most two buses,
+// and two buses are joined by one of the edited entries (so J_0^-1 has their blocks on the Ybus pattern) -- what a branch outage / parameter change / a
+// shunt change produce.  pos: row-CSR positions (-1 = none).
+unsigned char classify_patch(const jg_nr* h, const int* pos, int k) {
+    int a = -1, b = -1;
+    bool any = false, joined = false;
+    for (int m = 0; m < k; ++m) {
+        if (pos[m] < 0) continue;
+        any = true;
+        const int ij[2] = {h->csr_row[pos[m]], h->csr_col[pos[m]]};
+        for (int q = 0; q < 2; ++q) {
+            if (a < 0 || ij[q] == a) a = ij[q];
+            else if (b < 0 || ij[q] == b) b = ij[q];
+            else return 2;
+        }
+        if (ij[0] != ij[1]) joined = true;
+    }
+    if (!any) return 0;
+    return (b < 0 || joined) ? 1 : 2;
+}
 
 jg::GroupSel active_groups(jg_nr* h) { return jg::GroupSel{nullptr, h->d_glist, h->d_cflags + 3}; }
 
@@ -965,6 +1010,94 @@ int build_graphs(jg_nr* h) {
     return 0;
 }
 
+void drop_comp_graphs(jg_nr* h) {
+    if (h->execA2) { hipGraphExecDestroy(h->execA2); h->execA2 = nullptr; }
+    if (h->graphA2) { hipGraphDestroy(h->graphA2); h->graphA2 = nullptr; }
+    if (h->execC) { hipGraphExecDestroy(h->execC); h->execC = nullptr; }
+    if (h->graphC) { hipGraphDestroy(h->graphC); h->graphC = nullptr; }
+}
+
+void release_base(jg_nr_base* b) {
+    if (!b) return;
+    if (b->refs.fetch_sub(1) == 1) {
+        hipSetDevice(b->device);
+        b->cb.destroy();
+        if (b->stream) hipStreamDestroy(b->stream);
+        delete b;
+    }
+}
+
+void detach_base(jg_nr* h) {
+    if (!h->base) return;
+    if (h->stream) hipStreamSynchronize(h->stream);
+    drop_comp_graphs(h);
+    hipFree(h->d_cw); h->d_cw = nullptr;
+    release_base(h->base);
+    h->base = nullptr;
+    h->start_is_base = false;
+}
+
+// The two graphs of a compensated start (jg_comp.hpp).  A2: the verdict on the start point from a MISMATCH-ONLY pass (no Jacobian is assembled: nobody
+// factorises it).  C: the first iteration -- per-scenario correction of the right-hand side, ONE sweep pair on the base's factor with the state update
+// fused in, then the usual verdict on the new state (which assembles the Jacobian the second iteration factorises).
+int build_comp_graphs(jg_nr* h) {
+    if (h->execC) return 0;
+    const jg::CompBase& cb = h->base->cb;
+    std::lock_guard<std::mutex> lk(jg::capture_mutex());
+    NR_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    launch_assemble(h, active_groups(h), false);
+    launch_check(h, 1, h->d_group);
+    launch_compact(h, 0, true);
+    if (h->ld > 64) launch_assemble(h, active_groups(h), false, nullptr, 0, h->d_cflags);      // lanes moved: their mismatch rows again
+    NR_HIP(hipStreamEndCapture(h->stream, &h->graphA2));
+    NR_HIP(hipGraphInstantiate(&h->execA2, h->graphA2, nullptr, nullptr, 0));
+    NR_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    jg::CompFixArgs fa{h->d_ppos, h->d_pdg, h->d_pdb, h->mp, cb.rowptr, cb.colm, cb.posrow, cb.rowtype, cb.v0, cb.th0, cb.y0, cb.Zc,
+                       h->d_F, h->eng.status, h->d_active, h->ld, h->batch};
+    if (h->mp > 0) jg::launch_comp_fix(fa, h->stream);
+    jg::StateUpdate upd{h->d_va, h->d_vm, h->d_flags, h->d_active, -1.0};
+    const int rc = cb.solve(cb.split, h->stream, h->d_F, h->d_cw, h->d_inc, h->ld, h->batch, upd, active_groups(h));
+    launch_assemble(h, active_groups(h), true, nullptr, 0, nullptr, true);
+    launch_check(h, 1, h->d_group);
+    launch_compact(h, 0, true);
+    if (h->ld > 64) launch_assemble(h, active_groups(h), true, nullptr, 0, h->d_cflags, true);
+    hipError_t e = hipStreamEndCapture(h->stream, &h->graphC);
+    if (rc) return fail(rc, "the shared-factor sweep could not be captured");
+    NR_HIP(e);
+    NR_HIP(hipGraphInstantiate(&h->execC, h->graphC, nullptr, nullptr, 0));
+    return 0;
+}
+
+// mismatching injections between the lanes and the base (one word)
+__global__ void k_cmp_injection(const double* p, const double* q, const double* p0, const double* q0, int n, int ld, int batch, int* count) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    int bad = 0;
+    for (int i = blockIdx.y; i < n; i += gridDim.y) bad += (p[(size_t)i * ld + b] != p0[i]) || (q[(size_t)i * ld + b] != q0[i]);
+    if (bad) atomicAdd(count, bad);
+}
+
+// Does the next run start with the compensated iteration?  (every condition the algebra of jg_comp.hpp rests on)
+int comp_ready(jg_nr* h, bool& ready) {
+    ready = false;
+    if (!h->base || !h->first_mode || !h->start_is_base || h->refine || h->fast) return 0;
+    bool patched = false;
+    for (unsigned char c : h->patch_state) { if (c == 2) return 0; patched |= c == 1; }
+    if (patched) {                                               // an outage moves the mismatch of its two buses only if the injections are the base's
+        if (!h->inj_checked) {
+            NR_HIP(hipMemsetAsync(h->d_cmp, 0, sizeof(int), h->stream));
+            hipLaunchKernelGGL(k_cmp_injection, dim3((h->batch + 255) / 256, 64), dim3(256), 0, h->stream, h->d_p, h->d_q, h->base->cb.p0, h->base->cb.q0, h->n, h->ld, h->batch, h->d_cmp);
+            int bad = 0;
+            NR_HIP(jg::sync_copy(&bad, h->d_cmp, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            h->inj_checked = true; h->inj_equal = bad == 0;
+        }
+        if (!h->inj_equal) return 0;
+    }
+    if (int rc = build_comp_graphs(h)) return rc;
+    ready = true;
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1032,6 +1165,10 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
     std::thread eng_thread;
     try { eng_thread = std::thread(eng_work); } catch (const std::system_error&) { eng_work(); }     // no thread to be had: the analysis first, then the rest
     struct JoinEng { std::thread& t; ~JoinEng() { if (t.joinable()) t.join(); } } join_eng{eng_thread};     // every early return waits for it before the handle goes
+    h->csr_col = cl;
+    h->csr_row.assign(nnz, 0);
+    for (int i = 0; i < n; ++i) for (int p = rp[i]; p < rp[i + 1]; ++p) h->csr_row[p] = i;
+    h->patch_state.assign((size_t)batch, 0);
     // transpose permutation of the (structurally symmetric) pattern: tperm[p of (r,c)] = pointer of (c,r)
     h->tperm.assign(nnz, -1);
     for (int c = 0; c < n; ++c)
@@ -1166,6 +1303,8 @@ void jg_nr_destroy(jg_nr* h) {
     if (!h) return;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
+    detach_base(h);
+    hipFree(h->d_cmp);
     if (h->d_move) { hipFree(h->d_move); hipHostFree(h->h_move); }
     if (h->execA) hipGraphExecDestroy(h->execA);
     if (h->execB) hipGraphExecDestroy(h->execB);
@@ -1204,6 +1343,7 @@ int jg_nr_set_injection(jg_nr* h, const double* p, const double* q, int64_t stri
     if (int rc = put_bus_array(h, h->d_p, p, stride)) return rc;
     if (int rc = put_bus_array(h, h->d_q, q, stride)) return rc;
     h->jac_valid = false;
+    h->inj_checked = false;                                      // compared with the base's again before the next compensated start
     return 0;
 }
 
@@ -1214,6 +1354,7 @@ int jg_nr_set_voltage(jg_nr* h, const double* vm, const double* va, int64_t stri
     if (int rc = put_bus_array(h, h->d_vm, vm, stride)) return rc;
     if (int rc = put_bus_array(h, h->d_va, va, stride)) return rc;
     h->jac_valid = false;
+    h->start_is_base = false;
     return 0;
 }
 
@@ -1281,6 +1422,7 @@ int jg_nr_restore_voltage(jg_nr* h) {
     NR_HIP(hipMemcpyAsync(h->d_vm, h->d_vm0, bytes, hipMemcpyDeviceToDevice, h->stream));
     NR_HIP(hipMemcpyAsync(h->d_va, h->d_va0, bytes, hipMemcpyDeviceToDevice, h->stream));
     h->jac_valid = false;
+    h->start_is_base = false;
     return 0;
 }
 
@@ -1328,6 +1470,8 @@ int jg_nr_patch_ybus(jg_nr* h, int64_t scenario, int64_t k, const int64_t* ptr, 
         return fail(1, "jg_nr_patch_ybus: bad argument (scenario / entry count beyond max_patch)");
     if (int rc = set_device(h)) return rc;
     NR_HIP(hipStreamSynchronize(h->stream));
+    int allpos[8];
+    for (int m = 0; m < 8; ++m) allpos[m] = -1;
     for (int m = 0; m < h->mp; ++m) {
         int pos = -1; double g = 0.0, b = 0.0;
         if (m < k) {
@@ -1335,11 +1479,13 @@ int jg_nr_patch_ybus(jg_nr* h, int64_t scenario, int64_t k, const int64_t* ptr, 
             pos = h->tperm[ptr[m] - 1]; g = dy[2 * m]; b = dy[2 * m + 1];
             for (int mm = 0; mm < m; ++mm) if (ptr[mm] == ptr[m]) return fail(1, "jg_nr_patch_ybus: duplicate pointer");
         }
+        allpos[m] = pos;
         const size_t off = (size_t)m * h->ld + scenario;
         NR_HIP(jg::sync_copy(h->d_ppos + off, &pos, sizeof(int), hipMemcpyHostToDevice, h->stream));
         NR_HIP(jg::sync_copy(h->d_pdg + off, &g, sizeof(double), hipMemcpyHostToDevice, h->stream));
         NR_HIP(jg::sync_copy(h->d_pdb + off, &b, sizeof(double), hipMemcpyHostToDevice, h->stream));
     }
+    h->patch_state[(size_t)scenario] = classify_patch(h, allpos, h->mp);
     h->jac_valid = false;
     return 0;
 }
@@ -1349,7 +1495,7 @@ int jg_nr_patch_ybus_batch(jg_nr* h, int64_t scenario0, int64_t count, int64_t k
         return fail(1, "jg_nr_patch_ybus_batch: bad argument (scenario range / entry count beyond max_patch)");
     if (int rc = set_device(h)) return rc;
     NR_HIP(hipStreamSynchronize(h->stream));
-    std::vector<int> pos((size_t)count);
+    std::vector<int> pos((size_t)count), allpos((size_t)count * 8, -1);
     std::vector<double> g((size_t)count), b((size_t)count);
     for (int m = 0; m < h->mp; ++m) {
         for (int64_t s = 0; s < count; ++s) {
@@ -1360,12 +1506,14 @@ int jg_nr_patch_ybus_batch(jg_nr* h, int64_t scenario0, int64_t count, int64_t k
                 for (int mm = 0; mm < m; ++mm) if (ptr[s * k + mm] == p) return fail(1, "jg_nr_patch_ybus_batch: duplicate pointer");
                 pos[s] = h->tperm[p - 1]; g[s] = dy[2 * (s * k + m)]; b[s] = dy[2 * (s * k + m) + 1];
             }
+            allpos[(size_t)s * 8 + m] = pos[s];
         }
         const size_t off = (size_t)m * h->ld + scenario0;
         NR_HIP(jg::sync_copy(h->d_ppos + off, pos.data(), (size_t)count * sizeof(int), hipMemcpyHostToDevice, h->stream));
         NR_HIP(jg::sync_copy(h->d_pdg + off, g.data(), (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->stream));
         NR_HIP(jg::sync_copy(h->d_pdb + off, b.data(), (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->stream));
     }
+    for (int64_t s = 0; s < count; ++s) h->patch_state[(size_t)(scenario0 + s)] = classify_patch(h, &allpos[(size_t)s * 8], h->mp);
     h->jac_valid = false;
     return 0;
 }
@@ -1384,6 +1532,7 @@ int jg_nr_set_ybus(jg_nr* h, const double* y_reim, const double* yt_reim) {
     for (int p = 0; p < h->nnz; ++p) GBv[p] = double2{G[p], B[p]};
     NR_HIP(jg::sync_copy(h->d_GB, GBv.data(), GBv.size() * sizeof(double2), hipMemcpyHostToDevice, h->stream));
     h->jac_valid = false;
+    detach_base(h);                                              // an attached base was factorised for the old nodal matrix
     return 0;
 }
 
@@ -1407,6 +1556,7 @@ int jg_nr_solve(jg_nr* h) {
     if (h->fast) return fail(1, "jg_nr_solve: this handle runs fast Newton-Raphson; use jg_nr_fast_solve");
     if (int rc = set_device(h)) return rc;
     if (!h->jac_valid) launch_assemble(h);
+    h->start_is_base = false;
     h->f_stale = false;                                          // method.mismatch = the mismatch this step started from, for every scenario
     NR_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
     if (int rc = newton_step(h, jg::GroupSel{}, nullptr)) return fail(rc, h->eng.error);
@@ -1547,6 +1697,31 @@ int run_loop(jg_nr* h, int64_t max_iter, int defer_at) {
     return 0;
 }
 
+// The verdict on the start point and -- when every scenario starts from the attached base case (comp_ready) -- the first iteration on the base's
+// shared factor instead of a batched refactorisation (jg_comp.hpp).  The loop (run_loop) continues with refactorising iterations either way.
+int run_start(jg_nr* h, int64_t max_iter) {
+    bool comp = false;
+    if (int rc = comp_ready(h, comp)) return rc;
+    h->start_is_base = false;                                                  // whatever follows moves the state
+    arm_verdict(h);
+    NR_HIP(hipGraphLaunch(comp ? h->execA2 : h->execA, h->stream));
+    NR_HIP(wait_verdict(h));
+    if (!comp) { h->first_full += 1; return 0; }
+    h->first_comp += 1;
+    if (max_iter < 1 || *h->h_counter == 0) {                                  // nothing to iterate: the Jacobian getters find no assembly in place
+        h->jac_valid = false;
+        return 0;
+    }
+    const bool trace = getenv("JG_TRACE") != nullptr;
+    const double t0 = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    arm_verdict(h);
+    NR_HIP(hipGraphLaunch(h->execC, h->stream));
+    NR_HIP(wait_verdict(h));
+    if (trace) fprintf(stderr, "[jg_nr_run] iteration 1 on the shared base factor: %.1f us, %d scenarios still active\n",
+                       std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0, *h->h_counter);
+    return 0;
+}
+
 // End of a batched solve: lanes back to their home order, method.mismatch of every scenario at its final state, outputs.
 int run_finish(jg_nr* h, int32_t* iters, int32_t* status) {
     launch_compact(h, 1);                                                      // lanes back to their home order
@@ -1564,14 +1739,160 @@ int run_finish(jg_nr* h, int32_t* iters, int32_t* status) {
 
 }  // namespace
 
+
+// ---- first iteration of a common-start batch on ONE shared factor (jg_comp.hpp) -------------------------------------------------------
+__global__ void k_lane0(const double* src, double* dst, int n, int ld, int elem) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int c = 0; c < elem; ++c) dst[(size_t)i * elem + c] = src[((size_t)i * ld) * elem + c];
+}
+__global__ void k_broadcast(const double* src, double* dst, int n, int ld) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (b < ld) dst[(size_t)i * ld + b] = src[i];
+}
+
+int jg_nr_base_create(jg_nr_base** out, jg_nr* s, int64_t top_cap) {
+    if (!out || !s) return fail(1, "jg_nr_base_create: bad argument");
+    if (s->fast || s->refine) return fail(1, "jg_nr_base_create: the single-instance handle must run plain Newton-Raphson");
+    if (s->batch != 1) return fail(1, "jg_nr_base_create: pass a single-instance handle (batch = 1) that holds the base case's grid, injections and start state");
+    if (int rc = set_device(s)) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    NR_HIP(hipStreamSynchronize(s->stream));
+    // ONE factorisation of the Jacobian at the start state, plain rows (the compact factor is read from the entries), and y0 = J_0^-1 f_0
+    const bool jordan = s->eng.jordan;
+    s->eng.jordan = false;
+    NR_HIP(hipMemsetAsync(s->eng.status, 0, (size_t)s->ld * 4, s->stream));
+    launch_assemble(s, jg::GroupSel{}, true, nullptr, 0, nullptr, true);
+    int rc = s->eng.factor(s->stream, nullptr, s->d_F, jg::GroupSel{}, s->level0_done);
+    if (!rc) rc = s->eng.backsolve(s->stream, s->d_inc, jg::StateUpdate{}, jg::GroupSel{});
+    s->eng.jordan = jordan;
+    s->jac_valid = false;
+    if (rc) return fail(rc, s->eng.error);
+    NR_HIP(hipStreamSynchronize(s->stream));
+    int st0 = 0;
+    NR_HIP(jg::sync_copy(&st0, s->eng.status, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    if (st0 & 4) return fail(3, "jg_nr_base_create: zero or non-finite pivot (the Jacobian of the base case is singular)");
+    jg_nr_base* b = new jg_nr_base();
+    b->n = s->n; b->nnz = s->nnz; b->device = s->device;
+    b->colptr = s->colptr; b->rowval = s->rowval; b->type = s->type;
+    jg::CompBase& cb = b->cb;
+    cb.nnz = s->nnz;
+    auto bail = [&](int code, const std::string& m) { release_base(b); return fail(code, m); };
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) return bail(2, "jg_nr_base_create: stream creation failed");
+    const int n = s->n, nnz = s->nnz;
+    std::string err;
+    {   // the Ybus pattern as the correction kernel reads it: row of a position, position of the transposed entry
+        std::vector<int> rp(n + 1), tp(nnz, -1);
+        for (int i = 0; i <= n; ++i) rp[i] = (int)(s->colptr[i] - 1);
+        for (int p = 0; p < nnz; ++p) {
+            const int i = s->csr_row[p], j = s->csr_col[p];
+            const int* lo = s->csr_col.data() + rp[j]; const int* hi = s->csr_col.data() + rp[j + 1];
+            const int* q = std::lower_bound(lo, hi, i);
+            tp[p] = (int)(q - s->csr_col.data());
+        }
+        if (jg::upload(&cb.rowptr, rp, err, b->stream) || jg::upload(&cb.posrow, s->csr_row, err, b->stream) || jg::upload(&cb.tpos, tp, err, b->stream)) return bail(2, err);
+        hipError_t e = hipMalloc((void**)&cb.colm, (size_t)nnz * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void**)&cb.rowtype, (size_t)n * sizeof(int));
+        if (e == hipSuccess) e = jg::sync_copy(cb.colm, s->d_col, (size_t)nnz * sizeof(int), hipMemcpyDeviceToDevice, b->stream);
+        if (e == hipSuccess) e = jg::sync_copy(cb.rowtype, s->d_rowtype, (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, b->stream);
+        for (double** q : {&cb.v0, &cb.th0, &cb.p0, &cb.q0}) if (e == hipSuccess) e = hipMalloc((void**)q, (size_t)n * sizeof(double));
+        for (double** q : {&cb.f0, &cb.y0}) if (e == hipSuccess) e = hipMalloc((void**)q, (size_t)n * 2 * sizeof(double));
+        if (e != hipSuccess) return bail(2, std::string("jg_nr_base_create: ") + hipGetErrorString(e));
+        const dim3 g((n + 255) / 256), t(256);
+        hipLaunchKernelGGL(k_lane0, g, t, 0, b->stream, (const double*)s->d_vm, cb.v0, n, s->ld, 1);
+        hipLaunchKernelGGL(k_lane0, g, t, 0, b->stream, (const double*)s->d_va, cb.th0, n, s->ld, 1);
+        hipLaunchKernelGGL(k_lane0, g, t, 0, b->stream, (const double*)s->d_p, cb.p0, n, s->ld, 1);
+        hipLaunchKernelGGL(k_lane0, g, t, 0, b->stream, (const double*)s->d_q, cb.q0, n, s->ld, 1);
+        hipLaunchKernelGGL(k_lane0, g, t, 0, b->stream, (const double*)s->d_F, cb.f0, n, s->ld, 2);
+        hipLaunchKernelGGL(k_lane0, g, t, 0, b->stream, (const double*)s->d_inc, cb.y0, n, s->ld, 2);
+        if (hipStreamSynchronize(b->stream) != hipSuccess) return bail(2, "jg_nr_base_create: copy of the base state failed");
+    }
+    // default top: what keeps the dense product near the cost of the level launches it replaces (10 000-bus grid: 502 pivots = the levels above the 11th)
+    const int cap = top_cap < 0 ? -1 : (top_cap == 0 ? 512 : (int)std::min<int64_t>(top_cap, 4096));
+    if (int rc2 = cb.create(s->eng.plan->S, s->eng.X, s->eng.ld, cap, b->stream)) return bail(rc2, "jg_nr_base_create: " + cb.error);
+    if (int rc2 = jg::comp_form_z(cb, b->stream)) return bail(rc2, "jg_nr_base_create: " + cb.error);
+    b->create_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    *out = b;
+    return 0;
+}
+
+void jg_nr_base_destroy(jg_nr_base* b) { release_base(b); }
+
+int jg_nr_base_info(jg_nr_base* b, int64_t* info) {
+    if (!b || !info) return fail(1, "jg_nr_base_info: bad argument");
+    const jg::CompBase& cb = b->cb;
+    info[0] = cb.split.T.n_top; info[1] = cb.split.T.split; info[2] = (int64_t)cb.split.fwd.size(); info[3] = (int64_t)cb.split.bwd.size();
+    info[4] = (int64_t)cb.full.fwd.size(); info[5] = (int64_t)cb.full.bwd.size(); info[6] = (int64_t)(b->create_ms * 1000.0); info[7] = b->refs.load() - 1;
+    return 0;
+}
+
+int jg_nr_base_get(jg_nr_base* b, int which, double* out, int64_t cap) {
+    if (!b || !out) return fail(1, "jg_nr_base_get: bad argument");
+    const jg::CompBase& cb = b->cb;
+    const double* src = nullptr; size_t count = 0;
+    switch (which) {
+        case 0: src = cb.Zc; count = (size_t)cb.nnz * 4; break;                                  // J_0^-1 on the Ybus pattern, row-CSR order
+        case 1: src = cb.y0; count = (size_t)cb.n * 2; break;
+        case 2: src = cb.f0; count = (size_t)cb.n * 2; break;
+        case 3: src = cb.Sinv; count = cb.Sinv ? (size_t)(2 * cb.split.T.n_top) * cb.lds : 0; break;   // rows of lds doubles
+        case 4: src = cb.Mc; count = (size_t)cb.n_entries * 4; break;
+        default: return fail(1, "jg_nr_base_get: which = 0 (inverse on the pattern) | 1 (J0^-1 f0) | 2 (f0) | 3 (dense top inverse) | 4 (compact factor)");
+    }
+    if ((int64_t)count > cap) return fail(1, "jg_nr_base_get: buffer too small");
+    NR_HIP(hipSetDevice(b->device));
+    if (count) NR_HIP(jg::sync_copy(out, src, count * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    return 0;
+}
+
+int jg_nr_attach_base(jg_nr* h, jg_nr_base* b) {
+    if (!h) return fail(1, "jg_nr_attach_base: bad argument");
+    if (int rc = set_device(h)) return rc;
+    detach_base(h);
+    if (!b) return 0;
+    if (h->fast) return fail(1, "jg_nr_attach_base: fast Newton-Raphson factorises constant matrices once anyway");
+    if (b->device != h->device || b->n != h->n || b->nnz != h->nnz || b->colptr != h->colptr || b->rowval != h->rowval || b->type != h->type)
+        return fail(1, "jg_nr_attach_base: the base was built for another grid (pattern, bus types) or device");
+    const size_t bytes = b->cb.scratch_rows(b->cb.split) * (size_t)h->ld * 2 * sizeof(double);
+    NR_HIP(hipMalloc((void**)&h->d_cw, bytes));
+    NR_HIP(jg::sync_fill(h->d_cw, 0, bytes, h->stream));
+    if (!h->d_cmp) NR_HIP(hipMalloc((void**)&h->d_cmp, sizeof(int)));
+    b->refs.fetch_add(1);
+    h->base = b;
+    h->inj_checked = false;
+    return 0;
+}
+
+int jg_nr_start_from_base(jg_nr* h) {
+    if (!h || !h->base) return fail(1, "jg_nr_start_from_base: no base attached (jg_nr_attach_base)");
+    if (int rc = set_device(h)) return rc;
+    const dim3 g((h->ld + 255) / 256, h->n), t(256);
+    hipLaunchKernelGGL(k_broadcast, g, t, 0, h->stream, (const double*)h->base->cb.v0, h->d_vm, h->n, h->ld);
+    hipLaunchKernelGGL(k_broadcast, g, t, 0, h->stream, (const double*)h->base->cb.th0, h->d_va, h->n, h->ld);
+    NR_HIP(hipGetLastError());
+    h->jac_valid = false;
+    h->start_is_base = true;
+    return 0;
+}
+
+int jg_nr_set_first_iteration(jg_nr* h, int mode) {
+    if (!h || mode < 0 || mode > 1) return fail(1, "jg_nr_set_first_iteration: mode = 0 (always refactorise) | 1 (shared base factor when the conditions hold)");
+    h->first_mode = mode;
+    return 0;
+}
+
+int jg_nr_first_iteration_counts(jg_nr* h, int64_t* compensated, int64_t* refactorised) {
+    if (!h) return fail(1, "jg_nr_first_iteration_counts: bad argument");
+    if (compensated) *compensated = h->first_comp;
+    if (refactorised) *refactorised = h->first_full;
+    return 0;
+}
+
 int jg_nr_run(jg_nr* h, int64_t max_iter, double tol, int32_t* iters, int32_t* status) {
     if (!h || max_iter < 0 || !(tol > 0.0)) return fail(1, "jg_nr_run: bad argument");
     if (h->fast) return fail(1, "jg_nr_run: this handle runs fast Newton-Raphson; use jg_nr_fast_run");
     if (int rc = set_device(h)) return rc;
     if (int rc = run_setup(h, max_iter, tol, h->batch, false)) return rc;
-    arm_verdict(h);
-    NR_HIP(hipGraphLaunch(h->execA, h->stream));                               // acPowerFlow.jl:1406: mismatch!, verdict
-    NR_HIP(wait_verdict(h));
+    if (int rc = run_start(h, max_iter)) return rc;                            // acPowerFlow.jl:1406: mismatch!, verdict (+ a compensated first iteration)
     if (int rc = run_loop(h, max_iter, 0)) return rc;
     return run_finish(h, iters, status);
 }
@@ -1581,9 +1902,7 @@ int jg_nr_run_defer(jg_nr* h, int64_t max_iter, double tol, int64_t defer_at, in
     if (h->fast) return fail(1, "jg_nr_run_defer: this handle runs fast Newton-Raphson");
     if (int rc = set_device(h)) return rc;
     if (int rc = run_setup(h, max_iter, tol, h->batch, false)) return rc;
-    arm_verdict(h);
-    NR_HIP(hipGraphLaunch(h->execA, h->stream));
-    NR_HIP(wait_verdict(h));
+    if (int rc = run_start(h, max_iter)) return rc;
     if (int rc = run_loop(h, max_iter, h->ld > 64 ? (int)defer_at : 0)) return rc;   // one lane group: lanes are never packed, nothing to hand off
     *n_left = *h->h_counter;
     h->paused = true;

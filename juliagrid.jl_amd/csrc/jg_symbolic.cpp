@@ -1055,6 +1055,74 @@ void build_selected_inverse(BlockSymbolic& S) {
     }, NoExtra(), 0, FACT_WAVES);
 }
 
+// Tables of the shared-factor solve (jg_symbolic.hpp: CompTables).  Forward levels follow the elimination tree (a row's lower entries are
+// its descendants), so "forward level > split" is closed under taking ancestors: the top is a union of root paths and no bottom row
+// depends on it; a top row's partial sum is levelled behind the bottom rows it reads.
+void build_comp_tables(const BlockSymbolic& S, int top_cap, CompTables& out) {
+    const int n = S.n;
+    out = CompTables();
+    std::vector<int> flev(n, 1);
+    int maxlev = 1;
+    for (int r = 0; r < n; ++r) {
+        for (int p = S.l_ptr[r]; p < S.l_ptr[r + 1]; ++p) flev[r] = std::max(flev[r], flev[S.l_col[p]] + 1);
+        maxlev = std::max(maxlev, flev[r]);
+    }
+    std::vector<int> count(maxlev + 2, 0);
+    for (int r = 0; r < n; ++r) count[flev[r]]++;
+    int split = maxlev;                                           // pivots with flev > split form the top
+    if (top_cap >= 0) {
+        int above = 0;
+        while (split > 1 && above + count[split] <= top_cap) { above += count[split]; --split; }
+    }
+    out.split = split;
+    out.tpos.assign(n, -1);
+    for (int r = 0; r < n; ++r) if (flev[r] > split) { out.tpos[r] = (int)out.top.size(); out.top.push_back(r); }
+    out.n_top = (int)out.top.size();
+    const std::vector<int>& tpos = out.tpos;
+    // forward: bottom rows with all their terms; top rows with their bottom terms, one level behind the last bottom row they read
+    {
+        std::vector<int> level(n, 0), work(n, 0);
+        for (int r = 0; r < n; ++r) {
+            if (tpos[r] < 0) { level[r] = flev[r]; work[r] = S.l_ptr[r + 1] - S.l_ptr[r]; continue; }
+            int l = 1, w = 0;
+            for (int p = S.l_ptr[r]; p < S.l_ptr[r + 1]; ++p) if (tpos[S.l_col[p]] < 0) { l = std::max(l, flev[S.l_col[p]] + 1); ++w; }
+            level[r] = l; work[r] = w;
+        }
+        build_replay(level, work, COMP_T, out.fwd_seg, out.fwd_rec, out.n_fwd_levels, [&](int k, int sub, int wpi, int rpw, Rec* r) {
+            for (int j = 0; j < rpw; ++j) { r[j].w[0] = tpos[k] < 0 ? k : n + tpos[k]; r[j].w[1] = S.perm[k]; r[j].w[2] = -1; r[j].w[3] = 0; }
+            int q = 0, seen = 0;
+            for (int p = S.l_ptr[k]; p < S.l_ptr[k + 1]; ++p) {
+                if (tpos[k] >= 0 && tpos[S.l_col[p]] >= 0) continue;                 // a top row leaves its top terms to the dense inverse
+                if (seen++ % wpi != sub) continue;
+                Rec& x = r[q / COMP_T];
+                const int s = 4 + 2 * (q % COMP_T);
+                x.w[s] = S.l_ent[p]; x.w[s + 1] = S.l_col[p];
+                x.w[3]++; ++q;
+            }
+        }, NoExtra(), 0, 8);
+    }
+    // backward: bottom rows only (the top writes x_T itself), levelled on the bottom columns they read
+    {
+        std::vector<int> level(n, 0), work(n, 0);
+        for (int r = n - 1; r >= 0; --r) {
+            if (tpos[r] >= 0) continue;
+            int l = 1;
+            for (int p = S.u_ptr[r]; p < S.u_ptr[r + 1]; ++p) if (tpos[S.u_col[p]] < 0) l = std::max(l, level[S.u_col[p]] + 1);
+            level[r] = l; work[r] = S.u_ptr[r + 1] - S.u_ptr[r];
+        }
+        build_replay(level, work, COMP_T, out.bwd_seg, out.bwd_rec, out.n_bwd_levels, [&](int k, int sub, int wpi, int rpw, Rec* r) {
+            for (int j = 0; j < rpw; ++j) { r[j].w[0] = k; r[j].w[1] = S.perm[k]; r[j].w[2] = S.diag[k]; r[j].w[3] = 0; }
+            int q = 0;
+            for (int p = S.u_ptr[k] + sub; p < S.u_ptr[k + 1]; p += wpi, ++q) {
+                Rec& x = r[q / COMP_T];
+                const int s = 4 + 2 * (q % COMP_T);
+                x.w[s] = S.u_ent[p]; x.w[s + 1] = S.u_col[p];
+                x.w[3]++;
+            }
+        }, NoExtra(), 0, 8);
+    }
+}
+
 int analyze(int n, const int* rowptr, const int* col, long long policy64, BlockSymbolic& S) {
     S = BlockSymbolic();
     const int policy = (int)(policy64 & 0x7fffffff);

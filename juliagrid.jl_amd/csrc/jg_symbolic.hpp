@@ -191,6 +191,31 @@ struct BlockSymbolic {
     long long top_terms = 0;            // update terms executed inside tasks
 };
 
+// ---- shared-factor solve (compensation, jg_comp.hip): tables of x = A^-1 r for MANY right-hand sides on ONE numeric factor ----------
+// When every scenario of a batch starts from one state (an N-1 screen from the base-case solution: the reference's user loop
+// updateBranch! -> powerFlow!, /root/reference/src/powerSystem/branch.jl:453-459 with lu! + ldiv! of acPowerFlow.jl:890-897), the first Newton
+// matrices differ from ONE matrix by a rank <= 4 term per scenario: the step is then a solve with the SHARED factor of that matrix
+// (values wave-uniform: scalar loads; only the right-hand sides are batch-minor) plus a 4 x 4 correction per scenario.
+// The factor being constant, the sequential top of the elimination tree is replaced by the explicit dense inverse of its Schur
+// complement (one GEMM-shaped launch instead of ~60 dependency levels), and only the wide bottom levels stay level launches:
+//   forward  (bottom rows, by level): y_k = r_k - sum_c [Lh(k,c) D(c)^-1] y_c;  top rows collect their bottom terms only -> yt_t (row n + t)
+//   top:                              x_T = Sinv * yt_T
+//   backward (bottom rows, by level): x_k = D(k)^-1 y_k - sum_c [D(k)^-1 U(k,c)] x_c
+// Record (both sweeps): w0 target row of W (pivot k, or n + t for the partial row of top pivot T[t]), w1 rhs row / bus (original index of the
+// pivot), w2 diagonal entry (backward; -1 forward), w3 terms, then COMP_T x (factor entry, W row).  top_cap < 0: no top (every pivot a level
+// item: the bootstrap solver that forms Sinv).
+constexpr int COMP_T = 6;
+struct CompTables {
+    int n_top = 0, split = 0;           // pivots of the dense top; forward level above which a pivot belongs to it
+    std::vector<int> top;               // [n_top] pivots, ascending
+    std::vector<int> tpos;              // [n] index in top, -1 = bottom pivot
+    std::vector<Segment> fwd_seg, bwd_seg;
+    std::vector<Rec> fwd_rec, bwd_rec;
+    int n_fwd_levels = 0, n_bwd_levels = 0;
+};
+// top_cap: at most this many pivots in the dense top (the split is the lowest forward level that satisfies it); < 0: none.
+void build_comp_tables(const BlockSymbolic& S, int top_cap, CompTables& out);
+
 // pattern: CSR (rowptr[n+1], col[nnz]) 0-based, must contain the diagonal and be structurally
 // symmetric. policy bit 0: in-place factor storage (see BlockSymbolic::inplace); bit 1: symmetric VALUES (LDL' by
 // reading U(k,i)' for Lh(i,k): half the update terms; only the blocks on and above the diagonal must be assembled).

@@ -223,6 +223,64 @@ class AcPowerFlow:
         return ms.value
 
 
+class BaseCase:
+    """The base case of a screen (jgrid.h: jg_nr_base_*): ONE factorisation of the Jacobian at the state every scenario starts from, shared by the
+    batched analyses attached to it -- their first Newton iteration is then a sweep pair on that factor plus a 4 x 4 correction per scenario instead
+    of a batched refactorisation (the compensation method; the reference refactorises per scenario, branch.jl:453-459 + acPowerFlow.jl:890-897).
+
+    `single`: a batch-1 analysis whose current voltages / injections / nodal matrix ARE the base case (typically after powerFlow_)."""
+
+    def __init__(self, single: "AcPowerFlow", top_cap: int = 0):
+        if single.batch != 1:
+            raise ValueError("BaseCase: pass a single-instance analysis")
+        self._h = _lib.VP()
+        _lib.check(_lib.lib().jg_nr_base_create(C.byref(self._h), single._h, int(top_cap)))
+        self.n = single.system.bus.number
+        self.nnz = single.dims["nnzY"]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().jg_nr_base_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def info(self):
+        v = np.zeros(8, dtype=np.int64)
+        _lib.check(_lib.lib().jg_nr_base_info(self._h, v))
+        return dict(top_pivots=int(v[0]), split_level=int(v[1]), forward_launches=int(v[2]), backward_launches=int(v[3]),
+                    forward_launches_no_top=int(v[4]), backward_launches_no_top=int(v[5]), create_ms=v[6] / 1000.0, attached=int(v[7]))
+
+    def get(self, which: int, count: int):
+        out = np.zeros(int(count))
+        _lib.check(_lib.lib().jg_nr_base_get(self._h, int(which), out, out.size))
+        return out
+
+    def attach(self, an: "AcPowerFlow"):
+        """`an`'s scenarios may start from this base (startFromBase_)."""
+        _lib.check(_lib.lib().jg_nr_attach_base(an._h, self._h))
+        an._base = self
+
+
+def startFromBase_(an: AcPowerFlow):
+    """Every scenario of `an` starts from the attached base case's state (what setInitialPoint!(analysis, base) is per scenario in the reference's
+    loop, acPowerFlow.jl:1271-1295): the next powerFlow_ takes its first iteration on the base's shared factor when it can (jgrid.h)."""
+    _lib.check(_lib.lib().jg_nr_start_from_base(an._h))
+
+
+def setFirstIteration_(an: AcPowerFlow, shared: bool = True):
+    """shared=False: the first iteration refactorises like every other (A/B switch)."""
+    _lib.check(_lib.lib().jg_nr_set_first_iteration(an._h, 1 if shared else 0))
+
+
+def firstIterationCounts(an: AcPowerFlow):
+    """(runs that started on the shared factor, runs that refactorised)"""
+    a, b = C.c_int64(0), C.c_int64(0)
+    _lib.check(_lib.lib().jg_nr_first_iteration_counts(an._h, C.byref(a), C.byref(b)))
+    return int(a.value), int(b.value)
+
+
 def _push_voltage(an: AcPowerFlow, vm, va):
     vm = np.ascontiguousarray(vm, dtype=np.float64)
     va = np.ascontiguousarray(va, dtype=np.float64)
