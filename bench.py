@@ -392,6 +392,28 @@ def make_gather(jg, torch, dist, rank, world, local, cdev, force_dist, lanes, wi
     return deliver, label, (lambda: comm.close() if comm is not None else None)
 
 
+def device_state(index):
+    """Clocks, power and temperature of the GPU as rocm-smi reports them (the same build measures 267k - 312k NR it/s from box to box; the line
+    now records what the device was doing).  None when rocm-smi is missing or its output cannot be read; never raises."""
+    import shutil
+    import subprocess
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe, "-d", str(index), "--showclocks", "--showpower", "--showtemp", "--showuse", "--json"], capture_output=True, text=True, timeout=20).stdout
+        j = json.loads(out[out.index("{"):])
+        card = next(iter(j.values()))
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if any(t in kl for t in ("sclk", "mclk", "fclk", "socclk", "power", "temperature (sensor junction)", "temperature (sensor memory)", "gpu use")):
+                keep[k] = v
+        return keep
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def timed_regions(torch, dist, world, force_dist, cdev, run, steps):
     """The K-step region (fenced on both sides, max over ranks), repeated until about a second has been timed; (regions, iterations of one region, last status)."""
     def fence():
@@ -683,6 +705,8 @@ def main():
     ap.add_argument("--workload", choices=("nr", "se"), default="nr",
                     help="nr: batched N-1 Newton-Raphson (the headline metric); se: BASELINE config 4 as a sharded Monte-Carlo run -- `--batch` noisy realisations "
                          "per step of the PMU + legacy measurement set on the 9241-bus grid, Gauss-Newton WLS, the same line shape (GN iterations/s)")
+    ap.add_argument("--full-refactor", action="store_true", help="no base case: the first iteration of every batch refactorises like the others (the path of rounds 1-5)")
+    ap.add_argument("--top-cap", type=int, default=0, help="pivots in the dense top of the shared-factor sweeps (0: the library's default, < 0: none)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--no-se", action="store_true", help="skip the config4_se object")
     args = ap.parse_args()
@@ -824,21 +848,34 @@ def main():
     merge = max(1, min(merge, args.steps))
     lanes = B * merge
     inflight = args.inflight if args.inflight > 0 else max(3, min(12, 1536 // lanes))
-    cand = jg.outageList(system, 2 * total, seed=512)
+    #  the timed region is a SCREEN: its K steps solve K x `total` DISTINCT outages -- the seeded shuffle of every non-bridge branch, taken in
+    # order and cycled only when the grid has fewer solvable candidates than the region asks for -- and every device batch uploads its own outages inside the
+    # region (jg_nr_patch_ybus_batch: what updateBranch!(...; status = 0) is per scenario of the reference's loop, branch.jl:453-459)
+    cand = jg.outageList(system, system.branch.number, seed=512)
+    cand = cand[np.sort(np.unique(cand, return_index=True)[1])]          # every candidate once, in shuffle order (outageList tiles a short list)
     t0 = time.perf_counter()
-    pipe = jg.ContingencyPipeline(system, lanes, inflight=inflight, device=local, start=(vm0, va0), pool=args.pool)
-    t_pipe = time.perf_counter() - t0                  # handles + pools: ONE symbolic analysis (shared plan), device storage, start point
+    pipe = jg.ContingencyPipeline(system, lanes, inflight=inflight, device=local, start=(vm0, va0), pool=args.pool,
+                                  shared_first=not args.full_refactor, top_cap=args.top_cap)
+    t_pipe = time.perf_counter() - t0                  # handles + pools: ONE symbolic analysis (shared plan), device storage, start point, the base case's factor
     it_pre, st_pre = pipe.screen(cand, iteration=20, tolerance=1e-8)
     solvable = np.flatnonzero(st_pre == 0)
     if os.environ.get("JG_BENCH_PROBE_UNIFORM"):        # probe only: scenarios that all need the same number of iterations (no stragglers)
         solvable = np.flatnonzero((st_pre == 0) & (it_pre == int(os.environ["JG_BENCH_PROBE_UNIFORM"])))
     if solvable.size < total:
         raise SystemExit(f"only {solvable.size} of {cand.size} candidate contingencies have a power flow")
-    excluded = int(np.sum(st_pre[:solvable[total - 1] + 1] != 0))
-    chosen = cand[solvable[:total]]
-    labels = np.tile(chosen[lo:hi], merge)            # lane m * B + s = scenario s of the m-th step of the device batch
+    excluded = int(cand.size - solvable.size)
+    chosen = cand[solvable]                           # the screen's list: every solvable non-bridge outage, shuffle order
+
+    def step_labels(k):                               # this rank's share of step k of a region
+        idx = (k * total + np.arange(lo, hi)) % chosen.size
+        return chosen[idx]
+
+    def batch_labels(job):                            # lane m * B + s = scenario s of step job * merge + m
+        return np.concatenate([step_labels(job * merge + m) for m in range(merge)])
+
+    labels = batch_labels(0)
     for h in pipe.handles:
-        jg.setOutages_(h, labels)                     # the scenarios stay resident: a step re-solves them from the start point
+        jg.setOutages_(h, labels)
     an = pipe.handles[0]
     n = system.bus.number
     # result records: a ring the pipeline fills (the batch's own scenarios when its main phase ends, its stragglers when their pool
@@ -853,12 +890,16 @@ def main():
     # the ONE collective of a device batch (make_gather: the library's own C ABI by default for N > 1, torch.distributed as the fallback)
     gather, gather_label, gather_close = make_gather(jg, torch, dist, rank, world, local, cdev, force_dist, lanes, width)
 
+    gather_times = []
+
     def deliver(job, h):                              # caller's thread, job order: the record is complete -> the ONE collective
+        tg = time.perf_counter()
         gather(packed[job % ring])
+        gather_times.append(time.perf_counter() - tg)
 
     def run(steps):
         jobs = -(-steps // merge)                     # device batches; the last one may hold fewer real steps: its spare lanes are
-        out = pipe.run([None] * jobs, iteration=20, tolerance=1e-8, on_done=deliver,      # solved (and timed) but not counted
+        out = pipe.run([batch_labels(j) for j in range(jobs)], iteration=20, tolerance=1e-8, on_done=deliver,      # solved (and timed) but not counted
                        record=lambda j: packed[j % ring].data_ptr(), records=ring, summary=summary)
         real = [min(merge, steps - j * merge) * B for j in range(jobs)]
         return int(sum(int(np.sum(it[:r])) for (it, _), r in zip(out, real))), out[-1][1][:B]
@@ -868,7 +909,9 @@ def main():
     # mostly the fill and drain of the batches in flight plus whatever the box does in that instant.  So the SAME region -- K steps, fenced on
     # both sides, max over ranks -- is repeated until about a second has been timed (every rank takes the count from the max-reduced first
     # region: same number of collectives everywhere) and the line reports the MEDIAN region; min / max travel with it (timed_regions).
+    dev_state0 = device_state(local) if rank == 0 else None
     regions, iters_local, last_status = timed_regions(torch, dist, world, force_dist, cdev, run, args.steps)
+    dev_state1 = device_state(local) if rank == 0 else None
     dt = float(np.median(regions))
     #  when the K-step region cannot reach the pipeline's steady state (N = 8 at K = 20: 4 device batches, all in flight at once) the line
     # ALSO carries the same measurement over three rounds of the batches in flight -- value_steady; value stays the K of the caller
@@ -883,6 +926,24 @@ def main():
             c2 = torch.tensor([it_s], dtype=torch.int64, device=cdev)
             dist.all_reduce(c2, op=dist.ReduceOp.SUM)
             steady_extra[2] = int(c2.item())
+
+    #  the same regions with the first iteration refactorising like the others -- today's path against the path of rounds 1-5, same run, same box
+    full_extra = None
+    first_counts = [0, 0]
+    if pipe.base is not None:
+        for h in pipe.handles:
+            c = jg.firstIterationCounts(h)
+            first_counts[0] += c[0]; first_counts[1] += c[1]
+        pipe.setFirstIteration(False)
+        run(min(args.steps, 3 * len(pipe.handles) * merge))
+        rf, it_f, _ = timed_regions(torch, dist, world, force_dist, cdev, run, args.steps)
+        pipe.setFirstIteration(True)
+        full_extra = [float(np.median(rf)), it_f]
+        if world > 1:
+            c3 = torch.tensor([it_f], dtype=torch.int64, device=cdev)
+            dist.all_reduce(c3, op=dist.ReduceOp.SUM)
+            full_extra[1] = int(c3.item())
+    gather_ms = [1e3 * x for x in gather_times]
 
     conv_local = int(np.sum(last_status == 0))
     if world > 1:
@@ -910,6 +971,20 @@ def main():
             "lu": {"ms": t_lu, "bytes": ab["lu"], "launches": d["lu_launches"]},
             "solve": {"ms": t_sol, "bytes": ab["solve"], "launches": d["solve_launches"]},
         }
+        first_kern = None
+        if pipe.base is not None:
+            binfo = pipe.base.info
+            t_first_lin = timed(4, 12)
+            t_mis = timed(5, 24)
+            # algorithmic bytes of the shared-factor step: the right-hand side read once and the solution written once per scenario (the factor is shared:
+            # 2.2 MB per batch), the state read and written by the fused update; of the mismatch pass: SURVEY 8(d)'s assembly figure without the Jacobian stream
+            nn, bb = d["n"], an.batch
+            first_kern = {"shared_factor_step": {"ms": t_first_lin, "bytes": bb * (16 * nn + 16 * nn + 32 * nn) + 32 * d["lu_blocks"],
+                                                 "launches": binfo["forward_launches"] + binfo["backward_launches"] + 2},
+                          "mismatch_pass": {"ms": t_mis, "bytes": bb * (16 * nn + 32 * nn), "launches": 1}}
+            for k in first_kern.values():
+                k["GBps"] = k["bytes"] / (k["ms"] * 1e-3) / 1e9
+                k["frac"] = k["GBps"] / HBM_PEAK_GBS
         for k in kern.values():
             k["GBps"] = k["bytes"] / (k["ms"] * 1e-3) / 1e9
             k["frac"] = k["GBps"] / HBM_PEAK_GBS
@@ -968,8 +1043,10 @@ def main():
                                  f"state record, 2 n + 2 = {2 * n + 2} doubles per scenario (V | theta | iterations | status)",
                        "parallelism": f"scenario-sharded x{world}, one RCCL all-gather of the packed results per device batch "
                                       f"({merge} step(s) of {B} scenarios per GPU)",
-                       "scenario_selection": f"the first {total} solvable contingencies of a seeded shuffle of the non-bridge branches; "
-                                             f"{excluded} candidate(s) without a power flow skipped"},
+                       "scenario_selection": (f"a region's K x {total} = {args.steps * total} scenarios are taken in order from the seeded shuffle of ALL {chosen.size} solvable non-bridge "
+                                              f"outages of the grid ({excluded} candidate(s) without a power flow skipped), uploaded per device batch INSIDE the region; "
+                                              + ("every scenario of a region is a different outage" if args.steps * total <= chosen.size else
+                                                 f"the list is cycled: {args.steps * total - chosen.size} scenario(s) of a region repeat an earlier outage"))},
             "scenarios_per_s": nsc / dt,
             "ms_per_solve_batched": 1e3 * dt / nsc,
             "iterations_per_scenario": iters_total / nsc,
@@ -989,6 +1066,38 @@ def main():
             "roofline": roofline,
             "kernels": kern,
         }
+        # what a step costs by its kernels alone (each timed alone on one handle, all lanes active) against what the pipeline delivers: a batch of mean m iterations
+        # runs m + 1 assemblies and m factorisations + sweeps when every iteration refactorises; with the shared first iteration a mismatch pass, the shared-factor
+        # step, m assemblies and m - 1 factorisations + sweeps
+        m_it = iters_total / nsc
+        ksum_full = (m_it + 1) * t_asm + m_it * (t_lu + t_sol)
+        if first_kern is not None:
+            ksum = first_kern["mismatch_pass"]["ms"] + first_kern["shared_factor_step"]["ms"] + m_it * t_asm + (m_it - 1) * (t_lu + t_sol)
+            line["kernels_first_iteration"] = first_kern
+        else:
+            ksum = ksum_full
+        line["kernel_sum_ms"] = ksum / max(merge, 1)      # (the kernels were timed on a handle of B x merge lanes: `merge` steps of this rank)
+        line["kernel_sum_full_refactor_ms"] = ksum_full / max(merge, 1)
+        line["step_over_kernels"] = line["ms_per_step"] / line["kernel_sum_ms"]
+        line["kernel_sum_what"] = ("per step and GPU: the kernels of one device batch timed ALONE (HIP events, one handle, every lane active, no compaction) weighted by the mean "
+                                   "iteration count, divided by the steps a device batch holds; step_over_kernels = ms_per_step / kernel_sum_ms -- below 1 the batches in flight "
+                                   "overlap and finished lanes drop out, above 1 the pipeline loses time to launches, verdicts and compaction")
+        line["config"]["first_iteration"] = (
+            (f"shared base factor (compensation): ONE factorisation of the base-case Jacobian per pipeline, per scenario a 4 x 4 correction and one sweep pair on it "
+             f"({pipe.base.info['top_pivots']} pivots of the tree's top as a dense inverse, {pipe.base.info['forward_launches']} + {pipe.base.info['backward_launches']} level launches); "
+             f"iterations >= 2 refactorise.  {first_counts[0]} of {first_counts[0] + first_counts[1]} runs of the batches started that way")
+            if pipe.base is not None else "batched refactorisation (as every iteration)")
+        if full_extra:
+            line["value_full_refactor"] = full_extra[1] / full_extra[0]
+            line["ms_per_step_full_refactor"] = 1e3 * full_extra[0] / args.steps
+            line["full_refactor_what"] = "the same K-step regions in the same run with jg_nr_set_first_iteration(h, 0): every iteration refactorises (the path of rounds 1-5)"
+        if world > 1 and gather_ms:
+            line["gather_ms"] = float(np.mean(gather_ms))
+            line["gather_ms_max"] = float(np.max(gather_ms))
+            line["gather_exposed_ms"] = float(np.median(gather_ms[jobs_per_region - 1::jobs_per_region])) if len(gather_ms) >= jobs_per_region else float(gather_ms[-1])
+            line["gather_what"] = ("wall time of the ONE collective per device batch on rank 0 (pack + all-gather + stream synchronisation); gather_exposed_ms: that of the LAST "
+                                   "batch of a region, which no other batch in flight hides")
+        line["device_state"] = {"region_start": dev_state0, "region_end": dev_state1}
         if steady_extra:
             ks, dts, its = steady_extra
             line["value_steady"] = its / dts

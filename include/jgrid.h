@@ -177,7 +177,7 @@ int jg_nr_pack_rows_device(jg_nr* h, double* dst_dev, int64_t lane0, int64_t cou
  *                       sweep pair, the same two without a top (the set-up solver), creation time in microseconds, attached handles.
  *   jg_nr_base_get      test access: which = 0 J_0^-1 on the Ybus pattern [nnz][4] (row-CSR position (i, j) of the stored pattern: block
  *                       (theta_i, V_i) x (P_j, Q_j), row-major), 1 J_0^-1 f_0 [n][2], 2 f_0 [n][2], 3 the dense inverse of the top's Schur
- *                       complement (rows of the leading dimension info reports as cap / (2 pivots)), 4 the compact factor [entries][4].
+ *                       complement in the fragment order of the kernel that applies it (csrc/jg_comp.hip: k_ctop), 4 the compact factor [entries][4].
  */
 int jg_nr_base_create(jg_nr_base** out, jg_nr* single, int64_t top_cap);
 void jg_nr_base_destroy(jg_nr_base* b);
@@ -267,8 +267,9 @@ int jg_nr_screen_rows_device(jg_nr* h, double* rec_dev, int64_t lane0, int64_t c
 
 /* Measurement hooks (HIP events on the handle's own stream).
  * kernel: 0 fused mismatch+Jacobian assembly, 1 LU refactorization + fused forward elimination (all
- * launches), 2 backward sweep (no state update), 3 power!/current! branch kernel (all outputs).  Returns the mean
- * milliseconds of `reps` back-to-back executions. */
+ * launches), 2 backward sweep (no state update), 3 power!/current! branch kernel (all outputs), 4 the linear step of a first
+ * iteration on the shared base factor (per-scenario correction + sweep pair; needs jg_nr_attach_base), 5 the mismatch-only pass of such
+ * a start.  Returns the mean milliseconds of `reps` back-to-back executions. */
 int jg_nr_time_kernel(jg_nr* h, int kernel, int reps, double* mean_ms);
 
 /* ---------------------------------------------------------------------------------------------

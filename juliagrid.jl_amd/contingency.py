@@ -15,7 +15,7 @@ import numpy as np
 import threading
 
 from . import _lib
-from .powerflow import AcPowerFlow, newtonRaphson, powerFlow_, setOutage_, setOutages_, _push_voltage
+from .powerflow import AcPowerFlow, BaseCase, newtonRaphson, powerFlow_, setOutage_, setOutages_, startFromBase_, setFirstIteration_, _push_voltage
 from .system import PowerSystem
 
 
@@ -147,8 +147,14 @@ class ContingencyPipeline:
     the batch's results are still resident in `analysis` at that point.  With a pool the handle may already be running its next
     job: results are delivered through `record` (see run)."""
 
-    def __init__(self, system: PowerSystem, batch: int, inflight: int = 3, device: int = 0, start=None, pool: int = 0, defer_at: int = 64):
+    def __init__(self, system: PowerSystem, batch: int, inflight: int = 3, device: int = 0, start=None, pool: int = 0, defer_at: int = 64,
+                 shared_first: bool = True, top_cap: int = 0):
+        """shared_first (with a `start`): the start is a BASE CASE -- its Jacobian is factorised once (BaseCase) and the first Newton iteration of every
+        scenario is a sweep pair on that shared factor plus a 4 x 4 correction instead of a batched refactorisation (jgrid.h: jg_nr_base_*; the reference
+        refactorises per scenario, branch.jl:453-459 + acPowerFlow.jl:890-897).  The handles decide per run whether the conditions hold."""
         self.system, self.batch = system, int(batch)
+        self.base = None
+        self._shared_first, self._top_cap, self._device = bool(shared_first), int(top_cap), int(device)
         self.handles = [newtonRaphson(system, batch=self.batch, device=device, max_patch=4) for _ in range(max(1, int(inflight)))]
         self.defer_at = max(0, min(64, int(defer_at)))
         self.pools = []
@@ -177,12 +183,30 @@ class ContingencyPipeline:
             an.snapshot_voltage()
         for p in self.pools:                             # idle pool lanes compute along in their lane group: give them a sane state
             _push_voltage(p.handle, magnitude, angle)
+        if self.base is not None:
+            self.base.close()
+            self.base = None
+        if self._shared_first and np.ndim(magnitude) == 1:
+            single = newtonRaphson(self.system, batch=1, device=self._device)     # the system's own injections and nodal matrix, the common start
+            _push_voltage(single, magnitude, angle)
+            self.base = BaseCase(single, top_cap=self._top_cap)
+            single.close()
+            for an in self.handles:
+                self.base.attach(an)
+
+    def setFirstIteration(self, shared: bool = True):
+        """A/B switch: shared=False makes every handle refactorise in its first iteration as well (the base stays attached)."""
+        for an in self.handles:
+            setFirstIteration_(an, shared)
 
     def close(self):
         for an in self.handles:
             an.close()
         for p in self.pools:
             p.handle.close()
+        if self.base is not None:
+            self.base.close()
+            self.base = None
         self.handles, self.pools = [], []
 
     def setRating(self, rating):
@@ -290,7 +314,10 @@ class ContingencyPipeline:
                     elif job is not None:
                         labels = [int(x) if x else 0 for x in job]
                         setOutages_(an, labels + [0] * (self.batch - len(labels)))
-                    an.restore_voltage()
+                    if self.base is not None:
+                        startFromBase_(an)                        # device-side broadcast of the base state; the run takes its first iteration on the shared factor when it can
+                    else:
+                        an.restore_voltage()
                     if use_pool:
                         left = an.run_defer(iteration, tolerance, self.defer_at)
                         if left > 0:

@@ -127,54 +127,81 @@ __global__ __launch_bounds__(512, 4) void k_csweep(CSweepArgs a) {
 }
 
 // ---- the dense top: x_T = Sinv * yt_T --------------------------------------------------------------------------------------------------
-// A wave = CTOP_PIV pivots (2 CTOP_PIV rows of Sinv) x 64 scenarios: the rows of Sinv arrive as scalars (32 bytes per row and pair of pivots),
-// yt as one 16-byte load per pivot and lane, shared by the wave's rows.  Four waves per workgroup.
-constexpr int CTOP_PIV = 4, CTOP_WAVES = 4;
+// A GEMM [2 n_top x 2 n_top] x [2 n_top x scenarios] on the matrix cores (v_mfma_f64_16x16x4_f64: the one place of this path where a dense contraction IS
+// the work -- 1 GFLOP per 512 scenarios at 502 top pivots; a first version fed Sinv through scalar loads and ran at 5 % of the f64 peak, bound by the
+// latency of eight dependent s_loads per k step).  Workgroup = 16 rows of Sinv x the 64 scenarios of a lane group; its CTOP_WAVES waves split K and meet
+// in LDS.  Sinv is stored in FRAGMENT order (k_take_sinv): [row block][k step][64 lanes], lane l = A(row l & 15, k l >> 4) of the instruction, so a
+// fragment is one coalesced 512-byte load; the B fragment of scenarios 16 j .. 16 j + 15 is y(k l >> 4, scenario l & 15) read from the batch-minor scratch.
+// D: lane l holds rows (l >> 4) + 4 r, r < 4, of column l & 15 (cdna_hip_programming.md: the f64 form has its own map).
+constexpr int CTOP_WAVES = 4, CTOP_KPAD = 4 * CTOP_WAVES;     // K is padded to whole k steps of every wave
 struct CTopArgs {
-    const double* Sinv; int lds;
+    const double* Sinv; int n_ks;                                // k steps of 4 (padded K / 4)
     const int* piv; const int* bus;
     double* W; double* out; GroupSel sel; StateUpdate upd;
-    int ld, lanes, n, n_top;
+    int ld, lanes, n, n_top, n_rb;
 };
+typedef double d4v __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(64 * CTOP_WAVES) void k_ctop(CTopArgs a) {
-    int grp, bx;
-    const int nx = (a.n_top + CTOP_PIV * CTOP_WAVES - 1) / (CTOP_PIV * CTOP_WAVES);
-    if (!map_block(a.sel, a.ld, nx, grp, bx)) return;
+    __shared__ double part[CTOP_WAVES][4][4][64];                // [wave][scenario block][register][lane]
+    int grp, rb;
+    if (!map_block(a.sel, a.ld, a.n_rb, grp, rb)) return;
     const int lane = threadIdx.x;
     const int wave = uniform(threadIdx.y);
-    const int t0 = (bx * CTOP_WAVES + wave) * CTOP_PIV;
-    if (t0 >= a.n_top) return;
     const size_t ld = (size_t)a.ld;
-    const size_t b = (size_t)min(grp * 64 + lane, a.lanes - 1);
-    double acc[2 * CTOP_PIV];
+    const int kq = lane >> 4, col = lane & 15;
+    // B operand: k = 4 ks + kq = component (kq & 1) of top row 2 ks + (kq >> 1)
+    size_t boff[4];
 #pragma unroll
-    for (int r = 0; r < 2 * CTOP_PIV; ++r) acc[r] = 0.0;
-    const double2* y = (const double2*)a.W + (size_t)a.n * ld + b;        // row t of yt: y[t * ld]
-    const int npair = (a.n_top + 1) >> 1;                                 // the scratch holds an even number of top rows (the spare one is zero)
-    CDbl srow = (CDbl)a.Sinv + (size_t)(2 * t0) * a.lds;
-    double2 ya = y[0], yb = y[ld];
-    for (int p = 0; p < npair; ++p) {
-        const double2 ca = ya, cb = yb;
-        if (p + 1 < npair) { ya = y[(size_t)(2 * p + 2) * ld]; yb = y[(size_t)(2 * p + 3) * ld]; }
+    for (int j = 0; j < 4; ++j) boff[j] = (size_t)min(grp * 64 + 16 * j + col, a.lanes - 1) * 2 + (kq & 1);
+    const double* y = a.W + ((size_t)a.n + (kq >> 1)) * ld * 2;
+    const double* sa = a.Sinv + ((size_t)rb * a.n_ks) * 64 + lane;
+    d4v acc[4];
 #pragma unroll
-        for (int r = 0; r < 2 * CTOP_PIV; ++r) {
-            CDbl s = srow + (size_t)r * a.lds + 4 * p;
-            acc[r] = fma(s[3], cb.y, fma(s[2], cb.x, fma(s[1], ca.y, fma(s[0], ca.x, acc[r]))));
+    for (int j = 0; j < 4; ++j) acc[j] = d4v{0.0, 0.0, 0.0, 0.0};
+    const int per = a.n_ks / CTOP_WAVES;
+    const int k0 = wave * per, k1 = k0 + per;
+    constexpr int U = 4;                                         // k steps whose 5 U loads are in flight together (two waves per SIMD hide little)
+    for (int ks = k0; ks < k1; ks += U) {
+        double av[U], bv[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kk = min(ks + u, k1 - 1);                   // (a repeated step is not accumulated)
+            av[u] = sa[(size_t)kk * 64];
+            const double* yr = y + (size_t)(2 * kk) * ld * 2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[u][j] = yr[boff[j]];
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (ks + u < k1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u][j], acc[j], 0, 0, 0);
+            }
     }
 #pragma unroll
-    for (int q = 0; q < CTOP_PIV; ++q) {
-        const int t = t0 + q;
-        if (t >= a.n_top) break;
-        const int k = uniform(a.piv[t]), bus = uniform(a.bus[t]);
-        const double x0 = acc[2 * q], x1 = acc[2 * q + 1];
-        store_vec(a.W, (size_t)k, b, ld, x0, x1);
-        const bool act = a.upd.va ? (a.upd.active ? (a.upd.active[b] != 0) : true) : true;
-        if (!a.upd.va || act) store_vec(a.out, (size_t)bus, b, ld, x0, x1);
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wave][j][r][lane] = acc[j][r];
+    __syncthreads();
+    // wave j finishes scenario block j: row 16 rb + kq + 4 r = component (kq & 1) of top pivot 8 rb + (kq >> 1) + 2 r
+    const int j = wave;
+    const size_t b = (size_t)min(grp * 64 + 16 * j + col, a.lanes - 1);
+    const bool act = a.upd.va ? (a.upd.active ? (a.upd.active[b] != 0) : true) : true;
+    const int c = kq & 1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = 8 * rb + (kq >> 1) + 2 * r;
+        double x = 0.0;
+#pragma unroll
+        for (int w = 0; w < CTOP_WAVES; ++w) x += part[w][j][r][lane];
+        if (t >= a.n_top) continue;
+        const int k = a.piv[t], bus = a.bus[t];
+        a.W[((size_t)k * ld + b) * 2 + c] = x;
+        if (!a.upd.va || act) a.out[((size_t)bus * ld + b) * 2 + c] = x;
         if (a.upd.va && act) {
-            const int fl = uniform((int)a.upd.flags[bus]);
-            if (fl & 1) a.upd.va[(size_t)bus * ld + b] += a.upd.sign * x0;
-            if (fl & 2) a.upd.vm[(size_t)bus * ld + b] += a.upd.sign * x1;
+            const int fl = (int)a.upd.flags[bus];
+            double* st = c == 0 ? a.upd.va : a.upd.vm;
+            if (fl & (1 << c)) st[(size_t)bus * ld + b] += a.upd.sign * x;
         }
     }
 }
@@ -221,13 +248,16 @@ __global__ void k_unit_clear(double* rhs, const int* row, const int* comp, int l
     if (b >= count || row[b] < 0) return;
     rhs[((size_t)row[b] * ld + b) * 2 + comp[b]] = 0.0;
 }
-// Sinv[2 i + c][col0 + b] = x_(top pivot i, component c) of scenario b  (W in pivot order)
-__global__ void k_take_sinv(const double* W, const int* piv, double* Sinv, int lds, int n_top, int ld, int col0, int count) {
+// x_(top pivot i, component c) of scenario b = Sinv(row 2 i + c, column col0 + b), stored in the fragment order k_ctop reads (W in pivot order)
+__global__ void k_take_sinv(const double* W, const int* piv, double* Sinv, int n_ks, int n_top, int ld, int col0, int count) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
     if (b >= count || i >= n_top) return;
     const double2 x = *(const double2*)(W + ((size_t)piv[i] * ld + b) * 2);
-    Sinv[(size_t)(2 * i) * lds + col0 + b] = x.x;
-    Sinv[(size_t)(2 * i + 1) * lds + col0 + b] = x.y;
+    const int kc = col0 + b, ks = kc >> 2, kq = kc & 3;
+    for (int c = 0; c < 2; ++c) {
+        const int r = 2 * i + c, rb = r >> 4, rr = r & 15;
+        Sinv[((size_t)rb * n_ks + ks) * 64 + kq * 16 + rr] = c ? x.y : x.x;
+    }
 }
 // scenario b solved J_0 x = e_(bus[b], comp[b]): x holds column (bus, comp) of J_0^-1.  Its rows over the Ybus neighbours j of the bus are the
 // blocks Z(j, bus)(:, comp), stored at the row-CSR position of (j, bus) = the transposed position of (bus, j)
@@ -401,9 +431,9 @@ int CompBase::solve(const CompSweep& sw, hipStream_t st, const double* rhs, doub
         hipLaunchKernelGGL((k_csweep<false>), dim3(grid_blocks(ld / 64, (long long)L.grid * 2), L.nseg), dim3(64, 8), 8 * 64 * sizeof(double2), st, a);
     }
     if (sw.T.n_top > 0) {
-        CTopArgs t{Sinv, lds, sw.top_piv, sw.top_bus, Wc, out, sel, upd, ld, lanes, n, sw.T.n_top};
-        const int nx = (sw.T.n_top + CTOP_PIV * CTOP_WAVES - 1) / (CTOP_PIV * CTOP_WAVES);
-        hipLaunchKernelGGL(k_ctop, dim3(grid_blocks(ld / 64, nx)), dim3(64, CTOP_WAVES), 0, st, t);
+        const int n_rb = (2 * sw.T.n_top + 15) / 16;
+        CTopArgs t{Sinv, lds, sw.top_piv, sw.top_bus, Wc, out, sel, upd, ld, lanes, n, sw.T.n_top, n_rb};
+        hipLaunchKernelGGL(k_ctop, dim3(grid_blocks(ld / 64, n_rb)), dim3(64, CTOP_WAVES), 0, st, t);
     }
     a.rec = sw.bwd_rec; a.seg = sw.bwd_seg; a.upd = upd;
     for (const DevLaunch& L : sw.bwd) {
@@ -442,10 +472,11 @@ int CompBase::create(const BlockSymbolic& S, const double* Xsrc, int ldx, int to
     // Sinv: unit right-hand sides on the top rows through the level-only tables (x_T = S^-1 r_T when r vanishes below the top)
     const int nt = split.T.n_top;
     if (nt > 0) {
-        const int rows = ((2 * nt + 2 * CTOP_PIV * CTOP_WAVES - 1) / (2 * CTOP_PIV * CTOP_WAVES)) * (2 * CTOP_PIV * CTOP_WAVES);   // whole workgroups of k_ctop read their rows
-        lds = (2 * nt + 2 + 7) / 8 * 8;                          // (an odd top reads one spare pair of columns: against the zero row of the scratch)
-        CB_HIP(hipMalloc((void**)&Sinv, (size_t)rows * lds * sizeof(double)));
-        CB_HIP(sync_fill(Sinv, 0, (size_t)rows * lds * sizeof(double), st));
+        const int n_rb = (2 * nt + 15) / 16;
+        lds = (2 * nt + CTOP_KPAD - 1) / CTOP_KPAD * (CTOP_KPAD / 4);        // k steps of 4, whole shares of the waves that split K (jg_comp.hpp: lds = k steps)
+        const size_t sbytes = (size_t)n_rb * lds * 64 * sizeof(double);
+        CB_HIP(hipMalloc((void**)&Sinv, sbytes));
+        CB_HIP(sync_fill(Sinv, 0, sbytes, st));
         const int ldb = 512;
         double* rhs = nullptr; double* W = nullptr; double* out = nullptr; int* d_rowi = nullptr; int* d_comp = nullptr;
         const size_t vec = (size_t)n * ldb * 2 * sizeof(double);

@@ -27,7 +27,7 @@ struct CompBase {
     int n = 0, nnz = 0, n_entries = 0, device = 0;
     CompSweep full, split;               // every pivot a level item (bootstrap) / bottom levels + dense top
     double* Mc = nullptr;                // [n_entries][4]: Lh(i,k) D(k)^-1 below, D(i)^-1 U(i,j) above, the 2x2 LU of D(k) on the diagonal
-    double* Sinv = nullptr; int lds = 0; // [rows][lds] dense inverse of the top's Schur complement (rows, lds = 2 n_top padded)
+    double* Sinv = nullptr; int lds = 0; // dense inverse of the top's Schur complement in MFMA fragment order [row blocks of 16][lds k steps of 4][64] (jg_comp.hip: k_ctop)
     double* Zc = nullptr;                // [nnz][4]: block (unknowns of bus i, equations of bus j) of J_0^-1 at row-CSR position (i, j)
     double* v0 = nullptr; double* th0 = nullptr; double* f0 = nullptr; double* y0 = nullptr;    // start state [n], base mismatch / J_0^-1 f_0 [n][2]
     double* p0 = nullptr; double* q0 = nullptr;                                                   // injections of the base [n]
@@ -39,7 +39,7 @@ struct CompBase {
     void destroy();
     // x = J_0^-1 rhs for the scenarios of `sel`: rhs [n][ld][2] bus order, Wc scratch [(n + n_top_pad)][ld][2], out [n][ld][2] bus order; optional fused state update
     int solve(const CompSweep& sw, hipStream_t st, const double* rhs, double* Wc, double* out, int ld, int lanes, const StateUpdate& upd, const GroupSel& sel) const;
-    size_t scratch_rows(const CompSweep& sw) const { return (size_t)n + (size_t)((sw.T.n_top + 1) & ~1); }
+    size_t scratch_rows(const CompSweep& sw) const { return (size_t)n + (size_t)((sw.T.n_top + 7) & ~7); }      // the top's partial rows, padded (zero) to the k steps k_ctop reads: 16 values = 8 rows
 };
 
 // per-scenario correction of the right-hand side: F[a], F[b] -= c_s (see above); marks singular scenarios in lu_status (bit 2)

@@ -1495,23 +1495,35 @@ int jg_nr_patch_ybus_batch(jg_nr* h, int64_t scenario0, int64_t count, int64_t k
         return fail(1, "jg_nr_patch_ybus_batch: bad argument (scenario range / entry count beyond max_patch)");
     if (int rc = set_device(h)) return rc;
     NR_HIP(hipStreamSynchronize(h->stream));
-    std::vector<int> pos((size_t)count), allpos((size_t)count * 8, -1);
-    std::vector<double> g((size_t)count), b((size_t)count);
+    // A whole batch (what a screen uploads per job): the three slot arrays travel as ONE copy each -- [mp][ld] is contiguous -- instead of 3 x mp
+    // copies with a stream synchronisation apiece (a job of the pipeline pays this inside the timed region)
+    const bool whole = scenario0 == 0 && count == h->batch;
+    const size_t wld = whole ? (size_t)h->ld : (size_t)count;
+    std::vector<int> pos((size_t)h->mp * wld, -1), allpos((size_t)count * 8, -1);
+    std::vector<double> g((size_t)h->mp * wld, 0.0), b((size_t)h->mp * wld, 0.0);
     for (int m = 0; m < h->mp; ++m) {
+        int* pm = pos.data() + (size_t)m * wld; double* gm = g.data() + (size_t)m * wld; double* bm = b.data() + (size_t)m * wld;
         for (int64_t s = 0; s < count; ++s) {
-            pos[s] = -1; g[s] = 0.0; b[s] = 0.0;
             if (m < k && ptr[s * k + m] != 0) {
                 const int64_t p = ptr[s * k + m];
                 if (p < 1 || p > h->nnz) return fail(1, "jg_nr_patch_ybus_batch: pointer out of range");
                 for (int mm = 0; mm < m; ++mm) if (ptr[s * k + mm] == p) return fail(1, "jg_nr_patch_ybus_batch: duplicate pointer");
-                pos[s] = h->tperm[p - 1]; g[s] = dy[2 * (s * k + m)]; b[s] = dy[2 * (s * k + m) + 1];
+                pm[s] = h->tperm[p - 1]; gm[s] = dy[2 * (s * k + m)]; bm[s] = dy[2 * (s * k + m) + 1];
             }
-            allpos[(size_t)s * 8 + m] = pos[s];
+            allpos[(size_t)s * 8 + m] = pm[s];
         }
+    }
+    if (whole) {
+        NR_HIP(hipMemcpyAsync(h->d_ppos, pos.data(), pos.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        NR_HIP(hipMemcpyAsync(h->d_pdg, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        NR_HIP(hipMemcpyAsync(h->d_pdb, b.data(), b.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        NR_HIP(hipStreamSynchronize(h->stream));
+    } else
+    for (int m = 0; m < h->mp; ++m) {
         const size_t off = (size_t)m * h->ld + scenario0;
-        NR_HIP(jg::sync_copy(h->d_ppos + off, pos.data(), (size_t)count * sizeof(int), hipMemcpyHostToDevice, h->stream));
-        NR_HIP(jg::sync_copy(h->d_pdg + off, g.data(), (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        NR_HIP(jg::sync_copy(h->d_pdb + off, b.data(), (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        NR_HIP(jg::sync_copy(h->d_ppos + off, pos.data() + (size_t)m * wld, (size_t)count * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        NR_HIP(jg::sync_copy(h->d_pdg + off, g.data() + (size_t)m * wld, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        NR_HIP(jg::sync_copy(h->d_pdb + off, b.data() + (size_t)m * wld, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->stream));
     }
     for (int64_t s = 0; s < count; ++s) h->patch_state[(size_t)(scenario0 + s)] = classify_patch(h, &allpos[(size_t)s * 8], h->mp);
     h->jac_valid = false;
@@ -1834,7 +1846,7 @@ int jg_nr_base_get(jg_nr_base* b, int which, double* out, int64_t cap) {
         case 0: src = cb.Zc; count = (size_t)cb.nnz * 4; break;                                  // J_0^-1 on the Ybus pattern, row-CSR order
         case 1: src = cb.y0; count = (size_t)cb.n * 2; break;
         case 2: src = cb.f0; count = (size_t)cb.n * 2; break;
-        case 3: src = cb.Sinv; count = cb.Sinv ? (size_t)(2 * cb.split.T.n_top) * cb.lds : 0; break;   // rows of lds doubles
+        case 3: src = cb.Sinv; count = cb.Sinv ? (size_t)((2 * cb.split.T.n_top + 15) / 16) * cb.lds * 64 : 0; break;   // MFMA fragment order (jg_comp.hip: k_ctop)
         case 4: src = cb.Mc; count = (size_t)cb.n_entries * 4; break;
         default: return fail(1, "jg_nr_base_get: which = 0 (inverse on the pattern) | 1 (J0^-1 f0) | 2 (f0) | 3 (dense top inverse) | 4 (compact factor)");
     }
@@ -2401,7 +2413,8 @@ int jg_nr_screen_rows_device(jg_nr* h, double* rec_dev, int64_t lane0, int64_t c
 }
 
 int jg_nr_time_kernel(jg_nr* h, int kernel, int reps, double* mean_ms) {
-    if (!h || reps < 1 || !mean_ms || kernel < 0 || kernel > 3) return fail(1, "jg_nr_time_kernel: bad argument");
+    if (!h || reps < 1 || !mean_ms || kernel < 0 || kernel > 5) return fail(1, "jg_nr_time_kernel: bad argument");
+    if (kernel == 4 && (!h->base || !h->d_cw)) return fail(1, "jg_nr_time_kernel: kernel 4 (first iteration on the shared base factor) needs an attached base");
     if (h->fast && kernel < 2) return fail(1, "jg_nr_time_kernel: assembly / factorisation timing would overwrite the constant factor of a fast Newton-Raphson handle");
     if (int rc = set_device(h)) return rc;
     BranchArgs ba{};
@@ -2424,6 +2437,14 @@ int jg_nr_time_kernel(jg_nr* h, int kernel, int reps, double* mean_ms) {
             if (kernel == 0) launch_assemble(h, jg::GroupSel{}, true, nullptr, 0, nullptr, true);     // as the iteration runs it
             else if (kernel == 1) { if (int rc = h->eng.factor(h->stream, nullptr, h->d_F, jg::GroupSel{}, h->eng.plan->S.prefactor != 0)) return fail(rc, h->eng.error); }
             else if (kernel == 3) hipLaunchKernelGGL(k_branch_quantities, dim3((h->nb + 15) / 16, h->ld / 64), dim3(64, 16), 0, h->stream, ba);
+            else if (kernel == 4) {                              // the linear step of a compensated first iteration: correction + sweep pair on the shared factor (no state update)
+                const jg::CompBase& cb = h->base->cb;
+                jg::CompFixArgs fa{h->d_ppos, h->d_pdg, h->d_pdb, h->mp, cb.rowptr, cb.colm, cb.posrow, cb.rowtype, cb.v0, cb.th0, cb.y0, cb.Zc,
+                                   h->d_F, h->eng.status, nullptr, h->ld, h->batch};
+                if (h->mp > 0) jg::launch_comp_fix(fa, h->stream);
+                if (int rc = cb.solve(cb.split, h->stream, h->d_F, h->d_cw, h->d_inc, h->ld, h->batch, none, jg::GroupSel{})) return fail(rc, "shared-factor sweep failed");
+            }
+            else if (kernel == 5) launch_assemble(h, jg::GroupSel{}, false);      // the mismatch-only pass of a compensated start
             else { if (int rc = h->eng.backsolve(h->stream, h->d_inc, none, jg::GroupSel{})) return fail(rc, h->eng.error); }
         }
         NR_HIP(hipEventRecord(e1, h->stream));

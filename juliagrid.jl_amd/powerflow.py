@@ -632,6 +632,35 @@ def outagePatch(system: PowerSystem, label: int):
     return ptr, dy
 
 
+def outagePatchTable(system: PowerSystem):
+    """outagePatch of EVERY branch at once -- (pointers [nb, 4], deltas [nb, 4]) -- kept on the system until its AC model moves: a screen uploads the
+    outages of a whole device batch per job, and 2 048 pattern look-ups in Python per batch would cost more than the batch's power flows."""
+    rev = system.model.revision
+    key = (rev.acModel, rev.acPattern, rev.topology, system.branch.number)
+    tab = getattr(system, "_outage_table", None)
+    if tab is not None and tab[0] == key:
+        return tab[1], tab[2]
+    ac, Y = system.model.ac, system.model.ac.nodalMatrix
+    i = np.asarray(system.branch.layout.from_, dtype=np.int64)
+    j = np.asarray(system.branch.layout.to, dtype=np.int64)
+    n = system.bus.number
+    rows = np.asarray(Y.rowval, dtype=np.int64)
+    cols = np.repeat(np.arange(1, n + 1, dtype=np.int64), np.diff(np.asarray(Y.colptr, dtype=np.int64)))
+    keys = cols * (n + 1) + rows                                      # CSC order: ascending in (col, row)
+
+    def pos(r, c):
+        q = c * (n + 1) + r
+        p = np.searchsorted(keys, q)
+        if np.any(p >= keys.size) or np.any(keys[np.minimum(p, keys.size - 1)] != q):
+            raise KeyError("The sparse matrix pattern does not contain the requested entry.")
+        return p
+
+    ptr = np.stack([pos(i, i), pos(j, j), pos(i, j), pos(j, i)], axis=1).astype(np.int64) + 1
+    dy = -np.stack([ac.nodalFromFrom, ac.nodalToTo, ac.nodalFromTo, ac.nodalToFrom], axis=1).astype(np.complex128)
+    system._outage_table = (key, ptr, dy)
+    return ptr, dy
+
+
 def setOutage_(an: AcPowerFlow, scenario: int, label: int | None):
     """Scenario `scenario` of a batched analysis = base grid with branch `label` out of service
     (None restores the base grid)."""
@@ -649,14 +678,16 @@ def setOutage_(an: AcPowerFlow, scenario: int, label: int | None):
 def setOutages_(an: AcPowerFlow, labels, scenario0: int = 0):
     """setOutage_ for consecutive scenarios in ONE upload: scenario scenario0 + s = base grid with branch labels[s] out
     of service (0 / None = base grid)."""
-    labels = list(labels)
-    ptr = np.zeros((len(labels), 4), dtype=np.int64)
-    dy = np.zeros((len(labels), 4), dtype=np.complex128)
-    for s, lab in enumerate(labels):
-        if lab:
-            ptr[s], dy[s] = outagePatch(an.system, int(lab))
-    _lib.check(_lib.lib().jg_nr_patch_ybus_batch(an._h, int(scenario0), len(labels), 4, ptr.reshape(-1), _reim(dy.reshape(-1))))
-    an._outage_labels[scenario0:scenario0 + len(labels)] = [int(lab) if lab else 0 for lab in labels]
+    lab = np.array([int(x) if x else 0 for x in labels], dtype=np.int64)
+    labels = [int(x) for x in lab]
+    tptr, tdy = outagePatchTable(an.system)
+    if lab.size and (lab.min() < 0 or lab.max() > an.system.branch.number):
+        raise IndexError("setOutages_: branch label out of range")
+    on = lab > 0
+    ptr = np.where(on[:, None], tptr[np.maximum(lab, 1) - 1], 0)
+    dy = np.where(on[:, None], tdy[np.maximum(lab, 1) - 1], 0.0)
+    _lib.check(_lib.lib().jg_nr_patch_ybus_batch(an._h, int(scenario0), len(labels), 4, np.ascontiguousarray(ptr.reshape(-1)), _reim(np.ascontiguousarray(dy.reshape(-1)))))
+    an._outage_labels[scenario0:scenario0 + len(labels)] = lab
     if getattr(an.method, "fast", False):
         # fast Newton-Raphson: the outage also leaves the two constant matrices (branch.jl:477); every scenario keeps the shared B', B'' plus its own
         # (at most) 4 + 4 edits, and the batch is factorised ONCE -- the iterations stay forward / backward sweeps
