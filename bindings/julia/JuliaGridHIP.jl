@@ -531,6 +531,69 @@ function resume!(pool::NewtonRaphsonBatch, lanes::Int; iteration::Int64 = 20, to
     return nothing
 end
 
+# ---- the first iteration of a screen on ONE shared factor (jgrid.h: jg_nr_base_*): the reference refactorises per scenario of its loop
+# (branch.jl:453-459 + acPowerFlow.jl:890-897); batches whose scenarios all start from one base case pay one factorisation per BASE CASE
+"""
+    BaseCase(system; device = 0, topCap = 0, iteration = 20, tolerance = 1e-8)
+
+Solves the power flow of `system` (one instance on the device), then factorises the Jacobian at that solution ONCE and keeps what the batches
+attached to it need for a compensated first iteration (J0^-1 on the Ybus pattern, J0^-1 f0, the dense inverse of the top of the elimination tree:
+`topCap` pivots at most, 0 = default).  The state it was built at is the start of every attached batch (`startFromBase!`).
+"""
+mutable struct BaseCase
+    system::PowerSystem
+    ptr::Ptr{Cvoid}
+    function BaseCase(system::PowerSystem; device::Int = 0, topCap::Int = 0, iteration::Int64 = 20, tolerance::Float64 = 1e-8)
+        single = NewtonRaphsonBatch(system, 1; device = device, maxPatch = 0)
+        powerFlow!(single; iteration = iteration, tolerance = tolerance)
+        single.status[1] == 0 || throw(ErrorException("BaseCase: the power flow of the base case did not converge"))
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:jg_nr_base_create, lib), Cint, (Ref{Ptr{Cvoid}}, Ptr{Cvoid}, Int64), h, single.handle.ptr, topCap))
+        b = new(system, h[])
+        finalizer(x -> (x.ptr == C_NULL || ccall((:jg_nr_base_destroy, lib), Cvoid, (Ptr{Cvoid},), x.ptr); x.ptr = C_NULL), b)
+        return b
+    end
+end
+
+"(pivots in the dense top, split level, forward / backward level launches of a sweep pair, the same two without a top, creation time in microseconds, attached batches)"
+function baseInfo(base::BaseCase)
+    info = zeros(Int64, 8)
+    check(ccall((:jg_nr_base_info, lib), Cint, (Ptr{Cvoid}, Ptr{Int64}), base.ptr, info))
+    return info
+end
+
+"J0^-1 on the stored Ybus pattern, `[4, nnz]` (a 2 x 2 block (theta_i, V_i) x (P_j, Q_j) per stored entry, row-major, in row-CSR order of the pattern) -- test access"
+function baseInverseOnPattern(base::BaseCase)
+    nnz = length(base.system.model.ac.nodalMatrix.nzval)
+    out = zeros(Float64, 4, nnz)
+    check(ccall((:jg_nr_base_get, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Int64), base.ptr, 0, out, length(out)))
+    return out
+end
+
+"the scenarios of `b` may start from `base` (same grid and device); `nothing` detaches"
+function attach!(b::NewtonRaphsonBatch, base::Union{BaseCase, Nothing})
+    check(ccall((:jg_nr_attach_base, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), b.handle.ptr, base === nothing ? C_NULL : base.ptr))
+    return nothing
+end
+
+"every scenario of `b` starts from the attached base case's state (what setInitialPoint!(analysis, base) is per scenario of the reference's loop,
+acPowerFlow.jl:1271-1295); the next powerFlow! / powerFlowDefer! takes its first iteration on the base's shared factor when it can (jgrid.h lists the conditions)"
+function startFromBase!(b::NewtonRaphsonBatch)
+    check(ccall((:jg_nr_start_from_base, lib), Cint, (Ptr{Cvoid},), b.handle.ptr))
+    return nothing
+end
+
+"shared = false: the first iteration refactorises like every other (A/B switch)"
+firstIteration!(b::NewtonRaphsonBatch, shared::Bool = true) =
+    check(ccall((:jg_nr_set_first_iteration, lib), Cint, (Ptr{Cvoid}, Cint), b.handle.ptr, shared ? 1 : 0))
+
+"(runs of `b` that started on the shared factor, runs that refactorised)"
+function firstIterationCounts(b::NewtonRaphsonBatch)
+    a = Ref{Int64}(0); r = Ref{Int64}(0)
+    check(ccall((:jg_nr_first_iteration_counts, lib), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}), b.handle.ptr, a, r))
+    return Int(a[]), Int(r[])
+end
+
 # ------------------------------------------------------------------------------------------------------------------
 # Gauss-Newton WLS state estimation
 # ------------------------------------------------------------------------------------------------------------------
@@ -1072,7 +1135,7 @@ function timeKernel(analysis::HipStateEstimation, kernel::Int, reps::Int = 10)
     return ms[]
 end
 
-export HIP, HIPOrthogonal, NewtonRaphsonBatch, setOutages!, shareDevice!, branchQuantities, screenSummary, powerFlowDefer!, moveLanes!, finish!, resume!, jacobian!,
+export HIP, HIPOrthogonal, NewtonRaphsonBatch, BaseCase, baseInfo, baseInverseOnPattern, attach!, startFromBase!, firstIteration!, firstIterationCounts, setOutages!, shareDevice!, branchQuantities, screenSummary, powerFlowDefer!, moveLanes!, finish!, resume!, jacobian!,
        largestNormalizedResidual, normalizedResiduals, commUniqueId, Comm, shard, contingencyAnalysis, clearPlanCache,
        deviceCount, dims, setRefinement!, deviceMaps, setOutage!, snapshotVoltage!, restoreVoltage!, iterations, voltageDevice!, packResults!, packRows!,
        allgatherDevice, commRank, commWorld, timeKernel, GaussNewtonBatch, setRealisations!, monteCarloEstimation, fastPatch!, setReadings!, drawNoise!, measurementDevice

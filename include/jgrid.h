@@ -423,6 +423,9 @@ typedef struct jg_plan jg_plan;
 int jg_plan_create(jg_plan** p, int64_t n, const int32_t* rowptr, const int32_t* col, int64_t policy);
 void jg_plan_destroy(jg_plan* p);
 int64_t jg_plan_export(jg_plan* p, int which, int32_t* out, int64_t cap);
+/* The tables of the shared-factor solve behind jg_nr_base_create (csrc/jg_symbolic.hpp: CompTables) for a dense top of at most top_cap pivots (< 0: none):
+ * which = 0 {top pivots, split level, forward levels, backward levels}, 1 the top's pivots, 2 / 3 forward segments (x 8) / records (x 16), 4 / 5 backward. */
+int64_t jg_plan_comp_export(jg_plan* p, int64_t top_cap, int which, int32_t* out, int64_t cap);
 
 #ifdef __cplusplus
 }

@@ -151,6 +151,8 @@ def lib():
     L.jg_plan_destroy.restype = None
     L.jg_plan_export.argtypes = [VP, C.c_int, VP, C.c_int64]
     L.jg_plan_export.restype = C.c_int64
+    L.jg_plan_comp_export.argtypes = [VP, C.c_int64, C.c_int, VP, C.c_int64]
+    L.jg_plan_comp_export.restype = C.c_int64
     _lib = L
     return L
 
@@ -183,6 +185,8 @@ def plan_lib():
             _plan.jg_plan_destroy.restype = None
             _plan.jg_plan_export.argtypes = [VP, C.c_int, VP, C.c_int64]
             _plan.jg_plan_export.restype = C.c_int64
+            _plan.jg_plan_comp_export.argtypes = [VP, C.c_int64, C.c_int, VP, C.c_int64]
+            _plan.jg_plan_comp_export.restype = C.c_int64
     return _plan
 
 
@@ -219,6 +223,18 @@ class Plan:
         wave records [m,16]."""
         base = {"fact": 60, "bwd": 62, "fwd": 66, "sel": 68, "pre": 76, "bwdj": 79}[kind]
         return self.get(base).reshape(-1, 8), self.get(base + 1).reshape(-1, 16)
+
+    def comp_tables(self, top_cap):
+        """Tables of the shared-factor solve (jg_symbolic.hpp: CompTables): info (n_top, split, forward levels, backward levels), top pivots,
+        forward (segments [., 8], records [., 16]), backward (segments, records)."""
+        def get(which):
+            m = plan_lib().jg_plan_comp_export(self.h, int(top_cap), which, None, 0)
+            if m < 0:
+                raise KeyError(which)
+            out = np.zeros(max(m, 1), dtype=np.int32)
+            plan_lib().jg_plan_comp_export(self.h, int(top_cap), which, out.ctypes.data, m)
+            return out[:m]
+        return get(0), get(1), (get(2).reshape(-1, 8), get(3).reshape(-1, 16)), (get(4).reshape(-1, 8), get(5).reshape(-1, 16))
 
     def top_tables(self):
         """Multifrontal top (jg_symbolic.hpp): task headers [t,16], task data, launches [l,4] = task_begin, ntasks, class,

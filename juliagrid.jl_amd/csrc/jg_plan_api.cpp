@@ -81,4 +81,25 @@ int64_t jg_plan_export(jg_plan* p, int which, int32_t* out, int64_t cap) {
     return (int64_t)v->size();
 }
 
+// Tables of the shared-factor solve (jg_symbolic.hpp: CompTables) for a dense top of at most top_cap pivots (< 0: none).
+// which: 0 {n_top, split level, forward levels, backward levels}, 1 top pivots, 2 / 3 forward segments (x8) / records (x16), 4 / 5 backward segments / records.
+int64_t jg_plan_comp_export(jg_plan* p, int64_t top_cap, int which, int32_t* out, int64_t cap) {
+    if (!p || which < 0 || which > 5) return -1;
+    jg::CompTables T;
+    jg::build_comp_tables(p->S, (int)top_cap, T);
+    std::vector<int> tmp;
+    switch (which) {
+        case 0: tmp = {T.n_top, T.split, T.n_fwd_levels, T.n_bwd_levels}; break;
+        case 1: tmp = T.top; break;
+        case 2: tmp.assign((const int*)T.fwd_seg.data(), (const int*)T.fwd_seg.data() + T.fwd_seg.size() * 8); break;
+        case 3: tmp.assign((const int*)T.fwd_rec.data(), (const int*)T.fwd_rec.data() + T.fwd_rec.size() * 16); break;
+        case 4: tmp.assign((const int*)T.bwd_seg.data(), (const int*)T.bwd_seg.data() + T.bwd_seg.size() * 8); break;
+        default: tmp.assign((const int*)T.bwd_rec.data(), (const int*)T.bwd_rec.data() + T.bwd_rec.size() * 16); break;
+    }
+    if (!out) return (int64_t)tmp.size();
+    if ((int64_t)tmp.size() > cap) return -1;
+    if (!tmp.empty()) std::memcpy(out, tmp.data(), tmp.size() * sizeof(int));
+    return (int64_t)tmp.size();
+}
+
 }  // extern "C"

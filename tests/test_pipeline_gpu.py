@@ -166,9 +166,12 @@ def test_bench_default_pipeline_ends_at_the_oracle(jg, oracle):
     assert checked_pool >= 4
 
 
-def test_monte_carlo_injection_jobs_through_the_pipeline(jg, oracle):
+@pytest.mark.parametrize("shared_first", [False, True])
+def test_monte_carlo_injection_jobs_through_the_pipeline(jg, oracle, shared_first):
     """Jobs that carry per-scenario injections (load variations: the Monte-Carlo instances of the north star) instead of outage labels: three jobs on two handles
-    with a straggler pool and a ring of device records; every job's record is bitwise the record of a plain batch with the same injections, samples agree with the oracle."""
+    with a straggler pool and a ring of device records; every job's record is bitwise the record of a plain batch with the same injections, samples agree with the oracle.
+    shared_first (round 6): the pipeline's start is a base case and the first iteration of every job is a sweep pair on its shared factor (scenarios without Ybus edits:
+    J_s = J_0 whatever their injections) -- the record then equals the refactorising batch's to rounding, iteration counts exactly."""
     import torch
     t = load_case("case1354pegase")
     s = jg.powerSystem(t)
@@ -183,7 +186,7 @@ def test_monte_carlo_injection_jobs_through_the_pipeline(jg, oracle):
         scale = 1.0 + 0.05 * rng.standard_normal((B, 1))
         jobs.append({"active": s.bus.supply.active[None, :] - s.bus.demand.active[None, :] * scale,
                      "reactive": s.bus.supply.reactive[None, :] - s.bus.demand.reactive[None, :] * scale})
-    pipe = jg.ContingencyPipeline(s, B, inflight=2, start=start, pool=128)
+    pipe = jg.ContingencyPipeline(s, B, inflight=2, start=start, pool=128, shared_first=shared_first)
     ring = [torch.zeros((B, 2 * n + 2), dtype=torch.float64, device="cuda") for _ in range(3)]
     torch.cuda.current_stream().synchronize()                                    # the fill runs on torch's stream, the library writes on its own: finish it first
     seen = []
@@ -193,6 +196,8 @@ def test_monte_carlo_injection_jobs_through_the_pipeline(jg, oracle):
         torch.cuda.current_stream().synchronize()
 
     res = pipe.run(jobs, on_done=on_done, record=lambda j: ring[j % 3].data_ptr(), records=3)
+    started = [jg.firstIterationCounts(h) for h in pipe.handles]
+    assert sum(c[0] for c in started) == (len(jobs) if shared_first else 0) and sum(c[1] for c in started) == (0 if shared_first else len(jobs))
     pipe.close()
     ref = jg.newtonRaphson(s, batch=B, max_patch=4)
     for j, job in enumerate(jobs):
@@ -202,7 +207,10 @@ def test_monte_carlo_injection_jobs_through_the_pipeline(jg, oracle):
         rec = torch.zeros((B, 2 * n + 2), dtype=torch.float64, device="cuda")
         torch.cuda.current_stream().synchronize()                                    # the fill runs on torch's stream, the library writes on its own: finish it first
         ref.pack_results_device(rec.data_ptr())
-        assert torch.equal(rec, seen[j]), j
+        if shared_first:
+            assert torch.equal(rec[:, 2 * n:], seen[j][:, 2 * n:]) and float((rec[:, :2 * n] - seen[j][:, :2 * n]).abs().max()) <= 1e-10, j
+        else:
+            assert torch.equal(rec, seen[j]), j
         assert np.array_equal(res[j][0], ref.method.iteration) and np.all(res[j][1] == 0)
     osys = oracle.OracleSystem(t)
     o = oracle.OracleNR(osys)
