@@ -468,6 +468,10 @@ struct CompactArgs {
     int* dest; int* group; int* glist; int* flags; int* tmp; int ld; int restore;
     int* host_count;           // nullable: pinned host word that receives the number of active scenarios (what the host loop polls:
                                // a store from this kernel instead of a memset node and a 4-byte copy node per iteration, ~20 us each)
+    const double* params;      // [2] = defer_at of the run (jg_nr_run_defer; 0: none).  Once at most that many scenarios are active the host stops the batch and
+                               // hands them to a pool (jg_nr_move_lanes): packing them into the first lane group -- and sending every lane home again when the
+                               // batch finishes -- moved every row of the handle twice for lanes that leave anyway (round 6: k_lanes_permute was 5.8 % of the GPU
+                               // time of the pipeline).  The lanes stay where they are; dest[0 .. n_active) lists them for the hand-off, flags[4] says so.
 };
 
 // inclusive scan over the 1024 threads of the workgroup: shuffles inside a wave, the 16 wave totals through LDS (two barriers; the
@@ -499,9 +503,30 @@ __global__ __launch_bounds__(1024) void k_compact(CompactArgs a) {
     (void)block_scan_1024(cnt, wsum, t, n_active);
     const int groups_new = (n_active + 63) / 64;
     const int groups_cur = a.flags[2];
-    const bool permute = a.restore ? true : (n_active > 0 && groups_new < groups_cur);
+    const int defer_at = a.params ? (int)a.params[2] : 0;
+    const bool hold = !a.restore && defer_at > 0 && n_active > 0 && n_active <= defer_at;
+    bool moved = false;
+    if (a.restore) {                                              // lanes that never left home need no pass over the rows
+        int away = 0;
+        for (int b = b0; b < b1; ++b) away += a.lid[b] != b;
+        int any;
+        (void)block_scan_1024(away, wsum, t, any);
+        moved = any > 0;
+    }
+    const bool permute = a.restore ? moved : (!hold && n_active > 0 && groups_new < groups_cur);
     __syncthreads();
-    if (t == 0) { a.flags[0] = permute ? 1 : 0; a.flags[1] = n_active; if (permute) a.flags[2] = a.restore ? ngroups : groups_new; if (a.host_count) *a.host_count = n_active; }
+    if (t == 0) { a.flags[0] = permute ? 1 : 0; a.flags[1] = n_active; a.flags[4] = hold ? 1 : 0; if (permute) a.flags[2] = a.restore ? ngroups : groups_new; if (a.host_count) *a.host_count = n_active; }
+    if (a.restore && !permute) {
+        for (int g = t; g < ngroups; g += 1024) { a.group[g] = 1; a.glist[g] = g; }
+        if (t == 0) { a.flags[2] = ngroups; a.flags[3] = ngroups; }
+        return;
+    }
+    if (hold) {                                                   // the hand-off's list of the lanes that leave, in lane order
+        int tot;
+        const int incl = block_scan_1024(cnt, wsum, t, tot);
+        int r = incl - cnt;
+        for (int b = b0; b < b1; ++b) if (a.active[b] != 0) a.dest[r++] = b;
+    }
     if (!permute) {                                               // groups = those that still hold an active lane
         for (int g = t; g < ngroups; g += 1024) {
             int any = 0;
@@ -687,29 +712,36 @@ struct MovePlanArgs {
     int* s_active; int* s_iters; int* s_status; const int* s_lid; const int* s_ppos; int s_ld;
     int* d_active; int* d_iters; int* d_status; int* d_lu; int* d_ppos; int d_ld;
     int* map; int* home; int* count; int mp; int lane0; int cap;
+    const int* s_flags; const int* s_list; int* srcl;          // the source's compaction flags / list of the lanes that leave (k_compact: hold); [64] source lane of candidate p
 };
 __global__ __launch_bounds__(64) void k_move_plan(MovePlanArgs a) {
-    const int p = threadIdx.x;
-    const bool act = a.s_active[p] != 0;
+    const int p0 = threadIdx.x;
+    // where the p-th candidate sits: packed into the first lane group by a compaction, or -- the batch stopped for this hand-off (k_compact: hold) -- wherever
+    // it was, listed in the source's dest[]
+    const bool listed = a.s_flags[4] != 0;
+    const int p = listed ? (p0 < a.s_flags[1] ? a.s_list[p0] : -1) : p0;
+    a.srcl[p0] = p;
+    const bool act = p >= 0 && a.s_active[p] != 0;
     const unsigned long long m = __ballot(act);
-    const int r = __popcll(m & ((1ull << p) - 1ull));
+    const int r = __popcll(m & ((1ull << p0) - 1ull));
     const int total = __popcll(m);
     const bool fits = a.lane0 + total <= a.cap;
-    if (p == 0) a.count[0] = fits ? total : -1;
-    a.map[p] = -1;
+    if (p0 == 0) a.count[0] = fits ? total : -1;
+    a.map[p0] = -1;
     if (!act || !fits) return;
     const int d = a.lane0 + r;
-    a.map[p] = d;
+    a.map[p0] = d;
     a.home[r] = a.s_lid[p];
     a.d_active[d] = 1; a.d_iters[d] = a.s_iters[p]; a.d_status[d] = 1; a.d_lu[d] = 0;
     for (int k = 0; k < a.mp; ++k) a.d_ppos[(size_t)k * a.d_ld + d] = a.s_ppos[(size_t)k * a.s_ld + p];
     a.s_active[p] = 0; a.s_status[p] = 4;
 }
-struct MoveRowsArgs { const double* src[6]; double* dst[6]; int rows[6]; int s_ld; int d_ld; const int* map; };
+struct MoveRowsArgs { const double* src[6]; double* dst[6]; int rows[6]; int s_ld; int d_ld; const int* map; const int* srcl; };
 __global__ __launch_bounds__(256) void k_move_rows(MoveRowsArgs a) {
-    const int p = threadIdx.x & 63, sub = threadIdx.x >> 6;
-    const int d = a.map[p];
+    const int p0 = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int d = a.map[p0];
     if (d < 0) return;
+    const int p = a.srcl[p0];
     const int arr = blockIdx.y;
     const double* s = a.src[arr];
     double* t = a.dst[arr];
@@ -775,7 +807,7 @@ struct jg_nr {
     bool level0_done = false;        // the Jacobian in the factor storage came from an assembly that finished the plan's level 0
     bool f_stale = false;            // d_F does not hold every scenario's final mismatch yet (see run_finish)
     bool paused = false;             // jg_nr_run_defer stopped with scenarios still active (lanes compacted, not yet sent home)
-    int* d_move = nullptr;           // straggler hand-off: map[64] | home[64] | count[1] (device), home/count mirrored in h_move (pinned)
+    int* d_move = nullptr;           // straggler hand-off: map[64] | home[64] | count[1] | source lane[64] (device), home/count mirrored in h_move (pinned)
     int* h_move = nullptr;
     double host_launch_us = 0.0, host_wait_us = 0.0; long long host_iters = 0;   // JG_HOST_TIMING=1: what the host spent in hipGraphLaunch / waiting per iteration of run_loop
     double wait_us = 0.0;            // how long the host waited for the last verdicts (running mean; wait_verdict: polls the pinned word while this is short)
@@ -911,7 +943,7 @@ int put_bus_array(jg_nr* h, double* dst, const double* src, int64_t stride) {
 // pack the active scenarios into the leading lanes (restore = 1: send every lane back home)
 void launch_compact(jg_nr* h, int restore, bool report = false) {
     CompactArgs c{h->d_active, h->d_iters, h->d_status, h->eng.status, h->d_lid, h->d_ppos, h->mp, h->d_dest, h->d_group,
-                  h->d_glist, h->d_cflags, h->d_itmp, h->ld, restore, report ? h->h_counter_dev : nullptr};
+                  h->d_glist, h->d_cflags, h->d_itmp, h->ld, restore, report ? h->h_counter_dev : nullptr, h->d_params};
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, c);
     if (h->ld == 64) return;                       // one lane group: nothing to pack, lanes never leave their home order
     double* tmp = h->eng.X;                        // the factor is dead here (rebuilt by the next factorisation)
@@ -1260,9 +1292,9 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
         {(void**)&h->d_vm, n * ld * 8}, {(void**)&h->d_va, n * ld * 8}, {(void**)&h->d_p, n * ld * 8}, {(void**)&h->d_q, n * ld * 8},
         {(void**)&h->d_ppos, mpn * ld * 4}, {(void**)&h->d_pdg, mpn * ld * 8}, {(void**)&h->d_pdb, mpn * ld * 8},
         {(void**)&h->d_F, n * 2 * ld * 8}, {(void**)&h->d_inc, n * 2 * ld * 8}, {(void**)&h->d_part, (size_t)h->nchunk * 2 * ld * 8},
-        {(void**)&h->d_normp, ld * 8}, {(void**)&h->d_normq, ld * 8}, {(void**)&h->d_params, 2 * 8}, {(void**)&h->d_active, ld * 4},
+        {(void**)&h->d_normp, ld * 8}, {(void**)&h->d_normq, ld * 8}, {(void**)&h->d_params, 4 * 8}, {(void**)&h->d_active, ld * 4},
         {(void**)&h->d_iters, ld * 4}, {(void**)&h->d_status, ld * 4}, {(void**)&h->d_counter, 4}, {(void**)&h->d_group, (ld / 64) * 4},
-        {(void**)&h->d_lid, ld * 4}, {(void**)&h->d_dest, ld * 4}, {(void**)&h->d_cflags, 16}, {(void**)&h->d_itmp, ld * 4},
+        {(void**)&h->d_lid, ld * 4}, {(void**)&h->d_dest, ld * 4}, {(void**)&h->d_cflags, 32}, {(void**)&h->d_itmp, ld * 4},
         {(void**)&h->d_glist, std::max<size_t>(ld / 64, 8) * 4}};    // map_block reads the first eight entries in one scalar load
     size_t arena_bytes = 0;
     for (const Part& q : parts) arena_bytes += (q.bytes + 255) / 256 * 256;
@@ -1626,9 +1658,9 @@ namespace {
 
 // Start of a batched solve: every real scenario active, lanes in home order, all groups in use.  keep_iters: the lanes carry
 // their iteration counts (a pool of moved scenarios, jg_nr_resume).
-int run_setup(jg_nr* h, int64_t max_iter, double tol, int lanes, bool keep_iters) {
+int run_setup(jg_nr* h, int64_t max_iter, double tol, int lanes, bool keep_iters, int defer_at = 0) {
     if (int rc = build_graphs(h)) return rc;
-    const double params[2] = {tol, (double)max_iter};
+    const double params[3] = {tol, (double)max_iter, (double)defer_at};   // defer_at: see CompactArgs
     NR_HIP(hipMemcpyAsync(h->d_params, params, sizeof(params), hipMemcpyHostToDevice, h->stream));
     if (!keep_iters) {
         NR_HIP(hipMemsetAsync(h->d_iters, 0, (size_t)h->ld * 4, h->stream));      // acPowerFlow.jl:1401
@@ -1636,7 +1668,7 @@ int run_setup(jg_nr* h, int64_t max_iter, double tol, int lanes, bool keep_iters
     }
     std::vector<int> act(h->ld, 0), lid(h->ld);
     for (int b = 0; b < h->ld; ++b) { act[b] = b < lanes; lid[b] = b; }
-    const int cf[4] = {0, lanes, h->ld / 64, h->ld / 64};
+    const int cf[8] = {0, lanes, h->ld / 64, h->ld / 64, 0, 0, 0, 0};
     if (!keep_iters) NR_HIP(hipMemcpyAsync(h->d_active, act.data(), (size_t)h->ld * 4, hipMemcpyHostToDevice, h->stream));
     NR_HIP(hipMemcpyAsync(h->d_lid, lid.data(), (size_t)h->ld * 4, hipMemcpyHostToDevice, h->stream));
     NR_HIP(hipMemcpyAsync(h->d_cflags, cf, sizeof(cf), hipMemcpyHostToDevice, h->stream));
@@ -1683,7 +1715,7 @@ static hipError_t wait_verdict(jg_nr* h) {
 }
 
 // The iteration loop: one graph per iteration until no scenario is active (the iteration limit itself is kept on the device,
-// k_check) -- or, defer_at > 0, until at most defer_at (<= 64) scenarios are: they then sit in the first lane group.
+// k_check) -- or, defer_at > 0, until at most defer_at (<= 64) scenarios are: they stay in their lanes, listed for the hand-off (k_compact: hold).
 int run_loop(jg_nr* h, int64_t max_iter, int defer_at) {
     const bool trace = getenv("JG_TRACE") != nullptr;
     auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1913,7 +1945,7 @@ int jg_nr_run_defer(jg_nr* h, int64_t max_iter, double tol, int64_t defer_at, in
     if (!h || max_iter < 0 || !(tol > 0.0) || defer_at < 0 || defer_at > 64 || !n_left) return fail(1, "jg_nr_run_defer: bad argument (defer_at in 0..64)");
     if (h->fast) return fail(1, "jg_nr_run_defer: this handle runs fast Newton-Raphson");
     if (int rc = set_device(h)) return rc;
-    if (int rc = run_setup(h, max_iter, tol, h->batch, false)) return rc;
+    if (int rc = run_setup(h, max_iter, tol, h->batch, false, h->ld > 64 ? (int)defer_at : 0)) return rc;
     if (int rc = run_start(h, max_iter)) return rc;
     if (int rc = run_loop(h, max_iter, h->ld > 64 ? (int)defer_at : 0)) return rc;   // one lane group: lanes are never packed, nothing to hand off
     *n_left = *h->h_counter;
@@ -1941,21 +1973,21 @@ int jg_nr_move_lanes(jg_nr* dst, int64_t dst_lane0, jg_nr* src, int32_t* home, i
     if (int rc = set_device(dst)) return rc;
     for (jg_nr* h : {dst, src})
         if (!h->d_move) {
-            NR_HIP(hipMalloc((void**)&h->d_move, 129 * sizeof(int)));
+            NR_HIP(hipMalloc((void**)&h->d_move, 193 * sizeof(int)));
             NR_HIP(hipHostMalloc((void**)&h->h_move, 65 * sizeof(int)));
         }
     NR_HIP(hipStreamSynchronize(src->stream));
     int* map = dst->d_move; int* d_home = dst->d_move + 64; int* d_count = dst->d_move + 128;
     MovePlanArgs pa{src->d_active, src->d_iters, src->d_status, src->d_lid, src->d_ppos, src->ld,
                     dst->d_active, dst->d_iters, dst->d_status, dst->eng.status, dst->d_ppos, dst->ld,
-                    map, d_home, d_count, src->mp, (int)dst_lane0, dst->batch};
+                    map, d_home, d_count, src->mp, (int)dst_lane0, dst->batch, src->d_cflags, src->d_dest, dst->d_move + 129};
     hipLaunchKernelGGL(k_move_plan, dim3(1), dim3(64), 0, dst->stream, pa);
     MoveRowsArgs ra{};
     int na = 0;
     auto add = [&](const double* s, double* t, int rows) { ra.src[na] = s; ra.dst[na] = t; ra.rows[na] = rows; ++na; };
     add(src->d_vm, dst->d_vm, src->n); add(src->d_va, dst->d_va, src->n); add(src->d_p, dst->d_p, src->n); add(src->d_q, dst->d_q, src->n);
     if (src->mp > 0) { add(src->d_pdg, dst->d_pdg, src->mp); add(src->d_pdb, dst->d_pdb, src->mp); }
-    ra.s_ld = src->ld; ra.d_ld = dst->ld; ra.map = map;
+    ra.s_ld = src->ld; ra.d_ld = dst->ld; ra.map = map; ra.srcl = dst->d_move + 129;
     hipLaunchKernelGGL(k_move_rows, dim3((unsigned)std::min((src->n + 3) / 4, 1024), (unsigned)na), dim3(256), 0, dst->stream, ra);
     NR_HIP(hipGetLastError());
     NR_HIP(hipMemcpyAsync(dst->h_move, d_home, 65 * sizeof(int), hipMemcpyDeviceToHost, dst->stream));
