@@ -218,6 +218,17 @@ class AcStateEstimation:
             woff = np.zeros(1)
         _lib.check(_lib.lib().jg_gn_set_measurement(self._h, mean.reshape(-1), wdiag.reshape(-1), woff.reshape(-1), sm, sc))
         self.method.mean, self.method._wdiag, self.method._woff = mean, wdiag, woff
+        self._mirror_stale = False
+
+    def _sync_mirrors(self):
+        """ drawNoise_ rewrites se.mean / se.precision on the DEVICE only; whoever reads the host mirrors afterwards -- residualTest_'s bookkeeping,
+        objective, precision, chiTest -- pulls the lanes' own realisations first (their z-dependent weights with them: squared currents, rectangular PMUs)."""
+        if not getattr(self, "_mirror_stale", False):
+            return
+        mean, wd, wo = measurementDevice(self)
+        one = self.batch == 1
+        self.method.mean, self.method._wdiag, self.method._woff = (mean[0], wd[0], wo[0]) if one else (mean, wd, wo)
+        self._mirror_stale = False
 
     def setVoltage(self, magnitude, angle):
         vm = np.ascontiguousarray(magnitude, dtype=np.float64)
@@ -260,6 +271,7 @@ class AcStateEstimation:
     @property
     def precision(self):
         """se.precision as a dense [m, m] matrix (first scenario): diagonal + 2x2 PMU blocks."""
+        self._sync_mirrors()
         wd = np.atleast_2d(self.method._wdiag)[0]
         W = np.diag(wd)
         wo = np.atleast_2d(self.method._woff)[0] if self.method._corr.size else []
@@ -270,6 +282,7 @@ class AcStateEstimation:
     @property
     def objective(self):
         """se.objective = r' W r (equations.jl:689-698), evaluated on demand from the device residuals."""
+        self._sync_mirrors()
         res = np.atleast_2d(self.residual)
         wd = np.broadcast_to(np.atleast_2d(self.method._wdiag), res.shape)
         obj = np.sum(res * res * wd, axis=1)
@@ -449,13 +462,26 @@ def _upload_readings(an: AcStateEstimation):
 def drawNoise_(an: AcStateEstimation, seed: int, scale: float = 1.0, first: int = 0):
     """Monte-Carlo realisations drawn ON the device (jg_gn_draw_noise): lane b becomes realisation `first + b` of `seed` -- z + scale * sigma * N(0,1) on every raw
     reading (measurement/utility.jl:70-73) from a counter-based generator, then the acWLS value rules -- without a byte over PCIe; the same (seed, realisation)
-    gives the same numbers on any rank, in any batch, at any lane.  The host containers (method.mean, the precision) are NOT refreshed: read them back with
-    measurementDevice(an) when needed."""
+    gives the same numbers on any rank, in any batch, at any lane.  The host mirrors (method.mean, the precision) are marked stale and pulled from the device by
+    whoever reads them next (residualTest_, objective, precision, chiTest); rows a residual test removed stay removed in the new realisations."""
     if isinstance(an, PmuStateEstimation):
         raise TypeError("drawNoise_: Gauss-Newton analyses (the linear PMU model keeps its own rows)")
     if not getattr(an, "_readings_on_device", False):
         _upload_readings(an)
     _lib.check(_lib.lib().jg_gn_draw_noise(an._h, int(seed), float(scale), int(first)))
+    an._mirror_stale = True
+    gone = getattr(an, "_removed", None)
+    if gone is not None and np.any(gone):                         # the draw rewrote every row: what bad-data processing took out of a scenario's model goes out again
+        an._sync_mirrors()
+        mean = np.array(np.atleast_2d(an.method.mean))
+        wd = np.array(np.atleast_2d(an.method._wdiag))
+        wo = np.array(np.atleast_2d(an.method._woff))
+        mean[gone] = 0.0
+        wd[gone] = 0.0
+        for q, r in enumerate(an.method._corr):
+            wo[gone[:, r - 1] | gone[:, r], q] = 0.0
+        one = an.batch == 1
+        an._upload_measurement(mean[0] if one else mean, wd[0] if one else wd, (wo[0] if one else wo) if an.method._corr.size else np.zeros(0))
 
 
 def measurementDevice(an: AcStateEstimation):
@@ -536,6 +562,7 @@ def residualTest_(an: AcStateEstimation, threshold: float = 3.0):
     _lib.check(_lib.lib().jg_gn_residual_test(an._h, mx, idx))
     detect = mx > threshold
     mon, m = an.monitoring, an.dims["m"]
+    an._sync_mirrors()                                            # the lanes' own realisations, not the set the analysis was created with
     linear = isinstance(an, PmuStateEstimation)
     labels = []
     wd = np.array(np.broadcast_to(np.atleast_2d(an.method._wdiag), (an.batch, m)))
@@ -580,7 +607,8 @@ def residualTest_(an: AcStateEstimation, threshold: float = 3.0):
     if changed:
         one = an.batch == 1
         an._upload_measurement(mean[0] if one else mean, wd[0] if one else wd, (wo[0] if one else wo) if nc else np.zeros(0))
-        an._removed = getattr(an, "_removed", np.zeros((an.batch, m), dtype=bool)) | (wd == 0.0)
+        prev = getattr(an, "_removed", None)
+        an._removed = (np.zeros((an.batch, m), dtype=bool) if prev is None else prev) | (wd == 0.0)
         an.method.iteration = 0
     one = an.batch == 1
     return NS(detect=bool(detect[0]) if one else detect, maxNormalizedResidual=float(mx[0]) if one else mx,

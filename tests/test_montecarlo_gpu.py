@@ -257,3 +257,30 @@ def test_device_noise_follows_a_meter_updated_after_the_first_draw(jg):
     keep = np.ones(mean.shape[1], dtype=bool); keep[[rv, rw]] = False
     assert np.array_equal(mean[:, keep], base[:, keep]) and np.array_equal(wd[:, keep], wbase[:, keep])
     an.close()
+
+
+def test_host_mirrors_follow_realisations_drawn_on_the_device(jg, oracle):
+    """ drawNoise_ rewrites se.mean and se.precision on the device only.  Whoever reads the host mirrors afterwards must see the lanes' own realisations:
+    `objective` (host sum with the precision mirror: squared currents and rectangular PMUs carry z-dependent weights) equals the device's own reduction, a residual test
+    keeps every lane's noisy readings apart from the rows it removes, and a later draw does not revive a removed row."""
+    mon = _every_value_rule(jg, oracle)
+    B = 6
+    an = jg.gaussNewton(mon, batch=B)
+    jg.drawNoise_(an, 99, scale=1.0)
+    noisy = jg.measurementDevice(an)
+    jg.incrementSE_(an)
+    od, oh = an.objectiveDevice(), an.objective
+    assert np.all(np.abs(od - oh) <= 1e-10 * np.maximum(1.0, np.abs(od))), (od, oh)
+    assert np.abs(np.atleast_2d(an.precision) - np.diag(np.diag(np.atleast_2d(an.precision)))).max() > 0.0      # (correlated pairs present)
+    out = jg.residualTest_(an, threshold=0.0)                     # every scenario loses the row of its largest normalised residual
+    assert out.detect.all()
+    mean, wd, wo = jg.measurementDevice(an)
+    gone = wd == 0.0
+    assert (gone.sum(axis=1) >= (noisy[1] == 0.0).sum(axis=1) + 1).all() and (gone.sum(axis=1) <= (noisy[1] == 0.0).sum(axis=1) + 2).all()
+    keep = ~gone
+    assert np.array_equal(mean[keep], noisy[0][keep]) and np.array_equal(wd[keep], noisy[1][keep]), "the other rows keep the lane's own realisation"
+    assert not np.array_equal(mean[0][keep[0] & keep[1]], mean[1][keep[0] & keep[1]]), "lanes differ: nothing was reset to the shared base set"
+    jg.drawNoise_(an, 100, scale=1.0)                             # new realisations: the removed rows stay out of the model
+    m2, w2, _ = jg.measurementDevice(an)
+    assert np.all(w2[gone] == 0.0) and np.all(m2[gone] == 0.0) and not np.array_equal(m2[keep], mean[keep])
+    an.close()
