@@ -929,13 +929,9 @@ constexpr int TOP_THREADS = 320;        // 16 x 16 bulk threads + the pivot wave
 // column q, so nothing left of it moves: the diagonal blocks, Lh and the in-task multipliers U(i,q) stay what they are).  After the
 // last step a pivot row holds J(i, ext) and y'_i; the rows leave for their own region behind the factor entries.  Same step, same
 // barrier count, no extra arithmetic issued.
-// GL = 5 (round 5, opt-in experiment JG_TOP_G32=1): the front on a 32 x 32 thread grid -- 1 024 threads, CLS = 2 covers every front (<= 63 rows + the right-hand side) with FOUR
-// blocks per thread instead of nine or sixteen; block for block the same operations in the same order => the same bits.  No pivot wave (1 024 threads is the workgroup limit): the
-// owner of the next diagonal block factorises it.  Measured slower than the 16 x 16 grid even for lone workgroups (Engine::factor has the numbers).
-template <int CLS, bool PW, bool FUSE = false, bool JORDAN = false, int GL = 4>
-__global__ __launch_bounds__(PW ? TOP_THREADS : (1 << (2 * GL))) __attribute__((amdgpu_waves_per_eu(GL == 5 ? 4 : (CLS == 4 || (FUSE && CLS == 3) ? 2 : 4)))) void k_fact_top(TopArgs a) {
-    constexpr int G = 1 << GL;
-    static_assert(GL == 4 || (GL == 5 && CLS == 2 && !PW && !FUSE), "the 32 x 32 grid: CLS = 2, no pivot wave, one pivot per barrier");
+template <int CLS, bool PW, bool FUSE = false, bool JORDAN = false>
+__global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves_per_eu(CLS == 4 || (FUSE && CLS == 3) ? 2 : 4))) void k_fact_top(TopArgs a) {
+    constexpr int GL = 4, G = 1 << GL;                           // the front on a 16 x 16 thread grid (a 32 x 32 grid and one- / two-wave kernels were measured slower: tools/experiments/r05_*.patch)
     static_assert(!(PW && FUSE), "the fused step has no pivot wave");
     static_assert(!(JORDAN && FUSE), "the fused step keeps plain rows");
     __shared__ __attribute__((aligned(16))) double Dbuf[2][4];         // factorised pivot of the current / next step
@@ -1502,403 +1498,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CLS == 4 ? 
     if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pt[4] = wall_clock64(); }
 }
 
-// ---- narrow task kernels (round 5): ONE or TWO waves per (task, scenario) ----------------------------------------------------------
-// k_fact_top spreads a front over 256 threads: a pivot step is then ~0.2 us of arithmetic inside ~0.9 us of barrier, LDS round trips and publish
-// code, and a CU holds four scenarios (r04_top_task_profile.txt: 2 560 workgroups of a task level run in two to three rounds).  The step is a chain,
-// so what a launch of MANY tasks needs is more scenarios per CU, and what a chain needs is less synchronisation per step -- both say: fewer
-// threads per scenario.
-//   W1  fronts of class 2 (f + 1 <= 32):  ONE wave per scenario, 8 x 8 thread grid, 4 x 4 blocks per thread.  No workgroup barrier at all: the
-//       pivot row / column / pivot travel through LDS inside the wave (DS operations of a wave execute in order).  A workgroup is TOPW_SPW
-//       independent waves = consecutive scenarios (their gathers touch the same 128-byte lines of the batch-minor storage).
-//   W2  fronts of class 3 (f + 1 <= 48):  TWO waves per scenario, 8 x 16 grid, 6 x 3 blocks per thread, one 2-wave barrier per step.
-// Same elimination as k_fact_top<CLS, false, false, JORDAN>, block for block and term for term in the same order (ascending pivots, the same
-// fma forms, the same 2 x 2 LU): the results are BITWISE those of the wide kernel (tests/test_top_variants_gpu.py compares digests), so a plan
-// may run either.  New here: classes of the thread grid that a step cannot change are skipped with scalar branches -- row classes whose rows are
-// all finished (plain rows; a Jordan step touches the rows above too), column classes left of the pivot, classes beyond the task's own front
-// (a launch is compiled for its class, its fronts are 22 - 31 resp. 32 - 47 rows) -- the wide kernel runs every block of every thread in every step.
-constexpr int TOPW_SPW = 4;             // W1: scenarios (waves) per workgroup
-template <int GRL, int GCL, int CR, int CC, bool JORDAN>
-__global__ __launch_bounds__(((1 << (GRL + GCL)) == 64 ? 64 * TOPW_SPW : (1 << (GRL + GCL)))) __attribute__((amdgpu_waves_per_eu(2))) void k_fact_topw(TopArgs a) {
-    constexpr int GR = 1 << GRL, GC = 1 << GCL, NT = GR * GC, NW = NT / 64, SPW = NW == 1 ? TOPW_SPW : 1;
-    constexpr int NROW = CR * GR, NCOL = CC * GC;
-    static_assert(NT == 64 || NT == 128, "one or two waves per scenario");
-    __shared__ __attribute__((aligned(16))) double Dbuf_[SPW][2][4];
-    __shared__ __attribute__((aligned(16))) double Ubuf_[SPW][2][NCOL * 4];
-    __shared__ __attribute__((aligned(16))) double Lbuf_[SPW][2][NROW * 4];
-    __shared__ __attribute__((aligned(16))) double Dref_[SPW][NROW * 2];
-    int grp, x;
-    const int qpg = (a.lpg + SPW - 1) / SPW;                     // workgroups of a task per 64-lane group
-    if (!map_block(a.sel, a.ld, a.ntasks * qpg, grp, x)) return;
-    const int ti = x / qpg;
-    const int slot = NW == 1 ? uniform((int)threadIdx.y) : 0;    // W1: the wave's scenario inside the workgroup
-    const int s0 = (x - ti * qpg) * SPW + slot;
-    const int bb = grp * 64 + s0;
-    if (s0 >= a.lpg || bb >= a.lanes) return;                    // (W1: waves are independent -- no barrier follows; W2: uniform for the workgroup)
-    double (&Dbuf)[2][4] = Dbuf_[slot]; double (&Ubuf)[2][NCOL * 4] = Ubuf_[slot]; double (&Lbuf)[2][NROW * 4] = Lbuf_[slot]; double (&Dref)[NROW * 2] = Dref_[slot];
-    const int tid = threadIdx.x;
-    const int gi = tid >> GCL, gj = tid & (GC - 1);
-    auto sync = [&] {
-        if constexpr (NW == 1) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
-        else __syncthreads();
-    };
-    const bool prof = a.prof && tid == 0;
-    long long* pt = a.prof + ((size_t)(a.task_begin + ti) * a.ld + bb) * 8;
-    if (prof) {
-        pt[0] = wall_clock64();
-        unsigned hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        pt[5] = (long long)((xcc & 0xf) << 16 | ((hw >> 13) & 0x7) << 8 | ((hw >> 8) & 0xf));
-    }
-    const RecS h = load_rec(a.task, (size_t)a.task_begin + ti);
-    const int m = h[0], e = h[1], nchild = h[5], fprime = h[11];
-    const int f = fprime - 1;
-    const int re = (f + GR - 1) >> GRL, ce = (fprime + GC - 1) >> GCL;     // thread-grid classes the front reaches
-    const int* td = a.data + h[3];
-    const size_t b = (size_t)bb, ld = (size_t)a.ld;
-    double* stk = a.stack + b * (size_t)a.stack_stride;
-    int bad = 0;
-    Blk T[CR][CC];
-    {   // ---- load: entry map, then every gather of the thread in flight together
-        int code[CR][CC];
-#pragma unroll
-        for (int r = 0; r < CR; ++r)
-#pragma unroll
-            for (int c = 0; c < CC; ++c) {
-                const int i = r * GR + gi, j = c * GC + gj;
-                code[r][c] = (i < f && j < fprime) ? td[i * fprime + j] : -1;
-            }
-#pragma unroll
-        for (int r = 0; r < CR; ++r)
-#pragma unroll
-            for (int c = 0; c < CC; ++c) {
-                const int cd = code[r][c];
-                Blk v{0.0, 0.0, 0.0, 0.0};
-                if (cd <= -2) { const double2 y = load_vec(a.W, (size_t)(-(cd + 2)), b, ld); v.v00 = y.x; v.v10 = y.y; }
-                else if (cd >= 0 && !((cd >> 28) & 1)) {
-                    v = load_blk(a.X, (size_t)(cd & 0x0fffffff), b, ld);
-                    if ((cd >> 28) & 2) { const double sw = v.v01; v.v01 = v.v10; v.v10 = sw; }      // symmetric plans: Lh(i,c) = U(c,i)'
-                }
-                T[r][c] = v;
-                const int i = r * GR + gi, j = c * GC + gj;
-                if (i == j && i < m) *(double2*)(Dref + (size_t)i * 2) = row_max(v);                  // pivot guard: the block as it entered the task
-            }
-    }
-    if (prof) pt[1] = wall_clock64();
-    {   // ---- extend-add (child order fixed => deterministic)
-        const int* cd = td + h[7];
-        for (int ch = 0; ch < nchild; ++ch) {
-            const int coff = cd[0], cen = cd[1];
-            const int* inv = cd + 2;
-            const double* C = stk + coff;
-            int ri[CR], cj[CC];
-#pragma unroll
-            for (int r = 0; r < CR; ++r) { const int i = r * GR + gi; ri[r] = i < f ? inv[i] : -1; }
-#pragma unroll
-            for (int c = 0; c < CC; ++c) { const int j = c * GC + gj; cj[c] = j < fprime ? inv[j] : -1; }
-#pragma unroll
-            for (int r = 0; r < CR; ++r)
-#pragma unroll
-                for (int c = 0; c < CC; ++c)
-                    if (ri[r] >= 0 && cj[c] >= 0) {
-                        const double2* p = (const double2*)(C + ((size_t)ri[r] * (cen + 1) + cj[c]) * 4);
-                        const double2 q0 = p[0], q1 = p[1];
-                        T[r][c].v00 += q0.x; T[r][c].v01 += q0.y; T[r][c].v10 += q1.x; T[r][c].v11 += q1.y;
-                    }
-            cd += 2 + fprime;
-        }
-    }
-    if (prof) pt[2] = wall_clock64();
-    // ---- publish step 0 (zeros where a step must not touch: row: columns <= q, column: rows <= q resp. row q itself)
-#pragma unroll
-    for (int r = 0; r < CR; ++r)
-#pragma unroll
-        for (int c = 0; c < CC; ++c) {
-            const int i = r * GR + gi, j = c * GC + gj;
-            if (i == 0) lds_set(Ubuf[0], j, j > 0 ? T[r][c] : zero_blk());
-            if (j == 0) lds_set(Lbuf[0], i, i > 0 ? T[r][c] : zero_blk());
-        }
-    if (tid == 0) {
-        const Blk d0 = factor_diag(T[0][0], bad, *(const double2*)Dref);     // (Dref[0] was written by this very thread)
-        lds_set(Dbuf[0], 0, d0);
-        T[0][0] = d0;
-    }
-    sync();
-    // ---- pivot steps
-    for (int qv = 0; qv < m; ++qv) {
-        const int q = uniform(qv);
-        const int cur = q & 1, nxt = cur ^ 1;
-        Blk D = lds_get(Dbuf[cur], 0);
-        D = Blk{uniform_d(D.v00), uniform_d(D.v01), uniform_d(D.v10), uniform_d(D.v11)};
-        const int sw = uniform(D.v10 > 2.0 ? 1 : 0);
-        const double dl = D.v10 - 4.0 * sw;
-        const int rs = JORDAN ? 0 : (q + 1) >> GRL, cs = (q + 1) >> GCL;       // first classes with a row / column the step can change
-        Blk Lq[CR];
-#pragma unroll
-        for (int r = 0; r < CR; ++r) if (r >= rs && r < re) Lq[r] = lds_get(Lbuf[cur], r * GR + gi);
-#pragma unroll
-        for (int c = 0; c < CC; ++c)
-            if (c >= cs && c < ce) {
-                const double2* p = (const double2*)(Ubuf[cur] + (size_t)(c * GC + gj) * 4);
-                const double2 a0 = p[sw], a1 = p[sw ^ 1];
-                Blk z;                                           // z = D^-1 U(q, c): rows of U read in pivot order
-                z.v10 = (a1.x - dl * a0.x) * D.v11; z.v00 = (a0.x - D.v01 * z.v10) * D.v00;
-                z.v11 = (a1.y - dl * a0.y) * D.v11; z.v01 = (a0.y - D.v01 * z.v11) * D.v00;
-#pragma unroll
-                for (int r = 0; r < CR; ++r) if (r >= rs && r < re) blk_sub(T[r][c], Lq[r], z);
-            }
-        if (q + 1 < m) {                                         // the next pivot row / column / block leave their owners
-            const int rqr = (q + 1) >> GRL, tqr = (q + 1) & (GR - 1), rqc = (q + 1) >> GCL, tqc = (q + 1) & (GC - 1);
-            if (gi == tqr && gj == tqc) {                        // the owner of S(q+1, q+1): final now, factorised here
-                const double2 ref = *(const double2*)(Dref + (size_t)(q + 1) * 2);
-#pragma unroll
-                for (int r = 0; r < CR; ++r)
-#pragma unroll
-                    for (int c = 0; c < CC; ++c)
-                        if (r == rqr && c == rqc) {
-                            const Blk dn = factor_diag(T[r][c], bad, ref);
-                            lds_set(Dbuf[nxt], 0, dn);
-                            T[r][c] = dn;
-                        }
-            }
-            if (gi == tqr) {
-#pragma unroll
-                for (int r = 0; r < CR; ++r)
-                    if (r == rqr) {
-#pragma unroll
-                        for (int c = 0; c < CC; ++c) {
-                            if (c < rqc) lds_set(Ubuf[nxt], c * GC + gj, zero_blk());
-                            else if (c > rqc) lds_set(Ubuf[nxt], c * GC + gj, T[r][c]);
-                            else lds_set(Ubuf[nxt], c * GC + gj, gj > tqc ? T[r][c] : zero_blk());
-                        }
-                    }
-            }
-            if (gj == tqc) {
-#pragma unroll
-                for (int c = 0; c < CC; ++c)
-                    if (c == rqc) {
-#pragma unroll
-                        for (int r = 0; r < CR; ++r) {
-                            if (r < rqr) lds_set(Lbuf[nxt], r * GR + gi, JORDAN ? T[r][c] : zero_blk());     // JORDAN: the rows above lose column q + 1 too
-                            else if (r > rqr) lds_set(Lbuf[nxt], r * GR + gi, T[r][c]);
-                            else lds_set(Lbuf[nxt], r * GR + gi, (JORDAN ? gi != tqr : gi > tqr) ? T[r][c] : zero_blk());
-                        }
-                    }
-            }
-        }
-        sync();
-    }
-    if (prof) pt[3] = wall_clock64();
-    // ---- store
-    const int lgo = h[12];
-    double2* out = e > 0 ? stack_unit(a, b, h[4], lgo) : nullptr;
-    const int jb = JORDAN ? h[14] : -1;
-#pragma unroll
-    for (int r = 0; r < CR; ++r)
-#pragma unroll
-        for (int c = 0; c < CC; ++c) {
-            const int i = r * GR + gi, j = c * GC + gj;
-            const int cd = (i < f && j < fprime) ? td[i * fprime + j] : -1;
-            const Blk& v = T[r][c];
-            if (JORDAN && i < m && j >= m && j < f) store_blk(a.X, (size_t)(jb + i * e + (j - m)), b, ld, v.v00, v.v01, v.v10, v.v11);
-            else if (cd <= -2) store_vec(a.W, (size_t)(-(cd + 2)), b, ld, v.v00, v.v10);
-            else if (cd >= 0 && (!((cd >> 28) & 4) || (i == j && i < m))) store_blk(a.X, (size_t)(cd & 0x0fffffff), b, ld, v.v00, v.v01, v.v10, v.v11);
-            else if (i >= m && i < f && j >= m && j < fprime) {                              // update matrix | vector: scenario-major stack
-                double2* p = out + ((((size_t)(i - m) * (e + 1) + (j - m)) * 2) << lgo);
-                p[0] = double2{v.v00, v.v01}; p[(size_t)1 << lgo] = double2{v.v10, v.v11};
-            }
-        }
-    if (bad) atomicOr(a.status + b, 4);
-    if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pt[4] = wall_clock64(); }
-}
-
-// ---- grouped tasks (jg_symbolic.hpp): one workgroup per (task, G consecutive scenarios), G = 4 or 16 ---------------------------------
-// The same elimination as k_fact_top<CLS, false> -- dense front in registers, pivot row / column / pivot through LDS, one barrier per
-// pivot, the owner of the next diagonal block factorises it -- on G thread grids of T x T (T = 8 / 4) instead of one of 16 x 16:
-// thread (g, gi, gj), g fastest, owns blocks (r T + gi, c T + gj) of scenario bb0 + g.  A load / store instruction of the gather covers
-// G x 16 contiguous bytes of the batch-minor storage (one scenario per workgroup: 16 of every 1 024), the children's update blocks are
-// interleaved over the same G scenarios, and a pivot step of the workgroup advances G scenarios.  The pivot differs from lane to lane
-// here, so the row swap of its 2x2 LU is a select, not an address.  Geometry (G, T) comes from the task header: one kernel instance
-// serves every grouped task of a level.
-template <int CLS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_fact_grp(TopArgs a) {
-    __shared__ __attribute__((aligned(16))) double Dbuf[2][16 * 4];     // [buffer][scenario]: factorised pivot of the current / next step
-    __shared__ __attribute__((aligned(16))) double Ubuf[2][256 * 4];    // [buffer][front column x G + scenario]: pivot row U(q, c)
-    __shared__ __attribute__((aligned(16))) double Lbuf[2][256 * 4];    // pivot column Lh(i, q)
-    __shared__ __attribute__((aligned(16))) double Dref[256 * 2];       // [pivot x G + scenario]: row maxima of the chain's diagonal blocks as they entered the task
-    int grp, x;
-    if (!map_block(a.sel, a.ld, a.nwg, grp, x)) return;
-    const int wm = ((CIntPtr)a.wgmap)[a.wg_begin + x];
-    const int ti = wm >> 8;
-    const RecS h = load_rec(a.task, (size_t)ti);
-    const int m = h[0], e = h[1], nchild = h[5], fprime = h[11], lgo = h[12], lg = h[13];
-    const int f = fprime - 1;
-    const int lt = 4 - (lg >> 1);
-    const int bb0 = grp * 64 + ((wm & 255) << lg);
-    if (bb0 >= a.lanes) return;                                  // padding scenarios of the last group
-    const int tid = threadIdx.x;
-    const int g = tid & ((1 << lg) - 1), gj = (tid >> lg) & ((1 << lt) - 1), gi = tid >> (lg + lt);
-    const bool live = bb0 + g < a.lanes;                         // threads of a padding scenario compute on the last real one and store nothing
-    const size_t b = (size_t)min(bb0 + g, a.lanes - 1), ld = (size_t)a.ld;
-    const int* td = a.data + h[3];
-    int bad = 0;
-    const bool prof = a.prof && tid == 0;                        // JG_TOP_PROFILE: phase stamps of the workgroup's first scenario
-    long long* pt = a.prof + ((size_t)ti * a.ld + bb0) * 8;
-    if (prof) pt[0] = wall_clock64();
-    Blk T[CLS][CLS];
-    // ---- load: entry map, then every gather of the thread in flight together
-    {
-        int code[CLS][CLS];
-#pragma unroll
-        for (int r = 0; r < CLS; ++r)
-#pragma unroll
-            for (int c = 0; c < CLS; ++c) {
-                const int i = (r << lt) + gi, j = (c << lt) + gj;
-                code[r][c] = (i < f && j < fprime) ? td[i * fprime + j] : -1;
-            }
-#pragma unroll
-        for (int r = 0; r < CLS; ++r)
-#pragma unroll
-            for (int c = 0; c < CLS; ++c) {
-                const int cd = code[r][c];
-                Blk v{0.0, 0.0, 0.0, 0.0};
-                if (cd <= -2) { const double2 y = load_vec(a.W, (size_t)(-(cd + 2)), b, ld); v.v00 = y.x; v.v10 = y.y; }
-                else if (cd >= 0 && !((cd >> 28) & 1)) {
-                    v = load_blk(a.X, (size_t)(cd & 0x0fffffff), b, ld);
-                    if ((cd >> 28) & 2) { const double s = v.v01; v.v01 = v.v10; v.v10 = s; }        // symmetric plans: Lh(i,c) = U(c,i)'
-                }
-                T[r][c] = v;
-                // pivot guard (as in k_fact_top): what a pivot is compared with is its block as it ENTERED the task, before the children's
-                // update matrices come in -- taken after the extend-add the reference scale of an island's root was the cancelled value itself
-                const int i = (r << lt) + gi, j = (c << lt) + gj;
-                if (i == j && i < m) *(double2*)(Dref + (size_t)((i << lg) + g) * 2) = row_max(v);
-            }
-    }
-    if (prof) pt[1] = wall_clock64();
-    // ---- extend-add: the children's update blocks, interleaved over the scenarios of THIS workgroup (child order fixed => deterministic)
-    {
-        const int* cd = td + h[7];
-        for (int ch = 0; ch < nchild; ++ch) {
-            const int coff = cd[0], ce = cd[1];
-            const int* inv = cd + 2;
-            const double2* C = stack_unit(a, b, coff, lg);
-            int ri[CLS], cj[CLS];
-#pragma unroll
-            for (int r = 0; r < CLS; ++r) { const int i = (r << lt) + gi; ri[r] = i < f ? inv[i] : -1; }
-#pragma unroll
-            for (int c = 0; c < CLS; ++c) { const int j = (c << lt) + gj; cj[c] = j < fprime ? inv[j] : -1; }
-#pragma unroll
-            for (int r = 0; r < CLS; ++r)
-#pragma unroll
-                for (int c = 0; c < CLS; ++c)
-                    if (ri[r] >= 0 && cj[c] >= 0) {
-                        const double2* p = C + ((((size_t)ri[r] * (ce + 1) + cj[c]) * 2) << lg);
-                        const double2 s0 = p[0], s1 = p[(size_t)1 << lg];
-                        T[r][c].v00 += s0.x; T[r][c].v01 += s0.y; T[r][c].v10 += s1.x; T[r][c].v11 += s1.y;
-                    }
-            cd += 2 + fprime;
-        }
-    }
-    if (prof) pt[2] = wall_clock64();
-    // ---- publish step 0 (zeros where the step must not touch: row: columns <= q, column: rows <= q)
-#pragma unroll
-    for (int r = 0; r < CLS; ++r)
-#pragma unroll
-        for (int c = 0; c < CLS; ++c) {
-            const int i = (r << lt) + gi, j = (c << lt) + gj;
-            if (i == 0) lds_set(Ubuf[0], (j << lg) + g, j > 0 ? T[r][c] : zero_blk());
-            if (j == 0) lds_set(Lbuf[0], (i << lg) + g, i > 0 ? T[r][c] : zero_blk());
-        }
-    if (gi == 0 && gj == 0) {
-        const Blk d0 = factor_diag(T[0][0], bad, *(const double2*)(Dref + (size_t)g * 2));      // (written by this very thread in the load loop)
-        lds_set(Dbuf[0], g, d0);
-        T[0][0] = d0;
-    }
-    __syncthreads();
-    // ---- pivot steps
-    for (int qv = 0; qv < m; ++qv) {
-        const int q = uniform(qv);
-        const int cur = q & 1, nxt = cur ^ 1;
-        const Blk D = lds_get(Dbuf[cur], g);
-        const bool sw = D.v10 > 2.0;
-        const double dl = sw ? D.v10 - 4.0 : D.v10;
-        Blk Lq[CLS];
-#pragma unroll
-        for (int r = 0; r < CLS; ++r) Lq[r] = lds_get(Lbuf[cur], ((((r << lt) + gi)) << lg) + g);
-#pragma unroll
-        for (int c = 0; c < CLS; ++c) {
-            const double2* p = (const double2*)(Ubuf[cur] + (size_t)((((c << lt) + gj) << lg) + g) * 4);
-            const double2 r0 = p[0], r1 = p[1];
-            const double2 a0 = sw ? r1 : r0, a1 = sw ? r0 : r1;  // z = D^-1 U(q, c): rows of U in pivot order
-            Blk z;
-            z.v10 = (a1.x - dl * a0.x) * D.v11; z.v00 = (a0.x - D.v01 * z.v10) * D.v00;
-            z.v11 = (a1.y - dl * a0.y) * D.v11; z.v01 = (a0.y - D.v01 * z.v11) * D.v00;
-#pragma unroll
-            for (int r = 0; r < CLS; ++r) blk_sub(T[r][c], Lq[r], z);
-        }
-        if (q + 1 < m) {
-            const int rq = (q + 1) >> lt, tq = (q + 1) & ((1 << lt) - 1);
-            if (gi == tq && gj == tq) {                          // the owner of S(q+1, q+1): final now, factorised here
-                const double2 ref = *(const double2*)(Dref + (size_t)(((q + 1) << lg) + g) * 2);
-#pragma unroll
-                for (int r = 0; r < CLS; ++r)
-                    if (r == rq) {
-                        const Blk dn = factor_diag(T[r][r], bad, ref);
-                        lds_set(Dbuf[nxt], g, dn);
-                        T[r][r] = dn;
-                    }
-            }
-            if (gi == tq) {
-#pragma unroll
-                for (int r = 0; r < CLS; ++r)
-                    if (r == rq) {
-#pragma unroll
-                        for (int c = 0; c < CLS; ++c) {
-                            const int slot = (((c << lt) + gj) << lg) + g;
-                            if (c < rq) lds_set(Ubuf[nxt], slot, zero_blk());
-                            else if (c > rq) lds_set(Ubuf[nxt], slot, T[r][c]);
-                            else lds_set(Ubuf[nxt], slot, gj > tq ? T[r][c] : zero_blk());
-                        }
-                    }
-            }
-            if (gj == tq) {
-#pragma unroll
-                for (int c = 0; c < CLS; ++c)
-                    if (c == rq) {
-#pragma unroll
-                        for (int r = 0; r < CLS; ++r) {
-                            const int slot = (((r << lt) + gi) << lg) + g;
-                            if (r < rq) lds_set(Lbuf[nxt], slot, zero_blk());
-                            else if (r > rq) lds_set(Lbuf[nxt], slot, T[r][c]);
-                            else lds_set(Lbuf[nxt], slot, gi > tq ? T[r][c] : zero_blk());
-                        }
-                    }
-            }
-        }
-        __syncthreads();
-    }
-    if (prof) pt[3] = wall_clock64();
-    // ---- store
-    if (!live) return;
-    double2* out = e > 0 ? stack_unit(a, b, h[4], lgo) : nullptr;
-#pragma unroll
-    for (int r = 0; r < CLS; ++r)
-#pragma unroll
-        for (int c = 0; c < CLS; ++c) {
-            const int i = (r << lt) + gi, j = (c << lt) + gj;
-            const int cd = (i < f && j < fprime) ? td[i * fprime + j] : -1;
-            const Blk& v = T[r][c];
-            if (cd <= -2) store_vec(a.W, (size_t)(-(cd + 2)), b, ld, v.v00, v.v10);
-            else if (cd >= 0 && (!((cd >> 28) & 4) || (i == j && i < m))) store_blk(a.X, (size_t)(cd & 0x0fffffff), b, ld, v.v00, v.v01, v.v10, v.v11);
-            else if (i >= m && i < f && j >= m && j < fprime) {                              // update matrix | vector
-                double2* p = out + ((((size_t)(i - m) * (e + 1) + (j - m)) * 2) << lgo);
-                p[0] = double2{v.v00, v.v01}; p[(size_t)1 << lgo] = double2{v.v10, v.v11};
-            }
-        }
-    if (bad) atomicOr(a.status + b, 4);
-    if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pt[4] = wall_clock64(); pt[5] = 0; }
-}
-
 // per-level launch table: segment ranges and chunk totals
 void level_launches(const std::vector<Segment>& segs, std::vector<DevLaunch>& out) {
     out.clear();
@@ -1962,7 +1561,7 @@ std::shared_ptr<SharedPlan> acquire_plan(int n, const int* rowptr, const int* co
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess) { error = "no HIP device"; rc = 2; return nullptr; }
     if (n <= 0 || !rowptr || !col || rowptr[0] != 0) { error = "block pattern must be structurally symmetric with a full diagonal"; rc = 1; return nullptr; }
-    static const bool nocache = getenv("JG_PLAN_CACHE") && atoi(getenv("JG_PLAN_CACHE")) == 0;
+    static const bool nocache = knob("PLAN_CACHE", 1) == 0;
     const unsigned long long h = pattern_hash(n, rowptr, col, policy, device);
     //  The lock covers the look-up and the publication, NOT the analysis: creates of different patterns (other grids, other devices, other
     // threads) run side by side; a second handle of the SAME key waits for the first one's analysis, then hits.
@@ -2015,7 +1614,7 @@ std::shared_ptr<SharedPlan> acquire_plan(int n, const int* rowptr, const int* co
         rc = 2;
         return nullptr;
     }
-    if (getenv("JG_PLAN_TIMING")) fprintf(stderr, "[jg engine]   table upload %6.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - tu0);
+    if (knob_set("PLAN_TIMING")) fprintf(stderr, "[jg engine]   table upload %6.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - tu0);
     if (!nocache) {
         lock.lock();
         g_plans.push_back(p);
@@ -2039,17 +1638,17 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, long long 
     // large batches: the top starts where a level holds at most 384 items and 8 pivots on the large grids (ACTIVSg10k at 512 scenarios: 1.279 -> 1.241 ms
     // against 280 items / 4 pivots, which the small grids keep: case1354pegase 0.148 against 0.160 ms; the 9241-bus grid does not care)
     const bool defaults = !((policy >> 16) & 0x7fff);
-    if (defaults && ld_ >= 256 && !getenv("JG_TOP_NOSPLIT")) policy |= 8;
+    if (defaults && ld_ >= 256) policy |= 8;
     // round 4: large batches factorise the bottom of the tree in TASKS (jg_symbolic.hpp: shared operands of a pivot row / column staged in LDS, one
     // block load per update term instead of three).  JG_ROW_TASKS=0: the wave records of round 3; =2: tasks for every batch size.
     {
-        static const int tasks_env = getenv("JG_ROW_TASKS") ? atoi(getenv("JG_ROW_TASKS")) : 1;
+        static const int tasks_env = knob("ROW_TASKS", 1);
         if (defaults && !((policy >> 32) & 0xff) && (tasks_env == 2 || (tasks_env == 1 && ld_ >= 256))) policy |= 1LL << 50;
     }
     // round 3 (the top launches got cheaper: Jordan rows, 4-wave variant where it pays): on the large grids a large batch starts the top where a level
     // holds at most 12 pivots, whatever its item count (narrow = 127: no limit) -- ACTIVSg10k: level 22 instead of 27, 1.236 -> 1.213 ms at 512
     // scenarios, three interleaved runs each; the 9241-bus grid does not care; symmetric plans -- the Gauss-Newton gain -- keep the rule of round 2: 2.96 against 2.99 ms for factorisation + sweep
-    static const bool top_r02 = getenv("JG_TOP_R02") != nullptr;     // the rule of round 2 (384 items, 8 pivots)
+    constexpr bool top_r02 = false;                               // (the rule of round 2 -- 384 items, 8 pivots -- stays for symmetric plans: below)
     // a handful of scenarios (the owner sets `lanes` before create: a single power flow, up to 32 scenarios) of an unsymmetric matrix: the top starts as
     // low as the level schedule allows (no item limit) -- a task costs one workgroup per REAL scenario, and since the Jordan rows the pivots of the top
     // are the cheap ones of the backward sweep as well.  ACTIVSg10k, one scenario: factorisation 0.283 -> 0.244 ms, backward sweep 0.104 -> 0.060,
@@ -2061,7 +1660,7 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, long long 
     const bool lane64 = !top_r02 && ld_ == 64 && !tiny && n >= 4000 && !(policy & 2);
     if (defaults) policy |= ld_ >= 256 ? (n >= 4000 ? (top_r02 || (policy & 2) ? (47 << 16 | (384 / 8) << 24 | 8 << 4) : (47 << 16 | 127 << 24 | 12 << 4)) : (47 << 16 | (280 / 8) << 24 | 4 << 4))
                                               : ((n >= 4000 ? 26 : 24) << 16 | (tiny || lane64 ? 127 : 384 / 8) << 24 | (lane64 ? 15 << 4 : 0));
-    const bool timing = getenv("JG_PLAN_TIMING") != nullptr;
+    const bool timing = knob_set("PLAN_TIMING");
     auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double te0 = tnow();
     {
@@ -2076,7 +1675,7 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, long long 
     level_launches(plan->S.bwd_seg, bwd);
     level_launches(plan->S.bwdj_seg, bwdj);
     level_launches(plan->S.fwd_seg, fwd);
-    jordan = plan->S.jordan && !(getenv("JG_JORDAN") && atoi(getenv("JG_JORDAN")) == 0);
+    jordan = plan->S.jordan && knob("JORDAN", 1) != 0;
     // the device tables belong to the plan; the engine keeps plain aliases for its launches
     fact_rec = plan->fact_rec; bwd_rec = plan->bwd_rec; pre_rec = plan->pre_rec; fwd_rec = plan->fwd_rec;
     fact_seg = plan->fact_seg; bwd_seg = plan->bwd_seg; pre_seg = plan->pre_seg; fwd_seg = plan->fwd_seg;
@@ -2087,7 +1686,7 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, long long 
         const size_t sb = (size_t)(std::max<long long>(plan->S.top_stack_cls[0], 2) + plan->S.top_stack_cls[1] + plan->S.top_stack_cls[2]) * ld * sizeof(double);
         JG_HIP(hipMalloc((void**)&top_stack, sb));
         JG_HIP(sync_fill(top_stack, 0, sb, st));
-        if (getenv("JG_TOP_PROFILE")) {
+        if (knob_set("TOP_PROFILE")) {
             JG_HIP(hipMalloc((void**)&top_prof, plan->S.top_task.size() * ld * 8 * sizeof(long long)));
             JG_HIP(sync_fill(top_prof, 0, plan->S.top_task.size() * ld * 8 * sizeof(long long), st));
         }
@@ -2099,7 +1698,6 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, long long 
     JG_HIP(hipMalloc((void**)&status, (size_t)ld * sizeof(int)));
     JG_HIP(sync_fill(status, 0, (size_t)ld * sizeof(int), st));
     JG_HIP(hipGetDevice(&device));
-    probe_part = getenv("JG_PROBE_FACT_PART") ? atoi(getenv("JG_PROBE_FACT_PART")) : 0;
     if (timing) fprintf(stderr, "[jg engine] + factor storage, stacks               %6.1f ms\n", tnow() - te0);
     return 0;
 }
@@ -2173,13 +1771,12 @@ int Engine::factor(hipStream_t st, const double* A, const double* rhs, const Gro
         for (const TopLaunch& L : plan->S.top_launch) {
             t.task_begin = L.task_begin; t.ntasks = L.ntasks;
             const bool jordan = this->jordan && plan->S.jordan;
-            if (L.grouped) {                                     // every grouped task of the level: 4 or 16 scenarios per workgroup
-                t.wg_begin = L.wg_begin; t.nwg = L.nwg;
-                hipLaunchKernelGGL((k_fact_grp<4>), dim3(grid_blocks(ld / 64, L.nwg)), dim3(256), 0, st, t);
-                continue;
+            if (L.grouped) {                                     // plans with a "mid" policy (jg_symbolic.hpp): their kernel was retired with its measurements
+                error = "this plan holds grouped top tasks (policy bits 32-39): k_fact_grp left the library in round 6 (tools/experiments/r06_retired_kernels.patch)";
+                return 1;
             }
             // round 5: symmetric plans with Jordan rows (the Gauss-Newton gain by default) eliminate the upper triangle only (k_fact_top_sym); JG_TOP_SYM=0: the mirrored front
-            static const bool sym_env = !(getenv("JG_TOP_SYM") && atoi(getenv("JG_TOP_SYM")) == 0);
+            static const bool sym_env = knob("TOP_SYM", 1) != 0;
             if (plan->S.symmetric && jordan && sym_env) {
                 const dim3 grids(grid_blocks(ld / 64, (long long)L.ntasks * t.lpg));
                 if (L.cls == 2) hipLaunchKernelGGL((k_fact_top_sym<2>), grids, dim3(256), 0, st, t);
@@ -2187,45 +1784,16 @@ int Engine::factor(hipStream_t st, const double* A, const double* rhs, const Gro
                 else hipLaunchKernelGGL((k_fact_top_sym<4>), grids, dim3(256), 0, st, t);
                 continue;
             }
-            // round 5: narrow task kernels (k_fact_topw) for the front classes they exist for -- bitwise the results of k_fact_top.  JG_TOPW=1: W1 (class 2), 2: W2
-            // (class 3), 3: both; default 0 = the wide kernel everywhere: MEASURED SLOWER (profiles/r05_topw_ab.txt: factorisation of 512 scenarios 1.164 -> 1.189 ms
-            // with W1, -> 1.317 with W2, a single instance 0.241 -> 0.423 ms).  A lone wave issues one instruction per ~4.5 clocks whatever its kind, so a scenario's
-            // step on ONE wave (16 block updates + their bookkeeping, ~350 instructions at best, 766 as compiled) is slower than the same step spread over the four
-            // SIMDs of a CU, and the register file -- not the thread count -- caps the scenarios a CU holds (a 31-row front is 124 VGPRs x 64 lanes however it is
-            // dealt: 8 waves of W1 against 7 workgroups of k_fact_top<2>).  Kept as a checked experiment (tests/test_top_variants_gpu.py), DESIGN_LOG round 5.
-            static const int topw_env = getenv("JG_TOPW") ? atoi(getenv("JG_TOPW")) : 0;
-            if (L.cls == 2 && (topw_env & 1)) {
-                const dim3 gridw(grid_blocks(ld / 64, (long long)L.ntasks * ((t.lpg + TOPW_SPW - 1) / TOPW_SPW)));
-                if (jordan) hipLaunchKernelGGL((k_fact_topw<3, 3, 4, 4, true>), gridw, dim3(64, TOPW_SPW), 0, st, t);
-                else hipLaunchKernelGGL((k_fact_topw<3, 3, 4, 4, false>), gridw, dim3(64, TOPW_SPW), 0, st, t);
-                continue;
-            }
-            if (L.cls == 3 && (topw_env & 2)) {
-                const dim3 gridw(grid_blocks(ld / 64, (long long)L.ntasks * t.lpg));
-                if (jordan) hipLaunchKernelGGL((k_fact_topw<3, 4, 6, 3, true>), gridw, dim3(128), 0, st, t);
-                else hipLaunchKernelGGL((k_fact_topw<3, 4, 6, 3, false>), gridw, dim3(128), 0, st, t);
-                continue;
-            }
             const dim3 grid(grid_blocks(ld / 64, (long long)L.ntasks * t.lpg));
             // More workgroups than the CUs can hold WITH a pivot wave (1 per CU at CLS = 4, 2 at CLS = 3, 3 at CLS = 2): the 4-wave
             // variant, of which a CU holds twice as many; else the pivot-wave variant, whose step is 15 % shorter (measured at 512
             // scenarios: 0.86 against 1.02 us per step with two workgroups on a CU).
-            static const int pw_env = getenv("JG_TOP_PW") ? atoi(getenv("JG_TOP_PW")) : -1;
+            static const int pw_env = knob("TOP_PW", -1);
             const long long wgs = (long long)L.ntasks * std::min<long long>(t.lanes, (long long)t.lpg * (ld / 64));
             // (shared: the handle is one of several batches in flight on this GPU -- a CU with two 4-wave top workgroups still has room for a level
             // workgroup of another batch, with 5-wave ones it has not: +2-3 % on the 512 x 3 pipeline, -0.6 % on a lone factorisation; same bits)
             const bool pw = pw_env >= 0 ? pw_env != 0 : (!shared && wgs <= 256 * (L.cls == 4 ? 1 : (L.cls == 3 ? 2 : 3)));
-            static const int fuse_env = getenv("JG_TOP_FUSE") ? atoi(getenv("JG_TOP_FUSE")) : 0;
-            // round 5, OPT-IN (JG_TOP_G32=1): the front over 1 024 threads -- four blocks per thread whatever the class, a third of the instructions per wave and step
-            // (k_fact_top<2, false, false, ., 5>; same bits).  MEASURED SLOWER even for the lone workgroups of a single instance (profiles/r05_g32_ab.txt: factorisation 0.242 ->
-            // 0.258 ms on the 10k-bus grid, 0.079 -> 0.102 on case1354pegase): sixteen waves read four times the pivot row / column bytes from the CU's one LDS port (128 KB per
-            // step against 49 KB) and meet at a 16-wave barrier.  With the one- / two-wave kernels (JG_TOPW) this brackets the 16 x 16 grid from both sides.
-            static const int g32_env = getenv("JG_TOP_G32") ? atoi(getenv("JG_TOP_G32")) : 0;
-            if (g32_env > 0 && !(fuse_env && !jordan) && pw_env < 0) {
-                if (jordan) hipLaunchKernelGGL((k_fact_top<2, false, false, true, 5>), grid, dim3(1024), 0, st, t);
-                else hipLaunchKernelGGL((k_fact_top<2, false, false, false, 5>), grid, dim3(1024), 0, st, t);
-                continue;
-            }
+            static const int fuse_env = knob("TOP_FUSE", 0);
             if (jordan) {                                        // Jordan rows (jg_symbolic.hpp); the plain sweep's tables would read garbage after this
                 if (pw) {
                     if (L.cls == 2) hipLaunchKernelGGL((k_fact_top<2, true, false, true>), grid, dim3(TOP_THREADS), 0, st, t);

@@ -400,104 +400,6 @@ __global__ __launch_bounds__(256) void k_gn_gain(GainArgs a) {
     }
 }
 
-// The same sums with a bus row's operands STAGED IN LDS.  Bus rows that follow each other in pivot order are electrical
-// neighbours: the measurement rows they share put the same slots into many of their gain blocks (a slot of an injection row
-// with d + 1 slots is wanted by d + 1 bus rows, by every block of each).  k_gn_gain fetched each operand of each term from
-// memory (PMC, 512 scenarios: 9.1 GB fetched for 3.5 GB of unique input -- the waves in flight on one XCD span ~ 500 bus rows
-// x 70 KiB, far beyond its 4 MiB L2).  Here a TASK = a run of consecutive bus rows whose operands fit GAIN_LDS_SLOTS 1-KiB
-// images: the workgroup's 8 waves first stage every distinct slot once (raw image) and every distinct (weight, slot) pair once
-// (weighted image w*h: the left factor of a term), then the items of the task are dealt to the waves as runs of 64-byte records
-// and each term is two ds_read_b128 + four FMAs.  Sums run in the order of the contribution lists, as in k_gn_gain.
-//   stage entry: {slot, weight row | -1, weighted image | -1, raw image | -1}
-//   record: {head, dst, n, -, 12 x (weighted | raw << 16)} for a gain block, {head, dst, n, -, 6 x (weighted, residual row)} for a rhs row
-constexpr int GAIN_LDS_SLOTS = 80;                  // 80 KiB of LDS per workgroup (dynamic): two 8-wave workgroups per CU use its 160 KiB
-constexpr int GAIN_LDS_WAVES = 8;
-constexpr int GAIN_LDS_TB = 12, GAIN_LDS_TR = 6;    // terms per record: gain block / rhs row
-struct GainTask { int w[16]; };                     // n_stage, stage_off, rec_base, rec_end[8] (relative, cumulative per wave)
-struct GainLdsArgs {
-    const GainTask* task; const int* stage; const GainRec* rec;
-    const double* Hs; const double* res; const double* w;
-    double* Gv; double* rhs;
-    int n_tasks; int ld;
-};
-
-__global__ __launch_bounds__(64 * GAIN_LDS_WAVES, 2) void k_gn_gain_lds(GainLdsArgs a) {
-    extern __shared__ double2 img[];
-    const int lane = threadIdx.x;
-    const int wave = uniform(threadIdx.y);
-    const size_t ld = (size_t)a.ld;
-    int grp, bx;
-    if (!jg::map_block(jg::GroupSel{}, a.ld, a.n_tasks, grp, bx)) return;
-    const size_t b = (size_t)grp * 64 + lane;
-    typedef int i4 __attribute__((ext_vector_type(4)));
-    typedef const i4 __attribute__((address_space(4)))* CInt4;
-    const GRecS th = ((GRecPtr)a.task)[bx];
-    const int n_stage = th[0];
-    CInt4 st = (CInt4)a.stage + th[1];
-    int r = th[2] + (wave ? th[2 + wave] : 0);
-    const int r1 = th[2] + th[3 + wave];
-    GRecS cur = ((GRecPtr)a.rec)[r];                                             // the wave's first record travels while the images are staged (the table ends with a pad record)
-    constexpr int SU = 8;                                                        // independent slot loads per wave and trip
-    for (int e0 = wave * SU; e0 < n_stage; e0 += GAIN_LDS_WAVES * SU) {
-        static_assert(SU == 8, "operand list of the wait");
-        i4 d[SU]; jg::d2v hv[SU]; double wt[SU];
-#pragma unroll
-        for (int u = 0; u < SU; ++u) d[u] = st[min(e0 + u, n_stage - 1)];          // the stage entries first (scalar loads, all in flight together)
-#pragma unroll
-        for (int u = 0; u < SU; ++u) asm volatile("" : "=v"(hv[u]), "=v"(wt[u]));
-        const unsigned off8 = (unsigned)b * 8u, off16 = (unsigned)b * 16u;
-#pragma unroll
-        for (int u = 0; u < SU; ++u) if (e0 + u < n_stage) {                        // hand-placed requests, one wait (jg_engine.hpp: gload16)
-            jg::gload16(hv[u], (const char*)a.Hs + (size_t)d[u][0] * ld * 16, off16);
-            if (d[u][1] >= 0) jg::gload8(wt[u], (const char*)a.w + (size_t)d[u][1] * ld * 8, off8);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("" : "+v"(hv[0]), "+v"(wt[0]), "+v"(hv[1]), "+v"(wt[1]), "+v"(hv[2]), "+v"(wt[2]), "+v"(hv[3]), "+v"(wt[3]),
-                          "+v"(hv[4]), "+v"(wt[4]), "+v"(hv[5]), "+v"(wt[5]), "+v"(hv[6]), "+v"(wt[6]), "+v"(hv[7]), "+v"(wt[7]));
-#pragma unroll
-        for (int u = 0; u < SU; ++u) if (e0 + u < n_stage) {
-            const double w = d[u][1] >= 0 ? wt[u] : 0.0;
-            if (d[u][3] >= 0) img[d[u][3] * 64 + lane] = double2{hv[u].x, hv[u].y};
-            if (d[u][2] >= 0) img[d[u][2] * 64 + lane] = double2{w * hv[u].x, w * hv[u].y};
-        }
-    }
-    __syncthreads();
-    if (r >= r1) return;
-    double g00 = 0.0, g01 = 0.0, g10 = 0.0, g11 = 0.0;
-    for (; r < r1; ++r) {
-        GRecS nxt = cur;
-        if (r + 1 < r1) nxt = ((GRecPtr)a.rec)[r + 1];
-        const int head = cur[0], n = cur[2];
-        if (head & 1) {
-            double rs[GAIN_LDS_TR];
-#pragma unroll
-            for (int t = 0; t < GAIN_LDS_TR; ++t) if (t < n) rs[t] = a.res[(size_t)cur[5 + 2 * t] * ld + b];
-#pragma unroll
-            for (int t = 0; t < GAIN_LDS_TR; ++t) if (t < n) { const double2 l = img[cur[4 + 2 * t] * 64 + lane]; g00 += l.x * rs[t]; g01 += l.y * rs[t]; }
-        } else {
-#pragma unroll
-            for (int t = 0; t < GAIN_LDS_TB; ++t) if (t < n) {
-                const int q = cur[4 + t];
-                const double2 l = img[(q & 0xffff) * 64 + lane], y = img[(q >> 16) * 64 + lane];
-                g00 += l.x * y.x; g01 += l.x * y.y; g10 += l.y * y.x; g11 += l.y * y.y;
-            }
-        }
-        if (head & 256) {
-            if (head & 1) {
-                if (head & 16) g00 = 0.0;
-                jg::store_vec(a.rhs, (size_t)cur[1], b, ld, g00, g01);
-            } else {
-                if (head & 16) { g00 = 0.0; g01 = 0.0; }
-                if (head & 32) { g00 = 0.0; g10 = 0.0; }
-                if ((head & 48) == 48) g00 = 1.0;
-                jg::store_blk(a.Gv, (size_t)cur[1], b, ld, g00, g01, g10, g11);
-            }
-            g00 = 0.0; g01 = 0.0; g10 = 0.0; g11 = 0.0;
-        }
-        cur = nxt;
-    }
-}
-
 constexpr int NORM_ROWS = 64;
 
 // Correction pass of the orthogonal (Q-less) method: rho = res - H * inc over the slots of a row (the slack angle column
@@ -792,7 +694,6 @@ struct jg_gn {
     double* d_vm = nullptr; double* d_va = nullptr; double* d_mean = nullptr; double* d_w = nullptr;
     double* d_Hs = nullptr; double* d_res = nullptr; double* d_rhs = nullptr; double* d_inc = nullptr;
     GainRec* d_grec = nullptr; int* d_gwave = nullptr; GainRec* d_rrec = nullptr; int* d_rwave = nullptr;   // gain + rhs records of the items that are NOT staged (k_gn_gain), rhs records alone
-    GainTask* d_gtask = nullptr; int* d_gstage = nullptr; GainRec* d_trec = nullptr; int gain_tasks = 0, gain_lds_bytes = 0;   // LDS-staged tasks (k_gn_gain_lds)
     // bad-data test (built on first use)
     std::vector<RowDesc> rows_host; std::vector<int> slot_bus_host;
     int* d_pair_ptr = nullptr; int* d_pa = nullptr; int* d_pb = nullptr; int* d_pz = nullptr;
@@ -829,10 +730,6 @@ void launch_gain(jg_gn* h, bool correction = false) {
     GainArgs a{correction ? h->d_rrec : h->d_grec, correction ? h->d_rwave : h->d_gwave, h->d_Hs, correction ? h->d_rho : h->d_res, h->d_w, h->eng.X,
                correction ? h->d_rhs2 : h->d_rhs, nw, h->ld};
     if (nw > 0) hipLaunchKernelGGL(k_gn_gain, dim3(jg::grid_blocks(h->ld / 64, (nw + 3) / 4)), dim3(64, 4), 0, h->stream, a);
-    if (!correction && h->gain_tasks > 0) {
-        GainLdsArgs t{h->d_gtask, h->d_gstage, h->d_trec, h->d_Hs, h->d_res, h->d_w, h->eng.X, h->d_rhs, h->gain_tasks, h->ld};
-        hipLaunchKernelGGL(k_gn_gain_lds, dim3(jg::grid_blocks(h->ld / 64, h->gain_tasks)), dim3(64, GAIN_LDS_WAVES), (size_t)h->gain_lds_bytes, h->stream, t);
-    }
 }
 
 int launch_increment(jg_gn* h, const int* group) {
@@ -1083,9 +980,8 @@ int jg_gn_create(jg_gn** out, int64_t n, const int64_t* colptr, const int64_t* r
     const std::vector<int>& ip = h->eng.plan->S.iperm;
     // wave records (see k_gn_gain): bus rows in PIVOT order -- the postorder of the elimination tree keeps electrical
     // neighbours together whatever the bus numbering of the case is, and neighbours are what shares measurement rows
-    std::vector<GainRec> grec, rrec, trec;
-    std::vector<int> gwave{0}, rwave{0}, gstage;
-    std::vector<GainTask> gtask;
+    std::vector<GainRec> grec, rrec;
+    std::vector<int> gwave{0}, rwave{0};
     {
         const int slack = h->slack0;                                             // -1: the model has no slack (PMU-only)
         const std::vector<int>& src_entry = h->eng.plan->S.src_entry;
@@ -1110,88 +1006,8 @@ int jg_gn_create(jg_gn** out, int64_t n, const int64_t* colptr, const int64_t* r
         }
         const std::vector<int>& perm = h->eng.plan->S.perm;
         constexpr size_t WAVE_RECS = 4;                                          // a wave's share: about 4 records, whole items (2: 1.25 ms, 4: 1.19, 8: 1.21, 32: 1.50 at 512 scenarios)
-        // LDS-staged tasks (k_gn_gain_lds): consecutive bus rows in pivot order while their distinct operands fit the budget.
-        // OPT-IN (JG_GAIN_LDS=<images per task, at most 80>; default 0 = every item on the direct path, k_gn_gain).  Measured on
-        // BASELINE config 4 at 512 realisations (profiles/r02_gain_lds.txt): the staged gather fetches 4.08 GB per launch
-        // instead of 6.08 GB (-33 %, the unique input is 4.3 GB) but takes 1.63 ms instead of 1.20 ms: a task is a dependent
-        // chain (header -> stage table -> 80 KiB of loads -> barrier -> records) of ~ 6 us with at most two workgroups per CU
-        // to overlap it, whereas k_gn_gain keeps 32 waves x 12 loads per CU in flight and runs at 6.1 TB/s of L2-miss
-        // traffic.  A persistent, double-buffered variant is bounded by (4.08 + 1.3 GB) / 6.5 TB/s = 0.83 ms, i.e. it could
-        // save at most 6 % of a Gauss-Newton iteration; not built.
-        int budget = 0, max_recs = 96;
-        if (const char* e = getenv("JG_GAIN_LDS")) budget = std::max(0, std::min(GAIN_LDS_SLOTS, atoi(e)));
-        if (const char* e = getenv("JG_GAIN_LDS_RECS")) max_recs = std::max(8, atoi(e));
-        struct Item { int head, dst; const std::vector<Contrib>* cs; };
-        struct Open {
-            std::map<std::pair<int, int>, int> left;      // (weight row, slot) -> image
-            std::map<int, int> raw;                       // slot -> image
-            std::vector<Item> items;
-            int images = 0, recs = 0;
-        } cur;
-        auto recs_of = [&](const Item& it) { const int per = (it.head & 1) ? GAIN_LDS_TR : GAIN_LDS_TB; return std::max(1, ((int)it.cs->size() + per - 1) / per); };
-        auto flush = [&]() {
-            if (cur.items.empty()) return;
-            GainTask t{};
-            // stage list: one entry per slot that has a raw image or weighted images; further weights of the same slot get their own entry
-            std::map<int, std::vector<std::pair<int, int>>> by_slot;             // slot -> (weight row, weighted image)
-            for (const auto& kv : cur.left) by_slot[kv.first.second].push_back({kv.first.first, kv.second});
-            for (const auto& kv : cur.raw) by_slot[kv.first];
-            t.w[1] = (int)(gstage.size() / 4);
-            for (const auto& kv : by_slot) {
-                const auto rit = cur.raw.find(kv.first);
-                int raw_img = rit == cur.raw.end() ? -1 : rit->second;
-                if (kv.second.empty()) { gstage.insert(gstage.end(), {kv.first, -1, -1, raw_img}); continue; }
-                for (const auto& wl : kv.second) { gstage.insert(gstage.end(), {kv.first, wl.first, wl.second, raw_img}); raw_img = -1; }
-            }
-            t.w[0] = (int)(gstage.size() / 4) - t.w[1];
-            t.w[2] = (int)trec.size();
-            // records, dealt to the waves as runs of whole items with about equal record counts
-            const int target = (cur.recs + GAIN_LDS_WAVES - 1) / GAIN_LDS_WAVES;
-            int wave = 0, in_wave = 0;
-            for (const Item& it : cur.items) {
-                const int nr = recs_of(it);
-                if (in_wave > 0 && in_wave + nr > target && wave < GAIN_LDS_WAVES - 1) { t.w[3 + wave] = (int)trec.size() - t.w[2]; ++wave; in_wave = 0; }
-                const int per = (it.head & 1) ? GAIN_LDS_TR : GAIN_LDS_TB;
-                size_t q = 0;
-                do {
-                    GainRec r{};
-                    r.w[0] = it.head; r.w[1] = it.dst;
-                    int nt = 0;
-                    for (; nt < per && q < it.cs->size(); ++nt, ++q) {
-                        const Contrib& c = (*it.cs)[q];
-                        const int l = cur.left.at({c.w, c.a});
-                        if (it.head & 1) { r.w[4 + 2 * nt] = l; r.w[5 + 2 * nt] = c.b; }
-                        else r.w[4 + nt] = l | cur.raw.at(c.b) << 16;
-                    }
-                    r.w[2] = nt;
-                    if (q >= it.cs->size()) r.w[0] |= 256;
-                    trec.push_back(r);
-                } while (q < it.cs->size());
-                in_wave += nr;
-            }
-            for (; wave < GAIN_LDS_WAVES; ++wave) t.w[3 + wave] = (int)trec.size() - t.w[2];
-            gtask.push_back(t);
-            cur = Open();
-        };
-        auto add = [&](const Item& it) -> bool {                                 // false: the item alone exceeds the budget
-            for (int pass = 0; pass < 2; ++pass) {
-                int extra = 0;
-                std::set<std::pair<int, int>> nl; std::set<int> nr;
-                for (const Contrib& c : *it.cs) {
-                    if (!cur.left.count({c.w, c.a}) && nl.insert({c.w, c.a}).second) ++extra;
-                    if (!(it.head & 1) && !cur.raw.count(c.b) && nr.insert(c.b).second) ++extra;
-                }
-                if (cur.images + extra <= budget && (cur.items.empty() || cur.recs + recs_of(it) <= max_recs)) {
-                    for (const auto& l : nl) cur.left[l] = cur.images++;
-                    for (int x : nr) cur.raw[x] = cur.images++;
-                    cur.items.push_back(it); cur.recs += recs_of(it);
-                    return true;
-                }
-                if (cur.items.empty()) return false;
-                flush();
-            }
-            return false;
-        };
+        // (a variant that staged a run of bus rows' operands in LDS fetched a third less and ran a third slower -- a dependent chain per task against 32 waves x 12 loads in
+        // flight per CU: tools/experiments/r06_retired_kernels.patch, profiles/r02_gain_lds.txt)
         // (the order of the bus rows in the gather is free -- every item names its destination; pivot order, Cuthill-McKee on the
         // gain graph and on the bus graph measure the same 1.23-1.24 ms at 512 realisations, the case's own numbering 1.44)
         for (int k = 0; k < n; ++k) {
@@ -1199,31 +1015,16 @@ int jg_gn_create(jg_gn** out, int64_t n, const int64_t* colptr, const int64_t* r
             for (const auto& blk : by_row[i]) {
                 const int j = blk_col[blk.first];
                 const int head = 0 | (i == slack ? 16 : 0) | (j == slack ? 32 : 0);
-                if (budget > 0 && add(Item{head, src_entry[blk.first], blk.second})) continue;
                 emit(grec, head, src_entry[blk.first], *blk.second);
                 if (grec.size() - (size_t)gwave.back() >= WAVE_RECS) gwave.push_back((int)grec.size());
             }
-            if (!(budget > 0 && add(Item{1 | (i == slack ? 16 : 0), i, &rmap[i]}))) {
-                emit(grec, 1 | (i == slack ? 16 : 0), i, rmap[i]);
-                if (grec.size() - (size_t)gwave.back() >= WAVE_RECS) gwave.push_back((int)grec.size());
-            }
+            emit(grec, 1 | (i == slack ? 16 : 0), i, rmap[i]);
+            if (grec.size() - (size_t)gwave.back() >= WAVE_RECS) gwave.push_back((int)grec.size());
             emit(rrec, 1 | (i == slack ? 16 : 0), i, rmap[i]);
             if (rrec.size() - (size_t)rwave.back() >= WAVE_RECS) rwave.push_back((int)rrec.size());
         }
-        flush();
         if (gwave.back() != (int)grec.size()) gwave.push_back((int)grec.size());
         if (rwave.back() != (int)rrec.size()) rwave.push_back((int)rrec.size());
-        h->gain_tasks = (int)gtask.size();
-        trec.push_back(GainRec{});                                               // pad: a wave without records still prefetches one
-        h->gain_lds_bytes = std::max(budget, 1) * 1024;
-        if (h->gain_tasks > 0 && hipFuncSetAttribute((const void*)k_gn_gain_lds, hipFuncAttributeMaxDynamicSharedMemorySize, GAIN_LDS_SLOTS * 1024) != hipSuccess) {
-            jg_gn_destroy(h); return failg(2, "jg_gn_create: cannot reserve LDS for the staged gain gather");
-        }
-        if (getenv("JG_GAIN_STATS")) {
-            long long st = 0; for (const GainTask& t : gtask) st += t.w[0];
-            fprintf(stderr, "gain gather: %zu tasks, %lld staged images (%.1f per task), %zu task records, %zu direct records\n", gtask.size(), st,
-                    gtask.empty() ? 0.0 : (double)st / gtask.size(), trec.size(), grec.size());
-        }
         h->gain_waves = (int)gwave.size() - 1; h->rhs_waves = (int)rwave.size() - 1;
     }
     // work items of k_gn_rows: rows that share their operands go to one wave (see the kernel).  Grouped by the type CODE of a row (a row that is out of
@@ -1232,7 +1033,7 @@ int jg_gn_create(jg_gn** out, int64_t n, const int64_t* colptr, const int64_t* r
     {
         std::map<int, int> flow_item, inj_item;                                   // branch / bus -> its item
         std::vector<int> quad;                                                    // 4 ints per item
-        const bool fuse = !(getenv("JG_GN_FUSE") && atoi(getenv("JG_GN_FUSE")) == 0);
+        constexpr bool fuse = true;                                               // (every row on its own: tools/r04_rows_fuse.sh measured the fused items faster)
         for (int r = 0; r < m; ++r) {
             const int c = h->code[r], idx = rows[r].idx;
             const bool flow = c == 7 || c == 8 || c == 10 || c == 11, inj = c == 6 || c == 9;
@@ -1271,8 +1072,7 @@ int jg_gn_create(jg_gn** out, int64_t n, const int64_t* colptr, const int64_t* r
     if (jg::upload(&h->d_rows, rows, err, h->stream) || jg::upload(&h->d_items, items, err, h->stream) || jg::upload(&h->d_slot_bus, slot_bus, err, h->stream) || jg::upload(&h->d_br, br, err, h->stream) ||
         jg::upload(&h->d_rowptr, rp, err, h->stream) || jg::upload(&h->d_G, G, err, h->stream) || jg::upload(&h->d_B, B, err, h->stream) || jg::upload(&h->d_ydiag, ydiag, err, h->stream) ||
         jg::upload(&h->d_grec, grec, err, h->stream) || jg::upload(&h->d_gwave, gwave, err, h->stream) || jg::upload(&h->d_rrec, rrec, err, h->stream) ||
-        jg::upload(&h->d_rwave, rwave, err, h->stream) || jg::upload(&h->d_gtask, gtask, err, h->stream) || jg::upload(&h->d_gstage, gstage, err, h->stream) ||
-        jg::upload(&h->d_trec, trec, err, h->stream)) {
+        jg::upload(&h->d_rwave, rwave, err, h->stream)) {
         jg_gn_destroy(h); return failg(2, err);
     }
     const size_t ld = h->ld;
@@ -1315,7 +1115,7 @@ void jg_gn_destroy(jg_gn* h) {
     hipFree(h->d_pair_ptr); hipFree(h->d_pa); hipFree(h->d_pb); hipFree(h->d_pz); hipFree(h->d_nres); hipFree(h->d_amax_v); hipFree(h->d_amax_i);
     hipFree(h->d_bad_v); hipFree(h->d_bad_i);
     hipFree(h->d_obj); hipFree(h->d_objpart); hipFree(h->d_corr); hipFree(h->d_noise); hipFree(h->d_noise_bad); hipFree(h->d_stage);
-    hipFree(h->d_grec); hipFree(h->d_gwave); hipFree(h->d_rrec); hipFree(h->d_rwave); hipFree(h->d_gtask); hipFree(h->d_gstage); hipFree(h->d_trec);
+    hipFree(h->d_grec); hipFree(h->d_gwave); hipFree(h->d_rrec); hipFree(h->d_rwave);
     if (h->h_counter) hipHostFree(h->h_counter);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -1345,7 +1145,7 @@ int jg_gn_set_method(jg_gn* h, int method) {
         h->exec = nullptr; h->graph = nullptr;
     }
     h->method = method;
-    h->eng.jordan = method == 0 && h->eng.plan->S.jordan && !(getenv("JG_JORDAN") && atoi(getenv("JG_JORDAN")) == 0);   // method 1 runs forward() on the factor
+    h->eng.jordan = method == 0 && h->eng.plan->S.jordan && jg::knob("JORDAN", 1) != 0;   // method 1 runs forward() on the factor
     return 0;
 }
 
@@ -1500,7 +1300,7 @@ int jg_gn_run(jg_gn* h, int64_t max_iter, double tol, int32_t* iters, int32_t* s
     GN_HIP(hipMemsetAsync(h->d_group, 0xff, (size_t)(h->ld / 64) * sizeof(int), h->stream));
     // (round 5, as jg_nr_run: while the handle's iterations are SHORT the host arms the pinned word and polls it instead of paying a stream synchronise per
     // iteration; a long iteration -- config 4 at 512 lanes: 4.4 ms -- blocks as before, see wait_verdict in jg_nr.hip.  JG_POLL=0 switches polling off)
-    static const bool poll = !(getenv("JG_POLL") && atoi(getenv("JG_POLL")) == 0);
+    static const bool poll = jg::knob("POLL", 1) != 0;
     for (int64_t it = 0; it <= max_iter; ++it) {                                   // :1303
         const bool spin = poll && h->wait_us <= 800.0;
         if (spin) *(volatile int*)h->h_counter = -1;

@@ -959,7 +959,7 @@ void launch_compact(jg_nr* h, int restore, bool report = false) {
         add(h->d_vm, h->n, 1); add(h->d_va, h->n, 1); add(h->d_p, h->n, 1); add(h->d_q, h->n, 1);
         if (h->mp > 0) { add(h->d_pdg, h->mp, 1); add(h->d_pdb, h->mp, 1); }
         add(h->d_inc, h->n, 2);                    // a finished scenario keeps ITS last increment (method.increment) wherever its lane goes
-        static const bool inplace_env = !(getenv("JG_LANES_INPLACE") && atoi(getenv("JG_LANES_INPLACE")) == 0);
+        static const bool inplace_env = jg::knob("LANES_INPLACE", 1) != 0;
         if (h->ld <= LANES_INPLACE && inplace_env) {                      // one launch, in place (k_lanes_permute); JG_LANES_INPLACE=0: the two-pass move
             hipLaunchKernelGGL(k_lanes_permute, dim3((unsigned)std::min(max_rows, 2048), 1, (unsigned)na), dim3((unsigned)std::min(1024, h->ld)), 0, h->stream, ls, h->d_dest, h->d_cflags, h->ld);
             return;
@@ -1186,13 +1186,9 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
     std::atomic<int> stream_state{0};                           // 1: h->stream exists, -1: its creation failed (the analysis thread creates it first)
     auto eng_work = [&] {
         if (hipSetDevice(h->device) != hipSuccess) { h->eng.error = "hipSetDevice failed on the analysis thread"; eng_rc = 2; stream_state = -1; return; }
-        // JG_STREAM_PRIORITY (probe, tools/r05_overlap_probe.py): the handle's stream at that priority (lower = more urgent; hipDeviceGetStreamPriorityRange)
-        if (const char* pr = getenv("JG_STREAM_PRIORITY")) {
-            if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, atoi(pr)) != hipSuccess) { h->eng.error = "jg_nr_create: stream creation failed"; eng_rc = 2; stream_state = -1; return; }
-        } else
         if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { h->eng.error = "jg_nr_create: stream creation failed"; eng_rc = 2; stream_state = -1; return; }
         stream_state = 1;
-        eng_rc = h->eng.create((int)n, rp.data(), cl.data(), h->ld, (getenv("JG_NO_PREFACTOR") ? 1LL : 1LL | 4) | 1LL << 49, h->stream);
+        eng_rc = h->eng.create((int)n, rp.data(), cl.data(), h->ld, (jg::knob_set("NO_PREFACTOR") ? 1LL : 1LL | 4) | 1LL << 49, h->stream);
     };
     std::thread eng_thread;
     try { eng_thread = std::thread(eng_work); } catch (const std::system_error&) { eng_work(); }     // no thread to be had: the analysis first, then the rest
@@ -1257,7 +1253,7 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
     // ---- device upload ----------------------------------------------------------------------
     while (stream_state.load() == 0) std::this_thread::yield();
     if (stream_state.load() < 0) { if (eng_thread.joinable()) eng_thread.join(); std::string m = h->eng.error; jg_nr_destroy(h); return fail(2, m); }
-    if (getenv("JG_PLAN_TIMING")) fprintf(stderr, "[jg nr create] reference maps done at                  %6.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - tc0);
+    if (jg::knob_set("PLAN_TIMING")) fprintf(stderr, "[jg nr create] reference maps done at                  %6.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - tc0);
     std::vector<double> G(nnz), B(nnz);
     for (int p = 0; p < nnz; ++p) { G[p] = yt_reim[2 * p]; B[p] = yt_reim[2 * p + 1]; }
     std::vector<int> colm(nnz);                 // column | existence mask of the 2x2 block entries (row i, col j types)
@@ -1309,7 +1305,7 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
         if (eng_thread.joinable()) eng_thread.join(); jg_nr_destroy(h); return fail(2, "jg_nr_create: pinned allocation failed");
     }
     if (hipHostGetDevicePointer((void**)&h->h_counter_dev, h->h_counter, 0) != hipSuccess) { if (eng_thread.joinable()) eng_thread.join(); jg_nr_destroy(h); return fail(2, "jg_nr_create: pinned host word is not device-visible"); }
-    const bool timing = getenv("JG_PLAN_TIMING") != nullptr;
+    const bool timing = jg::knob_set("PLAN_TIMING");
     auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     if (timing) fprintf(stderr, "[jg nr create] maps, model upload, state arena done at %6.1f ms\n", tnow() - tc0);
     if (eng_thread.joinable()) eng_thread.join();
@@ -1329,7 +1325,7 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
 }
 
 void jg_nr_destroy(jg_nr* h) {
-    if (h && getenv("JG_HOST_TIMING") && h->host_iters > 0)
+    if (h && jg::knob_set("HOST_TIMING") && h->host_iters > 0)
         fprintf(stderr, "[jg host timing] %d lanes: %lld iterations, hipGraphLaunch %.1f us, wait for the verdict %.1f us per iteration\n", h->ld, h->host_iters,
                 h->host_launch_us / h->host_iters, h->host_wait_us / h->host_iters);
     if (!h) return;
@@ -1636,7 +1632,7 @@ int jg_nr_set_refine(jg_nr* h, int mode) {
     }
     h->refine = mode != 0;
     // a refined step runs forward() + backsolve() on the factor of the step: plain rows (Engine::jordan); back on when refinement goes off
-    h->eng.jordan = !h->refine && h->eng.plan->S.jordan && !(getenv("JG_JORDAN") && atoi(getenv("JG_JORDAN")) == 0);
+    h->eng.jordan = !h->refine && h->eng.plan->S.jordan && jg::knob("JORDAN", 1) != 0;
     return 0;
 }
 
@@ -1685,7 +1681,7 @@ int run_setup(jg_nr* h, int64_t max_iter, double tol, int lanes, bool keep_iters
 // the launch and polls it (bounded spin, then yields; hipStreamSynchronize after 2 s as the safety net).  The next graph is then launched while the tail of
 // the previous one (the predicated re-assembly of a compaction) still runs -- stream order keeps them apart.  JG_POLL=0: the synchronise of round 4.
 constexpr double POLL_BELOW_US = 800.0;   // a handle whose waits average more than this blocks in hipStreamSynchronize instead
-static bool poll_enabled() { static const bool on = !(getenv("JG_POLL") && atoi(getenv("JG_POLL")) == 0); return on; }
+static bool poll_enabled() { static const bool on = jg::knob("POLL", 1) != 0; return on; }
 static void arm_verdict(jg_nr* h) { if (poll_enabled()) *(volatile int*)h->h_counter = -1; }
 static hipError_t wait_verdict(jg_nr* h) {
     const auto t0 = std::chrono::steady_clock::now();
@@ -1717,7 +1713,7 @@ static hipError_t wait_verdict(jg_nr* h) {
 // The iteration loop: one graph per iteration until no scenario is active (the iteration limit itself is kept on the device,
 // k_check) -- or, defer_at > 0, until at most defer_at (<= 64) scenarios are: they stay in their lanes, listed for the hand-off (k_compact: hold).
 int run_loop(jg_nr* h, int64_t max_iter, int defer_at) {
-    const bool trace = getenv("JG_TRACE") != nullptr;
+    const bool trace = jg::knob_set("TRACE");
     auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (int64_t it = 0; it <= max_iter && *h->h_counter != 0; ++it) {
         if (defer_at > 0 && *h->h_counter <= defer_at) break;
@@ -1756,7 +1752,7 @@ int run_start(jg_nr* h, int64_t max_iter) {
         h->jac_valid = false;
         return 0;
     }
-    const bool trace = getenv("JG_TRACE") != nullptr;
+    const bool trace = jg::knob_set("TRACE");
     const double t0 = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
     arm_verdict(h);
     NR_HIP(hipGraphLaunch(h->execC, h->stream));

@@ -11,10 +11,24 @@
 #include <system_error>
 #include <thread>
 #include <cstdio>
+#include <cstring>
+#include <string>
 #include <cstdlib>
 #include <numeric>
 
 namespace jg {
+
+int knob(const char* name, int unset) {
+    static const char* const known[] = {"TRACE", "PLAN_CACHE", "POLL", "PLAN_THREADS", "PLAN_TIMING", "HOST_TIMING",
+                                        "TOP_PW", "TOP_FUSE", "TOP_SYM", "JORDAN", "CHAIN_SMALL", "NO_PREFACTOR", "LANES_INPLACE", "TOP_LEVEL", "ROW_TASKS", "ORDER_CHECK", "TOP_PROFILE"};
+    bool ok = false;
+    for (const char* k : known) ok = ok || std::strcmp(k, name) == 0;
+    if (!ok) return unset;
+    const std::string var = std::string("JG_") + name;
+    const char* e = getenv(var.c_str());
+    return e ? atoi(e) : unset;
+}
+
 
 void build_tables(BlockSymbolic& S);
 constexpr int NO_TOP_LEVEL = 0x7fffffff;
@@ -56,11 +70,7 @@ bool elimination_order(int n, std::vector<std::vector<int>>&& adj0, std::vector<
         }
         return d * (d - 1) / 2 - present / 2;
     };
-    long long wf = 20, wh = 0, wd = 0, wq = 1;                 // experiments: JG_ORDER="fill,height,degree,height^2" weights
-    if (const char* e = getenv("JG_ORDER")) {
-        long long a, b, c, q;
-        if (sscanf(e, "%lld,%lld,%lld,%lld", &a, &b, &c, &q) == 4) { wf = a; wh = b; wd = c; wq = q; }
-    }
+    const long long wf = 20, wh = 0, wd = 0, wq = 1;           // score = 20 fill + height^2 (other weightings were measured in rounds 2-3: DESIGN_LOG)
     auto key_of = [&](int v) -> long long {                    // score, then degree, packed (degree < 2^20); fillv[v] must be current
         const long long d = (long long)adj[v].size(), h = hv[v];
         return ((wf * fillv[v] + wh * h + wd * d + wq * h * h) << 20) | std::min<long long>(d, (1 << 20) - 1);
@@ -99,7 +109,7 @@ bool elimination_order(int n, std::vector<std::vector<int>>&& adj0, std::vector<
     for (int i = (hn - 2) / 4; i >= 0 && hn > 1; --i) sift_down(i);
     order.clear(); order.reserve(n);
     strct.assign(n, {});
-    const bool check = getenv("JG_ORDER_CHECK") != nullptr;     // tests: every incremental fill against a recount
+    const bool check = knob_set("ORDER_CHECK");     // tests: every incremental fill against a recount
     std::vector<int> merged, touched;
     std::vector<char> cadj;                                    // old adjacency inside the clique of the vertex being eliminated
     std::vector<long long> xcount, xr, oldpairs;
@@ -288,7 +298,7 @@ void build_replay(const std::vector<int>& level, const std::vector<int>& work, i
         recs.reserve(est + est / 4 + 1024);
     }
     n_levels = 0;
-    static const int wide_cap = getenv("JG_WIDE_WPI") ? atoi(getenv("JG_WIDE_WPI")) : 4;
+    constexpr int wide_cap = 4;
     constexpr bool has_extra = !std::is_same<Extra, NoExtra>::value;
     int nthreads = 1;
     if (n_items >= 4096) {
@@ -343,7 +353,7 @@ void build_replay(const std::vector<int>& level, const std::vector<int>& work, i
             p = q;
         }
     };
-    const bool rtiming = getenv("JG_PLAN_TIMING") != nullptr;
+    const bool rtiming = knob_set("PLAN_TIMING");
     auto rnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double r0 = rnow();
     if (nthreads > 1) {
@@ -454,8 +464,7 @@ void build_top(BlockSymbolic& S, int top_level, int soft_cap, int struct_min, in
         const int fprime = t.m + t.e + 1;                        // front rows / columns + the rhs column
         t.cls = fprime <= 32 ? 2 : (fprime <= 48 ? 3 : 4);       // blocks per thread and dimension on the 16 x 16 thread grid
         t.lg = 0;
-        static const int nogroup = getenv("JG_MID_NOGROUP") ? atoi(getenv("JG_MID_NOGROUP")) : 0;   // experiments: 1 = every task one scenario per workgroup, 2 = no 16-scenario geometry
-        if (mid_mmin > 0 && fprime <= 32 && nogroup != 1 && !(nogroup == 3 && (t.root() & 1))) { t.lg = fprime <= 16 && nogroup != 2 ? 4 : 2; t.cls = 4; }   // grouped: 16 / 4 scenarios per workgroup, 4 x 4 blocks per thread
+        if (mid_mmin > 0 && fprime <= 32) { t.lg = fprime <= 16 ? 4 : 2; t.cls = 4; }   // grouped: 16 / 4 scenarios per workgroup, 4 x 4 blocks per thread
 
         for (int k : t.piv) { const long long s = ssize(k); S.top_terms += s * (s + 1); }
     }
@@ -641,12 +650,6 @@ void build_tables(BlockSymbolic& S) {
             if (it < nE) { x.w[s] = lower_operand(S.t_a[t]); x.w[s + 1] = S.t_d[t]; x.w[s + 2] = S.t_b[t]; }
             else { x.w[s] = lower_operand(S.l_ent[t]); x.w[s + 1] = S.diag[S.l_col[t]]; x.w[s + 2] = S.l_col[t]; }
             x.w[3]++;
-            // TIMING PROBES (JG_PROBE_LOADS, wrong numbers -- tools/level_bound_probe.sh): what does a level launch wait for?
-            // 1: no update term at all (what is left: dispatch, record, the item's own block in and out, reduction);  2: every operand of a
-            // term is its pivot block (the same loads issued, all served from cache: no miss traffic)
-            static const int probe = getenv("JG_PROBE_LOADS") ? atoi(getenv("JG_PROBE_LOADS")) : 0;
-            if (probe == 1) x.w[3] = 0;
-            if (probe == 2 && it < nE) { x.w[s] = x.w[s + 1]; x.w[s + 2] = x.w[s + 1]; }
         }
     };
     S.n_sched_terms = S.top_terms;
@@ -660,8 +663,7 @@ void build_tables(BlockSymbolic& S) {
         loc[e] = ((long long)p << 33) | ((long long)(r > c ? 1 : 0) << 32) | (long long)(r > c ? r : c);
     }
     for (int r = 0; r < n; ++r) loc[nE + r] = ((long long)r << 33) | 0xffffffffLL;      // y_p right after U(p, .)
-    const char* io = getenv("JG_ITEM_ORDER");
-    const std::vector<long long>* locp = (io && atoi(io) == 0) ? nullptr : &loc;
+    const std::vector<long long>* locp = &loc;
     // the factorisation tables are two thirds of this function's time and independent of the others: they get a thread of their own
     // Plans with policy bit 50: the same items, levels and terms as TASKS (jg_symbolic.hpp) -- runs of items in the pivot order of their level
     // share a workgroup that stages their common operands, premultiplied by the pivot block, in LDS.
@@ -682,8 +684,7 @@ void build_tables(BlockSymbolic& S) {
         std::vector<LevelOut> outs(nlev + 1);
         auto side_of = [&](int it) { return it < nE && S.e_row[it] > S.e_col[it] ? 1 : 0; };
         auto group_of = [&](int it) -> long long { return it < nE ? ((long long)std::min(S.e_row[it], S.e_col[it]) << 1 | side_of(it)) : ((long long)(it - nE) << 1); };
-        // TIMING PROBES (JG_PROBE_LOADS, wrong numbers -- as in fill_fact above): 1: no update term at all; 2: every operand of a term is its pivot block
-        static const int probe = getenv("JG_PROBE_LOADS") ? atoi(getenv("JG_PROBE_LOADS")) : 0;
+        constexpr int probe = 0;
         auto term_of = [&](int it, int f, int& a, int& d, int& b) {
             const int t = ft_idx[f];
             if (it < nE) { a = lower_operand(S.t_a[t]); d = S.t_d[t]; b = S.t_b[t]; if (probe == 2) { a = d; b = d; } }
@@ -853,14 +854,14 @@ void build_tables(BlockSymbolic& S) {
         for (int l = 1; l <= nlev; ++l) if (!by[l].empty()) lorder.push_back(l);
         std::stable_sort(lorder.begin(), lorder.end(), [&](int x, int y) { return by[x].size() > by[y].size(); });
         int nthr = (int)std::max<size_t>(1, std::min<size_t>({(size_t)8, lorder.size(), (size_t)std::max(1u, std::thread::hardware_concurrency() / 2), (size_t)(nE + n) / 8192 + 1}));
-        if (const char* e = getenv("JG_PLAN_THREADS")) nthr = std::max(1, std::min(16, atoi(e)));     // tests: the tables must not depend on it
+        if (knob_set("PLAN_THREADS")) nthr = std::max(1, std::min(16, knob("PLAN_THREADS", nthr)));     // tests: the tables must not depend on it
         std::atomic<size_t> next{0};
         auto worker = [&] {
             Scratch sc; sc.slot_stamp.assign(nE, -1); sc.slot_idx.assign(nE, 0);
             for (size_t q = next++; q < lorder.size(); q = next++) {
                 const auto t0 = std::chrono::steady_clock::now();
                 do_level(lorder[q], sc, outs[lorder[q]]);
-                if (getenv("JG_PLAN_TIMING_LEVELS")) fprintf(stderr, "[jg plan]     level %d: %zu items %.2f ms\n", lorder[q], by[lorder[q]].size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+                (void)t0;
             }
         };
         {
@@ -879,7 +880,7 @@ void build_tables(BlockSymbolic& S) {
             ++S.n_fact_levels;
         }
     };
-    const bool timing = getenv("JG_PLAN_TIMING") != nullptr;
+    const bool timing = knob_set("PLAN_TIMING");
     auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tb0 = tnow();
     std::thread fact_thread = spawn_or_run([&] {
@@ -979,7 +980,7 @@ void build_tables(BlockSymbolic& S) {
                 x.w[3]++;
             }
         }, [&](int l, std::vector<Segment>& segs, std::vector<Rec>& recs) {
-            static const bool no_small = getenv("JG_CHAIN_SMALL") && atoi(getenv("JG_CHAIN_SMALL")) == 0;     // experiments: every chain a general task
+            static const bool no_small = knob("CHAIN_SMALL", 1) == 0;     // experiments: every chain a general task
             for (int small = 0; small < 2; ++small) {            // the general tasks (wpi 0), then the small ones (wpi -1, jg_symbolic.hpp)
             std::vector<int> cs;
             for (int c : chains_at[l]) if ((clen[c] <= CHAIN_SMALL_ROWS && !no_small) == (small != 0)) cs.push_back(c);
@@ -1134,7 +1135,6 @@ int analyze(int n, const int* rowptr, const int* col, long long policy64, BlockS
     S.jordan = (int)((policy64 >> 49) & 1);                       // a request here; build_top grants it
     S.fact_tasks = (int)((policy64 >> 50) & 1);
     S.task_rounds = (int)((policy64 >> 51) & 7);
-    if (const char* e = getenv("JG_TASK_ROUNDS")) S.task_rounds = atoi(e);
     if (S.task_rounds <= 0) S.task_rounds = 3;
     S.n = n;
     if (n <= 0) return 1;
@@ -1157,7 +1157,7 @@ int analyze(int n, const int* rowptr, const int* col, long long policy64, BlockS
             if (!std::binary_search(adj[j].begin(), adj[j].end(), i)) return 1;
 
     std::vector<std::vector<int>> strct;
-    const bool timing = getenv("JG_PLAN_TIMING") != nullptr;
+    const bool timing = knob_set("PLAN_TIMING");
     auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = tnow();
     auto lap = [&](const char* what) { if (timing) { const double t = tnow(); fprintf(stderr, "[jg plan] %-28s %8.1f ms\n", what, t - t0); t0 = t; } };
@@ -1315,8 +1315,7 @@ int analyze(int n, const int* rowptr, const int* col, long long policy64, BlockS
 
     {
         int top_level = (policy >> 8) & 0xff, soft = (policy >> 16) & 0xff;
-        if (const char* e = getenv("JG_TOP_LEVEL")) top_level = atoi(e);
-        if (const char* e = getenv("JG_TOP_FRONT")) soft = atoi(e);
+        if (knob_set("TOP_LEVEL")) top_level = knob("TOP_LEVEL", top_level);
         if (top_level == 0) {
             // default: the multifrontal top starts where the level schedule gets narrow -- the first dependency level from which
             // no level holds more than TOP_NARROW items (entries + rhs rows), but not below level TOP_LEVEL_MIN.  Measured on
@@ -1325,13 +1324,11 @@ int analyze(int n, const int* rowptr, const int* col, long long policy64, BlockS
             int narrow = ((policy >> 24) & 0x7f) * 8;             // the owner knows its batch: a task costs a workgroup per scenario
             if (narrow == 0) narrow = TOP_NARROW;
             if (narrow == 127 * 8) narrow = 0x7fffffff;           // 127: no item limit (the pivots-per-level limit decides)
-            if (const char* e = getenv("JG_TOP_ITEMS")) narrow = atoi(e);
             int nlev = 0;
             for (int e = 0; e < S.n_entries; ++e) nlev = std::max(nlev, S.e_level[e]);
             for (int r = 0; r < n; ++r) nlev = std::max(nlev, S.y_level[r]);
             int chains = (policy >> 4) & 0xf;                     // ... and at most this many pivots (parallel chains) per level (0: any;
             if (chains >= 13) chains = chains == 13 ? 18 : (chains == 14 ? 24 : 36);   // 13 / 14 / 15 stand for 18 / 24 / 36)
-            if (const char* e = getenv("JG_TOP_CHAINS")) chains = atoi(e);
             std::vector<int> cnt(nlev + 2, 0), piv(nlev + 2, 0);
             for (int e = 0; e < S.n_entries; ++e) if (!(S.symmetric && S.e_row[e] > S.e_col[e])) cnt[S.e_level[e]]++;
             for (int r = 0; r < n; ++r) { cnt[S.y_level[r]]++; piv[S.e_level[S.diag[r]]]++; }
@@ -1342,11 +1339,7 @@ int analyze(int n, const int* rowptr, const int* col, long long policy64, BlockS
         } else if (top_level >= 255) top_level = NO_TOP_LEVEL;   // policy / environment: no top by level
         if (soft <= 0) soft = TOP_FRONT_SOFT;
         int struct_min = 0, mid_mmin = 0, mid_strict = (int)((policy64 >> 48) & 1);
-        if (const char* e = getenv("JG_TOP_STRUCT")) struct_min = atoi(e);
         if (const int mid = (int)((policy64 >> 32) & 0xff)) { struct_min = mid; mid_mmin = (int)((policy64 >> 40) & 0xff); if (!mid_mmin) mid_mmin = 6; }
-        if (const char* e = getenv("JG_MID_STRUCT")) { struct_min = atoi(e); mid_mmin = struct_min > 0 ? std::max(mid_mmin, 6) : 0; }
-        if (const char* e = getenv("JG_MID_MMIN")) { if (mid_mmin) mid_mmin = std::max(1, atoi(e)); }
-        if (const char* e = getenv("JG_MID_STRICT")) mid_strict = atoi(e);
         lap("fill pattern, terms, levels");
         build_top(S, top_level, std::min(soft, TOP_FRONT_MAX), struct_min, mid_mmin, mid_strict);
         lap("top tasks");

@@ -16,6 +16,16 @@
 
 namespace jg {
 
+// ---- environment switches: ONE reader (jg_symbolic.cpp: knob) -------------------------------------------------------------------------------------------
+// A user needs six: JG_TRACE (per-iteration history of jg_nr_run / jg_gn_run on stderr), JG_PLAN_CACHE=0 (no sharing of symbolic analyses between
+// handles), JG_POLL=0 (the host always blocks in the stream synchronise), JG_PLAN_THREADS (host threads of the table builder), JG_PLAN_TIMING, JG_HOST_TIMING
+// (timings on stderr).  The rest are TEST HOOKS that force a code path the library also takes by itself, so that the suites can hold the variants against each
+// other (tests/test_top_variants_gpu.py, tests/test_plan_cpu.py): JG_TOP_PW, JG_TOP_FUSE, JG_TOP_SYM, JG_JORDAN, JG_CHAIN_SMALL, JG_NO_PREFACTOR, JG_LANES_INPLACE,
+// JG_TOP_LEVEL, JG_ROW_TASKS, JG_ORDER_CHECK, JG_TOP_PROFILE.  Nothing else is read: the switches of retired experiments left with their kernels
+// (tools/experiments/*.patch).
+int knob(const char* name, int unset);      // integer value of the environment variable JG_<name>; `unset` when it is not set (or not in the lists above)
+inline bool knob_set(const char* name) { return knob(name, -2147483647) != -2147483647; }
+
 // ---- device replay tables ("wave records") -----------------------------------------------------------------
 // The numeric kernels never chase pointers: every wave's work is a fixed-size 64-byte record at an address that
 // follows from (segment, chunk, wave) arithmetic alone, so it is fetched with ONE scalar load and can be

@@ -247,35 +247,3 @@ def test_island_whose_root_pivot_sits_in_the_top_tasks(jg, copies, batch):
     assert np.array_equal(an.status[keep], ref.status) and np.array_equal(an.method.iteration[keep], ref.method.iteration)
     assert np.array_equal(an.voltage.magnitude[keep], ref.voltage.magnitude) and np.array_equal(an.voltage.angle[keep], ref.voltage.angle)
     an.close(); ref.close()
-
-
-def test_island_root_inside_a_grouped_task(jg, monkeypatch):
-    """the grouped tasks (k_fact_grp, plans with a "mid" policy -- off by default, JG_MID_STRUCT switches them on) took the pivot guard's
-    reference scale after the extend-add, the defect round 3 fixed in k_fact_top.  The same tied instances with every pivot of 5 neighbours and more
-    (and its ancestors) in grouped tasks: the outage of a tie must still come back with status 3."""
-    from juliagrid.jl_amd.synthetic import tiledGrid
-    t = load_case("case1354pegase")
-    one = jg.newtonRaphson(jg.powerSystem(t))
-    jg.powerFlow_(one)
-    jg.power_(one)
-    slack = int(np.flatnonzero(np.asarray(one.system.bus.layout.type) == 3)[0])
-    p_slack = float(np.asarray(one.power.supply.active).reshape(-1)[slack])
-    one.close()
-    s = jg.powerSystem(tiledGrid(t, 3, slack_active=p_slack))
-    nb = s.branch.number
-    ties = [nb - 2 + c + 1 for c in range(2)]
-    good = [int(x) for x in jg.outageList(s, 66, seed=5)]
-    labels = good[:2] + [ties[0]] + good[2:-1] + ties[1:] + good[-1:]
-    monkeypatch.setenv("JG_MID_STRUCT", "5")
-    jg._lib.lib().jg_plan_cache_clear()                       # the environment is not part of a plan's key
-    try:
-        an = jg.contingencyAnalysis(s, labels)
-        jg.powerFlow_(an, iteration=20, tolerance=1e-8)
-        for i, lab in enumerate(labels):
-            if lab in ties:
-                assert an.status[i] == 3, f"tie {lab}: status {an.status[i]}"
-        assert (an.status == 0).sum() >= len(labels) - len(ties) - 2
-        an.close()
-    finally:
-        monkeypatch.delenv("JG_MID_STRUCT")
-        jg._lib.lib().jg_plan_cache_clear()

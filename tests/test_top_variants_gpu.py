@@ -47,22 +47,8 @@ def test_top_kernel_variants_and_level0_routes_give_the_same_bits(case, batch):
     assert _run(case, batch, JG_TOP_PW=1)[0] == ref                  # every top launch with the pivot wave
     assert _run(case, batch, JG_TOP_PW=0)[0] == ref                  # every top launch without
     assert _run(case, batch, JG_NO_PREFACTOR=1)[0] == ref            # plain plan: the level kernel factorises the leaf blocks
-    assert _run(case, batch, JG_ITEM_ORDER=0)[0] == ref              # items of a level dealt heaviest first
     assert _run(case, batch, JG_TOP_FUSE=1)[0] == ref                # two pivots per barrier: every thread redoes what the owners of the
                                                                      # second pivot's row / column / block do, operation for operation
-    assert _run(case, batch, JG_TOPW=3)[0] == ref                    # round 5: the one- / two-wave kernels (opt-in) for the front classes they exist for
-    assert _run(case, batch, JG_TOP_G32=1)[0] == ref                 # round 5: every front on a 32 x 32 thread grid (opt-in)
-
-
-@pytest.mark.parametrize("case,batch", [("case_ACTIVSg10k", 512), ("case_ACTIVSg10k", 1), ("case9241synth", 256)])
-def test_narrow_top_kernels_give_the_bits_of_the_wide_one(case, batch):
-    """k_fact_topw (one wave per scenario for fronts of class 2, two for class 3; jg_engine.hip) performs the elimination of k_fact_top operation for
-    operation and skips only blocks a step cannot change: same bits, in the plan class of the headline batch, of a single instance and of a 256-lane batch.
-    (Opt-in, JG_TOPW: measured slower than the wide kernel -- profiles/r05_topw_ab.txt -- and kept as a checked experiment.)"""
-    ref, iters = _run(case, batch)
-    assert iters >= 3 * batch
-    for mode in (1, 2, 3):
-        assert _run(case, batch, JG_TOPW=mode)[0] == ref, mode
 
 
 SCRIPT_STATE = r"""
@@ -78,34 +64,6 @@ jg.powerFlow_(an, iteration=20, tolerance=1e-8)
 np.savez({out!r}, it=np.asarray(an.method.iteration), st=np.asarray(an.status), vm=np.asarray(an.voltage.magnitude), va=np.asarray(an.voltage.angle))
 an.close()
 """
-
-
-@pytest.mark.parametrize("case,batch,env", [
-    ("case118", 70, dict(JG_TOP_LEVEL=1, JG_MID_STRUCT=1, JG_MID_MMIN=1)),                       # every pivot in a grouped task
-    ("case118", 70, dict(JG_TOP_LEVEL=1, JG_MID_STRUCT=1, JG_MID_MMIN=1, JG_MID_NOGROUP=3)),     # ... mixed with one-scenario tasks (all three update stacks)
-    ("case1354pegase", 300, dict(JG_MID_STRUCT=3, JG_MID_MMIN=4)),
-    ("case_ACTIVSg10k", 130, dict(JG_MID_STRUCT=8, JG_MID_MMIN=4)),
-    ("case_ACTIVSg10k", 512, dict(JG_MID_STRUCT=13, JG_MID_MMIN=4, JG_MID_STRICT=1)),
-])
-def test_grouped_tasks_match_the_default_plan(tmp_path, case, batch, env):
-    """Plans with grouped tasks below the top (k_fact_grp: 4 or 16 scenarios per workgroup, jg_symbolic.hpp "mid" policy; opt-in) against
-    the default plan: equal iteration counts and status, V / theta to 1e-9 (another summation order, not another algorithm)."""
-    outs = []
-    for i, e in enumerate((dict(), env)):
-        out = str(tmp_path / f"r{i}.npz")
-        ee = dict(os.environ)
-        ee.update({k: str(v) for k, v in e.items()})
-        r = subprocess.run([sys.executable, "-c", SCRIPT_STATE.format(root=ROOT, case=case, batch=batch, out=out)], env=ee, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        import numpy as np
-        with np.load(out) as z:
-            outs.append({k: z[k] for k in z.files})
-    a, b = outs
-    import numpy as np
-    assert np.array_equal(a["it"], b["it"]) and np.array_equal(a["st"], b["st"])
-    ok = a["st"] == 0
-    assert ok.sum() >= 0.9 * batch
-    assert np.abs(a["vm"] - b["vm"])[ok].max() < 1e-9 and np.abs(a["va"] - b["va"])[ok].max() < 1e-9
 
 
 def _state(tmp_path, tag, case, batch, env):
