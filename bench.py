@@ -842,7 +842,9 @@ def main():
     if args.merge > 0:
         merge = args.merge
     elif args.scaling == "strong":
-        merge = jg.deviceBatching(b_max, args.steps, 512)   # 512-lane batches with the fewest spare lanes in the last one; a run of at most 1 280 scenarios per rank: one or two wider batches
+        # device batches of the width the grid's size asks for (512 lanes on the 10 000-bus grid, up to 4 096 on small ones: contingency.recommendedLanes) with the
+        # fewest spare lanes in the last one; a run of at most 1.25 (2.5) such batches per rank: one (two) wider batches
+        merge = jg.deviceBatching(b_max, args.steps, jg.recommendedLanes(system.bus.number))
     else:
         merge = 1
     merge = max(1, min(merge, args.steps))
@@ -861,9 +863,9 @@ def main():
     solvable = np.flatnonzero(st_pre == 0)
     if os.environ.get("JG_BENCH_PROBE_UNIFORM"):        # probe only: scenarios that all need the same number of iterations (no stragglers)
         solvable = np.flatnonzero((st_pre == 0) & (it_pre == int(os.environ["JG_BENCH_PROBE_UNIFORM"])))
-    if solvable.size < total:
-        raise SystemExit(f"only {solvable.size} of {cand.size} candidate contingencies have a power flow")
-    excluded = int(cand.size - solvable.size)
+    if solvable.size < 1:
+        raise SystemExit(f"none of the {cand.size} candidate contingencies has a power flow")
+    excluded = int(cand.size - solvable.size)                  # (a step larger than the list -- small grids at large batches -- cycles it: scenario_selection says so)
     chosen = cand[solvable]                           # the screen's list: every solvable non-bridge outage, shuffle order
 
     def step_labels(k):                               # this rank's share of step k of a region

@@ -926,6 +926,7 @@ mutable struct GaussNewtonBatch
     iteration::Vector{Int32}
     status::Vector{Int32}                          # 0 converged, 1 iteration limit, 3 singular gain matrix
     objective::Vector{Float64}                     # se.objective = r' W r per realisation (equations.jl:689-698)
+    pairs::Int                                     # correlated rectangular PMUs: rows of `woff` in setRealisations!
 end
 
 function GaussNewtonBatch(monitoring::Measurement, batch::Int; device::Int = 0)
@@ -947,7 +948,7 @@ function GaussNewtonBatch(monitoring::Measurement, batch::Int; device::Int = 0)
         reim(ac.nodalMatrixTranspose.nzval), br.number, br.layout.from, br.layout.to, param,
         system.bus.layout.slack, length(code), code, status, m.index, length(corr), isempty(corr) ? Int64[0] : corr, batch, device))
     b = GaussNewtonBatch(monitoring, batch, Handle(h[], :gn), length(code), zeros(system.bus.number, batch), zeros(system.bus.number, batch),
-        zeros(Int32, batch), zeros(Int32, batch), zeros(batch))
+        zeros(Int32, batch), zeros(Int32, batch), zeros(batch), length(corr))
     W = m.precision
     wdiag = [W[r, r] for r = 1:length(m.mean)]
     woff = Float64[W[r, r + 1] for r in corr]
@@ -959,8 +960,11 @@ function GaussNewtonBatch(monitoring::Measurement, batch::Int; device::Int = 0)
 end
 
 "se.mean and the diagonal (+ pair terms `woff` [pairs, batch]) of se.precision per realisation: [rows, batch] each (acStateEstimation.jl:135-236)"
-function setRealisations!(b::GaussNewtonBatch, mean::Matrix{Float64}, wdiag::Matrix{Float64}, woff::Matrix{Float64} = zeros(1, b.batch))
+function setRealisations!(b::GaussNewtonBatch, mean::Matrix{Float64}, wdiag::Matrix{Float64}, woff::Matrix{Float64} = zeros(max(b.pairs, 1), b.batch))
     size(mean) == (b.rows, b.batch) && size(wdiag) == (b.rows, b.batch) || throw(DimensionMismatch("[rows, batch] means and precisions"))
+    # (ADVICE r05) the pair terms of correlated rectangular PMUs travel per realisation: a short `woff` would be read past its end, a default of zeros would silently
+    # drop the cross terms of the precision matrix
+    b.pairs == 0 || size(woff) == (b.pairs, b.batch) || throw(DimensionMismatch("[correlated pairs, batch] off-diagonal precision terms: $(b.pairs) pair(s) in this model"))
     check(ccall((:jg_gn_set_measurement, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Int64),
         b.handle.ptr, mean, wdiag, woff, b.rows, size(woff, 1)))
 end

@@ -322,7 +322,9 @@ int jg_gn_set_measurement(jg_gn* h, const double* mean, const double* wdiag, con
  * squared current magnitude; 4 / 5 rectangular PMU without / with its 2x2 precision block (5 exactly on the corr_row rows of jg_gn_create);
  * z1, v1, s1 magnitude (or the single quantity): mean, variance, status; z2, v2, s2 the PMU angle (ignored for kinds 0, 1).
  * jg_gn_draw_noise: lane b becomes realisation first_realisation + b of `seed`: z + scale * sigma * N(0,1) per raw reading from a counter-based generator
- * (splitmix64 finaliser + Box-Muller, csrc/jg_gn.hip: k_gn_noise -- the same realisation gets the same numbers on any rank, batch and lane), then the value
+ * (csrc/jg_gn.hip: k_gn_noise -- the same realisation gets the same numbers on any rank, batch and lane.  Exactly, for device d (0-based, in row order) and realisation r, in
+ * uint64 arithmetic:  c = (seed + 0x9E3779B97F4A7C15 * (2 d)) ^ (r * 0xD1B54A32D192ED03);  u1 = mix64(c), u2 = mix64(c + 0x9E3779B97F4A7C15) with mix64 the splitmix64 finaliser;
+ * uniform (0, 1] = ((u >> 11) + 1) 2^-53;  the two normals of the device = sqrt(-2 ln u1) (cos, sin)(2 pi u2) -- the numpy restatement is tests/test_montecarlo_gpu.py:_normals), then the value
  * rules: se.mean and se.precision of every scenario are rewritten in place, nothing crosses PCIe.  scale 0 restores the noise-free set.  Returns 1 when a
  * variance comes out zero or not finite (the reference's errorVariance).  jg_gn_get_measurement: se.mean / diag(se.precision) [batch][m], pair terms [batch][n_corr]. */
 int jg_gn_set_readings(jg_gn* h, int64_t ndev, const int64_t* row, const int8_t* kind, const double* z1, const double* v1, const int8_t* s1,

@@ -10,7 +10,7 @@ from .system import (updateBranch_ as updateBranchSystem_, updateBus_ as updateB
 from .powerflow import (AcPowerFlow, newtonRaphson, fastNewtonRaphsonBX, fastNewtonRaphsonXB, mismatch_, solve_, powerFlow_, setInitialPoint_, setRefinement_,   # noqa: F401
                         updateBranch_, updateBus_, updateGenerator_, addBranch_, dropZeros_, setOutage_, setOutages_, setInjection_, outagePatch, fastOutagePatch, initializeACPowerFlow, power_, current_, screenSummary_, reactiveLimit_, adjustAngle_,
                         BaseCase, startFromBase_, setFirstIteration_, firstIterationCounts)
-from .contingency import bridges, outageList, shard, deviceBatching, contingencyAnalysis, gatherResults, gatherResultsDevice, unpackResults, ContingencyPipeline   # noqa: F401
+from .contingency import bridges, outageList, shard, deviceBatching, recommendedLanes, contingencyAnalysis, gatherResults, gatherResultsDevice, unpackResults, ContingencyPipeline   # noqa: F401
 from .measurement import (Measurement, measurement, ems, addVoltmeter_, addAmmeter_, addWattmeter_, addVarmeter_,   # noqa: F401
                           addPmu_, exactQuantities)
 from .stateestimation import (WlsMethod, Normal, LU, KLU, QR, LDLt, LL, Orthogonal, PetersWilkinson,   # noqa: F401
@@ -28,7 +28,7 @@ __all__ = [
     "Measurement", "measurement", "ems", "addVoltmeter_", "addAmmeter_", "addWattmeter_", "addVarmeter_", "addPmu_",
     "exactQuantities", "AcStateEstimation", "PmuStateEstimation", "pmuStateEstimation", "gaussNewton", "incrementSE_", "solveSE_", "stateEstimation_", "setNoise_", "drawNoise_", "measurementDevice", "residualTest_", "normalizedResidual", "chiTest",
     "updateVoltmeter_", "updateAmmeter_", "updateWattmeter_", "updateVarmeter_", "updatePmu_",
-    "outagePatch", "fastOutagePatch", "initializeACPowerFlow", "bridges", "outageList", "shard", "deviceBatching", "contingencyAnalysis", "gatherResults", "gatherResultsDevice", "unpackResults",
+    "outagePatch", "fastOutagePatch", "initializeACPowerFlow", "bridges", "outageList", "shard", "deviceBatching", "recommendedLanes", "contingencyAnalysis", "gatherResults", "gatherResultsDevice", "unpackResults",
     "WlsMethod", "Normal", "LU", "KLU", "QR", "LDLt", "LL", "Orthogonal", "PetersWilkinson",
     "addBranch_", "dropZeros_", "addBranchSystem_", "dropZerosSystem_", "pegaseShaped", "case9241synth", "ContingencyPipeline", "MonteCarloPipeline", "gatherEstimates", "gatherEstimatesDevice", "unpackEstimates", "setOutages_", "power_", "current_", "screenSummary_", "reactiveLimit_", "adjustAngle_",
     "BaseCase", "startFromBase_", "setFirstIteration_", "firstIterationCounts",

@@ -79,11 +79,20 @@ def shard(count: int, rank: int, world: int) -> tuple[int, int]:
     return lo, min(lo + per, count)
 
 
+def recommendedLanes(buses: int) -> int:
+    """Scenarios per device batch by grid size: what keeps a launch around 5 million bus-lanes.  The 10 000-bus grid fills the chip at 512 lanes; a smaller grid at
+    512 lanes is launch-bound (case1354pegase, 50 launches per iteration over 1 354 buses: factorisation at 0.16 of the HBM roofline) and gains from wider batches
+    until the state arrays leave the Infinity Cache -- measured on one MI355X (profiles/r06_bench_1354.txt): 512 / 1 024 / 2 048 / 4 096 lanes = 1.61 / 1.82 / 2.47 /
+    2.80 million NR it/s, factorisation 0.156 / 0.241 / 0.289 / 0.322 of peak.  512 lanes x floor(10 000 / buses), at least 512, at most 4 096."""
+    return 512 * max(1, min(8, 10000 // max(1, int(buses))))
+
+
 def deviceBatching(share: int, steps: int, lanes: int = 512) -> int:
     """How many consecutive steps a rank solves together as one device batch (strong scaling: a rank's share of a step shrinks
-    with the number of ranks, the path is at its best around `lanes` scenarios per launch).  At most lanes // share steps; among
-    the upper half of that range the count that leaves the fewest spare lanes in the last batch of a run of `steps` steps,
-    the larger one on a tie.  1 when the share already fills the lanes."""
+    with the number of ranks, the path is at its best around `lanes` scenarios per launch -- recommendedLanes(buses)).  A rank whose whole run is at most
+    1.25 x lanes scenarios solves it as ONE batch, at most 2.5 x lanes as TWO that are both in flight (batches of up to 640 / 1 280 lanes at the default 512);
+    otherwise at most lanes // share steps: among the upper half of that range the count that leaves the fewest spare lanes in the last batch of a run of
+    `steps` steps, the larger one on a tie.  1 when the share already fills the lanes."""
     share, steps = max(1, int(share)), max(1, int(steps))
     if share < lanes:
         # (round 5) a rank whose WHOLE run is a batch or two -- N = 8 at the driver's K = 20: 20 x 64 = 1 280 scenarios -- solves it as ONE batch of up to 5/4 lanes resp.

@@ -66,11 +66,9 @@ struct GroupSel {
 // multiple of 8 keeps the pinning (group g on XCD g % 8); any other count is NOT padded (padding 9 groups to 16 slots
 // gave one XCD two groups and the others one: 1.79 -> 2.83 ms) -- workgroup (x, slot) then lands on XCD
 // (x * groups + slot) % 8, which rotates a group over the XCDs and balances them.
-// (round 5: 3, 5 and 6 groups are NOT padded to 4 resp. 8 any more -- three resp. two XCDs sat idle in every launch: a 320-lane batch, what a rank of an 8-GPU run merges at the driver's K = 20,
-// assembly 0.133 -> 0.096 ms, factorisation 1.055 -> 0.951, backward sweep 0.237 -> 0.215, its pipeline 194k -> 227k NR it/s; 7 groups stay padded -- unpadded the factorisation
-// is slower, 1.115 -> 1.185 ms; profiles/r05_nopad_ab.txt.  The third iteration of a 512-lane batch, compacted to 5 - 6 groups, gains too: +0.3 % on the headline.)
+// Every other count takes the BALANCED mapping below (groups_balanced), so what this function still decides is 1, 2, 4 and the multiples of 8.
 __host__ __device__ inline int group_stride(int groups) {
-    return groups >= 8 || groups == 5 || groups == 6 || groups == 3 ? groups : (groups <= 1 ? 1 : (groups <= 2 ? 2 : (groups <= 4 ? 4 : 8)));   // (3 groups: a 192-lane pipeline 214k -> 226k NR it/s)
+    return groups >= 8 ? groups : (groups <= 1 ? 1 : (groups <= 2 ? 2 : (groups <= 4 ? 4 : 8)));
 }
 // BALANCED mapping (round 5, JG_BALANCED_MAP below): every group count that cannot be pinned -- not 1, 2, 4 and no multiple of 8 -- takes the (group, chunk) pairs of a launch in
 // group-major order, cuts that list into EIGHT equal runs and gives run k to the workgroups that land on XCD k (id % 8 == k): every XCD gets the same number of workgroups whatever

@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) void k_gn_add(double* inc, const double* cor, 
 // PMUs through variancePmu / covariancePmu + precision!, equations.jl:576-666).  Drawn on the host, 512 realisations of config 4 are 50 M normals and
 // 0.8 GB over PCIe per job; here a wave owns one DEVICE (meter or PMU), its lanes the realisations: two normals per (device, realisation) from a
 // counter-based generator (no state: realisation r of seed s is the same numbers on any rank, in any batch, at any lane), the value rules, coalesced rows out.
-//   u = mix64(ctr), mix64 = the splitmix64 finaliser; ctr = seed + GOLDEN * (2 d + k) ^ realisation * 0xD1B54A32D192ED03;  uniform (0, 1] = ((u >> 11) + 1) 2^-53;
+//   c = (seed + GOLDEN * (2 d)) ^ (realisation * 0xD1B54A32D192ED03);  u1 = mix64(c), u2 = mix64(c + GOLDEN), mix64 = the splitmix64 finaliser;  uniform (0, 1] = ((u >> 11) + 1) 2^-53;
 //   Box-Muller: e1 = sqrt(-2 ln u1) cos(2 pi u2), e2 = ... sin(...).   tests/test_montecarlo_gpu.py restates it in numpy.
 struct NoiseDev { int row, kind, corr, st; double z1, v1, z2, v2; };   // kind 0 plain, 1 squared, 2 polar PMU, 3 polar PMU with squared magnitude, 4 / 5 rectangular PMU (un)correlated; st = st1 | st2 << 1
 __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
