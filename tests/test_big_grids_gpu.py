@@ -62,4 +62,23 @@ def test_single_instance_and_batch_on_a_big_grid(jg, oracle, which, n):
         assert np.abs(batch.voltage.magnitude[b] - v2).max() <= 1e-8 and np.abs(batch.voltage.angle[b] - a2).max() <= 1e-8
         for p, dv in zip(ptr, dy):
             o.add_ybus(p - 1, -dv)
+    # round 6: the same screen with its first iteration on the base case's shared factor (jg_nr_base_*: one factorisation, J0^-1 on the Ybus pattern by one solve
+    # per bus and component, a dense inverse of the tree's top) -- equal iteration counts, states to rounding
+    import time
+    it_ref, vm_ref, va_ref = batch.method.iteration.copy(), batch.voltage.magnitude.copy(), batch.voltage.angle.copy()
+    single = jg.newtonRaphson(s)
+    jg.powerflow._push_voltage(single, vm, va)
+    t0 = time.perf_counter()
+    base = jg.BaseCase(single)
+    t_base = time.perf_counter() - t0
+    single.close()
+    base.attach(batch)
+    jg.startFromBase_(batch)
+    jg.powerFlow_(batch, iteration=20, tolerance=1e-8)
+    assert jg.firstIterationCounts(batch) == (1, 1)
+    ok = st == 0
+    assert np.array_equal(np.asarray(batch.status), st) and np.array_equal(batch.method.iteration[ok], it_ref[ok])
+    assert np.abs(batch.voltage.magnitude[ok] - vm_ref[ok]).max() <= 1e-9 and np.abs(batch.voltage.angle[ok] - va_ref[ok]).max() <= 1e-9
+    print(f"[{which}] base case in {1e3 * t_base:.0f} ms: {base.info}")
+    base.close()
     batch.close()
