@@ -1079,6 +1079,15 @@ def main():
         else:
             ksum = ksum_full
         line["kernel_sum_ms"] = ksum / max(merge, 1)      # (the kernels were timed on a handle of B x merge lanes: `merge` steps of this rank)
+        # the same weighting for the ALGORITHMIC bytes of a step (SURVEY 8(d) per kernel): what the whole path moves per step against what the step takes
+        by_full = (m_it + 1) * ab["assembly"] + m_it * (ab["lu"] + ab["solve"])
+        by = (first_kern["mismatch_pass"]["bytes"] + first_kern["shared_factor_step"]["bytes"] + m_it * ab["assembly"] + (m_it - 1) * (ab["lu"] + ab["solve"])) if first_kern is not None else by_full
+        line["path_roofline"] = {"algorithmic_bytes_per_step": by / max(merge, 1) * world, "achieved_GBps": by / max(merge, 1) * world / (line["ms_per_step"] * 1e-3) / 1e9 / world,
+                                 "frac": by / max(merge, 1) / (line["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "what": "algorithmic bytes of one step (per GPU: achieved_GBps, frac) -- the kernels' SURVEY 8(d) figures weighted by the mean iteration count -- over ms_per_step; "
+                                         "the compensated first iteration lowers the bytes a step needs, so this fraction is not comparable across first-iteration modes: "
+                                         "algorithmic_bytes_per_step_full_refactor is what the same step moves when every iteration refactorises",
+                                 "algorithmic_bytes_per_step_full_refactor": by_full / max(merge, 1) * world}
         line["kernel_sum_full_refactor_ms"] = ksum_full / max(merge, 1)
         line["step_over_kernels"] = line["ms_per_step"] / line["kernel_sum_ms"]
         line["kernel_sum_what"] = ("per step and GPU: the kernels of one device batch timed ALONE (HIP events, one handle, every lane active, no compaction) weighted by the mean "
