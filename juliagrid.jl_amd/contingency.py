@@ -327,7 +327,10 @@ class ContingencyPipeline:
                         startFromBase_(an)                        # device-side broadcast of the base state; the run takes its first iteration on the shared factor when it can
                     else:
                         an.restore_voltage()
-                    if use_pool:
+                    # the LAST job of a handle finishes its own stragglers in lockstep: the hand-off pays when it frees the handle for its next job; at the end of a
+                    # run the pools' turns (one worker resumes them one after the other) would only queue the tails of the batches that end together (round 6:
+                    # a rank of the 8-GPU run at the driver's K = 20 -- two 640-lane batches, both the last of their handle)
+                    if use_pool and j + nh < nj:
                         left = an.run_defer(iteration, tolerance, self.defer_at)
                         if left > 0:
                             with lock:
