@@ -801,8 +801,10 @@ struct jg_nr {
     double* d_rating = nullptr; double* d_screen = nullptr; double* d_screc = nullptr;   // contingency screen: ratings [nb], partial maxima, the record [batch][10]
     jg::Engine eng;
     hipStream_t stream = nullptr;
-    hipGraph_t graphA = nullptr, graphB = nullptr;
-    hipGraphExec_t execA = nullptr, execB = nullptr;
+    hipGraph_t graphA = nullptr, graphB = nullptr, graphBm = nullptr, graphJ = nullptr;
+    hipGraphExec_t execA = nullptr, execB = nullptr, execBm = nullptr, execJ = nullptr;   // Bm / J: an iteration whose verdict assembles NO Jacobian / the Jacobian alone (run_loop)
+    int stop_hint = 0, iter_graphs = 0;               // iteration graphs after which the last run of this handle stopped / launched by the current run
+    long long last_guess_hit = 0, last_guess_miss = 0;
     bool jac_valid = false;
     bool level0_done = false;        // the Jacobian in the factor storage came from an assembly that finished the plan's level 0
     bool f_stale = false;            // d_F does not hold every scenario's final mismatch yet (see run_finish)
@@ -1039,7 +1041,29 @@ int build_graphs(jg_nr* h) {
     if (rc) return fail(rc, h->eng.error);
     NR_HIP(e);
     NR_HIP(hipGraphInstantiate(&h->execB, h->graphB, nullptr, nullptr, 0));
+    // graph Bm: the same iteration with a verdict from a MISMATCH-ONLY pass -- for the iteration the handle expects to be the last of its run (run_loop): the
+    // Jacobian a verdict assembles is wasted on every scenario that converges (nobody factorises it) and on every scenario that leaves for a pool (jg_nr_resume
+    // assembles where they arrive), 0.87 GB of a 512-scenario batch against 0.26 GB for the mismatch pass.  graph J: the Jacobian alone, when the guess was wrong.
+    NR_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    rc = newton_step(h, active_groups(h), h->d_active);
+    launch_assemble(h, active_groups(h), false);
+    launch_check(h, 1, h->d_group);
+    launch_compact(h, 0, true);
+    if (h->ld > 64) launch_assemble(h, active_groups(h), false, nullptr, 0, h->d_cflags);
+    e = hipStreamEndCapture(h->stream, &h->graphBm);
+    if (rc) return fail(rc, h->eng.error);
+    NR_HIP(e);
+    NR_HIP(hipGraphInstantiate(&h->execBm, h->graphBm, nullptr, nullptr, 0));
+    NR_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    launch_assemble(h, active_groups(h), true, nullptr, 0, nullptr, true);
+    NR_HIP(hipStreamEndCapture(h->stream, &h->graphJ));
+    NR_HIP(hipGraphInstantiate(&h->execJ, h->graphJ, nullptr, nullptr, 0));
     return 0;
+}
+
+void drop_iteration_graphs(jg_nr* h) {
+    for (hipGraphExec_t* e : {&h->execA, &h->execB, &h->execBm, &h->execJ}) if (*e) { hipGraphExecDestroy(*e); *e = nullptr; }
+    for (hipGraph_t* g : {&h->graphA, &h->graphB, &h->graphBm, &h->graphJ}) if (*g) { hipGraphDestroy(*g); *g = nullptr; }
 }
 
 void drop_comp_graphs(jg_nr* h) {
@@ -1326,18 +1350,15 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
 
 void jg_nr_destroy(jg_nr* h) {
     if (h && jg::knob_set("HOST_TIMING") && h->host_iters > 0)
-        fprintf(stderr, "[jg host timing] %d lanes: %lld iterations, hipGraphLaunch %.1f us, wait for the verdict %.1f us per iteration\n", h->ld, h->host_iters,
-                h->host_launch_us / h->host_iters, h->host_wait_us / h->host_iters);
+        fprintf(stderr, "[jg host timing] %d lanes: %lld iterations, hipGraphLaunch %.1f us, wait for the verdict %.1f us per iteration; last iteration guessed right %lld times, wrong %lld\n", h->ld, h->host_iters,
+                h->host_launch_us / h->host_iters, h->host_wait_us / h->host_iters, h->last_guess_hit, h->last_guess_miss);
     if (!h) return;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     detach_base(h);
     hipFree(h->d_cmp);
     if (h->d_move) { hipFree(h->d_move); hipHostFree(h->h_move); }
-    if (h->execA) hipGraphExecDestroy(h->execA);
-    if (h->execB) hipGraphExecDestroy(h->execB);
-    if (h->graphA) hipGraphDestroy(h->graphA);
-    if (h->graphB) hipGraphDestroy(h->graphB);
+    drop_iteration_graphs(h);
     h->eng.destroy();
     hipFree(h->d_stage);
     hipFree(h->d_R); hipFree(h->d_inc2[0]); hipFree(h->d_inc2[1]);
@@ -1625,10 +1646,7 @@ int jg_nr_set_refine(jg_nr* h, int mode) {
         NR_HIP(jg::sync_fill(h->d_inc2[1], 0, vec, h->stream));
     }
     if ((mode != 0) != h->refine) {                              // the iteration graph is captured for one mode
-        if (h->execB) { hipGraphExecDestroy(h->execB); h->execB = nullptr; }
-        if (h->graphB) { hipGraphDestroy(h->graphB); h->graphB = nullptr; }
-        if (h->execA) { hipGraphExecDestroy(h->execA); h->execA = nullptr; }
-        if (h->graphA) { hipGraphDestroy(h->graphA); h->graphA = nullptr; }
+        drop_iteration_graphs(h);
     }
     h->refine = mode != 0;
     // a refined step runs forward() + backsolve() on the factor of the step: plain rows (Engine::jordan); back on when refinement goes off
@@ -1641,10 +1659,7 @@ int jg_nr_set_shared(jg_nr* h, int mode) {
     if (int rc = set_device(h)) return rc;
     NR_HIP(hipStreamSynchronize(h->stream));
     if ((mode != 0) != h->eng.shared) {                          // the iteration graph holds the launches of the other choice
-        if (h->execB) { hipGraphExecDestroy(h->execB); h->execB = nullptr; }
-        if (h->graphB) { hipGraphDestroy(h->graphB); h->graphB = nullptr; }
-        if (h->execA) { hipGraphExecDestroy(h->execA); h->execA = nullptr; }
-        if (h->graphA) { hipGraphDestroy(h->graphA); h->graphA = nullptr; }
+        drop_iteration_graphs(h);
     }
     h->eng.shared = mode != 0;
     return 0;
@@ -1715,25 +1730,35 @@ static hipError_t wait_verdict(jg_nr* h) {
 int run_loop(jg_nr* h, int64_t max_iter, int defer_at) {
     const bool trace = jg::knob_set("TRACE");
     auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    for (int64_t it = 0; it <= max_iter && *h->h_counter != 0; ++it) {
+    for (int64_t it = h->iter_graphs; it <= max_iter && *h->h_counter != 0; ++it) {
         if (defer_at > 0 && *h->h_counter <= defer_at) break;
+        h->iter_graphs += 1;
+        // The iteration after which this handle's LAST run stopped is expected to end this one too (the batches of a screen behave alike): its verdict comes from a
+        // mismatch-only pass (graph Bm, build_graphs).  A wrong guess costs one more launch -- the Jacobian alone (graph J) -- before the next iteration.
+        const bool guess_last = h->stop_hint > 0 && h->iter_graphs == h->stop_hint;
         const double tc = now_us();
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (trace) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, h->stream); }
         if (!trace) arm_verdict(h);
-        NR_HIP(hipGraphLaunch(h->execB, h->stream));                           // solve!, then mismatch! and the verdict on the new state
+        NR_HIP(hipGraphLaunch(guess_last ? h->execBm : h->execB, h->stream));  // solve!, then mismatch! and the verdict on the new state
         const double tl = now_us();
         if (trace) hipEventRecord(e1, h->stream);
         NR_HIP(trace ? hipStreamSynchronize(h->stream) : wait_verdict(h));
         h->host_launch_us += tl - tc; h->host_wait_us += now_us() - tl; h->host_iters += 1;     // JG_HOST_TIMING: printed when the handle goes
+        if (guess_last) {
+            const bool stops = *h->h_counter == 0 || (defer_at > 0 && *h->h_counter <= defer_at) || it + 1 > max_iter;
+            if (stops) h->last_guess_hit += 1;
+            else { h->last_guess_miss += 1; NR_HIP(hipGraphLaunch(h->execJ, h->stream)); }     // the scenarios that go on need their Jacobian after all
+        }
         if (trace) {
             float ms = 0.f; hipEventElapsedTime(&ms, e0, e1); fprintf(stderr, "[jg_nr_run] graph on the device: %.1f us\n", 1e3 * ms); hipEventDestroy(e0); hipEventDestroy(e1);
             int cf[4];
             jg::sync_copy(cf, h->d_cflags, sizeof(cf), hipMemcpyDeviceToHost, h->stream);
-            fprintf(stderr, "[jg_nr_run] iteration %lld: %.1f us, %d scenarios still active, %d of %d lane groups in use%s\n", (long long)it + 1,
-                    now_us() - tc, *h->h_counter, cf[2], h->ld / 64, cf[0] ? " (compacted)" : "");
+            fprintf(stderr, "[jg_nr_run] iteration %lld: %.1f us, %d scenarios still active, %d of %d lane groups in use%s%s\n", (long long)it + 1,
+                    now_us() - tc, *h->h_counter, cf[2], h->ld / 64, cf[0] ? " (compacted)" : "", guess_last ? " (verdict without a Jacobian)" : "");
         }
     }
+    h->stop_hint = h->iter_graphs;
     return 0;
 }
 
@@ -1743,6 +1768,7 @@ int run_start(jg_nr* h, int64_t max_iter) {
     bool comp = false;
     if (int rc = comp_ready(h, comp)) return rc;
     h->start_is_base = false;                                                  // whatever follows moves the state
+    h->iter_graphs = 0;
     arm_verdict(h);
     NR_HIP(hipGraphLaunch(comp ? h->execA2 : h->execA, h->stream));
     NR_HIP(wait_verdict(h));
@@ -1757,6 +1783,7 @@ int run_start(jg_nr* h, int64_t max_iter) {
     arm_verdict(h);
     NR_HIP(hipGraphLaunch(h->execC, h->stream));
     NR_HIP(wait_verdict(h));
+    h->iter_graphs = 1;
     if (trace) fprintf(stderr, "[jg_nr_run] iteration 1 on the shared base factor: %.1f us, %d scenarios still active\n",
                        std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0, *h->h_counter);
     return 0;
@@ -2011,6 +2038,7 @@ int jg_nr_resume(jg_nr* h, int64_t lanes, int64_t max_iter, double tol, int32_t*
     launch_compact(h, 0, true);                                                // groups in use (the lanes are already packed)
     launch_assemble(h, active_groups(h), true, nullptr, 0, nullptr, true);     // the Jacobian of the state they arrived with; NO verdict:
     NR_HIP(hipStreamSynchronize(h->stream));                                   // theirs was taken (and counted) where they came from
+    h->iter_graphs = 0;
     if (int rc = run_loop(h, max_iter, 0)) return rc;
     h->paused = true;
     if (int rc = run_finish(h, nullptr, nullptr)) return rc;
