@@ -835,7 +835,7 @@ def main():
     if B < 1:
         raise SystemExit(f"rank {rank}: no scenarios ({total} scenarios over {world} ranks)")
     # Device batch: under strong scaling a rank's share of a step shrinks with N (64 scenarios at N = 8), and the path is at its best
-    # around 512 scenarios per launch (DESIGN 6).  The scenarios of a job are independent, so a rank solves its shares of M
+    # around 512 scenarios per launch (DESIGN.md 6).  The scenarios of a job are independent, so a rank solves its shares of M
     # consecutive steps together in ONE handle of M x B lanes (M = 512 // B): the same K x `total` scenarios are solved inside the
     # timed region, in wider launches, and the ONE collective then carries the records of M steps.  --merge 1 switches it off.
     b_max = -(-total // world)

@@ -903,7 +903,7 @@ __global__ __launch_bounds__(64 * TASK_WAVES, 4) void k_fact_task(FactArgs a) {
 }
 
 // TIMING PROBES of a pivot step (compile with -DJG_PROBE_TOP=1: the next pivot's row / column are not published, =3: the bulk threads take the published row as D^-1 U(q, .) -- no pivot read, no solve --, =2: one block update per
-// thread instead of CLS x CLS; wrong numbers -- tools/level_bound_probe.sh): what a step is made of.
+// thread instead of CLS x CLS; wrong numbers -- tools/experiments/level_bound_probe.sh, DESIGN_LOG.md 3.3): what a step is made of.
 #ifndef JG_PROBE_TOP
 #define JG_PROBE_TOP 0
 #endif
@@ -922,7 +922,7 @@ constexpr int TOP_THREADS = 320;        // 16 x 16 bulk threads + the pivot wave
 // columns, L(i, q+1) = L0(i, q+1) - L(i, q) z_q(q+1), U(q+1, c) = U0(q+1, c) - L(q+1, q) z_q(c) and the factorised D(q+1) itself -- the
 // very operations, in the very order, that the owners of those blocks perform in the one-pivot step (same bits) -- and applies both
 // pivots to its blocks.  A third more arithmetic per pivot, half the barriers and half the publish / read round trips: the step is
-// bound by those, not by the arithmetic.
+// bound by those (DESIGN_LOG.md 3.3), not by the arithmetic.
 // JORDAN (jg_symbolic.hpp: Jordan rows): the column of the next pivot is published with the blocks of the FINISHED pivot rows as they
 // stand instead of zeros, so the bulk update -- which touches every block of the grid anyway -- also eliminates column q from the rows
 // above it: rows i < q get row_i -= U(i,q) D(q)^-1 row_q over the columns c > q (the row of pivot q is published with zeros up to

@@ -419,7 +419,7 @@ void build_top(BlockSymbolic& S, int top_level, int soft_cap, int struct_min, in
     if (top_level != NO_TOP_LEVEL) for (int k = 0; k < n; ++k) if (S.e_level[S.diag[k]] >= top_level) top[k] = 1;
     // fronts of struct_min blocks and more go to the tasks wherever they sit in the tree, and so do their ancestors (a task hands
     // its update matrix to the task of its parent): per (pivot, scenario) a task step costs the same whatever the front, a
-    // level item costs per update term, and the two cross near 13 blocks
+    // level item costs per update term, and the two cross near 13 blocks (DESIGN_LOG.md 3.3)
     if (struct_min > 0) {
         for (int k = 0; k < n; ++k) if (ssize(k) >= struct_min) top[k] = 1;
         for (int k = 0; k < n; ++k) if (top[k] && parent(k) >= 0) top[parent(k)] = 1;

@@ -51,7 +51,7 @@ constexpr int FACT_WAVES = 8;   // FactRec: {kind, id, src, nterms, (a, d, b) x 
 constexpr int BWD_T = 6;    // BwdRec:  {k, bus, diag, nterms, (u_ent, u_col) x 6}; k -1 = idle wave
 // ---- factorisation TASKS (plans with policy bit 50, round 4) --------------------------------------------------------------
 // A level item pulls three operand blocks per update term -- Lh(i,k), D(k), U(k,j) -- through the vector memory pipe of its CU, and that
-// pipe (one 1 KiB wave-load per 16 clocks), not HBM, is what the level launches of a large batch wait for.  But the items that
+// pipe (one 1 KiB wave-load per 16 clocks), not HBM, is what the level launches of a large batch wait for (DESIGN_LOG.md 3.6).  But the items that
 // become final with pivot p share operands: every term of D(p), U(p, .) and y_p with pivot k reads the SAME Lh(p,k) and D(k), every term of
 // Lh(., p) the same U(k,p) and D(k).  A TASK is one 8-wave workgroup that owns a run of such items (whole pivot rows / columns, in the pivot order
 // of the level): it first STAGES the shared operands of its items in LDS, already multiplied by the pivot block --

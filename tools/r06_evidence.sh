@@ -7,7 +7,7 @@ python bench.py > gpurun_out/bench_$T.json 2> gpurun_out/bench_$T.err           
 python bench.py --steps 20 --warmup 2 --no-cpu --no-se 2>/dev/null | line > gpurun_out/bench_20_$T.json   # the driver's K
 python bench.py --steps 20 --warmup 2 --no-cpu --no-se --full-refactor 2>/dev/null | line > gpurun_out/bench_20_full_refactor_$T.json   # no base case at all: the pipeline of rounds 1-5
 python bench.py --workload se 2> gpurun_out/bench_se_$T.err | line > gpurun_out/bench_se_$T.json          # config 4 as a sharded Monte-Carlo run (N = 1; live PMC of the SE kernels)
-python bench.py --case case9241synth --steps 24 --warmup 3 --no-se --no-cpu 2>/dev/null | line > gpurun_out/bench_9241_$T.json
+python bench.py --case case9241synth --steps 24 --warmup 3 --no-se 2>/dev/null | line > gpurun_out/bench_9241_$T.json          # config 3: the 9241-bus stand-in with its own live PMC passes (roofline.traffic) and cpu legs
 python bench.py --case case1354pegase --steps 24 --warmup 3 --no-se --no-cpu 2>/dev/null | line > gpurun_out/bench_1354_$T.json
 for b in 512 1024 2048 4096; do python bench.py --case case1354pegase --batch $b --merge 1 --steps 20 --warmup 3 --no-cpu --no-se 2>/dev/null | line > gpurun_out/bench_1354_b${b}_$T.json; done
 python - <<'PY' > gpurun_out/bench_1354_lanes_$T.txt
@@ -60,6 +60,7 @@ python tools/pmc_se_summary.py gpurun_out/pmc_${T}_se_FETCH_SIZE/p_counter_colle
 for c in case1354pegase case9241synth case_ACTIVSg10k; do python tools/r06_single_probe.py $c 8 2>&1 | tail -1; done > gpurun_out/single_$T.txt
 python tools/r06_comp_profile.py -1 64 128 256 512 768 1024 1536 2048 2>&1 | grep top_cap > gpurun_out/comp_top_sweep_$T.txt
 tools/r06_merge_sweep.sh > gpurun_out/merge_sweep_$T.txt 2>&1
+tools/r06_n8_shape.sh > gpurun_out/n8_shape_$T.txt 2>&1
 python tools/time_fast.py > gpurun_out/fast_$T.txt 2>&1
 find gpurun_out -name "*.csv" -size +4M -delete; find gpurun_out -name "*.db" -delete
 python tools/r06_show.py gpurun_out/bench_$T.json; cat gpurun_out/bench_1354_lanes_$T.txt; cat gpurun_out/single_$T.txt; cat gpurun_out/run_pmc_${T}_comp.log | tail -12

@@ -20,5 +20,5 @@ PY
 grep -v "^calibration\|^{" $G/run_pmc_$T.log > $P/${T}_pmc_b512_per_kernel.txt; grep "^calibration\|^{" $G/run_pmc_$T.log >> $P/${T}_pmc_b512_per_kernel.txt
 cp $G/run_pmc_${T}_comp.log $P/${T}_pmc_first_iteration_per_kernel.txt
 cp $G/run_pmc_${T}_se.log $P/${T}_pmc_se_9241_per_kernel.txt
-for f in single comp_top_sweep merge_sweep fast timeline bench_1354_lanes; do [ -s $G/${f}_$T.txt ] && cp $G/${f}_$T.txt $P/${T}_${f}.txt; done
+for f in single comp_top_sweep merge_sweep n8_shape fast timeline bench_1354_lanes; do [ -s $G/${f}_$T.txt ] && cp $G/${f}_$T.txt $P/${T}_${f}.txt; done
 git status --short $P | head -40
