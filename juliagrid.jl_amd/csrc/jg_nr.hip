@@ -791,6 +791,7 @@ struct jg_nr {
     bool fast = false;                                // fast decoupled mode (jg_nr_fast_setup): constant B', B'' factorised once
     std::vector<double> fast_blk;                     // ... the shared block matrix diag(B', B'') as set up [nnz][4] (engine block order)
     std::vector<int> fp_entry; std::vector<double> fp_dp, fp_dq;   // per-scenario edits of B' / B'' (jg_nr_fast_patch_batch): [FAST_MP][batch] factor entry (-1: none), deltas
+    int* d_fp_entry = nullptr; double* d_fp_dp = nullptr; double* d_fp_dq = nullptr;   // ... their device copies (allocated on first use)
     double* d_R = nullptr;                            // rhs of the half-iterations
     double* d_inc2[2] = {nullptr, nullptr};           // increments of the theta / V half-iterations
     const int* fast_mask = nullptr;                   // scenarios that take the update (nullptr: all)
@@ -1362,6 +1363,7 @@ void jg_nr_destroy(jg_nr* h) {
     h->eng.destroy();
     hipFree(h->d_stage);
     hipFree(h->d_R); hipFree(h->d_inc2[0]); hipFree(h->d_inc2[1]);
+    hipFree(h->d_fp_entry); hipFree(h->d_fp_dp); hipFree(h->d_fp_dq);
     if (h->execFA) hipGraphExecDestroy(h->execFA);
     if (h->execFB) hipGraphExecDestroy(h->execFB);
     if (h->graphFA) hipGraphDestroy(h->graphFA);
@@ -2146,16 +2148,20 @@ static int fast_refactor(jg_nr* h) {
     bool any = false;
     for (int e : h->fp_entry) any = any || e >= 0;
     if (any) {
-        int* d_e = nullptr; double* d_p = nullptr; double* d_q = nullptr;
-        std::string err;
-        if (jg::upload(&d_e, h->fp_entry, err, h->stream) || jg::upload(&d_p, h->fp_dp, err, h->stream) || jg::upload(&d_q, h->fp_dq, err, h->stream)) {
-            hipFree(d_e); hipFree(d_p); hipFree(d_q);
-            return fail(2, err);
+        //  the edit tables live in buffers of the handle: three hipMalloc / hipFree pairs per call were device-wide synchronisations that could stall
+        // other pipeline threads in the middle of a graph capture
+        const size_t cnt = h->fp_entry.size();
+        if (!h->d_fp_entry) {
+            NR_HIP(hipMalloc((void**)&h->d_fp_entry, cnt * sizeof(int)));
+            NR_HIP(hipMalloc((void**)&h->d_fp_dp, cnt * sizeof(double)));
+            NR_HIP(hipMalloc((void**)&h->d_fp_dq, cnt * sizeof(double)));
         }
-        hipLaunchKernelGGL(k_fast_patch, dim3((h->batch + 255) / 256, FAST_MP), dim3(256), 0, h->stream, h->eng.X, d_e, d_p, d_q, h->ld, h->batch);
-        hipError_t e = hipStreamSynchronize(h->stream);
-        hipFree(d_e); hipFree(d_p); hipFree(d_q);
-        NR_HIP(e);
+        NR_HIP(hipMemcpyAsync(h->d_fp_entry, h->fp_entry.data(), cnt * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        NR_HIP(hipMemcpyAsync(h->d_fp_dp, h->fp_dp.data(), cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        NR_HIP(hipMemcpyAsync(h->d_fp_dq, h->fp_dq.data(), cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_fast_patch, dim3((h->batch + 255) / 256, FAST_MP), dim3(256), 0, h->stream, h->eng.X, (const int*)h->d_fp_entry, (const double*)h->d_fp_dp,
+                           (const double*)h->d_fp_dq, h->ld, h->batch);
+        NR_HIP(hipStreamSynchronize(h->stream));
     }
     NR_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
     h->eng.jordan = false;                                       // factor once, then forward() + backsolve() per half iteration: plain rows

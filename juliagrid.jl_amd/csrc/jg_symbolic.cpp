@@ -164,7 +164,7 @@ bool elimination_order(int n, std::vector<std::vector<int>>&& adj0, std::vector<
                 if (x > a) newedge.push_back(std::make_pair(a, x));
                 xcount[ia]++;
                 long long c = 0;                               // neighbours of x among the old neighbours of a outside the clique (v is in both lists)
-                for (int w : adj[x]) c += (mark[w] == stamp) & (seen[w] != epoch) & (w != v);
+                for (int w : adj[x]) c += (int)(mark[w] == stamp) & (int)(seen[w] != epoch) & (int)(w != v);
                 xr[ia] += c;
             }
         }
