@@ -930,7 +930,7 @@ constexpr int TOP_THREADS = 320;        // 16 x 16 bulk threads + the pivot wave
 // last step a pivot row holds J(i, ext) and y'_i; the rows leave for their own region behind the factor entries.  Same step, same
 // barrier count, no extra arithmetic issued.
 template <int CLS, bool PW, bool FUSE = false, bool JORDAN = false>
-__global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves_per_eu(CLS == 4 || (FUSE && CLS == 3) ? 2 : 4))) void k_fact_top(TopArgs a) {
+__global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves_per_eu(CLS == 4 || (FUSE && CLS == 3) ? 2 : (PW && CLS == 3 ? 3 : 4)))) void k_fact_top(TopArgs a) {
     constexpr int GL = 4, G = 1 << GL;                           // the front on a 16 x 16 thread grid (a 32 x 32 grid and one- / two-wave kernels were measured slower: tools/experiments/r05_*.patch)
     static_assert(!(PW && FUSE), "the fused step has no pivot wave");
     static_assert(!(JORDAN && FUSE), "the fused step keeps plain rows");
@@ -985,45 +985,133 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
                 const int i = r * G + gi, j = c * G + gj;
                 code[r][c] = (i < f && j < fprime) ? td[i * fprime + j] : -1;
             }
+        // (round 6, the variant of launches with FEW workgroups -- PW -- where nothing hides a latency: UNCONDITIONAL loads at clamped addresses, selected
+        // afterwards, all of a chunk of rows in flight together.  Behind `if (cd ...)` the compiler puts every block's two loads into a branch of their own with
+        // an s_waitcnt vmcnt(0) behind them: CLS^2 dependent round trips, 2.5 - 3.2 us of the ~20 us a task of a single instance takes.  The batched variant keeps
+        // the conditional form: 17 registers less at class 2, which is a workgroup more per CU.)
+        if constexpr (PW) {
+            constexpr int RC = CLS == 4 ? 2 : CLS;               // rows per chunk (class 4: two chunks, the loads of one need 64 registers)
 #pragma unroll
-        for (int r = 0; r < CLS; ++r)
+            for (int r0 = 0; r0 < CLS; r0 += RC) {
+                double2 g0[RC][CLS], g1[RC][CLS];
 #pragma unroll
-            for (int c = 0; c < CLS; ++c) {
-                const int cd = code[r][c];
-                Blk v{0.0, 0.0, 0.0, 0.0};
-                if (cd <= -2) { const double2 y = load_vec(a.W, (size_t)(-(cd + 2)), b, ld); v.v00 = y.x; v.v10 = y.y; }
-                else if (cd >= 0 && !((cd >> 28) & 1)) {
-                    v = load_blk(a.X, (size_t)(cd & 0x0fffffff), b, ld);
-                    if ((cd >> 28) & 2) { const double s = v.v01; v.v01 = v.v10; v.v10 = s; }        // symmetric plans: Lh(i,c) = U(c,i)'
-                }
-                T[r][c] = v;
-                // what the guard compares a pivot with: the block as it entered the task -- a pivot that the children's update matrices (or the
-                // task's own steps) cancel to rounding level is the signature of an island whose root sits in the top (taken after
-                // the extend-add the reference scale was the cancelled value itself)
-                if (r == c && gi == gj && r * G + gi < m) *(double2*)(Dref + (size_t)(r * G + gi) * 2) = row_max(v);
+                for (int r = r0; r < r0 + RC; ++r)
+#pragma unroll
+                    for (int c = 0; c < CLS; ++c) {
+                        const int cd = code[r][c];
+                        const bool isrhs = cd <= -2, isblk = cd >= 0 && !((cd >> 28) & 1);
+                        const char* px = (const char*)a.X + (size_t)(isblk ? (cd & 0x0fffffff) : 0) * ld * 32 + (unsigned)b * 16u;
+                        const char* pw = (const char*)a.W + (size_t)(isrhs ? -(cd + 2) : 0) * ld * 16 + (unsigned)b * 16u;
+                        g0[r - r0][c] = *(const double2*)(isrhs ? pw : px);
+                        g1[r - r0][c] = *(const double2*)(px + ld * 16);
+                    }
+#pragma unroll
+                for (int r = r0; r < r0 + RC; ++r)
+#pragma unroll
+                    for (int c = 0; c < CLS; ++c) {
+                        const int cd = code[r][c];
+                        const bool isrhs = cd <= -2, isblk = cd >= 0 && !((cd >> 28) & 1), tr = ((cd >> 28) & 2) != 0;   // tr: symmetric plans, Lh(i,c) = U(c,i)'
+                        const double2 a0 = g0[r - r0][c], a1 = g1[r - r0][c];
+                        Blk v;
+                        v.v00 = (isrhs || isblk) ? a0.x : 0.0;
+                        v.v01 = isblk ? (tr ? a1.x : a0.y) : 0.0;
+                        v.v10 = isrhs ? a0.y : (isblk ? (tr ? a0.y : a1.x) : 0.0);
+                        v.v11 = isblk ? a1.y : 0.0;
+                        T[r][c] = v;
+                    }
             }
-        if (prof) pt[1] = wall_clock64();
-        // ---- extend-add: every thread pulls what the children left for its blocks (child order fixed => deterministic)
-        const int* cd = td + h[7];
-        for (int ch = 0; ch < nchild; ++ch) {
-            const int coff = cd[0], ce = cd[1];
-            const int* inv = cd + 2;
-            const double* C = stk + coff;
-            int ri[CLS], cj[CLS];
-#pragma unroll
-            for (int r = 0; r < CLS; ++r) { const int i = r * G + gi; ri[r] = i < f ? inv[i] : -1; }
-#pragma unroll
-            for (int c = 0; c < CLS; ++c) { const int j = c * G + gj; cj[c] = j < fprime ? inv[j] : -1; }
+        } else {
 #pragma unroll
             for (int r = 0; r < CLS; ++r)
 #pragma unroll
-                for (int c = 0; c < CLS; ++c)
-                    if (ri[r] >= 0 && cj[c] >= 0) {
-                        const double2* p = (const double2*)(C + ((size_t)ri[r] * (ce + 1) + cj[c]) * 4);
-                        const double2 s0 = p[0], s1 = p[1];
-                        T[r][c].v00 += s0.x; T[r][c].v01 += s0.y; T[r][c].v10 += s1.x; T[r][c].v11 += s1.y;
+                for (int c = 0; c < CLS; ++c) {
+                    const int cd = code[r][c];
+                    Blk v{0.0, 0.0, 0.0, 0.0};
+                    if (cd <= -2) { const double2 y = load_vec(a.W, (size_t)(-(cd + 2)), b, ld); v.v00 = y.x; v.v10 = y.y; }
+                    else if (cd >= 0 && !((cd >> 28) & 1)) {
+                        v = load_blk(a.X, (size_t)(cd & 0x0fffffff), b, ld);
+                        if ((cd >> 28) & 2) { const double s = v.v01; v.v01 = v.v10; v.v10 = s; }        // symmetric plans: Lh(i,c) = U(c,i)'
                     }
-            cd += 2 + fprime;
+                    T[r][c] = v;
+                }
+        }
+        // what the guard compares a pivot with: the block as it entered the task -- a pivot that the children's update matrices (or the
+        // task's own steps) cancel to rounding level is the signature of an island whose root sits in the top (taken after
+        // the extend-add the reference scale was the cancelled value itself)
+#pragma unroll
+        for (int r = 0; r < CLS; ++r)
+            if (gi == gj && r * G + gi < m) *(double2*)(Dref + (size_t)(r * G + gi) * 2) = row_max(T[r][r]);
+        if (prof) pt[1] = wall_clock64();
+        // ---- extend-add: every thread pulls what the children left for its blocks (child order fixed => deterministic)
+        if constexpr (PW) {
+            // (round 6, launches with few workgroups: a child's blocks are requested TOGETHER -- unconditional loads at clamped offsets, added under a select: same
+            // bits -- and the record of the next child travels with them.  The conditional loads below compile to one round trip per block and two more per
+            // child record: 3 - 6 us of a single instance's task.)
+            const int* cd = td + h[7];
+            int n_coff = 0, n_ce = 0, n_ri[CLS], n_cj[CLS];
+            auto fetch = [&](const int* p) {
+                n_coff = p[0]; n_ce = p[1];
+#pragma unroll
+                for (int r = 0; r < CLS; ++r) { const int i = r * G + gi; const int v = p[2 + (i < f ? i : 0)]; n_ri[r] = i < f ? v : -1; }
+#pragma unroll
+                for (int c = 0; c < CLS; ++c) { const int j = c * G + gj; const int v = p[2 + (j < fprime ? j : 0)]; n_cj[c] = j < fprime ? v : -1; }
+            };
+            if (nchild > 0) fetch(cd);
+            for (int ch = 0; ch < nchild; ++ch) {
+                const int coff = n_coff, ce = n_ce;
+                int ri[CLS], cj[CLS];
+#pragma unroll
+                for (int r = 0; r < CLS; ++r) ri[r] = n_ri[r];
+#pragma unroll
+                for (int c = 0; c < CLS; ++c) cj[c] = n_cj[c];
+                cd += 2 + fprime;
+                if (ch + 1 < nchild) fetch(cd);
+                const double* C = stk + coff;
+                constexpr int RC = CLS == 4 ? 2 : CLS;
+#pragma unroll
+                for (int r0 = 0; r0 < CLS; r0 += RC) {
+                    double2 s0[RC][CLS], s1[RC][CLS];
+#pragma unroll
+                    for (int r = r0; r < r0 + RC; ++r)
+#pragma unroll
+                        for (int c = 0; c < CLS; ++c) {
+                            const bool ok = ri[r] >= 0 && cj[c] >= 0;
+                            const double2* p = (const double2*)(C + (ok ? ((size_t)ri[r] * (ce + 1) + cj[c]) * 4 : 0));
+                            s0[r - r0][c] = p[0]; s1[r - r0][c] = p[1];
+                        }
+#pragma unroll
+                    for (int r = r0; r < r0 + RC; ++r)
+#pragma unroll
+                        for (int c = 0; c < CLS; ++c) {
+                            const bool ok = ri[r] >= 0 && cj[c] >= 0;
+                            const double2 x0 = s0[r - r0][c], x1 = s1[r - r0][c];
+                            T[r][c].v00 = ok ? T[r][c].v00 + x0.x : T[r][c].v00; T[r][c].v01 = ok ? T[r][c].v01 + x0.y : T[r][c].v01;
+                            T[r][c].v10 = ok ? T[r][c].v10 + x1.x : T[r][c].v10; T[r][c].v11 = ok ? T[r][c].v11 + x1.y : T[r][c].v11;
+                        }
+                }
+            }
+        } else {
+            const int* cd = td + h[7];
+            for (int ch = 0; ch < nchild; ++ch) {
+                const int coff = cd[0], ce = cd[1];
+                const int* inv = cd + 2;
+                const double* C = stk + coff;
+                int ri[CLS], cj[CLS];
+#pragma unroll
+                for (int r = 0; r < CLS; ++r) { const int i = r * G + gi; ri[r] = i < f ? inv[i] : -1; }
+#pragma unroll
+                for (int c = 0; c < CLS; ++c) { const int j = c * G + gj; cj[c] = j < fprime ? inv[j] : -1; }
+#pragma unroll
+                for (int r = 0; r < CLS; ++r)
+#pragma unroll
+                    for (int c = 0; c < CLS; ++c)
+                        if (ri[r] >= 0 && cj[c] >= 0) {
+                            const double2* p = (const double2*)(C + ((size_t)ri[r] * (ce + 1) + cj[c]) * 4);
+                            const double2 s0 = p[0], s1 = p[1];
+                            T[r][c].v00 += s0.x; T[r][c].v01 += s0.y; T[r][c].v10 += s1.x; T[r][c].v11 += s1.y;
+                        }
+                cd += 2 + fprime;
+            }
         }
         if (prof) pt[2] = wall_clock64();
         // ---- publish step 0: row 0, column 0, the chain's diagonal blocks; thread 0 factorises D(0).
@@ -1284,12 +1372,24 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
         const int lgo = h[12];                                   // scenario interleave of the update block: that of the parent's workgroup
         double2* out = e > 0 ? stack_unit(a, b, h[4], lgo) : nullptr;
         const int jb = JORDAN ? h[14] : -1;                      // Jordan rows: block jb + i e + (j - m) for pivot row i, external column j
+        // (round 6, launches with few workgroups: the entry map of the thread's slots is requested in one go, ahead of the stores; read slot by slot every code
+        // waits -- s_waitcnt vmcnt(0) -- for the stores of the slot before it as well: 3 - 4 us per task of a single instance)
+        int code[CLS][CLS];
 #pragma unroll
         for (int r = 0; r < CLS; ++r)
 #pragma unroll
             for (int c = 0; c < CLS; ++c) {
                 const int i = r * G + gi, j = c * G + gj;
-                const int cd = (i < f && j < fprime) ? td[i * fprime + j] : -1;
+                const bool in = i < f && j < fprime;
+                if constexpr (PW) { const int v = td[in ? i * fprime + j : 0]; code[r][c] = in ? v : -1; }
+                else code[r][c] = in ? td[i * fprime + j] : -1;
+            }
+#pragma unroll
+        for (int r = 0; r < CLS; ++r)
+#pragma unroll
+            for (int c = 0; c < CLS; ++c) {
+                const int i = r * G + gi, j = c * G + gj;
+                const int cd = code[r][c];
                 const Blk& v = T[r][c];
                 if (JORDAN && i < m && j >= m && j < f) store_blk(a.X, (size_t)(jb + i * e + (j - m)), b, ld, v.v00, v.v01, v.v10, v.v11);
                 else if (cd <= -2) store_vec(a.W, (size_t)(-(cd + 2)), b, ld, v.v00, v.v10);
@@ -1660,6 +1760,12 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, long long 
     const bool lane64 = !top_r02 && ld_ == 64 && !tiny && n >= 4000 && !(policy & 2);
     if (defaults) policy |= ld_ >= 256 ? (n >= 4000 ? (top_r02 || (policy & 2) ? (47 << 16 | (384 / 8) << 24 | 8 << 4) : (47 << 16 | 127 << 24 | 12 << 4)) : (47 << 16 | (280 / 8) << 24 | 4 << 4))
                                               : ((n >= 4000 ? 26 : 24) << 16 | (tiny || lane64 ? 127 : 384 / 8) << 24 | (lane64 ? 15 << 4 : 0));
+    // round 6, a handful of scenarios: a top task takes at least 12 pivots instead of 8 where its front has room (jg_symbolic.hpp, policy bits 54-59).  The
+    // critical path of a single instance of the 10k-bus grid is a chain of 8-pivot tasks with 25-34 external rows -- 20 us each, 13 of them gather / extend-add /
+    // store -- and a lone workgroup steps through a class-4 front as fast as through a class-3 one: 1.603 -> 1.507 ms per solve with 12 (10: 1.549, 16: 1.500,
+    // 20: 1.556, 24: 1.66; the 9241-bus grid 1.488 / 1.495 / 1.490 / 1.54 for 8 / 10 / 12 / 16; case1354pegase does not care; a larger soft cap loses everywhere:
+    // tools/experiments/r06_mmin_sweep.sh, profiles/r06_mmin_sweep.txt)
+    if (defaults && tiny && !((policy >> 54) & 0x3f)) policy |= 12LL << 54;
     const bool timing = knob_set("PLAN_TIMING");
     auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double te0 = tnow();

@@ -437,7 +437,10 @@ void build_top(BlockSymbolic& S, int top_level, int soft_cap, int struct_min, in
         if (!top[k] || S.top_task_of[k] >= 0) continue;
         Task t{};
         t.e = ssize(k);
-        int cap = std::max(std::min(8, TOP_FRONT_MAX - t.e), soft_cap - t.e), lowcap = 0;
+        // a task takes at least top_mmin pivots (8; policy bits 54-59) where its front has room for them, and fills the front up to the soft cap
+        // (more than 8 only while the front stays in class 3 -- 47 rows + the rhs column: one class-4 task makes its whole launch run the class-4 kernel, 1.0 us per
+        // pivot step against 0.79)
+        int cap = std::max(std::min(std::min(S.top_mmin, std::max(8, 47 - t.e)), TOP_FRONT_MAX - t.e), soft_cap - t.e), lowcap = 0;
         if (mid_mmin > 0) {
             const int need = std::max(1, std::min(tsub[k], mid_mmin));
             int geo = 2;
@@ -1135,6 +1138,8 @@ int analyze(int n, const int* rowptr, const int* col, long long policy64, BlockS
     S.jordan = (int)((policy64 >> 49) & 1);                       // a request here; build_top grants it
     S.fact_tasks = (int)((policy64 >> 50) & 1);
     S.task_rounds = (int)((policy64 >> 51) & 7);
+    S.top_mmin = (int)((policy64 >> 54) & 0x3f);
+    if (S.top_mmin <= 0) S.top_mmin = 8;
     if (S.task_rounds <= 0) S.task_rounds = 3;
     S.n = n;
     if (n <= 0) return 1;

@@ -191,6 +191,7 @@ struct BlockSymbolic {
     int n_sel_levels = 0;
     // multifrontal top (see TopLaunch): empty when the plan has no top tasks
     int top_level = 0;                  // pivots whose diagonal becomes final at this level or later belong to top tasks (0: none)
+    int top_mmin = 8;                   // policy bits 54-59: a task takes at least this many pivots where its front has room (0 = default 8)
     std::vector<int> top_task_of;       // [n] task index of a pivot, -1 = bottom pivot
     std::vector<Rec> top_task;          // task headers, launch order
     std::vector<int> top_data;
@@ -239,6 +240,8 @@ void build_comp_tables(const BlockSymbolic& S, int top_cap, CompTables& out);
 // its geometry (smaller fronts form tasks of their own below it).
 // policy bit 49: Jordan rows for the pivots of the top tasks + a second set of backward tables over them (see TOP_FRONT_MAX above).
 // policy bit 50: the factorisation tables are TASKS (see TASK_WAVES above); bits 51-53: rounds a task is filled up to (0 = default 3).
+// policy bits 54-59: least number of pivots a top task takes where its front has room (0 = default 8; a handful of scenarios: 12 -- a task costs ~10 us of
+// gather / extend-add / store whatever it eliminates, and a lone workgroup steps through a 50-row front as fast as through a 30-row one).
 // Returns 0, or 1 on a malformed pattern.
 int analyze(int n, const int* rowptr, const int* col, long long policy, BlockSymbolic& out);
 // Replay tables of the selected inverse of a SYMMETRIC matrix on the factor pattern (see jg_symbolic.cpp); idempotent.
