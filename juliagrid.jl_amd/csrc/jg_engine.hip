@@ -491,6 +491,140 @@ __global__ __launch_bounds__(512, 4) void k_bwd_level8(BwdArgs a) {
     level_body<true, 8>(a, red);
 }
 
+// ---- backward sweep of a SINGLE instance (jg_symbolic.hpp: SingleTables): the lanes are ROWS, not scenarios ------------------------------------------
+// The level kernels above give a wave to one row of 64 scenarios; with ONE scenario 63 lanes idle and the sweep is 15 dependent launches of
+// ~4.7 us (ACTIVSg10k: 72 us of a 370 us iteration).  Two launches instead: the top's rows in one workgroup (levels = workgroup barriers, its
+// solution in LDS), the rows below the top as whole subtrees per workgroup with every sweep-independent operand requested before the first barrier.
+// Same arithmetic per row (x_k = D_k^-1 (y_k - sum U(k,c) x_c), state update fused); the sum of a top row is formed by four lanes (fixed order).
+struct Bwd1Args {
+    const int* t_row; const int* t_ptr; const int* t_term; const int* t_level;
+    const int* b_wg; const int* b_row; const int* b_term;
+    const double* X; const double* jc; double* W; double* out; GroupSel sel; StateUpdate upd;    // jc: the compact Jordan rows k_fact_top left (TopArgs::jc)
+    int ld, n_top_levels, n_wg, n_top;
+};
+struct Upd1 { int fl; bool act; double va, vm; };
+// act: is the scenario active (read ONCE per launch: a load of it per row is a round trip ahead of everything else the row asks for)
+__device__ __forceinline__ bool upd1_active(const StateUpdate& u, size_t b) { return u.va ? (u.active ? (u.active[b] != 0) : true) : false; }
+__device__ __forceinline__ Upd1 upd1_prefetch(const StateUpdate& u, bool act, int bus, size_t b, size_t ld) {
+    Upd1 p{0, act, 0.0, 0.0};
+    if (u.va) {
+        p.fl = (int)u.flags[bus];
+        p.va = u.va[(size_t)bus * ld + b];
+        p.vm = u.vm[(size_t)bus * ld + b];
+    }
+    return p;
+}
+__device__ __forceinline__ double2 bwd1_finish(const Bwd1Args& a, const Blk& d, double y0, double y1, int k, int bus, size_t b, size_t ld, const Upd1& p) {
+    double x0, x1;
+    dsolve(d, y0, y1, x0, x1);
+    store_vec(a.W, (size_t)k, b, ld, x0, x1);
+    if (!a.upd.va || p.act) store_vec(a.out, (size_t)bus, b, ld, x0, x1);       // a finished scenario keeps its last increment
+    if (a.upd.va) {
+        if (p.act && (p.fl & 1)) a.upd.va[(size_t)bus * ld + b] = p.va + a.upd.sign * x0;
+        if (p.act && (p.fl & 2)) a.upd.vm[(size_t)bus * ld + b] = p.vm + a.upd.sign * x1;
+    }
+    return double2{x0, x1};
+}
+
+// A workgroup barrier that orders LDS traffic only: __syncthreads() also waits (s_waitcnt vmcnt(0)) for every global store in flight -- the solution and state a
+// level has just written, which nobody of this launch reads back -- i.e. one store round trip per level.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(1024) void k_bwd1_top(Bwd1Args a) {
+    extern __shared__ __attribute__((aligned(16))) double red[];
+    // LDS: solution of the top rows (slot = position in t_row) | the rows' descriptors | their pointers -- the descriptors come in with ONE coalesced sweep at the
+    // start, so a row is one round trip to memory (slots, blocks, right-hand side, diagonal block, state: in flight together) and nothing is carried in flight
+    // from one row to the next (a prefetched descriptor made the compiler wait with vmcnt(0) at the loop header: behind the stores of the row before).
+    double2* xs = (double2*)red;
+    int4* rowd = (int4*)(xs + a.n_top);
+    int2* rowp = (int2*)(rowd + a.n_top);
+    int grp, bx;
+    if (!map_block(a.sel, a.ld, 1, grp, bx)) return;
+    const size_t b = (size_t)grp * 64, ld = (size_t)a.ld;
+    const int tid = threadIdx.x, quad = tid >> 2, q = tid & 3;
+    __shared__ int lvl[64];                                       // first row of every level
+    if (tid <= a.n_top_levels && tid < 64) lvl[tid] = a.t_level[tid];
+    for (int r = tid; r < a.n_top; r += 1024) { rowd[r] = *(const int4*)(a.t_row + 4 * (size_t)r); rowp[r] = *(const int2*)(a.t_ptr + 2 * (size_t)r); }
+    const bool act = upd1_active(a.upd, b);
+    __syncthreads();
+    constexpr int TQ = 8;                                         // terms per lane in flight
+    for (int L = 0; L < a.n_top_levels; ++L) {
+        const int r1 = lvl[L + 1];
+        for (int row = lvl[L] + quad; row < r1; row += 256) {
+            const int4 d = rowd[row];                             // pivot, bus, diagonal entry, terms
+            const int2 tp = rowp[row];                            // first block of the row in the compact Jordan rows, first slot of its column list
+            // (every lane of the quad asks for the row's right-hand side, diagonal block and state: same addresses, no branch -- and no wait -- ahead of the term loads)
+            const Upd1 up = upd1_prefetch(a.upd, act, d.y, b, ld);
+            const double2 yk = load_vec(a.W, (size_t)d.x, b, ld);
+            const Blk dg = load_blk(a.X, (size_t)d.z, b, ld);
+            double y0 = 0.0, y1 = 0.0;
+            for (int i0 = 0; i0 < d.w; i0 += 4 * TQ) {            // unconditional loads at clamped positions; lane q takes terms q, q + 4, ...
+                int sl[TQ]; double2 m0[TQ], m1[TQ];
+#pragma unroll
+                for (int u = 0; u < TQ; ++u) {
+                    const int i = i0 + 4 * u + q, ic = i < d.w ? i : 0;
+                    sl[u] = a.t_term[tp.y + ic];
+                    const double2* p = (const double2*)(a.jc + (size_t)(tp.x + ic) * 4);
+                    m0[u] = p[0]; m1[u] = p[1];
+                }
+#pragma unroll
+                for (int u = 0; u < TQ; ++u) {
+                    const bool ok = i0 + 4 * u + q < d.w;
+                    const double2 x = xs[sl[u]];
+                    y0 = ok ? y0 - (m0[u].x * x.x + m0[u].y * x.y) : y0;
+                    y1 = ok ? y1 - (m1[u].x * x.x + m1[u].y * x.y) : y1;
+                }
+            }
+            y0 += __shfl_xor(y0, 1); y1 += __shfl_xor(y1, 1);
+            y0 += __shfl_xor(y0, 2); y1 += __shfl_xor(y1, 2);
+            if (q == 0) xs[row] = bwd1_finish(a, dg, yk.x + y0, yk.y + y1, d.x, d.y, b, ld, up);
+        }
+        lds_barrier();
+    }
+}
+
+__global__ __launch_bounds__(SINGLE_BOTTOM_ROWS) void k_bwd1_bottom(Bwd1Args a) {
+    __shared__ __attribute__((aligned(16))) double2 xs[SINGLE_BOTTOM_ROWS];
+    int grp, w;
+    if (!map_block(a.sel, a.ld, a.n_wg, grp, w)) return;
+    const size_t b = (size_t)grp * 64, ld = (size_t)a.ld;
+    const int r0 = a.b_wg[2 * w], levels = a.b_wg[2 * w + 1], r1 = a.b_wg[2 * w + 2];
+    const int t = threadIdx.x;
+    const bool live = r0 + t < r1;
+    const int* rw = a.b_row + 6 * (size_t)(live ? r0 + t : r0);
+    const int k = rw[0], bus = rw[1], dgi = rw[2], nt = live ? rw[3] : 0, tp = rw[4], lev = live ? rw[5] : -1;
+    // everything that does not depend on the sweep, in flight together: the row's blocks, its right-hand side, the top's solution, the state
+    constexpr int TB = 8;
+    int2 tm[TB]; Blk m[TB]; double2 xt[TB];
+#pragma unroll
+    for (int u = 0; u < TB; ++u) tm[u] = *(const int2*)(a.b_term + 2 * (size_t)(tp + (u < nt ? u : 0)));
+    const Upd1 up = upd1_prefetch(a.upd, upd1_active(a.upd, b), bus, b, ld);
+    double2 y = load_vec(a.W, (size_t)k, b, ld);
+    const Blk dg = load_blk(a.X, (size_t)dgi, b, ld);
+#pragma unroll
+    for (int u = 0; u < TB; ++u) { m[u] = load_blk(a.X, (size_t)tm[u].x, b, ld); xt[u] = load_vec(a.W, (size_t)(tm[u].y >= 0 ? tm[u].y : 0), b, ld); }
+    for (int L = 0; L < levels; ++L) {
+        if (lev == L) {
+#pragma unroll
+            for (int u = 0; u < TB; ++u) {
+                const bool ok = u < nt;
+                const double2 x = tm[u].y >= 0 ? xt[u] : xs[ok ? -(tm[u].y + 1) : 0];
+                y.x = ok ? y.x - (m[u].v00 * x.x + m[u].v01 * x.y) : y.x;
+                y.y = ok ? y.y - (m[u].v10 * x.x + m[u].v11 * x.y) : y.y;
+            }
+            for (int u = TB; u < nt; ++u) {                       // rows of more than TB columns (rare below the top): one at a time
+                const int2 tr = *(const int2*)(a.b_term + 2 * (size_t)(tp + u));
+                const Blk mm = load_blk(a.X, (size_t)tr.x, b, ld);
+                const double2 x = tr.y >= 0 ? load_vec(a.W, (size_t)tr.y, b, ld) : xs[-(tr.y + 1)];
+                y.x -= mm.v00 * x.x + mm.v01 * x.y;
+                y.y -= mm.v10 * x.x + mm.v11 * x.y;
+            }
+            xs[t] = bwd1_finish(a, dg, y.x, y.y, k, bus, b, ld, up);
+        }
+        if (L + 1 < levels) lds_barrier();
+    }
+}
+
 // ---- selected inverse (Takahashi recursion on the factor pattern, symmetric matrices; tables: jg_symbolic.cpp) ----------
 struct SelArgs {
     const Rec* rec; const Segment* seg;
@@ -609,6 +743,7 @@ struct TopArgs {
     long long* prof;               // JG_TOP_PROFILE: [task][8] wall-clock stamps of scenario 0 (start, loaded, children, steps, stored), else null
     int ld, lanes, task_begin, ntasks, lpg;   // lpg: scenarios per 64-lane group that get a workgroup (64, or the real count of a single small group)
     const int* wgmap; int wg_begin, nwg;      // grouped launches (k_fact_grp): workgroup x of a group -> task << 8 | scenario block
+    double* jc; int jc_first;                 // ONE scenario (Engine::single_bwd): Jordan rows leave COMPACT -- block j at jc + 4 (j - jc_first), 32 contiguous bytes -- for k_bwd1_top
 };
 
 // Where scenario b keeps 16-byte unit q of a task's update block: the block is interleaved over the 2^lg scenarios that share a workgroup
@@ -1391,7 +1526,12 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
                 const int i = r * G + gi, j = c * G + gj;
                 const int cd = code[r][c];
                 const Blk& v = T[r][c];
-                if (JORDAN && i < m && j >= m && j < f) store_blk(a.X, (size_t)(jb + i * e + (j - m)), b, ld, v.v00, v.v01, v.v10, v.v11);
+                if (JORDAN && i < m && j >= m && j < f) {
+                    if (a.jc) {                                   // a single instance: the row's blocks side by side (the batch-minor storage puts the two halves of a block 1 KiB apart)
+                        double2* p = (double2*)(a.jc + (size_t)(jb - a.jc_first + i * e + (j - m)) * 4);
+                        p[0] = double2{v.v00, v.v01}; p[1] = double2{v.v10, v.v11};
+                    } else store_blk(a.X, (size_t)(jb + i * e + (j - m)), b, ld, v.v00, v.v01, v.v10, v.v11);
+                }
                 else if (cd <= -2) store_vec(a.W, (size_t)(-(cd + 2)), b, ld, v.v00, v.v10);
                 else if (cd >= 0 && (!((cd >> 28) & 4) || (!PW && i == j && i < m))) store_blk(a.X, (size_t)(cd & 0x0fffffff), b, ld, v.v00, v.v01, v.v10, v.v11);
                 else if (i >= m && i < f && j >= m && j < fprime) {                              // update matrix | vector: scenario-major stack
@@ -1630,6 +1770,7 @@ SharedPlan::~SharedPlan() {
     hipFree(fact_seg); hipFree(bwd_seg); hipFree(pre_seg); hipFree(fwd_seg); hipFree(sel_seg);
     hipFree(pre_row); hipFree(bwd_chain); hipFree(top_data); hipFree(top_wgmap);
     hipFree(bwdj_rec); hipFree(bwdj_seg);
+    hipFree(s1_t_row); hipFree(s1_t_ptr); hipFree(s1_t_term); hipFree(s1_t_level); hipFree(s1_b_wg); hipFree(s1_b_row); hipFree(s1_b_term);
 }
 
 namespace {
@@ -1782,6 +1923,29 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, long long 
     level_launches(plan->S.bwdj_seg, bwdj);
     level_launches(plan->S.fwd_seg, fwd);
     jordan = plan->S.jordan && knob("JORDAN", 1) != 0;
+    // ONE scenario on a Jordan plan: the tables of the row-per-lane sweep (built and uploaded by the first such engine of the plan; JG_SINGLE=0: the level launches)
+    if (ld == 64 && lanes == 1 && jordan && knob("SINGLE", 1) != 0) {
+        std::lock_guard<std::mutex> lock(plan->single_mutex);
+        if (!plan->single_tried) {
+            plan->single_tried = true;
+            SingleTables& T = plan->single;
+            build_single_tables(plan->S, T);
+            if (T.ok && ((size_t)T.n_top * 40 > 144 * 1024 || T.n_top_levels > 62)) T.ok = false;      // the top's solution (and its level table) must fit the LDS of one workgroup
+            if (T.ok) {
+                if (upload(&plan->s1_t_row, T.t_row, error, st) || upload(&plan->s1_t_ptr, T.t_ptr, error, st) || upload(&plan->s1_t_term, T.t_term, error, st) ||
+                    upload(&plan->s1_t_level, T.t_level, error, st) || upload(&plan->s1_b_wg, T.b_wg, error, st) || upload(&plan->s1_b_row, T.b_row, error, st) ||
+                    upload(&plan->s1_b_term, T.b_term, error, st)) return 2;
+                for (std::vector<int>* v : {&T.t_row, &T.t_ptr, &T.t_term, &T.t_level, &T.b_wg, &T.b_row, &T.b_term}) std::vector<int>().swap(*v);
+            }
+        }
+        single_bwd = plan->single.ok;
+        if (single_bwd) {
+            JG_HIP(hipFuncSetAttribute((const void*)k_bwd1_top, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+            const size_t jb = (size_t)std::max(plan->S.n_jordan, 1) * 4 * sizeof(double);
+            JG_HIP(hipMalloc((void**)&jc, jb));
+            JG_HIP(sync_fill(jc, 0, jb, st));
+        }
+    }
     // the device tables belong to the plan; the engine keeps plain aliases for its launches
     fact_rec = plan->fact_rec; bwd_rec = plan->bwd_rec; pre_rec = plan->pre_rec; fwd_rec = plan->fwd_rec;
     fact_seg = plan->fact_seg; bwd_seg = plan->bwd_seg; pre_seg = plan->pre_seg; fwd_seg = plan->fwd_seg;
@@ -1841,6 +2005,7 @@ void Engine::destroy() {
     fact_rec = bwd_rec = nullptr; fact_seg = bwd_seg = nullptr; pre_rec = nullptr; pre_seg = nullptr; pre_row = nullptr;
     hipFree(Zs); Zs = nullptr;
     hipFree(top_stack); top_stack = nullptr;
+    hipFree(jc); jc = nullptr; single_bwd = false;
     hipFree(X); hipFree(W); hipFree(status);
     status = nullptr;
     X = W = nullptr;
@@ -1872,7 +2037,7 @@ int Engine::factor(hipStream_t st, const double* A, const double* rhs, const Gro
     if (!plan->S.top_launch.empty() && probe_part != 1) {
         const long long s0 = std::max<long long>(plan->S.top_stack_cls[0], 2);
         TopArgs t{top_task, top_data, X, W, top_stack, status, sel, s0, {0, s0 * ld, (s0 + plan->S.top_stack_cls[1]) * ld}, {s0, plan->S.top_stack_cls[1], plan->S.top_stack_cls[2]},
-                  top_prof, ld, a.lanes, 0, 0, 64, top_wgmap, 0, 0};
+                  top_prof, ld, a.lanes, 0, 0, 64, top_wgmap, 0, 0, single_bwd && jordan ? jc : nullptr, plan->S.n_entries};
         if (ld == 64 && t.lanes < 64) t.lpg = t.lanes;
         for (const TopLaunch& L : plan->S.top_launch) {
             t.task_begin = L.task_begin; t.ntasks = L.ntasks;
@@ -1993,6 +2158,14 @@ int Engine::set_shared_matrix(hipStream_t st, const double* blocks_host) {
 }
 
 int Engine::backsolve(hipStream_t st, double* out, const StateUpdate& upd, const GroupSel& sel) {
+    if (single_bwd && jordan) {                                  // ONE scenario: rows per lane, two launches (k_bwd1_top, k_bwd1_bottom)
+        const SingleTables& T = plan->single;
+        Bwd1Args s{plan->s1_t_row, plan->s1_t_ptr, plan->s1_t_term, plan->s1_t_level, plan->s1_b_wg, plan->s1_b_row, plan->s1_b_term, X, jc, W, out, sel, upd, ld, T.n_top_levels, T.n_wg, T.n_top};
+        hipLaunchKernelGGL(k_bwd1_top, dim3(grid_blocks(ld / 64, 1)), dim3(1024), (size_t)T.n_top * 40, st, s);
+        if (T.n_wg > 0) hipLaunchKernelGGL(k_bwd1_bottom, dim3(grid_blocks(ld / 64, T.n_wg)), dim3(SINGLE_BOTTOM_ROWS), 0, st, s);
+        JG_HIP(hipGetLastError());
+        return 0;
+    }
     // jordan: the last factor() left Jordan rows (the flag must not change between a factorisation and its solves)
     BwdArgs a{jordan ? plan->bwdj_rec : bwd_rec, jordan ? plan->bwdj_seg : bwd_seg, bwd_chain, X, W, out, sel, upd, ld, 0, lanes > 0 ? lanes : ld, 0, 0, 1, 1};
     const std::vector<Segment>& segs = jordan ? plan->S.bwdj_seg : plan->S.bwd_seg;

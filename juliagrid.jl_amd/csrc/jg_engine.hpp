@@ -214,6 +214,12 @@ struct SharedPlan {
     Rec* bwdj_rec = nullptr; Segment* bwdj_seg = nullptr;    // Jordan plans: the backward sweep over Jordan rows (jg_symbolic.hpp)
     std::mutex sel_mutex;                           // the selected-inverse tables are built on first use
     bool sel_ready = false;
+    // single-instance sweep (jg_symbolic.hpp: SingleTables), built by the first engine of ONE scenario that takes this plan
+    std::mutex single_mutex;
+    bool single_tried = false;
+    SingleTables single;                            // host copy (counts; the index vectors are released after the upload)
+    int* s1_t_row = nullptr; int* s1_t_ptr = nullptr; int* s1_t_term = nullptr; int* s1_t_level = nullptr;
+    int* s1_b_wg = nullptr; int* s1_b_row = nullptr; int* s1_b_term = nullptr;
     ~SharedPlan();
 };
 // (n, pattern, policy, current device) -> plan; analysis + upload on a miss.  st: stream for the uploads.  nullptr + error on failure.
@@ -241,6 +247,8 @@ struct Engine {
     // Read by factor() and backsolve() at launch time: change it only between a backsolve and the next factorisation.
     bool jordan = false;
     int probe_part = 0;            // TIMING PROBE (JG_PROBE_FACT_PART at create: 1 = factor() launches the bottom levels only, 2 = the top only; wrong numbers) -- tools/r05_overlap_probe.py
+    double* jc = nullptr;          // single_bwd: the Jordan rows of the top tasks, compact ([n_jordan][4] doubles: k_fact_top writes, k_bwd1_top reads)
+    bool single_bwd = false;       // ONE scenario on a Jordan plan: backsolve() runs the row-per-lane sweep (k_bwd1_top / k_bwd1_bottom, jg_symbolic.hpp: SingleTables)
     bool shared = false;           // hint (jg_nr_set_shared): other batches are in flight on this GPU -- the top launches take the 4-wave variant (same bits)
     Rec* top_task = nullptr; int* top_data = nullptr;          // multifrontal top (jg_symbolic.hpp): task headers, task data
     int* top_wgmap = nullptr;                                  // workgroup map of the grouped launches

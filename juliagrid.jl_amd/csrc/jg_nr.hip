@@ -468,6 +468,9 @@ struct CompactArgs {
     int* dest; int* group; int* glist; int* flags; int* tmp; int ld; int restore;
     int* host_count;           // nullable: pinned host word that receives the number of active scenarios (what the host loop polls:
                                // a store from this kernel instead of a memset node and a 4-byte copy node per iteration, ~20 us each)
+    int* host_res;             // nullable (handles of ONE lane group): pinned host words [128] that receive iterations | status of the 64 lanes when the last scenario
+                               // has finished -- jg_nr_run then returns them without two blocking 4-byte-per-lane copies (~25 us each: a tenth of a single instance's solve
+                               // went into run_setup's and run_finish's small transfers, round 6)
     const double* params;      // [2] = defer_at of the run (jg_nr_run_defer; 0: none).  Once at most that many scenarios are active the host stops the batch and
                                // hands them to a pool (jg_nr_move_lanes): packing them into the first lane group -- and sending every lane home again when the
                                // batch finishes -- moved every row of the handle twice for lanes that leave anyway (round 6: k_lanes_permute was 5.8 % of the GPU
@@ -489,6 +492,21 @@ __device__ __forceinline__ int block_scan_1024(int v, int* wsum, int t, int& tot
     for (int k = 0; k < 16; ++k) { const int q = wsum[k]; off += k < w ? q : 0; total += q; }
     __syncthreads();
     return x + off;
+}
+
+// run_setup on the device: parameters of the run, every real scenario active with zero iterations, lanes in home order, all lane groups in use
+__global__ void k_run_setup(double* params, double tol, double max_iter, double defer_at, int* iters, int* lu_status, int* active, int* lid, int* cflags, int* group, int* glist,
+                            int ld, int lanes, int keep_iters) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < ld) {
+        if (!keep_iters) { iters[b] = 0; lu_status[b] = 0; active[b] = b < lanes ? 1 : 0; }
+        lid[b] = b;
+    }
+    if (b < ld / 64) { group[b] = 1; glist[b] = b; }
+    if (b == 0) {
+        params[0] = tol; params[1] = max_iter; params[2] = defer_at;
+        cflags[0] = 0; cflags[1] = lanes; cflags[2] = ld / 64; cflags[3] = ld / 64; cflags[4] = 0; cflags[5] = 0; cflags[6] = 0; cflags[7] = 0;
+    }
 }
 
 __global__ __launch_bounds__(1024) void k_compact(CompactArgs a) {
@@ -514,6 +532,7 @@ __global__ __launch_bounds__(1024) void k_compact(CompactArgs a) {
         moved = any > 0;
     }
     const bool permute = a.restore ? moved : (!hold && n_active > 0 && groups_new < groups_cur);
+    if (a.host_res && n_active == 0 && t < 64) { a.host_res[t] = a.iters[t]; a.host_res[64 + t] = a.status[t]; __threadfence_system(); }   // ... ahead of the word the host polls
     __syncthreads();
     if (t == 0) { a.flags[0] = permute ? 1 : 0; a.flags[1] = n_active; a.flags[4] = hold ? 1 : 0; if (permute) a.flags[2] = a.restore ? ngroups : groups_new; if (a.host_count) *a.host_count = n_active; }
     if (a.restore && !permute) {
@@ -814,7 +833,8 @@ struct jg_nr {
     int* h_move = nullptr;
     double host_launch_us = 0.0, host_wait_us = 0.0; long long host_iters = 0;   // JG_HOST_TIMING=1: what the host spent in hipGraphLaunch / waiting per iteration of run_loop
     double wait_us = 0.0;            // how long the host waited for the last verdicts (running mean; wait_verdict: polls the pinned word while this is short)
-    int* h_counter = nullptr;        // pinned
+    bool res_pinned = false;         // this run's verdicts write iterations | status behind the pinned verdict word (one lane group; run_finish)
+    int* h_counter = nullptr;        // pinned (129 ints: the verdict word, then iterations [64] | status [64] of a handle of one lane group)
     int* h_counter_dev = nullptr;    // its device alias
     // ---- first iteration on a shared factor (jg_comp.hpp; jg_nr_attach_base) ----
     std::vector<int> csr_row, csr_col;                // Ybus row-CSR position -> (row, column)
@@ -946,7 +966,7 @@ int put_bus_array(jg_nr* h, double* dst, const double* src, int64_t stride) {
 // pack the active scenarios into the leading lanes (restore = 1: send every lane back home)
 void launch_compact(jg_nr* h, int restore, bool report = false) {
     CompactArgs c{h->d_active, h->d_iters, h->d_status, h->eng.status, h->d_lid, h->d_ppos, h->mp, h->d_dest, h->d_group,
-                  h->d_glist, h->d_cflags, h->d_itmp, h->ld, restore, report ? h->h_counter_dev : nullptr, h->d_params};
+                  h->d_glist, h->d_cflags, h->d_itmp, h->ld, restore, report ? h->h_counter_dev : nullptr, report && h->ld == 64 ? h->h_counter_dev + 1 : nullptr, h->d_params};
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, c);
     if (h->ld == 64) return;                       // one lane group: nothing to pack, lanes never leave their home order
     double* tmp = h->eng.X;                        // the factor is dead here (rebuilt by the next factorisation)
@@ -1326,7 +1346,7 @@ int jg_nr_create(jg_nr** out, int64_t n, const int64_t* colptr, const int64_t* r
     }
     if (!ok) { if (eng_thread.joinable()) eng_thread.join(); jg_nr_destroy(h); return fail(2, "jg_nr_create: device allocation failed"); }
     if (jg::sync_fill(h->d_ppos, 0xff, mpn * ld * 4, h->stream) != hipSuccess ||     // -1 = no patch
-        hipHostMalloc((void**)&h->h_counter, sizeof(int)) != hipSuccess) {
+        hipHostMalloc((void**)&h->h_counter, 129 * sizeof(int)) != hipSuccess) {       // the verdict word + iterations | status of one lane group (k_compact: host_res)
         if (eng_thread.joinable()) eng_thread.join(); jg_nr_destroy(h); return fail(2, "jg_nr_create: pinned allocation failed");
     }
     if (hipHostGetDevicePointer((void**)&h->h_counter_dev, h->h_counter, 0) != hipSuccess) { if (eng_thread.joinable()) eng_thread.join(); jg_nr_destroy(h); return fail(2, "jg_nr_create: pinned host word is not device-visible"); }
@@ -1671,25 +1691,14 @@ namespace {
 
 // Start of a batched solve: every real scenario active, lanes in home order, all groups in use.  keep_iters: the lanes carry
 // their iteration counts (a pool of moved scenarios, jg_nr_resume).
+// ONE launch (round 6): until then three values, two fills and five small arrays went to the device through eight stream operations and a synchronise --
+// ~90 us on the host's side of every solve, 7 % of a single instance's.
 int run_setup(jg_nr* h, int64_t max_iter, double tol, int lanes, bool keep_iters, int defer_at = 0) {
     if (int rc = build_graphs(h)) return rc;
-    const double params[3] = {tol, (double)max_iter, (double)defer_at};   // defer_at: see CompactArgs
-    NR_HIP(hipMemcpyAsync(h->d_params, params, sizeof(params), hipMemcpyHostToDevice, h->stream));
-    if (!keep_iters) {
-        NR_HIP(hipMemsetAsync(h->d_iters, 0, (size_t)h->ld * 4, h->stream));      // acPowerFlow.jl:1401
-        NR_HIP(hipMemsetAsync(h->eng.status, 0, (size_t)h->ld * 4, h->stream));
-    }
-    std::vector<int> act(h->ld, 0), lid(h->ld);
-    for (int b = 0; b < h->ld; ++b) { act[b] = b < lanes; lid[b] = b; }
-    const int cf[8] = {0, lanes, h->ld / 64, h->ld / 64, 0, 0, 0, 0};
-    if (!keep_iters) NR_HIP(hipMemcpyAsync(h->d_active, act.data(), (size_t)h->ld * 4, hipMemcpyHostToDevice, h->stream));
-    NR_HIP(hipMemcpyAsync(h->d_lid, lid.data(), (size_t)h->ld * 4, hipMemcpyHostToDevice, h->stream));
-    NR_HIP(hipMemcpyAsync(h->d_cflags, cf, sizeof(cf), hipMemcpyHostToDevice, h->stream));
-    std::vector<int> grp(h->ld / 64, 1), gl(h->ld / 64);
-    for (size_t g = 0; g < gl.size(); ++g) gl[g] = (int)g;
-    NR_HIP(hipMemcpyAsync(h->d_group, grp.data(), grp.size() * 4, hipMemcpyHostToDevice, h->stream));
-    NR_HIP(hipMemcpyAsync(h->d_glist, gl.data(), gl.size() * 4, hipMemcpyHostToDevice, h->stream));
-    NR_HIP(hipStreamSynchronize(h->stream));
+    hipLaunchKernelGGL(k_run_setup, dim3((unsigned)((h->ld + 255) / 256)), dim3(256), 0, h->stream, h->d_params, tol, (double)max_iter, (double)defer_at,   // defer_at: see CompactArgs
+                       h->d_iters /* acPowerFlow.jl:1401 */, h->eng.status, h->d_active, h->d_lid, h->d_cflags, h->d_group, h->d_glist, h->ld, lanes, keep_iters ? 1 : 0);
+    NR_HIP(hipGetLastError());
+    h->res_pinned = h->ld == 64;
     return 0;
 }
 
@@ -1793,6 +1802,15 @@ int run_start(jg_nr* h, int64_t max_iter) {
 
 // End of a batched solve: lanes back to their home order, method.mismatch of every scenario at its final state, outputs.
 int run_finish(jg_nr* h, int32_t* iters, int32_t* status) {
+    if (h->ld == 64 && *h->h_counter == 0 && h->res_pinned) {                  // one lane group, every scenario finished: the last verdict (k_compact) has left iterations
+        h->f_stale = false;                                                    // and status in pinned host memory, the lanes never left their home order, and what
+        h->jac_valid = false;                                                  // k_compact's restore pass resets is rewritten by the next run_setup: no launch, no
+        h->paused = false;                                                     // blocking copies (the stream orders whatever follows behind the last graph)
+        h->res_pinned = false;
+        if (iters) std::memcpy(iters, h->h_counter + 1, (size_t)h->batch * 4);
+        if (status) std::memcpy(status, h->h_counter + 65, (size_t)h->batch * 4);
+        return 0;
+    }
     launch_compact(h, 1);                                                      // lanes back to their home order
     h->f_stale = h->ld > 64;                                                   // method.mismatch of every scenario at its final state: groups that dropped
                                                                                // out early hold other scenarios' rows after a compaction -- one mismatch-only

@@ -20,7 +20,7 @@ namespace jg {
 
 int knob(const char* name, int unset) {
     static const char* const known[] = {"TRACE", "PLAN_CACHE", "POLL", "PLAN_THREADS", "PLAN_TIMING", "HOST_TIMING",
-                                        "TOP_PW", "TOP_FUSE", "TOP_SYM", "JORDAN", "CHAIN_SMALL", "NO_PREFACTOR", "LANES_INPLACE", "TOP_LEVEL", "ROW_TASKS", "ORDER_CHECK", "TOP_PROFILE"};
+                                        "TOP_PW", "TOP_FUSE", "TOP_SYM", "JORDAN", "CHAIN_SMALL", "NO_PREFACTOR", "LANES_INPLACE", "TOP_LEVEL", "ROW_TASKS", "ORDER_CHECK", "TOP_PROFILE", "SINGLE"};
     bool ok = false;
     for (const char* k : known) ok = ok || std::strcmp(k, name) == 0;
     if (!ok) return unset;
@@ -1125,6 +1125,96 @@ void build_comp_tables(const BlockSymbolic& S, int top_cap, CompTables& out) {
             }
         }, NoExtra(), 0, 8);
     }
+}
+
+// Tables of the single-instance backward sweep (jg_symbolic.hpp: SingleTables).
+void build_single_tables(const BlockSymbolic& S, SingleTables& T) {
+    T = SingleTables();
+    const int n = S.n;
+    if (!S.jordan || S.top_task.empty() || S.symmetric) return;
+    std::vector<int> jrow(n, -1), jroot(n, -1), tlev(n, 0);
+    int max_tl = 0;
+    for (const Rec& h : S.top_task) max_tl = std::max(max_tl, h.w[10]);
+    for (const Rec& h : S.top_task) {
+        const int* piv = S.top_data.data() + h.w[3] + h.w[6];
+        for (int q = 0; q < h.w[0]; ++q) { jrow[piv[q]] = h.w[14] >= 0 ? h.w[14] + q * h.w[1] : 0; jroot[piv[q]] = h.w[2]; tlev[piv[q]] = max_tl - h.w[10]; }
+    }
+    // ---- top rows by level (root task = level 0); a row's columns are the pivots of ancestor tasks, i.e. of earlier levels
+    std::vector<int> rows;
+    for (int k = 0; k < n; ++k) if (jroot[k] >= 0) rows.push_back(k);
+    std::stable_sort(rows.begin(), rows.end(), [&](int a, int b) { return tlev[a] < tlev[b]; });
+    T.n_top = (int)rows.size();
+    T.n_top_levels = max_tl;
+    std::vector<int> slot(n, -1);
+    for (int i = 0; i < T.n_top; ++i) slot[rows[i]] = i;
+    T.t_level.assign(max_tl + 1, 0);
+    for (int k : rows) T.t_level[tlev[k] + 1]++;
+    for (int l = 0; l < max_tl; ++l) T.t_level[l + 1] += T.t_level[l];
+    std::vector<int> slist(n, -1);                               // root pivot of a task -> first slot of the task's column list (one list per task: its rows share ext(task))
+    for (int k : rows) {
+        const int root = jroot[k], e = S.u_ptr[root + 1] - S.u_ptr[root];
+        if (slist[root] < 0) {
+            slist[root] = (int)T.t_term.size();
+            for (int t = 0; t < e; ++t) {
+                const int c = S.u_col[S.u_ptr[root] + t];
+                if (slot[c] < 0 || tlev[c] >= tlev[k]) return;  // (cannot happen: ext(task) lies in ancestor tasks)
+                T.t_term.push_back(slot[c]);
+            }
+        }
+        T.t_row.push_back(k); T.t_row.push_back(S.perm[k]); T.t_row.push_back(S.diag[k]); T.t_row.push_back(e);
+        T.t_ptr.push_back(e > 0 ? jrow[k] - S.n_entries : 0); T.t_ptr.push_back(slist[root]);
+    }
+    if (T.t_term.empty()) T.t_term.push_back(0);
+    // ---- bottom rows: whole subtrees per workgroup
+    auto is_top = [&](int k) { return jroot[k] >= 0; };
+    auto parent = [&](int k) { return S.u_ptr[k + 1] > S.u_ptr[k] ? S.u_col[S.u_ptr[k]] : -1; };
+    std::vector<int> sub(n, 1);
+    for (int k = 0; k < n; ++k) if (parent(k) >= 0) sub[parent(k)] += sub[k];
+    std::vector<int> blev(n, 0);
+    for (int k = n - 1; k >= 0; --k) {
+        if (is_top(k)) continue;
+        for (int p = S.u_ptr[k]; p < S.u_ptr[k + 1]; ++p) { const int c = S.u_col[p]; if (!is_top(c)) blev[k] = std::max(blev[k], blev[c] + 1); }
+    }
+    // subtree roots in ascending order; a subtree = pivots root - sub[root] + 1 .. root, all below the top
+    std::vector<std::pair<int, int>> trees;                      // (first pivot, rows)
+    for (int k = 0; k < n; ++k) {
+        if (is_top(k)) continue;
+        const int p = parent(k);
+        if (p >= 0 && !is_top(p)) continue;
+        for (int q = k - sub[k] + 1; q <= k; ++q) if (is_top(q)) return;   // (a top pivot below a bottom one: the level rule forbids it)
+        if (sub[k] > SINGLE_BOTTOM_ROWS) return;                  // a subtree one workgroup cannot hold: the level launches stay
+        trees.push_back({k - sub[k] + 1, sub[k]});
+    }
+    std::vector<int> wg_of(n, -1), thr_of(n, -1);
+    T.b_wg.clear();
+    int cur_rows = SINGLE_BOTTOM_ROWS + 1;
+    std::vector<std::vector<int>> wg_rows;
+    for (const auto& tr : trees) {
+        if (cur_rows + tr.second > SINGLE_BOTTOM_ROWS) { wg_rows.emplace_back(); cur_rows = 0; }
+        for (int q = tr.first; q < tr.first + tr.second; ++q) { wg_of[q] = (int)wg_rows.size() - 1; thr_of[q] = cur_rows++; wg_rows.back().push_back(q); }
+    }
+    T.n_wg = (int)wg_rows.size();
+    for (int w = 0; w < T.n_wg; ++w) {
+        int levels = 0;
+        T.b_wg.push_back((int)T.b_row.size() / 6);
+        for (int k : wg_rows[w]) {
+            levels = std::max(levels, blev[k] + 1);
+            const int nt = S.u_ptr[k + 1] - S.u_ptr[k];
+            T.b_row.push_back(k); T.b_row.push_back(S.perm[k]); T.b_row.push_back(S.diag[k]); T.b_row.push_back(nt);
+            T.b_row.push_back((int)T.b_term.size() / 2); T.b_row.push_back(blev[k]);
+            for (int p = S.u_ptr[k]; p < S.u_ptr[k + 1]; ++p) {
+                const int c = S.u_col[p];
+                if (!is_top(c) && wg_of[c] != w) return;           // (cannot happen: the columns of a row are its ancestors)
+                T.b_term.push_back(S.u_ent[p]); T.b_term.push_back(is_top(c) ? c : -(1 + thr_of[c]));
+            }
+        }
+        T.b_wg.push_back(levels);
+        T.b_levels = std::max(T.b_levels, levels);
+    }
+    T.b_wg.push_back((int)T.b_row.size() / 6); T.b_wg.push_back(0);
+    T.n_bottom = (int)T.b_row.size() / 6;
+    if (T.n_top + T.n_bottom != n) return;
+    T.ok = true;
 }
 
 int analyze(int n, const int* rowptr, const int* col, long long policy64, BlockSymbolic& S) {

@@ -227,6 +227,31 @@ struct CompTables {
 // top_cap: at most this many pivots in the dense top (the split is the lowest forward level that satisfies it); < 0: none.
 void build_comp_tables(const BlockSymbolic& S, int top_cap, CompTables& out);
 
+// ---- backward sweep of a SINGLE instance (round 6, jg_engine.hip: k_bwd1_top / k_bwd1_bottom) -------------------------------------------
+// One scenario leaves 63 of a wave's 64 lanes idle in the level kernels, and its sweep is 15 dependent launches of ~4.7 us whatever they hold
+// (a Jordan plan of the 10k-bus grid: 8 task levels + 5 levels below the top).  Here the lanes are ROWS:
+//   top rows (pivots of the top tasks, Jordan rows over ext(task)): ONE workgroup walks their levels (root task first) with a workgroup barrier
+//     between levels; four lanes share a row, the solution of the top lives in LDS (slot = position of the row in t_row);
+//   bottom rows: a workgroup takes a run of whole bottom SUBTREES (a bottom pivot whose parent is a top pivot, with its descendants: contiguous
+//     in the postorder), one thread per row -- every operand that does not depend on the sweep (blocks, right-hand side, the top's solution,
+//     state-update operands) is requested before the first barrier, then the rows of a level finish between two barriers, at most
+//     TOP_LEVEL_MIN of them.
+// Rows (ints): t_row [.][4] = pivot, bus (original index), diagonal entry, terms; t_ptr [.][2] = first block of the row in the COMPACT Jordan rows (what k_fact_top
+//              leaves for a single instance: block j of the plan at 4 (j - n_entries) doubles, the e blocks of a row side by side), first slot of its column list;
+//              t_term = slots of the columns, one list per task (its rows share ext(task)).
+//              b_row [.][6] = pivot, bus, diagonal entry, terms, first term, level inside its subtree (0: top columns only);
+//              b_term [.][2] = entry, column: >= 0 a top pivot (row of W), < 0: -(1 + thread of the column's row in this workgroup).
+constexpr int SINGLE_BOTTOM_ROWS = 128;   // rows (threads) of a bottom workgroup
+struct SingleTables {
+    bool ok = false;                    // false: the plan does not qualify (no Jordan rows, a subtree above SINGLE_BOTTOM_ROWS rows, ...)
+    int n_top = 0, n_top_levels = 0;
+    std::vector<int> t_row, t_ptr, t_term, t_level;     // t_level [n_top_levels + 1]
+    int n_bottom = 0, n_wg = 0, b_levels = 0;
+    std::vector<int> b_wg;                              // [n_wg + 1][2]: first row, levels of the workgroup
+    std::vector<int> b_row, b_term;
+};
+void build_single_tables(const BlockSymbolic& S, SingleTables& out);
+
 // pattern: CSR (rowptr[n+1], col[nnz]) 0-based, must contain the diagonal and be structurally
 // symmetric. policy bit 0: in-place factor storage (see BlockSymbolic::inplace); bit 1: symmetric VALUES (LDL' by
 // reading U(k,i)' for Lh(i,k): half the update terms; only the blocks on and above the diagonal must be assembled).
