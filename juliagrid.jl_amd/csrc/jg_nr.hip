@@ -72,9 +72,12 @@ __device__ __forceinline__ void store_vec_nt(double* base, size_t item, size_t b
 // Fused mismatch + Jacobian assembly. blockDim (64, ASM_WAVES); 1-D grid, scenario group fastest (jg::map_block:
 // a group's V/theta gathers stay in one XCD's L2).
 // JAC = false: mismatch only (no Jacobian stores) -- the cheap pre-pass that decides which scenarios are still active.
-template <int MP, bool JAC>
-__global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(AsmArgs a) {
-    __shared__ double red[2][ASM_WAVES][64];
+// WAVES: waves of a workgroup (which always takes ASM_ROWS bus rows).  4: a wave walks four rows one after the other -- the throughput form; 16 (round 6, a handful of
+// scenarios): one row per wave -- a row is three dependent round trips (row header, Ybus entries, V / theta gathers), and with nothing else on the chip to hide them
+// four rows in sequence made the pass of a single instance 23 us long.
+template <int MP, bool JAC, int WAVES = ASM_WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_assemble(AsmArgs a) {
+    __shared__ double red[2][WAVES][64];
     int grp, bx;
     if (a.only_if && !uniform(*a.only_if)) return;
     if (!jg::map_block(a.sel, a.ld, a.nchunk, grp, bx)) return;   // every scenario of a skipped 64-lane group is finished
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(AsmArgs a) {
     double maxp = 0.0, maxq = 0.0;
     const int r0 = bx * ASM_ROWS;
     const int r1 = min(r0 + ASM_ROWS, a.n);
-    for (int i = r0 + wave; i < r1; i += ASM_WAVES) {
+    for (int i = r0 + wave; i < r1; i += WAVES) {
         const int p0 = uniform(a.rowptr[i]), p1 = uniform(a.rowptr[i + 1]);
         const int tfull = (int)((unsigned)uniform(a.rowtype[i]));   // bus type | (pivot + 1) << 2 where this pass also finishes the plan's level 0
         const int ti = tfull & 3, pre = tfull >> 2;
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(AsmArgs a) {
     __syncthreads();
     if (wave == 0) {
 #pragma unroll
-        for (int w = 1; w < ASM_WAVES; ++w) {
+        for (int w = 1; w < WAVES; ++w) {
             const double x = red[0][w][lane], y = red[1][w][lane];
             maxp = (x > maxp || x != x) ? x : maxp;
             maxq = (y > maxq || y != y) ? y : maxq;
@@ -898,6 +901,26 @@ void launch_assemble(jg_nr* h, const jg::GroupSel& sel = jg::GroupSel{}, bool ja
               h->eng.W, h->eng.status};
     if (jac && !only_if) h->level0_done = pre;
     dim3 grid(jg::grid_blocks(h->ld / 64, h->nchunk)), block(64, ASM_WAVES);
+    if (h->ld == 64 && h->batch <= 32 && !fd_mode && !pq_out) {      // a handful of scenarios: one row per wave (k_assemble: WAVES = 16); same arithmetic per row, same chunk maxima
+        const bool w16 = h->nchunk <= 512;                          // grids whose workgroups are all resident at once: one row per wave; larger ones: two
+        const dim3 wide(64, w16 ? 16 : 8);
+#define JG_ASM_WIDE(MPV, JACV) do { if (w16) hipLaunchKernelGGL((k_assemble<MPV, JACV, 16>), grid, wide, 0, h->stream, a); else hipLaunchKernelGGL((k_assemble<MPV, JACV, 8>), grid, wide, 0, h->stream, a); } while (0)
+        if (jac) {
+            switch (h->mp) {
+                case 0: JG_ASM_WIDE(0, true); break;
+                case 4: JG_ASM_WIDE(4, true); break;
+                default: JG_ASM_WIDE(8, true); break;
+            }
+        } else {
+            switch (h->mp) {
+                case 0: JG_ASM_WIDE(0, false); break;
+                case 4: JG_ASM_WIDE(4, false); break;
+                default: JG_ASM_WIDE(8, false); break;
+            }
+        }
+#undef JG_ASM_WIDE
+        return;
+    }
     if (jac) {
         switch (h->mp) {
             case 0: hipLaunchKernelGGL((k_assemble<0, true>), grid, block, 0, h->stream, a); break;
@@ -910,6 +933,75 @@ void launch_assemble(jg_nr* h, const jg::GroupSel& sel = jg::GroupSel{}, bool ja
             case 4: hipLaunchKernelGGL((k_assemble<4, false>), grid, block, 0, h->stream, a); break;
             default: hipLaunchKernelGGL((k_assemble<8, false>), grid, block, 0, h->stream, a); break;
         }
+    }
+}
+
+// The verdict of a handle of ONE lane group in one launch (round 6): k_check's norms and loop control, then what k_compact comes to when there is nothing to pack --
+// the count of active scenarios for the host, the group list of the next launches, iterations | status for jg_nr_run when the last scenario has finished.  Two
+// launches (12.5 + 4 us of a single instance's 330 us iteration: five trips of dependent loads over the 625 chunk norms, a launch boundary) become one of two trips.
+__global__ __launch_bounds__(1024) void k_verdict64(CheckArgs a, CompactArgs p) {
+    __shared__ double red[2][16][64];
+    const int lane = threadIdx.x, wave = threadIdx.y;
+    const int b = lane;
+    // every request of the launch leaves at once: the group flag (a finished group keeps its verdict: its assembly was skipped), what the loop control reads
+    // besides the norms, and the chunk maxima -- nothing is asked for behind a branch on something else that was asked for
+    const int grp_on = a.group ? a.group[0] : 1;
+    const double tol = a.params[0];
+    const int maxit = (int)a.params[1];
+    const int lus = a.lu_status[b], its = a.iters[b], act0 = a.active[b], st0 = a.status[b];
+    double mp = 0.0, mq = 0.0;
+    auto nmax = [](double x, double m) { return (x > m || x != x) ? x : m; };      // NaN-propagating: a NaN mismatch must not look converged
+    if (a.batch == 1) {
+        // ONE scenario: the threads are CHUNKS (scenario 0 of chunk t, t + 1024, ...): one round trip where 16 waves of 64 identical lanes took two to five
+        for (int c = wave * 64 + lane; c < a.nchunk; c += 1024) {
+            mp = nmax(a.part[((size_t)c * 2) * a.ld], mp);
+            mq = nmax(a.part[((size_t)c * 2 + 1) * a.ld], mq);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { mp = nmax(__shfl_xor(mp, d), mp); mq = nmax(__shfl_xor(mq, d), mq); }
+        if (lane < 16) { red[0][wave][0] = mp; red[1][wave][0] = mq; }            // (lanes 0 .. 15 write the same value)
+    } else {
+        constexpr int CU = 20;
+        for (int c0 = wave; c0 < a.nchunk; c0 += 16 * CU) {
+            double x[CU], y[CU];
+#pragma unroll
+            for (int u = 0; u < CU; ++u) {
+                const int c = min(c0 + 16 * u, a.nchunk - 1);     // a repeated chunk changes no maximum
+                x[u] = a.part[((size_t)c * 2) * a.ld + b]; y[u] = a.part[((size_t)c * 2 + 1) * a.ld + b];
+            }
+#pragma unroll
+            for (int u = 0; u < CU; ++u) { mp = nmax(x[u], mp); mq = nmax(y[u], mq); }
+        }
+        red[0][wave][lane] = mp;
+        red[1][wave][lane] = mq;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const bool skip = grp_on == 0;
+    int act = act0, it_out = its, st_out = st0;
+    if (!skip) {
+        const int src = a.batch == 1 ? 0 : lane;                  // one scenario: every lane takes its maxima (lanes beyond the batch alias the last scenario)
+        for (int w = a.batch == 1 ? 0 : 1; w < 16; ++w) { mp = nmax(red[0][w][src], mp); mq = nmax(red[1][w][src], mq); }
+        a.normp[b] = mp;
+        a.normq[b] = mq;
+        const bool real = b < a.batch;
+        const bool conv = mp < tol && mq < tol;                   // acPowerFlow.jl:1410 (strict)
+        const bool bad = (lus & 4) || mp != mp || mq != mq;
+        const bool go = real && !conv && !bad && its < maxit;     // acPowerFlow.jl:1414
+        act = go ? 1 : 0;
+        a.active[b] = act;
+        st_out = conv ? 0 : (bad ? 3 : 1);
+        a.status[b] = st_out;
+        if (go) { it_out = its + 1; a.iters[b] = it_out; atomicAdd(a.counter, 1); }     // solve! follows: iteration += 1 (:908)
+    }
+    const int n_active = __popcll(__ballot(act != 0));
+    if (p.host_res && n_active == 0) { p.host_res[lane] = it_out; p.host_res[64 + lane] = st_out; __threadfence_system(); }   // ... ahead of the word the host polls
+    if (lane == 0) {
+        p.flags[0] = 0; p.flags[1] = n_active; p.flags[4] = 0;
+        p.group[0] = n_active > 0 ? 1 : 0;
+        if (n_active > 0) p.glist[0] = 0;
+        p.flags[3] = n_active > 0 ? 1 : 0;
+        if (p.host_count) *p.host_count = n_active;
     }
 }
 
@@ -1043,10 +1135,20 @@ int build_graphs(jg_nr* h) {
     // one write stream per solve, against a second walk over Ybus per iteration), verdict per scenario, compaction of the
     // still-active lanes.  A compaction moves lanes (and stages them in the factor storage), so the assembly is repeated
     // on the packed lanes -- a launch that returns at once unless the compaction flag is set.
-    auto verdict = [&]() {
-        launch_assemble(h, active_groups(h), true, nullptr, 0, nullptr, true);
+    auto check_and_compact = [&]() {
+        if (h->ld == 64) {                             // one lane group: ONE launch (k_verdict64)
+            CheckArgs c{h->d_part, h->nchunk, h->ld, h->batch, h->d_params, h->d_normp, h->d_normq, h->d_active, h->d_iters, h->d_status, h->eng.status, h->d_counter, h->d_group, 1};
+            CompactArgs p{h->d_active, h->d_iters, h->d_status, h->eng.status, h->d_lid, h->d_ppos, h->mp, h->d_dest, h->d_group,
+                          h->d_glist, h->d_cflags, h->d_itmp, h->ld, 0, h->h_counter_dev, h->h_counter_dev + 1, h->d_params};
+            hipLaunchKernelGGL(k_verdict64, dim3(1), dim3(64, 16), 0, h->stream, c, p);
+            return;
+        }
         launch_check(h, 1, h->d_group);
         launch_compact(h, 0, true);                    // also reports the number of active scenarios to the host word
+    };
+    auto verdict = [&]() {
+        launch_assemble(h, active_groups(h), true, nullptr, 0, nullptr, true);
+        check_and_compact();
         if (h->ld > 64) launch_assemble(h, active_groups(h), true, nullptr, 0, h->d_cflags, true);
     };
     // graph A: the verdict on the start point
@@ -1068,8 +1170,7 @@ int build_graphs(jg_nr* h) {
     NR_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     rc = newton_step(h, active_groups(h), h->d_active);
     launch_assemble(h, active_groups(h), false);
-    launch_check(h, 1, h->d_group);
-    launch_compact(h, 0, true);
+    check_and_compact();
     if (h->ld > 64) launch_assemble(h, active_groups(h), false, nullptr, 0, h->d_cflags);
     e = hipStreamEndCapture(h->stream, &h->graphBm);
     if (rc) return fail(rc, h->eng.error);
