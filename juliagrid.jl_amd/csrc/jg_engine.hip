@@ -1037,6 +1037,93 @@ __global__ __launch_bounds__(64 * TASK_WAVES, 4) void k_fact_task(FactArgs a) {
     }
 }
 
+// ---- the factorisation below the top of a SINGLE instance (jg_symbolic.hpp: SINGLE_FACT_LEVELS): a thread per item ---------------------------------------
+struct Fact1Args {
+    const Rec* rec; const int* first; const int* wg;
+    const double* rhs; double* X; double* W; int* status; GroupSel sel;
+    int ld, n_wg, n_items;
+};
+// one item, worked on by FOUR lanes (a quad): lane q takes the item's records q, q + 4, ... (four terms each, in flight together: unconditional loads at clamped
+// operands) -- the long lists of the task-owned entries (up to dozens of bottom terms) would otherwise be a chain of round trips on one thread; the four partial
+// sums meet through two shuffles (fixed order), lane 0 adds the block / rhs row as assembled and stores like fact_finish
+__device__ __forceinline__ void fact1_item(const Fact1Args& a, int ri, int q, size_t b, size_t ld) {
+    const int4* rp = (const int4*)(a.rec + ri);
+    const int4 h = rp[0];                                         // kind, id, src, terms
+    const int kind = h.x, id = h.y, src = h.z, nt = h.w;
+    // (every lane of the quad asks for the item's own block: same address, no branch ahead of the term loads)
+    const double2 f0 = *(const double2*)(kind == 3 ? (const char*)a.rhs + ((size_t)src * ld + b) * 16 : (const char*)a.X + (size_t)(src >= 0 ? src : 0) * ld * 32 + b * 16);
+    const double2 f1 = *(const double2*)((const char*)a.X + (size_t)(kind != 3 && src >= 0 ? src : 0) * ld * 32 + ld * 16 + b * 16);
+    Blk c{0.0, 0.0, 0.0, 0.0};
+    for (int q0 = 4 * q; q0 < nt; q0 += 16) {
+        const int4* tr = rp + 4 * (q0 >> 2);
+        const int4 t1 = tr[1], t2 = tr[2], t3 = tr[3];
+        const int ta[4] = {t1.x, t1.w, t2.z, t3.y}, td[4] = {t1.y, t2.x, t2.w, t3.z}, tb[4] = {t1.z, t2.y, t3.x, t3.w};
+        const int cnt = min(4, nt - q0);
+        double2 l0[4], l1[4], d0[4], d1[4], u0[4], u1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int x = u < cnt ? u : 0;
+            const char* pl = (const char*)a.X + (size_t)ta[x] * ld * 32 + b * 16;
+            const char* pd = (const char*)a.X + (size_t)td[x] * ld * 32 + b * 16;
+            const char* pu = kind == 3 ? (const char*)a.W + ((size_t)tb[x] * ld + b) * 16 : (const char*)a.X + (size_t)tb[x] * ld * 32 + b * 16;
+            l0[u] = *(const double2*)pl; l1[u] = *(const double2*)(pl + ld * 16);
+            d0[u] = *(const double2*)pd; d1[u] = *(const double2*)(pd + ld * 16);
+            u0[u] = *(const double2*)pu; u1[u] = *(const double2*)(kind == 3 ? pu : pu + ld * 16);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (u < cnt) {
+                const Blk lt{l0[u].x, l0[u].y, l1[u].x, l1[u].y}, dt{d0[u].x, d0[u].y, d1[u].x, d1[u].y};
+                if (kind == 3) {                                  // y -= Lh(a) D(d)^-1 y_c
+                    double z0, z1;
+                    dsolve(dt, u0[u].x, u0[u].y, z0, z1);
+                    c.v00 -= lt.v00 * z0 + lt.v01 * z1;
+                    c.v01 -= lt.v10 * z0 + lt.v11 * z1;
+                } else term3(c, lt, dt, Blk{u0[u].x, u0[u].y, u1[u].x, u1[u].y});
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 1; d <= 2; d <<= 1) { c.v00 += __shfl_xor(c.v00, d); c.v01 += __shfl_xor(c.v01, d); c.v10 += __shfl_xor(c.v10, d); c.v11 += __shfl_xor(c.v11, d); }
+    if (q != 0) return;
+    Blk s{0.0, 0.0, 0.0, 0.0};                                    // the item as assembled
+    if (kind == 3) { s.v00 = f0.x; s.v01 = f0.y; }
+    else if (src >= 0) s = Blk{f0.x, f0.y, f1.x, f1.y};
+    const double2 ref = row_max(s);                               // what the rows of a diagonal block started from (pivot guard)
+    c.v00 += s.v00; c.v01 += s.v01; c.v10 += s.v10; c.v11 += s.v11;
+    if (kind == 3) { store_vec(a.W, (size_t)id, b, ld, c.v00, c.v01); return; }
+    if (kind == 2) {                                              // diagonal block: 2x2 LU with in-block partial pivoting, pivot guard
+        bool bad;
+        const Blk f = diag_lu(c, ref, bad);
+        if (bad) atomicOr(a.status + b, 4);
+        store_blk(a.X, (size_t)id, b, ld, f.v00, f.v01, f.v10, f.v11);
+    } else store_blk(a.X, (size_t)id, b, ld, c.v00, c.v01, c.v10, c.v11);
+}
+
+// f1: a workgroup = a run of whole bottom subtrees; its items level by level, a workgroup barrier between levels (what a level reads was written by this workgroup:
+// the CU's own L1 is coherent for its waves once the stores have been acknowledged -- __syncthreads waits for them)
+__global__ __launch_bounds__(256) void k_fact1_bottom(Fact1Args a) {
+    int grp, w;
+    if (!map_block(a.sel, a.ld, a.n_wg, grp, w)) return;
+    const size_t b = (size_t)grp * 64, ld = (size_t)a.ld;
+    const int* hdr = a.wg + (size_t)w * (SINGLE_FACT_LEVELS + 1);
+    const int last = hdr[SINGLE_FACT_LEVELS];
+    const int quad = (int)threadIdx.x >> 2, q = (int)threadIdx.x & 3;
+    for (int l = 0; l < SINGLE_FACT_LEVELS; ++l) {
+        const int i0 = hdr[l], i1 = hdr[l + 1];
+        for (int j = i0 + quad; j < i1; j += 64) fact1_item(a, a.first[j], q, b, ld);
+        if (i1 >= last) break;                                    // (uniform) nothing above this level in this workgroup
+        __syncthreads();
+    }
+}
+// f2: the partial sums of the task-owned entries and rhs rows (bottom terms only): every operand is final after f1
+__global__ __launch_bounds__(256) void k_fact1_partial(Fact1Args a) {
+    int grp, w;
+    if (!map_block(a.sel, a.ld, (a.n_items + 63) / 64, grp, w)) return;
+    const int j = w * 64 + ((int)threadIdx.x >> 2);
+    if (j < a.n_items) fact1_item(a, a.first[j], (int)threadIdx.x & 3, (size_t)grp * 64, (size_t)a.ld);
+}
+
 // TIMING PROBES of a pivot step (compile with -DJG_PROBE_TOP=1: the next pivot's row / column are not published, =3: the bulk threads take the published row as D^-1 U(q, .) -- no pivot read, no solve --, =2: one block update per
 // thread instead of CLS x CLS; wrong numbers -- tools/experiments/level_bound_probe.sh, DESIGN_LOG.md 3.3): what a step is made of.
 #ifndef JG_PROBE_TOP
@@ -1770,6 +1857,7 @@ SharedPlan::~SharedPlan() {
     hipFree(fact_seg); hipFree(bwd_seg); hipFree(pre_seg); hipFree(fwd_seg); hipFree(sel_seg);
     hipFree(pre_row); hipFree(bwd_chain); hipFree(top_data); hipFree(top_wgmap);
     hipFree(bwdj_rec); hipFree(bwdj_seg);
+    hipFree(f1_rec); hipFree(f1_first); hipFree(f1_wg); hipFree(f2_first);
     hipFree(s1_t_row); hipFree(s1_t_ptr); hipFree(s1_t_term); hipFree(s1_t_level); hipFree(s1_b_wg); hipFree(s1_b_row); hipFree(s1_b_term);
 }
 
@@ -1851,6 +1939,8 @@ std::shared_ptr<SharedPlan> acquire_plan(int n, const int* rowptr, const int* co
         upload(&p->bwd_seg, S.bwd_seg, error, st) || upload(&p->bwd_chain, S.bwd_chain, error, st) ||
         (S.jordan && (upload(&p->bwdj_rec, S.bwdj_rec, error, st) || upload(&p->bwdj_seg, S.bwdj_seg, error, st))) ||
         upload(&p->fwd_rec, S.fwd_rec, error, st) || upload(&p->fwd_seg, S.fwd_seg, error, st) ||
+        (S.single_fact_ok && (upload(&p->f1_rec, S.f_rec, error, st) || upload(&p->f1_first, S.f1_first, error, st) || upload(&p->f1_wg, S.f1_wg, error, st) ||
+                              upload(&p->f2_first, S.f2_first, error, st))) ||
         (!S.top_launch.empty() && (upload(&p->top_task, S.top_task, error, st) || upload(&p->top_data, S.top_data, error, st) || upload(&p->top_wgmap, S.top_wgmap, error, st)))) {
         rc = 2;
         return nullptr;
@@ -1907,6 +1997,7 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, long long 
     // 20: 1.556, 24: 1.66; the 9241-bus grid 1.488 / 1.495 / 1.490 / 1.54 for 8 / 10 / 12 / 16; case1354pegase does not care; a larger soft cap loses everywhere:
     // tools/experiments/r06_mmin_sweep.sh, profiles/r06_mmin_sweep.txt)
     if (defaults && tiny && !((policy >> 54) & 0x3f)) policy |= 12LL << 54;
+    if (defaults && tiny && lanes == 1 && knob("SINGLE", 1) != 0) policy |= 1LL << 60;      // ONE scenario: the plan also carries the thread-per-item tables of the bottom (k_fact1)
     const bool timing = knob_set("PLAN_TIMING");
     auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double te0 = tnow();
@@ -2024,8 +2115,15 @@ int Engine::factor(hipStream_t st, const double* A, const double* rhs, const Gro
             hipLaunchKernelGGL(k_fact_level, dim3(grid_blocks(ld / 64, (long long)L.grid * (16 / FACT_WAVES)), L.nseg), dim3(64, FACT_WAVES), FACT_WAVES * 256 * sizeof(double), st, p);
         }
     }
+    const bool single_fact = plan->S.single_fact_ok && lanes == 1 && plan->f1_rec && probe_part == 0;
+    if (single_fact) {                                           // ONE scenario: a thread per item -- the bottom subtrees in one launch, the partial sums of the task-owned items in a second
+        Fact1Args s{plan->f1_rec, plan->f1_first, plan->f1_wg, rhs, X, W, status, sel, ld, plan->S.n_f1_wg, 0};
+        if (s.n_wg > 0) hipLaunchKernelGGL(k_fact1_bottom, dim3(grid_blocks(ld / 64, s.n_wg)), dim3(256), 0, st, s);
+        s.first = plan->f2_first; s.n_items = (int)plan->S.f2_first.size();
+        if (s.n_items > 0) hipLaunchKernelGGL(k_fact1_partial, dim3(grid_blocks(ld / 64, (s.n_items + 63) / 64)), dim3(256), 0, st, s);
+    }
     for (const DevLaunch& L : fact) {
-        if (probe_part == 2) break;
+        if (probe_part == 2 || single_fact) break;
         a.seg_begin = L.seg_begin;
         { const Segment& g = plan->S.fact_seg[L.seg_begin]; a.s0_base = g.rec_base; a.s0_nchunks = g.nchunks; a.s0_wpi = g.wpi; a.s0_rpw = g.rpw; }
         if (plan->S.fact_tasks)                                  // TASKS (jg_symbolic.hpp): a workgroup per task, not per 8 item waves

@@ -655,6 +655,62 @@ void build_tables(BlockSymbolic& S) {
             x.w[3]++;
         }
     };
+    // ---- the same items for a SINGLE instance (policy bit 60; jg_symbolic.hpp: SINGLE_FACT_LEVELS): a thread per item, two launches
+    S.single_fact_ok = false; S.f_rec.clear(); S.f1_first.clear(); S.f1_wg.clear(); S.f2_first.clear(); S.n_f1_wg = 0;
+    if (S.want_single && has_top && !sym && S.inplace) {
+        auto parent = [&](int k) { return S.u_ptr[k + 1] > S.u_ptr[k] ? S.u_col[S.u_ptr[k]] : -1; };
+        auto item_pivot = [&](int it) { return it < nE ? owner(it) : it - nE; };
+        auto emit = [&](int it) {                               // records of one item; returns the index of the first
+            const int first = (int)S.f_rec.size();
+            const int nt = ft_ptr[it + 1] - ft_ptr[it];
+            const int nrec = std::max(1, (nt + 3) / 4);
+            S.f_rec.resize(S.f_rec.size() + nrec);
+            fill_fact(it, 0, 1, nrec, S.f_rec.data() + first);   // (kind, id, src in every record; words 4 .. 15: up to four terms each)
+            S.f_rec[first].w[3] = nt;                            // the first record carries the item's total
+            return first;
+        };
+        bool ok = true;
+        int maxlev = 0;
+        std::vector<int> sub(n, 1);
+        for (int k = 0; k < n; ++k) if (parent(k) >= 0) sub[parent(k)] += sub[k];
+        // bottom subtrees in ascending order, their scheduled items by level
+        std::vector<std::vector<int>> piv_items(n);
+        for (int it = 0; it < nE + n; ++it) {
+            if (level[it] <= 0) continue;
+            const int p = item_pivot(it);
+            if (in_top(p)) continue;
+            piv_items[p].push_back(it);
+            maxlev = std::max(maxlev, level[it]);
+        }
+        if (maxlev > SINGLE_FACT_LEVELS) ok = false;
+        std::vector<std::vector<int>> wg_items;                  // per workgroup: items (any order; sorted by level below)
+        int cur = SINGLE_FACT_ITEMS + 1;
+        for (int k = 0; k < n && ok; ++k) {
+            if (in_top(k)) continue;
+            const int p = parent(k);
+            if (p >= 0 && !in_top(p)) continue;                  // not the root of a bottom subtree
+            int cnt = 0;
+            for (int q = k - sub[k] + 1; q <= k; ++q) { if (in_top(q)) ok = false; cnt += (int)piv_items[q].size(); }
+            if (cnt == 0) continue;
+            if (cur + cnt > SINGLE_FACT_ITEMS) { wg_items.emplace_back(); cur = 0; }
+            for (int q = k - sub[k] + 1; q <= k; ++q) for (int it : piv_items[q]) wg_items.back().push_back(it);
+            cur += cnt;
+        }
+        if (ok) {
+            for (std::vector<int>& items : wg_items) {
+                std::stable_sort(items.begin(), items.end(), [&](int x, int y) { return level[x] < level[y]; });
+                size_t x = 0;
+                for (int l = 1; l <= SINGLE_FACT_LEVELS; ++l) {
+                    S.f1_wg.push_back((int)S.f1_first.size());
+                    while (x < items.size() && level[items[x]] == l) S.f1_first.push_back(emit(items[x++]));
+                }
+                S.f1_wg.push_back((int)S.f1_first.size());
+            }
+            S.n_f1_wg = (int)wg_items.size();
+            for (int it = 0; it < nE + n; ++it) if (level[it] > 0 && in_top(item_pivot(it))) S.f2_first.push_back(emit(it));
+            S.single_fact_ok = true;
+        }
+    }
     S.n_sched_terms = S.top_terms;
     for (int it = 0; it < nE + n; ++it) if (level[it] > 0) S.n_sched_terms += work[it];
     // Item order inside a level: everything that becomes final with pivot p = min(row, col) together -- U(p, .) and y_p share
@@ -1228,6 +1284,7 @@ int analyze(int n, const int* rowptr, const int* col, long long policy64, BlockS
     S.jordan = (int)((policy64 >> 49) & 1);                       // a request here; build_top grants it
     S.fact_tasks = (int)((policy64 >> 50) & 1);
     S.task_rounds = (int)((policy64 >> 51) & 7);
+    S.want_single = (int)((policy64 >> 60) & 1);
     S.top_mmin = (int)((policy64 >> 54) & 0x3f);
     if (S.top_mmin <= 0) S.top_mmin = 8;
     if (S.task_rounds <= 0) S.task_rounds = 3;

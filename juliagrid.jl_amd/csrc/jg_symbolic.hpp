@@ -191,6 +191,11 @@ struct BlockSymbolic {
     int n_sel_levels = 0;
     // multifrontal top (see TopLaunch): empty when the plan has no top tasks
     int top_level = 0;                  // pivots whose diagonal becomes final at this level or later belong to top tasks (0: none)
+    int want_single = 0;                // policy bit 60: also build the factorisation tables of a single instance (below)
+    bool single_fact_ok = false;
+    std::vector<Rec> f_rec;             // records of f1 and f2
+    std::vector<int> f1_first, f1_wg, f2_first;
+    int n_f1_wg = 0;
     int top_mmin = 8;                   // policy bits 54-59: a task takes at least this many pivots where its front has room (0 = default 8)
     std::vector<int> top_task_of;       // [n] task index of a pivot, -1 = bottom pivot
     std::vector<Rec> top_task;          // task headers, launch order
@@ -241,6 +246,16 @@ void build_comp_tables(const BlockSymbolic& S, int top_cap, CompTables& out);
 //              t_term = slots of the columns, one list per task (its rows share ext(task)).
 //              b_row [.][6] = pivot, bus, diagonal entry, terms, first term, level inside its subtree (0: top columns only);
 //              b_term [.][2] = entry, column: >= 0 a top pivot (row of W), < 0: -(1 + thread of the column's row in this workgroup).
+// The factorisation below the top of a SINGLE instance (policy bit 60, k_fact1 in jg_engine.hip): the level launches of a handful of scenarios give a wave to
+// every item and hold one live lane each; here a THREAD takes an item.  The items of the bottom pivots (D(p), U(p, .), Lh(., p), y_p of every pivot outside the top
+// tasks) depend on items of their own subtree only, so a workgroup takes a run of whole bottom subtrees and walks its levels with workgroup barriers: ONE launch
+// (f1); the partial sums of the task-owned entries / rhs rows (bottom terms only, jg_symbolic.cpp: build_tables) depend on bottom items alone: a second, flat
+// launch (f2).  Five level launches become two.
+//   record (16 ints): kind (0 / 1 raw entry, 2 diagonal block, 3 rhs row), id, src, terms of the ITEM, then up to four terms (a, d, b) as in a FactRec; an item of
+//   more than four terms continues in the records that follow (words 4 .. 15 only).  f1_first / f2_first: first record of every item; f1_wg [n_f1_wg][SINGLE_FACT_LEVELS + 1]:
+//   the workgroup's items of level l + 1 are f1_first[f1_wg[w][l] .. f1_wg[w][l + 1]).
+constexpr int SINGLE_FACT_LEVELS = 8;      // most levels below the top such a plan may have
+constexpr int SINGLE_FACT_ITEMS = 192;     // items a bottom workgroup is filled up to (256 threads = 64 quads, four lanes per item: most levels in one round)
 constexpr int SINGLE_BOTTOM_ROWS = 128;   // rows (threads) of a bottom workgroup
 struct SingleTables {
     bool ok = false;                    // false: the plan does not qualify (no Jordan rows, a subtree above SINGLE_BOTTOM_ROWS rows, ...)
@@ -265,6 +280,7 @@ void build_single_tables(const BlockSymbolic& S, SingleTables& out);
 // its geometry (smaller fronts form tasks of their own below it).
 // policy bit 49: Jordan rows for the pivots of the top tasks + a second set of backward tables over them (see TOP_FRONT_MAX above).
 // policy bit 50: the factorisation tables are TASKS (see TASK_WAVES above); bits 51-53: rounds a task is filled up to (0 = default 3).
+// policy bit 60: the plan serves ONE scenario: the factorisation tables of a single instance are built as well (SINGLE_FACT_LEVELS above).
 // policy bits 54-59: least number of pivots a top task takes where its front has room (0 = default 8; a handful of scenarios: 12 -- a task costs ~10 us of
 // gather / extend-add / store whatever it eliminates, and a lone workgroup steps through a 50-row front as fast as through a 30-row one).
 // Returns 0, or 1 on a malformed pattern.
