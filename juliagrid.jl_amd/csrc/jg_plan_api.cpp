@@ -35,6 +35,10 @@ void jg_plan_destroy(jg_plan* p) { delete p; }
 //        73 task of each pivot (-1: bottom), 74 {top_level, stack doubles per scenario (low 31 bits), top terms (low 31 bits), stack doubles per interleave class x3,
 //        Jordan plan (0 / 1), blocks of Jordan rows behind the factor entries, factorisation tables are TASKS (0 / 1: policy bit 50, jg_symbolic.hpp),
 //        rounds a task is filled up to, operands staged by the tasks, terms of task items in three-operand form}, 79 / 80 backward segments / records over Jordan rows
+//        81 - 85 the factorisation of a single instance below the top (plans with policy bit 60, jg_symbolic.hpp: SINGLE_FACT_LEVELS): records (x16), first record of the
+//        bottom items, [workgroups][levels + 1] ranges of them, first record of the partial items, {ok, workgroups, levels, items per workgroup}
+//        90 - 97 the backward sweep of a single instance (jg_symbolic.hpp: SingleTables): {ok, top rows, top levels, bottom rows, bottom workgroups, bottom levels, rows per
+//        workgroup}, t_row (x4), t_ptr (x2), t_term, t_level, b_wg (x2), b_row (x6), b_term (x2)
 // out == NULL returns the length.
 int64_t jg_plan_export(jg_plan* p, int which, int32_t* out, int64_t cap) {
     if (!p) return -1;
@@ -70,6 +74,21 @@ int64_t jg_plan_export(jg_plan* p, int which, int32_t* out, int64_t cap) {
                         S.fact_tasks, S.task_rounds, (int)S.n_staged, (int)S.n_direct_terms}; v = &tmp; break;
         case 79: tmp.assign((const int*)S.bwdj_seg.data(), (const int*)S.bwdj_seg.data() + S.bwdj_seg.size() * 8); v = &tmp; break;
         case 80: tmp.assign((const int*)S.bwdj_rec.data(), (const int*)S.bwdj_rec.data() + S.bwdj_rec.size() * 16); v = &tmp; break;
+        case 81: tmp.assign((const int*)S.f_rec.data(), (const int*)S.f_rec.data() + S.f_rec.size() * 16); v = &tmp; break;
+        case 82: v = &S.f1_first; break;
+        case 83: v = &S.f1_wg; break;
+        case 84: v = &S.f2_first; break;
+        case 85: tmp = {S.single_fact_ok ? 1 : 0, S.n_f1_wg, jg::SINGLE_FACT_LEVELS, jg::SINGLE_FACT_ITEMS}; v = &tmp; break;
+        case 90: case 91: case 92: case 93: case 94: case 95: case 96: case 97: {
+            jg::SingleTables T;
+            jg::build_single_tables(S, T);
+            switch (which) {
+                case 90: tmp = {T.ok ? 1 : 0, T.n_top, T.n_top_levels, T.n_bottom, T.n_wg, T.b_levels, jg::SINGLE_BOTTOM_ROWS}; break;
+                case 91: tmp = T.t_row; break;  case 92: tmp = T.t_ptr; break;  case 93: tmp = T.t_term; break;  case 94: tmp = T.t_level; break;
+                case 95: tmp = T.b_wg; break;   case 96: tmp = T.b_row; break;  default: tmp = T.b_term; break;
+            }
+            v = &tmp; break;
+        }
         case 75: tmp.assign(S.pre_pivot.begin(), S.pre_pivot.end()); v = &tmp; break;
         case 76: tmp.assign((const int*)S.pre_seg.data(), (const int*)S.pre_seg.data() + S.pre_seg.size() * 8); v = &tmp; break;
         case 77: tmp.assign((const int*)S.pre_rec.data(), (const int*)S.pre_rec.data() + S.pre_rec.size() * 16); v = &tmp; break;

@@ -44,13 +44,14 @@ class Replay:
     """inplace=True mirrors policy bit 0: the caller's blocks already sit in the factor storage and
     off-diagonal entries without update terms are not scheduled at all."""
 
-    def __init__(self, plan, inplace=False, symmetric=False, prefactor=False, producer=True, jordan=False):
+    def __init__(self, plan, inplace=False, symmetric=False, prefactor=False, producer=True, jordan=False, single=False):
         """prefactor mirrors policy bit 2: the pivots nobody updates (pre_pivot) are level-0 items -- finished by the producer
         (producer=True: their diagonal blocks arrive factorised, their rhs rows are in place) or by the plan's PRE tables.
         jordan mirrors Engine::jordan on a plan with policy bit 49: the top tasks eliminate above the diagonal too and leave Jordan rows
         behind the factor entries; the backward sweep walks the "bwdj" tables."""
         self.p = plan
         self.jordan = jordan
+        self.single = single            # policy bit 60: the items below the top come from the thread-per-item tables of a single instance (k_fact1_bottom / k_fact1_partial)
         self.prefactor, self.producer = prefactor, producer
         g = plan.get
         self.perm, self.e_row, self.e_col, self.e_src = g("perm"), g("e_row"), g("e_col"), g("e_src")
@@ -136,6 +137,8 @@ class Replay:
 
         current = None
         tables = [] if self.fact_tasks else [(lv, k, sb, rc) for lv, k, sb, rc in self._waves(self.fseg, self.frec)]
+        if self.single:
+            tables = self._single_items()
         if self.prefactor and not self.producer:             # plain blocks: the PRE tables run ahead of level 1, as level 0
             pseg, prec = self.p.replay_tables("pre")
             tables = [(0, ("pre",) + k, sb, rc) for lv, k, sb, rc in self._waves(pseg, prec)] + tables
@@ -183,6 +186,8 @@ class Replay:
                     self._task(si, c, self.frec[base + c * 8 * rpw: base + (c + 1) * 8 * rpw].reshape(8, rpw, 16), spw, level, A, rhs, X, Y, level_of, acc, meta)
             flush()
             terms_seen = int((self.frec[self.frec[:, 0] & 7 != 7, 3] & 0xff).sum())
+        elif self.single:
+            terms_seen = sum(int(r[3]) for _lv, _k, _sb, rc in tables for r in rc)
         else:
             terms_seen = 0
             for r in self.frec:
@@ -300,6 +305,44 @@ class Replay:
                 meta[key] = (level, kind, ident)
                 acc[key] = v
         assert all(s is None for s in state), "a share without its last record"
+
+    def _single_items(self):
+        """The thread-per-item tables as the stream factor() walks: f1 = (workgroup, level, item) with the levels replayed across all workgroups at once -- which is
+        only the device's order if every operand of an item is produced by ITS workgroup (asserted here) -- then f2 (the partial sums) as one more level."""
+        g = self.p.get
+        info = g(85)
+        assert info[0] == 1, "the plan carries no single-instance tables"
+        nlev = int(info[2])
+        rec, f1_first, f2_first = g(81).reshape(-1, 16), g(82), g(84)
+        f1_wg = g(83).reshape(-1, nlev + 1)
+        nE = self.nE
+
+        def item(first):
+            nt = int(rec[first][3])
+            out = rec[first: first + max(1, (nt + 3) // 4)].copy()
+            for i, r in enumerate(out):
+                r[3] = min(4, nt - 4 * i) if nt > 4 * i else 0
+            return out
+        wg_of = {}                                            # item (entry, or nE + rhs row) -> workgroup
+        for w in range(f1_wg.shape[0]):
+            for j in range(f1_wg[w, 0], f1_wg[w, nlev]):
+                r = rec[f1_first[j]]
+                wg_of[int(r[1]) + (nE if r[0] == 3 else 0)] = w
+        out = []
+        for l in range(nlev):
+            for w in range(f1_wg.shape[0]):
+                for j in range(f1_wg[w, l], f1_wg[w, l + 1]):
+                    recs = item(int(f1_first[j]))
+                    kind = int(recs[0][0])
+                    for r in recs:
+                        for t in range(int(r[3])):
+                            a, d, b = (int(v) for v in r[4 + 3 * t: 7 + 3 * t])
+                            for op in (a, d, b + nE if kind == 3 else b):
+                                assert wg_of.get(op, w) == w, "an item below the top reads an item of another workgroup"
+                    out.append((l + 1, ("f1", w, j), 0, recs))
+        for j, first in enumerate(f2_first):
+            out.append((nlev + 1, ("f2", j), 0, item(int(first))))
+        return out
 
     def _top_owned(self, e):
         return self.task_of.size > 0 and self.task_of[min(self.e_row[e], self.e_col[e])] >= 0
