@@ -836,6 +836,23 @@ def main():
         t_single.append(time.perf_counter() - t0)
     base_jacobian = base.jacobian if (rank == 0 and not args.no_cpu) else None     # for the splu leg (CSC of the reference, base state)
     base.close()
+    # the same solve through the level launches of a small batch (JG_SINGLE=0: what a single instance ran until round 6 -- a wave with one live lane per item)
+    t_single_levels = []
+    if rank == 0:
+        os.environ["JG_SINGLE"] = "0"
+        try:
+            lv = jg.newtonRaphson(jg.powerSystem(tables), batch=1, device=local)
+            jg.powerFlow_(lv)
+            for _ in range(5):
+                jg.setInitialPoint_(lv)
+                t0 = time.perf_counter()
+                jg.powerFlow_(lv, fetch=False)
+                t_single_levels.append(time.perf_counter() - t0)
+            lv.close()
+        except Exception:
+            t_single_levels = []
+        finally:
+            del os.environ["JG_SINGLE"]
     # The first handle of a process also pays the HIP context and the load of the library's code object.  What ONE MORE analysis costs in a
     # warm process (what a reference user pays per newtonRaphson() call) is measured twice: of the SAME grid while the library still holds
     # its plan (engines of one pattern share the symbolic analysis and the device tables), and after jg_plan_cache_clear (a full analysis):
@@ -1092,6 +1109,9 @@ def main():
             "converged_fraction": conv_total / total,
             "single_instance": {"ms_per_solve": 1e3 * float(np.median(t_single)), "iterations": base_iters,
                                 "ms_per_iteration": 1e3 * float(np.median(t_single)) / max(base_iters, 1),
+                                "ms_per_solve_level_launches": 1e3 * float(np.median(t_single_levels)) if t_single_levels else None,
+                                "level_launches_what": "the same warm solve with JG_SINGLE=0: the level launches of a small batch (a wave per item, one live lane) instead of the "
+                                                       "item-per-lane / row-per-lane kernels of ONE scenario (k_fact1_*, k_bwd1_*), same run",
                                 "setup_ms": 1e3 * (t_create2 + t_first2) - 1e3 * float(np.median(t_single)),
                                 "setup_what": f"a further analysis in a warm process with the library's plan cache emptied, on a system whose AC model exists: newtonRaphson() {1e3 * t_create2:.1f} ms (reference maps, "
                                               f"symbolic analysis of the block LU, replay tables, upload) + first powerFlow!() {1e3 * t_first2:.1f} ms (hipGraph capture) - one warm solve",

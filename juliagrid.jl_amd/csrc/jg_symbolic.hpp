@@ -21,7 +21,7 @@ namespace jg {
 // handles), JG_POLL=0 (the host always blocks in the stream synchronise), JG_PLAN_THREADS (host threads of the table builder), JG_PLAN_TIMING, JG_HOST_TIMING
 // (timings on stderr).  The rest are TEST HOOKS that force a code path the library also takes by itself, so that the suites can hold the variants against each
 // other (tests/test_top_variants_gpu.py, tests/test_plan_cpu.py): JG_TOP_PW, JG_TOP_FUSE, JG_TOP_SYM, JG_JORDAN, JG_CHAIN_SMALL, JG_NO_PREFACTOR, JG_LANES_INPLACE,
-// JG_TOP_LEVEL, JG_ROW_TASKS, JG_ORDER_CHECK, JG_TOP_PROFILE.  Nothing else is read: the switches of retired experiments left with their kernels
+// JG_TOP_LEVEL, JG_ROW_TASKS, JG_ORDER_CHECK, JG_TOP_PROFILE, JG_SINGLE.  Nothing else is read: the switches of retired experiments left with their kernels
 // (tools/experiments/*.patch).
 int knob(const char* name, int unset);      // integer value of the environment variable JG_<name>; `unset` when it is not set (or not in the lists above)
 inline bool knob_set(const char* name) { return knob(name, -2147483647) != -2147483647; }

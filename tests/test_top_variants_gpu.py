@@ -93,6 +93,19 @@ def test_jordan_rows_and_small_chains_match_the_plain_backward_sweep(tmp_path, c
         assert np.abs(ref["vm"] - b["vm"])[ok].max() < 1e-10 and np.abs(ref["va"] - b["va"])[ok].max() < 1e-10, tag
 
 
+@pytest.mark.parametrize("case", ["case118", "case1354pegase", "case9241synth", "case_ACTIVSg10k"])
+def test_single_instance_kernels_match_the_level_launches(tmp_path, case):
+    """Round 6: a handle of ONE scenario factorises below the top with a quad of lanes per item (k_fact1_bottom / k_fact1_partial) and sweeps backward with rows as
+    lanes (k_bwd1_top over compact Jordan rows, k_bwd1_bottom) instead of giving a wave with one live lane to every item (JG_SINGLE=0: the level launches).  Another
+    summation order of long term lists, the same algorithm: equal iteration count and status, V / theta to 1e-10."""
+    import numpy as np
+    ref = _state(tmp_path, "ref", case, 1, dict())
+    lvl = _state(tmp_path, "lvl", case, 1, dict(JG_SINGLE=0))
+    assert int(np.atleast_1d(ref["st"])[0]) == 0
+    assert np.array_equal(ref["it"], lvl["it"]) and np.array_equal(ref["st"], lvl["st"])
+    assert np.abs(ref["vm"] - lvl["vm"]).max() < 1e-10 and np.abs(ref["va"] - lvl["va"]).max() < 1e-10
+
+
 def test_refined_steps_switch_the_engine_back_to_plain_rows(jg):
     """Iterative refinement runs forward() + backsolve() on the factor of the step: the forward elimination of another right-hand side gives
     y, not the y' Jordan rows go with, so jg_nr_set_refine turns Engine::jordan off (and on again when refinement goes off).  A handle that
