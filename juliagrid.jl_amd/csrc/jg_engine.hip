@@ -558,7 +558,10 @@ __global__ __launch_bounds__(1024) void k_bwd1_top(Bwd1Args a) {
             const double2 yk = load_vec(a.W, (size_t)d.x, b, ld);
             const Blk dg = load_blk(a.X, (size_t)d.z, b, ld);
             double y0 = 0.0, y1 = 0.0;
-            for (int i0 = 0; i0 < d.w; i0 += 4 * TQ) {            // unconditional loads at clamped positions; lane q takes terms q, q + 4, ...
+#ifndef JG_PROBE_BWD1
+#define JG_PROBE_BWD1 0                 // TIMING PROBE (tools/experiments/r06_bwd1_probe.sh; wrong numbers): 1 no term loads (34 -> 19 us), 2 no stores (-> 28), 3 neither solve nor stores
+#endif
+            for (int i0 = 0; i0 < (JG_PROBE_BWD1 == 1 ? 0 : d.w); i0 += 4 * TQ) {            // unconditional loads at clamped positions; lane q takes terms q, q + 4, ...
                 int sl[TQ]; double2 m0[TQ], m1[TQ];
 #pragma unroll
                 for (int u = 0; u < TQ; ++u) {
@@ -577,6 +580,9 @@ __global__ __launch_bounds__(1024) void k_bwd1_top(Bwd1Args a) {
             }
             y0 += __shfl_xor(y0, 1); y1 += __shfl_xor(y1, 1);
             y0 += __shfl_xor(y0, 2); y1 += __shfl_xor(y1, 2);
+            if (JG_PROBE_BWD1 == 2) { if (q == 0) { double x0, x1; dsolve(dg, yk.x + y0, yk.y + y1, x0, x1); xs[row] = double2{x0, x1}; } }
+            else if (JG_PROBE_BWD1 == 3) { if (q == 0) xs[row] = double2{y0, y1}; }
+            else
             if (q == 0) xs[row] = bwd1_finish(a, dg, yk.x + y0, yk.y + y1, d.x, d.y, b, ld, up);
         }
         lds_barrier();
