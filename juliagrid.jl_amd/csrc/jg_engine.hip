@@ -1271,7 +1271,60 @@ __global__ __launch_bounds__(PW ? TOP_THREADS : 256) __attribute__((amdgpu_waves
             if (gi == gj && r * G + gi < m) *(double2*)(Dref + (size_t)(r * G + gi) * 2) = row_max(T[r][r]);
         if (prof) pt[1] = wall_clock64();
         // ---- extend-add: every thread pulls what the children left for its blocks (child order fixed => deterministic)
-        if constexpr (PW) {
+        if constexpr (PW && CLS == 2) {
+            // class 2 (four blocks per thread): the children come in PAIRS -- both records travel together, then both sets of blocks: a task of four children pays three
+            // round trips where child after child paid five (the 9241-bus grid: the extend-add was 3 - 6 of a task's ~16 us); added in child order under selects: same bits
+            constexpr int GC = 2;
+            const int* cd = td + h[7];
+            const int stride = 2 + fprime;
+            int n_coff[GC], n_ce[GC], n_ri[GC][CLS], n_cj[GC][CLS];
+            auto fetch = [&](int ch0) {
+#pragma unroll
+                for (int g = 0; g < GC; ++g) {
+                    const int* p = cd + (size_t)(ch0 + g < nchild ? ch0 + g : ch0) * stride;     // a missing second child re-reads the first (masked below)
+                    n_coff[g] = p[0]; n_ce[g] = p[1];
+#pragma unroll
+                    for (int r = 0; r < CLS; ++r) { const int i = r * G + gi; const int v = p[2 + (i < f ? i : 0)]; n_ri[g][r] = i < f ? v : -1; }
+#pragma unroll
+                    for (int c = 0; c < CLS; ++c) { const int j = c * G + gj; const int v = p[2 + (j < fprime ? j : 0)]; n_cj[g][c] = j < fprime ? v : -1; }
+                }
+            };
+            if (nchild > 0) fetch(0);
+            for (int ch0 = 0; ch0 < nchild; ch0 += GC) {
+                int coff[GC], ce[GC], ri[GC][CLS], cj[GC][CLS];
+#pragma unroll
+                for (int g = 0; g < GC; ++g) {
+                    coff[g] = n_coff[g]; ce[g] = n_ce[g];
+#pragma unroll
+                    for (int r = 0; r < CLS; ++r) ri[g][r] = n_ri[g][r];
+#pragma unroll
+                    for (int c = 0; c < CLS; ++c) cj[g][c] = n_cj[g][c];
+                }
+                if (ch0 + GC < nchild) fetch(ch0 + GC);
+                double2 s0[GC][CLS][CLS], s1[GC][CLS][CLS];
+#pragma unroll
+                for (int g = 0; g < GC; ++g)
+#pragma unroll
+                    for (int r = 0; r < CLS; ++r)
+#pragma unroll
+                        for (int c = 0; c < CLS; ++c) {
+                            const bool ok = ri[g][r] >= 0 && cj[g][c] >= 0;
+                            const double2* p = (const double2*)(stk + coff[g] + (ok ? ((size_t)ri[g][r] * (ce[g] + 1) + cj[g][c]) * 4 : 0));
+                            s0[g][r][c] = p[0]; s1[g][r][c] = p[1];
+                        }
+#pragma unroll
+                for (int g = 0; g < GC; ++g)
+#pragma unroll
+                    for (int r = 0; r < CLS; ++r)
+#pragma unroll
+                        for (int c = 0; c < CLS; ++c) {
+                            const bool ok = ch0 + g < nchild && ri[g][r] >= 0 && cj[g][c] >= 0;
+                            const double2 x0 = s0[g][r][c], x1 = s1[g][r][c];
+                            T[r][c].v00 = ok ? T[r][c].v00 + x0.x : T[r][c].v00; T[r][c].v01 = ok ? T[r][c].v01 + x0.y : T[r][c].v01;
+                            T[r][c].v10 = ok ? T[r][c].v10 + x1.x : T[r][c].v10; T[r][c].v11 = ok ? T[r][c].v11 + x1.y : T[r][c].v11;
+                        }
+            }
+        } else if constexpr (PW) {
             // (round 6, launches with few workgroups: a child's blocks are requested TOGETHER -- unconditional loads at clamped offsets, added under a select: same
             // bits -- and the record of the next child travels with them.  The conditional loads below compile to one round trip per block and two more per
             // child record: 3 - 6 us of a single instance's task.)
