@@ -501,6 +501,7 @@ struct Bwd1Args {
     const int* b_wg; const int* b_row; const int* b_term;
     const double* X; const double* jc; double* W; double* out; GroupSel sel; StateUpdate upd;    // jc: the compact Jordan rows k_fact_top left (TopArgs::jc)
     int ld, n_top_levels, n_wg, n_top;
+    const int* t_jb; const int* t_cslot; const int* t_toff; int max_terms;                // terms as lanes (k_bwd1_top2; SingleTables::flat_ok)
 };
 struct Upd1 { int fl; bool act; double va, vm; };
 // act: is the scenario active (read ONCE per launch: a load of it per row is a round trip ahead of everything else the row asks for)
@@ -553,13 +554,12 @@ __global__ __launch_bounds__(1024) void k_bwd1_top(Bwd1Args a) {
         for (int row = lvl[L] + quad; row < r1; row += 256) {
             const int4 d = rowd[row];                             // pivot, bus, diagonal entry, terms
             const int2 tp = rowp[row];                            // first block of the row in the compact Jordan rows, first slot of its column list
-            // (every lane of the quad asks for the row's right-hand side, diagonal block and state: same addresses, no branch -- and no wait -- ahead of the term loads)
-            const Upd1 up = upd1_prefetch(a.upd, act, d.y, b, ld);
+            // (every lane of the quad asks for the row's right-hand side and diagonal block: same addresses, no branch -- and no wait -- ahead of the term loads)
             const double2 yk = load_vec(a.W, (size_t)d.x, b, ld);
             const Blk dg = load_blk(a.X, (size_t)d.z, b, ld);
             double y0 = 0.0, y1 = 0.0;
 #ifndef JG_PROBE_BWD1
-#define JG_PROBE_BWD1 0                 // TIMING PROBE (tools/experiments/r06_bwd1_probe.sh; wrong numbers): 1 no term loads (34 -> 19 us), 2 no stores (-> 28), 3 neither solve nor stores
+#define JG_PROBE_BWD1 0                 // TIMING PROBE (tools/experiments/r06_bwd1_probe.sh; wrong numbers; measured on the form that stored inside the level loop): 1 no term loads (34 -> 19 us), 2 no stores (-> 28), 3 neither solve nor stores
 #endif
             for (int i0 = 0; i0 < (JG_PROBE_BWD1 == 1 ? 0 : d.w); i0 += 4 * TQ) {            // unconditional loads at clamped positions; lane q takes terms q, q + 4, ...
                 int sl[TQ]; double2 m0[TQ], m1[TQ];
@@ -580,12 +580,104 @@ __global__ __launch_bounds__(1024) void k_bwd1_top(Bwd1Args a) {
             }
             y0 += __shfl_xor(y0, 1); y1 += __shfl_xor(y1, 1);
             y0 += __shfl_xor(y0, 2); y1 += __shfl_xor(y1, 2);
-            if (JG_PROBE_BWD1 == 2) { if (q == 0) { double x0, x1; dsolve(dg, yk.x + y0, yk.y + y1, x0, x1); xs[row] = double2{x0, x1}; } }
-            else if (JG_PROBE_BWD1 == 3) { if (q == 0) xs[row] = double2{y0, y1}; }
-            else
-            if (q == 0) xs[row] = bwd1_finish(a, dg, yk.x + y0, yk.y + y1, d.x, d.y, b, ld, up);
+            if (JG_PROBE_BWD1 == 3) { if (q == 0) xs[row] = double2{y0, y1}; }
+            else if (q == 0) { double x0, x1; dsolve(dg, yk.x + y0, yk.y + y1, x0, x1); xs[row] = double2{x0, x1}; }   // the solution stays in LDS through the levels ...
         }
         lds_barrier();
+    }
+    // ... and leaves in ONE pass at the end (pivot order, bus order, fused state update): stores inside the level loop made the compiler wait at the head of the
+    // row loop for the acknowledgements of the row before (s_waitcnt vmcnt counts stores too), and the state operands rode in every row's round trip
+    if (JG_PROBE_BWD1 == 2) return;
+    for (int row = tid; row < a.n_top; row += 1024) {
+        const int4 d = rowd[row];
+        const Upd1 up = upd1_prefetch(a.upd, act, d.y, b, ld);
+        const double2 x = xs[row];
+        store_vec(a.W, (size_t)d.x, b, ld, x.x, x.y);
+        if (!a.upd.va || up.act) store_vec(a.out, (size_t)d.y, b, ld, x.x, x.y);       // a finished scenario keeps its last increment
+        if (a.upd.va) {
+            if (up.act && (up.fl & 1)) a.upd.va[(size_t)d.y * ld + b] = up.va + a.upd.sign * x.x;
+            if (up.act && (up.fl & 2)) a.upd.vm[(size_t)d.y * ld + b] = up.vm + a.upd.sign * x.y;
+        }
+    }
+}
+
+// The same sweep with the TERMS as lanes (SingleTables::flat_ok).  k_bwd1_top asks for a row's blocks from four lanes, eight requests each: on the two wide levels of a
+// 10k-bus grid that is 24 memory instructions per wave and round on 16 waves -- the CU retires one per ~16 clocks -- for slots that are half clamped duplicates, and a
+// round trip per level on top (32 us, of which 15 are those requests: probe builds).  Here lane g - g0 of a level takes block g (the compact blocks of a level follow
+// each other in row order: 64 lanes = 2 KiB of contiguous memory), multiplies it with its column's solution and leaves the product in LDS; a barrier later ONE lane per
+// row adds the row's products in column order, solves and publishes x.  The blocks of level l + 1 are requested before the rows of level l are summed (they do not
+// depend on the sweep).  LDS: xs [n_top] | row descriptors [n_top] | first term of a row [n_top] | products [most terms of a level].
+constexpr int BWD1_ROUNDS = 6;                                    // a level holds at most 6 x 1024 terms (else: k_bwd1_top)
+__global__ __launch_bounds__(1024) void k_bwd1_top2(Bwd1Args a) {
+    extern __shared__ __attribute__((aligned(16))) double red[];
+    double2* xs = (double2*)red;
+    int4* rowd = (int4*)(xs + a.n_top);
+    double2* prod = (double2*)(rowd + a.n_top);
+    int* toff = (int*)(prod + a.max_terms);
+    __shared__ int lvl[64], jb0[64], jbn[64];
+    int grp, bx;
+    if (!map_block(a.sel, a.ld, 1, grp, bx)) return;
+    const size_t b = (size_t)grp * 64, ld = (size_t)a.ld;
+    const int tid = threadIdx.x, wv = uniform(tid >> 6);
+    if (tid <= a.n_top_levels && tid < 64) lvl[tid] = a.t_level[tid];
+    if (tid < a.n_top_levels && tid < 64) { jb0[tid] = a.t_jb[2 * tid]; jbn[tid] = a.t_jb[2 * tid + 1]; }
+    for (int r = tid; r < a.n_top; r += 1024) { rowd[r] = *(const int4*)(a.t_row + 4 * (size_t)r); toff[r] = a.t_toff[r]; }
+    const bool act = upd1_active(a.upd, b);
+    __syncthreads();
+    double2 m0[BWD1_ROUNDS], m1[BWD1_ROUNDS]; int cs[BWD1_ROUNDS];
+#pragma unroll
+    for (int u = 0; u < BWD1_ROUNDS; ++u) { m0[u] = m1[u] = double2{0.0, 0.0}; cs[u] = 0; }
+    auto request = [&](int L) {                                   // blocks and column slots of level L: lane tid of round u takes term u * 1024 + tid
+        const int g0 = jb0[L], nt = jbn[L];
+#pragma unroll
+        for (int u = 0; u < BWD1_ROUNDS; ++u) {
+            if (u * 1024 + wv * 64 < nt) {                        // (wave-uniform: a wave beyond the level's terms issues nothing)
+                const int g = g0 + min(u * 1024 + tid, nt - 1);
+                const double2* p = (const double2*)(a.jc + (size_t)g * 4);
+                m0[u] = p[0]; m1[u] = p[1];
+                cs[u] = a.t_cslot[g];
+            }
+        }
+    };
+    request(0);
+    for (int L = 0; L < a.n_top_levels; ++L) {
+        const int r0 = lvl[L], nrow = lvl[L + 1] - r0, nt = jbn[L];
+        const int row = r0 + tid;
+        // the row of this thread: right-hand side and diagonal block leave now and are back when the products are in LDS (asked for one level ahead, together with
+        // the blocks, they were no faster: 1.070 against 1.060 ms per solve, tools/experiments/r06_bwd1_ab.sh)
+        int4 d{0, 0, 0, 0};
+        double2 yk{0.0, 0.0}; Blk dg{0.0, 0.0, 0.0, 0.0};
+        if (tid < nrow) { d = rowd[row]; yk = load_vec(a.W, (size_t)d.x, b, ld); dg = load_blk(a.X, (size_t)d.z, b, ld); }
+#pragma unroll
+        for (int u = 0; u < BWD1_ROUNDS; ++u) {
+            const int t = u * 1024 + tid;
+            if (u * 1024 + wv * 64 < nt && t < nt) {
+                const double2 x = xs[cs[u]];
+                prod[t] = double2{m0[u].x * x.x + m0[u].y * x.y, m1[u].x * x.x + m1[u].y * x.y};
+            }
+        }
+        if (L + 1 < a.n_top_levels) request(L + 1);
+        lds_barrier();
+        if (tid < nrow) {
+            double s0 = 0.0, s1 = 0.0;
+            const double2* pp = prod + toff[row];
+            for (int t = 0; t < d.w; ++t) { const double2 v = pp[t]; s0 += v.x; s1 += v.y; }
+            double x0, x1;
+            dsolve(dg, yk.x - s0, yk.y - s1, x0, x1);
+            xs[row] = double2{x0, x1};
+        }
+        lds_barrier();
+    }
+    for (int row = tid; row < a.n_top; row += 1024) {             // the solution leaves in one pass (k_bwd1_top)
+        const int4 d = rowd[row];
+        const Upd1 up = upd1_prefetch(a.upd, act, d.y, b, ld);
+        const double2 x = xs[row];
+        store_vec(a.W, (size_t)d.x, b, ld, x.x, x.y);
+        if (!a.upd.va || up.act) store_vec(a.out, (size_t)d.y, b, ld, x.x, x.y);
+        if (a.upd.va) {
+            if (up.act && (up.fl & 1)) a.upd.va[(size_t)d.y * ld + b] = up.va + a.upd.sign * x.x;
+            if (up.act && (up.fl & 2)) a.upd.vm[(size_t)d.y * ld + b] = up.vm + a.upd.sign * x.y;
+        }
     }
 }
 
@@ -1917,6 +2009,7 @@ SharedPlan::~SharedPlan() {
     hipFree(pre_row); hipFree(bwd_chain); hipFree(top_data); hipFree(top_wgmap);
     hipFree(bwdj_rec); hipFree(bwdj_seg);
     hipFree(f1_rec); hipFree(f1_first); hipFree(f1_wg); hipFree(f2_first);
+    hipFree(s1_t_jb); hipFree(s1_t_cslot); hipFree(s1_t_toff);
     hipFree(s1_t_row); hipFree(s1_t_ptr); hipFree(s1_t_term); hipFree(s1_t_level); hipFree(s1_b_wg); hipFree(s1_b_row); hipFree(s1_b_term);
 }
 
@@ -2085,12 +2178,16 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, long long 
                 if (upload(&plan->s1_t_row, T.t_row, error, st) || upload(&plan->s1_t_ptr, T.t_ptr, error, st) || upload(&plan->s1_t_term, T.t_term, error, st) ||
                     upload(&plan->s1_t_level, T.t_level, error, st) || upload(&plan->s1_b_wg, T.b_wg, error, st) || upload(&plan->s1_b_row, T.b_row, error, st) ||
                     upload(&plan->s1_b_term, T.b_term, error, st)) return 2;
-                for (std::vector<int>* v : {&T.t_row, &T.t_ptr, &T.t_term, &T.t_level, &T.b_wg, &T.b_row, &T.b_term}) std::vector<int>().swap(*v);
+                // terms as lanes (k_bwd1_top2): a level's rows on one thread each, its terms in BWD1_ROUNDS rounds of the workgroup, everything in its LDS
+                if (T.flat_ok && (T.max_level_rows > 1024 || T.max_level_terms > BWD1_ROUNDS * 1024 || (size_t)T.n_top * 36 + (size_t)T.max_level_terms * 16 > 144 * 1024)) T.flat_ok = false;
+                if (T.flat_ok && (upload(&plan->s1_t_jb, T.t_jb, error, st) || upload(&plan->s1_t_cslot, T.t_cslot, error, st) || upload(&plan->s1_t_toff, T.t_toff, error, st))) return 2;
+                for (std::vector<int>* v : {&T.t_row, &T.t_ptr, &T.t_term, &T.t_level, &T.b_wg, &T.b_row, &T.b_term, &T.t_jb, &T.t_cslot, &T.t_toff}) std::vector<int>().swap(*v);
             }
         }
         single_bwd = plan->single.ok;
         if (single_bwd) {
             JG_HIP(hipFuncSetAttribute((const void*)k_bwd1_top, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+            JG_HIP(hipFuncSetAttribute((const void*)k_bwd1_top2, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
             const size_t jb = (size_t)std::max(plan->S.n_jordan, 1) * 4 * sizeof(double);
             JG_HIP(hipMalloc((void**)&jc, jb));
             JG_HIP(sync_fill(jc, 0, jb, st));
@@ -2317,8 +2414,11 @@ int Engine::set_shared_matrix(hipStream_t st, const double* blocks_host) {
 int Engine::backsolve(hipStream_t st, double* out, const StateUpdate& upd, const GroupSel& sel) {
     if (single_bwd && jordan) {                                  // ONE scenario: rows per lane, two launches (k_bwd1_top, k_bwd1_bottom)
         const SingleTables& T = plan->single;
-        Bwd1Args s{plan->s1_t_row, plan->s1_t_ptr, plan->s1_t_term, plan->s1_t_level, plan->s1_b_wg, plan->s1_b_row, plan->s1_b_term, X, jc, W, out, sel, upd, ld, T.n_top_levels, T.n_wg, T.n_top};
-        hipLaunchKernelGGL(k_bwd1_top, dim3(grid_blocks(ld / 64, 1)), dim3(1024), (size_t)T.n_top * 40, st, s);
+        Bwd1Args s{plan->s1_t_row, plan->s1_t_ptr, plan->s1_t_term, plan->s1_t_level, plan->s1_b_wg, plan->s1_b_row, plan->s1_b_term, X, jc, W, out, sel, upd, ld, T.n_top_levels, T.n_wg, T.n_top,
+                   plan->s1_t_jb, plan->s1_t_cslot, plan->s1_t_toff, T.max_level_terms};
+        static const int flat_env = knob("SINGLE", 1);            // JG_SINGLE=2: the quad-per-row sweep (k_bwd1_top) where the terms-as-lanes one would run
+        if (T.flat_ok && flat_env != 2) hipLaunchKernelGGL(k_bwd1_top2, dim3(grid_blocks(ld / 64, 1)), dim3(1024), (size_t)T.n_top * 36 + (size_t)T.max_level_terms * 16, st, s);
+        else hipLaunchKernelGGL(k_bwd1_top, dim3(grid_blocks(ld / 64, 1)), dim3(1024), (size_t)T.n_top * 40, st, s);
         if (T.n_wg > 0) hipLaunchKernelGGL(k_bwd1_bottom, dim3(grid_blocks(ld / 64, T.n_wg)), dim3(SINGLE_BOTTOM_ROWS), 0, st, s);
         JG_HIP(hipGetLastError());
         return 0;

@@ -38,7 +38,7 @@ void jg_plan_destroy(jg_plan* p) { delete p; }
 //        81 - 85 the factorisation of a single instance below the top (plans with policy bit 60, jg_symbolic.hpp: SINGLE_FACT_LEVELS): records (x16), first record of the
 //        bottom items, [workgroups][levels + 1] ranges of them, first record of the partial items, {ok, workgroups, levels, items per workgroup}
 //        90 - 97 the backward sweep of a single instance (jg_symbolic.hpp: SingleTables): {ok, top rows, top levels, bottom rows, bottom workgroups, bottom levels, rows per
-//        workgroup}, t_row (x4), t_ptr (x2), t_term, t_level, b_wg (x2), b_row (x6), b_term (x2)
+//        workgroup, terms-as-lanes form granted, most terms / rows of a level}, t_row (x4), t_ptr (x2), t_term, t_level, b_wg (x2), b_row (x6), b_term (x2), 98 - 100 t_jb (x2), t_cslot, t_toff
 // out == NULL returns the length.
 int64_t jg_plan_export(jg_plan* p, int which, int32_t* out, int64_t cap) {
     if (!p) return -1;
@@ -79,13 +79,14 @@ int64_t jg_plan_export(jg_plan* p, int which, int32_t* out, int64_t cap) {
         case 83: v = &S.f1_wg; break;
         case 84: v = &S.f2_first; break;
         case 85: tmp = {S.single_fact_ok ? 1 : 0, S.n_f1_wg, jg::SINGLE_FACT_LEVELS, jg::SINGLE_FACT_ITEMS}; v = &tmp; break;
-        case 90: case 91: case 92: case 93: case 94: case 95: case 96: case 97: {
+        case 90: case 91: case 92: case 93: case 94: case 95: case 96: case 97: case 98: case 99: case 100: {
             jg::SingleTables T;
             jg::build_single_tables(S, T);
             switch (which) {
-                case 90: tmp = {T.ok ? 1 : 0, T.n_top, T.n_top_levels, T.n_bottom, T.n_wg, T.b_levels, jg::SINGLE_BOTTOM_ROWS}; break;
+                case 90: tmp = {T.ok ? 1 : 0, T.n_top, T.n_top_levels, T.n_bottom, T.n_wg, T.b_levels, jg::SINGLE_BOTTOM_ROWS, T.flat_ok ? 1 : 0, T.max_level_terms, T.max_level_rows}; break;
                 case 91: tmp = T.t_row; break;  case 92: tmp = T.t_ptr; break;  case 93: tmp = T.t_term; break;  case 94: tmp = T.t_level; break;
-                case 95: tmp = T.b_wg; break;   case 96: tmp = T.b_row; break;  default: tmp = T.b_term; break;
+                case 95: tmp = T.b_wg; break;   case 96: tmp = T.b_row; break;  case 97: tmp = T.b_term; break;
+                case 98: tmp = T.t_jb; break;   case 99: tmp = T.t_cslot; break; default: tmp = T.t_toff; break;
             }
             v = &tmp; break;
         }

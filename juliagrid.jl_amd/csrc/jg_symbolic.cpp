@@ -1221,6 +1221,32 @@ void build_single_tables(const BlockSymbolic& S, SingleTables& T) {
         T.t_ptr.push_back(e > 0 ? jrow[k] - S.n_entries : 0); T.t_ptr.push_back(slist[root]);
     }
     if (T.t_term.empty()) T.t_term.push_back(0);
+    // terms as lanes: the compact blocks of a level must follow each other in (row, column) order (levels themselves sit in reverse order: the tasks were numbered leaves first)
+    {
+        T.flat_ok = true;
+        T.t_jb.assign(2 * (size_t)max_tl, 0);                   // per level: first compact block, terms
+        T.t_cslot.assign((size_t)std::max(S.n_jordan, 1), 0);
+        long long covered = 0;
+        for (int l = 0; l < max_tl; ++l) {
+            T.max_level_rows = std::max(T.max_level_rows, T.t_level[l + 1] - T.t_level[l]);
+            int first = -1, terms = 0;
+            for (int i = T.t_level[l]; i < T.t_level[l + 1]; ++i) {
+                const int e = T.t_row[4 * i + 3], jb = T.t_ptr[2 * i], sl = T.t_ptr[2 * i + 1];
+                T.t_toff.push_back(terms);
+                if (e == 0) continue;
+                if (first < 0) first = jb;
+                if (jb != first + terms || jb + e > S.n_jordan) { T.flat_ok = false; break; }
+                for (int t = 0; t < e; ++t) T.t_cslot[jb + t] = T.t_term[sl + t];
+                terms += e;
+            }
+            if (!T.flat_ok) break;
+            T.t_jb[2 * l] = std::max(first, 0); T.t_jb[2 * l + 1] = terms;
+            T.max_level_terms = std::max(T.max_level_terms, terms);
+            covered += terms;
+        }
+        if (covered != S.n_jordan) T.flat_ok = false;            // (every block of the Jordan rows is some row's term)
+        if ((int)T.t_toff.size() != T.n_top) T.flat_ok = false;
+    }
     // ---- bottom rows: whole subtrees per workgroup
     auto is_top = [&](int k) { return jroot[k] >= 0; };
     auto parent = [&](int k) { return S.u_ptr[k + 1] > S.u_ptr[k] ? S.u_col[S.u_ptr[k]] : -1; };

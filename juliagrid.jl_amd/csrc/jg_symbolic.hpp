@@ -261,6 +261,11 @@ struct SingleTables {
     bool ok = false;                    // false: the plan does not qualify (no Jordan rows, a subtree above SINGLE_BOTTOM_ROWS rows, ...)
     int n_top = 0, n_top_levels = 0;
     std::vector<int> t_row, t_ptr, t_term, t_level;     // t_level [n_top_levels + 1]
+    // the same rows with the TERMS as lanes (k_bwd1_top2): the compact Jordan blocks of a level are contiguous and in (row, column) order, so term g of the plan is
+    // one lane's work -- block g, the slot of its column (t_cslot[g]) -- and a row sums its products from LDS (t_toff[row]: its first term inside its level)
+    bool flat_ok = false;                               // false: the blocks of some level are not contiguous in row order (k_bwd1_top sweeps instead)
+    std::vector<int> t_jb, t_cslot, t_toff;             // t_jb [n_top_levels][2]: first compact block of the level, its terms; t_cslot [n_jordan]; t_toff [n_top]
+    int max_level_terms = 0, max_level_rows = 0;
     int n_bottom = 0, n_wg = 0, b_levels = 0;
     std::vector<int> b_wg;                              // [n_wg + 1][2]: first row, levels of the workgroup
     std::vector<int> b_row, b_term;

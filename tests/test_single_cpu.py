@@ -48,6 +48,7 @@ def _single_backward(plan, X, Y, nE):
     info = g(90)
     assert info[0] == 1
     n_top, n_lev, n_bottom, n_wg, b_levels, rows_per_wg = (int(v) for v in info[1:7])
+    flat = 0
     t_row, t_ptr, t_term, t_level = g(91).reshape(-1, 4), g(92).reshape(-1, 2), g(93), g(94)
     b_wg, b_row, b_term = g(95).reshape(-1, 2), g(96).reshape(-1, 6), g(97).reshape(-1, 2)
     n = plan.n
@@ -69,6 +70,27 @@ def _single_backward(plan, X, Y, nE):
         for row, k, x in new:
             xs[row] = x; W[k] = x; done[k] = True
     assert not np.isnan(xs).any()
+    # the same levels with the TERMS as lanes (k_bwd1_top2): a level's compact blocks follow each other in (row, column) order
+    if info[7]:
+        t_jb, t_cslot, t_toff = g(98).reshape(-1, 2), g(99), g(100)
+        xs2 = np.full((n_top, 2), np.nan)
+        covered = 0
+        for L in range(n_lev):
+            g0, nt = (int(v) for v in t_jb[L])
+            assert nt <= info[8] and t_level[L + 1] - t_level[L] <= info[9]
+            prod = np.zeros((nt, 2))
+            for t in range(nt):
+                slot = int(t_cslot[g0 + t])
+                assert slot < t_level[L], "a term reads a column of its own or a later level"
+                prod[t] = X[nE + g0 + t] @ xs2[slot]
+            for row in range(t_level[L], t_level[L + 1]):
+                k, bus, dg, e = (int(v) for v in t_row[row])
+                o = int(t_toff[row])
+                assert e == 0 or (int(t_ptr[row][0]) == g0 + o and o + e <= nt), "the row's blocks are not where its products are"
+                xs2[row] = dsolve(X[dg], Y[k] - prod[o: o + e].sum(axis=0))
+            covered += nt
+        assert covered == len(t_cslot) or (covered == 0 and len(t_cslot) == 1)
+        assert np.abs(xs2 - xs).max() <= 1e-10 * max(1.0, np.abs(xs).max())
     assert n_top + n_bottom == n
     for w in range(n_wg):
         r0, levels, r1 = int(b_wg[w, 0]), int(b_wg[w, 1]), int(b_wg[w + 1, 0])
@@ -142,6 +164,7 @@ def test_single_tables_on_the_headline_grid(jg):
     finfo, binfo = plan.get(85), plan.get(90)
     assert finfo[0] == 1 and binfo[0] == 1
     assert binfo[1] + binfo[3] == Y.n and 4 <= binfo[2] <= 12 and binfo[5] <= 6
+    assert binfo[7] == 1 and binfo[8] <= 6 * 1024 and binfo[9] <= 1024        # the terms-as-lanes sweep of the top is granted on the headline grid
     f1_wg = plan.get(83).reshape(-1, int(finfo[2]) + 1)
     assert f1_wg.shape[0] == finfo[1] and (np.diff(f1_wg, axis=1) >= 0).all()
     assert (f1_wg[:, -1] - f1_wg[:, 0]).max() <= max(int(finfo[3]), 64 * 8)

@@ -104,6 +104,9 @@ def test_single_instance_kernels_match_the_level_launches(tmp_path, case):
     assert int(np.atleast_1d(ref["st"])[0]) == 0
     assert np.array_equal(ref["it"], lvl["it"]) and np.array_equal(ref["st"], lvl["st"])
     assert np.abs(ref["vm"] - lvl["vm"]).max() < 1e-10 and np.abs(ref["va"] - lvl["va"]).max() < 1e-10
+    quad = _state(tmp_path, "quad", case, 1, dict(JG_SINGLE=2))     # the top's sweep with a quad of lanes per row (k_bwd1_top) instead of the terms as lanes (k_bwd1_top2)
+    assert np.array_equal(ref["it"], quad["it"]) and np.array_equal(ref["st"], quad["st"])
+    assert np.abs(ref["vm"] - quad["vm"]).max() < 1e-10 and np.abs(ref["va"] - quad["va"]).max() < 1e-10
 
 
 def test_refined_steps_switch_the_engine_back_to_plain_rows(jg):
