@@ -57,7 +57,9 @@ done
 cd $REPO
 python tools/r06_pmc_comp.py gpurun_out/pmc_${T}_comp_FETCH_SIZE/p_counter_collection.csv gpurun_out/pmc_${T}_comp_WRITE_SIZE/p_counter_collection.csv 10000 512 gpurun_out/pmc_${T}_comp.json > gpurun_out/run_pmc_${T}_comp.log 2>&1
 python tools/pmc_se_summary.py gpurun_out/pmc_${T}_se_FETCH_SIZE/p_counter_collection.csv gpurun_out/pmc_${T}_se_WRITE_SIZE/p_counter_collection.csv 2 gpurun_out/pmc_${T}_se.json > gpurun_out/run_pmc_${T}_se.log 2>&1
-for c in case1354pegase case9241synth case_ACTIVSg10k; do python tools/r06_single_probe.py $c 8 2>&1 | tail -1; done > gpurun_out/single_$T.txt
+for c in case1354pegase case9241synth case_ACTIVSg10k; do python tools/r06_single_probe.py $c 8 2>&1 | tail -1; JG_SINGLE=0 python tools/r06_single_probe.py $c 8 2>&1 | tail -1 | sed 's/^/JG_SINGLE=0 (level launches) /'; done > gpurun_out/single_$T.txt
+timeout 300 bash tools/r06_single_timeline.sh case_ACTIVSg10k case9241synth case1354pegase > /dev/null 2>&1      # kernel traces of a warm single-instance solve: gpurun_out/single_timeline_<case>.txt
+JG_TOP_PROFILE=1 timeout 120 python tools/time_kernels.py 1 case_ACTIVSg10k 5 2>&1 | grep "top profile" | cut -c18- > gpurun_out/top_task_profile_single_$T.txt
 python tools/r06_comp_profile.py -1 64 128 256 512 768 1024 1536 2048 2>&1 | grep top_cap > gpurun_out/comp_top_sweep_$T.txt
 tools/r06_merge_sweep.sh > gpurun_out/merge_sweep_$T.txt 2>&1
 tools/r06_n8_shape.sh > gpurun_out/n8_shape_$T.txt 2>&1

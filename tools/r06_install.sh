@@ -20,5 +20,7 @@ PY
 grep -v "^calibration\|^{" $G/run_pmc_$T.log > $P/${T}_pmc_b512_per_kernel.txt; grep "^calibration\|^{" $G/run_pmc_$T.log >> $P/${T}_pmc_b512_per_kernel.txt
 cp $G/run_pmc_${T}_comp.log $P/${T}_pmc_first_iteration_per_kernel.txt
 cp $G/run_pmc_${T}_se.log $P/${T}_pmc_se_9241_per_kernel.txt
-for f in single comp_top_sweep merge_sweep n8_shape fast timeline bench_1354_lanes; do [ -s $G/${f}_$T.txt ] && cp $G/${f}_$T.txt $P/${T}_${f}.txt; done
+for f in single comp_top_sweep merge_sweep n8_shape fast timeline bench_1354_lanes top_task_profile_single; do [ -s $G/${f}_$T.txt ] && cp $G/${f}_$T.txt $P/${T}_${f}.txt; done
+[ -s $G/single_timeline_case_ACTIVSg10k.txt ] && cp $G/single_timeline_case_ACTIVSg10k.txt $P/${T}_single_timeline.txt
+for c in case9241synth case1354pegase; do [ -s $G/single_timeline_$c.txt ] && cp $G/single_timeline_$c.txt $P/${T}_single_timeline_$c.txt; done
 git status --short $P | head -40
