@@ -198,6 +198,106 @@ __global__ __launch_bounds__(64 * WAVES) void k_assemble(AsmArgs a) {
     }
 }
 
+// The assembly of ONE scenario (round 6): a THREAD per bus row.  k_assemble gives a wave to a row of 64 scenarios and walks four rows one after the other; with one
+// scenario that is four times three dependent round trips per wave (row header, Ybus entries, V / theta gathers) around the work of one lane.  Same arithmetic per
+// row, operation for operation (the leaf pivots of a prefactor plan leave factorised, the rhs row with them); the chunk maxima of sixteen rows meet through shuffles.
+template <int MP, bool JAC>
+__global__ __launch_bounds__(256) void k_assemble1(AsmArgs a) {
+    int grp, bx;
+    if (!jg::map_block(a.sel, a.ld, (a.n + 255) / 256, grp, bx)) return;
+    const size_t ld = (size_t)a.ld;
+    const size_t b = (size_t)grp * 64;
+    const int i0 = bx * 256 + (int)threadIdx.x;
+    const bool live = i0 < a.n;
+    const int i = live ? i0 : a.n - 1;
+    int ppos[MP > 0 ? MP : 1];
+#pragma unroll
+    for (int m = 0; m < MP; ++m) ppos[m] = a.ppos[(size_t)m * ld + b];
+    const int p0 = a.rowptr[i], p1 = live ? a.rowptr[i + 1] : p0;
+    const int tfull = (int)((unsigned)a.rowtype[i]);
+    const int ti = tfull & 3, pre = tfull >> 2;
+    const double vi = a.vm[(size_t)i * ld + b];
+    const double thi = a.va[(size_t)i * ld + b];
+    const double pinj = a.p[(size_t)i * ld + b], qinj = a.q[(size_t)i * ld + b];
+    double s1 = 0.0, s2 = 0.0, gii = 0.0, bii = 0.0;
+    int pd = 0;
+    for (int pc = p0; pc < p1; pc += CH) {
+        const int cnt = min(CH, p1 - pc);
+        int cm[CH], de[CH]; double2 gb[CH]; double vv[CH], tt[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int p = pc + (k < cnt ? k : 0);
+            cm[k] = a.colm[p];
+            de[k] = JAC ? a.dst[p] : 0;
+            gb[k] = a.GB[p];
+        }
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const size_t j = (size_t)(cm[k] & 0xffffff);
+            vv[k] = a.vm[j * ld + b];
+            tt[k] = a.va[j * ld + b];
+        }
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            if (k < cnt) {
+                const int p = pc + k;
+                const int j = cm[k] & 0xffffff;
+                const int mk = cm[k] >> 24;
+                double g = gb[k].x, bb = gb[k].y;
+#pragma unroll
+                for (int m = 0; m < MP; ++m)
+                    if (ppos[m] == p) { g += a.pdg[(size_t)m * ld + b]; bb += a.pdb[(size_t)m * ld + b]; }
+                const double vj = vv[k];
+                double s, c;
+                sincos(thi - tt[k], &s, &c);
+                const double ac = g * c + bb * s;
+                const double ad = g * s - bb * c;
+                s1 += vj * ac;
+                s2 += vj * ad;
+                if (j == i) { pd = de[k]; gii = g; bii = bb; }
+                else if (JAC) {
+                    jg::store_blk(a.A, (size_t)de[k], b, ld,
+                                  (mk & 1) ? vi * vj * ad : 0.0, (mk & 2) ? vi * ac : 0.0, (mk & 4) ? -(vi * vj) * ac : 0.0, (mk & 8) ? vi * ad : 0.0);
+                }
+            }
+        }
+    }
+    double fp = vi * s1 - pinj;
+    double fq = vi * s2 - qinj;
+    double d00 = -vi * s2 - bii * (vi * vi);
+    double d01 = s1 + gii * vi;
+    double d10 = vi * s1 - gii * (vi * vi);
+    double d11 = s2 - bii * vi;
+    if (ti == 3) { d00 = 1.0; d01 = 0.0; d10 = 0.0; d11 = 1.0; fp = 0.0; fq = 0.0; }
+    else if (ti == 2) { d01 = 0.0; d10 = 0.0; d11 = 1.0; fq = 0.0; }
+    if (live) {
+        if (JAC) {
+            if (pre) {
+                const jg::Blk raw{d00, d01, d10, d11};
+                bool bad;
+                const jg::Blk f = jg::diag_lu(raw, jg::row_max(raw), bad);
+                if (bad) fp = __builtin_nan("");
+                d00 = f.v00; d01 = f.v01; d10 = f.v10; d11 = f.v11;
+                jg::store_vec(a.W, (size_t)pre - 1, b, ld, fp, fq);
+            }
+            jg::store_blk(a.A, (size_t)pd, b, ld, d00, d01, d10, d11);
+        }
+        jg::store_vec(a.F, (size_t)i, b, ld, fp, fq);
+    }
+    // chunk maxima (a.rows consecutive rows = a.rows consecutive lanes; NaN-propagating: a NaN mismatch must not look converged)
+    double maxp = live ? fabs(fp) : 0.0, maxq = live ? fabs(fq) : 0.0;
+    for (int d = 1; d < ASM_ROWS; d <<= 1) {
+        const double x = __shfl_xor(maxp, d), y = __shfl_xor(maxq, d);
+        maxp = (x > maxp || x != x) ? x : maxp;
+        maxq = (y > maxq || y != y) ? y : maxq;
+    }
+    if (live && (i0 & (ASM_ROWS - 1)) == 0) {
+        const size_t ck = (size_t)(i0 / ASM_ROWS);
+        a.part[(ck * 2) * ld + b] = maxp;
+        a.part[(ck * 2 + 1) * ld + b] = maxq;
+    }
+}
+
 // ---- iterative refinement of the Newton step (opt-in, jg_nr_set_refine) ------------------------------------------------
 // The reference's default solver refines: UMFPACK's solve runs up to two steps of iterative refinement behind `ldiv!`
 // (/root/reference/src/backend/utility.jl:576-586 -> umfpack_solve, UMFPACK_IRSTEP = 2), which is what covers a weak pivot
@@ -901,6 +1001,24 @@ void launch_assemble(jg_nr* h, const jg::GroupSel& sel = jg::GroupSel{}, bool ja
               h->eng.W, h->eng.status};
     if (jac && !only_if) h->level0_done = pre;
     dim3 grid(jg::grid_blocks(h->ld / 64, h->nchunk)), block(64, ASM_WAVES);
+    static const bool single_env = jg::knob("SINGLE", 1) != 0;
+    if (h->ld == 64 && h->batch == 1 && !fd_mode && !pq_out && !only_if && single_env) {      // ONE scenario: a thread per bus row (k_assemble1)
+        const dim3 g1(jg::grid_blocks(1, (h->n + 255) / 256));
+        if (jac) {
+            switch (h->mp) {
+                case 0: hipLaunchKernelGGL((k_assemble1<0, true>), g1, dim3(256), 0, h->stream, a); break;
+                case 4: hipLaunchKernelGGL((k_assemble1<4, true>), g1, dim3(256), 0, h->stream, a); break;
+                default: hipLaunchKernelGGL((k_assemble1<8, true>), g1, dim3(256), 0, h->stream, a); break;
+            }
+        } else {
+            switch (h->mp) {
+                case 0: hipLaunchKernelGGL((k_assemble1<0, false>), g1, dim3(256), 0, h->stream, a); break;
+                case 4: hipLaunchKernelGGL((k_assemble1<4, false>), g1, dim3(256), 0, h->stream, a); break;
+                default: hipLaunchKernelGGL((k_assemble1<8, false>), g1, dim3(256), 0, h->stream, a); break;
+            }
+        }
+        return;
+    }
     if (h->ld == 64 && h->batch <= 32 && !fd_mode && !pq_out) {      // a handful of scenarios: one row per wave (k_assemble: WAVES = 16); same arithmetic per row, same chunk maxima
         const bool w16 = h->nchunk <= 512;                          // grids whose workgroups are all resident at once: one row per wave; larger ones: two
         const dim3 wide(64, w16 ? 16 : 8);
@@ -2141,6 +2259,7 @@ int jg_nr_move_lanes(jg_nr* dst, int64_t dst_lane0, jg_nr* src, int32_t* home, i
     for (int i = 0; i < c; ++i) home[i] = dst->h_move[i];
     *count = c;
     *src->h_counter = 0;
+    src->res_pinned = false;                                    // (the source's last verdict saw active scenarios: nothing stands behind its pinned word -- jg_nr_finish copies)
     dst->jac_valid = false;
     return 0;
 }
