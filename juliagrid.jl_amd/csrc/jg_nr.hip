@@ -198,16 +198,19 @@ __global__ __launch_bounds__(64 * WAVES) void k_assemble(AsmArgs a) {
     }
 }
 
-// The assembly of ONE scenario (round 6): a THREAD per bus row.  k_assemble gives a wave to a row of 64 scenarios and walks four rows one after the other; with one
-// scenario that is four times three dependent round trips per wave (row header, Ybus entries, V / theta gathers) around the work of one lane.  Same arithmetic per
-// row, operation for operation (the leaf pivots of a prefactor plan leave factorised, the rhs row with them); the chunk maxima of sixteen rows meet through shuffles.
+// The assembly of ONE scenario (round 6): a QUAD of lanes per bus row.  k_assemble gives a wave to a row of 64 scenarios and walks four rows one after the other; with one
+// scenario that is four times three dependent round trips per wave (row header, Ybus entries, V / theta gathers) around the work of one lane.  Here lane q of a row's quad
+// takes its Ybus entries q, q + 4, ... two at a time (a row of 19 entries is three trips instead of five, and a trip is two sincos per lane instead of four), the row sums
+// meet through two shuffles (fixed order), lane 0 finishes the row as k_assemble does (the leaf pivots of a prefactor plan leave factorised, the rhs row with them); the
+// chunk maxima of sixteen rows meet through shuffles as well.  Same formulas per entry; the row sums add in another order (V, theta within 1e-10: tests/test_top_variants_gpu.py).
 template <int MP, bool JAC>
 __global__ __launch_bounds__(256) void k_assemble1(AsmArgs a) {
     int grp, bx;
-    if (!jg::map_block(a.sel, a.ld, (a.n + 255) / 256, grp, bx)) return;
+    if (!jg::map_block(a.sel, a.ld, (a.n + 63) / 64, grp, bx)) return;
     const size_t ld = (size_t)a.ld;
     const size_t b = (size_t)grp * 64;
-    const int i0 = bx * 256 + (int)threadIdx.x;
+    const int q = (int)threadIdx.x & 3;
+    const int i0 = bx * 64 + ((int)threadIdx.x >> 2);
     const bool live = i0 < a.n;
     const int i = live ? i0 : a.n - 1;
     int ppos[MP > 0 ? MP : 1];
@@ -221,26 +224,26 @@ __global__ __launch_bounds__(256) void k_assemble1(AsmArgs a) {
     const double pinj = a.p[(size_t)i * ld + b], qinj = a.q[(size_t)i * ld + b];
     double s1 = 0.0, s2 = 0.0, gii = 0.0, bii = 0.0;
     int pd = 0;
-    for (int pc = p0; pc < p1; pc += CH) {
-        const int cnt = min(CH, p1 - pc);
-        int cm[CH], de[CH]; double2 gb[CH]; double vv[CH], tt[CH];
+    constexpr int C2 = 2;                                         // entries per lane and trip
+    for (int pc = p0 + q; pc < p1; pc += 4 * C2) {               // this lane's entries: pc, pc + 4
+        int cm[C2], de[C2]; double2 gb[C2]; double vv[C2], tt[C2];
 #pragma unroll
-        for (int k = 0; k < CH; ++k) {
-            const int p = pc + (k < cnt ? k : 0);
+        for (int k = 0; k < C2; ++k) {
+            const int p = pc + 4 * k < p1 ? pc + 4 * k : pc;
             cm[k] = a.colm[p];
             de[k] = JAC ? a.dst[p] : 0;
             gb[k] = a.GB[p];
         }
 #pragma unroll
-        for (int k = 0; k < CH; ++k) {
+        for (int k = 0; k < C2; ++k) {
             const size_t j = (size_t)(cm[k] & 0xffffff);
             vv[k] = a.vm[j * ld + b];
             tt[k] = a.va[j * ld + b];
         }
 #pragma unroll
-        for (int k = 0; k < CH; ++k) {
-            if (k < cnt) {
-                const int p = pc + k;
+        for (int k = 0; k < C2; ++k) {
+            const int p = pc + 4 * k;
+            if (p < p1) {
                 const int j = cm[k] & 0xffffff;
                 const int mk = cm[k] >> 24;
                 double g = gb[k].x, bb = gb[k].y;
@@ -262,6 +265,12 @@ __global__ __launch_bounds__(256) void k_assemble1(AsmArgs a) {
             }
         }
     }
+    // the quad's sums; the diagonal entry sat on exactly one lane (the others hold zeros)
+#pragma unroll
+    for (int d = 1; d <= 2; d <<= 1) {
+        s1 += __shfl_xor(s1, d); s2 += __shfl_xor(s2, d);
+        gii += __shfl_xor(gii, d); bii += __shfl_xor(bii, d); pd += __shfl_xor(pd, d);
+    }
     double fp = vi * s1 - pinj;
     double fq = vi * s2 - qinj;
     double d00 = -vi * s2 - bii * (vi * vi);
@@ -270,28 +279,29 @@ __global__ __launch_bounds__(256) void k_assemble1(AsmArgs a) {
     double d11 = s2 - bii * vi;
     if (ti == 3) { d00 = 1.0; d01 = 0.0; d10 = 0.0; d11 = 1.0; fp = 0.0; fq = 0.0; }
     else if (ti == 2) { d01 = 0.0; d10 = 0.0; d11 = 1.0; fq = 0.0; }
-    if (live) {
+    if (JAC && pre) {
+        const jg::Blk raw{d00, d01, d10, d11};
+        bool bad;
+        const jg::Blk f = jg::diag_lu(raw, jg::row_max(raw), bad);
+        if (bad) fp = __builtin_nan("");
+        d00 = f.v00; d01 = f.v01; d10 = f.v10; d11 = f.v11;
+    }
+    if (live && q == 0) {
         if (JAC) {
-            if (pre) {
-                const jg::Blk raw{d00, d01, d10, d11};
-                bool bad;
-                const jg::Blk f = jg::diag_lu(raw, jg::row_max(raw), bad);
-                if (bad) fp = __builtin_nan("");
-                d00 = f.v00; d01 = f.v01; d10 = f.v10; d11 = f.v11;
-                jg::store_vec(a.W, (size_t)pre - 1, b, ld, fp, fq);
-            }
+            if (pre) jg::store_vec(a.W, (size_t)pre - 1, b, ld, fp, fq);
             jg::store_blk(a.A, (size_t)pd, b, ld, d00, d01, d10, d11);
         }
         jg::store_vec(a.F, (size_t)i, b, ld, fp, fq);
     }
-    // chunk maxima (a.rows consecutive rows = a.rows consecutive lanes; NaN-propagating: a NaN mismatch must not look converged)
+    // chunk maxima: ASM_ROWS consecutive rows = 4 ASM_ROWS consecutive lanes = one wave (NaN-propagating: a NaN mismatch must not look converged)
+    static_assert(ASM_ROWS == 16, "a chunk of rows is one wave of quads");
     double maxp = live ? fabs(fp) : 0.0, maxq = live ? fabs(fq) : 0.0;
-    for (int d = 1; d < ASM_ROWS; d <<= 1) {
+    for (int d = 4; d < 64; d <<= 1) {
         const double x = __shfl_xor(maxp, d), y = __shfl_xor(maxq, d);
         maxp = (x > maxp || x != x) ? x : maxp;
         maxq = (y > maxq || y != y) ? y : maxq;
     }
-    if (live && (i0 & (ASM_ROWS - 1)) == 0) {
+    if (live && ((int)threadIdx.x & 63) == 0) {
         const size_t ck = (size_t)(i0 / ASM_ROWS);
         a.part[(ck * 2) * ld + b] = maxp;
         a.part[(ck * 2 + 1) * ld + b] = maxq;
@@ -1002,8 +1012,8 @@ void launch_assemble(jg_nr* h, const jg::GroupSel& sel = jg::GroupSel{}, bool ja
     if (jac && !only_if) h->level0_done = pre;
     dim3 grid(jg::grid_blocks(h->ld / 64, h->nchunk)), block(64, ASM_WAVES);
     static const bool single_env = jg::knob("SINGLE", 1) != 0;
-    if (h->ld == 64 && h->batch == 1 && !fd_mode && !pq_out && !only_if && single_env) {      // ONE scenario: a thread per bus row (k_assemble1)
-        const dim3 g1(jg::grid_blocks(1, (h->n + 255) / 256));
+    if (h->ld == 64 && h->batch == 1 && !fd_mode && !pq_out && !only_if && single_env) {      // ONE scenario: a quad of lanes per bus row (k_assemble1)
+        const dim3 g1(jg::grid_blocks(1, (h->n + 63) / 64));
         if (jac) {
             switch (h->mp) {
                 case 0: hipLaunchKernelGGL((k_assemble1<0, true>), g1, dim3(256), 0, h->stream, a); break;
