@@ -936,6 +936,7 @@ struct jg_nr {
     hipStream_t stream = nullptr;
     hipGraph_t graphA = nullptr, graphB = nullptr, graphBm = nullptr, graphJ = nullptr;
     hipGraphExec_t execA = nullptr, execB = nullptr, execBm = nullptr, execJ = nullptr;   // Bm / J: an iteration whose verdict assembles NO Jacobian / the Jacobian alone (run_loop)
+    hipGraph_t graphM = nullptr; hipGraphExec_t execM = nullptr; int m_iters = 0;          // ONE scenario: a whole solve of m_iters iterations as one graph (run_whole)
     int stop_hint = 0, iter_graphs = 0;               // iteration graphs after which the last run of this handle stopped / launched by the current run
     long long last_guess_hit = 0, last_guess_miss = 0;
     bool jac_valid = false;
@@ -1312,8 +1313,43 @@ int build_graphs(jg_nr* h) {
 }
 
 void drop_iteration_graphs(jg_nr* h) {
-    for (hipGraphExec_t* e : {&h->execA, &h->execB, &h->execBm, &h->execJ}) if (*e) { hipGraphExecDestroy(*e); *e = nullptr; }
-    for (hipGraph_t* g : {&h->graphA, &h->graphB, &h->graphBm, &h->graphJ}) if (*g) { hipGraphDestroy(*g); *g = nullptr; }
+    for (hipGraphExec_t* e : {&h->execA, &h->execB, &h->execBm, &h->execJ, &h->execM}) if (*e) { hipGraphExecDestroy(*e); *e = nullptr; }
+    for (hipGraph_t* g : {&h->graphA, &h->graphB, &h->graphBm, &h->graphJ, &h->graphM}) if (*g) { hipGraphDestroy(*g); *g = nullptr; }
+    h->m_iters = 0;
+}
+
+// ONE scenario: the whole solve as ONE graph (round 6).  Every graph costs ~10 us on the device before its first kernel starts (the gap between two iteration graphs in
+// the trace; launching the next graph ahead of the verdict did not close it), and a single instance launches one per iteration + one for the verdict on its start: 5 % of
+// its solve.  A handle of one scenario that has solved before knows how many iterations to expect (stop_hint); its next solve is the start verdict + that many iterations
+// in one graph -- only the LAST verdict reports to the host, from a mismatch-only pass as in graph Bm; an iteration behind the convergence runs as launches that return
+// at once (the group list is empty).  Fewer iterations than expected: nothing to do; more: graph J supplies the Jacobian and run_loop carries on.
+int build_whole_graph(jg_nr* h, int k) {
+    if (h->execM && h->m_iters == k) return 0;
+    if (h->execM) { hipGraphExecDestroy(h->execM); h->execM = nullptr; }
+    if (h->graphM) { hipGraphDestroy(h->graphM); h->graphM = nullptr; }
+    h->m_iters = 0;
+    std::lock_guard<std::mutex> lk(jg::capture_mutex());
+    NR_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    auto verdict64 = [&](bool report) {
+        CheckArgs c{h->d_part, h->nchunk, h->ld, h->batch, h->d_params, h->d_normp, h->d_normq, h->d_active, h->d_iters, h->d_status, h->eng.status, h->d_counter, h->d_group, 1};
+        CompactArgs p{h->d_active, h->d_iters, h->d_status, h->eng.status, h->d_lid, h->d_ppos, h->mp, h->d_dest, h->d_group,
+                      h->d_glist, h->d_cflags, h->d_itmp, h->ld, 0, report ? h->h_counter_dev : nullptr, report ? h->h_counter_dev + 1 : nullptr, h->d_params};
+        hipLaunchKernelGGL(k_verdict64, dim3(1), dim3(64, 16), 0, h->stream, c, p);
+    };
+    launch_assemble(h, active_groups(h), true, nullptr, 0, nullptr, true);       // the verdict on the start point (graph A)
+    verdict64(false);
+    int rc = 0;
+    for (int it = 1; it <= k && !rc; ++it) {
+        rc = newton_step(h, active_groups(h), h->d_active);
+        if (it < k) { launch_assemble(h, active_groups(h), true, nullptr, 0, nullptr, true); verdict64(false); }      // graph B
+        else { launch_assemble(h, active_groups(h), false); verdict64(true); }                                         // graph Bm: the expected last iteration
+    }
+    hipError_t e = hipStreamEndCapture(h->stream, &h->graphM);
+    if (rc) return fail(rc, h->eng.error);
+    NR_HIP(e);
+    NR_HIP(hipGraphInstantiate(&h->execM, h->graphM, nullptr, nullptr, 0));
+    h->m_iters = k;
+    return 0;
 }
 
 void drop_comp_graphs(jg_nr* h) {
@@ -1938,14 +1974,14 @@ int run_setup(jg_nr* h, int64_t max_iter, double tol, int lanes, bool keep_iters
 constexpr double POLL_BELOW_US = 800.0;   // a handle whose waits average more than this blocks in hipStreamSynchronize instead
 static bool poll_enabled() { static const bool on = jg::knob("POLL", 1) != 0; return on; }
 static void arm_verdict(jg_nr* h) { if (poll_enabled()) *(volatile int*)h->h_counter = -1; }
-static hipError_t wait_verdict(jg_nr* h) {
+static hipError_t wait_verdict(jg_nr* h, bool whole = false) {    // whole: the wait is a whole solve of one scenario (run_whole): polled whatever its length, and not counted into wait_us
     const auto t0 = std::chrono::steady_clock::now();
     auto elapsed = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); };
     // Polling pays where an iteration is SHORT (a single instance of the 10k-bus grid: 366 us per iteration; 1.595 ms per solve spinning against 1.656 with the
     // synchronise).  Where it is long -- a 512-lane batch: 1.6 ms, three of them in flight on a thread each -- the blocking wait is the right one: measured on one
     // box, interleaved (profiles/r05_poll_ab.txt), the pipeline loses 7 - 10 % to three spinning / napping host threads (254 - 264k against 282 - 287k NR it/s at
     // the driver's K = 20).  The handle remembers how long its last waits took and picks by that.
-    if (!poll_enabled() || h->wait_us > POLL_BELOW_US) {
+    if (!poll_enabled() || (!whole && h->wait_us > POLL_BELOW_US)) {
         const hipError_t e = hipStreamSynchronize(h->stream);
         h->wait_us = 0.5 * h->wait_us + 0.5 * elapsed();
         return e;
@@ -1961,7 +1997,7 @@ static hipError_t wait_verdict(jg_nr* h) {
         __builtin_ia32_pause();
 #endif
     }
-    h->wait_us = 0.5 * h->wait_us + 0.5 * elapsed();
+    if (!whole) h->wait_us = 0.5 * h->wait_us + 0.5 * elapsed();
     return hipSuccess;
 }
 
@@ -2026,6 +2062,31 @@ int run_start(jg_nr* h, int64_t max_iter) {
     h->iter_graphs = 1;
     if (trace) fprintf(stderr, "[jg_nr_run] iteration 1 on the shared base factor: %.1f us, %d scenarios still active\n",
                        std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0, *h->h_counter);
+    return 0;
+}
+
+// ONE scenario whose last run iterated: start verdict + that many iterations as one graph (build_whole_graph).  -1: the handle does not qualify (run_start / run_loop).
+int run_whole(jg_nr* h, int64_t max_iter) {
+    static const bool on = jg::knob("SINGLE", 1) == 1;
+    const int k = h->stop_hint;
+    if (!on || h->ld != 64 || h->batch != 1 || k < 1 || k > 12 || (int64_t)k > max_iter || h->refine || jg::knob_set("TRACE") || jg::knob_set("HOST_TIMING")) return -1;
+    bool comp = false;
+    if (int rc = comp_ready(h, comp)) return rc;
+    if (comp) return -1;                                         // a base case is attached: the compensated start (run_start)
+    if (int rc = build_whole_graph(h, k)) return rc;
+    h->start_is_base = false;
+    h->first_full += 1;
+    arm_verdict(h);
+    NR_HIP(hipGraphLaunch(h->execM, h->stream));
+    NR_HIP(wait_verdict(h, true));
+    h->iter_graphs = k;
+    if (*h->h_counter != 0) {                                    // more iterations than the last run took: the Jacobian of the new state, then the loop
+        h->last_guess_miss += 1;
+        NR_HIP(hipGraphLaunch(h->execJ, h->stream));
+        return run_loop(h, max_iter, 0);
+    }
+    h->last_guess_hit += 1;
+    h->stop_hint = std::max(1, (int)h->h_counter[1]);            // the iterations this solve took (pinned: k_verdict64) -- fewer than k: the next solve's graph shrinks
     return 0;
 }
 
@@ -2208,8 +2269,12 @@ int jg_nr_run(jg_nr* h, int64_t max_iter, double tol, int32_t* iters, int32_t* s
     if (h->fast) return fail(1, "jg_nr_run: this handle runs fast Newton-Raphson; use jg_nr_fast_run");
     if (int rc = set_device(h)) return rc;
     if (int rc = run_setup(h, max_iter, tol, h->batch, false)) return rc;
-    if (int rc = run_start(h, max_iter)) return rc;                            // acPowerFlow.jl:1406: mismatch!, verdict (+ a compensated first iteration)
-    if (int rc = run_loop(h, max_iter, 0)) return rc;
+    const int rw = run_whole(h, max_iter);                                     // ONE scenario that has solved before: the whole solve as one graph; -1: not such a handle
+    if (rw > 0) return rw;
+    if (rw < 0) {
+        if (int rc = run_start(h, max_iter)) return rc;                        // acPowerFlow.jl:1406: mismatch!, verdict (+ a compensated first iteration)
+        if (int rc = run_loop(h, max_iter, 0)) return rc;
+    }
     return run_finish(h, iters, status);
 }
 

@@ -88,6 +88,33 @@ def test_power_flow_matches_oracle(jg, oracle, name):
     assert max(o.mismatch()) < 1e-8
 
 
+@pytest.mark.parametrize("name", ["case118", "case1354pegase", "case_ACTIVSg10k"])
+def test_repeated_solves_of_one_handle_keep_the_reference_accounting(jg, oracle, name):
+    """Round 6: a handle of ONE scenario that has solved before runs its next solve as ONE graph of as many iterations as the last solve took (run_whole);
+    a solve that needs fewer runs the rest as empty launches, one that needs more gets its Jacobian (graph J) and carries on iteration by iteration.  Whatever
+    the order of easy and hard starts, every solve must report the reference's iteration count and state (acPowerFlow.jl:1389-1433)."""
+    s, an, o = _pair(jg, oracle, name)
+    vm0, va0 = an.voltage.magnitude.copy(), an.voltage.angle.copy()
+    assert o.power_flow() == 0
+    k, (vm, va) = o.iteration, o.voltage()
+    assert k >= 3
+
+    def check(iters):
+        assert an.status == 0 and an.method.iteration == iters
+        assert np.abs(an.voltage.magnitude - vm).max() <= 1e-8 and np.abs(an.voltage.angle - va).max() <= 1e-8
+    jg.powerFlow_(an); check(k)                                   # first solve: graph per iteration
+    jg.setInitialPoint_(an); jg.powerFlow_(an); check(k)          # the whole solve as one graph of k iterations
+    jg.powerFlow_(an); check(0)                                   # from the solution: converged at the start verdict, k empty iterations
+    jg.setInitialPoint_(an); jg.powerFlow_(an); check(k)          # expects 1 iteration, needs k: graph J, then the loop
+    jg.powerflow._push_voltage(an, 0.5 * (vm0 + vm), 0.5 * (va0 + va))                    # a start half-way: fewer iterations than k
+    o.set_voltage(0.5 * (vm0 + vm), 0.5 * (va0 + va)); assert o.power_flow() == 0
+    k2 = o.iteration
+    jg.powerFlow_(an); check(k2)
+    jg.setInitialPoint_(an); jg.powerFlow_(an, iteration=2)       # the limit below the expectation: the loop of single iterations, status 1
+    assert an.status == 1 and an.method.iteration == 2
+    jg.setInitialPoint_(an); jg.powerFlow_(an); check(k)
+
+
 def test_iteration_limit_and_loop_accounting(jg, oracle):
     """acPowerFlow.jl:1406-1420: at most `iteration` solves; status 1 when the limit hits."""
     s, an, o = _pair(jg, oracle, "case14test")
