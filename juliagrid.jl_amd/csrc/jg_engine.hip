@@ -2416,7 +2416,7 @@ int Engine::backsolve(hipStream_t st, double* out, const StateUpdate& upd, const
         const SingleTables& T = plan->single;
         Bwd1Args s{plan->s1_t_row, plan->s1_t_ptr, plan->s1_t_term, plan->s1_t_level, plan->s1_b_wg, plan->s1_b_row, plan->s1_b_term, X, jc, W, out, sel, upd, ld, T.n_top_levels, T.n_wg, T.n_top,
                    plan->s1_t_jb, plan->s1_t_cslot, plan->s1_t_toff, T.max_level_terms};
-        static const int flat_env = knob("SINGLE", 1);            // JG_SINGLE=2: the quad-per-row sweep (k_bwd1_top) where the terms-as-lanes one would run
+        const int flat_env = knob("SINGLE", 1);                   // JG_SINGLE=2: the quad-per-row sweep (k_bwd1_top) where the terms-as-lanes one would run
         if (T.flat_ok && flat_env != 2) hipLaunchKernelGGL(k_bwd1_top2, dim3(grid_blocks(ld / 64, 1)), dim3(1024), (size_t)T.n_top * 36 + (size_t)T.max_level_terms * 16, st, s);
         else hipLaunchKernelGGL(k_bwd1_top, dim3(grid_blocks(ld / 64, 1)), dim3(1024), (size_t)T.n_top * 40, st, s);
         if (T.n_wg > 0) hipLaunchKernelGGL(k_bwd1_bottom, dim3(grid_blocks(ld / 64, T.n_wg)), dim3(SINGLE_BOTTOM_ROWS), 0, st, s);

@@ -1012,7 +1012,7 @@ void launch_assemble(jg_nr* h, const jg::GroupSel& sel = jg::GroupSel{}, bool ja
               h->eng.W, h->eng.status};
     if (jac && !only_if) h->level0_done = pre;
     dim3 grid(jg::grid_blocks(h->ld / 64, h->nchunk)), block(64, ASM_WAVES);
-    static const bool single_env = jg::knob("SINGLE", 1) != 0;
+    const bool single_env = jg::knob("SINGLE", 1) != 0;           // (read at every capture: bench.py holds the two forms against each other in one process)
     if (h->ld == 64 && h->batch == 1 && !fd_mode && !pq_out && !only_if && single_env) {      // ONE scenario: a quad of lanes per bus row (k_assemble1)
         const dim3 g1(jg::grid_blocks(1, (h->n + 63) / 64));
         if (jac) {
@@ -2067,7 +2067,7 @@ int run_start(jg_nr* h, int64_t max_iter) {
 
 // ONE scenario whose last run iterated: start verdict + that many iterations as one graph (build_whole_graph).  -1: the handle does not qualify (run_start / run_loop).
 int run_whole(jg_nr* h, int64_t max_iter) {
-    static const bool on = jg::knob("SINGLE", 1) == 1;
+    const bool on = jg::knob("SINGLE", 1) == 1 && h->eng.single_bwd;   // (the handle was created as a single instance: JG_SINGLE at its creation)
     const int k = h->stop_hint;
     if (!on || h->ld != 64 || h->batch != 1 || k < 1 || k > 12 || (int64_t)k > max_iter || h->refine || jg::knob_set("TRACE") || jg::knob_set("HOST_TIMING")) return -1;
     bool comp = false;
