@@ -1272,7 +1272,7 @@ void build_single_tables(const BlockSymbolic& S, SingleTables& T) {
     int cur_rows = SINGLE_BOTTOM_ROWS + 1;
     std::vector<std::vector<int>> wg_rows;
     for (const auto& tr : trees) {
-        if (cur_rows + tr.second > SINGLE_BOTTOM_ROWS) { wg_rows.emplace_back(); cur_rows = 0; }
+        if (cur_rows + tr.second > SINGLE_BOTTOM_FILL) { wg_rows.emplace_back(); cur_rows = 0; }
         for (int q = tr.first; q < tr.first + tr.second; ++q) { wg_of[q] = (int)wg_rows.size() - 1; thr_of[q] = cur_rows++; wg_rows.back().push_back(q); }
     }
     T.n_wg = (int)wg_rows.size();
@@ -1507,6 +1507,10 @@ int analyze(int n, const int* rowptr, const int* col, long long policy64, BlockS
             for (int r = 0; r < n; ++r) nlev = std::max(nlev, S.y_level[r]);
             int chains = (policy >> 4) & 0xf;                     // ... and at most this many pivots (parallel chains) per level (0: any;
             if (chains >= 13) chains = chains == 13 ? 18 : (chains == 14 ? 24 : 36);   // 13 / 14 / 15 stand for 18 / 24 / 36)
+            // ONE scenario (policy bit 60): a level below the top costs its share of k_fact1_bottom / k_bwd1_bottom (~4 + 2 us), a task level ~20 us whatever it holds, so the
+            // wide levels stay below the top -- it starts where no level holds more than 150 pivots (ACTIVSg10k: level 6 instead of 5, 0.950 -> 0.863 ms per solve; 9241-bus
+            // grid: level 8, 0.972 -> 0.923; profiles/r06_top_level_sweep.txt)
+            if (S.want_single && chains == 0) chains = 150;
             std::vector<int> cnt(nlev + 2, 0), piv(nlev + 2, 0);
             for (int e = 0; e < S.n_entries; ++e) if (!(S.symmetric && S.e_row[e] > S.e_col[e])) cnt[S.e_level[e]]++;
             for (int r = 0; r < n; ++r) { cnt[S.y_level[r]]++; piv[S.e_level[S.diag[r]]]++; }

@@ -256,7 +256,8 @@ void build_comp_tables(const BlockSymbolic& S, int top_cap, CompTables& out);
 //   the workgroup's items of level l + 1 are f1_first[f1_wg[w][l] .. f1_wg[w][l + 1]).
 constexpr int SINGLE_FACT_LEVELS = 8;      // most levels below the top such a plan may have
 constexpr int SINGLE_FACT_ITEMS = 192;     // items a bottom workgroup is filled up to (256 threads = 64 quads, four lanes per item: most levels in one round)
-constexpr int SINGLE_BOTTOM_ROWS = 128;   // rows (threads) of a bottom workgroup
+constexpr int SINGLE_BOTTOM_ROWS = 256;   // threads of a bottom workgroup = most rows of ONE subtree
+constexpr int SINGLE_BOTTOM_FILL = 128;   // rows a bottom workgroup is filled up to with whole subtrees (more, smaller workgroups: more requests in flight)
 struct SingleTables {
     bool ok = false;                    // false: the plan does not qualify (no Jordan rows, a subtree above SINGLE_BOTTOM_ROWS rows, ...)
     int n_top = 0, n_top_levels = 0;
