@@ -655,8 +655,10 @@ void build_tables(BlockSymbolic& S) {
             x.w[3]++;
         }
     };
-    // ---- the same items for a SINGLE instance (policy bit 60; jg_symbolic.hpp: SINGLE_FACT_LEVELS): a thread per item, two launches
+    // ---- the same items for a SINGLE instance (policy bit 60; jg_symbolic.hpp: SINGLE_FACT_LEVELS): a thread per item, two launches (built on a thread of its own, beside the other tables:
+    // it only reads what the lists above hold)
     S.single_fact_ok = false; S.f_rec.clear(); S.f1_first.clear(); S.f1_wg.clear(); S.f2_first.clear(); S.n_f1_wg = 0;
+    auto build_single_fact = [&] {
     if (S.want_single && has_top && !sym && S.inplace) {
         auto parent = [&](int k) { return S.u_ptr[k + 1] > S.u_ptr[k] ? S.u_col[S.u_ptr[k]] : -1; };
         auto item_pivot = [&](int it) { return it < nE ? owner(it) : it - nE; };
@@ -711,6 +713,7 @@ void build_tables(BlockSymbolic& S) {
             S.single_fact_ok = true;
         }
     }
+    };
     S.n_sched_terms = S.top_terms;
     for (int it = 0; it < nE + n; ++it) if (level[it] > 0) S.n_sched_terms += work[it];
     // Item order inside a level: everything that becomes final with pivot p = min(row, col) together -- U(p, .) and y_p share
@@ -948,6 +951,8 @@ void build_tables(BlockSymbolic& S) {
         if (timing) fprintf(stderr, "[jg plan]   factorisation tables done at %6.1f ms\n", tnow() - tb0);
     });
     struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } join_fact{fact_thread};
+    std::thread single_thread = spawn_or_run(build_single_fact);
+    Join join_single{single_thread};
     // level 0 of a prefactor plan as tables of its own (for producers that deliver plain blocks): D(k) and y_k of the pivots
     // nobody updates -- and the forward-only tables: a thread of their own as well (round 4: the analysis is what a cold power flow waits for)
     S.pre_pivot.assign(n, 0); S.pre_seg.clear(); S.pre_rec.clear(); S.n_pre_levels = 0;
