@@ -1137,7 +1137,7 @@ __global__ __launch_bounds__(64 * TASK_WAVES, 4) void k_fact_task(FactArgs a) {
 
 // ---- the factorisation below the top of a SINGLE instance (jg_symbolic.hpp: SINGLE_FACT_LEVELS): a thread per item ---------------------------------------
 struct Fact1Args {
-    const Rec* rec; const int* first; const int* wg;
+    const Rec* rec; const int* wg; int item0;                     // item0: first of the partial items (k_fact1_partial)
     const double* rhs; double* X; double* W; int* status; GroupSel sel;
     int ld, n_wg, n_items;
 };
@@ -1146,14 +1146,15 @@ struct Fact1Args {
 // sums meet through two shuffles (fixed order), lane 0 adds the block / rhs row as assembled and stores like fact_finish
 __device__ __forceinline__ void fact1_item(const Fact1Args& a, int ri, int q, size_t b, size_t ld) {
     const int4* rp = (const int4*)(a.rec + ri);
-    const int4 h = rp[0];                                         // kind, id, src, terms
-    const int kind = h.x, id = h.y, src = h.z, nt = h.w;
+    const int4 h = rp[0];                                         // kind, id, src, terms | first continuation record << 10
+    const int kind = h.x, id = h.y, src = h.z, nt = h.w & 1023;
+    const int4* rc = (const int4*)(a.rec + (h.w >> 10)) - 4;      // record r >= 1 of the item: rc + 4 r
     // (every lane of the quad asks for the item's own block: same address, no branch ahead of the term loads)
     const double2 f0 = *(const double2*)(kind == 3 ? (const char*)a.rhs + ((size_t)src * ld + b) * 16 : (const char*)a.X + (size_t)(src >= 0 ? src : 0) * ld * 32 + b * 16);
     const double2 f1 = *(const double2*)((const char*)a.X + (size_t)(kind != 3 && src >= 0 ? src : 0) * ld * 32 + ld * 16 + b * 16);
     Blk c{0.0, 0.0, 0.0, 0.0};
     for (int q0 = 4 * q; q0 < nt; q0 += 16) {
-        const int4* tr = rp + 4 * (q0 >> 2);
+        const int4* tr = q0 < 4 ? rp : rc + 4 * (q0 >> 2);
         const int4 t1 = tr[1], t2 = tr[2], t3 = tr[3];
         const int ta[4] = {t1.x, t1.w, t2.z, t3.y}, td[4] = {t1.y, t2.x, t2.w, t3.z}, tb[4] = {t1.z, t2.y, t3.x, t3.w};
         const int cnt = min(4, nt - q0);
@@ -1209,7 +1210,7 @@ __global__ __launch_bounds__(256) void k_fact1_bottom(Fact1Args a) {
     const int quad = (int)threadIdx.x >> 2, q = (int)threadIdx.x & 3;
     for (int l = 0; l < SINGLE_FACT_LEVELS; ++l) {
         const int i0 = hdr[l], i1 = hdr[l + 1];
-        for (int j = i0 + quad; j < i1; j += 64) fact1_item(a, a.first[j], q, b, ld);
+        for (int j = i0 + quad; j < i1; j += 64) fact1_item(a, j, q, b, ld);
         if (i1 >= last) break;                                    // (uniform) nothing above this level in this workgroup
         __syncthreads();
     }
@@ -1219,7 +1220,7 @@ __global__ __launch_bounds__(256) void k_fact1_partial(Fact1Args a) {
     int grp, w;
     if (!map_block(a.sel, a.ld, (a.n_items + 63) / 64, grp, w)) return;
     const int j = w * 64 + ((int)threadIdx.x >> 2);
-    if (j < a.n_items) fact1_item(a, a.first[j], (int)threadIdx.x & 3, (size_t)grp * 64, (size_t)a.ld);
+    if (j < a.n_items) fact1_item(a, a.item0 + j, (int)threadIdx.x & 3, (size_t)grp * 64, (size_t)a.ld);
 }
 
 // TIMING PROBES of a pivot step (compile with -DJG_PROBE_TOP=1: the next pivot's row / column are not published, =3: the bulk threads take the published row as D^-1 U(q, .) -- no pivot read, no solve --, =2: one block update per
@@ -2008,7 +2009,7 @@ SharedPlan::~SharedPlan() {
     hipFree(fact_seg); hipFree(bwd_seg); hipFree(pre_seg); hipFree(fwd_seg); hipFree(sel_seg);
     hipFree(pre_row); hipFree(bwd_chain); hipFree(top_data); hipFree(top_wgmap);
     hipFree(bwdj_rec); hipFree(bwdj_seg);
-    hipFree(f1_rec); hipFree(f1_first); hipFree(f1_wg); hipFree(f2_first);
+    hipFree(f1_rec); hipFree(f1_wg);
     hipFree(s1_t_jb); hipFree(s1_t_cslot); hipFree(s1_t_toff);
     hipFree(s1_t_row); hipFree(s1_t_ptr); hipFree(s1_t_term); hipFree(s1_t_level); hipFree(s1_b_wg); hipFree(s1_b_row); hipFree(s1_b_term);
 }
@@ -2091,8 +2092,7 @@ std::shared_ptr<SharedPlan> acquire_plan(int n, const int* rowptr, const int* co
         upload(&p->bwd_seg, S.bwd_seg, error, st) || upload(&p->bwd_chain, S.bwd_chain, error, st) ||
         (S.jordan && (upload(&p->bwdj_rec, S.bwdj_rec, error, st) || upload(&p->bwdj_seg, S.bwdj_seg, error, st))) ||
         upload(&p->fwd_rec, S.fwd_rec, error, st) || upload(&p->fwd_seg, S.fwd_seg, error, st) ||
-        (S.single_fact_ok && (upload(&p->f1_rec, S.f_rec, error, st) || upload(&p->f1_first, S.f1_first, error, st) || upload(&p->f1_wg, S.f1_wg, error, st) ||
-                              upload(&p->f2_first, S.f2_first, error, st))) ||
+        (S.single_fact_ok && (upload(&p->f1_rec, S.f_rec, error, st) || upload(&p->f1_wg, S.f1_wg, error, st))) ||
         (!S.top_launch.empty() && (upload(&p->top_task, S.top_task, error, st) || upload(&p->top_data, S.top_data, error, st) || upload(&p->top_wgmap, S.top_wgmap, error, st)))) {
         rc = 2;
         return nullptr;
@@ -2273,9 +2273,9 @@ int Engine::factor(hipStream_t st, const double* A, const double* rhs, const Gro
     }
     const bool single_fact = plan->S.single_fact_ok && lanes == 1 && plan->f1_rec && probe_part == 0;
     if (single_fact) {                                           // ONE scenario: a thread per item -- the bottom subtrees in one launch, the partial sums of the task-owned items in a second
-        Fact1Args s{plan->f1_rec, plan->f1_first, plan->f1_wg, rhs, X, W, status, sel, ld, plan->S.n_f1_wg, 0};
+        Fact1Args s{plan->f1_rec, plan->f1_wg, (int)plan->S.f1_first.size(), rhs, X, W, status, sel, ld, plan->S.n_f1_wg, 0};
         if (s.n_wg > 0) hipLaunchKernelGGL(k_fact1_bottom, dim3(grid_blocks(ld / 64, s.n_wg)), dim3(256), 0, st, s);
-        s.first = plan->f2_first; s.n_items = (int)plan->S.f2_first.size();
+        s.n_items = (int)plan->S.f2_first.size();
         if (s.n_items > 0) hipLaunchKernelGGL(k_fact1_partial, dim3(grid_blocks(ld / 64, (s.n_items + 63) / 64)), dim3(256), 0, st, s);
     }
     for (const DevLaunch& L : fact) {

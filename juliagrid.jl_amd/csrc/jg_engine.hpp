@@ -221,7 +221,7 @@ struct SharedPlan {
     int* s1_t_row = nullptr; int* s1_t_ptr = nullptr; int* s1_t_term = nullptr; int* s1_t_level = nullptr;
     int* s1_b_wg = nullptr; int* s1_b_row = nullptr; int* s1_b_term = nullptr;
     int* s1_t_jb = nullptr; int* s1_t_cslot = nullptr; int* s1_t_toff = nullptr;    // the top rows with the terms as lanes (SingleTables::flat_ok)
-    Rec* f1_rec = nullptr; int* f1_first = nullptr; int* f1_wg = nullptr; int* f2_first = nullptr;   // plans with policy bit 60: the single-instance factorisation below the top
+    Rec* f1_rec = nullptr; int* f1_wg = nullptr;   // plans with policy bit 60: the single-instance factorisation below the top (records; the workgroups' item ranges by level)
     ~SharedPlan();
 };
 // (n, pattern, policy, current device) -> plan; analysis + upload on a miss.  st: stream for the uploads.  nullptr + error on failure.

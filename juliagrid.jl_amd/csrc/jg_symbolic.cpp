@@ -662,15 +662,10 @@ void build_tables(BlockSymbolic& S) {
     if (S.want_single && has_top && !sym && S.inplace) {
         auto parent = [&](int k) { return S.u_ptr[k + 1] > S.u_ptr[k] ? S.u_col[S.u_ptr[k]] : -1; };
         auto item_pivot = [&](int it) { return it < nE ? owner(it) : it - nE; };
-        auto emit = [&](int it) {                               // records of one item; returns the index of the first
-            const int first = (int)S.f_rec.size();
-            const int nt = ft_ptr[it + 1] - ft_ptr[it];
-            const int nrec = std::max(1, (nt + 3) / 4);
-            S.f_rec.resize(S.f_rec.size() + nrec);
-            fill_fact(it, 0, 1, nrec, S.f_rec.data() + first);   // (kind, id, src in every record; words 4 .. 15: up to four terms each)
-            S.f_rec[first].w[3] = nt;                            // the first record carries the item's total
-            return first;
-        };
+        // Records: the FIRST record of item j is record j (the items of a workgroup's level -- and the partial items behind them -- are read without an index in between);
+        // the records an item of more than four terms continues in follow all first records, word 3 of the first = terms | first continuation record << 10.
+        std::vector<int> order_items;                            // items in record order
+        auto emit = [&](int it) { order_items.push_back(it); return (int)order_items.size() - 1; };
         bool ok = true;
         int maxlev = 0;
         std::vector<int> sub(n, 1);
@@ -710,7 +705,26 @@ void build_tables(BlockSymbolic& S) {
             }
             S.n_f1_wg = (int)wg_items.size();
             for (int it = 0; it < nE + n; ++it) if (level[it] > 0 && in_top(item_pivot(it))) S.f2_first.push_back(emit(it));
-            S.single_fact_ok = true;
+            const int ni = (int)order_items.size();
+            size_t total = (size_t)ni;
+            for (int it : order_items) { const int nt = ft_ptr[it + 1] - ft_ptr[it]; if (nt > 1023) ok = false; total += (size_t)std::max(0, (nt + 3) / 4 - 1); }
+            if (total >= (1u << 21)) ok = false;
+            if (ok) {
+                S.f_rec.assign(total, Rec{});
+                size_t cont = (size_t)ni;
+                std::vector<Rec> tmp;
+                for (int j = 0; j < ni; ++j) {
+                    const int it = order_items[j];
+                    const int nt = ft_ptr[it + 1] - ft_ptr[it];
+                    const int nrec = std::max(1, (nt + 3) / 4);
+                    tmp.assign(nrec, Rec{});
+                    fill_fact(it, 0, 1, nrec, tmp.data());       // (kind, id, src in every record; words 4 .. 15: up to four terms each)
+                    S.f_rec[j] = tmp[0];
+                    S.f_rec[j].w[3] = nt | (int)(nrec > 1 ? cont : 0) << 10;
+                    for (int r = 1; r < nrec; ++r) S.f_rec[cont++] = tmp[r];
+                }
+            }
+            S.single_fact_ok = ok;
         }
     }
     };

@@ -251,9 +251,10 @@ void build_comp_tables(const BlockSymbolic& S, int top_cap, CompTables& out);
 // tasks) depend on items of their own subtree only, so a workgroup takes a run of whole bottom subtrees and walks its levels with workgroup barriers: ONE launch
 // (f1); the partial sums of the task-owned entries / rhs rows (bottom terms only, jg_symbolic.cpp: build_tables) depend on bottom items alone: a second, flat
 // launch (f2).  Five level launches become two.
-//   record (16 ints): kind (0 / 1 raw entry, 2 diagonal block, 3 rhs row), id, src, terms of the ITEM, then up to four terms (a, d, b) as in a FactRec; an item of
-//   more than four terms continues in the records that follow (words 4 .. 15 only).  f1_first / f2_first: first record of every item; f1_wg [n_f1_wg][SINGLE_FACT_LEVELS + 1]:
-//   the workgroup's items of level l + 1 are f1_first[f1_wg[w][l] .. f1_wg[w][l + 1]).
+//   record (16 ints): kind (0 / 1 raw entry, 2 diagonal block, 3 rhs row), id, src, word 3, then up to four terms (a, d, b) as in a FactRec.  The FIRST record of item j is
+//   record j (word 3 = terms of the item | first continuation record << 10); an item of more than four terms continues in records behind all first ones (words 4 .. 15
+//   only).  f1_wg [n_f1_wg][SINGLE_FACT_LEVELS + 1]: the workgroup's items of level l + 1 are f1_wg[w][l] .. f1_wg[w][l + 1]; the partial items follow the bottom items
+//   (f1_first / f2_first: the item numbers, kept for the CPU replay).
 constexpr int SINGLE_FACT_LEVELS = 8;      // most levels below the top such a plan may have
 constexpr int SINGLE_FACT_ITEMS = 192;     // items a bottom workgroup is filled up to (256 threads = 64 quads, four lanes per item: most levels in one round)
 constexpr int SINGLE_BOTTOM_ROWS = 256;   // threads of a bottom workgroup = most rows of ONE subtree

@@ -317,11 +317,13 @@ class Replay:
         f1_wg = g(83).reshape(-1, nlev + 1)
         nE = self.nE
 
-        def item(first):
-            nt = int(rec[first][3])
-            out = rec[first: first + max(1, (nt + 3) // 4)].copy()
+        def item(first):                                      # record `first` = the item's first record: word 3 = terms | first continuation record << 10
+            nt, cont = int(rec[first][3]) & 1023, int(rec[first][3]) >> 10
+            nrec = max(1, (nt + 3) // 4)
+            out = np.concatenate([rec[first: first + 1], rec[cont: cont + nrec - 1]]).copy() if nrec > 1 else rec[first: first + 1].copy()
             for i, r in enumerate(out):
                 r[3] = min(4, nt - 4 * i) if nt > 4 * i else 0
+                assert i == 0 or (int(r[0]), int(r[1])) == (int(out[0][0]), int(out[0][1]))
             return out
         wg_of = {}                                            # item (entry, or nE + rhs row) -> workgroup
         for w in range(f1_wg.shape[0]):
