@@ -1109,6 +1109,8 @@ def main():
             "converged_fraction": conv_total / total,
             "single_instance": {"ms_per_solve": 1e3 * float(np.median(t_single)), "iterations": base_iters,
                                 "ms_per_iteration": 1e3 * float(np.median(t_single)) / max(base_iters, 1),
+                                "what": "warm solves of ONE handle from the case's start point (setInitialPoint! between them, outside the clock): kernels whose lanes are items of the one "
+                                        "scenario, the whole solve as one hipGraph from the second solve on (DESIGN.md 3.5)",
                                 "ms_per_solve_level_launches": 1e3 * float(np.median(t_single_levels)) if t_single_levels else None,
                                 "level_launches_what": "the same warm solve with JG_SINGLE=0: the level launches of a small batch (a wave per item, one live lane) instead of the "
                                                        "item-per-lane / row-per-lane kernels of ONE scenario (k_fact1_*, k_bwd1_*), same run",
