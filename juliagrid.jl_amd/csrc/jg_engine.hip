@@ -2177,10 +2177,10 @@ int Engine::create(int n, const int* rowptr, const int* col, int ld_, long long 
             if (T.ok) {
                 if (upload(&plan->s1_t_row, T.t_row, error, st) || upload(&plan->s1_t_ptr, T.t_ptr, error, st) || upload(&plan->s1_t_term, T.t_term, error, st) ||
                     upload(&plan->s1_t_level, T.t_level, error, st) || upload(&plan->s1_b_wg, T.b_wg, error, st) || upload(&plan->s1_b_row, T.b_row, error, st) ||
-                    upload(&plan->s1_b_term, T.b_term, error, st)) return 2;
+                    upload(&plan->s1_b_term, T.b_term, error, st)) { T.ok = false; return 2; }      // (a later engine of the plan must not take tables that are not there)
                 // terms as lanes (k_bwd1_top2): a level's rows on one thread each, its terms in BWD1_ROUNDS rounds of the workgroup, everything in its LDS
                 if (T.flat_ok && (T.max_level_rows > 1024 || T.max_level_terms > BWD1_ROUNDS * 1024 || (size_t)T.n_top * 36 + (size_t)T.max_level_terms * 16 > 144 * 1024)) T.flat_ok = false;
-                if (T.flat_ok && (upload(&plan->s1_t_jb, T.t_jb, error, st) || upload(&plan->s1_t_cslot, T.t_cslot, error, st) || upload(&plan->s1_t_toff, T.t_toff, error, st))) return 2;
+                if (T.flat_ok && (upload(&plan->s1_t_jb, T.t_jb, error, st) || upload(&plan->s1_t_cslot, T.t_cslot, error, st) || upload(&plan->s1_t_toff, T.t_toff, error, st))) { T.ok = false; return 2; }
                 for (std::vector<int>* v : {&T.t_row, &T.t_ptr, &T.t_term, &T.t_level, &T.b_wg, &T.b_row, &T.b_term, &T.t_jb, &T.t_cslot, &T.t_toff}) std::vector<int>().swap(*v);
             }
         }
